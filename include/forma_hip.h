@@ -1,0 +1,235 @@
+/*
+ * forma_hip.h — C ABI of libforma_hip.so, the MI355X (gfx950) backend for forma's
+ * 4-stage raster pipeline (flatten -> pixel-grid rasterize -> sort -> per-tile paint).
+ *
+ * This is the drop-in boundary.  It replaces what
+ * `forma::cpu::Renderer::render` (reference forma/src/cpu/renderer.rs:75-224) does between
+ * "the composition's geometry store + layer table" and "the caller's RGBA8 buffer":
+ *
+ *   data in  = SegmentBuffer {x, y, ids}            reference forma/src/segment.rs:529-555
+ *              geom_id_to_order + InnerLayer         reference forma/src/composition/state.rs:30,
+ *                                                    forma/src/composition/layer.rs:26-41
+ *              Props per Order                       reference forma/src/styling.rs:438-442
+ *   data out = caller-owned `&mut [u8]` + LinearLayout{width, width_stride, height}
+ *                                                    reference forma/src/cpu/buffer/layout/mod.rs:167-222
+ *
+ * Conventions
+ *   - every entry point returns 0 on success and a negative FORMA_E_* code on failure; nothing
+ *     ever unwinds across the ABI (the reference panics; a Rust shim maps !=0 to panic!).
+ *   - all host pointers are borrowed for the duration of the call only.
+ *   - a context is single-threaded (the reference takes `&mut self`, renderer.rs:75); distinct
+ *     contexts may be used concurrently.  One HIP stream per context.
+ *   - plain pointers and sizes only; no torch / C++ types.
+ */
+#ifndef FORMA_HIP_H
+#define FORMA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- limits (reference forma/src/consts.rs:25-26,107-109) ---------------------------- */
+#define FORMA_MAX_WIDTH   65536u
+#define FORMA_MAX_HEIGHT  32768u
+#define FORMA_LAYER_LIMIT 0x1FFFFFu          /* 2^21 - 1 */
+#define FORMA_TILE        16u                /* CPU tile 16x16, consts.rs:31-43 */
+#define FORMA_NONE        0xFFFFFFFFu
+
+/* ---- error codes ---------------------------------------------------------------------- */
+#define FORMA_OK             0
+#define FORMA_E_ARG         -1   /* invalid argument (size limits, null pointer, stride)    */
+#define FORMA_E_HIP         -2   /* a HIP runtime call failed; see forma_hip_last_error    */
+#define FORMA_E_NO_DEVICE   -3   /* no gfx950 device visible                                */
+#define FORMA_E_CAPACITY    -4   /* caller-provided output capacity too small               */
+#define FORMA_E_STATE       -5   /* call sequence error (e.g. render before set_geometry)   */
+#define FORMA_E_INTERNAL    -6   /* device-side invariant violated (bounded spin expired…)  */
+
+typedef struct forma_hip_ctx forma_hip_ctx;
+
+/* ---- scene tables ---------------------------------------------------------------------- */
+
+/* One entry per geometry slot.  A slot is the device-side stand-in of a reference `GeomId`
+ * (segment.rs:100-131): `line_slot[i]` names the slot of the line point i -> point i+1, or
+ * FORMA_NONE for the gap between two polygonal chains (reference `ids[i] == None`).
+ * The entry folds `geom_id_to_order` and `InnerLayer` (segment.rs:141-149, layer.rs:26-41). */
+typedef struct forma_geom_t {
+    uint32_t order;    /* FORMA_NONE: geom not in the composition, layer disabled, order None */
+    uint32_t flags;    /* bit0: has_transform                                                  */
+    float    xf[6];    /* ux, uy, vx, vy, tx, ty  (AffineTransform::to_array, transform.rs:50) */
+} forma_geom_t;
+#define FORMA_GEOM_HAS_XF 1u
+
+/* Style table: `style_offsets[order]` indexes `style_words` (FORMA_NONE = order unused).
+ *
+ *  word0 header  bits 0..3   blend mode, ordinal of reference `BlendMode` (styling.rs:390-408)
+ *                bits 4..5   fill type: 0 solid, 1 linear gradient, 2 radial gradient, 3 texture
+ *                bit  6      fill rule: 0 NonZero, 1 EvenOdd                 (styling.rs:63-67)
+ *                bit  7      is_clipped                                      (styling.rs:416)
+ *                bit  8      func: 0 Draw, 1 Clip                            (styling.rs:421-428)
+ *                bits 16..31 gradient stop count
+ *  word1         n of Func::Clip(n), 0 for Draw
+ *  solid:        word2..5   r g b a (f32 bits)
+ *  gradient:     word2..5   start.x start.y end.x end.y, then 5 words per stop: r g b a stop
+ *  texture:      word2..7   ux uy vx vy tx ty (screen -> texture space), word8 image index
+ */
+#define FORMA_STYLE_BLEND(h)      ((h) & 0xFu)
+#define FORMA_STYLE_FILL(h)       (((h) >> 4) & 0x3u)
+#define FORMA_STYLE_EVENODD(h)    (((h) >> 6) & 0x1u)
+#define FORMA_STYLE_CLIPPED(h)    (((h) >> 7) & 0x1u)
+#define FORMA_STYLE_IS_CLIP(h)    (((h) >> 8) & 0x1u)
+#define FORMA_STYLE_STOPS(h)      ((h) >> 16)
+#define FORMA_FILL_SOLID   0u
+#define FORMA_FILL_LINEAR  1u
+#define FORMA_FILL_RADIAL  2u
+#define FORMA_FILL_TEXTURE 3u
+
+/* Image table entry; texels are 4 x u16 in the reference's bias-shifted half format
+ * (`f16`, styling.rs:224-259), row-major, in one pool.                                  */
+typedef struct forma_image_t {
+    uint64_t texel_offset;   /* first texel of this image in the pool (in texels) */
+    uint32_t width;
+    uint32_t height;
+} forma_image_t;
+
+/* Output channel selectors, reference forma/src/cpu/channel.rs:34-62. */
+enum { FORMA_CH_RED = 0, FORMA_CH_GREEN = 1, FORMA_CH_BLUE = 2, FORMA_CH_ALPHA = 3,
+       FORMA_CH_ZERO = 4, FORMA_CH_ONE = 5 };
+
+/* Crop rectangle in PIXELS; rounded out to the tile grid exactly like `Rect::new`
+ * (renderer.rs:43-52). */
+typedef struct forma_rect_t { uint32_t x0, x1, y0, y1; } forma_rect_t;
+
+/* Per-stage device times of the last render, in microseconds (HIP events on the context's
+ * stream).  Same split the reference exposes: trace spans cpu/renderer.rs:171-199 and
+ * gpu `Timings`, gpu/renderer/mod.rs:24-36.                                              */
+typedef struct forma_timings_t {
+    float    prepare_us;      /* prepare_lines + prefix sum            */
+    float    rasterize_us;    /* pixel-grid intersector                */
+    float    sort_us;         /* all radix passes                      */
+    float    sort_pass_us;    /* average of one scatter pass           */
+    float    carry_us;        /* runs + cover-carry pre-pass + tile lists */
+    float    paint_us;        /* per-tile painter                      */
+    float    total_us;        /* first kernel start -> last kernel end */
+    float    d2h_us;          /* image copy into caller memory (0 if dst == NULL) */
+    uint32_t n_lines;
+    uint32_t n_segments;      /* N = number of pixel segments          */
+    uint32_t n_sort_passes;   /* digit passes actually executed        */
+    uint32_t n_runs;          /* (tile, layer) runs in the sorted stream */
+    uint32_t n_tile_entries;  /* painted (tile, layer) pairs           */
+    uint32_t reserved;
+} forma_timings_t;
+
+/* ---- lifetime ----------------------------------------------------------------------------- */
+/* `device` is a HIP device ordinal (one process per GPU: pass LOCAL_RANK). */
+int  forma_hip_create(forma_hip_ctx** out, int device);
+void forma_hip_destroy(forma_hip_ctx* ctx);
+const char* forma_hip_last_error(const forma_hip_ctx* ctx);
+/* Library self-description: "forma_hip <version> gfx950". */
+const char* forma_hip_version(void);
+
+/* ---- scene upload (reference data crossing: SURVEY §8b row 3) ------------------------------ */
+/* Replace the device-resident geometry store.  n_points >= 0; line_slot has max(n_points-1,0)
+ * entries.  Replaces SegmentBufferView.{x,y,ids} (segment.rs:529-555).                        */
+int forma_hip_set_geometry(forma_hip_ctx* ctx, const float* x, const float* y,
+                           const uint32_t* line_slot, size_t n_points);
+int forma_hip_set_geoms(forma_hip_ctx* ctx, const forma_geom_t* geoms, size_t n_geoms);
+/* `unchanged` may be NULL (= every layer changed); else one byte per order, the reference's
+ * `Layer::is_unchanged(cache_id)` (layer.rs:179-189).                                         */
+int forma_hip_set_styles(forma_hip_ctx* ctx, const uint32_t* style_offsets, size_t n_orders,
+                         const uint32_t* style_words, size_t n_words,
+                         const uint8_t* unchanged);
+int forma_hip_set_images(forma_hip_ctx* ctx, const forma_image_t* images, size_t n_images,
+                         const uint16_t* texels, size_t n_texels);
+
+/* ---- stage 1: curve flattening (reference path.rs:473-538 `Primitives::into_segments`) ----- */
+/* Work items are produced by the host-side sequential pass (path.rs:252-445); all index
+ * arrays are absolute into the quad / spline tables.  Appends nothing to the context: pure
+ * map, results copied back to `out_x/out_y` (n_points each).                                  */
+typedef struct forma_flatten_tables_t {
+    /* per output point */
+    const uint32_t* point_commands;  /* PointCommand bits, path.rs:137-168                    */
+    const uint32_t* point_indices;   /* pi                                                    */
+    const uint32_t* quad_indices;    /* qi                                                    */
+    size_t          n_points;
+    /* per quad (3 control points each in qx/qy/qw) */
+    const float* qx; const float* qy; const float* qw;
+    const float* x0; const float* dx_recip; const float* k0; const float* dk;
+    const float* curvatures_recip;
+    const uint32_t* partial_spline;  /* partial_curvatures[i].0                               */
+    const float*    partial_curv;    /* partial_curvatures[i].1                               */
+    size_t          n_quads;
+    /* per spline */
+    const float* sp0x; const float* sp0y; const float* sp2x; const float* sp2y;
+    size_t       n_splines;
+} forma_flatten_tables_t;
+int forma_hip_flatten(forma_hip_ctx* ctx, const forma_flatten_tables_t* t,
+                      float* out_x, float* out_y);
+
+/* ---- stage entry points for parity tests (host arrays in, host arrays out) ----------------- */
+/* prepare_lines = SegmentBuffer::fill_cpu_view (segment.rs:275-402) on the uploaded geometry.
+ * Each output array has n_points-1 entries; `lengths` holds the INCLUSIVE prefix sums exactly
+ * like the reference (segment.rs:90-98,400).                                                   */
+int forma_hip_prepare_lines(forma_hip_ctx* ctx, uint32_t width, uint32_t height,
+                            uint32_t* orders, float* x0, float* y0, float* dx, float* dy,
+                            float* a, float* b, float* c, float* d, uint32_t* lengths);
+/* rasterize = Rasterizer::rasterize (cpu/rasterizer.rs:92-159) from caller-supplied line
+ * parameters; writes the unsorted u64 stream in reference order (line, then i).              */
+int forma_hip_rasterize(forma_hip_ctx* ctx, size_t n_lines,
+                        const uint32_t* orders, const float* x0, const float* y0,
+                        const float* dx, const float* dy, const float* a, const float* b,
+                        const float* c, const float* d, const uint32_t* lengths,
+                        uint64_t* out_segments, size_t capacity, size_t* out_n);
+/* sort = Rasterizer::sort (cpu/rasterizer.rs:161-164): stable LSB radix on key bits 20..63
+ * (`PixelSegment::cmp`, pixel_segment.rs:161-171).  In place on the host array.
+ * digit_bits: 4 or 8; 0 = library default.                                                    */
+int forma_hip_sort(forma_hip_ctx* ctx, uint64_t* segments, size_t n, int digit_bits);
+/* paint = painter::for_each_row (cpu/painter/mod.rs:717-778) over a caller-supplied SORTED
+ * stream with the uploaded styles.  dst/stride/channels/clear/crop as forma_hip_render.        */
+int forma_hip_paint(forma_hip_ctx* ctx, const uint64_t* sorted_segments, size_t n,
+                    uint8_t* dst, uint32_t width, uint32_t height, size_t stride_bytes,
+                    const uint8_t channels[4], const float clear_color[4],
+                    const forma_rect_t* crop_or_null);
+
+/* ---- the frame: cpu::Renderer::render (renderer.rs:75-224) ---------------------------------- */
+/* dst == NULL leaves the image device-resident (read it with forma_hip_read_image).
+ * cache_id >= 0 selects one of 32 buffer-layer caches (renderer.rs:68-73, buffer/mod.rs:113-197)
+ * and enables the tile_unchanged pass; -1 = no cache.  `timings` may be NULL.                   */
+int forma_hip_render(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t height,
+                     size_t stride_bytes, const uint8_t channels[4],
+                     const float clear_color[4], const forma_rect_t* crop_or_null,
+                     int cache_id, forma_timings_t* timings);
+/* Drop a cache's tile state (BufferLayerCache::clear, buffer/mod.rs:189-196). */
+int forma_hip_cache_clear(forma_hip_ctx* ctx, int cache_id);
+
+/* ---- inspection of the last render (parity tests at full size, bench) ---------------------- */
+/* which: 0 = unsorted stream (rasterizer order), 1 = sorted stream. */
+int forma_hip_read_segments(forma_hip_ctx* ctx, int which, uint64_t* out, size_t capacity,
+                            size_t* out_n);
+int forma_hip_read_image(forma_hip_ctx* ctx, uint8_t* dst, size_t stride_bytes);
+
+/* ---- multi-GPU: tile-row band ownership ---------------------------------------- */
+/* Restrict this context to tile rows [row0, row1): prepare_lines additionally culls lines
+ * entirely outside the band and the rasterizer drops pixel segments of other bands, so the
+ * sort and the painter only see the owner's segments.  row1 == 0 resets to the full canvas.    */
+int forma_hip_set_band(forma_hip_ctx* ctx, uint32_t row0, uint32_t row1);
+/* Device pointers for the exchange step (RCCL all-to-all is driven from the host language
+ * through torch.distributed on these buffers).  Valid until the next render/ingest call.        */
+int forma_hip_segments_device(forma_hip_ctx* ctx, int which, uint64_t** dev_ptr, size_t* n);
+/* Run stages 1-2 only (prepare + rasterize), leaving the unsorted stream on the device. */
+int forma_hip_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height,
+                              forma_timings_t* timings);
+/* Sort + paint a device-resident unsorted stream of n segments (after an exchange the caller
+ * wrote into the buffer returned by forma_hip_reserve_segments).                                */
+int forma_hip_reserve_segments(forma_hip_ctx* ctx, size_t n, uint64_t** dev_ptr);
+int forma_hip_sort_paint_frame(forma_hip_ctx* ctx, size_t n, uint8_t* dst, uint32_t width,
+                               uint32_t height, size_t stride_bytes,
+                               const uint8_t channels[4], const float clear_color[4],
+                               const forma_rect_t* crop_or_null, forma_timings_t* timings);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FORMA_HIP_H */

@@ -1,0 +1,1362 @@
+// forma_oracle.cpp — CPU ORACLE for forma's 4-stage raster pipeline.
+//
+// THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and the
+// `cpu_baseline` leg of bench.py may load it, and only as the checker / reported CPU baseline.
+// The product path (libforma_hip.so) never links, imports or calls anything in oracle/.
+//
+// What it is: a plain C++17 restatement of the reference's CPU backend (the reference is Rust and
+// cannot be built here: no cargo/rustc in the image).  Every function cites the reference
+// file:line it follows (paths relative to /root/reference/forma/src unless noted).  Arithmetic
+// rules: Rust never contracts a*b+c, only `mul_add` is fused -> build with
+// -ffp-contract=off and spell every fma; i8/i16 accumulators wrap; `f32::min/max` ignore NaN
+// (fminf/fmaxf); the SIMD `min/max/select` follow the AVX implementation the reference selects on
+// x86 (`utils/simd/avx.rs`), except `f32x8::recip` (AVX `rcp_ps`, ~12-bit) where the exact 1/x of
+// the portable implementation (`utils/simd/auto.rs:727-730`) is used.
+//
+// Parity pinning: tests/test_oracle_*.py check this file against the reference's own unit-test
+// vectors (rasterizer.rs:204-557, pixel_segment.rs:220-369, painter/mod.rs:1012-1781,
+// path.rs:1023-1627, composition/mod.rs:495-1428, ...) and the 32 CPU PNG goldens of e2e-tests.
+//
+// Third-party arithmetic not in the tree: crumsort 0.1.0 (unstable sort by the 44-bit `Ord`; tie
+// order arbitrary) is restated as a STABLE sort by `v >> 20` — the canonical order a stable LSB
+// radix sort produces; per-key multisets equal the reference's by construction.
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../include/forma_hip.h"
+
+namespace {
+
+constexpr int   PIXEL_WIDTH        = 16;   // consts.rs:21
+constexpr int   PIXEL_SHIFT        = 4;    // consts.rs:23
+constexpr int   TILE_W             = 16;   // consts.rs:31-43
+constexpr int   TILE_H             = 16;
+constexpr float MAX_ERROR          = 1.0f / 16.0f;   // path.rs:40
+constexpr float MAX_ANGLE_ERROR    = 0.001f;         // path.rs:41
+constexpr float F32_EPSILON        = 1.1920929e-7f;
+constexpr float PI_F               = 3.14159265358979323846f;
+constexpr float FRAC_PI_2_F        = 1.57079632679489661923f;
+
+inline float rust_min(float a, float b) { return fminf(a, b); }   // f32::min ignores NaN
+inline float rust_max(float a, float b) { return fmaxf(a, b); }
+inline float avx_min(float a, float b) { return a < b ? a : b; }  // _mm256_min_ps: 2nd on NaN
+inline float avx_max(float a, float b) { return a > b ? a : b; }
+inline uint32_t f2u_sat(float v) {                                // Rust `as u32` (saturating)
+    if (!(v > 0.0f)) return 0u;
+    if (v >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)v;
+}
+inline size_t f2usize_sat(float v) {
+    if (!(v > 0.0f)) return 0;
+    if (v >= 18446744073709551616.0f) return (size_t)-1;
+    return (size_t)v;
+}
+inline uint32_t bits(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+inline float    fbits(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+// ============================================================================================
+// Stage 1 — path building + curve flattening (path.rs)
+// ============================================================================================
+struct Pt { float x, y; };
+inline Pt  operator-(Pt a, Pt b) { return {a.x - b.x, a.y - b.y}; }
+inline float pt_len(Pt p) { return sqrtf(p.x * p.x + p.y * p.y); }   // math/point.rs:80-82
+
+float approx_atan2(float y, float x) {                               // math/point.rs:53-78
+    float x_abs = fabsf(x), y_abs = fabsf(y);
+    float a = rust_min(x_abs, y_abs) / rust_max(x_abs, y_abs);
+    float s = a * a;
+    float r = fmaf(fmaf(fmaf(s, -0.046496473f, 0.15931422f), s, -0.32762277f), s * a, a);
+    if (y_abs > x_abs) r = FRAC_PI_2_F - r;
+    if (x < 0.0f) r = PI_F - r;
+    if (y < 0.0f) r = -r;
+    return r;
+}
+struct OptF { bool some; float v; };
+OptF pt_angle(Pt p) {                                                // math/point.rs:84-86
+    if (pt_len(p) >= F32_EPSILON) return {true, approx_atan2(p.y, p.x)};
+    return {false, 0.0f};
+}
+
+inline float lerp(float t, float a, float b) { return fmaf(t, b, fmaf(-t, a, a)); }  // path.rs:44-46
+float curvature(float x) {                                                            // path.rs:48-51
+    const float C = 0.67f;
+    return x / (1.0f - C + sqrtf(sqrtf(fmaf(x * x, 0.25f, C * C * C * C))));
+}
+float inv_curvature(float k) {                                                        // path.rs:53-56
+    const float C = 0.39f;
+    return k * (1.0f - C + sqrtf(fmaf(k * k, 0.25f, C * C)));
+}
+
+struct WPt { Pt p; float w; };
+Pt applied(WPt p) { float r = 1.0f / p.w; return {p.p.x * r, p.p.y * r}; }            // path.rs:64-73
+
+WPt eval_cubic(float t, const WPt* q) {                                               // path.rs:75-120
+    auto ev = [&](float a, float b, float c, float d) {
+        return lerp(t, lerp(t, lerp(t, a, b), lerp(t, b, c)), lerp(t, lerp(t, b, c), lerp(t, c, d)));
+    };
+    WPt r;
+    r.p.x = ev(q[0].p.x, q[1].p.x, q[2].p.x, q[3].p.x);
+    r.p.y = ev(q[0].p.y, q[1].p.y, q[2].p.y, q[3].p.y);
+    r.w   = ev(q[0].w, q[1].w, q[2].w, q[3].w);
+    return r;
+}
+
+struct Spline { float curvature; Pt p0, p2; bool contour; };                          // path.rs:173-188
+
+struct Primitives {                                                                   // path.rs:190-203
+    OptF last_angle{false, 0};
+    bool contour = true;    // Option<Contour>, Default = Some(Contour) (path.rs:541-558)
+    std::vector<Spline> splines;
+    std::vector<float> x, y, weight, x0, dx_recip, k0, dk, curvatures_recip;
+    std::vector<std::pair<uint32_t, float>> partial_curvatures;
+
+    // path.rs:206-246
+    template <class F> Spline& last_spline_or_insert_with(OptF angle, Pt point, F f) {
+        bool take = false;
+        if (contour) { take = true; contour = false; }
+        else {
+            bool angle_changed = false;
+            if (last_angle.some && angle.some) {
+                float diff = fabsf(angle.v - last_angle.v);
+                if (diff > PI_F) diff -= PI_F;
+                if (diff > FRAC_PI_2_F) diff = PI_F - diff;
+                angle_changed = diff > MAX_ANGLE_ERROR;
+            }
+            if (!splines.empty()) {
+                Spline& s = splines.back();                           // new_spline_needed :182-186
+                bool needed = angle_changed || pt_len(point - s.p2) >= MAX_ERROR;
+                if (needed && s.contour) { s.contour = false; take = true; }
+            }
+        }
+        if (take) splines.push_back(f());
+        return splines.back();
+    }
+    void push_contour() { contour = true; }                           // path.rs:248-250
+
+    void push_line(WPt a, WPt b) {                                    // path.rs:252-269
+        Pt p0 = applied(a), p1 = applied(b);
+        Pt d = p1 - p0;
+        OptF angle = pt_angle(d);
+        Spline& s = last_spline_or_insert_with(angle, p0, [&] { return Spline{0.0f, p0, p1, true}; });
+        s.p2 = p1;
+        last_angle = angle;
+    }
+
+    void push_quad(WPt q0, WPt q1, WPt q2) {                          // path.rs:271-347
+        const float PIXEL_ACCURACY_RECIP = 1.0f / MAX_ERROR;
+        Pt p0 = applied(q0), p1 = applied(q1), p2 = applied(q2);
+        Pt a = p1 - p0, b = p2 - p1;
+        OptF in_angle = pt_angle(a), out_angle = pt_angle(b);
+        if (!in_angle.some && !out_angle.some) return;
+        if (!in_angle.some || !out_angle.some) { push_line(q0, q2); return; }
+        for (WPt q : {q0, q1, q2}) { x.push_back(q.p.x); y.push_back(q.p.y); weight.push_back(q.w); }
+        Spline& s = last_spline_or_insert_with(in_angle, p0, [&] { return Spline{0.0f, p0, p2, true}; });
+        s.p2 = p2;
+        Pt h = a - b;
+        float cross = fmaf(p2.x - p0.x, h.y, -(p2.y - p0.y) * h.x);
+        float cross_recip = 1.0f / cross;
+        float vx0 = fmaf(a.x, h.x, a.y * h.y) * cross_recip;
+        float vx2 = fmaf(b.x, h.x, b.y * h.y) * cross_recip;
+        float vdx_recip = 1.0f / (vx2 - vx0);
+        float scale = fabsf(cross / (pt_len(h) * (vx2 - vx0)));
+        float vk0 = curvature(vx0), vk2 = curvature(vx2);
+        float vdk = vk2 - vk0;
+        float cur = 0.5f * fabsf(vdk) * sqrtf(scale * PIXEL_ACCURACY_RECIP);
+        if (!std::isfinite(cur) || cur <= 1.0f) {
+            vx0 = 0.03662467f; vdx_recip = 1.0f; vk0 = 0.0f; vdk = 1.0f; cur = 2.0f;
+        }
+        float total = s.curvature + cur;
+        s.curvature = total;
+        last_angle = out_angle;
+        x0.push_back(vx0); dx_recip.push_back(vdx_recip); k0.push_back(vk0); dk.push_back(vdk);
+        curvatures_recip.push_back(1.0f / cur);
+        partial_curvatures.push_back({(uint32_t)splines.size() - 1, total});
+    }
+
+    void push_cubic(const WPt* q) {                                   // path.rs:349-398
+        const float MAX_CUBIC_ERROR_SQUARED = (36.0f * 36.0f / 3.0f) * MAX_ERROR * MAX_ERROR;
+        Pt p0 = applied(q[0]), p1 = applied(q[1]), p2 = applied(q[2]);
+        float dx = fmaf(p2.x, 3.0f, -p0.x) - fmaf(p1.x, 3.0f, -p1.x);
+        float dy = fmaf(p2.y, 3.0f, -p0.y) - fmaf(p1.y, 3.0f, -p1.y);
+        float err = fmaf(dx, dx, dy * dy);
+        float mult = rust_max(rust_max(q[1].w, q[2].w), 1.0f);
+        size_t subdivisions =
+            std::max<size_t>(f2usize_sat(ceilf(powf(err * (1.0f / MAX_CUBIC_ERROR_SQUARED), 1.0f / 6.0f) * mult)), 1);
+        float incr = 1.0f / (float)subdivisions;
+        Pt quad_p0 = p0;
+        for (size_t i = 1; i <= subdivisions; i++) {
+            float t = (float)i * incr;
+            Pt quad_p2 = applied(eval_cubic(t, q));
+            Pt mid = applied(eval_cubic(t - 0.5f * incr, q));
+            Pt quad_p1 = {fmaf(mid.x, 2.0f, -0.5f * (quad_p0.x + quad_p2.x)),
+                          fmaf(mid.y, 2.0f, -0.5f * (quad_p0.y + quad_p2.y))};
+            push_quad({quad_p0, 1.0f}, {quad_p1, 1.0f}, {quad_p2, 1.0f});
+            quad_p0 = quad_p2;
+        }
+    }
+
+    Pt eval_quad(size_t qi, float t) const {                          // path.rs:447-471
+        size_t i0 = 3 * qi, i1 = i0 + 1, i2 = i0 + 2;
+        float w = lerp(t, lerp(t, weight[i0], weight[i1]), lerp(t, weight[i1], weight[i2]));
+        float wr = 1.0f / w;
+        float px = lerp(t, lerp(t, x[i0], x[i1]), lerp(t, x[i1], x[i2])) * wr;
+        float py = lerp(t, lerp(t, y[i0], y[i1]), lerp(t, y[i1], y[i2])) * wr;
+        return {px, py};
+    }
+
+    // populate_buffers (path.rs:400-445) + the parallel map of into_segments (path.rs:473-538).
+    void into_segments(std::vector<float>& ox, std::vector<float>& oy, std::vector<uint8_t>& onc) const {
+        size_t i = 0;
+        const Spline* last = nullptr;
+        for (size_t si = 0; si < splines.size(); si++) {
+            const Spline& sp = splines[si];
+            size_t subdivisions = f2usize_sat(ceilf(sp.curvature));
+            float point_command = sp.curvature / (float)subdivisions;
+            bool needs_start = !last || last->contour || pt_len(last->p2 - sp.p0) > MAX_ERROR;
+            if (needs_start) { ox.push_back(sp.p0.x); oy.push_back(sp.p0.y); onc.push_back(0); }
+            for (size_t pi = 1; pi < subdivisions; pi++) {
+                if ((float)pi > partial_curvatures[i].second) i++;
+                size_t qi = i;
+                // map body, path.rs:503-531
+                uint32_t spline_i = partial_curvatures[qi].first;
+                float prev = 0.0f;
+                if (qi >= 1 && partial_curvatures[qi - 1].first == spline_i) prev = partial_curvatures[qi - 1].second;
+                float ratio = fmaf(point_command, (float)pi, -prev) * curvatures_recip[qi];
+                float xx = inv_curvature(fmaf(ratio, dk[qi], k0[qi]));
+                float t = (xx - x0[qi]) * dx_recip[qi];
+                if (t < 0.0f) t = 0.0f;                                // f32::clamp (NaN stays NaN)
+                if (t > 1.0f) t = 1.0f;
+                Pt p = eval_quad(qi, t);
+                ox.push_back(p.x); oy.push_back(p.y); onc.push_back(0);
+            }
+            ox.push_back(sp.p2.x); oy.push_back(sp.p2.y); onc.push_back(sp.contour ? 1 : 0);
+            last = &sp;
+            if (subdivisions > 0) i++;
+        }
+    }
+};
+
+enum PathCmd : uint8_t { CMD_MOVE = 0, CMD_LINE = 1, CMD_QUAD = 2, CMD_CUBIC = 3 };   // path.rs:560-566
+
+struct PathData {                                                      // path.rs:574-581, Default :656-667
+    std::vector<float> x{0.0f}, y{0.0f}, w{1.0f};
+    std::vector<uint8_t> cmds{CMD_MOVE};
+    size_t open_point_index = 0;
+
+    void close() {                                                     // path.rs:596-615
+        size_t len = x.size();
+        WPt last{{x[len - 1], y[len - 1]}, w[len - 1]};
+        WPt open{{x[open_point_index], y[open_point_index]}, w[open_point_index]};
+        Pt a = applied(last), b = applied(open);
+        if (!(a.x == b.x && a.y == b.y)) {
+            x.push_back(open.p.x); y.push_back(open.p.y); w.push_back(open.w);
+            cmds.push_back(CMD_LINE);
+        }
+    }
+    void move_to(float px, float py) {                                 // path.rs:783-810
+        size_t len = x.size();
+        if (cmds.back() == CMD_MOVE) { x[len - 1] = px; y[len - 1] = py; w[len - 1] = 1.0f; }
+        else {
+            close();
+            size_t opi = x.size();
+            x.push_back(px); y.push_back(py); w.push_back(1.0f);
+            cmds.push_back(CMD_MOVE);
+            open_point_index = opi;
+        }
+    }
+    void pt(float px, float py, float pw) { x.push_back(px); y.push_back(py); w.push_back(pw); }
+    void line_to(float px, float py) { pt(px, py, 1); cmds.push_back(CMD_LINE); }                // :812-826
+    void quad_to(float ax, float ay, float bx, float by) { pt(ax, ay, 1); pt(bx, by, 1); cmds.push_back(CMD_QUAD); }
+    void cubic_to(float ax, float ay, float bx, float by, float cx, float cy) {
+        pt(ax, ay, 1); pt(bx, by, 1); pt(cx, cy, 1); cmds.push_back(CMD_CUBIC);
+    }
+    void rat_quad_to(float ax, float ay, float bx, float by, float wt) {                         // :872-889
+        pt(ax * wt, ay * wt, wt); pt(bx, by, 1); cmds.push_back(CMD_QUAD);
+    }
+    void rat_cubic_to(float ax, float ay, float bx, float by, float cx, float cy, float w1, float w2) { // :891-912
+        pt(ax * w1, ay * w1, w1); pt(bx * w2, by * w2, w2); pt(cx, cy, 1); cmds.push_back(CMD_CUBIC);
+    }
+
+    // PathData::segments (path.rs:617-654)
+    void segments(std::vector<float>& ox, std::vector<float>& oy, std::vector<uint8_t>& onc) const {
+        Primitives prim;
+        size_t i = 0;
+        auto P = [&](size_t k) { return WPt{{x[k], y[k]}, w[k]}; };
+        for (uint8_t c : cmds) {
+            switch (c) {
+                case CMD_MOVE: i += 1; prim.push_contour(); break;
+                case CMD_LINE: i += 1; prim.push_line(P(i - 2), P(i - 1)); break;
+                case CMD_QUAD: i += 2; prim.push_quad(P(i - 3), P(i - 2), P(i - 1)); break;
+                case CMD_CUBIC: { i += 3; WPt q[4] = {P(i - 4), P(i - 3), P(i - 2), P(i - 1)}; prim.push_cubic(q); break; }
+            }
+        }
+        prim.into_segments(ox, oy, onc);
+    }
+};
+
+// ============================================================================================
+// Stage 2 — line preparation (segment.rs:275-402) and the pixel-grid intersector
+//           (cpu/rasterizer.rs:32-159, cpu/pixel_segment.rs:36-71)
+// ============================================================================================
+inline uint32_t integers_between(float a, float b) {                  // segment.rs:54-59
+    float mn = rust_min(a, b), mx = rust_max(a, b);
+    return f2u_sat(ceilf(mx) - floorf(mn) - 1.0f);
+}
+
+struct Lines {
+    std::vector<uint32_t> orders, lengths;
+    std::vector<float> x0, y0, dx, dy, a, b, c, d;
+    void resize(size_t n) {
+        orders.assign(n, 0); lengths.assign(n, 0);
+        for (auto* v : {&x0, &y0, &dx, &dy, &a, &b, &c, &d}) v->assign(n, 0.0f);
+    }
+};
+
+void prepare_lines(const float* x, const float* y, const uint32_t* line_slot, size_t n_points,
+                   const forma_geom_t* geoms, size_t n_geoms, float width, float height, Lines& L) {
+    size_t n = n_points ? n_points - 1 : 0;
+    L.resize(n);
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)n; i++) {
+        uint32_t slot = line_slot[i];
+        if (slot == FORMA_NONE || slot >= n_geoms) continue;          // id None / no layer -> empty_line
+        const forma_geom_t& g = geoms[slot];
+        if (g.order == FORMA_NONE) continue;                          // disabled / order None
+        float p0x = x[i], p0y = y[i], p1x = x[i + 1], p1y = y[i + 1];
+        if (g.flags & FORMA_GEOM_HAS_XF) {                            // transform_point segment.rs:30-39
+            float ux = g.xf[0], uy = g.xf[1], vx = g.xf[2], vy = g.xf[3], tx = g.xf[4], ty = g.xf[5];
+            float ax = fmaf(ux, p0x, fmaf(vx, p0y, tx)), ay = fmaf(uy, p0x, fmaf(vy, p0y, ty));
+            float bx = fmaf(ux, p1x, fmaf(vx, p1y, tx)), by = fmaf(uy, p1x, fmaf(vy, p1y, ty));
+            p0x = ax; p0y = ay; p1x = bx; p1y = by;
+        }
+        // skip_line segment.rs:41-52
+        if (p0y == p1y || (p0y >= height && p1y >= height) || (p0x >= width && p1x >= width) ||
+            (p0y <= 0.0f && p1y <= 0.0f))
+            continue;
+        float dx = p1x - p0x, dy = p1y - p0y;
+        float dxr = 1.0f / dx, dyr = 1.0f / dy;
+        float tox = dx != 0.0f ? rust_max((ceilf(p0x) - p0x) * dxr, (floorf(p0x) - p0x) * dxr) : 0.0f;
+        float toy = dy != 0.0f ? rust_max((ceilf(p0y) - p0y) * dyr, (floorf(p0y) - p0y) * dyr) : 0.0f;
+        L.orders[i] = g.order;
+        L.x0[i] = p0x * (float)PIXEL_WIDTH; L.y0[i] = p0y * (float)PIXEL_WIDTH;
+        L.dx[i] = dx * (float)PIXEL_WIDTH;  L.dy[i] = dy * (float)PIXEL_WIDTH;
+        L.a[i] = fabsf(dxr); L.b[i] = fabsf(dyr); L.c[i] = tox; L.d[i] = toy;
+        L.lengths[i] = integers_between(p0x, p1x) + integers_between(p0y, p1y) + 1;  // :86-88
+    }
+    uint32_t sum = 0;                                                  // prefix_sum segment.rs:90-98
+    for (size_t i = 0; i < n; i++) { sum += L.lengths[i]; L.lengths[i] = sum; }
+}
+
+inline float find_term(int32_t i, double a_ab, double b_ab, double cd_ab, float a, float b, float c, float d) {
+    float fi = (float)i;                                               // cpu/rasterizer.rs:32-61
+    float ja = std::isfinite(b) ? (float)ceil(fma(b_ab, (double)fi, -cd_ab)) : fi;
+    float jb = std::isfinite(a) ? (float)ceil(fma(a_ab, (double)fi, cd_ab)) : fi;
+    return rust_min(fmaf(a, ja, c), fmaf(b, jb, d));
+}
+inline int32_t round_sub(float v) { return (int32_t)floorf(v + 0.5f); }   // rasterizer.rs:78-80
+
+inline uint64_t pixel_segment_new(uint32_t layer, int16_t tile_x, int16_t tile_y, uint8_t lx, uint8_t ly,
+                                  uint8_t dam, int8_t cover) {       // cpu/pixel_segment.rs:36-71
+    auto bias = [](int16_t t) -> uint64_t {
+        int16_t v = (int16_t)(uint16_t)((uint16_t)t + 1u);           // wrapping i16 add
+        return (uint64_t)(v > 0 ? v : 0);
+    };
+    uint64_t val = 0;
+    val |= ((1ull << 11) - 1) & bias(tile_y);
+    val <<= 12; val |= ((1ull << 12) - 1) & bias(tile_x);
+    val <<= 21; val |= ((1ull << 21) - 1) & (uint64_t)layer;
+    val <<= 4;  val |= 0xFull & lx;
+    val <<= 4;  val |= 0xFull & ly;
+    val <<= 6;  val |= 0x3Full & dam;
+    val <<= 6;  val |= 0x3Full & (uint64_t)(int64_t)cover;
+    return val;
+}
+// field extractors, pixel_segment.rs:90-138
+inline int      seg_tile_y(uint64_t v) { return (int)(v >> 53) - 1; }
+inline int      seg_tile_x(uint64_t v) { return (int)((v >> 41) & 0xFFF) - 1; }
+inline uint32_t seg_layer(uint64_t v) { return (uint32_t)((v >> 20) & 0x1FFFFF); }
+inline int      seg_lx(uint64_t v) { return (int)((v >> 16) & 0xF); }
+inline int      seg_ly(uint64_t v) { return (int)((v >> 12) & 0xF); }
+inline int      seg_dam(uint64_t v) { return (int)((v >> 6) & 0x3F); }
+inline int      seg_cover(uint64_t v) { return (int)((int64_t)(v << 58) >> 58); }
+inline int16_t  seg_double_area(uint64_t v) { return (int16_t)(seg_dam(v) * seg_cover(v)); }
+
+inline uint64_t rasterize_one(const Lines& L, size_t li, uint32_t seg_i) {   // rasterizer.rs:63-76,103-157
+    float a = L.a[li], b = L.b[li], c = L.c[li], d = L.d[li];
+    int32_t i = (int32_t)seg_i - (c != 0.0f ? 1 : 0) - (d != 0.0f ? 1 : 0);
+    double sum_recip = 1.0 / ((double)a + (double)b);
+    double a_ab = (double)a * sum_recip, b_ab = (double)b * sum_recip;
+    double cd_ab = ((double)c - (double)d) * sum_recip;
+    float t0 = rust_max(find_term(i, a_ab, b_ab, cd_ab, a, b, c, d), 0.0f);
+    float t1 = rust_min(find_term(i + 1, a_ab, b_ab, cd_ab, a, b, c, d), 1.0f);
+    float x0f = fmaf(t0, L.dx[li], L.x0[li]), y0f = fmaf(t0, L.dy[li], L.y0[li]);
+    float x1f = fmaf(t1, L.dx[li], L.x0[li]), y1f = fmaf(t1, L.dy[li], L.y0[li]);
+    int32_t x0s = round_sub(x0f), x1s = round_sub(x1f), y0s = round_sub(y0f), y1s = round_sub(y1f);
+    int32_t border_x = std::min(x0s, x1s) >> PIXEL_SHIFT, border_y = std::min(y0s, y1s) >> PIXEL_SHIFT;
+    int16_t tile_x = (int16_t)(border_x >> 4), tile_y = (int16_t)(border_y >> 4);
+    uint8_t lx = (uint8_t)(border_x & (TILE_W - 1)), ly = (uint8_t)(border_y & (TILE_H - 1));
+    int32_t border = (int32_t)((uint32_t)border_x << PIXEL_SHIFT) + PIXEL_WIDTH;
+    int32_t height = y1s - y0s;
+    uint8_t dam = (uint8_t)(std::abs(x1s - x0s) + 2 * (border - std::max(x0s, x1s)));
+    int8_t cover = (int8_t)height;
+    return pixel_segment_new(L.orders[li], tile_x, tile_y, lx, ly, dam, cover);
+}
+
+void rasterize(const Lines& L, std::vector<uint64_t>& out) {           // rasterizer.rs:92-159
+    size_t n_lines = L.lengths.size();
+    size_t N = n_lines ? L.lengths[n_lines - 1] : 0;
+    out.resize(N);
+#pragma omp parallel for schedule(static, 4096)
+    for (long li = 0; li < (long)n_lines; li++) {                      // PrefixScanIter, prefix_scan.rs:30-63
+        uint32_t ex = li ? L.lengths[li - 1] : 0, in = L.lengths[li];
+        for (uint32_t k = ex; k < in; k++) out[k] = rasterize_one(L, (size_t)li, k - ex);
+    }
+}
+
+// ============================================================================================
+// Stage 3 — sort (cpu/rasterizer.rs:161-164, Ord pixel_segment.rs:161-171): stable on v >> 20
+// ============================================================================================
+void sort_segments(std::vector<uint64_t>& v, int threads) {
+    // LSD radix, 11-bit digits on bits 20..63, stable; identical result to std::stable_sort.
+    size_t n = v.size();
+    if (n < 2) return;
+    std::vector<uint64_t> tmp(n);
+    uint64_t* src = v.data(); uint64_t* dst = tmp.data();
+    (void)threads;
+    for (int shift = 20; shift < 64; shift += 11) {
+        const int B = 2048;
+        std::vector<size_t> cnt(B + 1, 0);
+        for (size_t i = 0; i < n; i++) cnt[((src[i] >> shift) & (B - 1)) + 1]++;
+        bool single = false;
+        for (int k = 0; k < B; k++) if (cnt[k + 1] == n) single = true;
+        if (single) continue;
+        for (int k = 0; k < B; k++) cnt[k + 1] += cnt[k];
+        for (size_t i = 0; i < n; i++) dst[cnt[(src[i] >> shift) & (B - 1)]++] = src[i];
+        std::swap(src, dst);
+    }
+    if (src != v.data()) memcpy(v.data(), src, n * 8);
+}
+
+// ============================================================================================
+// Stage 4 — painter (cpu/painter/mod.rs, cpu/painter/styling.rs, layer_workbench/**)
+// ============================================================================================
+struct Color { float r, g, b, a; };
+inline bool color_eq(Color x, Color y) { return x.r == y.r && x.g == y.g && x.b == y.b && x.a == y.a; }
+
+struct Stop { Color c; float stop; };
+struct Props {                                                         // styling.rs:438-442 decoded
+    bool even_odd = false, is_clip = false, is_clipped = false;
+    uint32_t clip_n = 0;
+    int blend = 0, fill = 0;
+    Color solid{0, 0, 0, 1};
+    float sx = 0, sy = 0, ex = 0, ey = 0;
+    std::vector<Stop> stops;
+    float tex[6]{};       // ux uy vx vy tx ty
+    uint32_t image = 0;
+};
+
+struct Images {
+    const forma_image_t* tab = nullptr; size_t n = 0;
+    const uint16_t* texels = nullptr;
+};
+
+Props decode_props(const uint32_t* w) {
+    Props p; uint32_t h = w[0];
+    p.even_odd = FORMA_STYLE_EVENODD(h); p.is_clip = FORMA_STYLE_IS_CLIP(h);
+    p.is_clipped = FORMA_STYLE_CLIPPED(h); p.clip_n = w[1];
+    p.blend = FORMA_STYLE_BLEND(h); p.fill = FORMA_STYLE_FILL(h);
+    if (p.is_clip) return p;
+    if (p.fill == FORMA_FILL_SOLID) p.solid = {fbits(w[2]), fbits(w[3]), fbits(w[4]), fbits(w[5])};
+    else if (p.fill == FORMA_FILL_TEXTURE) { for (int i = 0; i < 6; i++) p.tex[i] = fbits(w[2 + i]); p.image = w[8]; }
+    else {
+        p.sx = fbits(w[2]); p.sy = fbits(w[3]); p.ex = fbits(w[4]); p.ey = fbits(w[5]);
+        uint32_t ns = FORMA_STYLE_STOPS(h);
+        for (uint32_t s = 0; s < ns; s++) {
+            const uint32_t* q = w + 6 + 5 * s;
+            p.stops.push_back({{fbits(q[0]), fbits(q[1]), fbits(q[2]), fbits(q[3])}, fbits(q[4])});
+        }
+    }
+    return p;
+}
+
+struct Cover {                                                         // painter/mod.rs:169-215
+    int8_t c[16]{};
+    bool is_empty(bool even_odd) const {
+        for (int i = 0; i < 16; i++) {
+            if (!even_odd) { if (c[i] != 0) return false; }
+            else { int8_t a = (int8_t)(c[i] < 0 ? (int8_t)(-(uint8_t)c[i]) : c[i]); if ((a & 31) != 0) return false; }
+        }
+        return true;
+    }
+    bool is_full(bool even_odd) const {
+        for (int i = 0; i < 16; i++) {
+            int8_t a = (int8_t)(c[i] < 0 ? (int8_t)(-(uint8_t)c[i]) : c[i]);   // _mm_abs_epi8 (abs(-128) = -128)
+            if (!even_odd) { if (a != 16) return false; }
+            else { if ((a & 31) != 16) return false; }                 // one i8x16 chunk: any(all) == all
+        }
+        return true;
+    }
+};
+struct CoverCarry { Cover cover; uint32_t layer; };
+
+// ---- fills (cpu/painter/styling.rs:58-193) — evaluated per 8-lane column vector --------------
+inline float f16_to_f32(uint16_t h) { return h != 0 ? fbits(0x38000000u + ((uint32_t)h << 13)) : 0.0f; } // styling.rs:232-240
+
+void gradient_color_at(const Props& p, float x, float y, float out[4][8]) {   // styling.rs:58-143
+    float dx = p.ex - p.sx, dy = p.ey - p.sy;
+    float dot = dx * dx + dy * dy;
+    float dot_recip = 1.0f / dot;
+    float t[8];
+    if (p.fill == FORMA_FILL_LINEAR) {
+        float tx = (x - p.sx) * dx * dot_recip;
+        float ty = y - p.sy;
+        for (int j = 0; j < 8; j++) t[j] = fmaf(((float)j + ty) * dy, dot_recip, tx);
+    } else {
+        float px = x - p.sx;
+        float px2 = px * px;
+        float yy = y - p.sy;
+        for (int j = 0; j < 8; j++) { float py = (float)j + yy; t[j] = sqrtf(fmaf(py, py, px2) * dot_recip); }
+    }
+    uint32_t ch[4][8] = {};
+    bool mask[8], acc[8];
+    auto orsel = [&](const bool* m, const float v[4][8]) {
+        for (int c = 0; c < 4; c++) for (int j = 0; j < 8; j++) ch[c][j] |= m[j] ? bits(v[c][j]) : bits(0.0f);
+    };
+    bool any = false;
+    for (int j = 0; j < 8; j++) { mask[j] = t[j] <= p.stops[0].stop; any |= mask[j]; }
+    if (any) {
+        float v[4][8]; const Color& s = p.stops[0].c; float cc[4] = {s.r, s.g, s.b, s.a};
+        for (int c = 0; c < 4; c++) for (int j = 0; j < 8; j++) v[c][j] = cc[c];
+        orsel(mask, v);
+    }
+    float start_stop = 0.0f; Color start_color = p.stops[0].c;
+    for (int j = 0; j < 8; j++) acc[j] = mask[j];
+    for (size_t k = 1; k < p.stops.size(); k++) {
+        Color color = p.stops[k].c; float end_stop = p.stops[k].stop;
+        any = false;
+        for (int j = 0; j < 8; j++) { mask[j] = acc[j] ^ (t[j] < end_stop); any |= mask[j]; }
+        if (any) {
+            float d = end_stop - start_stop; float dr = 1.0f / d;
+            float v[4][8]; float sc[4] = {start_color.r, start_color.g, start_color.b, start_color.a};
+            float ec[4] = {color.r, color.g, color.b, color.a};
+            for (int j = 0; j < 8; j++) {
+                float lt = (t[j] - start_stop) * dr;
+                for (int c = 0; c < 4; c++) v[c][j] = fmaf(lt, ec[c], fmaf(-lt, sc[c], sc[c]));
+            }
+            orsel(mask, v);
+            for (int j = 0; j < 8; j++) acc[j] = acc[j] | mask[j];
+        }
+        start_stop = end_stop; start_color = color;
+    }
+    any = false;
+    for (int j = 0; j < 8; j++) { mask[j] = !acc[j]; any |= mask[j]; }
+    if (any) {
+        float v[4][8]; const Color& s = p.stops.back().c; float cc[4] = {s.r, s.g, s.b, s.a};
+        for (int c = 0; c < 4; c++) for (int j = 0; j < 8; j++) v[c][j] = cc[c];
+        orsel(mask, v);
+    }
+    for (int c = 0; c < 4; c++) for (int j = 0; j < 8; j++) out[c][j] = fbits(ch[c][j]);
+}
+
+void texture_color_at(const Props& p, const Images& im, float x, float y, float out[4][8]) { // styling.rs:145-193
+    const forma_image_t& I = im.tab[p.image];
+    float max_x = (float)I.width - 1.0f, max_y = (float)I.height - 1.0f;
+    float ux = p.tex[0], uy = p.tex[1], vx = p.tex[2], vy = p.tex[3], tx = p.tex[4], ty = p.tex[5];
+    for (int j = 0; j < 8; j++) {
+        float yy = y + (float)j;
+        float fx = fmaf(x, ux, fmaf(vx, yy, tx));
+        float fy = fmaf(x, uy, fmaf(vy, yy, ty));
+        // u32x8::from(f32x8): max(0) then truncate (avx.rs:326-332); min() first (AVX semantics)
+        float cx = avx_max(avx_min(fx, max_x), 0.0f), cy = avx_max(avx_min(fy, max_y), 0.0f);
+        uint32_t ix = (uint32_t)(int32_t)cx, iy = (uint32_t)(int32_t)cy;
+        uint32_t off = iy * I.width + ix;
+        const uint16_t* px = im.texels + 4 * (I.texel_offset + off);
+        for (int c = 0; c < 4; c++) out[c][j] = f16_to_f32(px[c]);
+    }
+}
+
+// ---- blend functions, SIMD form (cpu/painter/styling.rs:342-594) ------------------------------
+inline float lum3(float r, float g, float b) { return fmaf(r, 0.3f, fmaf(g, 0.59f, b * 0.11f)); }
+inline float sat3(float r, float g, float b) { return avx_max(r, avx_max(g, b)) - avx_min(r, avx_min(g, b)); }
+inline void clip_color(float& r, float& g, float& b) {                 // :364-396
+    float l = lum3(r, g, b);
+    float n = avx_min(r, avx_min(g, b));
+    float x = avx_max(r, avx_max(g, b));
+    float l_1 = l - 1.0f;
+    float x_l_recip = 1.0f / (x - l);                                  // exact recip (auto.rs:727-730)
+    float l_n_recip_l = (1.0f / (l - n)) * l;
+    auto one = [&](float c) {
+        float hi = fmaf(x_l_recip, fmaf(l, l_1 - c, c), l);
+        float lo = fmaf(l_n_recip_l, c - l, l);
+        float inner = (n < 0.0f) ? lo : c;
+        return (1.0f < x) ? hi : inner;
+    };
+    float nr = one(r), ng = one(g), nb = one(b);
+    r = nr; g = ng; b = nb;
+}
+inline void set_lum(float& r, float& g, float& b, float l) {           // :398-406
+    float d = l - lum3(r, g, b);
+    r += d; g += d; b += d;
+    clip_color(r, g, b);
+}
+inline void set_sat(float sat_dst, float sr, float sg, float sb, float out[3]) {   // :408-435
+    float src_min = avx_min(sr, avx_min(sg, sb));
+    float src_max = avx_max(sr, avx_max(sg, sb));
+    float src_mid = sr + sg + sb - src_min - src_max;
+    bool lt = src_min < src_max;
+    float sat_mid = lt ? (fmaf(sat_dst, -src_min, sat_dst * src_mid) / (src_max - src_min)) : 0.0f;
+    float sat_max = lt ? sat_dst : 0.0f;
+    float in[3] = {sr, sg, sb};
+    for (int k = 0; k < 3; k++) out[k] = (in[k] == src_max) ? sat_max : ((in[k] == src_min) ? 0.0f : sat_mid);
+}
+
+void blend_rgb(int mode, float dr, float dg, float db, float sr, float sg, float sb, float out[3]) {
+    float d[3] = {dr, dg, db}, s[3] = {sr, sg, sb};
+    switch (mode) {
+        case 0: out[0] = sr; out[1] = sg; out[2] = sb; return;                                  // Over
+        case 1: for (int k = 0; k < 3; k++) out[k] = d[k] * s[k]; return;                       // Multiply
+        case 2: for (int k = 0; k < 3; k++) out[k] = fmaf(d[k], -s[k], d[k]) + s[k]; return;    // Screen
+        case 3: for (int k = 0; k < 3; k++)                                                     // Overlay
+                out[k] = (d[k] <= 0.5f) ? (d[k] * s[k] * 2.0f) : (2.0f * (d[k] + s[k] - fmaf(d[k], s[k], 0.5f)));
+            return;
+        case 4: for (int k = 0; k < 3; k++) out[k] = avx_min(d[k], s[k]); return;               // Darken
+        case 5: for (int k = 0; k < 3; k++) out[k] = avx_max(d[k], s[k]); return;               // Lighten
+        case 6: for (int k = 0; k < 3; k++)                                                     // ColorDodge
+                out[k] = (s[k] == 1.0f) ? 1.0f : avx_min(1.0f, d[k] / (1.0f - s[k]));
+            return;
+        case 7: for (int k = 0; k < 3; k++)                                                     // ColorBurn
+                out[k] = (s[k] == 0.0f) ? 0.0f : (1.0f - avx_min(1.0f, (1.0f - d[k]) / s[k]));
+            return;
+        case 8: for (int k = 0; k < 3; k++)                                                     // HardLight
+                out[k] = (s[k] <= 0.5f) ? (d[k] * s[k] * 2.0f) : (2.0f * (d[k] + s[k] - fmaf(d[k], s[k], 0.5f)));
+            return;
+        case 9: for (int k = 0; k < 3; k++) {                                                   // SoftLight
+                float dd = (d[k] <= 0.25f) ? (fmaf(fmaf(16.0f, d[k], -12.0f), d[k], 4.0f) * d[k]) : sqrtf(d[k]);
+                float m = fmaf(2.0f, s[k], -1.0f);
+                out[k] = (s[k] <= 0.5f) ? fmaf(d[k] * (1.0f - d[k]), m, d[k]) : fmaf(dd - d[k], m, d[k]);
+            }
+            return;
+        case 10: for (int k = 0; k < 3; k++) out[k] = fabsf(d[k] - s[k]); return;               // Difference
+        case 11: for (int k = 0; k < 3; k++) out[k] = fmaf(-2.0f * d[k], s[k], d[k]) + s[k]; return; // Exclusion
+        case 12: {                                                                              // Hue
+            float t[3]; set_sat(sat3(dr, dg, db), sr, sg, sb, t);
+            set_lum(t[0], t[1], t[2], lum3(dr, dg, db)); out[0] = t[0]; out[1] = t[1]; out[2] = t[2]; return;
+        }
+        case 13: {                                                                              // Saturation
+            float t[3]; set_sat(sat3(sr, sg, sb), dr, dg, db, t);
+            set_lum(t[0], t[1], t[2], lum3(dr, dg, db)); out[0] = t[0]; out[1] = t[1]; out[2] = t[2]; return;
+        }
+        case 14: { float t[3] = {sr, sg, sb}; set_lum(t[0], t[1], t[2], lum3(dr, dg, db));      // Color
+                   out[0] = t[0]; out[1] = t[1]; out[2] = t[2]; return; }
+        default: { float t[3] = {dr, dg, db}; set_lum(t[0], t[1], t[2], lum3(sr, sg, sb));      // Luminosity
+                   out[0] = t[0]; out[1] = t[1]; out[2] = t[2]; return; }
+    }
+}
+
+// ---- scalar BlendMode::blend (cpu/painter/styling.rs:195-340), used by the solid-tile fold ----
+float scalar_blend_fn(int mode, int c, Color dst, Color src) {
+    auto ch = [](Color k, int i) { return i == 0 ? k.r : (i == 1 ? k.g : k.b); };
+    auto multiply = [](float d, float s) { return d * s; };
+    auto screen = [](float d, float s) { return d + s - (d * s); };
+    auto hard_light = [&](float d, float s) { return s <= 0.5f ? multiply(d, 2.0f * s) : screen(d, 2.0f * s - 1.0f); };
+    auto lum = [](Color k) { return fmaf(k.r, 0.3f, fmaf(k.g, 0.59f, k.b * 0.11f)); };
+    auto cmin = [](Color k) { return rust_min(k.r, rust_min(k.g, k.b)); };
+    auto cmax = [](Color k) { return rust_max(k.r, rust_max(k.g, k.b)); };
+    auto clip_color = [&](int i, Color k) {
+        float l = lum(k), n = cmin(k), x = cmax(k);
+        float v = ch(k, i);
+        if (n < 0.0f) { float t = (1.0f / (l - n)) * l; v = fmaf(t, v - l, l); }
+        if (x > 1.0f) { float l_1 = l - 1.0f; float xr = 1.0f / (x - l); v = fmaf(xr, fmaf(l, l_1 - v, v), l); }
+        return v;
+    };
+    auto set_lum = [&](int i, Color k, float l) { float dd = l - lum(k); k.r += dd; k.g += dd; k.b += dd; return clip_color(i, k); };
+    auto sat = [&](Color k) { return cmax(k) - cmin(k); };
+    auto set_sat = [&](Color k, float s) {
+        float cc[3] = {k.r, k.g, k.b};
+        int imin, imid, imax;                                          // Color::sorted styling.rs:38-50
+        bool a = cc[0] < cc[1], b = cc[0] < cc[2], cq = cc[1] < cc[2];
+        if (a && b && cq) { imin = 0; imid = 1; imax = 2; }
+        else if (a && b && !cq) { imin = 0; imid = 2; imax = 1; }
+        else if (a && !b) { imin = 2; imid = 0; imax = 1; }
+        else if (!a && b && cq) { imin = 1; imid = 0; imax = 2; }
+        else if (!a && !cq) { imin = 2; imid = 1; imax = 0; }
+        else { imin = 1; imid = 2; imax = 0; }
+        if (cc[imax] > cc[imin]) { cc[imid] = fmaf(s, cc[imid], -s * cc[imin]) / (cc[imax] - cc[imin]); cc[imax] = s; }
+        else { cc[imid] = 0.0f; cc[imax] = 0.0f; }
+        cc[imin] = 0.0f;
+        return Color{cc[0], cc[1], cc[2], k.a};
+    };
+    float d = ch(dst, c), s = ch(src, c);
+    switch (mode) {
+        case 0: return s;
+        case 1: return multiply(d, s);
+        case 2: return screen(d, s);
+        case 3: return hard_light(s, d);
+        case 4: return rust_min(d, s);
+        case 5: return rust_max(d, s);
+        case 6: return d == 0.0f ? 0.0f : (s == 1.0f ? 1.0f : rust_min(1.0f, d / (1.0f - s)));
+        case 7: return d == 1.0f ? 1.0f : (s == 0.0f ? 0.0f : 1.0f - rust_min(1.0f, (1.0f - d) / s));
+        case 8: return hard_light(d, s);
+        case 9: {
+            auto dfn = [](float v) { return v <= 0.25f ? ((16.0f * v - 12.0f) * v + 4.0f) * v : sqrtf(v); };
+            return s <= 0.5f ? d - (1.0f - 2.0f * s) * d * (1.0f - d) : d + (2.0f * s - 1.0f) * (dfn(d) - d);
+        }
+        case 10: return fabsf(d - s);
+        case 11: return d + s - 2.0f * d * s;
+        case 12: return set_lum(c, set_sat(src, sat(dst)), lum(dst));
+        case 13: return set_lum(c, set_sat(dst, sat(src)), lum(dst));
+        case 14: return set_lum(c, src, lum(dst));
+        default: return set_lum(c, dst, lum(src));
+    }
+}
+Color scalar_blend(int mode, Color dst, Color src) {                   // styling.rs:315-339
+    float ida = 1.0f - dst.a, k1 = ida * src.a, isa = 1.0f - src.a, k2 = dst.a * src.a;
+    float cr = fmaf(src.r, k1, scalar_blend_fn(mode, 0, dst, src) * k2);
+    float cg = fmaf(src.g, k1, scalar_blend_fn(mode, 1, dst, src) * k2);
+    float cb = fmaf(src.b, k1, scalar_blend_fn(mode, 2, dst, src) * k2);
+    return {fmaf(dst.r, isa, cr), fmaf(dst.g, isa, cg), fmaf(dst.b, isa, cb), fmaf(dst.a, isa, src.a)};
+}
+
+// ---- encode (painter/mod.rs:96-162, 466-483) ----------------------------------------------------
+inline float linear_to_srgb(float l) {                                 // :96-112
+    float s = sqrtf(l), s3 = l * s;
+    float m = l * 12.92f;
+    float n = fmaf(0.20101772f, s3, fmaf(-0.51280147f, l, fmaf(1.344401f, s, -0.030656587f)));
+    return (l <= 0.0031308f) ? m : n;
+}
+inline uint32_t to_u32_x8(float v) {                                   // to_u32x8 :134-143 (clamp = min(max).max(min))
+    float scaled = avx_max(avx_min(v * 255.0f, 255.0f), 0.0f);
+    return bits(scaled + fbits(0x4B000000u));
+}
+inline uint32_t to_u32_x4(float v) {                                   // to_u32x4 :145-154 (clamp = min(max(v,0),255))
+    float scaled = avx_min(avx_max(v * 255.0f, 0.0f), 255.0f);
+    return bits(scaled + fbits(0x4B000000u));
+}
+inline float color_channel(Color k, int c) {                           // styling.rs:52-61
+    switch (c) { case 0: return k.r; case 1: return k.g; case 2: return k.b; case 3: return k.a; case 4: return 0.0f; default: return 1.0f; }
+}
+void to_srgb_bytes(const float color[4], uint8_t out[4]) {             // painter/mod.rs:156-162
+    for (int i = 0; i < 3; i++) out[i] = (uint8_t)(to_u32_x4(linear_to_srgb(color[i])) & 0xFF);
+    out[3] = (uint8_t)(to_u32_x4(color[3]) & 0xFF);
+}
+
+// ---- CachedTile (painter/mod.rs:629-715) --------------------------------------------------------
+struct CachedTile {
+    uint8_t tags = 0; uint32_t layer_count = 0; uint8_t solid[4]{};
+    bool has_lc() const { return tags & 2; }
+    bool has_sc() const { return tags & 1; }
+};
+struct Cache {                                                         // buffer/mod.rs:104-111
+    bool has_clear = false; Color clear{};
+    std::vector<CachedTile> tiles;
+    bool has_dims = false; size_t w = 0, h = 0;
+    void clear_all() { has_clear = false; for (auto& t : tiles) t = CachedTile(); }   // :189-196
+};
+
+struct PaintCtx {
+    const std::vector<Props>* props_by_order;
+    const std::vector<uint8_t>* have_props;
+    const uint8_t* unchanged;   // per order, may be null
+    bool has_cache;
+    Images images;
+    const Props& get(uint32_t id) const { return (*props_by_order)[id]; }
+    bool is_unchanged(uint32_t id) const { return has_cache && unchanged && unchanged[id]; }   // renderer.rs:143-156
+};
+
+struct Painter {                                                       // painter/mod.rs:232-245
+    int16_t areas[256]; int8_t covers[17 * 16];
+    bool has_clip = false; float clip_mask[256]; uint32_t clip_last = 0;
+    float r[256], g[256], b[256], a[256];                              // column-major: x*16+y
+    uint8_t srgb[1024];
+
+    void clear_cells() { memset(areas, 0, sizeof areas); memset(covers, 0, sizeof covers); }   // :248-255
+    void acc_segment(uint64_t s) {                                     // :257-271
+        int x = seg_lx(s), y = seg_ly(s);
+        areas[x * 16 + y] = (int16_t)(areas[x * 16 + y] + seg_double_area(s));
+        covers[(x + 1) * 16 + y] = (int8_t)(covers[(x + 1) * 16 + y] + seg_cover(s));
+    }
+    void acc_cover(const Cover& c) { for (int i = 0; i < 16; i++) covers[i] = (int8_t)(covers[i] + c.c[i]); } // :273-275
+    void clear(Color k) { for (int i = 0; i < 256; i++) { r[i] = k.r; g[i] = k.g; b[i] = k.b; a[i] = k.a; } } // :277-288
+
+    static float coverage(int32_t A, bool even_odd) {                  // doubled_area_to_coverage :76-94
+        if (!even_odd) {
+            float v = fabsf((float)A * (1.0f / 512.0f));
+            return avx_max(avx_min(v, 1.0f), 0.0f);
+        }
+        int32_t v = (A & 1023) - 512; if (v < 0) v = -v;
+        return (float)(512 - v) * (1.0f / 512.0f);
+    }
+
+    Cover paint_layer(size_t tile_x, size_t tile_y, uint32_t layer_id, const Props& p, bool apply_clip,
+                      const PaintCtx& ctx) {                           // :290-347
+        int8_t acc[16] = {};
+        if (has_clip && clip_last < layer_id) has_clip = false;
+        for (int x = 0; x <= 16; x++) {
+            if (x != 0) {
+                int32_t A[16];
+                for (int y = 0; y < 16; y++) A[y] = 32 * (int32_t)acc[y] + (int32_t)areas[(x - 1) * 16 + y];  // :388-404
+                for (int yv = 0; yv < 2; yv++) {
+                    float cov[8]; bool all_zero = true;
+                    for (int j = 0; j < 8; j++) { cov[j] = coverage(A[yv * 8 + j], p.even_odd); if (!(cov[j] == 0.0f)) all_zero = false; }
+                    if (!p.is_clip) {
+                        if (all_zero) continue;
+                        if (apply_clip && !has_clip) continue;
+                        float fill[4][8];
+                        float fx = (float)(x - 1 + tile_x * 16), fy = (float)(yv * 8 + tile_y * 16);
+                        if (p.fill == FORMA_FILL_SOLID) {
+                            for (int j = 0; j < 8; j++) { fill[0][j] = p.solid.r; fill[1][j] = p.solid.g; fill[2][j] = p.solid.b; fill[3][j] = p.solid.a; }
+                        } else if (p.fill == FORMA_FILL_TEXTURE) texture_color_at(p, ctx.images, fx, fy, fill);
+                        else gradient_color_at(p, fx, fy, fill);
+                        for (int j = 0; j < 8; j++) {                  // blend_at :406-447
+                            int i = (x - 1) * 16 + yv * 8 + j;
+                            float src_a = fill[3][j] * cov[j];
+                            if (apply_clip && has_clip) src_a *= clip_mask[i];
+                            float bl[3];
+                            blend_rgb(p.blend, r[i], g[i], b[i], fill[0][j], fill[1][j], fill[2][j], bl);
+                            float ida = 1.0f - a[i], k1 = ida * src_a, isa = 1.0f - src_a, k2 = a[i] * src_a;
+                            float cr = fmaf(fill[0][j], k1, bl[0] * k2);
+                            float cg = fmaf(fill[1][j], k1, bl[1] * k2);
+                            float cb = fmaf(fill[2][j], k1, bl[2] * k2);
+                            r[i] = fmaf(r[i], isa, cr); g[i] = fmaf(g[i], isa, cg); b[i] = fmaf(b[i], isa, cb);
+                            a[i] = fmaf(a[i], isa, src_a);
+                        }
+                    } else {                                           // clip_at :449-464
+                        if (!has_clip) { has_clip = true; clip_last = layer_id + p.clip_n; for (int i = 0; i < 256; i++) clip_mask[i] = 0.0f; }
+                        for (int j = 0; j < 8; j++) clip_mask[(x - 1) * 16 + yv * 8 + j] = cov[j];
+                    }
+                }
+            }
+            for (int y = 0; y < 16; y++) acc[y] = (int8_t)(acc[y] + covers[x * 16 + y]);
+        }
+        Cover out; memcpy(out.c, acc, 16); return out;
+    }
+
+    void compute_srgb(const uint8_t ch[4]) {                           // :466-483
+        for (int i = 0; i < 256; i++) {
+            float sr = linear_to_srgb(r[i]), sg = linear_to_srgb(g[i]), sb = linear_to_srgb(b[i]);
+            for (int c = 0; c < 4; c++) {
+                float v;
+                switch (ch[c]) { case 0: v = sr; break; case 1: v = sg; break; case 2: v = sb; break; case 3: v = a[i]; break; case 4: v = 0.0f; break; default: v = 1.0f; }
+                srgb[i * 4 + c] = (uint8_t)(to_u32_x8(v) & 0xFF);
+            }
+        }
+    }
+};
+
+enum class TileOp { None, Solid, ColorBuffer };
+
+struct Workbench {                                                     // layer_workbench/mod.rs:147-342
+    struct Id { uint32_t id; bool mask; };
+    std::vector<Id> ids; size_t skipped = 0;
+    std::unordered_map<uint32_t, std::pair<size_t, size_t>> seg_ranges;   // inclusive
+    std::unordered_map<uint32_t, size_t> queue_idx;
+    std::vector<CoverCarry> queue, next_queue;
+    std::unordered_set<uint32_t> skip_clipping; bool layers_were_removed = true;
+
+    void init(std::vector<CoverCarry>&& cc) { queue = std::move(cc); }
+    void next_tile() {
+        ids.clear(); skipped = 0; seg_ranges.clear(); queue_idx.clear();
+        std::swap(queue, next_queue); next_queue.clear();
+        skip_clipping.clear(); layers_were_removed = true;
+    }
+    const Cover* cover(uint32_t id) const { auto it = queue_idx.find(id); return it == queue_idx.end() ? nullptr : &queue[it->second].cover; }
+    bool has_segments(uint32_t id) const { return seg_ranges.count(id) != 0; }
+    bool layer_is_full(uint32_t id, bool even_odd) const {             // :175-187
+        if (has_segments(id)) return false;
+        const Cover* c = cover(id); return c && c->is_full(even_odd);
+    }
+    bool cover_carry(const uint64_t* segs, uint32_t id, const PaintCtx& ctx, CoverCarry& out) const {  // :213-234
+        Cover acc;
+        auto it = seg_ranges.find(id);
+        if (it != seg_ranges.end())
+            for (size_t k = it->second.first; k <= it->second.second; k++) acc.c[seg_ly(segs[k])] = (int8_t)(acc.c[seg_ly(segs[k])] + seg_cover(segs[k]));
+        if (const Cover* c = cover(id)) for (int i = 0; i < 16; i++) acc.c[i] = (int8_t)(acc.c[i] + c->c[i]);
+        if (acc.is_empty(ctx.get(id).even_odd)) return false;
+        out = {acc, id}; return true;
+    }
+    void populate_layers(const uint64_t* segs, size_t n) {             // :250-278
+        size_t start = 0;
+        while (start < n) {
+            uint32_t id = seg_layer(segs[start]);
+            size_t end = start;
+            while (end + 1 < n && seg_layer(segs[end + 1]) == id) end++;
+            seg_ranges[id] = {start, end};
+            start = end + 1;
+        }
+        for (size_t i = 0; i < queue.size(); i++) queue_idx[queue[i].layer] = i;
+        std::vector<uint32_t> all;
+        for (auto& kv : seg_ranges) all.push_back(kv.first);
+        for (auto& kv : queue_idx) all.push_back(kv.first);
+        std::sort(all.begin(), all.end()); all.erase(std::unique(all.begin(), all.end()), all.end());
+        for (uint32_t id : all) ids.push_back({id, true});
+    }
+};
+
+struct TileCtx {
+    size_t tile_x, tile_y; const uint64_t* segs; size_t n;
+    bool has_cached_clear; Color cached_clear; CachedTile* cached_tile;
+    uint8_t channels[4]; Color clear;
+};
+
+// passes/*.rs.  Returns: 0 continue, 1 Break(None), 2 Break(Solid(color))
+int optimization_passes(Workbench& wb, const TileCtx& t, const PaintCtx& ctx, Color& solid) {
+    // tile_unchanged_pass (passes/tile_unchanged.rs)
+    {
+        bool clear_unchanged = t.has_cached_clear && color_eq(t.cached_clear, t.clear);
+        if (t.cached_tile) {
+            uint32_t layers = (uint32_t)wb.ids.size();
+            bool had = t.cached_tile->has_lc(); uint32_t prev = t.cached_tile->layer_count;
+            t.cached_tile->tags |= 2; t.cached_tile->layer_count = layers & 0xFFFFFF;
+            bool unchanged = false;
+            if (had) {
+                wb.layers_were_removed = layers < prev;
+                unchanged = prev == layers;
+                if (unchanged) for (auto& e : wb.ids) if (!ctx.is_unchanged(e.id)) { unchanged = false; break; }
+            }
+            if (clear_unchanged && unchanged) return 1;
+        }
+    }
+    // skip_trivial_clips_pass (passes/skip_trivial_clips.rs)
+    {
+        struct Clip { bool is_full; uint32_t last; size_t i; bool used; };
+        bool has = false; Clip clip{};
+        for (size_t i = wb.skipped; i < wb.ids.size(); i++) {
+            if (!wb.ids[i].mask) continue;
+            uint32_t id = wb.ids[i].id; const Props& p = ctx.get(id);
+            if (p.is_clip) {
+                bool full = wb.layer_is_full(id, p.even_odd);
+                clip = {full, id + p.clip_n, i, false}; has = true;
+                if (full) wb.ids[i].mask = false;
+            }
+            if (!p.is_clip && p.is_clipped) {
+                if (has && id <= clip.last) { if (clip.is_full) wb.skip_clipping.insert(id); else clip.used = true; }
+                else wb.ids[i].mask = false;
+            }
+            if (has && id > clip.last) { has = false; if (!clip.used) wb.ids[clip.i].mask = false; }
+        }
+        if (has && !clip.used) wb.ids[clip.i].mask = false;
+    }
+    // skip_fully_covered_layers_pass (passes/skip_fully_covered_layers.rs)
+    {
+        int first = 0;  // 0 none, 1 opaque, 2 incomplete
+        Color opaque{};
+        bool visible_unchanged = !wb.layers_were_removed;
+        for (size_t k = wb.ids.size(); k-- > wb.skipped;) {
+            if (!wb.ids[k].mask) continue;
+            uint32_t id = wb.ids[k].id; const Props& p = ctx.get(id);
+            if (!ctx.is_unchanged(id)) visible_unchanged = false;
+            bool is_clipped = !p.is_clip && p.is_clipped && !wb.skip_clipping.count(id);
+            if (is_clipped || !wb.layer_is_full(id, p.even_odd)) { if (first == 0) first = 2; }
+            else if (!p.is_clip && p.fill == FORMA_FILL_SOLID && p.blend == 0) {
+                if (p.solid.a == 1.0f) {
+                    if (first == 0) { first = 1; opaque = p.solid; }
+                    wb.skipped = k;
+                    break;
+                }
+            }
+        }
+        size_t skip_n; Color bottom;
+        if (first == 1) { if (visible_unchanged) return 1; skip_n = 1; bottom = opaque; }
+        else if (first == 0) { skip_n = 0; bottom = t.clear; }
+        else return 0;
+        Color dst = bottom; size_t seen = 0;
+        for (size_t k = wb.skipped; k < wb.ids.size(); k++) {
+            if (!wb.ids[k].mask) continue;
+            if (seen++ < skip_n) continue;
+            const Props& p = ctx.get(wb.ids[k].id);
+            if (!p.is_clip && p.fill == FORMA_FILL_SOLID) dst = scalar_blend(p.blend, dst, p.solid);
+            else return 0;
+        }
+        solid = dst; return 2;
+    }
+}
+
+TileOp drive_tile_painting(Workbench& wb, Painter& painter, const TileCtx& t, const PaintCtx& ctx, uint8_t solid_out[4]) {
+    wb.populate_layers(t.segs, t.n);                                   // layer_workbench/mod.rs:280-342
+    Color solid{};
+    int op = optimization_passes(wb, t, ctx, solid);
+    // CachedTile::convert_optimizer_op (painter/mod.rs:684-714)
+    bool brk = false; TileOp result = TileOp::ColorBuffer;
+    if (op == 2) {
+        float sel[4]; for (int c = 0; c < 4; c++) sel[c] = color_channel(solid, t.channels[c]);
+        uint8_t bytes[4]; to_srgb_bytes(sel, bytes);
+        bool unchanged = false;
+        if (t.cached_tile) {
+            bool had = t.cached_tile->has_sc(); uint8_t prev[4]; memcpy(prev, t.cached_tile->solid, 4);
+            t.cached_tile->tags |= 1; memcpy(t.cached_tile->solid, bytes, 4);
+            unchanged = had && memcmp(prev, bytes, 4) == 0;
+        }
+        brk = true;
+        if (unchanged) result = TileOp::None; else { result = TileOp::Solid; memcpy(solid_out, bytes, 4); }
+    } else if (op == 1) { brk = true; result = TileOp::None; }
+    else if (t.cached_tile) t.cached_tile->tags &= 2;                  // update_solid_color(None)
+
+    if (brk) {
+        for (auto& e : wb.ids) { CoverCarry cc; if (wb.cover_carry(t.segs, e.id, ctx, cc)) wb.next_queue.push_back(cc); }
+        wb.next_tile();
+        return result;
+    }
+    painter.clear(t.clear);
+    for (size_t k = 0; k < wb.ids.size(); k++) {
+        uint32_t id = wb.ids[k].id;
+        bool mask = k >= wb.skipped && wb.ids[k].mask;                 // iter_with_masks :77-82
+        if (mask) {
+            painter.clear_cells();
+            auto it = wb.seg_ranges.find(id);
+            if (it != wb.seg_ranges.end()) for (size_t s = it->second.first; s <= it->second.second; s++) painter.acc_segment(t.segs[s]);
+            if (const Cover* c = wb.cover(id)) painter.acc_cover(*c);
+            const Props& p = ctx.get(id);
+            bool apply_clip = !p.is_clip && p.is_clipped && !wb.skip_clipping.count(id);
+            Cover cov = painter.paint_layer(t.tile_x, t.tile_y, id, p, apply_clip, ctx);
+            if (!cov.is_empty(p.even_odd)) wb.next_queue.push_back({cov, id});
+        } else {
+            CoverCarry cc; if (wb.cover_carry(t.segs, id, ctx, cc)) wb.next_queue.push_back(cc);
+        }
+    }
+    wb.next_tile();
+    return TileOp::ColorBuffer;
+}
+
+struct Crop { bool some; size_t h0, h1, v0, v1; };                     // Rect, renderer.rs:37-53 (tile units)
+
+// Layout::write for LinearLayout (buffer/layout/mod.rs:264-295)
+void write_tile(uint8_t* buf, size_t stride, size_t width, size_t height, size_t tx, size_t ty,
+                const uint8_t* solid, const uint8_t* colors) {
+    size_t x0 = tx * 16, y0 = ty * 16;
+    size_t w = std::min<size_t>(16, width - x0), h = std::min<size_t>(16, height - y0);
+    for (size_t y = 0; y < h; y++) {
+        uint8_t* row = buf + (y0 + y) * stride + x0 * 4;
+        for (size_t x = 0; x < w; x++) memcpy(row + 4 * x, solid ? solid : colors + 4 * (x * 16 + y), 4);
+    }
+}
+
+// painter::for_each_row / print_row / paint_tile_row (painter/mod.rs:485-778)
+void paint(const uint64_t* segs, size_t n, const PaintCtx& ctx, uint8_t* buf, size_t width, size_t height,
+           size_t stride, const uint8_t channels[4], Color clear, Crop crop, Cache* cache, float* tile_dump) {
+    size_t tiles_w = (width + 15) / 16, tiles_h = (height + 15) / 16;
+    // drop tile_y < 0 (:731-734): stored tile_y field 0
+    size_t begin = 0;
+    while (begin < n && seg_tile_y(segs[begin]) < 0) begin++;
+    // row offsets
+    std::vector<size_t> row_start(tiles_h + 1, n);
+    {
+        size_t k = begin;
+        for (size_t j = 0; j < tiles_h; j++) {
+            while (k < n && (size_t)seg_tile_y(segs[k]) < j) k++;
+            row_start[j] = k;
+        }
+        while (k < n && (size_t)seg_tile_y(segs[k]) < tiles_h) k++;
+        row_start[tiles_h] = k;
+    }
+    bool has_prev_clear = cache && cache->has_clear; Color prev_clear = cache ? cache->clear : Color{};
+#pragma omp parallel
+    {
+        Painter painter; Workbench wb;
+#pragma omp for schedule(dynamic, 1)
+        for (long j = 0; j < (long)tiles_h; j++) {
+            if (crop.some && !((size_t)j >= crop.v0 && (size_t)j < crop.v1)) continue;     // print_row :588-592
+            const uint64_t* rs = segs + row_start[j]; size_t rn = row_start[j + 1] - row_start[j];
+            // covers left of row (:500-522)
+            std::map<uint32_t, Cover> left;
+            int tile_x_start = crop.some ? (int)(int16_t)crop.h0 : 0;
+            size_t k = 0;
+            while (k < rn && seg_tile_x(rs[k]) < tile_x_start) {
+                Cover& c = left[seg_layer(rs[k])];
+                c.c[seg_ly(rs[k])] = (int8_t)(c.c[seg_ly(rs[k])] + seg_cover(rs[k]));
+                k++;
+            }
+            std::vector<CoverCarry> init; for (auto& kv : left) init.push_back({kv.second, kv.first});
+            wb.init(std::move(init));
+            wb.next_queue.clear();
+            for (size_t tx = 0; tx < tiles_w; tx++) {
+                if (crop.some && !(tx >= crop.h0 && tx < crop.h1)) continue;
+                // the reference takes the prefix of the remaining slice whose tile_x == tx, located by a
+                // binary search on a sorted slice: everything up to the last element with tile_x <= tx
+                // that equals tx.  On sorted input that is the contiguous run with tile_x == tx.
+                size_t s0 = k;
+                while (k < rn && seg_tile_x(rs[k]) == (int)tx) k++;
+                // (elements with tile_x < tx cannot remain on sorted input)
+                TileCtx t{tx, (size_t)j, rs + s0, k - s0, has_prev_clear, prev_clear,
+                          cache ? &cache->tiles[j * tiles_w + tx] : nullptr, {channels[0], channels[1], channels[2], channels[3]}, clear};
+                painter.has_clip = false;                              // :551
+                uint8_t solid[4];
+                TileOp op = drive_tile_painting(wb, painter, t, ctx, solid);
+                if (op == TileOp::Solid) write_tile(buf, stride, width, height, tx, j, solid, nullptr);
+                else if (op == TileOp::ColorBuffer) {
+                    painter.compute_srgb(channels);
+                    write_tile(buf, stride, width, height, tx, j, nullptr, painter.srgb);
+                    if (tile_dump) {
+                        float* d = tile_dump + ((size_t)j * tiles_w + tx) * 1024;
+                        for (int i = 0; i < 256; i++) { d[i * 4] = painter.r[i]; d[i * 4 + 1] = painter.g[i]; d[i * 4 + 2] = painter.b[i]; d[i * 4 + 3] = painter.a[i]; }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- oracle context -------------------------------------------------------------------------------
+struct Oracle {
+    std::vector<float> x, y; std::vector<uint32_t> line_slot;
+    std::vector<forma_geom_t> geoms;
+    std::vector<uint32_t> style_offsets, style_words; std::vector<uint8_t> unchanged; bool has_unchanged = false;
+    std::vector<forma_image_t> images; std::vector<uint16_t> texels;
+    Lines lines; std::vector<uint64_t> unsorted, sorted;
+    std::map<int, Cache> caches;
+    std::vector<Props> props; std::vector<uint8_t> have;
+    // flatten scratch
+    std::vector<float> fx, fy; std::vector<uint8_t> fnc;
+    int threads = 1;
+
+    void decode_styles() {
+        props.assign(style_offsets.size(), Props()); have.assign(style_offsets.size(), 0);
+        for (size_t o = 0; o < style_offsets.size(); o++)
+            if (style_offsets[o] != FORMA_NONE) { props[o] = decode_props(&style_words[style_offsets[o]]); have[o] = 1; }
+    }
+    PaintCtx pctx(bool has_cache) {
+        PaintCtx c; c.props_by_order = &props; c.have_props = &have;
+        c.unchanged = has_unchanged ? unchanged.data() : nullptr; c.has_cache = has_cache;
+        c.images = {images.data(), images.size(), texels.data()};
+        return c;
+    }
+};
+
+void set_threads(int t) {
+#ifdef _OPENMP
+    omp_set_num_threads(t > 0 ? t : 1);
+#else
+    (void)t;
+#endif
+}
+
+}  // namespace
+
+// ================================================================================================
+// C API (ctypes).  Mirrors include/forma_hip.h entry-point shapes so tests feed both sides the same.
+// ================================================================================================
+extern "C" {
+
+void* oracle_create(void) { return new Oracle(); }
+void  oracle_destroy(void* o) { delete (Oracle*)o; }
+void  oracle_set_threads(void* o, int t) { ((Oracle*)o)->threads = t > 0 ? t : 1; }
+int   oracle_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_num_procs();
+#else
+    return 1;
+#endif
+}
+
+// ---- path builder + flatten --------------------------------------------------------------------
+void* oracle_path_new(void) { return new PathData(); }
+void  oracle_path_free(void* p) { delete (PathData*)p; }
+void  oracle_path_move_to(void* p, float x, float y) { ((PathData*)p)->move_to(x, y); }
+void  oracle_path_line_to(void* p, float x, float y) { ((PathData*)p)->line_to(x, y); }
+void  oracle_path_quad_to(void* p, float ax, float ay, float bx, float by) { ((PathData*)p)->quad_to(ax, ay, bx, by); }
+void  oracle_path_cubic_to(void* p, float ax, float ay, float bx, float by, float cx, float cy) { ((PathData*)p)->cubic_to(ax, ay, bx, by, cx, cy); }
+void  oracle_path_rat_quad_to(void* p, float ax, float ay, float bx, float by, float w) { ((PathData*)p)->rat_quad_to(ax, ay, bx, by, w); }
+void  oracle_path_rat_cubic_to(void* p, float ax, float ay, float bx, float by, float cx, float cy, float w1, float w2) {
+    ((PathData*)p)->rat_cubic_to(ax, ay, bx, by, cx, cy, w1, w2);
+}
+void  oracle_path_close(void* p) { ((PathData*)p)->close(); }           // PathBuilder::build closes (path.rs:914-924)
+// Path::transform with a non-affine 3x3 (path.rs:743-765): applies to control points + weights.
+void  oracle_path_transform9(void* p, const float* t) {
+    PathData* d = (PathData*)p;
+    for (size_t i = 0; i < d->x.size(); i++) {
+        float x = d->x[i], y = d->y[i], w = d->w[i];
+        d->x[i] = fmaf(t[0], x, fmaf(t[1], y, t[2] * w));
+        d->y[i] = fmaf(t[3], x, fmaf(t[4], y, t[5] * w));
+        d->w[i] = fmaf(t[6], x, fmaf(t[7], y, t[8] * w));
+    }
+}
+// Flatten; returns number of points.  Results are fetched with oracle_flatten_get.
+// `affine` (6 floats ux,uy,vx,vy,tx,ty) or NULL = GeomPresTransform applied per point (path.rs:689-706).
+size_t oracle_path_flatten(void* o_, void* p, const float* affine) {
+    Oracle* o = (Oracle*)o_;
+    o->fx.clear(); o->fy.clear(); o->fnc.clear();
+    ((PathData*)p)->segments(o->fx, o->fy, o->fnc);
+    if (affine)
+        for (size_t i = 0; i < o->fx.size(); i++) {
+            float x = o->fx[i], y = o->fy[i];
+            o->fx[i] = fmaf(affine[0], x, fmaf(affine[2], y, affine[4]));
+            o->fy[i] = fmaf(affine[1], x, fmaf(affine[3], y, affine[5]));
+        }
+    return o->fx.size();
+}
+void oracle_flatten_get(void* o_, float* x, float* y, uint8_t* new_contour) {
+    Oracle* o = (Oracle*)o_;
+    if (o->fx.empty()) return;
+    memcpy(x, o->fx.data(), o->fx.size() * 4); memcpy(y, o->fy.data(), o->fy.size() * 4);
+    memcpy(new_contour, o->fnc.data(), o->fnc.size());
+}
+// Raw command view of a path (for driving the product's flattener with identical inputs).
+size_t oracle_path_counts(void* p, size_t* n_cmds) { PathData* d = (PathData*)p; *n_cmds = d->cmds.size(); return d->x.size(); }
+void   oracle_path_get(void* p, float* x, float* y, float* w, uint8_t* cmds) {
+    PathData* d = (PathData*)p;
+    memcpy(x, d->x.data(), d->x.size() * 4); memcpy(y, d->y.data(), d->y.size() * 4); memcpy(w, d->w.data(), d->w.size() * 4);
+    memcpy(cmds, d->cmds.data(), d->cmds.size());
+}
+
+// ---- scene tables -------------------------------------------------------------------------------
+int oracle_set_geometry(void* o_, const float* x, const float* y, const uint32_t* line_slot, size_t n) {
+    Oracle* o = (Oracle*)o_;
+    o->x.assign(x, x + n); o->y.assign(y, y + n); o->line_slot.assign(line_slot, line_slot + (n ? n - 1 : 0));
+    return 0;
+}
+int oracle_set_geoms(void* o_, const forma_geom_t* g, size_t n) { ((Oracle*)o_)->geoms.assign(g, g + n); return 0; }
+int oracle_set_styles(void* o_, const uint32_t* off, size_t n_orders, const uint32_t* words, size_t n_words, const uint8_t* unchanged) {
+    Oracle* o = (Oracle*)o_;
+    o->style_offsets.assign(off, off + n_orders); o->style_words.assign(words, words + n_words);
+    o->has_unchanged = unchanged != nullptr;
+    if (unchanged) o->unchanged.assign(unchanged, unchanged + n_orders);
+    o->decode_styles();
+    return 0;
+}
+int oracle_set_images(void* o_, const forma_image_t* im, size_t n, const uint16_t* texels, size_t n_texels) {
+    Oracle* o = (Oracle*)o_;
+    o->images.assign(im, im + n); o->texels.assign(texels, texels + 4 * n_texels);
+    return 0;
+}
+
+// ---- stages -------------------------------------------------------------------------------------
+// width/height as f32 so that the reference tests' `usize::MAX as f32` can be passed.
+int oracle_prepare_lines(void* o_, float width, float height, uint32_t* orders, float* x0, float* y0, float* dx, float* dy,
+                         float* a, float* b, float* c, float* d, uint32_t* lengths) {
+    Oracle* o = (Oracle*)o_; set_threads(o->threads);
+    prepare_lines(o->x.data(), o->y.data(), o->line_slot.data(), o->x.size(), o->geoms.data(), o->geoms.size(), width, height, o->lines);
+    size_t n = o->lines.lengths.size();
+    if (orders && n) {
+        memcpy(orders, o->lines.orders.data(), n * 4); memcpy(lengths, o->lines.lengths.data(), n * 4);
+        memcpy(x0, o->lines.x0.data(), n * 4); memcpy(y0, o->lines.y0.data(), n * 4);
+        memcpy(dx, o->lines.dx.data(), n * 4); memcpy(dy, o->lines.dy.data(), n * 4);
+        memcpy(a, o->lines.a.data(), n * 4); memcpy(b, o->lines.b.data(), n * 4);
+        memcpy(c, o->lines.c.data(), n * 4); memcpy(d, o->lines.d.data(), n * 4);
+    }
+    return 0;
+}
+// rasterize the lines of the last oracle_prepare_lines; returns N.
+size_t oracle_rasterize(void* o_) {
+    Oracle* o = (Oracle*)o_; set_threads(o->threads);
+    rasterize(o->lines, o->unsorted);
+    return o->unsorted.size();
+}
+size_t oracle_sort(void* o_) {
+    Oracle* o = (Oracle*)o_;
+    o->sorted = o->unsorted;
+    sort_segments(o->sorted, o->threads);
+    return o->sorted.size();
+}
+void oracle_get_segments(void* o_, int which, uint64_t* out) {
+    Oracle* o = (Oracle*)o_; auto& v = which ? o->sorted : o->unsorted;
+    if (!v.empty()) memcpy(out, v.data(), v.size() * 8);
+}
+// stand-alone helpers for unit vectors
+void oracle_sort_array(uint64_t* v, size_t n) { std::vector<uint64_t> t(v, v + n); sort_segments(t, 1); if (n) memcpy(v, t.data(), n * 8); }
+uint64_t oracle_pixel_segment_new(uint32_t layer, int tile_x, int tile_y, int lx, int ly, int dam, int cover) {
+    return pixel_segment_new(layer, (int16_t)tile_x, (int16_t)tile_y, (uint8_t)lx, (uint8_t)ly, (uint8_t)dam, (int8_t)cover);
+}
+float oracle_find(int i, float a, float b, float c, float d) {         // rasterizer.rs tests :204-244
+    double sr = 1.0 / ((double)a + (double)b);
+    return find_term(i, (double)a * sr, (double)b * sr, ((double)c - (double)d) * sr, a, b, c, d);
+}
+float oracle_coverage(int32_t A, int even_odd) { return Painter::coverage(A, even_odd != 0); }
+void  oracle_srgb_bytes(const float color[4], uint8_t out[4]) { to_srgb_bytes(color, out); }
+float oracle_linear_to_srgb(float l) { return linear_to_srgb(l); }
+uint32_t oracle_to_u8(float v) { return to_u32_x8(v) & 0xFF; }
+void oracle_blend_simd(int mode, const float dst[3], const float src[3], float out[3]) { blend_rgb(mode, dst[0], dst[1], dst[2], src[0], src[1], src[2], out); }
+void oracle_blend_scalar(int mode, const float dst[4], const float src[4], float out[4]) {
+    Color r = scalar_blend(mode, {dst[0], dst[1], dst[2], dst[3]}, {src[0], src[1], src[2], src[3]});
+    out[0] = r.r; out[1] = r.g; out[2] = r.b; out[3] = r.a;
+}
+float oracle_blend_fn(int mode, int c, const float dst[4], const float src[4]) {
+    return scalar_blend_fn(mode, c, {dst[0], dst[1], dst[2], dst[3]}, {src[0], src[1], src[2], src[3]});
+}
+float oracle_f16_to_f32(uint16_t h) { return f16_to_f32(h); }
+uint16_t oracle_f32_to_f16(float v) { return v != 0.0f ? (uint16_t)((bits(v) - 0x38000000u) >> 13) : 0; }   // styling.rs:242-250
+float oracle_srgb_to_linear(uint8_t l8) {                              // to_linear, styling.rs:252-259
+    float l = (float)l8 * (1.0f / 255.0f);
+    return l <= 0.04045f ? l * (1.0f / 12.92f) : powf((l + 0.055f) * (1.0f / 1.055f), 2.4f);
+}
+void oracle_gradient_column(const uint32_t* style_words, float x, float y, float* out32) {
+    Props p = decode_props(style_words); float o[4][8]; gradient_color_at(p, x, y, o);
+    for (int c = 0; c < 4; c++) for (int j = 0; j < 8; j++) out32[c * 8 + j] = o[c][j];
+}
+
+// paint a caller-supplied sorted stream.  cache_id < 0: no cache.  tile_dump (optional): f32 rgba
+// of every ColorBuffer tile, [tiles_h][tiles_w][256 column-major][4].
+int oracle_paint(void* o_, const uint64_t* segs, size_t n, uint8_t* dst, uint32_t width, uint32_t height, size_t stride,
+                 const uint8_t channels[4], const float clear[4], const forma_rect_t* crop, int cache_id, float* tile_dump) {
+    Oracle* o = (Oracle*)o_; set_threads(o->threads);
+    uint8_t ch[4] = {channels[0], channels[1], channels[2], channels[3]};
+    Color cc{clear[0], clear[1], clear[2], clear[3]};
+    if (cc.a == 1.0f) for (int i = 0; i < 4; i++) if (ch[i] == FORMA_CH_ALPHA) ch[i] = FORMA_CH_ONE;   // renderer.rs:85-92
+    size_t tiles_w = (width + 15) / 16, tiles_h = (height + 15) / 16;
+    Cache* cache = nullptr;
+    if (cache_id >= 0) {                                               // renderer.rs:94-111
+        cache = &o->caches[cache_id];
+        cache->tiles.resize(tiles_w * tiles_h);
+        if (!cache->has_dims || cache->w != width || cache->h != height) { cache->has_dims = true; cache->w = width; cache->h = height; cache->clear_all(); }
+    }
+    Crop cr{false, 0, 0, 0, 0};
+    if (crop) cr = {true, crop->x0 / 16, (crop->x1 + 15) / 16, crop->y0 / 16, (crop->y1 + 15) / 16};  // Rect::new :43-52
+    PaintCtx ctx = o->pctx(cache != nullptr);
+    paint(segs, n, ctx, dst, width, height, stride, ch, cc, cr, cache, tile_dump);
+    if (cache) { cache->has_clear = true; cache->clear = cc; }         // renderer.rs:217-218
+    return 0;
+}
+int oracle_cache_clear(void* o_, int cache_id) { Oracle* o = (Oracle*)o_; auto it = o->caches.find(cache_id); if (it != o->caches.end()) it->second.clear_all(); return 0; }
+
+// the whole frame: cpu::Renderer::render (renderer.rs:75-224)
+int oracle_render(void* o_, uint8_t* dst, uint32_t width, uint32_t height, size_t stride, const uint8_t channels[4],
+                  const float clear[4], const forma_rect_t* crop, int cache_id, float* tile_dump) {
+    Oracle* o = (Oracle*)o_; set_threads(o->threads);
+    prepare_lines(o->x.data(), o->y.data(), o->line_slot.data(), o->x.size(), o->geoms.data(), o->geoms.size(), (float)width, (float)height, o->lines);
+    rasterize(o->lines, o->unsorted);
+    o->sorted = o->unsorted;
+    sort_segments(o->sorted, o->threads);
+    return oracle_paint(o_, o->sorted.data(), o->sorted.size(), dst, width, height, stride, channels, clear, crop, cache_id, tile_dump);
+}
+size_t oracle_last_n(void* o_) { return ((Oracle*)o_)->unsorted.size(); }
+
+// timing helper for the CPU baseline: run the 4 stages `iters` times, return seconds per stage.
+int oracle_time_frame(void* o_, uint32_t width, uint32_t height, int iters, double* out_prepare, double* out_raster,
+                      double* out_sort, double* out_paint) {
+#ifdef _OPENMP
+    Oracle* o = (Oracle*)o_; set_threads(o->threads);
+    std::vector<uint8_t> img((size_t)width * 4 * height);
+    uint8_t ch[4] = {0, 1, 2, 3}; Color cc{1, 1, 1, 1};
+    for (int i = 0; i < 4; i++) if (ch[i] == 3) ch[i] = 5;
+    double tp = 0, tr = 0, ts = 0, tq = 0;
+    for (int it = 0; it < iters; it++) {
+        double t0 = omp_get_wtime();
+        prepare_lines(o->x.data(), o->y.data(), o->line_slot.data(), o->x.size(), o->geoms.data(), o->geoms.size(), (float)width, (float)height, o->lines);
+        double t1 = omp_get_wtime();
+        rasterize(o->lines, o->unsorted);
+        double t2 = omp_get_wtime();
+        o->sorted = o->unsorted; sort_segments(o->sorted, o->threads);
+        double t3 = omp_get_wtime();
+        PaintCtx ctx = o->pctx(false);
+        paint(o->sorted.data(), o->sorted.size(), ctx, img.data(), width, height, (size_t)width * 4, ch, cc, Crop{false, 0, 0, 0, 0}, nullptr, nullptr);
+        double t4 = omp_get_wtime();
+        tp += t1 - t0; tr += t2 - t1; ts += t3 - t2; tq += t4 - t3;
+    }
+    *out_prepare = tp / iters; *out_raster = tr / iters; *out_sort = ts / iters; *out_paint = tq / iters;
+    return 0;
+#else
+    (void)o_; (void)width; (void)height; (void)iters; (void)out_prepare; (void)out_raster; (void)out_sort; (void)out_paint;
+    return -1;
+#endif
+}
+
+}  // extern "C"
