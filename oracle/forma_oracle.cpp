@@ -1208,6 +1208,25 @@ void   oracle_path_get(void* p, float* x, float* y, float* w, uint8_t* cmds) {
     memcpy(cmds, d->cmds.data(), d->cmds.size());
 }
 
+// Primitives-level API (path.rs tests :1023-1409 drive `Primitives` directly).
+void* oracle_prim_new(void) { return new Primitives(); }
+void  oracle_prim_free(void* p) { delete (Primitives*)p; }
+void  oracle_prim_push_contour(void* p) { ((Primitives*)p)->push_contour(); }
+void  oracle_prim_push_line(void* p, const float* q) { ((Primitives*)p)->push_line({{q[0], q[1]}, q[2]}, {{q[3], q[4]}, q[5]}); }
+void  oracle_prim_push_quad(void* p, const float* q) {
+    ((Primitives*)p)->push_quad({{q[0], q[1]}, q[2]}, {{q[3], q[4]}, q[5]}, {{q[6], q[7]}, q[8]});
+}
+void  oracle_prim_push_cubic(void* p, const float* q) {
+    WPt w[4] = {{{q[0], q[1]}, q[2]}, {{q[3], q[4]}, q[5]}, {{q[6], q[7]}, q[8]}, {{q[9], q[10]}, q[11]}};
+    ((Primitives*)p)->push_cubic(w);
+}
+size_t oracle_prim_flatten(void* o_, void* p) {
+    Oracle* o = (Oracle*)o_;
+    o->fx.clear(); o->fy.clear(); o->fnc.clear();
+    ((Primitives*)p)->into_segments(o->fx, o->fy, o->fnc);
+    return o->fx.size();
+}
+
 // ---- scene tables -------------------------------------------------------------------------------
 int oracle_set_geometry(void* o_, const float* x, const float* y, const uint32_t* line_slot, size_t n) {
     Oracle* o = (Oracle*)o_;

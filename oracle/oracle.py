@@ -67,6 +67,14 @@ def lib():
         L.oracle_path_counts.argtypes = [vp, vp]
         L.oracle_path_counts.restype = sz
         L.oracle_path_get.argtypes = [vp, vp, vp, vp, vp]
+        L.oracle_prim_new.restype = vp
+        L.oracle_prim_free.argtypes = [vp]
+        L.oracle_prim_push_contour.argtypes = [vp]
+        L.oracle_prim_push_line.argtypes = [vp, vp]
+        L.oracle_prim_push_quad.argtypes = [vp, vp]
+        L.oracle_prim_push_cubic.argtypes = [vp, vp]
+        L.oracle_prim_flatten.argtypes = [vp, vp]
+        L.oracle_prim_flatten.restype = sz
         L.oracle_set_geometry.argtypes = [vp, vp, vp, vp, sz]
         L.oracle_set_geoms.argtypes = [vp, vp, sz]
         L.oracle_set_styles.argtypes = [vp, vp, sz, vp, sz, vp]
@@ -164,6 +172,38 @@ class Path:
         return x, y, w, cmds
 
 
+class Primitives:
+    """oracle restatement of `Primitives` (reference forma/src/path.rs:190-558), weights default 1."""
+
+    def __init__(self):
+        self._h = lib().oracle_prim_new()
+
+    def __del__(self):
+        try:
+            lib().oracle_prim_free(self._h)
+        except Exception:
+            pass
+
+    @staticmethod
+    def _pts(pts):
+        out = []
+        for p in pts:
+            out += [p[0], p[1], p[2] if len(p) > 2 else 1.0]
+        return np.asarray(out, np.float32)
+
+    def push_contour(self):
+        lib().oracle_prim_push_contour(self._h); return self
+
+    def push_line(self, *pts):
+        a = self._pts(pts); lib().oracle_prim_push_line(self._h, _p(a)); return self
+
+    def push_quad(self, *pts):
+        a = self._pts(pts); lib().oracle_prim_push_quad(self._h, _p(a)); return self
+
+    def push_cubic(self, *pts):
+        a = self._pts(pts); lib().oracle_prim_push_cubic(self._h, _p(a)); return self
+
+
 class Oracle:
     def __init__(self, threads: int = 1):
         self._h = lib().oracle_create()
@@ -183,6 +223,12 @@ class Oracle:
     def flatten(self, path: Path):
         aff = None if path.affine is None else np.ascontiguousarray(path.affine, np.float32)
         n = lib().oracle_path_flatten(self._h, path._h, _p(aff))
+        x = np.empty(n, np.float32); y = np.empty(n, np.float32); nc = np.empty(n, np.uint8)
+        lib().oracle_flatten_get(self._h, _p(x), _p(y), _p(nc))
+        return x, y, nc
+
+    def flatten_primitives(self, prim: "Primitives"):
+        n = lib().oracle_prim_flatten(self._h, prim._h)
         x = np.empty(n, np.float32); y = np.empty(n, np.float32); nc = np.empty(n, np.uint8)
         lib().oracle_flatten_get(self._h, _p(x), _p(y), _p(nc))
         return x, y, nc
