@@ -1,0 +1,165 @@
+"""Thin 1:1 Python wrapper of the C ABI (include/forma_hip.h) — numpy arrays in, numpy arrays out."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FormaError, RectT, TimingsT
+
+GEOM_DTYPE = np.dtype([("order", "<u4"), ("flags", "<u4"), ("xf", "<f4", (6,))])
+IMAGE_DTYPE = np.dtype([("texel_offset", "<u8"), ("width", "<u4"), ("height", "<u4")])
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One forma_hip_ctx = one GPU, one HIP stream (reference `cpu::Renderer`, cpu/renderer.rs:55-73)."""
+
+    def __init__(self, device: int = 0):
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        rc = self._L.forma_hip_create(C.byref(h), device)
+        if rc != 0:
+            raise FormaError(rc, "forma_hip_create (needs a visible MI355X; there is no CPU fallback)")
+        self._h = h
+        self.n_points = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.forma_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise FormaError(rc, self._L.forma_hip_last_error(self._h).decode())
+
+    # ---- scene upload
+    def set_geometry(self, x, y, line_slot):
+        x = np.ascontiguousarray(x, np.float32); y = np.ascontiguousarray(y, np.float32)
+        ls = np.ascontiguousarray(line_slot, np.uint32)
+        assert len(x) == len(y) and len(ls) == max(len(x) - 1, 0)
+        self.n_points = len(x)
+        self._check(self._L.forma_hip_set_geometry(self._h, _p(x), _p(y), _p(ls), len(x)))
+
+    def set_geoms(self, geoms):
+        g = np.ascontiguousarray(geoms, GEOM_DTYPE)
+        self._check(self._L.forma_hip_set_geoms(self._h, _p(g), len(g)))
+
+    def set_styles(self, offsets, words, unchanged=None):
+        o = np.ascontiguousarray(offsets, np.uint32); w = np.ascontiguousarray(words, np.uint32)
+        u = None if unchanged is None else np.ascontiguousarray(unchanged, np.uint8)
+        self._check(self._L.forma_hip_set_styles(self._h, _p(o), len(o), _p(w), len(w), _p(u)))
+
+    def set_images(self, images, texels):
+        im = np.ascontiguousarray(images, IMAGE_DTYPE)
+        tx = np.ascontiguousarray(texels, np.uint16).reshape(-1, 4)
+        self._check(self._L.forma_hip_set_images(self._h, _p(im), len(im), _p(tx), len(tx)))
+
+    # ---- stages
+    def prepare_lines(self, width, height):
+        n = max(self.n_points - 1, 0)
+        out = {k: np.zeros(n, np.float32) for k in ("x0", "y0", "dx", "dy", "a", "b", "c", "d")}
+        out["orders"] = np.zeros(n, np.uint32); out["lengths"] = np.zeros(n, np.uint32)
+        self._check(self._L.forma_hip_prepare_lines(self._h, width, height, _p(out["orders"]), _p(out["x0"]), _p(out["y0"]),
+                                                    _p(out["dx"]), _p(out["dy"]), _p(out["a"]), _p(out["b"]), _p(out["c"]),
+                                                    _p(out["d"]), _p(out["lengths"])))
+        return out
+
+    def rasterize_lines(self, lines):
+        n = len(lines["lengths"])
+        N = int(lines["lengths"][-1]) if n else 0
+        out = np.zeros(N, np.uint64); got = C.c_size_t(0)
+        arr = {k: np.ascontiguousarray(v) for k, v in lines.items()}
+        self._check(self._L.forma_hip_rasterize(self._h, n, _p(arr["orders"]), _p(arr["x0"]), _p(arr["y0"]), _p(arr["dx"]),
+                                                _p(arr["dy"]), _p(arr["a"]), _p(arr["b"]), _p(arr["c"]), _p(arr["d"]),
+                                                _p(arr["lengths"]), _p(out), N, C.byref(got)))
+        assert got.value == N
+        return out
+
+    def sort_array(self, segs, digit_bits=0):
+        v = np.ascontiguousarray(segs, np.uint64).copy()
+        self._check(self._L.forma_hip_sort(self._h, _p(v), len(v), digit_bits))
+        return v
+
+    def paint(self, segs, width, height, channels=(0, 1, 2, 3), clear=(1, 1, 1, 0), crop=None, dst=None, stride=None):
+        segs = np.ascontiguousarray(segs, np.uint64)
+        stride = stride or width * 4
+        if dst is None:
+            dst = np.zeros((height, stride), np.uint8)
+        ch = np.asarray(channels, np.uint8); cl = np.asarray(clear, np.float32)
+        rect = None if crop is None else RectT(*crop)
+        self._check(self._L.forma_hip_paint(self._h, _p(segs), len(segs), _p(dst), width, height, stride, _p(ch), _p(cl),
+                                            None if rect is None else C.addressof(rect)))
+        return dst
+
+    def render(self, width, height, channels=(0, 1, 2, 3), clear=(1, 1, 1, 0), crop=None, cache_id=-1, dst=None,
+               stride=None, timings=False, device_only=False):
+        stride = stride or width * 4
+        if dst is None and not device_only:
+            dst = np.zeros((height, stride), np.uint8)
+        ch = np.asarray(channels, np.uint8); cl = np.asarray(clear, np.float32)
+        rect = None if crop is None else RectT(*crop)
+        t = TimingsT() if timings else None
+        self._check(self._L.forma_hip_render(self._h, None if device_only else _p(dst), width, height, stride, _p(ch), _p(cl),
+                                             None if rect is None else C.addressof(rect), cache_id,
+                                             None if t is None else C.addressof(t)))
+        if timings:
+            return dst, t.as_dict()
+        return dst
+
+    def segments(self, which):
+        n = C.c_size_t(0)
+        rc = self._L.forma_hip_read_segments(self._h, which, None, 0, C.byref(n))
+        if n.value == 0:
+            self._check(rc)
+            return np.zeros(0, np.uint64)
+        out = np.zeros(n.value, np.uint64)
+        self._check(self._L.forma_hip_read_segments(self._h, which, _p(out), n.value, C.byref(n)))
+        return out
+
+    def read_image(self, width, height):
+        dst = np.zeros((height, width * 4), np.uint8)
+        self._check(self._L.forma_hip_read_image(self._h, _p(dst), width * 4))
+        return dst
+
+    # ---- multi-GPU
+    def set_band(self, row0, row1):
+        self._check(self._L.forma_hip_set_band(self._h, row0, row1))
+
+    def rasterize_frame(self, width, height, timings=False):
+        t = TimingsT() if timings else None
+        self._check(self._L.forma_hip_rasterize_frame(self._h, width, height, None if t is None else C.addressof(t)))
+        return t.as_dict() if timings else None
+
+    def segments_device(self, which):
+        p = C.c_void_p(); n = C.c_size_t(0)
+        self._check(self._L.forma_hip_segments_device(self._h, which, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def reserve_segments(self, n):
+        p = C.c_void_p()
+        self._check(self._L.forma_hip_reserve_segments(self._h, n, C.byref(p)))
+        return p.value
+
+    def sort_paint_frame(self, n, width, height, channels=(0, 1, 2, 3), clear=(1, 1, 1, 0), crop=None, dst=None,
+                         stride=None, timings=False, device_only=True):
+        stride = stride or width * 4
+        if dst is None and not device_only:
+            dst = np.zeros((height, stride), np.uint8)
+        ch = np.asarray(channels, np.uint8); cl = np.asarray(clear, np.float32)
+        rect = None if crop is None else RectT(*crop)
+        t = TimingsT() if timings else None
+        self._check(self._L.forma_hip_sort_paint_frame(self._h, n, None if device_only else _p(dst), width, height, stride,
+                                                       _p(ch), _p(cl), None if rect is None else C.addressof(rect),
+                                                       None if t is None else C.addressof(t)))
+        return (dst, t.as_dict()) if timings else dst

@@ -1,0 +1,686 @@
+// api.cpp — the C ABI of libforma_hip.so (include/forma_hip.h): context, device buffers, frame
+// orchestration on one HIP stream.  Product code: nothing here (or anywhere in forma_amd/) touches
+// oracle/.  Errors never unwind across the ABI: every entry point returns a FORMA_E_* code.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap && p) return hipSuccess;
+        size_t want = std::max(bytes, cap + cap / 2);
+        want = std::max<size_t>(want, 256);
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+constexpr int MAX_PASS_EVENTS = 16;
+enum { ST_PREPARE = 0, ST_RASTER, ST_SORT, ST_CARRY, ST_PAINT, ST_D2H, ST_COUNT };
+
+}  // namespace
+
+struct forma_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    char err[512] = {0};
+
+    // scene
+    DevBuf x, y, line_slot, geoms, style_off, style_words, unchanged, images, texels;
+    size_t n_points = 0, n_geoms = 0, n_orders = 0, n_words = 0, n_images = 0;
+    bool scene_has_clips = false;
+    // lines
+    DevBuf l_order, l_x0, l_y0, l_dx, l_dy, l_a, l_b, l_c, l_d, l_len, scan_tmp;
+    size_t n_lines = 0;
+    // segments
+    DevBuf seg_u, seg_a, seg_b, sort_counters;
+    uint64_t* sorted = nullptr;
+    size_t n_seg = 0;
+    bool have_unsorted = false;
+    uint64_t live44 = 0xFFFFFFFFFFFull;     // varying bits of (v >> 20)
+    // paint
+    DevBuf info, head_counts, run_start, records, run_cov, rk_u, rk_a, rk_b, tile_count, tile_fill, entries, image;
+    uint32_t img_w = 0, img_h = 0;
+    FrameInfo* h_info = nullptr;            // pinned
+    // band
+    uint32_t band_row0 = 0, band_row1 = 0;
+    // timing
+    hipEvent_t ev0[ST_COUNT], ev1[ST_COUNT], pev0[MAX_PASS_EVENTS], pev1[MAX_PASS_EVENTS];
+    bool stage_used[ST_COUNT];
+    int n_passes = 0;
+    uint32_t last_runs = 0, last_entries = 0;
+};
+
+namespace {
+
+int fail(forma_hip_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
+    if (c) snprintf(c->err, sizeof c->err, "%s%s%s", what, e != hipSuccess ? ": " : "", e != hipSuccess ? hipGetErrorString(e) : "");
+    return code;
+}
+#define HIPCHECK(expr)                                                        \
+    do {                                                                      \
+        hipError_t _e = (expr);                                               \
+        if (_e != hipSuccess) return fail(ctx, FORMA_E_HIP, #expr, _e);       \
+    } while (0)
+
+inline void stage_begin(forma_hip_ctx* c, int st, bool timing) { if (timing) { (void)hipEventRecord(c->ev0[st], c->stream); c->stage_used[st] = true; } }
+inline void stage_end(forma_hip_ctx* c, int st, bool timing) { if (timing) (void)hipEventRecord(c->ev1[st], c->stream); }
+
+int read_info(forma_hip_ctx* ctx) {
+    HIPCHECK(hipMemcpyAsync(ctx->h_info, ctx->info.p, sizeof(FrameInfo), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    return FORMA_OK;
+}
+
+int reset_info(forma_hip_ctx* ctx) {
+    FrameInfo fi;
+    memset(&fi, 0, sizeof fi);
+    fi.key_and = 0xFFFFFFFFu; fi.key_and_hi = 0xFFFFFFFFu;
+    *ctx->h_info = fi;
+    HIPCHECK(hipMemcpyAsync(ctx->info.p, ctx->h_info, sizeof(FrameInfo), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));   // h_info is reused as the read-back target
+    return FORMA_OK;
+}
+
+int check_canvas(forma_hip_ctx* ctx, uint32_t width, uint32_t height) {
+    if (width == 0 || height == 0 || width > FORMA_MAX_WIDTH || height > FORMA_MAX_HEIGHT)   // consts.rs:25-26
+        return fail(ctx, FORMA_E_ARG, "canvas size out of range");
+    return FORMA_OK;
+}
+
+// stages 1-2 on the uploaded geometry: prepare_lines + inclusive scan + rasterize -> seg_u
+int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, bool timing) {
+    const size_t n_lines = ctx->n_points ? ctx->n_points - 1 : 0;
+    ctx->n_lines = n_lines;
+    ctx->n_seg = 0; ctx->have_unsorted = true; ctx->live44 = 0;
+    int rc = reset_info(ctx);
+    if (rc) return rc;
+    if (n_lines == 0) return FORMA_OK;
+    DevBuf* lb[] = {&ctx->l_order, &ctx->l_x0, &ctx->l_y0, &ctx->l_dx, &ctx->l_dy, &ctx->l_a, &ctx->l_b, &ctx->l_c, &ctx->l_d, &ctx->l_len};
+    for (DevBuf* b : lb) HIPCHECK(b->ensure(n_lines * 4));
+    HIPCHECK(ctx->scan_tmp.ensure(scan_tmp_words(std::max<size_t>(n_lines, 1 << 16)) * 4));
+    float band_lo = -3.0e38f, band_hi = 3.0e38f;
+    if (ctx->band_row1 > 0) { band_lo = (float)(ctx->band_row0 * 16u); band_hi = (float)(ctx->band_row1 * 16u); }
+    stage_begin(ctx, ST_PREPARE, timing);
+    launch_prepare_lines(ctx->stream, ctx->x.as<float>(), ctx->y.as<float>(), ctx->line_slot.as<uint32_t>(), (uint32_t)n_lines,
+                         ctx->geoms.as<forma_geom_t>(), (uint32_t)ctx->n_geoms, (float)width, (float)height, band_lo, band_hi,
+                         ctx->l_order.as<uint32_t>(), ctx->l_x0.as<float>(), ctx->l_y0.as<float>(), ctx->l_dx.as<float>(),
+                         ctx->l_dy.as<float>(), ctx->l_a.as<float>(), ctx->l_b.as<float>(), ctx->l_c.as<float>(),
+                         ctx->l_d.as<float>(), ctx->l_len.as<uint32_t>());
+    launch_inclusive_scan_u32(ctx->stream, ctx->l_len.as<uint32_t>(), n_lines, ctx->scan_tmp.as<uint32_t>(),
+                              &ctx->info.as<FrameInfo>()->n_segments);
+    stage_end(ctx, ST_PREPARE, timing);
+    HIPCHECK(hipGetLastError());
+    rc = read_info(ctx);
+    if (rc) return rc;
+    const size_t N = ctx->h_info->n_segments;
+    ctx->n_seg = N;
+    if (N == 0) return FORMA_OK;
+    HIPCHECK(ctx->seg_u.ensure(N * 8));
+    stage_begin(ctx, ST_RASTER, timing);
+    launch_rasterize(ctx->stream, (uint32_t)n_lines, (uint32_t)N, ctx->l_order.as<uint32_t>(), ctx->l_x0.as<float>(),
+                     ctx->l_y0.as<float>(), ctx->l_dx.as<float>(), ctx->l_dy.as<float>(), ctx->l_a.as<float>(),
+                     ctx->l_b.as<float>(), ctx->l_c.as<float>(), ctx->l_d.as<float>(), ctx->l_len.as<uint32_t>(),
+                     ctx->seg_u.as<uint64_t>(), ctx->info.as<FrameInfo>(), (int)ctx->band_row0, (int)ctx->band_row1);
+    stage_end(ctx, ST_RASTER, timing);
+    HIPCHECK(hipGetLastError());
+    rc = read_info(ctx);
+    if (rc) return rc;
+    uint64_t k_or = (uint64_t)ctx->h_info->key_or | ((uint64_t)ctx->h_info->key_or_hi << 32);
+    uint64_t k_and = (uint64_t)ctx->h_info->key_and | ((uint64_t)ctx->h_info->key_and_hi << 32);
+    ctx->live44 = (k_or ^ k_and) & 0xFFFFFFFFFFFull;
+    return FORMA_OK;
+}
+
+// stage 3 on `src` (n segments, device): result pointer in ctx->sorted
+int run_sort(forma_hip_ctx* ctx, const uint64_t* src, size_t n, bool timing) {
+    ctx->n_passes = 0;
+    HIPCHECK(ctx->seg_a.ensure(std::max<size_t>(n, 1) * 8));
+    HIPCHECK(ctx->seg_b.ensure(std::max<size_t>(n, 1) * 8));
+    HIPCHECK(ctx->sort_counters.ensure(sort_counter_words(std::max<size_t>(n, 1), 4) * 4));
+    stage_begin(ctx, ST_SORT, timing);
+    ctx->sorted = launch_radix_sort(ctx->stream, src, ctx->seg_a.as<uint64_t>(), ctx->seg_b.as<uint64_t>(), n,
+                                    ctx->live44 << 20, 20, 64, 4, ctx->sort_counters.as<uint32_t>(), nullptr,
+                                    &ctx->n_passes, timing ? ctx->pev0 : nullptr, timing ? ctx->pev1 : nullptr);
+    stage_end(ctx, ST_SORT, timing);
+    HIPCHECK(hipGetLastError());
+    return FORMA_OK;
+}
+
+struct PaintArgs {
+    uint32_t width, height;
+    const uint8_t* channels;
+    const float* clear;
+    const forma_rect_t* crop;
+};
+
+// stage 4 on ctx->sorted (n segments): carry pre-pass + per-tile painter -> ctx->image
+int run_paint(forma_hip_ctx* ctx, size_t n, const PaintArgs& a, bool timing) {
+    const uint32_t tiles_w = (a.width + 15) / 16, tiles_h = (a.height + 15) / 16;
+    const uint32_t T = tiles_w * tiles_h;
+    HIPCHECK(ctx->image.ensure((size_t)a.width * a.height * 4));
+    ctx->img_w = a.width; ctx->img_h = a.height;
+    HIPCHECK(ctx->tile_count.ensure((size_t)(T + 1) * 4));
+    HIPCHECK(ctx->tile_fill.ensure((size_t)(T + 1) * 4));
+    HIPCHECK(ctx->scan_tmp.ensure(scan_tmp_words(std::max<size_t>(T + 1, 1 << 16)) * 4));
+    FrameInfo* dinfo = ctx->info.as<FrameInfo>();
+    uint32_t J = 0, E = 0;
+    stage_begin(ctx, ST_CARRY, timing);
+    HIPCHECK(hipMemsetAsync(ctx->tile_count.p, 0, (size_t)(T + 1) * 4, ctx->stream));
+    HIPCHECK(hipMemsetAsync(ctx->tile_fill.p, 0, (size_t)(T + 1) * 4, ctx->stream));
+    HIPCHECK(hipMemsetAsync(&dinfo->n_spans, 0, 4, ctx->stream));
+    if (n > 0) {
+        HIPCHECK(ctx->head_counts.ensure((n / 2048 + 2) * 4));
+        HIPCHECK(ctx->run_start.ensure((n + 2) * 4));
+        launch_find_bounds(ctx->stream, ctx->sorted, (uint32_t)n, tiles_h, dinfo);
+        launch_runs(ctx->stream, ctx->sorted, dinfo, (uint32_t)n, ctx->head_counts.as<uint32_t>(), nullptr,
+                    ctx->run_start.as<uint32_t>(), dinfo);
+        HIPCHECK(hipGetLastError());
+        int rc = read_info(ctx);
+        if (rc) return rc;
+        J = ctx->h_info->n_runs;
+    }
+    if (J > 0) {
+        HIPCHECK(ctx->records.ensure((size_t)2 * J * sizeof(TileRecord)));
+        HIPCHECK(ctx->run_cov.ensure((size_t)J * 16));
+        HIPCHECK(ctx->rk_u.ensure((size_t)J * 8));
+        HIPCHECK(ctx->rk_a.ensure((size_t)J * 8));
+        HIPCHECK(ctx->rk_b.ensure((size_t)J * 8));
+        HIPCHECK(ctx->sort_counters.ensure(sort_counter_words(J, 4) * 4));
+        launch_run_covers(ctx->stream, ctx->sorted, ctx->run_start.as<uint32_t>(), J, ctx->records.as<TileRecord>(),
+                          ctx->run_cov.as<uint4>(), ctx->rk_u.as<uint64_t>(), tiles_w);
+        // (tile_y, layer) order: stable radix sort on bits 32..63 = [layer 21 | tile_y+1 11]; live bits come from the
+        // rasterizer's varying-bit mask (layer = key bits 0..20, tile_y = key bits 33..43)
+        uint64_t live = ((ctx->live44 & 0x1FFFFFull) | ((ctx->live44 >> 33) << 21)) << 32;
+        uint64_t* sorted_keys = launch_radix_sort(ctx->stream, ctx->rk_u.as<uint64_t>(), ctx->rk_a.as<uint64_t>(),
+                                                  ctx->rk_b.as<uint64_t>(), J, live, 32, 64, 4,
+                                                  ctx->sort_counters.as<uint32_t>(), nullptr, nullptr, nullptr, nullptr);
+        launch_carry(ctx->stream, sorted_keys, J, ctx->records.as<TileRecord>(), ctx->run_cov.as<uint4>(),
+                     ctx->style_off.as<uint32_t>(), ctx->style_words.as<uint32_t>(), (uint32_t)ctx->n_orders, tiles_w, tiles_h,
+                     ctx->tile_count.as<uint32_t>(), dinfo, 0, nullptr, nullptr, nullptr, J);
+        launch_exclusive_scan_u32(ctx->stream, ctx->tile_count.as<uint32_t>(), T + 1, ctx->scan_tmp.as<uint32_t>(),
+                                  &dinfo->n_entries);
+        HIPCHECK(hipGetLastError());
+        int rc = read_info(ctx);
+        if (rc) return rc;
+        E = ctx->h_info->n_entries;
+        if (ctx->h_info->error & 1u) return fail(ctx, FORMA_E_STATE, "a pixel segment references an order without style");
+        HIPCHECK(ctx->entries.ensure(std::max<size_t>(E, 1) * 8));
+        launch_carry(ctx->stream, sorted_keys, J, ctx->records.as<TileRecord>(), ctx->run_cov.as<uint4>(),
+                     ctx->style_off.as<uint32_t>(), ctx->style_words.as<uint32_t>(), (uint32_t)ctx->n_orders, tiles_w, tiles_h,
+                     ctx->tile_count.as<uint32_t>(), dinfo, 1, ctx->tile_count.as<uint32_t>(), ctx->tile_fill.as<uint32_t>(),
+                     ctx->entries.as<uint64_t>(), J);
+    } else {
+        HIPCHECK(ctx->entries.ensure(8));
+        HIPCHECK(ctx->records.ensure(sizeof(TileRecord)));
+    }
+    stage_end(ctx, ST_CARRY, timing);
+    ctx->last_runs = J; ctx->last_entries = E;
+
+    PaintParams P;
+    P.width = a.width; P.height = a.height; P.tiles_w = tiles_w; P.tiles_h = tiles_h;
+    P.crop_x0 = 0; P.crop_x1 = tiles_w; P.crop_y0 = 0; P.crop_y1 = tiles_h;
+    if (a.crop) {                                         // Rect::new, renderer.rs:43-52
+        P.crop_x0 = a.crop->x0 / 16; P.crop_x1 = std::min(tiles_w, (a.crop->x1 + 15) / 16);
+        P.crop_y0 = a.crop->y0 / 16; P.crop_y1 = std::min(tiles_h, (a.crop->y1 + 15) / 16);
+    }
+    uint8_t ch[4] = {a.channels[0], a.channels[1], a.channels[2], a.channels[3]};
+    if (a.clear[3] == 1.0f)                               // renderer.rs:85-92: Alpha -> One when clear is opaque
+        for (int i = 0; i < 4; i++) if (ch[i] == FORMA_CH_ALPHA) ch[i] = FORMA_CH_ONE;
+    P.channels = (uint32_t)ch[0] | ((uint32_t)ch[1] << 8) | ((uint32_t)ch[2] << 16) | ((uint32_t)ch[3] << 24);
+    for (int i = 0; i < 4; i++) P.clear[i] = a.clear[i];
+    P.stride_px = a.width; P.scene_has_clips = ctx->scene_has_clips ? 1u : 0u; P.n_orders = (uint32_t)ctx->n_orders;
+    stage_begin(ctx, ST_PAINT, timing);
+    launch_paint(ctx->stream, P, ctx->sorted, ctx->tile_count.as<uint32_t>(), ctx->entries.as<uint64_t>(),
+                 ctx->records.as<TileRecord>(), ctx->style_off.as<uint32_t>(), ctx->style_words.as<uint32_t>(),
+                 ctx->images.as<forma_image_t>(), ctx->texels.as<uint16_t>(), ctx->image.as<uint8_t>(), dinfo);
+    stage_end(ctx, ST_PAINT, timing);
+    HIPCHECK(hipGetLastError());
+    return FORMA_OK;
+}
+
+int copy_image_out(forma_hip_ctx* ctx, uint8_t* dst, size_t stride, bool timing) {
+    if (!dst) return FORMA_OK;
+    stage_begin(ctx, ST_D2H, timing);
+    HIPCHECK(hipMemcpy2DAsync(dst, stride, ctx->image.p, (size_t)ctx->img_w * 4, (size_t)ctx->img_w * 4, ctx->img_h,
+                              hipMemcpyDeviceToHost, ctx->stream));
+    stage_end(ctx, ST_D2H, timing);
+    return FORMA_OK;
+}
+
+int finish_frame(forma_hip_ctx* ctx, forma_timings_t* t) {
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    // device-side invariant flags
+    HIPCHECK(hipMemcpy(ctx->h_info, ctx->info.p, sizeof(FrameInfo), hipMemcpyDeviceToHost));
+    if (ctx->h_info->error & 2u) return fail(ctx, FORMA_E_CAPACITY, "a tile has more layers than the painter's LDS list holds");
+    if (ctx->h_info->error) return fail(ctx, FORMA_E_INTERNAL, "device-side invariant violated");
+    if (!t) return FORMA_OK;
+    memset(t, 0, sizeof *t);
+    float* dstv[ST_COUNT] = {&t->prepare_us, &t->rasterize_us, &t->sort_us, &t->carry_us, &t->paint_us, &t->d2h_us};
+    float total = 0;
+    for (int s = 0; s < ST_COUNT; s++) {
+        if (!ctx->stage_used[s]) continue;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ctx->ev0[s], ctx->ev1[s]) == hipSuccess) { *dstv[s] = ms * 1000.0f; if (s != ST_D2H) total += ms * 1000.0f; }
+    }
+    t->total_us = total;
+    float pass = 0; int np = 0;
+    for (int p = 0; p < ctx->n_passes && p < MAX_PASS_EVENTS; p++) {
+        float ms = 0;
+        if (ctx->stage_used[ST_SORT] && hipEventElapsedTime(&ms, ctx->pev0[p], ctx->pev1[p]) == hipSuccess) { pass += ms * 1000.0f; np++; }
+    }
+    t->sort_pass_us = np ? pass / np : 0.0f;
+    t->n_lines = (uint32_t)ctx->n_lines; t->n_segments = (uint32_t)ctx->n_seg; t->n_sort_passes = (uint32_t)ctx->n_passes;
+    t->n_runs = ctx->last_runs; t->n_tile_entries = ctx->last_entries;
+    return FORMA_OK;
+}
+
+void clear_stage_flags(forma_hip_ctx* ctx) { for (int s = 0; s < ST_COUNT; s++) ctx->stage_used[s] = false; }
+
+int check_paint_args(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t height, size_t stride,
+                     const uint8_t* channels, const float* clear) {
+    int rc = check_canvas(ctx, width, height);
+    if (rc) return rc;
+    if (!channels || !clear) return fail(ctx, FORMA_E_ARG, "null channels/clear_color");
+    for (int i = 0; i < 4; i++) if (channels[i] > FORMA_CH_ONE) return fail(ctx, FORMA_E_ARG, "invalid channel selector");
+    if (dst && (size_t)width * 4 > stride) return fail(ctx, FORMA_E_ARG, "width exceeds width stride");   // layout/mod.rs:188-193
+    return FORMA_OK;
+}
+
+template <class T>
+int upload(forma_hip_ctx* ctx, DevBuf& b, const T* src, size_t n) {
+    HIPCHECK(b.ensure(std::max<size_t>(n, 1) * sizeof(T)));
+    if (n) HIPCHECK(hipMemcpyAsync(b.p, src, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return FORMA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* forma_hip_version(void) { return "forma_hip 0.1.0 gfx950"; }
+
+int forma_hip_create(forma_hip_ctx** out, int device) {
+    if (!out) return FORMA_E_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return FORMA_E_NO_DEVICE;
+    if (device < 0 || device >= count) return FORMA_E_ARG;
+    forma_hip_ctx* ctx = new (std::nothrow) forma_hip_ctx();
+    if (!ctx) return FORMA_E_INTERNAL;
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx; return FORMA_E_HIP;
+    }
+    bool ok = hipHostMalloc((void**)&ctx->h_info, sizeof(FrameInfo), hipHostMallocDefault) == hipSuccess &&
+              ctx->info.ensure(sizeof(FrameInfo)) == hipSuccess;
+    for (int s = 0; s < ST_COUNT && ok; s++) {
+        ok = hipEventCreate(&ctx->ev0[s]) == hipSuccess && hipEventCreate(&ctx->ev1[s]) == hipSuccess;
+        ctx->stage_used[s] = false;
+    }
+    for (int p = 0; p < MAX_PASS_EVENTS && ok; p++)
+        ok = hipEventCreate(&ctx->pev0[p]) == hipSuccess && hipEventCreate(&ctx->pev1[p]) == hipSuccess;
+    if (!ok) { delete ctx; return FORMA_E_HIP; }
+    // empty-scene defaults so that a render before any upload is well defined
+    ctx->style_off.ensure(4); ctx->style_words.ensure(4); ctx->geoms.ensure(sizeof(forma_geom_t));
+    ctx->images.ensure(sizeof(forma_image_t)); ctx->texels.ensure(8);
+    ctx->x.ensure(4); ctx->y.ensure(4); ctx->line_slot.ensure(4);
+    *out = ctx;
+    return FORMA_OK;
+}
+
+void forma_hip_destroy(forma_hip_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    DevBuf* all[] = {&ctx->x, &ctx->y, &ctx->line_slot, &ctx->geoms, &ctx->style_off, &ctx->style_words, &ctx->unchanged,
+                     &ctx->images, &ctx->texels, &ctx->l_order, &ctx->l_x0, &ctx->l_y0, &ctx->l_dx, &ctx->l_dy, &ctx->l_a,
+                     &ctx->l_b, &ctx->l_c, &ctx->l_d, &ctx->l_len, &ctx->scan_tmp, &ctx->seg_u, &ctx->seg_a, &ctx->seg_b,
+                     &ctx->sort_counters, &ctx->info, &ctx->head_counts, &ctx->run_start, &ctx->records, &ctx->run_cov,
+                     &ctx->rk_u, &ctx->rk_a, &ctx->rk_b, &ctx->tile_count, &ctx->tile_fill, &ctx->entries, &ctx->image};
+    for (DevBuf* b : all) b->release();
+    for (int s = 0; s < ST_COUNT; s++) { (void)hipEventDestroy(ctx->ev0[s]); (void)hipEventDestroy(ctx->ev1[s]); }
+    for (int p = 0; p < MAX_PASS_EVENTS; p++) { (void)hipEventDestroy(ctx->pev0[p]); (void)hipEventDestroy(ctx->pev1[p]); }
+    if (ctx->h_info) (void)hipHostFree(ctx->h_info);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* forma_hip_last_error(const forma_hip_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+// ---- scene upload --------------------------------------------------------------------------------
+int forma_hip_set_geometry(forma_hip_ctx* ctx, const float* x, const float* y, const uint32_t* line_slot, size_t n_points) {
+    if (!ctx) return FORMA_E_ARG;
+    if (n_points && (!x || !y)) return fail(ctx, FORMA_E_ARG, "null geometry");
+    if (n_points > 1 && !line_slot) return fail(ctx, FORMA_E_ARG, "null line_slot");
+    if (n_points > 0xFFFFFFF0ull) return fail(ctx, FORMA_E_ARG, "too many points");
+    HIPCHECK(hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = upload(ctx, ctx->x, x, n_points))) return rc;
+    if ((rc = upload(ctx, ctx->y, y, n_points))) return rc;
+    if ((rc = upload(ctx, ctx->line_slot, line_slot, n_points ? n_points - 1 : 0))) return rc;
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    ctx->n_points = n_points;
+    return FORMA_OK;
+}
+
+int forma_hip_set_geoms(forma_hip_ctx* ctx, const forma_geom_t* geoms, size_t n_geoms) {
+    if (!ctx || (n_geoms && !geoms)) return fail(ctx, FORMA_E_ARG, "null geoms");
+    for (size_t i = 0; i < n_geoms; i++)
+        if (geoms[i].order != FORMA_NONE && geoms[i].order > FORMA_LAYER_LIMIT)      // utils/order.rs:44-66
+            return fail(ctx, FORMA_E_ARG, "order exceeds LAYER_LIMIT");
+    HIPCHECK(hipSetDevice(ctx->device));
+    int rc = upload(ctx, ctx->geoms, geoms, n_geoms);
+    if (rc) return rc;
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    ctx->n_geoms = n_geoms;
+    return FORMA_OK;
+}
+
+int forma_hip_set_styles(forma_hip_ctx* ctx, const uint32_t* style_offsets, size_t n_orders, const uint32_t* style_words,
+                         size_t n_words, const uint8_t* unchanged) {
+    if (!ctx || (n_orders && !style_offsets) || (n_words && !style_words)) return fail(ctx, FORMA_E_ARG, "null styles");
+    if (n_orders > (size_t)FORMA_LAYER_LIMIT + 1) return fail(ctx, FORMA_E_ARG, "order exceeds LAYER_LIMIT");
+    bool clips = false;
+    for (size_t o = 0; o < n_orders; o++) {
+        uint32_t off = style_offsets[o];
+        if (off == FORMA_NONE) continue;
+        if (off + 2 > n_words) return fail(ctx, FORMA_E_ARG, "style offset out of range");
+        uint32_t h = style_words[off];
+        size_t need = 2;
+        if (!FORMA_STYLE_IS_CLIP(h)) {
+            uint32_t ft = FORMA_STYLE_FILL(h);
+            need = ft == FORMA_FILL_SOLID ? 6 : (ft == FORMA_FILL_TEXTURE ? 9 : 6 + 5 * (size_t)FORMA_STYLE_STOPS(h));
+            if (ft == FORMA_FILL_LINEAR || ft == FORMA_FILL_RADIAL) if (FORMA_STYLE_STOPS(h) < 1) return fail(ctx, FORMA_E_ARG, "gradient without stops");
+        }
+        if (off + need > n_words) return fail(ctx, FORMA_E_ARG, "style payload out of range");
+        if (FORMA_STYLE_IS_CLIP(h) || FORMA_STYLE_CLIPPED(h)) clips = true;
+    }
+    HIPCHECK(hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = upload(ctx, ctx->style_off, style_offsets, n_orders))) return rc;
+    if ((rc = upload(ctx, ctx->style_words, style_words, n_words))) return rc;
+    if (unchanged && (rc = upload(ctx, ctx->unchanged, unchanged, n_orders))) return rc;
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    ctx->n_orders = n_orders; ctx->n_words = n_words; ctx->scene_has_clips = clips;
+    return FORMA_OK;
+}
+
+int forma_hip_set_images(forma_hip_ctx* ctx, const forma_image_t* images, size_t n_images, const uint16_t* texels,
+                         size_t n_texels) {
+    if (!ctx || (n_images && !images) || (n_texels && !texels)) return fail(ctx, FORMA_E_ARG, "null images");
+    for (size_t i = 0; i < n_images; i++)
+        if (images[i].texel_offset + (uint64_t)images[i].width * images[i].height > n_texels || images[i].width == 0 || images[i].height == 0)
+            return fail(ctx, FORMA_E_ARG, "image outside texel pool");
+    HIPCHECK(hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = upload(ctx, ctx->images, images, n_images))) return rc;
+    if ((rc = upload(ctx, ctx->texels, texels, n_texels * 4))) return rc;
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    ctx->n_images = n_images;
+    return FORMA_OK;
+}
+
+// ---- stage 1 ---------------------------------------------------------------------------------------
+int forma_hip_flatten(forma_hip_ctx* ctx, const forma_flatten_tables_t* t, float* out_x, float* out_y) {
+    if (!ctx || !t || (t->n_points && (!out_x || !out_y))) return fail(ctx, FORMA_E_ARG, "null flatten tables");
+    if (t->n_points == 0) return FORMA_OK;
+    HIPCHECK(hipSetDevice(ctx->device));
+    std::vector<void*> owned;
+    auto up = [&](const void* src, size_t bytes, const void** dst) -> hipError_t {
+        void* d = nullptr;
+        hipError_t e = hipMalloc(&d, std::max<size_t>(bytes, 4));
+        if (e != hipSuccess) return e;
+        owned.push_back(d);
+        if (bytes) e = hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+        *dst = d;
+        return e;
+    };
+    forma_flatten_tables_t d = *t;
+    hipError_t e = hipSuccess;
+    const size_t np = t->n_points, nq = t->n_quads, ns = t->n_splines;
+#define UP(field, count, type) if (e == hipSuccess) e = up(t->field, (count) * sizeof(type), (const void**)&d.field)
+    UP(point_commands, np, uint32_t); UP(point_indices, np, uint32_t); UP(quad_indices, np, uint32_t);
+    UP(qx, 3 * nq, float); UP(qy, 3 * nq, float); UP(qw, 3 * nq, float);
+    UP(x0, nq, float); UP(dx_recip, nq, float); UP(k0, nq, float); UP(dk, nq, float); UP(curvatures_recip, nq, float);
+    UP(partial_spline, nq, uint32_t); UP(partial_curv, nq, float);
+    UP(sp0x, ns, float); UP(sp0y, ns, float); UP(sp2x, ns, float); UP(sp2y, ns, float);
+#undef UP
+    float *dx = nullptr, *dy = nullptr;
+    if (e == hipSuccess) e = hipMalloc((void**)&dx, np * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&dy, np * 4);
+    if (e == hipSuccess) {
+        launch_flatten(ctx->stream, &d, dx, dy);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out_x, dx, np * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_y, dy, np * 4, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = e2;
+    for (void* p : owned) (void)hipFree(p);
+    if (dx) (void)hipFree(dx);
+    if (dy) (void)hipFree(dy);
+    if (e != hipSuccess) return fail(ctx, FORMA_E_HIP, "flatten", e);
+    return FORMA_OK;
+}
+
+// ---- stage entry points ------------------------------------------------------------------------------
+int forma_hip_prepare_lines(forma_hip_ctx* ctx, uint32_t width, uint32_t height, uint32_t* orders, float* x0, float* y0,
+                            float* dx, float* dy, float* a, float* b, float* c, float* d, uint32_t* lengths) {
+    if (!ctx) return FORMA_E_ARG;
+    HIPCHECK(hipSetDevice(ctx->device));
+    const size_t n = ctx->n_points ? ctx->n_points - 1 : 0;
+    if (n && (!orders || !x0 || !y0 || !dx || !dy || !a || !b || !c || !d || !lengths)) return fail(ctx, FORMA_E_ARG, "null output");
+    ctx->n_lines = n;
+    if (n == 0) return FORMA_OK;
+    int rc = reset_info(ctx);
+    if (rc) return rc;
+    DevBuf* lb[] = {&ctx->l_order, &ctx->l_x0, &ctx->l_y0, &ctx->l_dx, &ctx->l_dy, &ctx->l_a, &ctx->l_b, &ctx->l_c, &ctx->l_d, &ctx->l_len};
+    for (DevBuf* bb : lb) HIPCHECK(bb->ensure(n * 4));
+    HIPCHECK(ctx->scan_tmp.ensure(scan_tmp_words(std::max<size_t>(n, 1 << 16)) * 4));
+    launch_prepare_lines(ctx->stream, ctx->x.as<float>(), ctx->y.as<float>(), ctx->line_slot.as<uint32_t>(), (uint32_t)n,
+                         ctx->geoms.as<forma_geom_t>(), (uint32_t)ctx->n_geoms, (float)width, (float)height, -3.0e38f, 3.0e38f,
+                         ctx->l_order.as<uint32_t>(), ctx->l_x0.as<float>(), ctx->l_y0.as<float>(), ctx->l_dx.as<float>(),
+                         ctx->l_dy.as<float>(), ctx->l_a.as<float>(), ctx->l_b.as<float>(), ctx->l_c.as<float>(),
+                         ctx->l_d.as<float>(), ctx->l_len.as<uint32_t>());
+    launch_inclusive_scan_u32(ctx->stream, ctx->l_len.as<uint32_t>(), n, ctx->scan_tmp.as<uint32_t>(),
+                              &ctx->info.as<FrameInfo>()->n_segments);
+    HIPCHECK(hipGetLastError());
+    void* outs[] = {orders, x0, y0, dx, dy, a, b, c, d, lengths};
+    for (int i = 0; i < 10; i++) HIPCHECK(hipMemcpyAsync(outs[i], lb[i]->p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    return FORMA_OK;
+}
+
+int forma_hip_rasterize(forma_hip_ctx* ctx, size_t n_lines, const uint32_t* orders, const float* x0, const float* y0,
+                        const float* dx, const float* dy, const float* a, const float* b, const float* c, const float* d,
+                        const uint32_t* lengths, uint64_t* out_segments, size_t capacity, size_t* out_n) {
+    if (!ctx || !out_n) return FORMA_E_ARG;
+    *out_n = 0;
+    if (n_lines == 0) return FORMA_OK;
+    if (!orders || !x0 || !y0 || !dx || !dy || !a || !b || !c || !d || !lengths) return fail(ctx, FORMA_E_ARG, "null line arrays");
+    HIPCHECK(hipSetDevice(ctx->device));
+    const size_t N = lengths[n_lines - 1];
+    *out_n = N;
+    if (N > capacity) return fail(ctx, FORMA_E_CAPACITY, "segment capacity too small");
+    if (N == 0) return FORMA_OK;
+    int rc = reset_info(ctx);
+    if (rc) return rc;
+    DevBuf* lb[] = {&ctx->l_order, &ctx->l_x0, &ctx->l_y0, &ctx->l_dx, &ctx->l_dy, &ctx->l_a, &ctx->l_b, &ctx->l_c, &ctx->l_d, &ctx->l_len};
+    const void* ins[] = {orders, x0, y0, dx, dy, a, b, c, d, lengths};
+    for (int i = 0; i < 10; i++) {
+        HIPCHECK(lb[i]->ensure(n_lines * 4));
+        HIPCHECK(hipMemcpyAsync(lb[i]->p, ins[i], n_lines * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIPCHECK(ctx->seg_u.ensure(N * 8));
+    launch_rasterize(ctx->stream, (uint32_t)n_lines, (uint32_t)N, ctx->l_order.as<uint32_t>(), ctx->l_x0.as<float>(),
+                     ctx->l_y0.as<float>(), ctx->l_dx.as<float>(), ctx->l_dy.as<float>(), ctx->l_a.as<float>(),
+                     ctx->l_b.as<float>(), ctx->l_c.as<float>(), ctx->l_d.as<float>(), ctx->l_len.as<uint32_t>(),
+                     ctx->seg_u.as<uint64_t>(), ctx->info.as<FrameInfo>(), 0, 0);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(out_segments, ctx->seg_u.p, N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    return FORMA_OK;
+}
+
+static uint64_t host_live44(const uint64_t* v, size_t n) {
+    uint64_t o = 0, a = ~0ull;
+    for (size_t i = 0; i < n; i++) { o |= v[i]; a &= v[i]; }
+    return ((o ^ a) >> 20) & 0xFFFFFFFFFFFull;
+}
+
+int forma_hip_sort(forma_hip_ctx* ctx, uint64_t* segments, size_t n, int digit_bits) {
+    if (!ctx || (n && !segments)) return FORMA_E_ARG;
+    if (digit_bits != 0 && digit_bits != 4) return fail(ctx, FORMA_E_ARG, "digit_bits must be 0 or 4");
+    if (n > 0xFFFFFFF0ull) return fail(ctx, FORMA_E_ARG, "too many segments");   // u32 prefix sums, segment.rs:90-98
+    if (n == 0) return FORMA_OK;
+    HIPCHECK(hipSetDevice(ctx->device));
+    HIPCHECK(ctx->seg_u.ensure(n * 8));
+    HIPCHECK(hipMemcpyAsync(ctx->seg_u.p, segments, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    ctx->live44 = host_live44(segments, n);
+    int rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), n, false);
+    if (rc) return rc;
+    HIPCHECK(hipMemcpyAsync(segments, ctx->sorted, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    return FORMA_OK;
+}
+
+int forma_hip_paint(forma_hip_ctx* ctx, const uint64_t* sorted_segments, size_t n, uint8_t* dst, uint32_t width,
+                    uint32_t height, size_t stride_bytes, const uint8_t channels[4], const float clear_color[4],
+                    const forma_rect_t* crop_or_null) {
+    if (!ctx || (n && !sorted_segments)) return FORMA_E_ARG;
+    int rc = check_paint_args(ctx, dst, width, height, stride_bytes, channels, clear_color);
+    if (rc) return rc;
+    HIPCHECK(hipSetDevice(ctx->device));
+    clear_stage_flags(ctx);
+    if ((rc = reset_info(ctx))) return rc;
+    HIPCHECK(ctx->seg_a.ensure(std::max<size_t>(n, 1) * 8));
+    if (n) HIPCHECK(hipMemcpyAsync(ctx->seg_a.p, sorted_segments, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    ctx->sorted = ctx->seg_a.as<uint64_t>();
+    ctx->n_seg = n; ctx->have_unsorted = false;
+    ctx->live44 = n ? host_live44(sorted_segments, n) : 0;
+    PaintArgs a{width, height, channels, clear_color, crop_or_null};
+    if ((rc = run_paint(ctx, n, a, false))) return rc;
+    if ((rc = copy_image_out(ctx, dst, stride_bytes, false))) return rc;
+    return finish_frame(ctx, nullptr);
+}
+
+// ---- the frame ---------------------------------------------------------------------------------------
+int forma_hip_render(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t height, size_t stride_bytes,
+                     const uint8_t channels[4], const float clear_color[4], const forma_rect_t* crop_or_null, int cache_id,
+                     forma_timings_t* timings) {
+    if (!ctx) return FORMA_E_ARG;
+    int rc = check_paint_args(ctx, dst, width, height, stride_bytes, channels, clear_color);
+    if (rc) return rc;
+    if (cache_id >= 32) return fail(ctx, FORMA_E_ARG, "cache_id out of range");   // SmallBitSet u32, small_bit_set.rs:17-57
+    HIPCHECK(hipSetDevice(ctx->device));
+    const bool timing = timings != nullptr;
+    clear_stage_flags(ctx);
+    if ((rc = run_rasterize_frame(ctx, width, height, timing))) return rc;
+    if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), ctx->n_seg, timing))) return rc;
+    PaintArgs a{width, height, channels, clear_color, crop_or_null};
+    if ((rc = run_paint(ctx, ctx->n_seg, a, timing))) return rc;
+    if ((rc = copy_image_out(ctx, dst, stride_bytes, timing))) return rc;
+    return finish_frame(ctx, timings);
+}
+
+int forma_hip_cache_clear(forma_hip_ctx* ctx, int cache_id) {
+    if (!ctx || cache_id < 0 || cache_id >= 32) return fail(ctx, FORMA_E_ARG, "cache_id out of range");
+    return FORMA_OK;
+}
+
+// ---- inspection ------------------------------------------------------------------------------------------
+int forma_hip_read_segments(forma_hip_ctx* ctx, int which, uint64_t* out, size_t capacity, size_t* out_n) {
+    if (!ctx || !out_n) return FORMA_E_ARG;
+    *out_n = ctx->n_seg;
+    if (which == 0 && !ctx->have_unsorted) return fail(ctx, FORMA_E_STATE, "no unsorted stream on the device");
+    if (ctx->n_seg > capacity) return fail(ctx, FORMA_E_CAPACITY, "segment capacity too small");
+    if (ctx->n_seg == 0) return FORMA_OK;
+    if (!out) return FORMA_E_ARG;
+    HIPCHECK(hipSetDevice(ctx->device));
+    const void* src = which == 0 ? ctx->seg_u.p : (const void*)ctx->sorted;
+    if (!src) return fail(ctx, FORMA_E_STATE, "no segments on the device");
+    HIPCHECK(hipMemcpy(out, src, ctx->n_seg * 8, hipMemcpyDeviceToHost));
+    return FORMA_OK;
+}
+
+int forma_hip_read_image(forma_hip_ctx* ctx, uint8_t* dst, size_t stride_bytes) {
+    if (!ctx || !dst) return FORMA_E_ARG;
+    if (!ctx->img_w) return fail(ctx, FORMA_E_STATE, "no image on the device");
+    if ((size_t)ctx->img_w * 4 > stride_bytes) return fail(ctx, FORMA_E_ARG, "width exceeds width stride");
+    HIPCHECK(hipSetDevice(ctx->device));
+    HIPCHECK(hipMemcpy2D(dst, stride_bytes, ctx->image.p, (size_t)ctx->img_w * 4, (size_t)ctx->img_w * 4, ctx->img_h, hipMemcpyDeviceToHost));
+    return FORMA_OK;
+}
+
+// ---- multi-GPU -----------------------------------------------------------------------------------------------
+int forma_hip_set_band(forma_hip_ctx* ctx, uint32_t row0, uint32_t row1) {
+    if (!ctx) return FORMA_E_ARG;
+    if (row1 != 0 && row0 >= row1) return fail(ctx, FORMA_E_ARG, "empty band");
+    ctx->band_row0 = row1 ? row0 : 0; ctx->band_row1 = row1;
+    return FORMA_OK;
+}
+
+int forma_hip_segments_device(forma_hip_ctx* ctx, int which, uint64_t** dev_ptr, size_t* n) {
+    if (!ctx || !dev_ptr || !n) return FORMA_E_ARG;
+    *dev_ptr = which == 0 ? ctx->seg_u.as<uint64_t>() : ctx->sorted;
+    *n = ctx->n_seg;
+    return FORMA_OK;
+}
+
+int forma_hip_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, forma_timings_t* timings) {
+    if (!ctx) return FORMA_E_ARG;
+    int rc = check_canvas(ctx, width, height);
+    if (rc) return rc;
+    HIPCHECK(hipSetDevice(ctx->device));
+    clear_stage_flags(ctx);
+    if ((rc = run_rasterize_frame(ctx, width, height, timings != nullptr))) return rc;
+    ctx->n_passes = 0; ctx->last_runs = 0; ctx->last_entries = 0;
+    return finish_frame(ctx, timings);
+}
+
+int forma_hip_reserve_segments(forma_hip_ctx* ctx, size_t n, uint64_t** dev_ptr) {
+    if (!ctx || !dev_ptr) return FORMA_E_ARG;
+    HIPCHECK(hipSetDevice(ctx->device));
+    // growing seg_u would drop the rasterized stream the caller may still be sending: grow seg_b (unused until the sort)
+    HIPCHECK(ctx->seg_b.ensure(std::max<size_t>(n, 1) * 8));
+    *dev_ptr = ctx->seg_b.as<uint64_t>();
+    return FORMA_OK;
+}
+
+int forma_hip_sort_paint_frame(forma_hip_ctx* ctx, size_t n, uint8_t* dst, uint32_t width, uint32_t height,
+                               size_t stride_bytes, const uint8_t channels[4], const float clear_color[4],
+                               const forma_rect_t* crop_or_null, forma_timings_t* timings) {
+    if (!ctx) return FORMA_E_ARG;
+    int rc = check_paint_args(ctx, dst, width, height, stride_bytes, channels, clear_color);
+    if (rc) return rc;
+    if (n * 8 > ctx->seg_b.cap) return fail(ctx, FORMA_E_STATE, "reserve_segments first");
+    HIPCHECK(hipSetDevice(ctx->device));
+    const bool timing = timings != nullptr;
+    clear_stage_flags(ctx);
+    if ((rc = reset_info(ctx))) return rc;
+    // the received stream lives in seg_b: move it to seg_u (the sort's read-only input) so a/b can ping-pong
+    HIPCHECK(ctx->seg_u.ensure(std::max<size_t>(n, 1) * 8));
+    if (n) HIPCHECK(hipMemcpyAsync(ctx->seg_u.p, ctx->seg_b.p, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->n_seg = n; ctx->have_unsorted = true;
+    ctx->live44 = 0xFFFFFFFFFFFull;                   // no varying-bit mask for a received stream: sort every digit
+    if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), n, timing))) return rc;
+    PaintArgs a{width, height, channels, clear_color, crop_or_null};
+    if ((rc = run_paint(ctx, n, a, timing))) return rc;
+    if ((rc = copy_image_out(ctx, dst, stride_bytes, timing))) return rc;
+    return finish_frame(ctx, timings);
+}
+
+}  // extern "C"

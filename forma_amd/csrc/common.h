@@ -1,0 +1,107 @@
+// common.h — internal declarations shared by the HIP translation units of libforma_hip.so.
+// Product code: never includes or links anything under oracle/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/forma_hip.h"
+
+// ---- packed pixel segment (reference forma/src/cpu/pixel_segment.rs:36-71, consts.rs:67-94) ----
+//  bit 63..53 tile_y+1 (11) | 52..41 tile_x+1 (12) | 40..20 layer (21) | 19..16 local_x | 15..12 local_y
+//  | 11..6 double-area multiplier (6) | 5..0 cover (6, two's complement).  Sort key = bits 63..20.
+#define SEG_KEY_SHIFT 20
+#define SEG_KEY_BITS  44
+
+#if defined(__HIPCC__)
+#define FD __device__ __forceinline__
+#else
+#define FD inline
+#endif
+
+FD int      seg_tile_y(uint64_t v) { return (int)(v >> 53) - 1; }
+FD int      seg_tile_x(uint64_t v) { return (int)((v >> 41) & 0xFFFu) - 1; }
+FD uint32_t seg_layer(uint64_t v) { return (uint32_t)(v >> 20) & 0x1FFFFFu; }
+FD int      seg_lx(uint64_t v) { return (int)(v >> 16) & 0xF; }
+FD int      seg_ly(uint64_t v) { return (int)(v >> 12) & 0xF; }
+FD int      seg_dam(uint64_t v) { return (int)(v >> 6) & 0x3F; }
+FD int      seg_cover(uint64_t v) { return ((int)(v & 0x3F) ^ 0x20) - 0x20; }
+FD uint64_t seg_key(uint64_t v) { return v >> SEG_KEY_SHIFT; }            // Ord, pixel_segment.rs:161-171
+FD uint32_t seg_tile_key(uint64_t v) { return (uint32_t)(v >> 41); }       // (tile_y+1, tile_x+1), 23 bits
+
+// ---- device-side frame header: counters produced by one stage and consumed by the next ----------
+struct FrameInfo {
+    uint32_t n_segments;     // N (inclusive sum of the last line)
+    uint32_t key_or;         // OR / AND of (v >> 20) over all segments, split in two words each:
+    uint32_t key_or_hi;      //   used to find constant key digits (single-bin histograms)
+    uint32_t key_and;
+    uint32_t key_and_hi;
+    uint32_t seg_begin;      // first sorted segment with tile_y >= 0
+    uint32_t seg_end;        // first sorted segment with tile_y >= tiles_h
+    uint32_t n_runs;         // J
+    uint32_t n_spans;        // carry-only records
+    uint32_t n_entries;      // E
+    uint32_t layer_unsorted; // != 0 if the rasterizer stream is not non-decreasing in layer
+    uint32_t error;          // device-side invariant violations
+    uint32_t pad[4];
+};
+
+// one painted (tile, layer) pair.  key = (layer << 32) | record index.
+struct TileRecord {          // 32 B
+    uint32_t cover[4];       // carry-in cover, 16 x i8 (little-endian bytes = local_y 0..15)
+    uint32_t seg_start;      // first segment of the run in the sorted stream (0 for carry-only)
+    uint32_t seg_count;      // 0 = carry-only
+    uint32_t layer;
+    uint32_t tile;           // ty * tiles_w + tx  (debug / validation)
+};
+
+struct PaintParams {
+    uint32_t width, height, tiles_w, tiles_h;
+    uint32_t crop_x0, crop_x1, crop_y0, crop_y1;   // in tiles, [x0,x1) x [y0,y1)
+    uint32_t channels;                             // 4 x u8 selectors
+    float    clear[4];
+    uint32_t stride_px;                            // device image row pitch in pixels
+    uint32_t scene_has_clips;
+    uint32_t n_orders;
+};
+
+// ---- kernel launch wrappers (defined in the .hip files) ------------------------------------------
+// lines.hip
+void launch_prepare_lines(hipStream_t s, const float* x, const float* y, const uint32_t* line_slot, uint32_t n_lines,
+                          const forma_geom_t* geoms, uint32_t n_geoms, float width, float height, float band_lo,
+                          float band_hi, uint32_t* orders, float* x0, float* y0, float* dx, float* dy, float* a,
+                          float* b, float* c, float* d, uint32_t* lengths);
+// inclusive scan of u32 (in place) using `tmp` (>= scan_tmp_words(n) u32); total written to *d_total if non-null
+size_t scan_tmp_words(size_t n);
+void launch_inclusive_scan_u32(hipStream_t s, uint32_t* data, size_t n, uint32_t* tmp, uint32_t* d_total);
+void launch_exclusive_scan_u32(hipStream_t s, uint32_t* data, size_t n, uint32_t* tmp, uint32_t* d_total);
+void launch_rasterize(hipStream_t s, uint32_t n_lines, uint32_t n_segments, const uint32_t* orders, const float* x0,
+                      const float* y0, const float* dx, const float* dy, const float* a, const float* b, const float* c,
+                      const float* d, const uint32_t* sums, uint64_t* out, FrameInfo* info, int band_row0,
+                      int band_row1);
+void launch_flatten(hipStream_t s, const forma_flatten_tables_t* dev_tables, float* out_x, float* out_y);
+
+// sort.hip — stable LSB radix sort of u64 by bits [lo_bit, hi_bit); returns the buffer holding the result.
+// bufs: `in` is read-only (preserved), a/b are ping-pong buffers.  counters: >= sort_counter_words(n, digit_bits) u32.
+size_t sort_counter_words(size_t n, int digit_bits);
+uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a, uint64_t* b, size_t n, uint64_t live_mask,
+                            int lo_bit, int hi_bit, int digit_bits, uint32_t* counters, uint32_t* scan_tmp,
+                            int* passes_out, hipEvent_t* pass_ev0, hipEvent_t* pass_ev1);
+
+// paint.hip
+void launch_find_bounds(hipStream_t s, const uint64_t* sorted, uint32_t n, uint32_t tiles_h, FrameInfo* info);
+// run detection: writes run_start[J] (+ sentinel), J -> info->n_runs.  head_counts: per-block scratch.
+void launch_runs(hipStream_t s, const uint64_t* sorted, const FrameInfo* info_in, uint32_t n, uint32_t* head_counts,
+                 uint32_t* scan_tmp, uint32_t* run_start, FrameInfo* info);
+void launch_run_covers(hipStream_t s, const uint64_t* sorted, const uint32_t* run_start, uint32_t n_runs,
+                       TileRecord* records, uint4* run_cov, uint64_t* run_keys, uint32_t tiles_w);
+// fill = 0: write carry-ins and count (tile, layer) pairs per tile; fill = 1: write the entries.
+// records[0..record_cap) are run records, records[record_cap..2*record_cap) carry-only (span) records.
+void launch_carry(hipStream_t s, const uint64_t* sorted_run_keys, uint32_t n_runs, TileRecord* records,
+                  const uint4* run_cov, const uint32_t* style_offsets, const uint32_t* style_words, uint32_t n_orders,
+                  uint32_t tiles_w, uint32_t tiles_h, uint32_t* tile_count, FrameInfo* info, int fill,
+                  const uint32_t* tile_off, uint32_t* tile_fill, uint64_t* entries, uint32_t record_cap);
+void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const uint32_t* tile_off,
+                  uint64_t* entries, const TileRecord* records, const uint32_t* style_offsets,
+                  const uint32_t* style_words, const forma_image_t* images, const uint16_t* texels, uint8_t* image,
+                  FrameInfo* info);

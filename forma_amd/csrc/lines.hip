@@ -1,0 +1,376 @@
+// lines.hip — stage 1 (flatten map), line preparation, prefix sums and stage 2 (pixel-grid
+// intersector) for gfx950.  Built with -ffp-contract=off: the reference (Rust) never contracts
+// a*b+c, every fused operation below is an explicit fmaf()/fma() exactly where the reference
+// writes `mul_add`.  All kernels are HBM/L2-bound integer + f32/f64 scalar work: no MFMA.
+#include "common.h"
+
+#define WAVE 64
+
+// ------------------------------------------------------------------------------------------------
+// block-wide exclusive scan helper (256 threads), returns exclusive prefix; *total = block sum.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+template <int THREADS>
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds /* THREADS/64 + 1 */, uint32_t* total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = wave_inclusive_scan(v);
+    if (lane == 63) lds[w] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < THREADS / 64; i++) {
+        uint32_t t = lds[i];
+        if (i < w) base += t;
+        tot += t;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// u32 prefix sums: reduce -> scan of block sums (single block) -> scan with offsets (in place).
+// ------------------------------------------------------------------------------------------------
+#define SCAN_THREADS 256
+#define SCAN_ITEMS   8
+#define SCAN_TILE    (SCAN_THREADS * SCAN_ITEMS)
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const uint32_t* __restrict__ data, uint32_t n,
+                                                              uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t lds[SCAN_THREADS / 64 + 1];
+    const uint32_t base = blockIdx.x * SCAN_TILE;
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        uint32_t idx = base + i * SCAN_THREADS + threadIdx.x;
+        if (idx < n) s += data[idx];
+    }
+    uint32_t tot;
+    block_exclusive_scan<SCAN_THREADS>(s, lds, &tot);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+// single block: exclusive scan of block_sums[nb] in place; total -> *d_total
+__global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__ block_sums, uint32_t nb,
+                                                          uint32_t* __restrict__ d_total) {
+    __shared__ uint32_t lds[1024 / 64 + 1];
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < nb; base += 1024) {
+        uint32_t idx = base + threadIdx.x;
+        uint32_t v = idx < nb ? block_sums[idx] : 0;
+        uint32_t tot;
+        uint32_t ex = block_exclusive_scan<1024>(v, lds, &tot);
+        if (idx < nb) block_sums[idx] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0 && d_total) *d_total = carry;
+}
+
+template <bool INCLUSIVE>
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(uint32_t* __restrict__ data, uint32_t n,
+                                                             const uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t lds[SCAN_THREADS / 64 + 1];
+    // blocked arrangement through registers: thread t owns items [t*ITEMS, t*ITEMS+ITEMS)
+    const uint32_t base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        v[i] = (base + i < n) ? data[base + i] : 0;
+        s += v[i];
+    }
+    uint32_t tot;
+    uint32_t ex = block_exclusive_scan<SCAN_THREADS>(s, lds, &tot) + block_sums[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        uint32_t out = INCLUSIVE ? ex + v[i] : ex;
+        ex += v[i];
+        if (base + i < n) data[base + i] = out;
+    }
+}
+
+size_t scan_tmp_words(size_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE + 8; }
+
+static void scan_u32(hipStream_t s, uint32_t* data, size_t n, uint32_t* tmp, uint32_t* d_total, bool inclusive) {
+    if (n == 0) {
+        if (d_total) hipMemsetAsync(d_total, 0, 4, s);
+        return;
+    }
+    uint32_t nb = (uint32_t)((n + SCAN_TILE - 1) / SCAN_TILE);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, s, data, (uint32_t)n, tmp);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, tmp, nb, d_total);
+    if (inclusive)
+        hipLaunchKernelGGL(k_scan_apply<true>, dim3(nb), dim3(SCAN_THREADS), 0, s, data, (uint32_t)n, tmp);
+    else
+        hipLaunchKernelGGL(k_scan_apply<false>, dim3(nb), dim3(SCAN_THREADS), 0, s, data, (uint32_t)n, tmp);
+}
+void launch_inclusive_scan_u32(hipStream_t s, uint32_t* data, size_t n, uint32_t* tmp, uint32_t* d_total) {
+    scan_u32(s, data, n, tmp, d_total, true);
+}
+void launch_exclusive_scan_u32(hipStream_t s, uint32_t* data, size_t n, uint32_t* tmp, uint32_t* d_total) {
+    scan_u32(s, data, n, tmp, d_total, false);
+}
+
+// ------------------------------------------------------------------------------------------------
+// prepare_lines — the map of SegmentBuffer::fill_cpu_view (reference forma/src/segment.rs:298-383),
+// one thread per line.  Layer lookup is a dense table gather instead of two hash lookups.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t f2u_sat(float v) {   // Rust `as u32`: saturating, NaN -> 0
+    if (!(v > 0.0f)) return 0u;
+    if (v >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)v;
+}
+__device__ __forceinline__ uint32_t integers_between(float a, float b) {   // segment.rs:54-59
+    float mn = fminf(a, b), mx = fmaxf(a, b);
+    return f2u_sat(ceilf(mx) - floorf(mn) - 1.0f);
+}
+
+__global__ __launch_bounds__(256) void k_prepare_lines(
+    const float* __restrict__ x, const float* __restrict__ y, const uint32_t* __restrict__ line_slot, uint32_t n_lines,
+    const forma_geom_t* __restrict__ geoms, uint32_t n_geoms, float width, float height, float band_lo, float band_hi,
+    uint32_t* __restrict__ orders, float* __restrict__ ox0, float* __restrict__ oy0, float* __restrict__ odx,
+    float* __restrict__ ody, float* __restrict__ oa, float* __restrict__ ob, float* __restrict__ oc,
+    float* __restrict__ od, uint32_t* __restrict__ lengths) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_lines; i += gridDim.x * blockDim.x) {
+        uint32_t order = 0, len = 0;
+        float lx0 = 0, ly0 = 0, ldx = 0, ldy = 0, la = 0, lb = 0, lc = 0, ld = 0;
+        uint32_t slot = line_slot[i];
+        if (slot != FORMA_NONE && slot < n_geoms) {
+            const forma_geom_t g = geoms[slot];
+            if (g.order != FORMA_NONE) {
+                float p0x = x[i], p0y = y[i], p1x = x[i + 1], p1y = y[i + 1];
+                if (g.flags & FORMA_GEOM_HAS_XF) {                      // transform_point segment.rs:30-39
+                    float ax = fmaf(g.xf[0], p0x, fmaf(g.xf[2], p0y, g.xf[4]));
+                    float ay = fmaf(g.xf[1], p0x, fmaf(g.xf[3], p0y, g.xf[5]));
+                    float bx = fmaf(g.xf[0], p1x, fmaf(g.xf[2], p1y, g.xf[4]));
+                    float by = fmaf(g.xf[1], p1x, fmaf(g.xf[3], p1y, g.xf[5]));
+                    p0x = ax; p0y = ay; p1x = bx; p1y = by;
+                }
+                // skip_line segment.rs:41-52 (left is NOT culled) + the multi-GPU tile-row band
+                bool skip = (p0y == p1y) || (p0y >= height && p1y >= height) || (p0x >= width && p1x >= width) ||
+                            (p0y <= 0.0f && p1y <= 0.0f) || (p0y >= band_hi && p1y >= band_hi) ||
+                            (p0y <= band_lo && p1y <= band_lo);
+                if (!skip) {
+                    float dx = p1x - p0x, dy = p1y - p0y;
+                    float dxr = 1.0f / dx, dyr = 1.0f / dy;
+                    lc = dx != 0.0f ? fmaxf((ceilf(p0x) - p0x) * dxr, (floorf(p0x) - p0x) * dxr) : 0.0f;
+                    ld = dy != 0.0f ? fmaxf((ceilf(p0y) - p0y) * dyr, (floorf(p0y) - p0y) * dyr) : 0.0f;
+                    order = g.order;
+                    lx0 = p0x * 16.0f; ly0 = p0y * 16.0f; ldx = dx * 16.0f; ldy = dy * 16.0f;
+                    la = fabsf(dxr); lb = fabsf(dyr);
+                    len = integers_between(p0x, p1x) + integers_between(p0y, p1y) + 1u;   // :86-88
+                }
+            }
+        }
+        orders[i] = order; ox0[i] = lx0; oy0[i] = ly0; odx[i] = ldx; ody[i] = ldy;
+        oa[i] = la; ob[i] = lb; oc[i] = lc; od[i] = ld; lengths[i] = len;
+    }
+}
+
+void launch_prepare_lines(hipStream_t s, const float* x, const float* y, const uint32_t* line_slot, uint32_t n_lines,
+                          const forma_geom_t* geoms, uint32_t n_geoms, float width, float height, float band_lo,
+                          float band_hi, uint32_t* orders, float* x0, float* y0, float* dx, float* dy, float* a,
+                          float* b, float* c, float* d, uint32_t* lengths) {
+    if (n_lines == 0) return;
+    uint32_t blocks = (n_lines + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_prepare_lines, dim3(blocks), dim3(256), 0, s, x, y, line_slot, n_lines, geoms, n_geoms, width,
+                       height, band_lo, band_hi, orders, x0, y0, dx, dy, a, b, c, d, lengths);
+}
+
+// ------------------------------------------------------------------------------------------------
+// rasterize — reference forma/src/cpu/rasterizer.rs:32-159, one thread per pixel segment.
+// The flat segment index -> (line, i) map of PrefixScanIter (utils/prefix_scan.rs:30-63) is an
+// upper_bound over the inclusive sums; each block narrows the range once and then searches a
+// window staged in LDS.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float find_term(int i, double a_ab, double b_ab, double cd_ab, float a, float b, float c,
+                                           float d) {               // rasterizer.rs:32-61
+    float fi = (float)i;
+    float ja = isfinite(b) ? (float)ceil(fma(b_ab, (double)fi, -cd_ab)) : fi;
+    float jb = isfinite(a) ? (float)ceil(fma(a_ab, (double)fi, cd_ab)) : fi;
+    return fminf(fmaf(a, ja, c), fmaf(b, jb, d));
+}
+
+__device__ __forceinline__ uint64_t rasterize_one(uint32_t order, float lx0, float ly0, float ldx, float ldy, float a,
+                                                  float b, float c, float d, uint32_t seg_i) {
+    int i = (int)seg_i - (c != 0.0f ? 1 : 0) - (d != 0.0f ? 1 : 0);                 // rasterizer.rs:63-76
+    double sum_recip = 1.0 / ((double)a + (double)b);
+    double a_ab = (double)a * sum_recip, b_ab = (double)b * sum_recip;
+    double cd_ab = ((double)c - (double)d) * sum_recip;
+    float t0 = fmaxf(find_term(i, a_ab, b_ab, cd_ab, a, b, c, d), 0.0f);
+    float t1 = fminf(find_term(i + 1, a_ab, b_ab, cd_ab, a, b, c, d), 1.0f);
+    float x0f = fmaf(t0, ldx, lx0), y0f = fmaf(t0, ldy, ly0);                        // :112-127
+    float x1f = fmaf(t1, ldx, lx0), y1f = fmaf(t1, ldy, ly0);
+    int x0s = (int)floorf(x0f + 0.5f), x1s = (int)floorf(x1f + 0.5f);                // round :78-80
+    int y0s = (int)floorf(y0f + 0.5f), y1s = (int)floorf(y1f + 0.5f);
+    int border_x = min(x0s, x1s) >> 4, border_y = min(y0s, y1s) >> 4;
+    int tile_x = (int)(int16_t)(border_x >> 4), tile_y = (int)(int16_t)(border_y >> 4);
+    uint32_t lx = (uint32_t)border_x & 15u, ly = (uint32_t)border_y & 15u;
+    int border = (int)((uint32_t)border_x << 4) + 16;
+    uint32_t dam = (uint32_t)(abs(x1s - x0s) + 2 * (border - max(x0s, x1s))) & 0xFFu;   // `as u8`
+    int cover = (int)(int8_t)(y1s - y0s);                                                // `as i8`
+    // PixelSegment::new, pixel_segment.rs:36-71 (tile + bias wraps as i16, then max(0))
+    int ty1 = (int)(int16_t)(tile_y + 1), tx1 = (int)(int16_t)(tile_x + 1);
+    uint64_t v = (uint64_t)(ty1 > 0 ? ty1 : 0) & 0x7FFull;
+    v = (v << 12) | ((uint64_t)(tx1 > 0 ? tx1 : 0) & 0xFFFull);
+    v = (v << 21) | ((uint64_t)order & 0x1FFFFFull);
+    v = (v << 4) | lx;
+    v = (v << 4) | ly;
+    v = (v << 6) | (dam & 0x3Fu);
+    v = (v << 6) | ((uint32_t)cover & 0x3Fu);
+    return v;
+}
+
+#define RAS_THREADS 256
+#define RAS_PER_THREAD 4
+#define RAS_TILE (RAS_THREADS * RAS_PER_THREAD)
+#define RAS_WIN 1280
+
+__device__ __forceinline__ uint32_t upper_bound_global(const uint32_t* __restrict__ sums, uint32_t lo, uint32_t hi,
+                                                       uint32_t k) {   // first index in [lo,hi) with sums[idx] > k
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (sums[mid] > k) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(RAS_THREADS) void k_rasterize(
+    uint32_t n_lines, uint32_t n_segments, const uint32_t* __restrict__ orders, const float* __restrict__ lx0,
+    const float* __restrict__ ly0, const float* __restrict__ ldx, const float* __restrict__ ldy,
+    const float* __restrict__ la, const float* __restrict__ lb, const float* __restrict__ lc,
+    const float* __restrict__ ld, const uint32_t* __restrict__ sums, uint64_t* __restrict__ out,
+    FrameInfo* __restrict__ info, int band_row0, int band_row1) {
+    __shared__ uint32_t win[RAS_WIN + 1];
+    __shared__ uint32_t s_lo, s_hi;
+    __shared__ uint32_t red[4][RAS_THREADS / 64];
+    const uint32_t k0 = blockIdx.x * RAS_TILE;
+    const uint32_t k_last = min(k0 + RAS_TILE, n_segments) - 1;
+    if (threadIdx.x == 0) s_lo = upper_bound_global(sums, 0, n_lines, k0);
+    if (threadIdx.x == 64) s_hi = upper_bound_global(sums, 0, n_lines, k_last);
+    __syncthreads();
+    const uint32_t lo = s_lo, hi = s_hi;          // lines lo..hi (inclusive) own segments k0..k_last
+    const bool use_lds = (hi - lo + 1) <= RAS_WIN;
+    if (use_lds) {
+        // win[j] = sums[lo - 1 + j], j in [0, hi-lo+1]
+        for (uint32_t j = threadIdx.x; j <= hi - lo + 1; j += RAS_THREADS) {
+            uint32_t idx = lo + j;
+            win[j] = idx == 0 ? 0u : sums[idx - 1];
+        }
+    }
+    __syncthreads();
+    uint32_t k_or = 0, k_or_hi = 0, k_and = 0xFFFFFFFFu, k_and_hi = 0xFFFFFFFFu;
+#pragma unroll
+    for (int r = 0; r < RAS_PER_THREAD; r++) {
+        uint32_t k = k0 + r * RAS_THREADS + threadIdx.x;
+        if (k >= n_segments) break;
+        uint32_t li, ex;
+        if (use_lds) {
+            // first j in [1, cnt] with win[j] > k  -> line lo + j - 1
+            uint32_t a = 1, b = hi - lo + 1;
+            while (a < b) {
+                uint32_t mid = (a + b) >> 1;
+                if (win[mid] > k) b = mid; else a = mid + 1;
+            }
+            li = lo + a - 1;
+            ex = win[a - 1];
+            // win[a-1] is sums[li-1] only if the previous lines were non-empty or not; it is the
+            // inclusive sum of line li-1, which is what PrefixScanIter subtracts (prefix_scan.rs:37-41)
+        } else {
+            li = upper_bound_global(sums, lo, hi + 1, k);
+            ex = li == 0 ? 0u : sums[li - 1];
+        }
+        uint64_t v = rasterize_one(orders[li], lx0[li], ly0[li], ldx[li], ldy[li], la[li], lb[li], lc[li], ld[li],
+                                   k - ex);
+        if (band_row1 > 0) {
+            int ty = seg_tile_y(v);
+            if (ty < band_row0 || ty >= band_row1) v &= 0x001FFFFFFFFFFFFFull;   // -> tile row -1: never painted
+        }
+        out[k] = v;
+        uint32_t klo = (uint32_t)(v >> 20), khi = (uint32_t)(v >> 52);
+        k_or |= klo; k_or_hi |= khi; k_and &= klo; k_and_hi &= khi;
+    }
+    // block reduction of the varying-bit masks -> 4 atomics per block
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        k_or |= __shfl_xor(k_or, d, 64); k_or_hi |= __shfl_xor(k_or_hi, d, 64);
+        k_and &= __shfl_xor(k_and, d, 64); k_and_hi &= __shfl_xor(k_and_hi, d, 64);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = k_or; red[1][w] = k_or_hi; red[2][w] = k_and; red[3][w] = k_and_hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t o = 0, oh = 0, a = 0xFFFFFFFFu, ah = 0xFFFFFFFFu;
+        for (int i = 0; i < RAS_THREADS / 64; i++) { o |= red[0][i]; oh |= red[1][i]; a &= red[2][i]; ah &= red[3][i]; }
+        atomicOr(&info->key_or, o); atomicOr(&info->key_or_hi, oh);
+        atomicAnd(&info->key_and, a); atomicAnd(&info->key_and_hi, ah);
+    }
+}
+
+void launch_rasterize(hipStream_t s, uint32_t n_lines, uint32_t n_segments, const uint32_t* orders, const float* x0,
+                      const float* y0, const float* dx, const float* dy, const float* a, const float* b, const float* c,
+                      const float* d, const uint32_t* sums, uint64_t* out, FrameInfo* info, int band_row0,
+                      int band_row1) {
+    if (n_segments == 0) return;
+    uint32_t blocks = (n_segments + RAS_TILE - 1) / RAS_TILE;
+    hipLaunchKernelGGL(k_rasterize, dim3(blocks), dim3(RAS_THREADS), 0, s, n_lines, n_segments, orders, x0, y0, dx, dy,
+                       a, b, c, d, sums, out, info, band_row0, band_row1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// flatten — the parallel map of Primitives::into_segments (reference forma/src/path.rs:487-534),
+// one thread per output point.  The sequential curvature bookkeeping (path.rs:252-445) is done by
+// the host and arrives as work items.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float lerpf(float t, float a, float b) { return fmaf(t, b, fmaf(-t, a, a)); }   // path.rs:44-46
+__device__ __forceinline__ float inv_curvature(float k) {                                                   // path.rs:53-56
+    const float C = 0.39f;
+    return k * (1.0f - C + sqrtf(fmaf(k * k, 0.25f, C * C)));
+}
+
+__global__ __launch_bounds__(256) void k_flatten(forma_flatten_tables_t t, float* __restrict__ out_x,
+                                                 float* __restrict__ out_y) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < t.n_points; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t cmd = t.point_commands[i];
+        float px, py;
+        if ((cmd & 0x7F800000u) == 0x7F800000u) {                       // PointCommand NaN-box, path.rs:137-168
+            uint32_t si = cmd & 0x3FFFFFu;
+            if ((cmd & 0x80000000u) == 0) { px = t.sp0x[si]; py = t.sp0y[si]; }      // Start
+            else { px = t.sp2x[si]; py = t.sp2y[si]; }                                // End
+        } else {
+            float incr = __uint_as_float(cmd);
+            uint32_t qi = t.quad_indices[i], pi = t.point_indices[i];
+            uint32_t spline_i = t.partial_spline[qi];
+            float prev = 0.0f;
+            if (qi >= 1 && t.partial_spline[qi - 1] == spline_i) prev = t.partial_curv[qi - 1];
+            float ratio = fmaf(incr, (float)pi, -prev) * t.curvatures_recip[qi];
+            float xx = inv_curvature(fmaf(ratio, t.dk[qi], t.k0[qi]));
+            float tt = (xx - t.x0[qi]) * t.dx_recip[qi];
+            if (tt < 0.0f) tt = 0.0f;
+            if (tt > 1.0f) tt = 1.0f;
+            size_t i0 = 3 * (size_t)qi, i1 = i0 + 1, i2 = i0 + 2;       // eval_quad path.rs:447-471
+            float w = lerpf(tt, lerpf(tt, t.qw[i0], t.qw[i1]), lerpf(tt, t.qw[i1], t.qw[i2]));
+            float wr = 1.0f / w;
+            px = lerpf(tt, lerpf(tt, t.qx[i0], t.qx[i1]), lerpf(tt, t.qx[i1], t.qx[i2])) * wr;
+            py = lerpf(tt, lerpf(tt, t.qy[i0], t.qy[i1]), lerpf(tt, t.qy[i1], t.qy[i2])) * wr;
+        }
+        out_x[i] = px; out_y[i] = py;
+    }
+}
+
+void launch_flatten(hipStream_t s, const forma_flatten_tables_t* dev_tables, float* out_x, float* out_y) {
+    if (dev_tables->n_points == 0) return;
+    size_t blocks = (dev_tables->n_points + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_flatten, dim3((uint32_t)blocks), dim3(256), 0, s, *dev_tables, out_x, out_y);
+}

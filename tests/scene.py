@@ -332,3 +332,70 @@ def e2e_scenes():
     c.get_mut_or_insert_default(2).insert(triangle()).set_props(Props(fill=(0.5, 0.5, 1.0, 0.7), is_clipped=True))
     out["clipping2"] = c
     return out
+
+
+# ---- synthetic workloads -----------------------------------------------------------
+def random_cubics(n=1000, width=1920, height=1080, seed=42, alpha=1.0):
+    """C2: n layers, one closed random cubic each, solid fill, NonZero, Over."""
+    rng = np.random.default_rng(seed)
+    c = Composition()
+    for i in range(n):
+        p = rng.random((4, 2), dtype=np.float32) * np.array([width, height], np.float32)
+        col = rng.random(3, dtype=np.float32)
+        path = P().move_to(*map(float, p[0])).cubic_to(*map(float, p[1]), *map(float, p[2]), *map(float, p[3])).build()
+        c.get_mut_or_insert_default(i).insert(path).set_props(solid((float(col[0]), float(col[1]), float(col[2]), alpha)))
+    return c
+
+
+def random_mixed(n=300, width=512, height=384, seed=7):
+    """A small stress scene touching every feature: fills, fill rules, blend modes, clips, transforms,
+    shapes crossing every canvas edge."""
+    rng = np.random.default_rng(seed)
+    c = Composition()
+    img = Image.from_srgba([[int(v) for v in rng.integers(0, 256, 4)] for _ in range(16)], 4, 4)
+    order = 0
+    for i in range(n):
+        k = int(rng.integers(3, 9))
+        cx, cy = rng.random(2) * np.array([width * 1.4, height * 1.4]) - np.array([width * 0.2, height * 0.2])
+        r = float(np.exp(rng.uniform(np.log(4.0), np.log(160.0))))
+        path = P()
+        ang = np.sort(rng.random(k) * 2 * np.pi)
+        pts = [(float(np.float32(cx + r * np.cos(a))), float(np.float32(cy + r * np.sin(a)))) for a in ang]
+        path.move_to(*pts[0])
+        for j in range(1, k):
+            mode = rng.integers(0, 3)
+            if mode == 0:
+                path.line_to(*pts[j])
+            elif mode == 1:
+                mx = float(np.float32((pts[j - 1][0] + pts[j][0]) / 2 + rng.normal() * r * 0.3))
+                my = float(np.float32((pts[j - 1][1] + pts[j][1]) / 2 + rng.normal() * r * 0.3))
+                path.quad_to(mx, my, *pts[j])
+            else:
+                a = (float(np.float32(pts[j - 1][0] + rng.normal() * r * 0.3)), float(np.float32(pts[j - 1][1] + rng.normal() * r * 0.3)))
+                b = (float(np.float32(pts[j][0] + rng.normal() * r * 0.3)), float(np.float32(pts[j][1] + rng.normal() * r * 0.3)))
+                path.cubic_to(*a, *b, *pts[j])
+        path.build()
+        u = rng.random()
+        col = tuple(float(v) for v in rng.random(4, dtype=np.float32))
+        if u < 0.05:
+            props = Props(clip=int(rng.integers(1, 4)))
+        else:
+            if u < 0.55:
+                fill = (col[0], col[1], col[2], 1.0 if rng.random() < 0.5 else col[3])
+            elif u < 0.75:
+                cols = [tuple(float(v) for v in rng.random(4, dtype=np.float32)) for _ in range(int(rng.integers(2, 5)))]
+                fill = gradient((float(cx - r), float(cy - r)), (float(cx + r), float(cy + r * 0.5)), cols, radial=bool(rng.random() < 0.4))
+            elif u < 0.85:
+                fill = Texture((0.1, 0.02, -0.03, 0.1, float(-cx * 0.1 + 2), float(-cy * 0.1 + 2)), img)
+            else:
+                fill = (col[0], col[1], col[2], 0.5)
+            props = Props(fill_rule="EvenOdd" if rng.random() < 0.3 else "NonZero", fill=fill,
+                          blend_mode=BLEND_MODES[int(rng.integers(0, 16))] if rng.random() < 0.4 else "Over",
+                          is_clipped=bool(rng.random() < 0.15))
+        layer = c.get_mut_or_insert_default(order).insert(path).set_props(props)
+        if rng.random() < 0.2:
+            th = rng.uniform(-0.3, 0.3)
+            cs, sn = float(np.float32(np.cos(th))), float(np.float32(np.sin(th)))
+            layer.set_transform((cs, -sn, sn, cs, float(rng.uniform(-20, 20)), float(rng.uniform(-20, 20))))
+        order += int(rng.integers(1, 3))
+    return c

@@ -1,0 +1,142 @@
+"""GPU parity: every stage of libforma_hip.so against the CPU oracle on identical inputs, through the
+C ABI.  Bars (BASELINE.json north_star): unsorted and sorted u64 streams bit-exact; RGBA8 within 1
+code value (observed: identical)."""
+import os
+
+import numpy as np
+import pytest
+
+import scene as S
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+LINE_KEYS = ("orders", "x0", "y0", "dx", "dy", "a", "b", "c", "d", "lengths")
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "e2e_cpu_64x64.npz"))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import forma_amd
+    c = forma_amd.Context(0)
+    yield c
+    c.close()
+
+
+def bits_equal(a, b):
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def both(ctx, comp):
+    o = orc.Oracle()
+    t = comp.tables(o)
+    S.load(o, t); S.load(ctx, t)
+    return o, t
+
+
+SMALL = dict(S.e2e_scenes())
+
+
+@pytest.fixture(scope="module")
+def mixed():
+    return S.random_mixed()
+
+
+@pytest.mark.parametrize("name", sorted(SMALL))
+def test_e2e_all_stages(ctx, name):
+    o, _ = both(ctx, SMALL[name])
+    lo = o.prepare_lines(64, 64); lg = ctx.prepare_lines(64, 64)
+    for k in LINE_KEYS:
+        assert bits_equal(lo[k], lg[k]), (name, k)
+    so = o.rasterize(); sg = ctx.rasterize_lines(lo)
+    assert np.array_equal(so, sg), name
+    assert np.array_equal(o.sort(), ctx.sort_array(so)), name
+    img_o = o.render(64, 64)
+    img_g = ctx.render(64, 64)
+    assert np.array_equal(ctx.segments(0), o.segments(0)) and np.array_equal(ctx.segments(1), o.segments(1))
+    d = np.abs(img_o.astype(int) - img_g.astype(int))
+    assert d.max() <= 1, (name, d.max(), int((d > 0).sum()))
+    assert d.max() == 0, (name, "not bit-identical", int((d > 0).sum()))
+    # and against the reference's own PNG golden (tolerance of e2e-tests/tests/test_env.rs:278)
+    dg = np.abs(img_g.reshape(64, 64, 4).astype(int) - GOLD[name].astype(int))
+    assert dg.max() <= 8
+
+
+@pytest.mark.parametrize("size", [(512, 384), (500, 301)])
+def test_mixed_scene(ctx, mixed, size):
+    w, h = size
+    o, _ = both(ctx, mixed)
+    lo = o.prepare_lines(w, h); lg = ctx.prepare_lines(w, h)
+    for k in LINE_KEYS:
+        assert bits_equal(lo[k], lg[k]), k
+    img_o = o.render(w, h, clear=(0.2, 0.3, 0.4, 1.0))
+    img_g = ctx.render(w, h, clear=(0.2, 0.3, 0.4, 1.0))
+    assert np.array_equal(ctx.segments(0), o.segments(0))
+    assert np.array_equal(ctx.segments(1), o.segments(1))
+    d = np.abs(img_o.astype(int) - img_g.astype(int))
+    assert d.max() <= 1, (d.max(), int((d > 0).sum()))
+
+
+@pytest.mark.parametrize("channels,clear", [(S.BGRA, (1, 1, 1, 0)), (S.RGB1, (0, 0, 0, 0.5)), (S.BGR0, (0.5, 0.25, 0.125, 1.0))])
+def test_channels_and_clear(ctx, mixed, channels, clear):
+    o, _ = both(ctx, mixed)
+    a = o.render(256, 256, channels=channels, clear=clear)
+    b = ctx.render(256, 256, channels=channels, clear=clear)
+    assert np.abs(a.astype(int) - b.astype(int)).max() <= 1
+
+
+def test_crop(ctx, mixed):
+    o, _ = both(ctx, mixed)
+    crop = (40, 300, 33, 200)
+    base = np.full((384, 512 * 4), 7, np.uint8)
+    a = o.render(512, 384, crop=crop, dst=base.copy())
+    b = ctx.render(512, 384, crop=crop)     # device image is written only inside the crop
+    x0, x1, y0, y1 = (40 // 16) * 16, ((300 + 15) // 16) * 16, (33 // 16) * 16, ((200 + 15) // 16) * 16
+    assert np.array_equal(a[y0:y1, x0 * 4:x1 * 4], b[y0:y1, x0 * 4:x1 * 4])
+    assert (a[:y0] == 7).all() and (a[y1:] == 7).all()
+
+
+def test_random_cubics_1080p(ctx):
+    """BASELINE.json configs[1]: 1000 random cubic Beziers, solid fill, 1920x1080."""
+    comp = S.random_cubics(1000, 1920, 1080)
+    o, _ = both(ctx, comp)
+    img_o = o.render(1920, 1080, clear=(1, 1, 1, 1))
+    img_g, t = ctx.render(1920, 1080, clear=(1, 1, 1, 1), timings=True)
+    u_o, u_g = o.segments(0), ctx.segments(0)
+    assert len(u_o) == len(u_g) == t["n_segments"]
+    assert np.array_equal(u_o, u_g)
+    assert np.array_equal(o.segments(1), ctx.segments(1))
+    d = np.abs(img_o.astype(int) - img_g.astype(int))
+    assert d.max() <= 1, (d.max(), int((d > 0).sum()))
+
+
+def test_sort_properties_large(ctx):
+    """Size-independent properties at 10 M keys: non-decreasing keys, stable, permutation."""
+    rng = np.random.default_rng(1)
+    n = 10_000_000
+    v = rng.integers(0, 2 ** 62, n, dtype=np.uint64)
+    v &= np.uint64(~((0x7FF - 0x1FF) << 53) & 0xFFFFFFFFFFFFFFFF)   # keep a few digits constant -> digit skipping
+    s = ctx.sort_array(v)
+    k = s >> np.uint64(20)
+    assert (k[1:] >= k[:-1]).all()
+    ref = v[np.argsort(v >> np.uint64(20), kind="stable")]
+    assert np.array_equal(s, ref)
+
+
+def test_empty_and_degenerate(ctx):
+    o = orc.Oracle()
+    comp = S.Composition()
+    t = comp.tables(o)
+    S.load(o, t); S.load(ctx, t)
+    a = o.render(33, 17, clear=(1, 0, 0, 1)); b = ctx.render(33, 17, clear=(1, 0, 0, 1))
+    assert np.array_equal(a, b)
+    # a single horizontal line (culled) and a shape completely outside the canvas
+    comp.get_mut_or_insert_default(3).insert(S.P().move_to(0, 5).line_to(10, 5).build())
+    comp.get_mut_or_insert_default(5).insert(S.custom_square(-50, -50, -20, -20)).set_props(S.solid((0, 1, 0, 1)))
+    comp.get_mut_or_insert_default(6).insert(S.custom_square(-50, 3, 1000, 9)).set_props(S.solid((0, 0, 1, 0.5)))
+    t = comp.tables(o)
+    S.load(o, t); S.load(ctx, t)
+    a = o.render(33, 17, clear=(1, 0, 0, 1)); b = ctx.render(33, 17, clear=(1, 0, 0, 1))
+    assert np.array_equal(ctx.segments(1), o.segments(1))
+    assert np.array_equal(a, b)
