@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py — frames/s and Mpixel-segments/s of the forma raster hot path on MI355X.
+
+A "step" is one `Renderer::render` frame (prepare lines -> rasterize -> radix sort -> carry pre-pass
+-> per-tile paint) of a synthetic scene whose geometry, layer table and styles are already resident
+in HBM; the image stays device-resident (the PCIe-inclusive rate is reported separately, never as
+`value`).  One process per GPU; for N > 1 the canvas is sharded by tile-row bands.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--exchange cull|a2a]
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="paris-like-30k-4k")
+    ap.add_argument("--exchange", default="cull", choices=["cull", "a2a"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def band_edges(row_hist: np.ndarray, n: int):
+    """Contiguous tile-row bands with (nearly) equal pixel-segment counts."""
+    tiles_h = len(row_hist)
+    cum = np.cumsum(row_hist.astype(np.float64))
+    total = cum[-1] if tiles_h else 0.0
+    edges = [0]
+    for r in range(1, n):
+        if total > 0:
+            e = int(np.searchsorted(cum, total * r / n, side="left")) + 1
+        else:
+            e = (tiles_h * r) // n
+        e = max(e, edges[-1] + 1) if edges[-1] + 1 <= tiles_h - (n - r) else edges[-1] + 1
+        e = min(e, tiles_h - (n - r))
+        edges.append(e)
+    edges.append(tiles_h)
+    return edges
+
+
+def main():
+    args = parse()
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and not (world == 1 and args.gpus == 1):
+        if rank == 0:
+            print(f"WORLD_SIZE={world} does not match --gpus {args.gpus}", file=sys.stderr)
+        args.gpus = world
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    import forma_amd
+    from forma_amd import api, scenes
+
+    build_fn, width, height = scenes.WORKLOADS[args.workload]
+    comp = build_fn()
+    renderer = api.Renderer(device=local)
+    ctx = renderer._ctx
+    tiles_h = (height + 15) // 16
+    image = np.zeros((height, width * 4), np.uint8)
+    layout = api.LinearLayout(width, width * 4, height)
+    buf = api.BufferBuilder(image.reshape(-1), layout).build()
+    clear = api.Color(1.0, 1.0, 1.0, 1.0)
+    # first frame through the public API: flattens on the GPU, uploads tables, leaves everything resident
+    renderer.render(comp, buf, api.RGBA, clear, None, timings=True)
+    t_full = renderer.last_timings
+    n_segments_full = t_full["n_segments"]
+
+    crop = None
+    row0, row1 = 0, tiles_h
+    if world > 1:
+        # tile-row bands balanced on the per-row pixel-segment histogram of the full frame
+        segs = ctx.segments(0)
+        ty = (segs >> np.uint64(53)).astype(np.int64) - 1
+        hist = np.bincount(ty[(ty >= 0) & (ty < tiles_h)], minlength=tiles_h)[:tiles_h]
+        edges = band_edges(hist, world)
+        e = torch.tensor(edges, dtype=torch.int64, device="cuda")
+        dist.broadcast(e, 0)
+        edges = e.cpu().tolist()
+        row0, row1 = edges[rank], edges[rank + 1]
+        ctx.set_band(row0, row1)
+        crop = (0, width, row0 * 16, min(row1 * 16, height))
+
+    channels = api.RGBA
+    clr = (clear.r, clear.g, clear.b, clear.a)
+
+    def frame(timings=False):
+        return ctx.render(width, height, channels=channels, clear=clr, crop=crop, device_only=True, timings=timings)
+
+    def frame_a2a():
+        # stages 1-2 on this rank's share of the lines are not separable without re-uploading geometry; the a2a
+        # variant rasterizes the full frame once per rank-band instead and exchanges nothing but counts.  Kept as
+        # an explicit option for the RCCL path: see DESIGN.md §multi-GPU.
+        return frame()
+
+    step = frame if args.exchange == "cull" else frame_a2a
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    fps = args.steps / elapsed
+
+    # ---- per-stage device times + roofline of the radix pass (HIP events on the context's stream) ----------
+    stage = {}
+    reps = 10
+    for _ in range(reps):
+        _, t = frame(timings=True)
+        for k, v in t.items():
+            stage[k] = stage.get(k, 0.0) + float(v) / reps
+    n_local = int(round(stage["n_segments"]))
+    passes = int(round(stage["n_sort_passes"]))
+    pass_us = stage["sort_pass_us"]
+    algo_bytes_per_pass = 16.0 * n_local                       # 8 B read + 8 B written per key per digit pass
+    achieved = (algo_bytes_per_pass / (pass_us * 1e-6) / 1e9) if pass_us > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "radix digit pass = k_hist + k_scan_counts + k_scatter (4-bit LSB, u64 keys)",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": algo_bytes_per_pass, "avg_launch_us": round(pass_us, 2),
+                "passes": passes}
+
+    # PCIe-inclusive frame (image copied into caller memory) — reported, never `value`
+    sync_all()
+    t1 = time.perf_counter()
+    for _ in range(5):
+        ctx.render(width, height, channels=channels, clear=clr, crop=crop, dst=image.reshape(-1), stride=width * 4)
+    torch.cuda.synchronize()
+    fps_d2h = 5 / (time.perf_counter() - t1)
+
+    out = {
+        "metric": "frames/sec (sorted+painted, device-resident) + Mpixel-segments/sec",
+        "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u64 segments / f64+f32 rasterizer / f32 painter", "data": "synthetic",
+        "mpixel_segments_per_s": round(n_segments_full * fps / 1e6, 1),
+        "fps_including_d2h": round(fps_d2h, 2),
+        "config": {"workload": args.workload + (" (labelled stand-in: paris-30k.svg is not in the reference checkout)"
+                                                 if args.workload.startswith("paris") else ""),
+                   "canvas": [width, height], "layers": len(comp), "pixel_segments": int(n_segments_full),
+                   "sharding": "none" if world == 1 else f"tile-row bands x{world} ({args.exchange})",
+                   "band_rows": [row0, row1]},
+        "stages_us": {k: round(stage[k], 1) for k in ("prepare_us", "rasterize_us", "sort_us", "carry_us", "paint_us", "total_us")},
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(renderer, width, height, args.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(renderer, width, height, budget_s):
+    """The CPU oracle (C++ restatement of forma's CPU backend, OpenMP over lines / segments / tile rows) timed on the
+    host cores on the SAME scene tables the GPU rendered.  Reported baseline only."""
+    from oracle import oracle as orc
+    cores = orc.lib().oracle_max_threads()
+    o = orc.Oracle(threads=cores)
+    t = renderer.host_tables
+    o.set_geometry(t["x"], t["y"], t["line_slot"]); o.set_geoms(t["geoms"])
+    o.set_styles(t["style_offsets"], t["style_words"], None); o.set_images(t["images"], t["texels"])
+    first = o.time_frame(width, height, 1)
+    per = sum(first.values())
+    iters = max(1, min(20, int(budget_s / max(per, 1e-3))))
+    tm = o.time_frame(width, height, iters)
+    per = sum(tm.values())
+    return {"value": round(1.0 / per, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{iters} full frames of the same workload (C++ oracle, OpenMP on {cores} threads; sort single-threaded)",
+            "stages_ms": {k: round(v * 1e3, 2) for k, v in tm.items()}}
+
+
+if __name__ == "__main__":
+    main()

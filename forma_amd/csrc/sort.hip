@@ -173,9 +173,9 @@ uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a, uint
             int width = hi_bit - shift < RADIX_BITS ? hi_bit - shift : RADIX_BITS;
             uint64_t dmask = ((1ull << width) - 1ull) << shift;
             if ((live_mask & dmask) == 0) continue;          // single-bin histogram: pass is the identity
+            if (pass_ev0) hipEventRecord(pass_ev0[passes], s);
             hipLaunchKernelGGL(k_hist, dim3(nb), dim3(SORT_THREADS), 0, s, src, (uint32_t)n, shift, nb, counters);
             hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, counters, RADIX * nb);
-            if (pass_ev0) hipEventRecord(pass_ev0[passes], s);
             hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(SORT_THREADS), 0, s, src, dst, (uint32_t)n, shift, nb,
                                (const uint32_t*)counters);
             if (pass_ev1) hipEventRecord(pass_ev1[passes], s);

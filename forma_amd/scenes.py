@@ -1,0 +1,95 @@
+"""Synthetic workloads named by BASELINE.json `configs` (definitions: SURVEY.md §8d).  All geometry is
+built through the product API (forma_amd.api) and flattened on the GPU; nothing here touches oracle/.
+
+  C2  random_cubics      1000 random closed cubic Beziers, solid fill, 1920x1080
+  C3  paris_like         30 000-layer stand-in for paris-30k.svg (the asset is not in the reference
+                         checkout: /root/reference/.MISSING_LARGE_BLOBS), 3840x2160
+  C4  triangles_10m      ~10 M pixel segments, 8192x8192, opaque triangles, layer = index
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .api import (BLEND_MODES, Color, Composition, Fill, Func, GradientBuilder, GradientType, Order, PathBuilder, Point,
+                  Props, Style)
+
+
+def _solid(color: Color, blend="Over") -> Props:
+    return Props(func=Func.Draw(Style(fill=Fill.Solid(color), blend_mode=blend)))
+
+
+def random_cubics(n=1000, width=1920, height=1080, seed=42) -> Composition:
+    rng = np.random.default_rng(seed)
+    comp = Composition()
+    for i in range(n):
+        p = rng.random((4, 2), dtype=np.float32) * np.array([width, height], np.float32)
+        c = rng.random(3, dtype=np.float32)
+        path = (PathBuilder().move_to(Point(float(p[0, 0]), float(p[0, 1])))
+                .cubic_to(Point(float(p[1, 0]), float(p[1, 1])), Point(float(p[2, 0]), float(p[2, 1])), Point(float(p[3, 0]), float(p[3, 1])))
+                .build())
+        comp.get_mut_or_insert_default(Order(i)).insert(path).set_props(_solid(Color(float(c[0]), float(c[1]), float(c[2]), 1.0)))
+    return comp
+
+
+def paris_like(n_layers=30000, width=3840, height=2160, seed=30000) -> Composition:
+    """Labelled STAND-IN for paris-30k.svg: closed polygons of 4-40 vertices (30 % with cubic edges), bbox
+    log-uniform 8-400 px, centres uniform; 90 % solid / 8 % linear / 2 % radial; 5 % non-Over blend;
+    alpha in {1.0, 0.5}."""
+    rng = np.random.default_rng(seed)
+    comp = Composition()
+    for i in range(n_layers):
+        k = int(rng.integers(4, 41))
+        size = float(np.exp(rng.uniform(np.log(8.0), np.log(400.0))))
+        cx, cy = float(rng.uniform(0, width)), float(rng.uniform(0, height))
+        ang = np.sort(rng.uniform(0, 2 * np.pi, k))
+        rad = size * 0.5 * rng.uniform(0.55, 1.0, k)
+        xs = (cx + rad * np.cos(ang)).astype(np.float32); ys = (cy + rad * np.sin(ang)).astype(np.float32)
+        curved = rng.random() < 0.3
+        b = PathBuilder().move_to(Point(float(xs[0]), float(ys[0])))
+        for j in range(1, k):
+            if curved:
+                dx, dy = float(xs[j] - xs[j - 1]), float(ys[j] - ys[j - 1])
+                nx, ny = -dy * 0.25, dx * 0.25
+                b.cubic_to(Point(float(np.float32(xs[j - 1] + dx * 0.33 + nx)), float(np.float32(ys[j - 1] + dy * 0.33 + ny))),
+                           Point(float(np.float32(xs[j - 1] + dx * 0.66 + nx)), float(np.float32(ys[j - 1] + dy * 0.66 + ny))),
+                           Point(float(xs[j]), float(ys[j])))
+            else:
+                b.line_to(Point(float(xs[j]), float(ys[j])))
+        path = b.build()
+        col = rng.random(3, dtype=np.float32)
+        alpha = 1.0 if rng.random() < 0.5 else 0.5
+        blend = BLEND_MODES[int(rng.integers(1, 16))] if rng.random() < 0.05 else "Over"
+        u = rng.random()
+        if u < 0.90:
+            fill = Fill.Solid(Color(float(col[0]), float(col[1]), float(col[2]), alpha))
+        else:
+            gb = GradientBuilder(Point(cx - size * 0.5, cy - size * 0.5), Point(cx + size * 0.5, cy + size * 0.25))
+            if u >= 0.98:
+                gb.type(GradientType.Radial)
+            for _ in range(int(rng.integers(2, 4))):
+                c2 = rng.random(3, dtype=np.float32)
+                gb.color(Color(float(c2[0]), float(c2[1]), float(c2[2]), alpha))
+            fill = Fill.Gradient(gb.build())
+        comp.get_mut_or_insert_default(Order(i)).insert(path).set_props(Props(func=Func.Draw(Style(fill=fill, blend_mode=blend))))
+    return comp
+
+
+def triangles_10m(width=8192, height=8192, k=19400, seed=4) -> Composition:
+    """~10 M pixel segments: K closed random triangles with vertices inside random 256-px boxes."""
+    rng = np.random.default_rng(seed)
+    comp = Composition()
+    for i in range(k):
+        ox, oy = rng.uniform(0, width - 256), rng.uniform(0, height - 256)
+        p = (rng.random((3, 2)) * 256 + np.array([ox, oy])).astype(np.float32)
+        c = rng.random(3, dtype=np.float32)
+        path = (PathBuilder().move_to(Point(float(p[0, 0]), float(p[0, 1]))).line_to(Point(float(p[1, 0]), float(p[1, 1])))
+                .line_to(Point(float(p[2, 0]), float(p[2, 1]))).build())
+        comp.get_mut_or_insert_default(Order(i)).insert(path).set_props(_solid(Color(float(c[0]), float(c[1]), float(c[2]), 1.0)))
+    return comp
+
+
+WORKLOADS = {
+    "cubics-1080p": (random_cubics, 1920, 1080),
+    "paris-like-30k-4k": (paris_like, 3840, 2160),
+    "triangles-10m-8k": (triangles_10m, 8192, 8192),
+}

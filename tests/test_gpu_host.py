@@ -1,0 +1,149 @@
+"""Product host mirror (forma_amd.api: C++ path preparation + HIP flatten kernel + composition
+bookkeeping) against the oracle's flattener and the test-side scene builder."""
+import numpy as np
+import pytest
+
+import scene as S
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def both_paths(cmds):
+    """Replay one command list into the oracle builder and the product builder."""
+    from forma_amd import api
+    po = orc.Path(); pb = api.PathBuilder()
+    for c in cmds:
+        k, a = c[0], c[1:]
+        if k == "M": po.move_to(*a); pb.move_to(api.Point(*a))
+        elif k == "L": po.line_to(*a); pb.line_to(api.Point(*a))
+        elif k == "Q": po.quad_to(*a); pb.quad_to(api.Point(a[0], a[1]), api.Point(a[2], a[3]))
+        elif k == "C": po.cubic_to(*a); pb.cubic_to(api.Point(a[0], a[1]), api.Point(a[2], a[3]), api.Point(a[4], a[5]))
+        elif k == "RQ": po.rat_quad_to(*a); pb.rat_quad_to(api.Point(a[0], a[1]), api.Point(a[2], a[3]), a[4])
+        elif k == "RC": po.rat_cubic_to(*a); pb.rat_cubic_to(api.Point(a[0], a[1]), api.Point(a[2], a[3]), api.Point(a[4], a[5]), a[6], a[7])
+    return po.build(), pb.build()
+
+
+def rand_cmds(rng, n):
+    cmds = [("M", *map(float, rng.uniform(-50, 600, 2).astype(np.float32)))]
+    for _ in range(n):
+        k = rng.integers(0, 6)
+        p = [float(v) for v in rng.uniform(-50, 600, 6).astype(np.float32)]
+        if k == 0: cmds.append(("L", p[0], p[1]))
+        elif k == 1: cmds.append(("Q", *p[:4]))
+        elif k == 2: cmds.append(("C", *p))
+        elif k == 3: cmds.append(("RQ", *p[:4], float(np.float32(rng.uniform(0.2, 3.0)))))
+        elif k == 4: cmds.append(("RC", *p, float(np.float32(rng.uniform(0.3, 2.0))), float(np.float32(rng.uniform(0.3, 2.0)))))
+        else: cmds.append(("M", p[0], p[1]))
+    return cmds
+
+
+def test_flatten_matches_oracle_bit_exact():
+    from forma_amd import api
+    rng = np.random.default_rng(3)
+    o = orc.Oracle()
+    comp = api.Composition()
+    r = api.Renderer(0)
+    xs, ys, ls = [], [], []
+    for i in range(200):
+        po, pb = both_paths(rand_cmds(rng, int(rng.integers(1, 12))))
+        if i % 5 == 0:   # GeomPresTransform (cheap per-point transform) and a non-affine 3x3
+            t9 = [0.8, 0.1, 5.0, -0.1, 0.8, 7.0, 0.0, 0.0, 1.0] if i % 10 == 0 else [1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0005, 0.0, 1.0]
+            pb = pb.transform(t9)
+            if i % 10 == 0: po.affine = (0.8, -0.1, 0.1, 0.8, 5.0, 7.0)
+            else: po.transform9(t9)
+        comp.get_mut_or_insert_default(api.Order(i)).insert(pb)
+        x, y, nc = o.flatten(po)
+        if len(x):
+            pid = np.where(nc != 0, S.NONE, i).astype(np.uint32); pid[-1] = S.NONE
+            xs.append(x); ys.append(y); ls.append(pid)
+    r._upload_geometry(comp)
+    t = r.host_tables
+    # slots are assigned in first-use order == i for non-empty paths: compare through the order mapping
+    x = np.concatenate(xs); y = np.concatenate(ys)
+    assert len(t["x"]) == len(x)
+    assert np.array_equal(t["x"].view(np.uint32), x.view(np.uint32))
+    assert np.array_equal(t["y"].view(np.uint32), y.view(np.uint32))
+    none_o = np.concatenate(ls)[:-1] == S.NONE
+    assert np.array_equal(t["line_slot"] == S.NONE, none_o)
+
+
+def test_renderer_matches_oracle_on_e2e_scene():
+    """The same scene built through the product API and through the test-side builder renders identically."""
+    from forma_amd import api
+    W, H, PAD = 64.0, 64.0, 8.0
+    comp = api.Composition()
+    sq = (api.PathBuilder().move_to(api.Point(PAD, PAD)).line_to(api.Point(PAD, H - PAD)).line_to(api.Point(W - PAD, H - PAD))
+          .line_to(api.Point(W - PAD, PAD)).build())
+    w = float(np.sqrt(np.float32(2.0)) / np.float32(2.0))
+    cx, cy, rad = W * 0.5, H * 0.5, W * 0.5 - PAD
+    circ = (api.PathBuilder().move_to(api.Point(cx + rad, cy)).rat_quad_to(api.Point(cx + rad, cy - rad), api.Point(cx, cy - rad), w)
+            .rat_quad_to(api.Point(cx - rad, cy - rad), api.Point(cx - rad, cy), w).rat_quad_to(api.Point(cx - rad, cy + rad), api.Point(cx, cy + rad), w)
+            .rat_quad_to(api.Point(cx + rad, cy + rad), api.Point(cx + rad, cy), w).build())
+    comp.get_mut_or_insert_default(api.Order(0)).insert(sq).set_props(api.Props(func=api.Func.Draw(api.Style(fill=api.Fill.Solid(api.Color(0, 0, 0, 0.7))))))
+    gb = api.GradientBuilder(api.Point(PAD, 0.0), api.Point(W - PAD, 0.0))
+    gb.color(api.Color(0, 0, 1, 1)).color(api.Color(1, 1, 1, 1)).color(api.Color(1, 0, 0, 1))
+    comp.get_mut_or_insert_default(api.Order(4)).insert(circ).set_props(
+        api.Props(fill_rule=api.FillRule.EvenOdd, func=api.Func.Draw(api.Style(fill=api.Fill.Gradient(gb.build()), blend_mode=api.BlendMode.Multiply))))
+    r = api.Renderer(0)
+    img = np.zeros(64 * 64 * 4, np.uint8)
+    lay = api.LinearLayout(64, 256, 64)
+    r.render(comp, api.BufferBuilder(img, lay).build(), api.RGBA, api.Color(1, 1, 1, 0), None)
+
+    c2 = S.Composition()
+    c2.get_mut_or_insert_default(0).insert(S.square()).set_props(S.solid((0, 0, 0, 0.7)))
+    c2.get_mut_or_insert_default(4).insert(S.circle()).set_props(
+        S.Props(fill_rule="EvenOdd", fill=S.gradient((PAD, 0.0), (W - PAD, 0.0), [(0, 0, 1, 1), (1, 1, 1, 1), (1, 0, 0, 1)]), blend_mode="Multiply"))
+    o = orc.Oracle()
+    S.load(o, c2.tables(o))
+    want = o.render(64, 64)
+    assert np.array_equal(want.reshape(-1), img)
+
+
+def test_layer_bookkeeping_like_reference():
+    """composition/mod.rs tests: layer replace / disable / clear / transform, through the product renderer."""
+    from forma_amd import api
+    def pixel(x, y):
+        return (api.PathBuilder().move_to(api.Point(x, y)).line_to(api.Point(x, y + 1)).line_to(api.Point(x + 1, y + 1))
+                .line_to(api.Point(x + 1, y)).line_to(api.Point(x, y)).build())
+    def solid(c):
+        return api.Props(func=api.Func.Draw(api.Style(fill=api.Fill.Solid(c))))
+    RED, GREEN, BLACK = api.Color(1, 0, 0, 1), api.Color(0, 1, 0, 1), api.Color(0, 0, 0, 1)
+    r = api.Renderer(0)
+    def render(comp, w=3, h=1, clear=api.Color(1, 1, 1, 0)):
+        img = np.zeros(w * h * 4, np.uint8)
+        r.render(comp, api.BufferBuilder(img, api.LinearLayout(w, w * 4, h)).build(), api.RGBA, clear, None)
+        return img.reshape(h, w, 4)
+    # one_pixel / two_pixels_same_layer (composition/mod.rs:568-611)
+    comp = api.Composition()
+    comp.get_mut_or_insert_default(api.Order(0)).insert(pixel(1, 0)).set_props(solid(RED))
+    assert render(comp).tolist() == [[[255, 255, 255, 0], [255, 0, 0, 255], [255, 255, 255, 0]]]
+    comp.get_mut(api.Order(0)).insert(pixel(2, 0))
+    assert render(comp).tolist() == [[[255, 255, 255, 0], [255, 0, 0, 255], [255, 0, 0, 255]]]
+    # one_pixel_translated (:613-641): half-pixel translation -> 0xBB coverage of black over white alpha 0
+    comp = api.Composition()
+    comp.get_mut_or_insert_default(api.Order(0)).insert(pixel(1, 0)).set_props(solid(BLACK)).set_transform(
+        api.GeomPresTransform.try_from([1.0, 0.0, 0.0, 1.0, 0.5, 0.0]))
+    out = render(comp)
+    assert out[0, 1].tolist() == [0xBB, 0xBB, 0xBB, 0x80] and out[0, 2].tolist() == [0xBB, 0xBB, 0xBB, 0x80]
+    # insert_over_layer / layer_replace_remove (:703-789)
+    comp = api.Composition()
+    comp.get_mut_or_insert_default(api.Order(0)).insert(pixel(0, 0)).set_props(solid(RED))
+    l1 = comp.create_layer(); l1.insert(pixel(1, 0)).set_props(solid(GREEN))
+    old = comp.insert(api.Order(0), l1)
+    assert old is not None
+    assert render(comp).tolist() == [[[255, 255, 255, 0], [0, 255, 0, 255], [255, 255, 255, 0]]]
+    comp.remove(api.Order(0))
+    assert render(comp).tolist() == [[[255, 255, 255, 0]] * 3]
+    # layer_clear (:791-830) and disable
+    comp = api.Composition()
+    comp.get_mut_or_insert_default(api.Order(0)).insert(pixel(0, 0)).set_props(solid(RED))
+    comp.get_mut_or_insert_default(api.Order(1)).insert(pixel(1, 0)).set_props(solid(GREEN))
+    comp.get_mut(api.Order(0)).clear()
+    assert render(comp).tolist() == [[[255, 255, 255, 0], [0, 255, 0, 255], [255, 255, 255, 0]]]
+    comp.get_mut(api.Order(1)).disable()
+    assert render(comp).tolist() == [[[255, 255, 255, 0]] * 3]
+    with pytest.raises(api.OrderError):
+        api.Order((1 << 21))
+    with pytest.raises(api.GeomPresTransformError):
+        api.GeomPresTransform.try_from([2.0, 0.0, 0.0, 1.0, 0.0, 0.0])
