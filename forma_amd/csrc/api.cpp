@@ -3,6 +3,7 @@
 // oracle/.  Errors never unwind across the ABI: every entry point returns a FORMA_E_* code.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -42,14 +43,17 @@ struct forma_hip_ctx {
     size_t n_points = 0, n_geoms = 0, n_orders = 0, n_words = 0, n_images = 0;
     bool scene_has_clips = false;
     // lines
-    DevBuf l_order, l_x0, l_y0, l_dx, l_dy, l_a, l_b, l_c, l_d, l_len, scan_tmp;
-    size_t n_lines = 0;
+    DevBuf l_order, l_x0, l_y0, l_dx, l_dy, l_a, l_b, l_c, l_d, l_len, scan_tmp;   // parity entry points only
+    DevBuf cl_idx, cl_start, block_first, prep_scratch;                              // frame path: compacted line table
+    size_t n_lines = 0, n_compact = 0;
     // segments
     DevBuf seg_u, seg_a, seg_b, sort_counters;
     uint64_t* sorted = nullptr;
     size_t n_seg = 0;
     bool have_unsorted = false;
     uint64_t live44 = 0xFFFFFFFFFFFull;     // varying bits of (v >> 20)
+    bool layer_sorted = false;              // rasterizer stream is non-decreasing in layer
+    int digit_bits = 8;                     // radix digit width: 8 (default) or 4 (FORMA_HIP_DIGIT_BITS)
     // paint
     DevBuf info, head_counts, run_start, records, run_cov, rk_u, rk_a, rk_b, tile_count, tile_fill, entries, image;
     uint32_t img_w = 0, img_h = 0;
@@ -100,60 +104,92 @@ int check_canvas(forma_hip_ctx* ctx, uint32_t width, uint32_t height) {
     return FORMA_OK;
 }
 
-// stages 1-2 on the uploaded geometry: prepare_lines + inclusive scan + rasterize -> seg_u
-int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, bool timing) {
-    const size_t n_lines = ctx->n_points ? ctx->n_points - 1 : 0;
-    ctx->n_lines = n_lines;
-    ctx->n_seg = 0; ctx->have_unsorted = true; ctx->live44 = 0;
-    int rc = reset_info(ctx);
-    if (rc) return rc;
-    if (n_lines == 0) return FORMA_OK;
-    DevBuf* lb[] = {&ctx->l_order, &ctx->l_x0, &ctx->l_y0, &ctx->l_dx, &ctx->l_dy, &ctx->l_a, &ctx->l_b, &ctx->l_c, &ctx->l_d, &ctx->l_len};
-    for (DevBuf* b : lb) HIPCHECK(b->ensure(n_lines * 4));
-    HIPCHECK(ctx->scan_tmp.ensure(scan_tmp_words(std::max<size_t>(n_lines, 1 << 16)) * 4));
-    float band_lo = -3.0e38f, band_hi = 3.0e38f;
-    if (ctx->band_row1 > 0) { band_lo = (float)(ctx->band_row0 * 16u); band_hi = (float)(ctx->band_row1 * 16u); }
+// prepare + scan + compact -> (n_segments, n_compact) on the host, block_first valid for N
+int run_line_table(forma_hip_ctx* ctx, const LineSource& src, size_t n_lines, bool timing) {
+    HIPCHECK(ctx->cl_idx.ensure(n_lines * 4));
+    HIPCHECK(ctx->cl_start.ensure(n_lines * 4));
+    HIPCHECK(ctx->prep_scratch.ensure(prepare_scratch_words(n_lines) * 4));
+    HIPCHECK(ctx->block_first.ensure(4096));
+    const uint32_t bf_cap = (uint32_t)std::min<size_t>(ctx->block_first.cap / 4, 0xFFFFFFFFu);
     stage_begin(ctx, ST_PREPARE, timing);
-    launch_prepare_lines(ctx->stream, ctx->x.as<float>(), ctx->y.as<float>(), ctx->line_slot.as<uint32_t>(), (uint32_t)n_lines,
-                         ctx->geoms.as<forma_geom_t>(), (uint32_t)ctx->n_geoms, (float)width, (float)height, band_lo, band_hi,
-                         ctx->l_order.as<uint32_t>(), ctx->l_x0.as<float>(), ctx->l_y0.as<float>(), ctx->l_dx.as<float>(),
-                         ctx->l_dy.as<float>(), ctx->l_a.as<float>(), ctx->l_b.as<float>(), ctx->l_c.as<float>(),
-                         ctx->l_d.as<float>(), ctx->l_len.as<uint32_t>());
-    launch_inclusive_scan_u32(ctx->stream, ctx->l_len.as<uint32_t>(), n_lines, ctx->scan_tmp.as<uint32_t>(),
-                              &ctx->info.as<FrameInfo>()->n_segments);
+    launch_prepare_compact(ctx->stream, src, (uint32_t)n_lines, ctx->cl_idx.as<uint32_t>(), ctx->cl_start.as<uint32_t>(),
+                           ctx->block_first.as<uint32_t>(), bf_cap, ctx->prep_scratch.as<uint32_t>(), ctx->info.as<FrameInfo>());
     stage_end(ctx, ST_PREPARE, timing);
     HIPCHECK(hipGetLastError());
-    rc = read_info(ctx);
+    int rc = read_info(ctx);
     if (rc) return rc;
+    if (ctx->h_info->error & 4u) return fail(ctx, FORMA_E_INTERNAL, "look-back spin expired (prepare)");
     const size_t N = ctx->h_info->n_segments;
-    ctx->n_seg = N;
-    if (N == 0) return FORMA_OK;
-    HIPCHECK(ctx->seg_u.ensure(N * 8));
-    stage_begin(ctx, ST_RASTER, timing);
-    launch_rasterize(ctx->stream, (uint32_t)n_lines, (uint32_t)N, ctx->l_order.as<uint32_t>(), ctx->l_x0.as<float>(),
-                     ctx->l_y0.as<float>(), ctx->l_dx.as<float>(), ctx->l_dy.as<float>(), ctx->l_a.as<float>(),
-                     ctx->l_b.as<float>(), ctx->l_c.as<float>(), ctx->l_d.as<float>(), ctx->l_len.as<uint32_t>(),
-                     ctx->seg_u.as<uint64_t>(), ctx->info.as<FrameInfo>(), (int)ctx->band_row0, (int)ctx->band_row1);
-    stage_end(ctx, ST_RASTER, timing);
-    HIPCHECK(hipGetLastError());
-    rc = read_info(ctx);
+    ctx->n_seg = N; ctx->n_compact = ctx->h_info->n_compact;
+    const size_t need = (N + RAS_TILE - 1) / RAS_TILE + 1;
+    if (need > bf_cap) {                      // first frame at this size: grow, rebuild the block table
+        HIPCHECK(ctx->block_first.ensure(need * 4 * 2));
+        launch_block_first(ctx->stream, ctx->cl_start.as<uint32_t>(), (uint32_t)ctx->n_compact, (uint32_t)N,
+                           ctx->block_first.as<uint32_t>());
+    }
+    return FORMA_OK;
+}
+
+LineSource geometry_source(forma_hip_ctx* ctx, uint32_t width, uint32_t height) {
+    LineSource S;
+    memset(&S, 0, sizeof S);
+    S.x = ctx->x.as<float>(); S.y = ctx->y.as<float>(); S.line_slot = ctx->line_slot.as<uint32_t>();
+    S.geoms = ctx->geoms.as<forma_geom_t>(); S.n_geoms = (uint32_t)ctx->n_geoms;
+    S.width = (float)width; S.height = (float)height;
+    S.band_lo = -3.0e38f; S.band_hi = 3.0e38f;
+    if (ctx->band_row1 > 0) { S.band_lo = (float)(ctx->band_row0 * 16u); S.band_hi = (float)(ctx->band_row1 * 16u); }
+    return S;
+}
+
+int finish_rasterize(forma_hip_ctx* ctx) {
+    int rc = read_info(ctx);
     if (rc) return rc;
     uint64_t k_or = (uint64_t)ctx->h_info->key_or | ((uint64_t)ctx->h_info->key_or_hi << 32);
     uint64_t k_and = (uint64_t)ctx->h_info->key_and | ((uint64_t)ctx->h_info->key_and_hi << 32);
     ctx->live44 = (k_or ^ k_and) & 0xFFFFFFFFFFFull;
+    ctx->layer_sorted = ctx->h_info->layer_unsorted == 0;
     return FORMA_OK;
 }
 
+// stages 1-2 on the uploaded geometry: line table + rasterize -> seg_u
+int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, bool timing) {
+    const size_t n_lines = ctx->n_points ? ctx->n_points - 1 : 0;
+    ctx->n_lines = n_lines;
+    ctx->n_seg = 0; ctx->n_compact = 0; ctx->have_unsorted = true; ctx->live44 = 0; ctx->layer_sorted = true;
+    int rc = reset_info(ctx);
+    if (rc) return rc;
+    if (n_lines == 0) return FORMA_OK;
+    const LineSource S = geometry_source(ctx, width, height);
+    if ((rc = run_line_table(ctx, S, n_lines, timing))) return rc;
+    const size_t N = ctx->n_seg;
+    if (N == 0) return FORMA_OK;
+    if (N >= (1ull << 30)) return fail(ctx, FORMA_E_CAPACITY, "more than 2^30-1 pixel segments on one device");
+    HIPCHECK(ctx->seg_u.ensure(N * 8));
+    stage_begin(ctx, ST_RASTER, timing);
+    launch_rasterize(ctx->stream, S, (uint32_t)ctx->n_compact, (uint32_t)N, ctx->cl_idx.as<uint32_t>(),
+                     ctx->cl_start.as<uint32_t>(), ctx->block_first.as<uint32_t>(), ctx->seg_u.as<uint64_t>(),
+                     ctx->info.as<FrameInfo>(), (int)ctx->band_row0, (int)ctx->band_row1);
+    stage_end(ctx, ST_RASTER, timing);
+    HIPCHECK(hipGetLastError());
+    return finish_rasterize(ctx);
+}
+
 // stage 3 on `src` (n segments, device): result pointer in ctx->sorted
-int run_sort(forma_hip_ctx* ctx, const uint64_t* src, size_t n, bool timing) {
+int run_sort(forma_hip_ctx* ctx, const uint64_t* src, size_t n, bool timing, int digit_bits = 0) {
     ctx->n_passes = 0;
+    if (n >= (1ull << 30)) return fail(ctx, FORMA_E_CAPACITY, "more than 2^30-1 pixel segments on one device");
+    if (digit_bits == 0) digit_bits = ctx->digit_bits;
     HIPCHECK(ctx->seg_a.ensure(std::max<size_t>(n, 1) * 8));
     HIPCHECK(ctx->seg_b.ensure(std::max<size_t>(n, 1) * 8));
-    HIPCHECK(ctx->sort_counters.ensure(sort_counter_words(std::max<size_t>(n, 1), 4) * 4));
+    HIPCHECK(ctx->sort_counters.ensure(sort_scratch_words(std::max<size_t>(n, 1)) * 4));
+    uint64_t live = ctx->live44;
+    if (ctx->layer_sorted) live &= ~0x1FFFFFull;     // stream already non-decreasing in layer: stable sort by tile only
+    const SortPlan plan = make_sort_plan(live << 20, 20, 64, digit_bits);
+    ctx->n_passes = plan.n_passes;
     stage_begin(ctx, ST_SORT, timing);
-    ctx->sorted = launch_radix_sort(ctx->stream, src, ctx->seg_a.as<uint64_t>(), ctx->seg_b.as<uint64_t>(), n,
-                                    ctx->live44 << 20, 20, 64, 4, ctx->sort_counters.as<uint32_t>(), nullptr,
-                                    &ctx->n_passes, timing ? ctx->pev0 : nullptr, timing ? ctx->pev1 : nullptr);
+    ctx->sorted = (uint64_t*)launch_radix_sort(ctx->stream, src, ctx->seg_a.as<uint64_t>(), ctx->seg_b.as<uint64_t>(), n, plan,
+                                               digit_bits, ctx->sort_counters.as<uint32_t>(), &ctx->info.as<FrameInfo>()->error,
+                                               timing ? ctx->pev0 : nullptr, timing ? ctx->pev1 : nullptr);
     stage_end(ctx, ST_SORT, timing);
     HIPCHECK(hipGetLastError());
     return FORMA_OK;
@@ -198,15 +234,16 @@ int run_paint(forma_hip_ctx* ctx, size_t n, const PaintArgs& a, bool timing) {
         HIPCHECK(ctx->rk_u.ensure((size_t)J * 8));
         HIPCHECK(ctx->rk_a.ensure((size_t)J * 8));
         HIPCHECK(ctx->rk_b.ensure((size_t)J * 8));
-        HIPCHECK(ctx->sort_counters.ensure(sort_counter_words(J, 4) * 4));
+        HIPCHECK(ctx->sort_counters.ensure(sort_scratch_words(J) * 4));
         launch_run_covers(ctx->stream, ctx->sorted, ctx->run_start.as<uint32_t>(), J, ctx->records.as<TileRecord>(),
                           ctx->run_cov.as<uint4>(), ctx->rk_u.as<uint64_t>(), tiles_w);
         // (tile_y, layer) order: stable radix sort on bits 32..63 = [layer 21 | tile_y+1 11]; live bits come from the
         // rasterizer's varying-bit mask (layer = key bits 0..20, tile_y = key bits 33..43)
         uint64_t live = ((ctx->live44 & 0x1FFFFFull) | ((ctx->live44 >> 33) << 21)) << 32;
-        uint64_t* sorted_keys = launch_radix_sort(ctx->stream, ctx->rk_u.as<uint64_t>(), ctx->rk_a.as<uint64_t>(),
-                                                  ctx->rk_b.as<uint64_t>(), J, live, 32, 64, 4,
-                                                  ctx->sort_counters.as<uint32_t>(), nullptr, nullptr, nullptr, nullptr);
+        const SortPlan rk_plan = make_sort_plan(live, 32, 64, ctx->digit_bits);
+        const uint64_t* sorted_keys = launch_radix_sort(ctx->stream, ctx->rk_u.as<uint64_t>(), ctx->rk_a.as<uint64_t>(),
+                                                        ctx->rk_b.as<uint64_t>(), J, rk_plan, ctx->digit_bits,
+                                                        ctx->sort_counters.as<uint32_t>(), &dinfo->error, nullptr, nullptr);
         launch_carry(ctx->stream, sorted_keys, J, ctx->records.as<TileRecord>(), ctx->run_cov.as<uint4>(),
                      ctx->style_off.as<uint32_t>(), ctx->style_words.as<uint32_t>(), (uint32_t)ctx->n_orders, tiles_w, tiles_h,
                      ctx->tile_count.as<uint32_t>(), dinfo, 0, nullptr, nullptr, nullptr, J);
@@ -321,6 +358,7 @@ int forma_hip_create(forma_hip_ctx** out, int device) {
     forma_hip_ctx* ctx = new (std::nothrow) forma_hip_ctx();
     if (!ctx) return FORMA_E_INTERNAL;
     ctx->device = device;
+    if (const char* e = getenv("FORMA_HIP_DIGIT_BITS")) { if (atoi(e) == 4) ctx->digit_bits = 4; }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx; return FORMA_E_HIP;
     }
@@ -347,7 +385,8 @@ void forma_hip_destroy(forma_hip_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* all[] = {&ctx->x, &ctx->y, &ctx->line_slot, &ctx->geoms, &ctx->style_off, &ctx->style_words, &ctx->unchanged,
                      &ctx->images, &ctx->texels, &ctx->l_order, &ctx->l_x0, &ctx->l_y0, &ctx->l_dx, &ctx->l_dy, &ctx->l_a,
-                     &ctx->l_b, &ctx->l_c, &ctx->l_d, &ctx->l_len, &ctx->scan_tmp, &ctx->seg_u, &ctx->seg_a, &ctx->seg_b,
+                     &ctx->l_b, &ctx->l_c, &ctx->l_d, &ctx->l_len, &ctx->scan_tmp, &ctx->cl_idx, &ctx->cl_start,
+                     &ctx->block_first, &ctx->prep_scratch, &ctx->seg_u, &ctx->seg_a, &ctx->seg_b,
                      &ctx->sort_counters, &ctx->info, &ctx->head_counts, &ctx->run_start, &ctx->records, &ctx->run_cov,
                      &ctx->rk_u, &ctx->rk_a, &ctx->rk_b, &ctx->tile_count, &ctx->tile_fill, &ctx->entries, &ctx->image};
     for (DevBuf* b : all) b->release();
@@ -365,7 +404,7 @@ int forma_hip_set_geometry(forma_hip_ctx* ctx, const float* x, const float* y, c
     if (!ctx) return FORMA_E_ARG;
     if (n_points && (!x || !y)) return fail(ctx, FORMA_E_ARG, "null geometry");
     if (n_points > 1 && !line_slot) return fail(ctx, FORMA_E_ARG, "null line_slot");
-    if (n_points > 0xFFFFFFF0ull) return fail(ctx, FORMA_E_ARG, "too many points");
+    if (n_points >= (1ull << 30)) return fail(ctx, FORMA_E_ARG, "too many points");
     HIPCHECK(hipSetDevice(ctx->device));
     int rc;
     if ((rc = upload(ctx, ctx->x, x, n_points))) return rc;
@@ -524,11 +563,17 @@ int forma_hip_rasterize(forma_hip_ctx* ctx, size_t n_lines, const uint32_t* orde
         HIPCHECK(lb[i]->ensure(n_lines * 4));
         HIPCHECK(hipMemcpyAsync(lb[i]->p, ins[i], n_lines * 4, hipMemcpyHostToDevice, ctx->stream));
     }
+    LineSource S;
+    memset(&S, 0, sizeof S);
+    S.sums = ctx->l_len.as<uint32_t>(); S.orders = ctx->l_order.as<uint32_t>();
+    S.x0 = ctx->l_x0.as<float>(); S.y0 = ctx->l_y0.as<float>(); S.dx = ctx->l_dx.as<float>(); S.dy = ctx->l_dy.as<float>();
+    S.a = ctx->l_a.as<float>(); S.b = ctx->l_b.as<float>(); S.c = ctx->l_c.as<float>(); S.d = ctx->l_d.as<float>();
+    if ((rc = run_line_table(ctx, S, n_lines, false))) return rc;
+    if (ctx->n_seg != N) return fail(ctx, FORMA_E_INTERNAL, "prefix sums disagree");
     HIPCHECK(ctx->seg_u.ensure(N * 8));
-    launch_rasterize(ctx->stream, (uint32_t)n_lines, (uint32_t)N, ctx->l_order.as<uint32_t>(), ctx->l_x0.as<float>(),
-                     ctx->l_y0.as<float>(), ctx->l_dx.as<float>(), ctx->l_dy.as<float>(), ctx->l_a.as<float>(),
-                     ctx->l_b.as<float>(), ctx->l_c.as<float>(), ctx->l_d.as<float>(), ctx->l_len.as<uint32_t>(),
-                     ctx->seg_u.as<uint64_t>(), ctx->info.as<FrameInfo>(), 0, 0);
+    launch_rasterize(ctx->stream, S, (uint32_t)ctx->n_compact, (uint32_t)N, ctx->cl_idx.as<uint32_t>(),
+                     ctx->cl_start.as<uint32_t>(), ctx->block_first.as<uint32_t>(), ctx->seg_u.as<uint64_t>(),
+                     ctx->info.as<FrameInfo>(), 0, 0);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(out_segments, ctx->seg_u.p, N * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHECK(hipStreamSynchronize(ctx->stream));
@@ -543,17 +588,20 @@ static uint64_t host_live44(const uint64_t* v, size_t n) {
 
 int forma_hip_sort(forma_hip_ctx* ctx, uint64_t* segments, size_t n, int digit_bits) {
     if (!ctx || (n && !segments)) return FORMA_E_ARG;
-    if (digit_bits != 0 && digit_bits != 4) return fail(ctx, FORMA_E_ARG, "digit_bits must be 0 or 4");
+    if (digit_bits != 0 && digit_bits != 4 && digit_bits != 8) return fail(ctx, FORMA_E_ARG, "digit_bits must be 0, 4 or 8");
     if (n > 0xFFFFFFF0ull) return fail(ctx, FORMA_E_ARG, "too many segments");   // u32 prefix sums, segment.rs:90-98
     if (n == 0) return FORMA_OK;
     HIPCHECK(hipSetDevice(ctx->device));
     HIPCHECK(ctx->seg_u.ensure(n * 8));
     HIPCHECK(hipMemcpyAsync(ctx->seg_u.p, segments, n * 8, hipMemcpyHostToDevice, ctx->stream));
     ctx->live44 = host_live44(segments, n);
-    int rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), n, false);
+    ctx->layer_sorted = false;
+    int rc = reset_info(ctx);
     if (rc) return rc;
+    if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), n, false, digit_bits))) return rc;
     HIPCHECK(hipMemcpyAsync(segments, ctx->sorted, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    if ((rc = read_info(ctx))) return rc;
+    if (ctx->h_info->error) return fail(ctx, FORMA_E_INTERNAL, "device-side invariant violated (radix look-back)");
     return FORMA_OK;
 }
 

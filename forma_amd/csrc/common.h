@@ -42,8 +42,9 @@ struct FrameInfo {
     uint32_t n_spans;        // carry-only records
     uint32_t n_entries;      // E
     uint32_t layer_unsorted; // != 0 if the rasterizer stream is not non-decreasing in layer
-    uint32_t error;          // device-side invariant violations
-    uint32_t pad[4];
+    uint32_t error;          // device-side invariant violations (1 style, 2 tile depth, 4 look-back spin)
+    uint32_t n_compact;      // lines with at least one pixel segment
+    uint32_t pad[3];
 };
 
 // one painted (tile, layer) pair.  key = (layer << 32) | record index.
@@ -75,18 +76,43 @@ void launch_prepare_lines(hipStream_t s, const float* x, const float* y, const u
 size_t scan_tmp_words(size_t n);
 void launch_inclusive_scan_u32(hipStream_t s, uint32_t* data, size_t n, uint32_t* tmp, uint32_t* d_total);
 void launch_exclusive_scan_u32(hipStream_t s, uint32_t* data, size_t n, uint32_t* tmp, uint32_t* d_total);
-void launch_rasterize(hipStream_t s, uint32_t n_lines, uint32_t n_segments, const uint32_t* orders, const float* x0,
-                      const float* y0, const float* dx, const float* dy, const float* a, const float* b, const float* c,
-                      const float* d, const uint32_t* sums, uint64_t* out, FrameInfo* info, int band_row0,
-                      int band_row1);
+
+// The frame path: line lengths -> single-pass scan -> compacted table of the lines that own pixel segments
+// (cl_idx = line index, cl_start = index of its first pixel segment) + block_first[b] = compacted line that owns
+// pixel segment b * RAS_TILE.  Totals land in info->n_segments / n_compact.
+#define RAS_TILE 2048u
+struct LineSource {               // either the uploaded geometry (sums == nullptr) or caller-supplied line parameters
+    const float* x; const float* y; const uint32_t* line_slot; const forma_geom_t* geoms; uint32_t n_geoms;
+    float width, height, band_lo, band_hi;
+    const uint32_t* sums;         // inclusive sums of caller-supplied lengths (parity entry point), else nullptr
+    const uint32_t* orders; const float *x0, *y0, *dx, *dy, *a, *b, *c, *d;
+};
+size_t prepare_scratch_words(size_t n_lines);
+void launch_prepare_compact(hipStream_t s, const LineSource& src, uint32_t n_lines, uint32_t* cl_idx, uint32_t* cl_start,
+                            uint32_t* block_first, uint32_t bf_cap, uint32_t* scratch, FrameInfo* info);
+// rebuilds block_first when the buffer launch_prepare_compact saw was too small for N
+void launch_block_first(hipStream_t s, const uint32_t* cl_start, uint32_t n_compact, uint32_t n_segments,
+                        uint32_t* block_first);
+void launch_rasterize(hipStream_t s, const LineSource& src, uint32_t n_compact, uint32_t n_segments,
+                      const uint32_t* cl_idx, const uint32_t* cl_start, const uint32_t* block_first, uint64_t* out,
+                      FrameInfo* info, int band_row0, int band_row1);
 void launch_flatten(hipStream_t s, const forma_flatten_tables_t* dev_tables, float* out_x, float* out_y);
 
-// sort.hip — stable LSB radix sort of u64 by bits [lo_bit, hi_bit); returns the buffer holding the result.
-// bufs: `in` is read-only (preserved), a/b are ping-pong buffers.  counters: >= sort_counter_words(n, digit_bits) u32.
-size_t sort_counter_words(size_t n, int digit_bits);
-uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a, uint64_t* b, size_t n, uint64_t live_mask,
-                            int lo_bit, int hi_bit, int digit_bits, uint32_t* counters, uint32_t* scan_tmp,
-                            int* passes_out, hipEvent_t* pass_ev0, hipEvent_t* pass_ev1);
+// sort.hip — stable LSB radix sort of u64 (chained-scan "onesweep" passes over the live key bits).
+#define SORT_MAX_PASSES 12
+struct SortPlan {                 // digit p = (key >> shift[p]) & mask[p]
+    int      n_passes;
+    int      shift[SORT_MAX_PASSES];
+    uint32_t mask[SORT_MAX_PASSES];
+};
+// digits packed greedily over the live bits of [lo_bit, hi_bit); digit_bits = 4 or 8
+SortPlan make_sort_plan(uint64_t live_mask, int lo_bit, int hi_bit, int digit_bits);
+size_t sort_scratch_words(size_t n);
+// `in` is read-only (preserved), a/b are ping-pong buffers; returns the buffer holding the result (== in when the
+// plan is empty).  scratch: >= sort_scratch_words(n) u32.  err: device word, bit 2 set if a look-back spin expired.
+const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a, uint64_t* b, size_t n,
+                                  const SortPlan& plan, int digit_bits, uint32_t* scratch, uint32_t* err,
+                                  hipEvent_t* pass_ev0, hipEvent_t* pass_ev1);
 
 // paint.hip
 void launch_find_bounds(hipStream_t s, const uint64_t* sorted, uint32_t n, uint32_t tiles_h, FrameInfo* info);

@@ -121,8 +121,8 @@ void launch_exclusive_scan_u32(hipStream_t s, uint32_t* data, size_t n, uint32_t
 }
 
 // ------------------------------------------------------------------------------------------------
-// prepare_lines — the map of SegmentBuffer::fill_cpu_view (reference forma/src/segment.rs:298-383),
-// one thread per line.  Layer lookup is a dense table gather instead of two hash lookups.
+// line parameters — the map of SegmentBuffer::fill_cpu_view (reference forma/src/segment.rs:298-383).
+// Layer lookup is a dense table gather instead of two hash lookups.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t f2u_sat(float v) {   // Rust `as u32`: saturating, NaN -> 0
     if (!(v > 0.0f)) return 0u;
@@ -134,6 +134,43 @@ __device__ __forceinline__ uint32_t integers_between(float a, float b) {   // se
     return f2u_sat(ceilf(mx) - floorf(mn) - 1.0f);
 }
 
+struct LineP { uint32_t order, len; float x0, y0, dx, dy, a, b, c, d; };
+
+__device__ __forceinline__ LineP line_params(const float* __restrict__ x, const float* __restrict__ y,
+                                             const uint32_t* __restrict__ line_slot, uint32_t i,
+                                             const forma_geom_t* __restrict__ geoms, uint32_t n_geoms, float width,
+                                             float height, float band_lo, float band_hi) {
+    LineP L;
+    L.order = 0; L.len = 0; L.x0 = L.y0 = L.dx = L.dy = L.a = L.b = L.c = L.d = 0.0f;
+    const uint32_t slot = line_slot[i];
+    if (slot == FORMA_NONE || slot >= n_geoms) return L;
+    const forma_geom_t g = geoms[slot];
+    if (g.order == FORMA_NONE) return L;
+    float p0x = x[i], p0y = y[i], p1x = x[i + 1], p1y = y[i + 1];
+    if (g.flags & FORMA_GEOM_HAS_XF) {                      // transform_point segment.rs:30-39
+        float ax = fmaf(g.xf[0], p0x, fmaf(g.xf[2], p0y, g.xf[4]));
+        float ay = fmaf(g.xf[1], p0x, fmaf(g.xf[3], p0y, g.xf[5]));
+        float bx = fmaf(g.xf[0], p1x, fmaf(g.xf[2], p1y, g.xf[4]));
+        float by = fmaf(g.xf[1], p1x, fmaf(g.xf[3], p1y, g.xf[5]));
+        p0x = ax; p0y = ay; p1x = bx; p1y = by;
+    }
+    // skip_line segment.rs:41-52 (left is NOT culled) + the multi-GPU tile-row band
+    const bool skip = (p0y == p1y) || (p0y >= height && p1y >= height) || (p0x >= width && p1x >= width) ||
+                      (p0y <= 0.0f && p1y <= 0.0f) || (p0y >= band_hi && p1y >= band_hi) ||
+                      (p0y <= band_lo && p1y <= band_lo);
+    if (skip) return L;
+    const float dx = p1x - p0x, dy = p1y - p0y;
+    const float dxr = 1.0f / dx, dyr = 1.0f / dy;
+    L.c = dx != 0.0f ? fmaxf((ceilf(p0x) - p0x) * dxr, (floorf(p0x) - p0x) * dxr) : 0.0f;
+    L.d = dy != 0.0f ? fmaxf((ceilf(p0y) - p0y) * dyr, (floorf(p0y) - p0y) * dyr) : 0.0f;
+    L.order = g.order;
+    L.x0 = p0x * 16.0f; L.y0 = p0y * 16.0f; L.dx = dx * 16.0f; L.dy = dy * 16.0f;
+    L.a = fabsf(dxr); L.b = fabsf(dyr);
+    L.len = integers_between(p0x, p1x) + integers_between(p0y, p1y) + 1u;   // :86-88
+    return L;
+}
+
+// SoA writer: the parity entry point forma_hip_prepare_lines (one thread per line)
 __global__ __launch_bounds__(256) void k_prepare_lines(
     const float* __restrict__ x, const float* __restrict__ y, const uint32_t* __restrict__ line_slot, uint32_t n_lines,
     const forma_geom_t* __restrict__ geoms, uint32_t n_geoms, float width, float height, float band_lo, float band_hi,
@@ -141,38 +178,9 @@ __global__ __launch_bounds__(256) void k_prepare_lines(
     float* __restrict__ ody, float* __restrict__ oa, float* __restrict__ ob, float* __restrict__ oc,
     float* __restrict__ od, uint32_t* __restrict__ lengths) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_lines; i += gridDim.x * blockDim.x) {
-        uint32_t order = 0, len = 0;
-        float lx0 = 0, ly0 = 0, ldx = 0, ldy = 0, la = 0, lb = 0, lc = 0, ld = 0;
-        uint32_t slot = line_slot[i];
-        if (slot != FORMA_NONE && slot < n_geoms) {
-            const forma_geom_t g = geoms[slot];
-            if (g.order != FORMA_NONE) {
-                float p0x = x[i], p0y = y[i], p1x = x[i + 1], p1y = y[i + 1];
-                if (g.flags & FORMA_GEOM_HAS_XF) {                      // transform_point segment.rs:30-39
-                    float ax = fmaf(g.xf[0], p0x, fmaf(g.xf[2], p0y, g.xf[4]));
-                    float ay = fmaf(g.xf[1], p0x, fmaf(g.xf[3], p0y, g.xf[5]));
-                    float bx = fmaf(g.xf[0], p1x, fmaf(g.xf[2], p1y, g.xf[4]));
-                    float by = fmaf(g.xf[1], p1x, fmaf(g.xf[3], p1y, g.xf[5]));
-                    p0x = ax; p0y = ay; p1x = bx; p1y = by;
-                }
-                // skip_line segment.rs:41-52 (left is NOT culled) + the multi-GPU tile-row band
-                bool skip = (p0y == p1y) || (p0y >= height && p1y >= height) || (p0x >= width && p1x >= width) ||
-                            (p0y <= 0.0f && p1y <= 0.0f) || (p0y >= band_hi && p1y >= band_hi) ||
-                            (p0y <= band_lo && p1y <= band_lo);
-                if (!skip) {
-                    float dx = p1x - p0x, dy = p1y - p0y;
-                    float dxr = 1.0f / dx, dyr = 1.0f / dy;
-                    lc = dx != 0.0f ? fmaxf((ceilf(p0x) - p0x) * dxr, (floorf(p0x) - p0x) * dxr) : 0.0f;
-                    ld = dy != 0.0f ? fmaxf((ceilf(p0y) - p0y) * dyr, (floorf(p0y) - p0y) * dyr) : 0.0f;
-                    order = g.order;
-                    lx0 = p0x * 16.0f; ly0 = p0y * 16.0f; ldx = dx * 16.0f; ldy = dy * 16.0f;
-                    la = fabsf(dxr); lb = fabsf(dyr);
-                    len = integers_between(p0x, p1x) + integers_between(p0y, p1y) + 1u;   // :86-88
-                }
-            }
-        }
-        orders[i] = order; ox0[i] = lx0; oy0[i] = ly0; odx[i] = ldx; ody[i] = ldy;
-        oa[i] = la; ob[i] = lb; oc[i] = lc; od[i] = ld; lengths[i] = len;
+        const LineP L = line_params(x, y, line_slot, i, geoms, n_geoms, width, height, band_lo, band_hi);
+        orders[i] = L.order; ox0[i] = L.x0; oy0[i] = L.y0; odx[i] = L.dx; ody[i] = L.dy;
+        oa[i] = L.a; ob[i] = L.b; oc[i] = L.c; od[i] = L.d; lengths[i] = L.len;
     }
 }
 
@@ -188,11 +196,156 @@ void launch_prepare_lines(hipStream_t s, const float* x, const float* y, const u
 }
 
 // ------------------------------------------------------------------------------------------------
-// rasterize — reference forma/src/cpu/rasterizer.rs:32-159, one thread per pixel segment.
-// The flat segment index -> (line, i) map of PrefixScanIter (utils/prefix_scan.rs:30-63) is an
-// upper_bound over the inclusive sums; each block narrows the range once and then searches a
-// window staged in LDS.
+// prepare + scan + compact in ONE launch (frame path).  Replaces the serial `prefix_sum` of the
+// reference (segment.rs:90-98) and feeds the PrefixScanIter work split (utils/prefix_scan.rs:30-63):
+// a chained scan with decoupled look-back over tiles of PC_TILE lines; status word =
+// [flag 2 | line count 30 | segment sum 32] published with one relaxed agent-scope 8-byte store.
 // ------------------------------------------------------------------------------------------------
+#define PC_THREADS 256
+#define PC_IPT     8
+#define PC_TILE    (PC_THREADS * PC_IPT)
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+__device__ __forceinline__ uint64_t ld64_relaxed(const uint64_t* p) {
+    return __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st64_relaxed(uint64_t* p, uint64_t v) {
+    __hip_atomic_store((gu64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void mark_block_first(uint32_t* __restrict__ block_first, uint32_t bf_cap, uint32_t start,
+                                                 uint32_t len, uint32_t c) {
+    // every boundary b * RAS_TILE in [start, start + len) is owned by compacted line c
+    for (uint32_t b = (start + RAS_TILE - 1) / RAS_TILE; (uint64_t)b * RAS_TILE < (uint64_t)start + len; b++)
+        if (b < bf_cap) block_first[b] = c;
+}
+
+__global__ __launch_bounds__(PC_THREADS) void k_prepare_compact(LineSource S, uint32_t n_lines,
+                                                                uint32_t* __restrict__ cl_idx,
+                                                                uint32_t* __restrict__ cl_start,
+                                                                uint32_t* __restrict__ block_first, uint32_t bf_cap,
+                                                                uint64_t* __restrict__ status,
+                                                                uint32_t* __restrict__ ticket,
+                                                                FrameInfo* __restrict__ info) {
+    __shared__ uint32_t s_len[PC_TILE];
+    __shared__ uint32_t s_wsum[PC_THREADS / 64], s_wcnt[PC_THREADS / 64];
+    __shared__ uint32_t s_tile, s_psum, s_pcnt;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t ntiles = (n_lines + PC_TILE - 1) / PC_TILE;
+    while (true) {
+        if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+        __syncthreads();
+        const uint32_t tile = s_tile;
+        if (tile >= ntiles) break;
+        const uint32_t base = tile * PC_TILE;
+#pragma unroll
+        for (int r = 0; r < PC_IPT; r++) {
+            const uint32_t i = base + r * PC_THREADS + tid;
+            uint32_t len = 0;
+            if (i < n_lines) {
+                if (S.sums) len = S.sums[i] - (i ? S.sums[i - 1] : 0u);
+                else len = line_params(S.x, S.y, S.line_slot, i, S.geoms, S.n_geoms, S.width, S.height, S.band_lo, S.band_hi).len;
+            }
+            s_len[r * PC_THREADS + tid] = len;
+        }
+        __syncthreads();
+        uint32_t l[PC_IPT], sum = 0, cnt = 0;
+#pragma unroll
+        for (int q = 0; q < PC_IPT; q++) { l[q] = s_len[tid * PC_IPT + q]; sum += l[q]; cnt += l[q] ? 1u : 0u; }
+        uint32_t isum = sum, icnt = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t ts = __shfl_up(isum, d, 64), tc = __shfl_up(icnt, d, 64);
+            if (lane >= d) { isum += ts; icnt += tc; }
+        }
+        if (lane == 63) { s_wsum[w] = isum; s_wcnt[w] = icnt; }
+        __syncthreads();
+        uint32_t bsum = 0, bcnt = 0, tsum = 0, tcnt = 0;
+#pragma unroll
+        for (int i = 0; i < PC_THREADS / 64; i++) {
+            if (i < w) { bsum += s_wsum[i]; bcnt += s_wcnt[i]; }
+            tsum += s_wsum[i]; tcnt += s_wcnt[i];
+        }
+        if (tid == 0) {
+            uint64_t psum = 0, pcnt = 0;
+            if (tile > 0) {
+                st64_relaxed(&status[tile], (1ull << 62) | ((uint64_t)tcnt << 32) | tsum);
+                uint32_t p = tile - 1, spins = 0;
+                while (true) {
+                    const uint64_t v = ld64_relaxed(&status[p]);
+                    const uint32_t f = (uint32_t)(v >> 62);
+                    if (f == 0) {
+                        if (++spins > (1u << 24)) { atomicOr(&info->error, 4u); break; }
+                        __builtin_amdgcn_s_sleep(1);
+                        continue;
+                    }
+                    psum += (uint32_t)v; pcnt += (uint32_t)(v >> 32) & 0x3FFFFFFFu;
+                    if (f == 2 || p == 0) break;
+                    p--;
+                }
+            }
+            st64_relaxed(&status[tile], (2ull << 62) | (((pcnt + tcnt) & 0x3FFFFFFFull) << 32) | (uint32_t)(psum + tsum));
+            s_psum = (uint32_t)psum; s_pcnt = (uint32_t)pcnt;
+            if (tile == ntiles - 1) { info->n_segments = (uint32_t)(psum + tsum); info->n_compact = (uint32_t)(pcnt + tcnt); }
+        }
+        __syncthreads();
+        uint32_t start = s_psum + bsum + isum - sum;
+        uint32_t c = s_pcnt + bcnt + icnt - cnt;
+#pragma unroll
+        for (int q = 0; q < PC_IPT; q++) {
+            if (l[q]) {
+                cl_idx[c] = base + tid * PC_IPT + q;
+                cl_start[c] = start;
+                mark_block_first(block_first, bf_cap, start, l[q], c);
+                start += l[q]; c++;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+size_t prepare_scratch_words(size_t n_lines) { return 2 * ((n_lines + PC_TILE - 1) / PC_TILE + 1) + 16; }
+
+void launch_prepare_compact(hipStream_t s, const LineSource& src, uint32_t n_lines, uint32_t* cl_idx, uint32_t* cl_start,
+                            uint32_t* block_first, uint32_t bf_cap, uint32_t* scratch, FrameInfo* info) {
+    if (n_lines == 0) return;
+    const uint32_t ntiles = (n_lines + PC_TILE - 1) / PC_TILE;
+    // [ticket (16 words)] [status: ntiles u64] — re-initialised every call
+    (void)hipMemsetAsync(scratch, 0, (16 + 2 * (size_t)ntiles) * 4, s);
+    uint32_t grid = ntiles < 1024 ? ntiles : 1024;
+    hipLaunchKernelGGL(k_prepare_compact, dim3(grid), dim3(PC_THREADS), 0, s, src, n_lines, cl_idx, cl_start, block_first,
+                       bf_cap, (uint64_t*)(scratch + 16), scratch, info);
+}
+
+__global__ __launch_bounds__(256) void k_block_first(const uint32_t* __restrict__ cl_start, uint32_t n_compact,
+                                                     uint32_t n_segments, uint32_t* __restrict__ block_first) {
+    for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n_compact; c += gridDim.x * blockDim.x) {
+        const uint32_t start = cl_start[c];
+        const uint32_t end = c + 1 < n_compact ? cl_start[c + 1] : n_segments;
+        mark_block_first(block_first, 0xFFFFFFFFu, start, end - start, c);
+    }
+}
+void launch_block_first(hipStream_t s, const uint32_t* cl_start, uint32_t n_compact, uint32_t n_segments,
+                        uint32_t* block_first) {
+    if (n_compact == 0) return;
+    uint32_t blocks = (n_compact + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_block_first, dim3(blocks), dim3(256), 0, s, cl_start, n_compact, n_segments, block_first);
+}
+
+// ------------------------------------------------------------------------------------------------
+// rasterize — reference forma/src/cpu/rasterizer.rs:32-159, one thread per pixel segment.
+// A workgroup owns RAS_TILE consecutive pixel segments.  The compacted lines that own them are staged
+// in LDS once per workgroup together with everything that is constant along a line: the f32
+// parameters of segment.rs:341-383 (recomputed from the points: 12 B/line of HBM traffic instead of
+// 40) and the three f64 constants of `find` (rasterizer.rs:104-110, one f64 division per LINE instead
+// of one per pixel segment).  The flat index -> (line, i) map of PrefixScanIter
+// (utils/prefix_scan.rs:30-63) is a binary search over the staged window.
+// ------------------------------------------------------------------------------------------------
+#define RAS_THREADS 256
+#define RAS_PER_THREAD (RAS_TILE / RAS_THREADS)
+#define RAS_WIN 512
+
 __device__ __forceinline__ float find_term(int i, double a_ab, double b_ab, double cd_ab, float a, float b, float c,
                                            float d) {               // rasterizer.rs:32-61
     float fi = (float)i;
@@ -202,11 +355,9 @@ __device__ __forceinline__ float find_term(int i, double a_ab, double b_ab, doub
 }
 
 __device__ __forceinline__ uint64_t rasterize_one(uint32_t order, float lx0, float ly0, float ldx, float ldy, float a,
-                                                  float b, float c, float d, uint32_t seg_i) {
+                                                  float b, float c, float d, double a_ab, double b_ab, double cd_ab,
+                                                  uint32_t seg_i) {
     int i = (int)seg_i - (c != 0.0f ? 1 : 0) - (d != 0.0f ? 1 : 0);                 // rasterizer.rs:63-76
-    double sum_recip = 1.0 / ((double)a + (double)b);
-    double a_ab = (double)a * sum_recip, b_ab = (double)b * sum_recip;
-    double cd_ab = ((double)c - (double)d) * sum_recip;
     float t0 = fmaxf(find_term(i, a_ab, b_ab, cd_ab, a, b, c, d), 0.0f);
     float t1 = fminf(find_term(i + 1, a_ab, b_ab, cd_ab, a, b, c, d), 1.0f);
     float x0f = fmaf(t0, ldx, lx0), y0f = fmaf(t0, ldy, ly0);                        // :112-127
@@ -231,100 +382,106 @@ __device__ __forceinline__ uint64_t rasterize_one(uint32_t order, float lx0, flo
     return v;
 }
 
-#define RAS_THREADS 256
-#define RAS_PER_THREAD 4
-#define RAS_TILE (RAS_THREADS * RAS_PER_THREAD)
-#define RAS_WIN 1280
-
-__device__ __forceinline__ uint32_t upper_bound_global(const uint32_t* __restrict__ sums, uint32_t lo, uint32_t hi,
-                                                       uint32_t k) {   // first index in [lo,hi) with sums[idx] > k
-    while (lo < hi) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (sums[mid] > k) hi = mid; else lo = mid + 1;
+__device__ __forceinline__ LineP load_line(const LineSource& S, uint32_t li) {
+    if (S.sums) {
+        LineP L;
+        L.order = S.orders[li]; L.x0 = S.x0[li]; L.y0 = S.y0[li]; L.dx = S.dx[li]; L.dy = S.dy[li];
+        L.a = S.a[li]; L.b = S.b[li]; L.c = S.c[li]; L.d = S.d[li]; L.len = 1;
+        return L;
     }
-    return lo;
+    return line_params(S.x, S.y, S.line_slot, li, S.geoms, S.n_geoms, S.width, S.height, S.band_lo, S.band_hi);
 }
 
-__global__ __launch_bounds__(RAS_THREADS) void k_rasterize(
-    uint32_t n_lines, uint32_t n_segments, const uint32_t* __restrict__ orders, const float* __restrict__ lx0,
-    const float* __restrict__ ly0, const float* __restrict__ ldx, const float* __restrict__ ldy,
-    const float* __restrict__ la, const float* __restrict__ lb, const float* __restrict__ lc,
-    const float* __restrict__ ld, const uint32_t* __restrict__ sums, uint64_t* __restrict__ out,
-    FrameInfo* __restrict__ info, int band_row0, int band_row1) {
-    __shared__ uint32_t win[RAS_WIN + 1];
-    __shared__ uint32_t s_lo, s_hi;
-    __shared__ uint32_t red[4][RAS_THREADS / 64];
+__global__ __launch_bounds__(RAS_THREADS) void k_rasterize(LineSource S, uint32_t n_compact, uint32_t n_segments,
+                                                           const uint32_t* __restrict__ cl_idx,
+                                                           const uint32_t* __restrict__ cl_start,
+                                                           const uint32_t* __restrict__ block_first,
+                                                           uint64_t* __restrict__ out, FrameInfo* __restrict__ info,
+                                                           int band_row0, int band_row1) {
+    __shared__ uint32_t w_start[RAS_WIN + 1];
+    __shared__ uint32_t w_order[RAS_WIN];
+    __shared__ float w_x0[RAS_WIN], w_y0[RAS_WIN], w_dx[RAS_WIN], w_dy[RAS_WIN];
+    __shared__ float w_a[RAS_WIN], w_b[RAS_WIN], w_c[RAS_WIN], w_d[RAS_WIN];
+    __shared__ double w_aab[RAS_WIN], w_bab[RAS_WIN], w_cdab[RAS_WIN];
+    __shared__ uint32_t red[5][RAS_THREADS / 64];
+    const int tid = threadIdx.x;
+    const uint32_t nblocks = (n_segments + RAS_TILE - 1) / RAS_TILE;
     const uint32_t k0 = blockIdx.x * RAS_TILE;
-    const uint32_t k_last = min(k0 + RAS_TILE, n_segments) - 1;
-    if (threadIdx.x == 0) s_lo = upper_bound_global(sums, 0, n_lines, k0);
-    if (threadIdx.x == 64) s_hi = upper_bound_global(sums, 0, n_lines, k_last);
-    __syncthreads();
-    const uint32_t lo = s_lo, hi = s_hi;          // lines lo..hi (inclusive) own segments k0..k_last
-    const bool use_lds = (hi - lo + 1) <= RAS_WIN;
-    if (use_lds) {
-        // win[j] = sums[lo - 1 + j], j in [0, hi-lo+1]
-        for (uint32_t j = threadIdx.x; j <= hi - lo + 1; j += RAS_THREADS) {
-            uint32_t idx = lo + j;
-            win[j] = idx == 0 ? 0u : sums[idx - 1];
-        }
-    }
-    __syncthreads();
-    uint32_t k_or = 0, k_or_hi = 0, k_and = 0xFFFFFFFFu, k_and_hi = 0xFFFFFFFFu;
-#pragma unroll
-    for (int r = 0; r < RAS_PER_THREAD; r++) {
-        uint32_t k = k0 + r * RAS_THREADS + threadIdx.x;
-        if (k >= n_segments) break;
-        uint32_t li, ex;
-        if (use_lds) {
-            // first j in [1, cnt] with win[j] > k  -> line lo + j - 1
-            uint32_t a = 1, b = hi - lo + 1;
-            while (a < b) {
-                uint32_t mid = (a + b) >> 1;
-                if (win[mid] > k) b = mid; else a = mid + 1;
+    const uint32_t k1 = min(k0 + RAS_TILE, n_segments);                   // exclusive
+    const uint32_t lo = block_first[blockIdx.x];
+    const uint32_t hi = blockIdx.x + 1 < nblocks ? block_first[blockIdx.x + 1] : n_compact - 1;   // inclusive
+    uint32_t k_or = 0, k_or_hi = 0, k_and = 0xFFFFFFFFu, k_and_hi = 0xFFFFFFFFu, unsorted = 0;
+
+    for (uint32_t c0 = lo; c0 <= hi; c0 += RAS_WIN) {
+        const uint32_t cnt = min((uint32_t)RAS_WIN, hi - c0 + 1);
+        if (c0 != lo) __syncthreads();
+        for (uint32_t j = tid; j < cnt; j += RAS_THREADS) {
+            const uint32_t cidx = c0 + j;
+            const LineP L = load_line(S, cl_idx[cidx]);
+            w_start[j] = cl_start[cidx];
+            w_order[j] = L.order; w_x0[j] = L.x0; w_y0[j] = L.y0; w_dx[j] = L.dx; w_dy[j] = L.dy;
+            w_a[j] = L.a; w_b[j] = L.b; w_c[j] = L.c; w_d[j] = L.d;
+            const double sum_recip = 1.0 / ((double)L.a + (double)L.b);          // rasterizer.rs:104-110
+            w_aab[j] = (double)L.a * sum_recip; w_bab[j] = (double)L.b * sum_recip;
+            w_cdab[j] = ((double)L.c - (double)L.d) * sum_recip;
+            // is the stream non-decreasing in layer?  (lets the sort skip the layer digits)
+            if (cidx > 0) {
+                uint32_t prev_order;
+                if (S.sums) prev_order = S.orders[cl_idx[cidx - 1]];
+                else { const uint32_t ps = S.line_slot[cl_idx[cidx - 1]]; prev_order = S.geoms[ps].order; }
+                if (prev_order > L.order) unsorted = 1;
             }
-            li = lo + a - 1;
-            ex = win[a - 1];
-            // win[a-1] is sums[li-1] only if the previous lines were non-empty or not; it is the
-            // inclusive sum of line li-1, which is what PrefixScanIter subtracts (prefix_scan.rs:37-41)
-        } else {
-            li = upper_bound_global(sums, lo, hi + 1, k);
-            ex = li == 0 ? 0u : sums[li - 1];
         }
-        uint64_t v = rasterize_one(orders[li], lx0[li], ly0[li], ldx[li], ldy[li], la[li], lb[li], lc[li], ld[li],
-                                   k - ex);
-        if (band_row1 > 0) {
-            int ty = seg_tile_y(v);
-            if (ty < band_row0 || ty >= band_row1) v &= 0x001FFFFFFFFFFFFFull;   // -> tile row -1: never painted
+        if (tid == 0) w_start[cnt] = (c0 + cnt < n_compact) ? cl_start[c0 + cnt] : n_segments;
+        __syncthreads();
+        const uint32_t ka = max(k0, w_start[0]), kb = min(k1, w_start[cnt]);   // this chunk's share of the tile
+#pragma unroll
+        for (int r = 0; r < RAS_PER_THREAD; r++) {
+            const uint32_t k = k0 + r * RAS_THREADS + tid;
+            if (k < ka || k >= kb) continue;
+            uint32_t a = 0, b = cnt;                       // last j in [0, cnt) with w_start[j] <= k
+            while (b - a > 1) {
+                uint32_t mid = (a + b) >> 1;
+                if (w_start[mid] <= k) a = mid; else b = mid;
+            }
+            uint64_t v = rasterize_one(w_order[a], w_x0[a], w_y0[a], w_dx[a], w_dy[a], w_a[a], w_b[a], w_c[a], w_d[a],
+                                       w_aab[a], w_bab[a], w_cdab[a], k - w_start[a]);
+            if (band_row1 > 0) {
+                int ty = seg_tile_y(v);
+                if (ty < band_row0 || ty >= band_row1) v &= 0x001FFFFFFFFFFFFFull;   // -> tile row -1: never painted
+            }
+            out[k] = v;
+            uint32_t klo = (uint32_t)(v >> 20), khi = (uint32_t)(v >> 52);
+            k_or |= klo; k_or_hi |= khi; k_and &= klo; k_and_hi &= khi;
         }
-        out[k] = v;
-        uint32_t klo = (uint32_t)(v >> 20), khi = (uint32_t)(v >> 52);
-        k_or |= klo; k_or_hi |= khi; k_and &= klo; k_and_hi &= khi;
     }
-    // block reduction of the varying-bit masks -> 4 atomics per block
+    // block reduction of the varying-bit masks -> a few atomics per block
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         k_or |= __shfl_xor(k_or, d, 64); k_or_hi |= __shfl_xor(k_or_hi, d, 64);
         k_and &= __shfl_xor(k_and, d, 64); k_and_hi &= __shfl_xor(k_and_hi, d, 64);
+        unsorted |= __shfl_xor(unsorted, d, 64);
     }
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { red[0][w] = k_or; red[1][w] = k_or_hi; red[2][w] = k_and; red[3][w] = k_and_hi; }
+    const int w = tid >> 6;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t o = 0, oh = 0, a = 0xFFFFFFFFu, ah = 0xFFFFFFFFu;
-        for (int i = 0; i < RAS_THREADS / 64; i++) { o |= red[0][i]; oh |= red[1][i]; a &= red[2][i]; ah &= red[3][i]; }
+    if ((tid & 63) == 0) { red[0][w] = k_or; red[1][w] = k_or_hi; red[2][w] = k_and; red[3][w] = k_and_hi; red[4][w] = unsorted; }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t o = 0, oh = 0, a = 0xFFFFFFFFu, ah = 0xFFFFFFFFu, u = 0;
+        for (int i = 0; i < RAS_THREADS / 64; i++) { o |= red[0][i]; oh |= red[1][i]; a &= red[2][i]; ah &= red[3][i]; u |= red[4][i]; }
         atomicOr(&info->key_or, o); atomicOr(&info->key_or_hi, oh);
         atomicAnd(&info->key_and, a); atomicAnd(&info->key_and_hi, ah);
+        if (u) atomicOr(&info->layer_unsorted, 1u);
     }
 }
 
-void launch_rasterize(hipStream_t s, uint32_t n_lines, uint32_t n_segments, const uint32_t* orders, const float* x0,
-                      const float* y0, const float* dx, const float* dy, const float* a, const float* b, const float* c,
-                      const float* d, const uint32_t* sums, uint64_t* out, FrameInfo* info, int band_row0,
-                      int band_row1) {
-    if (n_segments == 0) return;
+void launch_rasterize(hipStream_t s, const LineSource& src, uint32_t n_compact, uint32_t n_segments,
+                      const uint32_t* cl_idx, const uint32_t* cl_start, const uint32_t* block_first, uint64_t* out,
+                      FrameInfo* info, int band_row0, int band_row1) {
+    if (n_segments == 0 || n_compact == 0) return;
     uint32_t blocks = (n_segments + RAS_TILE - 1) / RAS_TILE;
-    hipLaunchKernelGGL(k_rasterize, dim3(blocks), dim3(RAS_THREADS), 0, s, n_lines, n_segments, orders, x0, y0, dx, dy,
-                       a, b, c, d, sums, out, info, band_row0, band_row1);
+    hipLaunchKernelGGL(k_rasterize, dim3(blocks), dim3(RAS_THREADS), 0, s, src, n_compact, n_segments, cl_idx, cl_start,
+                       block_first, out, info, band_row0, band_row1);
 }
 
 // ------------------------------------------------------------------------------------------------

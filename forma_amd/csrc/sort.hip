@@ -2,192 +2,295 @@
 // (replaces `segments.par_crumsort()`, reference forma/src/cpu/rasterizer.rs:161-164, ordering =
 // `PixelSegment::cmp` on bits 20..63, cpu/pixel_segment.rs:161-171).
 //
-// 4-bit digits.  Per pass: k_hist (per-block digit counts via wavefront ballots) ->
-// k_scan_counts (one block, digit-major exclusive scan) -> k_scatter (ballot/popcount ranking inside
-// each wave, LDS staging so every digit run leaves the CU as one contiguous, coalesced store).
-// Constant digits (single-bin histograms) are skipped: the caller passes the mask of key bits that
-// vary at all, computed for free by the rasterizer.  HBM-bound byte shuffling: no MFMA.
+// Design (gfx950, HBM-bound byte shuffling, no MFMA):
+//   * digit plan: the caller passes the mask of key bits that vary at all (computed for free by the
+//     rasterizer); digits are packed greedily over LIVE bits only, so constant fields (the unused
+//     high bits of tile_y / tile_x / layer) cost nothing.  If the rasterizer stream is already
+//     non-decreasing in layer (the common case: geometry inserted in paint order) the layer bits are
+//     dropped from the plan too — a stable sort by (tile_y, tile_x) alone then yields exactly the
+//     stream a stable sort by the full 44-bit key would.
+//   * one up-front histogram kernel for ALL passes (1 read of the keys), then ONE kernel per digit
+//     pass: chained scan with decoupled look-back (tile status words = {flag, count} in one u32, the
+//     "R2 granule" form of the MI355X guide: the data is the flag, relaxed agent-scope accesses), so
+//     a pass moves 8 B in + 8 B out per key and nothing else.
+//   * ranking inside a tile: wavefront match-any from __ballot()s of the digit bits, v_mbcnt for the
+//     lane prefix, per-wave LDS digit counters; keys are staged in LDS so that every digit run leaves
+//     the CU as one contiguous, coalesced store.
+//   * persistent workgroups pull tiles with an atomic ticket: a tile only ever waits for tiles with
+//     a smaller ticket, which are already running — forward progress does not depend on dispatch
+//     order (guide: "HIP promises nothing about dispatch order").
 #include "common.h"
 
-#define SORT_THREADS 256
-#define SORT_WAVES   (SORT_THREADS / 64)
-#define SORT_KPT     16                              // keys per lane
-#define SORT_WKEYS   (64 * SORT_KPT)                 // keys per wave
-#define SORT_TILE    (SORT_THREADS * SORT_KPT)       // keys per block (4096 -> 32 KiB of LDS staging)
-#define RADIX_BITS   4
-#define RADIX        16
+#define OS_THREADS 512
+#define OS_WAVES   (OS_THREADS / 64)
+#define OS_KPT     16                               // keys per lane
+#define OS_TILE    (OS_THREADS * OS_KPT)            // 8192 keys per tile -> 64 KiB of LDS staging
+#define ST_AGG     1u                               // status flag: tile aggregate published
+#define ST_PREFIX  2u                               // status flag: inclusive prefix published
+#define ST_VALMASK 0x3FFFFFFFu
+#define SPIN_LIMIT (1u << 24)
 
-// mask of lanes (among `valid`) whose 4-bit digit equals dv, from the four digit-bit ballots
-__device__ __forceinline__ uint64_t digit_peers(uint64_t valid, uint64_t b0, uint64_t b1, uint64_t b2, uint64_t b3,
-                                                uint32_t dv) {
-    uint64_t m = valid;
-    m &= (dv & 1u) ? b0 : ~b0;
-    m &= (dv & 2u) ? b1 : ~b1;
-    m &= (dv & 4u) ? b2 : ~b2;
-    m &= (dv & 8u) ? b3 : ~b3;
+typedef __attribute__((address_space(1))) unsigned int gu32;
+
+__device__ __forceinline__ uint32_t ld_relaxed(const uint32_t* p) {
+    return __hip_atomic_load((gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_relaxed(uint32_t* p, uint32_t v) {
+    __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// lanes of this wave whose BITS-bit digit equals mine
+template <int BITS>
+__device__ __forceinline__ uint64_t match_any(uint32_t dg) {
+    uint64_t m = ~0ull;
+#pragma unroll
+    for (int b = 0; b < BITS; b++) {
+        const bool bit = (dg >> b) & 1u;
+        const uint64_t bal = __ballot(bit);
+        m &= bit ? bal : ~bal;
+    }
     return m;
 }
-
-__global__ __launch_bounds__(SORT_THREADS) void k_hist(const uint64_t* __restrict__ in, uint32_t n, int shift,
-                                                       uint32_t nblocks, uint32_t* __restrict__ counts) {
-    __shared__ uint32_t wave_hist[SORT_WAVES][RADIX];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t wbase = blockIdx.x * SORT_TILE + w * SORT_WKEYS;
-    const uint32_t dv = lane & 15;
-    uint32_t cnt = 0;
-#pragma unroll
-    for (int j = 0; j < SORT_KPT; j++) {
-        uint32_t idx = wbase + j * 64 + lane;
-        bool valid = idx < n;
-        uint64_t key = valid ? in[idx] : 0ull;
-        uint32_t dg = (uint32_t)(key >> shift) & 15u;
-        uint64_t vm = __ballot(valid);
-        uint64_t b0 = __ballot(dg & 1u), b1 = __ballot(dg & 2u), b2 = __ballot(dg & 4u), b3 = __ballot(dg & 8u);
-        cnt += __popcll(digit_peers(vm, b0, b1, b2, b3, dv));
-    }
-    if (lane < RADIX) wave_hist[w][lane] = cnt;
-    __syncthreads();
-    if (threadIdx.x < RADIX) {
-        uint32_t t = 0;
-#pragma unroll
-        for (int i = 0; i < SORT_WAVES; i++) t += wave_hist[i][threadIdx.x];
-        counts[threadIdx.x * nblocks + blockIdx.x] = t;
-    }
+__device__ __forceinline__ uint32_t lanes_below(uint64_t m) {          // popcount(m & lanemask_lt)
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-// single block: exclusive scan in place over RADIX * nblocks counters (digit-major)
-__global__ __launch_bounds__(1024) void k_scan_counts(uint32_t* __restrict__ counts, uint32_t n) {
-    __shared__ uint32_t lds[1024 / 64];
-    __shared__ uint32_t s_carry;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (uint32_t base = 0; base < n; base += 1024 * 4) {
-        uint32_t idx = base + threadIdx.x * 4;
-        uint32_t v[4], s = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) { v[i] = (idx + i < n) ? counts[idx + i] : 0; s += v[i]; }
-        uint32_t inc = s;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
-        if (lane == 63) lds[w] = inc;
-        __syncthreads();
-        uint32_t wbase = 0, tot = 0;
-#pragma unroll
-        for (int i = 0; i < 16; i++) { uint32_t t = lds[i]; if (i < w) wbase += t; tot += t; }
-        uint32_t ex = s_carry + wbase + inc - s;
-#pragma unroll
-        for (int i = 0; i < 4; i++) { if (idx + i < n) counts[idx + i] = ex; ex += v[i]; }
-        __syncthreads();
-        if (threadIdx.x == 0) s_carry += tot;
-        __syncthreads();
-    }
-}
+// ------------------------------------------------------------------------------------------------
+// up-front histograms of every planned digit: hist[p * 256 + d].  Per-lane run-length compression
+// (consecutive keys of a lane mostly share their tile digits) keeps the LDS atomics rare.
+// ------------------------------------------------------------------------------------------------
+#define HS_THREADS 256
+#define HS_KPT     16
+#define HS_TILE    (HS_THREADS * HS_KPT)
 
-__global__ __launch_bounds__(SORT_THREADS) void k_scatter(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
-                                                          uint32_t n, int shift, uint32_t nblocks,
-                                                          const uint32_t* __restrict__ offsets) {
-    __shared__ uint64_t staged[SORT_TILE];
-    __shared__ uint32_t wave_hist[SORT_WAVES][RADIX];
-    __shared__ uint32_t pos[SORT_WAVES][RADIX];
-    __shared__ uint32_t gdelta[RADIX];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint32_t bbase = blockIdx.x * SORT_TILE;
-    const uint32_t wbase = bbase + w * SORT_WKEYS;
-    const uint32_t dv = lane & 15;
-    const uint64_t lt_mask = (1ull << lane) - 1ull;
-
-    uint64_t keys[SORT_KPT];
-    uint32_t rnk[SORT_KPT];          // rank among same-digit keys of this wave, in stream order
-    uint32_t running = 0;            // lanes 0..15: keys of digit `lane` seen so far in this wave
-#pragma unroll
-    for (int j = 0; j < SORT_KPT; j++) {
-        uint32_t idx = wbase + j * 64 + lane;
-        keys[j] = idx < n ? in[idx] : 0ull;
-    }
-#pragma unroll
-    for (int j = 0; j < SORT_KPT; j++) {
-        uint32_t idx = wbase + j * 64 + lane;
-        bool valid = idx < n;
-        uint32_t dg = (uint32_t)(keys[j] >> shift) & 15u;
-        uint64_t vm = __ballot(valid);
-        uint64_t b0 = __ballot(dg & 1u), b1 = __ballot(dg & 2u), b2 = __ballot(dg & 4u), b3 = __ballot(dg & 8u);
-        uint64_t own = digit_peers(vm, b0, b1, b2, b3, dg);
-        uint32_t before = __shfl(running, (int)dg, 64);
-        rnk[j] = before + __popcll(own & lt_mask);
-        running += __popcll(digit_peers(vm, b0, b1, b2, b3, dv));
-    }
-    if (lane < RADIX) wave_hist[w][lane] = running;
+__global__ __launch_bounds__(HS_THREADS) void k_sort_hist(const uint64_t* __restrict__ in, uint32_t n, SortPlan plan,
+                                                          uint32_t* __restrict__ hist) {
+    __shared__ uint32_t lh[SORT_MAX_PASSES * 256];
+    const int P = plan.n_passes;
+    for (int i = threadIdx.x; i < P * 256; i += HS_THREADS) lh[i] = 0;
     __syncthreads();
-    if (threadIdx.x < RADIX) {
-        const uint32_t d = threadIdx.x;
-        uint32_t wh[SORT_WAVES], tot = 0;
+    const uint32_t ntiles = (n + HS_TILE - 1) / HS_TILE;
+    for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const uint32_t base = t * HS_TILE + threadIdx.x;
+        uint64_t k[HS_KPT];
 #pragma unroll
-        for (int i = 0; i < SORT_WAVES; i++) { wh[i] = wave_hist[i][d]; tot += wh[i]; }
-        uint32_t inc = tot;                        // exclusive scan over the 16 digits (lanes 0..15)
+        for (int j = 0; j < HS_KPT; j++) {
+            uint32_t idx = base + j * HS_THREADS;
+            k[j] = idx < n ? in[idx] : ~0ull;
+        }
+        const uint32_t nv = (base < n) ? min((uint32_t)HS_KPT, (n - base + HS_THREADS - 1) / HS_THREADS) : 0u;
+        for (int p = 0; p < P; p++) {
+            const int sh = plan.shift[p];
+            const uint32_t mk = plan.mask[p];
+            uint32_t cur = 0, cnt = 0;
 #pragma unroll
-        for (int s = 1; s < 16; s <<= 1) { uint32_t t = __shfl_up(inc, s, 16); if ((int)d >= s) inc += t; }
-        uint32_t local_base = inc - tot, acc = local_base;
-#pragma unroll
-        for (int i = 0; i < SORT_WAVES; i++) { pos[i][d] = acc; acc += wh[i]; }
-        gdelta[d] = offsets[d * nblocks + blockIdx.x] - local_base;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < SORT_KPT; j++) {
-        uint32_t idx = wbase + j * 64 + lane;
-        if (idx < n) {
-            uint32_t dg = (uint32_t)(keys[j] >> shift) & 15u;
-            staged[pos[w][dg] + rnk[j]] = keys[j];
+            for (int j = 0; j < HS_KPT; j++) {
+                if ((uint32_t)j < nv) {
+                    uint32_t d = (uint32_t)(k[j] >> sh) & mk;
+                    if (cnt && d != cur) { atomicAdd(&lh[p * 256 + cur], cnt); cnt = 0; }
+                    cur = d; cnt++;
+                }
+            }
+            if (cnt) atomicAdd(&lh[p * 256 + cur], cnt);
         }
     }
     __syncthreads();
-    const uint32_t nvalid = min((uint32_t)SORT_TILE, n - bbase);
-#pragma unroll
-    for (int j = 0; j < SORT_KPT; j++) {
-        uint32_t i = j * SORT_THREADS + threadIdx.x;
-        if (i < nvalid) {
-            uint64_t key = staged[i];
-            uint32_t dg = (uint32_t)(key >> shift) & 15u;
-            out[i + gdelta[dg]] = key;
-        }
+    for (int i = threadIdx.x; i < P * 256; i += HS_THREADS) {
+        uint32_t v = lh[i];
+        if (v) atomicAdd(&hist[i], v);
     }
 }
 
-size_t sort_counter_words(size_t n, int digit_bits) {
-    (void)digit_bits;
-    size_t nb = (n + SORT_TILE - 1) / SORT_TILE;
-    return RADIX * nb + 16;
+// ------------------------------------------------------------------------------------------------
+// one digit pass
+// ------------------------------------------------------------------------------------------------
+// exclusive scan of (a, b) over the first RADIX threads of the block; every thread must call.
+template <int RADIX>
+__device__ __forceinline__ void scan2_excl(uint32_t& a, uint32_t& b, uint32_t* lds /* 2 * 8 */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t ia = a, ib = b;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t ta = __shfl_up(ia, d, 64), tb = __shfl_up(ib, d, 64);
+        if (lane >= d) { ia += ta; ib += tb; }
+    }
+    if (RADIX > 64) {
+        if (lane == 63 && w < RADIX / 64) { lds[w] = ia; lds[8 + w] = ib; }
+        __syncthreads();
+        uint32_t ba = 0, bb = 0;
+#pragma unroll
+        for (int i = 0; i < RADIX / 64; i++) if (i < w) { ba += lds[i]; bb += lds[8 + i]; }
+        __syncthreads();
+        a = ba + ia - a; b = bb + ib - b;
+    } else {
+        a = ia - a; b = ib - b;
+    }
 }
 
-uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a, uint64_t* b, size_t n, uint64_t live_mask,
-                            int lo_bit, int hi_bit, int digit_bits, uint32_t* counters, uint32_t* scan_tmp,
-                            int* passes_out, hipEvent_t* pass_ev0, hipEvent_t* pass_ev1) {
-    (void)digit_bits; (void)scan_tmp;
-    int passes = 0;
+template <int BITS>
+__global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
+                                                         uint32_t n, int shift, uint32_t dmask,
+                                                         const uint32_t* __restrict__ ghist /* this pass, 256 */,
+                                                         uint32_t* __restrict__ status /* [ntiles][RADIX] */,
+                                                         uint32_t* __restrict__ ticket, uint32_t* __restrict__ err) {
+    constexpr int RADIX = 1 << BITS;
+    __shared__ uint64_t staged[OS_TILE];
+    __shared__ uint32_t whist[OS_WAVES][RADIX];
+    __shared__ uint32_t s_gdelta[RADIX];
+    __shared__ uint32_t s_scan[16];
+    __shared__ uint32_t s_tile;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t ntiles = (n + OS_TILE - 1) / OS_TILE;
+    volatile uint32_t* vh = &whist[w][0];
+
+    // global digit starts = exclusive scan of this pass's histogram (identical in every block)
+    uint32_t gstart = 0;
+    {
+        uint32_t g = (tid < RADIX) ? ghist[tid] : 0u, dummy = 0;
+        scan2_excl<RADIX>(g, dummy, s_scan);
+        gstart = g;
+    }
+
+    while (true) {
+        if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+        for (int i = tid; i < OS_WAVES * RADIX; i += OS_THREADS) (&whist[0][0])[i] = 0;
+        __syncthreads();
+        const uint32_t tile = s_tile;
+        if (tile >= ntiles) break;
+        const uint32_t bbase = tile * OS_TILE;
+        const uint32_t wbase = bbase + w * (64 * OS_KPT);
+
+        uint64_t keys[OS_KPT];
+        uint32_t rnk[OS_KPT / 2];                          // 16-bit ranks, two per register
+#pragma unroll
+        for (int j = 0; j < OS_KPT; j++) {
+            uint32_t idx = wbase + j * 64 + lane;
+            keys[j] = idx < n ? in[idx] : ~0ull;            // padding sorts last in stream order, never written
+        }
+        // ---- stable rank of every key among the same-digit keys of its wave ----------------------------
+#pragma unroll
+        for (int j = 0; j < OS_KPT; j++) {
+            const uint32_t dg = (uint32_t)(keys[j] >> shift) & dmask;
+            const uint64_t peers = match_any<BITS>(dg);
+            const uint32_t below = lanes_below(peers);
+            const uint32_t base = vh[dg];                     // every peer reads the same word (broadcast)
+            if (below == 0) vh[dg] = base + (uint32_t)__popcll(peers);   // LDS ops of a wave retire in order
+            if (j & 1) rnk[j >> 1] |= (base + below) << 16; else rnk[j >> 1] = base + below;
+        }
+        __syncthreads();
+        // ---- digit totals of the tile, per-wave bases, look-back ----------------------------------------
+        uint32_t tot = 0, lbase = 0;
+        if (tid < RADIX) {
+#pragma unroll
+            for (int i = 0; i < OS_WAVES; i++) tot += whist[i][tid];
+            if (tile > 0) st_relaxed(&status[(size_t)tile * RADIX + tid], (ST_AGG << 30) | tot);
+        }
+        {
+            uint32_t a = tot, dummy = 0;
+            scan2_excl<RADIX>(a, dummy, s_scan);
+            lbase = a;
+        }
+        if (tid < RADIX) {
+            uint32_t acc = lbase;
+#pragma unroll
+            for (int i = 0; i < OS_WAVES; i++) { uint32_t c = whist[i][tid]; whist[i][tid] = acc; acc += c; }
+            uint32_t excl = 0;
+            if (tile > 0) {
+                uint32_t p = tile - 1, spins = 0;
+                while (true) {
+                    uint32_t v = ld_relaxed(&status[(size_t)p * RADIX + tid]);
+                    uint32_t f = v >> 30;
+                    if (f == 0) {
+                        if (++spins > SPIN_LIMIT) { atomicOr(err, 4u); break; }
+                        __builtin_amdgcn_s_sleep(1);
+                        continue;
+                    }
+                    excl += v & ST_VALMASK;
+                    if (f == ST_PREFIX || p == 0) break;
+                    p--;
+                }
+            }
+            st_relaxed(&status[(size_t)tile * RADIX + tid], (ST_PREFIX << 30) | (excl + tot));
+            s_gdelta[tid] = gstart + excl - lbase;
+        }
+        __syncthreads();
+        // ---- stage in digit order, then coalesced stores --------------------------------------------------
+#pragma unroll
+        for (int j = 0; j < OS_KPT; j++) {
+            const uint32_t dg = (uint32_t)(keys[j] >> shift) & dmask;
+            staged[whist[w][dg] + ((rnk[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu)] = keys[j];
+        }
+        __syncthreads();
+        const uint32_t nvalid = min((uint32_t)OS_TILE, n - bbase);
+#pragma unroll
+        for (int j = 0; j < OS_KPT; j++) {
+            uint32_t i = j * OS_THREADS + tid;
+            if (i < nvalid) {
+                uint64_t key = staged[i];
+                uint32_t dg = (uint32_t)(key >> shift) & dmask;
+                out[i + s_gdelta[dg]] = key;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+SortPlan make_sort_plan(uint64_t live_mask, int lo_bit, int hi_bit, int digit_bits) {
+    SortPlan p;
+    p.n_passes = 0;
+    const int db = digit_bits == 4 ? 4 : 8;
+    int b = lo_bit;
+    while (b < hi_bit && p.n_passes < SORT_MAX_PASSES) {
+        if (!((live_mask >> b) & 1ull)) { b++; continue; }
+        int width = hi_bit - b < db ? hi_bit - b : db;
+        // trim dead bits at the top of the window
+        while (width > 1 && !((live_mask >> (b + width - 1)) & 1ull)) width--;
+        p.shift[p.n_passes] = b;
+        p.mask[p.n_passes] = (1u << width) - 1u;
+        p.n_passes++;
+        b += width;
+    }
+    return p;
+}
+
+size_t sort_scratch_words(size_t n) {
+    size_t ntiles = (n + OS_TILE - 1) / OS_TILE;
+    // [hist: MAX_PASSES*256] [tickets: MAX_PASSES] [pad to 64] [status: MAX_PASSES * ntiles * 256]
+    return (size_t)SORT_MAX_PASSES * 256 + 64 + (size_t)SORT_MAX_PASSES * (ntiles + 1) * 256;
+}
+
+const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a, uint64_t* b, size_t n,
+                                  const SortPlan& plan, int digit_bits, uint32_t* scratch, uint32_t* err,
+                                  hipEvent_t* pass_ev0, hipEvent_t* pass_ev1) {
+    if (n <= 1 || plan.n_passes == 0) return in;
+    const uint32_t ntiles = (uint32_t)((n + OS_TILE - 1) / OS_TILE);
+    uint32_t* hist = scratch;
+    uint32_t* tickets = scratch + (size_t)SORT_MAX_PASSES * 256;
+    uint32_t* status = tickets + 64;
+    const int P = plan.n_passes;
+    // zero hist + tickets + the status words of the passes that run (re-initialised every call)
+    (void)hipMemsetAsync(scratch, 0, ((size_t)SORT_MAX_PASSES * 256 + 64 + (size_t)P * ntiles * 256) * 4, s);
+    uint32_t hb = (uint32_t)((n + HS_TILE - 1) / HS_TILE);
+    if (hb > 2048) hb = 2048;
+    hipLaunchKernelGGL(k_sort_hist, dim3(hb), dim3(HS_THREADS), 0, s, in, (uint32_t)n, plan, hist);
+    uint32_t grid = ntiles < 512 ? ntiles : 512;          // persistent: 2 workgroups of 8 waves per CU
     const uint64_t* src = in;
     uint64_t* dst = a;
-    if (n > 1) {
-        const uint32_t nb = (uint32_t)((n + SORT_TILE - 1) / SORT_TILE);
-        for (int shift = lo_bit; shift < hi_bit; shift += RADIX_BITS) {
-            int width = hi_bit - shift < RADIX_BITS ? hi_bit - shift : RADIX_BITS;
-            uint64_t dmask = ((1ull << width) - 1ull) << shift;
-            if ((live_mask & dmask) == 0) continue;          // single-bin histogram: pass is the identity
-            if (pass_ev0) hipEventRecord(pass_ev0[passes], s);
-            hipLaunchKernelGGL(k_hist, dim3(nb), dim3(SORT_THREADS), 0, s, src, (uint32_t)n, shift, nb, counters);
-            hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, counters, RADIX * nb);
-            hipLaunchKernelGGL(k_scatter, dim3(nb), dim3(SORT_THREADS), 0, s, src, dst, (uint32_t)n, shift, nb,
-                               (const uint32_t*)counters);
-            if (pass_ev1) hipEventRecord(pass_ev1[passes], s);
-            src = dst;
-            dst = (dst == a) ? b : a;
-            passes++;
-        }
+    for (int p = 0; p < P; p++) {
+        if (pass_ev0) (void)hipEventRecord(pass_ev0[p], s);
+        uint32_t* st = status + (size_t)p * ntiles * 256;
+        if (digit_bits == 4)
+            hipLaunchKernelGGL(k_onesweep<4>, dim3(grid), dim3(OS_THREADS), 0, s, src, dst, (uint32_t)n, plan.shift[p],
+                               plan.mask[p], (const uint32_t*)(hist + p * 256), st, tickets + p, err);
+        else
+            hipLaunchKernelGGL(k_onesweep<8>, dim3(grid), dim3(OS_THREADS), 0, s, src, dst, (uint32_t)n, plan.shift[p],
+                               plan.mask[p], (const uint32_t*)(hist + p * 256), st, tickets + p, err);
+        if (pass_ev1) (void)hipEventRecord(pass_ev1[p], s);
+        src = dst;
+        dst = (dst == a) ? b : a;
     }
-    if (passes_out) *passes_out = passes;
-    if (passes == 0) {
-        if (n) hipMemcpyAsync(a, in, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, s);
-        return a;
-    }
-    return (uint64_t*)src;
+    return src;
 }
