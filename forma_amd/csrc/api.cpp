@@ -55,7 +55,7 @@ struct forma_hip_ctx {
     bool layer_sorted = false;              // rasterizer stream is non-decreasing in layer
     int digit_bits = 8;                     // radix digit width: 8 (default) or 4 (FORMA_HIP_DIGIT_BITS)
     // paint
-    DevBuf info, head_counts, run_start, records, run_cov, rk_u, rk_a, rk_b, tile_count, tile_fill, entries, image;
+    DevBuf info, records, run_cov, rk_u, rk_a, rk_b, blk_edge, runs_scratch, tile_first_run, row_tab, span_key, span_cov, image;
     uint32_t img_w = 0, img_h = 0;
     FrameInfo* h_info = nullptr;            // pinned
     // band
@@ -202,41 +202,43 @@ struct PaintArgs {
     const forma_rect_t* crop;
 };
 
-// stage 4 on ctx->sorted (n segments): carry pre-pass + per-tile painter -> ctx->image
+// stage 4 on ctx->sorted (n segments): runs + carry pre-pass + per-tile painter -> ctx->image
 int run_paint(forma_hip_ctx* ctx, size_t n, const PaintArgs& a, bool timing) {
     const uint32_t tiles_w = (a.width + 15) / 16, tiles_h = (a.height + 15) / 16;
     const uint32_t T = tiles_w * tiles_h;
     HIPCHECK(ctx->image.ensure((size_t)a.width * a.height * 4));
     ctx->img_w = a.width; ctx->img_h = a.height;
-    HIPCHECK(ctx->tile_count.ensure((size_t)(T + 1) * 4));
-    HIPCHECK(ctx->tile_fill.ensure((size_t)(T + 1) * 4));
-    HIPCHECK(ctx->scan_tmp.ensure(scan_tmp_words(std::max<size_t>(T + 1, 1 << 16)) * 4));
+    HIPCHECK(ctx->tile_first_run.ensure((size_t)(T + 1) * 4));
+    HIPCHECK(ctx->row_tab.ensure((size_t)(tiles_h + 1) * 4 * 3));
     FrameInfo* dinfo = ctx->info.as<FrameInfo>();
-    uint32_t J = 0, E = 0;
+    uint32_t* row_count = ctx->row_tab.as<uint32_t>();
+    uint32_t* row_span_lo = row_count + (tiles_h + 1);
+    uint32_t* row_span_cnt = row_span_lo + (tiles_h + 1);
+    uint32_t J = 0;
+    // capacity: a run needs at least one segment, and so does a span's left neighbour
+    const size_t cap = std::max<size_t>(n, 1);
+    HIPCHECK(ctx->records.ensure(cap * sizeof(TileRecord)));
+    HIPCHECK(ctx->run_cov.ensure(cap * 16));
+    HIPCHECK(ctx->rk_u.ensure(cap * 8));
+    HIPCHECK(ctx->blk_edge.ensure(runs_blocks(cap) * sizeof(BlkEdge)));
+    HIPCHECK(ctx->runs_scratch.ensure(runs_scratch_words(cap) * 4));
     stage_begin(ctx, ST_CARRY, timing);
-    HIPCHECK(hipMemsetAsync(ctx->tile_count.p, 0, (size_t)(T + 1) * 4, ctx->stream));
-    HIPCHECK(hipMemsetAsync(ctx->tile_fill.p, 0, (size_t)(T + 1) * 4, ctx->stream));
-    HIPCHECK(hipMemsetAsync(&dinfo->n_spans, 0, 4, ctx->stream));
+    launch_runs(ctx->stream, ctx->sorted, (uint32_t)n, tiles_w, tiles_h, ctx->records.as<TileRecord>(), ctx->run_cov.as<uint4>(),
+                ctx->rk_u.as<uint64_t>(), ctx->tile_first_run.as<uint32_t>(), ctx->blk_edge.as<BlkEdge>(), row_count,
+                ctx->runs_scratch.as<uint32_t>(), dinfo);
+    HIPCHECK(hipGetLastError());
     if (n > 0) {
-        HIPCHECK(ctx->head_counts.ensure((n / 2048 + 2) * 4));
-        HIPCHECK(ctx->run_start.ensure((n + 2) * 4));
-        launch_find_bounds(ctx->stream, ctx->sorted, (uint32_t)n, tiles_h, dinfo);
-        launch_runs(ctx->stream, ctx->sorted, dinfo, (uint32_t)n, ctx->head_counts.as<uint32_t>(), nullptr,
-                    ctx->run_start.as<uint32_t>(), dinfo);
-        HIPCHECK(hipGetLastError());
         int rc = read_info(ctx);
         if (rc) return rc;
+        if (ctx->h_info->error & 4u) return fail(ctx, FORMA_E_INTERNAL, "look-back spin expired (runs)");
         J = ctx->h_info->n_runs;
     }
     if (J > 0) {
-        HIPCHECK(ctx->records.ensure((size_t)2 * J * sizeof(TileRecord)));
-        HIPCHECK(ctx->run_cov.ensure((size_t)J * 16));
-        HIPCHECK(ctx->rk_u.ensure((size_t)J * 8));
         HIPCHECK(ctx->rk_a.ensure((size_t)J * 8));
         HIPCHECK(ctx->rk_b.ensure((size_t)J * 8));
+        HIPCHECK(ctx->span_key.ensure((size_t)J * 8));
+        HIPCHECK(ctx->span_cov.ensure((size_t)J * 16));
         HIPCHECK(ctx->sort_counters.ensure(sort_scratch_words(J) * 4));
-        launch_run_covers(ctx->stream, ctx->sorted, ctx->run_start.as<uint32_t>(), J, ctx->records.as<TileRecord>(),
-                          ctx->run_cov.as<uint4>(), ctx->rk_u.as<uint64_t>(), tiles_w);
         // (tile_y, layer) order: stable radix sort on bits 32..63 = [layer 21 | tile_y+1 11]; live bits come from the
         // rasterizer's varying-bit mask (layer = key bits 0..20, tile_y = key bits 33..43)
         uint64_t live = ((ctx->live44 & 0x1FFFFFull) | ((ctx->live44 >> 33) << 21)) << 32;
@@ -244,27 +246,16 @@ int run_paint(forma_hip_ctx* ctx, size_t n, const PaintArgs& a, bool timing) {
         const uint64_t* sorted_keys = launch_radix_sort(ctx->stream, ctx->rk_u.as<uint64_t>(), ctx->rk_a.as<uint64_t>(),
                                                         ctx->rk_b.as<uint64_t>(), J, rk_plan, ctx->digit_bits,
                                                         ctx->sort_counters.as<uint32_t>(), &dinfo->error, nullptr, nullptr);
-        launch_carry(ctx->stream, sorted_keys, J, ctx->records.as<TileRecord>(), ctx->run_cov.as<uint4>(),
-                     ctx->style_off.as<uint32_t>(), ctx->style_words.as<uint32_t>(), (uint32_t)ctx->n_orders, tiles_w, tiles_h,
-                     ctx->tile_count.as<uint32_t>(), dinfo, 0, nullptr, nullptr, nullptr, J);
-        launch_exclusive_scan_u32(ctx->stream, ctx->tile_count.as<uint32_t>(), T + 1, ctx->scan_tmp.as<uint32_t>(),
-                                  &dinfo->n_entries);
-        HIPCHECK(hipGetLastError());
-        int rc = read_info(ctx);
-        if (rc) return rc;
-        E = ctx->h_info->n_entries;
-        if (ctx->h_info->error & 1u) return fail(ctx, FORMA_E_STATE, "a pixel segment references an order without style");
-        HIPCHECK(ctx->entries.ensure(std::max<size_t>(E, 1) * 8));
-        launch_carry(ctx->stream, sorted_keys, J, ctx->records.as<TileRecord>(), ctx->run_cov.as<uint4>(),
-                     ctx->style_off.as<uint32_t>(), ctx->style_words.as<uint32_t>(), (uint32_t)ctx->n_orders, tiles_w, tiles_h,
-                     ctx->tile_count.as<uint32_t>(), dinfo, 1, ctx->tile_count.as<uint32_t>(), ctx->tile_fill.as<uint32_t>(),
-                     ctx->entries.as<uint64_t>(), J);
+        launch_carry_rows(ctx->stream, sorted_keys, ctx->records.as<TileRecord>(), ctx->run_cov.as<uint4>(),
+                          ctx->blk_edge.as<BlkEdge>(), (uint32_t)((n + 2047) / 2048), ctx->style_off.as<uint32_t>(),
+                          ctx->style_words.as<uint32_t>(), (uint32_t)ctx->n_orders, tiles_w, tiles_h, row_count, row_span_lo,
+                          row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(), dinfo);
     } else {
-        HIPCHECK(ctx->entries.ensure(8));
-        HIPCHECK(ctx->records.ensure(sizeof(TileRecord)));
+        HIPCHECK(ctx->span_key.ensure(8));
+        HIPCHECK(ctx->span_cov.ensure(16));
     }
     stage_end(ctx, ST_CARRY, timing);
-    ctx->last_runs = J; ctx->last_entries = E;
+    ctx->last_runs = J; ctx->last_entries = 0;
 
     PaintParams P;
     P.width = a.width; P.height = a.height; P.tiles_w = tiles_w; P.tiles_h = tiles_h;
@@ -280,9 +271,10 @@ int run_paint(forma_hip_ctx* ctx, size_t n, const PaintArgs& a, bool timing) {
     for (int i = 0; i < 4; i++) P.clear[i] = a.clear[i];
     P.stride_px = a.width; P.scene_has_clips = ctx->scene_has_clips ? 1u : 0u; P.n_orders = (uint32_t)ctx->n_orders;
     stage_begin(ctx, ST_PAINT, timing);
-    launch_paint(ctx->stream, P, ctx->sorted, ctx->tile_count.as<uint32_t>(), ctx->entries.as<uint64_t>(),
-                 ctx->records.as<TileRecord>(), ctx->style_off.as<uint32_t>(), ctx->style_words.as<uint32_t>(),
-                 ctx->images.as<forma_image_t>(), ctx->texels.as<uint16_t>(), ctx->image.as<uint8_t>(), dinfo);
+    launch_paint(ctx->stream, P, ctx->sorted, ctx->records.as<TileRecord>(), J, ctx->tile_first_run.as<uint32_t>(), row_span_lo,
+                 row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(), ctx->style_off.as<uint32_t>(),
+                 ctx->style_words.as<uint32_t>(), ctx->images.as<forma_image_t>(), ctx->texels.as<uint16_t>(),
+                 ctx->image.as<uint8_t>(), dinfo);
     stage_end(ctx, ST_PAINT, timing);
     HIPCHECK(hipGetLastError());
     return FORMA_OK;
@@ -387,8 +379,9 @@ void forma_hip_destroy(forma_hip_ctx* ctx) {
                      &ctx->images, &ctx->texels, &ctx->l_order, &ctx->l_x0, &ctx->l_y0, &ctx->l_dx, &ctx->l_dy, &ctx->l_a,
                      &ctx->l_b, &ctx->l_c, &ctx->l_d, &ctx->l_len, &ctx->scan_tmp, &ctx->cl_idx, &ctx->cl_start,
                      &ctx->block_first, &ctx->prep_scratch, &ctx->seg_u, &ctx->seg_a, &ctx->seg_b,
-                     &ctx->sort_counters, &ctx->info, &ctx->head_counts, &ctx->run_start, &ctx->records, &ctx->run_cov,
-                     &ctx->rk_u, &ctx->rk_a, &ctx->rk_b, &ctx->tile_count, &ctx->tile_fill, &ctx->entries, &ctx->image};
+                     &ctx->sort_counters, &ctx->info, &ctx->records, &ctx->run_cov, &ctx->rk_u, &ctx->rk_a, &ctx->rk_b,
+                     &ctx->blk_edge, &ctx->runs_scratch, &ctx->tile_first_run, &ctx->row_tab, &ctx->span_key, &ctx->span_cov,
+                     &ctx->image};
     for (DevBuf* b : all) b->release();
     for (int s = 0; s < ST_COUNT; s++) { (void)hipEventDestroy(ctx->ev0[s]); (void)hipEventDestroy(ctx->ev1[s]); }
     for (int p = 0; p < MAX_PASS_EVENTS; p++) { (void)hipEventDestroy(ctx->pev0[p]); (void)hipEventDestroy(ctx->pev1[p]); }

@@ -47,13 +47,13 @@ struct FrameInfo {
     uint32_t pad[3];
 };
 
-// one painted (tile, layer) pair.  key = (layer << 32) | record index.
+// one run of the sorted stream = one painted (tile, layer) pair that owns pixel segments
 struct TileRecord {          // 32 B
     uint32_t cover[4];       // carry-in cover, 16 x i8 (little-endian bytes = local_y 0..15)
-    uint32_t seg_start;      // first segment of the run in the sorted stream (0 for carry-only)
-    uint32_t seg_count;      // 0 = carry-only
+    uint32_t seg_start;      // first segment of the run in the sorted stream
+    uint32_t seg_count;
     uint32_t layer;
-    uint32_t tile;           // ty * tiles_w + tx  (debug / validation)
+    uint32_t tile;           // v >> 41 = ((tile_y + 1) << 12) | (tile_x + 1)
 };
 
 struct PaintParams {
@@ -115,19 +115,24 @@ const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a
                                   hipEvent_t* pass_ev0, hipEvent_t* pass_ev1);
 
 // paint.hip
-void launch_find_bounds(hipStream_t s, const uint64_t* sorted, uint32_t n, uint32_t tiles_h, FrameInfo* info);
-// run detection: writes run_start[J] (+ sentinel), J -> info->n_runs.  head_counts: per-block scratch.
-void launch_runs(hipStream_t s, const uint64_t* sorted, const FrameInfo* info_in, uint32_t n, uint32_t* head_counts,
-                 uint32_t* scan_tmp, uint32_t* run_start, FrameInfo* info);
-void launch_run_covers(hipStream_t s, const uint64_t* sorted, const uint32_t* run_start, uint32_t n_runs,
-                       TileRecord* records, uint4* run_cov, uint64_t* run_keys, uint32_t tiles_w);
-// fill = 0: write carry-ins and count (tile, layer) pairs per tile; fill = 1: write the entries.
-// records[0..record_cap) are run records, records[record_cap..2*record_cap) carry-only (span) records.
-void launch_carry(hipStream_t s, const uint64_t* sorted_run_keys, uint32_t n_runs, TileRecord* records,
-                  const uint4* run_cov, const uint32_t* style_offsets, const uint32_t* style_words, uint32_t n_orders,
-                  uint32_t tiles_w, uint32_t tiles_h, uint32_t* tile_count, FrameInfo* info, int fill,
-                  const uint32_t* tile_off, uint32_t* tile_fill, uint64_t* entries, uint32_t record_cap);
-void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const uint32_t* tile_off,
-                  uint64_t* entries, const TileRecord* records, const uint32_t* style_offsets,
+struct BlkEdge {             // what a k_runs tile contributes to a run that started before it
+    uint32_t cov[4];         // cover sum (16 x i8) of the segments before the tile's first key change
+    uint32_t cnt;            // their number
+    uint32_t has_boundary;   // 0: the whole tile is one run's interior
+    uint32_t pad[2];
+};
+size_t runs_scratch_words(size_t n);
+size_t runs_blocks(size_t n);
+// run detection + per-run cover sums; row_tab = [row_count | row_span_lo | row_span_cnt], (tiles_h + 1) words each
+void launch_runs(hipStream_t s, const uint64_t* sorted, uint32_t n, uint32_t tiles_w, uint32_t tiles_h, TileRecord* records,
+                 uint4* run_cov, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge, uint32_t* row_tab,
+                 uint32_t* scratch, FrameInfo* info);
+void launch_carry_rows(hipStream_t s, const uint64_t* sorted_run_keys, TileRecord* records, uint4* run_cov,
+                       const BlkEdge* blk_edge, uint32_t n_blk, const uint32_t* style_offsets, const uint32_t* style_words,
+                       uint32_t n_orders, uint32_t tiles_w, uint32_t tiles_h, const uint32_t* row_count,
+                       uint32_t* row_span_lo, uint32_t* row_span_cnt, uint64_t* span_key, uint4* span_cov, FrameInfo* info);
+void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, uint32_t n_runs,
+                  const uint32_t* tile_first_run, const uint32_t* row_span_lo, const uint32_t* row_span_cnt,
+                  const uint64_t* span_key, const uint4* span_cov, const uint32_t* style_offsets,
                   const uint32_t* style_words, const forma_image_t* images, const uint16_t* texels, uint8_t* image,
                   FrameInfo* info);

@@ -13,250 +13,372 @@
 #include "common.h"
 
 // ================================================================================================
-// bounds of the paintable part of the sorted stream (painter/mod.rs:731-734: tile_y < 0 dropped;
-// rows >= tiles_h are never visited)
+// helpers
 // ================================================================================================
-__global__ void k_find_bounds(const uint64_t* __restrict__ sorted, uint32_t n, uint32_t tiles_h, FrameInfo* info) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint32_t lo = 0, hi = n;
-    while (lo < hi) { uint32_t m = (lo + hi) >> 1; if ((sorted[m] >> 53) >= 1u) hi = m; else lo = m + 1; }
-    info->seg_begin = lo;
-    hi = n;
-    while (lo < hi) { uint32_t m = (lo + hi) >> 1; if ((sorted[m] >> 53) >= (uint64_t)tiles_h + 1u) hi = m; else lo = m + 1; }
-    info->seg_end = lo;
+typedef __attribute__((address_space(1))) unsigned int gu32;
+__device__ __forceinline__ uint32_t ld_relaxed(const uint32_t* p) {
+    return __hip_atomic_load((gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-void launch_find_bounds(hipStream_t s, const uint64_t* sorted, uint32_t n, uint32_t tiles_h, FrameInfo* info) {
-    hipLaunchKernelGGL(k_find_bounds, dim3(1), dim3(64), 0, s, sorted, n, tiles_h, info);
+__device__ __forceinline__ void st_relaxed(uint32_t* p, uint32_t v) {
+    __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-
-// ================================================================================================
-// runs: maximal runs of equal 44-bit key (tile_y, tile_x, layer) in the sorted stream
-// ================================================================================================
-#define RUN_THREADS 256
-#define RUN_ITEMS   8
-#define RUN_TILE    (RUN_THREADS * RUN_ITEMS)
-
-__device__ __forceinline__ uint32_t wave_inc_scan(uint32_t v) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(v, d, 64); if (lane >= d) v += t; }
-    return v;
-}
-
-template <bool WRITE>
-__global__ __launch_bounds__(RUN_THREADS) void k_run_heads(const uint64_t* __restrict__ sorted,
-                                                           const FrameInfo* __restrict__ info,
-                                                           uint32_t* __restrict__ head_counts,
-                                                           uint32_t* __restrict__ run_start) {
-    __shared__ uint32_t lds[RUN_THREADS / 64];
-    const uint32_t sb = info->seg_begin, se = info->seg_end;
-    const uint32_t base = blockIdx.x * RUN_TILE + threadIdx.x * RUN_ITEMS;
-    uint32_t flags = 0, cnt = 0;
-    if (base < se && base + RUN_ITEMS > sb) {
-        uint64_t prev = (base > sb && base > 0) ? seg_key(sorted[base - 1]) : ~0ull;
-#pragma unroll
-        for (int i = 0; i < RUN_ITEMS; i++) {
-            uint32_t idx = base + i;
-            if (idx >= sb && idx < se) {
-                uint64_t k = seg_key(sorted[idx]);
-                if (idx == sb || k != prev) { flags |= 1u << i; cnt++; }
-                prev = k;
-            }
-        }
-    }
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t inc = wave_inc_scan(cnt);
-    if (lane == 63) lds[w] = inc;
-    __syncthreads();
-    uint32_t wbase = 0, tot = 0;
-#pragma unroll
-    for (int i = 0; i < RUN_THREADS / 64; i++) { uint32_t t = lds[i]; if (i < w) wbase += t; tot += t; }
-    if (!WRITE) {
-        if (threadIdx.x == 0) head_counts[blockIdx.x] = tot;
-    } else {
-        uint32_t r = head_counts[blockIdx.x] + wbase + inc - cnt;      // head_counts now holds exclusive block offsets
-#pragma unroll
-        for (int i = 0; i < RUN_ITEMS; i++) {
-            uint32_t idx = base + i;
-            if (flags & (1u << i)) run_start[r++] = idx;
-            if (idx + 1 == se && idx >= sb) run_start[r] = se;          // sentinel run_start[J]
-        }
-    }
-}
-
-// single-block exclusive scan of per-block head counts, total -> info->n_runs
-__global__ __launch_bounds__(1024) void k_scan_heads(uint32_t* __restrict__ v, uint32_t nb, FrameInfo* info) {
-    __shared__ uint32_t lds[16];
-    __shared__ uint32_t s_carry;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (uint32_t base = 0; base < nb; base += 1024) {
-        uint32_t idx = base + threadIdx.x;
-        uint32_t x = idx < nb ? v[idx] : 0;
-        uint32_t inc = wave_inc_scan(x);
-        if (lane == 63) lds[w] = inc;
-        __syncthreads();
-        uint32_t wbase = 0, tot = 0;
-#pragma unroll
-        for (int i = 0; i < 16; i++) { uint32_t t = lds[i]; if (i < w) wbase += t; tot += t; }
-        if (idx < nb) v[idx] = s_carry + wbase + inc - x;
-        __syncthreads();
-        if (threadIdx.x == 0) s_carry += tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) info->n_runs = s_carry;
-}
-
-void launch_runs(hipStream_t s, const uint64_t* sorted, const FrameInfo* info_in, uint32_t n, uint32_t* head_counts,
-                 uint32_t* scan_tmp, uint32_t* run_start, FrameInfo* info) {
-    (void)scan_tmp;
-    if (n == 0) { hipMemsetAsync(&info->n_runs, 0, 4, s); return; }
-    uint32_t nb = (n + RUN_TILE - 1) / RUN_TILE;
-    hipLaunchKernelGGL(k_run_heads<false>, dim3(nb), dim3(RUN_THREADS), 0, s, sorted, info_in, head_counts, run_start);
-    hipLaunchKernelGGL(k_scan_heads, dim3(1), dim3(1024), 0, s, head_counts, nb, info);
-    hipLaunchKernelGGL(k_run_heads<true>, dim3(nb), dim3(RUN_THREADS), 0, s, sorted, info_in, head_counts, run_start);
-}
-
-// ================================================================================================
-// per-run cover sums (16 x i8, wrapping) — the quantity LayerWorkbench::cover_carry accumulates
-// (layer_workbench/mod.rs:213-234) — plus the (tile_y, layer, run) keys for the carry scan order
-// ================================================================================================
 __device__ __forceinline__ uint64_t swar_add8(uint64_t a, uint64_t b) {      // 8 wrapping i8 adds
     return ((a & 0x7F7F7F7F7F7F7F7Full) + (b & 0x7F7F7F7F7F7F7F7Full)) ^ ((a ^ b) & 0x8080808080808080ull);
 }
-
-__global__ __launch_bounds__(256) void k_run_covers(const uint64_t* __restrict__ sorted,
-                                                    const uint32_t* __restrict__ run_start, uint32_t n_runs,
-                                                    TileRecord* __restrict__ records, uint4* __restrict__ run_cov,
-                                                    uint64_t* __restrict__ run_keys, uint32_t tiles_w) {
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_runs; j += gridDim.x * blockDim.x) {
-        uint32_t s0 = run_start[j], s1 = run_start[j + 1];
-        uint64_t lo = 0, hi = 0;
-        uint64_t first = sorted[s0];
-        for (uint32_t s = s0; s < s1; s++) {
-            uint64_t v = s == s0 ? first : sorted[s];
-            int ly = seg_ly(v);
-            uint64_t add = (uint64_t)((uint32_t)seg_cover(v) & 0xFFu) << ((ly & 7) * 8);
-            if (ly < 8) lo = swar_add8(lo, add); else hi = swar_add8(hi, add);
-        }
-        TileRecord r;
-        run_cov[j] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
-        r.cover[0] = r.cover[1] = r.cover[2] = r.cover[3] = 0;           // carry-in, filled by k_carry
-        r.seg_start = s0; r.seg_count = s1 - s0; r.layer = seg_layer(first);
-        uint32_t ty = (uint32_t)(first >> 53) - 1u, txb = (uint32_t)(first >> 41) & 0xFFFu;   // txb = tile_x + 1
-        r.tile = ty * tiles_w + (txb - 1u);                                                   // meaningless for txb == 0
-        records[j] = r;
-        run_keys[j] = ((first >> 53) << 53) | ((uint64_t)seg_layer(first) << 32) | j;
-    }
+// add one segment's cover to the 16 x i8 accumulator (lo = local_y 0..7, hi = 8..15): acc_cover semantics of
+// LayerWorkbench::cover_carry (layer_workbench/mod.rs:213-234)
+__device__ __forceinline__ void acc_seg_cover(uint64_t v, uint64_t& lo, uint64_t& hi) {
+    const int ly = seg_ly(v);
+    const uint64_t add = (uint64_t)((uint32_t)seg_cover(v) & 0xFFu) << ((ly & 7) * 8);
+    if (ly < 8) lo = swar_add8(lo, add); else hi = swar_add8(hi, add);
 }
-void launch_run_covers(hipStream_t s, const uint64_t* sorted, const uint32_t* run_start, uint32_t n_runs,
-                       TileRecord* records, uint4* run_cov, uint64_t* run_keys, uint32_t tiles_w) {
-    if (n_runs == 0) return;
-    uint32_t blocks = (n_runs + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(k_run_covers, dim3(blocks), dim3(256), 0, s, sorted, run_start, n_runs, records, run_cov, run_keys, tiles_w);
+__device__ __forceinline__ bool seg_paintable(uint64_t v, uint32_t tiles_w, uint32_t tiles_h) {
+    // painter/mod.rs:731-734 drops tile_y < 0; rows >= tiles_h and tiles right of the canvas are never visited
+    // (:524-538); tile_x == -1 (stored 0) is the left-of-canvas bucket that only feeds the carry (:500-522)
+    const uint32_t tyb = (uint32_t)(v >> 53), txb = (uint32_t)(v >> 41) & 0xFFFu;
+    return tyb >= 1u && tyb <= tiles_h && txb <= tiles_w;
 }
-
-// ================================================================================================
-// carry pre-pass.  Runs arrive ordered by (tile_y, layer, tile_x) — `sorted_keys` is run_keys after a
-// stable radix sort on bits 32..63.  The head of each (tile_y, layer) group walks the group:
-//   carry-in(run)   = wrapping sum of the covers of all runs of the group with smaller tile_x
-//                     (painter/mod.rs:500-522 for the left-of-canvas bucket; layer_workbench :325-333)
-//   a carry survives a tile boundary only if !Cover::is_empty(fill_rule) (painter/mod.rs:187-198)
-//   tiles strictly between two runs of the group are "carry-only" tiles (span records).
-// Pass 0 (fill = 0) counts the (tile, layer) pairs per tile; pass 1 writes the entries.
-// ================================================================================================
-__device__ __forceinline__ bool cover_is_empty(uint64_t lo, uint64_t hi, bool even_odd) {
+__device__ __forceinline__ bool cover_is_empty(uint64_t lo, uint64_t hi, bool even_odd) {   // painter/mod.rs:187-198
     if (!even_odd) return (lo | hi) == 0;
-    // all (|c| & 31) == 0  <=>  c mod 32 == 0 for every byte
-    return ((lo | hi) & 0x1F1F1F1F1F1F1F1Full) == 0;
+    return ((lo | hi) & 0x1F1F1F1F1F1F1F1Full) == 0;      // all (|c| & 31) == 0  <=>  c mod 32 == 0 for every byte
 }
 
-__global__ __launch_bounds__(256) void k_carry(const uint64_t* __restrict__ sorted_keys, uint32_t n_runs,
-                                               TileRecord* __restrict__ records, const uint4* __restrict__ run_cov,
-                                               const uint32_t* __restrict__ style_offsets,
-                                               const uint32_t* __restrict__ style_words, uint32_t n_orders,
-                                               uint32_t tiles_w, uint32_t tiles_h, uint32_t* __restrict__ tile_count,
-                                               FrameInfo* __restrict__ info, int fill,
-                                               const uint32_t* __restrict__ tile_off, uint32_t* __restrict__ tile_fill,
-                                               uint64_t* __restrict__ entries, uint32_t record_cap) {
-    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_runs; k += gridDim.x * blockDim.x) {
-        uint64_t key = sorted_keys[k];
-        uint32_t group = (uint32_t)(key >> 32);
-        if (k > 0 && (uint32_t)(sorted_keys[k - 1] >> 32) == group) continue;     // not a group head
-        uint32_t layer = group & 0x1FFFFFu;
-        uint32_t ty = (group >> 21) - 1u;                                          // rows >= 0 only (bounds)
-        bool even_odd = false;
-        if (layer < n_orders && style_offsets[layer] != FORMA_NONE)
-            even_odd = FORMA_STYLE_EVENODD(style_words[style_offsets[layer]]);
-        else if (fill == 0) atomicOr(&info->error, 1u);
-        uint64_t acc_lo = 0, acc_hi = 0;
-        uint32_t kk = k;
-        uint32_t j = (uint32_t)key;
-        while (true) {
-            TileRecord* r = &records[j];
-            int tx = (int)(r->tile - ty * tiles_w);                               // signed tile_x (-1 = left of canvas)
-            const uint4 own = run_cov[j];
-            uint64_t own_lo = (uint64_t)own.x | ((uint64_t)own.y << 32), own_hi = (uint64_t)own.z | ((uint64_t)own.w << 32);
-            if (fill == 0) {                                                      // carry-in of this run's tile
-                r->cover[0] = (uint32_t)acc_lo; r->cover[1] = (uint32_t)(acc_lo >> 32);
-                r->cover[2] = (uint32_t)acc_hi; r->cover[3] = (uint32_t)(acc_hi >> 32);
-            }
-            acc_lo = swar_add8(acc_lo, own_lo); acc_hi = swar_add8(acc_hi, own_hi);
-            bool empty = cover_is_empty(acc_lo, acc_hi, even_odd);
-            if (empty) { acc_lo = 0; acc_hi = 0; }                                 // dropped carry (mod.rs:335-339)
-            // own (tile, layer) entry
-            if (tx >= 0 && tx < (int)tiles_w) {
-                uint32_t tile = ty * tiles_w + (uint32_t)tx;
-                if (fill == 0) atomicAdd(&tile_count[tile], 1u);
-                else entries[tile_off[tile] + atomicAdd(&tile_fill[tile], 1u)] = ((uint64_t)layer << 32) | j;
-            }
-            // next run of the group
-            uint32_t nj = 0; int ntx = (int)tiles_w; bool more = false;
-            if (kk + 1 < n_runs) {
-                uint64_t nk = sorted_keys[kk + 1];
-                if ((uint32_t)(nk >> 32) == group) {
-                    more = true; nj = (uint32_t)nk;
-                    const TileRecord* nr = &records[nj];
-                    ntx = (int)(nr->tile - ty * tiles_w);
-                }
-            }
-            int span_lo = tx + 1 > 0 ? tx + 1 : 0;
-            int span_hi = ntx < (int)tiles_w ? ntx : (int)tiles_w;                 // exclusive
-            if (!empty && span_lo < span_hi) {
-                uint32_t rec = 0;
-                if (fill) {
-                    rec = atomicAdd(&info->n_spans, 1u);
-                    TileRecord sr;
-                    sr.cover[0] = (uint32_t)acc_lo; sr.cover[1] = (uint32_t)(acc_lo >> 32);
-                    sr.cover[2] = (uint32_t)acc_hi; sr.cover[3] = (uint32_t)(acc_hi >> 32);
-                    sr.seg_start = 0; sr.seg_count = 0; sr.layer = layer; sr.tile = ty * tiles_w + (uint32_t)span_lo;
-                    rec += record_cap;                                             // span records live after the run records
-                    records[rec] = sr;
-                }
-                for (int t = span_lo; t < span_hi; t++) {
-                    uint32_t tile = ty * tiles_w + (uint32_t)t;
-                    if (fill == 0) atomicAdd(&tile_count[tile], 1u);
-                    else entries[tile_off[tile] + atomicAdd(&tile_fill[tile], 1u)] = ((uint64_t)layer << 32) | rec;
-                }
-            }
-            if (!more) break;
-            kk++; j = nj;
+// ================================================================================================
+// runs: maximal runs of equal 44-bit key (tile_y, tile_x, layer) in the sorted stream, found in ONE
+// pass (chained scan with look-back for the run index).  Per run: record {first segment, count, layer,
+// tile}, the wrapping i8 cover sum per pixel row (what LayerWorkbench::cover_carry accumulates), and
+// the (tile_y, layer | run) key the carry scan is ordered by.  Cover sums need no atomics: every thread
+// owns 8 consecutive segments, publishes the partial that precedes its first key change ("edge") and
+// the thread that owns a run's head walks the following edges until the next key change.
+// ================================================================================================
+#define RN_THREADS 256
+#define RN_IPT     8
+#define RN_TILE    (RN_THREADS * RN_IPT)
+#define RUN_OPEN   0x80000000u          // seg_count flag: the run continues past its workgroup's tile
+#define RN_ROWS    64                   // tile rows a workgroup aggregates in LDS before touching row_count[]
+
+#define SEGIDX(i) ((i) + ((i) >> 3))    // LDS skew: 8 consecutive u64 per lane at a 72-byte lane stride (no bank conflicts)
+
+__global__ __launch_bounds__(RN_THREADS) void k_runs(const uint64_t* __restrict__ sorted, uint32_t n, uint32_t tiles_w,
+                                                     uint32_t tiles_h, TileRecord* __restrict__ records,
+                                                     uint4* __restrict__ run_cov, uint64_t* __restrict__ run_keys,
+                                                     uint32_t* __restrict__ tile_first_run,
+                                                     BlkEdge* __restrict__ blk_edge, uint32_t* __restrict__ row_count,
+                                                     uint32_t* __restrict__ status, uint32_t* __restrict__ ticket,
+                                                     FrameInfo* __restrict__ info) {
+    __shared__ uint64_t s_seg[SEGIDX(RN_TILE) + 2];           // [0] = element before the tile, tile at 1 + SEGIDX(i)
+    __shared__ uint64_t s_elo[RN_THREADS], s_ehi[RN_THREADS];
+    __shared__ uint32_t s_ecnt[RN_THREADS], s_hasb[RN_THREADS];
+    __shared__ uint32_t s_w[RN_THREADS / 64];
+    __shared__ uint32_t s_rows[RN_ROWS];
+    __shared__ uint32_t s_tile, s_j0, s_row0;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t ntiles = (n + RN_TILE - 1) / RN_TILE;
+    while (true) {
+        if (tid == 0) { s_tile = atomicAdd(ticket, 1u); s_row0 = 0xFFFFFFFFu; }
+        if (tid < RN_ROWS) s_rows[tid] = 0;
+        __syncthreads();
+        const uint32_t tile = s_tile;
+        if (tile >= ntiles) break;
+        const uint32_t base = tile * RN_TILE;
+#pragma unroll
+        for (int r = 0; r < RN_IPT; r++) {
+            const uint32_t p = r * RN_THREADS + tid, idx = base + p;
+            s_seg[1 + SEGIDX(p)] = idx < n ? sorted[idx] : 0ull;        // padding: tile row -1, unpaintable, closes the last run
         }
+        if (tid == 0) s_seg[0] = base > 0 ? sorted[base - 1] : ~0ull;
+        __syncthreads();
+        // ---- pass 1: boundaries, paintable heads, the partial before the first boundary --------------------
+        const uint32_t t0 = tid * RN_IPT;
+        uint64_t pk = (tid == 0 ? s_seg[0] : s_seg[1 + SEGIDX(t0 - 1)]) >> SEG_KEY_SHIFT;
+        uint64_t lo = 0, hi = 0, e_lo = 0, e_hi = 0;
+        uint32_t cnt = 0, e_cnt = 0, nb = 0, nvh = 0;
+#pragma unroll
+        for (int q = 0; q < RN_IPT; q++) {
+            const uint64_t v = s_seg[1 + SEGIDX(t0 + q)];
+            const uint64_t key = v >> SEG_KEY_SHIFT;
+            if (key != pk || base + t0 + q == 0) {
+                if (nb == 0) { e_lo = lo; e_hi = hi; e_cnt = cnt; }
+                lo = 0; hi = 0; cnt = 0; nb++;
+                if (seg_paintable(v, tiles_w, tiles_h)) {
+                    nvh++;
+                    const uint32_t row = (uint32_t)(v >> 53) - 1u;
+                    atomicMin(&s_row0, row);
+                }
+            }
+            acc_seg_cover(v, lo, hi); cnt++;
+            pk = key;
+        }
+        if (nb == 0) { e_lo = lo; e_hi = hi; e_cnt = cnt; }
+        s_elo[tid] = e_lo; s_ehi[tid] = e_hi; s_ecnt[tid] = e_cnt; s_hasb[tid] = nb;
+        uint32_t inc = nvh;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+#pragma unroll
+        for (int i = 0; i < RN_THREADS / 64; i++) { uint32_t t = s_w[i]; if (i < w) wbase += t; tot += t; }
+        if (tid == 0) {                                   // run-index look-back
+            uint32_t excl = 0;
+            if (tile > 0) {
+                st_relaxed(&status[tile], (1u << 30) | tot);
+                uint32_t p = tile - 1, spins = 0;
+                while (true) {
+                    const uint32_t sv = ld_relaxed(&status[p]);
+                    const uint32_t f = sv >> 30;
+                    if (f == 0) {
+                        if (++spins > (1u << 24)) { atomicOr(&info->error, 4u); break; }
+                        __builtin_amdgcn_s_sleep(1);
+                        continue;
+                    }
+                    excl += sv & 0x3FFFFFFFu;
+                    if (f == 2u || p == 0) break;
+                    p--;
+                }
+            }
+            st_relaxed(&status[tile], (2u << 30) | (excl + tot));
+            s_j0 = excl;
+            if (tile == ntiles - 1) info->n_runs = excl + tot;
+        }
+        if (tid == 64) {                                  // the tile's own edge: everything before its first boundary
+            uint64_t blo = 0, bhi = 0; uint32_t bc = 0, hb = 0;
+            for (int t = 0; t < RN_THREADS; t++) {
+                blo = swar_add8(blo, s_elo[t]); bhi = swar_add8(bhi, s_ehi[t]); bc += s_ecnt[t];
+                if (s_hasb[t]) { hb = 1; break; }
+            }
+            BlkEdge e;
+            e.cov[0] = (uint32_t)blo; e.cov[1] = (uint32_t)(blo >> 32); e.cov[2] = (uint32_t)bhi; e.cov[3] = (uint32_t)(bhi >> 32);
+            e.cnt = bc; e.has_boundary = hb; e.pad[0] = e.pad[1] = 0;
+            blk_edge[tile] = e;
+        }
+        __syncthreads();
+        // ---- pass 2: one record per paintable head ------------------------------------------------------------
+        uint32_t j = s_j0 + wbase + inc - nvh;
+        const uint32_t row0 = s_row0;
+        if (nvh) {
+            int q = 0;
+            while (q < RN_IPT) {
+                const uint64_t v = s_seg[1 + SEGIDX(t0 + q)];
+                const uint64_t key = v >> SEG_KEY_SHIFT;
+                const uint64_t pv = (t0 + q == 0) ? s_seg[0] : s_seg[1 + SEGIDX(t0 + q - 1)];
+                const bool first = base + t0 + q == 0;
+                if ((key != (pv >> SEG_KEY_SHIFT) || first) && seg_paintable(v, tiles_w, tiles_h)) {
+                    uint64_t rlo = 0, rhi = 0; uint32_t rc = 0;
+                    int q2 = q;
+                    do { acc_seg_cover(s_seg[1 + SEGIDX(t0 + q2)], rlo, rhi); rc++; q2++; }
+                    while (q2 < RN_IPT && (s_seg[1 + SEGIDX(t0 + q2)] >> SEG_KEY_SHIFT) == key);
+                    uint32_t open = 0;
+                    if (q2 == RN_IPT) {                   // the run reaches the end of this thread: walk the next edges
+                        int t2 = tid + 1;
+                        while (true) {
+                            if (t2 == RN_THREADS) { open = RUN_OPEN; break; }
+                            rlo = swar_add8(rlo, s_elo[t2]); rhi = swar_add8(rhi, s_ehi[t2]); rc += s_ecnt[t2];
+                            if (s_hasb[t2]) break;
+                            t2++;
+                        }
+                    }
+                    const uint32_t tyb = (uint32_t)(v >> 53), txb = (uint32_t)(v >> 41) & 0xFFFu, layer = seg_layer(v);
+                    TileRecord r;
+                    r.cover[0] = r.cover[1] = r.cover[2] = r.cover[3] = 0;      // carry-in, written by k_carry_rows
+                    r.seg_start = base + t0 + q; r.seg_count = rc | open; r.layer = layer; r.tile = (uint32_t)(v >> 41);
+                    records[j] = r;
+                    run_cov[j] = make_uint4((uint32_t)rlo, (uint32_t)(rlo >> 32), (uint32_t)rhi, (uint32_t)(rhi >> 32));
+                    run_keys[j] = ((uint64_t)tyb << 53) | ((uint64_t)layer << 32) | j;
+                    if (txb >= 1u && ((uint32_t)(pv >> 41) != (uint32_t)(v >> 41) || first))
+                        tile_first_run[(tyb - 1u) * tiles_w + (txb - 1u)] = j;
+                    const uint32_t rr = (tyb - 1u) - row0;
+                    if (rr < RN_ROWS) atomicAdd(&s_rows[rr], 1u); else atomicAdd(&row_count[tyb - 1u], 1u);
+                    j++;
+                    q = q2;
+                } else q++;
+            }
+        }
+        __syncthreads();
+        if (tid < RN_ROWS && s_rows[tid]) atomicAdd(&row_count[row0 + tid], s_rows[tid]);
+        __syncthreads();
     }
 }
 
-void launch_carry(hipStream_t s, const uint64_t* sorted_run_keys, uint32_t n_runs, TileRecord* records,
-                  const uint4* run_cov, const uint32_t* style_offsets, const uint32_t* style_words, uint32_t n_orders,
-                  uint32_t tiles_w, uint32_t tiles_h, uint32_t* tile_count, FrameInfo* info, int fill,
-                  const uint32_t* tile_off, uint32_t* tile_fill, uint64_t* entries, uint32_t record_cap) {
-    if (n_runs == 0) return;
-    uint32_t blocks = (n_runs + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(k_carry, dim3(blocks), dim3(256), 0, s, sorted_run_keys, n_runs, records, run_cov, style_offsets,
-                       style_words, n_orders, tiles_w, tiles_h, tile_count, info, fill, tile_off, tile_fill, entries,
-                       record_cap);
+size_t runs_scratch_words(size_t n) { return (n + RN_TILE - 1) / RN_TILE + 1 + 16; }
+size_t runs_blocks(size_t n) { return (n + RN_TILE - 1) / RN_TILE + 1; }
+
+void launch_runs(hipStream_t s, const uint64_t* sorted, uint32_t n, uint32_t tiles_w, uint32_t tiles_h, TileRecord* records,
+                 uint4* run_cov, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge, uint32_t* row_count,
+                 uint32_t* scratch, FrameInfo* info) {
+    // per-frame state: ticket + status words, first-run table (NONE), per-row run counts
+    const uint32_t ntiles = (n + RN_TILE - 1) / RN_TILE;
+    (void)hipMemsetAsync(scratch, 0, (16 + (size_t)ntiles + 1) * 4, s);
+    (void)hipMemsetAsync(tile_first_run, 0xFF, (size_t)tiles_w * tiles_h * 4, s);
+    (void)hipMemsetAsync(row_count, 0, (size_t)(tiles_h + 1) * 4 * 3, s);      // row_count | row_span_lo | row_span_cnt
+    if (n == 0) return;
+    uint32_t grid = ntiles < 2048 ? ntiles : 2048;
+    hipLaunchKernelGGL(k_runs, dim3(grid), dim3(RN_THREADS), 0, s, sorted, n, tiles_w, tiles_h, records, run_cov, run_keys,
+                       tile_first_run, blk_edge, row_count, scratch + 16, scratch, info);
+}
+
+// ================================================================================================
+// carry pre-pass: one 1024-lane workgroup per tile row.  The row's runs arrive ordered by
+// (layer, tile_x) (run_keys after a stable radix sort on the (tile_y, layer) bits).  A segmented scan of
+// the 16 x i8 cover sums over each (row, layer) group gives every run its carry-in:
+//   carry-in(run) = wrapping sum of the covers of all runs of the group with smaller tile_x
+//                   (painter/mod.rs:500-522 for the left-of-canvas bucket; layer_workbench/mod.rs:325-333)
+// and, where the carry-out is not empty (Cover::is_empty, painter/mod.rs:187-198), a SPAN record for the
+// tiles strictly between this run and the next one of the group ("carry-only" tiles: interior of shapes).
+// Dropping an empty carry (mod.rs:335-339) equals carrying it: NonZero drops only all-zero covers and
+// EvenOdd coverage only sees covers modulo 32.  Spans of a row are written in (layer, tile_x) order into
+// the row's own slice [row_first_run, row_first_run + n) of the span arrays, so no counter is shared.
+// ================================================================================================
+#define CR_THREADS 1024
+#define CR_WAVES   (CR_THREADS / 64)
+
+__global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __restrict__ sorted_keys,
+                                                           TileRecord* __restrict__ records,
+                                                           uint4* __restrict__ run_cov,
+                                                           const BlkEdge* __restrict__ blk_edge, uint32_t n_blk,
+                                                           const uint32_t* __restrict__ style_offsets,
+                                                           const uint32_t* __restrict__ style_words, uint32_t n_orders,
+                                                           uint32_t tiles_w, uint32_t tiles_h,
+                                                           const uint32_t* __restrict__ row_count,
+                                                           uint32_t* __restrict__ row_span_lo,
+                                                           uint32_t* __restrict__ row_span_cnt,
+                                                           uint64_t* __restrict__ span_key, uint4* __restrict__ span_cov,
+                                                           FrameInfo* __restrict__ info) {
+    __shared__ uint32_t s_red[CR_WAVES];
+    __shared__ uint64_t s_wlo[CR_WAVES], s_whi[CR_WAVES];
+    __shared__ uint32_t s_wflag[CR_WAVES], s_wspan[CR_WAVES];
+    __shared__ uint32_t s_group[CR_THREADS + 1], s_txb[CR_THREADS + 1];
+    __shared__ uint64_t s_clo, s_chi;                  // carry across chunks: inclusive acc of the last element
+    __shared__ uint32_t s_cgroup, s_spans;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t ty = blockIdx.x;
+    // first run of this row = sum of the run counts of the rows above
+    uint32_t part = 0;
+    for (uint32_t r = tid; r < ty; r += CR_THREADS) part += row_count[r];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
+    if (lane == 0) s_red[w] = part;
+    if (tid == 0) { s_clo = 0; s_chi = 0; s_cgroup = 0xFFFFFFFFu; s_spans = 0; }
+    __syncthreads();
+    uint32_t row_lo = 0;
+#pragma unroll
+    for (int i = 0; i < CR_WAVES; i++) row_lo += s_red[i];
+    const uint32_t cnt = row_count[ty];
+    if (tid == 0) row_span_lo[ty] = row_lo;
+    for (uint32_t c0 = 0; c0 < cnt; c0 += CR_THREADS) {
+        const uint32_t k = row_lo + c0 + tid;
+        const bool active = c0 + tid < cnt;
+        uint32_t group = 0xFFFFFFFEu, jrun = 0, txb = 0, layer = 0;
+        uint64_t own_lo = 0, own_hi = 0;
+        bool even_odd = false;
+        if (active) {
+            const uint64_t key = sorted_keys[k];
+            group = (uint32_t)(key >> 32); jrun = (uint32_t)key; layer = group & 0x1FFFFFu;
+            TileRecord* r = &records[jrun];
+            txb = r->tile & 0xFFFu;
+            uint4 oc = run_cov[jrun];
+            own_lo = (uint64_t)oc.x | ((uint64_t)oc.y << 32); own_hi = (uint64_t)oc.z | ((uint64_t)oc.w << 32);
+            uint32_t sc = r->seg_count;
+            if (sc & RUN_OPEN) {                         // complete a run that crosses k_runs tiles with their edges
+                sc &= ~RUN_OPEN;
+                for (uint32_t b = r->seg_start / RN_TILE + 1; b < n_blk; b++) {
+                    const BlkEdge e = blk_edge[b];
+                    own_lo = swar_add8(own_lo, (uint64_t)e.cov[0] | ((uint64_t)e.cov[1] << 32));
+                    own_hi = swar_add8(own_hi, (uint64_t)e.cov[2] | ((uint64_t)e.cov[3] << 32));
+                    sc += e.cnt;
+                    if (e.has_boundary) break;
+                }
+                r->seg_count = sc;
+            }
+            if (layer < n_orders && style_offsets[layer] != FORMA_NONE)
+                even_odd = FORMA_STYLE_EVENODD(style_words[style_offsets[layer]]);
+            else atomicOr(&info->error, 1u);
+        }
+        s_group[tid] = group; s_txb[tid] = txb;
+        if (tid == CR_THREADS - 1) {                     // the element after this chunk (for the last lane's span)
+            uint32_t ng = 0xFFFFFFFDu, nt = 0;
+            if (c0 + CR_THREADS < cnt) {
+                const uint64_t nk = sorted_keys[k + 1];
+                ng = (uint32_t)(nk >> 32); nt = records[(uint32_t)nk].tile & 0xFFFu;
+            }
+            s_group[CR_THREADS] = ng; s_txb[CR_THREADS] = nt;
+        }
+        __syncthreads();
+        const uint32_t prev_group = tid ? s_group[tid - 1] : s_cgroup;
+        const bool head = active && group != prev_group;
+        // ---- segmented inclusive scan of (lo, hi) over the chunk ----------------------------------------------
+        uint64_t lo = own_lo, hi = own_hi;
+        uint32_t f = head ? 1u : 0u;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t tl = __shfl_up(lo, d, 64), th = __shfl_up(hi, d, 64);
+            const uint32_t tf = __shfl_up(f, d, 64);
+            if (lane >= d) { if (!f) { lo = swar_add8(lo, tl); hi = swar_add8(hi, th); } f |= tf; }
+        }
+        if (lane == 63) { s_wlo[w] = lo; s_whi[w] = hi; s_wflag[w] = f; }
+        __syncthreads();
+        if (tid == 0) {                                   // wave carry-ins (serial over 16 waves), seeded by the chunk carry
+            uint64_t clo = s_clo, chi = s_chi;
+            for (int i = 0; i < CR_WAVES; i++) {
+                const uint64_t wl = s_wlo[i], wh = s_whi[i];
+                const uint32_t wf = s_wflag[i];
+                s_wlo[i] = clo; s_whi[i] = chi;
+                if (wf) { clo = wl; chi = wh; } else { clo = swar_add8(clo, wl); chi = swar_add8(chi, wh); }
+            }
+        }
+        __syncthreads();
+        if (!f) { lo = swar_add8(lo, s_wlo[w]); hi = swar_add8(hi, s_whi[w]); }     // lo/hi = inclusive carry-out
+        // carry-in = inclusive value of the previous element of the group
+        uint64_t pl = __shfl_up(lo, 1, 64), ph = __shfl_up(hi, 1, 64);
+        __syncthreads();                                  // s_wlo reused below: every wave has read its carry-in
+        if (lane == 63) { s_wlo[w] = lo; s_whi[w] = hi; }
+        __syncthreads();
+        if (lane == 0) {
+            if (w == 0) { pl = s_clo; ph = s_chi; } else { pl = s_wlo[w - 1]; ph = s_whi[w - 1]; }
+        }
+        if (head) { pl = 0; ph = 0; }
+        bool has_span = false;
+        uint32_t span_lo = 0, span_hi = 0;
+        if (active) {
+            TileRecord* r = &records[jrun];
+            r->cover[0] = (uint32_t)pl; r->cover[1] = (uint32_t)(pl >> 32);
+            r->cover[2] = (uint32_t)ph; r->cover[3] = (uint32_t)(ph >> 32);
+            const bool last = c0 + tid + 1 == cnt;
+            const bool same_next = !last && s_group[tid + 1] == group;
+            span_lo = txb;                                                  // tile_x + 1
+            span_hi = same_next ? s_txb[tid + 1] - 1u : tiles_w;            // exclusive; next tile_x = txb_next - 1
+            if (span_hi > tiles_w) span_hi = tiles_w;
+            has_span = !cover_is_empty(lo, hi, even_odd) && span_lo < span_hi;
+        }
+        // ordered compaction of the spans
+        const uint64_t bal = __ballot(has_span);
+        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        if (lane == 0) s_wspan[w] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t sbase = s_spans, stot = 0;
+#pragma unroll
+        for (int i = 0; i < CR_WAVES; i++) { const uint32_t t = s_wspan[i]; if (i < w) sbase += t; stot += t; }
+        if (has_span) {
+            const uint32_t si = row_lo + sbase + before;
+            span_key[si] = ((uint64_t)layer << 32) | ((uint64_t)span_lo << 16) | span_hi;
+            span_cov[si] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+        }
+        __syncthreads();
+        if (tid == CR_THREADS - 1) { s_clo = lo; s_chi = hi; s_cgroup = group; }   // only used when the chunk is full
+        if (tid == 0) s_spans += stot;
+        __syncthreads();
+    }
+    if (tid == 0) row_span_cnt[ty] = s_spans;
+}
+
+void launch_carry_rows(hipStream_t s, const uint64_t* sorted_run_keys, TileRecord* records, uint4* run_cov,
+                       const BlkEdge* blk_edge, uint32_t n_blk, const uint32_t* style_offsets, const uint32_t* style_words,
+                       uint32_t n_orders, uint32_t tiles_w, uint32_t tiles_h, const uint32_t* row_count,
+                       uint32_t* row_span_lo, uint32_t* row_span_cnt, uint64_t* span_key, uint4* span_cov, FrameInfo* info) {
+    if (tiles_h == 0) return;
+    hipLaunchKernelGGL(k_carry_rows, dim3(tiles_h), dim3(CR_THREADS), 0, s, sorted_run_keys, records, run_cov, blk_edge, n_blk,
+                       style_offsets, style_words, n_orders, tiles_w, tiles_h, row_count, row_span_lo, row_span_cnt, span_key,
+                       span_cov, info);
 }
 
 // ================================================================================================
@@ -563,21 +685,26 @@ __device__ __forceinline__ bool cover_full(const uint32_t* c, bool even_odd) {  
 }
 
 __global__ __launch_bounds__(256) void k_paint(PaintParams P, const uint64_t* __restrict__ sorted,
-                                               const uint32_t* __restrict__ tile_off, uint64_t* __restrict__ entries,
-                                               const TileRecord* __restrict__ records,
+                                               const TileRecord* __restrict__ records, uint32_t n_runs,
+                                               const uint32_t* __restrict__ tile_first_run,
+                                               const uint32_t* __restrict__ row_span_lo,
+                                               const uint32_t* __restrict__ row_span_cnt,
+                                               const uint64_t* __restrict__ span_key,
+                                               const uint4* __restrict__ span_cov,
                                                const uint32_t* __restrict__ style_offsets,
                                                const uint32_t* __restrict__ style_words,
                                                const forma_image_t* __restrict__ images,
                                                const uint16_t* __restrict__ texels, uint8_t* __restrict__ image,
                                                FrameInfo* __restrict__ info) {
     __shared__ uint64_t e_key[MAXE_LDS];
-    __shared__ uint64_t e_tmp[MAXE_LDS];
+    __shared__ uint64_t e_tmp[MAXE_LDS];      // [0, na) own runs, [MAXE_LDS - nb, MAXE_LDS) ... spans are appended from na
     __shared__ uint32_t e_flag[MAXE_LDS];
     __shared__ int cells[256];
     __shared__ uint32_t s_skipped, s_solid, s_solid_bytes;
+    __shared__ uint32_t s_wcnt[4];
 
     // XCD-aware tile mapping: consecutive workgroups land on different XCDs (block b -> XCD b % 8); give
-    // each XCD a contiguous band of tiles so a tile row's records/styles stay in one L2.
+    // each XCD a contiguous band of tiles so a tile row's records/spans/styles stay in one L2.
     const uint32_t T = P.tiles_w * P.tiles_h;
     uint32_t bid = blockIdx.x;
     uint32_t per = (T + 7) / 8;
@@ -588,10 +715,52 @@ __global__ __launch_bounds__(256) void k_paint(PaintParams P, const uint64_t* __
 
     const int tid = threadIdx.x;
     const int lx = tid & 15, ly = tid >> 4;
-    const uint32_t e0 = tile_off[tile], e1 = tile_off[tile + 1];
-    const uint32_t ne = e1 - e0;
+    const int lane = tid & 63, wv = tid >> 6;
 
-    // ---- sort this tile's (layer, record) entries by layer: rank sort (keys are unique per tile) --------
+    // ---- this tile's layer list (LayerWorkbench::populate_layers, layer_workbench/mod.rs:250-278):
+    //      its own runs (contiguous records, ascending layer) merged with the row's spans that cross it.
+    //      entry = (layer << 32) | ref, ref = run index, or 0x80000000 | span index ------------------------------
+    const uint32_t my_tile_key = ((ty + 1u) << 12) | (tx + 1u);
+    uint32_t na = 0;
+    {
+        const uint32_t j0 = tile_first_run[tile];
+        if (j0 != FORMA_NONE) {
+            for (uint32_t c = 0;; c += 256) {                          // a tile's runs are contiguous from j0
+                const uint32_t j = j0 + c + tid;
+                bool mine = false; uint32_t layer = 0;
+                if (j < n_runs) { const TileRecord* r = &records[j]; mine = r->tile == my_tile_key; layer = r->layer; }
+                if (mine && c + tid < MAXE_LDS) e_tmp[c + tid] = ((uint64_t)layer << 32) | j;
+                const uint32_t got = (uint32_t)__syncthreads_count(mine ? 1 : 0);
+                na += got;
+                if (got < 256u) break;
+            }
+        }
+    }
+    uint32_t nb = 0;
+    {
+        const uint32_t sb = row_span_lo[ty], sc = row_span_cnt[ty];
+        for (uint32_t c = 0; c < sc; c += 256) {
+            bool hit = false; uint64_t sk = 0;
+            if (c + tid < sc) {
+                sk = span_key[sb + c + tid];
+                const uint32_t lo = (uint32_t)(sk >> 16) & 0xFFFFu, hi = (uint32_t)sk & 0xFFFFu;
+                hit = tx >= lo && tx < hi;
+            }
+            const uint64_t bal = __ballot(hit);
+            if (lane == 0) s_wcnt[wv] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            uint32_t base = nb, tot = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { const uint32_t t = s_wcnt[i]; if (i < wv) base += t; tot += t; }
+            if (hit) {
+                const uint32_t pos = na + base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                if (pos < MAXE_LDS) e_tmp[pos] = (sk & 0xFFFFFFFF00000000ull) | 0x80000000u | (sb + c + tid);
+            }
+            nb += tot;
+            __syncthreads();
+        }
+    }
+    const uint32_t ne = na + nb;
     uint64_t* keys = e_key;
     uint32_t* flags = e_flag;
     if (ne > MAXE_LDS) {
@@ -599,12 +768,15 @@ __global__ __launch_bounds__(256) void k_paint(PaintParams P, const uint64_t* __
         if (tid == 0) atomicOr(&info->error, 2u);
         return;
     }
-    for (uint32_t i = tid; i < ne; i += 256) e_tmp[i] = entries[e0 + i];
-    __syncthreads();
+    // merge by layer: a (tile, layer) pair is either a run or a span, so layers are unique across both lists
     for (uint32_t i = tid; i < ne; i += 256) {
-        uint64_t k = e_tmp[i];
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < ne; j++) rank += e_tmp[j] < k ? 1u : 0u;      // broadcast LDS reads
+        const uint64_t k = e_tmp[i];
+        const uint32_t layer = (uint32_t)(k >> 32);
+        uint32_t lo, hi;                                            // # entries of the OTHER list with a smaller layer
+        if (i < na) { lo = na; hi = ne; } else { lo = 0; hi = na; }
+        const uint32_t other0 = lo;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)(e_tmp[mid] >> 32) < layer) lo = mid + 1; else hi = mid; }
+        const uint32_t rank = (i < na ? i : i - na) + (lo - other0);
         keys[rank] = k;
     }
     __syncthreads();
@@ -612,7 +784,7 @@ __global__ __launch_bounds__(256) void k_paint(PaintParams P, const uint64_t* __
     for (uint32_t i = tid; i < ne; i += 256) {
         uint64_t k = keys[i];
         uint32_t layer = (uint32_t)(k >> 32);
-        const TileRecord* r = &records[(uint32_t)k];
+        const uint32_t ref = (uint32_t)k;
         uint32_t f = EF_MASK;
         if (layer >= P.n_orders || style_offsets[layer] == FORMA_NONE) f |= EF_BAD;
         else {
@@ -620,8 +792,12 @@ __global__ __launch_bounds__(256) void k_paint(PaintParams P, const uint64_t* __
             uint32_t h = w[0];
             bool eo = FORMA_STYLE_EVENODD(h);
             if (eo) f |= EF_EVENODD;
-            if (r->seg_count) f |= EF_HAS_SEGS;
-            else if (cover_full(r->cover, eo)) f |= EF_FULL;
+            if (!(ref & 0x80000000u)) f |= EF_HAS_SEGS;                      // a run always owns segments
+            else {
+                const uint4 cv = span_cov[ref & 0x7FFFFFFFu];
+                const uint32_t c4[4] = {cv.x, cv.y, cv.z, cv.w};
+                if (cover_full(c4, eo)) f |= EF_FULL;
+            }
             if (FORMA_STYLE_IS_CLIP(h)) f |= EF_IS_CLIP;
             else {
                 if (FORMA_STYLE_CLIPPED(h)) f |= EF_CLIPPED;
@@ -725,16 +901,17 @@ __global__ __launch_bounds__(256) void k_paint(PaintParams P, const uint64_t* __
         if (!(f & EF_MASK) || (f & EF_BAD)) continue;
         const uint64_t k = keys[i];
         const uint32_t layer = (uint32_t)(k >> 32);
-        const TileRecord* r = &records[(uint32_t)k];
+        const uint32_t ref = (uint32_t)k;
         const uint32_t* w = style_words + style_offsets[layer];
         const uint32_t h = w[0];
-        int carry = (int)(int8_t)(r->cover[ly >> 2] >> ((ly & 3) * 8));
+        const uint32_t* cvp = (ref & 0x80000000u) ? (const uint32_t*)&span_cov[ref & 0x7FFFFFFFu] : records[ref].cover;
+        int carry = (int)(int8_t)(cvp[ly >> 2] >> ((ly & 3) * 8));
         int A;
-        const uint32_t nseg = r->seg_count;
+        const uint32_t nseg = (ref & 0x80000000u) ? 0u : records[ref].seg_count;
         if (nseg) {
             cells[tid] = 0;
             __syncthreads();
-            const uint64_t* sp = sorted + r->seg_start;
+            const uint64_t* sp = sorted + records[ref].seg_start;
             for (uint32_t s = tid; s < nseg; s += 256) {                    // acc_segment :257-271
                 uint64_t v = sp[s];
                 int cv = seg_cover(v);
@@ -791,13 +968,14 @@ __global__ __launch_bounds__(256) void k_paint(PaintParams P, const uint64_t* __
     }
 }
 
-void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const uint32_t* tile_off,
-                  uint64_t* entries, const TileRecord* records, const uint32_t* style_offsets,
+void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, uint32_t n_runs,
+                  const uint32_t* tile_first_run, const uint32_t* row_span_lo, const uint32_t* row_span_cnt,
+                  const uint64_t* span_key, const uint4* span_cov, const uint32_t* style_offsets,
                   const uint32_t* style_words, const forma_image_t* images, const uint16_t* texels, uint8_t* image,
                   FrameInfo* info) {
     uint32_t T = p.tiles_w * p.tiles_h;
     if (T == 0) return;
     uint32_t per = (T + 7) / 8;
-    hipLaunchKernelGGL(k_paint, dim3(per * 8), dim3(256), 0, s, p, sorted, tile_off, entries, records, style_offsets,
-                       style_words, images, texels, image, info);
+    hipLaunchKernelGGL(k_paint, dim3(per * 8), dim3(256), 0, s, p, sorted, records, n_runs, tile_first_run, row_span_lo,
+                       row_span_cnt, span_key, span_cov, style_offsets, style_words, images, texels, image, info);
 }
