@@ -3,6 +3,7 @@
 // a*b+c, every fused operation below is an explicit fmaf()/fma() exactly where the reference
 // writes `mul_add`.  All kernels are HBM/L2-bound integer + f32/f64 scalar work: no MFMA.
 #include "common.h"
+#include "lookback.h"
 
 #define WAVE 64
 
@@ -205,13 +206,6 @@ void launch_prepare_lines(hipStream_t s, const float* x, const float* y, const u
 #define PC_IPT     8
 #define PC_TILE    (PC_THREADS * PC_IPT)
 
-typedef __attribute__((address_space(1))) unsigned long long gu64;
-__device__ __forceinline__ uint64_t ld64_relaxed(const uint64_t* p) {
-    return __hip_atomic_load((gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st64_relaxed(uint64_t* p, uint64_t v) {
-    __hip_atomic_store((gu64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 
 __device__ __forceinline__ void mark_block_first(uint32_t* __restrict__ block_first, uint32_t bf_cap, uint32_t start,
                                                  uint32_t len, uint32_t c) {
@@ -266,27 +260,17 @@ __global__ __launch_bounds__(PC_THREADS) void k_prepare_compact(LineSource S, ui
             if (i < w) { bsum += s_wsum[i]; bcnt += s_wcnt[i]; }
             tsum += s_wsum[i]; tcnt += s_wcnt[i];
         }
-        if (tid == 0) {
-            uint64_t psum = 0, pcnt = 0;
+        if (w == 0) {                                     // wave-parallel look-back (lookback.h)
+            uint32_t pcnt = 0, psum = 0;
             if (tile > 0) {
-                st64_relaxed(&status[tile], (1ull << 62) | ((uint64_t)tcnt << 32) | tsum);
-                uint32_t p = tile - 1, spins = 0;
-                while (true) {
-                    const uint64_t v = ld64_relaxed(&status[p]);
-                    const uint32_t f = (uint32_t)(v >> 62);
-                    if (f == 0) {
-                        if (++spins > (1u << 24)) { atomicOr(&info->error, 4u); break; }
-                        __builtin_amdgcn_s_sleep(1);
-                        continue;
-                    }
-                    psum += (uint32_t)v; pcnt += (uint32_t)(v >> 32) & 0x3FFFFFFFu;
-                    if (f == 2 || p == 0) break;
-                    p--;
-                }
+                if (lane == 0) lb_st64(&status[tile], ((uint64_t)LB_AGG << 62) | ((uint64_t)tcnt << 32) | tsum);
+                lb_lookback_u64(status, tile, &info->error, &pcnt, &psum);
             }
-            st64_relaxed(&status[tile], (2ull << 62) | (((pcnt + tcnt) & 0x3FFFFFFFull) << 32) | (uint32_t)(psum + tsum));
-            s_psum = (uint32_t)psum; s_pcnt = (uint32_t)pcnt;
-            if (tile == ntiles - 1) { info->n_segments = (uint32_t)(psum + tsum); info->n_compact = (uint32_t)(pcnt + tcnt); }
+            if (lane == 0) {
+                lb_st64(&status[tile], ((uint64_t)LB_PREFIX << 62) | ((uint64_t)((pcnt + tcnt) & 0x3FFFFFFFu) << 32) | (uint32_t)(psum + tsum));
+                s_psum = psum; s_pcnt = pcnt;
+                if (tile == ntiles - 1) { info->n_segments = psum + tsum; info->n_compact = pcnt + tcnt; }
+            }
         }
         __syncthreads();
         uint32_t start = s_psum + bsum + isum - sum;
@@ -469,9 +453,13 @@ __global__ __launch_bounds__(RAS_THREADS) void k_rasterize(LineSource S, uint32_
     if (tid == 0) {
         uint32_t o = 0, oh = 0, a = 0xFFFFFFFFu, ah = 0xFFFFFFFFu, u = 0;
         for (int i = 0; i < RAS_THREADS / 64; i++) { o |= red[0][i]; oh |= red[1][i]; a &= red[2][i]; ah &= red[3][i]; u |= red[4][i]; }
-        atomicOr(&info->key_or, o); atomicOr(&info->key_or_hi, oh);
-        atomicAnd(&info->key_and, a); atomicAnd(&info->key_and_hi, ah);
-        if (u) atomicOr(&info->layer_unsorted, 1u);
+        // the masks saturate after a few workgroups: only touch the (single-address, serialising) atomics when this
+        // workgroup adds information; a stale read merely costs a redundant atomic
+        if (o & ~lb_ld32(&info->key_or)) atomicOr(&info->key_or, o);
+        if (oh & ~lb_ld32(&info->key_or_hi)) atomicOr(&info->key_or_hi, oh);
+        if (~a & lb_ld32(&info->key_and)) atomicAnd(&info->key_and, a);
+        if (~ah & lb_ld32(&info->key_and_hi)) atomicAnd(&info->key_and_hi, ah);
+        if (u && !lb_ld32(&info->layer_unsorted)) atomicOr(&info->layer_unsorted, 1u);
     }
 }
 

@@ -11,17 +11,11 @@
 // along x with DPP row shifts (a DPP row is exactly one 16-pixel tile row) and blends in fp32.
 // Built with -ffp-contract=off; every fused op is an explicit fmaf where the reference has mul_add.
 #include "common.h"
+#include "lookback.h"
 
 // ================================================================================================
 // helpers
 // ================================================================================================
-typedef __attribute__((address_space(1))) unsigned int gu32;
-__device__ __forceinline__ uint32_t ld_relaxed(const uint32_t* p) {
-    return __hip_atomic_load((gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_relaxed(uint32_t* p, uint32_t v) {
-    __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 __device__ __forceinline__ uint64_t swar_add8(uint64_t a, uint64_t b) {      // 8 wrapping i8 adds
     return ((a & 0x7F7F7F7F7F7F7F7Full) + (b & 0x7F7F7F7F7F7F7F7Full)) ^ ((a ^ b) & 0x8080808080808080ull);
 }
@@ -119,27 +113,17 @@ __global__ __launch_bounds__(RN_THREADS) void k_runs(const uint64_t* __restrict_
         uint32_t wbase = 0, tot = 0;
 #pragma unroll
         for (int i = 0; i < RN_THREADS / 64; i++) { uint32_t t = s_w[i]; if (i < w) wbase += t; tot += t; }
-        if (tid == 0) {                                   // run-index look-back
+        if (w == 0) {                                     // run-index look-back, wave-parallel (lookback.h)
             uint32_t excl = 0;
             if (tile > 0) {
-                st_relaxed(&status[tile], (1u << 30) | tot);
-                uint32_t p = tile - 1, spins = 0;
-                while (true) {
-                    const uint32_t sv = ld_relaxed(&status[p]);
-                    const uint32_t f = sv >> 30;
-                    if (f == 0) {
-                        if (++spins > (1u << 24)) { atomicOr(&info->error, 4u); break; }
-                        __builtin_amdgcn_s_sleep(1);
-                        continue;
-                    }
-                    excl += sv & 0x3FFFFFFFu;
-                    if (f == 2u || p == 0) break;
-                    p--;
-                }
+                if (lane == 0) lb_st32(&status[tile], (LB_AGG << 30) | tot);
+                excl = lb_lookback_u32(status, tile, &info->error);
             }
-            st_relaxed(&status[tile], (2u << 30) | (excl + tot));
-            s_j0 = excl;
-            if (tile == ntiles - 1) info->n_runs = excl + tot;
+            if (lane == 0) {
+                lb_st32(&status[tile], (LB_PREFIX << 30) | (excl + tot));
+                s_j0 = excl;
+                if (tile == ntiles - 1) info->n_runs = excl + tot;
+            }
         }
         if (tid == 64) {                                  // the tile's own edge: everything before its first boundary
             uint64_t blo = 0, bhi = 0; uint32_t bc = 0, hb = 0;

@@ -20,39 +20,30 @@
 //     a smaller ticket, which are already running — forward progress does not depend on dispatch
 //     order (guide: "HIP promises nothing about dispatch order").
 #include "common.h"
+#include "lookback.h"
 
 #define OS_THREADS 512
 #define OS_WAVES   (OS_THREADS / 64)
 #define OS_KPT     16                               // keys per lane
-#define OS_TILE    (OS_THREADS * OS_KPT)            // 8192 keys per tile -> 64 KiB of LDS staging
-#define ST_AGG     1u                               // status flag: tile aggregate published
-#define ST_PREFIX  2u                               // status flag: inclusive prefix published
+#define OS_TILE    (OS_THREADS * OS_KPT)            // 8192 keys per tile -> 64 KiB of LDS staging, 2 workgroups per CU
 #define ST_VALMASK 0x3FFFFFFFu
-#define SPIN_LIMIT (1u << 24)
+#define OS_LBW     8                                // predecessor tiles examined per look-back probe
 
-typedef __attribute__((address_space(1))) unsigned int gu32;
-
-__device__ __forceinline__ uint32_t ld_relaxed(const uint32_t* p) {
-    return __hip_atomic_load((gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_relaxed(uint32_t* p, uint32_t v) {
-    __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// lanes of this wave whose BITS-bit digit equals mine
+// lanes of this wave whose BITS-bit digit equals mine, as two 32-bit halves.  Per digit bit: one sign-extending
+// bit-field extract, one compare (the ballot) and one 3-input boolean op per half — `m & ~(ballot ^ -bit)`.
 template <int BITS>
-__device__ __forceinline__ uint64_t match_any(uint32_t dg) {
-    uint64_t m = ~0ull;
+__device__ __forceinline__ void match_any(uint32_t dg, uint32_t& mlo, uint32_t& mhi) {
+    mlo = ~0u; mhi = ~0u;
 #pragma unroll
     for (int b = 0; b < BITS; b++) {
-        const bool bit = (dg >> b) & 1u;
-        const uint64_t bal = __ballot(bit);
-        m &= bit ? bal : ~bal;
+        const uint32_t nb = (uint32_t)(-(int32_t)((dg >> b) & 1u));       // 0 or 0xFFFFFFFF
+        const uint64_t bal = __ballot(nb != 0u);
+        mlo &= ~((uint32_t)bal ^ nb);
+        mhi &= ~((uint32_t)(bal >> 32) ^ nb);
     }
-    return m;
 }
-__device__ __forceinline__ uint32_t lanes_below(uint64_t m) {          // popcount(m & lanemask_lt)
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+__device__ __forceinline__ uint32_t lanes_below(uint32_t mlo, uint32_t mhi) {          // popcount(m & lanemask_lt)
+    return __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -76,22 +67,27 @@ __global__ __launch_bounds__(HS_THREADS) void k_sort_hist(const uint64_t* __rest
 #pragma unroll
         for (int j = 0; j < HS_KPT; j++) {
             uint32_t idx = base + j * HS_THREADS;
-            k[j] = idx < n ? in[idx] : ~0ull;
+            k[j] = idx < n ? in[idx] : 0ull;
         }
-        const uint32_t nv = (base < n) ? min((uint32_t)HS_KPT, (n - base + HS_THREADS - 1) / HS_THREADS) : 0u;
+        // Lane-adjacent run-length compression, then one LDS atomic per run: consecutive segments mostly share
+        // their tile digits, and 64 lanes adding to one LDS word would serialise.
+        const int lane = threadIdx.x & 63;
         for (int p = 0; p < P; p++) {
             const int sh = plan.shift[p];
             const uint32_t mk = plan.mask[p];
-            uint32_t cur = 0, cnt = 0;
 #pragma unroll
             for (int j = 0; j < HS_KPT; j++) {
-                if ((uint32_t)j < nv) {
-                    uint32_t d = (uint32_t)(k[j] >> sh) & mk;
-                    if (cnt && d != cur) { atomicAdd(&lh[p * 256 + cur], cnt); cnt = 0; }
-                    cur = d; cnt++;
+                const bool valid = base + j * HS_THREADS < n;
+                const uint32_t d = valid ? ((uint32_t)(k[j] >> sh) & mk) : 0xFFFFFFFFu;
+                const uint32_t dprev = __shfl_up(d, 1, 64);
+                const bool head = lane == 0 || d != dprev;
+                const uint64_t heads = __ballot(head);
+                if (head && valid) {
+                    const uint64_t above = lane == 63 ? 0ull : (heads >> (lane + 1));
+                    const uint32_t len = above ? (uint32_t)__builtin_ctzll(above) + 1u : (uint32_t)(64 - lane);
+                    atomicAdd(&lh[p * 256 + d], len);
                 }
             }
-            if (cnt) atomicAdd(&lh[p * 256 + cur], cnt);
         }
     }
     __syncthreads();
@@ -141,7 +137,6 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
     __shared__ uint32_t s_tile;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t ntiles = (n + OS_TILE - 1) / OS_TILE;
-    volatile uint32_t* vh = &whist[w][0];
 
     // global digit starts = exclusive scan of this pass's histogram (identical in every block)
     uint32_t gstart = 0;
@@ -167,15 +162,21 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
             uint32_t idx = wbase + j * 64 + lane;
             keys[j] = idx < n ? in[idx] : ~0ull;            // padding sorts last in stream order, never written
         }
-        // ---- stable rank of every key among the same-digit keys of its wave ----------------------------
+        // ---- stable rank of every key among the same-digit keys of its wave ----------------------------------
+        // per row: the lowest peer lane adds the class size to the wave's LDS digit counter, then every lane reads
+        // the counter back (LDS operations of one wave retire in order): rank = counter - class size + lanes below.
 #pragma unroll
         for (int j = 0; j < OS_KPT; j++) {
             const uint32_t dg = (uint32_t)(keys[j] >> shift) & dmask;
-            const uint64_t peers = match_any<BITS>(dg);
-            const uint32_t below = lanes_below(peers);
-            const uint32_t base = vh[dg];                     // every peer reads the same word (broadcast)
-            if (below == 0) vh[dg] = base + (uint32_t)__popcll(peers);   // LDS ops of a wave retire in order
-            if (j & 1) rnk[j >> 1] |= (base + below) << 16; else rnk[j >> 1] = base + below;
+            uint32_t mlo, mhi;
+            match_any<BITS>(dg, mlo, mhi);
+            const uint32_t below = lanes_below(mlo, mhi);
+            const uint32_t cnt = (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi);
+            if (below == 0) atomicAdd(&whist[w][dg], cnt);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    // compiler barrier: keep the read after the add
+            const uint32_t after = whist[w][dg];
+            const uint32_t r = after - cnt + below;
+            if (j & 1) rnk[j >> 1] |= r << 16; else rnk[j >> 1] = r;
         }
         __syncthreads();
         // ---- digit totals of the tile, per-wave bases, look-back ----------------------------------------
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
         if (tid < RADIX) {
 #pragma unroll
             for (int i = 0; i < OS_WAVES; i++) tot += whist[i][tid];
-            if (tile > 0) st_relaxed(&status[(size_t)tile * RADIX + tid], (ST_AGG << 30) | tot);
+            if (tile > 0) lb_st32(&status[(size_t)tile * RADIX + tid], (LB_AGG << 30) | tot);
         }
         {
             uint32_t a = tot, dummy = 0;
@@ -194,23 +195,37 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
             uint32_t acc = lbase;
 #pragma unroll
             for (int i = 0; i < OS_WAVES; i++) { uint32_t c = whist[i][tid]; whist[i][tid] = acc; acc += c; }
-            uint32_t excl = 0;
-            if (tile > 0) {
-                uint32_t p = tile - 1, spins = 0;
-                while (true) {
-                    uint32_t v = ld_relaxed(&status[(size_t)p * RADIX + tid]);
-                    uint32_t f = v >> 30;
-                    if (f == 0) {
-                        if (++spins > SPIN_LIMIT) { atomicOr(err, 4u); break; }
-                        __builtin_amdgcn_s_sleep(1);
-                        continue;
+        }
+        // ---- look-back: one lane per digit walks its own chain of status words, OS_LBW predecessors per probe.
+        //      (A one-at-a-time walk moves ~1 tile per L2 round trip, which is about the rate at which tiles retire:
+        //      the window of aggregate-only predecessors then never drains and the walk becomes the pass.)
+        uint32_t excl = 0;
+        if (tid < RADIX && tile > 0) {
+            int p = (int)tile - 1;
+            uint32_t spins = 0;
+            bool done = false;
+            while (!done) {
+                uint32_t v[OS_LBW];
+#pragma unroll
+                for (int i = 0; i < OS_LBW; i++)
+                    v[i] = p - i >= 0 ? lb_ld32(&status[(size_t)(p - i) * RADIX + tid]) : (LB_PREFIX << 30);
+                int used = 0;
+#pragma unroll
+                for (int i = 0; i < OS_LBW; i++) {
+                    if (!done && used == i) {
+                        const uint32_t f = v[i] >> 30;
+                        if (f != 0) { excl += v[i] & ST_VALMASK; used = i + 1; if (f == LB_PREFIX) done = true; }
                     }
-                    excl += v & ST_VALMASK;
-                    if (f == ST_PREFIX || p == 0) break;
-                    p--;
+                }
+                p -= used;
+                if (used == 0) {
+                    if (++spins > LB_SPIN_LIMIT) { atomicOr(err, 4u); break; }
+                    __builtin_amdgcn_s_sleep(1);
                 }
             }
-            st_relaxed(&status[(size_t)tile * RADIX + tid], (ST_PREFIX << 30) | (excl + tot));
+        }
+        if (tid < RADIX) {
+            lb_st32(&status[(size_t)tile * RADIX + tid], (LB_PREFIX << 30) | (excl + tot));
             s_gdelta[tid] = gstart + excl - lbase;
         }
         __syncthreads();
@@ -274,7 +289,7 @@ const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a
     // zero hist + tickets + the status words of the passes that run (re-initialised every call)
     (void)hipMemsetAsync(scratch, 0, ((size_t)SORT_MAX_PASSES * 256 + 64 + (size_t)P * ntiles * 256) * 4, s);
     uint32_t hb = (uint32_t)((n + HS_TILE - 1) / HS_TILE);
-    if (hb > 2048) hb = 2048;
+    if (hb > 1024) hb = 1024;                             // few workgroups: the final flush is 256 x passes global atomics each
     hipLaunchKernelGGL(k_sort_hist, dim3(hb), dim3(HS_THREADS), 0, s, in, (uint32_t)n, plan, hist);
     uint32_t grid = ntiles < 512 ? ntiles : 512;          // persistent: 2 workgroups of 8 waves per CU
     const uint64_t* src = in;
