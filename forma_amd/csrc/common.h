@@ -76,6 +76,7 @@ void launch_prepare_lines(hipStream_t s, const float* x, const float* y, const u
 size_t scan_tmp_words(size_t n);
 void launch_inclusive_scan_u32(hipStream_t s, uint32_t* data, size_t n, uint32_t* tmp, uint32_t* d_total);
 void launch_exclusive_scan_u32(hipStream_t s, uint32_t* data, size_t n, uint32_t* tmp, uint32_t* d_total);
+void launch_scan_small_u32(hipStream_t s, uint32_t* data, uint32_t n, uint32_t* d_total);
 
 // The frame path: line lengths -> single-pass scan -> compacted table of the lines that own pixel segments
 // (cl_idx = line index, cl_start = index of its first pixel segment) + block_first[b] = compacted line that owns

@@ -99,6 +99,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(uint32_t* __restric
     }
 }
 
+// exclusive scan in place of a small array (one workgroup); total -> *d_total
+void launch_scan_small_u32(hipStream_t s, uint32_t* data, uint32_t n, uint32_t* d_total) {
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, data, n, d_total);
+}
+
 size_t scan_tmp_words(size_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE + 8; }
 
 static void scan_u32(hipStream_t s, uint32_t* data, size_t n, uint32_t* tmp, uint32_t* d_total, bool inclusive) {

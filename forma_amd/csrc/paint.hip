@@ -41,164 +41,197 @@ __device__ __forceinline__ bool cover_is_empty(uint64_t lo, uint64_t hi, bool ev
 // runs: maximal runs of equal 44-bit key (tile_y, tile_x, layer) in the sorted stream, found in ONE
 // pass (chained scan with look-back for the run index).  Per run: record {first segment, count, layer,
 // tile}, the wrapping i8 cover sum per pixel row (what LayerWorkbench::cover_carry accumulates), and
-// the (tile_y, layer | run) key the carry scan is ordered by.  Cover sums need no atomics: every thread
-// owns 8 consecutive segments, publishes the partial that precedes its first key change ("edge") and
-// the thread that owns a run's head walks the following edges until the next key change.
+// the (tile_y, layer | run) key the carry scan is ordered by.
+//
+// A workgroup owns RN_TILE consecutive segments.  Key changes ("boundaries") are numbered with wavefront
+// ballots; segment i belongs to slot = number of boundaries at or before i (slot 0 = the run that was
+// already open when the tile began).  Every segment then does ONE LDS atomic add of its cover into
+// bins[slot][local_y]; the thread that owns a run's first segment packs the 16 bins to 16 x i8 and writes
+// the record.  A run that leaves the tile is flagged RUN_OPEN and completed by the consumer from the
+// following tiles' slot-0 sums (BlkEdge) — no workgroup ever waits for a later one.
 // ================================================================================================
-#define RN_THREADS 256
-#define RN_IPT     8
+#define RN_THREADS 512
+#define RN_IPT     4
 #define RN_TILE    (RN_THREADS * RN_IPT)
+#define RN_WAVES   (RN_THREADS / 64)
+#define RN_SLOTS   256                  // LDS accumulator slots per sweep (tiles with more runs sweep again)
+#define RN_STRIDE  17                   // words per slot: 16 bins + 1 pad (bank spread)
 #define RUN_OPEN   0x80000000u          // seg_count flag: the run continues past its workgroup's tile
 #define RN_ROWS    64                   // tile rows a workgroup aggregates in LDS before touching row_count[]
 
-#define SEGIDX(i) ((i) + ((i) >> 3))    // LDS skew: 8 consecutive u64 per lane at a 72-byte lane stride (no bank conflicts)
+__device__ __forceinline__ uint4 pack_bins(const int* b) {
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        w[k] = ((uint32_t)b[4 * k] & 0xFFu) | (((uint32_t)b[4 * k + 1] & 0xFFu) << 8) | (((uint32_t)b[4 * k + 2] & 0xFFu) << 16) |
+               ((uint32_t)b[4 * k + 3] << 24);
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
 
-__global__ __launch_bounds__(RN_THREADS) void k_runs(const uint64_t* __restrict__ sorted, uint32_t n, uint32_t tiles_w,
-                                                     uint32_t tiles_h, TileRecord* __restrict__ records,
-                                                     uint4* __restrict__ run_cov, uint64_t* __restrict__ run_keys,
-                                                     uint32_t* __restrict__ tile_first_run,
-                                                     BlkEdge* __restrict__ blk_edge, uint32_t* __restrict__ row_count,
-                                                     uint32_t* __restrict__ status, uint32_t* __restrict__ ticket,
-                                                     FrameInfo* __restrict__ info) {
-    __shared__ uint64_t s_seg[SEGIDX(RN_TILE) + 2];           // [0] = element before the tile, tile at 1 + SEGIDX(i)
-    __shared__ uint64_t s_elo[RN_THREADS], s_ehi[RN_THREADS];
-    __shared__ uint32_t s_ecnt[RN_THREADS], s_hasb[RN_THREADS];
-    __shared__ uint32_t s_w[RN_THREADS / 64];
-    __shared__ uint32_t s_rows[RN_ROWS];
-    __shared__ uint32_t s_tile, s_j0, s_row0;
+// pass A: paintable run heads per tile (the run index of a tile's first head is the exclusive scan of these)
+__global__ __launch_bounds__(RN_THREADS) void k_runs_count(const uint64_t* __restrict__ sorted, uint32_t n, uint32_t tiles_w,
+                                                           uint32_t tiles_h, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t s_c[RN_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t ntiles = (n + RN_TILE - 1) / RN_TILE;
-    while (true) {
-        if (tid == 0) { s_tile = atomicAdd(ticket, 1u); s_row0 = 0xFFFFFFFFu; }
+    const uint32_t base = blockIdx.x * RN_TILE;
+    uint32_t c = 0;
+#pragma unroll
+    for (int r = 0; r < RN_IPT; r++) {
+        const uint32_t idx = base + r * RN_THREADS + tid;
+        const uint64_t v = idx < n ? sorted[idx] : 0ull;
+        uint64_t pv = __shfl_up(v, 1, 64);
+        if (lane == 0) pv = (idx > 0 && idx < n) ? sorted[idx - 1] : 0ull;
+        const bool val = idx < n && ((((v ^ pv) >> SEG_KEY_SHIFT) != 0) || idx == 0) && seg_paintable(v, tiles_w, tiles_h);
+        c += (uint32_t)__popcll(__ballot(val));
+    }
+    if (lane == 0) s_c[w] = c;
+    __syncthreads();
+    if (tid == 0) { uint32_t t = 0; for (int q = 0; q < RN_WAVES; q++) t += s_c[q]; counts[blockIdx.x] = t; }
+}
+
+// pass B: one workgroup per tile, no inter-workgroup dependency
+__global__ __launch_bounds__(RN_THREADS, 8) void k_runs(const uint64_t* __restrict__ sorted, uint32_t n, uint32_t tiles_w,
+                                                        uint32_t tiles_h, TileRecord* __restrict__ records,
+                                                        uint4* __restrict__ run_cov, uint64_t* __restrict__ run_keys,
+                                                        uint32_t* __restrict__ tile_first_run,
+                                                        BlkEdge* __restrict__ blk_edge, uint32_t* __restrict__ row_count,
+                                                        const uint32_t* __restrict__ run_base) {
+    __shared__ uint64_t s_seg[RN_TILE + 1];                   // [0] = element before the tile, tile at [1 + i]
+    __shared__ int s_bins[RN_SLOTS * RN_STRIDE];
+    __shared__ uint16_t s_start[RN_TILE + 2];                 // s_start[slot] = tile-local index of the slot's first segment
+    __shared__ uint32_t s_cb[RN_IPT * RN_WAVES], s_cv[RN_WAVES];            // boundaries per (row, wave); heads per wave
+    __shared__ uint32_t s_rows[RN_ROWS];
+    __shared__ uint32_t s_row0, s_R;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    {
+        const uint32_t tile = blockIdx.x;
+        if (tid == 0) s_row0 = 0xFFFFFFFFu;
         if (tid < RN_ROWS) s_rows[tid] = 0;
-        __syncthreads();
-        const uint32_t tile = s_tile;
-        if (tile >= ntiles) break;
         const uint32_t base = tile * RN_TILE;
+        const uint32_t tile_n = min((uint32_t)RN_TILE, n - base);
 #pragma unroll
         for (int r = 0; r < RN_IPT; r++) {
-            const uint32_t p = r * RN_THREADS + tid, idx = base + p;
-            s_seg[1 + SEGIDX(p)] = idx < n ? sorted[idx] : 0ull;        // padding: tile row -1, unpaintable, closes the last run
+            const uint32_t i = r * RN_THREADS + tid;
+            s_seg[1 + i] = i < tile_n ? sorted[base + i] : 0ull;
         }
-        if (tid == 0) s_seg[0] = base > 0 ? sorted[base - 1] : ~0ull;
+        if (tid == 0) s_seg[0] = base > 0 ? sorted[base - 1] : 0ull;
         __syncthreads();
-        // ---- pass 1: boundaries, paintable heads, the partial before the first boundary --------------------
-        const uint32_t t0 = tid * RN_IPT;
-        uint64_t pk = (tid == 0 ? s_seg[0] : s_seg[1 + SEGIDX(t0 - 1)]) >> SEG_KEY_SHIFT;
-        uint64_t lo = 0, hi = 0, e_lo = 0, e_hi = 0;
-        uint32_t cnt = 0, e_cnt = 0, nb = 0, nvh = 0;
+        // ---- phase 1: boundaries numbered in segment order; count of paintable heads ------------------------------
+        uint32_t bmask = 0;                                  // bit r: my segment of row r is a boundary
+        uint32_t slot[RN_IPT];
+        uint32_t nval = 0;                                   // wave-uniform: paintable heads seen by this wave
 #pragma unroll
-        for (int q = 0; q < RN_IPT; q++) {
-            const uint64_t v = s_seg[1 + SEGIDX(t0 + q)];
-            const uint64_t key = v >> SEG_KEY_SHIFT;
-            if (key != pk || base + t0 + q == 0) {
-                if (nb == 0) { e_lo = lo; e_hi = hi; e_cnt = cnt; }
-                lo = 0; hi = 0; cnt = 0; nb++;
-                if (seg_paintable(v, tiles_w, tiles_h)) {
-                    nvh++;
-                    const uint32_t row = (uint32_t)(v >> 53) - 1u;
-                    atomicMin(&s_row0, row);
+        for (int r = 0; r < RN_IPT; r++) {
+            const uint32_t i = r * RN_THREADS + tid;
+            const uint64_t v = s_seg[1 + i], pv = s_seg[i];
+            const bool bnd = i < tile_n && ((((v ^ pv) >> SEG_KEY_SHIFT) != 0) || base + i == 0);
+            const bool val = bnd && seg_paintable(v, tiles_w, tiles_h);
+            const uint64_t bb = __ballot(bnd);
+            slot[r] = __builtin_amdgcn_mbcnt_hi((uint32_t)(bb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bb, 0u)) + (bnd ? 1u : 0u);
+            nval += (uint32_t)__popcll(__ballot(val));
+            if (bnd) bmask |= 1u << r;
+            if (val) atomicMin(&s_row0, (uint32_t)(v >> 53) - 1u);
+            if (lane == 0) s_cb[r * RN_WAVES + w] = (uint32_t)__popcll(bb);
+        }
+        if (lane == 0) s_cv[w] = nval;
+        __syncthreads();
+        if (w == 0) {                                         // exclusive scan of the 32 (row, wave) boundary counts
+            const uint32_t cb = lane < RN_IPT * RN_WAVES ? s_cb[lane] : 0u;
+            uint32_t ib = cb;
+#pragma unroll
+            for (int d = 1; d < 32; d <<= 1) { const uint32_t tb = __shfl_up(ib, d, 64); if (lane >= d) ib += tb; }
+            if (lane < RN_IPT * RN_WAVES) s_cb[lane] = ib - cb;
+            const uint32_t R = __shfl(ib, RN_IPT * RN_WAVES - 1, 64);
+            if (lane == 0) s_R = R;
+        }
+        __syncthreads();
+        const uint32_t R = s_R;
+#pragma unroll
+        for (int r = 0; r < RN_IPT; r++) {
+            slot[r] += s_cb[r * RN_WAVES + w];
+            if (bmask & (1u << r)) s_start[slot[r]] = (uint16_t)(r * RN_THREADS + tid);
+        }
+        if (tid == 0) { s_start[R + 1] = (uint16_t)tile_n; s_start[0] = 0; }
+        const uint32_t row0 = s_row0;
+        uint32_t jbase = run_base[tile];                     // run index of the next paintable head (uniform)
+        // ---- phase 2 + 3, RN_SLOTS slots per sweep -----------------------------------------------------------------
+        for (uint32_t s0 = 0; s0 <= R; s0 += RN_SLOTS) {
+            for (int k = tid; k < RN_SLOTS * RN_STRIDE; k += RN_THREADS) s_bins[k] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < RN_IPT; r++) {
+                const uint32_t i = r * RN_THREADS + tid;
+                const uint32_t sl = slot[r] - s0;
+                if (i < tile_n && sl < RN_SLOTS) {
+                    const uint64_t v = s_seg[1 + i];
+                    atomicAdd(&s_bins[sl * RN_STRIDE + seg_ly(v)], seg_cover(v));
                 }
             }
-            acc_seg_cover(v, lo, hi); cnt++;
-            pk = key;
-        }
-        if (nb == 0) { e_lo = lo; e_hi = hi; e_cnt = cnt; }
-        s_elo[tid] = e_lo; s_ehi[tid] = e_hi; s_ecnt[tid] = e_cnt; s_hasb[tid] = nb;
-        uint32_t inc = nvh;
+            __syncthreads();
+            // one thread per slot: slot s0 + tid (slot 0 = the run that was open when the tile began)
+            const uint32_t sg = s0 + tid;
+            uint32_t i = 0; uint64_t v = 0, pv = 0; bool val = false;
+            if (tid < RN_SLOTS && sg >= 1 && sg <= R) {
+                i = s_start[sg]; v = s_seg[1 + i]; pv = s_seg[i];
+                val = seg_paintable(v, tiles_w, tiles_h);
+            }
+            const uint64_t bv = __ballot(val);
+            if (lane == 0) s_cv[w] = (uint32_t)__popcll(bv);
+            __syncthreads();
+            uint32_t jw = jbase, jt = 0;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
-        if (lane == 63) s_w[w] = inc;
-        __syncthreads();
-        uint32_t wbase = 0, tot = 0;
+            for (int q = 0; q < RN_WAVES; q++) { const uint32_t t = s_cv[q]; if (q < w) jw += t; jt += t; }
+            if (val) {
+                const uint32_t j = jw + __builtin_amdgcn_mbcnt_hi((uint32_t)(bv >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bv, 0u));
+                int b[16];
 #pragma unroll
-        for (int i = 0; i < RN_THREADS / 64; i++) { uint32_t t = s_w[i]; if (i < w) wbase += t; tot += t; }
-        if (w == 0) {                                     // run-index look-back, wave-parallel (lookback.h)
-            uint32_t excl = 0;
-            if (tile > 0) {
-                if (lane == 0) lb_st32(&status[tile], (LB_AGG << 30) | tot);
-                excl = lb_lookback_u32(status, tile, &info->error);
+                for (int k = 0; k < 16; k++) b[k] = s_bins[tid * RN_STRIDE + k];
+                const uint32_t cnt = (uint32_t)s_start[sg + 1] - i;
+                const uint32_t open = (sg == R && tile_n == RN_TILE) ? RUN_OPEN : 0u;
+                const uint32_t tyb = (uint32_t)(v >> 53), txb = (uint32_t)(v >> 41) & 0xFFFu, layer = seg_layer(v);
+                TileRecord rec;
+                rec.cover[0] = rec.cover[1] = rec.cover[2] = rec.cover[3] = 0;   // carry-in, written by k_carry_rows
+                rec.seg_start = base + i; rec.seg_count = cnt | open; rec.layer = layer; rec.tile = (uint32_t)(v >> 41);
+                records[j] = rec;
+                run_cov[j] = pack_bins(b);
+                run_keys[j] = ((uint64_t)tyb << 53) | ((uint64_t)layer << 32) | j;
+                if (txb >= 1u && ((uint32_t)(pv >> 41) != (uint32_t)(v >> 41) || base + i == 0))
+                    tile_first_run[(tyb - 1u) * tiles_w + (txb - 1u)] = j;
+                const uint32_t rr = (tyb - 1u) - row0;
+                if (rr < RN_ROWS) atomicAdd(&s_rows[rr], 1u); else atomicAdd(&row_count[tyb - 1u], 1u);
             }
-            if (lane == 0) {
-                lb_st32(&status[tile], (LB_PREFIX << 30) | (excl + tot));
-                s_j0 = excl;
-                if (tile == ntiles - 1) info->n_runs = excl + tot;
+            jbase += jt;
+            if (sg == 0 && tid == 0) {                        // slot 0: what this tile adds to a run that began before it
+                int b[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) b[k] = s_bins[k];
+                const uint4 c = pack_bins(b);
+                BlkEdge e;
+                e.cov[0] = c.x; e.cov[1] = c.y; e.cov[2] = c.z; e.cov[3] = c.w;
+                e.cnt = R ? (uint32_t)s_start[1] : tile_n; e.has_boundary = R ? 1u : 0u; e.pad[0] = e.pad[1] = 0;
+                blk_edge[tile] = e;
             }
+            __syncthreads();
         }
-        if (tid == 64) {                                  // the tile's own edge: everything before its first boundary
-            uint64_t blo = 0, bhi = 0; uint32_t bc = 0, hb = 0;
-            for (int t = 0; t < RN_THREADS; t++) {
-                blo = swar_add8(blo, s_elo[t]); bhi = swar_add8(bhi, s_ehi[t]); bc += s_ecnt[t];
-                if (s_hasb[t]) { hb = 1; break; }
-            }
-            BlkEdge e;
-            e.cov[0] = (uint32_t)blo; e.cov[1] = (uint32_t)(blo >> 32); e.cov[2] = (uint32_t)bhi; e.cov[3] = (uint32_t)(bhi >> 32);
-            e.cnt = bc; e.has_boundary = hb; e.pad[0] = e.pad[1] = 0;
-            blk_edge[tile] = e;
-        }
-        __syncthreads();
-        // ---- pass 2: one record per paintable head ------------------------------------------------------------
-        uint32_t j = s_j0 + wbase + inc - nvh;
-        const uint32_t row0 = s_row0;
-        if (nvh) {
-            int q = 0;
-            while (q < RN_IPT) {
-                const uint64_t v = s_seg[1 + SEGIDX(t0 + q)];
-                const uint64_t key = v >> SEG_KEY_SHIFT;
-                const uint64_t pv = (t0 + q == 0) ? s_seg[0] : s_seg[1 + SEGIDX(t0 + q - 1)];
-                const bool first = base + t0 + q == 0;
-                if ((key != (pv >> SEG_KEY_SHIFT) || first) && seg_paintable(v, tiles_w, tiles_h)) {
-                    uint64_t rlo = 0, rhi = 0; uint32_t rc = 0;
-                    int q2 = q;
-                    do { acc_seg_cover(s_seg[1 + SEGIDX(t0 + q2)], rlo, rhi); rc++; q2++; }
-                    while (q2 < RN_IPT && (s_seg[1 + SEGIDX(t0 + q2)] >> SEG_KEY_SHIFT) == key);
-                    uint32_t open = 0;
-                    if (q2 == RN_IPT) {                   // the run reaches the end of this thread: walk the next edges
-                        int t2 = tid + 1;
-                        while (true) {
-                            if (t2 == RN_THREADS) { open = RUN_OPEN; break; }
-                            rlo = swar_add8(rlo, s_elo[t2]); rhi = swar_add8(rhi, s_ehi[t2]); rc += s_ecnt[t2];
-                            if (s_hasb[t2]) break;
-                            t2++;
-                        }
-                    }
-                    const uint32_t tyb = (uint32_t)(v >> 53), txb = (uint32_t)(v >> 41) & 0xFFFu, layer = seg_layer(v);
-                    TileRecord r;
-                    r.cover[0] = r.cover[1] = r.cover[2] = r.cover[3] = 0;      // carry-in, written by k_carry_rows
-                    r.seg_start = base + t0 + q; r.seg_count = rc | open; r.layer = layer; r.tile = (uint32_t)(v >> 41);
-                    records[j] = r;
-                    run_cov[j] = make_uint4((uint32_t)rlo, (uint32_t)(rlo >> 32), (uint32_t)rhi, (uint32_t)(rhi >> 32));
-                    run_keys[j] = ((uint64_t)tyb << 53) | ((uint64_t)layer << 32) | j;
-                    if (txb >= 1u && ((uint32_t)(pv >> 41) != (uint32_t)(v >> 41) || first))
-                        tile_first_run[(tyb - 1u) * tiles_w + (txb - 1u)] = j;
-                    const uint32_t rr = (tyb - 1u) - row0;
-                    if (rr < RN_ROWS) atomicAdd(&s_rows[rr], 1u); else atomicAdd(&row_count[tyb - 1u], 1u);
-                    j++;
-                    q = q2;
-                } else q++;
-            }
-        }
-        __syncthreads();
         if (tid < RN_ROWS && s_rows[tid]) atomicAdd(&row_count[row0 + tid], s_rows[tid]);
-        __syncthreads();
     }
 }
 
-size_t runs_scratch_words(size_t n) { return (n + RN_TILE - 1) / RN_TILE + 1 + 16; }
+size_t runs_scratch_words(size_t n) { return (n + RN_TILE - 1) / RN_TILE + 16; }
 size_t runs_blocks(size_t n) { return (n + RN_TILE - 1) / RN_TILE + 1; }
 
 void launch_runs(hipStream_t s, const uint64_t* sorted, uint32_t n, uint32_t tiles_w, uint32_t tiles_h, TileRecord* records,
-                 uint4* run_cov, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge, uint32_t* row_count,
+                 uint4* run_cov, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge, uint32_t* row_tab,
                  uint32_t* scratch, FrameInfo* info) {
-    // per-frame state: ticket + status words, first-run table (NONE), per-row run counts
-    const uint32_t ntiles = (n + RN_TILE - 1) / RN_TILE;
-    (void)hipMemsetAsync(scratch, 0, (16 + (size_t)ntiles + 1) * 4, s);
+    // per-frame state: first-run table (NONE), per-row run counts
     (void)hipMemsetAsync(tile_first_run, 0xFF, (size_t)tiles_w * tiles_h * 4, s);
-    (void)hipMemsetAsync(row_count, 0, (size_t)(tiles_h + 1) * 4 * 3, s);      // row_count | row_span_lo | row_span_cnt
-    if (n == 0) return;
-    uint32_t grid = ntiles < 2048 ? ntiles : 2048;
-    hipLaunchKernelGGL(k_runs, dim3(grid), dim3(RN_THREADS), 0, s, sorted, n, tiles_w, tiles_h, records, run_cov, run_keys,
-                       tile_first_run, blk_edge, row_count, scratch + 16, scratch, info);
+    (void)hipMemsetAsync(row_tab, 0, (size_t)(tiles_h + 1) * 4 * 3, s);        // row_count | row_span_lo | row_span_cnt
+    if (n == 0) { (void)hipMemsetAsync(&info->n_runs, 0, 4, s); return; }
+    const uint32_t ntiles = (n + RN_TILE - 1) / RN_TILE;
+    hipLaunchKernelGGL(k_runs_count, dim3(ntiles), dim3(RN_THREADS), 0, s, sorted, n, tiles_w, tiles_h, scratch);
+    launch_scan_small_u32(s, scratch, ntiles, &info->n_runs);                  // exclusive, in place; total -> n_runs
+    hipLaunchKernelGGL(k_runs, dim3(ntiles), dim3(RN_THREADS), 0, s, sorted, n, tiles_w, tiles_h, records, run_cov, run_keys,
+                       tile_first_run, blk_edge, row_tab, (const uint32_t*)scratch);
 }
 
 // ================================================================================================
