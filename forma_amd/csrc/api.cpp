@@ -55,7 +55,8 @@ struct forma_hip_ctx {
     bool layer_sorted = false;              // rasterizer stream is non-decreasing in layer
     int digit_bits = 8;                     // radix digit width: 8 (default) or 4 (FORMA_HIP_DIGIT_BITS)
     // paint
-    DevBuf info, records, run_cov, rk_u, rk_a, rk_b, blk_edge, runs_scratch, tile_first_run, row_tab, span_key, span_cov, image;
+    DevBuf prof;                            // FORMA_HIP_PROF=1: per-phase shader-clock sums of the painter (diagnostics)
+    DevBuf info, records, run_cov, rk_u, rk_a, rk_b, blk_edge, runs_scratch, tile_first_run, row_tab, span_key, span_cov, run_col, span_col, image;
     uint32_t img_w = 0, img_h = 0;
     FrameInfo* h_info = nullptr;            // pinned
     // band
@@ -238,6 +239,8 @@ int run_paint(forma_hip_ctx* ctx, size_t n, const PaintArgs& a, bool timing) {
         HIPCHECK(ctx->rk_b.ensure((size_t)J * 8));
         HIPCHECK(ctx->span_key.ensure((size_t)J * 8));
         HIPCHECK(ctx->span_cov.ensure((size_t)J * 16));
+        HIPCHECK(ctx->span_col.ensure((size_t)J * 16));
+        HIPCHECK(ctx->run_col.ensure((size_t)J * 16));
         HIPCHECK(ctx->sort_counters.ensure(sort_scratch_words(J) * 4));
         // (tile_y, layer) order: stable radix sort on bits 32..63 = [layer 21 | tile_y+1 11]; live bits come from the
         // rasterizer's varying-bit mask (layer = key bits 0..20, tile_y = key bits 33..43)
@@ -249,10 +252,13 @@ int run_paint(forma_hip_ctx* ctx, size_t n, const PaintArgs& a, bool timing) {
         launch_carry_rows(ctx->stream, sorted_keys, ctx->records.as<TileRecord>(), ctx->run_cov.as<uint4>(),
                           ctx->blk_edge.as<BlkEdge>(), (uint32_t)((n + 2047) / 2048), ctx->style_off.as<uint32_t>(),
                           ctx->style_words.as<uint32_t>(), (uint32_t)ctx->n_orders, tiles_w, tiles_h, row_count, row_span_lo,
-                          row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(), dinfo);
+                          row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(), ctx->run_col.as<uint4>(),
+                          ctx->span_col.as<uint4>(), dinfo);
     } else {
         HIPCHECK(ctx->span_key.ensure(8));
         HIPCHECK(ctx->span_cov.ensure(16));
+        HIPCHECK(ctx->span_col.ensure(16));
+        HIPCHECK(ctx->run_col.ensure(16));
     }
     stage_end(ctx, ST_CARRY, timing);
     ctx->last_runs = J; ctx->last_entries = 0;
@@ -272,9 +278,10 @@ int run_paint(forma_hip_ctx* ctx, size_t n, const PaintArgs& a, bool timing) {
     P.stride_px = a.width; P.scene_has_clips = ctx->scene_has_clips ? 1u : 0u; P.n_orders = (uint32_t)ctx->n_orders;
     stage_begin(ctx, ST_PAINT, timing);
     launch_paint(ctx->stream, P, ctx->sorted, ctx->records.as<TileRecord>(), J, ctx->tile_first_run.as<uint32_t>(), row_span_lo,
-                 row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(), ctx->style_off.as<uint32_t>(),
+                 row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(), ctx->run_col.as<uint4>(),
+                 ctx->span_col.as<uint4>(), ctx->style_off.as<uint32_t>(),
                  ctx->style_words.as<uint32_t>(), ctx->images.as<forma_image_t>(), ctx->texels.as<uint16_t>(),
-                 ctx->image.as<uint8_t>(), dinfo);
+                 ctx->image.as<uint8_t>(), dinfo, ctx->prof.p ? ctx->prof.as<unsigned long long>() : nullptr);
     stage_end(ctx, ST_PAINT, timing);
     HIPCHECK(hipGetLastError());
     return FORMA_OK;
@@ -351,6 +358,7 @@ int forma_hip_create(forma_hip_ctx** out, int device) {
     if (!ctx) return FORMA_E_INTERNAL;
     ctx->device = device;
     if (const char* e = getenv("FORMA_HIP_DIGIT_BITS")) { if (atoi(e) == 4) ctx->digit_bits = 4; }
+    const bool want_prof = getenv("FORMA_HIP_PROF") != nullptr;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx; return FORMA_E_HIP;
     }
@@ -363,6 +371,7 @@ int forma_hip_create(forma_hip_ctx** out, int device) {
     for (int p = 0; p < MAX_PASS_EVENTS && ok; p++)
         ok = hipEventCreate(&ctx->pev0[p]) == hipSuccess && hipEventCreate(&ctx->pev1[p]) == hipSuccess;
     if (!ok) { delete ctx; return FORMA_E_HIP; }
+    if (want_prof && ctx->prof.ensure(64 * 8) == hipSuccess) (void)hipMemset(ctx->prof.p, 0, 64 * 8);
     // empty-scene defaults so that a render before any upload is well defined
     ctx->style_off.ensure(4); ctx->style_words.ensure(4); ctx->geoms.ensure(sizeof(forma_geom_t));
     ctx->images.ensure(sizeof(forma_image_t)); ctx->texels.ensure(8);
@@ -375,12 +384,21 @@ void forma_hip_destroy(forma_hip_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->prof.p) {
+        unsigned long long h[64];
+        if (hipMemcpy(h, ctx->prof.p, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[8]) {
+            fprintf(stderr, "[forma_hip prof] painter tiles=%llu  avg cycles/tile: runs=%llu spans=%llu merge=%llu facts=%llu passes=%llu list+preload=%llu layers=%llu | avg ne=%.1f painted=%.1f segs=%.1f row_spans=%.0f\n",
+                    h[8], h[0] / h[8], h[1] / h[8], h[2] / h[8], h[3] / h[8], h[4] / h[8], h[5] / h[8], h[6] / h[8],
+                    (double)h[9] / h[8], (double)h[10] / h[8], (double)h[11] / h[8], (double)h[12] / h[8]);
+        }
+        ctx->prof.release();
+    }
     DevBuf* all[] = {&ctx->x, &ctx->y, &ctx->line_slot, &ctx->geoms, &ctx->style_off, &ctx->style_words, &ctx->unchanged,
                      &ctx->images, &ctx->texels, &ctx->l_order, &ctx->l_x0, &ctx->l_y0, &ctx->l_dx, &ctx->l_dy, &ctx->l_a,
                      &ctx->l_b, &ctx->l_c, &ctx->l_d, &ctx->l_len, &ctx->scan_tmp, &ctx->cl_idx, &ctx->cl_start,
                      &ctx->block_first, &ctx->prep_scratch, &ctx->seg_u, &ctx->seg_a, &ctx->seg_b,
                      &ctx->sort_counters, &ctx->info, &ctx->records, &ctx->run_cov, &ctx->rk_u, &ctx->rk_a, &ctx->rk_b,
-                     &ctx->blk_edge, &ctx->runs_scratch, &ctx->tile_first_run, &ctx->row_tab, &ctx->span_key, &ctx->span_cov,
+                     &ctx->blk_edge, &ctx->runs_scratch, &ctx->tile_first_run, &ctx->row_tab, &ctx->span_key, &ctx->span_cov, &ctx->run_col, &ctx->span_col,
                      &ctx->image};
     for (DevBuf* b : all) b->release();
     for (int s = 0; s < ST_COUNT; s++) { (void)hipEventDestroy(ctx->ev0[s]); (void)hipEventDestroy(ctx->ev1[s]); }

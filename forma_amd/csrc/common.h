@@ -131,9 +131,10 @@ void launch_runs(hipStream_t s, const uint64_t* sorted, uint32_t n, uint32_t til
 void launch_carry_rows(hipStream_t s, const uint64_t* sorted_run_keys, TileRecord* records, uint4* run_cov,
                        const BlkEdge* blk_edge, uint32_t n_blk, const uint32_t* style_offsets, const uint32_t* style_words,
                        uint32_t n_orders, uint32_t tiles_w, uint32_t tiles_h, const uint32_t* row_count,
-                       uint32_t* row_span_lo, uint32_t* row_span_cnt, uint64_t* span_key, uint4* span_cov, FrameInfo* info);
+                       uint32_t* row_span_lo, uint32_t* row_span_cnt, uint64_t* span_key, uint4* span_cov, uint4* run_col,
+                       uint4* span_col, FrameInfo* info);
 void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, uint32_t n_runs,
                   const uint32_t* tile_first_run, const uint32_t* row_span_lo, const uint32_t* row_span_cnt,
-                  const uint64_t* span_key, const uint4* span_cov, const uint32_t* style_offsets,
-                  const uint32_t* style_words, const forma_image_t* images, const uint16_t* texels, uint8_t* image,
-                  FrameInfo* info);
+                  const uint64_t* span_key, const uint4* span_cov, const uint4* run_col, const uint4* span_col,
+                  const uint32_t* style_offsets, const uint32_t* style_words, const forma_image_t* images,
+                  const uint16_t* texels, uint8_t* image, FrameInfo* info, unsigned long long* prof /* nullable: per-phase shader-clock sums (diagnostics) */);

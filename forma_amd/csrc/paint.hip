@@ -37,6 +37,32 @@ __device__ __forceinline__ bool cover_is_empty(uint64_t lo, uint64_t hi, bool ev
     return ((lo | hi) & 0x1F1F1F1F1F1F1F1Full) == 0;      // all (|c| & 31) == 0  <=>  c mod 32 == 0 for every byte
 }
 
+// style facts carried in bits 21..31 of a run record's `layer` word and of a span key's high word (= bits 53..63 of
+// the painter's entry keys): enough for LayerWorkbench's optimizer passes to classify a layer without the style table
+#define SF_FULL        0x001u     // spans only: Cover::is_full (painter/mod.rs:200-215)
+#define SF_IS_CLIP     0x002u
+#define SF_CLIPPED     0x004u
+#define SF_OPAQUE      0x008u     // solid fill with alpha == 1
+#define SF_EVENODD     0x010u
+#define SF_BLEND_SHIFT 5          // 4 bits: ordinal of BlendMode
+#define SF_FILL_SHIFT  9          // 2 bits: fill type
+#define LAYER_MASK     0x1FFFFFu
+
+__device__ __forceinline__ bool cover_full(const uint32_t* c, bool even_odd) {     // Cover::is_full painter/mod.rs:200-215
+    uint32_t ok = 1;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint32_t w = c[i];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            int8_t v = (int8_t)(w >> (8 * b));
+            int8_t a = (int8_t)(v < 0 ? -v : v);          // abs(-128) = -128 like _mm_abs_epi8
+            ok &= even_odd ? ((a & 31) == 16) : (a == 16);
+        }
+    }
+    return ok != 0;
+}
+
 // ================================================================================================
 // runs: maximal runs of equal 44-bit key (tile_y, tile_x, layer) in the sorted stream, found in ONE
 // pass (chained scan with look-back for the run index).  Per run: record {first segment, count, layer,
@@ -260,6 +286,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
                                                            uint32_t* __restrict__ row_span_lo,
                                                            uint32_t* __restrict__ row_span_cnt,
                                                            uint64_t* __restrict__ span_key, uint4* __restrict__ span_cov,
+                                                           uint4* __restrict__ run_col, uint4* __restrict__ span_col,
                                                            FrameInfo* __restrict__ info) {
     __shared__ uint32_t s_red[CR_WAVES];
     __shared__ uint64_t s_wlo[CR_WAVES], s_whi[CR_WAVES];
@@ -285,8 +312,9 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
     for (uint32_t c0 = 0; c0 < cnt; c0 += CR_THREADS) {
         const uint32_t k = row_lo + c0 + tid;
         const bool active = c0 + tid < cnt;
-        uint32_t group = 0xFFFFFFFEu, jrun = 0, txb = 0, layer = 0;
+        uint32_t group = 0xFFFFFFFEu, jrun = 0, txb = 0, layer = 0, sfl = 0;
         uint64_t own_lo = 0, own_hi = 0;
+        uint4 scol = make_uint4(0, 0, 0, 0);
         bool even_odd = false;
         if (active) {
             const uint64_t key = sorted_keys[k];
@@ -307,9 +335,22 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
                 }
                 r->seg_count = sc;
             }
-            if (layer < n_orders && style_offsets[layer] != FORMA_NONE)
-                even_odd = FORMA_STYLE_EVENODD(style_words[style_offsets[layer]]);
-            else atomicOr(&info->error, 1u);
+            if (layer < n_orders && style_offsets[layer] != FORMA_NONE) {
+                // everything the painter's optimizer passes need to know about the layer's style, so that a tile can
+                // classify its whole layer list without touching the style table (SF_* bits ride in the entry keys)
+                const uint32_t* sw = style_words + style_offsets[layer];
+                const uint32_t h = sw[0];
+                even_odd = FORMA_STYLE_EVENODD(h);
+                sfl = (even_odd ? SF_EVENODD : 0u) | (FORMA_STYLE_BLEND(h) << SF_BLEND_SHIFT) | (FORMA_STYLE_FILL(h) << SF_FILL_SHIFT);
+                if (FORMA_STYLE_IS_CLIP(h)) { sfl |= SF_IS_CLIP; scol = make_uint4(sw[1], 0, 0, 0); }
+                else {
+                    if (FORMA_STYLE_CLIPPED(h)) sfl |= SF_CLIPPED;
+                    scol = make_uint4(sw[2], sw[3], sw[4], sw[5]);
+                    if (FORMA_STYLE_FILL(h) == FORMA_FILL_SOLID && __uint_as_float(sw[5]) == 1.0f) sfl |= SF_OPAQUE;
+                }
+                r->layer = layer | (sfl << 21);
+                run_col[jrun] = scol;
+            } else atomicOr(&info->error, 1u);
         }
         s_group[tid] = group; s_txb[tid] = txb;
         if (tid == CR_THREADS - 1) {                     // the element after this chunk (for the last lane's span)
@@ -377,8 +418,11 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
         for (int i = 0; i < CR_WAVES; i++) { const uint32_t t = s_wspan[i]; if (i < w) sbase += t; stot += t; }
         if (has_span) {
             const uint32_t si = row_lo + sbase + before;
-            span_key[si] = ((uint64_t)layer << 32) | ((uint64_t)span_lo << 16) | span_hi;
-            span_cov[si] = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+            const uint32_t c4[4] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+            const uint32_t full = cover_full(c4, even_odd) ? SF_FULL : 0u;
+            span_key[si] = ((uint64_t)(layer | ((sfl | full) << 21)) << 32) | ((uint64_t)span_lo << 16) | span_hi;
+            span_cov[si] = make_uint4(c4[0], c4[1], c4[2], c4[3]);
+            span_col[si] = scol;
         }
         __syncthreads();
         if (tid == CR_THREADS - 1) { s_clo = lo; s_chi = hi; s_cgroup = group; }   // only used when the chunk is full
@@ -391,17 +435,20 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
 void launch_carry_rows(hipStream_t s, const uint64_t* sorted_run_keys, TileRecord* records, uint4* run_cov,
                        const BlkEdge* blk_edge, uint32_t n_blk, const uint32_t* style_offsets, const uint32_t* style_words,
                        uint32_t n_orders, uint32_t tiles_w, uint32_t tiles_h, const uint32_t* row_count,
-                       uint32_t* row_span_lo, uint32_t* row_span_cnt, uint64_t* span_key, uint4* span_cov, FrameInfo* info) {
+                       uint32_t* row_span_lo, uint32_t* row_span_cnt, uint64_t* span_key, uint4* span_cov, uint4* run_col,
+                       uint4* span_col, FrameInfo* info) {
     if (tiles_h == 0) return;
     hipLaunchKernelGGL(k_carry_rows, dim3(tiles_h), dim3(CR_THREADS), 0, s, sorted_run_keys, records, run_cov, blk_edge, n_blk,
                        style_offsets, style_words, n_orders, tiles_w, tiles_h, row_count, row_span_lo, row_span_cnt, span_key,
-                       span_cov, info);
+                       span_cov, run_col, span_col, info);
 }
 
 // ================================================================================================
 // the painter: one 256-lane workgroup per 16x16 tile, lane = local_y * 16 + local_x
 // ================================================================================================
 #define MAXE_LDS 1024
+#define TSEG_CAP 512      // pixel segments of a tile kept in LDS (the rest is read from HBM/L2)
+#define PBATCH   64       // painted entries whose per-layer data is staged in LDS at a time
 
 // entry flags
 #define EF_HAS_SEGS  0x001u
@@ -686,21 +733,6 @@ __device__ __forceinline__ void texture_at(const uint32_t* __restrict__ w, const
     out[0] = f16b_to_f32(p[0]); out[1] = f16b_to_f32(p[1]); out[2] = f16b_to_f32(p[2]); out[3] = f16b_to_f32(p[3]);
 }
 
-__device__ __forceinline__ bool cover_full(const uint32_t* c, bool even_odd) {     // Cover::is_full painter/mod.rs:200-215
-    uint32_t ok = 1;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        uint32_t w = c[i];
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            int8_t v = (int8_t)(w >> (8 * b));
-            int8_t a = (int8_t)(v < 0 ? -v : v);          // abs(-128) = -128 like _mm_abs_epi8
-            ok &= even_odd ? ((a & 31) == 16) : (a == 16);
-        }
-    }
-    return ok != 0;
-}
-
 __global__ __launch_bounds__(256) void k_paint(PaintParams P, const uint64_t* __restrict__ sorted,
                                                const TileRecord* __restrict__ records, uint32_t n_runs,
                                                const uint32_t* __restrict__ tile_first_run,
@@ -708,16 +740,23 @@ __global__ __launch_bounds__(256) void k_paint(PaintParams P, const uint64_t* __
                                                const uint32_t* __restrict__ row_span_cnt,
                                                const uint64_t* __restrict__ span_key,
                                                const uint4* __restrict__ span_cov,
+                                               const uint4* __restrict__ run_col, const uint4* __restrict__ span_col,
                                                const uint32_t* __restrict__ style_offsets,
                                                const uint32_t* __restrict__ style_words,
                                                const forma_image_t* __restrict__ images,
                                                const uint16_t* __restrict__ texels, uint8_t* __restrict__ image,
-                                               FrameInfo* __restrict__ info) {
-    __shared__ uint64_t e_key[MAXE_LDS];
-    __shared__ uint64_t e_tmp[MAXE_LDS];      // [0, na) own runs, [MAXE_LDS - nb, MAXE_LDS) ... spans are appended from na
+                                               FrameInfo* __restrict__ info, unsigned long long* __restrict__ prof) {
+#define PROF_MARK(k) do { if (prof && tid == 0) { const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
+                                                    atomicAdd(&prof[k], _t - t_prev); t_prev = _t; } } while (0)
+    __shared__ uint64_t e_key[MAXE_LDS];      // staging for the span scan (4 x 256), then the merged layer list
+    __shared__ uint64_t e_tmp[MAXE_LDS];      // [0, na) own runs, [na, ne) crossing spans; later the list of painted entries
     __shared__ uint32_t e_flag[MAXE_LDS];
-    __shared__ int cells[256];
-    __shared__ uint32_t s_skipped, s_solid, s_solid_bytes;
+    __shared__ int cells[2][256];             // double-buffered coverage cells: one barrier per layer with segments
+    __shared__ uint64_t t_seg[TSEG_CAP];      // the tile's own pixel segments (contiguous in the sorted stream)
+    __shared__ uint4 b_cov[PBATCH];           // per painted entry of the current batch: carry-in cover,
+    __shared__ uint4 b_col[PBATCH];           //   style words 2..5 (solid colour / gradient geometry),
+    __shared__ uint32_t b_seg0[PBATCH], b_nseg[PBATCH], b_flag[PBATCH], b_layer[PBATCH];
+    __shared__ uint32_t s_skipped, s_solid, s_solid_bytes, s_seg0, s_seg1;
     __shared__ uint32_t s_wcnt[4];
 
     // XCD-aware tile mapping: consecutive workgroups land on different XCDs (block b -> XCD b % 8); give
@@ -733,50 +772,80 @@ __global__ __launch_bounds__(256) void k_paint(PaintParams P, const uint64_t* __
     const int tid = threadIdx.x;
     const int lx = tid & 15, ly = tid >> 4;
     const int lane = tid & 63, wv = tid >> 6;
+    unsigned long long t_prev = prof ? __builtin_amdgcn_s_memtime() : 0ull;
 
     // ---- this tile's layer list (LayerWorkbench::populate_layers, layer_workbench/mod.rs:250-278):
     //      its own runs (contiguous records, ascending layer) merged with the row's spans that cross it.
     //      entry = (layer << 32) | ref, ref = run index, or 0x80000000 | span index ------------------------------
     const uint32_t my_tile_key = ((ty + 1u) << 12) | (tx + 1u);
     uint32_t na = 0;
+    if (tid == 0) { s_seg0 = 0; s_seg1 = 0; }
+    __syncthreads();
     {
         const uint32_t j0 = tile_first_run[tile];
         if (j0 != FORMA_NONE) {
             for (uint32_t c = 0;; c += 256) {                          // a tile's runs are contiguous from j0
                 const uint32_t j = j0 + c + tid;
-                bool mine = false; uint32_t layer = 0;
-                if (j < n_runs) { const TileRecord* r = &records[j]; mine = r->tile == my_tile_key; layer = r->layer; }
+                bool mine = false; uint32_t layer = 0, st = 0, cn = 0;
+                if (j < n_runs) { const TileRecord* r = &records[j]; mine = r->tile == my_tile_key; layer = r->layer; st = r->seg_start; cn = r->seg_count; }
                 if (mine && c + tid < MAXE_LDS) e_tmp[c + tid] = ((uint64_t)layer << 32) | j;
+                const uint64_t mb = __ballot(mine);
+                if (mine && c + tid == 0) s_seg0 = st;
+                // the last run of the tile: mine, and the next record is not (runs of a tile are a prefix of the probes)
+                const bool next_mine = (mb >> ((lane + 1) & 63)) & 1ull;
+                if (mine && lane < 63 && !next_mine) s_seg1 = st + cn;
+                if (mine && lane == 63) {
+                    const uint32_t jn = j + 1;
+                    if (jn >= n_runs || records[jn].tile != my_tile_key) s_seg1 = st + cn;
+                }
                 const uint32_t got = (uint32_t)__syncthreads_count(mine ? 1 : 0);
                 na += got;
                 if (got < 256u) break;
             }
         }
     }
+    PROF_MARK(0);
+    // ---- the tile's own segments, once (they are contiguous in the sorted stream); the loads fly during the span scan
+    const uint32_t seg0 = s_seg0, seg1 = s_seg1;
+    uint64_t tsv[TSEG_CAP / 256];
+#pragma unroll
+    for (int u = 0; u < TSEG_CAP / 256; u++) { const uint32_t i = u * 256 + tid; tsv[u] = i < seg1 - seg0 ? sorted[seg0 + i] : 0ull; }
+    // ---- spans of this tile row that cross the tile.  Each wave scans its own quarter of the row's span list and
+    //      stages its hits in order (no barrier per probe); the quarters are then concatenated. ---------------------
     uint32_t nb = 0;
     {
         const uint32_t sb = row_span_lo[ty], sc = row_span_cnt[ty];
-        for (uint32_t c = 0; c < sc; c += 256) {
-            bool hit = false; uint64_t sk = 0;
-            if (c + tid < sc) {
-                sk = span_key[sb + c + tid];
-                const uint32_t lo = (uint32_t)(sk >> 16) & 0xFFFFu, hi = (uint32_t)sk & 0xFFFFu;
-                hit = tx >= lo && tx < hi;
-            }
-            const uint64_t bal = __ballot(hit);
-            if (lane == 0) s_wcnt[wv] = (uint32_t)__popcll(bal);
-            __syncthreads();
-            uint32_t base = nb, tot = 0;
+        const uint32_t q = (sc + 3u) / 4u;
+        const uint32_t c_lo = min(sc, (uint32_t)wv * q), c_hi = min(sc, (uint32_t)(wv + 1) * q);
+        uint32_t cw = 0;
+        for (uint32_t c = c_lo; c < c_hi; c += 256) {
+            uint64_t sk[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) { const uint32_t t = s_wcnt[i]; if (i < wv) base += t; tot += t; }
-            if (hit) {
-                const uint32_t pos = na + base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                if (pos < MAXE_LDS) e_tmp[pos] = (sk & 0xFFFFFFFF00000000ull) | 0x80000000u | (sb + c + tid);
+            for (int u = 0; u < 4; u++) { const uint32_t i = c + u * 64 + lane; sk[u] = i < c_hi ? span_key[sb + i] : 0ull; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t lo = (uint32_t)(sk[u] >> 16) & 0xFFFFu, hi = (uint32_t)sk[u] & 0xFFFFu;   // padding: lo = hi = 0
+                const bool hit = tx >= lo && tx < hi;
+                const uint64_t bal = __ballot(hit);
+                if (hit) {
+                    const uint32_t pos = cw + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    if (pos < 256u) e_key[wv * 256 + pos] = (sk[u] & 0xFFFFFFFF00000000ull) | 0x80000000u | (sb + c + u * 64 + lane);
+                }
+                cw += (uint32_t)__popcll(bal);
             }
-            nb += tot;
-            __syncthreads();
         }
+        if (lane == 0) s_wcnt[wv] = cw;
+#pragma unroll
+        for (int u = 0; u < TSEG_CAP / 256; u++) t_seg[u * 256 + tid] = tsv[u];
+        __syncthreads();
+        uint32_t base = na, over = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const uint32_t t = s_wcnt[i]; if (i < wv) base += t; nb += t; over |= t > 256u ? 1u : 0u; }
+        if (over) nb = MAXE_LDS + 1;                                  // more than 256 crossing spans in one quarter: too deep
+        else for (uint32_t i = lane; i < cw; i += 64) if (base + i < MAXE_LDS) e_tmp[base + i] = e_key[wv * 256 + i];
+        __syncthreads();
     }
+    PROF_MARK(1);
     const uint32_t ne = na + nb;
     uint64_t* keys = e_key;
     uint32_t* flags = e_flag;
@@ -788,44 +857,36 @@ __global__ __launch_bounds__(256) void k_paint(PaintParams P, const uint64_t* __
     // merge by layer: a (tile, layer) pair is either a run or a span, so layers are unique across both lists
     for (uint32_t i = tid; i < ne; i += 256) {
         const uint64_t k = e_tmp[i];
-        const uint32_t layer = (uint32_t)(k >> 32);
+        const uint32_t layer = (uint32_t)(k >> 32) & LAYER_MASK;
         uint32_t lo, hi;                                            // # entries of the OTHER list with a smaller layer
         if (i < na) { lo = na; hi = ne; } else { lo = 0; hi = na; }
         const uint32_t other0 = lo;
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)(e_tmp[mid] >> 32) < layer) lo = mid + 1; else hi = mid; }
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (((uint32_t)(e_tmp[mid] >> 32) & LAYER_MASK) < layer) lo = mid + 1; else hi = mid; }
         const uint32_t rank = (i < na ? i : i - na) + (lo - other0);
         keys[rank] = k;
     }
     __syncthreads();
-    // ---- per-entry facts the optimizer passes need ---------------------------------------------------------
+    PROF_MARK(2);
+    // ---- per-entry facts the optimizer passes need: decoded from the SF_* bits the carry pre-pass put in the keys ----
     for (uint32_t i = tid; i < ne; i += 256) {
-        uint64_t k = keys[i];
-        uint32_t layer = (uint32_t)(k >> 32);
-        const uint32_t ref = (uint32_t)k;
+        const uint64_t k = keys[i];
+        const uint32_t sfl = (uint32_t)(k >> 53), ref = (uint32_t)k;
         uint32_t f = EF_MASK;
-        if (layer >= P.n_orders || style_offsets[layer] == FORMA_NONE) f |= EF_BAD;
+        if (sfl & SF_EVENODD) f |= EF_EVENODD;
+        if (!(ref & 0x80000000u)) f |= EF_HAS_SEGS;                          // a run always owns segments
+        else if (sfl & SF_FULL) f |= EF_FULL;
+        if (sfl & SF_IS_CLIP) f |= EF_IS_CLIP;
         else {
-            const uint32_t* w = style_words + style_offsets[layer];
-            uint32_t h = w[0];
-            bool eo = FORMA_STYLE_EVENODD(h);
-            if (eo) f |= EF_EVENODD;
-            if (!(ref & 0x80000000u)) f |= EF_HAS_SEGS;                      // a run always owns segments
-            else {
-                const uint4 cv = span_cov[ref & 0x7FFFFFFFu];
-                const uint32_t c4[4] = {cv.x, cv.y, cv.z, cv.w};
-                if (cover_full(c4, eo)) f |= EF_FULL;
-            }
-            if (FORMA_STYLE_IS_CLIP(h)) f |= EF_IS_CLIP;
-            else {
-                if (FORMA_STYLE_CLIPPED(h)) f |= EF_CLIPPED;
-                if (FORMA_STYLE_FILL(h) == FORMA_FILL_SOLID) { f |= EF_SOLID; if (__uint_as_float(w[5]) == 1.0f) f |= EF_OPAQUE; }
-                if (FORMA_STYLE_BLEND(h) == 0) f |= EF_OVER;
-            }
+            if (sfl & SF_CLIPPED) f |= EF_CLIPPED;
+            if (((sfl >> SF_FILL_SHIFT) & 3u) == FORMA_FILL_SOLID) f |= EF_SOLID;
+            if (sfl & SF_OPAQUE) f |= EF_OPAQUE;
+            if (((sfl >> SF_BLEND_SHIFT) & 15u) == 0u) f |= EF_OVER;
         }
         flags[i] = f;
     }
     __syncthreads();
 
+    PROF_MARK(3);
     const Col clear = {P.clear[0], P.clear[1], P.clear[2], P.clear[3]};
     // ---- optimizer passes (layer_workbench/passes/*.rs), serial over the tile's short layer list ------------
     if (tid == 0) {
@@ -836,7 +897,7 @@ __global__ __launch_bounds__(256) void k_paint(PaintParams P, const uint64_t* __
             for (uint32_t i = 0; i < ne; i++) {
                 uint32_t f = flags[i];
                 if (!(f & EF_MASK) || (f & EF_BAD)) continue;
-                uint32_t id = (uint32_t)(keys[i] >> 32);
+                uint32_t id = (uint32_t)(keys[i] >> 32) & LAYER_MASK;
                 if (f & EF_IS_CLIP) {
                     c_full = (f & EF_FULL) != 0;
                     c_last = id + style_words[style_offsets[id] + 1]; c_i = i; c_used = false; has = true;
@@ -861,7 +922,7 @@ __global__ __launch_bounds__(256) void k_paint(PaintParams P, const uint64_t* __
                     if (f & EF_OPAQUE) {
                         if (first == 0) {
                             first = 1; op_i = k;
-                            const uint32_t* w = style_words + style_offsets[(uint32_t)(keys[k] >> 32)];
+                            const uint32_t* w = style_words + style_offsets[(uint32_t)(keys[k] >> 32) & LAYER_MASK];
                             opaque.r = __uint_as_float(w[2]); opaque.g = __uint_as_float(w[3]);
                             opaque.b = __uint_as_float(w[4]); opaque.a = __uint_as_float(w[5]);
                         }
@@ -878,7 +939,7 @@ __global__ __launch_bounds__(256) void k_paint(PaintParams P, const uint64_t* __
                     if (!(f & EF_MASK) || (f & EF_BAD)) continue;
                     if (first == 1 && k == op_i) continue;         // the opaque layer itself is the bottom colour
                     if (!(f & EF_IS_CLIP) && (f & EF_SOLID)) {
-                        const uint32_t* w = style_words + style_offsets[(uint32_t)(keys[k] >> 32)];
+                        const uint32_t* w = style_words + style_offsets[(uint32_t)(keys[k] >> 32) & LAYER_MASK];
                         Col src = {__uint_as_float(w[2]), __uint_as_float(w[3]), __uint_as_float(w[4]), __uint_as_float(w[5])};
                         dst = sc_blend(FORMA_STYLE_BLEND(w[0]), dst, src);
                     } else ok = false;
@@ -898,6 +959,7 @@ __global__ __launch_bounds__(256) void k_paint(PaintParams P, const uint64_t* __
     }
     __syncthreads();
 
+    PROF_MARK(4);
     const uint32_t px = tx * 16u + (uint32_t)lx, py = ty * 16u + (uint32_t)ly;
     const bool in_image = px < P.width && py < P.height;
     uint32_t* out_px = (uint32_t*)image + (size_t)py * P.stride_px + px;
@@ -906,75 +968,119 @@ __global__ __launch_bounds__(256) void k_paint(PaintParams P, const uint64_t* __
         return;
     }
 
+    // ---- the entries that are actually painted, in layer order (reuses e_tmp) ----------------------------------
+    uint32_t* p_idx = (uint32_t*)e_tmp;
+    const uint32_t skipped = s_skipped;
+    uint32_t np = 0;
+    for (uint32_t c = 0; c < ne; c += 256) {
+        const uint32_t i = c + tid;
+        const bool keep = i >= skipped && i < ne && (flags[i] & EF_MASK) && !(flags[i] & EF_BAD);
+        const uint64_t bal = __ballot(keep);
+        if (lane == 0) s_wcnt[wv] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t base = np, tot = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const uint32_t t = s_wcnt[q]; if (q < wv) base += t; tot += t; }
+        if (keep) p_idx[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = i;
+        np += tot;
+        __syncthreads();
+    }
+    cells[0][tid] = 0; cells[1][tid] = 0;
+
+    PROF_MARK(5);
+    if (prof && tid == 0) { atomicAdd(&prof[8], 1ull); atomicAdd(&prof[9], (unsigned long long)ne); atomicAdd(&prof[10], (unsigned long long)np);
+                            atomicAdd(&prof[11], (unsigned long long)(seg1 - seg0)); atomicAdd(&prof[12], (unsigned long long)row_span_cnt[ty]); }
     // ---- paint (Painter::paint_layer, painter/mod.rs:290-347, one lane per pixel) --------------------------
     float dr = clear.r, dg = clear.g, db = clear.b, da = clear.a;          // Painter::clear :277-288
     bool clip_valid = false; uint32_t clip_last = 0; float clip_mask = 0.0f;
     const float fx = (float)px;                                             // x - 1 + tile_x * TILE_WIDTH  (:325)
     const float fybase = (float)(ty * 16u + ((uint32_t)ly & 8u));          // y * LANES + tile_y * TILE_HEIGHT (:326)
     const int jy = ly & 7;
-    const uint32_t skipped = s_skipped;
-    for (uint32_t i = skipped; i < ne; i++) {
-        const uint32_t f = flags[i];
-        if (!(f & EF_MASK) || (f & EF_BAD)) continue;
-        const uint64_t k = keys[i];
-        const uint32_t layer = (uint32_t)(k >> 32);
-        const uint32_t ref = (uint32_t)k;
-        const uint32_t* w = style_words + style_offsets[layer];
-        const uint32_t h = w[0];
-        const uint32_t* cvp = (ref & 0x80000000u) ? (const uint32_t*)&span_cov[ref & 0x7FFFFFFFu] : records[ref].cover;
-        int carry = (int)(int8_t)(cvp[ly >> 2] >> ((ly & 3) * 8));
-        int A;
-        const uint32_t nseg = (ref & 0x80000000u) ? 0u : records[ref].seg_count;
-        if (nseg) {
-            cells[tid] = 0;
-            __syncthreads();
-            const uint64_t* sp = sorted + records[ref].seg_start;
-            for (uint32_t s = tid; s < nseg; s += 256) {                    // acc_segment :257-271
-                uint64_t v = sp[s];
-                int cv = seg_cover(v);
-                atomicAdd(&cells[seg_ly(v) * 16 + seg_lx(v)], (int)((uint32_t)(seg_dam(v) * cv) << 16) + cv);
+    uint32_t cbuf = 0;
+    for (uint32_t b0 = 0; b0 < np; b0 += PBATCH) {
+        const uint32_t nbt = min((uint32_t)PBATCH, np - b0);
+        __syncthreads();                                                    // previous batch fully consumed; t_seg/cells visible
+        if ((uint32_t)tid < nbt) {                                          // everything the layer loop needs, into LDS
+            const uint32_t i = p_idx[b0 + tid];
+            const uint64_t k = keys[i];
+            const uint32_t ref = (uint32_t)k;
+            b_flag[tid] = flags[i] | ((uint32_t)(k >> 53) << 16);           // EF_* low, SF_* (blend / fill) high
+            b_layer[tid] = (uint32_t)(k >> 32) & LAYER_MASK;
+            if (ref & 0x80000000u) {
+                b_cov[tid] = span_cov[ref & 0x7FFFFFFFu]; b_col[tid] = span_col[ref & 0x7FFFFFFFu];
+                b_seg0[tid] = 0; b_nseg[tid] = 0;
+            } else {
+                const TileRecord* r = &records[ref];
+                b_cov[tid] = make_uint4(r->cover[0], r->cover[1], r->cover[2], r->cover[3]);
+                b_col[tid] = run_col[ref];
+                b_seg0[tid] = r->seg_start; b_nseg[tid] = r->seg_count;
             }
-            __syncthreads();
-            int S = cells[tid];
-            int c = (int)(int16_t)(S & 0xFFFF);
-            int area = (int)(int16_t)((uint32_t)(S - c) >> 16);
-            int inc = c;                                                    // signed cover prefix along x (one DPP row)
-            inc += dpp_row_shr(inc, 1); inc += dpp_row_shr(inc, 2); inc += dpp_row_shr(inc, 4); inc += dpp_row_shr(inc, 8);
-            int acc = (int)(int8_t)(carry + (inc - c));                     // i8 wrapping column accumulator :343-345
-            A = 32 * acc + area;                                            // compute_doubled_areas :388-404
-        } else {
-            A = 32 * carry;
         }
-        if (clip_valid && clip_last < layer) clip_valid = false;            // :298-302
-        const float cov = coverage_of(A, (f & EF_EVENODD) != 0);
-        if (f & EF_IS_CLIP) {                                               // clip_at :449-464
-            if (!clip_valid) { clip_valid = true; clip_last = layer + w[1]; }
-            clip_mask = cov;
-            continue;
+        __syncthreads();
+        for (uint32_t t = 0; t < nbt; t++) {
+            const uint32_t f = b_flag[t];
+            const uint32_t layer = b_layer[t];
+            const uint32_t sfl = f >> 16;
+            const uint4 cv4 = b_cov[t];
+            const uint32_t cw = (ly >> 2) == 0 ? cv4.x : ((ly >> 2) == 1 ? cv4.y : ((ly >> 2) == 2 ? cv4.z : cv4.w));
+            const int carry = (int)(int8_t)(cw >> ((ly & 3) * 8));
+            int A;
+            const uint32_t nseg = b_nseg[t];
+            if (nseg) {
+                int* cb = cells[cbuf];
+                const uint32_t off = b_seg0[t] - seg0;                      // position inside the tile's segment range
+                for (uint32_t sidx = tid; sidx < nseg; sidx += 256) {       // acc_segment :257-271
+                    const uint32_t o = off + sidx;
+                    const uint64_t v = o < TSEG_CAP ? t_seg[o] : sorted[seg0 + o];
+                    const int cv = seg_cover(v);
+                    atomicAdd(&cb[seg_ly(v) * 16 + seg_lx(v)], (int)((uint32_t)(seg_dam(v) * cv) << 16) + cv);
+                }
+                __syncthreads();
+                const int S = cb[tid];
+                cb[tid] = 0;                                                // ready for the layer after next
+                cbuf ^= 1u;
+                const int c = (int)(int16_t)(S & 0xFFFF);
+                const int area = (int)(int16_t)((uint32_t)(S - c) >> 16);
+                int inc = c;                                                // signed cover prefix along x (one DPP row)
+                inc += dpp_row_shr(inc, 1); inc += dpp_row_shr(inc, 2); inc += dpp_row_shr(inc, 4); inc += dpp_row_shr(inc, 8);
+                const int acc = (int)(int8_t)(carry + (inc - c));           // i8 wrapping column accumulator :343-345
+                A = 32 * acc + area;                                        // compute_doubled_areas :388-404
+            } else {
+                A = 32 * carry;
+            }
+            if (clip_valid && clip_last < layer) clip_valid = false;        // :298-302
+            const float cov = coverage_of(A, (f & EF_EVENODD) != 0);
+            if (f & EF_IS_CLIP) {                                           // clip_at :449-464
+                if (!clip_valid) { clip_valid = true; clip_last = layer + b_col[t].x; }
+                clip_mask = cov;
+                continue;
+            }
+            const bool apply_clip = (f & EF_CLIPPED) && !(f & EF_SKIPCLIP);
+            if (cov == 0.0f) continue;                                      // :317-319 (per pixel: blend with 0 is the identity)
+            if (apply_clip && !clip_valid) continue;                        // :321-323
+            float fill[4];
+            const uint32_t ft = (sfl >> SF_FILL_SHIFT) & 3u;
+            if (ft == FORMA_FILL_SOLID) {
+                const uint4 col = b_col[t];
+                fill[0] = __uint_as_float(col.x); fill[1] = __uint_as_float(col.y); fill[2] = __uint_as_float(col.z); fill[3] = __uint_as_float(col.w);
+            } else {                                                        // gradients / textures read their full style words
+                const uint32_t* w = style_words + style_offsets[layer];
+                if (ft == FORMA_FILL_TEXTURE) texture_at(w, images, texels, fx, fybase + (float)jy, fill);
+                else gradient_at(w, ft, FORMA_STYLE_STOPS(w[0]), fx, fybase, jy, fill);
+            }
+            float src_a = fill[3] * cov;                                    // blend_at :406-447
+            if (apply_clip) src_a *= clip_mask;
+            float bl[3];
+            blend_rgb((sfl >> SF_BLEND_SHIFT) & 15u, dr, dg, db, fill[0], fill[1], fill[2], bl);
+            float ida = 1.0f - da, k1 = ida * src_a, isa = 1.0f - src_a, k2 = da * src_a;
+            float cr = fmaf(fill[0], k1, bl[0] * k2);
+            float cg = fmaf(fill[1], k1, bl[1] * k2);
+            float cb2 = fmaf(fill[2], k1, bl[2] * k2);
+            dr = fmaf(dr, isa, cr); dg = fmaf(dg, isa, cg); db = fmaf(db, isa, cb2);
+            da = fmaf(da, isa, src_a);
         }
-        const bool apply_clip = (f & EF_CLIPPED) && !(f & EF_SKIPCLIP);
-        if (cov == 0.0f) continue;                                          // :317-319 (per pixel: blend with 0 is the identity)
-        if (apply_clip && !clip_valid) continue;                            // :321-323
-        float fill[4];
-        const uint32_t ft = FORMA_STYLE_FILL(h);
-        if (ft == FORMA_FILL_SOLID) {
-            fill[0] = __uint_as_float(w[2]); fill[1] = __uint_as_float(w[3]); fill[2] = __uint_as_float(w[4]); fill[3] = __uint_as_float(w[5]);
-        } else if (ft == FORMA_FILL_TEXTURE) {
-            texture_at(w, images, texels, fx, fybase + (float)jy, fill);
-        } else {
-            gradient_at(w, ft, FORMA_STYLE_STOPS(h), fx, fybase, jy, fill);
-        }
-        float src_a = fill[3] * cov;                                        // blend_at :406-447
-        if (apply_clip) src_a *= clip_mask;
-        float bl[3];
-        blend_rgb(FORMA_STYLE_BLEND(h), dr, dg, db, fill[0], fill[1], fill[2], bl);
-        float ida = 1.0f - da, k1 = ida * src_a, isa = 1.0f - src_a, k2 = da * src_a;
-        float cr = fmaf(fill[0], k1, bl[0] * k2);
-        float cg = fmaf(fill[1], k1, bl[1] * k2);
-        float cb = fmaf(fill[2], k1, bl[2] * k2);
-        dr = fmaf(dr, isa, cr); dg = fmaf(dg, isa, cg); db = fmaf(db, isa, cb);
-        da = fmaf(da, isa, src_a);
     }
+    PROF_MARK(6);
     // ---- compute_srgb :466-483 + channel select, straight to the row-major RGBA8 image ----------------------
     if (in_image) {
         float sr = linear_to_srgb(dr), sg = linear_to_srgb(dg), sb = linear_to_srgb(db);
@@ -987,12 +1093,13 @@ __global__ __launch_bounds__(256) void k_paint(PaintParams P, const uint64_t* __
 
 void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, uint32_t n_runs,
                   const uint32_t* tile_first_run, const uint32_t* row_span_lo, const uint32_t* row_span_cnt,
-                  const uint64_t* span_key, const uint4* span_cov, const uint32_t* style_offsets,
-                  const uint32_t* style_words, const forma_image_t* images, const uint16_t* texels, uint8_t* image,
-                  FrameInfo* info) {
+                  const uint64_t* span_key, const uint4* span_cov, const uint4* run_col, const uint4* span_col,
+                  const uint32_t* style_offsets, const uint32_t* style_words, const forma_image_t* images,
+                  const uint16_t* texels, uint8_t* image, FrameInfo* info, unsigned long long* prof) {
     uint32_t T = p.tiles_w * p.tiles_h;
     if (T == 0) return;
     uint32_t per = (T + 7) / 8;
     hipLaunchKernelGGL(k_paint, dim3(per * 8), dim3(256), 0, s, p, sorted, records, n_runs, tile_first_run, row_span_lo,
-                       row_span_cnt, span_key, span_cov, style_offsets, style_words, images, texels, image, info);
+                       row_span_cnt, span_key, span_cov, run_col, span_col, style_offsets, style_words, images, texels, image,
+                       info, prof);
 }
