@@ -56,7 +56,7 @@ struct forma_hip_ctx {
     int digit_bits = 8;                     // radix digit width: 8 (default) or 4 (FORMA_HIP_DIGIT_BITS)
     // paint
     DevBuf prof;                            // FORMA_HIP_PROF=1: per-phase shader-clock sums of the painter (diagnostics)
-    DevBuf info, records, run_cov, rk_u, rk_a, rk_b, blk_edge, runs_scratch, tile_first_run, row_tab, span_key, span_cov, run_col, span_col, image;
+    DevBuf info, records, run_cov, rk_u, rk_a, rk_b, blk_edge, runs_scratch, tile_first_run, row_tab, span_key, span_cov, run_col, span_col, paint_overflow, image;
     uint32_t img_w = 0, img_h = 0;
     FrameInfo* h_info = nullptr;            // pinned
     // band
@@ -211,6 +211,7 @@ int run_paint(forma_hip_ctx* ctx, size_t n, const PaintArgs& a, bool timing) {
     ctx->img_w = a.width; ctx->img_h = a.height;
     HIPCHECK(ctx->tile_first_run.ensure((size_t)(T + 1) * 4));
     HIPCHECK(ctx->row_tab.ensure((size_t)(tiles_h + 1) * 4 * 3));
+    HIPCHECK(ctx->paint_overflow.ensure((size_t)(T + 1) * 4));
     FrameInfo* dinfo = ctx->info.as<FrameInfo>();
     uint32_t* row_count = ctx->row_tab.as<uint32_t>();
     uint32_t* row_span_lo = row_count + (tiles_h + 1);
@@ -281,7 +282,7 @@ int run_paint(forma_hip_ctx* ctx, size_t n, const PaintArgs& a, bool timing) {
                  row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(), ctx->run_col.as<uint4>(),
                  ctx->span_col.as<uint4>(), ctx->style_off.as<uint32_t>(),
                  ctx->style_words.as<uint32_t>(), ctx->images.as<forma_image_t>(), ctx->texels.as<uint16_t>(),
-                 ctx->image.as<uint8_t>(), dinfo, ctx->prof.p ? ctx->prof.as<unsigned long long>() : nullptr);
+                 ctx->image.as<uint8_t>(), dinfo, ctx->paint_overflow.as<uint32_t>(), ctx->prof.p ? ctx->prof.as<unsigned long long>() : nullptr);
     stage_end(ctx, ST_PAINT, timing);
     HIPCHECK(hipGetLastError());
     return FORMA_OK;
@@ -300,7 +301,7 @@ int finish_frame(forma_hip_ctx* ctx, forma_timings_t* t) {
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     // device-side invariant flags
     HIPCHECK(hipMemcpy(ctx->h_info, ctx->info.p, sizeof(FrameInfo), hipMemcpyDeviceToHost));
-    if (ctx->h_info->error & 2u) return fail(ctx, FORMA_E_CAPACITY, "a tile has more layers than the painter's LDS list holds");
+    if (ctx->h_info->error & 2u) return fail(ctx, FORMA_E_CAPACITY, "a tile has more than 4096 layers (painter list capacity)");
     if (ctx->h_info->error) return fail(ctx, FORMA_E_INTERNAL, "device-side invariant violated");
     if (!t) return FORMA_OK;
     memset(t, 0, sizeof *t);
@@ -398,7 +399,7 @@ void forma_hip_destroy(forma_hip_ctx* ctx) {
                      &ctx->l_b, &ctx->l_c, &ctx->l_d, &ctx->l_len, &ctx->scan_tmp, &ctx->cl_idx, &ctx->cl_start,
                      &ctx->block_first, &ctx->prep_scratch, &ctx->seg_u, &ctx->seg_a, &ctx->seg_b,
                      &ctx->sort_counters, &ctx->info, &ctx->records, &ctx->run_cov, &ctx->rk_u, &ctx->rk_a, &ctx->rk_b,
-                     &ctx->blk_edge, &ctx->runs_scratch, &ctx->tile_first_run, &ctx->row_tab, &ctx->span_key, &ctx->span_cov, &ctx->run_col, &ctx->span_col,
+                     &ctx->blk_edge, &ctx->runs_scratch, &ctx->tile_first_run, &ctx->row_tab, &ctx->span_key, &ctx->span_cov, &ctx->run_col, &ctx->span_col, &ctx->paint_overflow,
                      &ctx->image};
     for (DevBuf* b : all) b->release();
     for (int s = 0; s < ST_COUNT; s++) { (void)hipEventDestroy(ctx->ev0[s]); (void)hipEventDestroy(ctx->ev1[s]); }

@@ -446,7 +446,6 @@ void launch_carry_rows(hipStream_t s, const uint64_t* sorted_run_keys, TileRecor
 // ================================================================================================
 // the painter: one 256-lane workgroup per 16x16 tile, lane = local_y * 16 + local_x
 // ================================================================================================
-#define MAXE_LDS 1024
 #define TSEG_CAP 512      // pixel segments of a tile kept in LDS (the rest is read from HBM/L2)
 #define PBATCH   64       // painted entries whose per-layer data is staged in LDS at a time
 
@@ -733,24 +732,28 @@ __device__ __forceinline__ void texture_at(const uint32_t* __restrict__ w, const
     out[0] = f16b_to_f32(p[0]); out[1] = f16b_to_f32(p[1]); out[2] = f16b_to_f32(p[2]); out[3] = f16b_to_f32(p[3]);
 }
 
-__global__ __launch_bounds__(256) void k_paint(PaintParams P, const uint64_t* __restrict__ sorted,
-                                               const TileRecord* __restrict__ records, uint32_t n_runs,
-                                               const uint32_t* __restrict__ tile_first_run,
-                                               const uint32_t* __restrict__ row_span_lo,
-                                               const uint32_t* __restrict__ row_span_cnt,
-                                               const uint64_t* __restrict__ span_key,
-                                               const uint4* __restrict__ span_cov,
-                                               const uint4* __restrict__ run_col, const uint4* __restrict__ span_col,
-                                               const uint32_t* __restrict__ style_offsets,
-                                               const uint32_t* __restrict__ style_words,
-                                               const forma_image_t* __restrict__ images,
-                                               const uint16_t* __restrict__ texels, uint8_t* __restrict__ image,
-                                               FrameInfo* __restrict__ info, unsigned long long* __restrict__ prof) {
+// One tile.  MAXE bounds the tile's layer list held in LDS; a tile that does not fit is appended to `overflow` (a
+// second, low-occupancy launch with a larger MAXE paints those).
+template <int MAXE>
+__device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t tile, const uint64_t* __restrict__ sorted,
+                                           const TileRecord* __restrict__ records, uint32_t n_runs,
+                                           const uint32_t* __restrict__ tile_first_run,
+                                           const uint32_t* __restrict__ row_span_lo,
+                                           const uint32_t* __restrict__ row_span_cnt,
+                                           const uint64_t* __restrict__ span_key, const uint4* __restrict__ span_cov,
+                                           const uint4* __restrict__ run_col, const uint4* __restrict__ span_col,
+                                           const uint32_t* __restrict__ style_offsets,
+                                           const uint32_t* __restrict__ style_words,
+                                           const forma_image_t* __restrict__ images,
+                                           const uint16_t* __restrict__ texels, uint8_t* __restrict__ image,
+                                           FrameInfo* __restrict__ info, uint32_t* __restrict__ overflow,
+                                           unsigned long long* __restrict__ prof) {
 #define PROF_MARK(k) do { if (prof && tid == 0) { const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
                                                     atomicAdd(&prof[k], _t - t_prev); t_prev = _t; } } while (0)
-    __shared__ uint64_t e_key[MAXE_LDS];      // staging for the span scan (4 x 256), then the merged layer list
-    __shared__ uint64_t e_tmp[MAXE_LDS];      // [0, na) own runs, [na, ne) crossing spans; later the list of painted entries
-    __shared__ uint32_t e_flag[MAXE_LDS];
+    constexpr int STAGE = MAXE / 4;           // span hits one wave may stage
+    __shared__ uint64_t e_key[MAXE];          // staging for the span scan (4 x STAGE), then the merged layer list
+    __shared__ uint64_t e_tmp[MAXE];          // [0, na) own runs, [na, ne) crossing spans; later the list of painted entries
+    __shared__ uint32_t e_flag[MAXE];
     __shared__ int cells[2][256];             // double-buffered coverage cells: one barrier per layer with segments
     __shared__ uint64_t t_seg[TSEG_CAP];      // the tile's own pixel segments (contiguous in the sorted stream)
     __shared__ uint4 b_cov[PBATCH];           // per painted entry of the current batch: carry-in cover,
@@ -759,16 +762,8 @@ __global__ __launch_bounds__(256) void k_paint(PaintParams P, const uint64_t* __
     __shared__ uint32_t s_skipped, s_solid, s_solid_bytes, s_seg0, s_seg1;
     __shared__ uint32_t s_wcnt[4];
 
-    // XCD-aware tile mapping: consecutive workgroups land on different XCDs (block b -> XCD b % 8); give
-    // each XCD a contiguous band of tiles so a tile row's records/spans/styles stay in one L2.
-    const uint32_t T = P.tiles_w * P.tiles_h;
-    uint32_t bid = blockIdx.x;
-    uint32_t per = (T + 7) / 8;
-    uint32_t tile = (bid & 7u) * per + (bid >> 3);
-    if (tile >= T || (bid >> 3) >= per) return;
     const uint32_t ty = tile / P.tiles_w, tx = tile - ty * P.tiles_w;
     if (tx < P.crop_x0 || tx >= P.crop_x1 || ty < P.crop_y0 || ty >= P.crop_y1) return;   // print_row :588-592, :525-529
-
     const int tid = threadIdx.x;
     const int lx = tid & 15, ly = tid >> 4;
     const int lane = tid & 63, wv = tid >> 6;
@@ -788,7 +783,7 @@ __global__ __launch_bounds__(256) void k_paint(PaintParams P, const uint64_t* __
                 const uint32_t j = j0 + c + tid;
                 bool mine = false; uint32_t layer = 0, st = 0, cn = 0;
                 if (j < n_runs) { const TileRecord* r = &records[j]; mine = r->tile == my_tile_key; layer = r->layer; st = r->seg_start; cn = r->seg_count; }
-                if (mine && c + tid < MAXE_LDS) e_tmp[c + tid] = ((uint64_t)layer << 32) | j;
+                if (mine && c + tid < MAXE) e_tmp[c + tid] = ((uint64_t)layer << 32) | j;
                 const uint64_t mb = __ballot(mine);
                 if (mine && c + tid == 0) s_seg0 = st;
                 // the last run of the tile: mine, and the next record is not (runs of a tile are a prefix of the probes)
@@ -829,7 +824,7 @@ __global__ __launch_bounds__(256) void k_paint(PaintParams P, const uint64_t* __
                 const uint64_t bal = __ballot(hit);
                 if (hit) {
                     const uint32_t pos = cw + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    if (pos < 256u) e_key[wv * 256 + pos] = (sk[u] & 0xFFFFFFFF00000000ull) | 0x80000000u | (sb + c + u * 64 + lane);
+                    if (pos < (uint32_t)STAGE) e_key[wv * STAGE + pos] = (sk[u] & 0xFFFFFFFF00000000ull) | 0x80000000u | (sb + c + u * 64 + lane);
                 }
                 cw += (uint32_t)__popcll(bal);
             }
@@ -840,18 +835,20 @@ __global__ __launch_bounds__(256) void k_paint(PaintParams P, const uint64_t* __
         __syncthreads();
         uint32_t base = na, over = 0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) { const uint32_t t = s_wcnt[i]; if (i < wv) base += t; nb += t; over |= t > 256u ? 1u : 0u; }
-        if (over) nb = MAXE_LDS + 1;                                  // more than 256 crossing spans in one quarter: too deep
-        else for (uint32_t i = lane; i < cw; i += 64) if (base + i < MAXE_LDS) e_tmp[base + i] = e_key[wv * 256 + i];
+        for (int i = 0; i < 4; i++) { const uint32_t t = s_wcnt[i]; if (i < wv) base += t; nb += t; over |= t > (uint32_t)STAGE ? 1u : 0u; }
+        if (over) nb = MAXE + 1;                                      // more crossing spans in one quarter than a wave may stage
+        else for (uint32_t i = lane; i < cw; i += 64) if (base + i < MAXE) e_tmp[base + i] = e_key[wv * STAGE + i];
         __syncthreads();
     }
     PROF_MARK(1);
     const uint32_t ne = na + nb;
     uint64_t* keys = e_key;
     uint32_t* flags = e_flag;
-    if (ne > MAXE_LDS) {
-        // pathological tile (> MAXE_LDS layers): not supported by the LDS path
-        if (tid == 0) atomicOr(&info->error, 2u);
+    if (ne > MAXE) {                                                  // does not fit this variant's LDS
+        if (tid == 0) {
+            if (overflow) overflow[1 + atomicAdd(&overflow[0], 1u)] = tile;
+            else atomicOr(&info->error, 2u);                          // deeper than the largest variant
+        }
         return;
     }
     // merge by layer: a (tile, layer) pair is either a run or a span, so layers are unique across both lists
@@ -1091,15 +1088,51 @@ __global__ __launch_bounds__(256) void k_paint(PaintParams P, const uint64_t* __
     }
 }
 
+#define PAINT_ARGS P, tile, sorted, records, n_runs, tile_first_run, row_span_lo, row_span_cnt, span_key, span_cov, run_col, span_col, \
+                   style_offsets, style_words, images, texels, image, info
+#define PAINT_PARAMS PaintParams P, const uint64_t* __restrict__ sorted, const TileRecord* __restrict__ records, uint32_t n_runs, \
+                     const uint32_t* __restrict__ tile_first_run, const uint32_t* __restrict__ row_span_lo, \
+                     const uint32_t* __restrict__ row_span_cnt, const uint64_t* __restrict__ span_key, \
+                     const uint4* __restrict__ span_cov, const uint4* __restrict__ run_col, const uint4* __restrict__ span_col, \
+                     const uint32_t* __restrict__ style_offsets, const uint32_t* __restrict__ style_words, \
+                     const forma_image_t* __restrict__ images, const uint16_t* __restrict__ texels, uint8_t* __restrict__ image, \
+                     FrameInfo* __restrict__ info
+
+// the common case: one workgroup per tile, lists of up to PAINT_MAXE entries, 8 workgroups per CU
+#define PAINT_MAXE      512
+#define PAINT_MAXE_DEEP 4096
+__global__ __launch_bounds__(256) void k_paint(PAINT_PARAMS, uint32_t* __restrict__ overflow, unsigned long long* __restrict__ prof) {
+    // XCD-aware tile mapping: consecutive workgroups land on different XCDs (block b -> XCD b % 8); give
+    // each XCD a contiguous band of tiles so a tile row's records/spans/styles stay in one L2.
+    const uint32_t T = P.tiles_w * P.tiles_h;
+    const uint32_t bid = blockIdx.x, per = (T + 7) / 8;
+    const uint32_t tile = (bid & 7u) * per + (bid >> 3);
+    if (tile >= T || (bid >> 3) >= per) return;
+    paint_tile<PAINT_MAXE>(PAINT_ARGS, overflow, prof);
+}
+// the rare deep tiles the first launch could not hold
+__global__ __launch_bounds__(256) void k_paint_deep(PAINT_PARAMS, const uint32_t* __restrict__ overflow) {
+    const uint32_t n = overflow[0];
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        const uint32_t tile = overflow[1 + i];
+        paint_tile<PAINT_MAXE_DEEP>(PAINT_ARGS, nullptr, nullptr);
+        __syncthreads();
+    }
+}
+
 void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, uint32_t n_runs,
                   const uint32_t* tile_first_run, const uint32_t* row_span_lo, const uint32_t* row_span_cnt,
                   const uint64_t* span_key, const uint4* span_cov, const uint4* run_col, const uint4* span_col,
                   const uint32_t* style_offsets, const uint32_t* style_words, const forma_image_t* images,
-                  const uint16_t* texels, uint8_t* image, FrameInfo* info, unsigned long long* prof) {
+                  const uint16_t* texels, uint8_t* image, FrameInfo* info, uint32_t* overflow, unsigned long long* prof) {
     uint32_t T = p.tiles_w * p.tiles_h;
     if (T == 0) return;
     uint32_t per = (T + 7) / 8;
+    (void)hipMemsetAsync(overflow, 0, 4, s);
     hipLaunchKernelGGL(k_paint, dim3(per * 8), dim3(256), 0, s, p, sorted, records, n_runs, tile_first_run, row_span_lo,
                        row_span_cnt, span_key, span_cov, run_col, span_col, style_offsets, style_words, images, texels, image,
-                       info, prof);
+                       info, overflow, prof);
+    hipLaunchKernelGGL(k_paint_deep, dim3(T < 256 ? T : 256), dim3(256), 0, s, p, sorted, records, n_runs, tile_first_run,
+                       row_span_lo, row_span_cnt, span_key, span_cov, run_col, span_col, style_offsets, style_words, images,
+                       texels, image, info, (const uint32_t*)overflow);
 }

@@ -140,8 +140,11 @@ class Layer:
 
 
 class Composition:
-    def __init__(self):
+    def __init__(self, insertion_order: bool = False):
         self.layers = {}
+        # the reference appends geometry to the SegmentBuffer when a path is inserted (segment.rs:180-198), i.e. in
+        # insertion order; sorted order is merely the common case (scenes built back to front)
+        self.insertion_order = insertion_order
 
     def get_mut_or_insert_default(self, order: int) -> Layer:
         return self.layers.setdefault(order, Layer())
@@ -149,7 +152,7 @@ class Composition:
     def tables(self, oracle: orc.Oracle):
         """Flatten every path (oracle) and build x, y, line_slot, geoms, styles, images."""
         xs, ys, ids = [], [], []
-        orders = sorted(self.layers)
+        orders = list(self.layers) if self.insertion_order else sorted(self.layers)
         geoms = np.zeros(len(orders), orc.GEOM_DTYPE)
         n_orders = (max(orders) + 1) if orders else 0
         offsets = np.full(n_orders, NONE, np.uint32)

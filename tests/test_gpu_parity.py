@@ -140,3 +140,37 @@ def test_empty_and_degenerate(ctx):
     a = o.render(33, 17, clear=(1, 0, 0, 1)); b = ctx.render(33, 17, clear=(1, 0, 0, 1))
     assert np.array_equal(ctx.segments(1), o.segments(1))
     assert np.array_equal(a, b)
+
+
+def test_deep_tiles_overflow_painter(ctx):
+    """> 512 translucent layers over the same tiles: the tile's layer list does not fit the common-case painter and is
+    painted by the deep variant (second launch)."""
+    rng = np.random.default_rng(3)
+    comp = S.Composition()
+    for i in range(700):
+        x0, y0 = rng.uniform(-10, 30, 2)
+        comp.get_mut_or_insert_default(i).insert(S.custom_square(float(x0), float(y0), float(x0 + rng.uniform(20, 60)), float(y0 + rng.uniform(20, 60)))) \
+            .set_props(S.solid((float(rng.random()), float(rng.random()), float(rng.random()), 0.05)))
+    o, _ = both(ctx, comp)
+    a = o.render(96, 80, clear=(1, 1, 1, 1)); b = ctx.render(96, 80, clear=(1, 1, 1, 1))
+    assert np.array_equal(ctx.segments(1), o.segments(1))
+    d = np.abs(a.astype(int) - b.astype(int))
+    assert d.max() <= 1, (d.max(), int((d > 0).sum()))
+
+
+def test_layers_inserted_out_of_order(ctx):
+    """Geometry inserted in an order that is NOT the paint order: the rasterizer stream is not layer-sorted, so the radix
+    sort must run its layer digits too (the layer-presorted shortcut must not fire)."""
+    rng = np.random.default_rng(11)
+    comp = S.Composition(insertion_order=True)
+    orders = rng.permutation(200)
+    for o_ in orders:
+        x0, y0 = rng.uniform(0, 200, 2)
+        comp.get_mut_or_insert_default(int(o_)).insert(S.custom_circle(float(x0), float(y0), float(rng.uniform(5, 40)))) \
+            .set_props(S.solid((float(rng.random()), float(rng.random()), float(rng.random()), float(rng.choice([1.0, 0.6])))))
+    o, _ = both(ctx, comp)
+    a = o.render(256, 256, clear=(0, 0, 0, 1)); b, t = ctx.render(256, 256, clear=(0, 0, 0, 1), timings=True)
+    assert np.array_equal(ctx.segments(0), o.segments(0))
+    assert np.array_equal(ctx.segments(1), o.segments(1))
+    assert t["n_sort_passes"] >= 3
+    assert np.abs(a.astype(int) - b.astype(int)).max() <= 1
