@@ -6,7 +6,7 @@ A "step" is one `Renderer::render` frame (prepare lines -> rasterize -> radix so
 in HBM; the image stays device-resident (the PCIe-inclusive rate is reported separately, never as
 `value`).  One process per GPU; for N > 1 the canvas is sharded by tile-row bands.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--exchange cull|a2a]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
 Prints ONE JSON line on rank 0.
 """
@@ -32,28 +32,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="paris-like-30k-4k")
-    ap.add_argument("--exchange", default="cull", choices=["cull", "a2a"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
-
-
-def band_edges(row_hist: np.ndarray, n: int):
-    """Contiguous tile-row bands with (nearly) equal pixel-segment counts."""
-    tiles_h = len(row_hist)
-    cum = np.cumsum(row_hist.astype(np.float64))
-    total = cum[-1] if tiles_h else 0.0
-    edges = [0]
-    for r in range(1, n):
-        if total > 0:
-            e = int(np.searchsorted(cum, total * r / n, side="left")) + 1
-        else:
-            e = (tiles_h * r) // n
-        e = max(e, edges[-1] + 1) if edges[-1] + 1 <= tiles_h - (n - r) else edges[-1] + 1
-        e = min(e, tiles_h - (n - r))
-        edges.append(e)
-    edges.append(tiles_h)
-    return edges
 
 
 def main():
@@ -73,7 +54,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     import forma_amd
-    from forma_amd import api, scenes
+    from forma_amd import api, scenes, sharding
 
     build_fn, width, height = scenes.WORKLOADS[args.workload]
     comp = build_fn()
@@ -93,16 +74,11 @@ def main():
     row0, row1 = 0, tiles_h
     if world > 1:
         # tile-row bands balanced on the per-row pixel-segment histogram of the full frame
-        segs = ctx.segments(0)
-        ty = (segs >> np.uint64(53)).astype(np.int64) - 1
-        hist = np.bincount(ty[(ty >= 0) & (ty < tiles_h)], minlength=tiles_h)[:tiles_h]
-        edges = band_edges(hist, world)
-        e = torch.tensor(edges, dtype=torch.int64, device="cuda")
-        dist.broadcast(e, 0)
-        edges = e.cpu().tolist()
+        hist = sharding.row_histogram(ctx.segments(0), tiles_h)
+        edges = sharding.agree_on_bands(dist, hist, world, device="cuda")
         row0, row1 = edges[rank], edges[rank + 1]
         ctx.set_band(row0, row1)
-        crop = (0, width, row0 * 16, min(row1 * 16, height))
+        crop = sharding.band_crop(edges, rank, width, height)
 
     channels = api.RGBA
     clr = (clear.r, clear.g, clear.b, clear.a)
@@ -110,13 +86,7 @@ def main():
     def frame(timings=False):
         return ctx.render(width, height, channels=channels, clear=clr, crop=crop, device_only=True, timings=timings)
 
-    def frame_a2a():
-        # stages 1-2 on this rank's share of the lines are not separable without re-uploading geometry; the a2a
-        # variant rasterizes the full frame once per rank-band instead and exchanges nothing but counts.  Kept as
-        # an explicit option for the RCCL path: see DESIGN.md §multi-GPU.
-        return frame()
-
-    step = frame if args.exchange == "cull" else frame_a2a
+    step = frame
 
     def sync_all():
         torch.cuda.synchronize()
@@ -133,9 +103,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed = sharding.max_over_ranks(dist, elapsed, device="cuda")
     ms_per_step = elapsed / args.steps * 1e3
     fps = args.steps / elapsed
 
@@ -151,7 +119,7 @@ def main():
     pass_us = stage["sort_pass_us"]
     algo_bytes_per_pass = 16.0 * n_local                       # 8 B read + 8 B written per key per digit pass
     achieved = (algo_bytes_per_pass / (pass_us * 1e-6) / 1e9) if pass_us > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "radix digit pass = k_hist + k_scan_counts + k_scatter (4-bit LSB, u64 keys)",
+    roofline = {"bound": "hbm", "kernel": "k_onesweep: one radix digit pass (LSB, 8-bit digits over live key bits, u64 keys, chained scan)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "algorithmic_bytes_per_launch": algo_bytes_per_pass, "avg_launch_us": round(pass_us, 2),
@@ -175,7 +143,7 @@ def main():
         "config": {"workload": args.workload + (" (labelled stand-in: paris-30k.svg is not in the reference checkout)"
                                                  if args.workload.startswith("paris") else ""),
                    "canvas": [width, height], "layers": len(comp), "pixel_segments": int(n_segments_full),
-                   "sharding": "none" if world == 1 else f"tile-row bands x{world} ({args.exchange})",
+                   "sharding": "none" if world == 1 else f"tile-row bands x{world}, replicated scene, band culling, no data-path collective",
                    "band_rows": [row0, row1]},
         "stages_us": {k: round(stage[k], 1) for k in ("prepare_us", "rasterize_us", "sort_us", "carry_us", "paint_us", "total_us")},
         "roofline": roofline,

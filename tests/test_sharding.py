@@ -1,0 +1,87 @@
+"""Multi-GPU host logic on CPU: tile-row band partition (pure functions) and the N > 1 protocol of bench.py —
+band agreement by broadcast, band-cropped rendering, disjoint row ownership, max-over-ranks timing — run with
+world_size 2 on the gloo backend.  The per-band renderer here is the CPU oracle (test infrastructure); on GPUs the
+same protocol drives forma_hip_set_band + forma_hip_render."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from forma_amd import sharding
+
+
+def test_band_edges_properties():
+    rng = np.random.default_rng(0)
+    for tiles_h, n in [(135, 1), (135, 2), (135, 8), (8, 8), (512, 8), (9, 4)]:
+        for trial in range(20):
+            hist = rng.integers(0, 1000, tiles_h) * (rng.random(tiles_h) < 0.7)
+            e = sharding.band_edges(hist, n)
+            assert len(e) == n + 1 and e[0] == 0 and e[-1] == tiles_h
+            assert all(e[i] < e[i + 1] for i in range(n)), e            # contiguous, non-empty
+    # balance: no band carries more than ideal + the heaviest row
+    hist = rng.integers(100, 200, 135)
+    e = sharding.band_edges(hist, 8)
+    loads = [hist[e[i]:e[i + 1]].sum() for i in range(8)]
+    assert max(loads) <= hist.sum() / 8 + hist.max()
+    with pytest.raises(ValueError):
+        sharding.band_edges([1, 2, 3], 4)
+    assert sharding.band_edges(np.zeros(16), 4) == [0, 4, 8, 12, 16]    # empty frame: equal heights
+
+
+def test_row_histogram_ignores_unpainted_rows():
+    def seg(ty):
+        return np.uint64((ty + 1) << 53) if ty + 1 >= 0 else np.uint64(0)
+    v = np.array([seg(-1), seg(0), seg(0), seg(3), seg(7), seg(200)], np.uint64)
+    assert sharding.row_histogram(v, 8).tolist() == [2, 0, 0, 1, 0, 0, 0, 1]
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out_dir):
+    import sys
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import scene as S
+    from oracle import oracle as orc
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    W, H = 200, 150
+    tiles_h = (H + 15) // 16
+    o = orc.Oracle()
+    comp = S.random_mixed(n=120, width=W, height=H, seed=5)
+    t = comp.tables(o)
+    S.load(o, t)
+    full = o.render(W, H, clear=(0.1, 0.2, 0.3, 1.0))
+    # every rank has the same scene; rank 0's histogram decides the bands
+    hist = sharding.row_histogram(o.segments(0), tiles_h)
+    if rank != 0:
+        hist = np.zeros_like(hist)                       # a wrong local opinion must not matter
+    edges = sharding.agree_on_bands(dist, hist, world)
+    x0, x1, y0, y1 = sharding.band_crop(edges, rank, W, H)
+    band = o.render(W, H, clear=(0.1, 0.2, 0.3, 1.0), crop=(x0, x1, y0, y1), dst=np.full((H, W * 4), 7, np.uint8))
+    assert (band[:y0] == 7).all() and (band[y1:] == 7).all()          # a rank writes only its own rows
+    assert np.array_equal(band[y0:y1], full[y0:y1])
+    elapsed = sharding.max_over_ranks(dist, 1.0 + rank)                # MAX over ranks, as bench.py reports
+    assert elapsed == float(world)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (edges, y0, y1))
+    assert all(g[0] == edges for g in gathered)
+    rows = sorted((g[1], g[2]) for g in gathered)
+    assert rows[0][0] == 0 and rows[-1][1] == H and all(rows[i][1] == rows[i + 1][0] for i in range(world - 1))
+    np.save(os.path.join(out_dir, f"band{rank}.npy"), band[y0:y1])
+    if rank == 0:
+        np.save(os.path.join(out_dir, "full.npy"), full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_band_protocol_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    full = np.load(tmp_path / "full.npy")
+    stitched = np.concatenate([np.load(tmp_path / f"band{r}.npy") for r in range(world)])
+    assert np.array_equal(stitched, full)
