@@ -55,6 +55,11 @@ struct forma_hip_ctx {
     bool layer_sorted = false;              // rasterizer stream is non-decreasing in layer
     int digit_bits = 8;                     // radix digit width: 8 (default) or 4 (FORMA_HIP_DIGIT_BITS)
     // paint
+    DevBuf info_init;                       // pristine FrameInfo (reset template)
+    // sort-plan speculation: the varying-bit mask and the layer-sortedness of a scene rarely change between frames, so
+    // forma_hip_render plans the sort from the previous frame's values and verifies them when the frame is done
+    bool pred_valid = false, pred_layer_sorted = false, speculated = false;
+    uint64_t pred_live44 = 0;
     DevBuf prof;                            // FORMA_HIP_PROF=1: per-phase shader-clock sums of the painter (diagnostics)
     DevBuf info, records, run_cov, rk_u, rk_a, rk_b, blk_edge, runs_scratch, tile_first_run, row_tab, span_key, span_cov, run_col, span_col, paint_overflow, image;
     uint32_t img_w = 0, img_h = 0;
@@ -89,13 +94,8 @@ int read_info(forma_hip_ctx* ctx) {
     return FORMA_OK;
 }
 
-int reset_info(forma_hip_ctx* ctx) {
-    FrameInfo fi;
-    memset(&fi, 0, sizeof fi);
-    fi.key_and = 0xFFFFFFFFu; fi.key_and_hi = 0xFFFFFFFFu;
-    *ctx->h_info = fi;
-    HIPCHECK(hipMemcpyAsync(ctx->info.p, ctx->h_info, sizeof(FrameInfo), hipMemcpyHostToDevice, ctx->stream));
-    HIPCHECK(hipStreamSynchronize(ctx->stream));   // h_info is reused as the read-back target
+int reset_info(forma_hip_ctx* ctx) {              // device-to-device from a template: no host round trip
+    HIPCHECK(hipMemcpyAsync(ctx->info.p, ctx->info_init.p, sizeof(FrameInfo), hipMemcpyDeviceToDevice, ctx->stream));
     return FORMA_OK;
 }
 
@@ -153,10 +153,11 @@ int finish_rasterize(forma_hip_ctx* ctx) {
 }
 
 // stages 1-2 on the uploaded geometry: line table + rasterize -> seg_u
-int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, bool timing) {
+int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, bool timing, bool speculate = false) {
     const size_t n_lines = ctx->n_points ? ctx->n_points - 1 : 0;
     ctx->n_lines = n_lines;
     ctx->n_seg = 0; ctx->n_compact = 0; ctx->have_unsorted = true; ctx->live44 = 0; ctx->layer_sorted = true;
+    ctx->speculated = false;
     int rc = reset_info(ctx);
     if (rc) return rc;
     if (n_lines == 0) return FORMA_OK;
@@ -172,6 +173,8 @@ int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, boo
                      ctx->info.as<FrameInfo>(), (int)ctx->band_row0, (int)ctx->band_row1);
     stage_end(ctx, ST_RASTER, timing);
     HIPCHECK(hipGetLastError());
+    ctx->speculated = speculate && ctx->pred_valid;
+    if (ctx->speculated) { ctx->live44 = ctx->pred_live44; ctx->layer_sorted = ctx->pred_layer_sorted; return FORMA_OK; }
     return finish_rasterize(ctx);
 }
 
@@ -194,6 +197,22 @@ int run_sort(forma_hip_ctx* ctx, const uint64_t* src, size_t n, bool timing, int
     stage_end(ctx, ST_SORT, timing);
     HIPCHECK(hipGetLastError());
     return FORMA_OK;
+}
+
+#define FORMA_RETRY 1     /* internal: the speculated sort plan was wrong, run the frame again */
+// h_info holds a fresh copy of the device FrameInfo: remember the sort-plan inputs of this frame and, if the plan was
+// speculated from the previous frame, verify it.  Called at the run-count read-back, i.e. BEFORE any kernel that
+// assumes a correctly sorted stream is launched (everything up to there is in-bounds for any digit plan).
+int verify_speculation(forma_hip_ctx* ctx) {
+    if (!ctx->have_unsorted || !ctx->n_seg) return FORMA_OK;
+    const uint64_t k_or = (uint64_t)ctx->h_info->key_or | ((uint64_t)ctx->h_info->key_or_hi << 32);
+    const uint64_t k_and = (uint64_t)ctx->h_info->key_and | ((uint64_t)ctx->h_info->key_and_hi << 32);
+    if (k_or == 0 && k_and == ~0ull) return FORMA_OK;            // masks untouched: the rasterizer did not run this frame
+    const uint64_t live = (k_or ^ k_and) & 0xFFFFFFFFFFFull;
+    const bool sorted = ctx->h_info->layer_unsorted == 0;
+    const bool wrong = ctx->speculated && (live != ctx->live44 || sorted != ctx->layer_sorted);
+    ctx->pred_valid = true; ctx->pred_live44 = live; ctx->pred_layer_sorted = sorted;
+    return wrong ? FORMA_RETRY : FORMA_OK;
 }
 
 struct PaintArgs {
@@ -232,6 +251,7 @@ int run_paint(forma_hip_ctx* ctx, size_t n, const PaintArgs& a, bool timing) {
     if (n > 0) {
         int rc = read_info(ctx);
         if (rc) return rc;
+        if ((rc = verify_speculation(ctx))) return rc;
         if (ctx->h_info->error & 4u) return fail(ctx, FORMA_E_INTERNAL, "look-back spin expired (runs)");
         J = ctx->h_info->n_runs;
     }
@@ -298,9 +318,9 @@ int copy_image_out(forma_hip_ctx* ctx, uint8_t* dst, size_t stride, bool timing)
 }
 
 int finish_frame(forma_hip_ctx* ctx, forma_timings_t* t) {
+    HIPCHECK(hipMemcpyAsync(ctx->h_info, ctx->info.p, sizeof(FrameInfo), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     // device-side invariant flags
-    HIPCHECK(hipMemcpy(ctx->h_info, ctx->info.p, sizeof(FrameInfo), hipMemcpyDeviceToHost));
     if (ctx->h_info->error & 2u) return fail(ctx, FORMA_E_CAPACITY, "a tile has more than 4096 layers (painter list capacity)");
     if (ctx->h_info->error) return fail(ctx, FORMA_E_INTERNAL, "device-side invariant violated");
     if (!t) return FORMA_OK;
@@ -364,7 +384,13 @@ int forma_hip_create(forma_hip_ctx** out, int device) {
         delete ctx; return FORMA_E_HIP;
     }
     bool ok = hipHostMalloc((void**)&ctx->h_info, sizeof(FrameInfo), hipHostMallocDefault) == hipSuccess &&
-              ctx->info.ensure(sizeof(FrameInfo)) == hipSuccess;
+              ctx->info.ensure(sizeof(FrameInfo)) == hipSuccess && ctx->info_init.ensure(sizeof(FrameInfo)) == hipSuccess;
+    if (ok) {
+        FrameInfo fi;
+        memset(&fi, 0, sizeof fi);
+        fi.key_and = 0xFFFFFFFFu; fi.key_and_hi = 0xFFFFFFFFu;
+        ok = hipMemcpy(ctx->info_init.p, &fi, sizeof fi, hipMemcpyHostToDevice) == hipSuccess;
+    }
     for (int s = 0; s < ST_COUNT && ok; s++) {
         ok = hipEventCreate(&ctx->ev0[s]) == hipSuccess && hipEventCreate(&ctx->ev1[s]) == hipSuccess;
         ctx->stage_used[s] = false;
@@ -398,7 +424,7 @@ void forma_hip_destroy(forma_hip_ctx* ctx) {
                      &ctx->images, &ctx->texels, &ctx->l_order, &ctx->l_x0, &ctx->l_y0, &ctx->l_dx, &ctx->l_dy, &ctx->l_a,
                      &ctx->l_b, &ctx->l_c, &ctx->l_d, &ctx->l_len, &ctx->scan_tmp, &ctx->cl_idx, &ctx->cl_start,
                      &ctx->block_first, &ctx->prep_scratch, &ctx->seg_u, &ctx->seg_a, &ctx->seg_b,
-                     &ctx->sort_counters, &ctx->info, &ctx->records, &ctx->run_cov, &ctx->rk_u, &ctx->rk_a, &ctx->rk_b,
+                     &ctx->sort_counters, &ctx->info, &ctx->info_init, &ctx->records, &ctx->run_cov, &ctx->rk_u, &ctx->rk_a, &ctx->rk_b,
                      &ctx->blk_edge, &ctx->runs_scratch, &ctx->tile_first_run, &ctx->row_tab, &ctx->span_key, &ctx->span_cov, &ctx->run_col, &ctx->span_col, &ctx->paint_overflow,
                      &ctx->image};
     for (DevBuf* b : all) b->release();
@@ -648,12 +674,17 @@ int forma_hip_render(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t 
     HIPCHECK(hipSetDevice(ctx->device));
     const bool timing = timings != nullptr;
     clear_stage_flags(ctx);
-    if ((rc = run_rasterize_frame(ctx, width, height, timing))) return rc;
-    if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), ctx->n_seg, timing))) return rc;
-    PaintArgs a{width, height, channels, clear_color, crop_or_null};
-    if ((rc = run_paint(ctx, ctx->n_seg, a, timing))) return rc;
-    if ((rc = copy_image_out(ctx, dst, stride_bytes, timing))) return rc;
-    return finish_frame(ctx, timings);
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if ((rc = run_rasterize_frame(ctx, width, height, timing, /*speculate=*/attempt == 0))) return rc;
+        if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), ctx->n_seg, timing))) return rc;
+        PaintArgs a{width, height, channels, clear_color, crop_or_null};
+        rc = run_paint(ctx, ctx->n_seg, a, timing);
+        if (rc == FORMA_RETRY) { clear_stage_flags(ctx); continue; }
+        if (rc) return rc;
+        if ((rc = copy_image_out(ctx, dst, stride_bytes, timing))) return rc;
+        return finish_frame(ctx, timings);
+    }
+    return fail(ctx, FORMA_E_INTERNAL, "sort plan did not converge");
 }
 
 int forma_hip_cache_clear(forma_hip_ctx* ctx, int cache_id) {
