@@ -748,7 +748,7 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
                                            const uint16_t* __restrict__ texels, uint8_t* __restrict__ image,
                                            FrameInfo* __restrict__ info, uint32_t* __restrict__ overflow,
                                            unsigned long long* __restrict__ prof) {
-#define PROF_MARK(k) do { if (prof && tid == 0) { const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
+#define PROF_MARK(k) do { if (prof && tid == 0 && (tile & 63u) == 0) { const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
                                                     atomicAdd(&prof[k], _t - t_prev); t_prev = _t; } } while (0)
     constexpr int STAGE = MAXE / 4;           // span hits one wave may stage
     __shared__ uint64_t e_key[MAXE];          // staging for the span scan (4 x STAGE), then the merged layer list
@@ -759,8 +759,8 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
     __shared__ uint4 b_cov[PBATCH];           // per painted entry of the current batch: carry-in cover,
     __shared__ uint4 b_col[PBATCH];           //   style words 2..5 (solid colour / gradient geometry),
     __shared__ uint32_t b_seg0[PBATCH], b_nseg[PBATCH], b_flag[PBATCH], b_layer[PBATCH];
-    __shared__ uint32_t s_skipped, s_solid, s_solid_bytes, s_seg0, s_seg1;
-    __shared__ uint32_t s_wcnt[4];
+    __shared__ uint32_t s_solid, s_solid_bytes, s_seg0, s_seg1;
+    __shared__ uint32_t s_wcnt[4], s_wblk[4];
 
     const uint32_t ty = tile / P.tiles_w, tx = tile - ty * P.tiles_w;
     if (tx < P.crop_x0 || tx >= P.crop_x1 || ty < P.crop_y0 || ty >= P.crop_y1) return;   // print_row :588-592, :525-529
@@ -773,30 +773,36 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
     //      its own runs (contiguous records, ascending layer) merged with the row's spans that cross it.
     //      entry = (layer << 32) | ref, ref = run index, or 0x80000000 | span index ------------------------------
     const uint32_t my_tile_key = ((ty + 1u) << 12) | (tx + 1u);
+    // first round of loads, all independent: where this tile's runs start, where this row's spans are
+    const uint32_t j0 = tile_first_run[tile];
+    const uint32_t sb = row_span_lo[ty], sc = row_span_cnt[ty];
     uint32_t na = 0;
     if (tid == 0) { s_seg0 = 0; s_seg1 = 0; }
+    // second round, issued together: the run records probed below and this wave's first 256 span keys
+    const uint32_t sq = (sc + 3u) / 4u;
+    const uint32_t c_lo = min(sc, (uint32_t)wv * sq), c_hi = min(sc, (uint32_t)(wv + 1) * sq);
+    uint64_t sk[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const uint32_t i = c_lo + u * 64 + lane; sk[u] = i < c_hi ? span_key[sb + i] : 0ull; }
     __syncthreads();
-    {
-        const uint32_t j0 = tile_first_run[tile];
-        if (j0 != FORMA_NONE) {
-            for (uint32_t c = 0;; c += 256) {                          // a tile's runs are contiguous from j0
-                const uint32_t j = j0 + c + tid;
-                bool mine = false; uint32_t layer = 0, st = 0, cn = 0;
-                if (j < n_runs) { const TileRecord* r = &records[j]; mine = r->tile == my_tile_key; layer = r->layer; st = r->seg_start; cn = r->seg_count; }
-                if (mine && c + tid < MAXE) e_tmp[c + tid] = ((uint64_t)layer << 32) | j;
-                const uint64_t mb = __ballot(mine);
-                if (mine && c + tid == 0) s_seg0 = st;
-                // the last run of the tile: mine, and the next record is not (runs of a tile are a prefix of the probes)
-                const bool next_mine = (mb >> ((lane + 1) & 63)) & 1ull;
-                if (mine && lane < 63 && !next_mine) s_seg1 = st + cn;
-                if (mine && lane == 63) {
-                    const uint32_t jn = j + 1;
-                    if (jn >= n_runs || records[jn].tile != my_tile_key) s_seg1 = st + cn;
-                }
-                const uint32_t got = (uint32_t)__syncthreads_count(mine ? 1 : 0);
-                na += got;
-                if (got < 256u) break;
+    if (j0 != FORMA_NONE) {
+        for (uint32_t c = 0;; c += 256) {                              // a tile's runs are contiguous from j0
+            const uint32_t j = j0 + c + tid;
+            bool mine = false; uint32_t layer = 0, st = 0, cn = 0;
+            if (j < n_runs) { const TileRecord* r = &records[j]; mine = r->tile == my_tile_key; layer = r->layer; st = r->seg_start; cn = r->seg_count; }
+            if (mine && c + tid < MAXE) e_tmp[c + tid] = ((uint64_t)layer << 32) | j;
+            const uint64_t mb = __ballot(mine);
+            if (mine && c + tid == 0) s_seg0 = st;
+            // the last run of the tile: mine, and the next record is not (runs of a tile are a prefix of the probes)
+            const bool next_mine = (mb >> ((lane + 1) & 63)) & 1ull;
+            if (mine && lane < 63 && !next_mine) s_seg1 = st + cn;
+            if (mine && lane == 63) {
+                const uint32_t jn = j + 1;
+                if (jn >= n_runs || records[jn].tile != my_tile_key) s_seg1 = st + cn;
             }
+            const uint32_t got = (uint32_t)__syncthreads_count(mine ? 1 : 0);
+            na += got;
+            if (got < 256u) break;
         }
     }
     PROF_MARK(0);
@@ -809,14 +815,12 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
     //      stages its hits in order (no barrier per probe); the quarters are then concatenated. ---------------------
     uint32_t nb = 0;
     {
-        const uint32_t sb = row_span_lo[ty], sc = row_span_cnt[ty];
-        const uint32_t q = (sc + 3u) / 4u;
-        const uint32_t c_lo = min(sc, (uint32_t)wv * q), c_hi = min(sc, (uint32_t)(wv + 1) * q);
         uint32_t cw = 0;
         for (uint32_t c = c_lo; c < c_hi; c += 256) {
-            uint64_t sk[4];
+            if (c != c_lo) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const uint32_t i = c + u * 64 + lane; sk[u] = i < c_hi ? span_key[sb + i] : 0ull; }
+                for (int u = 0; u < 4; u++) { const uint32_t i = c + u * 64 + lane; sk[u] = i < c_hi ? span_key[sb + i] : 0ull; }
+            }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const uint32_t lo = (uint32_t)(sk[u] >> 16) & 0xFFFFu, hi = (uint32_t)sk[u] & 0xFFFFu;   // padding: lo = hi = 0
@@ -885,73 +889,76 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
 
     PROF_MARK(3);
     const Col clear = {P.clear[0], P.clear[1], P.clear[2], P.clear[3]};
-    // ---- optimizer passes (layer_workbench/passes/*.rs), serial over the tile's short layer list ------------
-    if (tid == 0) {
-        uint32_t skipped = 0, solid = 0;
-        Col solid_col = clear;
-        if (P.scene_has_clips) {                                   // skip_trivial_clips_pass
-            bool has = false, c_full = false, c_used = false; uint32_t c_last = 0, c_i = 0;
-            for (uint32_t i = 0; i < ne; i++) {
-                uint32_t f = flags[i];
-                if (!(f & EF_MASK) || (f & EF_BAD)) continue;
-                uint32_t id = (uint32_t)(keys[i] >> 32) & LAYER_MASK;
-                if (f & EF_IS_CLIP) {
-                    c_full = (f & EF_FULL) != 0;
-                    c_last = id + style_words[style_offsets[id] + 1]; c_i = i; c_used = false; has = true;
-                    if (c_full) { f &= ~EF_MASK; flags[i] = f; }
-                }
-                if (!(f & EF_IS_CLIP) && (f & EF_CLIPPED)) {
-                    if (has && id <= c_last) { if (c_full) { f |= EF_SKIPCLIP; flags[i] = f; } else c_used = true; }
-                    else { f &= ~EF_MASK; flags[i] = f; }
-                }
-                if (has && id > c_last) { has = false; if (!c_used) flags[c_i] &= ~EF_MASK; }
+    // ---- optimizer passes (layer_workbench/passes/*.rs) -----------------------------------------------------------
+    if (P.scene_has_clips && tid == 0) {                               // skip_trivial_clips_pass: serial (clip state machine)
+        bool has = false, c_full = false, c_used = false; uint32_t c_last = 0, c_i = 0;
+        for (uint32_t i = 0; i < ne; i++) {
+            uint32_t f = flags[i];
+            if (!(f & EF_MASK)) continue;
+            uint32_t id = (uint32_t)(keys[i] >> 32) & LAYER_MASK;
+            if (f & EF_IS_CLIP) {
+                c_full = (f & EF_FULL) != 0;
+                c_last = id + style_words[style_offsets[id] + 1]; c_i = i; c_used = false; has = true;
+                if (c_full) { f &= ~EF_MASK; flags[i] = f; }
             }
-            if (has && !c_used) flags[c_i] &= ~EF_MASK;
+            if (!(f & EF_IS_CLIP) && (f & EF_CLIPPED)) {
+                if (has && id <= c_last) { if (c_full) { f |= EF_SKIPCLIP; flags[i] = f; } else c_used = true; }
+                else { f &= ~EF_MASK; flags[i] = f; }
+            }
+            if (has && id > c_last) { has = false; if (!c_used) flags[c_i] &= ~EF_MASK; }
         }
-        {                                                          // skip_fully_covered_layers_pass
-            int first = 0; Col opaque = clear; uint32_t op_i = 0;
-            for (uint32_t k = ne; k-- > 0;) {
-                uint32_t f = flags[k];
-                if (!(f & EF_MASK) || (f & EF_BAD)) continue;
-                bool clipped = !(f & EF_IS_CLIP) && (f & EF_CLIPPED) && !(f & EF_SKIPCLIP);
-                if (clipped || !(f & EF_FULL)) { if (first == 0) first = 2; }
-                else if (!(f & EF_IS_CLIP) && (f & EF_SOLID) && (f & EF_OVER)) {
-                    if (f & EF_OPAQUE) {
-                        if (first == 0) {
-                            first = 1; op_i = k;
-                            const uint32_t* w = style_words + style_offsets[(uint32_t)(keys[k] >> 32) & LAYER_MASK];
-                            opaque.r = __uint_as_float(w[2]); opaque.g = __uint_as_float(w[3]);
-                            opaque.b = __uint_as_float(w[4]); opaque.a = __uint_as_float(w[5]);
-                        }
-                        skipped = k;
-                        break;
-                    }
-                }
+        if (has && !c_used) flags[c_i] &= ~EF_MASK;
+    }
+    if (P.scene_has_clips) __syncthreads();
+    // skip_fully_covered_layers_pass (passes/skip_fully_covered_layers.rs), data-parallel: walking the list top-down,
+    // the reference stops at the topmost FULL, unclipped, solid, Over, opaque layer ("cover"); it may fold the tile to
+    // one colour only if nothing above that layer is clipped or partial ("blocker").
+    uint32_t top = 0, blk = 0;                                          // index + 1 of the topmost cover / blocker
+    for (uint32_t i = tid; i < ne; i += 256) {
+        const uint32_t f = flags[i];
+        if (!(f & EF_MASK)) continue;
+        const bool clipped = !(f & EF_IS_CLIP) && (f & EF_CLIPPED) && !(f & EF_SKIPCLIP);
+        if (clipped || !(f & EF_FULL)) blk = i + 1;
+        else if (!(f & EF_IS_CLIP) && (f & EF_SOLID) && (f & EF_OVER) && (f & EF_OPAQUE)) top = i + 1;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { top = max(top, (uint32_t)__shfl_xor(top, d, 64)); blk = max(blk, (uint32_t)__shfl_xor(blk, d, 64)); }
+    if (lane == 0) { s_wcnt[wv] = top; s_wblk[wv] = blk; }
+    __syncthreads();
+    top = max(max(s_wcnt[0], s_wcnt[1]), max(s_wcnt[2], s_wcnt[3]));
+    blk = max(max(s_wblk[0], s_wblk[1]), max(s_wblk[2], s_wblk[3]));
+    const uint32_t skipped = top ? top - 1u : 0u;
+    const int first = top ? (blk > top ? 2 : 1) : (blk ? 2 : 0);
+    if (tid == 0) s_solid = 0;
+    if (first != 2) {                                                   // fold: every layer from `skipped` up is a full cover
+        Col dst = clear; bool ok = true;
+        for (uint32_t k0 = skipped; k0 < ne; k0 += PBATCH) {
+            const uint32_t nbt = min((uint32_t)PBATCH, ne - k0);
+            __syncthreads();
+            if ((uint32_t)tid < nbt) {
+                const uint32_t ref = (uint32_t)keys[k0 + tid];
+                b_col[tid] = (ref & 0x80000000u) ? span_col[ref & 0x7FFFFFFFu] : run_col[ref];
             }
-            if (first != 2) {
-                Col dst = first == 1 ? opaque : clear;
-                bool ok = true;
-                for (uint32_t k = skipped; k < ne && ok; k++) {
-                    uint32_t f = flags[k];
-                    if (!(f & EF_MASK) || (f & EF_BAD)) continue;
-                    if (first == 1 && k == op_i) continue;         // the opaque layer itself is the bottom colour
-                    if (!(f & EF_IS_CLIP) && (f & EF_SOLID)) {
-                        const uint32_t* w = style_words + style_offsets[(uint32_t)(keys[k] >> 32) & LAYER_MASK];
-                        Col src = {__uint_as_float(w[2]), __uint_as_float(w[3]), __uint_as_float(w[4]), __uint_as_float(w[5])};
-                        dst = sc_blend(FORMA_STYLE_BLEND(w[0]), dst, src);
-                    } else ok = false;
+            __syncthreads();
+            if (tid == 0) {
+                for (uint32_t t = 0; t < nbt && ok; t++) {
+                    const uint32_t f = flags[k0 + t];
+                    if (!(f & EF_MASK)) continue;
+                    const uint4 c4 = b_col[t];
+                    const Col src = {__uint_as_float(c4.x), __uint_as_float(c4.y), __uint_as_float(c4.z), __uint_as_float(c4.w)};
+                    if (first == 1 && k0 + t == skipped) { dst = src; continue; }       // the opaque cover is the bottom colour
+                    if (!(f & EF_IS_CLIP) && (f & EF_SOLID)) dst = sc_blend((uint32_t)(keys[k0 + t] >> (53 + SF_BLEND_SHIFT)) & 15u, dst, src);
+                    else ok = false;
                 }
-                if (ok) { solid = 1; solid_col = dst; }
             }
         }
-        s_skipped = skipped; s_solid = solid;
-        if (solid) {                                                // to_srgb_bytes(channels.map(color.channel)) :156-162, 690
+        if (tid == 0 && ok) {                                           // to_srgb_bytes(channels.map(color.channel)) :156-162, 690
             float sel[4];
 #pragma unroll
-            for (int c = 0; c < 4; c++) sel[c] = sel_channel((P.channels >> (8 * c)) & 0xFFu, solid_col.r, solid_col.g, solid_col.b, solid_col.a);
-            uint32_t bytes = to_u8_x4(linear_to_srgb(sel[0])) | (to_u8_x4(linear_to_srgb(sel[1])) << 8) |
-                             (to_u8_x4(linear_to_srgb(sel[2])) << 16) | (to_u8_x4(sel[3]) << 24);
-            s_solid_bytes = bytes;
+            for (int c = 0; c < 4; c++) sel[c] = sel_channel((P.channels >> (8 * c)) & 0xFFu, dst.r, dst.g, dst.b, dst.a);
+            s_solid_bytes = to_u8_x4(linear_to_srgb(sel[0])) | (to_u8_x4(linear_to_srgb(sel[1])) << 8) |
+                            (to_u8_x4(linear_to_srgb(sel[2])) << 16) | (to_u8_x4(sel[3]) << 24);
+            s_solid = 1;
         }
     }
     __syncthreads();
@@ -967,7 +974,6 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
 
     // ---- the entries that are actually painted, in layer order (reuses e_tmp) ----------------------------------
     uint32_t* p_idx = (uint32_t*)e_tmp;
-    const uint32_t skipped = s_skipped;
     uint32_t np = 0;
     for (uint32_t c = 0; c < ne; c += 256) {
         const uint32_t i = c + tid;
@@ -985,7 +991,7 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
     cells[0][tid] = 0; cells[1][tid] = 0;
 
     PROF_MARK(5);
-    if (prof && tid == 0) { atomicAdd(&prof[8], 1ull); atomicAdd(&prof[9], (unsigned long long)ne); atomicAdd(&prof[10], (unsigned long long)np);
+    if (prof && tid == 0 && (tile & 63u) == 0) { atomicAdd(&prof[8], 1ull); atomicAdd(&prof[9], (unsigned long long)ne); atomicAdd(&prof[10], (unsigned long long)np);
                             atomicAdd(&prof[11], (unsigned long long)(seg1 - seg0)); atomicAdd(&prof[12], (unsigned long long)row_span_cnt[ty]); }
     // ---- paint (Painter::paint_layer, painter/mod.rs:290-347, one lane per pixel) --------------------------
     float dr = clear.r, dg = clear.g, db = clear.b, da = clear.a;          // Painter::clear :277-288
