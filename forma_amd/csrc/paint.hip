@@ -1094,6 +1094,339 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
     }
 }
 
+// ================================================================================================
+// the common-case painter: ONE WAVEFRONT PER TILE.  64 lanes own the 256 pixels (lane = local_x +
+// 16 * row-group, four rows per lane), so nothing in the kernel needs a workgroup barrier: the tile's
+// layer list, the coverage cells and the per-layer staging live in the wave's private slice of LDS and
+// LDS operations of one wave retire in order.  A CU then holds ~28 independent tiles instead of 8, which
+// is what this latency-bound stage needs (a tile is ~4 dependent memory round trips and ~6 painted
+// layers).  Lists deeper than WMAX go to the workgroup-per-tile variant above (k_paint_deep).
+// ================================================================================================
+#define WMAX 128          // layer-list capacity of the wave painter
+#define WB   16           // painted entries staged per batch
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor(v, d, 64));
+    return v;
+}
+
+__global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint64_t* __restrict__ sorted,
+                                                    const TileRecord* __restrict__ records, uint32_t n_runs,
+                                                    const uint32_t* __restrict__ tile_first_run,
+                                                    const uint32_t* __restrict__ row_span_lo,
+                                                    const uint32_t* __restrict__ row_span_cnt,
+                                                    const uint64_t* __restrict__ span_key,
+                                                    const uint4* __restrict__ span_cov, const uint4* __restrict__ run_col,
+                                                    const uint4* __restrict__ span_col,
+                                                    const uint32_t* __restrict__ style_offsets,
+                                                    const uint32_t* __restrict__ style_words,
+                                                    const forma_image_t* __restrict__ images,
+                                                    const uint16_t* __restrict__ texels, uint8_t* __restrict__ image,
+                                                    FrameInfo* __restrict__ info, uint32_t* __restrict__ overflow) {
+    __shared__ uint64_t w_key[1][WMAX];
+    __shared__ uint64_t w_tmp[1][WMAX];
+    __shared__ uint32_t w_flag[1][WMAX];
+    __shared__ int w_cells[1][2][256];
+    __shared__ uint4 w_cov[1][WB], w_col[1][WB];
+    __shared__ uint32_t w_seg0[1][WB], w_nseg[1][WB], w_bflag[1][WB], w_blayer[1][WB];
+
+    const int lane = threadIdx.x & 63, wv = 0;
+    // one-wave workgroups (a wave's slot frees as soon as ITS tile is done).  XCD-aware mapping: workgroup b runs on
+    // XCD b % 8; give each XCD a contiguous band of tiles so a tile row's records / spans stay in one L2
+    const uint32_t T = P.tiles_w * P.tiles_h, per = (T + 7) / 8;
+    const uint32_t bid = blockIdx.x;
+    if ((bid >> 3) >= per) return;
+    const uint32_t tile = (bid & 7u) * per + (bid >> 3);
+    if (tile >= T) return;
+    const uint32_t ty = tile / P.tiles_w, tx = tile - ty * P.tiles_w;
+    if (tx < P.crop_x0 || tx >= P.crop_x1 || ty < P.crop_y0 || ty >= P.crop_y1) return;   // print_row :588-592, :525-529
+
+    uint64_t* keys = w_key[wv];
+    uint64_t* tmp = w_tmp[wv];
+    uint32_t* flags = w_flag[wv];
+    const int lx = lane & 15, rg = lane >> 4;                           // this lane's pixels: (lx, 4 * rg + q), q = 0..3
+
+    // ---- the tile's layer list: own runs (contiguous records, ascending layer) + the row's spans that cross it --------
+    const uint32_t my_tile_key = ((ty + 1u) << 12) | (tx + 1u);
+    const uint32_t j0 = tile_first_run[tile];
+    const uint32_t sb = row_span_lo[ty], sc = row_span_cnt[ty];
+    uint64_t sk[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const uint32_t i = u * 64 + lane; sk[u] = i < sc ? span_key[sb + i] : 0ull; }
+    uint32_t na = 0;
+    if (j0 != FORMA_NONE) {
+        for (uint32_t c = 0;; c += 64) {                                // a tile's runs are contiguous from j0
+            const uint32_t j = j0 + c + lane;
+            bool mine = false; uint32_t layer = 0;
+            if (j < n_runs) { const TileRecord* r = &records[j]; mine = r->tile == my_tile_key; layer = r->layer; }
+            if (mine && c + lane < WMAX) tmp[c + lane] = ((uint64_t)layer << 32) | j;
+            const uint32_t got = (uint32_t)__popcll(__ballot(mine));
+            na += got;
+            if (got < 64u) break;
+        }
+    }
+    uint32_t nb = 0;
+    for (uint32_t c = 0; c < sc; c += 256) {
+        if (c) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t i = c + u * 64 + lane; sk[u] = i < sc ? span_key[sb + i] : 0ull; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t lo = (uint32_t)(sk[u] >> 16) & 0xFFFFu, hi = (uint32_t)sk[u] & 0xFFFFu;       // padding: lo = hi = 0
+            const bool hit = tx >= lo && tx < hi;
+            const uint64_t bal = __ballot(hit);
+            if (hit) {
+                const uint32_t pos = na + nb + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                if (pos < WMAX) tmp[pos] = (sk[u] & 0xFFFFFFFF00000000ull) | 0x80000000u | (sb + c + u * 64 + lane);
+            }
+            nb += (uint32_t)__popcll(bal);
+        }
+    }
+    const uint32_t ne = na + nb;
+    if (ne > WMAX) {                                                    // too deep for a wave: the workgroup variant paints it
+        if (lane == 0) overflow[1 + atomicAdd(&overflow[0], 1u)] = tile;
+        return;
+    }
+    wave_lds_sync();
+    // merge by layer (a (tile, layer) pair is either a run or a span: layers are unique across the two lists)
+    for (uint32_t i = lane; i < ne; i += 64) {
+        const uint64_t k = tmp[i];
+        const uint32_t layer = (uint32_t)(k >> 32) & LAYER_MASK;
+        uint32_t lo, hi;
+        if (i < na) { lo = na; hi = ne; } else { lo = 0; hi = na; }
+        const uint32_t other0 = lo;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (((uint32_t)(tmp[mid] >> 32) & LAYER_MASK) < layer) lo = mid + 1; else hi = mid; }
+        const uint32_t rank = (i < na ? i : i - na) + (lo - other0);
+        keys[rank] = k;
+        // per-entry facts for the optimizer passes, decoded from the SF_* bits of the key
+        const uint32_t sfl = (uint32_t)(k >> 53), ref = (uint32_t)k;
+        uint32_t f = EF_MASK;
+        if (sfl & SF_EVENODD) f |= EF_EVENODD;
+        if (!(ref & 0x80000000u)) f |= EF_HAS_SEGS;
+        else if (sfl & SF_FULL) f |= EF_FULL;
+        if (sfl & SF_IS_CLIP) f |= EF_IS_CLIP;
+        else {
+            if (sfl & SF_CLIPPED) f |= EF_CLIPPED;
+            if (((sfl >> SF_FILL_SHIFT) & 3u) == FORMA_FILL_SOLID) f |= EF_SOLID;
+            if (sfl & SF_OPAQUE) f |= EF_OPAQUE;
+            if (((sfl >> SF_BLEND_SHIFT) & 15u) == 0u) f |= EF_OVER;
+        }
+        flags[rank] = f;
+    }
+    wave_lds_sync();
+
+    const Col clear = {P.clear[0], P.clear[1], P.clear[2], P.clear[3]};
+    // ---- optimizer passes (layer_workbench/passes/*.rs) -------------------------------------------------------------
+    if (P.scene_has_clips) {                                            // skip_trivial_clips_pass: serial (clip state machine)
+        if (lane == 0) {
+            bool has = false, c_full = false, c_used = false; uint32_t c_last = 0, c_i = 0;
+            for (uint32_t i = 0; i < ne; i++) {
+                uint32_t f = flags[i];
+                if (!(f & EF_MASK)) continue;
+                const uint32_t id = (uint32_t)(keys[i] >> 32) & LAYER_MASK;
+                if (f & EF_IS_CLIP) {
+                    c_full = (f & EF_FULL) != 0;
+                    c_last = id + style_words[style_offsets[id] + 1]; c_i = i; c_used = false; has = true;
+                    if (c_full) { f &= ~EF_MASK; flags[i] = f; }
+                }
+                if (!(f & EF_IS_CLIP) && (f & EF_CLIPPED)) {
+                    if (has && id <= c_last) { if (c_full) { f |= EF_SKIPCLIP; flags[i] = f; } else c_used = true; }
+                    else { f &= ~EF_MASK; flags[i] = f; }
+                }
+                if (has && id > c_last) { has = false; if (!c_used) flags[c_i] &= ~EF_MASK; }
+            }
+            if (has && !c_used) flags[c_i] &= ~EF_MASK;
+        }
+        wave_lds_sync();
+    }
+    // skip_fully_covered_layers_pass: topmost FULL unclipped solid Over opaque layer ("cover") vs. topmost blocker
+    uint32_t top = 0, blk = 0;
+    for (uint32_t i = lane; i < ne; i += 64) {
+        const uint32_t f = flags[i];
+        if (!(f & EF_MASK)) continue;
+        const bool clipped = !(f & EF_IS_CLIP) && (f & EF_CLIPPED) && !(f & EF_SKIPCLIP);
+        if (clipped || !(f & EF_FULL)) blk = i + 1;
+        else if (!(f & EF_IS_CLIP) && (f & EF_SOLID) && (f & EF_OVER) && (f & EF_OPAQUE)) top = i + 1;
+    }
+    top = wave_max_u32(top); blk = wave_max_u32(blk);
+    const uint32_t skipped = top ? top - 1u : 0u;
+    const int first = top ? (blk > top ? 2 : 1) : (blk ? 2 : 0);
+
+    uint4* b_cov = w_cov[wv]; uint4* b_col = w_col[wv];
+    uint32_t* b_seg0 = w_seg0[wv]; uint32_t* b_nseg = w_nseg[wv]; uint32_t* b_flag = w_bflag[wv]; uint32_t* b_layer = w_blayer[wv];
+    const uint32_t px = tx * 16u + (uint32_t)lx;
+    if (first != 2) {                                                   // fold: every layer from `skipped` up is a full cover
+        Col dst = clear; bool ok = true;
+        for (uint32_t k0 = skipped; k0 < ne; k0 += WB) {
+            const uint32_t nbt = min((uint32_t)WB, ne - k0);
+            wave_lds_sync();
+            if ((uint32_t)lane < nbt) {
+                const uint32_t ref = (uint32_t)keys[k0 + lane];
+                b_col[lane] = (ref & 0x80000000u) ? span_col[ref & 0x7FFFFFFFu] : run_col[ref];
+            }
+            wave_lds_sync();
+            for (uint32_t t = 0; t < nbt && ok; t++) {                 // every lane folds the same (uniform) values
+                const uint32_t f = flags[k0 + t];
+                if (!(f & EF_MASK)) continue;
+                const uint4 c4 = b_col[t];
+                const Col src = {__uint_as_float(c4.x), __uint_as_float(c4.y), __uint_as_float(c4.z), __uint_as_float(c4.w)};
+                if (first == 1 && k0 + t == skipped) { dst = src; continue; }
+                if (!(f & EF_IS_CLIP) && (f & EF_SOLID)) dst = sc_blend((uint32_t)(keys[k0 + t] >> (53 + SF_BLEND_SHIFT)) & 15u, dst, src);
+                else ok = false;
+            }
+        }
+        if (ok) {                                                       // TileWriteOp::Solid: to_srgb_bytes :156-162, 690
+            float sel[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) sel[c] = sel_channel((P.channels >> (8 * c)) & 0xFFu, dst.r, dst.g, dst.b, dst.a);
+            const uint32_t bytes = to_u8_x4(linear_to_srgb(sel[0])) | (to_u8_x4(linear_to_srgb(sel[1])) << 8) |
+                                   (to_u8_x4(linear_to_srgb(sel[2])) << 16) | (to_u8_x4(sel[3]) << 24);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t py = ty * 16u + (uint32_t)(rg * 4 + q);
+                if (px < P.width && py < P.height) ((uint32_t*)image)[(size_t)py * P.stride_px + px] = bytes;
+            }
+            return;
+        }
+    }
+
+    // ---- the entries that are actually painted, in layer order (list reuses `tmp`) --------------------------------------
+    wave_lds_sync();
+    uint32_t* p_idx = (uint32_t*)tmp;
+    uint32_t np = 0;
+    for (uint32_t c = 0; c < ne; c += 64) {
+        const uint32_t i = c + lane;
+        const bool keep = i >= skipped && i < ne && (flags[i] & EF_MASK);
+        const uint64_t bal = __ballot(keep);
+        if (keep) p_idx[np + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = i;
+        np += (uint32_t)__popcll(bal);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) { w_cells[wv][0][q * 64 + lane] = 0; w_cells[wv][1][q * 64 + lane] = 0; }
+
+    // ---- paint (Painter::paint_layer, painter/mod.rs:290-347): four pixels per lane ------------------------------------
+    float dr[4], dg[4], db[4], da[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { dr[q] = clear.r; dg[q] = clear.g; db[q] = clear.b; da[q] = clear.a; }   // Painter::clear :277-288
+    bool clip_valid = false; uint32_t clip_last = 0; float clip_mask[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const float fx = (float)px;
+    uint32_t cbuf = 0;
+    for (uint32_t b0 = 0; b0 < np; b0 += WB) {
+        const uint32_t nbt = min((uint32_t)WB, np - b0);
+        wave_lds_sync();
+        if ((uint32_t)lane < nbt) {                                     // everything the layer loop needs, into LDS
+            const uint32_t i = p_idx[b0 + lane];
+            const uint64_t k = keys[i];
+            const uint32_t ref = (uint32_t)k;
+            b_flag[lane] = flags[i] | ((uint32_t)(k >> 53) << 16);
+            b_layer[lane] = (uint32_t)(k >> 32) & LAYER_MASK;
+            if (ref & 0x80000000u) {
+                b_cov[lane] = span_cov[ref & 0x7FFFFFFFu]; b_col[lane] = span_col[ref & 0x7FFFFFFFu];
+                b_seg0[lane] = 0; b_nseg[lane] = 0;
+            } else {
+                const TileRecord* r = &records[ref];
+                b_cov[lane] = make_uint4(r->cover[0], r->cover[1], r->cover[2], r->cover[3]);
+                b_col[lane] = run_col[ref];
+                b_seg0[lane] = r->seg_start; b_nseg[lane] = r->seg_count;
+            }
+        }
+        wave_lds_sync();
+        for (uint32_t t = 0; t < nbt; t++) {
+            const uint32_t f = b_flag[t];
+            const uint32_t layer = b_layer[t];
+            const uint32_t sfl = f >> 16;
+            const uint4 cv4 = b_cov[t];
+            const uint32_t cw = rg == 0 ? cv4.x : (rg == 1 ? cv4.y : (rg == 2 ? cv4.z : cv4.w));   // bytes = rows 4 rg .. 4 rg + 3
+            const uint32_t nseg = b_nseg[t];
+            int A[4];
+            if (nseg) {
+                int* cb = w_cells[wv][cbuf];
+                const uint64_t* sp = sorted + b_seg0[t];
+                for (uint32_t sidx = lane; sidx < nseg; sidx += 64) {   // acc_segment :257-271
+                    const uint64_t v = sp[sidx];
+                    const int cv = seg_cover(v);
+                    atomicAdd(&cb[seg_ly(v) * 16 + seg_lx(v)], (int)((uint32_t)(seg_dam(v) * cv) << 16) + cv);
+                }
+                wave_lds_sync();
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int ci = (rg * 4 + q) * 16 + lx;
+                    const int S = cb[ci];
+                    cb[ci] = 0;                                         // ready for the layer after next
+                    const int c = (int)(int16_t)(S & 0xFFFF);
+                    const int area = (int)(int16_t)((uint32_t)(S - c) >> 16);
+                    int inc = c;                                        // signed cover prefix along x (one DPP row)
+                    inc += dpp_row_shr(inc, 1); inc += dpp_row_shr(inc, 2); inc += dpp_row_shr(inc, 4); inc += dpp_row_shr(inc, 8);
+                    const int carry = (int)(int8_t)(cw >> (q * 8));
+                    const int acc = (int)(int8_t)(carry + (inc - c));   // i8 wrapping column accumulator :343-345
+                    A[q] = 32 * acc + area;                             // compute_doubled_areas :388-404
+                }
+                cbuf ^= 1u;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; q++) A[q] = 32 * (int)(int8_t)(cw >> (q * 8));
+            }
+            if (clip_valid && clip_last < layer) clip_valid = false;    // :298-302
+            const bool eo = (f & EF_EVENODD) != 0;
+            if (f & EF_IS_CLIP) {                                       // clip_at :449-464
+                if (!clip_valid) { clip_valid = true; clip_last = layer + b_col[t].x; }
+#pragma unroll
+                for (int q = 0; q < 4; q++) clip_mask[q] = coverage_of(A[q], eo);
+                continue;
+            }
+            const bool apply_clip = (f & EF_CLIPPED) && !(f & EF_SKIPCLIP);
+            if (apply_clip && !clip_valid) continue;                    // :321-323
+            const uint32_t ft = (sfl >> SF_FILL_SHIFT) & 3u;
+            const uint32_t bm = (sfl >> SF_BLEND_SHIFT) & 15u;
+            const uint4 col = b_col[t];
+            const uint32_t* w = (ft == FORMA_FILL_SOLID) ? nullptr : style_words + style_offsets[layer];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float cov = coverage_of(A[q], eo);
+                if (cov == 0.0f) continue;                              // :317-319 (blend with 0 is the identity)
+                float fill[4];
+                if (ft == FORMA_FILL_SOLID) {
+                    fill[0] = __uint_as_float(col.x); fill[1] = __uint_as_float(col.y); fill[2] = __uint_as_float(col.z); fill[3] = __uint_as_float(col.w);
+                } else {
+                    const int ly = rg * 4 + q;
+                    const float fybase = (float)(ty * 16u + ((uint32_t)ly & 8u));                     // :326
+                    if (ft == FORMA_FILL_TEXTURE) texture_at(w, images, texels, fx, fybase + (float)(ly & 7), fill);
+                    else gradient_at(w, ft, FORMA_STYLE_STOPS(w[0]), fx, fybase, ly & 7, fill);
+                }
+                float src_a = fill[3] * cov;                            // blend_at :406-447
+                if (apply_clip) src_a *= clip_mask[q];
+                float bl[3];
+                blend_rgb(bm, dr[q], dg[q], db[q], fill[0], fill[1], fill[2], bl);
+                const float ida = 1.0f - da[q], k1 = ida * src_a, isa = 1.0f - src_a, k2 = da[q] * src_a;
+                const float cr = fmaf(fill[0], k1, bl[0] * k2);
+                const float cg = fmaf(fill[1], k1, bl[1] * k2);
+                const float cb2 = fmaf(fill[2], k1, bl[2] * k2);
+                dr[q] = fmaf(dr[q], isa, cr); dg[q] = fmaf(dg[q], isa, cg); db[q] = fmaf(db[q], isa, cb2);
+                da[q] = fmaf(da[q], isa, src_a);
+            }
+        }
+    }
+    // ---- compute_srgb :466-483 + channel select, straight to the row-major RGBA8 image ----------------------------------
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint32_t py = ty * 16u + (uint32_t)(rg * 4 + q);
+        if (px < P.width && py < P.height) {
+            const float sr = linear_to_srgb(dr[q]), sg = linear_to_srgb(dg[q]), sb2 = linear_to_srgb(db[q]);
+            uint32_t out = 0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) out |= to_u8_x8(sel_channel((P.channels >> (8 * c)) & 0xFFu, sr, sg, sb2, da[q])) << (8 * c);
+            ((uint32_t*)image)[(size_t)py * P.stride_px + px] = out;
+        }
+    }
+}
+
 #define PAINT_ARGS P, tile, sorted, records, n_runs, tile_first_run, row_span_lo, row_span_cnt, span_key, span_cov, run_col, span_col, \
                    style_offsets, style_words, images, texels, image, info
 #define PAINT_PARAMS PaintParams P, const uint64_t* __restrict__ sorted, const TileRecord* __restrict__ records, uint32_t n_runs, \
@@ -1104,18 +1437,7 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
                      const forma_image_t* __restrict__ images, const uint16_t* __restrict__ texels, uint8_t* __restrict__ image, \
                      FrameInfo* __restrict__ info
 
-// the common case: one workgroup per tile, lists of up to PAINT_MAXE entries, 8 workgroups per CU
-#define PAINT_MAXE      512
 #define PAINT_MAXE_DEEP 4096
-__global__ __launch_bounds__(256) void k_paint(PAINT_PARAMS, uint32_t* __restrict__ overflow, unsigned long long* __restrict__ prof) {
-    // XCD-aware tile mapping: consecutive workgroups land on different XCDs (block b -> XCD b % 8); give
-    // each XCD a contiguous band of tiles so a tile row's records/spans/styles stay in one L2.
-    const uint32_t T = P.tiles_w * P.tiles_h;
-    const uint32_t bid = blockIdx.x, per = (T + 7) / 8;
-    const uint32_t tile = (bid & 7u) * per + (bid >> 3);
-    if (tile >= T || (bid >> 3) >= per) return;
-    paint_tile<PAINT_MAXE>(PAINT_ARGS, overflow, prof);
-}
 // the rare deep tiles the first launch could not hold
 __global__ __launch_bounds__(256) void k_paint_deep(PAINT_PARAMS, const uint32_t* __restrict__ overflow) {
     const uint32_t n = overflow[0];
@@ -1135,9 +1457,10 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
     if (T == 0) return;
     uint32_t per = (T + 7) / 8;
     (void)hipMemsetAsync(overflow, 0, 4, s);
-    hipLaunchKernelGGL(k_paint, dim3(per * 8), dim3(256), 0, s, p, sorted, records, n_runs, tile_first_run, row_span_lo,
+    (void)prof;
+    hipLaunchKernelGGL(k_paint_wave, dim3(per * 8), dim3(64), 0, s, p, sorted, records, n_runs, tile_first_run, row_span_lo,
                        row_span_cnt, span_key, span_cov, run_col, span_col, style_offsets, style_words, images, texels, image,
-                       info, overflow, prof);
+                       info, overflow);
     hipLaunchKernelGGL(k_paint_deep, dim3(T < 256 ? T : 256), dim3(256), 0, s, p, sorted, records, n_runs, tile_first_run,
                        row_span_lo, row_span_cnt, span_key, span_cov, run_col, span_col, style_offsets, style_words, images,
                        texels, image, info, (const uint32_t*)overflow);
