@@ -61,7 +61,7 @@ struct forma_hip_ctx {
     bool pred_valid = false, pred_layer_sorted = false, speculated = false;
     uint64_t pred_live44 = 0;
     DevBuf prof;                            // FORMA_HIP_PROF=1: per-phase shader-clock sums of the painter (diagnostics)
-    DevBuf info, records, run_cov, rk_u, rk_a, rk_b, blk_edge, runs_scratch, tile_first_run, row_tab, span_key, span_cov, run_col, span_col, paint_overflow, image;
+    DevBuf info, records, run_cov, rk_u, rk_a, rk_b, blk_edge, runs_scratch, row_tab, span_key, span_cov, run_col, span_col, image;
     uint32_t img_w = 0, img_h = 0;
     FrameInfo* h_info = nullptr;            // pinned
     // band
@@ -228,13 +228,16 @@ int run_paint(forma_hip_ctx* ctx, size_t n, const PaintArgs& a, bool timing) {
     const uint32_t T = tiles_w * tiles_h;
     HIPCHECK(ctx->image.ensure((size_t)a.width * a.height * 4));
     ctx->img_w = a.width; ctx->img_h = a.height;
-    HIPCHECK(ctx->tile_first_run.ensure((size_t)(T + 1) * 4));
-    HIPCHECK(ctx->row_tab.ensure((size_t)(tiles_h + 1) * 4 * 3));
-    HIPCHECK(ctx->paint_overflow.ensure((size_t)(T + 1) * 4));
+    // one buffer, zeroed by ONE memset per frame (launch_runs): [row_count | row_span_lo | row_span_cnt] (tiles_h + 1 words
+    // each) [painter overflow counter] [first-run table, T words]; the painter's overflow list (T words) follows un-zeroed
+    HIPCHECK(ctx->row_tab.ensure(((size_t)(tiles_h + 1) * 3 + 1 + 2 * (size_t)T) * 4));
     FrameInfo* dinfo = ctx->info.as<FrameInfo>();
     uint32_t* row_count = ctx->row_tab.as<uint32_t>();
     uint32_t* row_span_lo = row_count + (tiles_h + 1);
     uint32_t* row_span_cnt = row_span_lo + (tiles_h + 1);
+    uint32_t* paint_overflow = row_span_cnt + (tiles_h + 1);          // [0] = count, then the first-run table ...
+    uint32_t* tile_first_run = paint_overflow + 1;
+    uint32_t* overflow_list = tile_first_run + T;                       // ... then the list itself
     uint32_t J = 0;
     // capacity: a run needs at least one segment, and so does a span's left neighbour
     const size_t cap = std::max<size_t>(n, 1);
@@ -245,7 +248,7 @@ int run_paint(forma_hip_ctx* ctx, size_t n, const PaintArgs& a, bool timing) {
     HIPCHECK(ctx->runs_scratch.ensure(runs_scratch_words(cap) * 4));
     stage_begin(ctx, ST_CARRY, timing);
     launch_runs(ctx->stream, ctx->sorted, (uint32_t)n, tiles_w, tiles_h, ctx->records.as<TileRecord>(), ctx->run_cov.as<uint4>(),
-                ctx->rk_u.as<uint64_t>(), ctx->tile_first_run.as<uint32_t>(), ctx->blk_edge.as<BlkEdge>(), row_count,
+                ctx->rk_u.as<uint64_t>(), tile_first_run, ctx->blk_edge.as<BlkEdge>(), row_count,
                 ctx->runs_scratch.as<uint32_t>(), dinfo);
     HIPCHECK(hipGetLastError());
     if (n > 0) {
@@ -298,11 +301,11 @@ int run_paint(forma_hip_ctx* ctx, size_t n, const PaintArgs& a, bool timing) {
     for (int i = 0; i < 4; i++) P.clear[i] = a.clear[i];
     P.stride_px = a.width; P.scene_has_clips = ctx->scene_has_clips ? 1u : 0u; P.n_orders = (uint32_t)ctx->n_orders;
     stage_begin(ctx, ST_PAINT, timing);
-    launch_paint(ctx->stream, P, ctx->sorted, ctx->records.as<TileRecord>(), J, ctx->tile_first_run.as<uint32_t>(), row_span_lo,
+    launch_paint(ctx->stream, P, ctx->sorted, ctx->records.as<TileRecord>(), J, tile_first_run, row_span_lo,
                  row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(), ctx->run_col.as<uint4>(),
                  ctx->span_col.as<uint4>(), ctx->style_off.as<uint32_t>(),
                  ctx->style_words.as<uint32_t>(), ctx->images.as<forma_image_t>(), ctx->texels.as<uint16_t>(),
-                 ctx->image.as<uint8_t>(), dinfo, ctx->paint_overflow.as<uint32_t>(), ctx->prof.p ? ctx->prof.as<unsigned long long>() : nullptr);
+                 ctx->image.as<uint8_t>(), dinfo, paint_overflow, overflow_list, ctx->prof.p ? ctx->prof.as<unsigned long long>() : nullptr);
     stage_end(ctx, ST_PAINT, timing);
     HIPCHECK(hipGetLastError());
     return FORMA_OK;
@@ -425,7 +428,7 @@ void forma_hip_destroy(forma_hip_ctx* ctx) {
                      &ctx->l_b, &ctx->l_c, &ctx->l_d, &ctx->l_len, &ctx->scan_tmp, &ctx->cl_idx, &ctx->cl_start,
                      &ctx->block_first, &ctx->prep_scratch, &ctx->seg_u, &ctx->seg_a, &ctx->seg_b,
                      &ctx->sort_counters, &ctx->info, &ctx->info_init, &ctx->records, &ctx->run_cov, &ctx->rk_u, &ctx->rk_a, &ctx->rk_b,
-                     &ctx->blk_edge, &ctx->runs_scratch, &ctx->tile_first_run, &ctx->row_tab, &ctx->span_key, &ctx->span_cov, &ctx->run_col, &ctx->span_col, &ctx->paint_overflow,
+                     &ctx->blk_edge, &ctx->runs_scratch, &ctx->row_tab, &ctx->span_key, &ctx->span_cov, &ctx->run_col, &ctx->span_col,
                      &ctx->image};
     for (DevBuf* b : all) b->release();
     for (int s = 0; s < ST_COUNT; s++) { (void)hipEventDestroy(ctx->ev0[s]); (void)hipEventDestroy(ctx->ev1[s]); }

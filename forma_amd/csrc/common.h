@@ -137,5 +137,6 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
                   const uint32_t* tile_first_run, const uint32_t* row_span_lo, const uint32_t* row_span_cnt,
                   const uint64_t* span_key, const uint4* span_cov, const uint4* run_col, const uint4* span_col,
                   const uint32_t* style_offsets, const uint32_t* style_words, const forma_image_t* images,
-                  const uint16_t* texels, uint8_t* image, FrameInfo* info, uint32_t* overflow /* tiles_w * tiles_h + 1 words */,
+                  const uint16_t* texels, uint8_t* image, FrameInfo* info, uint32_t* overflow_n /* zeroed by launch_runs */,
+                  uint32_t* overflow_list /* tiles_w * tiles_h words */,
                   unsigned long long* prof /* nullable: per-phase shader-clock sums (diagnostics) */);

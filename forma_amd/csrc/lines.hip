@@ -219,91 +219,112 @@ __device__ __forceinline__ void mark_block_first(uint32_t* __restrict__ block_fi
         if (b < bf_cap) block_first[b] = c;
 }
 
-__global__ __launch_bounds__(PC_THREADS) void k_prepare_compact(LineSource S, uint32_t n_lines,
-                                                                uint32_t* __restrict__ cl_idx,
-                                                                uint32_t* __restrict__ cl_start,
-                                                                uint32_t* __restrict__ block_first, uint32_t bf_cap,
-                                                                uint64_t* __restrict__ status,
-                                                                uint32_t* __restrict__ ticket,
-                                                                FrameInfo* __restrict__ info) {
-    __shared__ uint32_t s_len[PC_TILE];
+// pass A: segment count of every line + per-tile (sum, non-empty count)
+__global__ __launch_bounds__(PC_THREADS) void k_line_len(LineSource S, uint32_t n_lines, uint32_t* __restrict__ lens,
+                                                         uint32_t* __restrict__ tile_sum, uint32_t* __restrict__ tile_cnt) {
     __shared__ uint32_t s_wsum[PC_THREADS / 64], s_wcnt[PC_THREADS / 64];
-    __shared__ uint32_t s_tile, s_psum, s_pcnt;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t ntiles = (n_lines + PC_TILE - 1) / PC_TILE;
-    while (true) {
-        if (tid == 0) s_tile = atomicAdd(ticket, 1u);
-        __syncthreads();
-        const uint32_t tile = s_tile;
-        if (tile >= ntiles) break;
-        const uint32_t base = tile * PC_TILE;
+    const uint32_t base = blockIdx.x * PC_TILE;
+    uint32_t sum = 0, cnt = 0;
 #pragma unroll
-        for (int r = 0; r < PC_IPT; r++) {
-            const uint32_t i = base + r * PC_THREADS + tid;
-            uint32_t len = 0;
-            if (i < n_lines) {
-                if (S.sums) len = S.sums[i] - (i ? S.sums[i - 1] : 0u);
-                else len = line_params(S.x, S.y, S.line_slot, i, S.geoms, S.n_geoms, S.width, S.height, S.band_lo, S.band_hi).len;
-            }
-            s_len[r * PC_THREADS + tid] = len;
+    for (int r = 0; r < PC_IPT; r++) {
+        const uint32_t i = base + r * PC_THREADS + tid;
+        uint32_t len = 0;
+        if (i < n_lines) {
+            if (S.sums) len = S.sums[i] - (i ? S.sums[i - 1] : 0u);
+            else len = line_params(S.x, S.y, S.line_slot, i, S.geoms, S.n_geoms, S.width, S.height, S.band_lo, S.band_hi).len;
+            lens[i] = len;
         }
-        __syncthreads();
-        uint32_t l[PC_IPT], sum = 0, cnt = 0;
+        sum += len; cnt += len ? 1u : 0u;
+    }
 #pragma unroll
-        for (int q = 0; q < PC_IPT; q++) { l[q] = s_len[tid * PC_IPT + q]; sum += l[q]; cnt += l[q] ? 1u : 0u; }
-        uint32_t isum = sum, icnt = cnt;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            uint32_t ts = __shfl_up(isum, d, 64), tc = __shfl_up(icnt, d, 64);
-            if (lane >= d) { isum += ts; icnt += tc; }
-        }
-        if (lane == 63) { s_wsum[w] = isum; s_wcnt[w] = icnt; }
-        __syncthreads();
-        uint32_t bsum = 0, bcnt = 0, tsum = 0, tcnt = 0;
-#pragma unroll
-        for (int i = 0; i < PC_THREADS / 64; i++) {
-            if (i < w) { bsum += s_wsum[i]; bcnt += s_wcnt[i]; }
-            tsum += s_wsum[i]; tcnt += s_wcnt[i];
-        }
-        if (w == 0) {                                     // wave-parallel look-back (lookback.h)
-            uint32_t pcnt = 0, psum = 0;
-            if (tile > 0) {
-                if (lane == 0) lb_st64(&status[tile], ((uint64_t)LB_AGG << 62) | ((uint64_t)tcnt << 32) | tsum);
-                lb_lookback_u64(status, tile, &info->error, &pcnt, &psum);
-            }
-            if (lane == 0) {
-                lb_st64(&status[tile], ((uint64_t)LB_PREFIX << 62) | ((uint64_t)((pcnt + tcnt) & 0x3FFFFFFFu) << 32) | (uint32_t)(psum + tsum));
-                s_psum = psum; s_pcnt = pcnt;
-                if (tile == ntiles - 1) { info->n_segments = psum + tsum; info->n_compact = pcnt + tcnt; }
-            }
-        }
-        __syncthreads();
-        uint32_t start = s_psum + bsum + isum - sum;
-        uint32_t c = s_pcnt + bcnt + icnt - cnt;
-#pragma unroll
-        for (int q = 0; q < PC_IPT; q++) {
-            if (l[q]) {
-                cl_idx[c] = base + tid * PC_IPT + q;
-                cl_start[c] = start;
-                mark_block_first(block_first, bf_cap, start, l[q], c);
-                start += l[q]; c++;
-            }
-        }
-        __syncthreads();
+    for (int d = 32; d >= 1; d >>= 1) { sum += __shfl_xor(sum, d, 64); cnt += __shfl_xor(cnt, d, 64); }
+    if (lane == 0) { s_wsum[w] = sum; s_wcnt[w] = cnt; }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t ts = 0, tc = 0;
+        for (int i = 0; i < PC_THREADS / 64; i++) { ts += s_wsum[i]; tc += s_wcnt[i]; }
+        tile_sum[blockIdx.x] = ts; tile_cnt[blockIdx.x] = tc;
     }
 }
 
-size_t prepare_scratch_words(size_t n_lines) { return 2 * ((n_lines + PC_TILE - 1) / PC_TILE + 1) + 16; }
+// pass B: one workgroup, exclusive scan of both per-tile arrays in place; totals -> info
+__global__ __launch_bounds__(1024) void k_scan_line_tiles(uint32_t* __restrict__ tile_sum, uint32_t* __restrict__ tile_cnt,
+                                                          uint32_t nb, FrameInfo* __restrict__ info) {
+    __shared__ uint32_t lds_a[17], lds_b[17];
+    uint32_t carry_a = 0, carry_b = 0;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (uint32_t base = 0; base < nb; base += 1024) {
+        const uint32_t idx = base + threadIdx.x;
+        const uint32_t a = idx < nb ? tile_sum[idx] : 0u, b = idx < nb ? tile_cnt[idx] : 0u;
+        uint32_t ia = a, ib = b;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t ta = __shfl_up(ia, d, 64), tb = __shfl_up(ib, d, 64);
+            if (lane >= d) { ia += ta; ib += tb; }
+        }
+        if (lane == 63) { lds_a[w] = ia; lds_b[w] = ib; }
+        __syncthreads();
+        uint32_t wa = 0, wb = 0, ta = 0, tb = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { if (i < w) { wa += lds_a[i]; wb += lds_b[i]; } ta += lds_a[i]; tb += lds_b[i]; }
+        if (idx < nb) { tile_sum[idx] = carry_a + wa + ia - a; tile_cnt[idx] = carry_b + wb + ib - b; }
+        carry_a += ta; carry_b += tb;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { info->n_segments = carry_a; info->n_compact = carry_b; }
+}
+
+// pass C: compacted line table (cl_idx, cl_start) + block_first; no inter-workgroup dependency
+__global__ __launch_bounds__(PC_THREADS) void k_line_compact(const uint32_t* __restrict__ lens, uint32_t n_lines,
+                                                             const uint32_t* __restrict__ tile_sum,
+                                                             const uint32_t* __restrict__ tile_cnt,
+                                                             uint32_t* __restrict__ cl_idx, uint32_t* __restrict__ cl_start,
+                                                             uint32_t* __restrict__ block_first, uint32_t bf_cap) {
+    __shared__ uint32_t s_wsum[PC_THREADS / 64], s_wcnt[PC_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t base = blockIdx.x * PC_TILE + tid * PC_IPT;         // 8 consecutive lines per thread
+    uint32_t l[PC_IPT], sum = 0, cnt = 0;
+#pragma unroll
+    for (int q = 0; q < PC_IPT; q++) { l[q] = base + q < n_lines ? lens[base + q] : 0u; sum += l[q]; cnt += l[q] ? 1u : 0u; }
+    uint32_t isum = sum, icnt = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t ts = __shfl_up(isum, d, 64), tc = __shfl_up(icnt, d, 64);
+        if (lane >= d) { isum += ts; icnt += tc; }
+    }
+    if (lane == 63) { s_wsum[w] = isum; s_wcnt[w] = icnt; }
+    __syncthreads();
+    uint32_t bsum = tile_sum[blockIdx.x], bcnt = tile_cnt[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < PC_THREADS / 64; i++) if (i < w) { bsum += s_wsum[i]; bcnt += s_wcnt[i]; }
+    uint32_t start = bsum + isum - sum, c = bcnt + icnt - cnt;
+#pragma unroll
+    for (int q = 0; q < PC_IPT; q++) {
+        if (l[q]) {
+            cl_idx[c] = base + q;
+            cl_start[c] = start;
+            mark_block_first(block_first, bf_cap, start, l[q], c);
+            start += l[q]; c++;
+        }
+    }
+}
+
+size_t prepare_scratch_words(size_t n_lines) { return n_lines + 2 * ((n_lines + PC_TILE - 1) / PC_TILE + 1) + 16; }
 
 void launch_prepare_compact(hipStream_t s, const LineSource& src, uint32_t n_lines, uint32_t* cl_idx, uint32_t* cl_start,
                             uint32_t* block_first, uint32_t bf_cap, uint32_t* scratch, FrameInfo* info) {
     if (n_lines == 0) return;
+    // chain-free: count -> scan (one workgroup) -> compact.  (A single-pass chained scan was 2x slower here: with only
+    // ~800 tiles the whole grid is resident at once, so every tile walks back through aggregates to tile 0.)
     const uint32_t ntiles = (n_lines + PC_TILE - 1) / PC_TILE;
-    // [ticket (16 words)] [status: ntiles u64] — re-initialised every call
-    (void)hipMemsetAsync(scratch, 0, (16 + 2 * (size_t)ntiles) * 4, s);
-    uint32_t grid = ntiles < 1024 ? ntiles : 1024;
-    hipLaunchKernelGGL(k_prepare_compact, dim3(grid), dim3(PC_THREADS), 0, s, src, n_lines, cl_idx, cl_start, block_first,
-                       bf_cap, (uint64_t*)(scratch + 16), scratch, info);
+    uint32_t* lens = scratch;
+    uint32_t* tile_sum = scratch + n_lines;
+    uint32_t* tile_cnt = tile_sum + ntiles + 1;
+    hipLaunchKernelGGL(k_line_len, dim3(ntiles), dim3(PC_THREADS), 0, s, src, n_lines, lens, tile_sum, tile_cnt);
+    hipLaunchKernelGGL(k_scan_line_tiles, dim3(1), dim3(1024), 0, s, tile_sum, tile_cnt, ntiles, info);
+    hipLaunchKernelGGL(k_line_compact, dim3(ntiles), dim3(PC_THREADS), 0, s, (const uint32_t*)lens, n_lines,
+                       (const uint32_t*)tile_sum, (const uint32_t*)tile_cnt, cl_idx, cl_start, block_first, bf_cap);
 }
 
 __global__ __launch_bounds__(256) void k_block_first(const uint32_t* __restrict__ cl_start, uint32_t n_compact,

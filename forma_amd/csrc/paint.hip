@@ -222,7 +222,7 @@ __global__ __launch_bounds__(RN_THREADS, 8) void k_runs(const uint64_t* __restri
                 run_cov[j] = pack_bins(b);
                 run_keys[j] = ((uint64_t)tyb << 53) | ((uint64_t)layer << 32) | j;
                 if (txb >= 1u && ((uint32_t)(pv >> 41) != (uint32_t)(v >> 41) || base + i == 0))
-                    tile_first_run[(tyb - 1u) * tiles_w + (txb - 1u)] = j;
+                    tile_first_run[(tyb - 1u) * tiles_w + (txb - 1u)] = j + 1u;        // 0 = the tile has no run
                 const uint32_t rr = (tyb - 1u) - row0;
                 if (rr < RN_ROWS) atomicAdd(&s_rows[rr], 1u); else atomicAdd(&row_count[tyb - 1u], 1u);
             }
@@ -249,9 +249,9 @@ size_t runs_blocks(size_t n) { return (n + RN_TILE - 1) / RN_TILE + 1; }
 void launch_runs(hipStream_t s, const uint64_t* sorted, uint32_t n, uint32_t tiles_w, uint32_t tiles_h, TileRecord* records,
                  uint4* run_cov, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge, uint32_t* row_tab,
                  uint32_t* scratch, FrameInfo* info) {
-    // per-frame state: first-run table (NONE), per-row run counts
-    (void)hipMemsetAsync(tile_first_run, 0xFF, (size_t)tiles_w * tiles_h * 4, s);
-    (void)hipMemsetAsync(row_tab, 0, (size_t)(tiles_h + 1) * 4 * 3, s);        // row_count | row_span_lo | row_span_cnt
+    // per-frame state, ONE memset: [row_count | row_span_lo | row_span_cnt | painter overflow counter | first-run table]
+    // are contiguous (api.cpp lays them out so); 0 in the first-run table = the tile has no run
+    (void)hipMemsetAsync(row_tab, 0, ((size_t)(tiles_h + 1) * 3 + 1 + (size_t)tiles_w * tiles_h) * 4, s);
     if (n == 0) { (void)hipMemsetAsync(&info->n_runs, 0, 4, s); return; }
     const uint32_t ntiles = (n + RN_TILE - 1) / RN_TILE;
     hipLaunchKernelGGL(k_runs_count, dim3(ntiles), dim3(RN_THREADS), 0, s, sorted, n, tiles_w, tiles_h, scratch);
@@ -774,7 +774,7 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
     //      entry = (layer << 32) | ref, ref = run index, or 0x80000000 | span index ------------------------------
     const uint32_t my_tile_key = ((ty + 1u) << 12) | (tx + 1u);
     // first round of loads, all independent: where this tile's runs start, where this row's spans are
-    const uint32_t j0 = tile_first_run[tile];
+    const uint32_t j0 = tile_first_run[tile] - 1u;                      // 0 stored = no run -> FORMA_NONE
     const uint32_t sb = row_span_lo[ty], sc = row_span_cnt[ty];
     uint32_t na = 0;
     if (tid == 0) { s_seg0 = 0; s_seg1 = 0; }
@@ -1128,7 +1128,8 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
                                                     const uint32_t* __restrict__ style_words,
                                                     const forma_image_t* __restrict__ images,
                                                     const uint16_t* __restrict__ texels, uint8_t* __restrict__ image,
-                                                    FrameInfo* __restrict__ info, uint32_t* __restrict__ overflow) {
+                                                    FrameInfo* __restrict__ info, uint32_t* __restrict__ overflow_n,
+                                                    uint32_t* __restrict__ overflow_list) {
     __shared__ uint64_t w_key[1][WMAX];
     __shared__ uint64_t w_tmp[1][WMAX];
     __shared__ uint32_t w_flag[1][WMAX];
@@ -1154,7 +1155,7 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
 
     // ---- the tile's layer list: own runs (contiguous records, ascending layer) + the row's spans that cross it --------
     const uint32_t my_tile_key = ((ty + 1u) << 12) | (tx + 1u);
-    const uint32_t j0 = tile_first_run[tile];
+    const uint32_t j0 = tile_first_run[tile] - 1u;                      // 0 stored = no run -> FORMA_NONE
     const uint32_t sb = row_span_lo[ty], sc = row_span_cnt[ty];
     uint64_t sk[4];
 #pragma unroll
@@ -1191,7 +1192,7 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
     }
     const uint32_t ne = na + nb;
     if (ne > WMAX) {                                                    // too deep for a wave: the workgroup variant paints it
-        if (lane == 0) overflow[1 + atomicAdd(&overflow[0], 1u)] = tile;
+        if (lane == 0) overflow_list[atomicAdd(overflow_n, 1u)] = tile;
         return;
     }
     wave_lds_sync();
@@ -1439,10 +1440,11 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
 
 #define PAINT_MAXE_DEEP 4096
 // the rare deep tiles the first launch could not hold
-__global__ __launch_bounds__(256) void k_paint_deep(PAINT_PARAMS, const uint32_t* __restrict__ overflow) {
-    const uint32_t n = overflow[0];
+__global__ __launch_bounds__(256) void k_paint_deep(PAINT_PARAMS, const uint32_t* __restrict__ overflow_n,
+                                                    const uint32_t* __restrict__ overflow_list) {
+    const uint32_t n = overflow_n[0];
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-        const uint32_t tile = overflow[1 + i];
+        const uint32_t tile = overflow_list[i];
         paint_tile<PAINT_MAXE_DEEP>(PAINT_ARGS, nullptr, nullptr);
         __syncthreads();
     }
@@ -1452,16 +1454,16 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
                   const uint32_t* tile_first_run, const uint32_t* row_span_lo, const uint32_t* row_span_cnt,
                   const uint64_t* span_key, const uint4* span_cov, const uint4* run_col, const uint4* span_col,
                   const uint32_t* style_offsets, const uint32_t* style_words, const forma_image_t* images,
-                  const uint16_t* texels, uint8_t* image, FrameInfo* info, uint32_t* overflow, unsigned long long* prof) {
+                  const uint16_t* texels, uint8_t* image, FrameInfo* info, uint32_t* overflow_n, uint32_t* overflow_list,
+                  unsigned long long* prof) {
     uint32_t T = p.tiles_w * p.tiles_h;
     if (T == 0) return;
     uint32_t per = (T + 7) / 8;
-    (void)hipMemsetAsync(overflow, 0, 4, s);
     (void)prof;
     hipLaunchKernelGGL(k_paint_wave, dim3(per * 8), dim3(64), 0, s, p, sorted, records, n_runs, tile_first_run, row_span_lo,
                        row_span_cnt, span_key, span_cov, run_col, span_col, style_offsets, style_words, images, texels, image,
-                       info, overflow);
+                       info, overflow_n, overflow_list);
     hipLaunchKernelGGL(k_paint_deep, dim3(T < 256 ? T : 256), dim3(256), 0, s, p, sorted, records, n_runs, tile_first_run,
                        row_span_lo, row_span_cnt, span_key, span_cov, run_col, span_col, style_offsets, style_words, images,
-                       texels, image, info, (const uint32_t*)overflow);
+                       texels, image, info, (const uint32_t*)overflow_n, (const uint32_t*)overflow_list);
 }

@@ -240,6 +240,14 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
 #pragma unroll
             for (int i = 0; i < OS_WAVES; i++) { uint32_t c = whist[i][tid]; whist[i][tid] = acc; acc += c; }
         }
+        __syncthreads();
+        // ---- stage in digit order (needs only tile-local positions), BEFORE the look-back: the key registers die here
+        //      and the staging of waves 4..7 overlaps the global round trips of the look-back lanes ---------------------
+#pragma unroll
+        for (int j = 0; j < OS_KPT; j++) {
+            const uint32_t dg = (uint32_t)(keys[j] >> shift) & dmask;
+            staged[whist[w][dg] + ((rnk[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu)] = keys[j];
+        }
         // ---- look-back: one lane per digit walks its own chain of status words, OS_LBW predecessors per probe.
         //      (A one-at-a-time walk moves ~1 tile per L2 round trip, which is about the rate at which tiles retire:
         //      the window of aggregate-only predecessors then never drains and the walk becomes the pass.)
@@ -273,13 +281,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
             s_gdelta[tid] = gstart + excl - lbase;
         }
         __syncthreads();
-        // ---- stage in digit order, then coalesced stores --------------------------------------------------
-#pragma unroll
-        for (int j = 0; j < OS_KPT; j++) {
-            const uint32_t dg = (uint32_t)(keys[j] >> shift) & dmask;
-            staged[whist[w][dg] + ((rnk[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu)] = keys[j];
-        }
-        __syncthreads();
+        // ---- coalesced stores: every digit run leaves the CU as one contiguous piece --------------------------------
         const uint32_t nvalid = min((uint32_t)OS_TILE, n - bbase);
 #pragma unroll
         for (int j = 0; j < OS_KPT; j++) {
