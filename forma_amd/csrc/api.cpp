@@ -59,6 +59,8 @@ struct forma_hip_ctx {
     // sort-plan speculation: the varying-bit mask and the layer-sortedness of a scene rarely change between frames, so
     // forma_hip_render plans the sort from the previous frame's values and verifies them when the frame is done
     bool pred_valid = false, pred_layer_sorted = false, speculated = false;
+    bool pred_counts_valid = false, no_async = false;    // N / J predictions for read-back-free frames (FORMA_HIP_SYNC=1 disables)
+    uint32_t pred_N = 0, pred_J = 0, pred_w = 0, pred_h = 0;
     uint64_t pred_live44 = 0;
     DevBuf prof;                            // FORMA_HIP_PROF=1: per-phase shader-clock sums of the painter (diagnostics)
     DevBuf info, records, run_cov, rk_u, rk_a, rk_b, blk_edge, runs_scratch, row_tab, span_key, span_cov, run_col, span_col, image;
@@ -105,21 +107,22 @@ int check_canvas(forma_hip_ctx* ctx, uint32_t width, uint32_t height) {
     return FORMA_OK;
 }
 
-// prepare + scan + compact -> (n_segments, n_compact) on the host, block_first valid for N
-int run_line_table(forma_hip_ctx* ctx, const LineSource& src, size_t n_lines, bool timing) {
+// prepare + scan + compact.  Synchronous form (bound_n == 0): (n_segments, n_compact) are read back and block_first is
+// valid for N.  Asynchronous form: nothing is read back, block_first is provisioned for bound_n segments.
+int run_line_table(forma_hip_ctx* ctx, const LineSource& src, size_t n_lines, bool timing, uint32_t bound_n = 0) {
     HIPCHECK(ctx->cl_idx.ensure(n_lines * 4));
     HIPCHECK(ctx->cl_start.ensure(n_lines * 4));
     HIPCHECK(ctx->prep_scratch.ensure(prepare_scratch_words(n_lines) * 4));
-    HIPCHECK(ctx->block_first.ensure(4096));
+    HIPCHECK(ctx->block_first.ensure(std::max<size_t>(4096, ((size_t)bound_n / RAS_TILE + 2) * 4)));
     const uint32_t bf_cap = (uint32_t)std::min<size_t>(ctx->block_first.cap / 4, 0xFFFFFFFFu);
     stage_begin(ctx, ST_PREPARE, timing);
     launch_prepare_compact(ctx->stream, src, (uint32_t)n_lines, ctx->cl_idx.as<uint32_t>(), ctx->cl_start.as<uint32_t>(),
                            ctx->block_first.as<uint32_t>(), bf_cap, ctx->prep_scratch.as<uint32_t>(), ctx->info.as<FrameInfo>());
     stage_end(ctx, ST_PREPARE, timing);
     HIPCHECK(hipGetLastError());
+    if (bound_n) return FORMA_OK;
     int rc = read_info(ctx);
     if (rc) return rc;
-    if (ctx->h_info->error & 4u) return fail(ctx, FORMA_E_INTERNAL, "look-back spin expired (prepare)");
     const size_t N = ctx->h_info->n_segments;
     ctx->n_seg = N; ctx->n_compact = ctx->h_info->n_compact;
     const size_t need = (N + RAS_TILE - 1) / RAS_TILE + 1;
@@ -152,8 +155,11 @@ int finish_rasterize(forma_hip_ctx* ctx) {
     return FORMA_OK;
 }
 
-// stages 1-2 on the uploaded geometry: line table + rasterize -> seg_u
-int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, bool timing, bool speculate = false) {
+// stages 1-2 on the uploaded geometry: line table + rasterize -> seg_u.
+// bound_n != 0: fully asynchronous (no read-back): N is only known to the device, buffers / grids are provisioned for
+// bound_n segments, the sort plan is the speculated one.
+int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, bool timing, bool speculate = false,
+                        uint32_t bound_n = 0) {
     const size_t n_lines = ctx->n_points ? ctx->n_points - 1 : 0;
     ctx->n_lines = n_lines;
     ctx->n_seg = 0; ctx->n_compact = 0; ctx->have_unsorted = true; ctx->live44 = 0; ctx->layer_sorted = true;
@@ -162,25 +168,39 @@ int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, boo
     if (rc) return rc;
     if (n_lines == 0) return FORMA_OK;
     const LineSource S = geometry_source(ctx, width, height);
-    if ((rc = run_line_table(ctx, S, n_lines, timing))) return rc;
-    const size_t N = ctx->n_seg;
-    if (N == 0) return FORMA_OK;
-    if (N >= (1ull << 30)) return fail(ctx, FORMA_E_CAPACITY, "more than 2^30-1 pixel segments on one device");
-    HIPCHECK(ctx->seg_u.ensure(N * 8));
+    if ((rc = run_line_table(ctx, S, n_lines, timing, bound_n))) return rc;
+    FrameInfo* dinfo = ctx->info.as<FrameInfo>();
+    DevCount nc_seg, nc_cmp;
+    if (bound_n) {
+        nc_seg = DevCount{&dinfo->n_segments, bound_n};
+        nc_cmp = DevCount{&dinfo->n_compact, (uint32_t)n_lines};
+    } else {
+        const size_t N = ctx->n_seg;
+        if (N == 0) return FORMA_OK;
+        if (N >= (1ull << 30)) return fail(ctx, FORMA_E_CAPACITY, "more than 2^30-1 pixel segments on one device");
+        nc_seg = DevCount{nullptr, (uint32_t)N};
+        nc_cmp = DevCount{nullptr, (uint32_t)ctx->n_compact};
+    }
+    HIPCHECK(ctx->seg_u.ensure((size_t)nc_seg.bound * 8));
     stage_begin(ctx, ST_RASTER, timing);
-    launch_rasterize(ctx->stream, S, (uint32_t)ctx->n_compact, (uint32_t)N, ctx->cl_idx.as<uint32_t>(),
-                     ctx->cl_start.as<uint32_t>(), ctx->block_first.as<uint32_t>(), ctx->seg_u.as<uint64_t>(),
-                     ctx->info.as<FrameInfo>(), (int)ctx->band_row0, (int)ctx->band_row1);
+    launch_rasterize(ctx->stream, S, nc_cmp, nc_seg, ctx->cl_idx.as<uint32_t>(), ctx->cl_start.as<uint32_t>(),
+                     ctx->block_first.as<uint32_t>(), ctx->seg_u.as<uint64_t>(), dinfo, (int)ctx->band_row0,
+                     (int)ctx->band_row1);
     stage_end(ctx, ST_RASTER, timing);
     HIPCHECK(hipGetLastError());
-    ctx->speculated = speculate && ctx->pred_valid;
-    if (ctx->speculated) { ctx->live44 = ctx->pred_live44; ctx->layer_sorted = ctx->pred_layer_sorted; return FORMA_OK; }
+    ctx->speculated = (speculate || bound_n) && ctx->pred_valid;
+    if (ctx->speculated) {
+        ctx->live44 = ctx->pred_live44; ctx->layer_sorted = ctx->pred_layer_sorted;
+        if (bound_n) launch_verify_plan(ctx->stream, dinfo, ctx->live44, ctx->layer_sorted);   // device-side guard
+        return FORMA_OK;
+    }
     return finish_rasterize(ctx);
 }
 
-// stage 3 on `src` (n segments, device): result pointer in ctx->sorted
-int run_sort(forma_hip_ctx* ctx, const uint64_t* src, size_t n, bool timing, int digit_bits = 0) {
+// stage 3 on `src` (nc segments, device): result pointer in ctx->sorted
+int run_sort(forma_hip_ctx* ctx, const uint64_t* src, DevCount nc, bool timing, int digit_bits = 0) {
     ctx->n_passes = 0;
+    const size_t n = nc.bound;
     if (n >= (1ull << 30)) return fail(ctx, FORMA_E_CAPACITY, "more than 2^30-1 pixel segments on one device");
     if (digit_bits == 0) digit_bits = ctx->digit_bits;
     HIPCHECK(ctx->seg_a.ensure(std::max<size_t>(n, 1) * 8));
@@ -191,7 +211,7 @@ int run_sort(forma_hip_ctx* ctx, const uint64_t* src, size_t n, bool timing, int
     const SortPlan plan = make_sort_plan(live << 20, 20, 64, digit_bits);
     ctx->n_passes = plan.n_passes;
     stage_begin(ctx, ST_SORT, timing);
-    ctx->sorted = (uint64_t*)launch_radix_sort(ctx->stream, src, ctx->seg_a.as<uint64_t>(), ctx->seg_b.as<uint64_t>(), n, plan,
+    ctx->sorted = (uint64_t*)launch_radix_sort(ctx->stream, src, ctx->seg_a.as<uint64_t>(), ctx->seg_b.as<uint64_t>(), nc, plan,
                                                digit_bits, ctx->sort_counters.as<uint32_t>(), &ctx->info.as<FrameInfo>()->error,
                                                timing ? ctx->pev0 : nullptr, timing ? ctx->pev1 : nullptr);
     stage_end(ctx, ST_SORT, timing);
@@ -223,7 +243,9 @@ struct PaintArgs {
 };
 
 // stage 4 on ctx->sorted (n segments): runs + carry pre-pass + per-tile painter -> ctx->image
-int run_paint(forma_hip_ctx* ctx, size_t n, const PaintArgs& a, bool timing) {
+// bound_j != 0: asynchronous — the run count stays on the device (info->n_runs), buffers are provisioned for bound_j runs.
+int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, uint32_t bound_j = 0) {
+    const size_t n = nc.bound;
     const uint32_t tiles_w = (a.width + 15) / 16, tiles_h = (a.height + 15) / 16;
     const uint32_t T = tiles_w * tiles_h;
     HIPCHECK(ctx->image.ensure((size_t)a.width * a.height * 4));
@@ -240,41 +262,46 @@ int run_paint(forma_hip_ctx* ctx, size_t n, const PaintArgs& a, bool timing) {
     uint32_t* overflow_list = tile_first_run + T;                       // ... then the list itself
     uint32_t J = 0;
     // capacity: a run needs at least one segment, and so does a span's left neighbour
-    const size_t cap = std::max<size_t>(n, 1);
+    const size_t cap = std::max<size_t>(bound_j ? bound_j : n, 1);
     HIPCHECK(ctx->records.ensure(cap * sizeof(TileRecord)));
     HIPCHECK(ctx->run_cov.ensure(cap * 16));
     HIPCHECK(ctx->rk_u.ensure(cap * 8));
-    HIPCHECK(ctx->blk_edge.ensure(runs_blocks(cap) * sizeof(BlkEdge)));
-    HIPCHECK(ctx->runs_scratch.ensure(runs_scratch_words(cap) * 4));
+    HIPCHECK(ctx->blk_edge.ensure(runs_blocks(std::max<size_t>(n, 1)) * sizeof(BlkEdge)));
+    HIPCHECK(ctx->runs_scratch.ensure(runs_scratch_words(std::max<size_t>(n, 1)) * 4));
     stage_begin(ctx, ST_CARRY, timing);
-    launch_runs(ctx->stream, ctx->sorted, (uint32_t)n, tiles_w, tiles_h, ctx->records.as<TileRecord>(), ctx->run_cov.as<uint4>(),
+    launch_runs(ctx->stream, ctx->sorted, nc, tiles_w, tiles_h, ctx->records.as<TileRecord>(), (uint32_t)cap, ctx->run_cov.as<uint4>(),
                 ctx->rk_u.as<uint64_t>(), tile_first_run, ctx->blk_edge.as<BlkEdge>(), row_count,
                 ctx->runs_scratch.as<uint32_t>(), dinfo);
     HIPCHECK(hipGetLastError());
-    if (n > 0) {
-        int rc = read_info(ctx);
-        if (rc) return rc;
-        if ((rc = verify_speculation(ctx))) return rc;
-        if (ctx->h_info->error & 4u) return fail(ctx, FORMA_E_INTERNAL, "look-back spin expired (runs)");
-        J = ctx->h_info->n_runs;
+    DevCount jc;
+    if (bound_j) jc = DevCount{&dinfo->n_runs, bound_j};
+    else {
+        if (n > 0) {
+            int rc = read_info(ctx);
+            if (rc) return rc;
+            if ((rc = verify_speculation(ctx))) return rc;
+            J = ctx->h_info->n_runs;
+        }
+        jc = DevCount{nullptr, J};
     }
-    if (J > 0) {
-        HIPCHECK(ctx->rk_a.ensure((size_t)J * 8));
-        HIPCHECK(ctx->rk_b.ensure((size_t)J * 8));
-        HIPCHECK(ctx->span_key.ensure((size_t)J * 8));
-        HIPCHECK(ctx->span_cov.ensure((size_t)J * 16));
-        HIPCHECK(ctx->span_col.ensure((size_t)J * 16));
-        HIPCHECK(ctx->run_col.ensure((size_t)J * 16));
-        HIPCHECK(ctx->sort_counters.ensure(sort_scratch_words(J) * 4));
+    if (jc.bound > 0) {
+        const size_t jb = jc.bound;
+        HIPCHECK(ctx->rk_a.ensure(jb * 8));
+        HIPCHECK(ctx->rk_b.ensure(jb * 8));
+        HIPCHECK(ctx->span_key.ensure(jb * 8));
+        HIPCHECK(ctx->span_cov.ensure(jb * 16));
+        HIPCHECK(ctx->span_col.ensure(jb * 16));
+        HIPCHECK(ctx->run_col.ensure(jb * 16));
+        HIPCHECK(ctx->sort_counters.ensure(sort_scratch_words(jb) * 4));
         // (tile_y, layer) order: stable radix sort on bits 32..63 = [layer 21 | tile_y+1 11]; live bits come from the
         // rasterizer's varying-bit mask (layer = key bits 0..20, tile_y = key bits 33..43)
         uint64_t live = ((ctx->live44 & 0x1FFFFFull) | ((ctx->live44 >> 33) << 21)) << 32;
         const SortPlan rk_plan = make_sort_plan(live, 32, 64, ctx->digit_bits);
         const uint64_t* sorted_keys = launch_radix_sort(ctx->stream, ctx->rk_u.as<uint64_t>(), ctx->rk_a.as<uint64_t>(),
-                                                        ctx->rk_b.as<uint64_t>(), J, rk_plan, ctx->digit_bits,
+                                                        ctx->rk_b.as<uint64_t>(), jc, rk_plan, ctx->digit_bits,
                                                         ctx->sort_counters.as<uint32_t>(), &dinfo->error, nullptr, nullptr);
         launch_carry_rows(ctx->stream, sorted_keys, ctx->records.as<TileRecord>(), ctx->run_cov.as<uint4>(),
-                          ctx->blk_edge.as<BlkEdge>(), (uint32_t)((n + 2047) / 2048), ctx->style_off.as<uint32_t>(),
+                          ctx->blk_edge.as<BlkEdge>(), nc, jc, ctx->style_off.as<uint32_t>(),
                           ctx->style_words.as<uint32_t>(), (uint32_t)ctx->n_orders, tiles_w, tiles_h, row_count, row_span_lo,
                           row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(), ctx->run_col.as<uint4>(),
                           ctx->span_col.as<uint4>(), dinfo);
@@ -301,7 +328,7 @@ int run_paint(forma_hip_ctx* ctx, size_t n, const PaintArgs& a, bool timing) {
     for (int i = 0; i < 4; i++) P.clear[i] = a.clear[i];
     P.stride_px = a.width; P.scene_has_clips = ctx->scene_has_clips ? 1u : 0u; P.n_orders = (uint32_t)ctx->n_orders;
     stage_begin(ctx, ST_PAINT, timing);
-    launch_paint(ctx->stream, P, ctx->sorted, ctx->records.as<TileRecord>(), J, tile_first_run, row_span_lo,
+    launch_paint(ctx->stream, P, ctx->sorted, ctx->records.as<TileRecord>(), jc, tile_first_run, row_span_lo,
                  row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(), ctx->run_col.as<uint4>(),
                  ctx->span_col.as<uint4>(), ctx->style_off.as<uint32_t>(),
                  ctx->style_words.as<uint32_t>(), ctx->images.as<forma_image_t>(), ctx->texels.as<uint16_t>(),
@@ -320,9 +347,11 @@ int copy_image_out(forma_hip_ctx* ctx, uint8_t* dst, size_t stride, bool timing)
     return FORMA_OK;
 }
 
-int finish_frame(forma_hip_ctx* ctx, forma_timings_t* t) {
-    HIPCHECK(hipMemcpyAsync(ctx->h_info, ctx->info.p, sizeof(FrameInfo), hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHECK(hipStreamSynchronize(ctx->stream));
+int finish_frame(forma_hip_ctx* ctx, forma_timings_t* t, bool have_info = false) {
+    if (!have_info) {
+        HIPCHECK(hipMemcpyAsync(ctx->h_info, ctx->info.p, sizeof(FrameInfo), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+    }
     // device-side invariant flags
     if (ctx->h_info->error & 2u) return fail(ctx, FORMA_E_CAPACITY, "a tile has more than 4096 layers (painter list capacity)");
     if (ctx->h_info->error) return fail(ctx, FORMA_E_INTERNAL, "device-side invariant violated");
@@ -383,6 +412,7 @@ int forma_hip_create(forma_hip_ctx** out, int device) {
     ctx->device = device;
     if (const char* e = getenv("FORMA_HIP_DIGIT_BITS")) { if (atoi(e) == 4) ctx->digit_bits = 4; }
     const bool want_prof = getenv("FORMA_HIP_PROF") != nullptr;
+    ctx->no_async = getenv("FORMA_HIP_SYNC") != nullptr;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx; return FORMA_E_HIP;
     }
@@ -453,6 +483,7 @@ int forma_hip_set_geometry(forma_hip_ctx* ctx, const float* x, const float* y, c
     if ((rc = upload(ctx, ctx->line_slot, line_slot, n_points ? n_points - 1 : 0))) return rc;
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     ctx->n_points = n_points;
+    ctx->pred_counts_valid = false;                       // new geometry: the next frame re-learns N and J synchronously
     return FORMA_OK;
 }
 
@@ -612,7 +643,7 @@ int forma_hip_rasterize(forma_hip_ctx* ctx, size_t n_lines, const uint32_t* orde
     if ((rc = run_line_table(ctx, S, n_lines, false))) return rc;
     if (ctx->n_seg != N) return fail(ctx, FORMA_E_INTERNAL, "prefix sums disagree");
     HIPCHECK(ctx->seg_u.ensure(N * 8));
-    launch_rasterize(ctx->stream, S, (uint32_t)ctx->n_compact, (uint32_t)N, ctx->cl_idx.as<uint32_t>(),
+    launch_rasterize(ctx->stream, S, DevCount{nullptr, (uint32_t)ctx->n_compact}, DevCount{nullptr, (uint32_t)N}, ctx->cl_idx.as<uint32_t>(),
                      ctx->cl_start.as<uint32_t>(), ctx->block_first.as<uint32_t>(), ctx->seg_u.as<uint64_t>(),
                      ctx->info.as<FrameInfo>(), 0, 0);
     HIPCHECK(hipGetLastError());
@@ -639,7 +670,7 @@ int forma_hip_sort(forma_hip_ctx* ctx, uint64_t* segments, size_t n, int digit_b
     ctx->layer_sorted = false;
     int rc = reset_info(ctx);
     if (rc) return rc;
-    if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), n, false, digit_bits))) return rc;
+    if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), DevCount{nullptr, (uint32_t)n}, false, digit_bits))) return rc;
     HIPCHECK(hipMemcpyAsync(segments, ctx->sorted, n * 8, hipMemcpyDeviceToHost, ctx->stream));
     if ((rc = read_info(ctx))) return rc;
     if (ctx->h_info->error) return fail(ctx, FORMA_E_INTERNAL, "device-side invariant violated (radix look-back)");
@@ -661,7 +692,7 @@ int forma_hip_paint(forma_hip_ctx* ctx, const uint64_t* sorted_segments, size_t 
     ctx->n_seg = n; ctx->have_unsorted = false;
     ctx->live44 = n ? host_live44(sorted_segments, n) : 0;
     PaintArgs a{width, height, channels, clear_color, crop_or_null};
-    if ((rc = run_paint(ctx, n, a, false))) return rc;
+    if ((rc = run_paint(ctx, DevCount{nullptr, (uint32_t)n}, a, false))) return rc;
     if ((rc = copy_image_out(ctx, dst, stride_bytes, false))) return rc;
     return finish_frame(ctx, nullptr);
 }
@@ -677,15 +708,37 @@ int forma_hip_render(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t 
     HIPCHECK(hipSetDevice(ctx->device));
     const bool timing = timings != nullptr;
     clear_stage_flags(ctx);
+    if (width != ctx->pred_w || height != ctx->pred_h) { ctx->pred_counts_valid = false; ctx->pred_w = width; ctx->pred_h = height; }
+    PaintArgs a{width, height, channels, clear_color, crop_or_null};
+    // 1. fully asynchronous attempt: no read-back inside the frame.  N, J and the sort plan are predicted from the previous
+    //    frame (bounds with slack); device-side guards keep a wrong guess memory-safe; verified when the frame is done.
+    if (ctx->pred_valid && ctx->pred_counts_valid && !ctx->no_async) {
+        const uint32_t bN = ctx->pred_N + ctx->pred_N / 16 + 4096, bJ = ctx->pred_J + ctx->pred_J / 16 + 4096;
+        FrameInfo* dinfo = ctx->info.as<FrameInfo>();
+        if ((rc = run_rasterize_frame(ctx, width, height, timing, true, bN))) return rc;
+        if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), DevCount{&dinfo->n_segments, bN}, timing))) return rc;
+        if ((rc = run_paint(ctx, DevCount{&dinfo->n_segments, bN}, a, timing, bJ))) return rc;
+        if ((rc = copy_image_out(ctx, dst, stride_bytes, timing))) return rc;
+        HIPCHECK(hipMemcpyAsync(ctx->h_info, ctx->info.p, sizeof(FrameInfo), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        const uint32_t N = ctx->h_info->n_segments, J = ctx->h_info->n_runs;
+        ctx->n_seg = N; ctx->n_compact = ctx->h_info->n_compact; ctx->last_runs = J;
+        const bool ok = !ctx->h_info->plan_bad && N <= bN && J <= bJ;
+        if (ok) { ctx->pred_N = N; ctx->pred_J = J; return finish_frame(ctx, timings, true); }
+        ctx->pred_counts_valid = false;                   // fall through: the synchronous path re-learns everything
+        clear_stage_flags(ctx);
+    }
+    // 2. synchronous path (first frame of a scene, or a prediction failed): N, the key masks and J are read back
     for (int attempt = 0; attempt < 2; attempt++) {
         if ((rc = run_rasterize_frame(ctx, width, height, timing, /*speculate=*/attempt == 0))) return rc;
-        if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), ctx->n_seg, timing))) return rc;
-        PaintArgs a{width, height, channels, clear_color, crop_or_null};
-        rc = run_paint(ctx, ctx->n_seg, a, timing);
+        if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), DevCount{nullptr, (uint32_t)ctx->n_seg}, timing))) return rc;
+        rc = run_paint(ctx, DevCount{nullptr, (uint32_t)ctx->n_seg}, a, timing);
         if (rc == FORMA_RETRY) { clear_stage_flags(ctx); continue; }
         if (rc) return rc;
         if ((rc = copy_image_out(ctx, dst, stride_bytes, timing))) return rc;
-        return finish_frame(ctx, timings);
+        rc = finish_frame(ctx, timings);
+        if (rc == FORMA_OK) { ctx->pred_N = (uint32_t)ctx->n_seg; ctx->pred_J = ctx->last_runs; ctx->pred_counts_valid = true; }
+        return rc;
     }
     return fail(ctx, FORMA_E_INTERNAL, "sort plan did not converge");
 }
@@ -724,6 +777,7 @@ int forma_hip_set_band(forma_hip_ctx* ctx, uint32_t row0, uint32_t row1) {
     if (!ctx) return FORMA_E_ARG;
     if (row1 != 0 && row0 >= row1) return fail(ctx, FORMA_E_ARG, "empty band");
     ctx->band_row0 = row1 ? row0 : 0; ctx->band_row1 = row1;
+    ctx->pred_counts_valid = false;
     return FORMA_OK;
 }
 
@@ -770,9 +824,9 @@ int forma_hip_sort_paint_frame(forma_hip_ctx* ctx, size_t n, uint8_t* dst, uint3
     if (n) HIPCHECK(hipMemcpyAsync(ctx->seg_u.p, ctx->seg_b.p, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
     ctx->n_seg = n; ctx->have_unsorted = true;
     ctx->live44 = 0xFFFFFFFFFFFull;                   // no varying-bit mask for a received stream: sort every digit
-    if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), n, timing))) return rc;
+    if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), DevCount{nullptr, (uint32_t)n}, timing))) return rc;
     PaintArgs a{width, height, channels, clear_color, crop_or_null};
-    if ((rc = run_paint(ctx, n, a, timing))) return rc;
+    if ((rc = run_paint(ctx, DevCount{nullptr, (uint32_t)n}, a, timing))) return rc;
     if ((rc = copy_image_out(ctx, dst, stride_bytes, timing))) return rc;
     return finish_frame(ctx, timings);
 }

@@ -44,7 +44,8 @@ struct FrameInfo {
     uint32_t layer_unsorted; // != 0 if the rasterizer stream is not non-decreasing in layer
     uint32_t error;          // device-side invariant violations (1 style, 2 tile depth, 4 look-back spin)
     uint32_t n_compact;      // lines with at least one pixel segment
-    uint32_t pad[3];
+    uint32_t plan_bad;       // asynchronous frames: the speculated sort plan does not match this frame's keys
+    uint32_t pad[2];
 };
 
 // one run of the sorted stream = one painted (tile, layer) pair that owns pixel segments
@@ -66,6 +67,17 @@ struct PaintParams {
     uint32_t n_orders;
 };
 
+// A count that lives on the device.  `ptr == nullptr`: the host knows it exactly (= bound).  Otherwise kernels read *ptr
+// and clamp it to `bound`, the size their launch grid / buffers were provisioned for: a frame can then be enqueued
+// without reading N or J back; the host checks afterwards that nothing exceeded its bound (else it re-runs the frame).
+struct DevCount {
+    const uint32_t* ptr;
+    uint32_t bound;
+};
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint32_t dev_count(DevCount c) { return c.ptr ? min(*c.ptr, c.bound) : c.bound; }
+#endif
+
 // ---- kernel launch wrappers (defined in the .hip files) ------------------------------------------
 // lines.hip
 void launch_prepare_lines(hipStream_t s, const float* x, const float* y, const uint32_t* line_slot, uint32_t n_lines,
@@ -76,7 +88,8 @@ void launch_prepare_lines(hipStream_t s, const float* x, const float* y, const u
 size_t scan_tmp_words(size_t n);
 void launch_inclusive_scan_u32(hipStream_t s, uint32_t* data, size_t n, uint32_t* tmp, uint32_t* d_total);
 void launch_exclusive_scan_u32(hipStream_t s, uint32_t* data, size_t n, uint32_t* tmp, uint32_t* d_total);
-void launch_scan_small_u32(hipStream_t s, uint32_t* data, uint32_t n, uint32_t* d_total);
+// exclusive scan in place of ceil(n / per) values by one workgroup; total -> *d_total
+void launch_scan_small_u32(hipStream_t s, uint32_t* data, DevCount n, uint32_t per, uint32_t* d_total);
 
 // The frame path: line lengths -> single-pass scan -> compacted table of the lines that own pixel segments
 // (cl_idx = line index, cl_start = index of its first pixel segment) + block_first[b] = compacted line that owns
@@ -94,9 +107,11 @@ void launch_prepare_compact(hipStream_t s, const LineSource& src, uint32_t n_lin
 // rebuilds block_first when the buffer launch_prepare_compact saw was too small for N
 void launch_block_first(hipStream_t s, const uint32_t* cl_start, uint32_t n_compact, uint32_t n_segments,
                         uint32_t* block_first);
-void launch_rasterize(hipStream_t s, const LineSource& src, uint32_t n_compact, uint32_t n_segments,
+void launch_rasterize(hipStream_t s, const LineSource& src, DevCount n_compact, DevCount n_segments,
                       const uint32_t* cl_idx, const uint32_t* cl_start, const uint32_t* block_first, uint64_t* out,
                       FrameInfo* info, int band_row0, int band_row1);
+// asynchronous frames: compare the key masks the rasterizer reduced with the ones the sort plan was built from
+void launch_verify_plan(hipStream_t s, FrameInfo* info, uint64_t live44, bool layer_sorted);
 void launch_flatten(hipStream_t s, const forma_flatten_tables_t* dev_tables, float* out_x, float* out_y);
 
 // sort.hip — stable LSB radix sort of u64 (chained-scan "onesweep" passes over the live key bits).
@@ -111,7 +126,7 @@ SortPlan make_sort_plan(uint64_t live_mask, int lo_bit, int hi_bit, int digit_bi
 size_t sort_scratch_words(size_t n);
 // `in` is read-only (preserved), a/b are ping-pong buffers; returns the buffer holding the result (== in when the
 // plan is empty).  scratch: >= sort_scratch_words(n) u32.  err: device word, bit 2 set if a look-back spin expired.
-const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a, uint64_t* b, size_t n,
+const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a, uint64_t* b, DevCount n,
                                   const SortPlan& plan, int digit_bits, uint32_t* scratch, uint32_t* err,
                                   hipEvent_t* pass_ev0, hipEvent_t* pass_ev1);
 
@@ -125,15 +140,16 @@ struct BlkEdge {             // what a k_runs tile contributes to a run that sta
 size_t runs_scratch_words(size_t n);
 size_t runs_blocks(size_t n);
 // run detection + per-run cover sums; row_tab = [row_count | row_span_lo | row_span_cnt], (tiles_h + 1) words each
-void launch_runs(hipStream_t s, const uint64_t* sorted, uint32_t n, uint32_t tiles_w, uint32_t tiles_h, TileRecord* records,
-                 uint4* run_cov, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge, uint32_t* row_tab,
-                 uint32_t* scratch, FrameInfo* info);
+void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount n, uint32_t tiles_w, uint32_t tiles_h, TileRecord* records,
+                 uint32_t rec_cap, uint4* run_cov, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge,
+                 uint32_t* row_tab, uint32_t* scratch, FrameInfo* info);
 void launch_carry_rows(hipStream_t s, const uint64_t* sorted_run_keys, TileRecord* records, uint4* run_cov,
-                       const BlkEdge* blk_edge, uint32_t n_blk, const uint32_t* style_offsets, const uint32_t* style_words,
+                       const BlkEdge* blk_edge, DevCount n_segments, DevCount n_runs, const uint32_t* style_offsets,
+                       const uint32_t* style_words,
                        uint32_t n_orders, uint32_t tiles_w, uint32_t tiles_h, const uint32_t* row_count,
                        uint32_t* row_span_lo, uint32_t* row_span_cnt, uint64_t* span_key, uint4* span_cov, uint4* run_col,
                        uint4* span_col, FrameInfo* info);
-void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, uint32_t n_runs,
+void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, DevCount n_runs,
                   const uint32_t* tile_first_run, const uint32_t* row_span_lo, const uint32_t* row_span_cnt,
                   const uint64_t* span_key, const uint4* span_cov, const uint4* run_col, const uint4* span_col,
                   const uint32_t* style_offsets, const uint32_t* style_words, const forma_image_t* images,

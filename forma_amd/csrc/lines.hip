@@ -61,8 +61,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_reduce(const uint32_t* __
 }
 
 // single block: exclusive scan of block_sums[nb] in place; total -> *d_total
-__global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__ block_sums, uint32_t nb,
+__global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__ block_sums, DevCount nc, uint32_t per,
                                                           uint32_t* __restrict__ d_total) {
+    const uint32_t nb = (dev_count(nc) + per - 1) / per;
     __shared__ uint32_t lds[1024 / 64 + 1];
     uint32_t carry = 0;
     for (uint32_t base = 0; base < nb; base += 1024) {
@@ -100,8 +101,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(uint32_t* __restric
 }
 
 // exclusive scan in place of a small array (one workgroup); total -> *d_total
-void launch_scan_small_u32(hipStream_t s, uint32_t* data, uint32_t n, uint32_t* d_total) {
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, data, n, d_total);
+void launch_scan_small_u32(hipStream_t s, uint32_t* data, DevCount n, uint32_t per, uint32_t* d_total) {
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, data, n, per, d_total);
 }
 
 size_t scan_tmp_words(size_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE + 8; }
@@ -113,7 +114,7 @@ static void scan_u32(hipStream_t s, uint32_t* data, size_t n, uint32_t* tmp, uin
     }
     uint32_t nb = (uint32_t)((n + SCAN_TILE - 1) / SCAN_TILE);
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, s, data, (uint32_t)n, tmp);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, tmp, nb, d_total);
+    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, tmp, DevCount{nullptr, nb}, 1u, d_total);
     if (inclusive)
         hipLaunchKernelGGL(k_scan_apply<true>, dim3(nb), dim3(SCAN_THREADS), 0, s, data, (uint32_t)n, tmp);
     else
@@ -402,7 +403,7 @@ __device__ __forceinline__ LineP load_line(const LineSource& S, uint32_t li) {
     return line_params(S.x, S.y, S.line_slot, li, S.geoms, S.n_geoms, S.width, S.height, S.band_lo, S.band_hi);
 }
 
-__global__ __launch_bounds__(RAS_THREADS) void k_rasterize(LineSource S, uint32_t n_compact, uint32_t n_segments,
+__global__ __launch_bounds__(RAS_THREADS) void k_rasterize(LineSource S, DevCount nc_compact, DevCount nc_segments,
                                                            const uint32_t* __restrict__ cl_idx,
                                                            const uint32_t* __restrict__ cl_start,
                                                            const uint32_t* __restrict__ block_first,
@@ -415,8 +416,10 @@ __global__ __launch_bounds__(RAS_THREADS) void k_rasterize(LineSource S, uint32_
     __shared__ double w_aab[RAS_WIN], w_bab[RAS_WIN], w_cdab[RAS_WIN];
     __shared__ uint32_t red[5][RAS_THREADS / 64];
     const int tid = threadIdx.x;
+    const uint32_t n_segments = dev_count(nc_segments), n_compact = dev_count(nc_compact);
     const uint32_t nblocks = (n_segments + RAS_TILE - 1) / RAS_TILE;
     const uint32_t k0 = blockIdx.x * RAS_TILE;
+    if (k0 >= n_segments) return;                                       // the grid was sized for the bound
     const uint32_t k1 = min(k0 + RAS_TILE, n_segments);                   // exclusive
     const uint32_t lo = block_first[blockIdx.x];
     const uint32_t hi = blockIdx.x + 1 < nblocks ? block_first[blockIdx.x + 1] : n_compact - 1;   // inclusive
@@ -489,11 +492,24 @@ __global__ __launch_bounds__(RAS_THREADS) void k_rasterize(LineSource S, uint32_
     }
 }
 
-void launch_rasterize(hipStream_t s, const LineSource& src, uint32_t n_compact, uint32_t n_segments,
+__global__ void k_verify_plan(FrameInfo* __restrict__ info, uint64_t live44, uint32_t layer_sorted) {
+    if (threadIdx.x) return;
+    if (info->n_segments == 0) return;                                  // nothing was rasterized: nothing to sort
+    const uint64_t k_or = (uint64_t)info->key_or | ((uint64_t)info->key_or_hi << 32);
+    const uint64_t k_and = (uint64_t)info->key_and | ((uint64_t)info->key_and_hi << 32);
+    const uint64_t live = (k_or ^ k_and) & 0xFFFFFFFFFFFull;
+    const uint32_t sorted = info->layer_unsorted == 0 ? 1u : 0u;
+    if (live != live44 || sorted != layer_sorted) info->plan_bad = 1u;
+}
+void launch_verify_plan(hipStream_t s, FrameInfo* info, uint64_t live44, bool layer_sorted) {
+    hipLaunchKernelGGL(k_verify_plan, dim3(1), dim3(64), 0, s, info, live44, layer_sorted ? 1u : 0u);
+}
+
+void launch_rasterize(hipStream_t s, const LineSource& src, DevCount n_compact, DevCount n_segments,
                       const uint32_t* cl_idx, const uint32_t* cl_start, const uint32_t* block_first, uint64_t* out,
                       FrameInfo* info, int band_row0, int band_row1) {
-    if (n_segments == 0 || n_compact == 0) return;
-    uint32_t blocks = (n_segments + RAS_TILE - 1) / RAS_TILE;
+    if (n_segments.bound == 0 || n_compact.bound == 0) return;
+    uint32_t blocks = (n_segments.bound + RAS_TILE - 1) / RAS_TILE;
     hipLaunchKernelGGL(k_rasterize, dim3(blocks), dim3(RAS_THREADS), 0, s, src, n_compact, n_segments, cl_idx, cl_start,
                        block_first, out, info, band_row0, band_row1);
 }

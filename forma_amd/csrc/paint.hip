@@ -95,9 +95,10 @@ __device__ __forceinline__ uint4 pack_bins(const int* b) {
 }
 
 // pass A: paintable run heads per tile (the run index of a tile's first head is the exclusive scan of these)
-__global__ __launch_bounds__(RN_THREADS) void k_runs_count(const uint64_t* __restrict__ sorted, uint32_t n, uint32_t tiles_w,
+__global__ __launch_bounds__(RN_THREADS) void k_runs_count(const uint64_t* __restrict__ sorted, DevCount nc, uint32_t tiles_w,
                                                            uint32_t tiles_h, uint32_t* __restrict__ counts) {
     __shared__ uint32_t s_c[RN_WAVES];
+    const uint32_t n = dev_count(nc);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t base = blockIdx.x * RN_TILE;
     uint32_t c = 0;
@@ -116,8 +117,8 @@ __global__ __launch_bounds__(RN_THREADS) void k_runs_count(const uint64_t* __res
 }
 
 // pass B: one workgroup per tile, no inter-workgroup dependency
-__global__ __launch_bounds__(RN_THREADS, 8) void k_runs(const uint64_t* __restrict__ sorted, uint32_t n, uint32_t tiles_w,
-                                                        uint32_t tiles_h, TileRecord* __restrict__ records,
+__global__ __launch_bounds__(RN_THREADS, 8) void k_runs(const uint64_t* __restrict__ sorted, DevCount nc, uint32_t tiles_w,
+                                                        uint32_t tiles_h, TileRecord* __restrict__ records, uint32_t rec_cap,
                                                         uint4* __restrict__ run_cov, uint64_t* __restrict__ run_keys,
                                                         uint32_t* __restrict__ tile_first_run,
                                                         BlkEdge* __restrict__ blk_edge, uint32_t* __restrict__ row_count,
@@ -129,6 +130,8 @@ __global__ __launch_bounds__(RN_THREADS, 8) void k_runs(const uint64_t* __restri
     __shared__ uint32_t s_rows[RN_ROWS];
     __shared__ uint32_t s_row0, s_R;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t n = dev_count(nc);
+    if (blockIdx.x * RN_TILE >= n) return;                              // the grid was sized for the bound
     {
         const uint32_t tile = blockIdx.x;
         if (tid == 0) s_row0 = 0xFFFFFFFFu;
@@ -218,9 +221,11 @@ __global__ __launch_bounds__(RN_THREADS, 8) void k_runs(const uint64_t* __restri
                 TileRecord rec;
                 rec.cover[0] = rec.cover[1] = rec.cover[2] = rec.cover[3] = 0;   // carry-in, written by k_carry_rows
                 rec.seg_start = base + i; rec.seg_count = cnt | open; rec.layer = layer; rec.tile = (uint32_t)(v >> 41);
-                records[j] = rec;
-                run_cov[j] = pack_bins(b);
-                run_keys[j] = ((uint64_t)tyb << 53) | ((uint64_t)layer << 32) | j;
+                if (j < rec_cap) {                                  // asynchronous frames provision for a predicted run count
+                    records[j] = rec;
+                    run_cov[j] = pack_bins(b);
+                    run_keys[j] = ((uint64_t)tyb << 53) | ((uint64_t)layer << 32) | j;
+                }
                 if (txb >= 1u && ((uint32_t)(pv >> 41) != (uint32_t)(v >> 41) || base + i == 0))
                     tile_first_run[(tyb - 1u) * tiles_w + (txb - 1u)] = j + 1u;        // 0 = the tile has no run
                 const uint32_t rr = (tyb - 1u) - row0;
@@ -246,17 +251,17 @@ __global__ __launch_bounds__(RN_THREADS, 8) void k_runs(const uint64_t* __restri
 size_t runs_scratch_words(size_t n) { return (n + RN_TILE - 1) / RN_TILE + 16; }
 size_t runs_blocks(size_t n) { return (n + RN_TILE - 1) / RN_TILE + 1; }
 
-void launch_runs(hipStream_t s, const uint64_t* sorted, uint32_t n, uint32_t tiles_w, uint32_t tiles_h, TileRecord* records,
-                 uint4* run_cov, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge, uint32_t* row_tab,
+void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t tiles_w, uint32_t tiles_h, TileRecord* records,
+                 uint32_t rec_cap, uint4* run_cov, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge, uint32_t* row_tab,
                  uint32_t* scratch, FrameInfo* info) {
     // per-frame state, ONE memset: [row_count | row_span_lo | row_span_cnt | painter overflow counter | first-run table]
     // are contiguous (api.cpp lays them out so); 0 in the first-run table = the tile has no run
     (void)hipMemsetAsync(row_tab, 0, ((size_t)(tiles_h + 1) * 3 + 1 + (size_t)tiles_w * tiles_h) * 4, s);
-    if (n == 0) { (void)hipMemsetAsync(&info->n_runs, 0, 4, s); return; }
-    const uint32_t ntiles = (n + RN_TILE - 1) / RN_TILE;
-    hipLaunchKernelGGL(k_runs_count, dim3(ntiles), dim3(RN_THREADS), 0, s, sorted, n, tiles_w, tiles_h, scratch);
-    launch_scan_small_u32(s, scratch, ntiles, &info->n_runs);                  // exclusive, in place; total -> n_runs
-    hipLaunchKernelGGL(k_runs, dim3(ntiles), dim3(RN_THREADS), 0, s, sorted, n, tiles_w, tiles_h, records, run_cov, run_keys,
+    if (nc.bound == 0) { (void)hipMemsetAsync(&info->n_runs, 0, 4, s); return; }
+    const uint32_t ntiles = (nc.bound + RN_TILE - 1) / RN_TILE;
+    hipLaunchKernelGGL(k_runs_count, dim3(ntiles), dim3(RN_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, scratch);
+    launch_scan_small_u32(s, scratch, nc, RN_TILE, &info->n_runs);             // exclusive, in place; total -> n_runs
+    hipLaunchKernelGGL(k_runs, dim3(ntiles), dim3(RN_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, records, rec_cap, run_cov, run_keys,
                        tile_first_run, blk_edge, row_tab, (const uint32_t*)scratch);
 }
 
@@ -278,7 +283,8 @@ void launch_runs(hipStream_t s, const uint64_t* sorted, uint32_t n, uint32_t til
 __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __restrict__ sorted_keys,
                                                            TileRecord* __restrict__ records,
                                                            uint4* __restrict__ run_cov,
-                                                           const BlkEdge* __restrict__ blk_edge, uint32_t n_blk,
+                                                           const BlkEdge* __restrict__ blk_edge, DevCount nc_segments,
+                                                           DevCount nc_runs,
                                                            const uint32_t* __restrict__ style_offsets,
                                                            const uint32_t* __restrict__ style_words, uint32_t n_orders,
                                                            uint32_t tiles_w, uint32_t tiles_h,
@@ -296,6 +302,9 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
     __shared__ uint32_t s_cgroup, s_spans;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t ty = blockIdx.x;
+    if (info->plan_bad) return;                                         // mis-sorted stream (async frame): the host re-runs
+    const uint32_t n_blk = (dev_count(nc_segments) + RN_TILE - 1) / RN_TILE;
+    const uint32_t n_runs = dev_count(nc_runs);
     // first run of this row = sum of the run counts of the rows above
     uint32_t part = 0;
     for (uint32_t r = tid; r < ty; r += CR_THREADS) part += row_count[r];
@@ -311,7 +320,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
     if (tid == 0) row_span_lo[ty] = row_lo;
     for (uint32_t c0 = 0; c0 < cnt; c0 += CR_THREADS) {
         const uint32_t k = row_lo + c0 + tid;
-        const bool active = c0 + tid < cnt;
+        const bool active = c0 + tid < cnt && k < n_runs;
         uint32_t group = 0xFFFFFFFEu, jrun = 0, txb = 0, layer = 0, sfl = 0;
         uint64_t own_lo = 0, own_hi = 0;
         uint4 scol = make_uint4(0, 0, 0, 0);
@@ -355,7 +364,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
         s_group[tid] = group; s_txb[tid] = txb;
         if (tid == CR_THREADS - 1) {                     // the element after this chunk (for the last lane's span)
             uint32_t ng = 0xFFFFFFFDu, nt = 0;
-            if (c0 + CR_THREADS < cnt) {
+            if (c0 + CR_THREADS < cnt && k + 1 < n_runs) {
                 const uint64_t nk = sorted_keys[k + 1];
                 ng = (uint32_t)(nk >> 32); nt = records[(uint32_t)nk].tile & 0xFFFu;
             }
@@ -433,12 +442,13 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
 }
 
 void launch_carry_rows(hipStream_t s, const uint64_t* sorted_run_keys, TileRecord* records, uint4* run_cov,
-                       const BlkEdge* blk_edge, uint32_t n_blk, const uint32_t* style_offsets, const uint32_t* style_words,
+                       const BlkEdge* blk_edge, DevCount n_segments, DevCount n_runs, const uint32_t* style_offsets,
+                       const uint32_t* style_words,
                        uint32_t n_orders, uint32_t tiles_w, uint32_t tiles_h, const uint32_t* row_count,
                        uint32_t* row_span_lo, uint32_t* row_span_cnt, uint64_t* span_key, uint4* span_cov, uint4* run_col,
                        uint4* span_col, FrameInfo* info) {
     if (tiles_h == 0) return;
-    hipLaunchKernelGGL(k_carry_rows, dim3(tiles_h), dim3(CR_THREADS), 0, s, sorted_run_keys, records, run_cov, blk_edge, n_blk,
+    hipLaunchKernelGGL(k_carry_rows, dim3(tiles_h), dim3(CR_THREADS), 0, s, sorted_run_keys, records, run_cov, blk_edge, n_segments, n_runs,
                        style_offsets, style_words, n_orders, tiles_w, tiles_h, row_count, row_span_lo, row_span_cnt, span_key,
                        span_cov, run_col, span_col, info);
 }
@@ -736,7 +746,7 @@ __device__ __forceinline__ void texture_at(const uint32_t* __restrict__ w, const
 // second, low-occupancy launch with a larger MAXE paints those).
 template <int MAXE>
 __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t tile, const uint64_t* __restrict__ sorted,
-                                           const TileRecord* __restrict__ records, uint32_t n_runs,
+                                           const TileRecord* __restrict__ records, const uint32_t n_runs,
                                            const uint32_t* __restrict__ tile_first_run,
                                            const uint32_t* __restrict__ row_span_lo,
                                            const uint32_t* __restrict__ row_span_cnt,
@@ -1117,7 +1127,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 }
 
 __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint64_t* __restrict__ sorted,
-                                                    const TileRecord* __restrict__ records, uint32_t n_runs,
+                                                    const TileRecord* __restrict__ records, DevCount nc_runs,
                                                     const uint32_t* __restrict__ tile_first_run,
                                                     const uint32_t* __restrict__ row_span_lo,
                                                     const uint32_t* __restrict__ row_span_cnt,
@@ -1138,6 +1148,8 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
     __shared__ uint32_t w_seg0[1][WB], w_nseg[1][WB], w_bflag[1][WB], w_blayer[1][WB];
 
     const int lane = threadIdx.x & 63, wv = 0;
+    if (info->plan_bad) return;                                         // mis-sorted stream (async frame): the host re-runs
+    const uint32_t n_runs = dev_count(nc_runs);
     // one-wave workgroups (a wave's slot frees as soon as ITS tile is done).  XCD-aware mapping: workgroup b runs on
     // XCD b % 8; give each XCD a contiguous band of tiles so a tile row's records / spans stay in one L2
     const uint32_t T = P.tiles_w * P.tiles_h, per = (T + 7) / 8;
@@ -1430,7 +1442,7 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
 
 #define PAINT_ARGS P, tile, sorted, records, n_runs, tile_first_run, row_span_lo, row_span_cnt, span_key, span_cov, run_col, span_col, \
                    style_offsets, style_words, images, texels, image, info
-#define PAINT_PARAMS PaintParams P, const uint64_t* __restrict__ sorted, const TileRecord* __restrict__ records, uint32_t n_runs, \
+#define PAINT_PARAMS PaintParams P, const uint64_t* __restrict__ sorted, const TileRecord* __restrict__ records, DevCount nc_runs, \
                      const uint32_t* __restrict__ tile_first_run, const uint32_t* __restrict__ row_span_lo, \
                      const uint32_t* __restrict__ row_span_cnt, const uint64_t* __restrict__ span_key, \
                      const uint4* __restrict__ span_cov, const uint4* __restrict__ run_col, const uint4* __restrict__ span_col, \
@@ -1442,7 +1454,9 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
 // the rare deep tiles the first launch could not hold
 __global__ __launch_bounds__(256) void k_paint_deep(PAINT_PARAMS, const uint32_t* __restrict__ overflow_n,
                                                     const uint32_t* __restrict__ overflow_list) {
+    if (info->plan_bad) return;
     const uint32_t n = overflow_n[0];
+    const uint32_t n_runs = dev_count(nc_runs);
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
         const uint32_t tile = overflow_list[i];
         paint_tile<PAINT_MAXE_DEEP>(PAINT_ARGS, nullptr, nullptr);
@@ -1450,7 +1464,7 @@ __global__ __launch_bounds__(256) void k_paint_deep(PAINT_PARAMS, const uint32_t
     }
 }
 
-void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, uint32_t n_runs,
+void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, DevCount n_runs,
                   const uint32_t* tile_first_run, const uint32_t* row_span_lo, const uint32_t* row_span_cnt,
                   const uint64_t* span_key, const uint4* span_cov, const uint4* run_col, const uint4* span_col,
                   const uint32_t* style_offsets, const uint32_t* style_words, const forma_image_t* images,

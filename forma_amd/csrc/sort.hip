@@ -98,8 +98,9 @@ __device__ __forceinline__ uint32_t lanes_below(uint32_t mlo, uint32_t mhi) {   
 #define HS_KPT     16
 #define HS_TILE    (HS_THREADS * HS_KPT)
 
-__global__ __launch_bounds__(HS_THREADS) void k_sort_hist(const uint64_t* __restrict__ in, uint32_t n, SortPlan plan,
+__global__ __launch_bounds__(HS_THREADS) void k_sort_hist(const uint64_t* __restrict__ in, DevCount nc, SortPlan plan,
                                                           uint32_t* __restrict__ hist) {
+    const uint32_t n = dev_count(nc);
     __shared__ uint32_t lh[SORT_MAX_PASSES * 256];
     const int P = plan.n_passes;
     for (int i = threadIdx.x; i < P * 256; i += HS_THREADS) lh[i] = 0;
@@ -169,11 +170,12 @@ __device__ __forceinline__ void scan2_excl(uint32_t& a, uint32_t& b, uint32_t* l
 
 template <int BITS>
 __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
-                                                         uint32_t n, int shift, uint32_t dmask,
+                                                         DevCount nc, int shift, uint32_t dmask,
                                                          const uint32_t* __restrict__ ghist /* this pass, 256 */,
                                                          uint32_t* __restrict__ status /* [ntiles][RADIX] */,
                                                          uint32_t* __restrict__ ticket, uint32_t* __restrict__ err) {
     constexpr int RADIX = 1 << BITS;
+    const uint32_t n = dev_count(nc);
     __shared__ uint64_t staged[OS_TILE];
     __shared__ uint32_t whist[OS_WAVES][RADIX];
     __shared__ uint32_t s_gdelta[RADIX];
@@ -323,9 +325,10 @@ size_t sort_scratch_words(size_t n) {
     return (size_t)SORT_MAX_PASSES * 256 + 64 + (size_t)SORT_MAX_PASSES * (ntiles + 1) * 256;
 }
 
-const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a, uint64_t* b, size_t n,
+const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a, uint64_t* b, DevCount nc,
                                   const SortPlan& plan, int digit_bits, uint32_t* scratch, uint32_t* err,
                                   hipEvent_t* pass_ev0, hipEvent_t* pass_ev1) {
+    const size_t n = nc.bound;                        // provisioning (grid, scratch); the kernels use the device count
     if (n <= 1 || plan.n_passes == 0) return in;
     const uint32_t ntiles = (uint32_t)((n + OS_TILE - 1) / OS_TILE);
     uint32_t* hist = scratch;
@@ -336,7 +339,7 @@ const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a
     (void)hipMemsetAsync(scratch, 0, ((size_t)SORT_MAX_PASSES * 256 + 64 + (size_t)P * ntiles * 256) * 4, s);
     uint32_t hb = (uint32_t)((n + HS_TILE - 1) / HS_TILE);
     if (hb > 1024) hb = 1024;                             // few workgroups: the final flush is 256 x passes global atomics each
-    hipLaunchKernelGGL(k_sort_hist, dim3(hb), dim3(HS_THREADS), 0, s, in, (uint32_t)n, plan, hist);
+    hipLaunchKernelGGL(k_sort_hist, dim3(hb), dim3(HS_THREADS), 0, s, in, nc, plan, hist);
     uint32_t grid = ntiles < 512 ? ntiles : 512;          // persistent: 2 workgroups of 8 waves per CU
     const uint64_t* src = in;
     uint64_t* dst = a;
@@ -344,10 +347,10 @@ const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a
         if (pass_ev0) (void)hipEventRecord(pass_ev0[p], s);
         uint32_t* st = status + (size_t)p * ntiles * 256;
         if (digit_bits == 4)
-            hipLaunchKernelGGL(k_onesweep<4>, dim3(grid), dim3(OS_THREADS), 0, s, src, dst, (uint32_t)n, plan.shift[p],
+            hipLaunchKernelGGL(k_onesweep<4>, dim3(grid), dim3(OS_THREADS), 0, s, src, dst, nc, plan.shift[p],
                                plan.mask[p], (const uint32_t*)(hist + p * 256), st, tickets + p, err);
         else
-            hipLaunchKernelGGL(k_onesweep<8>, dim3(grid), dim3(OS_THREADS), 0, s, src, dst, (uint32_t)n, plan.shift[p],
+            hipLaunchKernelGGL(k_onesweep<8>, dim3(grid), dim3(OS_THREADS), 0, s, src, dst, nc, plan.shift[p],
                                plan.mask[p], (const uint32_t*)(hist + p * 256), st, tickets + p, err);
         if (pass_ev1) (void)hipEventRecord(pass_ev1[p], s);
         src = dst;

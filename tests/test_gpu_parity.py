@@ -174,3 +174,40 @@ def test_layers_inserted_out_of_order(ctx):
     assert np.array_equal(ctx.segments(1), o.segments(1))
     assert t["n_sort_passes"] >= 3
     assert np.abs(a.astype(int) - b.astype(int)).max() <= 1
+
+
+def test_repeated_frames_take_the_asynchronous_path(ctx, mixed):
+    """From the second frame of a scene on, forma_hip_render enqueues the whole frame without reading N, J or the key
+    masks back (they are predicted from the previous frame and verified afterwards).  Same results, every frame."""
+    o, _ = both(ctx, mixed)
+    want = o.render(512, 384, clear=(0.2, 0.3, 0.4, 1.0))
+    for _ in range(4):
+        got, t = ctx.render(512, 384, clear=(0.2, 0.3, 0.4, 1.0), timings=True)
+        assert np.array_equal(ctx.segments(1), o.segments(1))
+        assert t["n_segments"] == len(o.segments(0))
+        assert np.abs(want.astype(int) - got.astype(int)).max() <= 1
+
+
+def test_prediction_failure_falls_back(ctx):
+    """Frame k+1 has far more pixel segments (and different live key bits) than frame k predicted: the asynchronous
+    attempt must detect it (bounds / plan guard) and the frame must still come out right."""
+    rng = np.random.default_rng(5)
+    comp = S.Composition()
+    for i in range(150):
+        x0, y0 = rng.uniform(0, 300, 2)
+        comp.get_mut_or_insert_default(i).insert(S.custom_circle(float(x0), float(y0), float(rng.uniform(5, 30)))) \
+            .set_props(S.solid((float(rng.random()), float(rng.random()), float(rng.random()), 0.7)))
+    o = orc.Oracle()
+    for shift in (-5000.0, -5000.0, 0.0, 0.0, -120.0, 40.0):          # off-canvas twice, then on, then partly
+        for order, layer in comp.layers.items():
+            layer.set_transform([1.0, 0.0, 0.0, 1.0, shift, 0.0])
+        t = comp.tables(o)
+        S.load(o, t)
+        ctx.set_geoms(t["geoms"])                                       # geometry and styles stay resident
+        if shift == -5000.0:
+            S.load(ctx, t)
+            ctx.render(320, 320, clear=(1, 1, 1, 1))                    # first frame of the scene: synchronous
+        want = o.render(320, 320, clear=(1, 1, 1, 1))
+        got = ctx.render(320, 320, clear=(1, 1, 1, 1))
+        assert np.array_equal(ctx.segments(1), o.segments(1)), shift
+        assert np.abs(want.astype(int) - got.astype(int)).max() <= 1, shift
