@@ -355,7 +355,7 @@ void launch_block_first(hipStream_t s, const uint32_t* cl_start, uint32_t n_comp
 // ------------------------------------------------------------------------------------------------
 #define RAS_THREADS 256
 #define RAS_PER_THREAD (RAS_TILE / RAS_THREADS)
-#define RAS_WIN 512
+#define RAS_WIN 256
 
 __device__ __forceinline__ float find_term(int i, double a_ab, double b_ab, double cd_ab, float a, float b, float c,
                                            float d) {               // rasterizer.rs:32-61
@@ -424,6 +424,10 @@ __global__ __launch_bounds__(RAS_THREADS) void k_rasterize(LineSource S, DevCoun
     const uint32_t lo = block_first[blockIdx.x];
     const uint32_t hi = blockIdx.x + 1 < nblocks ? block_first[blockIdx.x + 1] : n_compact - 1;   // inclusive
     uint32_t k_or = 0, k_or_hi = 0, k_and = 0xFFFFFFFFu, k_and_hi = 0xFFFFFFFFu, unsorted = 0;
+    const uint32_t kt = k0 + tid * RAS_PER_THREAD;                      // this thread's first segment
+    uint64_t vout[RAS_PER_THREAD];
+#pragma unroll
+    for (int q = 0; q < RAS_PER_THREAD; q++) vout[q] = 0;
 
     for (uint32_t c0 = lo; c0 <= hi; c0 += RAS_WIN) {
         const uint32_t cnt = min((uint32_t)RAS_WIN, hi - c0 + 1);
@@ -448,25 +452,45 @@ __global__ __launch_bounds__(RAS_THREADS) void k_rasterize(LineSource S, DevCoun
         if (tid == 0) w_start[cnt] = (c0 + cnt < n_compact) ? cl_start[c0 + cnt] : n_segments;
         __syncthreads();
         const uint32_t ka = max(k0, w_start[0]), kb = min(k1, w_start[cnt]);   // this chunk's share of the tile
-#pragma unroll
-        for (int r = 0; r < RAS_PER_THREAD; r++) {
-            const uint32_t k = k0 + r * RAS_THREADS + tid;
-            if (k < ka || k >= kb) continue;
-            uint32_t a = 0, b = cnt;                       // last j in [0, cnt) with w_start[j] <= k
+        // this thread's 8 consecutive segments that fall into the chunk: ONE binary search, then walk the lines
+        const uint32_t t_lo = max(kt, ka), t_hi = min(kt + RAS_PER_THREAD, kb);
+        if (t_lo < t_hi) {
+            uint32_t a = 0, b = cnt;                       // last j in [0, cnt) with w_start[j] <= t_lo
             while (b - a > 1) {
-                uint32_t mid = (a + b) >> 1;
-                if (w_start[mid] <= k) a = mid; else b = mid;
+                const uint32_t mid = (a + b) >> 1;
+                if (w_start[mid] <= t_lo) a = mid; else b = mid;
             }
-            uint64_t v = rasterize_one(w_order[a], w_x0[a], w_y0[a], w_dx[a], w_dy[a], w_a[a], w_b[a], w_c[a], w_d[a],
-                                       w_aab[a], w_bab[a], w_cdab[a], k - w_start[a]);
-            if (band_row1 > 0) {
-                int ty = seg_tile_y(v);
-                if (ty < band_row0 || ty >= band_row1) v &= 0x001FFFFFFFFFFFFFull;   // -> tile row -1: never painted
+            uint32_t l_start = w_start[a], l_next = w_start[a + 1], l_order = w_order[a];
+            float l_x0 = w_x0[a], l_y0 = w_y0[a], l_dx = w_dx[a], l_dy = w_dy[a], l_a = w_a[a], l_b = w_b[a], l_c = w_c[a], l_d = w_d[a];
+            double l_aab = w_aab[a], l_bab = w_bab[a], l_cdab = w_cdab[a];
+#pragma unroll
+            for (int q = 0; q < RAS_PER_THREAD; q++) {
+                const uint32_t k = kt + q;
+                if (k < t_lo || k >= t_hi) continue;
+                while (k >= l_next) {                      // next line (lines own >= 1 segment, so this advances by one)
+                    a++;
+                    l_start = l_next; l_next = w_start[a + 1]; l_order = w_order[a];
+                    l_x0 = w_x0[a]; l_y0 = w_y0[a]; l_dx = w_dx[a]; l_dy = w_dy[a];
+                    l_a = w_a[a]; l_b = w_b[a]; l_c = w_c[a]; l_d = w_d[a];
+                    l_aab = w_aab[a]; l_bab = w_bab[a]; l_cdab = w_cdab[a];
+                }
+                uint64_t v = rasterize_one(l_order, l_x0, l_y0, l_dx, l_dy, l_a, l_b, l_c, l_d, l_aab, l_bab, l_cdab, k - l_start);
+                if (band_row1 > 0) {
+                    int ty = seg_tile_y(v);
+                    if (ty < band_row0 || ty >= band_row1) v &= 0x001FFFFFFFFFFFFFull;   // -> tile row -1: never painted
+                }
+                vout[q] = v;
+                uint32_t klo = (uint32_t)(v >> 20), khi = (uint32_t)(v >> 52);
+                k_or |= klo; k_or_hi |= khi; k_and &= klo; k_and_hi &= khi;
             }
-            out[k] = v;
-            uint32_t klo = (uint32_t)(v >> 20), khi = (uint32_t)(v >> 52);
-            k_or |= klo; k_or_hi |= khi; k_and &= klo; k_and_hi &= khi;
         }
+    }
+    // 64 contiguous bytes per thread: 16-byte stores (the tile base is a multiple of 2048 segments)
+#pragma unroll
+    for (int q = 0; q < RAS_PER_THREAD; q += 2) {
+        const uint32_t k = kt + q;
+        if (k + 1 < k1) *reinterpret_cast<ulonglong2*>(out + k) = make_ulonglong2(vout[q], vout[q + 1]);
+        else if (k < k1) out[k] = vout[q];
     }
     // block reduction of the varying-bit masks -> a few atomics per block
 #pragma unroll
