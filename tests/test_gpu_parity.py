@@ -211,3 +211,38 @@ def test_prediction_failure_falls_back(ctx):
         got = ctx.render(320, 320, clear=(1, 1, 1, 1))
         assert np.array_equal(ctx.segments(1), o.segments(1)), shift
         assert np.abs(want.astype(int) - got.astype(int)).max() <= 1, shift
+
+
+def test_tile_row_bands_stitch_to_the_full_frame(ctx, mixed):
+    """Multi-GPU sharding, exercised on one device: forma_hip_set_band restricts a context to a band of tile rows (lines
+    outside are culled, foreign segments neutralised); painting every band with its crop and stitching the rows must
+    reproduce the un-sharded frame exactly.  Bands come from the same host logic bench.py uses."""
+    from forma_amd import sharding
+    W, H = 500, 301
+    o, _ = both(ctx, mixed)
+    full_o = o.render(W, H, clear=(0.2, 0.3, 0.4, 1.0))
+    ctx.set_band(0, 0)
+    full = ctx.render(W, H, clear=(0.2, 0.3, 0.4, 1.0))
+    tiles_h = (H + 15) // 16
+    hist = sharding.row_histogram(ctx.segments(0), tiles_h)
+    n_full = len(ctx.segments(0))
+    for world in (2, 3, 8):
+        edges = sharding.band_edges(hist, world)
+        out = np.zeros_like(full)
+        n_band_total = 0
+        for rank in range(world):
+            ctx.set_band(edges[rank], edges[rank + 1])
+            x0, x1, y0, y1 = sharding.band_crop(edges, rank, W, H)
+            for _ in range(2):                                           # second frame: the asynchronous path
+                img = ctx.render(W, H, clear=(0.2, 0.3, 0.4, 1.0), crop=(x0, x1, y0, y1))
+            out[y0:y1] = img[y0:y1]
+            s = ctx.segments(1)
+            ty = (s >> np.uint64(53)).astype(np.int64) - 1
+            own = (ty >= edges[rank]) & (ty < edges[rank + 1])
+            assert (ty[~own] == -1).all()                                # foreign segments are parked in tile row -1
+            n_band_total += int(own.sum())
+        assert n_band_total == int(hist.sum())                           # every paintable segment has exactly one owner
+        assert np.array_equal(out, full)
+    ctx.set_band(0, 0)
+    assert np.abs(full.astype(int) - full_o.astype(int)).max() <= 1
+    assert n_full == len(o.segments(0))
