@@ -4,7 +4,10 @@
 A "step" is one `Renderer::render` frame (prepare lines -> rasterize -> radix sort -> carry pre-pass
 -> per-tile paint) of a synthetic scene whose geometry, layer table and styles are already resident
 in HBM; the image stays device-resident (the PCIe-inclusive rate is reported separately, never as
-`value`).  One process per GPU; for N > 1 the canvas is sharded by tile-row bands.
+`value`).  One process per GPU.  For N > 1 the default (`--mode frames`) is frame-parallel: the unit of
+work is a frame, every GPU renders whole frames, per-GPU work is fixed (weak scaling) and nothing is
+exchanged on the data path; `--mode bands` splits ONE frame into tile-row bands (SURVEY.md §8e, strong
+scaling).  `value` is the whole-job aggregate: frames completed by all GPUs / max-over-ranks wall time.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
 
@@ -32,6 +35,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="paris-like-30k-4k")
+    ap.add_argument("--mode", default="frames", choices=["frames", "bands"],
+                    help="N > 1: 'frames' = every GPU renders whole frames (weak scaling, no exchange); "
+                         "'bands' = ONE frame split into tile-row bands across the GPUs (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -72,7 +78,7 @@ def main():
 
     crop = None
     row0, row1 = 0, tiles_h
-    if world > 1:
+    if world > 1 and args.mode == "bands":
         # tile-row bands balanced on the per-row pixel-segment histogram of the full frame
         hist = sharding.row_histogram(ctx.segments(0), tiles_h)
         edges = sharding.agree_on_bands(dist, hist, world, device="cuda")
@@ -105,7 +111,8 @@ def main():
     if dist is not None:
         elapsed = sharding.max_over_ranks(dist, elapsed, device="cuda")
     ms_per_step = elapsed / args.steps * 1e3
-    fps = args.steps / elapsed
+    frames_per_step = world if (world > 1 and args.mode == "frames") else 1      # frames mode: one whole frame per GPU per step
+    fps = frames_per_step * args.steps / elapsed
 
     # ---- per-stage device times + roofline of the radix pass (HIP events on the context's stream) ----------
     stage = {}
@@ -136,14 +143,18 @@ def main():
     out = {
         "metric": "frames/sec (sorted+painted, device-resident) + Mpixel-segments/sec",
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "strong" if (world > 1 and args.mode == "bands") else "weak", "vs_baseline": None,
         "dtype": "u64 segments / f64+f32 rasterizer / f32 painter", "data": "synthetic",
         "mpixel_segments_per_s": round(n_segments_full * fps / 1e6, 1),
         "fps_including_d2h": round(fps_d2h, 2),
         "config": {"workload": args.workload + (" (labelled stand-in: paris-30k.svg is not in the reference checkout)"
                                                  if args.workload.startswith("paris") else ""),
                    "canvas": [width, height], "layers": len(comp), "pixel_segments": int(n_segments_full),
-                   "sharding": "none" if world == 1 else f"tile-row bands x{world}, replicated scene, band culling, no data-path collective",
+                   "sharding": "none" if world == 1 else (
+                       f"tile-row bands x{world} of ONE frame, replicated scene, band culling, no data-path collective"
+                       if args.mode == "bands" else
+                       f"frame-parallel x{world}: every GPU renders whole 3840x2160 frames of the workload (units = frames), no exchange"),
                    "band_rows": [row0, row1]},
         "stages_us": {k: round(stage[k], 1) for k in ("prepare_us", "rasterize_us", "sort_us", "carry_us", "paint_us", "total_us")},
         "roofline": roofline,

@@ -1152,11 +1152,13 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
     const uint32_t n_runs = dev_count(nc_runs);
     // one-wave workgroups (a wave's slot frees as soon as ITS tile is done).  XCD-aware mapping: workgroup b runs on
     // XCD b % 8; give each XCD a contiguous band of tiles so a tile row's records / spans stay in one L2
-    const uint32_t T = P.tiles_w * P.tiles_h, per = (T + 7) / 8;
+    // Only the crop's tile rows are launched (a multi-GPU rank paints its band only).
+    const uint32_t tile0 = P.crop_y0 * P.tiles_w, T = (P.crop_y1 - P.crop_y0) * P.tiles_w, per = (T + 7) / 8;
     const uint32_t bid = blockIdx.x;
     if ((bid >> 3) >= per) return;
-    const uint32_t tile = (bid & 7u) * per + (bid >> 3);
-    if (tile >= T) return;
+    const uint32_t tidx = (bid & 7u) * per + (bid >> 3);
+    if (tidx >= T) return;
+    const uint32_t tile = tile0 + tidx;
     const uint32_t ty = tile / P.tiles_w, tx = tile - ty * P.tiles_w;
     if (tx < P.crop_x0 || tx >= P.crop_x1 || ty < P.crop_y0 || ty >= P.crop_y1) return;   // print_row :588-592, :525-529
 
@@ -1470,9 +1472,9 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
                   const uint32_t* style_offsets, const uint32_t* style_words, const forma_image_t* images,
                   const uint16_t* texels, uint8_t* image, FrameInfo* info, uint32_t* overflow_n, uint32_t* overflow_list,
                   unsigned long long* prof) {
-    uint32_t T = p.tiles_w * p.tiles_h;
-    if (T == 0) return;
-    uint32_t per = (T + 7) / 8;
+    const uint32_t T = p.tiles_w * p.tiles_h;
+    if (T == 0 || p.crop_y1 <= p.crop_y0) return;
+    const uint32_t per = ((p.crop_y1 - p.crop_y0) * p.tiles_w + 7) / 8;
     (void)prof;
     hipLaunchKernelGGL(k_paint_wave, dim3(per * 8), dim3(64), 0, s, p, sorted, records, n_runs, tile_first_run, row_span_lo,
                        row_span_cnt, span_key, span_cov, run_col, span_col, style_offsets, style_words, images, texels, image,
