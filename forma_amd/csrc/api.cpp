@@ -191,7 +191,7 @@ int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, boo
     ctx->speculated = (speculate || bound_n) && ctx->pred_valid;
     if (ctx->speculated) {
         ctx->live44 = ctx->pred_live44; ctx->layer_sorted = ctx->pred_layer_sorted;
-        if (bound_n) launch_verify_plan(ctx->stream, dinfo, ctx->live44, ctx->layer_sorted);   // device-side guard
+        // (asynchronous frames: k_runs_count verifies the plan on the device before anything relies on the sort order)
         return FORMA_OK;
     }
     return finish_rasterize(ctx);
@@ -271,7 +271,8 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     stage_begin(ctx, ST_CARRY, timing);
     launch_runs(ctx->stream, ctx->sorted, nc, tiles_w, tiles_h, ctx->records.as<TileRecord>(), (uint32_t)cap, ctx->run_cov.as<uint4>(),
                 ctx->rk_u.as<uint64_t>(), tile_first_run, ctx->blk_edge.as<BlkEdge>(), row_count,
-                ctx->runs_scratch.as<uint32_t>(), dinfo);
+                ctx->runs_scratch.as<uint32_t>(), dinfo, /*verify_plan=*/bound_j != 0 && ctx->speculated, ctx->live44,
+                ctx->layer_sorted);
     HIPCHECK(hipGetLastError());
     DevCount jc;
     if (bound_j) jc = DevCount{&dinfo->n_runs, bound_j};

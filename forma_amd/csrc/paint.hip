@@ -96,10 +96,26 @@ __device__ __forceinline__ uint4 pack_bins(const int* b) {
 
 // pass A: paintable run heads per tile (the run index of a tile's first head is the exclusive scan of these)
 __global__ __launch_bounds__(RN_THREADS) void k_runs_count(const uint64_t* __restrict__ sorted, DevCount nc, uint32_t tiles_w,
-                                                           uint32_t tiles_h, uint32_t* __restrict__ counts) {
+                                                           uint32_t tiles_h, uint32_t* __restrict__ counts,
+                                                           uint32_t* __restrict__ zero_base, uint32_t zero_words,
+                                                           FrameInfo* __restrict__ info, uint64_t spec_live44,
+                                                           uint32_t spec_flags /* bit0 verify, bit1 layer_sorted */) {
     __shared__ uint32_t s_c[RN_WAVES];
     const uint32_t n = dev_count(nc);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // housekeeping that would otherwise be separate launches: zero this frame's tile tables (row counts, span tables,
+    // painter overflow counter, first-run table: consumed by k_runs and later), verify the speculated sort plan
+    {
+        const uint32_t per = (zero_words + gridDim.x - 1) / gridDim.x;
+        const uint32_t z0 = blockIdx.x * per, z1 = min(zero_words, z0 + per);
+        for (uint32_t i = z0 + tid; i < z1; i += RN_THREADS) zero_base[i] = 0;
+        if (blockIdx.x == 0 && tid == 0 && (spec_flags & 1u) && info->n_segments) {
+            const uint64_t k_or = (uint64_t)info->key_or | ((uint64_t)info->key_or_hi << 32);
+            const uint64_t k_and = (uint64_t)info->key_and | ((uint64_t)info->key_and_hi << 32);
+            const uint32_t sorted_now = info->layer_unsorted == 0 ? 2u : 0u;
+            if (((k_or ^ k_and) & 0xFFFFFFFFFFFull) != spec_live44 || sorted_now != (spec_flags & 2u)) info->plan_bad = 1u;
+        }
+    }
     const uint32_t base = blockIdx.x * RN_TILE;
     uint32_t c = 0;
 #pragma unroll
@@ -122,16 +138,33 @@ __global__ __launch_bounds__(RN_THREADS, 8) void k_runs(const uint64_t* __restri
                                                         uint4* __restrict__ run_cov, uint64_t* __restrict__ run_keys,
                                                         uint32_t* __restrict__ tile_first_run,
                                                         BlkEdge* __restrict__ blk_edge, uint32_t* __restrict__ row_count,
-                                                        const uint32_t* __restrict__ run_base) {
+                                                        const uint32_t* __restrict__ run_counts, int counts_scanned,
+                                                        FrameInfo* __restrict__ info) {
     __shared__ uint64_t s_seg[RN_TILE + 1];                   // [0] = element before the tile, tile at [1 + i]
     __shared__ int s_bins[RN_SLOTS * RN_STRIDE];
     __shared__ uint16_t s_start[RN_TILE + 2];                 // s_start[slot] = tile-local index of the slot's first segment
     __shared__ uint32_t s_cb[RN_IPT * RN_WAVES], s_cv[RN_WAVES];            // boundaries per (row, wave); heads per wave
     __shared__ uint32_t s_rows[RN_ROWS];
-    __shared__ uint32_t s_row0, s_R;
+    __shared__ uint32_t s_row0, s_R, s_jb[RN_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t n = dev_count(nc);
     if (blockIdx.x * RN_TILE >= n) return;                              // the grid was sized for the bound
+    // run index of this tile's first head = sum of the head counts of the tiles before it.  The count array is a few
+    // KB and L2-resident, so every workgroup sums it itself (saves a scan launch); big frames get it pre-scanned.
+    uint32_t run_base0 = 0;
+    if (counts_scanned) run_base0 = run_counts[blockIdx.x];
+    else {
+        uint32_t acc = 0;
+        for (uint32_t i = tid; i < blockIdx.x; i += RN_THREADS) acc += run_counts[i];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+        if (lane == 0) s_jb[w] = acc;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < RN_WAVES; q++) run_base0 += s_jb[q];
+        const uint32_t ntl = (n + RN_TILE - 1) / RN_TILE;
+        if (blockIdx.x == ntl - 1 && tid == 0) info->n_runs = run_base0 + run_counts[blockIdx.x];
+    }
     {
         const uint32_t tile = blockIdx.x;
         if (tid == 0) s_row0 = 0xFFFFFFFFu;
@@ -182,7 +215,7 @@ __global__ __launch_bounds__(RN_THREADS, 8) void k_runs(const uint64_t* __restri
         }
         if (tid == 0) { s_start[R + 1] = (uint16_t)tile_n; s_start[0] = 0; }
         const uint32_t row0 = s_row0;
-        uint32_t jbase = run_base[tile];                     // run index of the next paintable head (uniform)
+        uint32_t jbase = run_base0;                          // run index of the next paintable head (uniform)
         // ---- phase 2 + 3, RN_SLOTS slots per sweep -----------------------------------------------------------------
         for (uint32_t s0 = 0; s0 <= R; s0 += RN_SLOTS) {
             for (int k = tid; k < RN_SLOTS * RN_STRIDE; k += RN_THREADS) s_bins[k] = 0;
@@ -253,16 +286,23 @@ size_t runs_blocks(size_t n) { return (n + RN_TILE - 1) / RN_TILE + 1; }
 
 void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t tiles_w, uint32_t tiles_h, TileRecord* records,
                  uint32_t rec_cap, uint4* run_cov, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge, uint32_t* row_tab,
-                 uint32_t* scratch, FrameInfo* info) {
-    // per-frame state, ONE memset: [row_count | row_span_lo | row_span_cnt | painter overflow counter | first-run table]
-    // are contiguous (api.cpp lays them out so); 0 in the first-run table = the tile has no run
-    (void)hipMemsetAsync(row_tab, 0, ((size_t)(tiles_h + 1) * 3 + 1 + (size_t)tiles_w * tiles_h) * 4, s);
-    if (nc.bound == 0) { (void)hipMemsetAsync(&info->n_runs, 0, 4, s); return; }
+                 uint32_t* scratch, FrameInfo* info, bool verify_plan, uint64_t spec_live44, bool spec_layer_sorted) {
+    // per-frame tile tables: [row_count | row_span_lo | row_span_cnt | painter overflow counter | first-run table] are
+    // contiguous (api.cpp lays them out so) and zeroed by k_runs_count; 0 in the first-run table = the tile has no run
+    const uint32_t zero_words = (tiles_h + 1) * 3 + 1 + tiles_w * tiles_h;
+    if (nc.bound == 0) {
+        (void)hipMemsetAsync(row_tab, 0, (size_t)zero_words * 4, s);
+        (void)hipMemsetAsync(&info->n_runs, 0, 4, s);
+        return;
+    }
     const uint32_t ntiles = (nc.bound + RN_TILE - 1) / RN_TILE;
-    hipLaunchKernelGGL(k_runs_count, dim3(ntiles), dim3(RN_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, scratch);
-    launch_scan_small_u32(s, scratch, nc, RN_TILE, &info->n_runs);             // exclusive, in place; total -> n_runs
+    const uint32_t flags = (verify_plan ? 1u : 0u) | (spec_layer_sorted ? 2u : 0u);
+    hipLaunchKernelGGL(k_runs_count, dim3(ntiles), dim3(RN_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, scratch, row_tab,
+                       zero_words, info, spec_live44, flags);
+    const int scanned = ntiles > 16384 ? 1 : 0;
+    if (scanned) launch_scan_small_u32(s, scratch, nc, RN_TILE, &info->n_runs);   // exclusive, in place; total -> n_runs
     hipLaunchKernelGGL(k_runs, dim3(ntiles), dim3(RN_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, records, rec_cap, run_cov, run_keys,
-                       tile_first_run, blk_edge, row_tab, (const uint32_t*)scratch);
+                       tile_first_run, blk_edge, row_tab, (const uint32_t*)scratch, scanned, info);
 }
 
 // ================================================================================================
