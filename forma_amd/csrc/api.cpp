@@ -42,6 +42,7 @@ struct forma_hip_ctx {
     DevBuf x, y, line_slot, geoms, style_off, style_words, unchanged, images, texels;
     size_t n_points = 0, n_geoms = 0, n_orders = 0, n_words = 0, n_images = 0;
     bool scene_has_clips = false;
+    bool have_unchanged = false;            // set_styles supplied per-order Layer::is_unchanged bytes
     // lines
     DevBuf l_order, l_x0, l_y0, l_dx, l_dy, l_a, l_b, l_c, l_d, l_len, scan_tmp;   // parity entry points only
     DevBuf cl_idx, cl_start, block_first, prep_scratch;                              // frame path: compacted line table
@@ -56,6 +57,22 @@ struct forma_hip_ctx {
     int digit_bits = 8;                     // radix digit width: 8 (default) or 4 (FORMA_HIP_DIGIT_BITS)
     // paint
     DevBuf info_init;                       // pristine FrameInfo (reset template)
+    // buffer-layer caches (reference cpu/buffer/mod.rs:113-197): per cache the CachedTile table, the device image the
+    // cache's buffer shows (tiles the painter skips keep last frame's pixels), and the cached clear colour
+    struct TileCache {
+        DevBuf tiles, image;
+        uint32_t w = 0, h = 0;
+        bool has_clear = false;
+        float clear[4] = {0, 0, 0, 0};
+    };
+    TileCache caches[32];
+    DevBuf cache_written;                   // one byte per tile: written this frame
+    uint8_t* h_written = nullptr;           // pinned copy of cache_written
+    size_t h_written_cap = 0;
+    uint8_t* h_stage = nullptr;             // pinned staging image for tile-granular copy-out
+    size_t h_stage_cap = 0;
+    int cur_cache = -1;                     // cache of the frame in flight
+    uint8_t* cur_image = nullptr;           // device image of the frame in flight / last frame
     // sort-plan speculation: the varying-bit mask and the layer-sortedness of a scene rarely change between frames, so
     // forma_hip_render plans the sort from the previous frame's values and verifies them when the frame is done
     bool pred_valid = false, pred_layer_sorted = false, speculated = false;
@@ -240,6 +257,7 @@ struct PaintArgs {
     const uint8_t* channels;
     const float* clear;
     const forma_rect_t* crop;
+    int cache_id = -1;
 };
 
 // stage 4 on ctx->sorted (n segments): runs + carry pre-pass + per-tile painter -> ctx->image
@@ -248,8 +266,29 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     const size_t n = nc.bound;
     const uint32_t tiles_w = (a.width + 15) / 16, tiles_h = (a.height + 15) / 16;
     const uint32_t T = tiles_w * tiles_h;
-    HIPCHECK(ctx->image.ensure((size_t)a.width * a.height * 4));
     ctx->img_w = a.width; ctx->img_h = a.height;
+    // where this frame is painted: the cache's own image (it must keep what its buffer showed last frame) or the scratch one
+    TileCacheArgs tc{nullptr, nullptr};
+    uint32_t clear_unchanged = 0;
+    ctx->cur_cache = a.cache_id;
+    if (a.cache_id >= 0) {
+        forma_hip_ctx::TileCache& c = ctx->caches[a.cache_id];
+        HIPCHECK(c.tiles.ensure((size_t)T * 8));
+        HIPCHECK(c.image.ensure((size_t)a.width * a.height * 4));
+        HIPCHECK(ctx->cache_written.ensure((size_t)T));
+        if (c.w != a.width || c.h != a.height) {                       // renderer.rs:94-111: new size -> cache cleared
+            c.w = a.width; c.h = a.height; c.has_clear = false;
+            HIPCHECK(hipMemsetAsync(c.tiles.p, 0, (size_t)T * 8, ctx->stream));
+            HIPCHECK(hipMemsetAsync(c.image.p, 0, (size_t)a.width * a.height * 4, ctx->stream));
+        }
+        HIPCHECK(hipMemsetAsync(ctx->cache_written.p, 0, (size_t)T, ctx->stream));
+        tc.tiles = c.tiles.as<uint2>(); tc.written = ctx->cache_written.as<uint8_t>();
+        clear_unchanged = c.has_clear && memcmp(c.clear, a.clear, sizeof c.clear) == 0 ? 1u : 0u;
+        ctx->cur_image = c.image.as<uint8_t>();
+    } else {
+        HIPCHECK(ctx->image.ensure((size_t)a.width * a.height * 4));
+        ctx->cur_image = ctx->image.as<uint8_t>();
+    }
     // one buffer, zeroed by ONE memset per frame (launch_runs): [row_count | row_span_lo | row_span_cnt] (tiles_h + 1 words
     // each) [painter overflow counter] [first-run table, T words]; the painter's overflow list (T words) follows un-zeroed
     HIPCHECK(ctx->row_tab.ensure(((size_t)(tiles_h + 1) * 3 + 1 + 2 * (size_t)T) * 4));
@@ -305,7 +344,8 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                           ctx->blk_edge.as<BlkEdge>(), nc, jc, ctx->style_off.as<uint32_t>(),
                           ctx->style_words.as<uint32_t>(), (uint32_t)ctx->n_orders, tiles_w, tiles_h, row_count, row_span_lo,
                           row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(), ctx->run_col.as<uint4>(),
-                          ctx->span_col.as<uint4>(), dinfo);
+                          ctx->span_col.as<uint4>(),
+                          (a.cache_id >= 0 && ctx->have_unchanged) ? ctx->unchanged.as<uint8_t>() : nullptr, dinfo);
     } else {
         HIPCHECK(ctx->span_key.ensure(8));
         HIPCHECK(ctx->span_cov.ensure(16));
@@ -328,22 +368,74 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     P.channels = (uint32_t)ch[0] | ((uint32_t)ch[1] << 8) | ((uint32_t)ch[2] << 16) | ((uint32_t)ch[3] << 24);
     for (int i = 0; i < 4; i++) P.clear[i] = a.clear[i];
     P.stride_px = a.width; P.scene_has_clips = ctx->scene_has_clips ? 1u : 0u; P.n_orders = (uint32_t)ctx->n_orders;
+    P.clear_unchanged = clear_unchanged;
     stage_begin(ctx, ST_PAINT, timing);
     launch_paint(ctx->stream, P, ctx->sorted, ctx->records.as<TileRecord>(), jc, tile_first_run, row_span_lo,
                  row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(), ctx->run_col.as<uint4>(),
                  ctx->span_col.as<uint4>(), ctx->style_off.as<uint32_t>(),
                  ctx->style_words.as<uint32_t>(), ctx->images.as<forma_image_t>(), ctx->texels.as<uint16_t>(),
-                 ctx->image.as<uint8_t>(), dinfo, paint_overflow, overflow_list, ctx->prof.p ? ctx->prof.as<unsigned long long>() : nullptr);
+                 ctx->cur_image, tc, dinfo, paint_overflow, overflow_list, ctx->prof.p ? ctx->prof.as<unsigned long long>() : nullptr);
     stage_end(ctx, ST_PAINT, timing);
     HIPCHECK(hipGetLastError());
     return FORMA_OK;
 }
 
-int copy_image_out(forma_hip_ctx* ctx, uint8_t* dst, size_t stride, bool timing) {
+// Copy what the frame wrote into the caller's buffer — and nothing else: tiles outside the crop, and with a buffer-layer
+// cache the tiles the painter skipped (TileWriteOp::None), keep whatever the caller's buffer holds (reference
+// cpu/buffer/layout/mod.rs:264-295 writes tile by tile; forma/src/cpu/buffer/mod.rs doc test "skipped rendering").
+int copy_image_out(forma_hip_ctx* ctx, uint8_t* dst, size_t stride, bool timing, const PaintArgs& a) {
     if (!dst) return FORMA_OK;
+    const uint32_t tiles_w = (a.width + 15) / 16, tiles_h = (a.height + 15) / 16;
+    uint32_t tx0 = 0, tx1 = tiles_w, ty0 = 0, ty1 = tiles_h;
+    if (a.crop) {
+        tx0 = a.crop->x0 / 16; tx1 = std::min(tiles_w, (a.crop->x1 + 15) / 16);
+        ty0 = a.crop->y0 / 16; ty1 = std::min(tiles_h, (a.crop->y1 + 15) / 16);
+    }
+    if (tx0 >= tx1 || ty0 >= ty1) return FORMA_OK;
+    const size_t px0 = (size_t)tx0 * 16, px1 = std::min<size_t>((size_t)tx1 * 16, a.width);
+    const size_t py0 = (size_t)ty0 * 16, py1 = std::min<size_t>((size_t)ty1 * 16, a.height);
+    const size_t pitch = (size_t)a.width * 4;
     stage_begin(ctx, ST_D2H, timing);
-    HIPCHECK(hipMemcpy2DAsync(dst, stride, ctx->image.p, (size_t)ctx->img_w * 4, (size_t)ctx->img_w * 4, ctx->img_h,
-                              hipMemcpyDeviceToHost, ctx->stream));
+    if (a.cache_id < 0) {
+        HIPCHECK(hipMemcpy2DAsync(dst + py0 * stride + px0 * 4, stride, ctx->cur_image + py0 * pitch + px0 * 4, pitch,
+                                  (px1 - px0) * 4, py1 - py0, hipMemcpyDeviceToHost, ctx->stream));
+        stage_end(ctx, ST_D2H, timing);
+        return FORMA_OK;
+    }
+    // cache attached: which tiles were written?
+    const size_t T = (size_t)tiles_w * tiles_h;
+    if (ctx->h_written_cap < T) {
+        if (ctx->h_written) (void)hipHostFree(ctx->h_written);
+        ctx->h_written = nullptr; ctx->h_written_cap = 0;
+        HIPCHECK(hipHostMalloc((void**)&ctx->h_written, T, hipHostMallocDefault));
+        ctx->h_written_cap = T;
+    }
+    HIPCHECK(hipMemcpyAsync(ctx->h_written, ctx->cache_written.p, T, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    size_t n_written = 0, n_crop = (size_t)(tx1 - tx0) * (ty1 - ty0);
+    for (uint32_t ty = ty0; ty < ty1; ty++) for (uint32_t tx = tx0; tx < tx1; tx++) n_written += ctx->h_written[(size_t)ty * tiles_w + tx] ? 1 : 0;
+    if (n_written == n_crop) {                                         // everything was painted: one strided copy
+        HIPCHECK(hipMemcpy2DAsync(dst + py0 * stride + px0 * 4, stride, ctx->cur_image + py0 * pitch + px0 * 4, pitch,
+                                  (px1 - px0) * 4, py1 - py0, hipMemcpyDeviceToHost, ctx->stream));
+    } else if (n_written) {                                            // stage, then copy only the written tiles
+        const size_t bytes = pitch * a.height;
+        if (ctx->h_stage_cap < bytes) {
+            if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+            ctx->h_stage = nullptr; ctx->h_stage_cap = 0;
+            HIPCHECK(hipHostMalloc((void**)&ctx->h_stage, bytes, hipHostMallocDefault));
+            ctx->h_stage_cap = bytes;
+        }
+        HIPCHECK(hipMemcpy2DAsync(ctx->h_stage + py0 * pitch + px0 * 4, pitch, ctx->cur_image + py0 * pitch + px0 * 4, pitch,
+                                  (px1 - px0) * 4, py1 - py0, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        for (uint32_t ty = ty0; ty < ty1; ty++)
+            for (uint32_t tx = tx0; tx < tx1; tx++) {
+                if (!ctx->h_written[(size_t)ty * tiles_w + tx]) continue;
+                const size_t x0 = (size_t)tx * 16, x1 = std::min<size_t>(x0 + 16, a.width);
+                const size_t y0 = (size_t)ty * 16, y1 = std::min<size_t>(y0 + 16, a.height);
+                for (size_t y = y0; y < y1; y++) memcpy(dst + y * stride + x0 * 4, ctx->h_stage + y * pitch + x0 * 4, (x1 - x0) * 4);
+            }
+    }
     stage_end(ctx, ST_D2H, timing);
     return FORMA_OK;
 }
@@ -465,6 +557,10 @@ void forma_hip_destroy(forma_hip_ctx* ctx) {
     for (int s = 0; s < ST_COUNT; s++) { (void)hipEventDestroy(ctx->ev0[s]); (void)hipEventDestroy(ctx->ev1[s]); }
     for (int p = 0; p < MAX_PASS_EVENTS; p++) { (void)hipEventDestroy(ctx->pev0[p]); (void)hipEventDestroy(ctx->pev1[p]); }
     if (ctx->h_info) (void)hipHostFree(ctx->h_info);
+    if (ctx->h_written) (void)hipHostFree(ctx->h_written);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    for (auto& c : ctx->caches) { c.tiles.release(); c.image.release(); }
+    ctx->cache_written.release();
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -527,6 +623,7 @@ int forma_hip_set_styles(forma_hip_ctx* ctx, const uint32_t* style_offsets, size
     if (unchanged && (rc = upload(ctx, ctx->unchanged, unchanged, n_orders))) return rc;
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     ctx->n_orders = n_orders; ctx->n_words = n_words; ctx->scene_has_clips = clips;
+    ctx->have_unchanged = unchanged != nullptr;
     return FORMA_OK;
 }
 
@@ -694,7 +791,7 @@ int forma_hip_paint(forma_hip_ctx* ctx, const uint64_t* sorted_segments, size_t 
     ctx->live44 = n ? host_live44(sorted_segments, n) : 0;
     PaintArgs a{width, height, channels, clear_color, crop_or_null};
     if ((rc = run_paint(ctx, DevCount{nullptr, (uint32_t)n}, a, false))) return rc;
-    if ((rc = copy_image_out(ctx, dst, stride_bytes, false))) return rc;
+    if ((rc = copy_image_out(ctx, dst, stride_bytes, false, a))) return rc;
     return finish_frame(ctx, nullptr);
 }
 
@@ -710,7 +807,11 @@ int forma_hip_render(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t 
     const bool timing = timings != nullptr;
     clear_stage_flags(ctx);
     if (width != ctx->pred_w || height != ctx->pred_h) { ctx->pred_counts_valid = false; ctx->pred_w = width; ctx->pred_h = height; }
-    PaintArgs a{width, height, channels, clear_color, crop_or_null};
+    PaintArgs a{width, height, channels, clear_color, crop_or_null, cache_id};
+    auto frame_done = [&](int r) {                       // renderer.rs:217-218: remember the clear colour in the cache
+        if (r == FORMA_OK && cache_id >= 0) { ctx->caches[cache_id].has_clear = true; memcpy(ctx->caches[cache_id].clear, clear_color, 16); }
+        return r;
+    };
     // 1. fully asynchronous attempt: no read-back inside the frame.  N, J and the sort plan are predicted from the previous
     //    frame (bounds with slack); device-side guards keep a wrong guess memory-safe; verified when the frame is done.
     if (ctx->pred_valid && ctx->pred_counts_valid && !ctx->no_async) {
@@ -719,13 +820,13 @@ int forma_hip_render(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t 
         if ((rc = run_rasterize_frame(ctx, width, height, timing, true, bN))) return rc;
         if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), DevCount{&dinfo->n_segments, bN}, timing))) return rc;
         if ((rc = run_paint(ctx, DevCount{&dinfo->n_segments, bN}, a, timing, bJ))) return rc;
-        if ((rc = copy_image_out(ctx, dst, stride_bytes, timing))) return rc;
+        if ((rc = copy_image_out(ctx, dst, stride_bytes, timing, a))) return rc;
         HIPCHECK(hipMemcpyAsync(ctx->h_info, ctx->info.p, sizeof(FrameInfo), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHECK(hipStreamSynchronize(ctx->stream));
         const uint32_t N = ctx->h_info->n_segments, J = ctx->h_info->n_runs;
         ctx->n_seg = N; ctx->n_compact = ctx->h_info->n_compact; ctx->last_runs = J;
         const bool ok = !ctx->h_info->plan_bad && N <= bN && J <= bJ;
-        if (ok) { ctx->pred_N = N; ctx->pred_J = J; return finish_frame(ctx, timings, true); }
+        if (ok) { ctx->pred_N = N; ctx->pred_J = J; return frame_done(finish_frame(ctx, timings, true)); }
         ctx->pred_counts_valid = false;                   // fall through: the synchronous path re-learns everything
         clear_stage_flags(ctx);
     }
@@ -736,16 +837,21 @@ int forma_hip_render(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t 
         rc = run_paint(ctx, DevCount{nullptr, (uint32_t)ctx->n_seg}, a, timing);
         if (rc == FORMA_RETRY) { clear_stage_flags(ctx); continue; }
         if (rc) return rc;
-        if ((rc = copy_image_out(ctx, dst, stride_bytes, timing))) return rc;
+        if ((rc = copy_image_out(ctx, dst, stride_bytes, timing, a))) return rc;
         rc = finish_frame(ctx, timings);
         if (rc == FORMA_OK) { ctx->pred_N = (uint32_t)ctx->n_seg; ctx->pred_J = ctx->last_runs; ctx->pred_counts_valid = true; }
-        return rc;
+        return frame_done(rc);
     }
     return fail(ctx, FORMA_E_INTERNAL, "sort plan did not converge");
 }
 
 int forma_hip_cache_clear(forma_hip_ctx* ctx, int cache_id) {
     if (!ctx || cache_id < 0 || cache_id >= 32) return fail(ctx, FORMA_E_ARG, "cache_id out of range");
+    HIPCHECK(hipSetDevice(ctx->device));
+    forma_hip_ctx::TileCache& c = ctx->caches[cache_id];               // BufferLayerCache::clear, buffer/mod.rs:189-196
+    c.has_clear = false;
+    if (c.tiles.p) HIPCHECK(hipMemsetAsync(c.tiles.p, 0, c.tiles.cap, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
     return FORMA_OK;
 }
 
@@ -769,7 +875,7 @@ int forma_hip_read_image(forma_hip_ctx* ctx, uint8_t* dst, size_t stride_bytes) 
     if (!ctx->img_w) return fail(ctx, FORMA_E_STATE, "no image on the device");
     if ((size_t)ctx->img_w * 4 > stride_bytes) return fail(ctx, FORMA_E_ARG, "width exceeds width stride");
     HIPCHECK(hipSetDevice(ctx->device));
-    HIPCHECK(hipMemcpy2D(dst, stride_bytes, ctx->image.p, (size_t)ctx->img_w * 4, (size_t)ctx->img_w * 4, ctx->img_h, hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy2D(dst, stride_bytes, ctx->cur_image, (size_t)ctx->img_w * 4, (size_t)ctx->img_w * 4, ctx->img_h, hipMemcpyDeviceToHost));
     return FORMA_OK;
 }
 
@@ -828,7 +934,7 @@ int forma_hip_sort_paint_frame(forma_hip_ctx* ctx, size_t n, uint8_t* dst, uint3
     if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), DevCount{nullptr, (uint32_t)n}, timing))) return rc;
     PaintArgs a{width, height, channels, clear_color, crop_or_null};
     if ((rc = run_paint(ctx, DevCount{nullptr, (uint32_t)n}, a, timing))) return rc;
-    if ((rc = copy_image_out(ctx, dst, stride_bytes, timing))) return rc;
+    if ((rc = copy_image_out(ctx, dst, stride_bytes, timing, a))) return rc;
     return finish_frame(ctx, timings);
 }
 

@@ -65,7 +65,19 @@ struct PaintParams {
     uint32_t stride_px;                            // device image row pitch in pixels
     uint32_t scene_has_clips;
     uint32_t n_orders;
+    uint32_t clear_unchanged;                      // buffer-layer cache: this frame's clear colour == the cached one
 };
+
+// buffer-layer cache (reference cpu/buffer/mod.rs:113-197, painter/mod.rs:629-715 `CachedTile`), device-resident:
+// per tile {x = tags (bit0 solid colour valid, bit1 layer count valid) | layer_count << 8, y = solid colour bytes}
+struct TileCacheArgs {
+    uint2*         tiles;        // nullptr: no cache attached to this frame
+    uint8_t*       written;      // one byte per tile: 1 = the painter wrote the tile this frame (TileWriteOp != None)
+};
+// entry reference word of the painter's layer list (low 32 bits of a key)
+#define REF_SPAN 0x80000000u     // index names a span record, else a run record
+#define REF_UNCH 0x40000000u     // the layer is unchanged since the cache's previous frame (Layer::is_unchanged)
+#define REF_IDX  0x3FFFFFFFu
 
 // A count that lives on the device.  `ptr == nullptr`: the host knows it exactly (= bound).  Otherwise kernels read *ptr
 // and clamp it to `bound`, the size their launch grid / buffers were provisioned for: a frame can then be enqueued
@@ -149,11 +161,11 @@ void launch_carry_rows(hipStream_t s, const uint64_t* sorted_run_keys, TileRecor
                        const uint32_t* style_words,
                        uint32_t n_orders, uint32_t tiles_w, uint32_t tiles_h, const uint32_t* row_count,
                        uint32_t* row_span_lo, uint32_t* row_span_cnt, uint64_t* span_key, uint4* span_cov, uint4* run_col,
-                       uint4* span_col, FrameInfo* info);
+                       uint4* span_col, const uint8_t* unchanged /* per order, nullable */, FrameInfo* info);
 void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, DevCount n_runs,
                   const uint32_t* tile_first_run, const uint32_t* row_span_lo, const uint32_t* row_span_cnt,
                   const uint64_t* span_key, const uint4* span_cov, const uint4* run_col, const uint4* span_col,
                   const uint32_t* style_offsets, const uint32_t* style_words, const forma_image_t* images,
-                  const uint16_t* texels, uint8_t* image, FrameInfo* info, uint32_t* overflow_n /* zeroed by launch_runs */,
+                  const uint16_t* texels, uint8_t* image, TileCacheArgs cache, FrameInfo* info, uint32_t* overflow_n /* zeroed by launch_runs */,
                   uint32_t* overflow_list /* tiles_w * tiles_h words */,
                   unsigned long long* prof /* nullable: per-phase shader-clock sums (diagnostics) */);

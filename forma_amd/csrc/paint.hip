@@ -109,6 +109,7 @@ __global__ __launch_bounds__(RN_THREADS) void k_runs_count(const uint64_t* __res
         const uint32_t per = (zero_words + gridDim.x - 1) / gridDim.x;
         const uint32_t z0 = blockIdx.x * per, z1 = min(zero_words, z0 + per);
         for (uint32_t i = z0 + tid; i < z1; i += RN_THREADS) zero_base[i] = 0;
+        if (blockIdx.x == 0 && tid == 0 && nc.ptr && *nc.ptr > nc.bound) info->plan_bad = 1u;   // more segments than provisioned
         if (blockIdx.x == 0 && tid == 0 && (spec_flags & 1u) && info->n_segments) {
             const uint64_t k_or = (uint64_t)info->key_or | ((uint64_t)info->key_or_hi << 32);
             const uint64_t k_and = (uint64_t)info->key_and | ((uint64_t)info->key_and_hi << 32);
@@ -333,6 +334,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
                                                            uint32_t* __restrict__ row_span_cnt,
                                                            uint64_t* __restrict__ span_key, uint4* __restrict__ span_cov,
                                                            uint4* __restrict__ run_col, uint4* __restrict__ span_col,
+                                                           const uint8_t* __restrict__ unchanged,
                                                            FrameInfo* __restrict__ info) {
     __shared__ uint32_t s_red[CR_WAVES];
     __shared__ uint64_t s_wlo[CR_WAVES], s_whi[CR_WAVES];
@@ -343,6 +345,10 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t ty = blockIdx.x;
     if (info->plan_bad) return;                                         // mis-sorted stream (async frame): the host re-runs
+    if (nc_runs.ptr && *nc_runs.ptr > nc_runs.bound) {                  // more runs than provisioned: the frame is void, and
+        if (threadIdx.x == 0) info->plan_bad = 1u;                      // the painters (next launches) must not touch anything
+        return;
+    }
     const uint32_t n_blk = (dev_count(nc_segments) + RN_TILE - 1) / RN_TILE;
     const uint32_t n_runs = dev_count(nc_runs);
     // first run of this row = sum of the run counts of the rows above
@@ -361,7 +367,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
     for (uint32_t c0 = 0; c0 < cnt; c0 += CR_THREADS) {
         const uint32_t k = row_lo + c0 + tid;
         const bool active = c0 + tid < cnt && k < n_runs;
-        uint32_t group = 0xFFFFFFFEu, jrun = 0, txb = 0, layer = 0, sfl = 0;
+        uint32_t group = 0xFFFFFFFEu, jrun = 0, txb = 0, layer = 0, sfl = 0, unch = 0;
         uint64_t own_lo = 0, own_hi = 0;
         uint4 scol = make_uint4(0, 0, 0, 0);
         bool even_odd = false;
@@ -399,6 +405,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
                 }
                 r->layer = layer | (sfl << 21);
                 run_col[jrun] = scol;
+                if (unchanged && unchanged[layer]) { unch = 1u; r->tile |= 0x80000000u; }   // Layer::is_unchanged(cache_id)
             } else atomicOr(&info->error, 1u);
         }
         s_group[tid] = group; s_txb[tid] = txb;
@@ -469,7 +476,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
             const uint32_t si = row_lo + sbase + before;
             const uint32_t c4[4] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
             const uint32_t full = cover_full(c4, even_odd) ? SF_FULL : 0u;
-            span_key[si] = ((uint64_t)(layer | ((sfl | full) << 21)) << 32) | ((uint64_t)span_lo << 16) | span_hi;
+            span_key[si] = ((uint64_t)(layer | ((sfl | full) << 21)) << 32) | ((uint64_t)unch << 31) | ((uint64_t)span_lo << 16) | span_hi;
             span_cov[si] = make_uint4(c4[0], c4[1], c4[2], c4[3]);
             span_col[si] = scol;
         }
@@ -486,11 +493,11 @@ void launch_carry_rows(hipStream_t s, const uint64_t* sorted_run_keys, TileRecor
                        const uint32_t* style_words,
                        uint32_t n_orders, uint32_t tiles_w, uint32_t tiles_h, const uint32_t* row_count,
                        uint32_t* row_span_lo, uint32_t* row_span_cnt, uint64_t* span_key, uint4* span_cov, uint4* run_col,
-                       uint4* span_col, FrameInfo* info) {
+                       uint4* span_col, const uint8_t* unchanged, FrameInfo* info) {
     if (tiles_h == 0) return;
     hipLaunchKernelGGL(k_carry_rows, dim3(tiles_h), dim3(CR_THREADS), 0, s, sorted_run_keys, records, run_cov, blk_edge, n_segments, n_runs,
                        style_offsets, style_words, n_orders, tiles_w, tiles_h, row_count, row_span_lo, row_span_cnt, span_key,
-                       span_cov, run_col, span_col, info);
+                       span_cov, run_col, span_col, unchanged, info);
 }
 
 // ================================================================================================
@@ -796,7 +803,7 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
                                            const uint32_t* __restrict__ style_words,
                                            const forma_image_t* __restrict__ images,
                                            const uint16_t* __restrict__ texels, uint8_t* __restrict__ image,
-                                           FrameInfo* __restrict__ info, uint32_t* __restrict__ overflow,
+                                           TileCacheArgs cache, FrameInfo* __restrict__ info, uint32_t* __restrict__ overflow,
                                            unsigned long long* __restrict__ prof) {
 #define PROF_MARK(k) do { if (prof && tid == 0 && (tile & 63u) == 0) { const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
                                                     atomicAdd(&prof[k], _t - t_prev); t_prev = _t; } } while (0)
@@ -838,9 +845,9 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
     if (j0 != FORMA_NONE) {
         for (uint32_t c = 0;; c += 256) {                              // a tile's runs are contiguous from j0
             const uint32_t j = j0 + c + tid;
-            bool mine = false; uint32_t layer = 0, st = 0, cn = 0;
-            if (j < n_runs) { const TileRecord* r = &records[j]; mine = r->tile == my_tile_key; layer = r->layer; st = r->seg_start; cn = r->seg_count; }
-            if (mine && c + tid < MAXE) e_tmp[c + tid] = ((uint64_t)layer << 32) | j;
+            bool mine = false; uint32_t layer = 0, st = 0, cn = 0, unch = 0;
+            if (j < n_runs) { const TileRecord* r = &records[j]; mine = (r->tile & 0x7FFFFFFFu) == my_tile_key; layer = r->layer; unch = (r->tile >> 31) ? REF_UNCH : 0u; st = r->seg_start; cn = r->seg_count; }
+            if (mine && c + tid < MAXE) e_tmp[c + tid] = ((uint64_t)layer << 32) | unch | j;
             const uint64_t mb = __ballot(mine);
             if (mine && c + tid == 0) s_seg0 = st;
             // the last run of the tile: mine, and the next record is not (runs of a tile are a prefix of the probes)
@@ -848,7 +855,7 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
             if (mine && lane < 63 && !next_mine) s_seg1 = st + cn;
             if (mine && lane == 63) {
                 const uint32_t jn = j + 1;
-                if (jn >= n_runs || records[jn].tile != my_tile_key) s_seg1 = st + cn;
+                if (jn >= n_runs || (records[jn].tile & 0x7FFFFFFFu) != my_tile_key) s_seg1 = st + cn;
             }
             const uint32_t got = (uint32_t)__syncthreads_count(mine ? 1 : 0);
             na += got;
@@ -873,12 +880,12 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const uint32_t lo = (uint32_t)(sk[u] >> 16) & 0xFFFFu, hi = (uint32_t)sk[u] & 0xFFFFu;   // padding: lo = hi = 0
+                const uint32_t lo = (uint32_t)(sk[u] >> 16) & 0x7FFFu, hi = (uint32_t)sk[u] & 0xFFFFu;   // padding: lo = hi = 0
                 const bool hit = tx >= lo && tx < hi;
                 const uint64_t bal = __ballot(hit);
                 if (hit) {
                     const uint32_t pos = cw + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    if (pos < (uint32_t)STAGE) e_key[wv * STAGE + pos] = (sk[u] & 0xFFFFFFFF00000000ull) | 0x80000000u | (sb + c + u * 64 + lane);
+                    if (pos < (uint32_t)STAGE) e_key[wv * STAGE + pos] = (sk[u] & 0xFFFFFFFF00000000ull) | REF_SPAN | (((uint32_t)sk[u] >> 31) ? REF_UNCH : 0u) | (sb + c + u * 64 + lane);
                 }
                 cw += (uint32_t)__popcll(bal);
             }
@@ -939,6 +946,26 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
 
     PROF_MARK(3);
     const Col clear = {P.clear[0], P.clear[1], P.clear[2], P.clear[3]};
+    // ---- buffer-layer cache: tile_unchanged_pass (passes/tile_unchanged.rs), the first pass ------------------------------
+    bool layers_were_removed = true;                                    // PassesSharedState default
+    uint32_t ct_tags = 0, ct_solid = 0;
+    if (cache.tiles) {
+        const uint2 ct = cache.tiles[tile];
+        ct_solid = ct.y;
+        int all_unch = 1;
+        for (uint32_t i = tid; i < ne; i += 256) if (!((uint32_t)keys[i] & REF_UNCH)) all_unch = 0;
+        all_unch = __syncthreads_and(all_unch);
+        const bool had = (ct.x & 2u) != 0;
+        const uint32_t prev = ct.x >> 8;
+        ct_tags = (ct.x & 1u) | 2u;                                     // update_layer_count(Some(layers))
+        bool tile_unchanged = false;
+        if (had) { layers_were_removed = ne < prev; tile_unchanged = prev == ne && all_unch; }
+        if (P.clear_unchanged && tile_unchanged) {                      // TileWriteOp::None
+            __syncthreads();                                            // every thread has read ct
+            if (tid == 0) cache.tiles[tile] = make_uint2(ct_tags | (ne << 8), ct_solid);
+            return;
+        }
+    }
     // ---- optimizer passes (layer_workbench/passes/*.rs) -----------------------------------------------------------
     if (P.scene_has_clips && tid == 0) {                               // skip_trivial_clips_pass: serial (clip state machine)
         bool has = false, c_full = false, c_used = false; uint32_t c_last = 0, c_i = 0;
@@ -979,6 +1006,14 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
     blk = max(max(s_wblk[0], s_wblk[1]), max(s_wblk[2], s_wblk[3]));
     const uint32_t skipped = top ? top - 1u : 0u;
     const int first = top ? (blk > top ? 2 : 1) : (blk ? 2 : 0);
+    if (cache.tiles && first == 1 && !layers_were_removed) {            // all visible layers unchanged: nothing to draw
+        int vis = 1;
+        for (uint32_t i = skipped + tid; i < ne; i += 256) if ((flags[i] & EF_MASK) && !((uint32_t)keys[i] & REF_UNCH)) vis = 0;
+        if (__syncthreads_and(vis)) {
+            if (tid == 0) cache.tiles[tile] = make_uint2(ct_tags | (ne << 8), ct_solid);
+            return;
+        }
+    }
     if (tid == 0) s_solid = 0;
     if (first != 2) {                                                   // fold: every layer from `skipped` up is a full cover
         Col dst = clear; bool ok = true;
@@ -987,7 +1022,7 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
             __syncthreads();
             if ((uint32_t)tid < nbt) {
                 const uint32_t ref = (uint32_t)keys[k0 + tid];
-                b_col[tid] = (ref & 0x80000000u) ? span_col[ref & 0x7FFFFFFFu] : run_col[ref];
+                b_col[tid] = (ref & 0x80000000u) ? span_col[ref & REF_IDX] : run_col[ref & REF_IDX];
             }
             __syncthreads();
             if (tid == 0) {
@@ -1018,7 +1053,16 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
     const bool in_image = px < P.width && py < P.height;
     uint32_t* out_px = (uint32_t*)image + (size_t)py * P.stride_px + px;
     if (s_solid) {
-        if (in_image) *out_px = s_solid_bytes;
+        const uint32_t bytes = s_solid_bytes;
+        if (cache.tiles) {                                              // CachedTile::convert_optimizer_op :690-707
+            const bool same = (ct_tags & 1u) && ct_solid == bytes;
+            if (tid == 0) {
+                cache.tiles[tile] = make_uint2(ct_tags | 1u | (ne << 8), bytes);
+                if (!same) cache.written[tile] = 1;
+            }
+            if (same) return;
+        }
+        if (in_image) *out_px = bytes;
         return;
     }
 
@@ -1060,12 +1104,12 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
             b_flag[tid] = flags[i] | ((uint32_t)(k >> 53) << 16);           // EF_* low, SF_* (blend / fill) high
             b_layer[tid] = (uint32_t)(k >> 32) & LAYER_MASK;
             if (ref & 0x80000000u) {
-                b_cov[tid] = span_cov[ref & 0x7FFFFFFFu]; b_col[tid] = span_col[ref & 0x7FFFFFFFu];
+                b_cov[tid] = span_cov[ref & REF_IDX]; b_col[tid] = span_col[ref & REF_IDX];
                 b_seg0[tid] = 0; b_nseg[tid] = 0;
             } else {
-                const TileRecord* r = &records[ref];
+                const TileRecord* r = &records[ref & REF_IDX];
                 b_cov[tid] = make_uint4(r->cover[0], r->cover[1], r->cover[2], r->cover[3]);
-                b_col[tid] = run_col[ref];
+                b_col[tid] = run_col[ref & REF_IDX];
                 b_seg0[tid] = r->seg_start; b_nseg[tid] = r->seg_count;
             }
         }
@@ -1142,6 +1186,10 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
         for (int c = 0; c < 4; c++) out |= to_u8_x8(sel_channel((P.channels >> (8 * c)) & 0xFFu, sr, sg, sb, da)) << (8 * c);
         *out_px = out;
     }
+    if (cache.tiles && tid == 0) {                                      // update_solid_color(None): painted, not solid
+        cache.tiles[tile] = make_uint2((ct_tags & 2u) | (ne << 8), ct_solid);
+        cache.written[tile] = 1;
+    }
 }
 
 // ================================================================================================
@@ -1178,7 +1226,8 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
                                                     const uint32_t* __restrict__ style_words,
                                                     const forma_image_t* __restrict__ images,
                                                     const uint16_t* __restrict__ texels, uint8_t* __restrict__ image,
-                                                    FrameInfo* __restrict__ info, uint32_t* __restrict__ overflow_n,
+                                                    TileCacheArgs cache, FrameInfo* __restrict__ info,
+                                                    uint32_t* __restrict__ overflow_n,
                                                     uint32_t* __restrict__ overflow_list) {
     __shared__ uint64_t w_key[1][WMAX];
     __shared__ uint64_t w_tmp[1][WMAX];
@@ -1218,9 +1267,9 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
     if (j0 != FORMA_NONE) {
         for (uint32_t c = 0;; c += 64) {                                // a tile's runs are contiguous from j0
             const uint32_t j = j0 + c + lane;
-            bool mine = false; uint32_t layer = 0;
-            if (j < n_runs) { const TileRecord* r = &records[j]; mine = r->tile == my_tile_key; layer = r->layer; }
-            if (mine && c + lane < WMAX) tmp[c + lane] = ((uint64_t)layer << 32) | j;
+            bool mine = false; uint32_t layer = 0, unch = 0;
+            if (j < n_runs) { const TileRecord* r = &records[j]; mine = (r->tile & 0x7FFFFFFFu) == my_tile_key; layer = r->layer; unch = (r->tile >> 31) ? REF_UNCH : 0u; }
+            if (mine && c + lane < WMAX) tmp[c + lane] = ((uint64_t)layer << 32) | unch | j;
             const uint32_t got = (uint32_t)__popcll(__ballot(mine));
             na += got;
             if (got < 64u) break;
@@ -1234,12 +1283,12 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const uint32_t lo = (uint32_t)(sk[u] >> 16) & 0xFFFFu, hi = (uint32_t)sk[u] & 0xFFFFu;       // padding: lo = hi = 0
+            const uint32_t lo = (uint32_t)(sk[u] >> 16) & 0x7FFFu, hi = (uint32_t)sk[u] & 0xFFFFu;       // padding: lo = hi = 0
             const bool hit = tx >= lo && tx < hi;
             const uint64_t bal = __ballot(hit);
             if (hit) {
                 const uint32_t pos = na + nb + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                if (pos < WMAX) tmp[pos] = (sk[u] & 0xFFFFFFFF00000000ull) | 0x80000000u | (sb + c + u * 64 + lane);
+                if (pos < WMAX) tmp[pos] = (sk[u] & 0xFFFFFFFF00000000ull) | REF_SPAN | (((uint32_t)sk[u] >> 31) ? REF_UNCH : 0u) | (sb + c + u * 64 + lane);
             }
             nb += (uint32_t)__popcll(bal);
         }
@@ -1278,6 +1327,25 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
     wave_lds_sync();
 
     const Col clear = {P.clear[0], P.clear[1], P.clear[2], P.clear[3]};
+    // ---- buffer-layer cache: tile_unchanged_pass (passes/tile_unchanged.rs), the first pass ------------------------------
+    bool layers_were_removed = true;                                    // PassesSharedState default
+    uint32_t ct_tags = 0, ct_solid = 0;
+    if (cache.tiles) {
+        const uint2 ct = cache.tiles[tile];
+        ct_solid = ct.y;
+        int all_unch = 1;
+        for (uint32_t i = lane; i < ne; i += 64) if (!((uint32_t)keys[i] & REF_UNCH)) all_unch = 0;
+        all_unch = __all(all_unch);
+        const bool had = (ct.x & 2u) != 0;
+        const uint32_t prev = ct.x >> 8;
+        ct_tags = (ct.x & 1u) | 2u;                                     // update_layer_count(Some(layers))
+        bool tile_unchanged = false;
+        if (had) { layers_were_removed = ne < prev; tile_unchanged = prev == ne && all_unch; }
+        if (P.clear_unchanged && tile_unchanged) {                      // TileWriteOp::None: the buffer keeps last frame's pixels
+            if (lane == 0) cache.tiles[tile] = make_uint2(ct_tags | (ne << 8), ct_solid);
+            return;
+        }
+    }
     // ---- optimizer passes (layer_workbench/passes/*.rs) -------------------------------------------------------------
     if (P.scene_has_clips) {                                            // skip_trivial_clips_pass: serial (clip state machine)
         if (lane == 0) {
@@ -1313,6 +1381,14 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
     top = wave_max_u32(top); blk = wave_max_u32(blk);
     const uint32_t skipped = top ? top - 1u : 0u;
     const int first = top ? (blk > top ? 2 : 1) : (blk ? 2 : 0);
+    if (cache.tiles && first == 1 && !layers_were_removed) {            // all visible layers unchanged: nothing to draw
+        int vis = 1;                                                    // (skip_fully_covered_layers.rs:41-47, 88-91)
+        for (uint32_t i = skipped + lane; i < ne; i += 64) if ((flags[i] & EF_MASK) && !((uint32_t)keys[i] & REF_UNCH)) vis = 0;
+        if (__all(vis)) {
+            if (lane == 0) cache.tiles[tile] = make_uint2(ct_tags | (ne << 8), ct_solid);
+            return;
+        }
+    }
 
     uint4* b_cov = w_cov[wv]; uint4* b_col = w_col[wv];
     uint32_t* b_seg0 = w_seg0[wv]; uint32_t* b_nseg = w_nseg[wv]; uint32_t* b_flag = w_bflag[wv]; uint32_t* b_layer = w_blayer[wv];
@@ -1324,7 +1400,7 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
             wave_lds_sync();
             if ((uint32_t)lane < nbt) {
                 const uint32_t ref = (uint32_t)keys[k0 + lane];
-                b_col[lane] = (ref & 0x80000000u) ? span_col[ref & 0x7FFFFFFFu] : run_col[ref];
+                b_col[lane] = (ref & 0x80000000u) ? span_col[ref & REF_IDX] : run_col[ref & REF_IDX];
             }
             wave_lds_sync();
             for (uint32_t t = 0; t < nbt && ok; t++) {                 // every lane folds the same (uniform) values
@@ -1343,6 +1419,14 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
             for (int c = 0; c < 4; c++) sel[c] = sel_channel((P.channels >> (8 * c)) & 0xFFu, dst.r, dst.g, dst.b, dst.a);
             const uint32_t bytes = to_u8_x4(linear_to_srgb(sel[0])) | (to_u8_x4(linear_to_srgb(sel[1])) << 8) |
                                    (to_u8_x4(linear_to_srgb(sel[2])) << 16) | (to_u8_x4(sel[3]) << 24);
+            if (cache.tiles) {                                          // CachedTile::convert_optimizer_op :690-707
+                const bool same = (ct_tags & 1u) && ct_solid == bytes;
+                if (lane == 0) {
+                    cache.tiles[tile] = make_uint2(ct_tags | 1u | (ne << 8), bytes);
+                    if (!same) cache.written[tile] = 1;
+                }
+                if (same) return;                                       // same solid colour as last frame: TileWriteOp::None
+            }
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 const uint32_t py = ty * 16u + (uint32_t)(rg * 4 + q);
@@ -1383,12 +1467,12 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
             b_flag[lane] = flags[i] | ((uint32_t)(k >> 53) << 16);
             b_layer[lane] = (uint32_t)(k >> 32) & LAYER_MASK;
             if (ref & 0x80000000u) {
-                b_cov[lane] = span_cov[ref & 0x7FFFFFFFu]; b_col[lane] = span_col[ref & 0x7FFFFFFFu];
+                b_cov[lane] = span_cov[ref & REF_IDX]; b_col[lane] = span_col[ref & REF_IDX];
                 b_seg0[lane] = 0; b_nseg[lane] = 0;
             } else {
-                const TileRecord* r = &records[ref];
+                const TileRecord* r = &records[ref & REF_IDX];
                 b_cov[lane] = make_uint4(r->cover[0], r->cover[1], r->cover[2], r->cover[3]);
-                b_col[lane] = run_col[ref];
+                b_col[lane] = run_col[ref & REF_IDX];
                 b_seg0[lane] = r->seg_start; b_nseg[lane] = r->seg_count;
             }
         }
@@ -1480,17 +1564,21 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
             ((uint32_t*)image)[(size_t)py * P.stride_px + px] = out;
         }
     }
+    if (cache.tiles && lane == 0) {                                     // update_solid_color(None): painted, not solid
+        cache.tiles[tile] = make_uint2((ct_tags & 2u) | (ne << 8), ct_solid);
+        cache.written[tile] = 1;
+    }
 }
 
 #define PAINT_ARGS P, tile, sorted, records, n_runs, tile_first_run, row_span_lo, row_span_cnt, span_key, span_cov, run_col, span_col, \
-                   style_offsets, style_words, images, texels, image, info
+                   style_offsets, style_words, images, texels, image, cache, info
 #define PAINT_PARAMS PaintParams P, const uint64_t* __restrict__ sorted, const TileRecord* __restrict__ records, DevCount nc_runs, \
                      const uint32_t* __restrict__ tile_first_run, const uint32_t* __restrict__ row_span_lo, \
                      const uint32_t* __restrict__ row_span_cnt, const uint64_t* __restrict__ span_key, \
                      const uint4* __restrict__ span_cov, const uint4* __restrict__ run_col, const uint4* __restrict__ span_col, \
                      const uint32_t* __restrict__ style_offsets, const uint32_t* __restrict__ style_words, \
                      const forma_image_t* __restrict__ images, const uint16_t* __restrict__ texels, uint8_t* __restrict__ image, \
-                     FrameInfo* __restrict__ info
+                     TileCacheArgs cache, FrameInfo* __restrict__ info
 
 #define PAINT_MAXE_DEEP 4096
 // the rare deep tiles the first launch could not hold
@@ -1510,7 +1598,8 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
                   const uint32_t* tile_first_run, const uint32_t* row_span_lo, const uint32_t* row_span_cnt,
                   const uint64_t* span_key, const uint4* span_cov, const uint4* run_col, const uint4* span_col,
                   const uint32_t* style_offsets, const uint32_t* style_words, const forma_image_t* images,
-                  const uint16_t* texels, uint8_t* image, FrameInfo* info, uint32_t* overflow_n, uint32_t* overflow_list,
+                  const uint16_t* texels, uint8_t* image, TileCacheArgs cache, FrameInfo* info, uint32_t* overflow_n,
+                  uint32_t* overflow_list,
                   unsigned long long* prof) {
     const uint32_t T = p.tiles_w * p.tiles_h;
     if (T == 0 || p.crop_y1 <= p.crop_y0) return;
@@ -1518,8 +1607,8 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
     (void)prof;
     hipLaunchKernelGGL(k_paint_wave, dim3(per * 8), dim3(64), 0, s, p, sorted, records, n_runs, tile_first_run, row_span_lo,
                        row_span_cnt, span_key, span_cov, run_col, span_col, style_offsets, style_words, images, texels, image,
-                       info, overflow_n, overflow_list);
+                       cache, info, overflow_n, overflow_list);
     hipLaunchKernelGGL(k_paint_deep, dim3(T < 256 ? T : 256), dim3(256), 0, s, p, sorted, records, n_runs, tile_first_run,
                        row_span_lo, row_span_cnt, span_key, span_cov, run_col, span_col, style_offsets, style_words, images,
-                       texels, image, info, (const uint32_t*)overflow_n, (const uint32_t*)overflow_list);
+                       texels, image, cache, info, (const uint32_t*)overflow_n, (const uint32_t*)overflow_list);
 }

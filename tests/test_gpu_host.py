@@ -147,3 +147,42 @@ def test_layer_bookkeeping_like_reference():
         api.Order((1 << 21))
     with pytest.raises(api.GeomPresTransformError):
         api.GeomPresTransform.try_from([2.0, 0.0, 0.0, 1.0, 0.0, 0.0])
+
+
+def test_buffer_layer_cache_through_the_product_api():
+    """Reference composition/mod.rs `render_changed_layers_only` and the BufferLayerCache doc test (buffer/mod.rs:125-165):
+    with a cache attached, a frame in which nothing changed leaves the caller's buffer untouched; changing one layer
+    repaints only the tiles it touches."""
+    from forma_amd import api
+    def rect(x0, y0, x1, y1):
+        return (api.PathBuilder().move_to(api.Point(x0, y0)).line_to(api.Point(x0, y1)).line_to(api.Point(x1, y1))
+                .line_to(api.Point(x1, y0)).line_to(api.Point(x0, y0)).build())
+    def solid(c):
+        return api.Props(func=api.Func.Draw(api.Style(fill=api.Fill.Solid(c))))
+    W, H = 48, 32                                                         # 3 x 2 tiles
+    comp = api.Composition()
+    comp.get_mut_or_insert_default(api.Order(0)).insert(rect(2, 2, 10, 10)).set_props(solid(api.Color(1, 0, 0, 1)))     # tile (0,0)
+    comp.get_mut_or_insert_default(api.Order(1)).insert(rect(34, 18, 44, 28)).set_props(solid(api.Color(0, 1, 0, 1)))   # tile (2,1)
+    r = api.Renderer(0)
+    cache = r.create_buffer_layer_cache()
+    assert cache is not None
+    lay = api.LinearLayout(W, W * 4, H)
+    img = np.zeros(W * H * 4, np.uint8)
+    white = api.Color(1, 1, 1, 1)
+    r.render(comp, api.BufferBuilder(img, lay).layer_cache(cache).build(), api.RGBA, white, None)
+    px = img.reshape(H, W, 4)
+    assert tuple(px[5, 5]) == (255, 0, 0, 255) and tuple(px[20, 40]) == (0, 255, 0, 255) and tuple(px[20, 5]) == (255, 255, 255, 255)
+    # frame 2: nothing changed, buffer wiped by the caller -> stays wiped
+    img[:] = 0
+    r.render(comp, api.BufferBuilder(img, lay).layer_cache(cache).build(), api.RGBA, white, None)
+    assert not img.any()
+    # frame 3: only layer 1 changes colour -> only tile (2,1) is rewritten
+    comp.get_mut_or_insert_default(api.Order(1)).set_props(solid(api.Color(0, 0, 1, 1)))
+    r.render(comp, api.BufferBuilder(img, lay).layer_cache(cache).build(), api.RGBA, white, None)
+    px = img.reshape(H, W, 4)
+    assert tuple(px[20, 40]) == (0, 0, 255, 255)
+    assert not px[:16].any() and not px[16:, :32].any()                   # the other five tiles were left alone
+    # cache.clear(): everything is drawn again
+    cache.clear()
+    r.render(comp, api.BufferBuilder(img, lay).layer_cache(cache).build(), api.RGBA, white, None)
+    assert tuple(px[5, 5]) == (255, 0, 0, 255) and tuple(px[20, 5]) == (255, 255, 255, 255)
