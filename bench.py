@@ -126,9 +126,19 @@ def main():
     pass_us = stage["sort_pass_us"]
     algo_bytes_per_pass = 16.0 * n_local                       # 8 B read + 8 B written per key per digit pass
     achieved = (algo_bytes_per_pass / (pass_us * 1e-6) / 1e9) if pass_us > 0 else 0.0
+    # HBM bytes per launch from the PMC counters (collected in separate rocprofv3 passes and corrected as the MI355X guide
+    # prescribes; bench.py cannot run under two profilers at once, so the committed summary of the same command is read)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        if args.workload == "paris-like-30k-4k" and world == 1:
+            traffic = pmc["kernels"][pmc["roofline_kernel"]]["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
     roofline = {"bound": "hbm", "kernel": "k_onesweep: one radix digit pass (LSB, 8-bit digits over live key bits, u64 keys, chained scan)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": algo_bytes_per_pass, "avg_launch_us": round(pass_us, 2),
                 "passes": passes}
 
