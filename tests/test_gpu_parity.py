@@ -246,3 +246,73 @@ def test_tile_row_bands_stitch_to_the_full_frame(ctx, mixed):
     ctx.set_band(0, 0)
     assert np.abs(full.astype(int) - full_o.astype(int)).max() <= 1
     assert n_full == len(o.segments(0))
+
+
+@pytest.mark.parametrize("size", [(1, 1), (16, 16), (17, 15), (3840, 16), (16, 2160), (33, 1000)])
+def test_odd_canvas_shapes(ctx, mixed, size):
+    """Single-tile, single-row, single-column and ragged canvases (partial edge tiles, cpu/buffer/layout/mod.rs:264-295)."""
+    w, h = size
+    o, _ = both(ctx, mixed)
+    a = o.render(w, h, clear=(0.5, 0.5, 0.5, 1.0)); b = ctx.render(w, h, clear=(0.5, 0.5, 0.5, 1.0))
+    assert np.array_equal(ctx.segments(0), o.segments(0))
+    assert np.array_equal(ctx.segments(1), o.segments(1))
+    assert np.abs(a.astype(int) - b.astype(int)).max() <= 1
+
+
+def test_layer_limit_and_far_away_geometry(ctx):
+    """Order = LAYER_LIMIT (2^21 - 1, consts.rs:107-109) uses every layer bit of the key; geometry far left of the canvas
+    collapses into the tile_x = -1 bucket (pixel_segment.rs:47-52) and still feeds the carry; geometry far above /
+    below / right is culled or parked."""
+    LIMIT = (1 << 21) - 1
+    comp = S.Composition()
+    comp.get_mut_or_insert_default(0).insert(S.custom_square(-3000.0, 10.0, 60.0, 50.0)).set_props(S.solid((1, 0, 0, 0.5)))        # 3000 px left
+    comp.get_mut_or_insert_default(7).insert(S.custom_square(20.0, -5000.0, 90.0, 5000.0)).set_props(S.solid((0, 1, 0, 0.5)))      # tall
+    comp.get_mut_or_insert_default(9).insert(S.custom_square(500.0, 500.0, 900.0, 900.0)).set_props(S.solid((0, 0, 1, 1)))         # off canvas
+    comp.get_mut_or_insert_default(LIMIT).insert(S.custom_circle(64.0, 64.0, 50.0)).set_props(S.solid((0, 0, 1, 0.5)))
+    o, _ = both(ctx, comp)
+    a = o.render(128, 128, clear=(1, 1, 1, 1)); b = ctx.render(128, 128, clear=(1, 1, 1, 1))
+    u = ctx.segments(0)
+    assert np.array_equal(u, o.segments(0)) and np.array_equal(ctx.segments(1), o.segments(1))
+    assert ((u >> np.uint64(20)) & np.uint64(0x1FFFFF)).max() == LIMIT
+    assert (((u >> np.uint64(41)) & np.uint64(0xFFF)) == 0).any()          # the left-of-canvas bucket is populated
+    assert np.array_equal(a, b)
+
+
+def test_argument_validation(ctx):
+    """The C ABI returns FORMA_E_ARG where the reference asserts / panics (consts.rs:25-26, layout/mod.rs:188-193)."""
+    from forma_amd._lib import FormaError
+    with pytest.raises(FormaError):
+        ctx.render(65537, 16)
+    with pytest.raises(FormaError):
+        ctx.render(16, 32769)
+    with pytest.raises(FormaError):
+        ctx.render(64, 64, dst=np.zeros((64, 64 * 4), np.uint8), stride=63 * 4)
+    with pytest.raises(FormaError):
+        ctx.render(64, 64, channels=(0, 1, 2, 9))
+    g = np.zeros(1, orc.GEOM_DTYPE); g[0]["order"] = 1 << 21
+    with pytest.raises(FormaError):
+        ctx.set_geoms(g)
+
+
+def test_triangles_10m_8k(ctx):
+    """BASELINE.json configs[3] at full size: ~10 M pixel segments on 8192 x 8192 — sorted stream bit-exact, image within
+    1 code value, plus the size-independent properties (permutation, non-decreasing keys)."""
+    comp = S.Composition()
+    rng = np.random.default_rng(4)
+    for i in range(19400):
+        ox, oy = rng.uniform(0, 8192 - 256), rng.uniform(0, 8192 - 256)
+        p = (rng.random((3, 2)) * 256 + np.array([ox, oy])).astype(np.float32)
+        comp.get_mut_or_insert_default(i).insert(S.P().move_to(float(p[0, 0]), float(p[0, 1])).line_to(float(p[1, 0]), float(p[1, 1]))
+                                                 .line_to(float(p[2, 0]), float(p[2, 1])).build()) \
+            .set_props(S.solid((float(rng.random()), float(rng.random()), float(rng.random()), 1.0)))
+    o, _ = both(ctx, comp)
+    a = o.render(8192, 8192, clear=(1, 1, 1, 1))
+    b, t = ctx.render(8192, 8192, clear=(1, 1, 1, 1), timings=True)
+    s = ctx.segments(1)
+    assert 9_000_000 < len(s) < 11_000_000 and t["n_segments"] == len(s)
+    assert np.array_equal(np.sort(ctx.segments(0)), np.sort(s))            # permutation of the rasterizer's stream
+    k = s >> np.uint64(20)
+    assert (k[1:] >= k[:-1]).all()
+    assert np.array_equal(s, o.segments(1))
+    d = np.abs(a.astype(np.int16) - b.astype(np.int16))
+    assert d.max() <= 1
