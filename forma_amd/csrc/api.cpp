@@ -79,7 +79,6 @@ struct forma_hip_ctx {
     bool pred_counts_valid = false, no_async = false;    // N / J predictions for read-back-free frames (FORMA_HIP_SYNC=1 disables)
     uint32_t pred_N = 0, pred_J = 0, pred_w = 0, pred_h = 0;
     uint64_t pred_live44 = 0;
-    DevBuf prof;                            // FORMA_HIP_PROF=1: per-phase shader-clock sums of the painter (diagnostics)
     DevBuf info, records, run_cov, rk_u, rk_a, rk_b, blk_edge, runs_scratch, row_tab, span_key, span_cov, run_col, span_col, image;
     uint32_t img_w = 0, img_h = 0;
     FrameInfo* h_info = nullptr;            // pinned
@@ -374,7 +373,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                  row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(), ctx->run_col.as<uint4>(),
                  ctx->span_col.as<uint4>(), ctx->style_off.as<uint32_t>(),
                  ctx->style_words.as<uint32_t>(), ctx->images.as<forma_image_t>(), ctx->texels.as<uint16_t>(),
-                 ctx->cur_image, tc, dinfo, paint_overflow, overflow_list, ctx->prof.p ? ctx->prof.as<unsigned long long>() : nullptr);
+                 ctx->cur_image, tc, dinfo, paint_overflow, overflow_list);
     stage_end(ctx, ST_PAINT, timing);
     HIPCHECK(hipGetLastError());
     return FORMA_OK;
@@ -504,7 +503,6 @@ int forma_hip_create(forma_hip_ctx** out, int device) {
     if (!ctx) return FORMA_E_INTERNAL;
     ctx->device = device;
     if (const char* e = getenv("FORMA_HIP_DIGIT_BITS")) { if (atoi(e) == 4) ctx->digit_bits = 4; }
-    const bool want_prof = getenv("FORMA_HIP_PROF") != nullptr;
     ctx->no_async = getenv("FORMA_HIP_SYNC") != nullptr;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx; return FORMA_E_HIP;
@@ -524,7 +522,6 @@ int forma_hip_create(forma_hip_ctx** out, int device) {
     for (int p = 0; p < MAX_PASS_EVENTS && ok; p++)
         ok = hipEventCreate(&ctx->pev0[p]) == hipSuccess && hipEventCreate(&ctx->pev1[p]) == hipSuccess;
     if (!ok) { delete ctx; return FORMA_E_HIP; }
-    if (want_prof && ctx->prof.ensure(64 * 8) == hipSuccess) (void)hipMemset(ctx->prof.p, 0, 64 * 8);
     // empty-scene defaults so that a render before any upload is well defined
     ctx->style_off.ensure(4); ctx->style_words.ensure(4); ctx->geoms.ensure(sizeof(forma_geom_t));
     ctx->images.ensure(sizeof(forma_image_t)); ctx->texels.ensure(8);
@@ -537,15 +534,6 @@ void forma_hip_destroy(forma_hip_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->prof.p) {
-        unsigned long long h[64];
-        if (hipMemcpy(h, ctx->prof.p, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[8]) {
-            fprintf(stderr, "[forma_hip prof] painter tiles=%llu  avg cycles/tile: runs=%llu spans=%llu merge=%llu facts=%llu passes=%llu list+preload=%llu layers=%llu | avg ne=%.1f painted=%.1f segs=%.1f row_spans=%.0f\n",
-                    h[8], h[0] / h[8], h[1] / h[8], h[2] / h[8], h[3] / h[8], h[4] / h[8], h[5] / h[8], h[6] / h[8],
-                    (double)h[9] / h[8], (double)h[10] / h[8], (double)h[11] / h[8], (double)h[12] / h[8]);
-        }
-        ctx->prof.release();
-    }
     DevBuf* all[] = {&ctx->x, &ctx->y, &ctx->line_slot, &ctx->geoms, &ctx->style_off, &ctx->style_words, &ctx->unchanged,
                      &ctx->images, &ctx->texels, &ctx->l_order, &ctx->l_x0, &ctx->l_y0, &ctx->l_dx, &ctx->l_dy, &ctx->l_a,
                      &ctx->l_b, &ctx->l_c, &ctx->l_d, &ctx->l_len, &ctx->scan_tmp, &ctx->cl_idx, &ctx->cl_start,

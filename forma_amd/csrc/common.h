@@ -122,8 +122,6 @@ void launch_block_first(hipStream_t s, const uint32_t* cl_start, uint32_t n_comp
 void launch_rasterize(hipStream_t s, const LineSource& src, DevCount n_compact, DevCount n_segments,
                       const uint32_t* cl_idx, const uint32_t* cl_start, const uint32_t* block_first, uint64_t* out,
                       FrameInfo* info, int band_row0, int band_row1);
-// asynchronous frames: compare the key masks the rasterizer reduced with the ones the sort plan was built from
-void launch_verify_plan(hipStream_t s, FrameInfo* info, uint64_t live44, bool layer_sorted);
 void launch_flatten(hipStream_t s, const forma_flatten_tables_t* dev_tables, float* out_x, float* out_y);
 
 // sort.hip — stable LSB radix sort of u64 (chained-scan "onesweep" passes over the live key bits).
@@ -167,5 +165,4 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
                   const uint64_t* span_key, const uint4* span_cov, const uint4* run_col, const uint4* span_col,
                   const uint32_t* style_offsets, const uint32_t* style_words, const forma_image_t* images,
                   const uint16_t* texels, uint8_t* image, TileCacheArgs cache, FrameInfo* info, uint32_t* overflow_n /* zeroed by launch_runs */,
-                  uint32_t* overflow_list /* tiles_w * tiles_h words */,
-                  unsigned long long* prof /* nullable: per-phase shader-clock sums (diagnostics) */);
+                  uint32_t* overflow_list /* tiles_w * tiles_h words */);

@@ -516,19 +516,6 @@ __global__ __launch_bounds__(RAS_THREADS) void k_rasterize(LineSource S, DevCoun
     }
 }
 
-__global__ void k_verify_plan(FrameInfo* __restrict__ info, uint64_t live44, uint32_t layer_sorted) {
-    if (threadIdx.x) return;
-    if (info->n_segments == 0) return;                                  // nothing was rasterized: nothing to sort
-    const uint64_t k_or = (uint64_t)info->key_or | ((uint64_t)info->key_or_hi << 32);
-    const uint64_t k_and = (uint64_t)info->key_and | ((uint64_t)info->key_and_hi << 32);
-    const uint64_t live = (k_or ^ k_and) & 0xFFFFFFFFFFFull;
-    const uint32_t sorted = info->layer_unsorted == 0 ? 1u : 0u;
-    if (live != live44 || sorted != layer_sorted) info->plan_bad = 1u;
-}
-void launch_verify_plan(hipStream_t s, FrameInfo* info, uint64_t live44, bool layer_sorted) {
-    hipLaunchKernelGGL(k_verify_plan, dim3(1), dim3(64), 0, s, info, live44, layer_sorted ? 1u : 0u);
-}
-
 void launch_rasterize(hipStream_t s, const LineSource& src, DevCount n_compact, DevCount n_segments,
                       const uint32_t* cl_idx, const uint32_t* cl_start, const uint32_t* block_first, uint64_t* out,
                       FrameInfo* info, int band_row0, int band_row1) {

@@ -517,7 +517,6 @@ void launch_carry_rows(hipStream_t s, const uint64_t* sorted_run_keys, TileRecor
 #define EF_MASK      0x080u     // still enabled after the optimizer passes
 #define EF_SKIPCLIP  0x100u     // passes_shared_state.skip_clipping contains this id
 #define EF_EVENODD   0x200u
-#define EF_BAD       0x400u
 
 __device__ __forceinline__ float avx_min(float a, float b) { return a < b ? a : b; }   // _mm256_min_ps semantics
 __device__ __forceinline__ float avx_max(float a, float b) { return a > b ? a : b; }
@@ -803,10 +802,7 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
                                            const uint32_t* __restrict__ style_words,
                                            const forma_image_t* __restrict__ images,
                                            const uint16_t* __restrict__ texels, uint8_t* __restrict__ image,
-                                           TileCacheArgs cache, FrameInfo* __restrict__ info, uint32_t* __restrict__ overflow,
-                                           unsigned long long* __restrict__ prof) {
-#define PROF_MARK(k) do { if (prof && tid == 0 && (tile & 63u) == 0) { const unsigned long long _t = __builtin_amdgcn_s_memtime(); \
-                                                    atomicAdd(&prof[k], _t - t_prev); t_prev = _t; } } while (0)
+                                           TileCacheArgs cache, FrameInfo* __restrict__ info, uint32_t* __restrict__ overflow) {
     constexpr int STAGE = MAXE / 4;           // span hits one wave may stage
     __shared__ uint64_t e_key[MAXE];          // staging for the span scan (4 x STAGE), then the merged layer list
     __shared__ uint64_t e_tmp[MAXE];          // [0, na) own runs, [na, ne) crossing spans; later the list of painted entries
@@ -824,7 +820,6 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
     const int tid = threadIdx.x;
     const int lx = tid & 15, ly = tid >> 4;
     const int lane = tid & 63, wv = tid >> 6;
-    unsigned long long t_prev = prof ? __builtin_amdgcn_s_memtime() : 0ull;
 
     // ---- this tile's layer list (LayerWorkbench::populate_layers, layer_workbench/mod.rs:250-278):
     //      its own runs (contiguous records, ascending layer) merged with the row's spans that cross it.
@@ -862,7 +857,6 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
             if (got < 256u) break;
         }
     }
-    PROF_MARK(0);
     // ---- the tile's own segments, once (they are contiguous in the sorted stream); the loads fly during the span scan
     const uint32_t seg0 = s_seg0, seg1 = s_seg1;
     uint64_t tsv[TSEG_CAP / 256];
@@ -901,7 +895,6 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
         else for (uint32_t i = lane; i < cw; i += 64) if (base + i < MAXE) e_tmp[base + i] = e_key[wv * STAGE + i];
         __syncthreads();
     }
-    PROF_MARK(1);
     const uint32_t ne = na + nb;
     uint64_t* keys = e_key;
     uint32_t* flags = e_flag;
@@ -924,7 +917,6 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
         keys[rank] = k;
     }
     __syncthreads();
-    PROF_MARK(2);
     // ---- per-entry facts the optimizer passes need: decoded from the SF_* bits the carry pre-pass put in the keys ----
     for (uint32_t i = tid; i < ne; i += 256) {
         const uint64_t k = keys[i];
@@ -944,7 +936,6 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
     }
     __syncthreads();
 
-    PROF_MARK(3);
     const Col clear = {P.clear[0], P.clear[1], P.clear[2], P.clear[3]};
     // ---- buffer-layer cache: tile_unchanged_pass (passes/tile_unchanged.rs), the first pass ------------------------------
     bool layers_were_removed = true;                                    // PassesSharedState default
@@ -1048,7 +1039,6 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
     }
     __syncthreads();
 
-    PROF_MARK(4);
     const uint32_t px = tx * 16u + (uint32_t)lx, py = ty * 16u + (uint32_t)ly;
     const bool in_image = px < P.width && py < P.height;
     uint32_t* out_px = (uint32_t*)image + (size_t)py * P.stride_px + px;
@@ -1071,7 +1061,7 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
     uint32_t np = 0;
     for (uint32_t c = 0; c < ne; c += 256) {
         const uint32_t i = c + tid;
-        const bool keep = i >= skipped && i < ne && (flags[i] & EF_MASK) && !(flags[i] & EF_BAD);
+        const bool keep = i >= skipped && i < ne && (flags[i] & EF_MASK);
         const uint64_t bal = __ballot(keep);
         if (lane == 0) s_wcnt[wv] = (uint32_t)__popcll(bal);
         __syncthreads();
@@ -1084,9 +1074,6 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
     }
     cells[0][tid] = 0; cells[1][tid] = 0;
 
-    PROF_MARK(5);
-    if (prof && tid == 0 && (tile & 63u) == 0) { atomicAdd(&prof[8], 1ull); atomicAdd(&prof[9], (unsigned long long)ne); atomicAdd(&prof[10], (unsigned long long)np);
-                            atomicAdd(&prof[11], (unsigned long long)(seg1 - seg0)); atomicAdd(&prof[12], (unsigned long long)row_span_cnt[ty]); }
     // ---- paint (Painter::paint_layer, painter/mod.rs:290-347, one lane per pixel) --------------------------
     float dr = clear.r, dg = clear.g, db = clear.b, da = clear.a;          // Painter::clear :277-288
     bool clip_valid = false; uint32_t clip_last = 0; float clip_mask = 0.0f;
@@ -1177,7 +1164,6 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
             da = fmaf(da, isa, src_a);
         }
     }
-    PROF_MARK(6);
     // ---- compute_srgb :466-483 + channel select, straight to the row-major RGBA8 image ----------------------
     if (in_image) {
         float sr = linear_to_srgb(dr), sg = linear_to_srgb(dg), sb = linear_to_srgb(db);
@@ -1589,7 +1575,7 @@ __global__ __launch_bounds__(256) void k_paint_deep(PAINT_PARAMS, const uint32_t
     const uint32_t n_runs = dev_count(nc_runs);
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
         const uint32_t tile = overflow_list[i];
-        paint_tile<PAINT_MAXE_DEEP>(PAINT_ARGS, nullptr, nullptr);
+        paint_tile<PAINT_MAXE_DEEP>(PAINT_ARGS, nullptr);
         __syncthreads();
     }
 }
@@ -1599,12 +1585,10 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
                   const uint64_t* span_key, const uint4* span_cov, const uint4* run_col, const uint4* span_col,
                   const uint32_t* style_offsets, const uint32_t* style_words, const forma_image_t* images,
                   const uint16_t* texels, uint8_t* image, TileCacheArgs cache, FrameInfo* info, uint32_t* overflow_n,
-                  uint32_t* overflow_list,
-                  unsigned long long* prof) {
+                  uint32_t* overflow_list) {
     const uint32_t T = p.tiles_w * p.tiles_h;
     if (T == 0 || p.crop_y1 <= p.crop_y0) return;
     const uint32_t per = ((p.crop_y1 - p.crop_y0) * p.tiles_w + 7) / 8;
-    (void)prof;
     hipLaunchKernelGGL(k_paint_wave, dim3(per * 8), dim3(64), 0, s, p, sorted, records, n_runs, tile_first_run, row_span_lo,
                        row_span_cnt, span_key, span_cov, run_col, span_col, style_offsets, style_words, images, texels, image,
                        cache, info, overflow_n, overflow_list);

@@ -195,8 +195,10 @@ int forma_hip_paint(forma_hip_ctx* ctx, const uint64_t* sorted_segments, size_t 
 
 /* ---- the frame: cpu::Renderer::render (renderer.rs:75-224) ---------------------------------- */
 /* dst == NULL leaves the image device-resident (read it with forma_hip_read_image).
- * cache_id >= 0 selects one of 32 buffer-layer caches (renderer.rs:68-73, buffer/mod.rs:113-197)
- * and enables the tile_unchanged pass; -1 = no cache.  `timings` may be NULL.                   */
+ * cache_id >= 0 selects one of 32 buffer-layer caches (renderer.rs:68-73, buffer/mod.rs:113-197): the
+ * device keeps the per-tile CachedTile state, the cached clear colour and the image the cache's
+ * buffer shows; tiles the optimizer passes skip (TileWriteOp::None) are NOT written into `dst`.
+ * -1 = no cache.  Only the crop rectangle (tile-rounded) is ever written.  `timings` may be NULL.  */
 int forma_hip_render(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t height,
                      size_t stride_bytes, const uint8_t channels[4],
                      const float clear_color[4], const forma_rect_t* crop_or_null,
