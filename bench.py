@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--mode", default="frames", choices=["frames", "bands"],
                     help="N > 1: 'frames' = every GPU renders whole frames (weak scaling, no exchange); "
                          "'bands' = ONE frame split into tile-row bands across the GPUs (strong scaling)")
+    ap.add_argument("--animated", action="store_true",
+                    help="also measure BASELINE config 5: the animated spaceship-like 4K scene, with and without the "
+                         "buffer-layer cache (per-tile damage tracking); reported under \"animated\", never as `value`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -170,12 +173,50 @@ def main():
         "roofline": roofline,
     }
 
+    if rank == 0 and world == 1 and args.animated:
+        out["animated"] = animated_leg(local)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(renderer, width, height, args.cpu_seconds)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def animated_leg(local, frames=240):
+    """BASELINE config 5 on one GPU: 3840x2160, 400 static + 121 moving layers, 60 Hz animation.  Every frame uploads the
+    layer table (transforms) and the per-order `unchanged` bytes exactly like `Renderer::render` would, then renders
+    device-resident with cache 0 (damage tracking) or without a cache (everything repainted)."""
+    import torch
+    from forma_amd import api, scenes
+    comp, moving, state = scenes.spaceship()
+    renderer = api.Renderer(device=local)
+    W, H = state["size"]
+    img = np.zeros(W * H * 4, np.uint8)
+    renderer.render(comp, api.BufferBuilder(img, api.LinearLayout(W, W * 4, H)).build(), api.RGBA, api.Color(0, 0, 0, 1), None)
+    ctx = renderer._ctx
+    t = renderer.host_tables
+    geoms = t["geoms"].copy()
+    slot_of_order = {int(geoms[i]["order"]): i for i in range(len(geoms)) if geoms[i]["order"] != 0xFFFFFFFF}
+    slots = np.array([slot_of_order[o] for o in moving])
+    unchanged = np.ones(len(t["style_offsets"]), np.uint8)
+    unchanged[np.array(moving)] = 0
+    res = {}
+    for label, cache_id, unch in (("no_cache", -1, None), ("with_cache", 0, unchanged)):
+        painted = []
+        for i in range(frames + 10):
+            if i == 10:
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+            geoms["flags"][slots] = 1
+            geoms["xf"][slots] = scenes.spaceship_transforms(state, i / 60.0)
+            ctx.set_geoms(geoms)
+            ctx.set_styles(t["style_offsets"], t["style_words"], unch if i > 0 else None)
+            ctx.render(W, H, clear=(0, 0, 0, 1), cache_id=cache_id, device_only=True)
+        torch.cuda.synchronize()
+        res[label] = round(frames / (time.perf_counter() - t0), 1)
+    return {"workload": "spaceship-like-4k (400 static + 121 moving layers, 60 Hz transforms)", "frames": frames,
+            "fps_no_cache": res["no_cache"], "fps_with_cache": res["with_cache"], "unit": "frames/s, device-resident, "
+            "including the per-frame layer-table upload"}
 
 
 def cpu_baseline(renderer, width, height, budget_s):

@@ -88,6 +88,62 @@ def triangles_10m(width=8192, height=8192, k=19400, seed=4) -> Composition:
     return comp
 
 
+def spaceship(width=3840, height=2160, enemies=120, stars=400, seed=43):
+    """Animated scene in the spirit of the reference's spaceship demo (demo/src/demos/spaceship.rs: `ship_path` :365-417,
+    `potatoe_path` :337-362, actors moved by GeomPresTransform [c, s, -s, c, x, y] :198-201), scaled to a 4K canvas:
+    a static star field and planets, one ship and `enemies` dented circles that drift and spin.  Returns the
+    composition and the orders of the moving layers; `spaceship_transforms(t)` gives their transforms at time t."""
+    rng = np.random.default_rng(seed)
+    comp = Composition()
+    order = 0
+    for _ in range(stars):                                  # static background: small discs and a few big planets
+        big = rng.random() < 0.03
+        r = float(rng.uniform(120, 400) if big else rng.uniform(2, 9))
+        x, y = float(rng.uniform(0, width)), float(rng.uniform(0, height))
+        w = 0.70710678
+        path = (PathBuilder().move_to(Point(x + r, y)).rat_quad_to(Point(x + r, y - r), Point(x, y - r), w)
+                .rat_quad_to(Point(x - r, y - r), Point(x - r, y), w).rat_quad_to(Point(x - r, y + r), Point(x, y + r), w)
+                .rat_quad_to(Point(x + r, y + r), Point(x + r, y), w).build())
+        c = rng.random(3)
+        comp.get_mut_or_insert_default(Order(order)).insert(path).set_props(
+            _solid(Color(float(c[0]) * 0.5, float(c[1]) * 0.5, float(c[2]), 1.0 if big else 0.8)))
+        order += 1
+    moving = []
+    ship = (PathBuilder().move_to(Point(0, 50)).line_to(Point(40, 50)).line_to(Point(40, 60))
+            .cubic_to(Point(47, 56), Point(54, 57), Point(60, 60)).line_to(Point(60, 50)).line_to(Point(80, 50)).line_to(Point(80, 10))
+            .cubic_to(Point(67, -3), Point(50, -13), Point(30, -20)).line_to(Point(25, -51)).line_to(Point(30, -52))
+            .line_to(Point(30, -70)).line_to(Point(21, -74)).cubic_to(Point(17, -90), Point(9, -102), Point(0, -107))
+            .cubic_to(Point(-9, -102), Point(-17, -90), Point(-21, -74)).line_to(Point(-30, -70)).line_to(Point(-30, -52))
+            .line_to(Point(-25, -51)).line_to(Point(-30, -20)).cubic_to(Point(-50, -13), Point(-67, -3), Point(-80, 10))
+            .line_to(Point(-80, 50)).line_to(Point(-60, 50)).line_to(Point(-60, 60))
+            .cubic_to(Point(-54, 57), Point(-47, 56), Point(-40, 60)).line_to(Point(-40, 50)).line_to(Point(0, 50)).build())
+    comp.get_mut_or_insert_default(Order(order)).insert(ship).set_props(_solid(Color(0.9, 0.9, 0.2, 1.0)))
+    moving.append(order); order += 1
+    for _ in range(enemies):
+        r = float(rng.uniform(20, 70))
+        b = PathBuilder().move_to(Point(r, 0.0))
+        for (cx, cy, ex, ey) in ((r, -r, 0.0, -r), (-r, -r, -r, 0.0), (-r, r, 0.0, r), (r, r, r, 0.0)):
+            b.rat_quad_to(Point(cx, cy), Point(ex, ey), float(rng.uniform(0.07, 1.4)))
+        c = rng.random(3)
+        comp.get_mut_or_insert_default(Order(order)).insert(b.build()).set_props(
+            _solid(Color(float(c[0]), float(c[1]) * 0.6, float(c[2]) * 0.4, 1.0)))
+        moving.append(order); order += 1
+    state = dict(pos=rng.uniform([0, 0], [width, height], (len(moving), 2)), vel=rng.uniform(-300, 300, (len(moving), 2)),
+                 ang=rng.uniform(0, 6.28, len(moving)), spin=rng.uniform(-2, 2, len(moving)), size=(width, height))
+    return comp, moving, state
+
+
+def spaceship_transforms(state, t: float) -> np.ndarray:
+    """[ux, uy, vx, vy, tx, ty] per moving layer at time t (seconds): rotation by angle(t), translation to the wrapped
+    position (AffineTransform::to_array order, math/transform.rs:50)."""
+    w, h = state["size"]
+    pos = state["pos"] + state["vel"] * t
+    pos[:, 0] = np.mod(pos[:, 0], w); pos[:, 1] = np.mod(pos[:, 1], h)
+    a = state["ang"] + state["spin"] * t
+    c, s_ = np.cos(a).astype(np.float32), np.sin(a).astype(np.float32)
+    return np.stack([c, s_, -s_, c, pos[:, 0].astype(np.float32), pos[:, 1].astype(np.float32)], axis=1).astype(np.float32)
+
+
 WORKLOADS = {
     "cubics-1080p": (random_cubics, 1920, 1080),
     "paris-like-30k-4k": (paris_like, 3840, 2160),

@@ -186,3 +186,26 @@ def test_buffer_layer_cache_through_the_product_api():
     cache.clear()
     r.render(comp, api.BufferBuilder(img, lay).layer_cache(cache).build(), api.RGBA, white, None)
     assert tuple(px[5, 5]) == (255, 0, 0, 255) and tuple(px[20, 5]) == (255, 255, 255, 255)
+
+
+def test_animated_scene_cached_frames_equal_full_repaints():
+    """BASELINE config 5 (spaceship demo with the per-tile damage optimizer) at a reduced size, through the product API:
+    a buffer carried from frame to frame with a BufferLayerCache must hold, after every frame, exactly the pixels a full
+    repaint of that frame produces (reference demo/src/demos/spaceship.rs + cpu/buffer/layer_cache semantics)."""
+    from forma_amd import api, scenes
+    W, H = 960, 544
+    comp, moving, state = scenes.spaceship(W, H, enemies=24, stars=60, seed=5)
+    r = api.Renderer(0)
+    cache = r.create_buffer_layer_cache()
+    lay = api.LinearLayout(W, W * 4, H)
+    carried = np.zeros(W * H * 4, np.uint8)
+    black = api.Color(0, 0, 0, 1)
+    for f in range(5):
+        xf = scenes.spaceship_transforms(state, f / 60.0)
+        for o, t in zip(moving, xf):
+            comp.get_mut(api.Order(o)).set_transform(api.GeomPresTransform.try_from([float(v) for v in t]))
+        r.render(comp, api.BufferBuilder(carried, lay).layer_cache(cache).build(), api.RGBA, black, None)
+        fresh = np.zeros(W * H * 4, np.uint8)
+        r.render(comp, api.BufferBuilder(fresh, lay).build(), api.RGBA, black, None)
+        assert np.array_equal(carried, fresh), f"frame {f}"
+        assert fresh.reshape(H, W, 4)[..., :3].any()
