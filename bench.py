@@ -38,6 +38,10 @@ def parse():
     ap.add_argument("--mode", default="frames", choices=["frames", "bands"],
                     help="N > 1: 'frames' = every GPU renders whole frames (weak scaling, no exchange); "
                          "'bands' = ONE frame split into tile-row bands across the GPUs (strong scaling)")
+    ap.add_argument("--svg", default=None, metavar="FILE",
+                    help="render this SVG file (e.g. the real paris-30k.svg) on a 3840x2160 canvas instead of a synthetic "
+                         "workload; loaded by forma_amd.svg like the reference demo's `svg` mode")
+    ap.add_argument("--svg-scale", type=float, default=1.0)
     ap.add_argument("--animated", action="store_true",
                     help="also measure BASELINE config 5: the animated spaceship-like 4K scene, with and without the "
                          "buffer-layer cache (per-tile damage tracking); reported under \"animated\", never as `value`")
@@ -65,8 +69,14 @@ def main():
     import forma_amd
     from forma_amd import api, scenes, sharding
 
-    build_fn, width, height = scenes.WORKLOADS[args.workload]
-    comp = build_fn()
+    if args.svg:
+        from forma_amd import svg as svg_loader
+        width, height = 3840, 2160
+        comp = svg_loader.Svg(args.svg, args.svg_scale).compose(api.Composition())
+        args.workload = "svg:" + os.path.basename(args.svg) + f" x{args.svg_scale:g}"
+    else:
+        build_fn, width, height = scenes.WORKLOADS[args.workload]
+        comp = build_fn()
     renderer = api.Renderer(device=local)
     ctx = renderer._ctx
     tiles_h = (height + 15) // 16

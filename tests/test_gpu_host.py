@@ -209,3 +209,87 @@ def test_animated_scene_cached_frames_equal_full_repaints():
         r.render(comp, api.BufferBuilder(fresh, lay).build(), api.RGBA, black, None)
         assert np.array_equal(carried, fresh), f"frame {f}"
         assert fresh.reshape(H, W, 4)[..., :3].any()
+
+
+def _random_svg(n=160, w=512, h=384, seed=17):
+    """An SVG document exercising every construct the loader knows: groups with transforms / fills / opacities, all path
+    commands incl. arcs, rects, both gradient kinds, blend modes, even-odd."""
+    rng = np.random.default_rng(seed)
+    out = [f'<svg xmlns="http://www.w3.org/2000/svg" width="{w}" height="{h}">',
+           '<linearGradient id="lg" gradientUnits="userSpaceOnUse" x1="40" y1="30" x2="400" y2="300">'
+           '<stop offset="0%" stop-color="#ff8000"/><stop offset="50%" stop-color="rgb(0,128,255)" stop-opacity="0.7"/>'
+           '<stop offset="100%" stop-color="seagreen"/></linearGradient>',
+           '<radialGradient id="rg" gradientUnits="userSpaceOnUse" cx="256" cy="192" r="180">'
+           '<stop offset="10%" stop-color="white"/><stop offset="90%" stop-color="#203040" stop-opacity="0.5"/></radialGradient>']
+    modes = ["normal", "multiply", "screen", "overlay", "darken", "lighten", "color-dodge", "color-burn", "hard-light",
+             "soft-light", "difference", "exclusion", "hue", "saturation", "color", "luminosity"]
+    for i in range(n):
+        x, y = rng.uniform(0, w - 60), rng.uniform(0, h - 60)
+        s = rng.uniform(10, 90)
+        kind = i % 8
+        fill = "#%02x%02x%02x" % tuple(int(v) for v in rng.integers(0, 256, 3))
+        if i % 11 == 0:
+            fill = "url(#lg)"
+        elif i % 13 == 0:
+            fill = "url(#rg)"
+        extra = ""
+        if i % 7 == 0:
+            extra += f' style="mix-blend-mode:{modes[(i // 7) % 16]}"'
+        if i % 5 == 0:
+            extra += ' fill-opacity="0.6"'
+        if i % 9 == 0:
+            extra += ' fill-rule="evenodd"'
+        if kind == 0:
+            d = f"M{x:.2f} {y:.2f}l{s:.2f} 0 0 {s:.2f}-{s:.2f} 0z m{s/4:.2f} {s/4:.2f}h{s/2:.2f}v{s/2:.2f}h-{s/2:.2f}z"
+        elif kind == 1:
+            d = f"M{x:.2f},{y:.2f}C{x+s:.2f},{y:.2f} {x+s:.2f},{y+s:.2f} {x:.2f},{y+s:.2f}S{x-s/2:.2f},{y+s/2:.2f} {x:.2f},{y:.2f}"
+        elif kind == 2:
+            d = f"M{x:.2f} {y:.2f}q{s:.2f} {s/3:.2f} {s/2:.2f} {s:.2f}t-{s/2:.2f} -{s/4:.2f}T{x:.2f} {y:.2f}"
+        elif kind == 3:
+            d = f"M{x:.2f} {y+s/2:.2f}a{s/2:.2f} {s/3:.2f} 0 1 0 {s:.2f} 0a{s/2:.2f} {s/3:.2f} 0 1 0 -{s:.2f} 0"
+        elif kind == 4:
+            d = f"M{x:.2f} {y:.2f}A{s:.2f} {s/2:.2f} 30 0 1 {x+s:.2f} {y+s/2:.2f}L{x:.2f} {y+s:.2f}Z"
+        elif kind == 5:
+            out.append(f'<rect x="{x:.2f}" y="{y:.2f}" width="{s:.2f}" height="{s*0.6:.2f}" fill="{fill}"{extra}/>')
+            continue
+        elif kind == 6:
+            out.append(f'<g transform="translate({x:.2f} {y:.2f}) rotate({rng.uniform(0, 90):.1f}) scale(0.8)" opacity="0.8" fill="{fill}">'
+                       f'<g opacity="0.9"><path d="M0 0L{s:.2f} 0L{s/2:.2f} {s:.2f}z"{extra}/></g></g>')
+            continue
+        else:
+            d = f"M{x:.2f} {y:.2f}c{s:.2f} 0 {s:.2f} {s:.2f} 0 {s:.2f}s-{s:.2f} -{s/2:.2f} 0 -{s:.2f}"
+        out.append(f'<path d="{d}" fill="{fill}"{extra}/>')
+    out.append('<path d="M0 0L10 10" stroke="#000"/></svg>')
+    return "\n".join(out)
+
+
+def test_svg_loader_route_matches_oracle():
+    """SVG text -> forma_amd.svg (mirror of demo/src/demos/svg.rs) -> Composition -> hip Renderer.  The
+    tables the renderer uploaded are replayed through the CPU oracle: streams bit-exact, image within 1 code value."""
+    from forma_amd import api, svg
+    W, H = 512, 384
+    doc = svg.Svg(_random_svg(), 1.0, is_text=True)
+    assert len(doc.paths) == 160
+    comp = doc.compose(api.Composition())
+    r = api.Renderer(0)
+    img = np.zeros(W * H * 4, np.uint8)
+    r.render(comp, api.BufferBuilder(img, api.LinearLayout(W, W * 4, H)).build(), api.RGBA, api.Color(1, 1, 1, 1), None)
+    o = orc.Oracle()
+    S.load(o, r.host_tables)
+    want = o.render(W, H, clear=(1.0, 1.0, 1.0, 1.0))
+    got = img.reshape(want.shape)
+    assert np.array_equal(o.segments(0), r._ctx.segments(0))          # unsorted stream, reference order
+    assert np.array_equal(o.segments(1), r._ctx.segments(1))          # sorted stream
+    diff = np.abs(want.astype(np.int16) - got.astype(np.int16))
+    assert diff.max() <= 1, f"max diff {diff.max()}"
+    assert (got != 255).any()
+    # scale = 2 renders the same picture twice as large (Path::transform after parsing, svg.rs:217-220)
+    doc2 = svg.Svg(_random_svg(), 2.0, is_text=True)
+    r2 = api.Renderer(0)
+    img2 = np.zeros(4 * W * H * 4, np.uint8)
+    r2.render(doc2.compose(api.Composition()), api.BufferBuilder(img2, api.LinearLayout(2 * W, 2 * W * 4, 2 * H)).build(),
+              api.RGBA, api.Color(1, 1, 1, 1), None)
+    o2 = orc.Oracle()
+    S.load(o2, r2.host_tables)
+    want2 = o2.render(2 * W, 2 * H, clear=(1.0, 1.0, 1.0, 1.0))
+    assert np.abs(want2.astype(np.int16) - img2.reshape(want2.shape).astype(np.int16)).max() <= 1
