@@ -82,6 +82,8 @@ struct forma_hip_ctx {
     DevBuf info, records, run_cov, rk_u, rk_a, rk_b, blk_edge, runs_scratch, row_tab, span_key, span_cov, run_col, span_col, image;
     uint32_t img_w = 0, img_h = 0;
     FrameInfo* h_info = nullptr;            // pinned
+    uint32_t* h_rows = nullptr;             // pinned: runs per tile row (synchronous frames), 2049 words
+    uint32_t pred_max_row = 0xFFFFFFFFu;    // most runs in one tile row of the last verified frame (unknown: no local sort)
     // band
     uint32_t band_row0 = 0, band_row1 = 0;
     // timing
@@ -313,33 +315,45 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                 ctx->layer_sorted);
     HIPCHECK(hipGetLastError());
     DevCount jc;
-    if (bound_j) jc = DevCount{&dinfo->n_runs, bound_j};
-    else {
+    // the runs of a tile row are ordered by (layer, tile_x) inside k_carry_rows when they fit its LDS; else by a global sort
+    bool local_sort = ctx->n_orders <= 65536 && !getenv("FORMA_HIP_GLOBAL_RUNSORT");
+    if (bound_j) {
+        jc = DevCount{&dinfo->n_runs, bound_j};
+        local_sort = local_sort && ctx->pred_max_row <= carry_rows_local_cap();     // wrong guess -> plan_bad -> synchronous re-run
+    } else {
         if (n > 0) {
+            HIPCHECK(hipMemcpyAsync(ctx->h_rows, row_count, (size_t)tiles_h * 4, hipMemcpyDeviceToHost, ctx->stream));
             int rc = read_info(ctx);
             if (rc) return rc;
             if ((rc = verify_speculation(ctx))) return rc;
             J = ctx->h_info->n_runs;
+            uint32_t mx = 0;
+            for (uint32_t r = 0; r < tiles_h; r++) mx = std::max(mx, ctx->h_rows[r]);
+            ctx->pred_max_row = mx;
+            local_sort = local_sort && mx <= carry_rows_local_cap();
         }
         jc = DevCount{nullptr, J};
     }
     if (jc.bound > 0) {
         const size_t jb = jc.bound;
-        HIPCHECK(ctx->rk_a.ensure(jb * 8));
-        HIPCHECK(ctx->rk_b.ensure(jb * 8));
         HIPCHECK(ctx->span_key.ensure(jb * 8));
         HIPCHECK(ctx->span_cov.ensure(jb * 16));
         HIPCHECK(ctx->span_col.ensure(jb * 16));
         HIPCHECK(ctx->run_col.ensure(jb * 16));
-        HIPCHECK(ctx->sort_counters.ensure(sort_scratch_words(jb) * 4));
-        // (tile_y, layer) order: stable radix sort on bits 32..63 = [layer 21 | tile_y+1 11]; live bits come from the
-        // rasterizer's varying-bit mask (layer = key bits 0..20, tile_y = key bits 33..43)
-        uint64_t live = ((ctx->live44 & 0x1FFFFFull) | ((ctx->live44 >> 33) << 21)) << 32;
-        const SortPlan rk_plan = make_sort_plan(live, 32, 64, ctx->digit_bits);
-        const uint64_t* sorted_keys = launch_radix_sort(ctx->stream, ctx->rk_u.as<uint64_t>(), ctx->rk_a.as<uint64_t>(),
-                                                        ctx->rk_b.as<uint64_t>(), jc, rk_plan, ctx->digit_bits,
-                                                        ctx->sort_counters.as<uint32_t>(), &dinfo->error, nullptr, nullptr);
-        launch_carry_rows(ctx->stream, sorted_keys, ctx->records.as<TileRecord>(), ctx->run_cov.as<uint4>(),
+        const uint64_t* sorted_keys = ctx->rk_u.as<uint64_t>();
+        if (!local_sort) {
+            HIPCHECK(ctx->rk_a.ensure(jb * 8));
+            HIPCHECK(ctx->rk_b.ensure(jb * 8));
+            HIPCHECK(ctx->sort_counters.ensure(sort_scratch_words(jb) * 4));
+            // (tile_y, layer) order: stable radix sort on bits 32..63 = [layer 21 | tile_y+1 11]; live bits come from the
+            // rasterizer's varying-bit mask (layer = key bits 0..20, tile_y = key bits 33..43)
+            uint64_t live = ((ctx->live44 & 0x1FFFFFull) | ((ctx->live44 >> 33) << 21)) << 32;
+            const SortPlan rk_plan = make_sort_plan(live, 32, 64, ctx->digit_bits);
+            sorted_keys = launch_radix_sort(ctx->stream, ctx->rk_u.as<uint64_t>(), ctx->rk_a.as<uint64_t>(),
+                                            ctx->rk_b.as<uint64_t>(), jc, rk_plan, ctx->digit_bits,
+                                            ctx->sort_counters.as<uint32_t>(), &dinfo->error, nullptr, nullptr);
+        }
+        launch_carry_rows(ctx->stream, local_sort, sorted_keys, ctx->records.as<TileRecord>(), ctx->run_cov.as<uint4>(),
                           ctx->blk_edge.as<BlkEdge>(), nc, jc, ctx->style_off.as<uint32_t>(),
                           ctx->style_words.as<uint32_t>(), (uint32_t)ctx->n_orders, tiles_w, tiles_h, row_count, row_span_lo,
                           row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(), ctx->run_col.as<uint4>(),
@@ -508,6 +522,7 @@ int forma_hip_create(forma_hip_ctx** out, int device) {
         delete ctx; return FORMA_E_HIP;
     }
     bool ok = hipHostMalloc((void**)&ctx->h_info, sizeof(FrameInfo), hipHostMallocDefault) == hipSuccess &&
+              hipHostMalloc((void**)&ctx->h_rows, 2049 * 4, hipHostMallocDefault) == hipSuccess &&
               ctx->info.ensure(sizeof(FrameInfo)) == hipSuccess && ctx->info_init.ensure(sizeof(FrameInfo)) == hipSuccess;
     if (ok) {
         FrameInfo fi;
@@ -545,6 +560,7 @@ void forma_hip_destroy(forma_hip_ctx* ctx) {
     for (int s = 0; s < ST_COUNT; s++) { (void)hipEventDestroy(ctx->ev0[s]); (void)hipEventDestroy(ctx->ev1[s]); }
     for (int p = 0; p < MAX_PASS_EVENTS; p++) { (void)hipEventDestroy(ctx->pev0[p]); (void)hipEventDestroy(ctx->pev1[p]); }
     if (ctx->h_info) (void)hipHostFree(ctx->h_info);
+    if (ctx->h_rows) (void)hipHostFree(ctx->h_rows);
     if (ctx->h_written) (void)hipHostFree(ctx->h_written);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     for (auto& c : ctx->caches) { c.tiles.release(); c.image.release(); }
@@ -814,7 +830,7 @@ int forma_hip_render(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t 
         const uint32_t N = ctx->h_info->n_segments, J = ctx->h_info->n_runs;
         ctx->n_seg = N; ctx->n_compact = ctx->h_info->n_compact; ctx->last_runs = J;
         const bool ok = !ctx->h_info->plan_bad && N <= bN && J <= bJ;
-        if (ok) { ctx->pred_N = N; ctx->pred_J = J; return frame_done(finish_frame(ctx, timings, true)); }
+        if (ok) { ctx->pred_N = N; ctx->pred_J = J; ctx->pred_max_row = ctx->h_info->max_row_runs; return frame_done(finish_frame(ctx, timings, true)); }
         ctx->pred_counts_valid = false;                   // fall through: the synchronous path re-learns everything
         clear_stage_flags(ctx);
     }

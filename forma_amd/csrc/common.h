@@ -45,7 +45,8 @@ struct FrameInfo {
     uint32_t error;          // device-side invariant violations (1 style, 2 tile depth, 4 look-back spin)
     uint32_t n_compact;      // lines with at least one pixel segment
     uint32_t plan_bad;       // asynchronous frames: the speculated sort plan does not match this frame's keys
-    uint32_t pad[2];
+    uint32_t max_row_runs;   // most runs in one tile row (the carry pre-pass sorts a row's runs in LDS when they fit)
+    uint32_t pad[1];
 };
 
 // one run of the sorted stream = one painted (tile, layer) pair that owns pixel segments
@@ -154,7 +155,8 @@ void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount n, uint32_t til
                  uint32_t rec_cap, uint4* run_cov, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge,
                  uint32_t* row_tab, uint32_t* scratch, FrameInfo* info, bool verify_plan, uint64_t spec_live44,
                  bool spec_layer_sorted);
-void launch_carry_rows(hipStream_t s, const uint64_t* sorted_run_keys, TileRecord* records, uint4* run_cov,
+uint32_t carry_rows_local_cap();      // most runs per tile row the in-LDS sort of launch_carry_rows(local_sort = true) takes
+void launch_carry_rows(hipStream_t s, bool local_sort, const uint64_t* sorted_run_keys, TileRecord* records, uint4* run_cov,
                        const BlkEdge* blk_edge, DevCount n_segments, DevCount n_runs, const uint32_t* style_offsets,
                        const uint32_t* style_words,
                        uint32_t n_orders, uint32_t tiles_w, uint32_t tiles_h, const uint32_t* row_count,

@@ -12,6 +12,7 @@
 // Built with -ffp-contract=off; every fused op is an explicit fmaf where the reference has mul_add.
 #include "common.h"
 #include "lookback.h"
+#include "radix_rank.h"
 
 // ================================================================================================
 // helpers
@@ -320,7 +321,15 @@ void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t ti
 // ================================================================================================
 #define CR_THREADS 1024
 #define CR_WAVES   (CR_THREADS / 64)
+#define CR_CAP     16384                // runs of one tile row that the in-LDS sort holds (2 x 64 KiB of 32-bit keys)
 
+// LOCAL = true: `sorted_keys` are the run keys as k_runs wrote them (stream order).  The runs of a tile row are contiguous
+// there ([row_lo, row_lo + cnt), tile_x-major), so the workgroup of the row orders them by (layer, tile_x) itself: a stable
+// LSB radix sort of `layer << 16 | index` in LDS, one or two 8-bit passes over the layer bits, wave-ranked like a sort
+// tile.  That replaces a global histogram + three chained radix passes over all J run keys (launch- and latency-bound:
+// ~60 us per frame at J = 1.3 M) by a few microseconds inside a kernel that is launched anyway.  Needs n_orders <= 65536
+// and cnt <= CR_CAP (checked on the device; the host falls back to the global sort, LOCAL = false).
+template <bool LOCAL>
 __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __restrict__ sorted_keys,
                                                            TileRecord* __restrict__ records,
                                                            uint4* __restrict__ run_cov,
@@ -342,6 +351,8 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
     __shared__ uint32_t s_group[CR_THREADS + 1], s_txb[CR_THREADS + 1];
     __shared__ uint64_t s_clo, s_chi;                  // carry across chunks: inclusive acc of the last element
     __shared__ uint32_t s_cgroup, s_spans;
+    __shared__ uint32_t s_ka[LOCAL ? CR_CAP : 1], s_kb[LOCAL ? CR_CAP : 1];
+    __shared__ uint32_t s_wh[LOCAL ? CR_WAVES * 256 : 1];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t ty = blockIdx.x;
     if (info->plan_bad) return;                                         // mis-sorted stream (async frame): the host re-runs
@@ -364,6 +375,71 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
     for (int i = 0; i < CR_WAVES; i++) row_lo += s_red[i];
     const uint32_t cnt = row_count[ty];
     if (tid == 0) row_span_lo[ty] = row_lo;
+    const uint32_t* lkeys = s_ka;                        // LOCAL: the row's runs, ordered by (layer, tile_x)
+    if (tid == 0 && cnt) atomicMax(&info->max_row_runs, cnt);
+    if (LOCAL) {
+        if (cnt > CR_CAP || row_lo + cnt > n_runs) {      // does not fit (or inconsistent counts): the host re-runs the frame
+            if (tid == 0) info->plan_bad = 1u;
+            return;
+        }
+        for (uint32_t e = tid; e < cnt; e += CR_THREADS)
+            s_ka[e] = (((uint32_t)(sorted_keys[row_lo + e] >> 32) & 0xFFFFu) << 16) | e;
+        uint32_t* src = s_ka;
+        uint32_t* dst = s_kb;
+        const uint32_t R = (cnt + CR_THREADS - 1) / CR_THREADS, CW = R * 64;       // key rows per wave, keys per wave
+        const int npass = n_orders > 256u ? 2 : 1;
+        for (int pass = 0; pass < npass; pass++) {
+            const int sh = 16 + 8 * pass;
+            for (int i = tid; i < CR_WAVES * 256; i += CR_THREADS) s_wh[i] = 0;
+            __syncthreads();
+            uint32_t kreg[CR_CAP / CR_THREADS], rreg[CR_CAP / CR_THREADS];
+#pragma unroll
+            for (int r = 0; r < CR_CAP / CR_THREADS; r++) {
+                if ((uint32_t)r < R) {
+                    const uint32_t e = w * CW + r * 64 + lane;
+                    const uint32_t key = e < cnt ? src[e] : 0xFFFFFFFFu;           // padding: last in stream order, digit 255
+                    const uint32_t dg = (key >> sh) & 0xFFu;
+                    uint32_t mlo, mhi;
+                    match_any<8>(dg, mlo, mhi);
+                    const uint32_t below = lanes_below(mlo, mhi);
+                    const uint32_t c = (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi);
+                    if (below == 0) atomicAdd(&s_wh[w * 256 + dg], c);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    const uint32_t after = s_wh[w * 256 + dg];
+                    kreg[r] = key; rreg[r] = after - c + below;
+                }
+            }
+            __syncthreads();
+            if (tid < 256) {                              // digit tid: start of every wave's share of it
+                uint32_t tot = 0;
+#pragma unroll
+                for (int i = 0; i < CR_WAVES; i++) tot += s_wh[i * 256 + tid];
+                uint32_t inc = tot;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+                if (lane == 63) s_red[w] = inc;
+                s_group[tid] = inc - tot;                 // exclusive within the wave (s_group is free until the main loop)
+            }
+            __syncthreads();
+            if (tid < 256) {
+                uint32_t acc = s_group[tid];
+                for (int i = 0; i < w; i++) acc += s_red[i];
+#pragma unroll
+                for (int i = 0; i < CR_WAVES; i++) { const uint32_t c = s_wh[i * 256 + tid]; s_wh[i * 256 + tid] = acc; acc += c; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < CR_CAP / CR_THREADS; r++) {
+                if ((uint32_t)r < R) {
+                    const uint32_t e = w * CW + r * 64 + lane;
+                    if (e < cnt) dst[s_wh[w * 256 + ((kreg[r] >> sh) & 0xFFu)] + rreg[r]] = kreg[r];
+                }
+            }
+            __syncthreads();
+            uint32_t* t = src; src = dst; dst = t;
+        }
+        lkeys = src;
+    }
     for (uint32_t c0 = 0; c0 < cnt; c0 += CR_THREADS) {
         const uint32_t k = row_lo + c0 + tid;
         const bool active = c0 + tid < cnt && k < n_runs;
@@ -372,8 +448,13 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
         uint4 scol = make_uint4(0, 0, 0, 0);
         bool even_odd = false;
         if (active) {
-            const uint64_t key = sorted_keys[k];
-            group = (uint32_t)(key >> 32); jrun = (uint32_t)key; layer = group & 0x1FFFFFu;
+            if (LOCAL) {
+                const uint32_t pk = lkeys[c0 + tid];
+                layer = pk >> 16; jrun = row_lo + (pk & 0xFFFFu); group = ((ty + 1u) << 21) | layer;
+            } else {
+                const uint64_t key = sorted_keys[k];
+                group = (uint32_t)(key >> 32); jrun = (uint32_t)key; layer = group & 0x1FFFFFu;
+            }
             TileRecord* r = &records[jrun];
             txb = r->tile & 0xFFFu;
             uint4 oc = run_cov[jrun];
@@ -412,8 +493,13 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
         if (tid == CR_THREADS - 1) {                     // the element after this chunk (for the last lane's span)
             uint32_t ng = 0xFFFFFFFDu, nt = 0;
             if (c0 + CR_THREADS < cnt && k + 1 < n_runs) {
-                const uint64_t nk = sorted_keys[k + 1];
-                ng = (uint32_t)(nk >> 32); nt = records[(uint32_t)nk].tile & 0xFFFu;
+                if (LOCAL) {
+                    const uint32_t pk = lkeys[c0 + CR_THREADS];
+                    ng = ((ty + 1u) << 21) | (pk >> 16); nt = records[row_lo + (pk & 0xFFFFu)].tile & 0xFFFu;
+                } else {
+                    const uint64_t nk = sorted_keys[k + 1];
+                    ng = (uint32_t)(nk >> 32); nt = records[(uint32_t)nk].tile & 0xFFFu;
+                }
             }
             s_group[CR_THREADS] = ng; s_txb[CR_THREADS] = nt;
         }
@@ -488,16 +574,23 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
     if (tid == 0) row_span_cnt[ty] = s_spans;
 }
 
-void launch_carry_rows(hipStream_t s, const uint64_t* sorted_run_keys, TileRecord* records, uint4* run_cov,
+uint32_t carry_rows_local_cap() { return CR_CAP; }
+
+void launch_carry_rows(hipStream_t s, bool local_sort, const uint64_t* sorted_run_keys, TileRecord* records, uint4* run_cov,
                        const BlkEdge* blk_edge, DevCount n_segments, DevCount n_runs, const uint32_t* style_offsets,
                        const uint32_t* style_words,
                        uint32_t n_orders, uint32_t tiles_w, uint32_t tiles_h, const uint32_t* row_count,
                        uint32_t* row_span_lo, uint32_t* row_span_cnt, uint64_t* span_key, uint4* span_cov, uint4* run_col,
                        uint4* span_col, const uint8_t* unchanged, FrameInfo* info) {
     if (tiles_h == 0) return;
-    hipLaunchKernelGGL(k_carry_rows, dim3(tiles_h), dim3(CR_THREADS), 0, s, sorted_run_keys, records, run_cov, blk_edge, n_segments, n_runs,
-                       style_offsets, style_words, n_orders, tiles_w, tiles_h, row_count, row_span_lo, row_span_cnt, span_key,
-                       span_cov, run_col, span_col, unchanged, info);
+    if (local_sort)
+        hipLaunchKernelGGL(k_carry_rows<true>, dim3(tiles_h), dim3(CR_THREADS), 0, s, sorted_run_keys, records, run_cov, blk_edge,
+                           n_segments, n_runs, style_offsets, style_words, n_orders, tiles_w, tiles_h, row_count, row_span_lo,
+                           row_span_cnt, span_key, span_cov, run_col, span_col, unchanged, info);
+    else
+        hipLaunchKernelGGL(k_carry_rows<false>, dim3(tiles_h), dim3(CR_THREADS), 0, s, sorted_run_keys, records, run_cov, blk_edge,
+                           n_segments, n_runs, style_offsets, style_words, n_orders, tiles_w, tiles_h, row_count, row_span_lo,
+                           row_span_cnt, span_key, span_cov, run_col, span_col, unchanged, info);
 }
 
 // ================================================================================================
