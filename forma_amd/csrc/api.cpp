@@ -40,6 +40,8 @@ struct forma_hip_ctx {
 
     // scene
     DevBuf x, y, line_slot, geoms, style_off, style_words, unchanged, images, texels;
+    DevBuf layer_sf, layer_col;             // per order: style summary for the carry pre-pass (set_styles)
+    std::vector<uint32_t> h_layer_sf, h_layer_col;
     size_t n_points = 0, n_geoms = 0, n_orders = 0, n_words = 0, n_images = 0;
     bool scene_has_clips = false;
     bool have_unchanged = false;            // set_styles supplied per-order Layer::is_unchanged bytes
@@ -354,8 +356,8 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                                             ctx->sort_counters.as<uint32_t>(), &dinfo->error, nullptr, nullptr);
         }
         launch_carry_rows(ctx->stream, local_sort, sorted_keys, ctx->records.as<TileRecord>(), ctx->run_cov.as<uint4>(),
-                          ctx->blk_edge.as<BlkEdge>(), nc, jc, ctx->style_off.as<uint32_t>(),
-                          ctx->style_words.as<uint32_t>(), (uint32_t)ctx->n_orders, tiles_w, tiles_h, row_count, row_span_lo,
+                          ctx->blk_edge.as<BlkEdge>(), nc, jc, ctx->layer_sf.as<uint32_t>(),
+                          ctx->layer_col.as<uint4>(), (uint32_t)ctx->n_orders, tiles_w, tiles_h, row_count, row_span_lo,
                           row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(), ctx->run_col.as<uint4>(),
                           ctx->span_col.as<uint4>(),
                           (a.cache_id >= 0 && ctx->have_unchanged) ? ctx->unchanged.as<uint8_t>() : nullptr, dinfo);
@@ -538,7 +540,7 @@ int forma_hip_create(forma_hip_ctx** out, int device) {
         ok = hipEventCreate(&ctx->pev0[p]) == hipSuccess && hipEventCreate(&ctx->pev1[p]) == hipSuccess;
     if (!ok) { delete ctx; return FORMA_E_HIP; }
     // empty-scene defaults so that a render before any upload is well defined
-    ctx->style_off.ensure(4); ctx->style_words.ensure(4); ctx->geoms.ensure(sizeof(forma_geom_t));
+    ctx->style_off.ensure(4); ctx->style_words.ensure(4); ctx->layer_sf.ensure(4); ctx->layer_col.ensure(16); ctx->geoms.ensure(sizeof(forma_geom_t));
     ctx->images.ensure(sizeof(forma_image_t)); ctx->texels.ensure(8);
     ctx->x.ensure(4); ctx->y.ensure(4); ctx->line_slot.ensure(4);
     *out = ctx;
@@ -549,7 +551,7 @@ void forma_hip_destroy(forma_hip_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    DevBuf* all[] = {&ctx->x, &ctx->y, &ctx->line_slot, &ctx->geoms, &ctx->style_off, &ctx->style_words, &ctx->unchanged,
+    DevBuf* all[] = {&ctx->x, &ctx->y, &ctx->line_slot, &ctx->geoms, &ctx->style_off, &ctx->style_words, &ctx->layer_sf, &ctx->layer_col, &ctx->unchanged,
                      &ctx->images, &ctx->texels, &ctx->l_order, &ctx->l_x0, &ctx->l_y0, &ctx->l_dx, &ctx->l_dy, &ctx->l_a,
                      &ctx->l_b, &ctx->l_c, &ctx->l_d, &ctx->l_len, &ctx->scan_tmp, &ctx->cl_idx, &ctx->cl_start,
                      &ctx->block_first, &ctx->prep_scratch, &ctx->seg_u, &ctx->seg_a, &ctx->seg_b,
@@ -606,6 +608,10 @@ int forma_hip_set_styles(forma_hip_ctx* ctx, const uint32_t* style_offsets, size
     if (!ctx || (n_orders && !style_offsets) || (n_words && !style_words)) return fail(ctx, FORMA_E_ARG, "null styles");
     if (n_orders > (size_t)FORMA_LAYER_LIMIT + 1) return fail(ctx, FORMA_E_ARG, "order exceeds LAYER_LIMIT");
     bool clips = false;
+    // per order: what the carry pre-pass attaches to every run and span of the layer (one gather instead of a chain through
+    // the offset table and the style words): SF_* flags and the four words the painter's fast paths read
+    ctx->h_layer_sf.assign(n_orders, 0u);
+    ctx->h_layer_col.assign(n_orders * 4, 0u);
     for (size_t o = 0; o < n_orders; o++) {
         uint32_t off = style_offsets[o];
         if (off == FORMA_NONE) continue;
@@ -619,11 +625,23 @@ int forma_hip_set_styles(forma_hip_ctx* ctx, const uint32_t* style_offsets, size
         }
         if (off + need > n_words) return fail(ctx, FORMA_E_ARG, "style payload out of range");
         if (FORMA_STYLE_IS_CLIP(h) || FORMA_STYLE_CLIPPED(h)) clips = true;
+        uint32_t sfl = (FORMA_STYLE_EVENODD(h) ? SF_EVENODD : 0u) | (FORMA_STYLE_BLEND(h) << SF_BLEND_SHIFT) | (FORMA_STYLE_FILL(h) << SF_FILL_SHIFT);
+        uint32_t* col = &ctx->h_layer_col[o * 4];
+        if (FORMA_STYLE_IS_CLIP(h)) { sfl |= SF_IS_CLIP; col[0] = style_words[off + 1]; }
+        else {
+            if (FORMA_STYLE_CLIPPED(h)) sfl |= SF_CLIPPED;
+            for (int k = 0; k < 4; k++) col[k] = style_words[off + 2 + k];
+            float alpha; memcpy(&alpha, &col[3], 4);
+            if (FORMA_STYLE_FILL(h) == FORMA_FILL_SOLID && alpha == 1.0f) sfl |= SF_OPAQUE;
+        }
+        ctx->h_layer_sf[o] = sfl | LSF_VALID;
     }
     HIPCHECK(hipSetDevice(ctx->device));
     int rc;
     if ((rc = upload(ctx, ctx->style_off, style_offsets, n_orders))) return rc;
     if ((rc = upload(ctx, ctx->style_words, style_words, n_words))) return rc;
+    if ((rc = upload(ctx, ctx->layer_sf, ctx->h_layer_sf.data(), n_orders))) return rc;
+    if ((rc = upload(ctx, ctx->layer_col, ctx->h_layer_col.data(), n_orders * 4))) return rc;
     if (unchanged && (rc = upload(ctx, ctx->unchanged, unchanged, n_orders))) return rc;
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     ctx->n_orders = n_orders; ctx->n_words = n_words; ctx->scene_has_clips = clips;

@@ -155,10 +155,20 @@ void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount n, uint32_t til
                  uint32_t rec_cap, uint4* run_cov, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge,
                  uint32_t* row_tab, uint32_t* scratch, FrameInfo* info, bool verify_plan, uint64_t spec_live44,
                  bool spec_layer_sorted);
+// style flags of a layer as the carry pre-pass and the painter pass them around (bits 21.. of a record's layer word)
+#define SF_FULL        0x001u     // spans only: Cover::is_full (painter/mod.rs:200-215)
+#define SF_IS_CLIP     0x002u
+#define SF_CLIPPED     0x004u
+#define SF_OPAQUE      0x008u     // solid fill with alpha == 1
+#define SF_EVENODD     0x010u
+#define SF_BLEND_SHIFT 5          // 4 bits: ordinal of BlendMode
+#define SF_FILL_SHIFT  9          // 2 bits: fill type
+#define LSF_VALID      0x80000000u // layer_sf[] entry: the order has a style (else FORMA_NONE)
+
 uint32_t carry_rows_local_cap();      // most runs per tile row the in-LDS sort of launch_carry_rows(local_sort = true) takes
 void launch_carry_rows(hipStream_t s, bool local_sort, const uint64_t* sorted_run_keys, TileRecord* records, uint4* run_cov,
-                       const BlkEdge* blk_edge, DevCount n_segments, DevCount n_runs, const uint32_t* style_offsets,
-                       const uint32_t* style_words,
+                       const BlkEdge* blk_edge, DevCount n_segments, DevCount n_runs, const uint32_t* layer_sf,
+                       const uint4* layer_col /* per order: SF_* | LSF_VALID, style words 2..5 (clip: word 1) */,
                        uint32_t n_orders, uint32_t tiles_w, uint32_t tiles_h, const uint32_t* row_count,
                        uint32_t* row_span_lo, uint32_t* row_span_cnt, uint64_t* span_key, uint4* span_cov, uint4* run_col,
                        uint4* span_col, const uint8_t* unchanged /* per order, nullable */, FrameInfo* info);

@@ -40,13 +40,6 @@ __device__ __forceinline__ bool cover_is_empty(uint64_t lo, uint64_t hi, bool ev
 
 // style facts carried in bits 21..31 of a run record's `layer` word and of a span key's high word (= bits 53..63 of
 // the painter's entry keys): enough for LayerWorkbench's optimizer passes to classify a layer without the style table
-#define SF_FULL        0x001u     // spans only: Cover::is_full (painter/mod.rs:200-215)
-#define SF_IS_CLIP     0x002u
-#define SF_CLIPPED     0x004u
-#define SF_OPAQUE      0x008u     // solid fill with alpha == 1
-#define SF_EVENODD     0x010u
-#define SF_BLEND_SHIFT 5          // 4 bits: ordinal of BlendMode
-#define SF_FILL_SHIFT  9          // 2 bits: fill type
 #define LAYER_MASK     0x1FFFFFu
 
 __device__ __forceinline__ bool cover_full(const uint32_t* c, bool even_odd) {     // Cover::is_full painter/mod.rs:200-215
@@ -322,6 +315,42 @@ void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t ti
 #define CR_THREADS 1024
 #define CR_WAVES   (CR_THREADS / 64)
 #define CR_CAP     16384                // runs of one tile row that the in-LDS sort holds (2 x 64 KiB of 32-bit keys)
+#define CR_CHUNK   (CR_THREADS - 1)     // runs per piece of the row walk (the last lane looks one run ahead)
+
+// workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight across it
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// what the carry scan gathers per run, requested one piece ahead
+struct CarryLoad {
+    bool active;
+    uint32_t group, jrun, layer, tile, sc, lsf;
+    uint4 oc, lcol;
+};
+template <bool LOCAL>
+__device__ __forceinline__ CarryLoad carry_load(uint32_t c0, int tid, uint32_t cnt, uint32_t row_lo, uint32_t n_runs, uint32_t ty,
+                                                const uint32_t* lkeys, const uint64_t* __restrict__ sorted_keys,
+                                                const TileRecord* __restrict__ records, const uint4* __restrict__ run_cov,
+                                                const uint32_t* __restrict__ layer_sf, const uint4* __restrict__ layer_col,
+                                                uint32_t n_orders) {
+    CarryLoad L;
+    const uint32_t k = row_lo + c0 + tid;
+    L.active = c0 + tid < cnt && k < n_runs;
+    L.group = 0xFFFFFFFEu; L.jrun = 0; L.layer = 0; L.tile = 0; L.sc = 0; L.lsf = 0;
+    L.oc = make_uint4(0, 0, 0, 0); L.lcol = make_uint4(0, 0, 0, 0);
+    if (L.active) {
+        if (LOCAL) {
+            const uint32_t pk = lkeys[c0 + tid];
+            L.layer = pk >> 16; L.jrun = row_lo + (pk & 0xFFFFu); L.group = ((ty + 1u) << 21) | L.layer;
+        } else {
+            const uint64_t key = sorted_keys[k];
+            L.group = (uint32_t)(key >> 32); L.jrun = (uint32_t)key; L.layer = L.group & 0x1FFFFFu;
+        }
+        L.tile = records[L.jrun].tile; L.sc = records[L.jrun].seg_count;
+        L.oc = run_cov[L.jrun];
+        if (L.layer < n_orders) { L.lsf = layer_sf[L.layer]; L.lcol = layer_col[L.layer]; }
+    }
+    return L;
+}
 
 // LOCAL = true: `sorted_keys` are the run keys as k_runs wrote them (stream order).  The runs of a tile row are contiguous
 // there ([row_lo, row_lo + cnt), tile_x-major), so the workgroup of the row orders them by (layer, tile_x) itself: a stable
@@ -335,8 +364,8 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
                                                            uint4* __restrict__ run_cov,
                                                            const BlkEdge* __restrict__ blk_edge, DevCount nc_segments,
                                                            DevCount nc_runs,
-                                                           const uint32_t* __restrict__ style_offsets,
-                                                           const uint32_t* __restrict__ style_words, uint32_t n_orders,
+                                                           const uint32_t* __restrict__ layer_sf,
+                                                           const uint4* __restrict__ layer_col, uint32_t n_orders,
                                                            uint32_t tiles_w, uint32_t tiles_h,
                                                            const uint32_t* __restrict__ row_count,
                                                            uint32_t* __restrict__ row_span_lo,
@@ -440,26 +469,26 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
         }
         lkeys = src;
     }
-    for (uint32_t c0 = 0; c0 < cnt; c0 += CR_THREADS) {
-        const uint32_t k = row_lo + c0 + tid;
-        const bool active = c0 + tid < cnt && k < n_runs;
-        uint32_t group = 0xFFFFFFFEu, jrun = 0, txb = 0, layer = 0, sfl = 0, unch = 0;
+    // The row is walked in pieces of CR_CHUNK = 1023 runs; lane 1023 holds the run AFTER the piece (only its group and tile
+    // are looked at: the span of lane 1022 ends where that run begins).  Everything a piece gathers from HBM — record,
+    // cover sums, the layer's style summary — is requested one piece ahead; the barriers inside the loop order LDS only
+    // (lds_barrier: no vmcnt wait), so those requests stay in flight behind the scan of the current piece.
+    CarryLoad nx = carry_load<LOCAL>(0, tid, cnt, row_lo, n_runs, ty, lkeys, sorted_keys, records, run_cov, layer_sf, layer_col, n_orders);
+    for (uint32_t c0 = 0; c0 < cnt; c0 += CR_CHUNK) {
+        const CarryLoad cu = nx;
+        if (c0 + CR_CHUNK < cnt)
+            nx = carry_load<LOCAL>(c0 + CR_CHUNK, tid, cnt, row_lo, n_runs, ty, lkeys, sorted_keys, records, run_cov, layer_sf, layer_col, n_orders);
+        const bool active = cu.active && tid < CR_CHUNK;                 // lane 1023 only looks ahead
+        const uint32_t group = cu.active ? cu.group : 0xFFFFFFFEu, jrun = cu.jrun, layer = cu.layer;
+        uint32_t txb = 0, sfl = 0, unch = 0;
         uint64_t own_lo = 0, own_hi = 0;
         uint4 scol = make_uint4(0, 0, 0, 0);
         bool even_odd = false;
+        if (cu.active) txb = cu.tile & 0xFFFu;
         if (active) {
-            if (LOCAL) {
-                const uint32_t pk = lkeys[c0 + tid];
-                layer = pk >> 16; jrun = row_lo + (pk & 0xFFFFu); group = ((ty + 1u) << 21) | layer;
-            } else {
-                const uint64_t key = sorted_keys[k];
-                group = (uint32_t)(key >> 32); jrun = (uint32_t)key; layer = group & 0x1FFFFFu;
-            }
             TileRecord* r = &records[jrun];
-            txb = r->tile & 0xFFFu;
-            uint4 oc = run_cov[jrun];
-            own_lo = (uint64_t)oc.x | ((uint64_t)oc.y << 32); own_hi = (uint64_t)oc.z | ((uint64_t)oc.w << 32);
-            uint32_t sc = r->seg_count;
+            own_lo = (uint64_t)cu.oc.x | ((uint64_t)cu.oc.y << 32); own_hi = (uint64_t)cu.oc.z | ((uint64_t)cu.oc.w << 32);
+            uint32_t sc = cu.sc;
             if (sc & RUN_OPEN) {                         // complete a run that crosses k_runs tiles with their edges
                 sc &= ~RUN_OPEN;
                 for (uint32_t b = r->seg_start / RN_TILE + 1; b < n_blk; b++) {
@@ -471,42 +500,21 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
                 }
                 r->seg_count = sc;
             }
-            if (layer < n_orders && style_offsets[layer] != FORMA_NONE) {
+            if (cu.lsf & LSF_VALID) {
                 // everything the painter's optimizer passes need to know about the layer's style, so that a tile can
                 // classify its whole layer list without touching the style table (SF_* bits ride in the entry keys)
-                const uint32_t* sw = style_words + style_offsets[layer];
-                const uint32_t h = sw[0];
-                even_odd = FORMA_STYLE_EVENODD(h);
-                sfl = (even_odd ? SF_EVENODD : 0u) | (FORMA_STYLE_BLEND(h) << SF_BLEND_SHIFT) | (FORMA_STYLE_FILL(h) << SF_FILL_SHIFT);
-                if (FORMA_STYLE_IS_CLIP(h)) { sfl |= SF_IS_CLIP; scol = make_uint4(sw[1], 0, 0, 0); }
-                else {
-                    if (FORMA_STYLE_CLIPPED(h)) sfl |= SF_CLIPPED;
-                    scol = make_uint4(sw[2], sw[3], sw[4], sw[5]);
-                    if (FORMA_STYLE_FILL(h) == FORMA_FILL_SOLID && __uint_as_float(sw[5]) == 1.0f) sfl |= SF_OPAQUE;
-                }
+                sfl = cu.lsf & ~LSF_VALID; scol = cu.lcol;
+                even_odd = (sfl & SF_EVENODD) != 0;
                 r->layer = layer | (sfl << 21);
                 run_col[jrun] = scol;
-                if (unchanged && unchanged[layer]) { unch = 1u; r->tile |= 0x80000000u; }   // Layer::is_unchanged(cache_id)
+                if (unchanged && unchanged[layer]) { unch = 1u; r->tile = cu.tile | 0x80000000u; }   // Layer::is_unchanged(cache_id)
             } else atomicOr(&info->error, 1u);
         }
         s_group[tid] = group; s_txb[tid] = txb;
-        if (tid == CR_THREADS - 1) {                     // the element after this chunk (for the last lane's span)
-            uint32_t ng = 0xFFFFFFFDu, nt = 0;
-            if (c0 + CR_THREADS < cnt && k + 1 < n_runs) {
-                if (LOCAL) {
-                    const uint32_t pk = lkeys[c0 + CR_THREADS];
-                    ng = ((ty + 1u) << 21) | (pk >> 16); nt = records[row_lo + (pk & 0xFFFFu)].tile & 0xFFFu;
-                } else {
-                    const uint64_t nk = sorted_keys[k + 1];
-                    ng = (uint32_t)(nk >> 32); nt = records[(uint32_t)nk].tile & 0xFFFu;
-                }
-            }
-            s_group[CR_THREADS] = ng; s_txb[CR_THREADS] = nt;
-        }
-        __syncthreads();
+        lds_barrier();
         const uint32_t prev_group = tid ? s_group[tid - 1] : s_cgroup;
         const bool head = active && group != prev_group;
-        // ---- segmented inclusive scan of (lo, hi) over the chunk ----------------------------------------------
+        // ---- segmented inclusive scan of (lo, hi) over the piece ----------------------------------------------
         uint64_t lo = own_lo, hi = own_hi;
         uint32_t f = head ? 1u : 0u;
 #pragma unroll
@@ -516,8 +524,8 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
             if (lane >= d) { if (!f) { lo = swar_add8(lo, tl); hi = swar_add8(hi, th); } f |= tf; }
         }
         if (lane == 63) { s_wlo[w] = lo; s_whi[w] = hi; s_wflag[w] = f; }
-        __syncthreads();
-        if (tid == 0) {                                   // wave carry-ins (serial over 16 waves), seeded by the chunk carry
+        lds_barrier();
+        if (tid == 0) {                                   // wave carry-ins (serial over 16 waves), seeded by the piece carry
             uint64_t clo = s_clo, chi = s_chi;
             for (int i = 0; i < CR_WAVES; i++) {
                 const uint64_t wl = s_wlo[i], wh = s_whi[i];
@@ -526,13 +534,13 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
                 if (wf) { clo = wl; chi = wh; } else { clo = swar_add8(clo, wl); chi = swar_add8(chi, wh); }
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (!f) { lo = swar_add8(lo, s_wlo[w]); hi = swar_add8(hi, s_whi[w]); }     // lo/hi = inclusive carry-out
         // carry-in = inclusive value of the previous element of the group
         uint64_t pl = __shfl_up(lo, 1, 64), ph = __shfl_up(hi, 1, 64);
-        __syncthreads();                                  // s_wlo reused below: every wave has read its carry-in
+        lds_barrier();                                    // s_wlo reused below: every wave has read its carry-in
         if (lane == 63) { s_wlo[w] = lo; s_whi[w] = hi; }
-        __syncthreads();
+        lds_barrier();
         if (lane == 0) {
             if (w == 0) { pl = s_clo; ph = s_chi; } else { pl = s_wlo[w - 1]; ph = s_whi[w - 1]; }
         }
@@ -554,7 +562,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
         const uint64_t bal = __ballot(has_span);
         const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
         if (lane == 0) s_wspan[w] = (uint32_t)__popcll(bal);
-        __syncthreads();
+        lds_barrier();
         uint32_t sbase = s_spans, stot = 0;
 #pragma unroll
         for (int i = 0; i < CR_WAVES; i++) { const uint32_t t = s_wspan[i]; if (i < w) sbase += t; stot += t; }
@@ -566,10 +574,10 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
             span_cov[si] = make_uint4(c4[0], c4[1], c4[2], c4[3]);
             span_col[si] = scol;
         }
-        __syncthreads();
-        if (tid == CR_THREADS - 1) { s_clo = lo; s_chi = hi; s_cgroup = group; }   // only used when the chunk is full
+        lds_barrier();
+        if (tid == CR_CHUNK - 1) { s_clo = lo; s_chi = hi; s_cgroup = group; }     // only used when the piece is full
         if (tid == 0) s_spans += stot;
-        __syncthreads();
+        lds_barrier();
     }
     if (tid == 0) row_span_cnt[ty] = s_spans;
 }
@@ -577,19 +585,19 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
 uint32_t carry_rows_local_cap() { return CR_CAP; }
 
 void launch_carry_rows(hipStream_t s, bool local_sort, const uint64_t* sorted_run_keys, TileRecord* records, uint4* run_cov,
-                       const BlkEdge* blk_edge, DevCount n_segments, DevCount n_runs, const uint32_t* style_offsets,
-                       const uint32_t* style_words,
+                       const BlkEdge* blk_edge, DevCount n_segments, DevCount n_runs, const uint32_t* layer_sf,
+                       const uint4* layer_col,
                        uint32_t n_orders, uint32_t tiles_w, uint32_t tiles_h, const uint32_t* row_count,
                        uint32_t* row_span_lo, uint32_t* row_span_cnt, uint64_t* span_key, uint4* span_cov, uint4* run_col,
                        uint4* span_col, const uint8_t* unchanged, FrameInfo* info) {
     if (tiles_h == 0) return;
     if (local_sort)
         hipLaunchKernelGGL(k_carry_rows<true>, dim3(tiles_h), dim3(CR_THREADS), 0, s, sorted_run_keys, records, run_cov, blk_edge,
-                           n_segments, n_runs, style_offsets, style_words, n_orders, tiles_w, tiles_h, row_count, row_span_lo,
+                           n_segments, n_runs, layer_sf, layer_col, n_orders, tiles_w, tiles_h, row_count, row_span_lo,
                            row_span_cnt, span_key, span_cov, run_col, span_col, unchanged, info);
     else
         hipLaunchKernelGGL(k_carry_rows<false>, dim3(tiles_h), dim3(CR_THREADS), 0, s, sorted_run_keys, records, run_cov, blk_edge,
-                           n_segments, n_runs, style_offsets, style_words, n_orders, tiles_w, tiles_h, row_count, row_span_lo,
+                           n_segments, n_runs, layer_sf, layer_col, n_orders, tiles_w, tiles_h, row_count, row_span_lo,
                            row_span_cnt, span_key, span_cov, run_col, span_col, unchanged, info);
 }
 
