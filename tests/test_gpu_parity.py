@@ -316,3 +316,63 @@ def test_triangles_10m_8k(ctx):
     assert np.array_equal(s, o.segments(1))
     d = np.abs(a.astype(np.int16) - b.astype(np.int16))
     assert d.max() <= 1
+
+
+def _many_small_squares(n, width, row_y=4.0, seed=21, first_order=0, size=6.0):
+    rng = np.random.default_rng(seed)
+    comp = S.Composition()
+    for i in range(n):
+        x0 = float(rng.uniform(0, width - size))
+        comp.get_mut_or_insert_default(first_order + i).insert(S.custom_square(x0, row_y, x0 + size, row_y + size)) \
+            .set_props(S.solid((float(rng.random()), float(rng.random()), float(rng.random()), 0.5)))
+    return comp
+
+
+def test_tile_row_with_more_runs_than_the_in_lds_sort_holds(ctx):
+    """The carry pre-pass orders a tile row's runs by (layer, tile_x) in LDS when the row has <= 16384 runs (the common
+    case) and by a global radix sort otherwise.  18 000 small layers in ONE tile row take the second path — on the
+    synchronous first frame and on the read-back-free frames after it."""
+    comp = _many_small_squares(18000, 1024)
+    o, _ = both(ctx, comp)
+    want = o.render(1024, 32, clear=(1, 1, 1, 1))
+    for _ in range(3):
+        got = ctx.render(1024, 32, clear=(1, 1, 1, 1))
+        assert np.array_equal(ctx.segments(1), o.segments(1))
+        assert np.abs(want.astype(int) - got.astype(int)).max() <= 1
+
+
+def test_row_run_count_jumps_between_frames(ctx):
+    """Frame k fits the in-LDS run sort, frame k+1 (same geometry, layers moved into one row) does not: the asynchronous
+    frame guessed 'fits', the device guard voids it and the synchronous re-run takes the global sort.  And back."""
+    rng = np.random.default_rng(8)
+    comp = S.Composition()
+    n = 17500
+    for i in range(n):
+        x0, y0 = float(rng.uniform(0, 1000)), float(rng.uniform(0, 1000))
+        comp.get_mut_or_insert_default(i).insert(S.custom_square(x0, y0, x0 + 5.0, y0 + 5.0)) \
+            .set_props(S.solid((float(rng.random()), float(rng.random()), float(rng.random()), 0.6)))
+    o = orc.Oracle()
+    t = comp.tables(o)
+    S.load(o, t); S.load(ctx, t)
+    base_geoms = t["geoms"].copy()
+    for squash in (False, False, True, True, False, False):
+        g = base_geoms.copy()
+        if squash:                                   # y -> y / 128: every layer lands in the first tile rows
+            g["flags"] = 1
+            g["xf"] = np.array([1.0, 0.0, 0.0, 1.0 / 128.0, 0.0, 2.0], np.float32)   # [ux, vx, uy, vy, tx, ty]
+        o.set_geoms(g); ctx.set_geoms(g)
+        want = o.render(1024, 1024, clear=(0, 0, 0, 1))
+        got = ctx.render(1024, 1024, clear=(0, 0, 0, 1))
+        assert np.array_equal(ctx.segments(1), o.segments(1)), squash
+        assert np.abs(want.astype(int) - got.astype(int)).max() <= 1, squash
+
+
+def test_orders_above_16_bits_use_the_global_run_sort(ctx):
+    """The in-LDS run sort packs `layer << 16 | index`: scenes whose orders do not fit 16 bits keep the global sort."""
+    comp = _many_small_squares(300, 256, first_order=70000, size=20.0)
+    o, _ = both(ctx, comp)
+    want = o.render(256, 64, clear=(1, 1, 1, 1))
+    for _ in range(2):
+        got = ctx.render(256, 64, clear=(1, 1, 1, 1))
+        assert np.array_equal(ctx.segments(1), o.segments(1))
+        assert np.abs(want.astype(int) - got.astype(int)).max() <= 1
