@@ -23,10 +23,10 @@
 #include "lookback.h"
 #include "radix_rank.h"
 
-#define OS_THREADS 512
+#define OS_THREADS 1024
 #define OS_WAVES   (OS_THREADS / 64)
 #define OS_KPT     16                               // keys per lane
-#define OS_TILE    (OS_THREADS * OS_KPT)            // 8192 keys per tile -> 64 KiB of LDS staging, 2 workgroups per CU
+#define OS_TILE    (OS_THREADS * OS_KPT)            // 16384 keys per tile -> 128 KiB of LDS staging, 1 workgroup (16 waves) per CU
 #define ST_VALMASK 0x3FFFFFFFu
 #define OS_LBW     8                                // predecessor tiles examined per look-back probe
 
@@ -280,7 +280,8 @@ const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a
     uint32_t hb = (uint32_t)((n + HS_TILE - 1) / HS_TILE);
     if (hb > 1024) hb = 1024;                             // few workgroups: the final flush is 256 x passes global atomics each
     hipLaunchKernelGGL(k_sort_hist, dim3(hb), dim3(HS_THREADS), 0, s, in, nc, plan, hist);
-    uint32_t grid = ntiles < 512 ? ntiles : 512;          // persistent: 2 workgroups of 8 waves per CU
+    const uint32_t cap = 512u * 512u / OS_THREADS;        // persistent: 16 waves per CU
+    uint32_t grid = ntiles < cap ? ntiles : cap;
     const uint64_t* src = in;
     uint64_t* dst = a;
     for (int p = 0; p < P; p++) {
