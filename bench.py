@@ -143,7 +143,7 @@ def main():
     # prescribes; bench.py cannot run under two profilers at once, so the committed summary of the same command is read)
     traffic = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01s_pmc_traffic.json")) as f:     # tools/pmc_traffic.py, current kernels
             pmc = json.load(f)
         if args.workload == "paris-like-30k-4k" and world == 1:
             traffic = pmc["kernels"][pmc["roofline_kernel"]]["hbm_bytes_per_launch"]
