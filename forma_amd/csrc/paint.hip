@@ -301,8 +301,8 @@ void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t ti
 }
 
 // ================================================================================================
-// carry pre-pass: one 1024-lane workgroup per tile row.  The row's runs arrive ordered by
-// (layer, tile_x) (run_keys after a stable radix sort on the (tile_y, layer) bits).  A segmented scan of
+// carry pre-pass: one 1024-lane workgroup per tile row.  The row's runs are brought into (layer, tile_x) order (LOCAL:
+// by the workgroup itself in LDS; else run_keys after a stable radix sort on the (tile_y, layer) bits).  A segmented scan of
 // the 16 x i8 cover sums over each (row, layer) group gives every run its carry-in:
 //   carry-in(run) = wrapping sum of the covers of all runs of the group with smaller tile_x
 //                   (painter/mod.rs:500-522 for the left-of-canvas bucket; layer_workbench/mod.rs:325-333)
