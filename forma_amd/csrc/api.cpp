@@ -480,7 +480,7 @@ int finish_frame(forma_hip_ctx* ctx, forma_timings_t* t, bool have_info = false)
     }
     t->sort_pass_us = np ? pass / np : 0.0f;
     t->n_lines = (uint32_t)ctx->n_lines; t->n_segments = (uint32_t)ctx->n_seg; t->n_sort_passes = (uint32_t)ctx->n_passes;
-    t->n_runs = ctx->last_runs; t->n_tile_entries = ctx->last_entries;
+    t->n_runs = ctx->last_runs ? ctx->last_runs : ctx->h_info->n_runs; t->n_tile_entries = ctx->h_info->n_spans;
     return FORMA_OK;
 }
 

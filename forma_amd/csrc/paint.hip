@@ -579,7 +579,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
         if (tid == 0) s_spans += stot;
         lds_barrier();
     }
-    if (tid == 0) row_span_cnt[ty] = s_spans;
+    if (tid == 0) { row_span_cnt[ty] = s_spans; if (s_spans) atomicAdd(&info->n_spans, s_spans); }
 }
 
 uint32_t carry_rows_local_cap() { return CR_CAP; }

@@ -118,7 +118,7 @@ typedef struct forma_timings_t {
     uint32_t n_segments;      /* N = number of pixel segments          */
     uint32_t n_sort_passes;   /* digit passes actually executed        */
     uint32_t n_runs;          /* (tile, layer) runs in the sorted stream */
-    uint32_t n_tile_entries;  /* painted (tile, layer) pairs           */
+    uint32_t n_tile_entries;  /* carry-only span records of the frame  */
     uint32_t reserved;
 } forma_timings_t;
 
