@@ -525,14 +525,21 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
         }
         if (lane == 63) { s_wlo[w] = lo; s_whi[w] = hi; s_wflag[w] = f; }
         lds_barrier();
-        if (tid == 0) {                                   // wave carry-ins (serial over 16 waves), seeded by the piece carry
-            uint64_t clo = s_clo, chi = s_chi;
-            for (int i = 0; i < CR_WAVES; i++) {
-                const uint64_t wl = s_wlo[i], wh = s_whi[i];
-                const uint32_t wf = s_wflag[i];
-                s_wlo[i] = clo; s_whi[i] = chi;
-                if (wf) { clo = wl; chi = wh; } else { clo = swar_add8(clo, wl); chi = swar_add8(chi, wh); }
+        if (w == 0) {                                     // wave carry-ins: segmented scan of the 16 wave totals, seeded by the
+            const bool in = lane < CR_WAVES;              // piece carry — done by 16 lanes, not by one lane 16 times
+            uint64_t l = in ? s_wlo[lane] : 0ull, h = in ? s_whi[lane] : 0ull;
+            uint32_t fl = in ? s_wflag[lane] : 0u;
+            const uint64_t seed_lo = s_clo, seed_hi = s_chi;
+            if (lane == 0 && !fl) { l = swar_add8(seed_lo, l); h = swar_add8(seed_hi, h); }
+#pragma unroll
+            for (int d = 1; d < CR_WAVES; d <<= 1) {
+                const uint64_t tl = __shfl_up(l, d, 64), th = __shfl_up(h, d, 64);
+                const uint32_t tf = __shfl_up(fl, d, 64);
+                if (lane >= d) { if (!fl) { l = swar_add8(l, tl); h = swar_add8(h, th); } fl |= tf; }
             }
+            uint64_t el = __shfl_up(l, 1, 64), eh = __shfl_up(h, 1, 64);      // exclusive: what runs into wave `lane`
+            if (lane == 0) { el = seed_lo; eh = seed_hi; }
+            if (in) { s_wlo[lane] = el; s_whi[lane] = eh; }
         }
         lds_barrier();
         if (!f) { lo = swar_add8(lo, s_wlo[w]); hi = swar_add8(hi, s_whi[w]); }     // lo/hi = inclusive carry-out
