@@ -81,7 +81,7 @@ struct forma_hip_ctx {
     bool pred_counts_valid = false, no_async = false;    // N / J predictions for read-back-free frames (FORMA_HIP_SYNC=1 disables)
     uint32_t pred_N = 0, pred_J = 0, pred_w = 0, pred_h = 0;
     uint64_t pred_live44 = 0;
-    DevBuf info, records, run_cov, rk_u, rk_a, rk_b, blk_edge, runs_scratch, row_tab, span_key, span_cov, run_col, span_col, image;
+    DevBuf info, records, rk_u, rk_a, rk_b, blk_edge, runs_scratch, row_tab, span_key, span_cov, image;
     uint32_t img_w = 0, img_h = 0;
     FrameInfo* h_info = nullptr;            // pinned
     uint32_t* h_rows = nullptr;             // pinned: runs per tile row (synchronous frames), 2049 words
@@ -306,12 +306,11 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     // capacity: a run needs at least one segment, and so does a span's left neighbour
     const size_t cap = std::max<size_t>(bound_j ? bound_j : n, 1);
     HIPCHECK(ctx->records.ensure(cap * sizeof(TileRecord)));
-    HIPCHECK(ctx->run_cov.ensure(cap * 16));
     HIPCHECK(ctx->rk_u.ensure(cap * 8));
     HIPCHECK(ctx->blk_edge.ensure(runs_blocks(std::max<size_t>(n, 1)) * sizeof(BlkEdge)));
     HIPCHECK(ctx->runs_scratch.ensure(runs_scratch_words(std::max<size_t>(n, 1)) * 4));
     stage_begin(ctx, ST_CARRY, timing);
-    launch_runs(ctx->stream, ctx->sorted, nc, tiles_w, tiles_h, ctx->records.as<TileRecord>(), (uint32_t)cap, ctx->run_cov.as<uint4>(),
+    launch_runs(ctx->stream, ctx->sorted, nc, tiles_w, tiles_h, ctx->records.as<TileRecord>(), (uint32_t)cap,
                 ctx->rk_u.as<uint64_t>(), tile_first_run, ctx->blk_edge.as<BlkEdge>(), row_count,
                 ctx->runs_scratch.as<uint32_t>(), dinfo, /*verify_plan=*/bound_j != 0 && ctx->speculated, ctx->live44,
                 ctx->layer_sorted);
@@ -340,8 +339,6 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
         const size_t jb = jc.bound;
         HIPCHECK(ctx->span_key.ensure(jb * 8));
         HIPCHECK(ctx->span_cov.ensure(jb * 16));
-        HIPCHECK(ctx->span_col.ensure(jb * 16));
-        HIPCHECK(ctx->run_col.ensure(jb * 16));
         const uint64_t* sorted_keys = ctx->rk_u.as<uint64_t>();
         if (!local_sort) {
             HIPCHECK(ctx->rk_a.ensure(jb * 8));
@@ -355,17 +352,14 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                                             ctx->rk_b.as<uint64_t>(), jc, rk_plan, ctx->digit_bits,
                                             ctx->sort_counters.as<uint32_t>(), &dinfo->error, nullptr, nullptr);
         }
-        launch_carry_rows(ctx->stream, local_sort, sorted_keys, ctx->records.as<TileRecord>(), ctx->run_cov.as<uint4>(),
+        launch_carry_rows(ctx->stream, local_sort, sorted_keys, ctx->records.as<TileRecord>(),
                           ctx->blk_edge.as<BlkEdge>(), nc, jc, ctx->layer_sf.as<uint32_t>(),
-                          ctx->layer_col.as<uint4>(), (uint32_t)ctx->n_orders, tiles_w, tiles_h, row_count, row_span_lo,
-                          row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(), ctx->run_col.as<uint4>(),
-                          ctx->span_col.as<uint4>(),
+                          (uint32_t)ctx->n_orders, tiles_w, tiles_h, row_count, row_span_lo,
+                          row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(),
                           (a.cache_id >= 0 && ctx->have_unchanged) ? ctx->unchanged.as<uint8_t>() : nullptr, dinfo);
     } else {
         HIPCHECK(ctx->span_key.ensure(8));
         HIPCHECK(ctx->span_cov.ensure(16));
-        HIPCHECK(ctx->span_col.ensure(16));
-        HIPCHECK(ctx->run_col.ensure(16));
     }
     stage_end(ctx, ST_CARRY, timing);
     ctx->last_runs = J; ctx->last_entries = 0;
@@ -386,8 +380,8 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     P.clear_unchanged = clear_unchanged;
     stage_begin(ctx, ST_PAINT, timing);
     launch_paint(ctx->stream, P, ctx->sorted, ctx->records.as<TileRecord>(), jc, tile_first_run, row_span_lo,
-                 row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(), ctx->run_col.as<uint4>(),
-                 ctx->span_col.as<uint4>(), ctx->style_off.as<uint32_t>(),
+                 row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(), ctx->layer_col.as<uint4>(),
+                 ctx->style_off.as<uint32_t>(),
                  ctx->style_words.as<uint32_t>(), ctx->images.as<forma_image_t>(), ctx->texels.as<uint16_t>(),
                  ctx->cur_image, tc, dinfo, paint_overflow, overflow_list);
     stage_end(ctx, ST_PAINT, timing);
@@ -555,8 +549,8 @@ void forma_hip_destroy(forma_hip_ctx* ctx) {
                      &ctx->images, &ctx->texels, &ctx->l_order, &ctx->l_x0, &ctx->l_y0, &ctx->l_dx, &ctx->l_dy, &ctx->l_a,
                      &ctx->l_b, &ctx->l_c, &ctx->l_d, &ctx->l_len, &ctx->scan_tmp, &ctx->cl_idx, &ctx->cl_start,
                      &ctx->block_first, &ctx->prep_scratch, &ctx->seg_u, &ctx->seg_a, &ctx->seg_b,
-                     &ctx->sort_counters, &ctx->info, &ctx->info_init, &ctx->records, &ctx->run_cov, &ctx->rk_u, &ctx->rk_a, &ctx->rk_b,
-                     &ctx->blk_edge, &ctx->runs_scratch, &ctx->row_tab, &ctx->span_key, &ctx->span_cov, &ctx->run_col, &ctx->span_col,
+                     &ctx->sort_counters, &ctx->info, &ctx->info_init, &ctx->records, &ctx->rk_u, &ctx->rk_a, &ctx->rk_b,
+                     &ctx->blk_edge, &ctx->runs_scratch, &ctx->row_tab, &ctx->span_key, &ctx->span_cov,
                      &ctx->image};
     for (DevBuf* b : all) b->release();
     for (int s = 0; s < ST_COUNT; s++) { (void)hipEventDestroy(ctx->ev0[s]); (void)hipEventDestroy(ctx->ev1[s]); }

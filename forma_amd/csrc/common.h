@@ -51,7 +51,8 @@ struct FrameInfo {
 
 // one run of the sorted stream = one painted (tile, layer) pair that owns pixel segments
 struct TileRecord {          // 32 B
-    uint32_t cover[4];       // carry-in cover, 16 x i8 (little-endian bytes = local_y 0..15)
+    uint32_t cover[4];       // 16 x i8 (little-endian bytes = local_y 0..15): the run's own cover sum out of k_runs,
+                             // replaced by its carry-in cover in k_carry_rows
     uint32_t seg_start;      // first segment of the run in the sorted stream
     uint32_t seg_count;
     uint32_t layer;
@@ -152,7 +153,7 @@ size_t runs_scratch_words(size_t n);
 size_t runs_blocks(size_t n);
 // run detection + per-run cover sums; row_tab = [row_count | row_span_lo | row_span_cnt], (tiles_h + 1) words each
 void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount n, uint32_t tiles_w, uint32_t tiles_h, TileRecord* records,
-                 uint32_t rec_cap, uint4* run_cov, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge,
+                 uint32_t rec_cap, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge,
                  uint32_t* row_tab, uint32_t* scratch, FrameInfo* info, bool verify_plan, uint64_t spec_live44,
                  bool spec_layer_sorted);
 // style flags of a layer as the carry pre-pass and the painter pass them around (bits 21.. of a record's layer word)
@@ -166,15 +167,15 @@ void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount n, uint32_t til
 #define LSF_VALID      0x80000000u // layer_sf[] entry: the order has a style (else FORMA_NONE)
 
 uint32_t carry_rows_local_cap();      // most runs per tile row the in-LDS sort of launch_carry_rows(local_sort = true) takes
-void launch_carry_rows(hipStream_t s, bool local_sort, const uint64_t* sorted_run_keys, TileRecord* records, uint4* run_cov,
-                       const BlkEdge* blk_edge, DevCount n_segments, DevCount n_runs, const uint32_t* layer_sf,
-                       const uint4* layer_col /* per order: SF_* | LSF_VALID, style words 2..5 (clip: word 1) */,
-                       uint32_t n_orders, uint32_t tiles_w, uint32_t tiles_h, const uint32_t* row_count,
-                       uint32_t* row_span_lo, uint32_t* row_span_cnt, uint64_t* span_key, uint4* span_cov, uint4* run_col,
-                       uint4* span_col, const uint8_t* unchanged /* per order, nullable */, FrameInfo* info);
+void launch_carry_rows(hipStream_t s, bool local_sort, const uint64_t* sorted_run_keys, TileRecord* records,
+                       const BlkEdge* blk_edge, DevCount n_segments, DevCount n_runs,
+                       const uint32_t* layer_sf /* per order: SF_* | LSF_VALID */, uint32_t n_orders, uint32_t tiles_w,
+                       uint32_t tiles_h, const uint32_t* row_count, uint32_t* row_span_lo, uint32_t* row_span_cnt,
+                       uint64_t* span_key, uint4* span_cov, const uint8_t* unchanged /* per order, nullable */, FrameInfo* info);
 void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, DevCount n_runs,
                   const uint32_t* tile_first_run, const uint32_t* row_span_lo, const uint32_t* row_span_cnt,
-                  const uint64_t* span_key, const uint4* span_cov, const uint4* run_col, const uint4* span_col,
+                  const uint64_t* span_key, const uint4* span_cov,
+                  const uint4* layer_col /* per order: style words 2..5 (clip: word 1) */,
                   const uint32_t* style_offsets, const uint32_t* style_words, const forma_image_t* images,
                   const uint16_t* texels, uint8_t* image, TileCacheArgs cache, FrameInfo* info, uint32_t* overflow_n /* zeroed by launch_runs */,
                   uint32_t* overflow_list /* tiles_w * tiles_h words */);

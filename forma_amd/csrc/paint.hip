@@ -130,7 +130,7 @@ __global__ __launch_bounds__(RN_THREADS) void k_runs_count(const uint64_t* __res
 // pass B: one workgroup per tile, no inter-workgroup dependency
 __global__ __launch_bounds__(RN_THREADS, 8) void k_runs(const uint64_t* __restrict__ sorted, DevCount nc, uint32_t tiles_w,
                                                         uint32_t tiles_h, TileRecord* __restrict__ records, uint32_t rec_cap,
-                                                        uint4* __restrict__ run_cov, uint64_t* __restrict__ run_keys,
+                                                        uint64_t* __restrict__ run_keys,
                                                         uint32_t* __restrict__ tile_first_run,
                                                         BlkEdge* __restrict__ blk_edge, uint32_t* __restrict__ row_count,
                                                         const uint32_t* __restrict__ run_counts, int counts_scanned,
@@ -247,11 +247,11 @@ __global__ __launch_bounds__(RN_THREADS, 8) void k_runs(const uint64_t* __restri
                 const uint32_t open = (sg == R && tile_n == RN_TILE) ? RUN_OPEN : 0u;
                 const uint32_t tyb = (uint32_t)(v >> 53), txb = (uint32_t)(v >> 41) & 0xFFFu, layer = seg_layer(v);
                 TileRecord rec;
-                rec.cover[0] = rec.cover[1] = rec.cover[2] = rec.cover[3] = 0;   // carry-in, written by k_carry_rows
+                const uint4 own = pack_bins(b);                                  // the run's own cover sum; k_carry_rows turns it
+                rec.cover[0] = own.x; rec.cover[1] = own.y; rec.cover[2] = own.z; rec.cover[3] = own.w;   // into the carry-in
                 rec.seg_start = base + i; rec.seg_count = cnt | open; rec.layer = layer; rec.tile = (uint32_t)(v >> 41);
                 if (j < rec_cap) {                                  // asynchronous frames provision for a predicted run count
                     records[j] = rec;
-                    run_cov[j] = pack_bins(b);
                     run_keys[j] = ((uint64_t)tyb << 53) | ((uint64_t)layer << 32) | j;
                 }
                 if (txb >= 1u && ((uint32_t)(pv >> 41) != (uint32_t)(v >> 41) || base + i == 0))
@@ -280,7 +280,7 @@ size_t runs_scratch_words(size_t n) { return (n + RN_TILE - 1) / RN_TILE + 16; }
 size_t runs_blocks(size_t n) { return (n + RN_TILE - 1) / RN_TILE + 1; }
 
 void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t tiles_w, uint32_t tiles_h, TileRecord* records,
-                 uint32_t rec_cap, uint4* run_cov, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge, uint32_t* row_tab,
+                 uint32_t rec_cap, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge, uint32_t* row_tab,
                  uint32_t* scratch, FrameInfo* info, bool verify_plan, uint64_t spec_live44, bool spec_layer_sorted) {
     // per-frame tile tables: [row_count | row_span_lo | row_span_cnt | painter overflow counter | first-run table] are
     // contiguous (api.cpp lays them out so) and zeroed by k_runs_count; 0 in the first-run table = the tile has no run
@@ -296,7 +296,7 @@ void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t ti
                        zero_words, info, spec_live44, flags);
     const int scanned = ntiles > 16384 ? 1 : 0;
     if (scanned) launch_scan_small_u32(s, scratch, nc, RN_TILE, &info->n_runs);   // exclusive, in place; total -> n_runs
-    hipLaunchKernelGGL(k_runs, dim3(ntiles), dim3(RN_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, records, rec_cap, run_cov, run_keys,
+    hipLaunchKernelGGL(k_runs, dim3(ntiles), dim3(RN_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, records, rec_cap, run_keys,
                        tile_first_run, blk_edge, row_tab, (const uint32_t*)scratch, scanned, info);
 }
 
@@ -323,20 +323,19 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // what the carry scan gathers per run, requested one piece ahead
 struct CarryLoad {
     bool active;
-    uint32_t group, jrun, layer, tile, sc, lsf;
-    uint4 oc, lcol;
+    uint32_t group, jrun, layer, tile, sc, seg_start, lsf;
+    uint4 oc;
 };
 template <bool LOCAL>
 __device__ __forceinline__ CarryLoad carry_load(uint32_t c0, int tid, uint32_t cnt, uint32_t row_lo, uint32_t n_runs, uint32_t ty,
                                                 const uint32_t* lkeys, const uint64_t* __restrict__ sorted_keys,
-                                                const TileRecord* __restrict__ records, const uint4* __restrict__ run_cov,
-                                                const uint32_t* __restrict__ layer_sf, const uint4* __restrict__ layer_col,
-                                                uint32_t n_orders) {
+                                                const TileRecord* __restrict__ records,
+                                                const uint32_t* __restrict__ layer_sf, uint32_t n_orders) {
     CarryLoad L;
     const uint32_t k = row_lo + c0 + tid;
     L.active = c0 + tid < cnt && k < n_runs;
-    L.group = 0xFFFFFFFEu; L.jrun = 0; L.layer = 0; L.tile = 0; L.sc = 0; L.lsf = 0;
-    L.oc = make_uint4(0, 0, 0, 0); L.lcol = make_uint4(0, 0, 0, 0);
+    L.group = 0xFFFFFFFEu; L.jrun = 0; L.layer = 0; L.tile = 0; L.sc = 0; L.seg_start = 0; L.lsf = 0;
+    L.oc = make_uint4(0, 0, 0, 0);
     if (L.active) {
         if (LOCAL) {
             const uint32_t pk = lkeys[c0 + tid];
@@ -345,9 +344,12 @@ __device__ __forceinline__ CarryLoad carry_load(uint32_t c0, int tid, uint32_t c
             const uint64_t key = sorted_keys[k];
             L.group = (uint32_t)(key >> 32); L.jrun = (uint32_t)key; L.layer = L.group & 0x1FFFFFu;
         }
-        L.tile = records[L.jrun].tile; L.sc = records[L.jrun].seg_count;
-        L.oc = run_cov[L.jrun];
-        if (L.layer < n_orders) { L.lsf = layer_sf[L.layer]; L.lcol = layer_col[L.layer]; }
+        // the record in two 16-byte gathers (one cache line): own cover sum | seg_start, seg_count, layer, tile
+        const uint4* rp = reinterpret_cast<const uint4*>(&records[L.jrun]);
+        L.oc = rp[0];
+        const uint4 tail = rp[1];
+        L.seg_start = tail.x; L.sc = tail.y; L.tile = tail.w;
+        if (L.layer < n_orders) L.lsf = layer_sf[L.layer];
     }
     return L;
 }
@@ -361,17 +363,14 @@ __device__ __forceinline__ CarryLoad carry_load(uint32_t c0, int tid, uint32_t c
 template <bool LOCAL>
 __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __restrict__ sorted_keys,
                                                            TileRecord* __restrict__ records,
-                                                           uint4* __restrict__ run_cov,
                                                            const BlkEdge* __restrict__ blk_edge, DevCount nc_segments,
                                                            DevCount nc_runs,
-                                                           const uint32_t* __restrict__ layer_sf,
-                                                           const uint4* __restrict__ layer_col, uint32_t n_orders,
+                                                           const uint32_t* __restrict__ layer_sf, uint32_t n_orders,
                                                            uint32_t tiles_w, uint32_t tiles_h,
                                                            const uint32_t* __restrict__ row_count,
                                                            uint32_t* __restrict__ row_span_lo,
                                                            uint32_t* __restrict__ row_span_cnt,
                                                            uint64_t* __restrict__ span_key, uint4* __restrict__ span_cov,
-                                                           uint4* __restrict__ run_col, uint4* __restrict__ span_col,
                                                            const uint8_t* __restrict__ unchanged,
                                                            FrameInfo* __restrict__ info) {
     __shared__ uint32_t s_red[CR_WAVES];
@@ -473,16 +472,15 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
     // are looked at: the span of lane 1022 ends where that run begins).  Everything a piece gathers from HBM — record,
     // cover sums, the layer's style summary — is requested one piece ahead; the barriers inside the loop order LDS only
     // (lds_barrier: no vmcnt wait), so those requests stay in flight behind the scan of the current piece.
-    CarryLoad nx = carry_load<LOCAL>(0, tid, cnt, row_lo, n_runs, ty, lkeys, sorted_keys, records, run_cov, layer_sf, layer_col, n_orders);
+    CarryLoad nx = carry_load<LOCAL>(0, tid, cnt, row_lo, n_runs, ty, lkeys, sorted_keys, records, layer_sf, n_orders);
     for (uint32_t c0 = 0; c0 < cnt; c0 += CR_CHUNK) {
         const CarryLoad cu = nx;
         if (c0 + CR_CHUNK < cnt)
-            nx = carry_load<LOCAL>(c0 + CR_CHUNK, tid, cnt, row_lo, n_runs, ty, lkeys, sorted_keys, records, run_cov, layer_sf, layer_col, n_orders);
+            nx = carry_load<LOCAL>(c0 + CR_CHUNK, tid, cnt, row_lo, n_runs, ty, lkeys, sorted_keys, records, layer_sf, n_orders);
         const bool active = cu.active && tid < CR_CHUNK;                 // lane 1023 only looks ahead
         const uint32_t group = cu.active ? cu.group : 0xFFFFFFFEu, jrun = cu.jrun, layer = cu.layer;
         uint32_t txb = 0, sfl = 0, unch = 0;
         uint64_t own_lo = 0, own_hi = 0;
-        uint4 scol = make_uint4(0, 0, 0, 0);
         bool even_odd = false;
         if (cu.active) txb = cu.tile & 0xFFFu;
         if (active) {
@@ -491,7 +489,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
             uint32_t sc = cu.sc;
             if (sc & RUN_OPEN) {                         // complete a run that crosses k_runs tiles with their edges
                 sc &= ~RUN_OPEN;
-                for (uint32_t b = r->seg_start / RN_TILE + 1; b < n_blk; b++) {
+                for (uint32_t b = cu.seg_start / RN_TILE + 1; b < n_blk; b++) {
                     const BlkEdge e = blk_edge[b];
                     own_lo = swar_add8(own_lo, (uint64_t)e.cov[0] | ((uint64_t)e.cov[1] << 32));
                     own_hi = swar_add8(own_hi, (uint64_t)e.cov[2] | ((uint64_t)e.cov[3] << 32));
@@ -503,10 +501,9 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
             if (cu.lsf & LSF_VALID) {
                 // everything the painter's optimizer passes need to know about the layer's style, so that a tile can
                 // classify its whole layer list without touching the style table (SF_* bits ride in the entry keys)
-                sfl = cu.lsf & ~LSF_VALID; scol = cu.lcol;
+                sfl = cu.lsf & ~LSF_VALID;
                 even_odd = (sfl & SF_EVENODD) != 0;
                 r->layer = layer | (sfl << 21);
-                run_col[jrun] = scol;
                 if (unchanged && unchanged[layer]) { unch = 1u; r->tile = cu.tile | 0x80000000u; }   // Layer::is_unchanged(cache_id)
             } else atomicOr(&info->error, 1u);
         }
@@ -579,7 +576,6 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
             const uint32_t full = cover_full(c4, even_odd) ? SF_FULL : 0u;
             span_key[si] = ((uint64_t)(layer | ((sfl | full) << 21)) << 32) | ((uint64_t)unch << 31) | ((uint64_t)span_lo << 16) | span_hi;
             span_cov[si] = make_uint4(c4[0], c4[1], c4[2], c4[3]);
-            span_col[si] = scol;
         }
         lds_barrier();
         if (tid == CR_CHUNK - 1) { s_clo = lo; s_chi = hi; s_cgroup = group; }     // only used when the piece is full
@@ -591,21 +587,20 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
 
 uint32_t carry_rows_local_cap() { return CR_CAP; }
 
-void launch_carry_rows(hipStream_t s, bool local_sort, const uint64_t* sorted_run_keys, TileRecord* records, uint4* run_cov,
+void launch_carry_rows(hipStream_t s, bool local_sort, const uint64_t* sorted_run_keys, TileRecord* records,
                        const BlkEdge* blk_edge, DevCount n_segments, DevCount n_runs, const uint32_t* layer_sf,
-                       const uint4* layer_col,
                        uint32_t n_orders, uint32_t tiles_w, uint32_t tiles_h, const uint32_t* row_count,
-                       uint32_t* row_span_lo, uint32_t* row_span_cnt, uint64_t* span_key, uint4* span_cov, uint4* run_col,
-                       uint4* span_col, const uint8_t* unchanged, FrameInfo* info) {
+                       uint32_t* row_span_lo, uint32_t* row_span_cnt, uint64_t* span_key, uint4* span_cov,
+                       const uint8_t* unchanged, FrameInfo* info) {
     if (tiles_h == 0) return;
     if (local_sort)
-        hipLaunchKernelGGL(k_carry_rows<true>, dim3(tiles_h), dim3(CR_THREADS), 0, s, sorted_run_keys, records, run_cov, blk_edge,
-                           n_segments, n_runs, layer_sf, layer_col, n_orders, tiles_w, tiles_h, row_count, row_span_lo,
-                           row_span_cnt, span_key, span_cov, run_col, span_col, unchanged, info);
+        hipLaunchKernelGGL(k_carry_rows<true>, dim3(tiles_h), dim3(CR_THREADS), 0, s, sorted_run_keys, records, blk_edge,
+                           n_segments, n_runs, layer_sf, n_orders, tiles_w, tiles_h, row_count, row_span_lo,
+                           row_span_cnt, span_key, span_cov, unchanged, info);
     else
-        hipLaunchKernelGGL(k_carry_rows<false>, dim3(tiles_h), dim3(CR_THREADS), 0, s, sorted_run_keys, records, run_cov, blk_edge,
-                           n_segments, n_runs, layer_sf, layer_col, n_orders, tiles_w, tiles_h, row_count, row_span_lo,
-                           row_span_cnt, span_key, span_cov, run_col, span_col, unchanged, info);
+        hipLaunchKernelGGL(k_carry_rows<false>, dim3(tiles_h), dim3(CR_THREADS), 0, s, sorted_run_keys, records, blk_edge,
+                           n_segments, n_runs, layer_sf, n_orders, tiles_w, tiles_h, row_count, row_span_lo,
+                           row_span_cnt, span_key, span_cov, unchanged, info);
 }
 
 // ================================================================================================
@@ -905,7 +900,7 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
                                            const uint32_t* __restrict__ row_span_lo,
                                            const uint32_t* __restrict__ row_span_cnt,
                                            const uint64_t* __restrict__ span_key, const uint4* __restrict__ span_cov,
-                                           const uint4* __restrict__ run_col, const uint4* __restrict__ span_col,
+                                           const uint4* __restrict__ layer_col,
                                            const uint32_t* __restrict__ style_offsets,
                                            const uint32_t* __restrict__ style_words,
                                            const forma_image_t* __restrict__ images,
@@ -1120,8 +1115,7 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
             const uint32_t nbt = min((uint32_t)PBATCH, ne - k0);
             __syncthreads();
             if ((uint32_t)tid < nbt) {
-                const uint32_t ref = (uint32_t)keys[k0 + tid];
-                b_col[tid] = (ref & 0x80000000u) ? span_col[ref & REF_IDX] : run_col[ref & REF_IDX];
+                b_col[tid] = layer_col[(uint32_t)(keys[k0 + tid] >> 32) & LAYER_MASK];
             }
             __syncthreads();
             if (tid == 0) {
@@ -1198,13 +1192,13 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
             const uint32_t ref = (uint32_t)k;
             b_flag[tid] = flags[i] | ((uint32_t)(k >> 53) << 16);           // EF_* low, SF_* (blend / fill) high
             b_layer[tid] = (uint32_t)(k >> 32) & LAYER_MASK;
+            b_col[tid] = layer_col[(uint32_t)(k >> 32) & LAYER_MASK];
             if (ref & 0x80000000u) {
-                b_cov[tid] = span_cov[ref & REF_IDX]; b_col[tid] = span_col[ref & REF_IDX];
+                b_cov[tid] = span_cov[ref & REF_IDX];
                 b_seg0[tid] = 0; b_nseg[tid] = 0;
             } else {
                 const TileRecord* r = &records[ref & REF_IDX];
                 b_cov[tid] = make_uint4(r->cover[0], r->cover[1], r->cover[2], r->cover[3]);
-                b_col[tid] = run_col[ref & REF_IDX];
                 b_seg0[tid] = r->seg_start; b_nseg[tid] = r->seg_count;
             }
         }
@@ -1314,8 +1308,7 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
                                                     const uint32_t* __restrict__ row_span_lo,
                                                     const uint32_t* __restrict__ row_span_cnt,
                                                     const uint64_t* __restrict__ span_key,
-                                                    const uint4* __restrict__ span_cov, const uint4* __restrict__ run_col,
-                                                    const uint4* __restrict__ span_col,
+                                                    const uint4* __restrict__ span_cov, const uint4* __restrict__ layer_col,
                                                     const uint32_t* __restrict__ style_offsets,
                                                     const uint32_t* __restrict__ style_words,
                                                     const forma_image_t* __restrict__ images,
@@ -1493,8 +1486,7 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
             const uint32_t nbt = min((uint32_t)WB, ne - k0);
             wave_lds_sync();
             if ((uint32_t)lane < nbt) {
-                const uint32_t ref = (uint32_t)keys[k0 + lane];
-                b_col[lane] = (ref & 0x80000000u) ? span_col[ref & REF_IDX] : run_col[ref & REF_IDX];
+                b_col[lane] = layer_col[(uint32_t)(keys[k0 + lane] >> 32) & LAYER_MASK];
             }
             wave_lds_sync();
             for (uint32_t t = 0; t < nbt && ok; t++) {                 // every lane folds the same (uniform) values
@@ -1560,13 +1552,13 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
             const uint32_t ref = (uint32_t)k;
             b_flag[lane] = flags[i] | ((uint32_t)(k >> 53) << 16);
             b_layer[lane] = (uint32_t)(k >> 32) & LAYER_MASK;
+            b_col[lane] = layer_col[(uint32_t)(k >> 32) & LAYER_MASK];
             if (ref & 0x80000000u) {
-                b_cov[lane] = span_cov[ref & REF_IDX]; b_col[lane] = span_col[ref & REF_IDX];
+                b_cov[lane] = span_cov[ref & REF_IDX];
                 b_seg0[lane] = 0; b_nseg[lane] = 0;
             } else {
                 const TileRecord* r = &records[ref & REF_IDX];
                 b_cov[lane] = make_uint4(r->cover[0], r->cover[1], r->cover[2], r->cover[3]);
-                b_col[lane] = run_col[ref & REF_IDX];
                 b_seg0[lane] = r->seg_start; b_nseg[lane] = r->seg_count;
             }
         }
@@ -1664,12 +1656,12 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
     }
 }
 
-#define PAINT_ARGS P, tile, sorted, records, n_runs, tile_first_run, row_span_lo, row_span_cnt, span_key, span_cov, run_col, span_col, \
+#define PAINT_ARGS P, tile, sorted, records, n_runs, tile_first_run, row_span_lo, row_span_cnt, span_key, span_cov, layer_col, \
                    style_offsets, style_words, images, texels, image, cache, info
 #define PAINT_PARAMS PaintParams P, const uint64_t* __restrict__ sorted, const TileRecord* __restrict__ records, DevCount nc_runs, \
                      const uint32_t* __restrict__ tile_first_run, const uint32_t* __restrict__ row_span_lo, \
                      const uint32_t* __restrict__ row_span_cnt, const uint64_t* __restrict__ span_key, \
-                     const uint4* __restrict__ span_cov, const uint4* __restrict__ run_col, const uint4* __restrict__ span_col, \
+                     const uint4* __restrict__ span_cov, const uint4* __restrict__ layer_col, \
                      const uint32_t* __restrict__ style_offsets, const uint32_t* __restrict__ style_words, \
                      const forma_image_t* __restrict__ images, const uint16_t* __restrict__ texels, uint8_t* __restrict__ image, \
                      TileCacheArgs cache, FrameInfo* __restrict__ info
@@ -1690,7 +1682,7 @@ __global__ __launch_bounds__(256) void k_paint_deep(PAINT_PARAMS, const uint32_t
 
 void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, DevCount n_runs,
                   const uint32_t* tile_first_run, const uint32_t* row_span_lo, const uint32_t* row_span_cnt,
-                  const uint64_t* span_key, const uint4* span_cov, const uint4* run_col, const uint4* span_col,
+                  const uint64_t* span_key, const uint4* span_cov, const uint4* layer_col,
                   const uint32_t* style_offsets, const uint32_t* style_words, const forma_image_t* images,
                   const uint16_t* texels, uint8_t* image, TileCacheArgs cache, FrameInfo* info, uint32_t* overflow_n,
                   uint32_t* overflow_list) {
@@ -1698,9 +1690,9 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
     if (T == 0 || p.crop_y1 <= p.crop_y0) return;
     const uint32_t per = ((p.crop_y1 - p.crop_y0) * p.tiles_w + 7) / 8;
     hipLaunchKernelGGL(k_paint_wave, dim3(per * 8), dim3(64), 0, s, p, sorted, records, n_runs, tile_first_run, row_span_lo,
-                       row_span_cnt, span_key, span_cov, run_col, span_col, style_offsets, style_words, images, texels, image,
+                       row_span_cnt, span_key, span_cov, layer_col, style_offsets, style_words, images, texels, image,
                        cache, info, overflow_n, overflow_list);
     hipLaunchKernelGGL(k_paint_deep, dim3(T < 256 ? T : 256), dim3(256), 0, s, p, sorted, records, n_runs, tile_first_run,
-                       row_span_lo, row_span_cnt, span_key, span_cov, run_col, span_col, style_offsets, style_words, images,
+                       row_span_lo, row_span_cnt, span_key, span_cov, layer_col, style_offsets, style_words, images,
                        texels, image, cache, info, (const uint32_t*)overflow_n, (const uint32_t*)overflow_list);
 }
