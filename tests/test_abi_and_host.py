@@ -91,3 +91,38 @@ def test_host_path_builder_closes_contours():
     from forma_amd.api import _host
     # 3 points + the closing line back to the start = 4 flattened points, all produced without a GPU
     assert _host().forma_host_path_points(p._h) == 4
+
+
+def test_header_is_plain_c_and_struct_layouts_match_ctypes(tmp_path):
+    """The boundary is a C ABI: include/forma_hip.h must compile as C11 (what cgo / bindgen / a Rust `extern "C"` block
+    consume), and the struct sizes / field offsets the Python binding assumes must be the compiler's."""
+    import shutil
+    import subprocess
+    from forma_amd import context
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    prog = tmp_path / "abi.c"
+    prog.write_text(r'''
+#include <stddef.h>
+#include <stdio.h>
+#include "forma_hip.h"
+int main(void) {
+    printf("geom %zu %zu %zu %zu\n", sizeof(forma_geom_t), offsetof(forma_geom_t, order), offsetof(forma_geom_t, flags), offsetof(forma_geom_t, xf));
+    printf("rect %zu\n", sizeof(forma_rect_t));
+    printf("image %zu\n", sizeof(forma_image_t));
+    printf("timings %zu %zu %zu\n", sizeof(forma_timings_t), offsetof(forma_timings_t, n_lines), offsetof(forma_timings_t, n_tile_entries));
+    return 0;
+}
+''')
+    exe = tmp_path / "abi"
+    subprocess.run([gcc, "-std=c11", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(prog), "-o", str(exe)],
+                   check=True)
+    out = dict(line.split(" ", 1) for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    g = context.GEOM_DTYPE
+    assert out["geom"].split() == [str(g.itemsize), str(g.fields["order"][1]), str(g.fields["flags"][1]), str(g.fields["xf"][1])]
+    assert int(out["image"]) == context.IMAGE_DTYPE.itemsize
+    assert int(out["rect"]) == 16
+    from forma_amd import _lib
+    t = _lib.TimingsT
+    assert out["timings"].split() == [str(C.sizeof(t)), str(t.n_lines.offset), str(t.n_tile_entries.offset)]
