@@ -293,3 +293,28 @@ def test_svg_loader_route_matches_oracle():
     S.load(o2, r2.host_tables)
     want2 = o2.render(2 * W, 2 * H, clear=(1.0, 1.0, 1.0, 1.0))
     assert np.abs(want2.astype(np.int16) - img2.reshape(want2.shape).astype(np.int16)).max() <= 1
+
+
+def test_paris_like_30k_4k_full_size():
+    """BASELINE.json configs[2] — the workload bench.py reports — at full size through the product API: 30 000 layers
+    (solid / linear / radial fills, 16 blend modes, translucent) on 3840 x 2160, ~13.8 M pixel segments.  Both segment
+    streams bit-exact against the oracle, image within 1 code value, on the synchronous first frame and on a
+    read-back-free second frame."""
+    from forma_amd import api, scenes
+    fn, W, H = scenes.WORKLOADS["paris-like-30k-4k"]
+    comp = fn()
+    r = api.Renderer(0)
+    img = np.zeros(W * H * 4, np.uint8)
+    lay = api.LinearLayout(W, W * 4, H)
+    r.render(comp, api.BufferBuilder(img, lay).build(), api.RGBA, api.Color(1, 1, 1, 1), None, timings=True)
+    assert r.last_timings["n_segments"] > 13_000_000
+    o = orc.Oracle()
+    S.load(o, r.host_tables)
+    want = o.render(W, H, clear=(1.0, 1.0, 1.0, 1.0))
+    assert np.array_equal(o.segments(0), r._ctx.segments(0))
+    assert np.array_equal(o.segments(1), r._ctx.segments(1))
+    d = np.abs(want.astype(np.int16) - img.reshape(want.shape).astype(np.int16))
+    assert d.max() <= 1, (int(d.max()), int((d > 0).sum()))
+    img2 = np.zeros(W * H * 4, np.uint8)
+    r.render(comp, api.BufferBuilder(img2, lay).build(), api.RGBA, api.Color(1, 1, 1, 1), None)
+    assert np.array_equal(img, img2)
