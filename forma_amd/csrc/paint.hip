@@ -89,12 +89,13 @@ __device__ __forceinline__ uint4 pack_bins(const int* b) {
 }
 
 // pass A: paintable run heads per tile (the run index of a tile's first head is the exclusive scan of these)
-__global__ __launch_bounds__(RN_THREADS) void k_runs_count(const uint64_t* __restrict__ sorted, DevCount nc, uint32_t tiles_w,
+#define RC_THREADS 256
+__global__ __launch_bounds__(RC_THREADS) void k_runs_count(const uint64_t* __restrict__ sorted, DevCount nc, uint32_t tiles_w,
                                                            uint32_t tiles_h, uint32_t* __restrict__ counts,
                                                            uint32_t* __restrict__ zero_base, uint32_t zero_words,
                                                            FrameInfo* __restrict__ info, uint64_t spec_live44,
                                                            uint32_t spec_flags /* bit0 verify, bit1 layer_sorted */) {
-    __shared__ uint32_t s_c[RN_WAVES];
+    __shared__ uint32_t s_c[RC_THREADS / 64];
     const uint32_t n = dev_count(nc);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // housekeeping that would otherwise be separate launches: zero this frame's tile tables (row counts, span tables,
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(RN_THREADS) void k_runs_count(const uint64_t* __res
     {
         const uint32_t per = (zero_words + gridDim.x - 1) / gridDim.x;
         const uint32_t z0 = blockIdx.x * per, z1 = min(zero_words, z0 + per);
-        for (uint32_t i = z0 + tid; i < z1; i += RN_THREADS) zero_base[i] = 0;
+        for (uint32_t i = z0 + tid; i < z1; i += RC_THREADS) zero_base[i] = 0;
         if (blockIdx.x == 0 && tid == 0 && nc.ptr && *nc.ptr > nc.bound) info->plan_bad = 1u;   // more segments than provisioned
         if (blockIdx.x == 0 && tid == 0 && (spec_flags & 1u) && info->n_segments) {
             const uint64_t k_or = (uint64_t)info->key_or | ((uint64_t)info->key_or_hi << 32);
@@ -111,20 +112,38 @@ __global__ __launch_bounds__(RN_THREADS) void k_runs_count(const uint64_t* __res
             if (((k_or ^ k_and) & 0xFFFFFFFFFFFull) != spec_live44 || sorted_now != (spec_flags & 2u)) info->plan_bad = 1u;
         }
     }
-    const uint32_t base = blockIdx.x * RN_TILE;
-    uint32_t c = 0;
+    // A pure streaming read, shaped like the copy kernels that reach 6 TB/s on this chip (tools/ubench_bw.hip): 256-lane
+    // workgroups in a grid-stride loop, eight 16-byte loads (two consecutive segments each) in flight per lane.  One
+    // iteration covers two k_runs tiles (waves 0-1 and 2-3).
+    const uint4* s4 = (const uint4*)sorted;                              // hipMalloc'd: 16-byte aligned
+    const uint32_t ntiles = (n + RN_TILE - 1) / RN_TILE;
+    for (uint32_t t0 = blockIdx.x * 2; t0 < ntiles; t0 += gridDim.x * 2) {
+        const uint32_t wbase = t0 * RN_TILE + w * 1024;                   // this wave's 1024 consecutive segments
+        uint4 v[8];
 #pragma unroll
-    for (int r = 0; r < RN_IPT; r++) {
-        const uint32_t idx = base + r * RN_THREADS + tid;
-        const uint64_t v = idx < n ? sorted[idx] : 0ull;
-        uint64_t pv = __shfl_up(v, 1, 64);
-        if (lane == 0) pv = (idx > 0 && idx < n) ? sorted[idx - 1] : 0ull;
-        const bool val = idx < n && ((((v ^ pv) >> SEG_KEY_SHIFT) != 0) || idx == 0) && seg_paintable(v, tiles_w, tiles_h);
-        c += (uint32_t)__popcll(__ballot(val));
+        for (int q = 0; q < 8; q++) {
+            const uint32_t i0 = wbase + q * 128 + lane * 2;
+            v[q] = i0 + 1 < n ? s4[i0 >> 1] : make_uint4(0, 0, 0, 0);
+            if (i0 + 1 == n) { const uint64_t k = sorted[i0]; v[q].x = (uint32_t)k; v[q].y = (uint32_t)(k >> 32); }
+        }
+        uint64_t before = (wbase > 0 && wbase < n) ? sorted[wbase - 1] : 0ull;   // the segment in front of the wave's piece
+        uint32_t c = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t i0 = wbase + q * 128 + lane * 2;
+            const uint64_t k0 = (uint64_t)v[q].x | ((uint64_t)v[q].y << 32), k1 = (uint64_t)v[q].z | ((uint64_t)v[q].w << 32);
+            uint64_t pk = __shfl_up(k1, 1, 64);
+            if (lane == 0) pk = before;
+            before = __shfl(k1, 63, 64);
+            const bool h0 = i0 < n && ((((k0 ^ pk) >> SEG_KEY_SHIFT) != 0) || i0 == 0) && seg_paintable(k0, tiles_w, tiles_h);
+            const bool h1 = i0 + 1 < n && (((k1 ^ k0) >> SEG_KEY_SHIFT) != 0) && seg_paintable(k1, tiles_w, tiles_h);
+            c += (uint32_t)__popcll(__ballot(h0)) + (uint32_t)__popcll(__ballot(h1));
+        }
+        if (lane == 0) s_c[w] = c;
+        __syncthreads();
+        if (tid < 2 && t0 + tid < ntiles) counts[t0 + tid] = s_c[2 * tid] + s_c[2 * tid + 1];
+        __syncthreads();
     }
-    if (lane == 0) s_c[w] = c;
-    __syncthreads();
-    if (tid == 0) { uint32_t t = 0; for (int q = 0; q < RN_WAVES; q++) t += s_c[q]; counts[blockIdx.x] = t; }
 }
 
 // pass B: one workgroup per tile, no inter-workgroup dependency
@@ -292,7 +311,8 @@ void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t ti
     }
     const uint32_t ntiles = (nc.bound + RN_TILE - 1) / RN_TILE;
     const uint32_t flags = (verify_plan ? 1u : 0u) | (spec_layer_sorted ? 2u : 0u);
-    hipLaunchKernelGGL(k_runs_count, dim3(ntiles), dim3(RN_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, scratch, row_tab,
+    const uint32_t cgrid = std::min<uint32_t>((ntiles + 1) / 2, 4096u);
+    hipLaunchKernelGGL(k_runs_count, dim3(cgrid), dim3(RC_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, scratch, row_tab,
                        zero_words, info, spec_live44, flags);
     const int scanned = ntiles > 16384 ? 1 : 0;
     if (scanned) launch_scan_small_u32(s, scratch, nc, RN_TILE, &info->n_runs);   // exclusive, in place; total -> n_runs
