@@ -34,6 +34,7 @@
 // up-front histograms of every planned digit: hist[p * 256 + d].  Per-lane run-length compression
 // (consecutive keys of a lane mostly share their tile digits) keeps the LDS atomics rare.
 // ------------------------------------------------------------------------------------------------
+#define HS_COPIES  8
 #define HS_THREADS 256
 #define HS_KPT     16
 #define HS_TILE    (HS_THREADS * HS_KPT)
@@ -76,9 +77,13 @@ __global__ __launch_bounds__(HS_THREADS) void k_sort_hist(const uint64_t* __rest
         }
     }
     __syncthreads();
+    // the flush is up to 256 x P global atomics per workgroup on the same few hundred words: HS_COPIES private copies (one
+    // per workgroup residue class, i.e. per XCD under round-robin dispatch) cut the same-address queue by that factor;
+    // k_onesweep adds the copies up when it scans the histogram
+    uint32_t* mine = hist + (size_t)(blockIdx.x % HS_COPIES) * (SORT_MAX_PASSES * 256);
     for (int i = threadIdx.x; i < P * 256; i += HS_THREADS) {
         uint32_t v = lh[i];
-        if (v) atomicAdd(&hist[i], v);
+        if (v) atomicAdd(&mine[i], v);
     }
 }
 
@@ -127,7 +132,11 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
     // global digit starts = exclusive scan of this pass's histogram (identical in every block)
     uint32_t gstart = 0;
     {
-        uint32_t g = (tid < RADIX) ? ghist[tid] : 0u, dummy = 0;
+        uint32_t g = 0, dummy = 0;
+        if (tid < RADIX) {
+#pragma unroll
+            for (int c = 0; c < HS_COPIES; c++) g += ghist[(size_t)c * (SORT_MAX_PASSES * 256) + tid];
+        }
         scan2_excl<RADIX>(g, dummy, s_scan);
         gstart = g;
     }
@@ -261,8 +270,8 @@ SortPlan make_sort_plan(uint64_t live_mask, int lo_bit, int hi_bit, int digit_bi
 
 size_t sort_scratch_words(size_t n) {
     size_t ntiles = (n + OS_TILE - 1) / OS_TILE;
-    // [hist: MAX_PASSES*256] [tickets: MAX_PASSES] [pad to 64] [status: MAX_PASSES * ntiles * 256]
-    return (size_t)SORT_MAX_PASSES * 256 + 64 + (size_t)SORT_MAX_PASSES * (ntiles + 1) * 256;
+    // [hist: HS_COPIES x MAX_PASSES*256] [tickets: MAX_PASSES] [pad to 64] [status: MAX_PASSES * ntiles * 256]
+    return (size_t)HS_COPIES * SORT_MAX_PASSES * 256 + 64 + (size_t)SORT_MAX_PASSES * (ntiles + 1) * 256;
 }
 
 const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a, uint64_t* b, DevCount nc,
@@ -272,11 +281,11 @@ const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a
     if (n <= 1 || plan.n_passes == 0) return in;
     const uint32_t ntiles = (uint32_t)((n + OS_TILE - 1) / OS_TILE);
     uint32_t* hist = scratch;
-    uint32_t* tickets = scratch + (size_t)SORT_MAX_PASSES * 256;
+    uint32_t* tickets = scratch + (size_t)HS_COPIES * SORT_MAX_PASSES * 256;
     uint32_t* status = tickets + 64;
     const int P = plan.n_passes;
     // zero hist + tickets + the status words of the passes that run (re-initialised every call)
-    (void)hipMemsetAsync(scratch, 0, ((size_t)SORT_MAX_PASSES * 256 + 64 + (size_t)P * ntiles * 256) * 4, s);
+    (void)hipMemsetAsync(scratch, 0, ((size_t)HS_COPIES * SORT_MAX_PASSES * 256 + 64 + (size_t)P * ntiles * 256) * 4, s);
     uint32_t hb = (uint32_t)((n + HS_TILE - 1) / HS_TILE);
     if (hb > 1024) hb = 1024;                             // few workgroups: the final flush is 256 x passes global atomics each
     hipLaunchKernelGGL(k_sort_hist, dim3(hb), dim3(HS_THREADS), 0, s, in, nc, plan, hist);
