@@ -34,7 +34,7 @@
 // up-front histograms of every planned digit: hist[p * 256 + d].  Per-lane run-length compression
 // (consecutive keys of a lane mostly share their tile digits) keeps the LDS atomics rare.
 // ------------------------------------------------------------------------------------------------
-#define HS_COPIES  8
+#define HS_COPIES  16
 #define HS_THREADS 256
 #define HS_KPT     16
 #define HS_TILE    (HS_THREADS * HS_KPT)
@@ -287,7 +287,7 @@ const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a
     // zero hist + tickets + the status words of the passes that run (re-initialised every call)
     (void)hipMemsetAsync(scratch, 0, ((size_t)HS_COPIES * SORT_MAX_PASSES * 256 + 64 + (size_t)P * ntiles * 256) * 4, s);
     uint32_t hb = (uint32_t)((n + HS_TILE - 1) / HS_TILE);
-    if (hb > 1024) hb = 1024;                             // few workgroups: the final flush is 256 x passes global atomics each
+    if (hb > 2048) hb = 2048;                             // few workgroups: the final flush is 256 x passes global atomics each
     hipLaunchKernelGGL(k_sort_hist, dim3(hb), dim3(HS_THREADS), 0, s, in, nc, plan, hist);
     const uint32_t cap = 512u * 512u / OS_THREADS;        // persistent: 16 waves per CU
     uint32_t grid = ntiles < cap ? ntiles : cap;
