@@ -507,12 +507,13 @@ __global__ __launch_bounds__(RAS_THREADS) void k_rasterize(LineSource S, DevCoun
         uint32_t o = 0, oh = 0, a = 0xFFFFFFFFu, ah = 0xFFFFFFFFu, u = 0;
         for (int i = 0; i < RAS_THREADS / 64; i++) { o |= red[0][i]; oh |= red[1][i]; a &= red[2][i]; ah &= red[3][i]; u |= red[4][i]; }
         // the masks saturate after a few workgroups: only touch the (single-address, serialising) atomics when this
-        // workgroup adds information; a stale read merely costs a redundant atomic
-        if (o & ~lb_ld32(&info->key_or)) atomicOr(&info->key_or, o);
-        if (oh & ~lb_ld32(&info->key_or_hi)) atomicOr(&info->key_or_hi, oh);
-        if (~a & lb_ld32(&info->key_and)) atomicAnd(&info->key_and, a);
-        if (~ah & lb_ld32(&info->key_and_hi)) atomicAnd(&info->key_and_hi, ah);
-        if (u && !lb_ld32(&info->layer_unsorted)) atomicOr(&info->layer_unsorted, 1u);
+        // workgroup adds information; the reads go through the caches: a stale one merely costs a redundant atomic (which
+        // drops the line from this XCD's L2, so the next read is fresh)
+        if (o & ~lb_ld32_cached(&info->key_or)) atomicOr(&info->key_or, o);
+        if (oh & ~lb_ld32_cached(&info->key_or_hi)) atomicOr(&info->key_or_hi, oh);
+        if (~a & lb_ld32_cached(&info->key_and)) atomicAnd(&info->key_and, a);
+        if (~ah & lb_ld32_cached(&info->key_and_hi)) atomicAnd(&info->key_and_hi, ah);
+        if (u && !lb_ld32_cached(&info->layer_unsorted)) atomicOr(&info->layer_unsorted, 1u);
     }
 }
 

@@ -23,6 +23,11 @@ typedef __attribute__((address_space(1))) unsigned long long lb_gu64;
 __device__ __forceinline__ uint32_t lb_ld32(const uint32_t* p) {
     return __hip_atomic_load((lb_gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Same word through the caches (no coherence bits): may be STALE.  Only for hints whose staleness costs a redundant
+// operation, never correctness.
+__device__ __forceinline__ uint32_t lb_ld32_cached(const uint32_t* p) {
+    return __hip_atomic_load((lb_gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+}
 __device__ __forceinline__ void lb_st32(uint32_t* p, uint32_t v) {
     __hip_atomic_store((lb_gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
