@@ -9,9 +9,11 @@ work is a frame, every GPU renders whole frames, per-GPU work is fixed (weak sca
 exchanged on the data path; `--mode bands` splits ONE frame into tile-row bands (SURVEY.md §8e, strong
 scaling).  `value` is the whole-job aggregate: frames completed by all GPUs / max-over-ranks wall time.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME | --svg FILE [--svg-scale S]] [--animated]
 
-Prints ONE JSON line on rank 0.
+`--svg` renders a real SVG document (e.g. the reference's paris-30k.svg, which is not in its checkout) through
+forma_amd/svg.py instead of the labelled stand-in; `--animated` adds the BASELINE config-5 leg (spaceship-like scene with
+and without the buffer-layer cache) under "animated".  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
