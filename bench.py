@@ -226,9 +226,19 @@ def animated_leg(local, frames=240):
             ctx.render(W, H, clear=(0, 0, 0, 1), cache_id=cache_id, device_only=True)
         torch.cuda.synchronize()
         res[label] = round(frames / (time.perf_counter() - t0), 1)
+    # damaged-tile fraction: tiles the cached frames actually rewrite, from a few frames rendered into a host buffer
+    host = np.zeros((H, W * 4), np.uint8)
+    damaged = []
+    for i in range(frames + 10, frames + 18):
+        geoms["xf"][slots] = scenes.spaceship_transforms(state, i / 60.0)
+        ctx.set_geoms(geoms)
+        ctx.set_styles(t["style_offsets"], t["style_words"], unchanged)
+        _, tm = ctx.render(W, H, clear=(0, 0, 0, 1), cache_id=0, dst=host, timings=True)
+        damaged.append(tm["n_tiles_written"])
+    tiles = ((W + 15) // 16) * ((H + 15) // 16)
     return {"workload": "spaceship-like-4k (400 static + 121 moving layers, 60 Hz transforms)", "frames": frames,
             "fps_no_cache": res["no_cache"], "fps_with_cache": res["with_cache"], "unit": "frames/s, device-resident, "
-            "including the per-frame layer-table upload"}
+            "including the per-frame layer-table upload", "damaged_tile_fraction": round(float(np.mean(damaged)) / tiles, 4)}
 
 
 def cpu_baseline(renderer, width, height, budget_s):

@@ -41,10 +41,10 @@ class TimingsT(C.Structure):
     _fields_ = [("prepare_us", C.c_float), ("rasterize_us", C.c_float), ("sort_us", C.c_float), ("sort_pass_us", C.c_float),
                 ("carry_us", C.c_float), ("paint_us", C.c_float), ("total_us", C.c_float), ("d2h_us", C.c_float),
                 ("n_lines", C.c_uint32), ("n_segments", C.c_uint32), ("n_sort_passes", C.c_uint32), ("n_runs", C.c_uint32),
-                ("n_tile_entries", C.c_uint32), ("reserved", C.c_uint32)]
+                ("n_tile_entries", C.c_uint32), ("n_tiles_written", C.c_uint32)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 class FlattenTablesT(C.Structure):

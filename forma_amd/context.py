@@ -117,6 +117,9 @@ class Context:
             return dst, t.as_dict()
         return dst
 
+    def cache_clear(self, cache_id):                    # BufferLayerCache::clear
+        self._check(self._L.forma_hip_cache_clear(self._h, cache_id))
+
     def segments(self, which):
         n = C.c_size_t(0)
         rc = self._L.forma_hip_read_segments(self._h, which, None, 0, C.byref(n))

@@ -92,7 +92,7 @@ struct forma_hip_ctx {
     hipEvent_t ev0[ST_COUNT], ev1[ST_COUNT], pev0[MAX_PASS_EVENTS], pev1[MAX_PASS_EVENTS];
     bool stage_used[ST_COUNT];
     int n_passes = 0;
-    uint32_t last_runs = 0, last_entries = 0;
+    uint32_t last_runs = 0, last_entries = 0, last_written = 0;
 };
 
 namespace {
@@ -400,7 +400,9 @@ int copy_image_out(forma_hip_ctx* ctx, uint8_t* dst, size_t stride, bool timing,
         tx0 = a.crop->x0 / 16; tx1 = std::min(tiles_w, (a.crop->x1 + 15) / 16);
         ty0 = a.crop->y0 / 16; ty1 = std::min(tiles_h, (a.crop->y1 + 15) / 16);
     }
+    ctx->last_written = 0;
     if (tx0 >= tx1 || ty0 >= ty1) return FORMA_OK;
+    ctx->last_written = (tx1 - tx0) * (ty1 - ty0);
     const size_t px0 = (size_t)tx0 * 16, px1 = std::min<size_t>((size_t)tx1 * 16, a.width);
     const size_t py0 = (size_t)ty0 * 16, py1 = std::min<size_t>((size_t)ty1 * 16, a.height);
     const size_t pitch = (size_t)a.width * 4;
@@ -423,6 +425,7 @@ int copy_image_out(forma_hip_ctx* ctx, uint8_t* dst, size_t stride, bool timing,
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     size_t n_written = 0, n_crop = (size_t)(tx1 - tx0) * (ty1 - ty0);
     for (uint32_t ty = ty0; ty < ty1; ty++) for (uint32_t tx = tx0; tx < tx1; tx++) n_written += ctx->h_written[(size_t)ty * tiles_w + tx] ? 1 : 0;
+    ctx->last_written = (uint32_t)n_written;
     if (n_written == n_crop) {                                         // everything was painted: one strided copy
         HIPCHECK(hipMemcpy2DAsync(dst + py0 * stride + px0 * 4, stride, ctx->cur_image + py0 * pitch + px0 * 4, pitch,
                                   (px1 - px0) * 4, py1 - py0, hipMemcpyDeviceToHost, ctx->stream));
@@ -475,6 +478,7 @@ int finish_frame(forma_hip_ctx* ctx, forma_timings_t* t, bool have_info = false)
     t->sort_pass_us = np ? pass / np : 0.0f;
     t->n_lines = (uint32_t)ctx->n_lines; t->n_segments = (uint32_t)ctx->n_seg; t->n_sort_passes = (uint32_t)ctx->n_passes;
     t->n_runs = ctx->last_runs ? ctx->last_runs : ctx->h_info->n_runs; t->n_tile_entries = ctx->h_info->n_spans;
+    t->n_tiles_written = ctx->last_written;
     return FORMA_OK;
 }
 

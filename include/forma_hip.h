@@ -119,7 +119,7 @@ typedef struct forma_timings_t {
     uint32_t n_sort_passes;   /* digit passes actually executed        */
     uint32_t n_runs;          /* (tile, layer) runs in the sorted stream */
     uint32_t n_tile_entries;  /* carry-only span records of the frame  */
-    uint32_t reserved;
+    uint32_t n_tiles_written; /* tiles copied into dst (all tiles of the crop without a cache; the damaged ones with one) */
 } forma_timings_t;
 
 /* ---- lifetime ----------------------------------------------------------------------------- */

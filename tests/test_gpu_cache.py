@@ -136,3 +136,24 @@ def test_separate_caches_do_not_interfere(ctx):
     s0 = [np.full((h, w * 4), 5, np.uint8), np.full((h, w * 4), 5, np.uint8)]
     frame(o, ctx, comp, s0, w, h, (1, 1, 1, 1), 1, False)                 # cleared cache: everything is drawn again
     assert np.abs(s0[0].astype(int) - s0[1].astype(int)).max() <= 1 and (s0[1] != 5).any()
+
+
+def test_written_tile_count_is_reported(ctx):
+    """forma_timings_t.n_tiles_written = the damage: every tile without a cache, only the rewritten ones with one."""
+    w, h = 256, 192
+    o = orc.Oracle()
+    comp = build()
+    set_unchanged(comp, False)
+    t = comp.tables(o)
+    S.load(ctx, t)
+    _, tm = ctx.render(w, h, clear=(1, 1, 1, 1), timings=True)
+    assert tm["n_tiles_written"] == (w // 16) * (h // 16)
+    buf = np.zeros((h, w * 4), np.uint8)
+    ctx.cache_clear(5)
+    _, tm = ctx.render(w, h, clear=(1, 1, 1, 1), cache_id=5, dst=buf, timings=True)
+    assert tm["n_tiles_written"] == (w // 16) * (h // 16)
+    set_unchanged(comp, True)
+    t = comp.tables(o)
+    ctx.set_styles(t["style_offsets"], t["style_words"], t["unchanged"])
+    _, tm = ctx.render(w, h, clear=(1, 1, 1, 1), cache_id=5, dst=buf, timings=True)
+    assert tm["n_tiles_written"] == 0
