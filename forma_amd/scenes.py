@@ -5,6 +5,8 @@ built through the product API (forma_amd.api) and flattened on the GPU; nothing 
   C3  paris_like         30 000-layer stand-in for paris-30k.svg (the asset is not in the reference
                          checkout: /root/reference/.MISSING_LARGE_BLOBS), 3840x2160
   C4  triangles_10m      ~10 M pixel segments, 8192x8192, opaque triangles, layer = index
+  C5  spaceship          animated spaceship-like scene at 4K (damage tracking through the buffer-layer cache)
+  --  circles            the reference demo's `circles` mode (translucent discs, 1000x1000)
 """
 from __future__ import annotations
 
@@ -71,6 +73,25 @@ def paris_like(n_layers=30000, width=3840, height=2160, seed=30000) -> Compositi
                 gb.color(Color(float(c2[0]), float(c2[1]), float(c2[2]), alpha))
             fill = Fill.Gradient(gb.build())
         comp.get_mut_or_insert_default(Order(i)).insert(path).set_props(Props(func=Func.Draw(Style(fill=fill, blend_mode=blend))))
+    return comp
+
+
+def circles(count=100, width=1000, height=1000, seed=42) -> Composition:
+    """The reference demo's `circles` mode (demo/src/demos/circles.rs:22-129): `count` translucent discs (alpha 0.2, radius
+    10..50, four rational quadratics of weight sqrt(2)/2 each) at random positions, order = index.  The reference draws
+    its randoms from `StdRng::seed_from_u64(42)` (ChaCha12, not reproducible without the `rand` crate); this uses numpy's
+    generator — same distribution, not the same discs."""
+    rng = np.random.default_rng(seed)
+    w = float(np.sqrt(np.float32(2.0)) / np.float32(2.0))
+    comp = Composition()
+    for order in range(count):
+        r_, g_, b_ = (float(v) for v in rng.random(3, dtype=np.float32))
+        x, y = float(rng.uniform(0, width)), float(rng.uniform(0, height))
+        rad = float(rng.uniform(10.0, 50.0))
+        path = (PathBuilder().move_to(Point(x + rad, y)).rat_quad_to(Point(x + rad, y - rad), Point(x, y - rad), w)
+                .rat_quad_to(Point(x - rad, y - rad), Point(x - rad, y), w).rat_quad_to(Point(x - rad, y + rad), Point(x, y + rad), w)
+                .rat_quad_to(Point(x + rad, y + rad), Point(x + rad, y), w).build())
+        comp.get_mut_or_insert_default(Order(order)).clear().insert(path).set_props(_solid(Color(r_, g_, b_, 0.2)))
     return comp
 
 
@@ -148,4 +169,6 @@ WORKLOADS = {
     "cubics-1080p": (random_cubics, 1920, 1080),
     "paris-like-30k-4k": (paris_like, 3840, 2160),
     "triangles-10m-8k": (triangles_10m, 8192, 8192),
+    "circles-100": (circles, 1000, 1000),                                       # the demo's defaults
+    "circles-20k": (lambda: circles(20000), 1000, 1000),                        # ~120 translucent layers deep per tile
 }

@@ -318,3 +318,19 @@ def test_paris_like_30k_4k_full_size():
     img2 = np.zeros(W * H * 4, np.uint8)
     r.render(comp, api.BufferBuilder(img2, lay).build(), api.RGBA, api.Color(1, 1, 1, 1), None)
     assert np.array_equal(img, img2)
+
+
+def test_circles_demo_scene_matches_oracle():
+    """The reference demo's `circles` mode (demo/src/demos/circles.rs) through the product API: 3 000 translucent discs
+    on 1000 x 1000 — tiles ~20 layers deep, nothing opaque, so every layer is blended."""
+    from forma_amd import api, scenes
+    comp = scenes.circles(3000)
+    r = api.Renderer(0)
+    W = H = 1000
+    img = np.zeros(W * H * 4, np.uint8)
+    r.render(comp, api.BufferBuilder(img, api.LinearLayout(W, W * 4, H)).build(), api.RGBA, api.Color(1, 1, 1, 1), None)
+    o = orc.Oracle()
+    S.load(o, r.host_tables)
+    want = o.render(W, H, clear=(1.0, 1.0, 1.0, 1.0))
+    assert np.array_equal(o.segments(1), r._ctx.segments(1))
+    assert np.abs(want.astype(np.int16) - img.reshape(want.shape).astype(np.int16)).max() <= 1
