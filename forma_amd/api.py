@@ -370,6 +370,8 @@ class _Shared:
         self.geom_id_to_order: Dict[int, Optional[int]] = {}
         self.next_geom_id = 1
         self.geometry_version = 0
+        self.table_version = 0         # bumped by every change that the per-frame layer / style tables depend on
+        self.unchanged_version = 0     # bumped when a render call changes some layer's is_unchanged set
 
     def new_geom_id(self) -> int:
         g = self.next_geom_id; self.next_geom_id += 1; return g
@@ -391,6 +393,7 @@ class Layer:
         self._shared.pushes.append((self.geom_id, path))
         self._shared.geom_id_to_order[self.geom_id] = self.order
         self._shared.geometry_version += 1
+        self._shared.table_version += 1
         self.lines_count += max(n - 1, 0)
         self.is_unchanged_.clear()
         return self
@@ -400,6 +403,7 @@ class Layer:
         self.geom_id = self._shared.new_geom_id()
         self._shared.geom_id_to_order[self.geom_id] = self.order
         self._shared.geometry_version += 1
+        self._shared.table_version += 1
         self.lines_count = 0
         self.is_unchanged_.clear()
         return self
@@ -409,11 +413,14 @@ class Layer:
             self.order = order
             self.is_unchanged_.clear()
         self._shared.geom_id_to_order[self.geom_id] = order
+        self._shared.table_version += 1
 
     def is_enabled(self) -> bool:
         return self.is_enabled_
 
     def set_is_enabled(self, v: bool) -> "Layer":
+        if self.is_enabled_ != v:
+            self._shared.table_version += 1
         self.is_enabled_ = v; return self
 
     def disable(self):
@@ -431,6 +438,7 @@ class Layer:
         if (old is None) != (new is None) or (old is not None and old.t != new.t):
             self.is_unchanged_.clear()
             self.affine_transform = new
+            self._shared.table_version += 1
         return self
 
     def props(self) -> Props:
@@ -440,6 +448,7 @@ class Layer:
         if self.props_ != props:
             self.is_unchanged_.clear()
             self.props_ = props
+            self._shared.table_version += 1
         return self
 
 
@@ -463,6 +472,7 @@ class Composition:
         layer._set_order(int(order))
         old = self.layers.get(int(order))
         self.layers[int(order)] = layer
+        self._shared.table_version += 1
         if old is not None and old is not layer:
             old._set_order(None)
             self._shared.geom_id_to_order[old.geom_id] = None
@@ -472,6 +482,7 @@ class Composition:
         layer = self.layers.pop(int(order), None)
         if layer is not None:
             layer._shared.geom_id_to_order[layer.geom_id] = None
+            self._shared.table_version += 1
         return layer
 
     def get(self, order: Order) -> Optional[Layer]:
@@ -554,6 +565,8 @@ class Renderer:
         self._slot_of: Dict[int, int] = {}
         self.last_timings = None
         self.host_tables: Dict[str, np.ndarray] = {}     # last uploaded scene tables (inspection / tests / bench)
+        self._tables_key = None                          # (composition, table version, unchanged version, cache) on the device
+        self._marked_key = None                          # (composition, table version, cache) whose layers are all marked unchanged
 
     def create_buffer_layer_cache(self) -> Optional[BufferLayerCache]:     # at most 32 (SmallBitSet)
         for i in range(32):
@@ -635,7 +648,11 @@ class Renderer:
         if self._geom_owner is not sh or self._geom_version != sh.geometry_version:
             self._upload_geometry(composition)
         cache_id = buffer.layer_cache.id if buffer.layer_cache else None
-        self._upload_tables(composition, cache_id)
+        # the layer / style / unchanged tables stay resident: they are rebuilt only when something they depend on changed
+        key = (sh, sh.table_version, sh.unchanged_version if cache_id is not None else -1, cache_id)
+        if key != self._tables_key:
+            self._upload_tables(composition, cache_id)
+            self._tables_key = key
         dst = buffer.buffer
         assert dst.dtype == np.uint8 and dst.size >= lay.width_stride * lay.height
         rect = None if crop is None else (crop.horizontal.start, crop.horizontal.stop, crop.vertical.start, crop.vertical.stop)
@@ -648,8 +665,15 @@ class Renderer:
         if buffer.flusher is not None:                        # Flusher::flush per written row slice (layout/mod.rs:283-294)
             buffer.flusher.flush(dst)
         if cache_id is not None:                              # renderer.rs:217-223
-            for layer in composition.layers.values():
-                if layer.is_enabled_:
-                    layer.is_unchanged_.add(cache_id)
-                else:
-                    layer.is_unchanged_.discard(cache_id)
+            mkey = (sh, sh.table_version, cache_id)
+            if mkey != self._marked_key:                      # (nothing to do when this exact state was marked already)
+                changed = False
+                for layer in composition.layers.values():
+                    if layer.is_enabled_:
+                        if cache_id not in layer.is_unchanged_:
+                            layer.is_unchanged_.add(cache_id); changed = True
+                    elif cache_id in layer.is_unchanged_:
+                        layer.is_unchanged_.discard(cache_id); changed = True
+                if changed:
+                    sh.unchanged_version += 1
+                self._marked_key = mkey

@@ -126,3 +126,61 @@ int main(void) {
     from forma_amd import _lib
     t = _lib.TimingsT
     assert out["timings"].split() == [str(C.sizeof(t)), str(t.n_lines.offset), str(t.n_tile_entries.offset)]
+
+
+class _FakeCtx:
+    """Stands in for forma_amd.Context in host-logic tests: records table uploads, renders nothing."""
+    def __init__(self):
+        self.uploads = 0
+        self.unchanged = None
+        self._h = None
+
+    def set_geometry(self, *a): pass
+    def set_geoms(self, g): self.uploads += 1
+    def set_styles(self, off, words, unchanged): self.unchanged = None if unchanged is None else np.array(unchanged)
+    def set_images(self, *a): pass
+
+    def render(self, w, h, **kw):
+        return (None, {}) if kw.get("timings") else None
+
+
+def test_renderer_keeps_tables_resident_until_something_changes():
+    """Renderer.render re-uploads the per-frame layer / style tables only when the composition changed (or a cached frame
+    changed the layers' is_unchanged bits, renderer.rs:217-223) — host logic, exercised with a recording context."""
+    from forma_amd import api
+    r = api.Renderer.__new__(api.Renderer)
+    r._ctx = _FakeCtx(); r._caches = set(); r._geom_owner = None; r._geom_version = -1; r._slot_of = {}
+    r.last_timings = {}; r.host_tables = {}; r._tables_key = None; r._marked_key = None
+    r._upload_geometry = lambda comp: (setattr(r, "_geom_owner", comp._shared), setattr(r, "_geom_version", comp._shared.geometry_version),
+                                       setattr(r, "_slot_of", {l.geom_id: i for i, l in enumerate(comp.layers.values())}))
+    comp = api.Composition()
+    tri = api.PathBuilder().move_to(api.Point(1, 1)).line_to(api.Point(9, 1)).line_to(api.Point(9, 9)).build()
+    for o in range(3):
+        comp.get_mut_or_insert_default(api.Order(o)).insert(tri)
+    buf = lambda cache=None: (api.BufferBuilder(np.zeros(64 * 64 * 4, np.uint8), api.LinearLayout(64, 256, 64)).layer_cache(cache).build()
+                              if cache else api.BufferBuilder(np.zeros(64 * 64 * 4, np.uint8), api.LinearLayout(64, 256, 64)).build())
+    r.render(comp, buf()); r.render(comp, buf()); r.render(comp, buf())
+    assert r._ctx.uploads == 1                                    # static scene: one upload
+    comp.get_mut(api.Order(1)).set_props(api.Props(fill_rule=api.FillRule.EvenOdd))
+    r.render(comp, buf()); r.render(comp, buf())
+    assert r._ctx.uploads == 2                                    # a style changed: one more
+    comp.get_mut(api.Order(1)).set_props(api.Props(fill_rule=api.FillRule.EvenOdd))   # same value: not a change
+    r.render(comp, buf())
+    assert r._ctx.uploads == 2
+    cache = api.BufferLayerCache(0, r)
+    r.render(comp, buf(cache))                                    # first cached frame: nothing is "unchanged" yet
+    assert r._ctx.uploads == 3 and not r._ctx.unchanged.any()
+    r.render(comp, buf(cache))                                    # second: every layer is
+    assert r._ctx.uploads == 4 and r._ctx.unchanged.all()
+    r.render(comp, buf(cache)); r.render(comp, buf(cache))
+    assert r._ctx.uploads == 4                                    # ... and it stays that way
+    comp.get_mut(api.Order(2)).set_transform(api.GeomPresTransform.try_from([1, 0, 0, 1, 2, 0]))
+    r.render(comp, buf(cache))
+    assert r._ctx.uploads == 5 and list(r._ctx.unchanged) == [1, 1, 0]
+    comp.get_mut(api.Order(0)).disable()
+    r.render(comp, buf(cache))
+    assert r._ctx.uploads == 6
+    other = api.Composition()
+    other.get_mut_or_insert_default(api.Order(0)).insert(tri)
+    r.render(other, buf()); r.render(comp, buf(cache))
+    assert r._ctx.uploads == 8                                    # another composition in between: both re-upload
