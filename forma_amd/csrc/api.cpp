@@ -78,6 +78,7 @@ struct forma_hip_ctx {
     // sort-plan speculation: the varying-bit mask and the layer-sortedness of a scene rarely change between frames, so
     // forma_hip_render plans the sort from the previous frame's values and verifies them when the frame is done
     bool pred_valid = false, pred_layer_sorted = false, speculated = false;
+    bool global_runsort = false;           // FORMA_HIP_GLOBAL_RUNSORT=1: never order a row's runs in LDS (test switch)
     bool pred_counts_valid = false, no_async = false;    // N / J predictions for read-back-free frames (FORMA_HIP_SYNC=1 disables)
     uint32_t pred_N = 0, pred_J = 0, pred_w = 0, pred_h = 0;
     uint64_t pred_live44 = 0;
@@ -317,7 +318,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     HIPCHECK(hipGetLastError());
     DevCount jc;
     // the runs of a tile row are ordered by (layer, tile_x) inside k_carry_rows when they fit its LDS; else by a global sort
-    bool local_sort = ctx->n_orders <= 65536 && !getenv("FORMA_HIP_GLOBAL_RUNSORT");
+    bool local_sort = ctx->n_orders <= 65536 && !ctx->global_runsort;
     if (bound_j) {
         jc = DevCount{&dinfo->n_runs, bound_j};
         local_sort = local_sort && ctx->pred_max_row <= carry_rows_local_cap();     // wrong guess -> plan_bad -> synchronous re-run
@@ -518,6 +519,7 @@ int forma_hip_create(forma_hip_ctx** out, int device) {
     ctx->device = device;
     if (const char* e = getenv("FORMA_HIP_DIGIT_BITS")) { if (atoi(e) == 4) ctx->digit_bits = 4; }
     ctx->no_async = getenv("FORMA_HIP_SYNC") != nullptr;
+    ctx->global_runsort = getenv("FORMA_HIP_GLOBAL_RUNSORT") != nullptr;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx; return FORMA_E_HIP;
     }
