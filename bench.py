@@ -37,9 +37,11 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="paris-like-30k-4k")
-    ap.add_argument("--mode", default="frames", choices=["frames", "bands"],
+    ap.add_argument("--mode", default="frames", choices=["frames", "bands", "exchange"],
                     help="N > 1: 'frames' = every GPU renders whole frames (weak scaling, no exchange); "
-                         "'bands' = ONE frame split into tile-row bands across the GPUs (strong scaling)")
+                         "'bands' = ONE frame split into tile-row bands across the GPUs, scene replicated (strong scaling, no "
+                         "exchange); 'exchange' = ONE frame: every GPU rasterizes 1/N of the lines, an RCCL all-to-all moves the "
+                         "pixel segments to the GPU that owns their tile row, which sorts and paints its band (strong scaling)")
     ap.add_argument("--svg", default=None, metavar="FILE",
                     help="render this SVG file (e.g. the real paris-30k.svg) on a 3840x2160 canvas instead of a synthetic "
                          "workload; loaded by forma_amd.svg like the reference demo's `svg` mode")
@@ -108,6 +110,33 @@ def main():
         return ctx.render(width, height, channels=channels, clear=clr, crop=crop, device_only=True, timings=timings)
 
     step = frame
+    if args.mode == "exchange":
+        # line-sharded rasterization + all-to-all of pixel segments to their tile-row owners (sharding.exchange_segments)
+        tab = renderer.host_tables
+        hist = sharding.row_histogram(ctx.segments(0), tiles_h)
+        edges = sharding.agree_on_bands(dist, hist, world, device="cuda") if world > 1 else [0, tiles_h]
+        row0, row1 = edges[rank], edges[rank + 1]
+        crop = sharding.band_crop(edges, rank, width, height)
+        cuts = sharding.line_shares(ctx.prepare_lines(width, height)["lengths"], world)
+        ctx.set_geometry(*sharding.slice_geometry(tab["x"], tab["y"], tab["line_slot"], cuts[rank], cuts[rank + 1]))
+        empty = torch.empty(0, dtype=torch.int64, device=torch.device("cuda", local))
+
+        def frame(timings=False):                           # noqa: F811
+            t1 = ctx.rasterize_frame(width, height, timings=timings)
+            seg = ctx.unsorted_view()
+            recv = sharding.exchange_segments(dist, empty if seg is None else seg, edges, world, out_alloc=ctx.reserve_view)
+            torch.cuda.synchronize()                        # the exchange ran on torch's stream; the context has its own
+            r = ctx.sort_paint_frame(int(recv.numel()), width, height, channels=channels, clear=clr, crop=crop,
+                                     device_only=True, timings=timings)
+            if not timings:
+                return r
+            t2 = r[1]
+            for k in ("prepare_us", "rasterize_us"):
+                t2[k] = t1[k]
+            t2["total_us"] = t2["total_us"] + t1["total_us"]
+            return r[0], t2
+
+        step = frame
 
     def sync_all():
         torch.cuda.synchronize()
@@ -136,7 +165,7 @@ def main():
         _, t = frame(timings=True)
         for k, v in t.items():
             stage[k] = stage.get(k, 0.0) + float(v) / reps
-    n_local = int(round(stage["n_segments"]))
+    n_local = int(round(stage["n_segments"]))                 # (exchange mode: the segments this rank received)
     passes = int(round(stage["n_sort_passes"]))
     pass_us = stage["sort_pass_us"]
     algo_bytes_per_pass = 16.0 * n_local                       # 8 B read + 8 B written per key per digit pass
@@ -160,16 +189,19 @@ def main():
     # PCIe-inclusive frame (image copied into caller memory) — reported, never `value`
     sync_all()
     t1 = time.perf_counter()
-    for _ in range(5):
-        ctx.render(width, height, channels=channels, clear=clr, crop=crop, dst=image.reshape(-1), stride=width * 4)
-    torch.cuda.synchronize()
-    fps_d2h = 5 / (time.perf_counter() - t1)
+    if args.mode == "exchange":
+        fps_d2h = 0.0                                       # (not measured in this mode)
+    else:
+        for _ in range(5):
+            ctx.render(width, height, channels=channels, clear=clr, crop=crop, dst=image.reshape(-1), stride=width * 4)
+        torch.cuda.synchronize()
+        fps_d2h = 5 / (time.perf_counter() - t1)
 
     out = {
         "metric": "frames/sec (sorted+painted, device-resident) + Mpixel-segments/sec",
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "strong" if (world > 1 and args.mode == "bands") else "weak", "vs_baseline": None,
+        "scaling": "strong" if (world > 1 and args.mode in ("bands", "exchange")) else "weak", "vs_baseline": None,
         "dtype": "u64 segments / f64+f32 rasterizer / f32 painter", "data": "synthetic",
         "mpixel_segments_per_s": round(n_segments_full * fps / 1e6, 1),
         "fps_including_d2h": round(fps_d2h, 2),
@@ -179,6 +211,8 @@ def main():
                    "sharding": "none" if world == 1 else (
                        f"tile-row bands x{world} of ONE frame, replicated scene, band culling, no data-path collective"
                        if args.mode == "bands" else
+                       f"lines / {world} rasterized per GPU, RCCL all-to-all of pixel segments to tile-row owners, band-local sort + paint"
+                       if args.mode == "exchange" else
                        f"frame-parallel x{world}: every GPU renders whole 3840x2160 frames of the workload (units = frames), no exchange"),
                    "band_rows": [row0, row1]},
         "stages_us": {k: round(stage[k], 1) for k in ("prepare_us", "rasterize_us", "sort_us", "carry_us", "paint_us", "total_us")},

@@ -26,6 +26,7 @@ class Context:
         if rc != 0:
             raise FormaError(rc, "forma_hip_create (needs a visible MI355X; there is no CPU fallback)")
         self._h = h
+        self.device = device
         self.n_points = 0
 
     def close(self):
@@ -153,6 +154,23 @@ class Context:
         p = C.c_void_p()
         self._check(self._L.forma_hip_reserve_segments(self._h, n, C.byref(p)))
         return p.value
+
+    def device_view(self, ptr, n):
+        """torch int64 view (no copy) of n u64 at device address `ptr` of this context's GPU, for torch.distributed."""
+        import torch
+
+        class _Span:
+            pass
+        sp = _Span()
+        sp.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
+        return torch.as_tensor(sp, device=torch.device("cuda", self.device))
+
+    def unsorted_view(self):
+        ptr, n = self.segments_device(0)
+        return self.device_view(ptr, n) if n else None
+
+    def reserve_view(self, n):
+        return self.device_view(self.reserve_segments(max(int(n), 1)), max(int(n), 1))[: int(n)]
 
     def sort_paint_frame(self, n, width, height, channels=(0, 1, 2, 3), clear=(1, 1, 1, 0), crop=None, dst=None,
                          stride=None, timings=False, device_only=True):

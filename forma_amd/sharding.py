@@ -61,3 +61,60 @@ def max_over_ranks(dist, seconds: float, device=None) -> float:
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+# ---- exchange mode: the north star's literal layout ------------------------------------------------------------------
+# Stage 2 emits segments in LINE order, stages 3-4 own them by TILE ROW.  In `bands` mode every rank rasterizes the whole
+# (replicated) scene and keeps its band; in `exchange` mode every rank rasterizes 1/world of the LINES and the pixel
+# segments travel to the rank that owns their tile row: one all-to-all of u64 payloads (RCCL over xGMI on GPUs; each pair
+# of GPUs has its own link, so the exchange is per-link bound), then each rank sorts and paints its band.
+
+def line_shares(inclusive_sums: Sequence[int], world: int) -> List[int]:
+    """Cut lines 0..n into `world` contiguous ranges [c[r], c[r+1]) carrying (nearly) equal pixel-segment counts.
+    `inclusive_sums[i]` = pixel segments of lines 0..i — the `lengths` array of forma_hip_prepare_lines (the reference's
+    `lengths` after its prefix sum, segment.rs:90-98)."""
+    cum = np.asarray(inclusive_sums, np.float64)
+    n = len(cum)
+    total = float(cum[-1]) if n else 0.0
+    cuts = [0]
+    for r in range(1, world):
+        c = int(np.searchsorted(cum, total * r / world, side="left")) + 1 if total > 0 else (n * r) // world
+        cuts.append(min(max(c, cuts[-1]), n))
+    cuts.append(n)
+    return cuts
+
+
+def slice_geometry(x: np.ndarray, y: np.ndarray, line_slot: np.ndarray, l0: int, l1: int):
+    """The points and slots of lines [l0, l1): line i joins points i and i + 1, so the slice keeps one point more."""
+    if l1 <= l0:
+        return x[:0].copy(), y[:0].copy(), line_slot[:0].copy()
+    return x[l0:l1 + 1].copy(), y[l0:l1 + 1].copy(), line_slot[l0:l1].copy()
+
+
+def exchange_segments(dist, seg, edges: Sequence[int], world: int, out_alloc=None):
+    """seg: this rank's pixel segments (torch int64 view of the u64 stream, any device), in line order.  Returns the
+    segments of this rank's band [edges[rank], edges[rank + 1]), ordered by source rank and, within a source, in its line
+    order — i.e. in global line order when ranks hold ascending line ranges, which is what keeps the sort stable.
+    Segments of rows outside [0, edges[-1]) are never painted (painter/mod.rs:731-734) and are dropped here.
+    `out_alloc(n)` may provide the receive buffer (e.g. a view of the renderer's own segment buffer)."""
+    import torch
+    ty = ((seg >> 53) & 0x7FF) - 1                                       # tile row; -1 = clamped "above the canvas"
+    inner = torch.tensor(list(edges[1:-1]), dtype=torch.int64, device=seg.device)
+    owner = torch.bucketize(ty, inner, right=True)
+    owner = torch.where((ty >= edges[0]) & (ty < edges[-1]), owner, torch.full_like(owner, world))
+    order = torch.argsort(owner, stable=True)
+    counts = torch.bincount(owner, minlength=world + 1)[:world]
+    n_send = int(counts.sum())
+    send = seg[order][:n_send].contiguous()
+    if world == 1:
+        if out_alloc is None:
+            return send
+        out = out_alloc(n_send)
+        out.copy_(send)
+        return out
+    cnt_out = torch.zeros(world, dtype=torch.int64, device=seg.device)
+    dist.all_to_all_single(cnt_out, counts.contiguous())
+    out_sizes, in_sizes = [int(v) for v in cnt_out.tolist()], [int(v) for v in counts.tolist()]
+    recv = out_alloc(sum(out_sizes)) if out_alloc is not None else torch.empty(sum(out_sizes), dtype=torch.int64, device=seg.device)
+    dist.all_to_all_single(recv, send, output_split_sizes=out_sizes, input_split_sizes=in_sizes)
+    return recv

@@ -18,3 +18,12 @@ def oracle_mod():
     from oracle import oracle as orc
     orc.build()
     return orc
+
+
+# PyTorch bundles its own copy of the HIP runtime (same soname as /opt/rocm's).  When a test uses torch tensors on the GPU
+# next to libforma_hip.so (the multi-GPU exchange path), torch must be loaded FIRST so that both share one runtime;
+# loaded the other way round torch fails with "No HIP GPUs are available".
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    pass

@@ -376,3 +376,26 @@ def test_orders_above_16_bits_use_the_global_run_sort(ctx):
         got = ctx.render(256, 64, clear=(1, 1, 1, 1))
         assert np.array_equal(ctx.segments(1), o.segments(1))
         assert np.abs(want.astype(int) - got.astype(int)).max() <= 1
+
+
+def test_exchange_pipeline_on_one_gpu(ctx, mixed):
+    """The `--mode exchange` data path with world = 1: rasterize only, take the unsorted stream as a torch view of the
+    context's buffer, bucket it by tile-row owner (sharding.exchange_segments), hand it back through reserve_segments and
+    sort + paint it — same image as a plain render, received stream = the painted rows of the rasterizer's stream."""
+    import torch
+    from forma_amd import sharding
+    o, _ = both(ctx, mixed)
+    W, H = 512, 384
+    tiles_h = (H + 15) // 16
+    want = ctx.render(W, H, clear=(0.2, 0.3, 0.4, 1.0))
+    full = ctx.segments(0)
+    ctx.rasterize_frame(W, H)
+    seg = ctx.unsorted_view()
+    assert seg.is_cuda and seg.numel() == len(full)
+    assert np.array_equal(seg.cpu().numpy().view(np.uint64), full)
+    recv = sharding.exchange_segments(None, seg, [0, tiles_h], 1, out_alloc=ctx.reserve_view)
+    torch.cuda.synchronize()
+    ty = (full >> np.uint64(53)).astype(np.int64) - 1
+    assert np.array_equal(recv.cpu().numpy().view(np.uint64), full[(ty >= 0) & (ty < tiles_h)])
+    got = ctx.sort_paint_frame(int(recv.numel()), W, H, clear=(0.2, 0.3, 0.4, 1.0), device_only=False)
+    assert np.array_equal(got, want)

@@ -85,3 +85,67 @@ def test_two_rank_band_protocol_gloo(tmp_path):
     full = np.load(tmp_path / "full.npy")
     stitched = np.concatenate([np.load(tmp_path / f"band{r}.npy") for r in range(world)])
     assert np.array_equal(stitched, full)
+
+
+def test_line_shares_and_geometry_slices():
+    rng = np.random.default_rng(1)
+    lengths = rng.integers(0, 50, 1000)
+    for world in (1, 2, 3, 8):
+        c = sharding.line_shares(np.cumsum(lengths), world)
+        assert len(c) == world + 1 and c[0] == 0 and c[-1] == 1000 and all(c[i] <= c[i + 1] for i in range(world))
+        loads = [lengths[c[i]:c[i + 1]].sum() for i in range(world)]
+        assert max(loads) <= lengths.sum() / world + 2 * lengths.max()
+    x = np.arange(11, dtype=np.float32); y = x * 2; ls = np.arange(10, dtype=np.uint32)
+    sx, sy, sl = sharding.slice_geometry(x, y, ls, 3, 7)
+    assert sx.tolist() == [3, 4, 5, 6, 7] and sl.tolist() == [3, 4, 5, 6] and len(sy) == 5
+    assert all(len(a) == 0 for a in sharding.slice_geometry(x, y, ls, 4, 4))
+
+
+def _exchange_worker(rank, world, port, out_dir):
+    import sys
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import scene as S
+    from oracle import oracle as orc
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    W, H = 200, 150
+    tiles_h = (H + 15) // 16
+    clear = (0.1, 0.2, 0.3, 1.0)
+    comp = S.random_mixed(n=120, width=W, height=H, seed=5)
+    ref = orc.Oracle()
+    t = comp.tables(ref)
+    S.load(ref, t)
+    full = ref.render(W, H, clear=clear)
+    full_stream = ref.segments(0)
+    sums = ref.prepare_lines(W, H)["lengths"]                           # inclusive prefix sums
+    edges = sharding.agree_on_bands(dist, sharding.row_histogram(full_stream, tiles_h), world)
+    cuts = sharding.line_shares(sums, world)
+    # this rank rasterizes only ITS lines (the scene tables are replicated, the geometry is sliced) ...
+    o = orc.Oracle()
+    S.load(o, t)
+    o.set_geometry(*sharding.slice_geometry(t["x"], t["y"], t["line_slot"], cuts[rank], cuts[rank + 1]))
+    o.prepare_lines(W, H)
+    mine = o.rasterize()
+    total = torch.tensor([len(mine)], dtype=torch.int64)
+    dist.all_reduce(total)
+    assert int(total) == len(full_stream)                              # the shares partition the stream
+    # ... and the pixel segments travel to the owner of their tile row
+    got = sharding.exchange_segments(dist, torch.from_numpy(mine.view(np.int64).copy()), edges, world).numpy().view(np.uint64)
+    ty = (full_stream >> np.uint64(53)).astype(np.int64) - 1
+    want = full_stream[(ty >= edges[rank]) & (ty < edges[rank + 1])]
+    assert np.array_equal(got, want)                                   # same segments, same (global line) order
+    srt = got[np.argsort(got >> np.uint64(20), kind="stable")]
+    x0, x1, y0, y1 = sharding.band_crop(edges, rank, W, H)
+    band = ref.paint(srt, W, H, clear=clear, crop=(x0, x1, y0, y1), dst=np.full((H, W * 4), 7, np.uint8))
+    assert np.array_equal(band[y0:y1], full[y0:y1])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_exchange_protocol_gloo(tmp_path):
+    """`bench.py --mode exchange` on CPU: line-sharded rasterization, all-to-all of pixel segments by tile-row owner, band-local
+    sort + paint — the received stream is the band's slice of the single-GPU stream in the same order, the bands stitch."""
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_exchange_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
