@@ -428,21 +428,43 @@ void rasterize(const Lines& L, std::vector<uint64_t>& out) {           // raster
 // Stage 3 — sort (cpu/rasterizer.rs:161-164, Ord pixel_segment.rs:161-171): stable on v >> 20
 // ============================================================================================
 void sort_segments(std::vector<uint64_t>& v, int threads) {
-    // LSD radix, 11-bit digits on bits 20..63, stable; identical result to std::stable_sort.
+    // LSD radix, 11-bit digits on bits 20..63, stable; identical result to std::stable_sort.  Parallel the classic way
+    // (the reference sorts with rayon's par_crumsort): every thread histograms a contiguous chunk, the (digit, thread)
+    // counts are scanned digit-major, every thread scatters its chunk — chunks are in stream order, so it stays stable.
     size_t n = v.size();
     if (n < 2) return;
     std::vector<uint64_t> tmp(n);
     uint64_t* src = v.data(); uint64_t* dst = tmp.data();
-    (void)threads;
+    const int B = 2048;
+    int T = threads > 0 ? threads : 1;
+    if (n < (size_t)T * 4096) T = 1;
+    if (T > 256) T = 256;
+    std::vector<size_t> cnt((size_t)T * B);
     for (int shift = 20; shift < 64; shift += 11) {
-        const int B = 2048;
-        std::vector<size_t> cnt(B + 1, 0);
-        for (size_t i = 0; i < n; i++) cnt[((src[i] >> shift) & (B - 1)) + 1]++;
+        std::fill(cnt.begin(), cnt.end(), 0);
+#pragma omp parallel num_threads(T)
+        {
+            const int t = omp_get_thread_num();
+            const size_t i0 = n * (size_t)t / T, i1 = n * (size_t)(t + 1) / T;
+            size_t* c = &cnt[(size_t)t * B];
+            for (size_t i = i0; i < i1; i++) c[(src[i] >> shift) & (B - 1)]++;
+        }
         bool single = false;
-        for (int k = 0; k < B; k++) if (cnt[k + 1] == n) single = true;
+        size_t run = 0;
+        for (int k = 0; k < B; k++) {                       // exclusive scan, digit-major then thread
+            size_t tot = 0;
+            for (int t = 0; t < T; t++) { const size_t c = cnt[(size_t)t * B + k]; cnt[(size_t)t * B + k] = run + tot; tot += c; }
+            if (tot == n) single = true;
+            run += tot;
+        }
         if (single) continue;
-        for (int k = 0; k < B; k++) cnt[k + 1] += cnt[k];
-        for (size_t i = 0; i < n; i++) dst[cnt[(src[i] >> shift) & (B - 1)]++] = src[i];
+#pragma omp parallel num_threads(T)
+        {
+            const int t = omp_get_thread_num();
+            const size_t i0 = n * (size_t)t / T, i1 = n * (size_t)(t + 1) / T;
+            size_t* c = &cnt[(size_t)t * B];
+            for (size_t i = i0; i < i1; i++) dst[c[(src[i] >> shift) & (B - 1)]++] = src[i];
+        }
         std::swap(src, dst);
     }
     if (src != v.data()) memcpy(v.data(), src, n * 8);
