@@ -317,9 +317,9 @@ inline uint32_t integers_between(float a, float b) {                  // segment
 struct Lines {
     std::vector<uint32_t> orders, lengths;
     std::vector<float> x0, y0, dx, dy, a, b, c, d;
-    void resize(size_t n) {
-        orders.assign(n, 0); lengths.assign(n, 0);
-        for (auto* v : {&x0, &y0, &dx, &dy, &a, &b, &c, &d}) v->assign(n, 0.0f);
+    void resize(size_t n) {                               // (entries are (re)written by prepare_lines, zeros included)
+        orders.resize(n); lengths.resize(n);
+        for (auto* v : {&x0, &y0, &dx, &dy, &a, &b, &c, &d}) v->resize(n);
     }
 };
 
@@ -329,6 +329,8 @@ void prepare_lines(const float* x, const float* y, const uint32_t* line_slot, si
     L.resize(n);
 #pragma omp parallel for schedule(static)
     for (long i = 0; i < (long)n; i++) {
+        L.orders[i] = 0; L.lengths[i] = 0;                             // empty_line unless the line survives the tests below
+        L.x0[i] = L.y0[i] = L.dx[i] = L.dy[i] = L.a[i] = L.b[i] = L.c[i] = L.d[i] = 0.0f;
         uint32_t slot = line_slot[i];
         if (slot == FORMA_NONE || slot >= n_geoms) continue;          // id None / no layer -> empty_line
         const forma_geom_t& g = geoms[slot];
@@ -427,6 +429,13 @@ void rasterize(const Lines& L, std::vector<uint64_t>& out) {           // raster
 // ============================================================================================
 // Stage 3 — sort (cpu/rasterizer.rs:161-164, Ord pixel_segment.rs:161-171): stable on v >> 20
 // ============================================================================================
+void copy_segments(const std::vector<uint64_t>& from, std::vector<uint64_t>& to) {
+    to.resize(from.size());
+    const long n = (long)from.size();
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < n; i++) to[i] = from[i];
+}
+
 void sort_segments(std::vector<uint64_t>& v, int threads) {
     // LSD radix, 11-bit digits on bits 20..63, stable; identical result to std::stable_sort.  Parallel the classic way
     // (the reference sorts with rayon's par_crumsort): every thread histograms a contiguous chunk, the (digit, thread)
@@ -1294,7 +1303,7 @@ size_t oracle_rasterize(void* o_) {
 }
 size_t oracle_sort(void* o_) {
     Oracle* o = (Oracle*)o_;
-    o->sorted = o->unsorted;
+    copy_segments(o->unsorted, o->sorted);
     sort_segments(o->sorted, o->threads);
     return o->sorted.size();
 }
@@ -1364,7 +1373,7 @@ int oracle_render(void* o_, uint8_t* dst, uint32_t width, uint32_t height, size_
     Oracle* o = (Oracle*)o_; set_threads(o->threads);
     prepare_lines(o->x.data(), o->y.data(), o->line_slot.data(), o->x.size(), o->geoms.data(), o->geoms.size(), (float)width, (float)height, o->lines);
     rasterize(o->lines, o->unsorted);
-    o->sorted = o->unsorted;
+    copy_segments(o->unsorted, o->sorted);
     sort_segments(o->sorted, o->threads);
     return oracle_paint(o_, o->sorted.data(), o->sorted.size(), dst, width, height, stride, channels, clear, crop, cache_id, tile_dump);
 }
@@ -1385,7 +1394,7 @@ int oracle_time_frame(void* o_, uint32_t width, uint32_t height, int iters, doub
         double t1 = omp_get_wtime();
         rasterize(o->lines, o->unsorted);
         double t2 = omp_get_wtime();
-        o->sorted = o->unsorted; sort_segments(o->sorted, o->threads);
+        copy_segments(o->unsorted, o->sorted); sort_segments(o->sorted, o->threads);
         double t3 = omp_get_wtime();
         PaintCtx ctx = o->pctx(false);
         paint(o->sorted.data(), o->sorted.size(), ctx, img.data(), width, height, (size_t)width * 4, ch, cc, Crop{false, 0, 0, 0, 0}, nullptr, nullptr);
