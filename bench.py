@@ -290,7 +290,7 @@ def cpu_baseline(renderer, width, height, budget_s):
     tm = o.time_frame(width, height, iters)
     per = sum(tm.values())
     return {"value": round(1.0 / per, 3), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{iters} full frames of the same workload (C++ oracle, OpenMP on {cores} threads)",
+            "sample": f"{iters} full frames of the same workload (C++ oracle, OpenMP on {cores} threads; sort single-threaded)",
             "stages_ms": {k: round(v * 1e3, 2) for k, v in tm.items()}}
 
 

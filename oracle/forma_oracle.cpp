@@ -317,9 +317,9 @@ inline uint32_t integers_between(float a, float b) {                  // segment
 struct Lines {
     std::vector<uint32_t> orders, lengths;
     std::vector<float> x0, y0, dx, dy, a, b, c, d;
-    void resize(size_t n) {                               // (entries are (re)written by prepare_lines, zeros included)
-        orders.resize(n); lengths.resize(n);
-        for (auto* v : {&x0, &y0, &dx, &dy, &a, &b, &c, &d}) v->resize(n);
+    void resize(size_t n) {
+        orders.assign(n, 0); lengths.assign(n, 0);
+        for (auto* v : {&x0, &y0, &dx, &dy, &a, &b, &c, &d}) v->assign(n, 0.0f);
     }
 };
 
@@ -329,8 +329,6 @@ void prepare_lines(const float* x, const float* y, const uint32_t* line_slot, si
     L.resize(n);
 #pragma omp parallel for schedule(static)
     for (long i = 0; i < (long)n; i++) {
-        L.orders[i] = 0; L.lengths[i] = 0;                             // empty_line unless the line survives the tests below
-        L.x0[i] = L.y0[i] = L.dx[i] = L.dy[i] = L.a[i] = L.b[i] = L.c[i] = L.d[i] = 0.0f;
         uint32_t slot = line_slot[i];
         if (slot == FORMA_NONE || slot >= n_geoms) continue;          // id None / no layer -> empty_line
         const forma_geom_t& g = geoms[slot];
@@ -429,51 +427,22 @@ void rasterize(const Lines& L, std::vector<uint64_t>& out) {           // raster
 // ============================================================================================
 // Stage 3 — sort (cpu/rasterizer.rs:161-164, Ord pixel_segment.rs:161-171): stable on v >> 20
 // ============================================================================================
-void copy_segments(const std::vector<uint64_t>& from, std::vector<uint64_t>& to) {
-    to.resize(from.size());
-    const long n = (long)from.size();
-#pragma omp parallel for schedule(static)
-    for (long i = 0; i < n; i++) to[i] = from[i];
-}
-
 void sort_segments(std::vector<uint64_t>& v, int threads) {
-    // LSD radix, 11-bit digits on bits 20..63, stable; identical result to std::stable_sort.  Parallel the classic way
-    // (the reference sorts with rayon's par_crumsort): every thread histograms a contiguous chunk, the (digit, thread)
-    // counts are scanned digit-major, every thread scatters its chunk — chunks are in stream order, so it stays stable.
+    // LSD radix, 11-bit digits on bits 20..63, stable; identical result to std::stable_sort.
     size_t n = v.size();
     if (n < 2) return;
     std::vector<uint64_t> tmp(n);
     uint64_t* src = v.data(); uint64_t* dst = tmp.data();
-    const int B = 2048;
-    int T = threads > 0 ? threads : 1;
-    if (n < (size_t)T * 4096) T = 1;
-    if (T > 256) T = 256;
-    std::vector<size_t> cnt((size_t)T * B);
+    (void)threads;
     for (int shift = 20; shift < 64; shift += 11) {
-        std::fill(cnt.begin(), cnt.end(), 0);
-#pragma omp parallel num_threads(T)
-        {
-            const int t = omp_get_thread_num();
-            const size_t i0 = n * (size_t)t / T, i1 = n * (size_t)(t + 1) / T;
-            size_t* c = &cnt[(size_t)t * B];
-            for (size_t i = i0; i < i1; i++) c[(src[i] >> shift) & (B - 1)]++;
-        }
+        const int B = 2048;
+        std::vector<size_t> cnt(B + 1, 0);
+        for (size_t i = 0; i < n; i++) cnt[((src[i] >> shift) & (B - 1)) + 1]++;
         bool single = false;
-        size_t run = 0;
-        for (int k = 0; k < B; k++) {                       // exclusive scan, digit-major then thread
-            size_t tot = 0;
-            for (int t = 0; t < T; t++) { const size_t c = cnt[(size_t)t * B + k]; cnt[(size_t)t * B + k] = run + tot; tot += c; }
-            if (tot == n) single = true;
-            run += tot;
-        }
+        for (int k = 0; k < B; k++) if (cnt[k + 1] == n) single = true;
         if (single) continue;
-#pragma omp parallel num_threads(T)
-        {
-            const int t = omp_get_thread_num();
-            const size_t i0 = n * (size_t)t / T, i1 = n * (size_t)(t + 1) / T;
-            size_t* c = &cnt[(size_t)t * B];
-            for (size_t i = i0; i < i1; i++) dst[c[(src[i] >> shift) & (B - 1)]++] = src[i];
-        }
+        for (int k = 0; k < B; k++) cnt[k + 1] += cnt[k];
+        for (size_t i = 0; i < n; i++) dst[cnt[(src[i] >> shift) & (B - 1)]++] = src[i];
         std::swap(src, dst);
     }
     if (src != v.data()) memcpy(v.data(), src, n * 8);
@@ -1303,7 +1272,7 @@ size_t oracle_rasterize(void* o_) {
 }
 size_t oracle_sort(void* o_) {
     Oracle* o = (Oracle*)o_;
-    copy_segments(o->unsorted, o->sorted);
+    o->sorted = o->unsorted;
     sort_segments(o->sorted, o->threads);
     return o->sorted.size();
 }
@@ -1373,7 +1342,7 @@ int oracle_render(void* o_, uint8_t* dst, uint32_t width, uint32_t height, size_
     Oracle* o = (Oracle*)o_; set_threads(o->threads);
     prepare_lines(o->x.data(), o->y.data(), o->line_slot.data(), o->x.size(), o->geoms.data(), o->geoms.size(), (float)width, (float)height, o->lines);
     rasterize(o->lines, o->unsorted);
-    copy_segments(o->unsorted, o->sorted);
+    o->sorted = o->unsorted;
     sort_segments(o->sorted, o->threads);
     return oracle_paint(o_, o->sorted.data(), o->sorted.size(), dst, width, height, stride, channels, clear, crop, cache_id, tile_dump);
 }
@@ -1394,7 +1363,7 @@ int oracle_time_frame(void* o_, uint32_t width, uint32_t height, int iters, doub
         double t1 = omp_get_wtime();
         rasterize(o->lines, o->unsorted);
         double t2 = omp_get_wtime();
-        copy_segments(o->unsorted, o->sorted); sort_segments(o->sorted, o->threads);
+        o->sorted = o->unsorted; sort_segments(o->sorted, o->threads);
         double t3 = omp_get_wtime();
         PaintCtx ctx = o->pctx(false);
         paint(o->sorted.data(), o->sorted.size(), ctx, img.data(), width, height, (size_t)width * 4, ch, cc, Crop{false, 0, 0, 0, 0}, nullptr, nullptr);
