@@ -75,6 +75,7 @@ SYMBOLS = {
     "forma_hip_cache_clear": (_i, [_vp, _i]),
     "forma_hip_read_segments": (_i, [_vp, _i, _vp, _sz, _vp]),
     "forma_hip_read_image": (_i, [_vp, _vp, _sz]),
+    "forma_hip_tiles_written": (_i, [_vp, _vp, _sz]),
     "forma_hip_set_band": (_i, [_vp, _u32, _u32]),
     "forma_hip_segments_device": (_i, [_vp, _i, _vp, _vp]),
     "forma_hip_rasterize_frame": (_i, [_vp, _u32, _u32, _vp]),

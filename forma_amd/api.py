@@ -27,6 +27,7 @@ from ._lib import FormaError
 from .context import Context, GEOM_DTYPE, IMAGE_DTYPE
 
 LAYER_LIMIT = (1 << 21) - 1          # consts.rs:107-109
+LINES_GARBAGE_THRESHOLD = 2          # composition/mod.rs:33
 MAX_WIDTH, MAX_HEIGHT = 1 << 16, 1 << 15
 NONE = 0xFFFFFFFF
 
@@ -50,6 +51,7 @@ def _host():
         L.forma_host_path_free.argtypes = [vp]
         L.forma_host_path_transform.argtypes = [vp, vp]; L.forma_host_path_transform.restype = vp
         L.forma_host_path_points.argtypes = [vp]; L.forma_host_path_points.restype = sz
+        L.forma_host_path_lines.argtypes = [vp]; L.forma_host_path_lines.restype = sz
         L.forma_host_batch_new.restype = vp
         L.forma_host_batch_free.argtypes = [vp]
         L.forma_host_batch_add.argtypes = [vp, vp, C.c_uint32]
@@ -366,7 +368,7 @@ def _encode_props(p: Props, images: List[Image]) -> List[int]:
 # ---- composition (forma/src/composition/{mod,layer,state}.rs) -------------------------------------------
 class _Shared:
     def __init__(self):
-        self.pushes: List[Tuple[int, Path]] = []     # (geom_id, path) in SegmentBuffer order
+        self.pushes: List[Tuple[int, Path, int]] = []   # (geom_id, path, lines) in SegmentBuffer order
         self.geom_id_to_order: Dict[int, Optional[int]] = {}
         self.next_geom_id = 1
         self.geometry_version = 0
@@ -383,25 +385,30 @@ class Layer:
         self.is_enabled_ = True
         self.affine_transform: Optional[GeomPresTransform] = None
         self.order: Optional[int] = None
-        self.geom_id = shared.new_geom_id()
+        self.geom_id_ = shared.new_geom_id()
         self.props_ = Props()
         self.is_unchanged_: set = set()
         self.lines_count = 0
 
+    def geom_id(self) -> int:                                 # layer.rs:143-145
+        return self.geom_id_
+
     def insert(self, path: Path) -> "Layer":                  # layer.rs:90-111
         n = _host().forma_host_path_points(path._h)
-        self._shared.pushes.append((self.geom_id, path))
-        self._shared.geom_id_to_order[self.geom_id] = self.order
-        self._shared.geometry_version += 1
+        lines = _host().forma_host_path_lines(path._h)        # ids that are Some: what SegmentBuffer::len counts
+        self._shared.pushes.append((self.geom_id_, path, lines))
+        self._shared.geom_id_to_order[self.geom_id_] = self.order
+        if n:
+            self._shared.geometry_version += 1
         self._shared.table_version += 1
-        self.lines_count += max(n - 1, 0)
+        self.lines_count += lines
         self.is_unchanged_.clear()
         return self
 
     def clear(self) -> "Layer":                               # layer.rs:113-129
-        self._shared.geom_id_to_order.pop(self.geom_id, None)
-        self.geom_id = self._shared.new_geom_id()
-        self._shared.geom_id_to_order[self.geom_id] = self.order
+        self._shared.geom_id_to_order.pop(self.geom_id_, None)
+        self.geom_id_ = self._shared.new_geom_id()
+        self._shared.geom_id_to_order[self.geom_id_] = self.order
         self._shared.geometry_version += 1
         self._shared.table_version += 1
         self.lines_count = 0
@@ -412,7 +419,7 @@ class Layer:
         if order is not None and self.order != order:
             self.order = order
             self.is_unchanged_.clear()
-        self._shared.geom_id_to_order[self.geom_id] = order
+        self._shared.geom_id_to_order[self.geom_id_] = order
         self._shared.table_version += 1
 
     def is_enabled(self) -> bool:
@@ -475,15 +482,35 @@ class Composition:
         self._shared.table_version += 1
         if old is not None and old is not layer:
             old._set_order(None)
-            self._shared.geom_id_to_order[old.geom_id] = None
         return old
 
     def remove(self, order: Order) -> Optional[Layer]:
         layer = self.layers.pop(int(order), None)
         if layer is not None:
-            layer._shared.geom_id_to_order[layer.geom_id] = None
-            self._shared.table_version += 1
+            layer._set_order(None)
         return layer
+
+    def get_order_if_stored(self, geom_id: int) -> Optional[Order]:      # composition/mod.rs:234-241
+        o = self._shared.geom_id_to_order.get(geom_id)
+        return None if o is None else Order(o)
+
+    def builder_len(self) -> int:                                         # composition/mod.rs:345-352
+        return sum(n for _, _, n in self._shared.pushes)
+
+    def actual_len(self) -> int:                                          # composition/mod.rs:354-356
+        return sum(l.lines_count for l in self.layers.values())
+
+    def compact_geom(self) -> bool:
+        """Geometry garbage collection (composition/mod.rs:372-384): drops the pushes of geometry ids nobody can reach
+        any more once they make up at least half of the store.  Returns True if anything was dropped."""
+        sh = self._shared
+        if self.builder_len() >= self.actual_len() * LINES_GARBAGE_THRESHOLD:
+            live = [p for p in sh.pushes if p[0] in sh.geom_id_to_order]
+            if len(live) != len(sh.pushes):
+                sh.pushes = live
+                sh.geometry_version += 1
+                return True
+        return False
 
     def get(self, order: Order) -> Optional[Layer]:
         return self.layers.get(int(order))
@@ -515,20 +542,109 @@ class Rect:                                   # pixels; rounded out to tiles by 
     vertical: range
 
 
-class LinearLayout:                           # cpu/buffer/layout/mod.rs:167-222
+class TileFill:
+    """What `Layout.write` receives (cpu/buffer/layout/mod.rs:36-44): ("solid", [u8; 4]) or ("full", colors) with colors a
+    [256][4] uint8 array in COLUMN-major order (index = x * TILE_HEIGHT + y), exactly the reference's `TileFill::Full`."""
+
+    @staticmethod
+    def Solid(color):
+        return ("solid", color)
+
+    @staticmethod
+    def Full(colors):
+        return ("full", colors)
+
+
+class Layout:
+    """A buffer's layout description (reference trait `Layout`, cpu/buffer/layout/mod.rs:51-163).  Subclass it to describe
+    a non-linear buffer: the renderer then hands every written tile to `write` (the generic, host-side path);
+    `LinearLayout` is the fast path (one strided device-to-host copy straight into the caller's buffer)."""
+
+    def width(self) -> int:
+        raise NotImplementedError
+
+    def height(self) -> int:
+        raise NotImplementedError
+
+    def slices_per_tile(self) -> int:
+        raise NotImplementedError
+
+    def slices(self, buffer: np.ndarray) -> list:
+        """writable views of `buffer`, tile-major: tiles ordered by (tile_y, tile_x), `slices_per_tile()` views each"""
+        raise NotImplementedError
+
+    @staticmethod
+    def write(slices: list, flusher, fill) -> None:
+        raise NotImplementedError
+
+    def width_in_tiles(self) -> int:
+        return (self.width() + 15) >> 4
+
+    def height_in_tiles(self) -> int:
+        return (self.height() + 15) >> 4
+
+
+class LinearLayout(Layout):                   # cpu/buffer/layout/mod.rs:167-295
     def __init__(self, width: int, width_stride: int, height: int):
         if width * 4 > width_stride:
             raise AssertionError(f"width exceeds width stride: {width} * 4 > {width_stride}")
-        self.width, self.width_stride, self.height = width, width_stride, height
+        self._w, self.width_stride, self._h = width, width_stride, height
+
+    def width(self) -> int:
+        return self._w
+
+    def height(self) -> int:
+        return self._h
+
+    def slices_per_tile(self) -> int:
+        return 16
+
+    def slices(self, buffer: np.ndarray) -> list:                        # :186-213: rows of every tile, sorted by (tile_y, tile_x)
+        flat = buffer.reshape(-1)
+        assert self._h * self.width_stride <= flat.size, "height * width_stride exceeds buffer length"
+        out = []
+        for ty in range(self.height_in_tiles()):
+            for tx in range(self.width_in_tiles()):
+                for y in range(ty * 16, ty * 16 + 16):
+                    if y >= self._h:
+                        out.append(flat[0:0])                            # (edge tiles: fewer rows; keep slices_per_tile entries)
+                        continue
+                    o = y * self.width_stride + tx * 64
+                    out.append(flat[o: o + min(64, (self._w - tx * 16) * 4)])
+        return out
+
+    @staticmethod
+    def write(slices: list, flusher, fill) -> None:                      # :264-295
+        kind, payload = fill
+        for y, row in enumerate(slices):
+            px = row.reshape(-1, 4)
+            if kind == "solid":
+                px[:] = np.asarray(payload, np.uint8)
+            else:
+                px[:] = np.asarray(payload, np.uint8).reshape(-1, 4)[np.arange(len(px)) * 16 + y]
+        if flusher is not None:
+            for row in slices:
+                if len(row):
+                    flusher.flush(row[:64])
 
 
-class BufferLayerCache:
+class BufferLayerCache:                       # cpu/buffer/mod.rs:165-197
     def __init__(self, cache_id: int, renderer: "Renderer"):
         self.id = cache_id
         self._renderer = renderer
 
     def clear(self):
-        self._renderer._ctx._check(self._renderer._ctx._L.forma_hip_cache_clear(self._renderer._ctx._h, self.id))
+        self._renderer._ctx.cache_clear(self.id)
+
+    def __del__(self):                        # IdDropper (cpu/buffer/mod.rs:98-111): the id returns to the renderer's pool
+        try:
+            r = self._renderer
+            if self.id in r._caches:
+                r._caches.discard(self.id)
+                r._ctx.cache_clear(self.id)   # the next owner of the id starts from an empty cache
+                r._tables_key = None
+        except Exception:
+            pass
 
 
 @dataclass
@@ -578,8 +694,7 @@ class Renderer:
     # -- geometry store: flatten every live path in one HIP launch, keep the result resident on the device
     def _upload_geometry(self, comp: Composition):
         sh = comp._shared
-        live = [(g, p) for g, p in sh.pushes if g in sh.geom_id_to_order]      # compact_geom, composition/mod.rs:372-384
-        sh.pushes = live
+        live = [(g, p) for g, p, _ in sh.pushes]      # garbage is kept until compact_geom drops it; its slots get order NONE
         slot_of: Dict[int, int] = {}
         H = _host()
         batch = H.forma_host_batch_new()
@@ -604,7 +719,7 @@ class Renderer:
         sh = comp._shared
         geoms = np.zeros(max(len(self._slot_of), 1), GEOM_DTYPE)
         geoms["order"] = NONE
-        by_geom = {l.geom_id: l for l in comp.layers.values()}
+        by_geom = {l.geom_id_: l for l in comp.layers.values()}
         for g, slot in self._slot_of.items():
             layer = by_geom.get(g)
             order = sh.geom_id_to_order.get(g)
@@ -642,8 +757,10 @@ class Renderer:
     def render(self, composition: Composition, buffer: Buffer, channels=RGBA, clear_color: Color = Color(1, 1, 1, 1),
                crop: Optional[Rect] = None, timings: bool = False):
         lay = buffer.layout
-        if lay.width > MAX_WIDTH or lay.height > MAX_HEIGHT:
+        W, H = lay.width(), lay.height()
+        if W > MAX_WIDTH or H > MAX_HEIGHT:
             raise FormaError(-1, "canvas exceeds MAX_WIDTH x MAX_HEIGHT")
+        composition.compact_geom()                            # renderer.rs:113
         sh = composition._shared
         if self._geom_owner is not sh or self._geom_version != sh.geometry_version:
             self._upload_geometry(composition)
@@ -654,16 +771,37 @@ class Renderer:
             self._upload_tables(composition, cache_id)
             self._tables_key = key
         dst = buffer.buffer
-        assert dst.dtype == np.uint8 and dst.size >= lay.width_stride * lay.height
         rect = None if crop is None else (crop.horizontal.start, crop.horizontal.stop, crop.vertical.start, crop.vertical.stop)
-        out = self._ctx.render(lay.width, lay.height, channels=channels,
-                               clear=(clear_color.r, clear_color.g, clear_color.b, clear_color.a), crop=rect,
-                               cache_id=-1 if cache_id is None else cache_id, dst=dst.reshape(-1),
-                               stride=lay.width_stride, timings=timings)
+        clear = (clear_color.r, clear_color.g, clear_color.b, clear_color.a)
+        cid = -1 if cache_id is None else cache_id
+        if type(lay) is LinearLayout:                         # fast path: one strided copy of what was written
+            assert dst.dtype == np.uint8 and dst.size >= lay.width_stride * H
+            out = self._ctx.render(W, H, channels=channels, clear=clear, crop=rect, cache_id=cid, dst=dst.reshape(-1),
+                                   stride=lay.width_stride, timings=timings)
+            if buffer.flusher is not None:                    # Flusher::flush on every row slice of every written tile
+                flat = dst.reshape(-1)                        # (layout/mod.rs:283-294, painter/mod.rs:537-548)
+                tw = (W + 15) >> 4
+                for t in np.flatnonzero(self._ctx.tiles_written(W, H)):
+                    ty, tx = divmod(int(t), tw)
+                    n = min(64, (W - tx * 16) * 4)
+                    for y in range(ty * 16, min(ty * 16 + 16, H)):
+                        o = y * lay.width_stride + tx * 64
+                        buffer.flusher.flush(flat[o: o + n])
+        else:                                                 # generic Layout: every written tile goes through Layout::write
+            out = self._ctx.render(W, H, channels=channels, clear=clear, crop=rect, cache_id=cid, dst=None, timings=timings,
+                                   device_only=True)
+            img = self._ctx.read_image(W, H).reshape(H, W, 4)
+            slices = lay.slices(dst)
+            spt = lay.slices_per_tile()
+            tw = (W + 15) >> 4
+            for t in np.flatnonzero(self._ctx.tiles_written(W, H)):
+                ty, tx = divmod(int(t), tw)
+                tile = np.zeros((16, 16, 4), np.uint8)        # [x][y]: column-major like TileFill::Full
+                blk = img[ty * 16: ty * 16 + 16, tx * 16: tx * 16 + 16]
+                tile[: blk.shape[1], : blk.shape[0]] = blk.transpose(1, 0, 2)
+                type(lay).write(slices[int(t) * spt: (int(t) + 1) * spt], buffer.flusher, TileFill.Full(tile.reshape(256, 4)))
         if timings:
-            self.last_timings = out[1]
-        if buffer.flusher is not None:                        # Flusher::flush per written row slice (layout/mod.rs:283-294)
-            buffer.flusher.flush(dst)
+            self.last_timings = out[1] if isinstance(out, tuple) else out
         if cache_id is not None:                              # renderer.rs:217-223
             mkey = (sh, sh.table_version, cache_id)
             if mkey != self._marked_key:                      # (nothing to do when this exact state was marked already)

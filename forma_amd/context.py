@@ -131,6 +131,13 @@ class Context:
         self._check(self._L.forma_hip_read_segments(self._h, which, _p(out), n.value, C.byref(n)))
         return out
 
+    def tiles_written(self, width, height):
+        """one byte per tile of the last frame: 1 = the frame wrote the tile (forma_hip_tiles_written)"""
+        n = ((width + 15) // 16) * ((height + 15) // 16)
+        flags = np.zeros(n, np.uint8)
+        self._check(self._L.forma_hip_tiles_written(self._h, _p(flags), n))
+        return flags
+
     def read_image(self, width, height):
         dst = np.zeros((height, width * 4), np.uint8)
         self._check(self._L.forma_hip_read_image(self._h, _p(dst), width * 4))

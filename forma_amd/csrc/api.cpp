@@ -43,6 +43,9 @@ struct forma_hip_ctx {
     DevBuf layer_sf, layer_col;             // per order: style summary for the carry pre-pass (set_styles)
     std::vector<uint32_t> h_layer_sf, h_layer_col;
     size_t n_points = 0, n_geoms = 0, n_orders = 0, n_words = 0, n_images = 0;
+    uint32_t max_geom_order = 0;            // largest order any geom slot names (FORMA_NONE slots aside)
+    uint32_t max_image_index = 0;           // largest image index a texture style names
+    bool any_texture = false;
     bool scene_has_clips = false;
     bool have_unchanged = false;            // set_styles supplied per-order Layer::is_unchanged bytes
     // lines
@@ -94,6 +97,9 @@ struct forma_hip_ctx {
     bool stage_used[ST_COUNT];
     int n_passes = 0;
     uint32_t last_runs = 0, last_entries = 0, last_written = 0;
+    // what the last frame wrote, for forma_hip_tiles_written (host-side Flusher / generic Layout::write)
+    uint32_t lw_tiles_w = 0, lw_tiles_h = 0, lw_tx0 = 0, lw_tx1 = 0, lw_ty0 = 0, lw_ty1 = 0;
+    bool lw_valid = false, lw_cache = false, lw_flags_on_host = false;
 };
 
 namespace {
@@ -268,6 +274,8 @@ struct PaintArgs {
 // bound_j != 0: asynchronous — the run count stays on the device (info->n_runs), buffers are provisioned for bound_j runs.
 int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, uint32_t bound_j = 0) {
     const size_t n = nc.bound;
+    // set_styles and set_images are separate calls: the image a texture style names is checked where both are known
+    if (ctx->any_texture && ctx->max_image_index >= ctx->n_images) return fail(ctx, FORMA_E_ARG, "texture style names an image that was not uploaded");
     const uint32_t tiles_w = (a.width + 15) / 16, tiles_h = (a.height + 15) / 16;
     const uint32_t T = tiles_w * tiles_h;
     ctx->img_w = a.width; ctx->img_h = a.height;
@@ -318,7 +326,8 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     HIPCHECK(hipGetLastError());
     DevCount jc;
     // the runs of a tile row are ordered by (layer, tile_x) inside k_carry_rows when they fit its LDS; else by a global sort
-    bool local_sort = ctx->n_orders <= 65536 && !ctx->global_runsort;
+    // (the in-LDS key holds 16 layer bits: every order a geom can produce has to fit, not just the style table)
+    bool local_sort = ctx->n_orders <= 65536 && ctx->max_geom_order < 65536 && !ctx->global_runsort;
     if (bound_j) {
         jc = DevCount{&dinfo->n_runs, bound_j};
         local_sort = local_sort && ctx->pred_max_row <= carry_rows_local_cap();     // wrong guess -> plan_bad -> synchronous re-run
@@ -394,7 +403,6 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
 // cache the tiles the painter skipped (TileWriteOp::None), keep whatever the caller's buffer holds (reference
 // cpu/buffer/layout/mod.rs:264-295 writes tile by tile; forma/src/cpu/buffer/mod.rs doc test "skipped rendering").
 int copy_image_out(forma_hip_ctx* ctx, uint8_t* dst, size_t stride, bool timing, const PaintArgs& a) {
-    if (!dst) return FORMA_OK;
     const uint32_t tiles_w = (a.width + 15) / 16, tiles_h = (a.height + 15) / 16;
     uint32_t tx0 = 0, tx1 = tiles_w, ty0 = 0, ty1 = tiles_h;
     if (a.crop) {
@@ -402,6 +410,9 @@ int copy_image_out(forma_hip_ctx* ctx, uint8_t* dst, size_t stride, bool timing,
         ty0 = a.crop->y0 / 16; ty1 = std::min(tiles_h, (a.crop->y1 + 15) / 16);
     }
     ctx->last_written = 0;
+    ctx->lw_valid = true; ctx->lw_tiles_w = tiles_w; ctx->lw_tiles_h = tiles_h; ctx->lw_cache = a.cache_id >= 0; ctx->lw_flags_on_host = false;
+    ctx->lw_tx0 = tx0; ctx->lw_tx1 = std::max(tx0, tx1); ctx->lw_ty0 = ty0; ctx->lw_ty1 = std::max(ty0, ty1);
+    if (!dst) return FORMA_OK;
     if (tx0 >= tx1 || ty0 >= ty1) return FORMA_OK;
     ctx->last_written = (tx1 - tx0) * (ty1 - ty0);
     const size_t px0 = (size_t)tx0 * 16, px1 = std::min<size_t>((size_t)tx1 * 16, a.width);
@@ -424,6 +435,7 @@ int copy_image_out(forma_hip_ctx* ctx, uint8_t* dst, size_t stride, bool timing,
     }
     HIPCHECK(hipMemcpyAsync(ctx->h_written, ctx->cache_written.p, T, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHECK(hipStreamSynchronize(ctx->stream));
+    ctx->lw_flags_on_host = true;
     size_t n_written = 0, n_crop = (size_t)(tx1 - tx0) * (ty1 - ty0);
     for (uint32_t ty = ty0; ty < ty1; ty++) for (uint32_t tx = tx0; tx < tx1; tx++) n_written += ctx->h_written[(size_t)ty * tiles_w + tx] ? 1 : 0;
     ctx->last_written = (uint32_t)n_written;
@@ -592,14 +604,18 @@ int forma_hip_set_geometry(forma_hip_ctx* ctx, const float* x, const float* y, c
 
 int forma_hip_set_geoms(forma_hip_ctx* ctx, const forma_geom_t* geoms, size_t n_geoms) {
     if (!ctx || (n_geoms && !geoms)) return fail(ctx, FORMA_E_ARG, "null geoms");
-    for (size_t i = 0; i < n_geoms; i++)
-        if (geoms[i].order != FORMA_NONE && geoms[i].order > FORMA_LAYER_LIMIT)      // utils/order.rs:44-66
+    uint32_t max_order = 0;
+    for (size_t i = 0; i < n_geoms; i++) {
+        if (geoms[i].order == FORMA_NONE) continue;
+        if (geoms[i].order > FORMA_LAYER_LIMIT)                                      // utils/order.rs:44-66
             return fail(ctx, FORMA_E_ARG, "order exceeds LAYER_LIMIT");
+        max_order = std::max(max_order, geoms[i].order);
+    }
     HIPCHECK(hipSetDevice(ctx->device));
     int rc = upload(ctx, ctx->geoms, geoms, n_geoms);
     if (rc) return rc;
     HIPCHECK(hipStreamSynchronize(ctx->stream));
-    ctx->n_geoms = n_geoms;
+    ctx->n_geoms = n_geoms; ctx->max_geom_order = max_order;
     return FORMA_OK;
 }
 
@@ -612,9 +628,10 @@ int forma_hip_set_styles(forma_hip_ctx* ctx, const uint32_t* style_offsets, size
     // the offset table and the style words): SF_* flags and the four words the painter's fast paths read
     ctx->h_layer_sf.assign(n_orders, 0u);
     ctx->h_layer_col.assign(n_orders * 4, 0u);
+    uint32_t max_image = 0; bool any_texture = false;
     for (size_t o = 0; o < n_orders; o++) {
-        uint32_t off = style_offsets[o];
-        if (off == FORMA_NONE) continue;
+        const size_t off = style_offsets[o];                 // size_t: `off + 2` must not wrap in 32 bits
+        if (style_offsets[o] == FORMA_NONE) continue;
         if (off + 2 > n_words) return fail(ctx, FORMA_E_ARG, "style offset out of range");
         uint32_t h = style_words[off];
         size_t need = 2;
@@ -624,6 +641,7 @@ int forma_hip_set_styles(forma_hip_ctx* ctx, const uint32_t* style_offsets, size
             if (ft == FORMA_FILL_LINEAR || ft == FORMA_FILL_RADIAL) if (FORMA_STYLE_STOPS(h) < 1) return fail(ctx, FORMA_E_ARG, "gradient without stops");
         }
         if (off + need > n_words) return fail(ctx, FORMA_E_ARG, "style payload out of range");
+        if (!FORMA_STYLE_IS_CLIP(h) && FORMA_STYLE_FILL(h) == FORMA_FILL_TEXTURE) { any_texture = true; max_image = std::max(max_image, style_words[off + 8]); }
         if (FORMA_STYLE_IS_CLIP(h) || FORMA_STYLE_CLIPPED(h)) clips = true;
         uint32_t sfl = (FORMA_STYLE_EVENODD(h) ? SF_EVENODD : 0u) | (FORMA_STYLE_BLEND(h) << SF_BLEND_SHIFT) | (FORMA_STYLE_FILL(h) << SF_FILL_SHIFT);
         uint32_t* col = &ctx->h_layer_col[o * 4];
@@ -646,6 +664,7 @@ int forma_hip_set_styles(forma_hip_ctx* ctx, const uint32_t* style_offsets, size
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     ctx->n_orders = n_orders; ctx->n_words = n_words; ctx->scene_has_clips = clips;
     ctx->have_unchanged = unchanged != nullptr;
+    ctx->any_texture = any_texture; ctx->max_image_index = max_image;
     return FORMA_OK;
 }
 
@@ -842,13 +861,18 @@ int forma_hip_render(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t 
         if ((rc = run_rasterize_frame(ctx, width, height, timing, true, bN))) return rc;
         if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), DevCount{&dinfo->n_segments, bN}, timing))) return rc;
         if ((rc = run_paint(ctx, DevCount{&dinfo->n_segments, bN}, a, timing, bJ))) return rc;
-        if ((rc = copy_image_out(ctx, dst, stride_bytes, timing, a))) return rc;
+        // the frame is verified BEFORE anything lands in caller memory: a mispredicted frame never shows in `dst`
         HIPCHECK(hipMemcpyAsync(ctx->h_info, ctx->info.p, sizeof(FrameInfo), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHECK(hipStreamSynchronize(ctx->stream));
         const uint32_t N = ctx->h_info->n_segments, J = ctx->h_info->n_runs;
         ctx->n_seg = N; ctx->n_compact = ctx->h_info->n_compact; ctx->last_runs = J;
         const bool ok = !ctx->h_info->plan_bad && N <= bN && J <= bJ;
-        if (ok) { ctx->pred_N = N; ctx->pred_J = J; ctx->pred_max_row = ctx->h_info->max_row_runs; return frame_done(finish_frame(ctx, timings, true)); }
+        if (ok) {
+            ctx->pred_N = N; ctx->pred_J = J; ctx->pred_max_row = ctx->h_info->max_row_runs;
+            if ((rc = copy_image_out(ctx, dst, stride_bytes, timing, a))) return rc;
+            if (dst) HIPCHECK(hipStreamSynchronize(ctx->stream));
+            return frame_done(finish_frame(ctx, timings, true));
+        }
         ctx->pred_counts_valid = false;                   // fall through: the synchronous path re-learns everything
         clear_stage_flags(ctx);
     }
@@ -898,6 +922,32 @@ int forma_hip_read_image(forma_hip_ctx* ctx, uint8_t* dst, size_t stride_bytes) 
     if ((size_t)ctx->img_w * 4 > stride_bytes) return fail(ctx, FORMA_E_ARG, "width exceeds width stride");
     HIPCHECK(hipSetDevice(ctx->device));
     HIPCHECK(hipMemcpy2D(dst, stride_bytes, ctx->cur_image, (size_t)ctx->img_w * 4, (size_t)ctx->img_w * 4, ctx->img_h, hipMemcpyDeviceToHost));
+    return FORMA_OK;
+}
+
+int forma_hip_tiles_written(forma_hip_ctx* ctx, uint8_t* flags, size_t n_tiles) {
+    if (!ctx || !flags) return FORMA_E_ARG;
+    if (!ctx->lw_valid) return fail(ctx, FORMA_E_STATE, "no frame rendered yet");
+    const size_t T = (size_t)ctx->lw_tiles_w * ctx->lw_tiles_h;
+    if (n_tiles < T) return fail(ctx, FORMA_E_CAPACITY, "tile flag capacity too small");
+    memset(flags, 0, n_tiles);
+    if (ctx->lw_cache && !ctx->lw_flags_on_host) {        // device-resident frame (dst == NULL): fetch the flags now
+        HIPCHECK(hipSetDevice(ctx->device));
+        if (ctx->h_written_cap < T) {
+            if (ctx->h_written) (void)hipHostFree(ctx->h_written);
+            ctx->h_written = nullptr; ctx->h_written_cap = 0;
+            HIPCHECK(hipHostMalloc((void**)&ctx->h_written, T, hipHostMallocDefault));
+            ctx->h_written_cap = T;
+        }
+        HIPCHECK(hipMemcpyAsync(ctx->h_written, ctx->cache_written.p, T, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        ctx->lw_flags_on_host = true;
+    }
+    for (uint32_t ty = ctx->lw_ty0; ty < ctx->lw_ty1; ty++)
+        for (uint32_t tx = ctx->lw_tx0; tx < ctx->lw_tx1; tx++) {
+            const size_t t = (size_t)ty * ctx->lw_tiles_w + tx;
+            flags[t] = ctx->lw_cache ? (ctx->h_written[t] ? 1 : 0) : 1;
+        }
     return FORMA_OK;
 }
 
@@ -953,6 +1003,7 @@ int forma_hip_sort_paint_frame(forma_hip_ctx* ctx, size_t n, uint8_t* dst, uint3
     if (n) HIPCHECK(hipMemcpyAsync(ctx->seg_u.p, ctx->seg_b.p, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
     ctx->n_seg = n; ctx->have_unsorted = true;
     ctx->live44 = 0xFFFFFFFFFFFull;                   // no varying-bit mask for a received stream: sort every digit
+    ctx->layer_sorted = false; ctx->speculated = false; // slices that are layer-sorted need not concatenate to a layer-sorted stream
     if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), DevCount{nullptr, (uint32_t)n}, timing))) return rc;
     PaintArgs a{width, height, channels, clear_color, crop_or_null};
     if ((rc = run_paint(ctx, DevCount{nullptr, (uint32_t)n}, a, timing))) return rc;

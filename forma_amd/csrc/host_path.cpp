@@ -341,6 +341,14 @@ void* forma_host_build(void* b) { return new Path(((PathBuilder*)b)->build()); }
 void  forma_host_path_free(void* p) { delete (Path*)p; }
 void* forma_host_path_transform(void* p, const float* t9) { return new Path(((Path*)p)->transform(t9)); }
 size_t forma_host_path_points(void* p) { return ((Path*)p)->plan().point_commands.size(); }
+// lines the path adds to the geometry store = ids that are Some (SegmentBuffer::len, segment.rs:159-178): every point but
+// the last one and the points that end a contour
+size_t forma_host_path_lines(void* p) {
+    const FlattenPlan& pl = ((Path*)p)->plan();
+    size_t n = 0;
+    for (size_t i = 0; i + 1 < pl.new_contour.size(); i++) n += pl.new_contour[i] ? 0 : 1;
+    return n;
+}
 
 void* forma_host_batch_new(void) { return new FlattenBatch(); }
 void  forma_host_batch_free(void* b) { delete (FlattenBatch*)b; }

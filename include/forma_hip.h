@@ -212,6 +212,12 @@ int forma_hip_read_segments(forma_hip_ctx* ctx, int which, uint64_t* out, size_t
                             size_t* out_n);
 int forma_hip_read_image(forma_hip_ctx* ctx, uint8_t* dst, size_t stride_bytes);
 
+/* Which tiles the last forma_hip_render / _paint / _sort_paint_frame call wrote (TileWriteOp != None inside the crop):
+ * one byte per tile, row-major [tiles_h][tiles_w], tiles = ceil(size / 16).  This is what lets the host side run the
+ * reference's per-tile hooks after the one strided copy: `Flusher::flush` on every row slice of every written tile
+ * and a user `Layout::write` (cpu/buffer/layout/mod.rs:29-34, 51-163, 264-295; painter/mod.rs:537-548).          */
+int forma_hip_tiles_written(forma_hip_ctx* ctx, uint8_t* flags, size_t n_tiles);
+
 /* ---- multi-GPU: tile-row band ownership ---------------------------------------- */
 /* Restrict this context to tile rows [row0, row1): prepare_lines additionally culls lines
  * entirely outside the band and the rasterizer drops pixel segments of other bands, so the

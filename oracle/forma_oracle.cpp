@@ -895,11 +895,13 @@ struct Workbench {                                                     // layer_
             start = end + 1;
         }
         for (size_t i = 0; i < queue.size(); i++) queue_idx[queue[i].layer] = i;
-        std::vector<uint32_t> all;
-        for (auto& kv : seg_ranges) all.push_back(kv.first);
-        for (auto& kv : queue_idx) all.push_back(kv.first);
-        std::sort(all.begin(), all.end()); all.erase(std::unique(all.begin(), all.end()), all.end());
-        for (uint32_t id : all) ids.push_back({id, true});
+        // ids.extend(segment_ranges.keys ++ queue_indices.keys) with mask = true, then sort_and_dedup (:266-277,
+        // MaskedVec :105-118): cells already present (a second populate without next_tile, as the reference's own
+        // tests do) keep their place in front of the newly pushed duplicates
+        for (auto& kv : seg_ranges) ids.push_back({kv.first, true});
+        for (auto& kv : queue_idx) ids.push_back({kv.first, true});
+        std::stable_sort(ids.begin(), ids.end(), [](const Id& a, const Id& b) { return a.id < b.id; });
+        ids.erase(std::unique(ids.begin(), ids.end(), [](const Id& a, const Id& b) { return a.id == b.id; }), ids.end());
     }
 };
 
@@ -909,77 +911,78 @@ struct TileCtx {
     uint8_t channels[4]; Color clear;
 };
 
-// passes/*.rs.  Returns: 0 continue, 1 Break(None), 2 Break(Solid(color))
-int optimization_passes(Workbench& wb, const TileCtx& t, const PaintCtx& ctx, Color& solid) {
-    // tile_unchanged_pass (passes/tile_unchanged.rs)
-    {
-        bool clear_unchanged = t.has_cached_clear && color_eq(t.cached_clear, t.clear);
-        if (t.cached_tile) {
-            uint32_t layers = (uint32_t)wb.ids.size();
-            bool had = t.cached_tile->has_lc(); uint32_t prev = t.cached_tile->layer_count;
-            t.cached_tile->tags |= 2; t.cached_tile->layer_count = layers & 0xFFFFFF;
-            bool unchanged = false;
-            if (had) {
-                wb.layers_were_removed = layers < prev;
-                unchanged = prev == layers;
-                if (unchanged) for (auto& e : wb.ids) if (!ctx.is_unchanged(e.id)) { unchanged = false; break; }
+// passes/*.rs.  Every pass returns: 0 Continue, 1 Break(None), 2 Break(Solid(color)) — the reference's
+// ControlFlow<OptimizerTileWriteOp> (layer_workbench/mod.rs:124-128).
+int tile_unchanged_pass(Workbench& wb, const TileCtx& t, const PaintCtx& ctx) {      // passes/tile_unchanged.rs:25-57
+    bool clear_unchanged = t.has_cached_clear && color_eq(t.cached_clear, t.clear);
+    if (!t.cached_tile) return 0;
+    uint32_t layers = (uint32_t)wb.ids.size();
+    bool had = t.cached_tile->has_lc(); uint32_t prev = t.cached_tile->layer_count;
+    t.cached_tile->tags |= 2; t.cached_tile->layer_count = layers & 0xFFFFFF;  // update_layer_count(Some(layers)), 3 LE bytes
+    bool unchanged = false;
+    if (had) {
+        wb.layers_were_removed = layers < prev;
+        unchanged = prev == layers;
+        if (unchanged) for (auto& e : wb.ids) if (!ctx.is_unchanged(e.id)) { unchanged = false; break; }
+    }
+    return (clear_unchanged && unchanged) ? 1 : 0;
+}
+int skip_trivial_clips_pass(Workbench& wb, const TileCtx&, const PaintCtx& ctx) {    // passes/skip_trivial_clips.rs:28-112
+    struct Clip { bool is_full; uint32_t last; size_t i; bool used; };
+    bool has = false; Clip clip{};
+    for (size_t i = wb.skipped; i < wb.ids.size(); i++) {
+        if (!wb.ids[i].mask) continue;
+        uint32_t id = wb.ids[i].id; const Props& p = ctx.get(id);
+        if (p.is_clip) {
+            bool full = wb.layer_is_full(id, p.even_odd);
+            clip = {full, id + p.clip_n, i, false}; has = true;
+            if (full) wb.ids[i].mask = false;
+        }
+        if (!p.is_clip && p.is_clipped) {
+            if (has && id <= clip.last) { if (clip.is_full) wb.skip_clipping.insert(id); else clip.used = true; }
+            else wb.ids[i].mask = false;
+        }
+        if (has && id > clip.last) { has = false; if (!clip.used) wb.ids[clip.i].mask = false; }
+    }
+    if (has && !clip.used) wb.ids[clip.i].mask = false;
+    return 0;
+}
+int skip_fully_covered_layers_pass(Workbench& wb, const TileCtx& t, const PaintCtx& ctx, Color& solid) {   // passes/skip_fully_covered_layers.rs:27-119
+    int first = 0;  // 0 none, 1 opaque, 2 incomplete
+    Color opaque{};
+    bool visible_unchanged = !wb.layers_were_removed;
+    for (size_t k = wb.ids.size(); k-- > wb.skipped;) {
+        if (!wb.ids[k].mask) continue;
+        uint32_t id = wb.ids[k].id; const Props& p = ctx.get(id);
+        if (!ctx.is_unchanged(id)) visible_unchanged = false;
+        bool is_clipped = !p.is_clip && p.is_clipped && !wb.skip_clipping.count(id);
+        if (is_clipped || !wb.layer_is_full(id, p.even_odd)) { if (first == 0) first = 2; }
+        else if (!p.is_clip && p.fill == FORMA_FILL_SOLID && p.blend == 0) {
+            if (p.solid.a == 1.0f) {
+                if (first == 0) { first = 1; opaque = p.solid; }
+                wb.skipped = k;
+                break;
             }
-            if (clear_unchanged && unchanged) return 1;
         }
     }
-    // skip_trivial_clips_pass (passes/skip_trivial_clips.rs)
-    {
-        struct Clip { bool is_full; uint32_t last; size_t i; bool used; };
-        bool has = false; Clip clip{};
-        for (size_t i = wb.skipped; i < wb.ids.size(); i++) {
-            if (!wb.ids[i].mask) continue;
-            uint32_t id = wb.ids[i].id; const Props& p = ctx.get(id);
-            if (p.is_clip) {
-                bool full = wb.layer_is_full(id, p.even_odd);
-                clip = {full, id + p.clip_n, i, false}; has = true;
-                if (full) wb.ids[i].mask = false;
-            }
-            if (!p.is_clip && p.is_clipped) {
-                if (has && id <= clip.last) { if (clip.is_full) wb.skip_clipping.insert(id); else clip.used = true; }
-                else wb.ids[i].mask = false;
-            }
-            if (has && id > clip.last) { has = false; if (!clip.used) wb.ids[clip.i].mask = false; }
-        }
-        if (has && !clip.used) wb.ids[clip.i].mask = false;
-    }
-    // skip_fully_covered_layers_pass (passes/skip_fully_covered_layers.rs)
-    {
-        int first = 0;  // 0 none, 1 opaque, 2 incomplete
-        Color opaque{};
-        bool visible_unchanged = !wb.layers_were_removed;
-        for (size_t k = wb.ids.size(); k-- > wb.skipped;) {
-            if (!wb.ids[k].mask) continue;
-            uint32_t id = wb.ids[k].id; const Props& p = ctx.get(id);
-            if (!ctx.is_unchanged(id)) visible_unchanged = false;
-            bool is_clipped = !p.is_clip && p.is_clipped && !wb.skip_clipping.count(id);
-            if (is_clipped || !wb.layer_is_full(id, p.even_odd)) { if (first == 0) first = 2; }
-            else if (!p.is_clip && p.fill == FORMA_FILL_SOLID && p.blend == 0) {
-                if (p.solid.a == 1.0f) {
-                    if (first == 0) { first = 1; opaque = p.solid; }
-                    wb.skipped = k;
-                    break;
-                }
-            }
-        }
-        size_t skip_n; Color bottom;
-        if (first == 1) { if (visible_unchanged) return 1; skip_n = 1; bottom = opaque; }
-        else if (first == 0) { skip_n = 0; bottom = t.clear; }
+    size_t skip_n; Color bottom;
+    if (first == 1) { if (visible_unchanged) return 1; skip_n = 1; bottom = opaque; }
+    else if (first == 0) { skip_n = 0; bottom = t.clear; }
+    else return 0;
+    Color dst = bottom; size_t seen = 0;
+    for (size_t k = wb.skipped; k < wb.ids.size(); k++) {
+        if (!wb.ids[k].mask) continue;
+        if (seen++ < skip_n) continue;
+        const Props& p = ctx.get(wb.ids[k].id);
+        if (!p.is_clip && p.fill == FORMA_FILL_SOLID) dst = scalar_blend(p.blend, dst, p.solid);
         else return 0;
-        Color dst = bottom; size_t seen = 0;
-        for (size_t k = wb.skipped; k < wb.ids.size(); k++) {
-            if (!wb.ids[k].mask) continue;
-            if (seen++ < skip_n) continue;
-            const Props& p = ctx.get(wb.ids[k].id);
-            if (!p.is_clip && p.fill == FORMA_FILL_SOLID) dst = scalar_blend(p.blend, dst, p.solid);
-            else return 0;
-        }
-        solid = dst; return 2;
     }
+    solid = dst; return 2;
+}
+int optimization_passes(Workbench& wb, const TileCtx& t, const PaintCtx& ctx, Color& solid) {   // layer_workbench/mod.rs:236-248
+    if (int r = tile_unchanged_pass(wb, t, ctx)) return r;
+    if (int r = skip_trivial_clips_pass(wb, t, ctx)) return r;
+    return skip_fully_covered_layers_pass(wb, t, ctx, solid);
 }
 
 TileOp drive_tile_painting(Workbench& wb, Painter& painter, const TileCtx& t, const PaintCtx& ctx, uint8_t solid_out[4]) {
@@ -1031,19 +1034,26 @@ TileOp drive_tile_painting(Workbench& wb, Painter& painter, const TileCtx& t, co
 struct Crop { bool some; size_t h0, h1, v0, v1; };                     // Rect, renderer.rs:37-53 (tile units)
 
 // Layout::write for LinearLayout (buffer/layout/mod.rs:264-295)
+// Flusher (buffer/layout/mod.rs:29-34): called for every row slice of a tile after the tile was written
+typedef void (*oracle_flush_fn)(uint8_t* slice, size_t len, void* user);
+struct FlusherRef { oracle_flush_fn fn; void* user; };
+
 void write_tile(uint8_t* buf, size_t stride, size_t width, size_t height, size_t tx, size_t ty,
-                const uint8_t* solid, const uint8_t* colors) {
+                const uint8_t* solid, const uint8_t* colors, FlusherRef flusher) {
     size_t x0 = tx * 16, y0 = ty * 16;
     size_t w = std::min<size_t>(16, width - x0), h = std::min<size_t>(16, height - y0);
     for (size_t y = 0; y < h; y++) {
         uint8_t* row = buf + (y0 + y) * stride + x0 * 4;
         for (size_t x = 0; x < w; x++) memcpy(row + 4 * x, solid ? solid : colors + 4 * (x * 16 + y), 4);
     }
+    if (flusher.fn)                                                    // :283-294: row.get_mut(..TILE_WIDTH * 4) or the (shorter) row
+        for (size_t y = 0; y < h; y++) flusher.fn(buf + (y0 + y) * stride + x0 * 4, w * 4, flusher.user);
 }
 
 // painter::for_each_row / print_row / paint_tile_row (painter/mod.rs:485-778)
 void paint(const uint64_t* segs, size_t n, const PaintCtx& ctx, uint8_t* buf, size_t width, size_t height,
-           size_t stride, const uint8_t channels[4], Color clear, Crop crop, Cache* cache, float* tile_dump) {
+           size_t stride, const uint8_t channels[4], Color clear, Crop crop, Cache* cache, float* tile_dump,
+           FlusherRef flusher = FlusherRef{nullptr, nullptr}) {
     size_t tiles_w = (width + 15) / 16, tiles_h = (height + 15) / 16;
     // drop tile_y < 0 (:731-734): stored tile_y field 0
     size_t begin = 0;
@@ -1092,10 +1102,10 @@ void paint(const uint64_t* segs, size_t n, const PaintCtx& ctx, uint8_t* buf, si
                 painter.has_clip = false;                              // :551
                 uint8_t solid[4];
                 TileOp op = drive_tile_painting(wb, painter, t, ctx, solid);
-                if (op == TileOp::Solid) write_tile(buf, stride, width, height, tx, j, solid, nullptr);
+                if (op == TileOp::Solid) write_tile(buf, stride, width, height, tx, j, solid, nullptr, flusher);
                 else if (op == TileOp::ColorBuffer) {
                     painter.compute_srgb(channels);
-                    write_tile(buf, stride, width, height, tx, j, nullptr, painter.srgb);
+                    write_tile(buf, stride, width, height, tx, j, nullptr, painter.srgb, flusher);
                     if (tile_dump) {
                         float* d = tile_dump + ((size_t)j * tiles_w + tx) * 1024;
                         for (int i = 0; i < 256; i++) { d[i * 4] = painter.r[i]; d[i * 4 + 1] = painter.g[i]; d[i * 4 + 2] = painter.b[i]; d[i * 4 + 3] = painter.a[i]; }
@@ -1314,8 +1324,9 @@ void oracle_gradient_column(const uint32_t* style_words, float x, float y, float
 
 // paint a caller-supplied sorted stream.  cache_id < 0: no cache.  tile_dump (optional): f32 rgba
 // of every ColorBuffer tile, [tiles_h][tiles_w][256 column-major][4].
-int oracle_paint(void* o_, const uint64_t* segs, size_t n, uint8_t* dst, uint32_t width, uint32_t height, size_t stride,
-                 const uint8_t channels[4], const float clear[4], const forma_rect_t* crop, int cache_id, float* tile_dump) {
+static int paint_entry(void* o_, const uint64_t* segs, size_t n, uint8_t* dst, uint32_t width, uint32_t height, size_t stride,
+                       const uint8_t channels[4], const float clear[4], const forma_rect_t* crop, int cache_id, float* tile_dump,
+                       FlusherRef flusher) {
     Oracle* o = (Oracle*)o_; set_threads(o->threads);
     uint8_t ch[4] = {channels[0], channels[1], channels[2], channels[3]};
     Color cc{clear[0], clear[1], clear[2], clear[3]};
@@ -1330,9 +1341,19 @@ int oracle_paint(void* o_, const uint64_t* segs, size_t n, uint8_t* dst, uint32_
     Crop cr{false, 0, 0, 0, 0};
     if (crop) cr = {true, crop->x0 / 16, (crop->x1 + 15) / 16, crop->y0 / 16, (crop->y1 + 15) / 16};  // Rect::new :43-52
     PaintCtx ctx = o->pctx(cache != nullptr);
-    paint(segs, n, ctx, dst, width, height, stride, ch, cc, cr, cache, tile_dump);
+    paint(segs, n, ctx, dst, width, height, stride, ch, cc, cr, cache, tile_dump, flusher);
     if (cache) { cache->has_clear = true; cache->clear = cc; }         // renderer.rs:217-218
     return 0;
+}
+int oracle_paint(void* o_, const uint64_t* segs, size_t n, uint8_t* dst, uint32_t width, uint32_t height, size_t stride,
+                 const uint8_t channels[4], const float clear[4], const forma_rect_t* crop, int cache_id, float* tile_dump) {
+    return paint_entry(o_, segs, n, dst, width, height, stride, channels, clear, crop, cache_id, tile_dump, FlusherRef{nullptr, nullptr});
+}
+// the same with a Flusher (Buffer::flusher, cpu/buffer/mod.rs:43-49; painter::for_each_row's `flusher` argument)
+int oracle_paint_flush(void* o_, const uint64_t* segs, size_t n, uint8_t* dst, uint32_t width, uint32_t height, size_t stride,
+                       const uint8_t channels[4], const float clear[4], const forma_rect_t* crop, int cache_id,
+                       oracle_flush_fn fn, void* user) {
+    return paint_entry(o_, segs, n, dst, width, height, stride, channels, clear, crop, cache_id, nullptr, FlusherRef{fn, user});
 }
 int oracle_cache_clear(void* o_, int cache_id) { Oracle* o = (Oracle*)o_; auto it = o->caches.find(cache_id); if (it != o->caches.end()) it->second.clear_all(); return 0; }
 
@@ -1345,6 +1366,15 @@ int oracle_render(void* o_, uint8_t* dst, uint32_t width, uint32_t height, size_
     o->sorted = o->unsorted;
     sort_segments(o->sorted, o->threads);
     return oracle_paint(o_, o->sorted.data(), o->sorted.size(), dst, width, height, stride, channels, clear, crop, cache_id, tile_dump);
+}
+int oracle_render_flush(void* o_, uint8_t* dst, uint32_t width, uint32_t height, size_t stride, const uint8_t channels[4],
+                        const float clear[4], const forma_rect_t* crop, int cache_id, oracle_flush_fn fn, void* user) {
+    Oracle* o = (Oracle*)o_; set_threads(o->threads);
+    prepare_lines(o->x.data(), o->y.data(), o->line_slot.data(), o->x.size(), o->geoms.data(), o->geoms.size(), (float)width, (float)height, o->lines);
+    rasterize(o->lines, o->unsorted);
+    o->sorted = o->unsorted;
+    sort_segments(o->sorted, o->threads);
+    return oracle_paint_flush(o_, o->sorted.data(), o->sorted.size(), dst, width, height, stride, channels, clear, crop, cache_id, fn, user);
 }
 size_t oracle_last_n(void* o_) { return ((Oracle*)o_)->unsorted.size(); }
 
@@ -1377,5 +1407,83 @@ int oracle_time_frame(void* o_, uint32_t width, uint32_t height, int iters, doub
     return -1;
 #endif
 }
+
+
+// ---- LayerWorkbench / Painter harness: lets tests restate the reference's own unit tests of
+//      layer_workbench/mod.rs:475-1307 and painter/mod.rs:976-1000 (`paint_tile`) against this oracle ----------
+struct WbHarness {
+    Oracle* o; Workbench wb; Painter painter; CachedTile cached; bool use_cached = false;
+    std::vector<uint64_t> segs; TileCtx t{};
+};
+void* oracle_wb_new(void* o_) { WbHarness* h = new WbHarness(); h->o = (Oracle*)o_; return h; }
+void  oracle_wb_free(void* h) { delete (WbHarness*)h; }
+void  oracle_wb_init(void* h_, const uint32_t* layers, const int8_t* covers, size_t n) {        // LayerWorkbench::init :196-199
+    WbHarness* h = (WbHarness*)h_; std::vector<CoverCarry> cc(n);
+    for (size_t i = 0; i < n; i++) { cc[i].layer = layers[i]; memcpy(cc[i].cover.c, covers + 16 * i, 16); }
+    h->wb.init(std::move(cc));
+}
+void oracle_wb_cached_tile_set(void* h_, int use, int has_lc, uint32_t lc, int has_sc, const uint8_t sc[4]) {
+    WbHarness* h = (WbHarness*)h_; h->use_cached = use != 0;
+    h->cached.tags = (uint8_t)((has_lc ? 2 : 0) | (has_sc ? 1 : 0)); h->cached.layer_count = lc & 0xFFFFFF;
+    if (sc) memcpy(h->cached.solid, sc, 4);
+}
+void oracle_wb_cached_tile_get(void* h_, int* has_lc, uint32_t* lc, int* has_sc, uint8_t sc[4]) {
+    WbHarness* h = (WbHarness*)h_; *has_lc = h->cached.has_lc(); *lc = h->cached.layer_count; *has_sc = h->cached.has_sc(); memcpy(sc, h->cached.solid, 4);
+}
+void oracle_wb_context(void* h_, uint32_t tile_x, uint32_t tile_y, const uint64_t* segs, size_t n, int has_cached_clear,
+                       const float cached_clear[4], const uint8_t channels[4], const float clear[4]) {   // Context :130-139
+    WbHarness* h = (WbHarness*)h_; h->segs.assign(segs, segs + n);
+    h->t.tile_x = tile_x; h->t.tile_y = tile_y; h->t.segs = h->segs.data(); h->t.n = n;
+    h->t.has_cached_clear = has_cached_clear != 0;
+    h->t.cached_clear = has_cached_clear ? Color{cached_clear[0], cached_clear[1], cached_clear[2], cached_clear[3]} : Color{};
+    h->t.cached_tile = h->use_cached ? &h->cached : nullptr;
+    memcpy(h->t.channels, channels, 4); h->t.clear = {clear[0], clear[1], clear[2], clear[3]};
+}
+void oracle_wb_populate(void* h_) { WbHarness* h = (WbHarness*)h_; h->wb.populate_layers(h->t.segs, h->t.n); }
+void oracle_wb_next_tile(void* h_) { ((WbHarness*)h_)->wb.next_tile(); }
+// which: 0 tile_unchanged, 1 skip_trivial_clips, 2 skip_fully_covered_layers.  Returns 0 Continue / 1 Break(None) / 2 Break(Solid)
+int oracle_wb_pass(void* h_, int which, float solid[4]) {
+    WbHarness* h = (WbHarness*)h_; PaintCtx ctx = h->o->pctx(true); Color c{};
+    int r = which == 0 ? tile_unchanged_pass(h->wb, h->t, ctx) : which == 1 ? skip_trivial_clips_pass(h->wb, h->t, ctx)
+                                                                           : skip_fully_covered_layers_pass(h->wb, h->t, ctx, c);
+    if (r == 2 && solid) { solid[0] = c.r; solid[1] = c.g; solid[2] = c.b; solid[3] = c.a; }
+    return r;
+}
+// drive_tile_painting :280-342.  Returns TileWriteOp: 0 None, 1 Solid (bytes in solid_out), 2 ColorBuffer
+int oracle_wb_drive(void* h_, uint8_t solid_out[4]) {
+    WbHarness* h = (WbHarness*)h_; PaintCtx ctx = h->o->pctx(true);
+    h->painter.has_clip = false;                                       // paint_tile_row :551 (`self.clip = None`)
+    return (int)drive_tile_painting(h->wb, h->painter, h->t, ctx, solid_out);
+}
+void oracle_wb_colors(void* h_, float* out1024) {                      // Painter::colors (tests), column-major x * 16 + y
+    WbHarness* h = (WbHarness*)h_;
+    for (int i = 0; i < 256; i++) { out1024[4 * i] = h->painter.r[i]; out1024[4 * i + 1] = h->painter.g[i]; out1024[4 * i + 2] = h->painter.b[i]; out1024[4 * i + 3] = h->painter.a[i]; }
+}
+size_t oracle_wb_ids(void* h_, uint32_t* out, size_t cap, int masked_only) {   // MaskedVec::iter_masked / iter
+    WbHarness* h = (WbHarness*)h_; size_t k = 0;
+    for (size_t i = 0; i < h->wb.ids.size(); i++) {
+        if (masked_only && !(i >= h->wb.skipped && h->wb.ids[i].mask)) continue;
+        if (k < cap) out[k] = h->wb.ids[i].id;
+        k++;
+    }
+    return k;
+}
+int oracle_wb_skip_clipping(void* h_, uint32_t id) { return (int)((WbHarness*)h_)->wb.skip_clipping.count(id); }
+int oracle_wb_seg_range(void* h_, uint32_t id, size_t* lo, size_t* hi) {
+    WbHarness* h = (WbHarness*)h_; auto it = h->wb.seg_ranges.find(id);
+    if (it == h->wb.seg_ranges.end()) return 0;
+    *lo = it->second.first; *hi = it->second.second; return 1;
+}
+int oracle_wb_queue_index(void* h_, uint32_t id) {
+    WbHarness* h = (WbHarness*)h_; auto it = h->wb.queue_idx.find(id);
+    return it == h->wb.queue_idx.end() ? -1 : (int)it->second;
+}
+size_t oracle_wb_queue(void* h_, uint32_t* layers, int8_t* covers, size_t cap) {    // carries handed to the next tile
+    WbHarness* h = (WbHarness*)h_; size_t n = h->wb.queue.size();
+    for (size_t i = 0; i < n && i < cap; i++) { layers[i] = h->wb.queue[i].layer; memcpy(covers + 16 * i, h->wb.queue[i].cover.c, 16); }
+    return n;
+}
+int oracle_cover_is_empty(const int8_t c[16], int even_odd) { Cover k; memcpy(k.c, c, 16); return k.is_empty(even_odd != 0); }
+int oracle_cover_is_full(const int8_t c[16], int even_odd) { Cover k; memcpy(k.c, c, 16); return k.is_full(even_odd != 0); }
 
 }  // extern "C"

@@ -39,6 +39,14 @@ IMAGE_DTYPE = np.dtype([("texel_offset", "<u8"), ("width", "<u4"), ("height", "<
 NONE = 0xFFFFFFFF
 
 _lib = None
+FLUSH_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t, C.c_void_p)   # Flusher::flush(slice) (buffer/layout/mod.rs:29-34)
+
+
+def _flush_cb(flusher):
+    """ctypes trampoline: `flusher(view)` gets a writable uint8 numpy view of the row slice."""
+    def cb(ptr, n, _user):
+        flusher(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(n,)))
+    return FLUSH_FN(cb)
 
 
 def lib():
@@ -117,6 +125,28 @@ def lib():
         L.oracle_last_n.restype = sz
         L.oracle_time_frame.argtypes = [vp, u32, u32, i32, vp, vp, vp, vp]
         L.oracle_time_frame.restype = i32
+        L.oracle_paint_flush.argtypes = [vp, vp, sz, vp, u32, u32, sz, vp, vp, vp, i32, FLUSH_FN, vp]
+        L.oracle_paint_flush.restype = i32
+        L.oracle_render_flush.argtypes = [vp, vp, u32, u32, sz, vp, vp, vp, i32, FLUSH_FN, vp]
+        L.oracle_render_flush.restype = i32
+        L.oracle_wb_new.argtypes = [vp]; L.oracle_wb_new.restype = vp
+        L.oracle_wb_free.argtypes = [vp]
+        L.oracle_wb_init.argtypes = [vp, vp, vp, sz]
+        L.oracle_wb_cached_tile_set.argtypes = [vp, i32, i32, u32, i32, vp]
+        L.oracle_wb_cached_tile_get.argtypes = [vp, vp, vp, vp, vp]
+        L.oracle_wb_context.argtypes = [vp, u32, u32, vp, sz, i32, vp, vp, vp]
+        L.oracle_wb_populate.argtypes = [vp]
+        L.oracle_wb_next_tile.argtypes = [vp]
+        L.oracle_wb_pass.argtypes = [vp, i32, vp]; L.oracle_wb_pass.restype = i32
+        L.oracle_wb_drive.argtypes = [vp, vp]; L.oracle_wb_drive.restype = i32
+        L.oracle_wb_colors.argtypes = [vp, vp]
+        L.oracle_wb_ids.argtypes = [vp, vp, sz, i32]; L.oracle_wb_ids.restype = sz
+        L.oracle_wb_skip_clipping.argtypes = [vp, u32]; L.oracle_wb_skip_clipping.restype = i32
+        L.oracle_wb_seg_range.argtypes = [vp, u32, vp, vp]; L.oracle_wb_seg_range.restype = i32
+        L.oracle_wb_queue_index.argtypes = [vp, u32]; L.oracle_wb_queue_index.restype = i32
+        L.oracle_wb_queue.argtypes = [vp, vp, vp, sz]; L.oracle_wb_queue.restype = sz
+        L.oracle_cover_is_empty.argtypes = [vp, i32]; L.oracle_cover_is_empty.restype = i32
+        L.oracle_cover_is_full.argtypes = [vp, i32]; L.oracle_cover_is_full.restype = i32
         _lib = L
     return _lib
 
@@ -278,7 +308,7 @@ class Oracle:
         return out
 
     def paint(self, segs, width, height, channels=(0, 1, 2, 3), clear=(1, 1, 1, 0), crop=None, cache_id=-1,
-              dst=None, stride=None, dump_tiles=False):
+              dst=None, stride=None, dump_tiles=False, flusher=None):
         segs = np.ascontiguousarray(segs, np.uint64)
         stride = stride or width * 4
         if dst is None:
@@ -288,20 +318,30 @@ class Oracle:
         dump = None
         if dump_tiles:
             dump = np.zeros((((height + 15) // 16), ((width + 15) // 16), 256, 4), np.float32)
-        rc = lib().oracle_paint(self._h, _p(segs), len(segs), _p(dst), width, height, stride, _p(ch), _p(cl),
-                                None if rect is None else C.addressof(rect), cache_id, _p(dump))
+        if flusher is not None:
+            cb = _flush_cb(flusher)
+            rc = lib().oracle_paint_flush(self._h, _p(segs), len(segs), _p(dst), width, height, stride, _p(ch), _p(cl),
+                                          None if rect is None else C.addressof(rect), cache_id, cb, None)
+        else:
+            rc = lib().oracle_paint(self._h, _p(segs), len(segs), _p(dst), width, height, stride, _p(ch), _p(cl),
+                                    None if rect is None else C.addressof(rect), cache_id, _p(dump))
         assert rc == 0
         return (dst, dump) if dump_tiles else dst
 
     def render(self, width, height, channels=(0, 1, 2, 3), clear=(1, 1, 1, 0), crop=None, cache_id=-1,
-               dst=None, stride=None):
+               dst=None, stride=None, flusher=None):
         stride = stride or width * 4
         if dst is None:
             dst = np.zeros((height, stride), np.uint8)
         ch = np.asarray(channels, np.uint8); cl = np.asarray(clear, np.float32)
         rect = None if crop is None else RectT(*crop)
-        rc = lib().oracle_render(self._h, _p(dst), width, height, stride, _p(ch), _p(cl),
-                                 None if rect is None else C.addressof(rect), cache_id, None)
+        if flusher is not None:
+            cb = _flush_cb(flusher)
+            rc = lib().oracle_render_flush(self._h, _p(dst), width, height, stride, _p(ch), _p(cl),
+                                           None if rect is None else C.addressof(rect), cache_id, cb, None)
+        else:
+            rc = lib().oracle_render(self._h, _p(dst), width, height, stride, _p(ch), _p(cl),
+                                     None if rect is None else C.addressof(rect), cache_id, None)
         assert rc == 0
         return dst
 
@@ -319,6 +359,116 @@ class Oracle:
         rc = lib().oracle_time_frame(self._h, width, height, iters, *[C.byref(v) for v in t])
         assert rc == 0
         return dict(prepare=t[0].value, rasterize=t[1].value, sort=t[2].value, paint=t[3].value)
+
+
+class Workbench:
+    """Harness over the oracle's LayerWorkbench + Painter restatement (reference
+    cpu/painter/layer_workbench/mod.rs:147-342, passes/*.rs, cpu/painter/mod.rs:232-483) so that the reference's own
+    unit tests of those files can be replayed against the oracle.  Layer props / is_unchanged come from the owning
+    Oracle's style table (`Oracle.set_styles(offsets, words, unchanged)`)."""
+    CONTINUE, BREAK_NONE, BREAK_SOLID = 0, 1, 2          # ControlFlow<OptimizerTileWriteOp>
+    OP_NONE, OP_SOLID, OP_COLOR_BUFFER = 0, 1, 2         # TileWriteOp
+
+    def __init__(self, oracle: "Oracle"):
+        self._o = oracle
+        self._h = lib().oracle_wb_new(oracle._h)
+
+    def __del__(self):
+        try:
+            lib().oracle_wb_free(self._h)
+        except Exception:
+            pass
+
+    def init(self, carries):
+        """carries: [(layer_id, 16 x i8 cover)]"""
+        layers = np.asarray([c[0] for c in carries], np.uint32)
+        covers = np.asarray([c[1] for c in carries], np.int8).reshape(-1, 16) if carries else np.zeros((0, 16), np.int8)
+        covers = np.ascontiguousarray(covers)
+        lib().oracle_wb_init(self._h, _p(layers), _p(covers), len(layers))
+
+    def cached_tile(self, use=True, layer_count=None, solid_color=None):
+        sc = np.asarray(solid_color if solid_color is not None else [0, 0, 0, 0], np.uint8)
+        lib().oracle_wb_cached_tile_set(self._h, int(use), int(layer_count is not None), int(layer_count or 0),
+                                        int(solid_color is not None), _p(sc))
+
+    def cached_tile_state(self):
+        has_lc, lc, has_sc = C.c_int(0), C.c_uint32(0), C.c_int(0)
+        sc = np.zeros(4, np.uint8)
+        lib().oracle_wb_cached_tile_get(self._h, C.byref(has_lc), C.byref(lc), C.byref(has_sc), _p(sc))
+        return (lc.value if has_lc.value else None), (sc.tolist() if has_sc.value else None)
+
+    def context(self, segments=(), tile_x=0, tile_y=0, cached_clear_color=None, channels=(0, 1, 2, 3), clear_color=(0, 0, 0, 0)):
+        segs = np.ascontiguousarray(segments, np.uint64)
+        cc = np.asarray(cached_clear_color if cached_clear_color is not None else [0, 0, 0, 0], np.float32)
+        ch = np.asarray(channels, np.uint8); cl = np.asarray(clear_color, np.float32)
+        lib().oracle_wb_context(self._h, tile_x, tile_y, _p(segs), len(segs), int(cached_clear_color is not None), _p(cc), _p(ch), _p(cl))
+
+    def populate_layers(self):
+        lib().oracle_wb_populate(self._h)
+
+    def next_tile(self):
+        lib().oracle_wb_next_tile(self._h)
+
+    def _pass(self, which):
+        solid = np.zeros(4, np.float32)
+        r = lib().oracle_wb_pass(self._h, which, _p(solid))
+        return (r, tuple(float(v) for v in solid)) if r == 2 else (r, None)
+
+    def tile_unchanged_pass(self):
+        return self._pass(0)
+
+    def skip_trivial_clips_pass(self):
+        return self._pass(1)
+
+    def skip_fully_covered_layers_pass(self):
+        return self._pass(2)
+
+    def drive_tile_painting(self):
+        solid = np.zeros(4, np.uint8)
+        op = lib().oracle_wb_drive(self._h, _p(solid))
+        return (op, solid.tolist()) if op == 1 else (op, None)
+
+    def colors(self):
+        out = np.zeros((256, 4), np.float32)
+        lib().oracle_wb_colors(self._h, _p(out))
+        return out
+
+    def ids(self, masked=True):
+        out = np.zeros(4096, np.uint32)
+        n = lib().oracle_wb_ids(self._h, _p(out), len(out), int(masked))
+        return out[:n].tolist()
+
+    def skip_clipping_contains(self, layer_id):
+        return bool(lib().oracle_wb_skip_clipping(self._h, layer_id))
+
+    def segment_range(self, layer_id):
+        lo, hi = C.c_size_t(0), C.c_size_t(0)
+        ok = lib().oracle_wb_seg_range(self._h, layer_id, C.byref(lo), C.byref(hi))
+        return (lo.value, hi.value) if ok else None
+
+    def queue_index(self, layer_id):
+        i = lib().oracle_wb_queue_index(self._h, layer_id)
+        return None if i < 0 else i
+
+    def queue(self):
+        layers = np.zeros(4096, np.uint32); covers = np.zeros((4096, 16), np.int8)
+        n = lib().oracle_wb_queue(self._h, _p(layers), _p(covers), 4096)
+        return [(int(layers[i]), covers[i].tolist()) for i in range(n)]
+
+
+def cover_is_empty(cover16, even_odd=False):
+    c = np.asarray(cover16, np.int8)
+    return bool(lib().oracle_cover_is_empty(_p(c), int(even_odd)))
+
+
+def cover_is_full(cover16, even_odd=False):
+    c = np.asarray(cover16, np.int8)
+    return bool(lib().oracle_cover_is_full(_p(c), int(even_odd)))
+
+
+def pixel_segment(layer, tile_x, tile_y, local_x, local_y, dam, cover):
+    """PixelSegment::new (reference cpu/pixel_segment.rs:36-71)"""
+    return int(lib().oracle_pixel_segment_new(layer, tile_x, tile_y, local_x, local_y, dam, cover))
 
 
 # ---- field extractors of the packed u64 (reference cpu/pixel_segment.rs:90-138) ---------------

@@ -152,7 +152,7 @@ def test_renderer_keeps_tables_resident_until_something_changes():
     r._ctx = _FakeCtx(); r._caches = set(); r._geom_owner = None; r._geom_version = -1; r._slot_of = {}
     r.last_timings = {}; r.host_tables = {}; r._tables_key = None; r._marked_key = None
     r._upload_geometry = lambda comp: (setattr(r, "_geom_owner", comp._shared), setattr(r, "_geom_version", comp._shared.geometry_version),
-                                       setattr(r, "_slot_of", {l.geom_id: i for i, l in enumerate(comp.layers.values())}))
+                                       setattr(r, "_slot_of", {l.geom_id(): i for i, l in enumerate(comp.layers.values())}))
     comp = api.Composition()
     tri = api.PathBuilder().move_to(api.Point(1, 1)).line_to(api.Point(9, 1)).line_to(api.Point(9, 9)).build()
     for o in range(3):

@@ -1,0 +1,289 @@
+"""GPU parity, part 2: entry points and configurations that round 1 left untested (VERDICT r1 "What's weak" 2):
+the 4-bit radix instantiation (the north star's literal digit width), `forma_hip_paint`, the remaining channel orders,
+BASELINE config 1 at 256 x 256, config 5 (deterministic spaceship) at 3840 x 2160 with the buffer-layer cache, the
+Flusher and a non-linear `Layout` through the product API.  Everything goes through the C ABI / product API and is
+compared with the oracle on identical inputs."""
+import os
+
+import numpy as np
+import pytest
+
+import scene as S
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import forma_amd
+    c = forma_amd.Context(0)
+    yield c
+    c.close()
+
+
+def both(ctx, comp):
+    o = orc.Oracle()
+    t = comp.tables(o)
+    S.load(o, t); S.load(ctx, t)
+    return o, t
+
+
+# ---- a8: the 4-bit digit pass ---------------------------------------------------------------------------------------------
+def test_sort_4bit_digits_10m_keys(ctx):
+    """forma_hip_sort(..., digit_bits = 4): k_onesweep<4>, 11 passes over the 44 key bits.  Same properties as the 8-bit
+    test: keys non-decreasing, stable, a permutation — i.e. bit-identical to a stable sort by `v >> 20`."""
+    rng = np.random.default_rng(11)
+    n = 10_000_000
+    v = rng.integers(0, 2 ** 63, n, dtype=np.uint64)
+    s = ctx.sort_array(v, digit_bits=4)
+    ref = v[np.argsort(v >> np.uint64(20), kind="stable")]
+    assert np.array_equal(s, ref)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 63, 64, 65, 16383, 16384, 16385, 100_001])
+def test_sort_ragged_sizes_both_digit_widths(ctx, n):
+    rng = np.random.default_rng(n + 5)
+    v = rng.integers(0, 2 ** 63, n, dtype=np.uint64)
+    v &= np.uint64(0xFFFFF00FFFFFFFFF)                      # a dead nibble inside the key: digit skipping with 4-bit digits
+    ref = v[np.argsort(v >> np.uint64(20), kind="stable")]
+    for bits in (4, 8):
+        assert np.array_equal(ctx.sort_array(v, digit_bits=bits), ref), (n, bits)
+
+
+def test_whole_frames_with_4bit_digits():
+    """One context created under FORMA_HIP_DIGIT_BITS=4 renders whole frames (synchronous first frame, read-back-free
+    second frame, out-of-order layers = full-key sort): streams bit-identical, image identical."""
+    import forma_amd
+    os.environ["FORMA_HIP_DIGIT_BITS"] = "4"
+    try:
+        c4 = forma_amd.Context(0)
+    finally:
+        del os.environ["FORMA_HIP_DIGIT_BITS"]
+    try:
+        for comp, (w, h) in ((S.random_mixed(), (512, 384)), (S.random_cubics(300, 1920, 1080), (1920, 1080))):
+            o, _ = both(c4, comp)
+            want = o.render(w, h, clear=(0.1, 0.2, 0.3, 1.0))
+            for frame in range(2):
+                got, tm = c4.render(w, h, clear=(0.1, 0.2, 0.3, 1.0), timings=True)
+                assert np.array_equal(c4.segments(0), o.segments(0)) and np.array_equal(c4.segments(1), o.segments(1))
+                assert np.abs(want.astype(int) - got.astype(int)).max() <= 1
+            assert tm["n_sort_passes"] >= 3                 # 4-bit digits: more passes than the 8-bit plan's two
+        comp = S.Composition(insertion_order=True)          # geometry pushed out of paint order: the layer digits are sorted too
+        for order in (5, 1, 9, 3, 70000):
+            comp.get_mut_or_insert_default(order).insert(S.custom_circle(100 + order % 7 * 20, 90, 60)).set_props(S.solid((order % 3 / 2, 0.5, 0.2, 0.8)))
+        o, _ = both(c4, comp)
+        want = o.render(320, 200)
+        got = c4.render(320, 200)
+        assert np.array_equal(c4.segments(1), o.segments(1)) and np.abs(want.astype(int) - got.astype(int)).max() <= 1
+    finally:
+        c4.close()
+
+
+# ---- forma_hip_paint --------------------------------------------------------------------------------------------------------
+def seg(layer, tile_x, tile_y=0, lx=0, ly=0, dam=0, cover=0):
+    return orc.pixel_segment(layer, tile_x, tile_y, lx, ly, dam, cover)
+
+
+def styles(props_by_layer):
+    n = max(props_by_layer) + 1
+    offsets = np.full(n, S.NONE, np.uint32); words = []
+    for lid, p in sorted(props_by_layer.items()):
+        offsets[lid] = len(words); words += S.encode_props(p, [])
+    return offsets, np.asarray(words, np.uint32)
+
+
+def test_paint_entry_point_on_reference_vectors(ctx):
+    """forma_hip_paint on the hand-built sorted streams of the reference's painter tests `skip_opaque_tiles`
+    (painter/mod.rs:1606-1715: left-of-canvas carry, opaque cover hides lower layers) and `crop` (:1717-1781)."""
+    T = 16
+    segments = [seg(2, -1, 0, T - 1, y, 0, 16) for y in range(T)] + [seg(0, -1, 0, T - 1, 0, 0, 16), seg(1, 0, 0, 0, 1, 0, 16)]
+    segments += [seg(2, 1, 0, T - 1, y, 0, -16) for y in range(T)]
+    segments.sort()
+    off, words = styles({0: S.solid((0, 0, 1, 1)), 1: S.solid((0, 1, 0, 1)), 2: S.solid((1, 0, 0, 1))})
+    o = orc.Oracle(); o.set_styles(off, words); ctx.set_styles(off, words)
+    want = o.paint(segments, 3 * T, T, clear=(0, 0, 0, 1))
+    got = ctx.paint(segments, 3 * T, T, clear=(0, 0, 0, 1))
+    assert np.array_equal(want, got)
+    px = got.reshape(T, 3 * T, 4)
+    assert (px[:, :2 * T] == [255, 0, 0, 255]).all() and (px[0, 2 * T:] == [0, 0, 255, 255]).all() and (px[1, 2 * T:] == [0, 255, 0, 255]).all()
+    assert (px[2:, 2 * T:] == [0, 0, 0, 255]).all()
+    # crop: only the tiles of the (tile-rounded) rectangle are written into the caller's buffer
+    segments = sorted(seg(0, 0, j, T - 1, y, 0, 16) for j in range(3) for y in range(T))
+    off, words = styles({0: S.solid((0, 0, 1, 1))})
+    o.set_styles(off, words); ctx.set_styles(off, words)
+    crop = (T, 2 * T + T // 2, T, 2 * T)
+    want = o.paint(segments, 3 * T, 3 * T, clear=(1, 0, 0, 1), crop=crop)
+    got = ctx.paint(segments, 3 * T, 3 * T, clear=(1, 0, 0, 1), crop=crop, dst=np.zeros((3 * T, 3 * T * 4), np.uint8))
+    assert np.array_equal(want, got)
+    px = got.reshape(3 * T, 3 * T, 4)
+    assert not px[:T].any() and not px[2 * T:].any() and not px[T:2 * T, :T].any() and (px[T:2 * T, T:] == [0, 0, 255, 255]).all()
+
+
+def test_paint_entry_point_on_rendered_streams(ctx):
+    """forma_hip_paint(sorted stream of the oracle) == oracle.paint(same stream), with odd strides, all fills / blends /
+    clips (random_mixed) and an empty stream."""
+    comp = S.random_mixed()
+    o, _ = both(ctx, comp)
+    w, h = 500, 301
+    o.prepare_lines(w, h); o.rasterize(); srt = o.sort()
+    stride = w * 4 + 12
+    want = o.paint(srt, w, h, clear=(0.3, 0.3, 0.3, 1.0), stride=stride, dst=np.full((h, stride), 9, np.uint8))
+    got = ctx.paint(srt, w, h, clear=(0.3, 0.3, 0.3, 1.0), stride=stride, dst=np.full((h, stride), 9, np.uint8))
+    assert np.abs(want.astype(int) - got.astype(int)).max() <= 1
+    assert (got[:, w * 4:] == 9).all()                      # bytes between the row and the stride are never touched
+    want = o.paint(np.zeros(0, np.uint64), 40, 24, clear=(0.5, 0.25, 1.0, 0.5))
+    got = ctx.paint(np.zeros(0, np.uint64), 40, 24, clear=(0.5, 0.25, 1.0, 0.5))
+    assert np.array_equal(want, got)
+
+
+# ---- a16 / f4: every channel order of cpu/channel.rs:57-62 ---------------------------------------------------------------------
+@pytest.mark.parametrize("channels", [S.RGBA, S.BGRA, S.RGB0, S.BGR0, S.RGB1, S.BGR1], ids=["RGBA", "BGRA", "RGB0", "BGR0", "RGB1", "BGR1"])
+@pytest.mark.parametrize("clear", [(1.0, 1.0, 1.0, 0.0), (0.2, 0.4, 0.6, 1.0)], ids=["clear_alpha0", "clear_opaque"])
+def test_all_channel_orders(ctx, channels, clear):
+    o, _ = both(ctx, S.random_mixed(n=120, width=256, height=160, seed=3))
+    a = o.render(256, 160, channels=channels, clear=clear)
+    b = ctx.render(256, 160, channels=channels, clear=clear)
+    assert np.abs(a.astype(int) - b.astype(int)).max() <= 1
+    assert np.array_equal(a, b)
+
+
+# ---- BASELINE configs[0]: the e2e shapes at 256 x 256 -------------------------------------------------------------------------
+def test_config1_e2e_scenes_at_256(ctx, monkeypatch):
+    """the e2e scene builders with WIDTH = HEIGHT = 256, PADDING = 32 (16 x 16 tiles), every stage."""
+    monkeypatch.setattr(S, "WIDTH", 256.0); monkeypatch.setattr(S, "HEIGHT", 256.0); monkeypatch.setattr(S, "PADDING", 32.0)
+    scenes = S.e2e_scenes()
+    for name in ("linear_gradient", "radial_gradient", "solid_color__blue", "blend_modes__Hue", "blend_modes__SoftLight",
+                 "fill_rules__EvenOdd", "clipping", "clipping2", "texture"):
+        o, _ = both(ctx, scenes[name])
+        want = o.render(256, 256)
+        got = ctx.render(256, 256)
+        assert np.array_equal(ctx.segments(0), o.segments(0)), name
+        assert np.array_equal(ctx.segments(1), o.segments(1)), name
+        assert np.array_equal(want, got), name
+
+
+# ---- BASELINE configs[4]: deterministic spaceship at 4K with the per-tile damage optimizer --------------------------------------
+def test_config5_spaceship_4k_with_cache_matches_oracle():
+    """`forma_amd.spaceship.Spaceship` (the reference demo's game logic) at 3840 x 2160, BGR1, clear
+    (1, 1, 1, 0), one persistent BufferLayerCache (demo/src/runner.rs:150-165).  The product and the oracle-backed mirror
+    of the API run the same game for 4 s of game time (240 frames); after EVERY frame the two carried buffers must hold
+    the same bytes, and on sampled frames the same set of tiles must have been rewritten."""
+    import ref_api
+    from forma_amd import api
+    from forma_amd.spaceship import Spaceship
+    W, H = 3840, 2160
+    sides = []
+    for a in (ref_api, api):
+        comp, r = a.Composition(), a.Renderer()
+        sides.append(dict(api=a, comp=comp, r=r, cache=r.create_buffer_layer_cache(), game=Spaceship(a, W, H),
+                          buf=np.zeros(W * H * 4, np.uint8), lay=a.LinearLayout(W, W * 4, H)))
+    partial = 0
+    for f in range(240):
+        sample = f < 8 or f % 8 == 0
+        touched = []
+        for s in sides:
+            s["game"].compose(s["comp"])
+            before = s["buf"].copy() if sample else None
+            s["r"].render(s["comp"], s["api"].BufferBuilder(s["buf"], s["lay"]).layer_cache(s["cache"]).build(), s["api"].BGR1,
+                          s["api"].Color(1, 1, 1, 0), None)
+            if sample:
+                touched.append((s["buf"] != before).reshape(H // 16, 16, W // 16, 16, 4).any(axis=(1, 3, 4)))
+        assert len(sides[0]["game"].actors) == len(sides[1]["game"].actors)
+        assert np.array_equal(sides[0]["buf"], sides[1]["buf"]), f"frame {f}"
+        if sample:
+            assert np.array_equal(touched[0], touched[1]), f"frame {f}: different tiles rewritten"
+            partial += int(touched[1].any() and not touched[1].all())
+    assert partial >= 10                                    # partial damage (a few tiles per frame) was actually exercised
+    assert len(sides[1]["game"].actors) >= 5
+
+
+# ---- a17 / f4: Flusher and a generic Layout through the product API -------------------------------------------------------------
+def test_generic_layout_and_flusher():
+    from forma_amd import api
+
+    class Tiled(api.Layout):                                # cpu/buffer/layout/mod.rs:51-163: a user-defined Layout
+        def __init__(self, w, h):
+            self._w, self._h = w, h
+
+        def width(self): return self._w
+        def height(self): return self._h
+        def slices_per_tile(self): return 16
+
+        def slices(self, buffer):
+            tiles = buffer.reshape(self.height_in_tiles() * self.width_in_tiles(), 16, 64)
+            return [tiles[t, y] for t in range(len(tiles)) for y in range(16)]
+
+        @staticmethod
+        def write(slices, flusher, fill):
+            kind, payload = fill
+            for y, row in enumerate(slices):
+                px = row.reshape(16, 4)
+                px[:] = payload if kind == "solid" else np.asarray(payload).reshape(16, 16, 4)[:, y]
+            if flusher is not None:
+                for row in slices:
+                    flusher.flush(row)
+
+    class Counting:
+        def __init__(self): self.n = 0
+        def flush(self, s): self.n += 1; assert len(s) == 64
+
+    W, H = 80, 48                                           # 5 x 3 tiles
+    comp = api.Composition()
+    P = api.Point
+    tri = api.PathBuilder().move_to(P(4, 4)).line_to(P(70, 10)).line_to(P(30, 44)).build()
+    gb = api.GradientBuilder(P(0, 0), P(80, 48)); gb.color(api.Color(1, 0, 0, 1)).color(api.Color(0, 0, 1, 1))
+    comp.get_mut_or_insert_default(api.Order(0)).insert(tri).set_props(api.Props(func=api.Func.Draw(api.Style(fill=api.Fill.Gradient(gb.build())))))
+    r = api.Renderer(0)
+    linear = np.zeros(W * H * 4, np.uint8)
+    r.render(comp, api.BufferBuilder(linear, api.LinearLayout(W, W * 4, H)).build(), api.RGBA, api.Color(1, 1, 1, 1), None)
+    tiled = np.zeros(W * H * 4, np.uint8)
+    fl = Counting()
+    r.render(comp, api.BufferBuilder(tiled, Tiled(W, H)).flusher(fl).build(), api.RGBA, api.Color(1, 1, 1, 1), None)
+    want = linear.reshape(3, 16, 5, 16, 4).transpose(0, 2, 1, 3, 4).reshape(-1)
+    assert np.array_equal(tiled, want)
+    assert fl.n == 15 * 16
+    # with a cache, a second identical frame writes nothing through the layout
+    cache = r.create_buffer_layer_cache()
+    r.render(comp, api.BufferBuilder(tiled, Tiled(W, H)).layer_cache(cache).build(), api.RGBA, api.Color(1, 1, 1, 1), None)
+    tiled[:] = 7; fl = Counting()
+    r.render(comp, api.BufferBuilder(tiled, Tiled(W, H)).layer_cache(cache).flusher(fl).build(), api.RGBA, api.Color(1, 1, 1, 1), None)
+    assert (tiled == 7).all() and fl.n == 0
+
+
+def test_tiles_written_reports_crop_and_damage(ctx):
+    o, t = both(ctx, S.random_mixed(n=60, width=160, height=96, seed=8))
+    ctx.render(160, 96, crop=(20, 100, 10, 40))
+    f = ctx.tiles_written(160, 96).reshape(6, 10)
+    want = np.zeros((6, 10), np.uint8); want[0:3, 1:7] = 1
+    assert np.array_equal(f, want)
+    ctx.cache_clear(7)
+    buf = np.zeros((96, 640), np.uint8)
+    ctx.render(160, 96, cache_id=7, dst=buf)
+    assert ctx.tiles_written(160, 96).all()
+    un = np.ones_like(t["unchanged"])
+    ctx.set_styles(t["style_offsets"], t["style_words"], un)
+    ctx.render(160, 96, cache_id=7, dst=buf)
+    assert not ctx.tiles_written(160, 96).any()
+    ctx.render(160, 96, cache_id=7, device_only=True)        # device-resident frame: flags fetched on demand
+    assert not ctx.tiles_written(160, 96).any()
+
+
+def test_bad_texture_index_and_style_offsets_are_rejected(ctx):
+    """a style offset near 2^32 must not wrap; a texture style naming an image that was never uploaded is an
+    argument error at render time (set_styles / set_images are separate calls)."""
+    from forma_amd import FormaError
+    with pytest.raises(FormaError):
+        ctx.set_styles(np.asarray([0xFFFFFFFE], np.uint32), np.zeros(8, np.uint32))
+    img = S.Image.from_srgba([[255, 0, 0, 255]] * 4, 2, 2)
+    comp = S.Composition()
+    comp.get_mut_or_insert_default(0).insert(S.square()).set_props(S.Props(fill=S.Texture((1, 0, 0, 1, 0, 0), img)))
+    o = orc.Oracle()
+    t = comp.tables(o)
+    S.load(ctx, t)
+    ctx.set_images(np.zeros(0, orc.IMAGE_DTYPE), np.zeros((0, 4), np.uint16))
+    with pytest.raises(FormaError):
+        ctx.render(64, 64)
+    S.load(ctx, t)
+    S.load(o, t)
+    assert np.array_equal(ctx.render(64, 64), o.render(64, 64))
