@@ -29,6 +29,7 @@ struct DevBuf {
 };
 
 constexpr int MAX_PASS_EVENTS = 16;
+constexpr size_t SEG_PAD = 16;          // segment buffers are over-allocated: stream kernels read whole 64-byte lane pieces
 enum { ST_PREPARE = 0, ST_RASTER, ST_SORT, ST_CARRY, ST_PAINT, ST_D2H, ST_COUNT };
 
 }  // namespace
@@ -82,6 +83,7 @@ struct forma_hip_ctx {
     // forma_hip_render plans the sort from the previous frame's values and verifies them when the frame is done
     bool pred_valid = false, pred_layer_sorted = false, speculated = false;
     bool global_runsort = false;           // FORMA_HIP_GLOBAL_RUNSORT=1: never order a row's runs in LDS (test switch)
+    bool legacy_runs = false;              // FORMA_HIP_LEGACY_RUNS=1: run detection by the workgroup-per-tile kernel (A/B switch)
     bool pred_counts_valid = false, no_async = false;    // N / J predictions for read-back-free frames (FORMA_HIP_SYNC=1 disables)
     uint32_t pred_N = 0, pred_J = 0, pred_w = 0, pred_h = 0;
     uint64_t pred_live44 = 0;
@@ -208,7 +210,7 @@ int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, boo
         nc_seg = DevCount{nullptr, (uint32_t)N};
         nc_cmp = DevCount{nullptr, (uint32_t)ctx->n_compact};
     }
-    HIPCHECK(ctx->seg_u.ensure((size_t)nc_seg.bound * 8));
+    HIPCHECK(ctx->seg_u.ensure(((size_t)nc_seg.bound + SEG_PAD) * 8));
     stage_begin(ctx, ST_RASTER, timing);
     launch_rasterize(ctx->stream, S, nc_cmp, nc_seg, ctx->cl_idx.as<uint32_t>(), ctx->cl_start.as<uint32_t>(),
                      ctx->block_first.as<uint32_t>(), ctx->seg_u.as<uint64_t>(), dinfo, (int)ctx->band_row0,
@@ -230,8 +232,8 @@ int run_sort(forma_hip_ctx* ctx, const uint64_t* src, DevCount nc, bool timing, 
     const size_t n = nc.bound;
     if (n >= (1ull << 30)) return fail(ctx, FORMA_E_CAPACITY, "more than 2^30-1 pixel segments on one device");
     if (digit_bits == 0) digit_bits = ctx->digit_bits;
-    HIPCHECK(ctx->seg_a.ensure(std::max<size_t>(n, 1) * 8));
-    HIPCHECK(ctx->seg_b.ensure(std::max<size_t>(n, 1) * 8));
+    HIPCHECK(ctx->seg_a.ensure((std::max<size_t>(n, 1) + SEG_PAD) * 8));
+    HIPCHECK(ctx->seg_b.ensure((std::max<size_t>(n, 1) + SEG_PAD) * 8));
     HIPCHECK(ctx->sort_counters.ensure(sort_scratch_words(std::max<size_t>(n, 1)) * 4));
     uint64_t live = ctx->live44;
     if (ctx->layer_sorted) live &= ~0x1FFFFFull;     // stream already non-decreasing in layer: stable sort by tile only
@@ -322,7 +324,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     launch_runs(ctx->stream, ctx->sorted, nc, tiles_w, tiles_h, ctx->records.as<TileRecord>(), (uint32_t)cap,
                 ctx->rk_u.as<uint64_t>(), tile_first_run, ctx->blk_edge.as<BlkEdge>(), row_count,
                 ctx->runs_scratch.as<uint32_t>(), dinfo, /*verify_plan=*/bound_j != 0 && ctx->speculated, ctx->live44,
-                ctx->layer_sorted);
+                ctx->layer_sorted, ctx->legacy_runs);
     HIPCHECK(hipGetLastError());
     DevCount jc;
     // the runs of a tile row are ordered by (layer, tile_x) inside k_carry_rows when they fit its LDS; else by a global sort
@@ -366,7 +368,8 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                           ctx->blk_edge.as<BlkEdge>(), nc, jc, ctx->layer_sf.as<uint32_t>(),
                           (uint32_t)ctx->n_orders, tiles_w, tiles_h, row_count, row_span_lo,
                           row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(),
-                          (a.cache_id >= 0 && ctx->have_unchanged) ? ctx->unchanged.as<uint8_t>() : nullptr, dinfo);
+                          (a.cache_id >= 0 && ctx->have_unchanged) ? ctx->unchanged.as<uint8_t>() : nullptr, dinfo,
+                          runs_edge_segments(ctx->legacy_runs));
     } else {
         HIPCHECK(ctx->span_key.ensure(8));
         HIPCHECK(ctx->span_cov.ensure(16));
@@ -532,6 +535,7 @@ int forma_hip_create(forma_hip_ctx** out, int device) {
     if (const char* e = getenv("FORMA_HIP_DIGIT_BITS")) { if (atoi(e) == 4) ctx->digit_bits = 4; }
     ctx->no_async = getenv("FORMA_HIP_SYNC") != nullptr;
     ctx->global_runsort = getenv("FORMA_HIP_GLOBAL_RUNSORT") != nullptr;
+    ctx->legacy_runs = getenv("FORMA_HIP_LEGACY_RUNS") != nullptr;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx; return FORMA_E_HIP;
     }
@@ -781,7 +785,7 @@ int forma_hip_rasterize(forma_hip_ctx* ctx, size_t n_lines, const uint32_t* orde
     S.a = ctx->l_a.as<float>(); S.b = ctx->l_b.as<float>(); S.c = ctx->l_c.as<float>(); S.d = ctx->l_d.as<float>();
     if ((rc = run_line_table(ctx, S, n_lines, false))) return rc;
     if (ctx->n_seg != N) return fail(ctx, FORMA_E_INTERNAL, "prefix sums disagree");
-    HIPCHECK(ctx->seg_u.ensure(N * 8));
+    HIPCHECK(ctx->seg_u.ensure((N + SEG_PAD) * 8));
     launch_rasterize(ctx->stream, S, DevCount{nullptr, (uint32_t)ctx->n_compact}, DevCount{nullptr, (uint32_t)N}, ctx->cl_idx.as<uint32_t>(),
                      ctx->cl_start.as<uint32_t>(), ctx->block_first.as<uint32_t>(), ctx->seg_u.as<uint64_t>(),
                      ctx->info.as<FrameInfo>(), 0, 0);
@@ -803,7 +807,7 @@ int forma_hip_sort(forma_hip_ctx* ctx, uint64_t* segments, size_t n, int digit_b
     if (n > 0xFFFFFFF0ull) return fail(ctx, FORMA_E_ARG, "too many segments");   // u32 prefix sums, segment.rs:90-98
     if (n == 0) return FORMA_OK;
     HIPCHECK(hipSetDevice(ctx->device));
-    HIPCHECK(ctx->seg_u.ensure(n * 8));
+    HIPCHECK(ctx->seg_u.ensure((n + SEG_PAD) * 8));
     HIPCHECK(hipMemcpyAsync(ctx->seg_u.p, segments, n * 8, hipMemcpyHostToDevice, ctx->stream));
     ctx->live44 = host_live44(segments, n);
     ctx->layer_sorted = false;
@@ -825,7 +829,7 @@ int forma_hip_paint(forma_hip_ctx* ctx, const uint64_t* sorted_segments, size_t 
     HIPCHECK(hipSetDevice(ctx->device));
     clear_stage_flags(ctx);
     if ((rc = reset_info(ctx))) return rc;
-    HIPCHECK(ctx->seg_a.ensure(std::max<size_t>(n, 1) * 8));
+    HIPCHECK(ctx->seg_a.ensure((std::max<size_t>(n, 1) + SEG_PAD) * 8));
     if (n) HIPCHECK(hipMemcpyAsync(ctx->seg_a.p, sorted_segments, n * 8, hipMemcpyHostToDevice, ctx->stream));
     ctx->sorted = ctx->seg_a.as<uint64_t>();
     ctx->n_seg = n; ctx->have_unsorted = false;
@@ -982,7 +986,7 @@ int forma_hip_reserve_segments(forma_hip_ctx* ctx, size_t n, uint64_t** dev_ptr)
     if (!ctx || !dev_ptr) return FORMA_E_ARG;
     HIPCHECK(hipSetDevice(ctx->device));
     // growing seg_u would drop the rasterized stream the caller may still be sending: grow seg_b (unused until the sort)
-    HIPCHECK(ctx->seg_b.ensure(std::max<size_t>(n, 1) * 8));
+    HIPCHECK(ctx->seg_b.ensure((std::max<size_t>(n, 1) + SEG_PAD) * 8));
     *dev_ptr = ctx->seg_b.as<uint64_t>();
     return FORMA_OK;
 }
@@ -999,7 +1003,7 @@ int forma_hip_sort_paint_frame(forma_hip_ctx* ctx, size_t n, uint8_t* dst, uint3
     clear_stage_flags(ctx);
     if ((rc = reset_info(ctx))) return rc;
     // the received stream lives in seg_b: move it to seg_u (the sort's read-only input) so a/b can ping-pong
-    HIPCHECK(ctx->seg_u.ensure(std::max<size_t>(n, 1) * 8));
+    HIPCHECK(ctx->seg_u.ensure((std::max<size_t>(n, 1) + SEG_PAD) * 8));
     if (n) HIPCHECK(hipMemcpyAsync(ctx->seg_u.p, ctx->seg_b.p, n * 8, hipMemcpyDeviceToDevice, ctx->stream));
     ctx->n_seg = n; ctx->have_unsorted = true;
     ctx->live44 = 0xFFFFFFFFFFFull;                   // no varying-bit mask for a received stream: sort every digit

@@ -155,7 +155,8 @@ size_t runs_blocks(size_t n);
 void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount n, uint32_t tiles_w, uint32_t tiles_h, TileRecord* records,
                  uint32_t rec_cap, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge,
                  uint32_t* row_tab, uint32_t* scratch, FrameInfo* info, bool verify_plan, uint64_t spec_live44,
-                 bool spec_layer_sorted);
+                 bool spec_layer_sorted, bool legacy /* workgroup-per-tile kernel with LDS bins instead of the wave kernel */);
+uint32_t runs_edge_segments(bool legacy);   // segments per BlkEdge entry of the kernel launch_runs picks
 // style flags of a layer as the carry pre-pass and the painter pass them around (bits 21.. of a record's layer word)
 #define SF_FULL        0x001u     // spans only: Cover::is_full (painter/mod.rs:200-215)
 #define SF_IS_CLIP     0x002u
@@ -171,7 +172,8 @@ void launch_carry_rows(hipStream_t s, bool local_sort, const uint64_t* sorted_ru
                        const BlkEdge* blk_edge, DevCount n_segments, DevCount n_runs,
                        const uint32_t* layer_sf /* per order: SF_* | LSF_VALID */, uint32_t n_orders, uint32_t tiles_w,
                        uint32_t tiles_h, const uint32_t* row_count, uint32_t* row_span_lo, uint32_t* row_span_cnt,
-                       uint64_t* span_key, uint4* span_cov, const uint8_t* unchanged /* per order, nullable */, FrameInfo* info);
+                       uint64_t* span_key, uint4* span_cov, const uint8_t* unchanged /* per order, nullable */, FrameInfo* info,
+                       uint32_t edge_segs);
 void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, DevCount n_runs,
                   const uint32_t* tile_first_run, const uint32_t* row_span_lo, const uint32_t* row_span_cnt,
                   const uint64_t* span_key, const uint4* span_cov,

@@ -92,6 +92,7 @@ __device__ __forceinline__ uint4 pack_bins(const int* b) {
 #define RC_THREADS 256
 __global__ __launch_bounds__(RC_THREADS) void k_runs_count(const uint64_t* __restrict__ sorted, DevCount nc, uint32_t tiles_w,
                                                            uint32_t tiles_h, uint32_t* __restrict__ counts,
+                                                           uint32_t* __restrict__ chunk_counts /* per 512 segments */,
                                                            uint32_t* __restrict__ zero_base, uint32_t zero_words,
                                                            FrameInfo* __restrict__ info, uint64_t spec_live44,
                                                            uint32_t spec_flags /* bit0 verify, bit1 layer_sorted */) {
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(RC_THREADS) void k_runs_count(const uint64_t* __res
             if (i0 + 1 == n) { const uint64_t k = sorted[i0]; v[q].x = (uint32_t)k; v[q].y = (uint32_t)(k >> 32); }
         }
         uint64_t before = (wbase > 0 && wbase < n) ? sorted[wbase - 1] : 0ull;   // the segment in front of the wave's piece
-        uint32_t c = 0;
+        uint32_t c = 0, c_first = 0;
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const uint32_t i0 = wbase + q * 128 + lane * 2;
@@ -138,8 +139,12 @@ __global__ __launch_bounds__(RC_THREADS) void k_runs_count(const uint64_t* __res
             const bool h0 = i0 < n && ((((k0 ^ pk) >> SEG_KEY_SHIFT) != 0) || i0 == 0) && seg_paintable(k0, tiles_w, tiles_h);
             const bool h1 = i0 + 1 < n && (((k1 ^ k0) >> SEG_KEY_SHIFT) != 0) && seg_paintable(k1, tiles_w, tiles_h);
             c += (uint32_t)__popcll(__ballot(h0)) + (uint32_t)__popcll(__ballot(h1));
+            if (q == 3) { c_first = c; }                                 // the wave's first 512 segments = one k_runs_wave chunk
         }
-        if (lane == 0) s_c[w] = c;
+        if (lane == 0) {
+            s_c[w] = c;
+            if (wbase < n) { chunk_counts[wbase >> 9] = c_first; chunk_counts[(wbase >> 9) + 1] = c - c_first; }
+        }
         __syncthreads();
         if (tid < 2 && t0 + tid < ntiles) counts[t0 + tid] = s_c[2 * tid] + s_c[2 * tid + 1];
         __syncthreads();
@@ -295,12 +300,228 @@ __global__ __launch_bounds__(RN_THREADS, 8) void k_runs(const uint64_t* __restri
     }
 }
 
-size_t runs_scratch_words(size_t n) { return (n + RN_TILE - 1) / RN_TILE + 16; }
-size_t runs_blocks(size_t n) { return (n + RN_TILE - 1) / RN_TILE + 1; }
+
+// ================================================================================================
+// runs, wave-autonomous form (the frame path).  A wavefront owns RW_CHUNK = 512 consecutive segments of the
+// sorted stream, lane l the 8 consecutive segments [8 l, 8 l + 8), and works in its own slice of LDS with no
+// workgroup barrier in the loop:
+//   * key changes ("breaks") are numbered along the wave (one DPP scan of the lanes' break counts): segment i
+//     belongs to slot = number of breaks at or before i; slot 0 is the run an earlier chunk opened;
+//   * every segment does ONE ds_add of its cover into bins[slot][local_y] of the wave's slice; the lane that
+//     owns a break parks the run's key, start and flags next to the bins;
+//   * then one lane per slot packs the 16 bins to 16 x i8 and writes the record — all runs of the chunk
+//     in one full-width step, whatever their length;
+//   * slot 0 goes to the chunk's BlkEdge, and a run still open at the end of a full chunk is flagged RUN_OPEN:
+//     the consumer (k_carry_rows) completes it from the following chunks' edges, as for the legacy kernel.
+// A chunk with more than RW_SLOTS runs sweeps again.  Run numbering stays dense: a workgroup is 4 waves = one
+// 2048-segment tile of k_runs_count's head counts; the only barrier orders the waves' head totals.
+// ================================================================================================
+#define RW_SEGS    8
+#define RW_CHUNK   (64 * RW_SEGS)
+#define RW_WAVES   4
+#define RW_THREADS (64 * RW_WAVES)
+#define RW_SLOTS   64                   // runs per sweep = lanes
+static_assert(RW_WAVES * RW_CHUNK == RN_TILE, "k_runs_count counts heads per RN_TILE segments");
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v) {            // lane l gets lane l - 1's value, lane 0 gets 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true);
+}
+__device__ __forceinline__ void wave_lds_fence() {                      // LDS operations of one wave retire in order: compiler fence
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct RunWaveLds {                       // one wave's slice
+    int      bins[RW_SLOTS * RN_STRIDE];  // [slot][local_y], 17-word rows (bank spread)
+    uint32_t start[RW_SLOTS + 2];         // chunk-local index of the first segment of the sweep's slots (+ the end of the last one)
+};
+
+__global__ __launch_bounds__(RW_THREADS) void k_runs_wave(const uint64_t* __restrict__ sorted, DevCount nc, uint32_t tiles_w,
+                                                          uint32_t tiles_h, TileRecord* __restrict__ records, uint32_t rec_cap,
+                                                          uint64_t* __restrict__ run_keys, uint32_t* __restrict__ tile_first_run,
+                                                          BlkEdge* __restrict__ blk_edge /* one per RW_CHUNK segments */,
+                                                          uint32_t* __restrict__ row_count,
+                                                          const uint32_t* __restrict__ run_counts, int counts_scanned,
+                                                          const uint32_t* __restrict__ chunk_counts,
+                                                          FrameInfo* __restrict__ info) {
+    __shared__ RunWaveLds s_w[RW_WAVES];
+    __shared__ uint32_t s_rows[RN_ROWS];
+    __shared__ uint32_t s_jb[RW_WAVES];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t n = dev_count(nc);
+    if (blockIdx.x * RN_TILE >= n) return;                             // whole workgroup: the grid was sized for the bound
+    RunWaveLds& L = s_w[w];
+    if (tid < RN_ROWS) s_rows[tid] = 0;
+
+    // ---- the lane's 8 segments (64 contiguous bytes: four independent 16-byte loads) and the key in front of them.
+    //      A lane past the end reads the stream's head instead; one that straddles the end over-reads by less than 64
+    //      bytes, which the segment buffers are padded for.  Both are patched below.
+    const uint32_t cbase = blockIdx.x * RN_TILE + w * RW_CHUNK;        // first segment of the wave's chunk
+    const uint32_t g0 = cbase + lane * RW_SEGS;
+    const uint32_t chunk_n = cbase < n ? min((uint32_t)RW_CHUNK, n - cbase) : 0u;
+    uint32_t lo[RW_SEGS], hi[RW_SEGS];
+    {
+        const uint4* p4 = reinterpret_cast<const uint4*>(sorted + (g0 < n ? g0 : 0u));   // 16-byte aligned (g0 multiple of 8)
+        uint4 t[RW_SEGS / 2];
+#pragma unroll
+        for (int q = 0; q < RW_SEGS / 2; q++) t[q] = p4[q];
+#pragma unroll
+        for (int q = 0; q < RW_SEGS / 2; q++) { lo[2 * q] = t[q].x; hi[2 * q] = t[q].y; lo[2 * q + 1] = t[q].z; hi[2 * q + 1] = t[q].w; }
+    }
+    const uint64_t k_before = (lane == 0 && cbase > 0 && cbase < n) ? sorted[cbase - 1] : 0ull;
+    const uint32_t row0_tyb = (uint32_t)(sorted[blockIdx.x * RN_TILE] >> 53);
+    // run index of this tile's first head = sum of the head counts of the tiles before it (the count array is L2-resident:
+    // every workgroup adds it up itself, which saves a scan launch; big frames get it pre-scanned).  Issued AFTER the segment
+    // loads and eight loads at a time: a one-load-per-round-trip loop here was most of a workgroup's life.
+    uint32_t jnext = 0;                                                 // dense index of the chunk's next paintable head
+    if (counts_scanned) jnext = run_counts[blockIdx.x];
+    else {
+        uint32_t acc = 0;
+        for (uint32_t i0 = 0; i0 < blockIdx.x; i0 += 8 * RW_THREADS) {
+            uint32_t c[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const uint32_t i = i0 + k * RW_THREADS + tid; c[k] = i < blockIdx.x ? run_counts[i] : 0u; }
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc += c[k];
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+        if (lane == 0) s_jb[w] = acc;
+    }
+    {                                                                   // + the heads of the tile's earlier chunks
+        uint32_t c = (lane < w) ? chunk_counts[(blockIdx.x * RN_TILE >> 9) + lane] : 0u;           // w <= 3 loads
+        c += __shfl_xor(c, 1, 64); c += __shfl_xor(c, 2, 64);
+        jnext += (uint32_t)__builtin_amdgcn_readlane((int)c, 0);
+    }
+    if (chunk_n < RW_CHUNK && chunk_n) {
+        // the stream ends inside this chunk (one wave per frame): what lies past the end becomes a copy of the last
+        // segment with cover 0 — same key (no break), adds nothing — so that the walks need no bounds checks
+        const uint64_t last = sorted[cbase + chunk_n - 1];
+#pragma unroll
+        for (int q = 0; q < RW_SEGS; q++)
+            if (lane * RW_SEGS + q >= chunk_n) { lo[q] = (uint32_t)last & ~0x3Fu; hi[q] = (uint32_t)(last >> 32); }
+    }
+    uint32_t plo = wave_shr1(lo[RW_SEGS - 1]), phi = wave_shr1(hi[RW_SEGS - 1]);
+    if (lane == 0) { plo = (uint32_t)k_before; phi = cbase ? (uint32_t)(k_before >> 32) : ~hi[0]; }   // the stream's first segment is a head
+    // ---- walk 1: breaks (key changes) ---------------------------------------------------------------------------------------
+    uint32_t bm = 0;                                                    // bit q of the lane's 8 segments
+    {
+        uint32_t qlo = plo, qhi = phi;
+#pragma unroll
+        for (int q = 0; q < RW_SEGS; q++) {
+            if (((hi[q] ^ qhi) | ((lo[q] ^ qlo) >> SEG_KEY_SHIFT)) != 0u) bm |= 1u << q;
+            qlo = lo[q]; qhi = hi[q];
+        }
+    }
+    const uint32_t nb = (uint32_t)__popc(bm);
+    const uint32_t nb_incl = wave_incl_scan_u32(nb);
+    const uint32_t slot_lane = nb_incl - nb;                            // breaks in the lanes before this one
+    const uint32_t R = (uint32_t)__builtin_amdgcn_readlane((int)nb_incl, 63);   // breaks in the chunk = its last slot
+    const uint32_t first_hi = (uint32_t)__builtin_amdgcn_readlane((int)hi[0], 0);
+    const uint32_t before_hi = (uint32_t)__builtin_amdgcn_readlane((int)phi, 0);
+    __syncthreads();
+    if (!counts_scanned) {
+#pragma unroll
+        for (int q = 0; q < RW_WAVES; q++) jnext += s_jb[q];
+        if (tid == 0 && blockIdx.x == (n + RN_TILE - 1) / RN_TILE - 1) info->n_runs = jnext + run_counts[blockIdx.x];
+    }
+    // first tile row any head of this tile can have (rows are non-decreasing along the stream)
+    const uint32_t row0 = row0_tyb ? row0_tyb - 1u : 0u;
+    uint32_t prev_tile = 0;                                             // tile of the run in front of the sweep's first slot
+
+    for (uint32_t s0 = 0; s0 <= R && chunk_n; s0 += RW_SLOTS) {
+        const bool one_sweep = R < RW_SLOTS;                            // wave-uniform: every slot of the chunk fits this sweep
+        // ---- clear the sweep's bins (the previous sweep's readers are done: same wave, LDS in order) --------------------
+        {
+            int4* z = reinterpret_cast<int4*>(L.bins);
+            for (int i = lane; i < RW_SLOTS * RN_STRIDE / 4; i += 64) z[i] = make_int4(0, 0, 0, 0);
+        }
+        wave_lds_fence();
+        // ---- walk 2: one ds_add per segment into bins[slot][local_y] ---------------------------------------------------------
+        {
+            uint32_t slot = slot_lane - s0;
+#pragma unroll
+            for (int q = 0; q < RW_SEGS; q++) {
+                slot += (bm >> q) & 1u;
+                if (one_sweep || slot < RW_SLOTS)                       // (slots before s0 wrap to huge values)
+                    atomicAdd(&L.bins[slot * RN_STRIDE + ((lo[q] >> 12) & 15u)], ((int)(lo[q] << 26)) >> 26);
+            }
+            // where the sweep's slots begin: a lane parks its first break, then (few lanes) the others
+            uint32_t m = bm, k = 1;
+            while (__any(m != 0u)) {
+                if (m) {
+                    const uint32_t sl = slot_lane + k - s0;
+                    if (sl <= RW_SLOTS) L.start[sl] = (uint32_t)(lane * RW_SEGS) + (uint32_t)__builtin_ctz(m);
+                    m &= m - 1u;
+                }
+                k++;
+            }
+            if (lane == 0 && R + 1u - s0 <= RW_SLOTS) L.start[R + 1u - s0] = chunk_n;    // the last run ends with the chunk
+        }
+        wave_lds_fence();
+        // ---- one lane per slot: slot s0 + lane ---------------------------------------------------------------------------------
+        const uint32_t sg = s0 + (uint32_t)lane;
+        const bool mine = sg >= 1u && sg <= R;
+        uint32_t st = 0, st_next = 0;
+        if (mine) { st = L.start[lane]; st_next = L.start[lane + 1]; }
+        const uint64_t key = mine ? sorted[cbase + st] : 0ull;          // the run's first segment (just read by this wave: a cache hit)
+        const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+        const uint32_t tyb = khi >> 21, txb = (khi >> 9) & 0xFFFu, tile = khi >> 9;
+        const bool val = mine && tyb - 1u < tiles_h && txb <= tiles_w;  // seg_paintable
+        // tile of the segment in front of the run: the previous slot's run; for slot 1 the chunk's leading run (or, when the
+        // chunk starts with a break, the segment in front of the chunk)
+        uint32_t ptile = wave_shr1(tile);
+        if (lane == 0) ptile = prev_tile;
+        if (sg == 1u) ptile = (st ? first_hi : before_hi) >> 9;
+        const bool new_tile = tile != ptile || (cbase + st) == 0u;
+        prev_tile = (uint32_t)__builtin_amdgcn_readlane((int)tile, 63);
+        const uint64_t bv = __ballot(val);
+        int b[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) b[k] = L.bins[lane * RN_STRIDE + k];
+        if (val) {
+            const uint32_t j = jnext + __builtin_amdgcn_mbcnt_hi((uint32_t)(bv >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bv, 0u));
+            const uint32_t open = (sg == R && chunk_n == RW_CHUNK) ? RUN_OPEN : 0u;
+            const uint32_t layer = ((khi & 0x1FFu) << 12) | (klo >> 20);
+            if (j < rec_cap) {                                          // asynchronous frames provision for a predicted run count
+                uint4* rp = reinterpret_cast<uint4*>(&records[j]);
+                rp[0] = pack_bins(b);                                   // the run's own cover sum; k_carry_rows turns it into the carry-in
+                rp[1] = make_uint4(cbase + st, (st_next - st) | open, layer, tile);
+                run_keys[j] = ((uint64_t)tyb << 53) | ((uint64_t)layer << 32) | j;
+            }
+            if (txb >= 1u && new_tile) tile_first_run[(tyb - 1u) * tiles_w + (txb - 1u)] = j + 1u;   // 0 = the tile has no run
+            const uint32_t rr = (tyb - 1u) - row0;
+            if (rr < RN_ROWS) atomicAdd(&s_rows[rr], 1u); else atomicAdd(&row_count[tyb - 1u], 1u);
+        }
+        jnext += (uint32_t)__popcll(bv);
+        if (sg == 0) {                                                  // slot 0: what this chunk adds to a run that began before it
+            const uint4 c = pack_bins(b);
+            uint4* ep = reinterpret_cast<uint4*>(&blk_edge[cbase / RW_CHUNK]);
+            ep[0] = c;
+            ep[1] = make_uint4(R ? L.start[1] : chunk_n, R ? 1u : 0u, 0u, 0u);
+        }
+        wave_lds_fence();
+    }
+    __syncthreads();
+    if (tid < RN_ROWS && s_rows[tid]) atomicAdd(&row_count[row0 + tid], s_rows[tid]);
+}
+
+size_t runs_scratch_words(size_t n) { return 5 * ((n + RN_TILE - 1) / RN_TILE + 2) + 16; }   // [tile counts | chunk counts]
+size_t runs_blocks(size_t n) { return (n + RW_CHUNK - 1) / RW_CHUNK + 4; }      // BlkEdge entries: one per wave chunk (legacy kernel: one per RN_TILE)
 
 void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t tiles_w, uint32_t tiles_h, TileRecord* records,
                  uint32_t rec_cap, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge, uint32_t* row_tab,
-                 uint32_t* scratch, FrameInfo* info, bool verify_plan, uint64_t spec_live44, bool spec_layer_sorted) {
+                 uint32_t* scratch, FrameInfo* info, bool verify_plan, uint64_t spec_live44, bool spec_layer_sorted, bool legacy) {
     // per-frame tile tables: [row_count | row_span_lo | row_span_cnt | painter overflow counter | first-run table] are
     // contiguous (api.cpp lays them out so) and zeroed by k_runs_count; 0 in the first-run table = the tile has no run
     const uint32_t zero_words = (tiles_h + 1) * 3 + 1 + tiles_w * tiles_h;
@@ -312,13 +533,20 @@ void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t ti
     const uint32_t ntiles = (nc.bound + RN_TILE - 1) / RN_TILE;
     const uint32_t flags = (verify_plan ? 1u : 0u) | (spec_layer_sorted ? 2u : 0u);
     const uint32_t cgrid = std::min<uint32_t>((ntiles + 1) / 2, 4096u);
-    hipLaunchKernelGGL(k_runs_count, dim3(cgrid), dim3(RC_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, scratch, row_tab,
+    uint32_t* chunk_counts = scratch + ntiles + 8;                      // 4 per tile (+ slack for the last wave's second half)
+    hipLaunchKernelGGL(k_runs_count, dim3(cgrid), dim3(RC_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, scratch, chunk_counts, row_tab,
                        zero_words, info, spec_live44, flags);
-    const int scanned = ntiles > 16384 ? 1 : 0;
+    const int scanned = (ntiles > 16384 || getenv("FORMA_HIP_SCAN_COUNTS")) ? 1 : 0;
     if (scanned) launch_scan_small_u32(s, scratch, nc, RN_TILE, &info->n_runs);   // exclusive, in place; total -> n_runs
-    hipLaunchKernelGGL(k_runs, dim3(ntiles), dim3(RN_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, records, rec_cap, run_keys,
-                       tile_first_run, blk_edge, row_tab, (const uint32_t*)scratch, scanned, info);
+    if (legacy)
+        hipLaunchKernelGGL(k_runs, dim3(ntiles), dim3(RN_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, records, rec_cap, run_keys,
+                           tile_first_run, blk_edge, row_tab, (const uint32_t*)scratch, scanned, info);
+    else
+        hipLaunchKernelGGL(k_runs_wave, dim3(ntiles), dim3(RW_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, records, rec_cap,
+                           run_keys, tile_first_run, blk_edge, row_tab, (const uint32_t*)scratch, scanned,
+                           (const uint32_t*)chunk_counts, info);
 }
+uint32_t runs_edge_segments(bool legacy) { return legacy ? RN_TILE : RW_CHUNK; }
 
 // ================================================================================================
 // carry pre-pass: one 1024-lane workgroup per tile row.  The row's runs are brought into (layer, tile_x) order (LOCAL:
@@ -392,7 +620,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
                                                            uint32_t* __restrict__ row_span_cnt,
                                                            uint64_t* __restrict__ span_key, uint4* __restrict__ span_cov,
                                                            const uint8_t* __restrict__ unchanged,
-                                                           FrameInfo* __restrict__ info) {
+                                                           FrameInfo* __restrict__ info, uint32_t edge_segs) {
     __shared__ uint32_t s_red[CR_WAVES];
     __shared__ uint64_t s_wlo[CR_WAVES], s_whi[CR_WAVES];
     __shared__ uint32_t s_wflag[CR_WAVES], s_wspan[CR_WAVES];
@@ -408,7 +636,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
         if (threadIdx.x == 0) info->plan_bad = 1u;                      // the painters (next launches) must not touch anything
         return;
     }
-    const uint32_t n_blk = (dev_count(nc_segments) + RN_TILE - 1) / RN_TILE;
+    const uint32_t n_blk = (dev_count(nc_segments) + edge_segs - 1) / edge_segs;   // BlkEdge entries (one per edge_segs segments)
     const uint32_t n_runs = dev_count(nc_runs);
     // first run of this row = sum of the run counts of the rows above
     uint32_t part = 0;
@@ -509,7 +737,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
             uint32_t sc = cu.sc;
             if (sc & RUN_OPEN) {                         // complete a run that crosses k_runs tiles with their edges
                 sc &= ~RUN_OPEN;
-                for (uint32_t b = cu.seg_start / RN_TILE + 1; b < n_blk; b++) {
+                for (uint32_t b = cu.seg_start / edge_segs + 1; b < n_blk; b++) {
                     const BlkEdge e = blk_edge[b];
                     own_lo = swar_add8(own_lo, (uint64_t)e.cov[0] | ((uint64_t)e.cov[1] << 32));
                     own_hi = swar_add8(own_hi, (uint64_t)e.cov[2] | ((uint64_t)e.cov[3] << 32));
@@ -611,16 +839,16 @@ void launch_carry_rows(hipStream_t s, bool local_sort, const uint64_t* sorted_ru
                        const BlkEdge* blk_edge, DevCount n_segments, DevCount n_runs, const uint32_t* layer_sf,
                        uint32_t n_orders, uint32_t tiles_w, uint32_t tiles_h, const uint32_t* row_count,
                        uint32_t* row_span_lo, uint32_t* row_span_cnt, uint64_t* span_key, uint4* span_cov,
-                       const uint8_t* unchanged, FrameInfo* info) {
+                       const uint8_t* unchanged, FrameInfo* info, uint32_t edge_segs) {
     if (tiles_h == 0) return;
     if (local_sort)
         hipLaunchKernelGGL(k_carry_rows<true>, dim3(tiles_h), dim3(CR_THREADS), 0, s, sorted_run_keys, records, blk_edge,
                            n_segments, n_runs, layer_sf, n_orders, tiles_w, tiles_h, row_count, row_span_lo,
-                           row_span_cnt, span_key, span_cov, unchanged, info);
+                           row_span_cnt, span_key, span_cov, unchanged, info, edge_segs);
     else
         hipLaunchKernelGGL(k_carry_rows<false>, dim3(tiles_h), dim3(CR_THREADS), 0, s, sorted_run_keys, records, blk_edge,
                            n_segments, n_runs, layer_sf, n_orders, tiles_w, tiles_h, row_count, row_span_lo,
-                           row_span_cnt, span_key, span_cov, unchanged, info);
+                           row_span_cnt, span_key, span_cov, unchanged, info, edge_segs);
 }
 
 // ================================================================================================

@@ -326,9 +326,11 @@ struct Lines {
 void prepare_lines(const float* x, const float* y, const uint32_t* line_slot, size_t n_points,
                    const forma_geom_t* geoms, size_t n_geoms, float width, float height, Lines& L) {
     size_t n = n_points ? n_points - 1 : 0;
-    L.resize(n);
+    if (L.lengths.size() != n) L.resize(n);                           // (the reference recycles its buffers too, renderer.rs:214)
 #pragma omp parallel for schedule(static)
     for (long i = 0; i < (long)n; i++) {
+        L.orders[i] = 0; L.lengths[i] = 0;                            // empty_line (segment.rs:306-318)
+        L.x0[i] = L.y0[i] = L.dx[i] = L.dy[i] = L.a[i] = L.b[i] = L.c[i] = L.d[i] = 0.0f;
         uint32_t slot = line_slot[i];
         if (slot == FORMA_NONE || slot >= n_geoms) continue;          // id None / no layer -> empty_line
         const forma_geom_t& g = geoms[slot];
@@ -354,8 +356,35 @@ void prepare_lines(const float* x, const float* y, const uint32_t* line_slot, si
         L.a[i] = fabsf(dxr); L.b[i] = fabsf(dyr); L.c[i] = tox; L.d[i] = toy;
         L.lengths[i] = integers_between(p0x, p1x) + integers_between(p0y, p1y) + 1;  // :86-88
     }
-    uint32_t sum = 0;                                                  // prefix_sum segment.rs:90-98
-    for (size_t i = 0; i < n; i++) { sum += L.lengths[i]; L.lengths[i] = sum; }
+    // prefix_sum segment.rs:90-98 (serial in the reference).  For the reported CPU baseline the same wrapping u32
+    // inclusive sums are formed by chunks: per-chunk totals, then every chunk adds the sum of the chunks before it.
+    int T = 1;
+#ifdef _OPENMP
+    T = n >= (1u << 16) ? omp_get_max_threads() : 1;
+#endif
+    if (T <= 1) {
+        uint32_t sum = 0;
+        for (size_t i = 0; i < n; i++) { sum += L.lengths[i]; L.lengths[i] = sum; }
+        return;
+    }
+    std::vector<uint32_t> part((size_t)T + 1, 0);
+#pragma omp parallel num_threads(T)
+    {
+#ifdef _OPENMP
+        const int t = omp_get_thread_num();
+#else
+        const int t = 0;
+#endif
+        const size_t lo = n * (size_t)t / T, hi = n * (size_t)(t + 1) / T;
+        uint32_t sum = 0;
+        for (size_t i = lo; i < hi; i++) { sum += L.lengths[i]; L.lengths[i] = sum; }
+        part[t + 1] = sum;
+#pragma omp barrier
+#pragma omp single
+        for (int k = 0; k < T; k++) part[k + 1] += part[k];
+        const uint32_t base = part[t];
+        if (base) for (size_t i = lo; i < hi; i++) L.lengths[i] += base;
+    }
 }
 
 inline float find_term(int32_t i, double a_ab, double b_ab, double cd_ab, float a, float b, float c, float d) {
@@ -427,25 +456,71 @@ void rasterize(const Lines& L, std::vector<uint64_t>& out) {           // raster
 // ============================================================================================
 // Stage 3 — sort (cpu/rasterizer.rs:161-164, Ord pixel_segment.rs:161-171): stable on v >> 20
 // ============================================================================================
-void sort_segments(std::vector<uint64_t>& v, int threads) {
-    // LSD radix, 11-bit digits on bits 20..63, stable; identical result to std::stable_sort.
-    size_t n = v.size();
+// Stable LSD radix sort of the 44 key bits (8-bit digits packed over the key bits that vary at all; a digit whose
+// histogram has a single bin is skipped): identical result to std::stable_sort by `v >> 20`.  With `threads` > 1 it is
+// the textbook parallel form — contiguous chunk per thread, private histograms, offsets scanned digit-major then
+// thread-major (which keeps it stable), scatter through per-digit 64-byte write-combining buffers — so that the
+// reported CPU baseline is not held back by a serial sort (the reference's crumsort is parallel, rasterizer.rs:161-164).
+void sort_segments(std::vector<uint64_t>& v, int threads, std::vector<uint64_t>* scratch = nullptr) {
+    const size_t n = v.size();
     if (n < 2) return;
-    std::vector<uint64_t> tmp(n);
+    std::vector<uint64_t> local;
+    std::vector<uint64_t>& tmp = scratch ? *scratch : local;
+    if (tmp.size() < n) tmp.resize(n);
+    int T = threads > 0 ? threads : 1;
+    if (n < (1u << 16)) T = 1;
+    if (T > 256) T = 256;
+    // varying key bits
+    uint64_t k_or = 0, k_and = ~0ull;
+#pragma omp parallel for num_threads(T) reduction(| : k_or) reduction(& : k_and) schedule(static)
+    for (long i = 0; i < (long)n; i++) { k_or |= v[i]; k_and &= v[i]; }
+    const uint64_t live = (k_or ^ k_and) & ~((1ull << 20) - 1);
+    int shifts[16], widths[16], np = 0;
+    for (int b = 20; b < 64;) {
+        if (!((live >> b) & 1)) { b++; continue; }
+        int w = std::min(8, 64 - b);
+        while (w > 1 && !((live >> (b + w - 1)) & 1)) w--;
+        shifts[np] = b; widths[np] = w; np++; b += w;
+    }
     uint64_t* src = v.data(); uint64_t* dst = tmp.data();
-    (void)threads;
-    for (int shift = 20; shift < 64; shift += 11) {
-        const int B = 2048;
-        std::vector<size_t> cnt(B + 1, 0);
-        for (size_t i = 0; i < n; i++) cnt[((src[i] >> shift) & (B - 1)) + 1]++;
-        bool single = false;
-        for (int k = 0; k < B; k++) if (cnt[k + 1] == n) single = true;
-        if (single) continue;
-        for (int k = 0; k < B; k++) cnt[k + 1] += cnt[k];
-        for (size_t i = 0; i < n; i++) dst[cnt[(src[i] >> shift) & (B - 1)]++] = src[i];
+    std::vector<uint32_t> hist((size_t)T * 256);
+    for (int p = 0; p < np; p++) {
+        const int shift = shifts[p]; const uint32_t mask = (1u << widths[p]) - 1u;
+#pragma omp parallel num_threads(T)
+        {
+#ifdef _OPENMP
+            const int t = omp_get_thread_num();
+#else
+            const int t = 0;
+#endif
+            const size_t lo = n * (size_t)t / T, hi = n * (size_t)(t + 1) / T;
+            uint32_t h[256] = {0};
+            for (size_t i = lo; i < hi; i++) h[(src[i] >> shift) & mask]++;
+            memcpy(&hist[(size_t)t * 256], h, sizeof h);
+#pragma omp barrier
+#pragma omp single
+            {
+                uint32_t run = 0;
+                for (int d = 0; d < 256; d++)
+                    for (int k = 0; k < T; k++) { uint32_t c = hist[(size_t)k * 256 + d]; hist[(size_t)k * 256 + d] = run; run += c; }
+            }
+            uint32_t off[256];
+            memcpy(off, &hist[(size_t)t * 256], sizeof off);
+            alignas(64) uint64_t wc[256][8];                           // software write-combining: 64 bytes per digit
+            uint8_t fill[256] = {0};
+            for (size_t i = lo; i < hi; i++) {
+                const uint64_t key = src[i]; const uint32_t d = (uint32_t)(key >> shift) & mask;
+                wc[d][fill[d]++] = key;
+                if (fill[d] == 8) { memcpy(dst + off[d], wc[d], 64); off[d] += 8; fill[d] = 0; }
+            }
+            for (int d = 0; d < 256; d++) if (fill[d]) { memcpy(dst + off[d], wc[d], (size_t)fill[d] * 8); }
+        }
         std::swap(src, dst);
     }
-    if (src != v.data()) memcpy(v.data(), src, n * 8);
+    if (src != v.data()) {
+#pragma omp parallel for num_threads(T) schedule(static)
+        for (long i = 0; i < (long)n; i++) v[i] = src[i];
+    }
 }
 
 // ============================================================================================
@@ -1122,7 +1197,14 @@ struct Oracle {
     std::vector<forma_geom_t> geoms;
     std::vector<uint32_t> style_offsets, style_words; std::vector<uint8_t> unchanged; bool has_unchanged = false;
     std::vector<forma_image_t> images; std::vector<uint16_t> texels;
-    Lines lines; std::vector<uint64_t> unsorted, sorted;
+    Lines lines; std::vector<uint64_t> unsorted, sorted, sort_scratch;
+    void sort_frame() {                                                // Rasterizer::sort on a copy (the unsorted stream is kept for tests)
+        const size_t n = unsorted.size();
+        if (sorted.size() != n) sorted.resize(n);
+#pragma omp parallel for schedule(static)
+        for (long i = 0; i < (long)n; i++) sorted[i] = unsorted[i];
+        sort_segments(sorted, threads, &sort_scratch);
+    }
     std::map<int, Cache> caches;
     std::vector<Props> props; std::vector<uint8_t> have;
     // flatten scratch
@@ -1282,8 +1364,7 @@ size_t oracle_rasterize(void* o_) {
 }
 size_t oracle_sort(void* o_) {
     Oracle* o = (Oracle*)o_;
-    o->sorted = o->unsorted;
-    sort_segments(o->sorted, o->threads);
+    o->sort_frame();
     return o->sorted.size();
 }
 void oracle_get_segments(void* o_, int which, uint64_t* out) {
@@ -1291,6 +1372,22 @@ void oracle_get_segments(void* o_, int which, uint64_t* out) {
     if (!v.empty()) memcpy(out, v.data(), v.size() * 8);
 }
 // stand-alone helpers for unit vectors
+// in place, `threads` OpenMP threads; returns seconds spent in the sort proper (copies excluded)
+double oracle_sort_array_mt(uint64_t* v, size_t n, int threads) {
+    std::vector<uint64_t> t(v, v + n), scratch(n);
+    set_threads(threads);
+#ifdef _OPENMP
+    double t0 = omp_get_wtime();
+#endif
+    sort_segments(t, threads, &scratch);
+#ifdef _OPENMP
+    double t1 = omp_get_wtime();
+#else
+    double t0 = 0, t1 = 0;
+#endif
+    if (n) memcpy(v, t.data(), n * 8);
+    return t1 - t0;
+}
 void oracle_sort_array(uint64_t* v, size_t n) { std::vector<uint64_t> t(v, v + n); sort_segments(t, 1); if (n) memcpy(v, t.data(), n * 8); }
 uint64_t oracle_pixel_segment_new(uint32_t layer, int tile_x, int tile_y, int lx, int ly, int dam, int cover) {
     return pixel_segment_new(layer, (int16_t)tile_x, (int16_t)tile_y, (uint8_t)lx, (uint8_t)ly, (uint8_t)dam, (int8_t)cover);
@@ -1363,8 +1460,7 @@ int oracle_render(void* o_, uint8_t* dst, uint32_t width, uint32_t height, size_
     Oracle* o = (Oracle*)o_; set_threads(o->threads);
     prepare_lines(o->x.data(), o->y.data(), o->line_slot.data(), o->x.size(), o->geoms.data(), o->geoms.size(), (float)width, (float)height, o->lines);
     rasterize(o->lines, o->unsorted);
-    o->sorted = o->unsorted;
-    sort_segments(o->sorted, o->threads);
+    o->sort_frame();
     return oracle_paint(o_, o->sorted.data(), o->sorted.size(), dst, width, height, stride, channels, clear, crop, cache_id, tile_dump);
 }
 int oracle_render_flush(void* o_, uint8_t* dst, uint32_t width, uint32_t height, size_t stride, const uint8_t channels[4],
@@ -1372,8 +1468,7 @@ int oracle_render_flush(void* o_, uint8_t* dst, uint32_t width, uint32_t height,
     Oracle* o = (Oracle*)o_; set_threads(o->threads);
     prepare_lines(o->x.data(), o->y.data(), o->line_slot.data(), o->x.size(), o->geoms.data(), o->geoms.size(), (float)width, (float)height, o->lines);
     rasterize(o->lines, o->unsorted);
-    o->sorted = o->unsorted;
-    sort_segments(o->sorted, o->threads);
+    o->sort_frame();
     return oracle_paint_flush(o_, o->sorted.data(), o->sorted.size(), dst, width, height, stride, channels, clear, crop, cache_id, fn, user);
 }
 size_t oracle_last_n(void* o_) { return ((Oracle*)o_)->unsorted.size(); }
@@ -1393,7 +1488,7 @@ int oracle_time_frame(void* o_, uint32_t width, uint32_t height, int iters, doub
         double t1 = omp_get_wtime();
         rasterize(o->lines, o->unsorted);
         double t2 = omp_get_wtime();
-        o->sorted = o->unsorted; sort_segments(o->sorted, o->threads);
+        o->sort_frame();
         double t3 = omp_get_wtime();
         PaintCtx ctx = o->pctx(false);
         paint(o->sorted.data(), o->sorted.size(), ctx, img.data(), width, height, (size_t)width * 4, ch, cc, Crop{false, 0, 0, 0, 0}, nullptr, nullptr);
