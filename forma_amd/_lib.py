@@ -41,7 +41,7 @@ class TimingsT(C.Structure):
     _fields_ = [("prepare_us", C.c_float), ("rasterize_us", C.c_float), ("sort_us", C.c_float), ("sort_pass_us", C.c_float),
                 ("carry_us", C.c_float), ("paint_us", C.c_float), ("total_us", C.c_float), ("d2h_us", C.c_float),
                 ("n_lines", C.c_uint32), ("n_segments", C.c_uint32), ("n_sort_passes", C.c_uint32), ("n_runs", C.c_uint32),
-                ("n_tile_entries", C.c_uint32), ("n_tiles_written", C.c_uint32)]
+                ("n_tile_entries", C.c_uint32), ("n_tiles_written", C.c_uint32), ("exchange_us", C.c_float)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -81,6 +81,11 @@ SYMBOLS = {
     "forma_hip_rasterize_frame": (_i, [_vp, _u32, _u32, _vp]),
     "forma_hip_reserve_segments": (_i, [_vp, _sz, _vp]),
     "forma_hip_sort_paint_frame": (_i, [_vp, _sz, _vp, _u32, _u32, _sz, _vp, _vp, _vp, _vp]),
+    "forma_hip_stream": (_i, [_vp, _vp]),
+    "forma_hip_exchange_plan": (_i, [_vp, _vp, _u32, _u32]),
+    "forma_hip_exchange_buffers": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "forma_hip_rasterize_bucket_frame": (_i, [_vp, _u32, _u32, _vp]),
+    "forma_hip_gather_sort_paint_frame": (_i, [_vp, _vp, _u32, _u32, _sz, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

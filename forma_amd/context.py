@@ -191,3 +191,49 @@ class Context:
                                                        _p(ch), _p(cl), None if rect is None else C.addressof(rect),
                                                        None if t is None else C.addressof(t)))
         return (dst, t.as_dict()) if timings else dst
+
+    # ---- multi-GPU, exchange layout (include/forma_hip.h, last section)
+    def stream_handle(self) -> int:
+        p = C.c_void_p()
+        self._check(self._L.forma_hip_stream(self._h, C.byref(p)))
+        return p.value or 0
+
+    def exchange_plan(self, row_edges, pair_capacity):
+        e = np.ascontiguousarray(row_edges, np.uint32)
+        self._check(self._L.forma_hip_exchange_plan(self._h, _p(e), len(e) - 1, int(pair_capacity)))
+        self._xplan = (len(e) - 1, int(pair_capacity))
+
+    def exchange_views(self):
+        """torch views (no copies) of the send / receive buckets (int64, n_ranks * capacity) and their counts (int32, 2 per rank)"""
+        n, cap = self._xplan
+        ps, pc, pr, prc = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._check(self._L.forma_hip_exchange_buffers(self._h, C.byref(ps), C.byref(pc), C.byref(pr), C.byref(prc)))
+        return (self.device_view(ps.value, n * cap), self._device_view_i32(pc.value, 2 * n),
+                self.device_view(pr.value, n * cap), self._device_view_i32(prc.value, 2 * n))
+
+    def _device_view_i32(self, ptr, n):
+        import torch
+
+        class _Span:
+            pass
+        sp = _Span()
+        sp.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
+        return torch.as_tensor(sp, device=torch.device("cuda", self.device))
+
+    def rasterize_bucket_frame(self, width, height, timings=False):
+        t = TimingsT() if timings else None
+        self._check(self._L.forma_hip_rasterize_bucket_frame(self._h, width, height, None if t is None else C.addressof(t)))
+        return t.as_dict() if timings else None
+
+    def gather_sort_paint_frame(self, width, height, channels=(0, 1, 2, 3), clear=(1, 1, 1, 0), crop=None, dst=None, stride=None,
+                                timings=False, device_only=True):
+        stride = stride or width * 4
+        if dst is None and not device_only:
+            dst = np.zeros((height, stride), np.uint8)
+        ch = np.asarray(channels, np.uint8); cl = np.asarray(clear, np.float32)
+        rect = None if crop is None else RectT(*crop)
+        t = TimingsT() if timings else None
+        self._check(self._L.forma_hip_gather_sort_paint_frame(self._h, None if device_only else _p(dst), width, height, stride,
+                                                              _p(ch), _p(cl), None if rect is None else C.addressof(rect),
+                                                              None if t is None else C.addressof(t)))
+        return (dst, t.as_dict()) if timings else dst

@@ -30,7 +30,7 @@ struct DevBuf {
 
 constexpr int MAX_PASS_EVENTS = 16;
 constexpr size_t SEG_PAD = 16;          // segment buffers are over-allocated: stream kernels read whole 64-byte lane pieces
-enum { ST_PREPARE = 0, ST_RASTER, ST_SORT, ST_CARRY, ST_PAINT, ST_D2H, ST_COUNT };
+enum { ST_PREPARE = 0, ST_RASTER, ST_SORT, ST_CARRY, ST_PAINT, ST_D2H, ST_XCHG, ST_COUNT };
 
 }  // namespace
 
@@ -94,6 +94,13 @@ struct forma_hip_ctx {
     uint32_t pred_max_row = 0xFFFFFFFFu;    // most runs in one tile row of the last verified frame (unknown: no local sort)
     // band
     uint32_t band_row0 = 0, band_row1 = 0;
+    // multi-GPU exchange (forma_hip_exchange_plan): owner bands, per-pair capacity, send / receive buckets and their counts
+    OwnerBands xbands{};
+    uint32_t xcap = 0;
+    bool xplanned = false;
+    DevBuf xsend, xrecv, xsend_counts, xrecv_counts, xscratch;
+    bool xpred_valid = false;               // the local rasterized count of the previous exchange frame is known
+    uint32_t xpred_N = 0;
     // timing
     hipEvent_t ev0[ST_COUNT], ev1[ST_COUNT], pev0[MAX_PASS_EVENTS], pev1[MAX_PASS_EVENTS];
     bool stage_used[ST_COUNT];
@@ -478,7 +485,7 @@ int finish_frame(forma_hip_ctx* ctx, forma_timings_t* t, bool have_info = false)
     if (ctx->h_info->error) return fail(ctx, FORMA_E_INTERNAL, "device-side invariant violated");
     if (!t) return FORMA_OK;
     memset(t, 0, sizeof *t);
-    float* dstv[ST_COUNT] = {&t->prepare_us, &t->rasterize_us, &t->sort_us, &t->carry_us, &t->paint_us, &t->d2h_us};
+    float* dstv[ST_COUNT] = {&t->prepare_us, &t->rasterize_us, &t->sort_us, &t->carry_us, &t->paint_us, &t->d2h_us, &t->exchange_us};
     float total = 0;
     for (int s = 0; s < ST_COUNT; s++) {
         if (!ctx->stage_used[s]) continue;
@@ -573,7 +580,7 @@ void forma_hip_destroy(forma_hip_ctx* ctx) {
                      &ctx->block_first, &ctx->prep_scratch, &ctx->seg_u, &ctx->seg_a, &ctx->seg_b,
                      &ctx->sort_counters, &ctx->info, &ctx->info_init, &ctx->records, &ctx->rk_u, &ctx->rk_a, &ctx->rk_b,
                      &ctx->blk_edge, &ctx->runs_scratch, &ctx->row_tab, &ctx->span_key, &ctx->span_cov,
-                     &ctx->image};
+                     &ctx->image, &ctx->xsend, &ctx->xrecv, &ctx->xsend_counts, &ctx->xrecv_counts, &ctx->xscratch};
     for (DevBuf* b : all) b->release();
     for (int s = 0; s < ST_COUNT; s++) { (void)hipEventDestroy(ctx->ev0[s]); (void)hipEventDestroy(ctx->ev1[s]); }
     for (int p = 0; p < MAX_PASS_EVENTS; p++) { (void)hipEventDestroy(ctx->pev0[p]); (void)hipEventDestroy(ctx->pev1[p]); }
@@ -1013,6 +1020,144 @@ int forma_hip_sort_paint_frame(forma_hip_ctx* ctx, size_t n, uint8_t* dst, uint3
     if ((rc = run_paint(ctx, DevCount{nullptr, (uint32_t)n}, a, timing))) return rc;
     if ((rc = copy_image_out(ctx, dst, stride_bytes, timing, a))) return rc;
     return finish_frame(ctx, timings);
+}
+
+
+// ---- multi-GPU, exchange layout: every rank rasterizes 1/G of the LINES, pixel segments travel to the rank
+//      that owns their tile row (ONE all-to-all of u64 payloads, driven by the host language on this context's stream),
+//      the owner sorts and paints its band ---------------------------------------------------------------------------------
+int forma_hip_stream(forma_hip_ctx* ctx, void** stream) {
+    if (!ctx || !stream) return FORMA_E_ARG;
+    *stream = (void*)ctx->stream;
+    return FORMA_OK;
+}
+
+int forma_hip_exchange_plan(forma_hip_ctx* ctx, const uint32_t* row_edges, uint32_t n_ranks, uint32_t pair_capacity) {
+    if (!ctx || !row_edges) return FORMA_E_ARG;
+    if (n_ranks < 1 || n_ranks > FORMA_MAX_RANKS) return fail(ctx, FORMA_E_ARG, "1 .. 8 ranks");
+    for (uint32_t g = 0; g < n_ranks; g++) if (row_edges[g] >= row_edges[g + 1]) return fail(ctx, FORMA_E_ARG, "tile-row bands must be ascending and non-empty");
+    if (pair_capacity == 0 || (uint64_t)pair_capacity * n_ranks >= (1ull << 30)) return fail(ctx, FORMA_E_ARG, "pair capacity out of range");
+    HIPCHECK(hipSetDevice(ctx->device));
+    ctx->xbands.n = n_ranks;
+    for (uint32_t g = 0; g <= n_ranks; g++) ctx->xbands.edge[g] = row_edges[g];
+    ctx->xcap = pair_capacity;
+    const size_t words = (size_t)n_ranks * pair_capacity;
+    HIPCHECK(ctx->xsend.ensure((words + SEG_PAD) * 8));
+    HIPCHECK(ctx->xrecv.ensure((words + SEG_PAD) * 8));
+    HIPCHECK(ctx->xsend_counts.ensure(FORMA_MAX_RANKS * 8));
+    HIPCHECK(ctx->xrecv_counts.ensure(FORMA_MAX_RANKS * 8));
+    HIPCHECK(hipMemsetAsync(ctx->xsend_counts.p, 0, FORMA_MAX_RANKS * 8, ctx->stream));
+    HIPCHECK(hipMemsetAsync(ctx->xrecv_counts.p, 0, FORMA_MAX_RANKS * 8, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    ctx->xplanned = true;
+    ctx->pred_valid = false; ctx->pred_counts_valid = false; ctx->xpred_valid = false;
+    return FORMA_OK;
+}
+
+int forma_hip_exchange_buffers(forma_hip_ctx* ctx, uint64_t** send, uint32_t** send_counts, uint64_t** recv, uint32_t** recv_counts) {
+    if (!ctx || !send || !send_counts || !recv || !recv_counts) return FORMA_E_ARG;
+    if (!ctx->xplanned) return fail(ctx, FORMA_E_STATE, "forma_hip_exchange_plan first");
+    *send = ctx->xsend.as<uint64_t>(); *send_counts = ctx->xsend_counts.as<uint32_t>();
+    *recv = ctx->xrecv.as<uint64_t>(); *recv_counts = ctx->xrecv_counts.as<uint32_t>();
+    return FORMA_OK;
+}
+
+int forma_hip_rasterize_bucket_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, forma_timings_t* timings) {
+    if (!ctx) return FORMA_E_ARG;
+    if (!ctx->xplanned) return fail(ctx, FORMA_E_STATE, "forma_hip_exchange_plan first");
+    int rc = check_canvas(ctx, width, height);
+    if (rc) return rc;
+    HIPCHECK(hipSetDevice(ctx->device));
+    const bool timing = timings != nullptr;
+    clear_stage_flags(ctx);
+    // read-back-free when the previous frame's local segment count is known (bound with slack; the bucket scan flags an
+    // excess to every receiver), else synchronous
+    const uint32_t bN = (ctx->xpred_valid && !ctx->no_async) ? ctx->xpred_N + ctx->xpred_N / 16 + 4096 : 0;
+    if ((rc = run_rasterize_frame(ctx, width, height, timing, false, bN))) return rc;
+    FrameInfo* dinfo = ctx->info.as<FrameInfo>();
+    DevCount nc = bN ? DevCount{&dinfo->n_segments, bN} : DevCount{nullptr, (uint32_t)ctx->n_seg};
+    if (!bN) { ctx->xpred_N = (uint32_t)ctx->n_seg; ctx->xpred_valid = true; }
+    HIPCHECK(ctx->seg_u.ensure(((size_t)std::max<uint32_t>(nc.bound, 1) + SEG_PAD) * 8));
+    HIPCHECK(ctx->xscratch.ensure(owner_scratch_words(std::max<size_t>(nc.bound, 1)) * 4));
+    stage_begin(ctx, ST_XCHG, timing);
+    launch_owner_bucket(ctx->stream, ctx->seg_u.as<uint64_t>(), nc, ctx->xbands, ctx->xcap, ctx->xscratch.as<uint32_t>(),
+                        ctx->xsend.as<uint64_t>(), ctx->xsend_counts.as<uint32_t>(), dinfo);
+    stage_end(ctx, ST_XCHG, timing);
+    HIPCHECK(hipGetLastError());
+    if (timing) {                                            // (the only host wait of this call, and only when timings are asked for)
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        ctx->n_passes = 0; ctx->last_runs = 0;
+        HIPCHECK(hipMemcpy(ctx->h_info, ctx->info.p, sizeof(FrameInfo), hipMemcpyDeviceToHost));
+        return finish_frame(ctx, timings, true);
+    }
+    return FORMA_OK;
+}
+
+int forma_hip_gather_sort_paint_frame(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t height, size_t stride_bytes,
+                                      const uint8_t channels[4], const float clear_color[4], const forma_rect_t* crop_or_null,
+                                      forma_timings_t* timings) {
+    if (!ctx) return FORMA_E_ARG;
+    if (!ctx->xplanned) return fail(ctx, FORMA_E_STATE, "forma_hip_exchange_plan first");
+    int rc = check_paint_args(ctx, dst, width, height, stride_bytes, channels, clear_color);
+    if (rc) return rc;
+    HIPCHECK(hipSetDevice(ctx->device));
+    const bool timing = timings != nullptr;
+    clear_stage_flags(ctx);
+    const uint32_t G = ctx->xbands.n, bound = G * ctx->xcap;
+    // one rank: what was bucketed is what is received (no collective ran)
+    const uint64_t* recv = G == 1 ? ctx->xsend.as<uint64_t>() : ctx->xrecv.as<uint64_t>();
+    const uint32_t* rcnt = G == 1 ? ctx->xsend_counts.as<uint32_t>() : ctx->xrecv_counts.as<uint32_t>();
+    FrameInfo* dinfo = ctx->info.as<FrameInfo>();
+    PaintArgs a{width, height, channels, clear_color, crop_or_null};
+    HIPCHECK(ctx->seg_u.ensure(((size_t)bound + SEG_PAD) * 8));
+    auto gather = [&]() -> int {
+        int r = reset_info(ctx);
+        if (r) return r;
+        stage_begin(ctx, ST_XCHG, timing);
+        launch_gather_chunks(ctx->stream, recv, rcnt, G, ctx->xcap, ctx->seg_u.as<uint64_t>(), dinfo);
+        stage_end(ctx, ST_XCHG, timing);
+        ctx->have_unsorted = true; ctx->n_lines = 0;
+        return FORMA_OK;
+    };
+    if (ctx->pred_valid && ctx->pred_counts_valid && !ctx->no_async) {       // read-back-free, verified when the frame is done
+        const uint32_t bJ = ctx->pred_J + ctx->pred_J / 16 + 4096;
+        if ((rc = gather())) return rc;
+        ctx->live44 = ctx->pred_live44; ctx->layer_sorted = ctx->pred_layer_sorted; ctx->speculated = true;
+        if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), DevCount{&dinfo->n_segments, bound}, timing))) return rc;
+        if ((rc = run_paint(ctx, DevCount{&dinfo->n_segments, bound}, a, timing, bJ))) return rc;
+        HIPCHECK(hipMemcpyAsync(ctx->h_info, ctx->info.p, sizeof(FrameInfo), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        if (ctx->h_info->exchange_overflow) return fail(ctx, FORMA_E_CAPACITY, "exchange: a bucket exceeds the pair capacity (re-plan)");
+        const uint32_t N = ctx->h_info->n_segments, J = ctx->h_info->n_runs;
+        ctx->n_seg = N; ctx->last_runs = J;
+        if (!ctx->h_info->plan_bad && J <= bJ) {
+            ctx->pred_J = J; ctx->pred_max_row = ctx->h_info->max_row_runs;
+            if ((rc = copy_image_out(ctx, dst, stride_bytes, timing, a))) return rc;
+            if (dst) HIPCHECK(hipStreamSynchronize(ctx->stream));
+            return finish_frame(ctx, timings, true);
+        }
+        ctx->pred_counts_valid = false;
+        clear_stage_flags(ctx);
+    }
+    for (int attempt = 0; attempt < 2; attempt++) {                            // synchronous: N, key masks and J are read back
+        if ((rc = gather())) return rc;
+        if ((rc = read_info(ctx))) return rc;
+        if (ctx->h_info->exchange_overflow) return fail(ctx, FORMA_E_CAPACITY, "exchange: a bucket exceeds the pair capacity (re-plan)");
+        ctx->n_seg = ctx->h_info->n_segments;
+        const uint64_t k_or = (uint64_t)ctx->h_info->key_or | ((uint64_t)ctx->h_info->key_or_hi << 32);
+        const uint64_t k_and = (uint64_t)ctx->h_info->key_and | ((uint64_t)ctx->h_info->key_and_hi << 32);
+        ctx->live44 = ctx->n_seg ? ((k_or ^ k_and) & 0xFFFFFFFFFFFull) : 0;
+        ctx->layer_sorted = ctx->h_info->layer_unsorted == 0; ctx->speculated = false;
+        if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), DevCount{nullptr, (uint32_t)ctx->n_seg}, timing))) return rc;
+        rc = run_paint(ctx, DevCount{nullptr, (uint32_t)ctx->n_seg}, a, timing);
+        if (rc == FORMA_RETRY) { clear_stage_flags(ctx); continue; }
+        if (rc) return rc;
+        if ((rc = copy_image_out(ctx, dst, stride_bytes, timing, a))) return rc;
+        rc = finish_frame(ctx, timings);
+        if (rc == FORMA_OK) { ctx->pred_J = ctx->last_runs; ctx->pred_counts_valid = true; }
+        return rc;
+    }
+    return fail(ctx, FORMA_E_INTERNAL, "sort plan did not converge");
 }
 
 }  // extern "C"

@@ -46,7 +46,7 @@ struct FrameInfo {
     uint32_t n_compact;      // lines with at least one pixel segment
     uint32_t plan_bad;       // asynchronous frames: the speculated sort plan does not match this frame's keys
     uint32_t max_row_runs;   // most runs in one tile row (the carry pre-pass sorts a row's runs in LDS when they fit)
-    uint32_t pad[1];
+    uint32_t exchange_overflow;   // multi-GPU exchange: a bucket did not fit the agreed pair capacity (here or at a sender)
 };
 
 // one run of the sorted stream = one painted (tile, layer) pair that owns pixel segments
@@ -141,6 +141,17 @@ size_t sort_scratch_words(size_t n);
 const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a, uint64_t* b, DevCount n,
                                   const SortPlan& plan, int digit_bits, uint32_t* scratch, uint32_t* err,
                                   hipEvent_t* pass_ev0, hipEvent_t* pass_ev1);
+
+// exchange.hip — multi-GPU: bucket a rank's pixel segments by tile-row owner, gather what the owner received
+#define FORMA_MAX_RANKS 8
+struct OwnerBands { uint32_t n; uint32_t edge[FORMA_MAX_RANKS + 1]; };   // rank g owns tile rows [edge[g], edge[g + 1])
+size_t owner_scratch_words(size_t n);
+// stable partition of seg[0 .. n) into send[g * capacity + ...]; send_counts[2 g] = segments for rank g, [2 g + 1] = overflow flag
+void launch_owner_bucket(hipStream_t s, const uint64_t* seg, DevCount n, const OwnerBands& B, uint32_t capacity,
+                         uint32_t* scratch, uint64_t* send, uint32_t* send_counts, FrameInfo* info);
+// recv[s * capacity + ...] (recv_counts[2 s] segments from rank s) -> out, info->{n_segments, key masks, layer_unsorted}
+void launch_gather_chunks(hipStream_t s, const uint64_t* recv, const uint32_t* recv_counts, uint32_t n_ranks, uint32_t capacity,
+                          uint64_t* out, FrameInfo* info);
 
 // paint.hip
 struct BlkEdge {             // what a k_runs tile contributes to a run that started before it

@@ -1,0 +1,226 @@
+// exchange.hip — multi-GPU step between stage 2 and stage 3: the pixel segments a rank rasterized
+// from ITS share of the lines are bucketed by the rank that owns their tile row, so that ONE all-to-all over xGMI
+// delivers them, and the owner gathers what it received into one stream for its sort and painter.
+//
+// `tile_y` is the most significant key field and the cover carry never crosses tile rows (reference
+// forma/src/cpu/painter/mod.rs:518-522, 741-776: rows are the CPU backend's unit of parallelism too), so a rank that
+// holds every segment of a band of rows, in global line order, produces exactly the rows a single device would.
+// Everything here is a stable partition of byte-sized work: HBM-bound, wavefront ballots for the ranks, no MFMA.
+//
+//   k_owner_count   : per 2048-segment block, segments per owner                       (1 read of the stream)
+//   k_owner_scan    : per owner, exclusive scan of the block counts; totals -> the counts the ranks exchange
+//   k_owner_scatter : stable scatter into the send buffer, bucket g at [g * C, g * C + count_g)
+//   k_gather_chunks : received buckets (rank-major = global line order) -> one contiguous stream, its length, the
+//                     varying-bit masks of its keys and whether it is non-decreasing in layer (what the sort plan needs)
+#include "common.h"
+
+#define XB_WAVES   4
+#define XB_THREADS (64 * XB_WAVES)
+#define XB_ROWS    8                         // segments per lane
+#define XB_TILE    (XB_THREADS * XB_ROWS)    // 2048: wave w owns [512 w, 512 w + 512) of the block, row j = 64 consecutive ones
+
+__device__ __forceinline__ uint32_t owner_of(uint64_t v, const OwnerBands& B) {
+    const int ty = (int)(v >> 53) - 1;
+    if (ty < (int)B.edge[0] || ty >= (int)B.edge[B.n]) return B.n;       // never painted (painter/mod.rs:731-734): dropped
+    uint32_t g = 0;
+#pragma unroll
+    for (int k = 1; k < FORMA_MAX_RANKS; k++) g += (k < (int)B.n && ty >= (int)B.edge[k]) ? 1u : 0u;
+    return g;
+}
+
+__global__ __launch_bounds__(XB_THREADS) void k_owner_count(const uint64_t* __restrict__ seg, DevCount nc, OwnerBands B,
+                                                            uint32_t* __restrict__ block_counts /* [n + 1][nblocks] */,
+                                                            uint32_t nblocks_cap) {
+    __shared__ uint32_t s_c[XB_WAVES][FORMA_MAX_RANKS + 1];
+    const uint32_t n = dev_count(nc);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t base = blockIdx.x * XB_TILE + w * (64 * XB_ROWS);
+    uint32_t cnt[FORMA_MAX_RANKS + 1];
+#pragma unroll
+    for (int g = 0; g <= FORMA_MAX_RANKS; g++) cnt[g] = 0;
+    uint64_t v[XB_ROWS];
+#pragma unroll
+    for (int j = 0; j < XB_ROWS; j++) { const uint32_t i = base + j * 64 + lane; v[j] = i < n ? seg[i] : 0ull; }
+#pragma unroll
+    for (int j = 0; j < XB_ROWS; j++) {
+        const uint32_t i = base + j * 64 + lane;
+        const uint32_t o = i < n ? owner_of(v[j], B) : 0xFFu;
+#pragma unroll
+        for (int g = 0; g <= FORMA_MAX_RANKS; g++) if (g <= (int)B.n) cnt[g] += (uint32_t)__popcll(__ballot(o == (uint32_t)g));
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int g = 0; g <= FORMA_MAX_RANKS; g++) s_c[w][g] = cnt[g];
+    }
+    __syncthreads();
+    if (tid <= (int)B.n) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int q = 0; q < XB_WAVES; q++) t += s_c[q][tid];
+        block_counts[(size_t)tid * nblocks_cap + blockIdx.x] = t;
+    }
+}
+
+// one workgroup; per owner g: block_counts[g][0 .. nb) -> exclusive prefix in place, total -> counts
+__global__ __launch_bounds__(1024) void k_owner_scan(uint32_t* __restrict__ block_counts, DevCount nc, uint32_t nblocks_cap,
+                                                     uint32_t n_owners /* n + 1 */, uint32_t capacity,
+                                                     uint32_t* __restrict__ send_counts /* [n][2] */, FrameInfo* __restrict__ info) {
+    __shared__ uint32_t lds[17];
+    __shared__ uint32_t s_over;
+    const uint32_t nb = (dev_count(nc) + XB_TILE - 1) / XB_TILE;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_over = 0;
+    __syncthreads();
+    for (uint32_t g = 0; g < n_owners; g++) {
+        uint32_t* row = block_counts + (size_t)g * nblocks_cap;
+        uint32_t carry = 0;
+        for (uint32_t b0 = 0; b0 < nb; b0 += 1024) {
+            const uint32_t i = b0 + threadIdx.x;
+            const uint32_t v = i < nb ? row[i] : 0u;
+            uint32_t inc = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+            if (lane == 63) lds[w] = inc;
+            __syncthreads();
+            uint32_t wb = 0, tot = 0;
+#pragma unroll
+            for (int q = 0; q < 16; q++) { const uint32_t t = lds[q]; if (q < w) wb += t; tot += t; }
+            if (i < nb) row[i] = carry + wb + inc - v;
+            carry += tot;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0 && g + 1 < n_owners) {                      // (the last owner is the dropped bucket)
+            send_counts[2 * g] = carry < capacity ? carry : capacity;
+            if (carry > capacity) s_over = 1;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < n_owners - 1) send_counts[2 * threadIdx.x + 1] = s_over;   // every receiver learns that this sender overflowed
+    if (threadIdx.x == 0 && s_over) info->exchange_overflow = 1u;
+}
+
+__global__ __launch_bounds__(XB_THREADS) void k_owner_scatter(const uint64_t* __restrict__ seg, DevCount nc, OwnerBands B,
+                                                              const uint32_t* __restrict__ block_offs, uint32_t nblocks_cap,
+                                                              uint32_t capacity, uint64_t* __restrict__ send /* [n][capacity] */) {
+    __shared__ uint32_t s_c[XB_WAVES][FORMA_MAX_RANKS + 1];
+    const uint32_t n = dev_count(nc);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t base = blockIdx.x * XB_TILE + w * (64 * XB_ROWS);
+    uint64_t v[XB_ROWS];
+#pragma unroll
+    for (int j = 0; j < XB_ROWS; j++) { const uint32_t i = base + j * 64 + lane; v[j] = i < n ? seg[i] : 0ull; }
+    uint32_t own = 0;                                                   // 4 bits per row
+    uint32_t cnt[FORMA_MAX_RANKS + 1];
+#pragma unroll
+    for (int g = 0; g <= FORMA_MAX_RANKS; g++) cnt[g] = 0;
+#pragma unroll
+    for (int j = 0; j < XB_ROWS; j++) {
+        const uint32_t i = base + j * 64 + lane;
+        const uint32_t o = i < n ? owner_of(v[j], B) : 0xFu;
+        own |= o << (4 * j);
+#pragma unroll
+        for (int g = 0; g < FORMA_MAX_RANKS; g++) if (g < (int)B.n) cnt[g] += (uint32_t)__popcll(__ballot(o == (uint32_t)g));
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int g = 0; g < FORMA_MAX_RANKS; g++) s_c[w][g] = cnt[g];
+    }
+    __syncthreads();
+    // position of the wave's first segment of owner g inside bucket g: blocks before + waves before (index order = (w, j, lane))
+    uint32_t run[FORMA_MAX_RANKS];
+#pragma unroll
+    for (int g = 0; g < FORMA_MAX_RANKS; g++) {
+        uint32_t r = 0;
+        if (g < (int)B.n) {
+            r = block_offs[(size_t)g * nblocks_cap + blockIdx.x];
+#pragma unroll
+            for (int q = 0; q < XB_WAVES; q++) if (q < w) r += s_c[q][g];
+        }
+        run[g] = r;
+    }
+    const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+#pragma unroll
+    for (int j = 0; j < XB_ROWS; j++) {
+        const uint32_t o = (own >> (4 * j)) & 0xFu;
+#pragma unroll
+        for (int g = 0; g < FORMA_MAX_RANKS; g++) {
+            if (g < (int)B.n) {
+                const uint64_t bg = __ballot(o == (uint32_t)g);
+                if (o == (uint32_t)g) {
+                    const uint32_t pos = run[g] + (uint32_t)__popcll(bg & lt);
+                    if (pos < capacity) send[(size_t)g * capacity + pos] = v[j];
+                }
+                run[g] += (uint32_t)__popcll(bg);
+            }
+        }
+    }
+}
+
+// received buckets (chunk s = what rank s sent: [s * capacity, + counts[2 s])), rank-major, -> out[0 .. N_r)
+__global__ __launch_bounds__(256) void k_gather_chunks(const uint64_t* __restrict__ recv, const uint32_t* __restrict__ recv_counts,
+                                                       uint32_t n_ranks, uint32_t capacity, uint64_t* __restrict__ out,
+                                                       FrameInfo* __restrict__ info) {
+    __shared__ uint32_t red[5][4];
+    uint32_t start[FORMA_MAX_RANKS + 1];
+    uint32_t acc = 0, over = 0;
+#pragma unroll
+    for (int s = 0; s < FORMA_MAX_RANKS; s++) {
+        start[s] = acc;
+        if (s < (int)n_ranks) { const uint32_t c = recv_counts[2 * s]; over |= recv_counts[2 * s + 1] | (c > capacity ? 1u : 0u); acc += c < capacity ? c : capacity; }
+    }
+    start[FORMA_MAX_RANKS] = acc;
+    const uint32_t total = acc;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { info->n_segments = total; if (over) info->exchange_overflow = 1u; }
+    uint32_t k_or = 0, k_or_hi = 0, k_and = 0xFFFFFFFFu, k_and_hi = 0xFFFFFFFFu, unsorted = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        uint32_t s = 0;
+#pragma unroll
+        for (int q = 1; q < FORMA_MAX_RANKS; q++) s += (q < (int)n_ranks && i >= start[q]) ? 1u : 0u;
+        const uint64_t v = recv[(size_t)s * capacity + (i - start[s])];
+        out[i] = v;
+        const uint32_t klo = (uint32_t)(v >> 20), khi = (uint32_t)(v >> 52);
+        k_or |= klo; k_or_hi |= khi; k_and &= klo; k_and_hi &= khi;
+        if (i > 0) {                                                    // is the stream non-decreasing in layer?
+            uint32_t ps = s, pi = i - 1;
+            while (pi < start[ps]) ps--;                                // (empty chunks in between)
+            const uint64_t pv = recv[(size_t)ps * capacity + (pi - start[ps])];
+            if (seg_layer(pv) > seg_layer(v)) unsorted = 1;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        k_or |= __shfl_xor(k_or, d, 64); k_or_hi |= __shfl_xor(k_or_hi, d, 64);
+        k_and &= __shfl_xor(k_and, d, 64); k_and_hi &= __shfl_xor(k_and_hi, d, 64);
+        unsorted |= __shfl_xor(unsorted, d, 64);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = k_or; red[1][w] = k_or_hi; red[2][w] = k_and; red[3][w] = k_and_hi; red[4][w] = unsorted; }
+    __syncthreads();
+    if (threadIdx.x == 0 && total) {
+        uint32_t o = 0, oh = 0, a = 0xFFFFFFFFu, ah = 0xFFFFFFFFu, u = 0;
+        for (int q = 0; q < 4; q++) { o |= red[0][q]; oh |= red[1][q]; a &= red[2][q]; ah &= red[3][q]; u |= red[4][q]; }
+        atomicOr(&info->key_or, o); atomicOr(&info->key_or_hi, oh);
+        atomicAnd(&info->key_and, a); atomicAnd(&info->key_and_hi, ah);
+        if (u) atomicOr(&info->layer_unsorted, 1u);
+    }
+}
+
+size_t owner_scratch_words(size_t n) { return (size_t)(FORMA_MAX_RANKS + 1) * ((n + XB_TILE - 1) / XB_TILE + 1); }
+
+void launch_owner_bucket(hipStream_t s, const uint64_t* seg, DevCount nc, const OwnerBands& B, uint32_t capacity,
+                         uint32_t* scratch, uint64_t* send, uint32_t* send_counts, FrameInfo* info) {
+    const uint32_t nblocks = (uint32_t)((nc.bound + XB_TILE - 1) / XB_TILE);
+    const uint32_t cap = nblocks + 1;
+    if (nblocks == 0) { (void)hipMemsetAsync(send_counts, 0, (size_t)B.n * 8, s); return; }
+    hipLaunchKernelGGL(k_owner_count, dim3(nblocks), dim3(XB_THREADS), 0, s, seg, nc, B, scratch, cap);
+    hipLaunchKernelGGL(k_owner_scan, dim3(1), dim3(1024), 0, s, scratch, nc, cap, B.n + 1, capacity, send_counts, info);
+    hipLaunchKernelGGL(k_owner_scatter, dim3(nblocks), dim3(XB_THREADS), 0, s, seg, nc, B, (const uint32_t*)scratch, cap, capacity, send);
+}
+
+void launch_gather_chunks(hipStream_t s, const uint64_t* recv, const uint32_t* recv_counts, uint32_t n_ranks, uint32_t capacity,
+                          uint64_t* out, FrameInfo* info) {
+    const size_t bound = (size_t)n_ranks * capacity;
+    uint32_t grid = (uint32_t)std::min<size_t>((bound + 255) / 256, 8192);
+    if (grid == 0) grid = 1;
+    hipLaunchKernelGGL(k_gather_chunks, dim3(grid), dim3(256), 0, s, recv, recv_counts, n_ranks, capacity, out, info);
+}

@@ -1536,6 +1536,19 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
 // is what this latency-bound stage needs (a tile is ~4 dependent memory round trips and ~6 painted
 // layers).  Lists deeper than WMAX go to the workgroup-per-tile variant above (k_paint_deep).
 // ================================================================================================
+#ifdef PAINT_PROF
+// -DPAINT_PROF (tools only): shader-clock stamps at the phase boundaries of k_paint_wave, summed over all tiles
+__device__ unsigned long long g_paint_prof[24];
+#define PP_STAMP(i) do { const unsigned long long _t = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&g_paint_prof[i], _t - pp_t); pp_t = _t; } while (0)
+#define PP_COUNT(i, v) do { if (lane == 0) atomicAdd(&g_paint_prof[i], (unsigned long long)(v)); } while (0)
+extern "C" int forma_hip_debug_paint_prof(unsigned long long* out24, int reset) {
+    if (reset) { unsigned long long z[24] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_paint_prof), z, sizeof z); }
+    return (int)hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_paint_prof), 24 * 8);
+}
+#else
+#define PP_STAMP(i) do { } while (0)
+#define PP_COUNT(i, v) do { } while (0)
+#endif
 #define WMAX 128          // layer-list capacity of the wave painter
 #define WB   16           // painted entries staged per batch
 
@@ -1590,6 +1603,10 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
     uint64_t* tmp = w_tmp[wv];
     uint32_t* flags = w_flag[wv];
     const int lx = lane & 15, rg = lane >> 4;                           // this lane's pixels: (lx, 4 * rg + q), q = 0..3
+#ifdef PAINT_PROF
+    unsigned long long pp_t = __builtin_readcyclecounter();
+    PP_COUNT(16, 1);
+#endif
 
     // ---- the tile's layer list: own runs (contiguous records, ascending layer) + the row's spans that cross it --------
     const uint32_t my_tile_key = ((ty + 1u) << 12) | (tx + 1u);
@@ -1629,6 +1646,8 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
         }
     }
     const uint32_t ne = na + nb;
+    PP_STAMP(0);                                                        // 0: tile's runs + crossing spans found
+    PP_COUNT(17, ne); PP_COUNT(18, sc);
     if (ne > WMAX) {                                                    // too deep for a wave: the workgroup variant paints it
         if (lane == 0) overflow_list[atomicAdd(overflow_n, 1u)] = tile;
         return;
@@ -1661,6 +1680,7 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
     }
     wave_lds_sync();
 
+    PP_STAMP(1);                                                        // 1: merged by layer, flags decoded
     const Col clear = {P.clear[0], P.clear[1], P.clear[2], P.clear[3]};
     // ---- buffer-layer cache: tile_unchanged_pass (passes/tile_unchanged.rs), the first pass ------------------------------
     bool layers_were_removed = true;                                    // PassesSharedState default
@@ -1728,6 +1748,7 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
     uint4* b_cov = w_cov[wv]; uint4* b_col = w_col[wv];
     uint32_t* b_seg0 = w_seg0[wv]; uint32_t* b_nseg = w_nseg[wv]; uint32_t* b_flag = w_bflag[wv]; uint32_t* b_layer = w_blayer[wv];
     const uint32_t px = tx * 16u + (uint32_t)lx;
+    PP_STAMP(2);                                                        // 2: optimizer passes (clips, topmost cover)
     if (first != 2) {                                                   // fold: every layer from `skipped` up is a full cover
         Col dst = clear; bool ok = true;
         for (uint32_t k0 = skipped; k0 < ne; k0 += WB) {
@@ -1766,8 +1787,10 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
                 const uint32_t py = ty * 16u + (uint32_t)(rg * 4 + q);
                 if (px < P.width && py < P.height) ((uint32_t*)image)[(size_t)py * P.stride_px + px] = bytes;
             }
+            PP_STAMP(3); PP_COUNT(19, 1);                               // 3: solid fold + store (19: solid tiles)
             return;
         }
+        PP_STAMP(4);                                                    // 4: fold attempted, failed
     }
 
     // ---- the entries that are actually painted, in layer order (list reuses `tmp`) --------------------------------------
@@ -1785,6 +1808,7 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
     for (int q = 0; q < 4; q++) { w_cells[wv][0][q * 64 + lane] = 0; w_cells[wv][1][q * 64 + lane] = 0; }
 
     // ---- paint (Painter::paint_layer, painter/mod.rs:290-347): four pixels per lane ------------------------------------
+    PP_STAMP(5); PP_COUNT(20, np);                                      // 5: painted-entry list (20: painted entries)
     float dr[4], dg[4], db[4], da[4];
 #pragma unroll
     for (int q = 0; q < 4; q++) { dr[q] = clear.r; dg[q] = clear.g; db[q] = clear.b; da[q] = clear.a; }   // Painter::clear :277-288
@@ -1811,6 +1835,7 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
             }
         }
         wave_lds_sync();
+        PP_STAMP(6);                                                    // 6: batch staging (records / covers / colours gathered)
         for (uint32_t t = 0; t < nbt; t++) {
             const uint32_t f = b_flag[t];
             const uint32_t layer = b_layer[t];
@@ -1820,6 +1845,7 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
             const uint32_t nseg = b_nseg[t];
             int A[4];
             if (nseg) {
+                PP_COUNT(21, nseg);
                 int* cb = w_cells[wv][cbuf];
                 const uint64_t* sp = sorted + b_seg0[t];
                 for (uint32_t sidx = lane; sidx < nseg; sidx += 64) {   // acc_segment :257-271
@@ -1842,6 +1868,7 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
                     A[q] = 32 * acc + area;                             // compute_doubled_areas :388-404
                 }
                 cbuf ^= 1u;
+                PP_STAMP(7);                                            // 7: segment accumulation + cover prefix
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; q++) A[q] = 32 * (int)(int8_t)(cw >> (q * 8));
@@ -1884,6 +1911,7 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
                 dr[q] = fmaf(dr[q], isa, cr); dg[q] = fmaf(dg[q], isa, cg); db[q] = fmaf(db[q], isa, cb2);
                 da[q] = fmaf(da[q], isa, src_a);
             }
+            PP_STAMP(8);                                                // 8: coverage + fill + blend of one layer
         }
     }
     // ---- compute_srgb :466-483 + channel select, straight to the row-major RGBA8 image ----------------------------------
@@ -1898,6 +1926,7 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
             ((uint32_t*)image)[(size_t)py * P.stride_px + px] = out;
         }
     }
+    PP_STAMP(9);                                                        // 9: sRGB encode + store
     if (cache.tiles && lane == 0) {                                     // update_solid_color(None): painted, not solid
         cache.tiles[tile] = make_uint2((ct_tags & 2u) | (ne << 8), ct_solid);
         cache.written[tile] = 1;

@@ -118,3 +118,60 @@ def exchange_segments(dist, seg, edges: Sequence[int], world: int, out_alloc=Non
     recv = out_alloc(sum(out_sizes)) if out_alloc is not None else torch.empty(sum(out_sizes), dtype=torch.int64, device=seg.device)
     dist.all_to_all_single(recv, send, output_split_sizes=out_sizes, input_split_sizes=in_sizes)
     return recv
+
+
+# ---- the exchange frame, device-side (include/forma_hip.h "multi-GPU, exchange layout") -------------------------------------
+def pair_capacity(max_pair_count: int) -> int:
+    """Slots per (sender, owner) bucket: the largest bucket seen, 6 % slack, a multiple of 2048 (whole rasterizer blocks)."""
+    c = int(max_pair_count) + int(max_pair_count) // 16 + 4096
+    return (c + 2047) // 2048 * 2048
+
+
+class ExchangeFrame:
+    """One rank's side of `bench.py --mode exchange`: lines [cuts[rank], cuts[rank + 1]) are rasterized here, bucketed by
+    tile-row owner with HIP kernels (no torch op on the data path), ONE equal-split all-to-all of the bucket counts and one
+    of the padded buckets run on the context's own stream (RCCL through torch.distributed, ordered by events: no host
+    synchronisation), then this rank gathers what it received, sorts and paints its band."""
+
+    def __init__(self, ctx, dist, rank: int, world: int, edges: Sequence[int], width: int, height: int, capacity: int):
+        import torch
+        self.ctx, self.dist, self.rank, self.world = ctx, dist, rank, world
+        self.edges = [int(e) for e in edges]
+        self.width, self.height = width, height
+        self.crop = band_crop(self.edges, rank, width, height)
+        ctx.exchange_plan(self.edges, capacity)
+        self.send, self.send_counts, self.recv, self.recv_counts = ctx.exchange_views()
+        self.stream = torch.cuda.ExternalStream(ctx.stream_handle(), device=torch.device("cuda", ctx.device))
+
+    def frame(self, channels=(0, 1, 2, 3), clear=(1, 1, 1, 1), dst=None, stride=None, timings=False, device_only=True):
+        import torch
+        t1 = self.ctx.rasterize_bucket_frame(self.width, self.height, timings=timings)
+        if self.world > 1:
+            with torch.cuda.stream(self.stream):                       # collectives ordered after the bucket kernels, before the gather
+                self.dist.all_to_all_single(self.recv_counts, self.send_counts)
+                self.dist.all_to_all_single(self.recv, self.send)
+        r = self.ctx.gather_sort_paint_frame(self.width, self.height, channels=channels, clear=clear, crop=self.crop, dst=dst,
+                                             stride=stride, timings=timings, device_only=device_only)
+        if not timings:
+            return r
+        t2 = r[1]
+        for k in ("prepare_us", "rasterize_us"):
+            t2[k] = t1[k]
+        t2["exchange_us"] = t2.get("exchange_us", 0.0) + t1.get("exchange_us", 0.0)
+        t2["total_us"] = t2["total_us"] + t1["total_us"]
+        t2["n_lines"] = t1["n_lines"]
+        return r[0], t2
+
+
+def max_pair_count(dist, local_segments: np.ndarray, edges: Sequence[int], world: int, device=None) -> int:
+    """The largest (sender, owner) bucket of a frame: this rank's segments per owner band, maximum over all ranks."""
+    import torch
+    ty = (local_segments >> np.uint64(53)).astype(np.int64) - 1
+    keep = (ty >= edges[0]) & (ty < edges[-1])
+    owner = np.searchsorted(np.asarray(edges[1:-1], np.int64), ty[keep], side="right")
+    mx = int(np.bincount(owner, minlength=world).max()) if keep.any() else 0
+    if dist is None or world == 1:
+        return mx
+    t = torch.tensor([mx], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())

@@ -120,6 +120,7 @@ typedef struct forma_timings_t {
     uint32_t n_runs;          /* (tile, layer) runs in the sorted stream */
     uint32_t n_tile_entries;  /* carry-only span records of the frame  */
     uint32_t n_tiles_written; /* tiles copied into dst (all tiles of the crop without a cache; the damaged ones with one) */
+    float    exchange_us;     /* multi-GPU: bucketing by tile-row owner (sender) + gathering the received buckets (owner) */
 } forma_timings_t;
 
 /* ---- lifetime ----------------------------------------------------------------------------- */
@@ -236,6 +237,30 @@ int forma_hip_sort_paint_frame(forma_hip_ctx* ctx, size_t n, uint8_t* dst, uint3
                                uint32_t height, size_t stride_bytes,
                                const uint8_t channels[4], const float clear_color[4],
                                const forma_rect_t* crop_or_null, forma_timings_t* timings);
+
+
+/* ---- multi-GPU, exchange layout: rasterize 1/G of the lines per GPU, ONE all-to-all of pixel segments over xGMI --------
+ * One process per GPU, every rank holds the layer / style tables and ITS contiguous share of the lines
+ * (forma_hip_set_geometry with a slice).  Rank g owns the tile rows [row_edges[g], row_edges[g + 1]).  Per frame:
+ *   1. forma_hip_rasterize_bucket_frame: stages 1-2 on the local lines, then a stable partition of the local pixel
+ *      segments by owner into `send`: bucket g at send[g * pair_capacity], send_counts[2 g] segments (send_counts[2 g + 1]
+ *      != 0: this sender overflowed the capacity — every receiver then fails the frame with FORMA_E_CAPACITY and the
+ *      host re-plans with a larger capacity);
+ *   2. the host language runs the collective on forma_hip_stream's stream: an equal-split all-to-all of the counts
+ *      (2 words per pair) and of the payload (pair_capacity u64 per pair) from send / send_counts into recv / recv_counts
+ *      — RCCL through torch.distributed in this repository; with one rank nothing is exchanged;
+ *   3. forma_hip_gather_sort_paint_frame: the received buckets, rank-major (= global line order, which keeps the sort
+ *      bit-exact), become one stream; sort + paint of the band as in forma_hip_render (crop = the band).
+ * No call waits for the device except the end of step 3 (and step 1 when timings are requested).                        */
+int forma_hip_stream(forma_hip_ctx* ctx, void** hip_stream);
+int forma_hip_exchange_plan(forma_hip_ctx* ctx, const uint32_t* row_edges /* n_ranks + 1 */, uint32_t n_ranks /* <= 8 */,
+                            uint32_t pair_capacity);
+int forma_hip_exchange_buffers(forma_hip_ctx* ctx, uint64_t** send, uint32_t** send_counts, uint64_t** recv,
+                               uint32_t** recv_counts);
+int forma_hip_rasterize_bucket_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, forma_timings_t* timings);
+int forma_hip_gather_sort_paint_frame(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t height,
+                                      size_t stride_bytes, const uint8_t channels[4], const float clear_color[4],
+                                      const forma_rect_t* crop_or_null, forma_timings_t* timings);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,169 @@
+"""Multi-GPU exchange layout (include/forma_hip.h last section) on the GPU: rasterize a share of the lines,
+bucket the pixel segments by tile-row owner with the HIP kernels, move the buckets, gather + sort + paint the band.
+
+* one rank: the whole pipeline against the oracle and against a plain render;
+* G ranks on ONE device: G contexts play the ranks, the all-to-all is done by hand with device copies between their
+  bucket buffers — every kernel of the exchange path runs exactly as it would on G devices, the bands must stitch to the
+  single-device frame and each rank's sorted stream must equal the oracle's stream restricted to its band;
+* layers pushed out of paint order (a slice can look layer-sorted while the gathered stream is not);
+* a real 2-process RCCL run when the box has two GPUs (skipped on a single-GPU box)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import scene as S
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def scene_tables(comp):
+    o = orc.Oracle()
+    t = comp.tables(o)
+    S.load(o, t)
+    return o, t
+
+
+def run_ranks(t, W, H, G, clear, frames=2):
+    """G contexts on device 0 play G ranks; returns per rank (image rows of its band, its sorted stream), edges."""
+    import torch
+    import forma_amd
+    from forma_amd import sharding
+    tiles_h = (H + 15) // 16
+    ref = forma_amd.Context(0)
+    S.load(ref, t)
+    lengths = ref.prepare_lines(W, H)["lengths"]
+    ref.render(W, H, clear=clear)
+    full_stream = ref.segments(0)
+    edges = sharding.band_edges(sharding.row_histogram(full_stream, tiles_h), G)
+    cuts = sharding.line_shares(lengths, G)
+    ctxs, mx = [], 0
+    for r in range(G):
+        c = forma_amd.Context(0)
+        S.load(c, t)
+        c.set_geometry(*sharding.slice_geometry(t["x"], t["y"], t["line_slot"], cuts[r], cuts[r + 1]))
+        c.rasterize_frame(W, H)
+        mx = max(mx, sharding.max_pair_count(None, c.segments(0), edges, G))
+        ctxs.append(c)
+    cap = sharding.pair_capacity(mx)
+    xs = [sharding.ExchangeFrame(c, None, r, G, edges, W, H, cap) for r, c in enumerate(ctxs)]
+    out = None
+    for _ in range(frames):                                            # frame 1 synchronous, frame 2 read-back-free
+        for x in xs:
+            x.ctx.rasterize_bucket_frame(W, H)
+        torch.cuda.synchronize()
+        for r, x in enumerate(xs):                                     # the all-to-all, by hand: recv[r][s] = send[s][r]
+            for s, y in enumerate(xs):
+                if G > 1:
+                    x.recv[s * cap:(s + 1) * cap].copy_(y.send[r * cap:(r + 1) * cap])
+                    x.recv_counts[2 * s:2 * s + 2].copy_(y.send_counts[2 * r:2 * r + 2])
+        torch.cuda.synchronize()
+        out = []
+        for r, x in enumerate(xs):
+            img = np.full((H, W * 4), 7, np.uint8)
+            x.ctx.gather_sort_paint_frame(W, H, clear=clear, crop=x.crop, dst=img, device_only=False)
+            y0, y1 = x.crop[2], x.crop[3]
+            assert (img[:y0] == 7).all() and (img[y1:] == 7).all()    # a rank writes only its own rows
+            out.append((img[y0:y1].copy(), x.ctx.segments(1)))
+    for c in ctxs:
+        c.close()
+    ref.close()
+    return out, edges
+
+
+@pytest.mark.parametrize("G", [1, 2, 3, 8])
+def test_exchange_path_with_G_ranks_on_one_device(G):
+    W, H = 512, 384
+    clear = (0.2, 0.3, 0.4, 1.0)
+    o, t = scene_tables(S.random_mixed())
+    want = o.render(W, H, clear=clear)
+    sorted_full = o.segments(1)
+    out, edges = run_ranks(t, W, H, G, clear)
+    stitched = np.concatenate([img for img, _ in out])
+    assert np.array_equal(stitched, want)
+    ty = (sorted_full >> np.uint64(53)).astype(np.int64) - 1
+    for r, (_, srt) in enumerate(out):                                 # bit-exact sorted stream of the band
+        assert np.array_equal(srt, sorted_full[(ty >= edges[r]) & (ty < edges[r + 1])]), r
+
+
+def test_exchange_with_layers_pushed_out_of_paint_order():
+    """Geometry appended in insertion order [5, 1, 9, 3, 0]: each rank's slice may be layer-sorted by itself while the
+    gathered band is not — the gather kernel checks the stream it actually sorts (api.cpp sort_paint_frame)."""
+    W, H = 320, 208
+    comp = S.Composition(insertion_order=True)
+    for order, (x, y) in zip((5, 1, 9, 3, 0), ((60, 60), (120, 80), (180, 100), (240, 120), (150, 150))):
+        comp.get_mut_or_insert_default(order).insert(S.custom_circle(x, y, 70)).set_props(S.solid((order / 9, 0.4, 0.6, 0.7)))
+    o, t = scene_tables(comp)
+    want = o.render(W, H)
+    out, _ = run_ranks(t, W, H, 3, (1, 1, 1, 0))
+    assert np.array_equal(np.concatenate([img for img, _ in out]), want)
+
+
+def test_exchange_capacity_overflow_is_reported():
+    import forma_amd
+    from forma_amd import sharding, FormaError
+    W, H = 256, 160
+    o, t = scene_tables(S.random_mixed(n=80, width=W, height=H, seed=2))
+    c = forma_amd.Context(0)
+    S.load(c, t)
+    x = sharding.ExchangeFrame(c, None, 0, 1, [0, (H + 15) // 16], W, H, 2048)     # far too small on purpose
+    with pytest.raises(FormaError) as e:
+        x.frame(device_only=True)
+    assert e.value.code == -4
+    c.rasterize_frame(W, H)
+    cap = sharding.pair_capacity(sharding.max_pair_count(None, c.segments(0), x.edges, 1))
+    x = sharding.ExchangeFrame(c, None, 0, 1, x.edges, W, H, cap)                  # re-planned
+    img = x.frame(clear=(1, 1, 1, 0), device_only=False, dst=np.zeros((H, W * 4), np.uint8))
+    assert np.array_equal(img, o.render(W, H))
+    c.close()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _rccl_worker(rank, world, port, out_dir):
+    import sys
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import scene as S2
+    import forma_amd
+    from forma_amd import sharding
+    from oracle import oracle as orc2
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    W, H = 512, 384
+    tiles_h = (H + 15) // 16
+    clear = (0.2, 0.3, 0.4, 1.0)
+    o = orc2.Oracle()
+    t = S2.random_mixed().tables(o)
+    S2.load(o, t)
+    want = o.render(W, H, clear=clear)
+    c = forma_amd.Context(rank)
+    S2.load(c, t)
+    lengths = c.prepare_lines(W, H)["lengths"]
+    c.render(W, H, clear=clear)
+    edges = sharding.agree_on_bands(dist, sharding.row_histogram(c.segments(0), tiles_h), world, device="cuda")
+    cuts = sharding.line_shares(lengths, world)
+    c.set_geometry(*sharding.slice_geometry(t["x"], t["y"], t["line_slot"], cuts[rank], cuts[rank + 1]))
+    c.rasterize_frame(W, H)
+    cap = sharding.pair_capacity(sharding.max_pair_count(dist, c.segments(0), edges, world, device="cuda"))
+    x = sharding.ExchangeFrame(c, dist, rank, world, edges, W, H, cap)
+    for _ in range(3):
+        img = x.frame(clear=clear, device_only=False, dst=np.full((H, W * 4), 7, np.uint8))
+    y0, y1 = x.crop[2], x.crop[3]
+    assert np.array_equal(img[y0:y1], want[y0:y1])
+    assert (img[:y0] == 7).all() and (img[y1:] == 7).all()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_over_rccl():
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import torch.multiprocessing as mp
+    mp.spawn(_rccl_worker, args=(2, _free_port(), ""), nprocs=2, join=True)

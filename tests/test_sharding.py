@@ -149,3 +149,76 @@ def test_two_rank_exchange_protocol_gloo(tmp_path):
     import torch.multiprocessing as mp
     world = 2
     mp.spawn(_exchange_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+
+
+def _padded_worker(rank, world, port, out_dir):
+    """The device-side exchange protocol (forma_hip_rasterize_bucket_frame -> equal-split all-to-all of counts and padded
+    buckets -> forma_hip_gather_sort_paint_frame) with the bucket / gather kernels restated in numpy: what crosses the
+    collective, and in which layout, is exactly what sharding.ExchangeFrame moves over RCCL."""
+    import sys
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import scene as S
+    from oracle import oracle as orc
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    W, H = 200, 150
+    tiles_h = (H + 15) // 16
+    clear = (0.1, 0.2, 0.3, 1.0)
+    comp = S.Composition(insertion_order=True)                          # layers pushed out of paint order on purpose
+    rng = np.random.default_rng(3)
+    for order in rng.permutation(40):
+        comp.get_mut_or_insert_default(int(order)).insert(S.custom_circle(float(rng.uniform(0, W)), float(rng.uniform(0, H)), float(rng.uniform(8, 60)))) \
+            .set_props(S.solid((float(rng.random()), float(rng.random()), float(rng.random()), 0.7)))
+    ref = orc.Oracle()
+    t = comp.tables(ref)
+    S.load(ref, t)
+    full = ref.render(W, H, clear=clear)
+    full_stream = ref.segments(0)
+    sums = ref.prepare_lines(W, H)["lengths"]
+    edges = sharding.agree_on_bands(dist, sharding.row_histogram(full_stream, tiles_h), world)
+    cuts = sharding.line_shares(sums, world)
+    o = orc.Oracle()
+    S.load(o, t)
+    o.set_geometry(*sharding.slice_geometry(t["x"], t["y"], t["line_slot"], cuts[rank], cuts[rank + 1]))
+    o.prepare_lines(W, H)
+    mine = o.rasterize()
+    cap = sharding.pair_capacity(sharding.max_pair_count(dist, mine, edges, world))
+    # k_owner_count / _scan / _scatter: stable partition into padded buckets + (count, overflow) pairs
+    ty = (mine >> np.uint64(53)).astype(np.int64) - 1
+    owner = np.searchsorted(np.asarray(edges[1:-1], np.int64), ty, side="right")
+    owner[(ty < edges[0]) | (ty >= edges[-1])] = world
+    send = np.zeros(world * cap, np.int64); counts = np.zeros(2 * world, np.int32)
+    for g in range(world):
+        b = mine[owner == g]
+        assert len(b) <= cap
+        send[g * cap: g * cap + len(b)] = b.view(np.int64); counts[2 * g] = len(b)
+    recv = torch.zeros(world * cap, dtype=torch.int64); rc = torch.zeros(2 * world, dtype=torch.int32)
+    dist.all_to_all_single(rc, torch.from_numpy(counts))
+    dist.all_to_all_single(recv, torch.from_numpy(send))
+    # k_gather_chunks: rank-major concatenation of the valid prefix of every bucket
+    got = np.concatenate([recv.numpy()[s * cap: s * cap + int(rc[2 * s])] for s in range(world)]).view(np.uint64)
+    tyf = (full_stream >> np.uint64(53)).astype(np.int64) - 1
+    want = full_stream[(tyf >= edges[rank]) & (tyf < edges[rank + 1])]
+    assert np.array_equal(got, want)                                   # the band's slice of the single-device stream, same order
+    layers = (got >> np.uint64(20)) & np.uint64(0x1FFFFF)
+    assert (np.diff(layers.astype(np.int64)) < 0).any()                 # ... and it is NOT layer-sorted: the sort needs the layer digits
+    srt = got[np.argsort(got >> np.uint64(20), kind="stable")]
+    x0, x1, y0, y1 = sharding.band_crop(edges, rank, W, H)
+    band = ref.paint(srt, W, H, clear=clear, crop=(x0, x1, y0, y1), dst=np.full((H, W * 4), 7, np.uint8))
+    assert np.array_equal(band[y0:y1], full[y0:y1])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_padded_bucket_exchange_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_padded_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+
+
+def test_pair_capacity_and_max_pair_count():
+    assert sharding.pair_capacity(0) == 4096 and sharding.pair_capacity(100000) % 2048 == 0 and sharding.pair_capacity(100000) >= 106000
+    def seg(ty):
+        return np.uint64((ty + 1) << 53)
+    v = np.array([seg(0), seg(1), seg(1), seg(5), seg(9), seg(9), seg(9), seg(40)], np.uint64)
+    assert sharding.max_pair_count(None, v, [0, 2, 6, 10], 3) == 3
