@@ -1,26 +1,35 @@
 #!/usr/bin/env python3
 """bench.py — frames/s and Mpixel-segments/s of the forma raster hot path on MI355X.
 
-A "step" is one `Renderer::render` frame (prepare lines -> rasterize -> radix sort -> carry pre-pass
--> per-tile paint) of a synthetic scene whose geometry, layer table and styles are already resident
-in HBM; the image stays device-resident (the PCIe-inclusive rate is reported separately, never as
-`value`).  One process per GPU.  For N > 1 the default (`--mode frames`) is frame-parallel: the unit of
-work is a frame, every GPU renders whole frames, per-GPU work is fixed (weak scaling) and nothing is
-exchanged on the data path; `--mode bands` splits ONE frame into tile-row bands (SURVEY.md §8e, strong
-scaling).  `value` is the whole-job aggregate: frames completed by all GPUs / max-over-ranks wall time.
+A "step" is one `Renderer::render` frame (prepare lines -> rasterize -> radix sort -> carry pre-pass -> per-tile paint)
+of a synthetic scene whose geometry, layer table and styles are already resident in HBM; the image stays device-resident
+(the PCIe-inclusive rate is reported separately, never as `value`).  One process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME | --svg FILE [--svg-scale S]] [--animated]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME | --svg FILE [--svg-scale S]]
+                    [--in-flight F] [--mode exchange|bands|frames] [--animated] [--no-cpu-baseline]
 
-`--svg` renders a real SVG document (e.g. the reference's paris-30k.svg, which is not in its checkout) through
-forma_amd/svg.py instead of the labelled stand-in; `--animated` adds the BASELINE config-5 leg (spaceship-like scene with
-and without the buffer-layer cache) under "animated".  Prints ONE JSON line on rank 0.
+N = 1: `value` = frames completed / wall time of exactly K frames with `--in-flight` F frames in flight (default 3): F
+renderer contexts on the one GPU, each with its own HIP stream and buffers, each fed by its own host thread.  Every frame
+does all of the work (nothing is shared between contexts but the scene description); the kernels of this path are
+latency-bound, so frames that overlap fill the machine — what a frame server or an animation export does.  The rate of
+ONE context rendering frame after frame (`fps_one_frame_in_flight`, with its per-frame latency and per-stage device times)
+is always reported next to it, as is the spread over five more blocks of K frames.
+
+N > 1 (default `--mode exchange`, strong scaling, the north star's layout): ONE frame is split — every GPU rasterizes 1/N
+of the lines, HIP kernels bucket the pixel segments by tile-row owner, one RCCL all-to-all over xGMI moves them, the owner
+sorts and paints its band.  `--mode bands` replicates the scene and culls by band (no exchange); `--mode frames` renders
+whole frames on every GPU (weak scaling).  `value` is always the whole-job aggregate / max-over-ranks wall time.
+
+Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
+import threading
 import time
 
 import numpy as np
@@ -29,28 +38,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2   # wave64 VALU instructions/ns the chip can issue: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles
+PMC_FILE = os.path.join("profiles", "r02_pmc_summary.json")   # tools/pmc_round.py: separate rocprofv3 --pmc passes of this command
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--workload", default="paris-like-30k-4k")
-    ap.add_argument("--mode", default="frames", choices=["frames", "bands", "exchange"],
-                    help="N > 1: 'frames' = every GPU renders whole frames (weak scaling, no exchange); "
-                         "'bands' = ONE frame split into tile-row bands across the GPUs, scene replicated (strong scaling, no "
-                         "exchange); 'exchange' = ONE frame: every GPU rasterizes 1/N of the lines, an RCCL all-to-all moves the "
-                         "pixel segments to the GPU that owns their tile row, which sorts and paints its band (strong scaling)")
-    ap.add_argument("--svg", default=None, metavar="FILE",
-                    help="render this SVG file (e.g. the real paris-30k.svg) on a 3840x2160 canvas instead of a synthetic "
-                         "workload; loaded by forma_amd.svg like the reference demo's `svg` mode")
+    ap.add_argument("--in-flight", type=int, default=3, help="N = 1: renderer contexts rendering concurrently (frames in flight)")
+    ap.add_argument("--mode", default="exchange", choices=["exchange", "bands", "frames"],
+                    help="N > 1: 'exchange' = ONE frame, lines / N rasterized per GPU, all-to-all of pixel segments to the "
+                         "tile-row owners (strong scaling); 'bands' = ONE frame, scene replicated, band culling, no exchange "
+                         "(strong scaling); 'frames' = every GPU renders whole frames (weak scaling)")
+    ap.add_argument("--svg", default=None, metavar="FILE", help="render this SVG (e.g. the real paris-30k.svg) instead of a synthetic workload")
     ap.add_argument("--svg-scale", type=float, default=1.0)
-    ap.add_argument("--animated", action="store_true",
-                    help="also measure BASELINE config 5: the animated spaceship-like 4K scene, with and without the "
-                         "buffer-layer cache (per-tile damage tracking); reported under \"animated\", never as `value`")
+    ap.add_argument("--animated", action="store_true", help="also measure BASELINE config 5 (deterministic spaceship, 4K, damage cache)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     return ap.parse_args()
 
 
@@ -70,7 +77,6 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
-    import forma_amd
     from forma_amd import api, scenes, sharding
 
     if args.svg:
@@ -81,62 +87,47 @@ def main():
     else:
         build_fn, width, height = scenes.WORKLOADS[args.workload]
         comp = build_fn()
-    renderer = api.Renderer(device=local)
-    ctx = renderer._ctx
     tiles_h = (height + 15) // 16
-    image = np.zeros((height, width * 4), np.uint8)
-    layout = api.LinearLayout(width, width * 4, height)
-    buf = api.BufferBuilder(image.reshape(-1), layout).build()
     clear = api.Color(1.0, 1.0, 1.0, 1.0)
-    # first frame through the public API: flattens on the GPU, uploads tables, leaves everything resident
-    renderer.render(comp, buf, api.RGBA, clear, None, timings=True)
-    t_full = renderer.last_timings
-    n_segments_full = t_full["n_segments"]
+    clr = (clear.r, clear.g, clear.b, clear.a)
+    channels = api.RGBA
 
-    crop = None
-    row0, row1 = 0, tiles_h
-    if world > 1 and args.mode == "bands":
-        # tile-row bands balanced on the per-row pixel-segment histogram of the full frame
+    def make_renderer():
+        """a context with the scene resident: first frame through the public API (flattens on the GPU, uploads the tables)"""
+        r = api.Renderer(device=local)
+        img = np.zeros((height, width * 4), np.uint8)
+        r.render(comp, api.BufferBuilder(img.reshape(-1), api.LinearLayout(width, width * 4, height)).build(), api.RGBA, clear, None, timings=True)
+        return r, img
+
+    renderer, image = make_renderer()
+    ctx = renderer._ctx
+    n_segments_full = renderer.last_timings["n_segments"]
+    mode = args.mode if (world > 1 or os.environ.get("FORMA_BENCH_MODE_AT_1")) else "single"   # (env: exercise a sharded mode on one GPU)
+    in_flight = max(1, args.in_flight) if mode == "single" else 1     # (a sharded frame is one context per GPU)
+    pool = [ctx] + [make_renderer()[0]._ctx for _ in range(in_flight - 1)]
+
+    crop, row0, row1, xf = None, 0, tiles_h, None
+    if mode == "bands":
         hist = sharding.row_histogram(ctx.segments(0), tiles_h)
-        edges = sharding.agree_on_bands(dist, hist, world, device="cuda")
+        edges = sharding.agree_on_bands(dist, hist, world, device="cuda") if dist is not None else sharding.band_edges(hist, 1)
         row0, row1 = edges[rank], edges[rank + 1]
         ctx.set_band(row0, row1)
         crop = sharding.band_crop(edges, rank, width, height)
-
-    channels = api.RGBA
-    clr = (clear.r, clear.g, clear.b, clear.a)
-
-    def frame(timings=False):
-        return ctx.render(width, height, channels=channels, clear=clr, crop=crop, device_only=True, timings=timings)
-
-    step = frame
-    if args.mode == "exchange":
-        # line-sharded rasterization + all-to-all of pixel segments to their tile-row owners (sharding.exchange_segments)
+    elif mode == "exchange":
         tab = renderer.host_tables
         hist = sharding.row_histogram(ctx.segments(0), tiles_h)
-        edges = sharding.agree_on_bands(dist, hist, world, device="cuda") if world > 1 else [0, tiles_h]
+        edges = sharding.agree_on_bands(dist, hist, world, device="cuda") if dist is not None else sharding.band_edges(hist, 1)
         row0, row1 = edges[rank], edges[rank + 1]
-        crop = sharding.band_crop(edges, rank, width, height)
         cuts = sharding.line_shares(ctx.prepare_lines(width, height)["lengths"], world)
         ctx.set_geometry(*sharding.slice_geometry(tab["x"], tab["y"], tab["line_slot"], cuts[rank], cuts[rank + 1]))
-        empty = torch.empty(0, dtype=torch.int64, device=torch.device("cuda", local))
+        ctx.rasterize_frame(width, height)
+        cap = sharding.pair_capacity(sharding.max_pair_count(dist, ctx.segments(0), edges, world, device="cuda"))
+        xf = sharding.ExchangeFrame(ctx, dist, rank, world, edges, width, height, cap)
 
-        def frame(timings=False):                           # noqa: F811
-            t1 = ctx.rasterize_frame(width, height, timings=timings)
-            seg = ctx.unsorted_view()
-            recv = sharding.exchange_segments(dist, empty if seg is None else seg, edges, world, out_alloc=ctx.reserve_view)
-            torch.cuda.synchronize()                        # the exchange ran on torch's stream; the context has its own
-            r = ctx.sort_paint_frame(int(recv.numel()), width, height, channels=channels, clear=clr, crop=crop,
-                                     device_only=True, timings=timings)
-            if not timings:
-                return r
-            t2 = r[1]
-            for k in ("prepare_us", "rasterize_us"):
-                t2[k] = t1[k]
-            t2["total_us"] = t2["total_us"] + t1["total_us"]
-            return r[0], t2
-
-        step = frame
+    def frame(c=ctx, timings=False):
+        if xf is not None:
+            return xf.frame(channels=channels, clear=clr, timings=timings, device_only=True)
+        return c.render(width, height, channels=channels, clear=clr, crop=crop, device_only=True, timings=timings)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -144,81 +135,118 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        elapsed = sharding.max_over_ranks(dist, elapsed, device="cuda")
-    ms_per_step = elapsed / args.steps * 1e3
-    frames_per_step = world if (world > 1 and args.mode == "frames") else 1      # frames mode: one whole frame per GPU per step
-    fps = frames_per_step * args.steps / elapsed
+    def run_block(steps, ctxs):
+        """exactly `steps` frames, len(ctxs) in flight: wall seconds (max over ranks)"""
+        share = [steps // len(ctxs) + (1 if i < steps % len(ctxs) else 0) for i in range(len(ctxs))]
+        sync_all()
+        t0 = time.perf_counter()
+        if len(ctxs) == 1:
+            for _ in range(steps):
+                frame(ctxs[0])
+        else:
+            ths = [threading.Thread(target=lambda c=c, n=n: [frame(c) for _ in range(n)]) for c, n in zip(ctxs, share)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+        sync_all()
+        dt = time.perf_counter() - t0
+        return sharding.max_over_ranks(dist, dt, device="cuda") if dist is not None else dt
 
-    # ---- per-stage device times + roofline of the radix pass (HIP events on the context's stream) ----------
-    stage = {}
-    reps = 10
+    for c in pool:
+        for _ in range(max(1, args.warmup // len(pool))):
+            frame(c)
+    elapsed = run_block(args.steps, pool)                       # THE timed region: exactly K frames
+    frames_per_step = world if mode == "frames" else 1          # frames mode: one whole frame per GPU per step
+    fps = frames_per_step * args.steps / elapsed
+    ms_per_step = elapsed / args.steps * 1e3
+    # spread: five more blocks of K frames, pipelined and with one frame in flight
+    blocks = [frames_per_step * args.steps / run_block(args.steps, pool) for _ in range(5)]
+    blocks1 = [frames_per_step * args.steps / run_block(args.steps, pool[:1]) for _ in range(5)] if in_flight > 1 else blocks
+
+    # ---- per-stage device times + roofline of the radix pass (HIP events on the context's stream, one frame in flight) ----
+    stage, reps = {}, 10
     for _ in range(reps):
         _, t = frame(timings=True)
         for k, v in t.items():
             stage[k] = stage.get(k, 0.0) + float(v) / reps
-    n_local = int(round(stage["n_segments"]))                 # (exchange mode: the segments this rank received)
+    n_local = int(round(stage["n_segments"]))                   # (exchange / bands: the segments this rank sorts)
     passes = int(round(stage["n_sort_passes"]))
     pass_us = stage["sort_pass_us"]
-    algo_bytes_per_pass = 16.0 * n_local                       # 8 B read + 8 B written per key per digit pass
+    algo_bytes_per_pass = 16.0 * n_local                        # 8 B read + 8 B written per key per digit pass (SURVEY §8d)
     achieved = (algo_bytes_per_pass / (pass_us * 1e-6) / 1e9) if pass_us > 0 else 0.0
-    # HBM bytes per launch from the PMC counters (collected in separate rocprofv3 passes and corrected as the MI355X guide
-    # prescribes; bench.py cannot run under two profilers at once, so the committed summary of the same command is read)
-    traffic = None
+    pmc = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01s_pmc_traffic.json")) as f:     # tools/pmc_traffic.py, current kernels
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
             pmc = json.load(f)
-        if args.workload == "paris-like-30k-4k" and world == 1:
-            traffic = pmc["kernels"][pmc["roofline_kernel"]]["hbm_bytes_per_launch"]
     except Exception:
-        traffic = None
-    roofline = {"bound": "hbm", "kernel": "k_onesweep: one radix digit pass (LSB, 8-bit digits over live key bits, u64 keys, chained scan)",
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": algo_bytes_per_pass, "avg_launch_us": round(pass_us, 2),
-                "passes": passes}
+        pmc = None
+    use_pmc = pmc is not None and args.workload == "paris-like-30k-4k" and world == 1
+    roofline = {"bound": "hbm", "kernel": "k_onesweep<8>: one radix digit pass (LSB, 8-bit digits over live key bits, u64 keys, chained scan)",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": pmc["kernels"]["k_onesweep<8>"]["hbm_bytes_per_launch"] if use_pmc else None,
+                "traffic_source": (PMC_FILE + " — separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this command on "
+                                   "the committed build (gfx950: FETCH_SIZE x 2), NOT measured in this run") if use_pmc else None,
+                "algorithmic_bytes_per_launch": algo_bytes_per_pass, "avg_launch_us": round(pass_us, 2), "passes": passes}
+    # the painter is not an HBM kernel: VALU issue and LDS bound it.  Live: its launch time; from the committed counters of
+    # the same build: wave-level VALU instructions per launch and the LDS bank-conflict ratio.
+    painter = {"kernel": "k_paint_wave (one wavefront per 16x16 tile)", "bound": "valu+lds", "avg_launch_us": round(stage["paint_us"], 1),
+               "hbm_algorithmic_bytes": 8.0 * n_local + 4.0 * width * height,
+               "hbm_achieved_GBs": round((8.0 * n_local + 4.0 * width * height) / max(stage["paint_us"], 1e-3) / 1e3, 1)}
+    if use_pmc and "k_paint_wave" in pmc["kernels"]:
+        k = pmc["kernels"]["k_paint_wave"]
+        valu = k.get("SQ_INSTS_VALU")
+        if valu:
+            ach = valu / max(stage["paint_us"], 1e-3) / 1e3       # G wave-instructions / s
+            painter.update({"valu_wave_instructions_per_launch": valu, "achieved": round(ach, 1), "peak": round(VALU_PEAK_GINST, 1),
+                            "unit": "G wave64 VALU instructions/s", "frac": round(ach / VALU_PEAK_GINST, 4)})
+        if k.get("SQ_LDS_IDX_ACTIVE"):
+            painter["lds_bank_conflict_ratio"] = round(k.get("SQ_LDS_BANK_CONFLICT", 0) / k["SQ_LDS_IDX_ACTIVE"], 4)
+        painter["counters_source"] = PMC_FILE + " (separate --pmc passes, NOT this run)"
 
-    # PCIe-inclusive frame (image copied into caller memory) — reported, never `value`
-    sync_all()
-    t1 = time.perf_counter()
-    if args.mode == "exchange":
-        fps_d2h = 0.0                                       # (not measured in this mode)
-    else:
-        for _ in range(5):
-            ctx.render(width, height, channels=channels, clear=clr, crop=crop, dst=image.reshape(-1), stride=width * 4)
+    # PCIe-inclusive frames (image copied into caller memory) — reported, never `value`
+    fps_d2h = None
+    if mode in ("single", "frames", "bands"):
+        imgs = [image] + [np.zeros_like(image) for _ in pool[1:]]
+
+        def d2h_frames(c, img, n):
+            for _ in range(n):
+                c.render(width, height, channels=channels, clear=clr, crop=crop, dst=img.reshape(-1), stride=width * 4)
+        sync_all()
+        t1 = time.perf_counter()
+        ths = [threading.Thread(target=d2h_frames, args=(c, im, 6)) for c, im in zip(pool, imgs)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
         torch.cuda.synchronize()
-        fps_d2h = 5 / (time.perf_counter() - t1)
+        fps_d2h = round(6 * len(pool) / (time.perf_counter() - t1), 2)
 
+    sharding_txt = {
+        "single": "none", "frames": f"frame-parallel x{world}: every GPU renders whole frames of the workload (units = frames), no exchange",
+        "bands": f"tile-row bands x{world} of ONE frame, replicated scene, band culling, no data-path collective",
+        "exchange": f"ONE frame: lines / {world} rasterized per GPU, HIP bucketing by tile-row owner, one RCCL all-to-all of pixel segments "
+                    f"(padded equal split on the context's stream), band-local sort + paint"}[mode]
     out = {
         "metric": "frames/sec (sorted+painted, device-resident) + Mpixel-segments/sec",
         "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "strong" if (world > 1 and args.mode in ("bands", "exchange")) else "weak", "vs_baseline": None,
+        "scaling": "weak" if mode in ("single", "frames") else "strong", "vs_baseline": None,
         "dtype": "u64 segments / f64+f32 rasterizer / f32 painter", "data": "synthetic",
         "mpixel_segments_per_s": round(n_segments_full * fps / 1e6, 1),
-        "fps_including_d2h": round(fps_d2h, 2),
+        "frames_in_flight": in_flight,
+        "fps_blocks": {"median": round(statistics.median(blocks), 1), "min": round(min(blocks), 1), "max": round(max(blocks), 1), "blocks": 5},
+        "fps_one_frame_in_flight": {"median": round(statistics.median(blocks1), 1), "min": round(min(blocks1), 1), "max": round(max(blocks1), 1),
+                                    "frame_latency_ms": round(1e3 / statistics.median(blocks1), 4)},
+        "fps_including_d2h": fps_d2h,
         "config": {"workload": args.workload + (" (labelled stand-in: paris-30k.svg is not in the reference checkout)"
                                                  if args.workload.startswith("paris") else ""),
                    "canvas": [width, height], "layers": len(comp), "pixel_segments": int(n_segments_full),
-                   "sharding": "none" if world == 1 else (
-                       f"tile-row bands x{world} of ONE frame, replicated scene, band culling, no data-path collective"
-                       if args.mode == "bands" else
-                       f"lines / {world} rasterized per GPU, RCCL all-to-all of pixel segments to tile-row owners, band-local sort + paint"
-                       if args.mode == "exchange" else
-                       f"frame-parallel x{world}: every GPU renders whole 3840x2160 frames of the workload (units = frames), no exchange"),
-                   "band_rows": [row0, row1]},
-        "stages_us": {k: round(stage[k], 1) for k in ("prepare_us", "rasterize_us", "sort_us", "carry_us", "paint_us", "total_us")},
+                   "frames_in_flight": in_flight, "sharding": sharding_txt, "band_rows": [row0, row1]},
+        "stages_us": {k: round(stage.get(k, 0.0), 1) for k in ("prepare_us", "rasterize_us", "exchange_us", "sort_us", "carry_us", "paint_us", "total_us")},
         "roofline": roofline,
+        "roofline_painter": painter,
     }
-
     if rank == 0 and world == 1 and args.animated:
         out["animated"] = animated_leg(local)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -230,49 +258,41 @@ def main():
 
 
 def animated_leg(local, frames=240):
-    """BASELINE config 5 on one GPU: 3840x2160, 400 static + 121 moving layers, 60 Hz animation.  Every frame uploads the
-    layer table (transforms) and the per-order `unchanged` bytes exactly like `Renderer::render` would, then renders
-    device-resident with cache 0 (damage tracking) or without a cache (everything repainted)."""
+    """BASELINE config 5 on one GPU: the deterministic spaceship (forma_amd/spaceship.py = the reference demo's game logic,
+    fixed dt = 1/60 s) at 3840 x 2160, BGR1, clear (1, 1, 1, 0), through the product API exactly as the demo's runner does
+    (demo/src/runner.rs:150-165): compose, then render into a caller buffer — with one persistent BufferLayerCache (damage
+    tracking) and without a cache.  The game logic runs on the host between frames and is not timed."""
     import torch
-    from forma_amd import api, scenes
-    comp, moving, state = scenes.spaceship()
-    renderer = api.Renderer(device=local)
-    W, H = state["size"]
-    img = np.zeros(W * H * 4, np.uint8)
-    renderer.render(comp, api.BufferBuilder(img, api.LinearLayout(W, W * 4, H)).build(), api.RGBA, api.Color(0, 0, 0, 1), None)
-    ctx = renderer._ctx
-    t = renderer.host_tables
-    geoms = t["geoms"].copy()
-    slot_of_order = {int(geoms[i]["order"]): i for i in range(len(geoms)) if geoms[i]["order"] != 0xFFFFFFFF}
-    slots = np.array([slot_of_order[o] for o in moving])
-    unchanged = np.ones(len(t["style_offsets"]), np.uint8)
-    unchanged[np.array(moving)] = 0
+    from forma_amd import api
+    from forma_amd.spaceship import Spaceship
+    W, H = 3840, 2160
     res = {}
-    for label, cache_id, unch in (("no_cache", -1, None), ("with_cache", 0, unchanged)):
-        painted = []
-        for i in range(frames + 10):
-            if i == 10:
-                torch.cuda.synchronize(); t0 = time.perf_counter()
-            geoms["flags"][slots] = 1
-            geoms["xf"][slots] = scenes.spaceship_transforms(state, i / 60.0)
-            ctx.set_geoms(geoms)
-            ctx.set_styles(t["style_offsets"], t["style_words"], unch if i > 0 else None)
-            ctx.render(W, H, clear=(0, 0, 0, 1), cache_id=cache_id, device_only=True)
-        torch.cuda.synchronize()
-        res[label] = round(frames / (time.perf_counter() - t0), 1)
-    # damaged-tile fraction (SURVEY §8d C5): tiles the cached frames actually rewrite, from a few frames rendered into a host buffer
-    host = np.zeros((H, W * 4), np.uint8)
-    damaged = []
-    for i in range(frames + 10, frames + 18):
-        geoms["xf"][slots] = scenes.spaceship_transforms(state, i / 60.0)
-        ctx.set_geoms(geoms)
-        ctx.set_styles(t["style_offsets"], t["style_words"], unchanged)
-        _, tm = ctx.render(W, H, clear=(0, 0, 0, 1), cache_id=0, dst=host, timings=True)
-        damaged.append(tm["n_tiles_written"])
-    tiles = ((W + 15) // 16) * ((H + 15) // 16)
-    return {"workload": "spaceship-like-4k (400 static + 121 moving layers, 60 Hz transforms)", "frames": frames,
-            "fps_no_cache": res["no_cache"], "fps_with_cache": res["with_cache"], "unit": "frames/s, device-resident, "
-            "including the per-frame layer-table upload", "damaged_tile_fraction": round(float(np.mean(damaged)) / tiles, 4)}
+    for label, cached in (("no_cache", False), ("with_cache", True)):
+        comp, r = api.Composition(), api.Renderer(device=local)
+        cache = r.create_buffer_layer_cache() if cached else None
+        game = Spaceship(api, W, H)
+        buf = np.zeros(W * H * 4, np.uint8)
+        lay = api.LinearLayout(W, W * 4, H)
+        spent, written, tiles = 0.0, [], ((W + 15) // 16) * ((H + 15) // 16)
+        for f in range(frames):
+            game.compose(comp)
+            b = api.BufferBuilder(buf, lay)
+            if cached:
+                b = b.layer_cache(cache)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r.render(comp, b.build(), api.BGR1, api.Color(1, 1, 1, 0), None)
+            spent += time.perf_counter() - t0
+            if cached and f >= 10:
+                written.append(int(r._ctx.tiles_written(W, H).sum()))
+        res[label] = round(frames / spent, 1)
+        if cached:
+            res["damaged_tile_fraction"] = round(float(np.mean(written)) / tiles, 4)
+            res["actors_at_end"] = len(game.actors)
+    return {"workload": "spaceship (deterministic re-implementation of demo/src/demos/spaceship.rs, 3840x2160, BGR1)", "frames": frames,
+            "fps_no_cache": res["no_cache"], "fps_with_cache": res["with_cache"], "damaged_tile_fraction": res["damaged_tile_fraction"],
+            "actors_at_end": res["actors_at_end"],
+            "unit": "frames/s of Renderer::render into a caller buffer (table upload + D2H of the written tiles included)"}
 
 
 def cpu_baseline(renderer, width, height, budget_s):
