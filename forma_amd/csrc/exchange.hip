@@ -156,35 +156,47 @@ __global__ __launch_bounds__(XB_THREADS) void k_owner_scatter(const uint64_t* __
     }
 }
 
-// received buckets (chunk s = what rank s sent: [s * capacity, + counts[2 s])), rank-major, -> out[0 .. N_r)
+// received buckets (chunk s = what rank s sent: [s * capacity, + counts[2 s])), rank-major, -> out[0 .. N_r).
+// blockIdx.y = chunk: every workgroup copies a contiguous piece of ONE chunk (coalesced 8-byte loads and stores).
 __global__ __launch_bounds__(256) void k_gather_chunks(const uint64_t* __restrict__ recv, const uint32_t* __restrict__ recv_counts,
                                                        uint32_t n_ranks, uint32_t capacity, uint64_t* __restrict__ out,
                                                        FrameInfo* __restrict__ info) {
     __shared__ uint32_t red[5][4];
-    uint32_t start[FORMA_MAX_RANKS + 1];
-    uint32_t acc = 0, over = 0;
-#pragma unroll
-    for (int s = 0; s < FORMA_MAX_RANKS; s++) {
-        start[s] = acc;
-        if (s < (int)n_ranks) { const uint32_t c = recv_counts[2 * s]; over |= recv_counts[2 * s + 1] | (c > capacity ? 1u : 0u); acc += c < capacity ? c : capacity; }
+    const uint32_t s = blockIdx.y;
+    uint32_t start = 0, total = 0, over = 0, prev_chunk = 0xFFFFFFFFu, prev_cnt = 0;
+    for (uint32_t q = 0; q < n_ranks; q++) {                            // (uniform: <= 8 scalar loads)
+        const uint32_t c0 = recv_counts[2 * q];
+        over |= recv_counts[2 * q + 1] | (c0 > capacity ? 1u : 0u);
+        const uint32_t c = c0 < capacity ? c0 : capacity;
+        if (q < s) { start += c; if (c) { prev_chunk = q; prev_cnt = c; } }
+        total += c;
     }
-    start[FORMA_MAX_RANKS] = acc;
-    const uint32_t total = acc;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { info->n_segments = total; if (over) info->exchange_overflow = 1u; }
+    const uint32_t cnt0 = recv_counts[2 * s];
+    const uint32_t cnt = cnt0 < capacity ? cnt0 : capacity;
+    if (blockIdx.x == 0 && s == 0 && threadIdx.x == 0) { info->n_segments = total; if (over) info->exchange_overflow = 1u; }
+    const uint64_t* src = recv + (size_t)s * capacity;
     uint32_t k_or = 0, k_or_hi = 0, k_and = 0xFFFFFFFFu, k_and_hi = 0xFFFFFFFFu, unsorted = 0;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        uint32_t s = 0;
+    for (uint32_t k0 = blockIdx.x * 1024; k0 < cnt; k0 += gridDim.x * 1024) {
+        uint64_t v[4], pv[4];
 #pragma unroll
-        for (int q = 1; q < FORMA_MAX_RANKS; q++) s += (q < (int)n_ranks && i >= start[q]) ? 1u : 0u;
-        const uint64_t v = recv[(size_t)s * capacity + (i - start[s])];
-        out[i] = v;
-        const uint32_t klo = (uint32_t)(v >> 20), khi = (uint32_t)(v >> 52);
-        k_or |= klo; k_or_hi |= khi; k_and &= klo; k_and_hi &= khi;
-        if (i > 0) {                                                    // is the stream non-decreasing in layer?
-            uint32_t ps = s, pi = i - 1;
-            while (pi < start[ps]) ps--;                                // (empty chunks in between)
-            const uint64_t pv = recv[(size_t)ps * capacity + (pi - start[ps])];
-            if (seg_layer(pv) > seg_layer(v)) unsorted = 1;
+        for (int j = 0; j < 4; j++) {
+            const uint32_t k = k0 + j * 256 + threadIdx.x;
+            v[j] = k < cnt ? src[k] : 0ull;
+            pv[j] = ((threadIdx.x & 63) == 0 && k < cnt && k > 0) ? src[k - 1] : 0ull;   // lane 0: the element in front of the wave's row
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const uint64_t up = __shfl_up(v[j], 1, 64); if (threadIdx.x & 63) pv[j] = up; }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t k = k0 + j * 256 + threadIdx.x;
+            if (k < cnt) {
+                out[start + k] = v[j];
+                const uint32_t klo = (uint32_t)(v[j] >> 20), khi = (uint32_t)(v[j] >> 52);
+                k_or |= klo; k_or_hi |= khi; k_and &= klo; k_and_hi &= khi;
+                uint64_t p = pv[j];
+                if (k == 0) p = prev_chunk != 0xFFFFFFFFu ? recv[(size_t)prev_chunk * capacity + prev_cnt - 1] : v[j];
+                if (seg_layer(p) > seg_layer(v[j])) unsorted = 1;       // is the gathered stream non-decreasing in layer?
+            }
         }
     }
 #pragma unroll
@@ -196,11 +208,14 @@ __global__ __launch_bounds__(256) void k_gather_chunks(const uint64_t* __restric
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red[0][w] = k_or; red[1][w] = k_or_hi; red[2][w] = k_and; red[3][w] = k_and_hi; red[4][w] = unsorted; }
     __syncthreads();
-    if (threadIdx.x == 0 && total) {
+    if (threadIdx.x == 0 && blockIdx.x * 1024 < cnt) {
         uint32_t o = 0, oh = 0, a = 0xFFFFFFFFu, ah = 0xFFFFFFFFu, u = 0;
         for (int q = 0; q < 4; q++) { o |= red[0][q]; oh |= red[1][q]; a &= red[2][q]; ah &= red[3][q]; u |= red[4][q]; }
-        atomicOr(&info->key_or, o); atomicOr(&info->key_or_hi, oh);
-        atomicAnd(&info->key_and, a); atomicAnd(&info->key_and_hi, ah);
+        // (few workgroups add information once the masks have saturated: see k_rasterize)
+        if (o & ~info->key_or) atomicOr(&info->key_or, o);
+        if (oh & ~info->key_or_hi) atomicOr(&info->key_or_hi, oh);
+        if (~a & info->key_and) atomicAnd(&info->key_and, a);
+        if (~ah & info->key_and_hi) atomicAnd(&info->key_and_hi, ah);
         if (u) atomicOr(&info->layer_unsorted, 1u);
     }
 }
@@ -219,8 +234,8 @@ void launch_owner_bucket(hipStream_t s, const uint64_t* seg, DevCount nc, const 
 
 void launch_gather_chunks(hipStream_t s, const uint64_t* recv, const uint32_t* recv_counts, uint32_t n_ranks, uint32_t capacity,
                           uint64_t* out, FrameInfo* info) {
-    const size_t bound = (size_t)n_ranks * capacity;
-    uint32_t grid = (uint32_t)std::min<size_t>((bound + 255) / 256, 8192);
-    if (grid == 0) grid = 1;
-    hipLaunchKernelGGL(k_gather_chunks, dim3(grid), dim3(256), 0, s, recv, recv_counts, n_ranks, capacity, out, info);
+    uint32_t gx = (capacity + 1023) / 1024;
+    if (gx > 2048) gx = 2048;
+    if (gx == 0) gx = 1;
+    hipLaunchKernelGGL(k_gather_chunks, dim3(gx, n_ranks), dim3(256), 0, s, recv, recv_counts, n_ranks, capacity, out, info);
 }
