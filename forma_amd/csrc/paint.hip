@@ -1538,12 +1538,15 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
 // ================================================================================================
 #ifdef PAINT_PROF
 // -DPAINT_PROF (tools only): shader-clock stamps at the phase boundaries of k_paint_wave, summed over all tiles
-__device__ unsigned long long g_paint_prof[24];
-#define PP_STAMP(i) do { const unsigned long long _t = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&g_paint_prof[i], _t - pp_t); pp_t = _t; } while (0)
-#define PP_COUNT(i, v) do { if (lane == 0) atomicAdd(&g_paint_prof[i], (unsigned long long)(v)); } while (0)
+__device__ unsigned long long g_paint_prof[256][24];       // 256 copies by workgroup: same-address atomics would dominate the stamps
+#define PP_STAMP(i) do { const unsigned long long _t = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&g_paint_prof[blockIdx.x & 255][i], _t - pp_t); pp_t = __builtin_readcyclecounter(); } while (0)
+#define PP_COUNT(i, v) do { if (lane == 0) atomicAdd(&g_paint_prof[blockIdx.x & 255][i], (unsigned long long)(v)); } while (0)
 extern "C" int forma_hip_debug_paint_prof(unsigned long long* out24, int reset) {
-    if (reset) { unsigned long long z[24] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_paint_prof), z, sizeof z); }
-    return (int)hipMemcpyFromSymbol(out24, HIP_SYMBOL(g_paint_prof), 24 * 8);
+    static unsigned long long h[256][24];
+    if (reset) { for (int c = 0; c < 256; c++) for (int i = 0; i < 24; i++) h[c][i] = 0; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_paint_prof), h, sizeof h); }
+    int rc = (int)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_paint_prof), sizeof h);
+    for (int i = 0; i < 24; i++) { out24[i] = 0; for (int c = 0; c < 256; c++) out24[i] += h[c][i]; }
+    return rc;
 }
 #else
 #define PP_STAMP(i) do { } while (0)

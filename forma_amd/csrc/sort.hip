@@ -23,12 +23,17 @@
 #include "lookback.h"
 #include "radix_rank.h"
 
+#ifndef OS_THREADS
 #define OS_THREADS 1024
+#endif
 #define OS_WAVES   (OS_THREADS / 64)
 #define OS_KPT     16                               // keys per lane
 #define OS_TILE    (OS_THREADS * OS_KPT)            // 16384 keys per tile -> 128 KiB of LDS staging, 1 workgroup (16 waves) per CU
 #define ST_VALMASK 0x3FFFFFFFu
-#define OS_LBW     8                                // predecessor tiles examined per look-back probe
+#ifndef OS_LBW
+#define OS_LBW     8
+#endif
+//                                                  // predecessor tiles examined per look-back probe
 
 // ------------------------------------------------------------------------------------------------
 // up-front histograms of every planned digit: hist[p * 256 + d].  Per-lane run-length compression
@@ -113,6 +118,18 @@ __device__ __forceinline__ void scan2_excl(uint32_t& a, uint32_t& b, uint32_t* l
     }
 }
 
+#ifdef SORT_PROF
+// -DSORT_PROF (tools only): shader-clock stamps at the phase boundaries of k_onesweep (thread 0), summed over all tiles
+__device__ unsigned long long g_sort_prof[16];
+#define SP_STAMP(i) do { const unsigned long long _t = __builtin_readcyclecounter(); if (tid == 0) atomicAdd(&g_sort_prof[i], _t - sp_t); sp_t = _t; } while (0)
+extern "C" int forma_hip_debug_sort_prof(unsigned long long* out16, int reset) {
+    if (reset) { unsigned long long z[16] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_sort_prof), z, sizeof z); }
+    return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sort_prof), 16 * 8);
+}
+#else
+#define SP_STAMP(i) do { } while (0)
+#endif
+
 template <int BITS>
 __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
                                                          DevCount nc, int shift, uint32_t dmask,
@@ -141,12 +158,20 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
         gstart = g;
     }
 
+#ifdef SORT_PROF
+    unsigned long long sp_t = __builtin_readcyclecounter();
+#endif
     while (true) {
+        SP_STAMP(7);                                        // scatter + end barrier (and the prologue, once)
         if (tid == 0) s_tile = atomicAdd(ticket, 1u);
         for (int i = tid; i < OS_WAVES * RADIX; i += OS_THREADS) (&whist[0][0])[i] = 0;
         __syncthreads();
         const uint32_t tile = s_tile;
         if (tile >= ntiles) break;
+        SP_STAMP(0);                                        // ticket + clear + barrier
+#ifdef SORT_PROF
+        if (tid == 0) atomicAdd(&g_sort_prof[15], 1ull);
+#endif
         const uint32_t bbase = tile * OS_TILE;
         const uint32_t wbase = bbase + w * (64 * OS_KPT);
 
@@ -157,6 +182,10 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
             uint32_t idx = wbase + j * 64 + lane;
             keys[j] = idx < n ? in[idx] : ~0ull;            // padding sorts last in stream order, never written
         }
+#ifdef SORT_PROF
+        if (keys[OS_KPT - 1] == 0x123456789ull) atomicAdd(&g_sort_prof[14], 1ull);      // forces the loads to have landed
+        SP_STAMP(1);                                        // key loads
+#endif
         // ---- stable rank of every key among the same-digit keys of its wave ----------------------------------
         // per row: the lowest peer lane adds the class size to the wave's LDS digit counter, then every lane reads
         // the counter back (LDS operations of one wave retire in order): rank = counter - class size + lanes below.
@@ -174,6 +203,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
             if (j & 1) rnk[j >> 1] |= r << 16; else rnk[j >> 1] = r;
         }
         __syncthreads();
+        SP_STAMP(2);                                        // rank + barrier
         // ---- digit totals of the tile, per-wave bases, look-back ----------------------------------------
         uint32_t tot = 0, lbase = 0;
         if (tid < RADIX) {
@@ -192,6 +222,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
             for (int i = 0; i < OS_WAVES; i++) { uint32_t c = whist[i][tid]; whist[i][tid] = acc; acc += c; }
         }
         __syncthreads();
+        SP_STAMP(3);                                        // totals, scan, bases
         // ---- stage in digit order (needs only tile-local positions), BEFORE the look-back: the key registers die here
         //      and the staging of waves 4..7 overlaps the global round trips of the look-back lanes ---------------------
 #pragma unroll
@@ -199,6 +230,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
             const uint32_t dg = (uint32_t)(keys[j] >> shift) & dmask;
             staged[whist[w][dg] + ((rnk[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu)] = keys[j];
         }
+        SP_STAMP(4);                                        // staging (issue)
         // ---- look-back: one lane per digit walks its own chain of status words, OS_LBW predecessors per probe.
         //      (A one-at-a-time walk moves ~1 tile per L2 round trip, which is about the rate at which tiles retire:
         //      the window of aggregate-only predecessors then never drains and the walk becomes the pass.)
@@ -232,6 +264,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
             s_gdelta[tid] = gstart + excl - lbase;
         }
         __syncthreads();
+        SP_STAMP(5);                                        // look-back + barrier
         // ---- coalesced stores: every digit run leaves the CU as one contiguous piece --------------------------------
         const uint32_t nvalid = min((uint32_t)OS_TILE, n - bbase);
 #pragma unroll
