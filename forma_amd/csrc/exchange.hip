@@ -7,7 +7,9 @@
 // holds every segment of a band of rows, in global line order, produces exactly the rows a single device would.
 // Everything here is a stable partition of byte-sized work: HBM-bound, wavefront ballots for the ranks, no MFMA.
 //
-//   k_owner_count   : per 2048-segment block, segments per owner                       (1 read of the stream)
+//   k_owner_count   : per 2048-segment block, segments per owner                       (1 read of the stream; counting
+//                     inside the rasterizer instead — two ballots per 64 segments in the common one-owner case — was
+//                     measured: rasterizer +65 us for the 29 us this kernel takes, dropped)
 //   k_owner_scan    : per owner, exclusive scan of the block counts; totals -> the counts the ranks exchange
 //   k_owner_scatter : stable scatter into the send buffer, bucket g at [g * C, g * C + count_g)
 //   k_gather_chunks : received buckets (rank-major = global line order) -> one contiguous stream, its length, the
@@ -61,42 +63,47 @@ __global__ __launch_bounds__(XB_THREADS) void k_owner_count(const uint64_t* __re
     }
 }
 
-// one workgroup; per owner g: block_counts[g][0 .. nb) -> exclusive prefix in place, total -> counts
+// one workgroup PER OWNER g (blockIdx.x): block_counts[g][0 .. nb) -> exclusive prefix in place, total -> the count the ranks
+// exchange.  A thread owns a contiguous piece of the row and has all of its loads in flight at once (the first version walked
+// the row 1024 blocks at a time, one dependent global round trip per step: 15 us for 6720 blocks x 2 owners).
+#define XS_PER 8
 __global__ __launch_bounds__(1024) void k_owner_scan(uint32_t* __restrict__ block_counts, DevCount nc, uint32_t nblocks_cap,
                                                      uint32_t n_owners /* n + 1 */, uint32_t capacity,
-                                                     uint32_t* __restrict__ send_counts /* [n][2] */, FrameInfo* __restrict__ info) {
+                                                     uint32_t* __restrict__ send_counts /* [n][2], zeroed */, FrameInfo* __restrict__ info) {
     __shared__ uint32_t lds[17];
-    __shared__ uint32_t s_over;
     const uint32_t nb = (dev_count(nc) + XB_TILE - 1) / XB_TILE;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_over = 0;
-    __syncthreads();
-    for (uint32_t g = 0; g < n_owners; g++) {
-        uint32_t* row = block_counts + (size_t)g * nblocks_cap;
-        uint32_t carry = 0;
-        for (uint32_t b0 = 0; b0 < nb; b0 += 1024) {
-            const uint32_t i = b0 + threadIdx.x;
-            const uint32_t v = i < nb ? row[i] : 0u;
-            uint32_t inc = v;
+    const uint32_t g = blockIdx.x;
+    uint32_t* row = block_counts + (size_t)g * nblocks_cap;
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < nb; b0 += 1024 * XS_PER) {
+        const uint32_t i0 = b0 + threadIdx.x * XS_PER;
+        uint32_t v[XS_PER], sum = 0;
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
-            if (lane == 63) lds[w] = inc;
-            __syncthreads();
-            uint32_t wb = 0, tot = 0;
+        for (int k = 0; k < XS_PER; k++) { v[k] = i0 + k < nb ? row[i0 + k] : 0u; }
 #pragma unroll
-            for (int q = 0; q < 16; q++) { const uint32_t t = lds[q]; if (q < w) wb += t; tot += t; }
-            if (i < nb) row[i] = carry + wb + inc - v;
-            carry += tot;
-            __syncthreads();
-        }
-        if (threadIdx.x == 0 && g + 1 < n_owners) {                      // (the last owner is the dropped bucket)
-            send_counts[2 * g] = carry < capacity ? carry : capacity;
-            if (carry > capacity) s_over = 1;
+        for (int k = 0; k < XS_PER; k++) sum += v[k];
+        uint32_t inc = sum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+        if (lane == 63) lds[w] = inc;
+        __syncthreads();
+        uint32_t wb = 0, tot = 0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) { const uint32_t t = lds[q]; if (q < w) wb += t; tot += t; }
+        uint32_t run = carry + wb + inc - sum;
+#pragma unroll
+        for (int k = 0; k < XS_PER; k++) { if (i0 + k < nb) row[i0 + k] = run; run += v[k]; }
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && g + 1 < n_owners) {                          // (the last owner is the dropped bucket)
+        send_counts[2 * g] = carry < capacity ? carry : capacity;
+        if (carry > capacity) {                                          // every receiver learns that this sender overflowed
+            for (uint32_t t = 0; t + 1 < n_owners; t++) atomicOr(&send_counts[2 * t + 1], 1u);
+            info->exchange_overflow = 1u;
         }
     }
-    __syncthreads();
-    if (threadIdx.x < n_owners - 1) send_counts[2 * threadIdx.x + 1] = s_over;   // every receiver learns that this sender overflowed
-    if (threadIdx.x == 0 && s_over) info->exchange_overflow = 1u;
 }
 
 __global__ __launch_bounds__(XB_THREADS) void k_owner_scatter(const uint64_t* __restrict__ seg, DevCount nc, OwnerBands B,
@@ -226,9 +233,10 @@ void launch_owner_bucket(hipStream_t s, const uint64_t* seg, DevCount nc, const 
                          uint32_t* scratch, uint64_t* send, uint32_t* send_counts, FrameInfo* info) {
     const uint32_t nblocks = (uint32_t)((nc.bound + XB_TILE - 1) / XB_TILE);
     const uint32_t cap = nblocks + 1;
-    if (nblocks == 0) { (void)hipMemsetAsync(send_counts, 0, (size_t)B.n * 8, s); return; }
+    (void)hipMemsetAsync(send_counts, 0, (size_t)FORMA_MAX_RANKS * 8, s);
+    if (nblocks == 0) return;
     hipLaunchKernelGGL(k_owner_count, dim3(nblocks), dim3(XB_THREADS), 0, s, seg, nc, B, scratch, cap);
-    hipLaunchKernelGGL(k_owner_scan, dim3(1), dim3(1024), 0, s, scratch, nc, cap, B.n + 1, capacity, send_counts, info);
+    hipLaunchKernelGGL(k_owner_scan, dim3(B.n + 1), dim3(1024), 0, s, scratch, nc, cap, B.n + 1, capacity, send_counts, info);
     hipLaunchKernelGGL(k_owner_scatter, dim3(nblocks), dim3(XB_THREADS), 0, s, seg, nc, B, (const uint32_t*)scratch, cap, capacity, send);
 }
 

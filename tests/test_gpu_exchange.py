@@ -161,6 +161,58 @@ def _rccl_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+def _rccl_world1_worker(rank, world, port, out_dir):
+    """Everything `bench.py --mode exchange` asks of RCCL, on ONE GPU with a world of one: the process group on the `nccl`
+    backend, the band agreement / maxima / time reduce on CUDA tensors, and the two equal-split all-to-alls on the context's
+    own stream with the LIBRARY's buffers (memory torch did not allocate) as send and receive tensors."""
+    import sys
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import scene as S2
+    import forma_amd
+    from forma_amd import sharding
+    from oracle import oracle as orc2
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    W, H = 512, 384
+    tiles_h = (H + 15) // 16
+    o = orc2.Oracle()
+    t = S2.random_mixed().tables(o)
+    S2.load(o, t)
+    want = o.render(W, H)
+    c = forma_amd.Context(0)
+    S2.load(c, t)
+    c.render(W, H)
+    edges = sharding.agree_on_bands(dist, sharding.row_histogram(c.segments(0), tiles_h), 1, device="cuda")
+    assert edges == [0, tiles_h]
+    c.rasterize_frame(W, H)
+    stream0 = c.segments(0)
+    mx = sharding.max_pair_count(dist, stream0, edges, 1, device="cuda")
+    assert sharding.max_over_ranks(dist, 1.5, device="cuda") == 1.5
+    x = sharding.ExchangeFrame(c, dist, 0, 1, edges, W, H, sharding.pair_capacity(mx))
+    c.rasterize_bucket_frame(W, H)
+    x.recv.zero_(); x.recv_counts.zero_()
+    with torch.cuda.stream(x.stream):                                  # what ExchangeFrame.frame does when world > 1
+        dist.all_to_all_single(x.recv_counts, x.send_counts)
+        dist.all_to_all_single(x.recv, x.send)
+    x.stream.synchronize()
+    n = int(x.recv_counts[0].item())
+    ty = (stream0 >> np.uint64(53)).astype(np.int64) - 1
+    kept = stream0[(ty >= 0) & (ty < tiles_h)]
+    assert n == len(kept) and int(x.recv_counts[1].item()) == 0
+    assert np.array_equal(x.recv[:n].cpu().numpy().view(np.uint64), kept)     # the bucket arrived, in rasterizer order
+    img = x.frame(clear=(1, 1, 1, 0), device_only=False, dst=np.zeros((H, W * 4), np.uint8))
+    assert np.array_equal(img, want)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_calls_on_library_buffers_with_a_world_of_one():
+    import torch.multiprocessing as mp
+    mp.spawn(_rccl_world1_worker, args=(1, _free_port(), ""), nprocs=1, join=True)
+
+
 def test_two_ranks_over_rccl():
     import torch
     if torch.cuda.device_count() < 2:
