@@ -71,11 +71,21 @@ def main():
         if rank == 0:
             print(f"WORLD_SIZE={world} does not match --gpus {args.gpus}", file=sys.stderr)
         args.gpus = world
+    # Rehearsal switches (never set by the driver): FORMA_BENCH_BACKEND=gloo runs the whole multi-process flow without RCCL
+    # (collectives on CPU tensors, the all-to-all staged through host memory), FORMA_BENCH_ONE_DEVICE=1 puts every rank on
+    # device 0 — together they let N ranks share the one GPU of a single-GPU box and exercise all the host logic of N > 1.
+    backend = os.environ.get("FORMA_BENCH_BACKEND", "nccl")
+    if os.environ.get("FORMA_BENCH_ONE_DEVICE"):
+        local = 0
+    cdev = "cuda" if backend == "nccl" else "cpu"                # where the small control tensors of the collectives live
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from forma_amd import api, scenes, sharding
 
@@ -110,19 +120,19 @@ def main():
         crop, row0, row1, xf = None, 0, tiles_h, None
         if mode == "bands":
             hist = sharding.row_histogram(ctx.segments(0), tiles_h)
-            edges = sharding.agree_on_bands(dist, hist, world, device="cuda") if dist is not None else sharding.band_edges(hist, 1)
+            edges = sharding.agree_on_bands(dist, hist, world, device=cdev) if dist is not None else sharding.band_edges(hist, 1)
             row0, row1 = edges[rank], edges[rank + 1]
             ctx.set_band(row0, row1)
             crop = sharding.band_crop(edges, rank, width, height)
         elif mode == "exchange":
             tab = renderer.host_tables
             hist = sharding.row_histogram(ctx.segments(0), tiles_h)
-            edges = sharding.agree_on_bands(dist, hist, world, device="cuda") if dist is not None else sharding.band_edges(hist, 1)
+            edges = sharding.agree_on_bands(dist, hist, world, device=cdev) if dist is not None else sharding.band_edges(hist, 1)
             row0, row1 = edges[rank], edges[rank + 1]
             cuts = sharding.line_shares(ctx.prepare_lines(width, height)["lengths"], world)
             ctx.set_geometry(*sharding.slice_geometry(tab["x"], tab["y"], tab["line_slot"], cuts[rank], cuts[rank + 1]))
             ctx.rasterize_frame(width, height)
-            cap = sharding.pair_capacity(sharding.max_pair_count(dist, ctx.segments(0), edges, world, device="cuda"))
+            cap = sharding.pair_capacity(sharding.max_pair_count(dist, ctx.segments(0), edges, world, device=cdev))
             xf = sharding.ExchangeFrame(ctx, dist, rank, world, edges, width, height, cap)
 
         def frame(c=ctx, timings=False):
@@ -169,7 +179,7 @@ def main():
                 for a in per:
                     for k, v in a.items():
                         acc[k] = acc.get(k, 0) + v
-            return sharding.max_over_ranks(dist, dt, device="cuda") if dist is not None else dt
+            return sharding.max_over_ranks(dist, dt, device=cdev) if dist is not None else dt
 
         for c in pool:
             for _ in range(max(1, args.warmup // len(pool))):
@@ -262,6 +272,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak" if mode in ("single", "frames") else "strong", "vs_baseline": None,
             "dtype": "u64 segments / f64+f32 rasterizer / f32 painter", "data": "synthetic",
+            **({"rehearsal_backend": backend} if backend != "nccl" else {}),
             "mpixel_segments_per_s": round(n_segments_full * fps / 1e6, 1),
             "frames_in_flight": in_flight,
             "fps_blocks": {"median": round(statistics.median(blocks), 1), "min": round(min(blocks), 1), "max": round(max(blocks), 1), "blocks": 5},
@@ -291,7 +302,7 @@ def main():
         """every rank reports whether ITS attempt succeeded; the attempt counts only if all did"""
         if dist is None:
             return ok
-        t = torch.tensor([1 if ok else 0], device="cuda", dtype=torch.int32)
+        t = torch.tensor([1 if ok else 0], device=cdev, dtype=torch.int32)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(int(t.item()))
 

@@ -146,10 +146,18 @@ class ExchangeFrame:
     def frame(self, channels=(0, 1, 2, 3), clear=(1, 1, 1, 1), dst=None, stride=None, timings=False, device_only=True):
         import torch
         t1 = self.ctx.rasterize_bucket_frame(self.width, self.height, timings=timings)
-        if self.world > 1:
+        if self.world > 1 and self.dist.get_backend() == "nccl":
             with torch.cuda.stream(self.stream):                       # collectives ordered after the bucket kernels, before the gather
                 self.dist.all_to_all_single(self.recv_counts, self.send_counts)
                 self.dist.all_to_all_single(self.recv, self.send)
+        elif self.world > 1:                                           # rehearsal without RCCL (gloo): staged through host memory
+            self.stream.synchronize()
+            for dst_t, src_t in ((self.recv_counts, self.send_counts), (self.recv, self.send)):
+                h_in, h_out = src_t.cpu(), torch.empty_like(src_t, device="cpu")
+                self.dist.all_to_all_single(h_out, h_in)
+                with torch.cuda.stream(self.stream):
+                    dst_t.copy_(h_out)
+            self.stream.synchronize()
         r = self.ctx.gather_sort_paint_frame(self.width, self.height, channels=channels, clear=clear, crop=self.crop, dst=dst,
                                              stride=stride, timings=timings, device_only=device_only)
         if not timings:
