@@ -1548,7 +1548,9 @@ extern "C" int forma_hip_debug_paint_prof(unsigned long long* out24, int reset) 
     for (int i = 0; i < 24; i++) { out24[i] = 0; for (int c = 0; c < 256; c++) out24[i] += h[c][i]; }
     return rc;
 }
+#define PP_STAMP_IN(i) PP_STAMP(i)
 #else
+#define PP_STAMP_IN(i) do { } while (0)
 #define PP_STAMP(i) do { } while (0)
 #define PP_COUNT(i, v) do { } while (0)
 #endif
@@ -1889,6 +1891,26 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
             const uint32_t ft = (sfl >> SF_FILL_SHIFT) & 3u;
             const uint32_t bm = (sfl >> SF_BLEND_SHIFT) & 15u;
             const uint4 col = b_col[t];
+            if (ft == FORMA_FILL_SOLID && bm == 0u && !apply_clip) {
+                // the common layer — solid colour, BlendMode::Over, not clipped — as straight-line code: the generic loop
+                // below dispatches on fill type and blend mode once per PIXEL (it is unrolled over the four pixels of a
+                // lane), ~4x the instructions.  Same operations in the same order, so the same bits.
+                const float fr = __uint_as_float(col.x), fg = __uint_as_float(col.y), fb = __uint_as_float(col.z), fa = __uint_as_float(col.w);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float cov = coverage_of(A[q], eo);
+                    const float src_a = fa * cov;                       // blend_at :406-447 with blend = Over (the source colour)
+                    const float ida = 1.0f - da[q], k1 = ida * src_a, isa = 1.0f - src_a, k2 = da[q] * src_a;
+                    const float nr = fmaf(dr[q], isa, fmaf(fr, k1, fr * k2));
+                    const float ng = fmaf(dg[q], isa, fmaf(fg, k1, fg * k2));
+                    const float nb2 = fmaf(db[q], isa, fmaf(fb, k1, fb * k2));
+                    const float na2 = fmaf(da[q], isa, src_a);
+                    const bool skip = cov == 0.0f;                      // :317-319
+                    dr[q] = skip ? dr[q] : nr; dg[q] = skip ? dg[q] : ng; db[q] = skip ? db[q] : nb2; da[q] = skip ? da[q] : na2;
+                }
+                PP_STAMP_IN(8);
+                continue;
+            }
             const uint32_t* w = (ft == FORMA_FILL_SOLID) ? nullptr : style_words + style_offsets[layer];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
