@@ -1590,7 +1590,9 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
     __shared__ uint32_t w_seg0[1][WB], w_nseg[1][WB], w_bflag[1][WB], w_blayer[1][WB];
 
     const int lane = threadIdx.x & 63, wv = 0;
-    if (info->plan_bad) return;                                         // mis-sorted stream (async frame): the host re-runs
+    // The guard word, the run count and the tile's three table entries are independent loads: issue all of them before
+    // the first is tested (as written before, `plan_bad` was a global round trip of its own in front of everything).
+    const uint32_t plan_bad = info->plan_bad;                           // mis-sorted stream (async frame): the host re-runs
     const uint32_t n_runs = dev_count(nc_runs);
     // one-wave workgroups (a wave's slot frees as soon as ITS tile is done).  XCD-aware mapping: workgroup b runs on
     // XCD b % 8; give each XCD a contiguous band of tiles so a tile row's records / spans stay in one L2
@@ -1617,6 +1619,7 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
     const uint32_t my_tile_key = ((ty + 1u) << 12) | (tx + 1u);
     const uint32_t j0 = tile_first_run[tile] - 1u;                      // 0 stored = no run -> FORMA_NONE
     const uint32_t sb = row_span_lo[ty], sc = row_span_cnt[ty];
+    if (plan_bad) return;
     uint64_t sk[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) { const uint32_t i = u * 64 + lane; sk[u] = i < sc ? span_key[sb + i] : 0ull; }
