@@ -508,7 +508,10 @@ __global__ __launch_bounds__(RAS_THREADS) void k_rasterize(LineSource S, DevCoun
         for (int i = 0; i < RAS_THREADS / 64; i++) { o |= red[0][i]; oh |= red[1][i]; a &= red[2][i]; ah &= red[3][i]; u |= red[4][i]; }
         // the masks saturate after a few workgroups: only touch the (single-address, serialising) atomics when this
         // workgroup adds information; the reads go through the caches: a stale one merely costs a redundant atomic (which
-        // drops the line from this XCD's L2, so the next read is fresh)
+        // drops the line from this XCD's L2, so the next read is fresh).  Measured and rejected: reading the five words when
+        // the workgroup starts (so that the round trip is over by now) — every workgroup of the grid's first wave then sees
+        // empty masks and all of them queue on the same words: 96 -> 220 us; reducing before the stores instead of after
+        // them — the stores' drain is what staggers the workgroups' arrival here: 103 -> 120...190 us
         if (o & ~lb_ld32_cached(&info->key_or)) atomicOr(&info->key_or, o);
         if (oh & ~lb_ld32_cached(&info->key_or_hi)) atomicOr(&info->key_or_hi, oh);
         if (~a & lb_ld32_cached(&info->key_and)) atomicAnd(&info->key_and, a);
