@@ -4,6 +4,20 @@
 // writes `mul_add`.  All kernels are HBM/L2-bound integer + f32/f64 scalar work: no MFMA.
 #include "common.h"
 #include "lookback.h"
+#ifdef RAS_PROF
+// -DRAS_PROF (tools only): shader-clock stamps at the phase boundaries of k_rasterize (thread 0 of every workgroup)
+__device__ unsigned long long g_ras_prof[64][8];
+#define RP_STAMP(i) do { const unsigned long long _t = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_ras_prof[blockIdx.x & 63][i], _t - rp_t); rp_t = __builtin_readcyclecounter(); } while (0)
+extern "C" int forma_hip_debug_ras_prof(unsigned long long* out8, int reset) {
+    static unsigned long long h[64][8];
+    if (reset) { for (int c = 0; c < 64; c++) for (int i = 0; i < 8; i++) h[c][i] = 0; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_ras_prof), h, sizeof h); }
+    int rc = (int)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ras_prof), sizeof h);
+    for (int i = 0; i < 8; i++) { out8[i] = 0; for (int c = 0; c < 64; c++) out8[i] += h[c][i]; }
+    return rc;
+}
+#else
+#define RP_STAMP(i) do { } while (0)
+#endif
 
 #define WAVE 64
 
@@ -421,6 +435,10 @@ __global__ __launch_bounds__(RAS_THREADS) void k_rasterize(LineSource S, DevCoun
     const uint32_t k0 = blockIdx.x * RAS_TILE;
     if (k0 >= n_segments) return;                                       // the grid was sized for the bound
     const uint32_t k1 = min(k0 + RAS_TILE, n_segments);                   // exclusive
+#ifdef RAS_PROF
+    unsigned long long rp_t = __builtin_readcyclecounter();
+    if (tid == 0) atomicAdd(&g_ras_prof[blockIdx.x & 63][7], 1ull);
+#endif
     const uint32_t lo = block_first[blockIdx.x];
     const uint32_t hi = blockIdx.x + 1 < nblocks ? block_first[blockIdx.x + 1] : n_compact - 1;   // inclusive
     uint32_t k_or = 0, k_or_hi = 0, k_and = 0xFFFFFFFFu, k_and_hi = 0xFFFFFFFFu, unsorted = 0;
@@ -451,6 +469,7 @@ __global__ __launch_bounds__(RAS_THREADS) void k_rasterize(LineSource S, DevCoun
         }
         if (tid == 0) w_start[cnt] = (c0 + cnt < n_compact) ? cl_start[c0 + cnt] : n_segments;
         __syncthreads();
+        RP_STAMP(0);                                                    // lines staged (load chain + f64 constants + barrier)
         const uint32_t ka = max(k0, w_start[0]), kb = min(k1, w_start[cnt]);   // this chunk's share of the tile
         // this thread's 8 consecutive segments that fall into the chunk: ONE binary search, then walk the lines
         const uint32_t t_lo = max(kt, ka), t_hi = min(kt + RAS_PER_THREAD, kb);
@@ -460,6 +479,7 @@ __global__ __launch_bounds__(RAS_THREADS) void k_rasterize(LineSource S, DevCoun
                 const uint32_t mid = (a + b) >> 1;
                 if (w_start[mid] <= t_lo) a = mid; else b = mid;
             }
+            RP_STAMP(1);                                                // binary search
             uint32_t l_start = w_start[a], l_next = w_start[a + 1], l_order = w_order[a];
             float l_x0 = w_x0[a], l_y0 = w_y0[a], l_dx = w_dx[a], l_dy = w_dy[a], l_a = w_a[a], l_b = w_b[a], l_c = w_c[a], l_d = w_d[a];
             double l_aab = w_aab[a], l_bab = w_bab[a], l_cdab = w_cdab[a];
@@ -485,6 +505,7 @@ __global__ __launch_bounds__(RAS_THREADS) void k_rasterize(LineSource S, DevCoun
             }
         }
     }
+    RP_STAMP(2);                                                        // the 8 pixel segments of the lane
     // 64 contiguous bytes per thread: 16-byte stores (the tile base is a multiple of 2048 segments)
 #pragma unroll
     for (int q = 0; q < RAS_PER_THREAD; q += 2) {
@@ -518,6 +539,7 @@ __global__ __launch_bounds__(RAS_THREADS) void k_rasterize(LineSource S, DevCoun
         if (~ah & lb_ld32_cached(&info->key_and_hi)) atomicAnd(&info->key_and_hi, ah);
         if (u && !lb_ld32_cached(&info->layer_unsorted)) atomicOr(&info->layer_unsorted, 1u);
     }
+    RP_STAMP(3);                                                        // stores + mask reduction
 }
 
 void launch_rasterize(hipStream_t s, const LineSource& src, DevCount n_compact, DevCount n_segments,
