@@ -52,6 +52,7 @@ struct forma_hip_ctx {
     // lines
     DevBuf l_order, l_x0, l_y0, l_dx, l_dy, l_a, l_b, l_c, l_d, l_len, scan_tmp;   // parity entry points only
     DevBuf cl_idx, cl_start, block_first, prep_scratch;                              // frame path: compacted line table
+    DevBuf ras_masks;                       // k_rasterize: key masks per workgroup (8 words), combined by k_reduce_masks
     size_t n_lines = 0, n_compact = 0;
     // segments
     DevBuf seg_u, seg_a, seg_b, sort_counters;
@@ -218,10 +219,11 @@ int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, boo
         nc_cmp = DevCount{nullptr, (uint32_t)ctx->n_compact};
     }
     HIPCHECK(ctx->seg_u.ensure(((size_t)nc_seg.bound + SEG_PAD) * 8));
+    HIPCHECK(ctx->ras_masks.ensure(((size_t)nc_seg.bound / RAS_TILE + 2) * 32));
     stage_begin(ctx, ST_RASTER, timing);
     launch_rasterize(ctx->stream, S, nc_cmp, nc_seg, ctx->cl_idx.as<uint32_t>(), ctx->cl_start.as<uint32_t>(),
                      ctx->block_first.as<uint32_t>(), ctx->seg_u.as<uint64_t>(), dinfo, (int)ctx->band_row0,
-                     (int)ctx->band_row1);
+                     (int)ctx->band_row1, ctx->ras_masks.as<uint32_t>());
     stage_end(ctx, ST_RASTER, timing);
     HIPCHECK(hipGetLastError());
     ctx->speculated = (speculate || bound_n) && ctx->pred_valid;
@@ -793,9 +795,10 @@ int forma_hip_rasterize(forma_hip_ctx* ctx, size_t n_lines, const uint32_t* orde
     if ((rc = run_line_table(ctx, S, n_lines, false))) return rc;
     if (ctx->n_seg != N) return fail(ctx, FORMA_E_INTERNAL, "prefix sums disagree");
     HIPCHECK(ctx->seg_u.ensure((N + SEG_PAD) * 8));
+    HIPCHECK(ctx->ras_masks.ensure((N / RAS_TILE + 2) * 32));
     launch_rasterize(ctx->stream, S, DevCount{nullptr, (uint32_t)ctx->n_compact}, DevCount{nullptr, (uint32_t)N}, ctx->cl_idx.as<uint32_t>(),
                      ctx->cl_start.as<uint32_t>(), ctx->block_first.as<uint32_t>(), ctx->seg_u.as<uint64_t>(),
-                     ctx->info.as<FrameInfo>(), 0, 0);
+                     ctx->info.as<FrameInfo>(), 0, 0, ctx->ras_masks.as<uint32_t>());
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(out_segments, ctx->seg_u.p, N * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHECK(hipStreamSynchronize(ctx->stream));

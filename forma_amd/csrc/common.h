@@ -123,7 +123,7 @@ void launch_block_first(hipStream_t s, const uint32_t* cl_start, uint32_t n_comp
                         uint32_t* block_first);
 void launch_rasterize(hipStream_t s, const LineSource& src, DevCount n_compact, DevCount n_segments,
                       const uint32_t* cl_idx, const uint32_t* cl_start, const uint32_t* block_first, uint64_t* out,
-                      FrameInfo* info, int band_row0, int band_row1);
+                      FrameInfo* info, int band_row0, int band_row1, uint32_t* wg_masks /* 8 words per RAS_TILE block */);
 void launch_flatten(hipStream_t s, const forma_flatten_tables_t* dev_tables, float* out_x, float* out_y);
 
 // sort.hip — stable LSB radix sort of u64 (chained-scan "onesweep" passes over the live key bits).

@@ -422,7 +422,7 @@ __global__ __launch_bounds__(RAS_THREADS) void k_rasterize(LineSource S, DevCoun
                                                            const uint32_t* __restrict__ cl_start,
                                                            const uint32_t* __restrict__ block_first,
                                                            uint64_t* __restrict__ out, FrameInfo* __restrict__ info,
-                                                           int band_row0, int band_row1) {
+                                                           int band_row0, int band_row1, uint32_t* __restrict__ wg_masks) {
     __shared__ uint32_t w_start[RAS_WIN + 1];
     __shared__ uint32_t w_order[RAS_WIN];
     __shared__ float w_x0[RAS_WIN], w_y0[RAS_WIN], w_dx[RAS_WIN], w_dy[RAS_WIN];
@@ -527,28 +527,48 @@ __global__ __launch_bounds__(RAS_THREADS) void k_rasterize(LineSource S, DevCoun
     if (tid == 0) {
         uint32_t o = 0, oh = 0, a = 0xFFFFFFFFu, ah = 0xFFFFFFFFu, u = 0;
         for (int i = 0; i < RAS_THREADS / 64; i++) { o |= red[0][i]; oh |= red[1][i]; a &= red[2][i]; ah &= red[3][i]; u |= red[4][i]; }
-        // the masks saturate after a few workgroups: only touch the (single-address, serialising) atomics when this
-        // workgroup adds information; the reads go through the caches: a stale one merely costs a redundant atomic (which
-        // drops the line from this XCD's L2, so the next read is fresh).  Measured and rejected: reading the five words when
-        // the workgroup starts (so that the round trip is over by now) — every workgroup of the grid's first wave then sees
-        // empty masks and all of them queue on the same words: 96 -> 220 us; reducing before the stores instead of after
-        // them — the stores' drain is what staggers the workgroups' arrival here: 103 -> 120...190 us
-        if (o & ~lb_ld32_cached(&info->key_or)) atomicOr(&info->key_or, o);
-        if (oh & ~lb_ld32_cached(&info->key_or_hi)) atomicOr(&info->key_or_hi, oh);
-        if (~a & lb_ld32_cached(&info->key_and)) atomicAnd(&info->key_and, a);
-        if (~ah & lb_ld32_cached(&info->key_and_hi)) atomicAnd(&info->key_and_hi, ah);
-        if (u && !lb_ld32_cached(&info->layer_unsorted)) atomicOr(&info->layer_unsorted, 1u);
+        // one record per workgroup, combined by k_reduce_masks: five plain stores.  (Until round 2 every workgroup read the
+        // frame's masks through the caches and issued atomics when it added information: thread 0 of each of the 6 700
+        // workgroups then finished thousands of clocks after its workgroup's stores, holding the workgroup's LDS and
+        // registers; reading the words earlier, or reducing before the stores, turned it into a same-address storm.)
+        uint32_t* m = wg_masks + (size_t)blockIdx.x * 8;
+        m[0] = o; m[1] = oh; m[2] = a; m[3] = ah; m[4] = u;
     }
     RP_STAMP(3);                                                        // stores + mask reduction
 }
 
+// the per-workgroup key masks of k_rasterize -> info->{key_or, key_or_hi, key_and, key_and_hi, layer_unsorted}
+__global__ __launch_bounds__(1024) void k_reduce_masks(const uint32_t* __restrict__ wg_masks, DevCount nc_segments,
+                                                       FrameInfo* __restrict__ info) {
+    __shared__ uint32_t red[5][16];
+    const uint32_t nb = (dev_count(nc_segments) + RAS_TILE - 1) / RAS_TILE;
+    uint32_t o = 0, oh = 0, a = 0xFFFFFFFFu, ah = 0xFFFFFFFFu, u = 0;
+    for (uint32_t b = threadIdx.x; b < nb; b += 1024) {
+        const uint4 m = *reinterpret_cast<const uint4*>(wg_masks + (size_t)b * 8);
+        o |= m.x; oh |= m.y; a &= m.z; ah &= m.w; u |= wg_masks[(size_t)b * 8 + 4];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        o |= __shfl_xor(o, d, 64); oh |= __shfl_xor(oh, d, 64); a &= __shfl_xor(a, d, 64); ah &= __shfl_xor(ah, d, 64);
+        u |= __shfl_xor(u, d, 64);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = o; red[1][w] = oh; red[2][w] = a; red[3][w] = ah; red[4][w] = u; }
+    __syncthreads();
+    if (threadIdx.x == 0 && nb) {
+        for (int i = 1; i < 16; i++) { o |= red[0][i]; oh |= red[1][i]; a &= red[2][i]; ah &= red[3][i]; u |= red[4][i]; }
+        info->key_or = o; info->key_or_hi = oh; info->key_and = a; info->key_and_hi = ah; info->layer_unsorted = u;
+    }
+}
+
 void launch_rasterize(hipStream_t s, const LineSource& src, DevCount n_compact, DevCount n_segments,
                       const uint32_t* cl_idx, const uint32_t* cl_start, const uint32_t* block_first, uint64_t* out,
-                      FrameInfo* info, int band_row0, int band_row1) {
+                      FrameInfo* info, int band_row0, int band_row1, uint32_t* wg_masks) {
     if (n_segments.bound == 0 || n_compact.bound == 0) return;
     uint32_t blocks = (n_segments.bound + RAS_TILE - 1) / RAS_TILE;
     hipLaunchKernelGGL(k_rasterize, dim3(blocks), dim3(RAS_THREADS), 0, s, src, n_compact, n_segments, cl_idx, cl_start,
-                       block_first, out, info, band_row0, band_row1);
+                       block_first, out, info, band_row0, band_row1, wg_masks);
+    hipLaunchKernelGGL(k_reduce_masks, dim3(1), dim3(1024), 0, s, (const uint32_t*)wg_masks, n_segments, info);
 }
 
 // ------------------------------------------------------------------------------------------------
