@@ -430,7 +430,10 @@ __global__ __launch_bounds__(RAS_THREADS) void k_rasterize(LineSource S, DevCoun
     __shared__ double w_aab[RAS_WIN], w_bab[RAS_WIN], w_cdab[RAS_WIN];
     __shared__ uint32_t red[5][RAS_THREADS / 64];
     const int tid = threadIdx.x;
+    // the two counts and the workgroup's two table entries are independent loads: all four in flight before the first test
+    // (the table is provisioned for the grid, so the entries exist even for a workgroup past the end)
     const uint32_t n_segments = dev_count(nc_segments), n_compact = dev_count(nc_compact);
+    const uint32_t bf_lo = block_first[blockIdx.x], bf_hi = block_first[blockIdx.x + 1];
     const uint32_t nblocks = (n_segments + RAS_TILE - 1) / RAS_TILE;
     const uint32_t k0 = blockIdx.x * RAS_TILE;
     if (k0 >= n_segments) return;                                       // the grid was sized for the bound
@@ -439,8 +442,8 @@ __global__ __launch_bounds__(RAS_THREADS) void k_rasterize(LineSource S, DevCoun
     unsigned long long rp_t = __builtin_readcyclecounter();
     if (tid == 0) atomicAdd(&g_ras_prof[blockIdx.x & 63][7], 1ull);
 #endif
-    const uint32_t lo = block_first[blockIdx.x];
-    const uint32_t hi = blockIdx.x + 1 < nblocks ? block_first[blockIdx.x + 1] : n_compact - 1;   // inclusive
+    const uint32_t lo = bf_lo;
+    const uint32_t hi = blockIdx.x + 1 < nblocks ? bf_hi : n_compact - 1;   // inclusive
     uint32_t k_or = 0, k_or_hi = 0, k_and = 0xFFFFFFFFu, k_and_hi = 0xFFFFFFFFu, unsorted = 0;
     const uint32_t kt = k0 + tid * RAS_PER_THREAD;                      // this thread's first segment
     uint64_t vout[RAS_PER_THREAD];
