@@ -53,6 +53,7 @@ struct forma_hip_ctx {
     DevBuf l_order, l_x0, l_y0, l_dx, l_dy, l_a, l_b, l_c, l_d, l_len, scan_tmp;   // parity entry points only
     DevBuf cl_idx, cl_start, block_first, prep_scratch;                              // frame path: compacted line table
     DevBuf ras_masks;                       // k_rasterize: key masks per workgroup (8 words), combined by k_reduce_masks
+    PendingMasks pending_masks{nullptr, 0u}; // ... or, on read-back-free frames, by k_runs_count
     size_t n_lines = 0, n_compact = 0;
     // segments
     DevBuf seg_u, seg_a, seg_b, sort_counters;
@@ -99,7 +100,7 @@ struct forma_hip_ctx {
     OwnerBands xbands{};
     uint32_t xcap = 0;
     bool xplanned = false;
-    DevBuf xsend, xrecv, xsend_counts, xrecv_counts, xscratch;
+    DevBuf xsend, xrecv, xsend_counts, xrecv_counts, xscratch, xmask;
     bool xpred_valid = false;               // the local rasterized count of the previous exchange frame is known
     uint32_t xpred_N = 0;
     // timing
@@ -223,7 +224,9 @@ int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, boo
     stage_begin(ctx, ST_RASTER, timing);
     launch_rasterize(ctx->stream, S, nc_cmp, nc_seg, ctx->cl_idx.as<uint32_t>(), ctx->cl_start.as<uint32_t>(),
                      ctx->block_first.as<uint32_t>(), ctx->seg_u.as<uint64_t>(), dinfo, (int)ctx->band_row0,
-                     (int)ctx->band_row1, ctx->ras_masks.as<uint32_t>());
+                     (int)ctx->band_row1, ctx->ras_masks.as<uint32_t>(), /*reduce_now=*/bound_n == 0);
+    // read-back-free frame: the masks stay per-workgroup records until k_runs_count combines them (nothing reads them earlier)
+    ctx->pending_masks = bound_n ? PendingMasks{ctx->ras_masks.as<uint32_t>(), 0u} : PendingMasks{nullptr, 0u};
     stage_end(ctx, ST_RASTER, timing);
     HIPCHECK(hipGetLastError());
     ctx->speculated = (speculate || bound_n) && ctx->pred_valid;
@@ -333,7 +336,8 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     launch_runs(ctx->stream, ctx->sorted, nc, tiles_w, tiles_h, ctx->records.as<TileRecord>(), (uint32_t)cap,
                 ctx->rk_u.as<uint64_t>(), tile_first_run, ctx->blk_edge.as<BlkEdge>(), row_count,
                 ctx->runs_scratch.as<uint32_t>(), dinfo, /*verify_plan=*/bound_j != 0 && ctx->speculated, ctx->live44,
-                ctx->layer_sorted, ctx->legacy_runs);
+                ctx->layer_sorted, ctx->legacy_runs, ctx->pending_masks);
+    ctx->pending_masks = PendingMasks{nullptr, 0u};
     HIPCHECK(hipGetLastError());
     DevCount jc;
     // the runs of a tile row are ordered by (layer, tile_x) inside k_carry_rows when they fit its LDS; else by a global sort
@@ -798,7 +802,7 @@ int forma_hip_rasterize(forma_hip_ctx* ctx, size_t n_lines, const uint32_t* orde
     HIPCHECK(ctx->ras_masks.ensure((N / RAS_TILE + 2) * 32));
     launch_rasterize(ctx->stream, S, DevCount{nullptr, (uint32_t)ctx->n_compact}, DevCount{nullptr, (uint32_t)N}, ctx->cl_idx.as<uint32_t>(),
                      ctx->cl_start.as<uint32_t>(), ctx->block_first.as<uint32_t>(), ctx->seg_u.as<uint64_t>(),
-                     ctx->info.as<FrameInfo>(), 0, 0, ctx->ras_masks.as<uint32_t>());
+                     ctx->info.as<FrameInfo>(), 0, 0, ctx->ras_masks.as<uint32_t>(), true);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(out_segments, ctx->seg_u.p, N * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHECK(hipStreamSynchronize(ctx->stream));
@@ -1113,18 +1117,22 @@ int forma_hip_gather_sort_paint_frame(forma_hip_ctx* ctx, uint8_t* dst, uint32_t
     FrameInfo* dinfo = ctx->info.as<FrameInfo>();
     PaintArgs a{width, height, channels, clear_color, crop_or_null};
     HIPCHECK(ctx->seg_u.ensure(((size_t)bound + SEG_PAD) * 8));
-    auto gather = [&]() -> int {
+    HIPCHECK(ctx->xmask.ensure(gather_mask_words(G, ctx->xcap) * 4));
+    auto gather = [&](bool read_back_free) -> int {
         int r = reset_info(ctx);
         if (r) return r;
         stage_begin(ctx, ST_XCHG, timing);
-        launch_gather_chunks(ctx->stream, recv, rcnt, G, ctx->xcap, ctx->seg_u.as<uint64_t>(), dinfo);
+        launch_gather_chunks(ctx->stream, recv, rcnt, G, ctx->xcap, ctx->seg_u.as<uint64_t>(), dinfo, ctx->xmask.as<uint32_t>(),
+                             /*reduce_now=*/!read_back_free);
+        ctx->pending_masks = read_back_free ? PendingMasks{ctx->xmask.as<uint32_t>(), (uint32_t)(gather_mask_words(G, ctx->xcap) / 8)}
+                                            : PendingMasks{nullptr, 0u};
         stage_end(ctx, ST_XCHG, timing);
         ctx->have_unsorted = true; ctx->n_lines = 0;
         return FORMA_OK;
     };
     if (ctx->pred_valid && ctx->pred_counts_valid && !ctx->no_async) {       // read-back-free, verified when the frame is done
         const uint32_t bJ = ctx->pred_J + ctx->pred_J / 16 + 4096;
-        if ((rc = gather())) return rc;
+        if ((rc = gather(true))) return rc;
         ctx->live44 = ctx->pred_live44; ctx->layer_sorted = ctx->pred_layer_sorted; ctx->speculated = true;
         if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), DevCount{&dinfo->n_segments, bound}, timing))) return rc;
         if ((rc = run_paint(ctx, DevCount{&dinfo->n_segments, bound}, a, timing, bJ))) return rc;
@@ -1143,7 +1151,7 @@ int forma_hip_gather_sort_paint_frame(forma_hip_ctx* ctx, uint8_t* dst, uint32_t
         clear_stage_flags(ctx);
     }
     for (int attempt = 0; attempt < 2; attempt++) {                            // synchronous: N, key masks and J are read back
-        if ((rc = gather())) return rc;
+        if ((rc = gather(false))) return rc;
         if ((rc = read_info(ctx))) return rc;
         if (ctx->h_info->exchange_overflow) return fail(ctx, FORMA_E_CAPACITY, "exchange: a bucket exceeds the pair capacity (re-plan)");
         ctx->n_seg = ctx->h_info->n_segments;

@@ -109,6 +109,10 @@ void launch_scan_small_u32(hipStream_t s, uint32_t* data, DevCount n, uint32_t p
 // (cl_idx = line index, cl_start = index of its first pixel segment) + block_first[b] = compacted line that owns
 // pixel segment b * RAS_TILE.  Totals land in info->n_segments / n_compact.
 #define RAS_TILE 2048u
+// Key masks of a stream as per-workgroup records (8 words: or, or_hi, and, and_hi, layer_unsorted, pad) that nobody has
+// combined yet: on read-back-free frames k_runs_count does it (rec == nullptr: info already holds them).
+// n_fixed == 0: one record per RAS_TILE block of the info->n_segments segments (k_rasterize); else exactly n_fixed (k_gather_chunks).
+struct PendingMasks { const uint32_t* rec; uint32_t n_fixed; };
 struct LineSource {               // either the uploaded geometry (sums == nullptr) or caller-supplied line parameters
     const float* x; const float* y; const uint32_t* line_slot; const forma_geom_t* geoms; uint32_t n_geoms;
     float width, height, band_lo, band_hi;
@@ -123,7 +127,8 @@ void launch_block_first(hipStream_t s, const uint32_t* cl_start, uint32_t n_comp
                         uint32_t* block_first);
 void launch_rasterize(hipStream_t s, const LineSource& src, DevCount n_compact, DevCount n_segments,
                       const uint32_t* cl_idx, const uint32_t* cl_start, const uint32_t* block_first, uint64_t* out,
-                      FrameInfo* info, int band_row0, int band_row1, uint32_t* wg_masks /* 8 words per RAS_TILE block */);
+                      FrameInfo* info, int band_row0, int band_row1, uint32_t* wg_masks /* 8 words per RAS_TILE block */,
+                      bool reduce_now /* false: the caller hands the records on as PendingMasks */);
 void launch_flatten(hipStream_t s, const forma_flatten_tables_t* dev_tables, float* out_x, float* out_y);
 
 // sort.hip — stable LSB radix sort of u64 (chained-scan "onesweep" passes over the live key bits).
@@ -150,8 +155,9 @@ size_t owner_scratch_words(size_t n);
 void launch_owner_bucket(hipStream_t s, const uint64_t* seg, DevCount n, const OwnerBands& B, uint32_t capacity,
                          uint32_t* scratch, uint64_t* send, uint32_t* send_counts, FrameInfo* info);
 // recv[s * capacity + ...] (recv_counts[2 s] segments from rank s) -> out, info->{n_segments, key masks, layer_unsorted}
+size_t gather_mask_words(uint32_t n_ranks, uint32_t capacity);
 void launch_gather_chunks(hipStream_t s, const uint64_t* recv, const uint32_t* recv_counts, uint32_t n_ranks, uint32_t capacity,
-                          uint64_t* out, FrameInfo* info);
+                          uint64_t* out, FrameInfo* info, uint32_t* mask_records /* gather_mask_words() */, bool reduce_now);
 
 // paint.hip
 struct BlkEdge {             // what a k_runs tile contributes to a run that started before it
@@ -166,7 +172,8 @@ size_t runs_blocks(size_t n);
 void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount n, uint32_t tiles_w, uint32_t tiles_h, TileRecord* records,
                  uint32_t rec_cap, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge,
                  uint32_t* row_tab, uint32_t* scratch, FrameInfo* info, bool verify_plan, uint64_t spec_live44,
-                 bool spec_layer_sorted, bool legacy /* workgroup-per-tile kernel with LDS bins instead of the wave kernel */);
+                 bool spec_layer_sorted, bool legacy /* workgroup-per-tile kernel with LDS bins instead of the wave kernel */,
+                 PendingMasks pm);
 uint32_t runs_edge_segments(bool legacy);   // segments per BlkEdge entry of the kernel launch_runs picks
 // style flags of a layer as the carry pre-pass and the painter pass them around (bits 21.. of a record's layer word)
 #define SF_FULL        0x001u     // spans only: Cover::is_full (painter/mod.rs:200-215)

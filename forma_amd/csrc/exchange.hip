@@ -167,7 +167,7 @@ __global__ __launch_bounds__(XB_THREADS) void k_owner_scatter(const uint64_t* __
 // blockIdx.y = chunk: every workgroup copies a contiguous piece of ONE chunk (coalesced 8-byte loads and stores).
 __global__ __launch_bounds__(256) void k_gather_chunks(const uint64_t* __restrict__ recv, const uint32_t* __restrict__ recv_counts,
                                                        uint32_t n_ranks, uint32_t capacity, uint64_t* __restrict__ out,
-                                                       FrameInfo* __restrict__ info) {
+                                                       FrameInfo* __restrict__ info, uint32_t* __restrict__ mask_records) {
     __shared__ uint32_t red[5][4];
     const uint32_t s = blockIdx.y;
     uint32_t start = 0, total = 0, over = 0, prev_chunk = 0xFFFFFFFFu, prev_cnt = 0;
@@ -215,15 +215,33 @@ __global__ __launch_bounds__(256) void k_gather_chunks(const uint64_t* __restric
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red[0][w] = k_or; red[1][w] = k_or_hi; red[2][w] = k_and; red[3][w] = k_and_hi; red[4][w] = unsorted; }
     __syncthreads();
-    if (threadIdx.x == 0 && blockIdx.x * 1024 < cnt) {
-        uint32_t o = 0, oh = 0, a = 0xFFFFFFFFu, ah = 0xFFFFFFFFu, u = 0;
+    if (threadIdx.x == 0) {                                             // one record per workgroup (neutral if it copied nothing),
+        uint32_t o = 0, oh = 0, a = 0xFFFFFFFFu, ah = 0xFFFFFFFFu, u = 0; // combined by k_reduce_gather_masks: see k_rasterize
         for (int q = 0; q < 4; q++) { o |= red[0][q]; oh |= red[1][q]; a &= red[2][q]; ah &= red[3][q]; u |= red[4][q]; }
-        // (few workgroups add information once the masks have saturated: see k_rasterize)
-        if (o & ~info->key_or) atomicOr(&info->key_or, o);
-        if (oh & ~info->key_or_hi) atomicOr(&info->key_or_hi, oh);
-        if (~a & info->key_and) atomicAnd(&info->key_and, a);
-        if (~ah & info->key_and_hi) atomicAnd(&info->key_and_hi, ah);
-        if (u) atomicOr(&info->layer_unsorted, 1u);
+        uint32_t* m = mask_records + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        m[0] = o; m[1] = oh; m[2] = a; m[3] = ah; m[4] = u;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_reduce_gather_masks(const uint32_t* __restrict__ rec, uint32_t n_records,
+                                                              FrameInfo* __restrict__ info) {
+    __shared__ uint32_t red[5][16];
+    uint32_t o = 0, oh = 0, a = 0xFFFFFFFFu, ah = 0xFFFFFFFFu, u = 0;
+    for (uint32_t b = threadIdx.x; b < n_records; b += 1024) {
+        const uint4 m = *reinterpret_cast<const uint4*>(rec + (size_t)b * 8);
+        o |= m.x; oh |= m.y; a &= m.z; ah &= m.w; u |= rec[(size_t)b * 8 + 4];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        o |= __shfl_xor(o, d, 64); oh |= __shfl_xor(oh, d, 64); a &= __shfl_xor(a, d, 64); ah &= __shfl_xor(ah, d, 64);
+        u |= __shfl_xor(u, d, 64);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = o; red[1][w] = oh; red[2][w] = a; red[3][w] = ah; red[4][w] = u; }
+    __syncthreads();
+    if (threadIdx.x == 0 && info->n_segments) {                         // (an empty band keeps the reset masks)
+        for (int i = 1; i < 16; i++) { o |= red[0][i]; oh |= red[1][i]; a &= red[2][i]; ah &= red[3][i]; u |= red[4][i]; }
+        info->key_or = o; info->key_or_hi = oh; info->key_and = a; info->key_and_hi = ah; info->layer_unsorted = u;
     }
 }
 
@@ -240,10 +258,18 @@ void launch_owner_bucket(hipStream_t s, const uint64_t* seg, DevCount nc, const 
     hipLaunchKernelGGL(k_owner_scatter, dim3(nblocks), dim3(XB_THREADS), 0, s, seg, nc, B, (const uint32_t*)scratch, cap, capacity, send);
 }
 
-void launch_gather_chunks(hipStream_t s, const uint64_t* recv, const uint32_t* recv_counts, uint32_t n_ranks, uint32_t capacity,
-                          uint64_t* out, FrameInfo* info) {
+size_t gather_mask_words(uint32_t n_ranks, uint32_t capacity) {
     uint32_t gx = (capacity + 1023) / 1024;
     if (gx > 2048) gx = 2048;
     if (gx == 0) gx = 1;
-    hipLaunchKernelGGL(k_gather_chunks, dim3(gx, n_ranks), dim3(256), 0, s, recv, recv_counts, n_ranks, capacity, out, info);
+    return (size_t)gx * n_ranks * 8;
+}
+
+void launch_gather_chunks(hipStream_t s, const uint64_t* recv, const uint32_t* recv_counts, uint32_t n_ranks, uint32_t capacity,
+                          uint64_t* out, FrameInfo* info, uint32_t* mask_records, bool reduce_now) {
+    uint32_t gx = (capacity + 1023) / 1024;
+    if (gx > 2048) gx = 2048;
+    if (gx == 0) gx = 1;
+    hipLaunchKernelGGL(k_gather_chunks, dim3(gx, n_ranks), dim3(256), 0, s, recv, recv_counts, n_ranks, capacity, out, info, mask_records);
+    if (reduce_now) hipLaunchKernelGGL(k_reduce_gather_masks, dim3(1), dim3(1024), 0, s, (const uint32_t*)mask_records, gx * n_ranks, info);
 }

@@ -546,9 +546,16 @@ __global__ __launch_bounds__(1024) void k_reduce_masks(const uint32_t* __restric
     __shared__ uint32_t red[5][16];
     const uint32_t nb = (dev_count(nc_segments) + RAS_TILE - 1) / RAS_TILE;
     uint32_t o = 0, oh = 0, a = 0xFFFFFFFFu, ah = 0xFFFFFFFFu, u = 0;
-    for (uint32_t b = threadIdx.x; b < nb; b += 1024) {
-        const uint4 m = *reinterpret_cast<const uint4*>(wg_masks + (size_t)b * 8);
-        o |= m.x; oh |= m.y; a &= m.z; ah &= m.w; u |= wg_masks[(size_t)b * 8 + 4];
+    for (uint32_t b0 = 0; b0 < nb; b0 += 8 * 1024) {                    // 8 records per thread in flight: one round trip for 8192 blocks
+        uint4 m[8]; uint32_t mu[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t b = b0 + k * 1024 + threadIdx.x;
+            m[k] = b < nb ? *reinterpret_cast<const uint4*>(wg_masks + (size_t)b * 8) : make_uint4(0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu);
+            mu[k] = b < nb ? wg_masks[(size_t)b * 8 + 4] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { o |= m[k].x; oh |= m[k].y; a &= m[k].z; ah &= m[k].w; u |= mu[k]; }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -566,12 +573,12 @@ __global__ __launch_bounds__(1024) void k_reduce_masks(const uint32_t* __restric
 
 void launch_rasterize(hipStream_t s, const LineSource& src, DevCount n_compact, DevCount n_segments,
                       const uint32_t* cl_idx, const uint32_t* cl_start, const uint32_t* block_first, uint64_t* out,
-                      FrameInfo* info, int band_row0, int band_row1, uint32_t* wg_masks) {
+                      FrameInfo* info, int band_row0, int band_row1, uint32_t* wg_masks, bool reduce_now) {
     if (n_segments.bound == 0 || n_compact.bound == 0) return;
     uint32_t blocks = (n_segments.bound + RAS_TILE - 1) / RAS_TILE;
     hipLaunchKernelGGL(k_rasterize, dim3(blocks), dim3(RAS_THREADS), 0, s, src, n_compact, n_segments, cl_idx, cl_start,
                        block_first, out, info, band_row0, band_row1, wg_masks);
-    hipLaunchKernelGGL(k_reduce_masks, dim3(1), dim3(1024), 0, s, (const uint32_t*)wg_masks, n_segments, info);
+    if (reduce_now) hipLaunchKernelGGL(k_reduce_masks, dim3(1), dim3(1024), 0, s, (const uint32_t*)wg_masks, n_segments, info);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -95,8 +95,10 @@ __global__ __launch_bounds__(RC_THREADS) void k_runs_count(const uint64_t* __res
                                                            uint32_t* __restrict__ chunk_counts /* per 512 segments */,
                                                            uint32_t* __restrict__ zero_base, uint32_t zero_words,
                                                            FrameInfo* __restrict__ info, uint64_t spec_live44,
-                                                           uint32_t spec_flags /* bit0 verify, bit1 layer_sorted */) {
+                                                           uint32_t spec_flags /* bit0 verify, bit1 layer_sorted */,
+                                                           PendingMasks pm) {
     __shared__ uint32_t s_c[RC_THREADS / 64];
+    __shared__ uint32_t s_red[5][RC_THREADS / 64];
     const uint32_t n = dev_count(nc);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // housekeeping that would otherwise be separate launches: zero this frame's tile tables (row counts, span tables,
@@ -106,11 +108,42 @@ __global__ __launch_bounds__(RC_THREADS) void k_runs_count(const uint64_t* __res
         const uint32_t z0 = blockIdx.x * per, z1 = min(zero_words, z0 + per);
         for (uint32_t i = z0 + tid; i < z1; i += RC_THREADS) zero_base[i] = 0;
         if (blockIdx.x == 0 && tid == 0 && nc.ptr && *nc.ptr > nc.bound) info->plan_bad = 1u;   // more segments than provisioned
-        if (blockIdx.x == 0 && tid == 0 && (spec_flags & 1u) && info->n_segments) {
-            const uint64_t k_or = (uint64_t)info->key_or | ((uint64_t)info->key_or_hi << 32);
-            const uint64_t k_and = (uint64_t)info->key_and | ((uint64_t)info->key_and_hi << 32);
-            const uint32_t sorted_now = info->layer_unsorted == 0 ? 2u : 0u;
-            if (((k_or ^ k_and) & 0xFFFFFFFFFFFull) != spec_live44 || sorted_now != (spec_flags & 2u)) info->plan_bad = 1u;
+        if (blockIdx.x == 0) {
+            // the key masks of the stream: on read-back-free frames the producer (k_rasterize / k_gather_chunks) left one
+            // record per workgroup and nobody needed them combined until now — this workgroup does it instead of a launch
+            uint32_t o = 0, oh = 0, a = 0xFFFFFFFFu, ah = 0xFFFFFFFFu, u = 0;
+            if (pm.rec) {
+                const uint32_t nrec = pm.n_fixed ? pm.n_fixed : (info->n_segments + RAS_TILE - 1) / RAS_TILE;
+                for (uint32_t b0 = 0; b0 < nrec; b0 += 8 * RC_THREADS) {
+                    uint4 m[8]; uint32_t mu[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const uint32_t b = b0 + k * RC_THREADS + tid;
+                        m[k] = b < nrec ? *reinterpret_cast<const uint4*>(pm.rec + (size_t)b * 8) : make_uint4(0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu);
+                        mu[k] = b < nrec ? pm.rec[(size_t)b * 8 + 4] : 0u;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { o |= m[k].x; oh |= m[k].y; a &= m[k].z; ah &= m[k].w; u |= mu[k]; }
+                }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    o |= __shfl_xor(o, d, 64); oh |= __shfl_xor(oh, d, 64); a &= __shfl_xor(a, d, 64); ah &= __shfl_xor(ah, d, 64);
+                    u |= __shfl_xor(u, d, 64);
+                }
+                if (lane == 0) { s_red[0][w] = o; s_red[1][w] = oh; s_red[2][w] = a; s_red[3][w] = ah; s_red[4][w] = u; }
+                __syncthreads();
+                if (tid == 0 && info->n_segments) {
+                    for (int i = 1; i < RC_THREADS / 64; i++) { o |= s_red[0][i]; oh |= s_red[1][i]; a &= s_red[2][i]; ah &= s_red[3][i]; u |= s_red[4][i]; }
+                    info->key_or = o; info->key_or_hi = oh; info->key_and = a; info->key_and_hi = ah; info->layer_unsorted = u;
+                }
+            } else if (tid == 0) {
+                o = info->key_or; oh = info->key_or_hi; a = info->key_and; ah = info->key_and_hi; u = info->layer_unsorted;
+            }
+            if (tid == 0 && (spec_flags & 1u) && info->n_segments) {
+                const uint64_t k_or = (uint64_t)o | ((uint64_t)oh << 32), k_and = (uint64_t)a | ((uint64_t)ah << 32);
+                const uint32_t sorted_now = u == 0 ? 2u : 0u;
+                if (((k_or ^ k_and) & 0xFFFFFFFFFFFull) != spec_live44 || sorted_now != (spec_flags & 2u)) info->plan_bad = 1u;
+            }
         }
     }
     // A pure streaming read, shaped like the copy kernels that reach 6 TB/s on this chip (tools/ubench_bw.hip): 256-lane
@@ -521,7 +554,8 @@ size_t runs_blocks(size_t n) { return (n + RW_CHUNK - 1) / RW_CHUNK + 4; }      
 
 void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t tiles_w, uint32_t tiles_h, TileRecord* records,
                  uint32_t rec_cap, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge, uint32_t* row_tab,
-                 uint32_t* scratch, FrameInfo* info, bool verify_plan, uint64_t spec_live44, bool spec_layer_sorted, bool legacy) {
+                 uint32_t* scratch, FrameInfo* info, bool verify_plan, uint64_t spec_live44, bool spec_layer_sorted, bool legacy,
+                 PendingMasks pm) {
     // per-frame tile tables: [row_count | row_span_lo | row_span_cnt | painter overflow counter | first-run table] are
     // contiguous (api.cpp lays them out so) and zeroed by k_runs_count; 0 in the first-run table = the tile has no run
     const uint32_t zero_words = (tiles_h + 1) * 3 + 1 + tiles_w * tiles_h;
@@ -535,7 +569,7 @@ void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t ti
     const uint32_t cgrid = std::min<uint32_t>((ntiles + 1) / 2, 4096u);
     uint32_t* chunk_counts = scratch + ntiles + 8;                      // 4 per tile (+ slack for the last wave's second half)
     hipLaunchKernelGGL(k_runs_count, dim3(cgrid), dim3(RC_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, scratch, chunk_counts, row_tab,
-                       zero_words, info, spec_live44, flags);
+                       zero_words, info, spec_live44, flags, pm);
     const int scanned = (ntiles > 16384 || getenv("FORMA_HIP_SCAN_COUNTS")) ? 1 : 0;
     if (scanned) launch_scan_small_u32(s, scratch, nc, RN_TILE, &info->n_runs);   // exclusive, in place; total -> n_runs
     if (legacy)
