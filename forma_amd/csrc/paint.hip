@@ -665,16 +665,21 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
     __shared__ uint32_t s_wh[LOCAL ? CR_WAVES * 256 : 1];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t ty = blockIdx.x;
-    if (info->plan_bad) return;                                         // mis-sorted stream (async frame): the host re-runs
-    if (nc_runs.ptr && *nc_runs.ptr > nc_runs.bound) {                  // more runs than provisioned: the frame is void, and
-        if (threadIdx.x == 0) info->plan_bad = 1u;                      // the painters (next launches) must not touch anything
-        return;
-    }
+    // the guard word, the two device-side counts and the row counts are independent loads: all of them are issued before
+    // the first is tested (one global round trip instead of four in front of a kernel whose 135 workgroups are all latency)
+    const uint32_t plan_bad = info->plan_bad;                           // mis-sorted stream (async frame): the host re-runs
+    const uint32_t runs_dev = nc_runs.ptr ? *nc_runs.ptr : nc_runs.bound;
     const uint32_t n_blk = (dev_count(nc_segments) + edge_segs - 1) / edge_segs;   // BlkEdge entries (one per edge_segs segments)
-    const uint32_t n_runs = dev_count(nc_runs);
     // first run of this row = sum of the run counts of the rows above
     uint32_t part = 0;
     for (uint32_t r = tid; r < ty; r += CR_THREADS) part += row_count[r];
+    const uint32_t cnt = row_count[ty];
+    if (plan_bad) return;
+    if (runs_dev > nc_runs.bound) {                                     // more runs than provisioned: the frame is void, and
+        if (threadIdx.x == 0) info->plan_bad = 1u;                      // the painters (next launches) must not touch anything
+        return;
+    }
+    const uint32_t n_runs = runs_dev < nc_runs.bound ? runs_dev : nc_runs.bound;    // = dev_count(nc_runs)
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) part += __shfl_xor(part, d, 64);
     if (lane == 0) s_red[w] = part;
@@ -683,7 +688,6 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
     uint32_t row_lo = 0;
 #pragma unroll
     for (int i = 0; i < CR_WAVES; i++) row_lo += s_red[i];
-    const uint32_t cnt = row_count[ty];
     if (tid == 0) row_span_lo[ty] = row_lo;
     const uint32_t* lkeys = s_ka;                        // LOCAL: the row's runs, ordered by (layer, tile_x)
     if (tid == 0 && cnt) atomicMax(&info->max_row_runs, cnt);
