@@ -235,15 +235,20 @@ __device__ __forceinline__ void mark_block_first(uint32_t* __restrict__ block_fi
 }
 
 // pass A: segment count of every line + per-tile (sum, non-empty count)
-__global__ __launch_bounds__(PC_THREADS) void k_line_len(LineSource S, uint32_t n_lines, uint32_t* __restrict__ lens,
+// A line costs a chain of dependent loads (slot -> geom entry; the points) behind data-dependent early exits, so the lines of
+// one thread are served one after the other: with 8 lines per thread (256-lane workgroups) the kernel took 8 such chains,
+// 19 us for 1.6 M lines on a chip that was three-quarters idle.  1024 lanes x 2 lines per tile of the same 2048 lines.
+#define PL_THREADS 1024
+#define PL_IPT     (PC_TILE / PL_THREADS)
+__global__ __launch_bounds__(PL_THREADS) void k_line_len(LineSource S, uint32_t n_lines, uint32_t* __restrict__ lens,
                                                          uint32_t* __restrict__ tile_sum, uint32_t* __restrict__ tile_cnt) {
-    __shared__ uint32_t s_wsum[PC_THREADS / 64], s_wcnt[PC_THREADS / 64];
+    __shared__ uint32_t s_wsum[PL_THREADS / 64], s_wcnt[PL_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t base = blockIdx.x * PC_TILE;
     uint32_t sum = 0, cnt = 0;
 #pragma unroll
-    for (int r = 0; r < PC_IPT; r++) {
-        const uint32_t i = base + r * PC_THREADS + tid;
+    for (int r = 0; r < PL_IPT; r++) {
+        const uint32_t i = base + r * PL_THREADS + tid;
         uint32_t len = 0;
         if (i < n_lines) {
             if (S.sums) len = S.sums[i] - (i ? S.sums[i - 1] : 0u);
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(PC_THREADS) void k_line_len(LineSource S, uint32_t 
     __syncthreads();
     if (tid == 0) {
         uint32_t ts = 0, tc = 0;
-        for (int i = 0; i < PC_THREADS / 64; i++) { ts += s_wsum[i]; tc += s_wcnt[i]; }
+        for (int i = 0; i < PL_THREADS / 64; i++) { ts += s_wsum[i]; tc += s_wcnt[i]; }
         tile_sum[blockIdx.x] = ts; tile_cnt[blockIdx.x] = tc;
     }
 }
@@ -309,8 +314,8 @@ __global__ __launch_bounds__(PC_THREADS) void k_line_compact(const uint32_t* __r
         if (lane >= d) { isum += ts; icnt += tc; }
     }
     if (lane == 63) { s_wsum[w] = isum; s_wcnt[w] = icnt; }
+    uint32_t bsum = tile_sum[blockIdx.x], bcnt = tile_cnt[blockIdx.x];   // (in flight across the barrier)
     __syncthreads();
-    uint32_t bsum = tile_sum[blockIdx.x], bcnt = tile_cnt[blockIdx.x];
 #pragma unroll
     for (int i = 0; i < PC_THREADS / 64; i++) if (i < w) { bsum += s_wsum[i]; bcnt += s_wcnt[i]; }
     uint32_t start = bsum + isum - sum, c = bcnt + icnt - cnt;
@@ -336,7 +341,7 @@ void launch_prepare_compact(hipStream_t s, const LineSource& src, uint32_t n_lin
     uint32_t* lens = scratch;
     uint32_t* tile_sum = scratch + n_lines;
     uint32_t* tile_cnt = tile_sum + ntiles + 1;
-    hipLaunchKernelGGL(k_line_len, dim3(ntiles), dim3(PC_THREADS), 0, s, src, n_lines, lens, tile_sum, tile_cnt);
+    hipLaunchKernelGGL(k_line_len, dim3(ntiles), dim3(PL_THREADS), 0, s, src, n_lines, lens, tile_sum, tile_cnt);
     hipLaunchKernelGGL(k_scan_line_tiles, dim3(1), dim3(1024), 0, s, tile_sum, tile_cnt, ntiles, info);
     hipLaunchKernelGGL(k_line_compact, dim3(ntiles), dim3(PC_THREADS), 0, s, (const uint32_t*)lens, n_lines,
                        (const uint32_t*)tile_sum, (const uint32_t*)tile_cnt, cl_idx, cl_start, block_first, bf_cap);
