@@ -597,10 +597,23 @@ uint32_t runs_edge_segments(bool legacy) { return legacy ? RN_TILE : RW_CHUNK; }
 #define CR_THREADS 1024
 #define CR_WAVES   (CR_THREADS / 64)
 #define CR_CAP     16384                // runs of one tile row that the in-LDS sort holds (2 x 64 KiB of 32-bit keys)
-#define CR_CHUNK   (CR_THREADS - 1)     // runs per piece of the row walk (the last lane looks one run ahead)
+#define CR_RPT     4                    // consecutive runs of the (layer, tile_x) order per lane in the row walk
+#define CR_PIECE   (CR_THREADS * CR_RPT)   // runs per piece
 
 // workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight across it
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+#ifdef CR_PROF
+// -DCR_PROF (tools only): shader-clock stamps at the phase boundaries of k_carry_rows (thread 0 of every row's workgroup)
+__device__ unsigned long long g_cr_prof[8];
+#define CRP_STAMP(i) do { const unsigned long long _t = __builtin_readcyclecounter(); if (threadIdx.x == 0) atomicAdd(&g_cr_prof[i], _t - crp_t); crp_t = __builtin_readcyclecounter(); } while (0)
+extern "C" int forma_hip_debug_cr_prof(unsigned long long* out8, int reset) {
+    if (reset) { unsigned long long z[8] = {0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cr_prof), z, sizeof z); }
+    return (int)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_cr_prof), 8 * 8);
+}
+#else
+#define CRP_STAMP(i) do { } while (0)
+#endif
 
 // what the carry scan gathers per run, requested one piece ahead
 struct CarryLoad {
@@ -658,13 +671,18 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
     __shared__ uint32_t s_red[CR_WAVES];
     __shared__ uint64_t s_wlo[CR_WAVES], s_whi[CR_WAVES];
     __shared__ uint32_t s_wflag[CR_WAVES], s_wspan[CR_WAVES];
-    __shared__ uint32_t s_group[CR_THREADS + 1], s_txb[CR_THREADS + 1];
+    __shared__ uint32_t s_group[256];                  // scratch of the in-LDS sort
+    __shared__ uint32_t s_nb[LOCAL ? 1 : 2 * (CR_PIECE + 1)];   // group / tile_x of a piece's runs (LOCAL: in the sort's idle buffer)
     __shared__ uint64_t s_clo, s_chi;                  // carry across chunks: inclusive acc of the last element
     __shared__ uint32_t s_cgroup, s_spans;
     __shared__ uint32_t s_ka[LOCAL ? CR_CAP : 1], s_kb[LOCAL ? CR_CAP : 1];
     __shared__ uint32_t s_wh[LOCAL ? CR_WAVES * 256 : 1];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t ty = blockIdx.x;
+#ifdef CR_PROF
+    unsigned long long crp_t = __builtin_readcyclecounter();
+    if (threadIdx.x == 0) atomicAdd(&g_cr_prof[7], 1ull);
+#endif
     // the guard word, the two device-side counts and the row counts are independent loads: all of them are issued before
     // the first is tested (one global round trip instead of four in front of a kernel whose 135 workgroups are all latency)
     const uint32_t plan_bad = info->plan_bad;                           // mis-sorted stream (async frame): the host re-runs
@@ -696,8 +714,11 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
             if (tid == 0) info->plan_bad = 1u;
             return;
         }
+        CRP_STAMP(0);                                                   // prologue: counts, row prefix
         for (uint32_t e = tid; e < cnt; e += CR_THREADS)
             s_ka[e] = (((uint32_t)(sorted_keys[row_lo + e] >> 32) & 0xFFFFu) << 16) | e;
+        __syncthreads();
+        CRP_STAMP(1);                                                   // the row's run keys into LDS
         uint32_t* src = s_ka;
         uint32_t* dst = s_kb;
         const uint32_t R = (cnt + CR_THREADS - 1) / CR_THREADS, CW = R * 64;       // key rows per wave, keys per wave
@@ -753,53 +774,81 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
             uint32_t* t = src; src = dst; dst = t;
         }
         lkeys = src;
+        CRP_STAMP(2);                                                   // in-LDS sort by layer
     }
-    // The row is walked in pieces of CR_CHUNK = 1023 runs; lane 1023 holds the run AFTER the piece (only its group and tile
-    // are looked at: the span of lane 1022 ends where that run begins).  Everything a piece gathers from HBM — record,
-    // cover sums, the layer's style summary — is requested one piece ahead; the barriers inside the loop order LDS only
-    // (lds_barrier: no vmcnt wait), so those requests stay in flight behind the scan of the current piece.
-    CarryLoad nx = carry_load<LOCAL>(0, tid, cnt, row_lo, n_runs, ty, lkeys, sorted_keys, records, layer_sf, n_orders);
-    for (uint32_t c0 = 0; c0 < cnt; c0 += CR_CHUNK) {
-        const CarryLoad cu = nx;
-        if (c0 + CR_CHUNK < cnt)
-            nx = carry_load<LOCAL>(c0 + CR_CHUNK, tid, cnt, row_lo, n_runs, ty, lkeys, sorted_keys, records, layer_sf, n_orders);
-        const bool active = cu.active && tid < CR_CHUNK;                 // lane 1023 only looks ahead
-        const uint32_t group = cu.active ? cu.group : 0xFFFFFFFEu, jrun = cu.jrun, layer = cu.layer;
-        uint32_t txb = 0, sfl = 0, unch = 0;
-        uint64_t own_lo = 0, own_hi = 0;
-        bool even_odd = false;
-        if (cu.active) txb = cu.tile & 0xFFFu;
-        if (active) {
-            TileRecord* r = &records[jrun];
-            own_lo = (uint64_t)cu.oc.x | ((uint64_t)cu.oc.y << 32); own_hi = (uint64_t)cu.oc.z | ((uint64_t)cu.oc.w << 32);
-            uint32_t sc = cu.sc;
-            if (sc & RUN_OPEN) {                         // complete a run that crosses k_runs tiles with their edges
-                sc &= ~RUN_OPEN;
-                for (uint32_t b = cu.seg_start / edge_segs + 1; b < n_blk; b++) {
-                    const BlkEdge e = blk_edge[b];
-                    own_lo = swar_add8(own_lo, (uint64_t)e.cov[0] | ((uint64_t)e.cov[1] << 32));
-                    own_hi = swar_add8(own_hi, (uint64_t)e.cov[2] | ((uint64_t)e.cov[3] << 32));
-                    sc += e.cnt;
-                    if (e.has_boundary) break;
-                }
-                r->seg_count = sc;
-            }
-            if (cu.lsf & LSF_VALID) {
-                // everything the painter's optimizer passes need to know about the layer's style, so that a tile can
-                // classify its whole layer list without touching the style table (SF_* bits ride in the entry keys)
-                sfl = cu.lsf & ~LSF_VALID;
-                even_odd = (sfl & SF_EVENODD) != 0;
-                r->layer = layer | (sfl << 21);
-                if (unchanged && unchanged[layer]) { unch = 1u; r->tile = cu.tile | 0x80000000u; }   // Layer::is_unchanged(cache_id)
-            } else atomicOr(&info->error, 1u);
+    // The row is walked in pieces of CR_PIECE = 1024 x CR_RPT runs, a lane owning CR_RPT CONSECUTIVE runs of the (layer,
+    // tile_x) order: all of a lane's gathers (record, cover sums, the layer's style summary) are in flight at once, the
+    // segmented scan runs serially over the lane's runs and once across lanes per piece, and the barriers order LDS only.
+    // (One run per lane — 1023 runs per piece, five pieces for an average 4K row — spent 43 % of the kernel in the per-piece
+    // cross-lane machinery and 27 % waiting for one round of gathers per piece: tools/cr_prof.py.)
+    // Group / tile_x of every run of the piece (+ the run after it) sit in LDS for the neighbour tests; LOCAL: in the sort's
+    // idle buffer.
+    uint32_t* a_group = LOCAL ? (lkeys == s_ka ? s_kb : s_ka) : s_nb;
+    uint32_t* a_txb = a_group + (CR_PIECE + 1);
+    for (uint32_t c0 = 0; c0 < cnt; c0 += CR_PIECE) {
+        CRP_STAMP(4);                                                   // (rest of the previous piece: span compaction + stores)
+        CarryLoad cl[CR_RPT];
+#pragma unroll
+        for (int k = 0; k < CR_RPT; k++)
+            cl[k] = carry_load<LOCAL>(c0, tid * CR_RPT + k, cnt, row_lo, n_runs, ty, lkeys, sorted_keys, records, layer_sf, n_orders);
+        if (tid == 0) {                                                 // the run after the piece: only its group and tile_x
+            const CarryLoad la = carry_load<LOCAL>(c0, CR_PIECE, cnt, row_lo, n_runs, ty, lkeys, sorted_keys, records, layer_sf, n_orders);
+            a_group[CR_PIECE] = la.active ? la.group : 0xFFFFFFFEu;
+            a_txb[CR_PIECE] = la.active ? (la.tile & 0xFFFu) : 0u;
         }
-        s_group[tid] = group; s_txb[tid] = txb;
+        uint32_t group[CR_RPT], txb[CR_RPT], meta[CR_RPT];              // meta: sfl (11 bits) | unch << 11 | even_odd << 12 | active << 13
+        uint64_t own_lo[CR_RPT], own_hi[CR_RPT];
+#pragma unroll
+        for (int k = 0; k < CR_RPT; k++) {
+            const CarryLoad& cu = cl[k];
+            const bool active = cu.active;
+            group[k] = active ? cu.group : 0xFFFFFFFEu;
+            txb[k] = active ? (cu.tile & 0xFFFu) : 0u;
+            own_lo[k] = 0; own_hi[k] = 0;
+            uint32_t sfl = 0, unch = 0;
+            bool even_odd = false;
+            if (active) {
+                TileRecord* r = &records[cu.jrun];
+                own_lo[k] = (uint64_t)cu.oc.x | ((uint64_t)cu.oc.y << 32); own_hi[k] = (uint64_t)cu.oc.z | ((uint64_t)cu.oc.w << 32);
+                uint32_t sc = cu.sc;
+                if (sc & RUN_OPEN) {                     // complete a run that crosses k_runs tiles with their edges
+                    sc &= ~RUN_OPEN;
+                    for (uint32_t bb = cu.seg_start / edge_segs + 1; bb < n_blk; bb++) {
+                        const BlkEdge e = blk_edge[bb];
+                        own_lo[k] = swar_add8(own_lo[k], (uint64_t)e.cov[0] | ((uint64_t)e.cov[1] << 32));
+                        own_hi[k] = swar_add8(own_hi[k], (uint64_t)e.cov[2] | ((uint64_t)e.cov[3] << 32));
+                        sc += e.cnt;
+                        if (e.has_boundary) break;
+                    }
+                    r->seg_count = sc;
+                }
+                if (cu.lsf & LSF_VALID) {
+                    // everything the painter's optimizer passes need to know about the layer's style, so that a tile can
+                    // classify its whole layer list without touching the style table (SF_* bits ride in the entry keys)
+                    sfl = cu.lsf & ~LSF_VALID;
+                    even_odd = (sfl & SF_EVENODD) != 0;
+                    r->layer = cu.layer | (sfl << 21);
+                    if (unchanged && unchanged[cu.layer]) { unch = 1u; r->tile = cu.tile | 0x80000000u; }   // Layer::is_unchanged(cache_id)
+                } else atomicOr(&info->error, 1u);
+            }
+            meta[k] = sfl | (unch << 11) | ((even_odd ? 1u : 0u) << 12) | ((active ? 1u : 0u) << 13);
+            a_group[tid * CR_RPT + k] = group[k]; a_txb[tid * CR_RPT + k] = txb[k];
+        }
         lds_barrier();
-        const uint32_t prev_group = tid ? s_group[tid - 1] : s_cgroup;
-        const bool head = active && group != prev_group;
-        // ---- segmented inclusive scan of (lo, hi) over the piece ----------------------------------------------
-        uint64_t lo = own_lo, hi = own_hi;
-        uint32_t f = head ? 1u : 0u;
+        CRP_STAMP(3);                                                   // piece: gathers landed (records, covers, style summary)
+        // ---- heads, and the lane's own segmented sums: (lo, hi) = sum since the lane's last head, f = the lane holds a head --
+        const uint32_t prev_group0 = tid ? a_group[tid * CR_RPT - 1] : s_cgroup;
+        uint32_t headm = 0;
+        uint64_t lo = 0, hi = 0;
+#pragma unroll
+        for (int k = 0; k < CR_RPT; k++) {
+            const bool active = (meta[k] >> 13) & 1u;
+            const bool head = active && group[k] != (k ? group[k - 1] : prev_group0);
+            if (head) { headm |= 1u << k; lo = own_lo[k]; hi = own_hi[k]; }
+            else { lo = swar_add8(lo, own_lo[k]); hi = swar_add8(hi, own_hi[k]); }
+        }
+        uint32_t f = headm ? 1u : 0u;
+        // ---- segmented inclusive scan of the lane sums over the piece --------------------------------------------------------
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint64_t tl = __shfl_up(lo, d, 64), th = __shfl_up(hi, d, 64);
@@ -825,8 +874,8 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
             if (in) { s_wlo[lane] = el; s_whi[lane] = eh; }
         }
         lds_barrier();
-        if (!f) { lo = swar_add8(lo, s_wlo[w]); hi = swar_add8(hi, s_whi[w]); }     // lo/hi = inclusive carry-out
-        // carry-in = inclusive value of the previous element of the group
+        if (!f) { lo = swar_add8(lo, s_wlo[w]); hi = swar_add8(hi, s_whi[w]); }     // lo/hi = inclusive value at the lane's last run
+        // what runs into the lane's first run = inclusive value at the previous lane's last run
         uint64_t pl = __shfl_up(lo, 1, 64), ph = __shfl_up(hi, 1, 64);
         lds_barrier();                                    // s_wlo reused below: every wave has read its carry-in
         if (lane == 63) { s_wlo[w] = lo; s_whi[w] = hi; }
@@ -834,37 +883,55 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
         if (lane == 0) {
             if (w == 0) { pl = s_clo; ph = s_chi; } else { pl = s_wlo[w - 1]; ph = s_whi[w - 1]; }
         }
-        if (head) { pl = 0; ph = 0; }
-        bool has_span = false;
-        uint32_t span_lo = 0, span_hi = 0;
-        if (active) {
-            TileRecord* r = &records[jrun];
-            r->cover[0] = (uint32_t)pl; r->cover[1] = (uint32_t)(pl >> 32);
-            r->cover[2] = (uint32_t)ph; r->cover[3] = (uint32_t)(ph >> 32);
-            const bool last = c0 + tid + 1 == cnt;
-            const bool same_next = !last && s_group[tid + 1] == group;
-            span_lo = txb;                                                  // tile_x + 1
-            span_hi = same_next ? s_txb[tid + 1] - 1u : tiles_w;            // exclusive; next tile_x = txb_next - 1
-            if (span_hi > tiles_w) span_hi = tiles_w;
-            has_span = !cover_is_empty(lo, hi, even_odd) && span_lo < span_hi;
+        // ---- second walk over the lane's runs, seeded: carry-in of every run, its carry-out, the span behind it --------------
+        uint64_t out_lo[CR_RPT], out_hi[CR_RPT];
+        uint32_t span_lo[CR_RPT], span_hi[CR_RPT], spanm = 0;
+#pragma unroll
+        for (int k = 0; k < CR_RPT; k++) {
+            const bool active = (meta[k] >> 13) & 1u;
+            if ((headm >> k) & 1u) { pl = 0; ph = 0; }
+            if (active) {
+                TileRecord* r = &records[cl[k].jrun];
+                *reinterpret_cast<uint4*>(&r->cover[0]) = make_uint4((uint32_t)pl, (uint32_t)(pl >> 32), (uint32_t)ph, (uint32_t)(ph >> 32));
+            }
+            pl = swar_add8(pl, own_lo[k]); ph = swar_add8(ph, own_hi[k]);            // inclusive = this run's carry-out
+            out_lo[k] = pl; out_hi[k] = ph;
+            span_lo[k] = txb[k]; span_hi[k] = 0;
+            if (active) {
+                const uint32_t e = c0 + tid * CR_RPT + k;
+                const bool last = e + 1 == cnt;
+                const uint32_t ngroup = (k + 1 < CR_RPT) ? group[(k + 1) % CR_RPT] : a_group[tid * CR_RPT + CR_RPT];
+                const uint32_t ntxb = (k + 1 < CR_RPT) ? txb[(k + 1) % CR_RPT] : a_txb[tid * CR_RPT + CR_RPT];
+                const bool same_next = !last && ngroup == group[k];
+                uint32_t sh = same_next ? ntxb - 1u : tiles_w;          // exclusive; next tile_x = txb_next - 1
+                if (sh > tiles_w) sh = tiles_w;
+                span_hi[k] = sh;                                         // span_lo = tile_x + 1
+                if (!cover_is_empty(pl, ph, (meta[k] >> 12) & 1u) && span_lo[k] < sh) spanm |= 1u << k;
+            }
         }
         // ordered compaction of the spans
-        const uint64_t bal = __ballot(has_span);
-        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-        if (lane == 0) s_wspan[w] = (uint32_t)__popcll(bal);
+        const uint32_t nsp = (uint32_t)__popc(spanm);
+        const uint32_t nsp_incl = wave_incl_scan_u32(nsp);
+        if (lane == 63) s_wspan[w] = nsp_incl;
         lds_barrier();
-        uint32_t sbase = s_spans, stot = 0;
+        uint32_t sbase = s_spans + nsp_incl - nsp, stot = 0;
 #pragma unroll
         for (int i = 0; i < CR_WAVES; i++) { const uint32_t t = s_wspan[i]; if (i < w) sbase += t; stot += t; }
-        if (has_span) {
-            const uint32_t si = row_lo + sbase + before;
-            const uint32_t c4[4] = {(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
-            const uint32_t full = cover_full(c4, even_odd) ? SF_FULL : 0u;
-            span_key[si] = ((uint64_t)(layer | ((sfl | full) << 21)) << 32) | ((uint64_t)unch << 31) | ((uint64_t)span_lo << 16) | span_hi;
-            span_cov[si] = make_uint4(c4[0], c4[1], c4[2], c4[3]);
+#pragma unroll
+        for (int k = 0; k < CR_RPT; k++) {
+            if ((spanm >> k) & 1u) {
+                const uint32_t si = row_lo + sbase;
+                sbase++;
+                const bool even_odd = (meta[k] >> 12) & 1u;
+                const uint32_t sfl = meta[k] & 0x7FFu, unch = (meta[k] >> 11) & 1u;
+                const uint32_t c4[4] = {(uint32_t)out_lo[k], (uint32_t)(out_lo[k] >> 32), (uint32_t)out_hi[k], (uint32_t)(out_hi[k] >> 32)};
+                const uint32_t full = cover_full(c4, even_odd) ? SF_FULL : 0u;
+                span_key[si] = ((uint64_t)(cl[k].layer | ((sfl | full) << 21)) << 32) | ((uint64_t)unch << 31) | ((uint64_t)span_lo[k] << 16) | span_hi[k];
+                span_cov[si] = make_uint4(c4[0], c4[1], c4[2], c4[3]);
+            }
         }
         lds_barrier();
-        if (tid == CR_CHUNK - 1) { s_clo = lo; s_chi = hi; s_cgroup = group; }     // only used when the piece is full
+        if (tid == CR_THREADS - 1) { s_clo = out_lo[CR_RPT - 1]; s_chi = out_hi[CR_RPT - 1]; s_cgroup = group[CR_RPT - 1]; }   // only used when the piece is full
         if (tid == 0) s_spans += stot;
         lds_barrier();
     }
