@@ -597,7 +597,9 @@ uint32_t runs_edge_segments(bool legacy) { return legacy ? RN_TILE : RW_CHUNK; }
 #define CR_THREADS 1024
 #define CR_WAVES   (CR_THREADS / 64)
 #define CR_CAP     16384                // runs of one tile row that the in-LDS sort holds (2 x 64 KiB of 32-bit keys)
-#define CR_RPT     4                    // consecutive runs of the (layer, tile_x) order per lane in the row walk
+#ifndef CR_RPT
+#define CR_RPT     4                    // consecutive runs of the (layer, tile_x) order per lane in the row walk (2, 6: same; 8: slower)
+#endif
 #define CR_PIECE   (CR_THREADS * CR_RPT)   // runs per piece
 
 // workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight across it
