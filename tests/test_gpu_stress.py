@@ -1,0 +1,73 @@
+"""Randomised whole-frame parity after the round-2 kernel changes: many seeds of the all-features scene generator at
+canvas shapes chosen to hit the paths a fixed scene list misses — tile rows with more runs than one piece of the carry
+walk (4096), rows beyond the in-LDS sort's capacity (16384: global run-key sort), one-tile-high and one-tile-wide
+canvases, canvases that are not multiples of the tile size.  Every case: first frame (synchronous) and second frame
+(read-back-free) both bit-equal to the oracle in the sorted stream and in the image."""
+import numpy as np
+import pytest
+
+import scene as S
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # seed, shapes, width, height
+    (11, 300, 512, 384), (12, 300, 333, 211), (13, 120, 16, 400), (14, 120, 700, 16), (15, 500, 1000, 1000),
+    (16, 800, 1920, 1080), (17, 60, 50, 50), (18, 1500, 2048, 96),
+    (19, 6000, 4096, 64),          # rows with > 4096 runs: several pieces of the carry walk
+    (20, 16000, 16384, 48),        # rows with > 16384 runs: the in-LDS sort does not fit, global run-key sort
+    (21, 2000, 3840, 2160), (22, 40, 4000, 30),
+]
+
+
+@pytest.mark.parametrize("seed,n,W,H", CASES)
+def test_random_scene_matches_oracle(seed, n, W, H):
+    import forma_amd
+    comp = S.random_mixed(n=n, width=W, height=H, seed=seed)
+    o = orc.Oracle()
+    t = comp.tables(o)
+    S.load(o, t)
+    clear = (0.1, 0.2, 0.3, 1.0) if seed % 2 else (1.0, 1.0, 1.0, 0.0)
+    want = o.render(W, H, clear=clear)
+    want_sorted = o.segments(1)
+    c = forma_amd.Context(0)
+    try:
+        S.load(c, t)
+        for frame in range(3):                                           # synchronous, then read-back-free twice
+            got = c.render(W, H, clear=clear)
+            assert np.array_equal(c.segments(1), want_sorted), (seed, frame)
+            assert np.array_equal(got, want), (seed, frame, int(np.abs(got.astype(int) - want.astype(int)).max()))
+    finally:
+        c.close()
+
+
+def test_rows_beyond_the_local_sort_take_the_global_sort_and_deep_tiles_are_reported():
+    """The two capacity edges of the carry pre-pass / painter on one wide, flat canvas: (a) case 20 above really has a tile
+    row with more than 16384 runs (so k_carry_rows<false> + the global run-key sort ran, not the in-LDS sort); (b) a tile
+    with more than 4096 layers fails the frame with FORMA_E_CAPACITY instead of painting something wrong.
+    (b) is reached the way real scenes reach it: a canvas height that is not a multiple of 16 — lines entirely below the
+    canvas are culled (segment.rs:41-52), so every layer that crosses the bottom edge keeps a non-zero cover on the invisible
+    pixel rows of the last tile row, and that cover is carried (non-empty, painter/mod.rs:187-198) across the whole row."""
+    import forma_amd
+    from forma_amd import FormaError
+    W, H = 16384, 48
+    o = orc.Oracle()
+    t = S.random_mixed(n=16000, width=W, height=H, seed=20).tables(o)
+    c = forma_amd.Context(0)
+    try:
+        S.load(c, t)
+        c.render(W, H)
+        srt = c.segments(1)
+        key = srt >> np.uint64(20)                                       # (tile_y, tile_x, layer)
+        heads = np.concatenate(([True], key[1:] != key[:-1]))
+        ty = (srt[heads] >> np.uint64(53)).astype(np.int64) - 1
+        per_row = np.bincount(ty[(ty >= 0) & (ty < 3)], minlength=3)
+        assert per_row.max() > 16384, per_row
+        t2 = S.random_mixed(n=16000, width=8192, height=40, seed=20).tables(o)
+        S.load(c, t2)
+        with pytest.raises(FormaError) as e:
+            c.render(8192, 40)
+        assert e.value.code == -4
+    finally:
+        c.close()
