@@ -729,6 +729,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
             const int sh = 16 + 8 * pass;
             for (int i = tid; i < CR_WAVES * 256; i += CR_THREADS) s_wh[i] = 0;
             __syncthreads();
+            CRP_STAMP(5);                                               // sort: counters cleared
             uint32_t kreg[CR_CAP / CR_THREADS], rreg[CR_CAP / CR_THREADS];
 #pragma unroll
             for (int r = 0; r < CR_CAP / CR_THREADS; r++) {
@@ -747,6 +748,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
                 }
             }
             __syncthreads();
+            CRP_STAMP(6);                                               // sort: keys ranked inside their wave
             if (tid < 256) {                              // digit tid: start of every wave's share of it
                 uint32_t tot = 0;
 #pragma unroll

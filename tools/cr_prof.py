@@ -18,8 +18,9 @@ for _ in range(N):
     r._ctx.render(W, H, clear=(1, 1, 1, 1), device_only=True)
 L.forma_hip_debug_cr_prof(buf, 0)
 rows = buf[7]
-names = ["0 prologue (counts, row prefix)", "1 run keys -> LDS", "2 in-LDS sort by layer", "3 pieces: waiting for the gathers", "4 pieces: scan, carry, spans, stores"]
-tot = sum(buf[i] for i in range(5))
+names = ["0 prologue (counts, row prefix)", "1 run keys -> LDS", "2 in-LDS sort: digit totals, bases, scatter", "3 pieces: waiting for the gathers", "4 pieces: scan, carry, spans, stores",
+         "5 in-LDS sort: clearing the counters", "6 in-LDS sort: ranking"]
+tot = sum(buf[i] for i in range(7))
 print(f"{wl}: {rows / N:.0f} rows per frame")
 for i, n in enumerate(names):
     print(f"  {n:44s} {buf[i] / rows:9.0f} clocks/row  {100 * buf[i] / tot:5.1f}%")
