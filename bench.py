@@ -215,7 +215,7 @@ def main():
         use_pmc = pmc is not None and workload == "paris-like-30k-4k" and world == 1
         roofline = {"bound": "hbm", "kernel": "k_onesweep<8>: one radix digit pass (LSB, 8-bit digits over live key bits, u64 keys, chained scan)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": pmc["kernels"]["k_onesweep<8>"]["hbm_bytes_per_launch"] if use_pmc else None,
+                    "traffic": next((v.get("hbm_bytes_per_launch") for k, v in pmc["kernels"].items() if k.startswith("k_onesweep<8")), None) if use_pmc else None,
                     "traffic_source": (PMC_FILE + " — separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this command on "
                                        "the committed build (gfx950: FETCH_SIZE x 2), NOT measured in this run") if use_pmc else None,
                     "algorithmic_bytes_per_launch": algo_bytes_per_pass, "avg_launch_us": round(pass_us, 2), "passes": passes,

@@ -101,6 +101,7 @@ struct forma_hip_ctx {
     uint32_t xcap = 0;
     bool xplanned = false;
     DevBuf xsend, xrecv, xsend_counts, xrecv_counts, xscratch, xmask;
+    bool xgather_always = false;              // FORMA_HIP_XGATHER=1: materialise the received stream before sorting it
     bool xpred_valid = false;               // the local rasterized count of the previous exchange frame is known
     uint32_t xpred_N = 0;
     // timing
@@ -239,7 +240,8 @@ int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, boo
 }
 
 // stage 3 on `src` (nc segments, device): result pointer in ctx->sorted
-int run_sort(forma_hip_ctx* ctx, const uint64_t* src, DevCount nc, bool timing, int digit_bits = 0) {
+int run_sort(forma_hip_ctx* ctx, const uint64_t* src, DevCount nc, bool timing, int digit_bits = 0,
+             const ChunkedSrc* chunked = nullptr) {
     ctx->n_passes = 0;
     const size_t n = nc.bound;
     if (n >= (1ull << 30)) return fail(ctx, FORMA_E_CAPACITY, "more than 2^30-1 pixel segments on one device");
@@ -254,7 +256,8 @@ int run_sort(forma_hip_ctx* ctx, const uint64_t* src, DevCount nc, bool timing, 
     stage_begin(ctx, ST_SORT, timing);
     ctx->sorted = (uint64_t*)launch_radix_sort(ctx->stream, src, ctx->seg_a.as<uint64_t>(), ctx->seg_b.as<uint64_t>(), nc, plan,
                                                digit_bits, ctx->sort_counters.as<uint32_t>(), &ctx->info.as<FrameInfo>()->error,
-                                               timing ? ctx->pev0 : nullptr, timing ? ctx->pev1 : nullptr);
+                                               timing ? ctx->pev0 : nullptr, timing ? ctx->pev1 : nullptr, chunked,
+                                               ctx->info.as<FrameInfo>());
     stage_end(ctx, ST_SORT, timing);
     HIPCHECK(hipGetLastError());
     return FORMA_OK;
@@ -549,6 +552,7 @@ int forma_hip_create(forma_hip_ctx** out, int device) {
     ctx->no_async = getenv("FORMA_HIP_SYNC") != nullptr;
     ctx->global_runsort = getenv("FORMA_HIP_GLOBAL_RUNSORT") != nullptr;
     ctx->legacy_runs = getenv("FORMA_HIP_LEGACY_RUNS") != nullptr;
+    ctx->xgather_always = getenv("FORMA_HIP_XGATHER") != nullptr;
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx; return FORMA_E_HIP;
     }
@@ -1117,7 +1121,7 @@ int forma_hip_gather_sort_paint_frame(forma_hip_ctx* ctx, uint8_t* dst, uint32_t
     FrameInfo* dinfo = ctx->info.as<FrameInfo>();
     PaintArgs a{width, height, channels, clear_color, crop_or_null};
     HIPCHECK(ctx->seg_u.ensure(((size_t)bound + SEG_PAD) * 8));
-    HIPCHECK(ctx->xmask.ensure(gather_mask_words(G, ctx->xcap) * 4));
+    HIPCHECK(ctx->xmask.ensure(std::max<size_t>(gather_mask_words(G, ctx->xcap), (size_t)2048 * 8) * 4));
     auto gather = [&](bool read_back_free) -> int {
         int r = reset_info(ctx);
         if (r) return r;
@@ -1132,9 +1136,22 @@ int forma_hip_gather_sort_paint_frame(forma_hip_ctx* ctx, uint8_t* dst, uint32_t
     };
     if (ctx->pred_valid && ctx->pred_counts_valid && !ctx->no_async) {       // read-back-free, verified when the frame is done
         const uint32_t bJ = ctx->pred_J + ctx->pred_J / 16 + 4096;
-        if ((rc = gather(true))) return rc;
         ctx->live44 = ctx->pred_live44; ctx->layer_sorted = ctx->pred_layer_sorted; ctx->speculated = true;
-        if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), DevCount{&dinfo->n_segments, bound}, timing))) return rc;
+        uint64_t live = ctx->live44;
+        if (ctx->layer_sorted) live &= ~0x1FFFFFull;
+        // The received buckets are sorted where they lie: the histogram kernel and the first digit pass read the rank-major
+        // concatenation through a logical -> physical index map, so nothing is gathered (k_gather_chunks: one more read and
+        // write of the whole band).  Needs at least one digit pass; FORMA_HIP_XGATHER=1 keeps the gather (A/B, tests).
+        if (!ctx->xgather_always && live != 0 && bound > 1) {
+            if ((rc = reset_info(ctx))) return rc;
+            ctx->have_unsorted = false; ctx->n_lines = 0;
+            const ChunkedSrc C{rcnt, G, ctx->xcap, ctx->xmask.as<uint32_t>()};
+            if ((rc = run_sort(ctx, recv, DevCount{&dinfo->n_segments, bound}, timing, 0, &C))) return rc;
+            ctx->pending_masks = PendingMasks{ctx->xmask.as<uint32_t>(), sort_hist_blocks(bound)};
+        } else {
+            if ((rc = gather(true))) return rc;
+            if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), DevCount{&dinfo->n_segments, bound}, timing))) return rc;
+        }
         if ((rc = run_paint(ctx, DevCount{&dinfo->n_segments, bound}, a, timing, bJ))) return rc;
         HIPCHECK(hipMemcpyAsync(ctx->h_info, ctx->info.p, sizeof(FrameInfo), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHECK(hipStreamSynchronize(ctx->stream));

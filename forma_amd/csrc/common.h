@@ -143,9 +143,17 @@ SortPlan make_sort_plan(uint64_t live_mask, int lo_bit, int hi_bit, int digit_bi
 size_t sort_scratch_words(size_t n);
 // `in` is read-only (preserved), a/b are ping-pong buffers; returns the buffer holding the result (== in when the
 // plan is empty).  scratch: >= sort_scratch_words(n) u32.  err: device word, bit 2 set if a look-back spin expired.
+// Multi-GPU exchange: the stream to sort is NOT contiguous — it is the rank-major concatenation of the n_chunks received
+// buckets, bucket q at in[q * capacity .. + min(counts[2 q], capacity)) (counts[2 q + 1] != 0: that sender overflowed).
+// k_sort_hist and the first digit pass read it in place (logical index -> bucket by <= 7 compares), which removes the
+// gather kernel; k_sort_hist also publishes the total (info->n_segments), the overflow flag and, per workgroup, the key
+// masks / layer-order bit the sort plan is verified with (mask_records, 8 words each: PendingMasks).  n_chunks == 0: plain.
+struct ChunkedSrc { const uint32_t* counts; uint32_t n_chunks; uint32_t capacity; uint32_t* mask_records; };
+uint32_t sort_hist_blocks(size_t n);           // grid of k_sort_hist for n keys = number of mask records it writes
 const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a, uint64_t* b, DevCount n,
                                   const SortPlan& plan, int digit_bits, uint32_t* scratch, uint32_t* err,
-                                  hipEvent_t* pass_ev0, hipEvent_t* pass_ev1);
+                                  hipEvent_t* pass_ev0, hipEvent_t* pass_ev1,
+                                  const ChunkedSrc* chunked = nullptr, FrameInfo* info = nullptr);
 
 // exchange.hip — multi-GPU: bucket a rank's pixel segments by tile-row owner, gather what the owner received
 #define FORMA_MAX_RANKS 8

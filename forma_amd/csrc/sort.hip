@@ -22,6 +22,7 @@
 #include "common.h"
 #include "lookback.h"
 #include "radix_rank.h"
+#include <string.h>
 
 #ifndef OS_THREADS
 #define OS_THREADS 1024
@@ -44,9 +45,48 @@
 #define HS_KPT     16
 #define HS_TILE    (HS_THREADS * HS_KPT)
 
+// logical index of the rank-major concatenation of the received buckets -> position in the receive buffer (ChunkedSrc)
+struct ChunkMap { uint32_t n; uint32_t pre[FORMA_MAX_RANKS]; uint32_t gap[FORMA_MAX_RANKS]; uint32_t total, over; };
+__device__ __forceinline__ ChunkMap load_chunk_map(const ChunkedSrc& C, uint32_t bound) {
+    ChunkMap M;
+    M.n = C.n_chunks; M.total = 0; M.over = 0;
+    uint32_t prev = 0;
+#pragma unroll
+    for (int q = 0; q < FORMA_MAX_RANKS; q++) {                          // (uniform: <= 8 scalar loads)
+        uint32_t c = 0;
+        if (q < (int)C.n_chunks) {
+            const uint32_t c0 = C.counts[2 * q];
+            M.over |= C.counts[2 * q + 1] | (c0 > C.capacity ? 1u : 0u);
+            c = c0 < C.capacity ? c0 : C.capacity;
+        }
+        M.pre[q] = M.total;                                             // first logical index of bucket q
+        M.gap[q] = q ? C.capacity - prev : 0u;                          // unused slots between bucket q - 1's data and bucket q
+        M.total += c; prev = c;
+    }
+    if (M.total > bound) M.total = bound;
+    return M;
+}
+__device__ __forceinline__ uint32_t chunk_phys(const ChunkMap& M, uint32_t idx) {
+    uint32_t p = idx;
+#pragma unroll
+    for (int q = 1; q < FORMA_MAX_RANKS; q++) {
+        if (q >= (int)M.n) break;                                       // uniform: costs nothing for the buckets that do not exist
+        p += idx >= M.pre[q] ? M.gap[q] : 0u;
+    }
+    return p;
+}
+
+template <bool CHUNKED>      // CHUNKED = false is the plain kernel, instruction for instruction
 __global__ __launch_bounds__(HS_THREADS) void k_sort_hist(const uint64_t* __restrict__ in, DevCount nc, SortPlan plan,
-                                                          uint32_t* __restrict__ hist) {
-    const uint32_t n = dev_count(nc);
+                                                          uint32_t* __restrict__ hist, ChunkedSrc C, FrameInfo* __restrict__ info) {
+    constexpr bool chunked = CHUNKED;
+    ChunkMap M;
+    if (chunked) {
+        M = load_chunk_map(C, nc.bound);
+        if (blockIdx.x == 0 && threadIdx.x == 0) { info->n_segments = M.total; if (M.over) info->exchange_overflow = 1u; }
+    }
+    const uint32_t n = chunked ? M.total : dev_count(nc);
+    uint32_t k_or = 0, k_or_hi = 0, k_and = 0xFFFFFFFFu, k_and_hi = 0xFFFFFFFFu, unsorted = 0;
     __shared__ uint32_t lh[SORT_MAX_PASSES * 256];
     const int P = plan.n_passes;
     for (int i = threadIdx.x; i < P * 256; i += HS_THREADS) lh[i] = 0;
@@ -58,7 +98,29 @@ __global__ __launch_bounds__(HS_THREADS) void k_sort_hist(const uint64_t* __rest
 #pragma unroll
         for (int j = 0; j < HS_KPT; j++) {
             uint32_t idx = base + j * HS_THREADS;
-            k[j] = idx < n ? in[idx] : 0ull;
+            k[j] = idx < n ? in[chunked ? chunk_phys(M, idx) : idx] : 0ull;
+        }
+        if (chunked) {
+            // the facts the sort plan is verified with (what k_gather_chunks computed when the stream was materialised):
+            // OR / AND of the key bits, and whether the logical stream is non-decreasing in layer — also across buckets
+            uint32_t front[HS_KPT];                                    // lane 0 of a wave: layer of the key in front of each of its rows
+#pragma unroll
+            for (int j = 0; j < HS_KPT; j++) {
+                const uint32_t idx = base + j * HS_THREADS;
+                front[j] = ((threadIdx.x & 63) == 0 && idx > 0 && idx < n) ? seg_layer(in[chunk_phys(M, idx - 1)]) : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < HS_KPT; j++) {
+                const uint32_t idx = base + j * HS_THREADS;
+                const uint32_t klo = (uint32_t)(k[j] >> 20), khi = (uint32_t)(k[j] >> 52);
+                const uint32_t layer = klo & 0x1FFFFFu;
+                uint32_t pl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)layer, 0x138, 0xF, 0xF, true);   // wave_shr:1
+                if ((threadIdx.x & 63) == 0) pl = front[j];
+                if (idx < n) {
+                    k_or |= klo; k_or_hi |= khi; k_and &= klo; k_and_hi &= khi;
+                    unsorted |= pl > layer ? 1u : 0u;
+                }
+            }
         }
         // Lane-adjacent run-length compression, then one LDS atomic per run: consecutive segments mostly share
         // their tile digits, and 64 lanes adding to one LDS word would serialise.
@@ -89,6 +151,24 @@ __global__ __launch_bounds__(HS_THREADS) void k_sort_hist(const uint64_t* __rest
     for (int i = threadIdx.x; i < P * 256; i += HS_THREADS) {
         uint32_t v = lh[i];
         if (v) atomicAdd(&mine[i], v);
+    }
+    if (chunked && C.mask_records) {                                    // one record per workgroup (neutral if it saw no key)
+        __shared__ uint32_t red[5][HS_THREADS / 64];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            k_or |= __shfl_xor(k_or, d, 64); k_or_hi |= __shfl_xor(k_or_hi, d, 64);
+            k_and &= __shfl_xor(k_and, d, 64); k_and_hi &= __shfl_xor(k_and_hi, d, 64);
+            unsorted |= __shfl_xor(unsorted, d, 64);
+        }
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { red[0][w] = k_or; red[1][w] = k_or_hi; red[2][w] = k_and; red[3][w] = k_and_hi; red[4][w] = unsorted; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t o = 0, oh = 0, a = 0xFFFFFFFFu, ah = 0xFFFFFFFFu, u = 0;
+            for (int q = 0; q < HS_THREADS / 64; q++) { o |= red[0][q]; oh |= red[1][q]; a &= red[2][q]; ah &= red[3][q]; u |= red[4][q]; }
+            uint32_t* m = C.mask_records + (size_t)blockIdx.x * 8;
+            m[0] = o; m[1] = oh; m[2] = a; m[3] = ah; m[4] = u;
+        }
     }
 }
 
@@ -140,14 +220,18 @@ extern "C" int forma_hip_debug_sort_prof(unsigned long long* out16, int reset) {
 #define SP_STAMP(i) do { } while (0)
 #endif
 
-template <int BITS>
+template <int BITS, bool CHUNKED>
 __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
                                                          DevCount nc, int shift, uint32_t dmask,
                                                          const uint32_t* __restrict__ ghist /* this pass, 256 */,
                                                          uint32_t* __restrict__ status /* [ntiles][RADIX] */,
-                                                         uint32_t* __restrict__ ticket, uint32_t* __restrict__ err) {
+                                                         uint32_t* __restrict__ ticket, uint32_t* __restrict__ err,
+                                                         ChunkedSrc C /* first pass of a chunked stream, else n_chunks = 0 */) {
     constexpr int RADIX = 1 << BITS;
-    const uint32_t n = dev_count(nc);
+    const uint32_t n = dev_count(nc);                       // (chunked: k_sort_hist has published the total)
+    constexpr bool chunked = CHUNKED;                       // (one bucket at offset 0 is launched as a plain stream)
+    ChunkMap M;
+    if (chunked) M = load_chunk_map(C, nc.bound);
     __shared__ uint64_t staged[OS_TILE];
     __shared__ uint32_t whist[OS_WAVES][RADIX];
     __shared__ uint32_t s_gdelta[RADIX];
@@ -195,7 +279,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
 #pragma unroll
         for (int j = 0; j < OS_KPT; j++) {
             uint32_t idx = wbase + j * 64 + lane;
-            keys[j] = idx < n ? in[idx] : ~0ull;            // padding sorts last in stream order, never written
+            keys[j] = idx < n ? in[chunked ? chunk_phys(M, idx) : idx] : ~0ull;   // padding sorts last in stream order, never written
         }
 #ifdef SORT_PROF
         if (keys[OS_KPT - 1] == 0x123456789ull) atomicAdd(&g_sort_prof[14], 1ull);      // forces the loads to have landed
@@ -322,6 +406,11 @@ SortPlan make_sort_plan(uint64_t live_mask, int lo_bit, int hi_bit, int digit_bi
     return p;
 }
 
+uint32_t sort_hist_blocks(size_t n) {
+    uint32_t hb = (uint32_t)((n + HS_TILE - 1) / HS_TILE);
+    return hb > 2048 ? 2048u : hb;                        // few workgroups: the final flush is 256 x passes global atomics each
+}
+
 size_t sort_scratch_words(size_t n) {
     size_t ntiles = (n + OS_TILE - 1) / OS_TILE;
     // [hist: HS_COPIES x MAX_PASSES*256] [tickets: MAX_PASSES] [pad to 64] [status: MAX_PASSES * ntiles * 256]
@@ -330,7 +419,7 @@ size_t sort_scratch_words(size_t n) {
 
 const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a, uint64_t* b, DevCount nc,
                                   const SortPlan& plan, int digit_bits, uint32_t* scratch, uint32_t* err,
-                                  hipEvent_t* pass_ev0, hipEvent_t* pass_ev1) {
+                                  hipEvent_t* pass_ev0, hipEvent_t* pass_ev1, const ChunkedSrc* chunked, FrameInfo* info) {
     const size_t n = nc.bound;                        // provisioning (grid, scratch); the kernels use the device count
     if (n <= 1 || plan.n_passes == 0) return in;
     const uint32_t ntiles = (uint32_t)((n + OS_TILE - 1) / OS_TILE);
@@ -340,9 +429,12 @@ const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a
     const int P = plan.n_passes;
     // zero hist + tickets + the status words of the passes that run (re-initialised every call)
     (void)hipMemsetAsync(scratch, 0, ((size_t)HS_COPIES * SORT_MAX_PASSES * 256 + 64 + (size_t)P * ntiles * 256) * 4, s);
-    uint32_t hb = (uint32_t)((n + HS_TILE - 1) / HS_TILE);
-    if (hb > 2048) hb = 2048;                             // few workgroups: the final flush is 256 x passes global atomics each
-    hipLaunchKernelGGL(k_sort_hist, dim3(hb), dim3(HS_THREADS), 0, s, in, nc, plan, hist);
+    const uint32_t hb = sort_hist_blocks(n);
+    ChunkedSrc C0;
+    memset(&C0, 0, sizeof C0);
+    const ChunkedSrc C = chunked ? *chunked : C0;
+    if (chunked) hipLaunchKernelGGL(k_sort_hist<true>, dim3(hb), dim3(HS_THREADS), 0, s, in, nc, plan, hist, C, info);
+    else hipLaunchKernelGGL(k_sort_hist<false>, dim3(hb), dim3(HS_THREADS), 0, s, in, nc, plan, hist, C, info);
     const uint32_t cap = 512u * 512u / OS_THREADS;        // persistent: 16 waves per CU
     uint32_t grid = ntiles < cap ? ntiles : cap;
     const uint64_t* src = in;
@@ -350,12 +442,12 @@ const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a
     for (int p = 0; p < P; p++) {
         if (pass_ev0) (void)hipEventRecord(pass_ev0[p], s);
         uint32_t* st = status + (size_t)p * ntiles * 256;
-        if (digit_bits == 4)
-            hipLaunchKernelGGL(k_onesweep<4>, dim3(grid), dim3(OS_THREADS), 0, s, src, dst, nc, plan.shift[p],
-                               plan.mask[p], (const uint32_t*)(hist + p * 256), st, tickets + p, err);
-        else
-            hipLaunchKernelGGL(k_onesweep<8>, dim3(grid), dim3(OS_THREADS), 0, s, src, dst, nc, plan.shift[p],
-                               plan.mask[p], (const uint32_t*)(hist + p * 256), st, tickets + p, err);
+        const bool ch = p == 0 && C.n_chunks > 1;                      // only the first pass reads the received buckets in place
+#define OS_LAUNCH(B, CH) hipLaunchKernelGGL((k_onesweep<B, CH>), dim3(grid), dim3(OS_THREADS), 0, s, src, dst, nc, plan.shift[p], \
+                                           plan.mask[p], (const uint32_t*)(hist + p * 256), st, tickets + p, err, ch ? C : C0)
+        if (digit_bits == 4) { if (ch) OS_LAUNCH(4, true); else OS_LAUNCH(4, false); }
+        else { if (ch) OS_LAUNCH(8, true); else OS_LAUNCH(8, false); }
+#undef OS_LAUNCH
         if (pass_ev1) (void)hipEventRecord(pass_ev1[p], s);
         src = dst;
         dst = (dst == a) ? b : a;
