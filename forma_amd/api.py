@@ -81,6 +81,12 @@ class AffineTransform:                       # math/transform.rs:22-57
     def to_array(self):
         return [self.ux, self.uy, self.vx, self.vy, self.tx, self.ty]
 
+    def transform(self, p: "Point") -> "Point":        # math/transform.rs:43-48 (f32, fused multiply-adds)
+        f = np.float32
+        def fma(a, b, c):                               # exact for f32 operands: the product of two f32 fits an f64
+            return f(np.float64(f(a)) * np.float64(f(b)) + np.float64(f(c)))
+        return Point(float(fma(self.ux, p.x, fma(self.vx, p.y, self.tx))), float(fma(self.uy, p.x, fma(self.vy, p.y, self.ty))))
+
 
 class GeomPresTransformError(ValueError):
     pass
@@ -106,6 +112,9 @@ class GeomPresTransform:
 
     def is_identity(self) -> bool:
         return self.t == AffineTransform()
+
+    def transform(self, p: "Point") -> "Point":
+        return self.t.transform(p)
 
     def to_array(self):
         t = self.t
