@@ -385,7 +385,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                           (uint32_t)ctx->n_orders, tiles_w, tiles_h, row_count, row_span_lo,
                           row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(),
                           (a.cache_id >= 0 && ctx->have_unchanged) ? ctx->unchanged.as<uint8_t>() : nullptr, dinfo,
-                          runs_edge_segments(ctx->legacy_runs));
+                          runs_edge_segments(ctx->legacy_runs), (a.height & 15u) ? (a.height & 15u) : 16u);
     } else {
         HIPCHECK(ctx->span_key.ensure(8));
         HIPCHECK(ctx->span_cov.ensure(16));

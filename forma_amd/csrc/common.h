@@ -199,7 +199,8 @@ void launch_carry_rows(hipStream_t s, bool local_sort, const uint64_t* sorted_ru
                        const uint32_t* layer_sf /* per order: SF_* | LSF_VALID */, uint32_t n_orders, uint32_t tiles_w,
                        uint32_t tiles_h, const uint32_t* row_count, uint32_t* row_span_lo, uint32_t* row_span_cnt,
                        uint64_t* span_key, uint4* span_cov, const uint8_t* unchanged /* per order, nullable */, FrameInfo* info,
-                       uint32_t edge_segs);
+                       uint32_t edge_segs,
+                       uint32_t vis_last /* visible pixel rows of the last tile row (height % 16, 16 if 0) */);
 void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, DevCount n_runs,
                   const uint32_t* tile_first_run, const uint32_t* row_span_lo, const uint32_t* row_span_cnt,
                   const uint64_t* span_key, const uint4* span_cov,

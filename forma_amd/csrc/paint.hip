@@ -669,7 +669,8 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
                                                            uint32_t* __restrict__ row_span_cnt,
                                                            uint64_t* __restrict__ span_key, uint4* __restrict__ span_cov,
                                                            const uint8_t* __restrict__ unchanged,
-                                                           FrameInfo* __restrict__ info, uint32_t edge_segs) {
+                                                           FrameInfo* __restrict__ info, uint32_t edge_segs,
+                                                           uint32_t vis_last /* visible pixel rows of the last tile row, 16 = all */) {
     __shared__ uint32_t s_red[CR_WAVES];
     __shared__ uint64_t s_wlo[CR_WAVES], s_whi[CR_WAVES];
     __shared__ uint32_t s_wflag[CR_WAVES], s_wspan[CR_WAVES];
@@ -681,6 +682,17 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
     __shared__ uint32_t s_wh[LOCAL ? CR_WAVES * 256 : 1];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t ty = blockIdx.x;
+    // A canvas whose height is not a multiple of 16: lines entirely below it are culled (segment.rs:41-52), so a layer that
+    // crosses the bottom edge keeps a non-zero cover on the INVISIBLE pixel rows of the last tile row.  The reference carries
+    // it (Cover::is_empty looks at all 16 rows) and paints the layer with zero visible coverage in every tile to the right;
+    // here such a carry produces no span: its pixels are never written (painter/mod.rs:537-548 writes the canvas rows only),
+    // and a busy scene would otherwise put thousands of invisible layers into every tile of that row.  Only the emptiness
+    // test of carry-only spans is masked; covers, runs and the `full` flag are untouched.
+    uint64_t vis_lo = ~0ull, vis_hi = ~0ull;
+    if (ty + 1 == tiles_h && vis_last < 16u) {
+        vis_lo = vis_last >= 8u ? ~0ull : ((1ull << (8u * vis_last)) - 1ull);
+        vis_hi = vis_last <= 8u ? 0ull : ((1ull << (8u * (vis_last - 8u))) - 1ull);
+    }
 #ifdef CR_PROF
     unsigned long long crp_t = __builtin_readcyclecounter();
     if (threadIdx.x == 0) atomicAdd(&g_cr_prof[7], 1ull);
@@ -910,7 +922,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
                 uint32_t sh = same_next ? ntxb - 1u : tiles_w;          // exclusive; next tile_x = txb_next - 1
                 if (sh > tiles_w) sh = tiles_w;
                 span_hi[k] = sh;                                         // span_lo = tile_x + 1
-                if (!cover_is_empty(pl, ph, (meta[k] >> 12) & 1u) && span_lo[k] < sh) spanm |= 1u << k;
+                if (!cover_is_empty(pl & vis_lo, ph & vis_hi, (meta[k] >> 12) & 1u) && span_lo[k] < sh) spanm |= 1u << k;
             }
         }
         // ordered compaction of the spans
@@ -948,16 +960,16 @@ void launch_carry_rows(hipStream_t s, bool local_sort, const uint64_t* sorted_ru
                        const BlkEdge* blk_edge, DevCount n_segments, DevCount n_runs, const uint32_t* layer_sf,
                        uint32_t n_orders, uint32_t tiles_w, uint32_t tiles_h, const uint32_t* row_count,
                        uint32_t* row_span_lo, uint32_t* row_span_cnt, uint64_t* span_key, uint4* span_cov,
-                       const uint8_t* unchanged, FrameInfo* info, uint32_t edge_segs) {
+                       const uint8_t* unchanged, FrameInfo* info, uint32_t edge_segs, uint32_t vis_last) {
     if (tiles_h == 0) return;
     if (local_sort)
         hipLaunchKernelGGL(k_carry_rows<true>, dim3(tiles_h), dim3(CR_THREADS), 0, s, sorted_run_keys, records, blk_edge,
                            n_segments, n_runs, layer_sf, n_orders, tiles_w, tiles_h, row_count, row_span_lo,
-                           row_span_cnt, span_key, span_cov, unchanged, info, edge_segs);
+                           row_span_cnt, span_key, span_cov, unchanged, info, edge_segs, vis_last);
     else
         hipLaunchKernelGGL(k_carry_rows<false>, dim3(tiles_h), dim3(CR_THREADS), 0, s, sorted_run_keys, records, blk_edge,
                            n_segments, n_runs, layer_sf, n_orders, tiles_w, tiles_h, row_count, row_span_lo,
-                           row_span_cnt, span_key, span_cov, unchanged, info, edge_segs);
+                           row_span_cnt, span_key, span_cov, unchanged, info, edge_segs, vis_last);
 }
 
 // ================================================================================================

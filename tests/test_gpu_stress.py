@@ -43,12 +43,9 @@ def test_random_scene_matches_oracle(seed, n, W, H):
 
 
 def test_rows_beyond_the_local_sort_take_the_global_sort_and_deep_tiles_are_reported():
-    """The two capacity edges of the carry pre-pass / painter on one wide, flat canvas: (a) case 20 above really has a tile
-    row with more than 16384 runs (so k_carry_rows<false> + the global run-key sort ran, not the in-LDS sort); (b) a tile
-    with more than 4096 layers fails the frame with FORMA_E_CAPACITY instead of painting something wrong.
-    (b) is reached the way real scenes reach it: a canvas height that is not a multiple of 16 — lines entirely below the
-    canvas are culled (segment.rs:41-52), so every layer that crosses the bottom edge keeps a non-zero cover on the invisible
-    pixel rows of the last tile row, and that cover is carried (non-empty, painter/mod.rs:187-198) across the whole row."""
+    """Capacity edges of the carry pre-pass / painter: (a) case 20 above really has a tile row with more than 16384 runs (so
+    k_carry_rows<false> + the global run-key sort ran, not the in-LDS sort); (b) a tile with more than 4096 layers fails the
+    frame with FORMA_E_CAPACITY instead of painting something wrong."""
     import forma_amd
     from forma_amd import FormaError
     W, H = 16384, 48
@@ -64,10 +61,32 @@ def test_rows_beyond_the_local_sort_take_the_global_sort_and_deep_tiles_are_repo
         ty = (srt[heads] >> np.uint64(53)).astype(np.int64) - 1
         per_row = np.bincount(ty[(ty >= 0) & (ty < 3)], minlength=3)
         assert per_row.max() > 16384, per_row
-        t2 = S.random_mixed(n=16000, width=8192, height=40, seed=20).tables(o)
-        S.load(c, t2)
+        comp = S.Composition()
+        for order in range(4200):                                        # 4200 layers over the same tile
+            comp.get_mut_or_insert_default(order).insert(S.custom_square(2, 2, 30, 30)).set_props(S.solid((0.5, 0.5, 0.5, 0.5)))
+        S.load(c, comp.tables(o))
         with pytest.raises(FormaError) as e:
-            c.render(8192, 40)
+            c.render(32, 32)
         assert e.value.code == -4
+    finally:
+        c.close()
+
+
+def test_layers_cut_by_the_bottom_edge_do_not_pile_up_in_a_partial_last_tile_row():
+    """Canvas height not a multiple of 16: lines entirely below the canvas are culled (segment.rs:41-52), so a layer that crosses
+    the bottom edge keeps a non-zero cover on the invisible pixel rows of the last tile row, which the reference carries through
+    every tile to the right (and paints with zero visible coverage).  16 000 shapes on 8192 x 40 put 4 529 such layers into
+    one tile — beyond the painter's list.  The carry pre-pass drops carries that are empty on the VISIBLE rows: same pixels."""
+    import forma_amd
+    W, H = 8192, 40
+    o = orc.Oracle()
+    t = S.random_mixed(n=16000, width=W, height=H, seed=20).tables(o)
+    S.load(o, t)
+    want = o.render(W, H)
+    c = forma_amd.Context(0)
+    try:
+        S.load(c, t)
+        for _ in range(2):
+            assert np.array_equal(c.render(W, H), want)
     finally:
         c.close()
