@@ -208,11 +208,13 @@ def _rccl_world1_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
+@pytest.mark.timeout(240)
 def test_rccl_calls_on_library_buffers_with_a_world_of_one():
     import torch.multiprocessing as mp
     mp.spawn(_rccl_world1_worker, args=(1, _free_port(), ""), nprocs=1, join=True)
 
 
+@pytest.mark.timeout(300)                      # (first executed on a multi-GPU node by the driver: fail, never hang)
 def test_two_ranks_over_rccl():
     import torch
     if torch.cuda.device_count() < 2:
