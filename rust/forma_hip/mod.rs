@@ -392,10 +392,12 @@ impl Renderer {
             if let Some(inner) = inner {
                 if let (true, Some(order)) = (inner.is_enabled, inner.order) {
                     geoms[slot as usize] = match inner.affine_transform.as_ref() {
+                        // the ABI wants AffineTransform::to_array's order (ux, uy, vx, vy, tx, ty; transform.rs:54-56), not
+                        // GeomPresTransform::to_array's (ux, vx, uy, vy, tx, ty; :194-198): take the inner transform
                         Some(transform) => forma_geom_t {
                             order: order.as_u32(),
                             flags: ffi::FORMA_GEOM_HAS_XF,
-                            xf: transform.to_array(),
+                            xf: transform.0.to_array(),
                         },
                         None => forma_geom_t {
                             order: order.as_u32(),
