@@ -157,17 +157,13 @@ __device__ __forceinline__ uint32_t integers_between(float a, float b) {   // se
 
 struct LineP { uint32_t order, len; float x0, y0, dx, dy, a, b, c, d; };
 
-__device__ __forceinline__ LineP line_params(const float* __restrict__ x, const float* __restrict__ y,
-                                             const uint32_t* __restrict__ line_slot, uint32_t i,
-                                             const forma_geom_t* __restrict__ geoms, uint32_t n_geoms, float width,
-                                             float height, float band_lo, float band_hi) {
+// the arithmetic half of line_params: everything after the loads (so that a caller can have the loads of several lines in
+// flight before it looks at any of them)
+__device__ __forceinline__ LineP line_params_loaded(const forma_geom_t& g, float p0x, float p0y, float p1x, float p1y, float width,
+                                                    float height, float band_lo, float band_hi) {
     LineP L;
     L.order = 0; L.len = 0; L.x0 = L.y0 = L.dx = L.dy = L.a = L.b = L.c = L.d = 0.0f;
-    const uint32_t slot = line_slot[i];
-    if (slot == FORMA_NONE || slot >= n_geoms) return L;
-    const forma_geom_t g = geoms[slot];
     if (g.order == FORMA_NONE) return L;
-    float p0x = x[i], p0y = y[i], p1x = x[i + 1], p1y = y[i + 1];
     if (g.flags & FORMA_GEOM_HAS_XF) {                      // transform_point segment.rs:30-39
         float ax = fmaf(g.xf[0], p0x, fmaf(g.xf[2], p0y, g.xf[4]));
         float ay = fmaf(g.xf[1], p0x, fmaf(g.xf[3], p0y, g.xf[5]));
@@ -189,6 +185,24 @@ __device__ __forceinline__ LineP line_params(const float* __restrict__ x, const 
     L.a = fabsf(dxr); L.b = fabsf(dyr);
     L.len = integers_between(p0x, p1x) + integers_between(p0y, p1y) + 1u;   // :86-88
     return L;
+}
+__device__ __forceinline__ LineP line_params(const float* __restrict__ x, const float* __restrict__ y,
+                                             const uint32_t* __restrict__ line_slot, uint32_t i,
+                                             const forma_geom_t* __restrict__ geoms, uint32_t n_geoms, float width,
+                                             float height, float band_lo, float band_hi) {
+    const uint32_t slot = line_slot[i];
+    if (slot == FORMA_NONE || slot >= n_geoms) {
+        LineP L;
+        L.order = 0; L.len = 0; L.x0 = L.y0 = L.dx = L.dy = L.a = L.b = L.c = L.d = 0.0f;
+        return L;
+    }
+    const forma_geom_t g = geoms[slot];
+    if (g.order == FORMA_NONE) {
+        LineP L;
+        L.order = 0; L.len = 0; L.x0 = L.y0 = L.dx = L.dy = L.a = L.b = L.c = L.d = 0.0f;
+        return L;
+    }
+    return line_params_loaded(g, x[i], y[i], x[i + 1], y[i + 1], width, height, band_lo, band_hi);
 }
 
 // SoA writer: the parity entry point forma_hip_prepare_lines (one thread per line)
@@ -246,16 +260,38 @@ __global__ __launch_bounds__(PL_THREADS) void k_line_len(LineSource S, uint32_t 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t base = blockIdx.x * PC_TILE;
     uint32_t sum = 0, cnt = 0;
+    if (S.sums) {
 #pragma unroll
-    for (int r = 0; r < PL_IPT; r++) {
-        const uint32_t i = base + r * PL_THREADS + tid;
-        uint32_t len = 0;
-        if (i < n_lines) {
-            if (S.sums) len = S.sums[i] - (i ? S.sums[i - 1] : 0u);
-            else len = line_params(S.x, S.y, S.line_slot, i, S.geoms, S.n_geoms, S.width, S.height, S.band_lo, S.band_hi).len;
-            lens[i] = len;
+        for (int r = 0; r < PL_IPT; r++) {
+            const uint32_t i = base + r * PL_THREADS + tid;
+            uint32_t len = 0;
+            if (i < n_lines) { len = S.sums[i] - (i ? S.sums[i - 1] : 0u); lens[i] = len; }
+            sum += len; cnt += len ? 1u : 0u;
         }
-        sum += len; cnt += len ? 1u : 0u;
+    } else {
+        // two rounds of loads for ALL of the thread's lines (slot + points, then the geom entries), then the arithmetic
+        uint32_t slot[PL_IPT];
+        float p0x[PL_IPT], p0y[PL_IPT], p1x[PL_IPT], p1y[PL_IPT];
+        forma_geom_t g[PL_IPT];
+#pragma unroll
+        for (int r = 0; r < PL_IPT; r++) {
+            const uint32_t i = base + r * PL_THREADS + tid;
+            const bool in = i < n_lines;
+            slot[r] = in ? S.line_slot[i] : FORMA_NONE;
+            p0x[r] = in ? S.x[i] : 0.0f; p0y[r] = in ? S.y[i] : 0.0f; p1x[r] = in ? S.x[i + 1] : 0.0f; p1y[r] = in ? S.y[i + 1] : 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < PL_IPT; r++) {
+            if (slot[r] != FORMA_NONE && slot[r] < S.n_geoms) g[r] = S.geoms[slot[r]];
+            else { g[r].order = FORMA_NONE; g[r].flags = 0; }
+        }
+#pragma unroll
+        for (int r = 0; r < PL_IPT; r++) {
+            const uint32_t i = base + r * PL_THREADS + tid;
+            const uint32_t len = line_params_loaded(g[r], p0x[r], p0y[r], p1x[r], p1y[r], S.width, S.height, S.band_lo, S.band_hi).len;
+            if (i < n_lines) lens[i] = len;
+            sum += len; cnt += len ? 1u : 0u;
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { sum += __shfl_xor(sum, d, 64); cnt += __shfl_xor(cnt, d, 64); }
