@@ -354,16 +354,25 @@ __global__ __launch_bounds__(PC_THREADS) void k_line_compact(const uint32_t* __r
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < PC_THREADS / 64; i++) if (i < w) { bsum += s_wsum[i]; bcnt += s_wcnt[i]; }
+    // the tile's entries go through LDS so that they leave as full, coalesced rows (a lane's entries are consecutive but the
+    // lanes' pieces are ~8 words apart: written directly, every store instruction touched 16 partial cache lines)
+    __shared__ uint32_t s_idx[PC_TILE], s_start[PC_TILE];
+    const uint32_t tile_c0 = tile_cnt[blockIdx.x];                      // first compacted index of the tile (same load as above: cached)
+    uint32_t tile_n = 0;
+#pragma unroll
+    for (int i = 0; i < PC_THREADS / 64; i++) tile_n += s_wcnt[i];
     uint32_t start = bsum + isum - sum, c = bcnt + icnt - cnt;
 #pragma unroll
     for (int q = 0; q < PC_IPT; q++) {
         if (l[q]) {
-            cl_idx[c] = base + q;
-            cl_start[c] = start;
+            s_idx[c - tile_c0] = base + q;
+            s_start[c - tile_c0] = start;
             mark_block_first(block_first, bf_cap, start, l[q], c);
             start += l[q]; c++;
         }
     }
+    __syncthreads();
+    for (uint32_t e = tid; e < tile_n; e += PC_THREADS) { cl_idx[tile_c0 + e] = s_idx[e]; cl_start[tile_c0 + e] = s_start[e]; }
 }
 
 size_t prepare_scratch_words(size_t n_lines) { return n_lines + 2 * ((n_lines + PC_TILE - 1) / PC_TILE + 1) + 16; }
