@@ -20,6 +20,15 @@ of the lines, HIP kernels bucket the pixel segments by tile-row owner, one RCCL 
 sorts and paints its band.  `--mode bands` replicates the scene and culls by band (no exchange); `--mode frames` renders
 whole frames on every GPU (weak scaling).  `value` is always the whole-job aggregate / max-over-ranks wall time.
 
+`roofline` (the radix digit pass, HBM-bound) and `stages_us` come from a second timed region of the same run — K more
+frames with ONE frame in flight and HIP events recorded at the stage boundaries on the context's stream: with several frames
+in flight the kernels of different frames time-share the chip and a launch duration is no longer the kernel's own.
+`roofline.traffic` is NOT measured in the run: it is read from profiles/r02_pmc_summary.json (separate rocprofv3 --pmc passes
+of the same build, tools/pmc_round.py) and labelled so.  `cpu_baseline` = the C++ oracle on the same scene tables, N = 1 only.
+
+Rehearsal switches for single-GPU boxes (never set by the driver): FORMA_BENCH_MODE_AT_1=1 runs the sharded mode with one
+rank; FORMA_BENCH_BACKEND=gloo + FORMA_BENCH_ONE_DEVICE=1 run N ranks on one GPU without RCCL.
+
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
