@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 import struct
+import weakref
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -388,6 +389,11 @@ class _Shared:
         g = self.next_geom_id; self.next_geom_id += 1; return g
 
 
+def _drop_layer(shared: "_Shared", gid_cell):
+    shared.geom_id_to_order.pop(gid_cell[0], None)
+    shared.table_version += 1
+
+
 class Layer:
     def __init__(self, shared: _Shared):
         self._shared = shared
@@ -398,6 +404,11 @@ class Layer:
         self.props_ = Props()
         self.is_unchanged_: set = set()
         self.lines_count = 0
+        # `impl Drop for Layer` (layer.rs:356-363): a layer that goes away takes its geometry id out of
+        # geom_id_to_order, which is what lets compact_geom collect its lines.  The id lives in a one-element
+        # list because Layer::clear replaces it.
+        self._gid_cell = [self.geom_id_]
+        self._drop = weakref.finalize(self, _drop_layer, shared, self._gid_cell)
 
     def geom_id(self) -> int:                                 # layer.rs:143-145
         return self.geom_id_
@@ -417,6 +428,7 @@ class Layer:
     def clear(self) -> "Layer":                               # layer.rs:113-129
         self._shared.geom_id_to_order.pop(self.geom_id_, None)
         self.geom_id_ = self._shared.new_geom_id()
+        self._gid_cell[0] = self.geom_id_
         self._shared.geom_id_to_order[self.geom_id_] = self.order
         self._shared.geometry_version += 1
         self._shared.table_version += 1

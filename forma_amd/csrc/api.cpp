@@ -103,7 +103,8 @@ struct forma_hip_ctx {
     DevBuf xsend, xrecv, xsend_counts, xrecv_counts, xscratch, xmask;
     bool xgather_always = false;              // FORMA_HIP_XGATHER=1: materialise the received stream before sorting it
     bool xpred_valid = false;               // the local rasterized count of the previous exchange frame is known
-    uint32_t xpred_N = 0;
+    uint32_t xpred_N = 0, xpred_w = 0, xpred_h = 0;
+    uint32_t* h_xlocal = nullptr;           // pinned: [0] = local segment count of the last bucket frame (copied on the stream), [1] = 1 when pending
     // timing
     hipEvent_t ev0[ST_COUNT], ev1[ST_COUNT], pev0[MAX_PASS_EVENTS], pev1[MAX_PASS_EVENTS];
     bool stage_used[ST_COUNT];
@@ -558,6 +559,7 @@ int forma_hip_create(forma_hip_ctx** out, int device) {
     }
     bool ok = hipHostMalloc((void**)&ctx->h_info, sizeof(FrameInfo), hipHostMallocDefault) == hipSuccess &&
               hipHostMalloc((void**)&ctx->h_rows, 2049 * 4, hipHostMallocDefault) == hipSuccess &&
+              hipHostMalloc((void**)&ctx->h_xlocal, 2 * 4, hipHostMallocDefault) == hipSuccess &&
               ctx->info.ensure(sizeof(FrameInfo)) == hipSuccess && ctx->info_init.ensure(sizeof(FrameInfo)) == hipSuccess;
     if (ok) {
         FrameInfo fi;
@@ -590,12 +592,14 @@ void forma_hip_destroy(forma_hip_ctx* ctx) {
                      &ctx->block_first, &ctx->prep_scratch, &ctx->seg_u, &ctx->seg_a, &ctx->seg_b,
                      &ctx->sort_counters, &ctx->info, &ctx->info_init, &ctx->records, &ctx->rk_u, &ctx->rk_a, &ctx->rk_b,
                      &ctx->blk_edge, &ctx->runs_scratch, &ctx->row_tab, &ctx->span_key, &ctx->span_cov,
-                     &ctx->image, &ctx->xsend, &ctx->xrecv, &ctx->xsend_counts, &ctx->xrecv_counts, &ctx->xscratch};
+                     &ctx->image, &ctx->xsend, &ctx->xrecv, &ctx->xsend_counts, &ctx->xrecv_counts, &ctx->xscratch,
+                     &ctx->ras_masks, &ctx->xmask};
     for (DevBuf* b : all) b->release();
     for (int s = 0; s < ST_COUNT; s++) { (void)hipEventDestroy(ctx->ev0[s]); (void)hipEventDestroy(ctx->ev1[s]); }
     for (int p = 0; p < MAX_PASS_EVENTS; p++) { (void)hipEventDestroy(ctx->pev0[p]); (void)hipEventDestroy(ctx->pev1[p]); }
     if (ctx->h_info) (void)hipHostFree(ctx->h_info);
     if (ctx->h_rows) (void)hipHostFree(ctx->h_rows);
+    if (ctx->h_xlocal) (void)hipHostFree(ctx->h_xlocal);
     if (ctx->h_written) (void)hipHostFree(ctx->h_written);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     for (auto& c : ctx->caches) { c.tiles.release(); c.image.release(); }
@@ -620,6 +624,7 @@ int forma_hip_set_geometry(forma_hip_ctx* ctx, const float* x, const float* y, c
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     ctx->n_points = n_points;
     ctx->pred_counts_valid = false;                       // new geometry: the next frame re-learns N and J synchronously
+    ctx->xpred_valid = false;
     return FORMA_OK;
 }
 
@@ -978,7 +983,7 @@ int forma_hip_set_band(forma_hip_ctx* ctx, uint32_t row0, uint32_t row1) {
     if (!ctx) return FORMA_E_ARG;
     if (row1 != 0 && row0 >= row1) return fail(ctx, FORMA_E_ARG, "empty band");
     ctx->band_row0 = row1 ? row0 : 0; ctx->band_row1 = row1;
-    ctx->pred_counts_valid = false;
+    ctx->pred_counts_valid = false; ctx->xpred_valid = false;
     return FORMA_OK;
 }
 
@@ -1081,8 +1086,16 @@ int forma_hip_rasterize_bucket_frame(forma_hip_ctx* ctx, uint32_t width, uint32_
     HIPCHECK(hipSetDevice(ctx->device));
     const bool timing = timings != nullptr;
     clear_stage_flags(ctx);
-    // read-back-free when the previous frame's local segment count is known (bound with slack; the bucket scan flags an
-    // excess to every receiver), else synchronous
+    // read-back-free when the previous frame's local segment count is known (bound with slack), else synchronous.  A frame
+    // whose true count exceeds the bound is flagged by k_owner_scan to every receiver (FORMA_E_CAPACITY -> the host re-plans).
+    // The true count of every bucket frame is copied to a pinned word on the stream; the owner's half of the frame ends in a
+    // stream synchronisation, so by the next bucket frame it has landed and refreshes the prediction (an animation drifts).
+    if (width != ctx->xpred_w || height != ctx->xpred_h) { ctx->xpred_valid = false; ctx->xpred_w = width; ctx->xpred_h = height; }
+    if (ctx->xpred_valid && ctx->h_xlocal[1]) {
+        HIPCHECK(hipStreamSynchronize(ctx->stream));      // (a no-op after forma_hip_gather_sort_paint_frame)
+        ctx->xpred_N = ctx->h_xlocal[0];
+    }
+    ctx->h_xlocal[1] = 0;
     const uint32_t bN = (ctx->xpred_valid && !ctx->no_async) ? ctx->xpred_N + ctx->xpred_N / 16 + 4096 : 0;
     if ((rc = run_rasterize_frame(ctx, width, height, timing, false, bN))) return rc;
     FrameInfo* dinfo = ctx->info.as<FrameInfo>();
@@ -1095,6 +1108,10 @@ int forma_hip_rasterize_bucket_frame(forma_hip_ctx* ctx, uint32_t width, uint32_
                         ctx->xsend.as<uint64_t>(), ctx->xsend_counts.as<uint32_t>(), dinfo);
     stage_end(ctx, ST_XCHG, timing);
     HIPCHECK(hipGetLastError());
+    if (bN) {
+        HIPCHECK(hipMemcpyAsync(&ctx->h_xlocal[0], &dinfo->n_segments, 4, hipMemcpyDeviceToHost, ctx->stream));
+        ctx->h_xlocal[1] = 1;
+    }
     if (timing) {                                            // (the only host wait of this call, and only when timings are asked for)
         HIPCHECK(hipStreamSynchronize(ctx->stream));
         ctx->n_passes = 0; ctx->last_runs = 0;

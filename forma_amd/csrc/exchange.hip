@@ -97,6 +97,10 @@ __global__ __launch_bounds__(1024) void k_owner_scan(uint32_t* __restrict__ bloc
         carry += tot;
         __syncthreads();
     }
+    if (threadIdx.x == 0 && g == 0 && nc.ptr && *nc.ptr > nc.bound) {     // read-back-free frame: more local segments than were
+        for (uint32_t t = 0; t + 1 < n_owners; t++) atomicOr(&send_counts[2 * t + 1], 1u);   // provisioned — the excess was never
+        info->exchange_overflow = 1u;                                    // rasterized: every receiver fails the frame, the host re-plans
+    }
     if (threadIdx.x == 0 && g + 1 < n_owners) {                          // (the last owner is the dropped bucket)
         send_counts[2 * g] = carry < capacity ? carry : capacity;
         if (carry > capacity) {                                          // every receiver learns that this sender overflowed

@@ -113,7 +113,9 @@ __global__ __launch_bounds__(RC_THREADS) void k_runs_count(const uint64_t* __res
             // record per workgroup and nobody needed them combined until now — this workgroup does it instead of a launch
             uint32_t o = 0, oh = 0, a = 0xFFFFFFFFu, ah = 0xFFFFFFFFu, u = 0;
             if (pm.rec) {
-                const uint32_t nrec = pm.n_fixed ? pm.n_fixed : (info->n_segments + RAS_TILE - 1) / RAS_TILE;
+                // (the CLAMPED count: the producer wrote one record per block of the provisioned bound, and a frame whose true
+                //  count exceeds it is voided by plan_bad above — reading info->n_segments here walked past the buffer)
+                const uint32_t nrec = pm.n_fixed ? pm.n_fixed : (n + RAS_TILE - 1) / RAS_TILE;
                 for (uint32_t b0 = 0; b0 < nrec; b0 += 8 * RC_THREADS) {
                     uint4 m[8]; uint32_t mu[8];
 #pragma unroll

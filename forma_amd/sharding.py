@@ -1,11 +1,19 @@
-"""Tile-row sharding of a frame across GPUs.
+"""Tile-row sharding of a frame across GPUs: the HOST logic of the process-per-GPU launcher.
 
 `tile_y` is the most significant field of the pixel-segment key and the cover carry never crosses tile rows
 (reference forma/src/cpu/painter/mod.rs:518-522, 741-776: rows are the CPU backend's unit of parallelism too), so a
-frame splits into contiguous bands of tile rows with no data-path exchange: every rank holds the whole (small)
-scene, culls lines outside its band and rasterizes / sorts / paints only its own rows.  This module is the host
-logic: choose the bands, agree on them across ranks, and time the frame the way bench.py reports it.  It has no
-GPU dependency (the collectives are `torch.distributed`: RCCL on GPUs, gloo in the CPU tests).
+band of tile rows is a complete, independent sort + paint problem.  Three layouts are driven from here:
+
+* `exchange` (the north star's): every rank rasterizes 1/world of the LINES (`line_shares`, `slice_geometry`), HIP kernels
+  bucket the pixel segments by tile-row owner, one padded equal-split all-to-all moves them (`ExchangeFrame`: RCCL through
+  torch.distributed on the context's own stream; `pair_capacity`, `max_pair_count` size the buckets), the owner sorts and
+  paints its band (`band_edges`, `agree_on_bands`, `band_crop`);
+* `bands`: replicated scene, band culling, no data-path collective;
+* `frames`: whole frames per GPU.
+
+The single-process form of the exchange layout — `forma_hip_create_multi`, RCCL inside libforma_hip.so — needs none of
+this module: `forma_hip_render` on a multi-device context plans bands, line shares and capacities itself (csrc/multi.cpp).
+This module has no GPU dependency (the collectives are `torch.distributed`: RCCL on GPUs, gloo in the CPU tests).
 """
 from __future__ import annotations
 
@@ -89,35 +97,6 @@ def slice_geometry(x: np.ndarray, y: np.ndarray, line_slot: np.ndarray, l0: int,
     if l1 <= l0:
         return x[:0].copy(), y[:0].copy(), line_slot[:0].copy()
     return x[l0:l1 + 1].copy(), y[l0:l1 + 1].copy(), line_slot[l0:l1].copy()
-
-
-def exchange_segments(dist, seg, edges: Sequence[int], world: int, out_alloc=None):
-    """seg: this rank's pixel segments (torch int64 view of the u64 stream, any device), in line order.  Returns the
-    segments of this rank's band [edges[rank], edges[rank + 1]), ordered by source rank and, within a source, in its line
-    order — i.e. in global line order when ranks hold ascending line ranges, which is what keeps the sort stable.
-    Segments of rows outside [0, edges[-1]) are never painted (painter/mod.rs:731-734) and are dropped here.
-    `out_alloc(n)` may provide the receive buffer (e.g. a view of the renderer's own segment buffer)."""
-    import torch
-    ty = ((seg >> 53) & 0x7FF) - 1                                       # tile row; -1 = clamped "above the canvas"
-    inner = torch.tensor(list(edges[1:-1]), dtype=torch.int64, device=seg.device)
-    owner = torch.bucketize(ty, inner, right=True)
-    owner = torch.where((ty >= edges[0]) & (ty < edges[-1]), owner, torch.full_like(owner, world))
-    order = torch.argsort(owner, stable=True)
-    counts = torch.bincount(owner, minlength=world + 1)[:world]
-    n_send = int(counts.sum())
-    send = seg[order][:n_send].contiguous()
-    if world == 1:
-        if out_alloc is None:
-            return send
-        out = out_alloc(n_send)
-        out.copy_(send)
-        return out
-    cnt_out = torch.zeros(world, dtype=torch.int64, device=seg.device)
-    dist.all_to_all_single(cnt_out, counts.contiguous())
-    out_sizes, in_sizes = [int(v) for v in cnt_out.tolist()], [int(v) for v in counts.tolist()]
-    recv = out_alloc(sum(out_sizes)) if out_alloc is not None else torch.empty(sum(out_sizes), dtype=torch.int64, device=seg.device)
-    dist.all_to_all_single(recv, send, output_split_sizes=out_sizes, input_split_sizes=in_sizes)
-    return recv
 
 
 # ---- the exchange frame, device-side (include/forma_hip.h "multi-GPU, exchange layout") -------------------------------------

@@ -184,3 +184,36 @@ def test_renderer_keeps_tables_resident_until_something_changes():
     other.get_mut_or_insert_default(api.Order(0)).insert(tri)
     r.render(other, buf()); r.render(comp, buf(cache))
     assert r._ctx.uploads == 8                                    # another composition in between: both re-upload
+
+
+def test_dropped_layers_release_their_geometry():
+    """`impl Drop for Layer` (composition/layer.rs:356-363) removes the layer's geometry id from geom_id_to_order, so
+    compact_geom (composition/mod.rs:372-384) can collect the lines of layers an application removed or replaced —
+    without it the store of an app that creates and removes layers every frame grows without bound."""
+    import gc
+    from forma_amd import api
+    comp = api.Composition()
+    tri = api.PathBuilder().move_to(api.Point(1, 1)).line_to(api.Point(9, 1)).line_to(api.Point(9, 9)).build()
+    comp.get_mut_or_insert_default(api.Order(0)).insert(tri)
+    for frame in range(6):                                       # a fresh layer at order 1 every frame, the old one dropped
+        comp.insert(api.Order(1), comp.create_layer().insert(tri))
+        gc.collect()
+        assert len(comp._shared.geom_id_to_order) == 2, frame     # order 0's id + the live order-1 layer's id
+        comp.compact_geom()
+        assert comp.builder_len() <= 2 * max(comp.actual_len(), 1) + 3
+    removed = comp.remove(api.Order(1))
+    assert removed is not None and comp._shared.geom_id_to_order[removed.geom_id()] is None   # held by the caller: still known
+    gid = removed.geom_id()
+    del removed
+    gc.collect()
+    assert gid not in comp._shared.geom_id_to_order
+    comp.compact_geom()
+    assert comp.builder_len() == comp.actual_len() == 3           # only order 0's triangle (3 lines) is left
+    lay = comp.get_mut(api.Order(0))
+    old = lay.geom_id()
+    lay.clear()                                                   # Layer::clear takes a new id; the drop must release the NEW one
+    new = lay.geom_id()
+    assert old not in comp._shared.geom_id_to_order and new in comp._shared.geom_id_to_order
+    comp.remove(api.Order(0)); del lay
+    gc.collect()
+    assert not comp._shared.geom_id_to_order

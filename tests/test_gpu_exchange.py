@@ -26,8 +26,10 @@ def scene_tables(comp):
     return o, t
 
 
-def run_ranks(t, W, H, G, clear, frames=2):
-    """G contexts on device 0 play G ranks; returns per rank (image rows of its band, its sorted stream), edges."""
+def run_ranks(t, W, H, G, clear, frames=2, check=None, geoms_per_frame=None):
+    """G contexts on device 0 play G ranks; returns per rank (image rows of its band, its sorted stream) of the LAST frame,
+    and the band edges.  Frame 1 is synchronous on every rank, the following ones are read-back-free (sort in place through
+    the chunk map).  `check(frame, out, edges)` is called after every frame."""
     import torch
     import forma_amd
     from forma_amd import sharding
@@ -37,6 +39,7 @@ def run_ranks(t, W, H, G, clear, frames=2):
     lengths = ref.prepare_lines(W, H)["lengths"]
     ref.render(W, H, clear=clear)
     full_stream = ref.segments(0)
+    ref.close()
     edges = sharding.band_edges(sharding.row_histogram(full_stream, tiles_h), G)
     cuts = sharding.line_shares(lengths, G)
     ctxs, mx = [], 0
@@ -50,7 +53,10 @@ def run_ranks(t, W, H, G, clear, frames=2):
     cap = sharding.pair_capacity(mx)
     xs = [sharding.ExchangeFrame(c, None, r, G, edges, W, H, cap) for r, c in enumerate(ctxs)]
     out = None
-    for _ in range(frames):                                            # frame 1 synchronous, frame 2 read-back-free
+    for f in range(frames):                                            # frame 1 synchronous, the others read-back-free
+        if geoms_per_frame is not None:
+            for c in ctxs:
+                c.set_geoms(geoms_per_frame[f])
         for x in xs:
             x.ctx.rasterize_bucket_frame(W, H)
         torch.cuda.synchronize()
@@ -67,9 +73,10 @@ def run_ranks(t, W, H, G, clear, frames=2):
             y0, y1 = x.crop[2], x.crop[3]
             assert (img[:y0] == 7).all() and (img[y1:] == 7).all()    # a rank writes only its own rows
             out.append((img[y0:y1].copy(), x.ctx.segments(1)))
+        if check is not None:
+            check(f, out, edges)
     for c in ctxs:
         c.close()
-    ref.close()
     return out, edges
 
 
@@ -117,6 +124,109 @@ def test_exchange_capacity_overflow_is_reported():
     x = sharding.ExchangeFrame(c, None, 0, 1, x.edges, W, H, cap)                  # re-planned
     img = x.frame(clear=(1, 1, 1, 0), device_only=False, dst=np.zeros((H, W * 4), np.uint8))
     assert np.array_equal(img, o.render(W, H))
+    c.close()
+
+
+def _full_size(workload):
+    """scene tables of a BASELINE workload (flattened on the GPU through the product API) + the oracle's frame"""
+    from forma_amd import api, scenes
+    fn, W, H = scenes.WORKLOADS[workload]
+    r = api.Renderer(0)
+    r.render(fn(), api.BufferBuilder(np.zeros(W * H * 4, np.uint8), api.LinearLayout(W, W * 4, H)).build(), api.RGBA,
+             api.Color(1, 1, 1, 1), None)
+    t = dict(r.host_tables)
+    r._ctx.close()
+    o = orc.Oracle()
+    S.load(o, t)
+    want = o.render(W, H, clear=(1.0, 1.0, 1.0, 1.0))
+    return t, W, H, want, o.segments(1)
+
+
+@pytest.fixture(scope="module")
+def triangles_10m():
+    return _full_size("triangles-10m-8k")
+
+
+@pytest.fixture(scope="module")
+def paris_like():
+    return _full_size("paris-like-30k-4k")
+
+
+def _check_full(G, data, frames=3):
+    """every rank's sorted stream == the oracle's sorted stream restricted to its band, bands stitch to the oracle's image
+    within one code value — on the synchronous first frame AND on the read-back-free frames (in-place sort of the received
+    buckets through the chunk map, sort.hip k_sort_hist<true> / k_onesweep<8, true>)"""
+    t, W, H, want, sorted_full = data
+    ty = (sorted_full >> np.uint64(53)).astype(np.int64) - 1
+    seen = []
+
+    def check(f, out, edges):
+        stitched = np.concatenate([img for img, _ in out])
+        d = np.abs(stitched.astype(np.int16) - want.astype(np.int16))
+        assert d.max() <= 1, (f, int(d.max()))
+        for r, (_, srt) in enumerate(out):
+            band = sorted_full[(ty >= edges[r]) & (ty < edges[r + 1])]
+            assert len(srt) == len(band), (f, r, len(srt), len(band))
+            assert np.array_equal(srt, band), (f, r)
+        seen.append(f)
+
+    run_ranks(t, W, H, G, (1.0, 1.0, 1.0, 1.0), frames=frames, check=check)
+    assert seen == list(range(frames))
+
+
+@pytest.mark.parametrize("G", [2, 8])
+def test_exchange_full_size_triangles_10m_8k(G, triangles_10m):
+    """BASELINE config 4 (10 M pixel segments, 8192 x 8192 — the configuration the 8-GPU target is quoted on) through the
+    exchange path with G emulated ranks: buckets of > 2048 blocks, multi-tile look-back over the chunk-mapped first pass."""
+    _check_full(G, triangles_10m)
+
+
+@pytest.mark.parametrize("G", [2, 8])
+def test_exchange_full_size_paris_like_30k_4k(G, paris_like):
+    """BASELINE config 3 stand-in (13.8 M pixel segments, 30 000 layers, gradients + blends) through the exchange path."""
+    _check_full(G, paris_like)
+
+
+def test_exchange_local_count_outgrows_its_bound_between_frames():
+    """a read-back-free bucket frame provisions for the previous frame's local segment count + 6 %.  When
+    a transform makes the scene grow past that, the excess is never rasterized — the frame must FAIL with FORMA_E_CAPACITY
+    (k_owner_scan flags it to every receiver) instead of returning a wrong image; after a re-plan it renders right."""
+    import forma_amd
+    from forma_amd import sharding, FormaError
+    W, H = 512, 384
+    o, t = scene_tables(S.random_mixed())
+    tiles_h = (H + 15) // 16
+    c = forma_amd.Context(0)
+    S.load(c, t)
+    c.rasterize_frame(W, H)
+    edges = [0, tiles_h]
+    x = sharding.ExchangeFrame(c, None, 0, 1, edges, W, H, 4 * sharding.pair_capacity(len(c.segments(0))))
+    want = o.render(W, H)
+    for _ in range(3):                                                 # synchronous, then read-back-free
+        img = x.frame(clear=(1, 1, 1, 0), device_only=False, dst=np.zeros((H, W * 4), np.uint8))
+        assert np.array_equal(img, want)
+    g = t["geoms"].copy()                                              # every layer scaled by 1.5 around the origin: N grows ~1.5x
+    g["flags"] = 1
+    g["xf"] = np.array([1.5, 0.0, 0.0, 1.5, 0.0, 0.0], np.float32)
+    o.set_geoms(g); c.set_geoms(g)
+    want2 = o.render(W, H)
+    assert len(o.segments(0)) > 1.2 * len(c.segments(0))
+    with pytest.raises(FormaError) as e:
+        x.frame(clear=(1, 1, 1, 0), device_only=False, dst=np.zeros((H, W * 4), np.uint8))
+    assert e.value.code == -4
+    c.rasterize_frame(W, H)
+    x = sharding.ExchangeFrame(c, None, 0, 1, edges, W, H, 4 * sharding.pair_capacity(len(c.segments(0))))   # re-planned
+    for _ in range(3):
+        img = x.frame(clear=(1, 1, 1, 0), device_only=False, dst=np.zeros((H, W * 4), np.uint8))
+        assert np.array_equal(img, want2)
+    g2 = t["geoms"].copy()                                             # a drift the 6 % slack covers: stays read-back-free and right
+    g2["flags"] = 1
+    g2["xf"] = np.array([1.5, 0.0, 0.0, 1.5, 3.0, 2.0], np.float32)
+    o.set_geoms(g2); c.set_geoms(g2)
+    want3 = o.render(W, H)
+    for _ in range(2):
+        img = x.frame(clear=(1, 1, 1, 0), device_only=False, dst=np.zeros((H, W * 4), np.uint8))
+        assert np.array_equal(img, want3)
     c.close()
 
 

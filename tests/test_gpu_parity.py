@@ -378,12 +378,11 @@ def test_orders_above_16_bits_use_the_global_run_sort(ctx):
         assert np.abs(want.astype(int) - got.astype(int)).max() <= 1
 
 
-def test_exchange_pipeline_on_one_gpu(ctx, mixed):
-    """The `--mode exchange` data path with world = 1: rasterize only, take the unsorted stream as a torch view of the
-    context's buffer, bucket it by tile-row owner (sharding.exchange_segments), hand it back through reserve_segments and
-    sort + paint it — same image as a plain render, received stream = the painted rows of the rasterizer's stream."""
+def test_received_stream_entry_points_on_one_gpu(ctx, mixed):
+    """forma_hip_rasterize_frame / _segments_device / _reserve_segments / _sort_paint_frame — the entry points a host-driven
+    exchange uses — with world = 1: rasterize only, take the unsorted stream as a torch view of the context's buffer, keep
+    the painted rows, hand them back through reserve_segments and sort + paint them: same image as a plain render."""
     import torch
-    from forma_amd import sharding
     o, _ = both(ctx, mixed)
     W, H = 512, 384
     tiles_h = (H + 15) // 16
@@ -393,9 +392,12 @@ def test_exchange_pipeline_on_one_gpu(ctx, mixed):
     seg = ctx.unsorted_view()
     assert seg.is_cuda and seg.numel() == len(full)
     assert np.array_equal(seg.cpu().numpy().view(np.uint64), full)
-    recv = sharding.exchange_segments(None, seg, [0, tiles_h], 1, out_alloc=ctx.reserve_view)
+    ty = ((seg >> 53) & 0x7FF) - 1
+    kept = seg[(ty >= 0) & (ty < tiles_h)]
+    recv = ctx.reserve_view(int(kept.numel()))
+    recv.copy_(kept)
     torch.cuda.synchronize()
-    ty = (full >> np.uint64(53)).astype(np.int64) - 1
-    assert np.array_equal(recv.cpu().numpy().view(np.uint64), full[(ty >= 0) & (ty < tiles_h)])
+    tyh = (full >> np.uint64(53)).astype(np.int64) - 1
+    assert np.array_equal(recv.cpu().numpy().view(np.uint64), full[(tyh >= 0) & (tyh < tiles_h)])
     got = ctx.sort_paint_frame(int(recv.numel()), W, H, clear=(0.2, 0.3, 0.4, 1.0), device_only=False)
     assert np.array_equal(got, want)

@@ -1,6 +1,6 @@
 """Pins the oracle's LayerWorkbench / optimizer-pass restatement (oracle/forma_oracle.cpp: Workbench,
 tile_unchanged_pass, skip_trivial_clips_pass, skip_fully_covered_layers_pass, drive_tile_painting) to the
-reference's own unit tests of `forma/src/cpu/painter/layer_workbench/mod.rs:475-1307` — every test of that
+reference's own unit tests of `forma/src/cpu/painter/layer_workbench/mod.rs:346-1307` — every test of that
 module except `masked_vec` (a container test; its behaviour is covered through the ids the passes leave).
 Each test below is the reference test of the same name, replayed through oracle.Workbench: same carries,
 same segments, same props, same cached tile state, same expected ids / ControlFlow / TileWriteOp."""
@@ -11,17 +11,17 @@ import scene as S
 from oracle import oracle as orc
 
 WHITEF = (1.0, 1.0, 1.0, 1.0)
-BLACKF = (0.0, 0.0, 0.0, 0.0)          # sic: the reference test module's BLACKF has alpha 0 (mod.rs:496-501)
+BLACKF = (0.0, 0.0, 0.0, 0.0)          # sic: the reference test module's BLACKF has alpha 0 (mod.rs:364-369)
 REDF = (1.0, 0.0, 0.0, 1.0)
 RED = [255, 0, 0, 255]
 WHITE = [255, 255, 255, 255]
-PARTIAL = [1] * 16                      # cover(id, CoverType::Partial), mod.rs:583-596
+PARTIAL = [1] * 16                      # cover(id, CoverType::Partial), mod.rs:452-468
 FULL = [16] * 16                        # consts::PIXEL_WIDTH
 
 CONT, BRK_NONE, BRK_SOLID = orc.Workbench.CONTINUE, orc.Workbench.BREAK_NONE, orc.Workbench.BREAK_SOLID
 
 
-def segment(layer_id):                  # mod.rs:598-600
+def segment(layer_id):                  # mod.rs:470-472
     return orc.pixel_segment(layer_id, 0, 0, 0, 0, 0, 0)
 
 
@@ -44,7 +44,7 @@ def bench(props_by_layer, unchanged=None):
 DEFAULT = S.Props()                     # Props::default(): NonZero, Draw(solid black alpha 1, Over, not clipped)
 
 
-def test_populate_layers():             # mod.rs:602-661
+def test_populate_layers():             # mod.rs:474-537
     o, wb = bench({i: DEFAULT for i in range(6)})
     wb.init([(0, PARTIAL), (3, PARTIAL), (4, PARTIAL)])
     wb.context([segment(0), segment(1), segment(1), segment(2), segment(5), segment(5), segment(5)],
@@ -55,7 +55,7 @@ def test_populate_layers():             # mod.rs:602-661
     assert [wb.queue_index(i) for i in range(6)] == [0, None, None, 1, 2, None]
 
 
-def test_skip_unchanged():              # mod.rs:663-760
+def test_skip_unchanged():              # mod.rs:539-653
     o, wb = bench({i: DEFAULT for i in range(6)}, unchanged=lambda lid: lid < 5)
     wb.cached_tile(layer_count=4)
     segs = [segment(i) for i in range(5)]
@@ -80,7 +80,7 @@ def test_skip_unchanged():              # mod.rs:663-760
     assert wb.cached_tile_state()[0] == 5
 
 
-def test_skip_full_clip():              # mod.rs:762-819
+def test_skip_full_clip():              # mod.rs:655-714
     props = {0: DEFAULT, 1: S.Props(clip=1), 2: S.Props(is_clipped=True), 3: S.Props(clip=1)}
     o, wb = bench(props)
     wb.init([(0, PARTIAL), (1, FULL), (2, PARTIAL), (3, FULL)])
@@ -92,7 +92,7 @@ def test_skip_full_clip():              # mod.rs:762-819
     assert wb.skip_clipping_contains(2)
 
 
-def test_skip_layer_outside_of_clip():  # mod.rs:821-863
+def test_skip_layer_outside_of_clip():  # mod.rs:716-760
     o, wb = bench({0: S.Props(is_clipped=True), 1: S.Props(is_clipped=True)})
     wb.init([(0, PARTIAL), (1, PARTIAL)])
     wb.context([], cached_clear_color=BLACKF, clear_color=BLACKF)
@@ -101,7 +101,7 @@ def test_skip_layer_outside_of_clip():  # mod.rs:821-863
     assert wb.ids() == []
 
 
-def test_skip_without_layer_usage():    # mod.rs:865-914
+def test_skip_without_layer_usage():    # mod.rs:762-811
     props = {0: DEFAULT, 1: S.Props(clip=1), 3: DEFAULT, 4: S.Props(clip=1)}
     o, wb = bench(props)
     wb.init([(0, PARTIAL), (1, PARTIAL), (3, PARTIAL), (4, PARTIAL)])
@@ -111,7 +111,7 @@ def test_skip_without_layer_usage():    # mod.rs:865-914
     assert wb.ids() == [0, 3]
 
 
-def test_skip_everything_below_opaque():    # mod.rs:916-966
+def test_skip_everything_below_opaque():    # mod.rs:813-858
     o, wb = bench({i: DEFAULT for i in range(4)})
     wb.init([(0, PARTIAL), (1, PARTIAL), (2, FULL)])
     wb.context([segment(3)], cached_clear_color=BLACKF, clear_color=BLACKF)
@@ -124,7 +124,7 @@ def gray50(blend):
     return S.Props(fill=(0.5, 0.5, 0.5, 0.5), blend_mode=blend)
 
 
-def test_blend_top_full_layers():       # mod.rs:968-1029
+def test_blend_top_full_layers():       # mod.rs:860-920
     o, wb = bench({0: gray50("Over"), 1: gray50("Multiply")})
     wb.init([(0, FULL), (1, FULL)])
     wb.context([], cached_clear_color=BLACKF, clear_color=BLACKF)
@@ -132,7 +132,7 @@ def test_blend_top_full_layers():       # mod.rs:968-1029
     assert wb.skip_fully_covered_layers_pass() == (BRK_SOLID, (0.28125, 0.28125, 0.28125, 0.75))
 
 
-def test_blend_top_full_layers_with_clear_color():   # mod.rs:1031-1087
+def test_blend_top_full_layers_with_clear_color():   # mod.rs:922-978
     o, wb = bench({0: gray50("Multiply"), 1: gray50("Multiply")})
     wb.init([(0, FULL), (1, FULL)])
     wb.context([], cached_clear_color=WHITEF, clear_color=WHITEF)
@@ -140,7 +140,7 @@ def test_blend_top_full_layers_with_clear_color():   # mod.rs:1031-1087
     assert wb.skip_fully_covered_layers_pass() == (BRK_SOLID, (0.5625, 0.5625, 0.5625, 1.0))
 
 
-def test_skip_fully_covered_layers_clip():           # mod.rs:1089-1139
+def test_skip_fully_covered_layers_clip():           # mod.rs:980-1029
     o, wb = bench({0: S.Props(clip=1), 1: S.Props(blend_mode="Multiply")})
     wb.init([(0, PARTIAL), (1, FULL)])
     wb.context([], cached_clear_color=WHITEF, clear_color=WHITEF)
@@ -148,14 +148,14 @@ def test_skip_fully_covered_layers_clip():           # mod.rs:1089-1139
     assert wb.skip_fully_covered_layers_pass()[0] == CONT
 
 
-def test_skip_clip_then_blend():        # mod.rs:1141-1189
+def test_skip_clip_then_blend():        # mod.rs:1031-1080
     o, wb = bench({0: S.Props(clip=1), 1: gray50("Multiply")})
     wb.init([(0, PARTIAL), (1, FULL)])
     wb.context([], cached_clear_color=WHITEF, clear_color=WHITEF)
     assert wb.drive_tile_painting() == (orc.Workbench.OP_SOLID, [224, 224, 224, 255])
 
 
-def test_skip_visible_is_unchanged():   # mod.rs:1191-1305
+def test_skip_visible_is_unchanged():   # mod.rs:1082-1217
     props = {0: DEFAULT, 1: DEFAULT, 2: S.Props(fill=REDF)}
     o, wb = bench(props, unchanged=lambda lid: lid != 0)
     wb.init([(0, PARTIAL), (1, PARTIAL), (2, FULL)])
@@ -183,7 +183,7 @@ def test_skip_visible_is_unchanged():   # mod.rs:1191-1305
     assert wb.skip_fully_covered_layers_pass() == (BRK_SOLID, REDF)
 
 
-def test_skip_solid_color_is_unchanged():   # mod.rs:1307-1391
+def test_skip_solid_color_is_unchanged():   # mod.rs:1219-1305
     o, wb = bench({0: S.Props(fill=REDF)})
     wb.init([(0, FULL)])
     wb.cached_tile(use=False)
@@ -208,7 +208,7 @@ def test_skip_solid_color_is_unchanged():   # mod.rs:1307-1391
 
 
 def test_masked_ids_after_mask_and_skip():
-    """MaskedVec::{set_mask, skip_until, iter_masked} (mod.rs:60-118, test `masked_vec` :540-575) as the passes use it:
+    """MaskedVec::{set_mask, skip_until, iter_masked} (mod.rs:64-118, test `masked_vec` :417-450) as the passes use it:
     a full opaque cover in the middle hides everything below (skip_until), a full clip is masked out (set_mask)."""
     props = {0: DEFAULT, 1: DEFAULT, 2: S.Props(fill=REDF), 3: S.Props(clip=2), 4: S.Props(is_clipped=True), 6: DEFAULT}
     o, wb = bench(props)

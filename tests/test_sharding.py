@@ -101,56 +101,6 @@ def test_line_shares_and_geometry_slices():
     assert all(len(a) == 0 for a in sharding.slice_geometry(x, y, ls, 4, 4))
 
 
-def _exchange_worker(rank, world, port, out_dir):
-    import sys
-    import torch
-    import torch.distributed as dist
-    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    import scene as S
-    from oracle import oracle as orc
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
-    W, H = 200, 150
-    tiles_h = (H + 15) // 16
-    clear = (0.1, 0.2, 0.3, 1.0)
-    comp = S.random_mixed(n=120, width=W, height=H, seed=5)
-    ref = orc.Oracle()
-    t = comp.tables(ref)
-    S.load(ref, t)
-    full = ref.render(W, H, clear=clear)
-    full_stream = ref.segments(0)
-    sums = ref.prepare_lines(W, H)["lengths"]                           # inclusive prefix sums
-    edges = sharding.agree_on_bands(dist, sharding.row_histogram(full_stream, tiles_h), world)
-    cuts = sharding.line_shares(sums, world)
-    # this rank rasterizes only ITS lines (the scene tables are replicated, the geometry is sliced) ...
-    o = orc.Oracle()
-    S.load(o, t)
-    o.set_geometry(*sharding.slice_geometry(t["x"], t["y"], t["line_slot"], cuts[rank], cuts[rank + 1]))
-    o.prepare_lines(W, H)
-    mine = o.rasterize()
-    total = torch.tensor([len(mine)], dtype=torch.int64)
-    dist.all_reduce(total)
-    assert int(total) == len(full_stream)                              # the shares partition the stream
-    # ... and the pixel segments travel to the owner of their tile row
-    got = sharding.exchange_segments(dist, torch.from_numpy(mine.view(np.int64).copy()), edges, world).numpy().view(np.uint64)
-    ty = (full_stream >> np.uint64(53)).astype(np.int64) - 1
-    want = full_stream[(ty >= edges[rank]) & (ty < edges[rank + 1])]
-    assert np.array_equal(got, want)                                   # same segments, same (global line) order
-    srt = got[np.argsort(got >> np.uint64(20), kind="stable")]
-    x0, x1, y0, y1 = sharding.band_crop(edges, rank, W, H)
-    band = ref.paint(srt, W, H, clear=clear, crop=(x0, x1, y0, y1), dst=np.full((H, W * 4), 7, np.uint8))
-    assert np.array_equal(band[y0:y1], full[y0:y1])
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-def test_two_rank_exchange_protocol_gloo(tmp_path):
-    """`bench.py --mode exchange` on CPU: line-sharded rasterization, all-to-all of pixel segments by tile-row owner, band-local
-    sort + paint — the received stream is the band's slice of the single-GPU stream in the same order, the bands stitch."""
-    import torch.multiprocessing as mp
-    world = 2
-    mp.spawn(_exchange_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-
-
 def _padded_worker(rank, world, port, out_dir):
     """The device-side exchange protocol (forma_hip_rasterize_bucket_frame -> equal-split all-to-all of counts and padded
     buckets -> forma_hip_gather_sort_paint_frame) with the bucket / gather kernels restated in numpy: what crosses the
