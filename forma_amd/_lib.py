@@ -16,7 +16,7 @@ SO_PATH = os.path.join(CSRC, "libforma_hip.so")
 NONE = 0xFFFFFFFF
 
 ERRORS = {0: "FORMA_OK", -1: "FORMA_E_ARG", -2: "FORMA_E_HIP", -3: "FORMA_E_NO_DEVICE", -4: "FORMA_E_CAPACITY",
-          -5: "FORMA_E_STATE", -6: "FORMA_E_INTERNAL"}
+          -5: "FORMA_E_STATE", -6: "FORMA_E_INTERNAL", -7: "FORMA_E_COMM"}
 
 
 class FormaError(RuntimeError):
@@ -59,6 +59,7 @@ class FlattenTablesT(C.Structure):
 _vp, _sz, _u32, _i = C.c_void_p, C.c_size_t, C.c_uint32, C.c_int
 SYMBOLS = {
     "forma_hip_create": (_i, [C.POINTER(_vp), _i]),
+    "forma_hip_create_multi": (_i, [C.POINTER(_vp), C.POINTER(_i), _i]),
     "forma_hip_destroy": (None, [_vp]),
     "forma_hip_last_error": (C.c_char_p, [_vp]),
     "forma_hip_version": (C.c_char_p, []),
@@ -73,6 +74,8 @@ SYMBOLS = {
     "forma_hip_paint": (_i, [_vp, _vp, _sz, _vp, _u32, _u32, _sz, _vp, _vp, _vp]),
     "forma_hip_render": (_i, [_vp, _vp, _u32, _u32, _sz, _vp, _vp, _vp, _i, _vp]),
     "forma_hip_cache_clear": (_i, [_vp, _i]),
+    "forma_hip_set_frames_in_flight": (_i, [_vp, _i]),
+    "forma_hip_sync": (_i, [_vp]),
     "forma_hip_read_segments": (_i, [_vp, _i, _vp, _sz, _vp]),
     "forma_hip_read_image": (_i, [_vp, _vp, _sz]),
     "forma_hip_tiles_written": (_i, [_vp, _vp, _sz]),

@@ -694,8 +694,11 @@ class BufferBuilder:
 class Renderer:
     """`forma::hip::Renderer`: same three methods as `cpu::Renderer` (cpu/renderer.rs:61-224)."""
 
-    def __init__(self, device: int = 0):
-        self._ctx = Context(device)
+    def __init__(self, device: int = 0, devices=None, frames_in_flight: int = 1):
+        """`Renderer::new()` (cpu/renderer.rs:63-65).  `devices`: one renderer over several GPUs of this process
+        (forma_hip_create_multi — the Rust shim's `Renderer::with_devices`); `frames_in_flight`: device-resident frames
+        are pipelined inside the renderer (forma_hip_set_frames_in_flight)."""
+        self._ctx = Context(device, devices=devices, frames_in_flight=frames_in_flight)
         self._caches = set()
         self._geom_version = None
         self._geom_owner = None

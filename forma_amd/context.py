@@ -17,17 +17,35 @@ def _p(a):
 
 
 class Context:
-    """One forma_hip_ctx = one GPU, one HIP stream (reference `cpu::Renderer`, cpu/renderer.rs:55-73)."""
+    """One forma_hip_ctx (reference `cpu::Renderer`, cpu/renderer.rs:55-73): one GPU and one HIP stream, or — `devices` —
+    several GPUs behind the same calls (forma_hip_create_multi: line-sharded rasterization, one RCCL all-to-all of pixel
+    segments, band-local sort + paint, every device writing its rows of the caller's buffer)."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, devices=None, frames_in_flight: int = 1):
         self._L = _lib.lib()
         h = C.c_void_p()
-        rc = self._L.forma_hip_create(C.byref(h), device)
+        if devices is not None:
+            devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+            rc = self._L.forma_hip_create_multi(C.byref(h), devs, len(devices))
+            device = int(devices[0])
+        else:
+            rc = self._L.forma_hip_create(C.byref(h), device)
         if rc != 0:
             raise FormaError(rc, "forma_hip_create (needs a visible MI355X; there is no CPU fallback)")
         self._h = h
         self.device = device
+        self.devices = None if devices is None else [int(d) for d in devices]
         self.n_points = 0
+        if frames_in_flight != 1:
+            self.set_frames_in_flight(frames_in_flight)
+
+    def set_frames_in_flight(self, n: int):
+        """forma_hip_set_frames_in_flight: device-resident, cache-less frames are enqueued on n frame slots; see sync()"""
+        self._check(self._L.forma_hip_set_frames_in_flight(self._h, int(n)))
+
+    def sync(self):
+        """forma_hip_sync: wait for every enqueued frame, raise the first error one of them produced"""
+        self._check(self._L.forma_hip_sync(self._h))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -1,126 +1,21 @@
 // api.cpp — the C ABI of libforma_hip.so (include/forma_hip.h): context, device buffers, frame
 // orchestration on one HIP stream.  Product code: nothing here (or anywhere in forma_amd/) touches
 // oracle/.  Errors never unwind across the ABI: every entry point returns a FORMA_E_* code.
-#include <algorithm>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
 #include <new>
-#include <vector>
 
-#include "common.h"
+#include "ctx.h"
 
-namespace {
-
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    hipError_t ensure(size_t bytes) {
-        if (bytes <= cap && p) return hipSuccess;
-        size_t want = std::max(bytes, cap + cap / 2);
-        want = std::max<size_t>(want, 256);
-        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
-        hipError_t e = hipMalloc(&p, want);
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-    template <class T> T* as() const { return (T*)p; }
-};
-
-constexpr int MAX_PASS_EVENTS = 16;
-constexpr size_t SEG_PAD = 16;          // segment buffers are over-allocated: stream kernels read whole 64-byte lane pieces
-enum { ST_PREPARE = 0, ST_RASTER, ST_SORT, ST_CARRY, ST_PAINT, ST_D2H, ST_XCHG, ST_COUNT };
-
-}  // namespace
-
-struct forma_hip_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    char err[512] = {0};
-
-    // scene
-    DevBuf x, y, line_slot, geoms, style_off, style_words, unchanged, images, texels;
-    DevBuf layer_sf, layer_col;             // per order: style summary for the carry pre-pass (set_styles)
-    std::vector<uint32_t> h_layer_sf, h_layer_col;
-    size_t n_points = 0, n_geoms = 0, n_orders = 0, n_words = 0, n_images = 0;
-    uint32_t max_geom_order = 0;            // largest order any geom slot names (FORMA_NONE slots aside)
-    uint32_t max_image_index = 0;           // largest image index a texture style names
-    bool any_texture = false;
-    bool scene_has_clips = false;
-    bool have_unchanged = false;            // set_styles supplied per-order Layer::is_unchanged bytes
-    // lines
-    DevBuf l_order, l_x0, l_y0, l_dx, l_dy, l_a, l_b, l_c, l_d, l_len, scan_tmp;   // parity entry points only
-    DevBuf cl_idx, cl_start, block_first, prep_scratch;                              // frame path: compacted line table
-    DevBuf ras_masks;                       // k_rasterize: key masks per workgroup (8 words), combined by k_reduce_masks
-    PendingMasks pending_masks{nullptr, 0u}; // ... or, on read-back-free frames, by k_runs_count
-    size_t n_lines = 0, n_compact = 0;
-    // segments
-    DevBuf seg_u, seg_a, seg_b, sort_counters;
-    uint64_t* sorted = nullptr;
-    size_t n_seg = 0;
-    bool have_unsorted = false;
-    uint64_t live44 = 0xFFFFFFFFFFFull;     // varying bits of (v >> 20)
-    bool layer_sorted = false;              // rasterizer stream is non-decreasing in layer
-    int digit_bits = 8;                     // radix digit width: 8 (default) or 4 (FORMA_HIP_DIGIT_BITS)
-    // paint
-    DevBuf info_init;                       // pristine FrameInfo (reset template)
-    // buffer-layer caches (reference cpu/buffer/mod.rs:113-197): per cache the CachedTile table, the device image the
-    // cache's buffer shows (tiles the painter skips keep last frame's pixels), and the cached clear colour
-    struct TileCache {
-        DevBuf tiles, image;
-        uint32_t w = 0, h = 0;
-        bool has_clear = false;
-        float clear[4] = {0, 0, 0, 0};
-    };
-    TileCache caches[32];
-    DevBuf cache_written;                   // one byte per tile: written this frame
-    uint8_t* h_written = nullptr;           // pinned copy of cache_written
-    size_t h_written_cap = 0;
-    uint8_t* h_stage = nullptr;             // pinned staging image for tile-granular copy-out
-    size_t h_stage_cap = 0;
-    int cur_cache = -1;                     // cache of the frame in flight
-    uint8_t* cur_image = nullptr;           // device image of the frame in flight / last frame
-    // sort-plan speculation: the varying-bit mask and the layer-sortedness of a scene rarely change between frames, so
-    // forma_hip_render plans the sort from the previous frame's values and verifies them when the frame is done
-    bool pred_valid = false, pred_layer_sorted = false, speculated = false;
-    bool global_runsort = false;           // FORMA_HIP_GLOBAL_RUNSORT=1: never order a row's runs in LDS (test switch)
-    bool legacy_runs = false;              // FORMA_HIP_LEGACY_RUNS=1: run detection by the workgroup-per-tile kernel (A/B switch)
-    bool pred_counts_valid = false, no_async = false;    // N / J predictions for read-back-free frames (FORMA_HIP_SYNC=1 disables)
-    uint32_t pred_N = 0, pred_J = 0, pred_w = 0, pred_h = 0;
-    uint64_t pred_live44 = 0;
-    DevBuf info, records, rk_u, rk_a, rk_b, blk_edge, runs_scratch, row_tab, span_key, span_cov, image;
-    uint32_t img_w = 0, img_h = 0;
-    FrameInfo* h_info = nullptr;            // pinned
-    uint32_t* h_rows = nullptr;             // pinned: runs per tile row (synchronous frames), 2049 words
-    uint32_t pred_max_row = 0xFFFFFFFFu;    // most runs in one tile row of the last verified frame (unknown: no local sort)
-    // band
-    uint32_t band_row0 = 0, band_row1 = 0;
-    // multi-GPU exchange (forma_hip_exchange_plan): owner bands, per-pair capacity, send / receive buckets and their counts
-    OwnerBands xbands{};
-    uint32_t xcap = 0;
-    bool xplanned = false;
-    DevBuf xsend, xrecv, xsend_counts, xrecv_counts, xscratch, xmask;
-    bool xgather_always = false;              // FORMA_HIP_XGATHER=1: materialise the received stream before sorting it
-    bool xpred_valid = false;               // the local rasterized count of the previous exchange frame is known
-    uint32_t xpred_N = 0, xpred_w = 0, xpred_h = 0;
-    uint32_t* h_xlocal = nullptr;           // pinned: [0] = local segment count of the last bucket frame (copied on the stream), [1] = 1 when pending
-    // timing
-    hipEvent_t ev0[ST_COUNT], ev1[ST_COUNT], pev0[MAX_PASS_EVENTS], pev1[MAX_PASS_EVENTS];
-    bool stage_used[ST_COUNT];
-    int n_passes = 0;
-    uint32_t last_runs = 0, last_entries = 0, last_written = 0;
-    // what the last frame wrote, for forma_hip_tiles_written (host-side Flusher / generic Layout::write)
-    uint32_t lw_tiles_w = 0, lw_tiles_h = 0, lw_tx0 = 0, lw_tx1 = 0, lw_ty0 = 0, lw_ty1 = 0;
-    bool lw_valid = false, lw_cache = false, lw_flags_on_host = false;
-};
-
-namespace {
-
-int fail(forma_hip_ctx* c, int code, const char* what, hipError_t e = hipSuccess) {
+int fd_fail(forma_hip_ctx* c, int code, const char* what, hipError_t e) {
     if (c) snprintf(c->err, sizeof c->err, "%s%s%s", what, e != hipSuccess ? ": " : "", e != hipSuccess ? hipGetErrorString(e) : "");
     return code;
 }
+
+namespace {
+
+inline int fail(forma_hip_ctx* c, int code, const char* what, hipError_t e = hipSuccess) { return fd_fail(c, code, what, e); }
+void share_scene(forma_hip_ctx* o);                        // (defined with the frame-slot code below)
+void invalidate_counts(forma_hip_ctx* o);
+inline forma_hip_ctx* last_slot(forma_hip_ctx* ctx) { return ctx->last ? ctx->last : ctx; }
 #define HIPCHECK(expr)                                                        \
     do {                                                                      \
         hipError_t _e = (expr);                                               \
@@ -177,7 +72,8 @@ int run_line_table(forma_hip_ctx* ctx, const LineSource& src, size_t n_lines, bo
 LineSource geometry_source(forma_hip_ctx* ctx, uint32_t width, uint32_t height) {
     LineSource S;
     memset(&S, 0, sizeof S);
-    S.x = ctx->x.as<float>(); S.y = ctx->y.as<float>(); S.line_slot = ctx->line_slot.as<uint32_t>();
+    const size_t l0 = ctx->line_ranged ? ctx->line_lo : 0;              // a share of the lines: line i joins points i and i + 1
+    S.x = ctx->x.as<float>() + l0; S.y = ctx->y.as<float>() + l0; S.line_slot = ctx->line_slot.as<uint32_t>() + l0;
     S.geoms = ctx->geoms.as<forma_geom_t>(); S.n_geoms = (uint32_t)ctx->n_geoms;
     S.width = (float)width; S.height = (float)height;
     S.band_lo = -3.0e38f; S.band_hi = 3.0e38f;
@@ -200,7 +96,8 @@ int finish_rasterize(forma_hip_ctx* ctx) {
 // bound_n segments, the sort plan is the speculated one.
 int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, bool timing, bool speculate = false,
                         uint32_t bound_n = 0) {
-    const size_t n_lines = ctx->n_points ? ctx->n_points - 1 : 0;
+    const size_t all_lines = ctx->n_points ? ctx->n_points - 1 : 0;
+    const size_t n_lines = ctx->line_ranged ? std::min(ctx->line_hi, all_lines) - std::min(ctx->line_lo, all_lines) : all_lines;
     ctx->n_lines = n_lines;
     ctx->n_seg = 0; ctx->n_compact = 0; ctx->have_unsorted = true; ctx->live44 = 0; ctx->layer_sorted = true;
     ctx->speculated = false;
@@ -536,6 +433,20 @@ int upload(forma_hip_ctx* ctx, DevBuf& b, const T* src, size_t n) {
 
 }  // namespace
 
+// entry points that work on the context's own frame buffers: frames in flight are finished first; on a multi-device context
+// the stage entry points (host arrays in, host arrays out) run on its first device, the single-device frame plumbing is refused
+#define ENTER_STAGE(ctx)                                                                        \
+    do {                                                                                        \
+        if (ctx->multi) ctx = multi_first(ctx);                                                 \
+        else { const int _rc = fd_drain(ctx); if (_rc) return _rc; ctx->last = ctx; }           \
+    } while (0)
+#define ENTER_SINGLE(ctx)                                                                       \
+    do {                                                                                        \
+        if (!ctx) return FORMA_E_ARG;                                                           \
+        if (ctx->multi) return fail(ctx, FORMA_E_STATE, "not available on a multi-device context (forma_hip_render does the whole frame)"); \
+        const int _rc = fd_drain(ctx); if (_rc) return _rc; ctx->last = ctx;                    \
+    } while (0)
+
 extern "C" {
 
 const char* forma_hip_version(void) { return "forma_hip 0.1.0 gfx950"; }
@@ -582,8 +493,21 @@ int forma_hip_create(forma_hip_ctx** out, int device) {
     return FORMA_OK;
 }
 
+int forma_hip_create_multi(forma_hip_ctx** out, const int* devices, int n) {
+    if (!out || !devices || n < 1 || n > FORMA_MAX_RANKS) return FORMA_E_ARG;
+    // one device: a plain context, unless FORMA_HIP_FORCE_EXCHANGE=1 asks for the exchange path with a world of one
+    // (rehearsal on single-GPU machines: same planner, same workers, same collective calls)
+    if (n == 1 && !getenv("FORMA_HIP_FORCE_EXCHANGE")) return forma_hip_create(out, devices[0]);
+    return multi_create(out, devices, n);
+}
+
 void forma_hip_destroy(forma_hip_ctx* ctx) {
     if (!ctx) return;
+    if (ctx->multi) { multi_destroy(ctx); return; }
+    (void)hipSetDevice(ctx->device);
+    (void)fd_drain(ctx);
+    for (forma_hip_ctx* sl : ctx->slots) if (sl != ctx) { sl->owner = nullptr; forma_hip_destroy(sl); }
+    ctx->slots.clear();
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     DevBuf* all[] = {&ctx->x, &ctx->y, &ctx->line_slot, &ctx->geoms, &ctx->style_off, &ctx->style_words, &ctx->layer_sf, &ctx->layer_col, &ctx->unchanged,
@@ -616,15 +540,17 @@ int forma_hip_set_geometry(forma_hip_ctx* ctx, const float* x, const float* y, c
     if (n_points && (!x || !y)) return fail(ctx, FORMA_E_ARG, "null geometry");
     if (n_points > 1 && !line_slot) return fail(ctx, FORMA_E_ARG, "null line_slot");
     if (n_points >= (1ull << 30)) return fail(ctx, FORMA_E_ARG, "too many points");
+    if (ctx->multi) return multi_set_geometry(ctx, x, y, line_slot, n_points);
     HIPCHECK(hipSetDevice(ctx->device));
     int rc;
+    if ((rc = fd_drain(ctx))) return rc;                  // frames in flight still read the old buffers
     if ((rc = upload(ctx, ctx->x, x, n_points))) return rc;
     if ((rc = upload(ctx, ctx->y, y, n_points))) return rc;
     if ((rc = upload(ctx, ctx->line_slot, line_slot, n_points ? n_points - 1 : 0))) return rc;
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     ctx->n_points = n_points;
-    ctx->pred_counts_valid = false;                       // new geometry: the next frame re-learns N and J synchronously
-    ctx->xpred_valid = false;
+    invalidate_counts(ctx);                               // new geometry: the next frame re-learns N and J synchronously
+    share_scene(ctx);
     return FORMA_OK;
 }
 
@@ -637,11 +563,14 @@ int forma_hip_set_geoms(forma_hip_ctx* ctx, const forma_geom_t* geoms, size_t n_
             return fail(ctx, FORMA_E_ARG, "order exceeds LAYER_LIMIT");
         max_order = std::max(max_order, geoms[i].order);
     }
+    if (ctx->multi) return multi_set_geoms(ctx, geoms, n_geoms);
     HIPCHECK(hipSetDevice(ctx->device));
-    int rc = upload(ctx, ctx->geoms, geoms, n_geoms);
+    int rc = fd_drain(ctx);
     if (rc) return rc;
+    if ((rc = upload(ctx, ctx->geoms, geoms, n_geoms))) return rc;
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     ctx->n_geoms = n_geoms; ctx->max_geom_order = max_order;
+    share_scene(ctx);
     return FORMA_OK;
 }
 
@@ -649,6 +578,7 @@ int forma_hip_set_styles(forma_hip_ctx* ctx, const uint32_t* style_offsets, size
                          size_t n_words, const uint8_t* unchanged) {
     if (!ctx || (n_orders && !style_offsets) || (n_words && !style_words)) return fail(ctx, FORMA_E_ARG, "null styles");
     if (n_orders > (size_t)FORMA_LAYER_LIMIT + 1) return fail(ctx, FORMA_E_ARG, "order exceeds LAYER_LIMIT");
+    if (ctx->multi) return multi_set_styles(ctx, style_offsets, n_orders, style_words, n_words, unchanged);
     bool clips = false;
     // per order: what the carry pre-pass attaches to every run and span of the layer (one gather instead of a chain through
     // the offset table and the style words): SF_* flags and the four words the painter's fast paths read
@@ -682,6 +612,7 @@ int forma_hip_set_styles(forma_hip_ctx* ctx, const uint32_t* style_offsets, size
     }
     HIPCHECK(hipSetDevice(ctx->device));
     int rc;
+    if ((rc = fd_drain(ctx))) return rc;
     if ((rc = upload(ctx, ctx->style_off, style_offsets, n_orders))) return rc;
     if ((rc = upload(ctx, ctx->style_words, style_words, n_words))) return rc;
     if ((rc = upload(ctx, ctx->layer_sf, ctx->h_layer_sf.data(), n_orders))) return rc;
@@ -691,6 +622,7 @@ int forma_hip_set_styles(forma_hip_ctx* ctx, const uint32_t* style_offsets, size
     ctx->n_orders = n_orders; ctx->n_words = n_words; ctx->scene_has_clips = clips;
     ctx->have_unchanged = unchanged != nullptr;
     ctx->any_texture = any_texture; ctx->max_image_index = max_image;
+    share_scene(ctx);
     return FORMA_OK;
 }
 
@@ -700,12 +632,15 @@ int forma_hip_set_images(forma_hip_ctx* ctx, const forma_image_t* images, size_t
     for (size_t i = 0; i < n_images; i++)
         if (images[i].texel_offset + (uint64_t)images[i].width * images[i].height > n_texels || images[i].width == 0 || images[i].height == 0)
             return fail(ctx, FORMA_E_ARG, "image outside texel pool");
+    if (ctx->multi) return multi_set_images(ctx, images, n_images, texels, n_texels);
     HIPCHECK(hipSetDevice(ctx->device));
     int rc;
+    if ((rc = fd_drain(ctx))) return rc;
     if ((rc = upload(ctx, ctx->images, images, n_images))) return rc;
     if ((rc = upload(ctx, ctx->texels, texels, n_texels * 4))) return rc;
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     ctx->n_images = n_images;
+    share_scene(ctx);
     return FORMA_OK;
 }
 
@@ -713,6 +648,7 @@ int forma_hip_set_images(forma_hip_ctx* ctx, const forma_image_t* images, size_t
 int forma_hip_flatten(forma_hip_ctx* ctx, const forma_flatten_tables_t* t, float* out_x, float* out_y) {
     if (!ctx || !t || (t->n_points && (!out_x || !out_y))) return fail(ctx, FORMA_E_ARG, "null flatten tables");
     if (t->n_points == 0) return FORMA_OK;
+    if (ctx->multi) ctx = multi_first(ctx);
     HIPCHECK(hipSetDevice(ctx->device));
     std::vector<void*> owned;
     auto up = [&](const void* src, size_t bytes, const void** dst) -> hipError_t {
@@ -756,6 +692,7 @@ int forma_hip_flatten(forma_hip_ctx* ctx, const forma_flatten_tables_t* t, float
 int forma_hip_prepare_lines(forma_hip_ctx* ctx, uint32_t width, uint32_t height, uint32_t* orders, float* x0, float* y0,
                             float* dx, float* dy, float* a, float* b, float* c, float* d, uint32_t* lengths) {
     if (!ctx) return FORMA_E_ARG;
+    ENTER_STAGE(ctx);
     HIPCHECK(hipSetDevice(ctx->device));
     const size_t n = ctx->n_points ? ctx->n_points - 1 : 0;
     if (n && (!orders || !x0 || !y0 || !dx || !dy || !a || !b || !c || !d || !lengths)) return fail(ctx, FORMA_E_ARG, "null output");
@@ -787,6 +724,7 @@ int forma_hip_rasterize(forma_hip_ctx* ctx, size_t n_lines, const uint32_t* orde
     *out_n = 0;
     if (n_lines == 0) return FORMA_OK;
     if (!orders || !x0 || !y0 || !dx || !dy || !a || !b || !c || !d || !lengths) return fail(ctx, FORMA_E_ARG, "null line arrays");
+    ENTER_STAGE(ctx);
     HIPCHECK(hipSetDevice(ctx->device));
     const size_t N = lengths[n_lines - 1];
     *out_n = N;
@@ -829,6 +767,7 @@ int forma_hip_sort(forma_hip_ctx* ctx, uint64_t* segments, size_t n, int digit_b
     if (digit_bits != 0 && digit_bits != 4 && digit_bits != 8) return fail(ctx, FORMA_E_ARG, "digit_bits must be 0, 4 or 8");
     if (n > 0xFFFFFFF0ull) return fail(ctx, FORMA_E_ARG, "too many segments");   // u32 prefix sums, segment.rs:90-98
     if (n == 0) return FORMA_OK;
+    ENTER_STAGE(ctx);
     HIPCHECK(hipSetDevice(ctx->device));
     HIPCHECK(ctx->seg_u.ensure((n + SEG_PAD) * 8));
     HIPCHECK(hipMemcpyAsync(ctx->seg_u.p, segments, n * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -849,6 +788,7 @@ int forma_hip_paint(forma_hip_ctx* ctx, const uint64_t* sorted_segments, size_t 
     if (!ctx || (n && !sorted_segments)) return FORMA_E_ARG;
     int rc = check_paint_args(ctx, dst, width, height, stride_bytes, channels, clear_color);
     if (rc) return rc;
+    ENTER_STAGE(ctx);
     HIPCHECK(hipSetDevice(ctx->device));
     clear_stage_flags(ctx);
     if ((rc = reset_info(ctx))) return rc;
@@ -864,48 +804,55 @@ int forma_hip_paint(forma_hip_ctx* ctx, const uint64_t* sorted_segments, size_t 
 }
 
 // ---- the frame ---------------------------------------------------------------------------------------
-int forma_hip_render(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t height, size_t stride_bytes,
-                     const uint8_t channels[4], const float clear_color[4], const forma_rect_t* crop_or_null, int cache_id,
-                     forma_timings_t* timings) {
-    if (!ctx) return FORMA_E_ARG;
-    int rc = check_paint_args(ctx, dst, width, height, stride_bytes, channels, clear_color);
-    if (rc) return rc;
-    if (cache_id >= 32) return fail(ctx, FORMA_E_ARG, "cache_id out of range");   // SmallBitSet u32, small_bit_set.rs:17-57
-    HIPCHECK(hipSetDevice(ctx->device));
-    const bool timing = timings != nullptr;
-    clear_stage_flags(ctx);
-    if (width != ctx->pred_w || height != ctx->pred_h) { ctx->pred_counts_valid = false; ctx->pred_w = width; ctx->pred_h = height; }
-    PaintArgs a{width, height, channels, clear_color, crop_or_null, cache_id};
-    auto frame_done = [&](int r) {                       // renderer.rs:217-218: remember the clear colour in the cache
-        if (r == FORMA_OK && cache_id >= 0) { ctx->caches[cache_id].has_clear = true; memcpy(ctx->caches[cache_id].clear, clear_color, 16); }
-        return r;
-    };
-    // 1. fully asynchronous attempt: no read-back inside the frame.  N, J and the sort plan are predicted from the previous
-    //    frame (bounds with slack); device-side guards keep a wrong guess memory-safe; verified when the frame is done.
-    if (ctx->pred_valid && ctx->pred_counts_valid && !ctx->no_async) {
-        const uint32_t bN = ctx->pred_N + ctx->pred_N / 16 + 4096, bJ = ctx->pred_J + ctx->pred_J / 16 + 4096;
-        FrameInfo* dinfo = ctx->info.as<FrameInfo>();
-        if ((rc = run_rasterize_frame(ctx, width, height, timing, true, bN))) return rc;
-        if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), DevCount{&dinfo->n_segments, bN}, timing))) return rc;
-        if ((rc = run_paint(ctx, DevCount{&dinfo->n_segments, bN}, a, timing, bJ))) return rc;
-        // the frame is verified BEFORE anything lands in caller memory: a mispredicted frame never shows in `dst`
-        HIPCHECK(hipMemcpyAsync(ctx->h_info, ctx->info.p, sizeof(FrameInfo), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHECK(hipStreamSynchronize(ctx->stream));
-        const uint32_t N = ctx->h_info->n_segments, J = ctx->h_info->n_runs;
-        ctx->n_seg = N; ctx->n_compact = ctx->h_info->n_compact; ctx->last_runs = J;
-        const bool ok = !ctx->h_info->plan_bad && N <= bN && J <= bJ;
-        if (ok) {
-            ctx->pred_N = N; ctx->pred_J = J; ctx->pred_max_row = ctx->h_info->max_row_runs;
-            if ((rc = copy_image_out(ctx, dst, stride_bytes, timing, a))) return rc;
-            if (dst) HIPCHECK(hipStreamSynchronize(ctx->stream));
-            return frame_done(finish_frame(ctx, timings, true));
-        }
-        ctx->pred_counts_valid = false;                   // fall through: the synchronous path re-learns everything
+}  // extern "C"
+
+namespace {
+
+void frame_done(forma_hip_ctx* ctx, int rc, const PaintArgs& a) {      // renderer.rs:217-218: remember the clear colour in the cache
+    if (rc == FORMA_OK && a.cache_id >= 0) { ctx->caches[a.cache_id].has_clear = true; memcpy(ctx->caches[a.cache_id].clear, a.clear, 16); }
+}
+
+// A read-back-free frame, first half: everything is enqueued on the context's stream, nothing waits.  N, J and the sort
+// plan are predicted from the previous frame (bounds with slack); device-side guards keep a wrong guess memory-safe.
+int enqueue_async_frame(forma_hip_ctx* ctx, const PaintArgs& a, bool timing, uint32_t* bN_out, uint32_t* bJ_out) {
+    const uint32_t bN = ctx->pred_N + ctx->pred_N / 16 + 4096, bJ = ctx->pred_J + ctx->pred_J / 16 + 4096;
+    *bN_out = bN; *bJ_out = bJ;
+    FrameInfo* dinfo = ctx->info.as<FrameInfo>();
+    int rc;
+    if ((rc = run_rasterize_frame(ctx, a.width, a.height, timing, true, bN))) return rc;
+    if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), DevCount{&dinfo->n_segments, bN}, timing))) return rc;
+    if ((rc = run_paint(ctx, DevCount{&dinfo->n_segments, bN}, a, timing, bJ))) return rc;
+    HIPCHECK(hipMemcpyAsync(ctx->h_info, ctx->info.p, sizeof(FrameInfo), hipMemcpyDeviceToHost, ctx->stream));
+    return FORMA_OK;
+}
+
+// ... second half: wait, verify.  FORMA_RETRY: a prediction failed, nothing of the frame may be used (the caller re-runs it
+// synchronously).  The frame is verified BEFORE anything lands in caller memory: a mispredicted frame never shows in `dst`.
+int complete_async_frame(forma_hip_ctx* ctx, const PaintArgs& a, uint8_t* dst, size_t stride_bytes, bool timing,
+                         forma_timings_t* timings, uint32_t bN, uint32_t bJ) {
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    const uint32_t N = ctx->h_info->n_segments, J = ctx->h_info->n_runs;
+    ctx->n_seg = N; ctx->n_compact = ctx->h_info->n_compact; ctx->last_runs = J;
+    const bool ok = !ctx->h_info->plan_bad && N <= bN && J <= bJ;
+    if (!ok) {
+        ctx->pred_counts_valid = false;                   // the synchronous path re-learns everything
         clear_stage_flags(ctx);
+        return FORMA_RETRY;
     }
-    // 2. synchronous path (first frame of a scene, or a prediction failed): N, the key masks and J are read back
+    ctx->pred_N = N; ctx->pred_J = J; ctx->pred_max_row = ctx->h_info->max_row_runs;
+    int rc;
+    if ((rc = copy_image_out(ctx, dst, stride_bytes, timing, a))) return rc;
+    if (dst) HIPCHECK(hipStreamSynchronize(ctx->stream));
+    rc = finish_frame(ctx, timings, true);
+    frame_done(ctx, rc, a);
+    return rc;
+}
+
+// the synchronous frame (first frame of a scene, or a prediction failed): N, the key masks and J are read back
+int render_sync(forma_hip_ctx* ctx, const PaintArgs& a, uint8_t* dst, size_t stride_bytes, bool timing, forma_timings_t* timings) {
+    int rc;
     for (int attempt = 0; attempt < 2; attempt++) {
-        if ((rc = run_rasterize_frame(ctx, width, height, timing, /*speculate=*/attempt == 0))) return rc;
+        if ((rc = run_rasterize_frame(ctx, a.width, a.height, timing, /*speculate=*/attempt == 0))) return rc;
         if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), DevCount{nullptr, (uint32_t)ctx->n_seg}, timing))) return rc;
         rc = run_paint(ctx, DevCount{nullptr, (uint32_t)ctx->n_seg}, a, timing);
         if (rc == FORMA_RETRY) { clear_stage_flags(ctx); continue; }
@@ -913,13 +860,147 @@ int forma_hip_render(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t 
         if ((rc = copy_image_out(ctx, dst, stride_bytes, timing, a))) return rc;
         rc = finish_frame(ctx, timings);
         if (rc == FORMA_OK) { ctx->pred_N = (uint32_t)ctx->n_seg; ctx->pred_J = ctx->last_runs; ctx->pred_counts_valid = true; }
-        return frame_done(rc);
+        frame_done(ctx, rc, a);
+        return rc;
     }
     return fail(ctx, FORMA_E_INTERNAL, "sort plan did not converge");
 }
 
+// one whole frame on one slot, returning when `dst` (if any) is written
+int render_on(forma_hip_ctx* ctx, uint8_t* dst, const PaintArgs& a, size_t stride_bytes, forma_timings_t* timings) {
+    const bool timing = timings != nullptr;
+    clear_stage_flags(ctx);
+    if (a.width != ctx->pred_w || a.height != ctx->pred_h) { ctx->pred_counts_valid = false; ctx->pred_w = a.width; ctx->pred_h = a.height; }
+    if (ctx->pred_valid && ctx->pred_counts_valid && !ctx->no_async) {
+        uint32_t bN, bJ;
+        int rc = enqueue_async_frame(ctx, a, timing, &bN, &bJ);
+        if (rc) return rc;
+        rc = complete_async_frame(ctx, a, dst, stride_bytes, timing, timings, bN, bJ);
+        if (rc != FORMA_RETRY) return rc;
+    }
+    return render_sync(ctx, a, dst, stride_bytes, timing, timings);
+}
+
+// frames in flight: finish the frame a slot still owes (wait, verify, re-run synchronously if a prediction failed)
+int settle_slot(forma_hip_ctx* sl) {
+    if (!sl->pending) return FORMA_OK;
+    sl->pending = false;
+    forma_hip_ctx* ctx = sl;
+    HIPCHECK(hipSetDevice(sl->device));
+    const forma_hip_ctx::Deferred& d = sl->def;
+    PaintArgs a{d.width, d.height, d.channels, d.clear, d.has_crop ? &d.crop : nullptr, -1};
+    int rc = complete_async_frame(sl, a, nullptr, 0, false, nullptr, d.bN, d.bJ);
+    if (rc == FORMA_RETRY) rc = render_sync(sl, a, nullptr, 0, false, nullptr);
+    return rc;
+}
+
+}  // namespace
+
+// every frame the context still owes is finished; the first error of a deferred frame is reported here (and kept as the
+// owner's last error text)
+int fd_drain(forma_hip_ctx* ctx) {
+    int first = FORMA_OK;
+    for (forma_hip_ctx* sl : ctx->slots) {
+        const int rc = settle_slot(sl);
+        if (rc && !first) { first = rc; if (sl != ctx) memcpy(ctx->err, sl->err, sizeof ctx->err); }
+    }
+    return first;
+}
+
+namespace {
+
+// slots[1..] see the owner's scene through borrowed buffers: refresh the views and the scalars after every upload
+void share_scene(forma_hip_ctx* o) {
+    for (forma_hip_ctx* sl : o->slots) {
+        if (sl == o) continue;
+        sl->x.borrow(o->x); sl->y.borrow(o->y); sl->line_slot.borrow(o->line_slot); sl->geoms.borrow(o->geoms);
+        sl->style_off.borrow(o->style_off); sl->style_words.borrow(o->style_words); sl->unchanged.borrow(o->unchanged);
+        sl->images.borrow(o->images); sl->texels.borrow(o->texels); sl->layer_sf.borrow(o->layer_sf); sl->layer_col.borrow(o->layer_col);
+        sl->n_points = o->n_points; sl->n_geoms = o->n_geoms; sl->n_orders = o->n_orders; sl->n_words = o->n_words; sl->n_images = o->n_images;
+        sl->max_geom_order = o->max_geom_order; sl->max_image_index = o->max_image_index; sl->any_texture = o->any_texture;
+        sl->scene_has_clips = o->scene_has_clips; sl->have_unchanged = o->have_unchanged;
+        sl->band_row0 = o->band_row0; sl->band_row1 = o->band_row1;
+        sl->line_ranged = o->line_ranged; sl->line_lo = o->line_lo; sl->line_hi = o->line_hi;
+    }
+}
+void invalidate_counts(forma_hip_ctx* o) {                 // new geometry / band: every slot re-learns N and J synchronously
+    o->pred_counts_valid = false; o->xpred_valid = false;
+    for (forma_hip_ctx* sl : o->slots) { sl->pred_counts_valid = false; sl->xpred_valid = false; }
+}
+}  // namespace
+
+extern "C" {
+
+int forma_hip_render(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t height, size_t stride_bytes,
+                     const uint8_t channels[4], const float clear_color[4], const forma_rect_t* crop_or_null, int cache_id,
+                     forma_timings_t* timings) {
+    if (!ctx) return FORMA_E_ARG;
+    int rc = check_paint_args(ctx, dst, width, height, stride_bytes, channels, clear_color);
+    if (rc) return rc;
+    if (cache_id >= 32) return fail(ctx, FORMA_E_ARG, "cache_id out of range");   // SmallBitSet u32, small_bit_set.rs:17-57
+    if (ctx->multi) return multi_render(ctx, dst, width, height, stride_bytes, channels, clear_color, crop_or_null, cache_id, timings);
+    HIPCHECK(hipSetDevice(ctx->device));
+    PaintArgs a{width, height, channels, clear_color, crop_or_null, cache_id};
+    // Several frames in flight: a device-resident frame without a cache is ENQUEUED on the next slot and this call returns;
+    // it is verified (and, if a prediction failed, re-run) when the slot is needed again or when any call needs its result.
+    // Frames that write caller memory, use a buffer-layer cache (frame k + 1 reads what frame k left in it) or ask for
+    // timings keep the synchronous contract of the reference: `dst` is fully written when the call returns.
+    if (ctx->slots.size() > 1 && !dst && cache_id < 0 && !timings) {
+        forma_hip_ctx* sl = ctx->slots[ctx->next_slot++ % ctx->slots.size()];
+        if ((rc = settle_slot(sl))) { if (sl != ctx) memcpy(ctx->err, sl->err, sizeof ctx->err); return rc; }
+        ctx->last = sl;
+        clear_stage_flags(sl);
+        if (width != sl->pred_w || height != sl->pred_h) { sl->pred_counts_valid = false; sl->pred_w = width; sl->pred_h = height; }
+        if (sl->pred_valid && sl->pred_counts_valid && !sl->no_async) {
+            forma_hip_ctx::Deferred& d = sl->def;
+            d.width = width; d.height = height; memcpy(d.channels, channels, 4); memcpy(d.clear, clear_color, 16);
+            d.has_crop = crop_or_null != nullptr; if (crop_or_null) d.crop = *crop_or_null;
+            PaintArgs as{width, height, d.channels, d.clear, d.has_crop ? &d.crop : nullptr, -1};
+            rc = enqueue_async_frame(sl, as, false, &d.bN, &d.bJ);
+            if (rc == FORMA_OK) sl->pending = true;
+        } else {
+            rc = render_sync(sl, a, nullptr, 0, false, nullptr);
+        }
+        if (rc && sl != ctx) memcpy(ctx->err, sl->err, sizeof ctx->err);
+        return rc;
+    }
+    if ((rc = fd_drain(ctx))) return rc;
+    ctx->last = ctx;
+    return render_on(ctx, dst, a, stride_bytes, timings);
+}
+
+int forma_hip_set_frames_in_flight(forma_hip_ctx* ctx, int n) {
+    if (!ctx) return FORMA_E_ARG;
+    if (n < 1 || n > FORMA_MAX_FRAMES_IN_FLIGHT) return fail(ctx, FORMA_E_ARG, "frames in flight: 1 .. 4");
+    if (ctx->multi) return n == 1 ? FORMA_OK : fail(ctx, FORMA_E_STATE, "a multi-device context has one frame in flight");
+    int rc = fd_drain(ctx);
+    if (rc) return rc;
+    if (ctx->slots.empty()) ctx->slots.push_back(ctx);
+    while ((int)ctx->slots.size() > n) { forma_hip_ctx* sl = ctx->slots.back(); ctx->slots.pop_back(); forma_hip_destroy(sl); }
+    while ((int)ctx->slots.size() < n) {
+        forma_hip_ctx* sl = nullptr;
+        if ((rc = forma_hip_create(&sl, ctx->device))) return fail(ctx, rc, "frames in flight: cannot create a frame slot");
+        sl->owner = ctx;
+        sl->digit_bits = ctx->digit_bits; sl->no_async = ctx->no_async; sl->global_runsort = ctx->global_runsort; sl->legacy_runs = ctx->legacy_runs;
+        ctx->slots.push_back(sl);
+    }
+    if (ctx->slots.size() == 1) ctx->slots.clear();
+    ctx->next_slot = 0; ctx->last = ctx;
+    HIPCHECK(hipSetDevice(ctx->device));
+    share_scene(ctx);
+    return FORMA_OK;
+}
+
+int forma_hip_sync(forma_hip_ctx* ctx) {
+    if (!ctx) return FORMA_E_ARG;
+    if (ctx->multi) return FORMA_OK;                       // (every frame of a multi-device context is complete when render returns)
+    return fd_drain(ctx);
+}
+
 int forma_hip_cache_clear(forma_hip_ctx* ctx, int cache_id) {
     if (!ctx || cache_id < 0 || cache_id >= 32) return fail(ctx, FORMA_E_ARG, "cache_id out of range");
+    if (ctx->multi) return multi_cache_clear(ctx, cache_id);
+    { const int rc = fd_drain(ctx); if (rc) return rc; }
     HIPCHECK(hipSetDevice(ctx->device));
     forma_hip_ctx::TileCache& c = ctx->caches[cache_id];               // BufferLayerCache::clear, buffer/mod.rs:189-196
     c.has_clear = false;
@@ -931,6 +1012,12 @@ int forma_hip_cache_clear(forma_hip_ctx* ctx, int cache_id) {
 // ---- inspection ------------------------------------------------------------------------------------------
 int forma_hip_read_segments(forma_hip_ctx* ctx, int which, uint64_t* out, size_t capacity, size_t* out_n) {
     if (!ctx || !out_n) return FORMA_E_ARG;
+    if (ctx->multi) return multi_read_segments(ctx, which, out, capacity, out_n);
+    { const int rc = fd_drain(ctx); if (rc) return rc; }
+    forma_hip_ctx* const owner = ctx;
+    ctx = last_slot(ctx);                                 // the slot that rendered the most recent frame
+    if (ctx != owner) ctx->err[0] = 0;
+    struct CopyErr { forma_hip_ctx* o; forma_hip_ctx* s; ~CopyErr() { if (o != s && s->err[0]) memcpy(o->err, s->err, sizeof o->err); } } copy_err{owner, ctx};
     *out_n = ctx->n_seg;
     if (which == 0 && !ctx->have_unsorted) return fail(ctx, FORMA_E_STATE, "no unsorted stream on the device");
     if (ctx->n_seg > capacity) return fail(ctx, FORMA_E_CAPACITY, "segment capacity too small");
@@ -945,6 +1032,12 @@ int forma_hip_read_segments(forma_hip_ctx* ctx, int which, uint64_t* out, size_t
 
 int forma_hip_read_image(forma_hip_ctx* ctx, uint8_t* dst, size_t stride_bytes) {
     if (!ctx || !dst) return FORMA_E_ARG;
+    if (ctx->multi) return multi_read_image(ctx, dst, stride_bytes);
+    { const int rc = fd_drain(ctx); if (rc) return rc; }
+    forma_hip_ctx* const owner = ctx;
+    ctx = last_slot(ctx);
+    if (ctx != owner) ctx->err[0] = 0;
+    struct CopyErr { forma_hip_ctx* o; forma_hip_ctx* s; ~CopyErr() { if (o != s && s->err[0]) memcpy(o->err, s->err, sizeof o->err); } } copy_err{owner, ctx};
     if (!ctx->img_w) return fail(ctx, FORMA_E_STATE, "no image on the device");
     if ((size_t)ctx->img_w * 4 > stride_bytes) return fail(ctx, FORMA_E_ARG, "width exceeds width stride");
     HIPCHECK(hipSetDevice(ctx->device));
@@ -954,6 +1047,12 @@ int forma_hip_read_image(forma_hip_ctx* ctx, uint8_t* dst, size_t stride_bytes) 
 
 int forma_hip_tiles_written(forma_hip_ctx* ctx, uint8_t* flags, size_t n_tiles) {
     if (!ctx || !flags) return FORMA_E_ARG;
+    if (ctx->multi) return multi_tiles_written(ctx, flags, n_tiles);
+    { const int rc = fd_drain(ctx); if (rc) return rc; }
+    forma_hip_ctx* const owner = ctx;
+    ctx = last_slot(ctx);
+    if (ctx != owner) ctx->err[0] = 0;
+    struct CopyErr { forma_hip_ctx* o; forma_hip_ctx* s; ~CopyErr() { if (o != s && s->err[0]) memcpy(o->err, s->err, sizeof o->err); } } copy_err{owner, ctx};
     if (!ctx->lw_valid) return fail(ctx, FORMA_E_STATE, "no frame rendered yet");
     const size_t T = (size_t)ctx->lw_tiles_w * ctx->lw_tiles_h;
     if (n_tiles < T) return fail(ctx, FORMA_E_CAPACITY, "tile flag capacity too small");
@@ -980,22 +1079,24 @@ int forma_hip_tiles_written(forma_hip_ctx* ctx, uint8_t* flags, size_t n_tiles) 
 
 // ---- multi-GPU -----------------------------------------------------------------------------------------------
 int forma_hip_set_band(forma_hip_ctx* ctx, uint32_t row0, uint32_t row1) {
-    if (!ctx) return FORMA_E_ARG;
+    ENTER_SINGLE(ctx);
     if (row1 != 0 && row0 >= row1) return fail(ctx, FORMA_E_ARG, "empty band");
     ctx->band_row0 = row1 ? row0 : 0; ctx->band_row1 = row1;
-    ctx->pred_counts_valid = false; ctx->xpred_valid = false;
+    invalidate_counts(ctx);
+    share_scene(ctx);
     return FORMA_OK;
 }
 
 int forma_hip_segments_device(forma_hip_ctx* ctx, int which, uint64_t** dev_ptr, size_t* n) {
     if (!ctx || !dev_ptr || !n) return FORMA_E_ARG;
+    ENTER_SINGLE(ctx);
     *dev_ptr = which == 0 ? ctx->seg_u.as<uint64_t>() : ctx->sorted;
     *n = ctx->n_seg;
     return FORMA_OK;
 }
 
 int forma_hip_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, forma_timings_t* timings) {
-    if (!ctx) return FORMA_E_ARG;
+    ENTER_SINGLE(ctx);
     int rc = check_canvas(ctx, width, height);
     if (rc) return rc;
     HIPCHECK(hipSetDevice(ctx->device));
@@ -1007,6 +1108,7 @@ int forma_hip_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t heigh
 
 int forma_hip_reserve_segments(forma_hip_ctx* ctx, size_t n, uint64_t** dev_ptr) {
     if (!ctx || !dev_ptr) return FORMA_E_ARG;
+    ENTER_SINGLE(ctx);
     HIPCHECK(hipSetDevice(ctx->device));
     // growing seg_u would drop the rasterized stream the caller may still be sending: grow seg_b (unused until the sort)
     HIPCHECK(ctx->seg_b.ensure((std::max<size_t>(n, 1) + SEG_PAD) * 8));
@@ -1017,7 +1119,7 @@ int forma_hip_reserve_segments(forma_hip_ctx* ctx, size_t n, uint64_t** dev_ptr)
 int forma_hip_sort_paint_frame(forma_hip_ctx* ctx, size_t n, uint8_t* dst, uint32_t width, uint32_t height,
                                size_t stride_bytes, const uint8_t channels[4], const float clear_color[4],
                                const forma_rect_t* crop_or_null, forma_timings_t* timings) {
-    if (!ctx) return FORMA_E_ARG;
+    ENTER_SINGLE(ctx);
     int rc = check_paint_args(ctx, dst, width, height, stride_bytes, channels, clear_color);
     if (rc) return rc;
     if (n * 8 > ctx->seg_b.cap) return fail(ctx, FORMA_E_STATE, "reserve_segments first");
@@ -1044,14 +1146,18 @@ int forma_hip_sort_paint_frame(forma_hip_ctx* ctx, size_t n, uint8_t* dst, uint3
 //      the owner sorts and paints its band ---------------------------------------------------------------------------------
 int forma_hip_stream(forma_hip_ctx* ctx, void** stream) {
     if (!ctx || !stream) return FORMA_E_ARG;
+    if (ctx->multi) return fail(ctx, FORMA_E_STATE, "a multi-device context has one stream per device");
     *stream = (void*)ctx->stream;
     return FORMA_OK;
 }
 
 int forma_hip_exchange_plan(forma_hip_ctx* ctx, const uint32_t* row_edges, uint32_t n_ranks, uint32_t pair_capacity) {
     if (!ctx || !row_edges) return FORMA_E_ARG;
+    ENTER_SINGLE(ctx);
     if (n_ranks < 1 || n_ranks > FORMA_MAX_RANKS) return fail(ctx, FORMA_E_ARG, "1 .. 8 ranks");
-    for (uint32_t g = 0; g < n_ranks; g++) if (row_edges[g] >= row_edges[g + 1]) return fail(ctx, FORMA_E_ARG, "tile-row bands must be ascending and non-empty");
+    // (a band may be empty — a canvas with fewer tile rows than ranks: its owner receives nothing and paints nothing)
+    for (uint32_t g = 0; g < n_ranks; g++) if (row_edges[g] > row_edges[g + 1]) return fail(ctx, FORMA_E_ARG, "tile-row band edges must not decrease");
+    if (row_edges[0] >= row_edges[n_ranks]) return fail(ctx, FORMA_E_ARG, "no tile rows");
     if (pair_capacity == 0 || (uint64_t)pair_capacity * n_ranks >= (1ull << 30)) return fail(ctx, FORMA_E_ARG, "pair capacity out of range");
     HIPCHECK(hipSetDevice(ctx->device));
     ctx->xbands.n = n_ranks;
@@ -1072,6 +1178,7 @@ int forma_hip_exchange_plan(forma_hip_ctx* ctx, const uint32_t* row_edges, uint3
 
 int forma_hip_exchange_buffers(forma_hip_ctx* ctx, uint64_t** send, uint32_t** send_counts, uint64_t** recv, uint32_t** recv_counts) {
     if (!ctx || !send || !send_counts || !recv || !recv_counts) return FORMA_E_ARG;
+    ENTER_SINGLE(ctx);
     if (!ctx->xplanned) return fail(ctx, FORMA_E_STATE, "forma_hip_exchange_plan first");
     *send = ctx->xsend.as<uint64_t>(); *send_counts = ctx->xsend_counts.as<uint32_t>();
     *recv = ctx->xrecv.as<uint64_t>(); *recv_counts = ctx->xrecv_counts.as<uint32_t>();
@@ -1079,7 +1186,7 @@ int forma_hip_exchange_buffers(forma_hip_ctx* ctx, uint64_t** send, uint32_t** s
 }
 
 int forma_hip_rasterize_bucket_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, forma_timings_t* timings) {
-    if (!ctx) return FORMA_E_ARG;
+    ENTER_SINGLE(ctx);
     if (!ctx->xplanned) return fail(ctx, FORMA_E_STATE, "forma_hip_exchange_plan first");
     int rc = check_canvas(ctx, width, height);
     if (rc) return rc;
@@ -1124,19 +1231,31 @@ int forma_hip_rasterize_bucket_frame(forma_hip_ctx* ctx, uint32_t width, uint32_
 int forma_hip_gather_sort_paint_frame(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t height, size_t stride_bytes,
                                       const uint8_t channels[4], const float clear_color[4], const forma_rect_t* crop_or_null,
                                       forma_timings_t* timings) {
+    ENTER_SINGLE(ctx);
+    return fd_gather_sort_paint(ctx, dst, width, height, stride_bytes, channels, clear_color, crop_or_null, -1, timings);
+}
+
+}  // extern "C"
+
+int fd_gather_sort_paint(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t height, size_t stride_bytes,
+                         const uint8_t channels[4], const float clear_color[4], const forma_rect_t* crop_or_null, int cache_id,
+                         forma_timings_t* timings) {
     if (!ctx) return FORMA_E_ARG;
     if (!ctx->xplanned) return fail(ctx, FORMA_E_STATE, "forma_hip_exchange_plan first");
     int rc = check_paint_args(ctx, dst, width, height, stride_bytes, channels, clear_color);
     if (rc) return rc;
+    if (cache_id >= 32) return fail(ctx, FORMA_E_ARG, "cache_id out of range");
     HIPCHECK(hipSetDevice(ctx->device));
     const bool timing = timings != nullptr;
     clear_stage_flags(ctx);
     const uint32_t G = ctx->xbands.n, bound = G * ctx->xcap;
     // one rank: what was bucketed is what is received (no collective ran)
-    const uint64_t* recv = G == 1 ? ctx->xsend.as<uint64_t>() : ctx->xrecv.as<uint64_t>();
-    const uint32_t* rcnt = G == 1 ? ctx->xsend_counts.as<uint32_t>() : ctx->xrecv_counts.as<uint32_t>();
+    // (xuse_recv: a collective did run with a world of one — the RCCL rehearsal of a multi-device context on one GPU)
+    const bool self = G == 1 && !ctx->xuse_recv;
+    const uint64_t* recv = self ? ctx->xsend.as<uint64_t>() : ctx->xrecv.as<uint64_t>();
+    const uint32_t* rcnt = self ? ctx->xsend_counts.as<uint32_t>() : ctx->xrecv_counts.as<uint32_t>();
     FrameInfo* dinfo = ctx->info.as<FrameInfo>();
-    PaintArgs a{width, height, channels, clear_color, crop_or_null};
+    PaintArgs a{width, height, channels, clear_color, crop_or_null, cache_id};
     HIPCHECK(ctx->seg_u.ensure(((size_t)bound + SEG_PAD) * 8));
     HIPCHECK(ctx->xmask.ensure(std::max<size_t>(gather_mask_words(G, ctx->xcap), (size_t)2048 * 8) * 4));
     auto gather = [&](bool read_back_free) -> int {
@@ -1179,7 +1298,9 @@ int forma_hip_gather_sort_paint_frame(forma_hip_ctx* ctx, uint8_t* dst, uint32_t
             ctx->pred_J = J; ctx->pred_max_row = ctx->h_info->max_row_runs;
             if ((rc = copy_image_out(ctx, dst, stride_bytes, timing, a))) return rc;
             if (dst) HIPCHECK(hipStreamSynchronize(ctx->stream));
-            return finish_frame(ctx, timings, true);
+            rc = finish_frame(ctx, timings, true);
+            frame_done(ctx, rc, a);
+            return rc;
         }
         ctx->pred_counts_valid = false;
         clear_stage_flags(ctx);
@@ -1200,9 +1321,73 @@ int forma_hip_gather_sort_paint_frame(forma_hip_ctx* ctx, uint8_t* dst, uint32_t
         if ((rc = copy_image_out(ctx, dst, stride_bytes, timing, a))) return rc;
         rc = finish_frame(ctx, timings);
         if (rc == FORMA_OK) { ctx->pred_J = ctx->last_runs; ctx->pred_counts_valid = true; }
+        frame_done(ctx, rc, a);
         return rc;
     }
     return fail(ctx, FORMA_E_INTERNAL, "sort plan did not converge");
 }
 
-}  // extern "C"
+
+// ---- helpers of the multi-device planner (multi.cpp) ---------------------------------------------------------------------
+int fd_set_line_range(forma_hip_ctx* ctx, bool ranged, size_t lo, size_t hi) {
+    if (!ctx) return FORMA_E_ARG;
+    if (ranged && lo > hi) return fail(ctx, FORMA_E_ARG, "line range");
+    int rc = fd_drain(ctx);
+    if (rc) return rc;
+    ctx->line_ranged = ranged; ctx->line_lo = ranged ? lo : 0; ctx->line_hi = ranged ? hi : 0;
+    invalidate_counts(ctx);
+    share_scene(ctx);
+    return FORMA_OK;
+}
+
+int fd_line_sums(forma_hip_ctx* ctx, uint32_t width, uint32_t height, std::vector<uint32_t>& sums) {
+    if (!ctx) return FORMA_E_ARG;
+    int rc = fd_drain(ctx);
+    if (rc) return rc;
+    HIPCHECK(hipSetDevice(ctx->device));
+    const size_t n = ctx->n_points ? ctx->n_points - 1 : 0;
+    sums.assign(n, 0u);
+    if (n == 0) return FORMA_OK;
+    // per-line lengths of ALL lines (the frame path's count kernel, segment.rs:298-383 restated in k_line_len), then the scan
+    HIPCHECK(ctx->l_len.ensure(n * 4));
+    HIPCHECK(ctx->prep_scratch.ensure(prepare_scratch_words(n) * 4));
+    HIPCHECK(ctx->scan_tmp.ensure(scan_tmp_words(std::max<size_t>(n, 1 << 16)) * 4));
+    const bool keep = ctx->line_ranged;
+    ctx->line_ranged = false;
+    const LineSource S = geometry_source(ctx, width, height);
+    ctx->line_ranged = keep;
+    launch_line_lengths(ctx->stream, S, (uint32_t)n, ctx->l_len.as<uint32_t>(), ctx->prep_scratch.as<uint32_t>());
+    launch_inclusive_scan_u32(ctx->stream, ctx->l_len.as<uint32_t>(), n, ctx->scan_tmp.as<uint32_t>(), nullptr);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(sums.data(), ctx->l_len.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    return FORMA_OK;
+}
+
+int fd_row_histogram(forma_hip_ctx* ctx, uint32_t width, uint32_t height, uint32_t* hist, uint32_t* n_segments) {
+    if (!ctx || !hist) return FORMA_E_ARG;
+    int rc = fd_drain(ctx);
+    if (rc) return rc;
+    HIPCHECK(hipSetDevice(ctx->device));
+    clear_stage_flags(ctx);
+    if ((rc = run_rasterize_frame(ctx, width, height, false))) return rc;          // synchronous: n_seg is known afterwards
+    HIPCHECK(ctx->xscratch.ensure(std::max<size_t>(2048 * 4, ctx->xscratch.cap)));
+    launch_row_histogram(ctx->stream, ctx->seg_u.as<uint64_t>(), DevCount{nullptr, (uint32_t)ctx->n_seg}, ctx->xscratch.as<uint32_t>());
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(hist, ctx->xscratch.p, 2048 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    if (n_segments) *n_segments = (uint32_t)ctx->n_seg;
+    return FORMA_OK;
+}
+
+int fd_copy_image_rows(forma_hip_ctx* ctx, uint8_t* dst, size_t stride_bytes, uint32_t y0, uint32_t y1) {
+    if (!ctx || !dst) return FORMA_E_ARG;
+    if (!ctx->img_w || !ctx->cur_image) return fail(ctx, FORMA_E_STATE, "no image on the device");
+    y1 = std::min(y1, ctx->img_h);
+    if (y0 >= y1) return FORMA_OK;
+    HIPCHECK(hipSetDevice(ctx->device));
+    const size_t pitch = (size_t)ctx->img_w * 4;
+    HIPCHECK(hipMemcpy2D(dst + (size_t)y0 * stride_bytes, stride_bytes, ctx->cur_image + (size_t)y0 * pitch, pitch, pitch, y1 - y0,
+                         hipMemcpyDeviceToHost));
+    return FORMA_OK;
+}

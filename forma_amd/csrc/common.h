@@ -122,6 +122,7 @@ struct LineSource {               // either the uploaded geometry (sums == nullp
 size_t prepare_scratch_words(size_t n_lines);
 void launch_prepare_compact(hipStream_t s, const LineSource& src, uint32_t n_lines, uint32_t* cl_idx, uint32_t* cl_start,
                             uint32_t* block_first, uint32_t bf_cap, uint32_t* scratch, FrameInfo* info);
+void launch_line_lengths(hipStream_t s, const LineSource& src, uint32_t n_lines, uint32_t* lens, uint32_t* scratch /* prepare_scratch_words */);
 // rebuilds block_first when the buffer launch_prepare_compact saw was too small for N
 void launch_block_first(hipStream_t s, const uint32_t* cl_start, uint32_t n_compact, uint32_t n_segments,
                         uint32_t* block_first);
@@ -162,6 +163,7 @@ size_t owner_scratch_words(size_t n);
 // stable partition of seg[0 .. n) into send[g * capacity + ...]; send_counts[2 g] = segments for rank g, [2 g + 1] = overflow flag
 void launch_owner_bucket(hipStream_t s, const uint64_t* seg, DevCount n, const OwnerBands& B, uint32_t capacity,
                          uint32_t* scratch, uint64_t* send, uint32_t* send_counts, FrameInfo* info);
+void launch_row_histogram(hipStream_t s, const uint64_t* seg, DevCount n, uint32_t* hist /* 2048 words */);
 // recv[s * capacity + ...] (recv_counts[2 s] segments from rank s) -> out, info->{n_segments, key masks, layer_unsorted}
 size_t gather_mask_words(uint32_t n_ranks, uint32_t capacity);
 void launch_gather_chunks(hipStream_t s, const uint64_t* recv, const uint32_t* recv_counts, uint32_t n_ranks, uint32_t capacity,

@@ -1,0 +1,173 @@
+// ctx.h — the context behind the C ABI (include/forma_hip.h), shared by api.cpp (one device) and multi.cpp (several
+// devices behind one context).  Private to libforma_hip.so.
+#pragma once
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    bool borrowed = false;                  // a frame slot's view of its owner's scene buffer: never grown or freed here
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap && p) return hipSuccess;
+        if (borrowed) return hipErrorInvalidValue;
+        size_t want = std::max(bytes, cap + cap / 2);
+        want = std::max<size_t>(want, 256);
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p && !borrowed) (void)hipFree(p); p = nullptr; cap = 0; borrowed = false; }
+    void borrow(const DevBuf& o) { release(); p = o.p; cap = o.cap; borrowed = true; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+constexpr int MAX_PASS_EVENTS = 16;
+constexpr size_t SEG_PAD = 16;          // segment buffers are over-allocated: stream kernels read whole 64-byte lane pieces
+enum { ST_PREPARE = 0, ST_RASTER, ST_SORT, ST_CARRY, ST_PAINT, ST_D2H, ST_XCHG, ST_COUNT };
+
+struct forma_hip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    char err[512] = {0};
+
+    // scene
+    DevBuf x, y, line_slot, geoms, style_off, style_words, unchanged, images, texels;
+    DevBuf layer_sf, layer_col;             // per order: style summary for the carry pre-pass (set_styles)
+    std::vector<uint32_t> h_layer_sf, h_layer_col;
+    size_t n_points = 0, n_geoms = 0, n_orders = 0, n_words = 0, n_images = 0;
+    uint32_t max_geom_order = 0;            // largest order any geom slot names (FORMA_NONE slots aside)
+    uint32_t max_image_index = 0;           // largest image index a texture style names
+    bool any_texture = false;
+    bool scene_has_clips = false;
+    bool have_unchanged = false;            // set_styles supplied per-order Layer::is_unchanged bytes
+    // lines
+    DevBuf l_order, l_x0, l_y0, l_dx, l_dy, l_a, l_b, l_c, l_d, l_len, scan_tmp;   // parity entry points only
+    DevBuf cl_idx, cl_start, block_first, prep_scratch;                              // frame path: compacted line table
+    DevBuf ras_masks;                       // k_rasterize: key masks per workgroup (8 words), combined by k_reduce_masks
+    PendingMasks pending_masks{nullptr, 0u}; // ... or, on read-back-free frames, by k_runs_count
+    size_t n_lines = 0, n_compact = 0;
+    // segments
+    DevBuf seg_u, seg_a, seg_b, sort_counters;
+    uint64_t* sorted = nullptr;
+    size_t n_seg = 0;
+    bool have_unsorted = false;
+    uint64_t live44 = 0xFFFFFFFFFFFull;     // varying bits of (v >> 20)
+    bool layer_sorted = false;              // rasterizer stream is non-decreasing in layer
+    int digit_bits = 8;                     // radix digit width: 8 (default) or 4 (FORMA_HIP_DIGIT_BITS)
+    // paint
+    DevBuf info_init;                       // pristine FrameInfo (reset template)
+    // buffer-layer caches (reference cpu/buffer/mod.rs:113-197): per cache the CachedTile table, the device image the
+    // cache's buffer shows (tiles the painter skips keep last frame's pixels), and the cached clear colour
+    struct TileCache {
+        DevBuf tiles, image;
+        uint32_t w = 0, h = 0;
+        bool has_clear = false;
+        float clear[4] = {0, 0, 0, 0};
+    };
+    TileCache caches[32];
+    DevBuf cache_written;                   // one byte per tile: written this frame
+    uint8_t* h_written = nullptr;           // pinned copy of cache_written
+    size_t h_written_cap = 0;
+    uint8_t* h_stage = nullptr;             // pinned staging image for tile-granular copy-out
+    size_t h_stage_cap = 0;
+    int cur_cache = -1;                     // cache of the frame in flight
+    uint8_t* cur_image = nullptr;           // device image of the frame in flight / last frame
+    // sort-plan speculation: the varying-bit mask and the layer-sortedness of a scene rarely change between frames, so
+    // forma_hip_render plans the sort from the previous frame's values and verifies them when the frame is done
+    bool pred_valid = false, pred_layer_sorted = false, speculated = false;
+    bool global_runsort = false;           // FORMA_HIP_GLOBAL_RUNSORT=1: never order a row's runs in LDS (test switch)
+    bool legacy_runs = false;              // FORMA_HIP_LEGACY_RUNS=1: run detection by the workgroup-per-tile kernel (A/B switch)
+    bool pred_counts_valid = false, no_async = false;    // N / J predictions for read-back-free frames (FORMA_HIP_SYNC=1 disables)
+    uint32_t pred_N = 0, pred_J = 0, pred_w = 0, pred_h = 0;
+    uint64_t pred_live44 = 0;
+    DevBuf info, records, rk_u, rk_a, rk_b, blk_edge, runs_scratch, row_tab, span_key, span_cov, image;
+    uint32_t img_w = 0, img_h = 0;
+    FrameInfo* h_info = nullptr;            // pinned
+    uint32_t* h_rows = nullptr;             // pinned: runs per tile row (synchronous frames), 2049 words
+    uint32_t pred_max_row = 0xFFFFFFFFu;    // most runs in one tile row of the last verified frame (unknown: no local sort)
+    // band
+    uint32_t band_row0 = 0, band_row1 = 0;
+    // a sub-range [line_lo, line_hi) of the uploaded lines (line i joins points i and i + 1) when line_ranged.
+    // A multi-device context uploads the whole geometry to every device and gives each its share of the LINES (multi.cpp).
+    bool line_ranged = false;
+    size_t line_lo = 0, line_hi = 0;
+    // frames in flight inside ONE context (forma_hip_set_frames_in_flight): slots[0] is the context itself, the others are
+    // full contexts (own stream, own per-frame buffers) that BORROW the scene buffers.  A device-resident, cache-less frame
+    // is enqueued on the next slot and verified when that slot is needed again (or at any call that needs the result).
+    forma_hip_ctx* owner = nullptr;         // extra slots: the context they belong to
+    std::vector<forma_hip_ctx*> slots;      // of the owner (empty = one frame in flight)
+    unsigned next_slot = 0;
+    forma_hip_ctx* last = nullptr;          // the slot that holds the most recent frame (inspection calls read it)
+    bool pending = false;                   // this slot holds an enqueued frame nobody has verified yet
+    struct Deferred {
+        uint32_t width = 0, height = 0, bN = 0, bJ = 0;
+        uint8_t channels[4] = {0, 1, 2, 3};
+        float clear[4] = {0, 0, 0, 0};
+        bool has_crop = false;
+        forma_rect_t crop = {0, 0, 0, 0};
+    } def;
+    // several devices behind this context (forma_hip_create_multi): the context is then a shell, the work happens in
+    // multi->kid[g] (one full context per device)
+    struct MultiState* multi = nullptr;
+    // multi-GPU exchange (forma_hip_exchange_plan): owner bands, per-pair capacity, send / receive buckets and their counts
+    OwnerBands xbands{};
+    uint32_t xcap = 0;
+    bool xplanned = false;
+    DevBuf xsend, xrecv, xsend_counts, xrecv_counts, xscratch, xmask;
+    bool xuse_recv = false;                   // one rank, but a collective DID run (RCCL rehearsal): the buckets are in xrecv
+    bool xgather_always = false;              // FORMA_HIP_XGATHER=1: materialise the received stream before sorting it
+    bool xpred_valid = false;               // the local rasterized count of the previous exchange frame is known
+    uint32_t xpred_N = 0, xpred_w = 0, xpred_h = 0;
+    uint32_t* h_xlocal = nullptr;           // pinned: [0] = local segment count of the last bucket frame (copied on the stream), [1] = 1 when pending
+    // timing
+    hipEvent_t ev0[ST_COUNT], ev1[ST_COUNT], pev0[MAX_PASS_EVENTS], pev1[MAX_PASS_EVENTS];
+    bool stage_used[ST_COUNT];
+    int n_passes = 0;
+    uint32_t last_runs = 0, last_entries = 0, last_written = 0;
+    // what the last frame wrote, for forma_hip_tiles_written (host-side Flusher / generic Layout::write)
+    uint32_t lw_tiles_w = 0, lw_tiles_h = 0, lw_tx0 = 0, lw_tx1 = 0, lw_ty0 = 0, lw_ty1 = 0;
+    bool lw_valid = false, lw_cache = false, lw_flags_on_host = false;
+};
+
+
+// ---- internals shared by api.cpp and multi.cpp -------------------------------------------------------------------------
+int fd_fail(forma_hip_ctx* c, int code, const char* what, hipError_t e = hipSuccess);
+// every frame the context still owes (frames in flight) is finished; the first error of a deferred frame is returned
+int fd_drain(forma_hip_ctx* ctx);
+// restrict the context to lines [lo, hi) of the uploaded geometry (ranged == false: all of them)
+int fd_set_line_range(forma_hip_ctx* ctx, bool ranged, size_t lo, size_t hi);
+// inclusive prefix sums of the pixel-segment counts of ALL uploaded lines at this canvas size (the reference's `lengths`
+// after prefix_sum, segment.rs:90-98,400) — what the line shares of a multi-device plan are cut from
+int fd_line_sums(forma_hip_ctx* ctx, uint32_t width, uint32_t height, std::vector<uint32_t>& sums);
+// stages 1-2 on the context's line range (synchronous), then pixel segments per tile row -> hist[0 .. 2048)
+int fd_row_histogram(forma_hip_ctx* ctx, uint32_t width, uint32_t height, uint32_t* hist /* 2048 */, uint32_t* n_segments);
+// forma_hip_gather_sort_paint_frame with a buffer-layer cache
+int fd_gather_sort_paint(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t height, size_t stride_bytes,
+                         const uint8_t channels[4], const float clear_color[4], const forma_rect_t* crop_or_null, int cache_id,
+                         forma_timings_t* timings);
+// rows [y0, y1) of the context's last image -> dst (row-major, stride bytes per row, dst addresses row 0)
+int fd_copy_image_rows(forma_hip_ctx* ctx, uint8_t* dst, size_t stride_bytes, uint32_t y0, uint32_t y1);
+
+// multi.cpp: the entry points of a multi-device context (ctx->multi != nullptr)
+int  multi_create(forma_hip_ctx** out, const int* devices, int n);
+void multi_destroy(forma_hip_ctx* ctx);
+int  multi_set_geometry(forma_hip_ctx* ctx, const float* x, const float* y, const uint32_t* line_slot, size_t n_points);
+int  multi_set_geoms(forma_hip_ctx* ctx, const forma_geom_t* geoms, size_t n_geoms);
+int  multi_set_styles(forma_hip_ctx* ctx, const uint32_t* style_offsets, size_t n_orders, const uint32_t* style_words,
+                      size_t n_words, const uint8_t* unchanged);
+int  multi_set_images(forma_hip_ctx* ctx, const forma_image_t* images, size_t n_images, const uint16_t* texels, size_t n_texels);
+int  multi_render(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t height, size_t stride_bytes,
+                  const uint8_t channels[4], const float clear_color[4], const forma_rect_t* crop_or_null, int cache_id,
+                  forma_timings_t* timings);
+int  multi_cache_clear(forma_hip_ctx* ctx, int cache_id);
+int  multi_read_segments(forma_hip_ctx* ctx, int which, uint64_t* out, size_t capacity, size_t* out_n);
+int  multi_read_image(forma_hip_ctx* ctx, uint8_t* dst, size_t stride_bytes);
+int  multi_tiles_written(forma_hip_ctx* ctx, uint8_t* flags, size_t n_tiles);
+forma_hip_ctx* multi_first(forma_hip_ctx* ctx);      // the device-0 context (stage entry points run there)

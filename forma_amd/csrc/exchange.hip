@@ -249,6 +249,37 @@ __global__ __launch_bounds__(1024) void k_reduce_gather_masks(const uint32_t* __
     }
 }
 
+// pixel segments per tile row (planning of a multi-device context: band edges and pair capacities come from it).  Row r
+// of the canvas is bin r; bin 2047 collects what is never painted (tile_y < 0 stored as row 0 - 1, rows >= 2047).  A lane
+// walks 8 consecutive segments and adds whole runs (consecutive segments mostly share their row).
+__global__ __launch_bounds__(256) void k_row_histogram(const uint64_t* __restrict__ seg, DevCount nc, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t lh[2048];
+    const uint32_t n = dev_count(nc);
+    for (int i = threadIdx.x; i < 2048; i += 256) lh[i] = 0;
+    __syncthreads();
+    for (uint32_t base = (blockIdx.x * 256 + threadIdx.x) * 8; base < n; base += gridDim.x * 256 * 8) {
+        uint32_t cur = 0xFFFFFFFFu, run = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            if (base + q >= n) break;
+            const uint32_t tyb = (uint32_t)(seg[base + q] >> 53);
+            const uint32_t bin = tyb >= 1u && tyb <= 2047u ? tyb - 1u : 2047u;
+            if (bin != cur) { if (run) atomicAdd(&lh[cur], run); cur = bin; run = 0; }
+            run++;
+        }
+        if (run) atomicAdd(&lh[cur], run);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2048; i += 256) if (lh[i]) atomicAdd(&hist[i], lh[i]);
+}
+void launch_row_histogram(hipStream_t s, const uint64_t* seg, DevCount n, uint32_t* hist /* 2048 words, zeroed here */) {
+    (void)hipMemsetAsync(hist, 0, 2048 * 4, s);
+    if (n.bound == 0) return;
+    uint32_t blocks = (n.bound + 2047) / 2048;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_row_histogram, dim3(blocks), dim3(256), 0, s, seg, n, hist);
+}
+
 size_t owner_scratch_words(size_t n) { return (size_t)(FORMA_MAX_RANKS + 1) * ((n + XB_TILE - 1) / XB_TILE + 1); }
 
 void launch_owner_bucket(hipStream_t s, const uint64_t* seg, DevCount nc, const OwnerBands& B, uint32_t capacity,

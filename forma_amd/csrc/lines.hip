@@ -392,6 +392,15 @@ void launch_prepare_compact(hipStream_t s, const LineSource& src, uint32_t n_lin
                        (const uint32_t*)tile_sum, (const uint32_t*)tile_cnt, cl_idx, cl_start, block_first, bf_cap);
 }
 
+// only the per-line pixel-segment counts (the planner of a multi-device context cuts its line shares from their prefix sums)
+void launch_line_lengths(hipStream_t s, const LineSource& src, uint32_t n_lines, uint32_t* lens, uint32_t* scratch) {
+    if (n_lines == 0) return;
+    const uint32_t ntiles = (n_lines + PC_TILE - 1) / PC_TILE;
+    uint32_t* tile_sum = scratch + n_lines;
+    uint32_t* tile_cnt = tile_sum + ntiles + 1;
+    hipLaunchKernelGGL(k_line_len, dim3(ntiles), dim3(PL_THREADS), 0, s, src, n_lines, lens, tile_sum, tile_cnt);
+}
+
 __global__ __launch_bounds__(256) void k_block_first(const uint32_t* __restrict__ cl_start, uint32_t n_compact,
                                                      uint32_t n_segments, uint32_t* __restrict__ block_first) {
     for (uint32_t c = blockIdx.x * blockDim.x + threadIdx.x; c < n_compact; c += gridDim.x * blockDim.x) {

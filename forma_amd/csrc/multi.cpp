@@ -1,0 +1,552 @@
+// multi.cpp — several MI355X behind ONE context (forma_hip_create_multi, include/forma_hip.h).
+//
+// The reference renderer is one object with one `render` call (forma/src/cpu/renderer.rs:61-84) whose parallelism is
+// internal (a Rayon pool over tile rows, painter/mod.rs:741-776).  The same shape here: the caller sees one context and
+// one forma_hip_render; inside, every device has a full single-device context (a "kid": own stream, own buffers, the
+// whole scene) and a dedicated host thread, and a frame is
+//
+//   kid g: lines [cuts[g], cuts[g + 1])  --k_line_* / k_rasterize-->  its pixel segments, in line order
+//          --k_owner_count / _scan / _scatter-->  G buckets, bucket r = segments whose tile row device r owns
+//   ONE all-to-all over xGMI: RCCL, grouped ncclAllToAll of the padded buckets (and of their {count, overflow} pairs) on the
+//          kids' streams — equal splits, so no count has to reach the host first; every GPU pair has its own link
+//   kid g: received buckets, rank-major = global line order  --stable radix sort (in place through the chunk map), carry
+//          pre-pass, painter-->  its band of tile rows  --hipMemcpy2D-->  its rows of the caller's buffer
+//
+// `tile_y` is the most significant key field and the cover carry never crosses tile rows (painter/mod.rs:518-522), so a
+// band is a complete sort + paint problem; the stable partition and the rank-major concatenation keep every band's sorted
+// stream bit-identical to the corresponding slice of the single-device stream.
+//
+// The PLAN (which lines a device rasterizes, which rows it owns, how big a bucket may get) is made from measurements of
+// the scene itself on the first frame of a geometry / canvas size: prefix sums of the line lengths -> line shares of equal
+// pixel-segment counts; per-device tile-row histograms -> bands of equal pixel-segment counts and the largest bucket.
+// A frame whose buckets outgrow the plan fails on the device (FORMA_E_CAPACITY inside), the context re-plans and re-runs it.
+//
+// RCCL is loaded with dlopen on first use: single-device users of libforma_hip.so never map the 570 MB library, and the
+// process may already hold one (PyTorch ships its own copy under the same soname; the loader then hands back that one).
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <new>
+#include <thread>
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>            // types and prototypes only: every call goes through the table below
+
+#include "ctx.h"
+
+namespace {
+
+// ---- RCCL, resolved at run time ------------------------------------------------------------------------------------------
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclAllToAll) AllToAll = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    char why[256] = {0};
+};
+
+RcclApi* rccl_api() {
+    static std::mutex m;
+    static RcclApi api;
+    static bool tried = false;
+    std::lock_guard<std::mutex> lock(m);
+    if (!tried) {
+        tried = true;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) { api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (api.handle) break; }
+        if (!api.handle) { snprintf(api.why, sizeof api.why, "dlopen(librccl): %s", dlerror()); return &api; }
+#define RCCL_SYM(field, name) api.field = (decltype(api.field))dlsym(api.handle, name); \
+        if (!api.field) { snprintf(api.why, sizeof api.why, "librccl lacks %s", name); api.handle = nullptr; return &api; }
+        RCCL_SYM(CommInitAll, "ncclCommInitAll") RCCL_SYM(CommDestroy, "ncclCommDestroy") RCCL_SYM(GroupStart, "ncclGroupStart")
+        RCCL_SYM(GroupEnd, "ncclGroupEnd") RCCL_SYM(AllToAll, "ncclAllToAll") RCCL_SYM(GetErrorString, "ncclGetErrorString")
+#undef RCCL_SYM
+    }
+    return &api;
+}
+
+// ---- host-side synchronisation of the per-device threads ------------------------------------------------------------------------
+// Frames are short (a few hundred microseconds), so waiting threads spin first and only then sleep.
+inline void cpu_relax() {
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+}
+struct SpinBarrier {
+    std::atomic<int> arrived{0};
+    std::atomic<unsigned> phase{0};
+    void wait(int n) {
+        const unsigned ph = phase.load(std::memory_order_acquire);
+        if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+            arrived.store(0, std::memory_order_relaxed);
+            phase.store(ph + 1, std::memory_order_release);
+            return;
+        }
+        for (unsigned spins = 0; phase.load(std::memory_order_acquire) == ph; spins++) {
+            if (spins < 20000) cpu_relax(); else std::this_thread::yield();
+        }
+    }
+};
+
+struct FrameJob {
+    uint8_t* dst = nullptr;
+    uint32_t width = 0, height = 0;
+    size_t stride = 0;
+    uint8_t channels[4] = {0, 1, 2, 3};
+    float clear[4] = {0, 0, 0, 0};
+    bool has_crop = false;
+    forma_rect_t crop = {0, 0, 0, 0};
+    int cache_id = -1;
+    bool timings = false;
+};
+
+}  // namespace
+
+struct MultiState {
+    int G = 0;
+    forma_hip_ctx* owner = nullptr;
+    forma_hip_ctx* kid[FORMA_MAX_RANKS] = {nullptr};
+    int dev[FORMA_MAX_RANKS] = {0};
+    bool duplicates = false;                  // a device is listed twice: rehearsal on one GPU, device copies instead of RCCL
+    bool use_rccl = false;
+    ncclComm_t comm[FORMA_MAX_RANKS] = {nullptr};
+    hipEvent_t ev_bucket[FORMA_MAX_RANKS] = {nullptr};
+    // the plan
+    bool planned = false;
+    uint32_t plan_w = 0, plan_h = 0, cap = 0;
+    uint32_t edges[FORMA_MAX_RANKS + 1] = {0};
+    size_t cuts[FORMA_MAX_RANKS + 1] = {0};
+    uint32_t plans_made = 0;
+    bool cache_used[32] = {false};
+    // the per-device threads
+    std::thread th[FORMA_MAX_RANKS];
+    std::mutex m;
+    std::condition_variable cv_job, cv_done;
+    std::atomic<uint64_t> job_gen{0};
+    std::atomic<int> done{0};
+    bool quit = false;
+    FrameJob job;
+    SpinBarrier bar;
+    int rc_stage[FORMA_MAX_RANKS] = {0};      // result of the first half of the frame, read by everybody after barrier A
+    int rc_coll = 0;                          // result of the collective (leader), read after barrier B
+    int rc[FORMA_MAX_RANKS] = {0};
+    forma_timings_t tm[FORMA_MAX_RANKS];
+    forma_rect_t band_crop[FORMA_MAX_RANKS];
+    // what the last frame was (inspection calls)
+    bool last_valid = false;
+    uint32_t last_w = 0, last_h = 0;
+};
+
+namespace {
+
+#define MFAIL(code, what) fd_fail(ctx, code, what)
+
+void copy_err(forma_hip_ctx* ctx, const forma_hip_ctx* from) { memcpy(ctx->err, from->err, sizeof ctx->err); }
+
+// ---- planning (host logic; the Python launcher's copy is forma_amd/sharding.py) --------------------------------------------------
+// lines 0..n cut into G contiguous ranges carrying (nearly) equal pixel-segment counts
+void line_shares(const std::vector<uint32_t>& sums, int G, size_t* cuts) {
+    const size_t n = sums.size();
+    const double total = n ? (double)sums[n - 1] : 0.0;
+    cuts[0] = 0;
+    for (int r = 1; r < G; r++) {
+        size_t c;
+        if (total > 0) c = (size_t)(std::lower_bound(sums.begin(), sums.end(), (uint32_t)std::min(total * r / G, 4294967295.0)) - sums.begin()) + 1;
+        else c = n * r / G;
+        cuts[r] = std::min(std::max(c, cuts[r - 1]), n);
+    }
+    cuts[G] = n;
+}
+
+// tiles_h tile rows cut into G contiguous bands with (nearly) equal pixel-segment counts; with fewer rows than devices the
+// first tiles_h bands hold one row each and the rest are empty
+void band_edges(const std::vector<uint64_t>& hist, uint32_t tiles_h, int G, uint32_t* edges) {
+    std::vector<double> cum(tiles_h);
+    double acc = 0;
+    for (uint32_t r = 0; r < tiles_h; r++) { acc += (double)hist[r]; cum[r] = acc; }
+    edges[0] = 0;
+    for (int r = 1; r < G; r++) {
+        uint32_t e;
+        if (acc > 0) e = (uint32_t)(std::lower_bound(cum.begin(), cum.end(), acc * r / G) - cum.begin()) + 1;
+        else e = (uint32_t)((uint64_t)tiles_h * r / G);
+        e = std::max(e, std::min(edges[r - 1] + 1, tiles_h));                  // every band keeps a row while rows are left ...
+        const uint32_t left = (uint32_t)(G - r);                             // ... and leaves one for each band after it
+        if (tiles_h >= left) e = std::min(e, tiles_h - left);
+        e = std::max(e, edges[r - 1]);
+        edges[r] = std::min(e, tiles_h);
+    }
+    edges[G] = tiles_h;
+}
+
+uint32_t pair_capacity(uint64_t max_pair) {          // 6 % slack, whole 2048-segment blocks
+    const uint64_t c = max_pair + max_pair / 16 + 4096;
+    return (uint32_t)std::min<uint64_t>((c + 2047) / 2048 * 2048, 0x3FFFFFFFull);
+}
+
+int make_plan(forma_hip_ctx* ctx, uint32_t width, uint32_t height) {
+    MultiState* M = ctx->multi;
+    const int G = M->G;
+    const uint32_t tiles_h = (height + 15) / 16;
+    int rc;
+    std::vector<uint32_t> sums;
+    if ((rc = fd_line_sums(M->kid[0], width, height, sums))) { copy_err(ctx, M->kid[0]); return rc; }
+    line_shares(sums, G, M->cuts);
+    std::vector<uint32_t> hist((size_t)G * 2048, 0u);
+    for (int g = 0; g < G; g++) {
+        if ((rc = fd_set_line_range(M->kid[g], true, M->cuts[g], M->cuts[g + 1]))) { copy_err(ctx, M->kid[g]); return rc; }
+        if ((rc = fd_row_histogram(M->kid[g], width, height, &hist[(size_t)g * 2048], nullptr))) { copy_err(ctx, M->kid[g]); return rc; }
+    }
+    std::vector<uint64_t> all(std::max<uint32_t>(tiles_h, 1), 0ull);
+    for (int g = 0; g < G; g++) for (uint32_t r = 0; r < tiles_h && r < 2047; r++) all[r] += hist[(size_t)g * 2048 + r];
+    band_edges(all, tiles_h, G, M->edges);
+    uint64_t max_pair = 0;
+    for (int s = 0; s < G; s++)
+        for (int g = 0; g < G; g++) {
+            uint64_t c = 0;
+            for (uint32_t r = M->edges[g]; r < M->edges[g + 1] && r < 2047; r++) c += hist[(size_t)s * 2048 + r];
+            max_pair = std::max(max_pair, c);
+        }
+    M->cap = pair_capacity(max_pair);
+    if ((uint64_t)M->cap * G >= (1ull << 30)) return MFAIL(FORMA_E_CAPACITY, "multi-device plan: more than 2^30-1 bucket slots per device");
+    for (int g = 0; g < G; g++) {
+        if ((rc = forma_hip_exchange_plan(M->kid[g], M->edges, (uint32_t)G, M->cap))) { copy_err(ctx, M->kid[g]); return rc; }
+        M->kid[g]->xuse_recv = G == 1 && M->use_rccl;      // a world of one still runs its collective (the point of the rehearsal)
+        // a band that moved invalidates what a buffer-layer cache remembers about its rows: start over (everything repaints once)
+        for (int c = 0; c < 32; c++)
+            if (M->cache_used[c] && (rc = forma_hip_cache_clear(M->kid[g], c))) { copy_err(ctx, M->kid[g]); return rc; }
+    }
+    M->planned = true; M->plan_w = width; M->plan_h = height; M->plans_made++;
+    return FORMA_OK;
+}
+
+// ---- one device's part of a frame (its own thread) ----------------------------------------------------------------------------------
+void add_timings(forma_timings_t& t, const forma_timings_t& a) {
+    t.prepare_us += a.prepare_us; t.rasterize_us += a.rasterize_us; t.sort_us += a.sort_us; t.carry_us += a.carry_us;
+    t.paint_us += a.paint_us; t.total_us += a.total_us; t.d2h_us += a.d2h_us; t.exchange_us += a.exchange_us;
+    t.sort_pass_us = std::max(t.sort_pass_us, a.sort_pass_us);
+    t.n_lines += a.n_lines; t.n_sort_passes = std::max(t.n_sort_passes, a.n_sort_passes);
+    t.n_segments = std::max(t.n_segments, a.n_segments);   // (the first half counts what was rasterized, the second what is sorted)
+    t.n_runs += a.n_runs; t.n_tile_entries += a.n_tile_entries; t.n_tiles_written += a.n_tiles_written;
+}
+
+void device_frame(MultiState* M, int g) {
+    forma_hip_ctx* kid = M->kid[g];
+    const FrameJob& J = M->job;
+    const int G = M->G;
+    forma_timings_t t1, t2;
+    memset(&t1, 0, sizeof t1); memset(&t2, 0, sizeof t2);
+    int rc = forma_hip_rasterize_bucket_frame(kid, J.width, J.height, J.timings ? &t1 : nullptr);
+    if (rc == FORMA_OK && !M->use_rccl && G > 1 && hipEventRecord(M->ev_bucket[g], kid->stream) != hipSuccess)
+        rc = fd_fail(kid, FORMA_E_HIP, "hipEventRecord (bucket)");
+    M->rc_stage[g] = rc;
+    M->bar.wait(G);                                        // A: every device has enqueued its buckets
+    bool ok = true;
+    for (int r = 0; r < G; r++) ok = ok && M->rc_stage[r] == FORMA_OK;
+    if (ok && M->use_rccl) {
+        // The canonical single-process form: ONE thread issues the collective for every communicator inside a group, each
+        // on its device's stream, behind the bucket kernels already enqueued there.  Equal splits (the pair capacity): no
+        // count has to reach the host before the exchange can be enqueued; the {count, overflow} pairs travel alongside.
+        if (g == 0) {
+            RcclApi* R = rccl_api();
+            ncclResult_t r = R->GroupStart();
+            for (int q = 0; q < G && r == ncclSuccess; q++) {
+                forma_hip_ctx* k = M->kid[q];
+                r = R->AllToAll(k->xsend_counts.p, k->xrecv_counts.p, 2, ncclUint32, M->comm[q], k->stream);
+                if (r == ncclSuccess) r = R->AllToAll(k->xsend.p, k->xrecv.p, M->cap, ncclUint64, M->comm[q], k->stream);
+            }
+            const ncclResult_t e = R->GroupEnd();
+            if (r == ncclSuccess) r = e;
+            M->rc_coll = FORMA_OK;
+            if (r != ncclSuccess) {
+                snprintf(kid->err, sizeof kid->err, "RCCL all-to-all: %s", R->GetErrorString(r));
+                M->rc_coll = FORMA_E_COMM;
+            }
+        }
+        M->bar.wait(G);                                    // B: the collective is enqueued on every stream
+        if (M->rc_coll) { ok = false; rc = M->rc_coll; if (g) memcpy(kid->err, M->kid[0]->err, sizeof kid->err); }
+    } else if (ok && G > 1) {
+        // rehearsal / FORMA_HIP_XCHG=copy: the same data movement with device copies — recv[g][s] = send[s][g], each behind
+        // the sender's bucket kernels (event) and in front of this device's gather (stream order)
+        for (int s = 0; s < G && rc == FORMA_OK; s++) {
+            forma_hip_ctx* src = M->kid[s];
+            if (hipStreamWaitEvent(kid->stream, M->ev_bucket[s], 0) != hipSuccess) { rc = fd_fail(kid, FORMA_E_HIP, "hipStreamWaitEvent"); break; }
+            hipError_t e1, e2;
+            if (M->dev[s] == M->dev[g]) {
+                e1 = hipMemcpyAsync(kid->xrecv.as<uint64_t>() + (size_t)s * M->cap, src->xsend.as<uint64_t>() + (size_t)g * M->cap,
+                                    (size_t)M->cap * 8, hipMemcpyDeviceToDevice, kid->stream);
+                e2 = hipMemcpyAsync(kid->xrecv_counts.as<uint32_t>() + 2 * s, src->xsend_counts.as<uint32_t>() + 2 * g, 8,
+                                    hipMemcpyDeviceToDevice, kid->stream);
+            } else {
+                e1 = hipMemcpyPeerAsync(kid->xrecv.as<uint64_t>() + (size_t)s * M->cap, M->dev[g],
+                                        src->xsend.as<uint64_t>() + (size_t)g * M->cap, M->dev[s], (size_t)M->cap * 8, kid->stream);
+                e2 = hipMemcpyPeerAsync(kid->xrecv_counts.as<uint32_t>() + 2 * s, M->dev[g], src->xsend_counts.as<uint32_t>() + 2 * g,
+                                        M->dev[s], 8, kid->stream);
+            }
+            if (e1 != hipSuccess || e2 != hipSuccess) rc = fd_fail(kid, FORMA_E_HIP, "bucket copy", e1 != hipSuccess ? e1 : e2);
+        }
+        ok = rc == FORMA_OK;
+    }
+    if (ok) {
+        rc = fd_gather_sort_paint(kid, J.dst, J.width, J.height, J.stride, J.channels, J.clear, &M->band_crop[g], J.cache_id,
+                                  J.timings ? &t2 : nullptr);
+    } else if (rc == FORMA_OK) {
+        rc = FORMA_E_STATE;                                // another device failed: this one did not paint
+        snprintf(kid->err, sizeof kid->err, "another device of the context failed its part of the frame");
+    }
+    if (J.timings) { add_timings(t1, t2); M->tm[g] = t1; }
+    M->rc[g] = rc;
+}
+
+void worker_main(MultiState* M, int g) {
+    (void)hipSetDevice(M->dev[g]);
+    uint64_t seen = 0;
+    for (;;) {
+        // spin briefly for the next frame (back-to-back frames), then sleep
+        unsigned spins = 0;
+        while (M->job_gen.load(std::memory_order_acquire) == seen) {
+            if (++spins < 40000) { cpu_relax(); continue; }
+            std::unique_lock<std::mutex> lock(M->m);
+            M->cv_job.wait(lock, [&] { return M->job_gen.load(std::memory_order_acquire) != seen || M->quit; });
+            break;
+        }
+        if (M->quit) return;
+        seen = M->job_gen.load(std::memory_order_acquire);
+        device_frame(M, g);
+        if (M->done.fetch_add(1, std::memory_order_acq_rel) + 1 == M->G) {
+            std::lock_guard<std::mutex> lock(M->m);
+            M->cv_done.notify_all();
+        }
+    }
+}
+
+int run_frame(forma_hip_ctx* ctx) {
+    MultiState* M = ctx->multi;
+    M->done.store(0, std::memory_order_release);
+    {
+        std::lock_guard<std::mutex> lock(M->m);
+        M->job_gen.fetch_add(1, std::memory_order_acq_rel);
+    }
+    M->cv_job.notify_all();
+    unsigned spins = 0;
+    while (M->done.load(std::memory_order_acquire) != M->G) {
+        if (++spins < 40000) { cpu_relax(); continue; }
+        std::unique_lock<std::mutex> lock(M->m);
+        M->cv_done.wait(lock, [&] { return M->done.load(std::memory_order_acquire) == M->G; });
+    }
+    // the most specific failure wins: a capacity overflow (re-plan) over a plain error over "another device failed"
+    int first = FORMA_OK, pick = -1;
+    for (int g = 0; g < M->G; g++) {
+        const int r = M->rc[g];
+        if (r == FORMA_OK) continue;
+        const bool better = pick < 0 || (r == FORMA_E_CAPACITY && first != FORMA_E_CAPACITY) || (first == FORMA_E_STATE && r != FORMA_E_STATE);
+        if (better) { first = r; pick = g; }
+    }
+    if (pick >= 0) copy_err(ctx, M->kid[pick]);
+    return first;
+}
+
+}  // namespace
+
+// ---- entry points (dispatched from api.cpp when ctx->multi) -----------------------------------------------------------------------
+int multi_create(forma_hip_ctx** out, const int* devices, int n) {
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return FORMA_E_NO_DEVICE;
+    for (int i = 0; i < n; i++) if (devices[i] < 0 || devices[i] >= count) return FORMA_E_ARG;
+    forma_hip_ctx* ctx = new (std::nothrow) forma_hip_ctx();
+    MultiState* M = new (std::nothrow) MultiState();
+    if (!ctx || !M) { delete ctx; delete M; return FORMA_E_INTERNAL; }
+    ctx->multi = M; ctx->device = devices[0];
+    M->owner = ctx; M->G = n;
+    for (int i = 0; i < n; i++) { M->dev[i] = devices[i]; for (int j = 0; j < i; j++) if (devices[j] == devices[i]) M->duplicates = true; }
+    const char* x = getenv("FORMA_HIP_XCHG");
+    M->use_rccl = !M->duplicates && !(x && !strcmp(x, "copy"));
+    int rc = FORMA_OK;
+    for (int i = 0; i < n && rc == FORMA_OK; i++) {
+        rc = forma_hip_create(&M->kid[i], devices[i]);
+        if (rc == FORMA_OK && hipEventCreateWithFlags(&M->ev_bucket[i], hipEventDisableTiming) != hipSuccess) rc = FORMA_E_HIP;
+    }
+    if (rc == FORMA_OK && !M->use_rccl && !M->duplicates) {             // copies between distinct devices: peer access both ways
+        for (int i = 0; i < n; i++) {
+            (void)hipSetDevice(devices[i]);
+            for (int j = 0; j < n; j++) if (j != i) (void)hipDeviceEnablePeerAccess(devices[j], 0);   // (already enabled is fine)
+        }
+        (void)hipGetLastError();
+    }
+    if (rc == FORMA_OK && M->use_rccl) {
+        RcclApi* R = rccl_api();
+        if (!R->handle) rc = FORMA_E_COMM;
+        else if (R->CommInitAll(M->comm, n, M->dev) != ncclSuccess) rc = FORMA_E_COMM;
+    }
+    if (rc != FORMA_OK) { multi_destroy(ctx); return rc; }
+    for (int g = 0; g < n; g++) M->th[g] = std::thread(worker_main, M, g);
+    (void)hipSetDevice(devices[0]);
+    *out = ctx;
+    return FORMA_OK;
+}
+
+void multi_destroy(forma_hip_ctx* ctx) {
+    MultiState* M = ctx->multi;
+    if (M) {
+        {
+            std::lock_guard<std::mutex> lock(M->m);
+            M->quit = true;
+            M->job_gen.fetch_add(1, std::memory_order_acq_rel);
+        }
+        M->cv_job.notify_all();
+        for (int g = 0; g < M->G; g++) if (M->th[g].joinable()) M->th[g].join();
+        if (M->use_rccl) { RcclApi* R = rccl_api(); for (int g = 0; g < M->G; g++) if (M->comm[g] && R->handle) (void)R->CommDestroy(M->comm[g]); }
+        for (int g = 0; g < M->G; g++) {
+            if (M->ev_bucket[g]) { (void)hipSetDevice(M->dev[g]); (void)hipEventDestroy(M->ev_bucket[g]); }
+            if (M->kid[g]) forma_hip_destroy(M->kid[g]);
+        }
+        delete M;
+    }
+    ctx->multi = nullptr;
+    delete ctx;
+}
+
+forma_hip_ctx* multi_first(forma_hip_ctx* ctx) { return ctx->multi->kid[0]; }
+
+#define EACH_KID(call)                                                              \
+    do {                                                                            \
+        MultiState* M = ctx->multi;                                                 \
+        for (int g = 0; g < M->G; g++) {                                            \
+            forma_hip_ctx* k = M->kid[g];                                           \
+            const int rc = (call);                                                  \
+            if (rc) { copy_err(ctx, k); return rc; }                                \
+        }                                                                           \
+    } while (0)
+
+int multi_set_geometry(forma_hip_ctx* ctx, const float* x, const float* y, const uint32_t* line_slot, size_t n_points) {
+    ctx->multi->planned = false;                          // new geometry: new line shares, new bands
+    EACH_KID(forma_hip_set_geometry(k, x, y, line_slot, n_points));
+    EACH_KID(fd_set_line_range(k, false, 0, 0));
+    return FORMA_OK;
+}
+int multi_set_geoms(forma_hip_ctx* ctx, const forma_geom_t* geoms, size_t n_geoms) {
+    // (transforms move segments between bands: the plan stays — its capacity carries 6 % slack and a frame that outgrows it
+    //  re-plans; a layer that is switched on or off changes far less than that in practice)
+    EACH_KID(forma_hip_set_geoms(k, geoms, n_geoms));
+    return FORMA_OK;
+}
+int multi_set_styles(forma_hip_ctx* ctx, const uint32_t* style_offsets, size_t n_orders, const uint32_t* style_words, size_t n_words,
+                     const uint8_t* unchanged) {
+    EACH_KID(forma_hip_set_styles(k, style_offsets, n_orders, style_words, n_words, unchanged));
+    return FORMA_OK;
+}
+int multi_set_images(forma_hip_ctx* ctx, const forma_image_t* images, size_t n_images, const uint16_t* texels, size_t n_texels) {
+    EACH_KID(forma_hip_set_images(k, images, n_images, texels, n_texels));
+    return FORMA_OK;
+}
+int multi_cache_clear(forma_hip_ctx* ctx, int cache_id) {
+    EACH_KID(forma_hip_cache_clear(k, cache_id));
+    return FORMA_OK;
+}
+
+int multi_render(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t height, size_t stride_bytes, const uint8_t channels[4],
+                 const float clear_color[4], const forma_rect_t* crop_or_null, int cache_id, forma_timings_t* timings) {
+    MultiState* M = ctx->multi;
+    const int G = M->G;
+    const uint32_t tiles_h = (height + 15) / 16;
+    if (cache_id >= 0) M->cache_used[cache_id] = true;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        if (!M->planned || M->plan_w != width || M->plan_h != height) {
+            const int rc = make_plan(ctx, width, height);
+            if (rc) return rc;
+        }
+        FrameJob& J = M->job;
+        J.dst = dst; J.width = width; J.height = height; J.stride = stride_bytes;
+        memcpy(J.channels, channels, 4); memcpy(J.clear, clear_color, 16);
+        J.has_crop = crop_or_null != nullptr; if (crop_or_null) J.crop = *crop_or_null;
+        J.cache_id = cache_id; J.timings = timings != nullptr;
+        // a device paints (and copies out) the intersection of its band with the crop, tile-rounded like Rect::new (renderer.rs:43-52)
+        for (int g = 0; g < G; g++) {
+            uint32_t ty0 = M->edges[g], ty1 = M->edges[g + 1];
+            uint32_t x0 = 0, x1 = width;
+            if (crop_or_null) {
+                ty0 = std::max(ty0, crop_or_null->y0 / 16); ty1 = std::min(ty1, std::min(tiles_h, (crop_or_null->y1 + 15) / 16));
+                x0 = crop_or_null->x0; x1 = crop_or_null->x1;
+            }
+            if (ty0 >= ty1) { ty0 = M->edges[g]; ty1 = ty0; }              // nothing of the band is inside the crop
+            M->band_crop[g] = forma_rect_t{x0, x1, ty0 * 16, std::min(ty1 * 16, height)};
+            if (ty0 == ty1) M->band_crop[g].y1 = M->band_crop[g].y0;
+        }
+        const int rc = run_frame(ctx);
+        if (rc == FORMA_E_CAPACITY && attempt < 2 && strstr(ctx->err, "exchange")) {   // a bucket outgrew the plan: measure again
+            M->planned = false;
+            continue;
+        }
+        if (rc) return rc;
+        M->last_valid = true; M->last_w = width; M->last_h = height;
+        if (timings) {
+            // devices work side by side: a stage takes as long as its slowest device; counts add up
+            memset(timings, 0, sizeof *timings);
+            for (int g = 0; g < G; g++) {
+                const forma_timings_t& t = M->tm[g];
+                timings->prepare_us = std::max(timings->prepare_us, t.prepare_us); timings->rasterize_us = std::max(timings->rasterize_us, t.rasterize_us);
+                timings->sort_us = std::max(timings->sort_us, t.sort_us); timings->sort_pass_us = std::max(timings->sort_pass_us, t.sort_pass_us);
+                timings->carry_us = std::max(timings->carry_us, t.carry_us); timings->paint_us = std::max(timings->paint_us, t.paint_us);
+                timings->total_us = std::max(timings->total_us, t.total_us); timings->d2h_us = std::max(timings->d2h_us, t.d2h_us);
+                timings->exchange_us = std::max(timings->exchange_us, t.exchange_us);
+                timings->n_lines += t.n_lines; timings->n_segments += t.n_segments; timings->n_runs += t.n_runs;
+                timings->n_tile_entries += t.n_tile_entries; timings->n_tiles_written += t.n_tiles_written;
+                timings->n_sort_passes = std::max(timings->n_sort_passes, t.n_sort_passes);
+            }
+        }
+        return FORMA_OK;
+    }
+    return MFAIL(FORMA_E_CAPACITY, "multi-device plan did not converge");
+}
+
+int multi_read_segments(forma_hip_ctx* ctx, int which, uint64_t* out, size_t capacity, size_t* out_n) {
+    MultiState* M = ctx->multi;
+    *out_n = 0;
+    if (which != 1) return MFAIL(FORMA_E_STATE, "a multi-device context holds no single unsorted stream (which = 1: the sorted stream of the painted rows)");
+    if (!M->last_valid) return MFAIL(FORMA_E_STATE, "no frame rendered yet");
+    size_t total = 0;
+    for (int g = 0; g < M->G; g++) total += M->kid[g]->n_seg;
+    *out_n = total;
+    if (total > capacity) return MFAIL(FORMA_E_CAPACITY, "segment capacity too small");
+    if (total == 0) return FORMA_OK;
+    if (!out) return FORMA_E_ARG;
+    size_t at = 0;
+    for (int g = 0; g < M->G; g++) {                      // bands ascend in tile_y, the most significant key field
+        size_t n = 0;
+        const int rc = forma_hip_read_segments(M->kid[g], 1, out + at, capacity - at, &n);
+        if (rc) { copy_err(ctx, M->kid[g]); return rc; }
+        at += n;
+    }
+    return FORMA_OK;
+}
+
+int multi_read_image(forma_hip_ctx* ctx, uint8_t* dst, size_t stride_bytes) {
+    MultiState* M = ctx->multi;
+    if (!M->last_valid) return MFAIL(FORMA_E_STATE, "no image on the device");
+    if ((size_t)M->last_w * 4 > stride_bytes) return MFAIL(FORMA_E_ARG, "width exceeds width stride");
+    for (int g = 0; g < M->G; g++) {
+        const int rc = fd_copy_image_rows(M->kid[g], dst, stride_bytes, M->edges[g] * 16, std::min(M->edges[g + 1] * 16, M->last_h));
+        if (rc) { copy_err(ctx, M->kid[g]); return rc; }
+    }
+    return FORMA_OK;
+}
+
+int multi_tiles_written(forma_hip_ctx* ctx, uint8_t* flags, size_t n_tiles) {
+    MultiState* M = ctx->multi;
+    if (!M->last_valid) return MFAIL(FORMA_E_STATE, "no frame rendered yet");
+    const uint32_t tiles_w = (M->last_w + 15) / 16, tiles_h = (M->last_h + 15) / 16;
+    const size_t T = (size_t)tiles_w * tiles_h;
+    if (n_tiles < T) return MFAIL(FORMA_E_CAPACITY, "tile flag capacity too small");
+    memset(flags, 0, n_tiles);
+    std::vector<uint8_t> tmp(T);
+    for (int g = 0; g < M->G; g++) {
+        if (M->edges[g] >= M->edges[g + 1]) continue;
+        const int rc = forma_hip_tiles_written(M->kid[g], tmp.data(), T);
+        if (rc) { copy_err(ctx, M->kid[g]); return rc; }
+        for (uint32_t ty = M->edges[g]; ty < M->edges[g + 1] && ty < tiles_h; ty++)
+            memcpy(flags + (size_t)ty * tiles_w, tmp.data() + (size_t)ty * tiles_w, tiles_w);
+    }
+    return FORMA_OK;
+}

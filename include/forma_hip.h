@@ -46,6 +46,7 @@ extern "C" {
 #define FORMA_E_CAPACITY    -4   /* caller-provided output capacity too small               */
 #define FORMA_E_STATE       -5   /* call sequence error (e.g. render before set_geometry)   */
 #define FORMA_E_INTERNAL    -6   /* device-side invariant violated (bounded spin expired…)  */
+#define FORMA_E_COMM        -7   /* multi-device context: an RCCL call failed / librccl could not be loaded */
 
 typedef struct forma_hip_ctx forma_hip_ctx;
 
@@ -126,6 +127,27 @@ typedef struct forma_timings_t {
 /* ---- lifetime ----------------------------------------------------------------------------- */
 /* `device` is a HIP device ordinal (one process per GPU: pass LOCAL_RANK). */
 int  forma_hip_create(forma_hip_ctx** out, int device);
+/* ONE context over `n` devices of this process: what `Renderer::new()` (cpu/renderer.rs:63-65)
+ * becomes when the renderer owns several GPUs.  The scene calls (set_geometry / set_geoms / set_styles / set_images) and
+ * forma_hip_render keep their signatures and their contract — `dst` is fully written when render returns — and the
+ * whole multi-GPU frame happens inside the library, one host thread per device:
+ *   every device holds the scene and rasterizes ITS share of the lines (equal pixel-segment counts, cut from the prefix
+ *   sums of the line lengths) -> HIP kernels bucket the pixel segments by the device that owns their tile row -> ONE
+ *   all-to-all over xGMI (RCCL: ncclCommInitAll over the devices, grouped ncclAllToAll of the padded buckets and their
+ *   counts on the devices' streams, no host synchronisation) -> every device sorts and paints its band of tile rows and
+ *   copies its rows straight into `dst` (disjoint row ranges, no gather collective).
+ * Bands (equal pixel-segment counts per device), line shares and bucket capacities are planned on the first frame of a
+ * geometry / canvas size and re-planned when a bucket outgrows its capacity.  Buffer-layer caches, crops, channel orders
+ * and forma_hip_read_image / _read_segments(1) / _tiles_written work as on one device; forma_hip_read_segments(1) returns
+ * the sorted stream of the PAINTED tile rows (segments above or below the canvas are dropped before the exchange, they
+ * are never painted: painter/mod.rs:731-734).  The stage entry points (flatten, prepare_lines, rasterize, sort, paint)
+ * run on devices[0]; the single-device plumbing of the process-per-GPU layout (set_band, *_frame, exchange_*) returns
+ * FORMA_E_STATE.  librccl is loaded on first use (dlopen), so single-device users never map it.
+ * n == 1 is forma_hip_create(devices[0]).  A device may be listed more than once: the "devices" are then contexts on the
+ * same GPU and the all-to-all is done with device-to-device copies instead of RCCL — a rehearsal mode for single-GPU
+ * machines (tests), not a way to go faster.  n <= FORMA_MAX_DEVICES. */
+#define FORMA_MAX_DEVICES 8
+int  forma_hip_create_multi(forma_hip_ctx** out, const int* devices, int n);
 void forma_hip_destroy(forma_hip_ctx* ctx);
 const char* forma_hip_last_error(const forma_hip_ctx* ctx);
 /* Library self-description: "forma_hip <version> gfx950". */
@@ -206,6 +228,21 @@ int forma_hip_render(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t 
                      int cache_id, forma_timings_t* timings);
 /* Drop a cache's tile state (BufferLayerCache::clear, buffer/mod.rs:189-196). */
 int forma_hip_cache_clear(forma_hip_ctx* ctx, int cache_id);
+
+/* Frames in flight inside ONE context.  The kernels of a frame are bound by their own dependent round trips, not by a
+ * chip-wide resource, so a second frame on another HIP stream fills the gaps (+25-30 % frames/s).  With n > 1 the
+ * context keeps n frame slots (own stream and per-frame buffers, ONE shared scene); a forma_hip_render call that leaves
+ * the image on the device (dst == NULL), uses no buffer-layer cache and asks for no timings ENQUEUES its frame on the
+ * next slot and returns.  The frame is verified — and re-run if a speculation of the read-back-free path failed — when
+ * its slot comes round again or when any call needs its result: forma_hip_read_image / _read_segments / _tiles_written
+ * refer to the most recent frame, every scene upload and forma_hip_sync wait for all of them.  An error of a deferred
+ * frame is returned by the call that completes it.  Frames with dst != NULL keep the reference's contract (the caller's
+ * buffer is fully written when render returns, cpu/buffer/mod.rs:43-49); cache frames stay in order (frame k + 1 reads
+ * what frame k left in the cache).  Default 1: every render call is complete when it returns. */
+#define FORMA_MAX_FRAMES_IN_FLIGHT 4
+int forma_hip_set_frames_in_flight(forma_hip_ctx* ctx, int n);
+/* Wait for every enqueued frame; returns the first error any of them produced. */
+int forma_hip_sync(forma_hip_ctx* ctx);
 
 /* ---- inspection of the last render (parity tests at full size, bench) ---------------------- */
 /* which: 0 = unsorted stream (rasterizer order), 1 = sorted stream. */

@@ -1,0 +1,331 @@
+"""SURVEY.md §8(e) behind the C ABI: `forma_hip_create_multi` — ONE context over several devices whose `forma_hip_render` is
+the whole multi-GPU frame (line-sharded rasterization -> HIP bucketing by tile-row owner -> one all-to-all -> band-local sort
++ paint -> every device copies its rows into the ONE caller buffer) — and frames in flight inside one context
+(`forma_hip_set_frames_in_flight`).
+
+This pool hands out single-GPU boxes, so the devices of most tests are the same GPU listed several times: every device still
+has its own context, stream, buffers and host thread, the planner / bucket / gather / chunk-mapped sort run exactly as on G
+GPUs, and the all-to-all is done with device copies (the library's rehearsal transport).  The RCCL transport is exercised
+with a world of one (FORMA_HIP_FORCE_EXCHANGE=1: ncclCommInitAll over one device, grouped ncclAllToAll on the library's own
+buffers and stream) and, when two GPUs are visible, for real."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import scene as S
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def oracle_for(t):
+    o = orc.Oracle()
+    S.load(o, t)
+    return o
+
+
+def painted_rows(sorted_full, tiles_h):
+    ty = (sorted_full >> np.uint64(53)).astype(np.int64) - 1
+    return sorted_full[(ty >= 0) & (ty < tiles_h)]
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0], [0] * 8])
+def test_multi_device_context_matches_the_oracle(devices):
+    import forma_amd
+    W, H = 512, 384
+    clear = (0.2, 0.3, 0.4, 1.0)
+    o = orc.Oracle()
+    t = S.random_mixed().tables(o)
+    S.load(o, t)
+    want = o.render(W, H, clear=clear)
+    c = forma_amd.Context(devices=devices)
+    S.load(c, t)
+    for frame in range(4):                                             # plan + synchronous, then read-back-free
+        img = np.full((H, W * 4), 7, np.uint8)
+        c.render(W, H, clear=clear, dst=img)
+        assert np.array_equal(img, want), frame
+        assert np.array_equal(c.segments(1), painted_rows(o.segments(1), (H + 15) // 16)), frame
+        assert np.array_equal(c.read_image(W, H), want)
+        assert c.tiles_written(W, H).all()
+    img, tm = c.render(W, H, clear=clear, timings=True)
+    assert np.array_equal(img, want) and tm["n_segments"] > 0 and tm["exchange_us"] > 0
+    c.close()
+
+
+def test_multi_device_e2e_scenes_and_tiny_canvases():
+    """the reference's e2e scenes (64 x 64: four tile rows) on 2 and 8 devices — more devices than tile rows leaves bands empty"""
+    import forma_amd
+    for devices in ([0, 0], [0] * 8):
+        c = forma_amd.Context(devices=devices)
+        for name, comp in S.e2e_scenes().items():
+            o = orc.Oracle()
+            t = comp.tables(o)
+            S.load(o, t); S.load(c, t)
+            want = o.render(64, 64)
+            for frame in range(2):
+                got = c.render(64, 64)
+                assert np.abs(want.astype(int) - got.astype(int)).max() <= 1, (name, len(devices), frame)
+        c.close()
+
+
+def test_multi_device_crop_channels_and_device_resident_frames():
+    import forma_amd
+    W, H = 500, 333                                                     # odd canvas: partial last tile row and column
+    o = orc.Oracle()
+    t = S.random_mixed(width=W, height=H, seed=5).tables(o)
+    S.load(o, t)
+    c = forma_amd.Context(devices=[0, 0, 0])
+    S.load(c, t)
+    for ch in (S.RGBA, S.BGR1, S.RGB0):
+        want = o.render(W, H, channels=ch, clear=(0.1, 0.2, 0.3, 0.5))
+        got = c.render(W, H, channels=ch, clear=(0.1, 0.2, 0.3, 0.5))
+        assert np.array_equal(got, want), ch
+    crop = (40, 300, 50, 250)
+    want = o.render(W, H, crop=crop, dst=np.full((H, W * 4), 9, np.uint8))
+    got = c.render(W, H, crop=crop, dst=np.full((H, W * 4), 9, np.uint8))
+    assert np.array_equal(got, want)
+    c.render(W, H, device_only=True)                                    # image stays on the devices, assembled on request
+    assert np.array_equal(c.read_image(W, H), o.render(W, H))
+    c.close()
+
+
+def test_multi_device_replans_when_the_scene_outgrows_its_buckets():
+    """a transform that makes every layer 1.6x larger overflows the planned bucket capacity: the frame fails ON THE DEVICE,
+    the context re-plans (new line shares, bands, capacity) and re-runs it — the caller only ever sees the right image"""
+    import forma_amd
+    W, H = 512, 384
+    o = orc.Oracle()
+    t = S.random_mixed().tables(o)
+    S.load(o, t)
+    c = forma_amd.Context(devices=[0, 0])
+    S.load(c, t)
+    for _ in range(3):
+        assert np.array_equal(c.render(W, H), o.render(W, H))
+    g = t["geoms"].copy()
+    g["flags"] = 1
+    g["xf"] = np.array([1.6, 0.0, 0.0, 1.6, -60.0, -40.0], np.float32)
+    o.set_geoms(g); c.set_geoms(g)
+    want = o.render(W, H)
+    for _ in range(3):
+        assert np.array_equal(c.render(W, H), want)
+    assert np.array_equal(c.segments(1), painted_rows(o.segments(1), (H + 15) // 16))
+    c.close()
+
+
+def test_multi_device_buffer_layer_cache():
+    """damage tracking across devices: every device keeps the cache state of its band; an unchanged frame writes nothing,
+    a moved layer rewrites the tiles the oracle-backed reference rewrites"""
+    import forma_amd
+    W, H = 256, 256
+    comp = S.Composition()
+    comp.get_mut_or_insert_default(0).insert(S.custom_square(0, 0, W, H)).set_props(S.solid((0.9, 0.9, 0.8, 1.0)))
+    comp.get_mut_or_insert_default(1).insert(S.custom_circle(80, 90, 40)).set_props(S.solid((0.8, 0.1, 0.1, 1.0)))
+    comp.get_mut_or_insert_default(2).insert(S.custom_circle(170, 180, 30)).set_props(S.solid((0.1, 0.2, 0.9, 0.6)))
+    o = orc.Oracle()
+    t = comp.tables(o)
+    S.load(o, t)
+    c = forma_amd.Context(devices=[0, 0, 0])
+    S.load(c, t)
+    n_orders = len(t["style_offsets"])
+
+    def frame(unchanged):
+        """both backends render into sentinel-filled buffers: a tile the optimizer skips (TileWriteOp::None) keeps the sentinel"""
+        u = np.asarray(unchanged, np.uint8)
+        o.set_styles(t["style_offsets"], t["style_words"], u); c.set_styles(t["style_offsets"], t["style_words"], u)
+        so, sc = np.full((H, W * 4), 201, np.uint8), np.full((H, W * 4), 201, np.uint8)
+        o.render(W, H, cache_id=0, dst=so)
+        c.render(W, H, cache_id=0, dst=sc)
+        assert np.array_equal(so, sc)
+        tiles = (sc != 201).reshape(H // 16, 16, W // 16, 16, 4).any(axis=(1, 3, 4))
+        assert np.array_equal(tiles.reshape(-1), c.tiles_written(W, H) != 0)
+        return tiles
+
+    assert frame([0] * n_orders).all()
+    assert not frame([1] * n_orders).any()                              # nothing changed: nothing written, on any device
+    g = t["geoms"].copy()                                               # layer 2 moves
+    g[2]["flags"] = 1
+    g[2]["xf"] = np.array([1, 0, 0, 1, -30.0, -20.0], np.float32)
+    o.set_geoms(g); c.set_geoms(g)
+    w = frame([1, 1, 0])
+    assert w.any() and not w.all()
+    assert not frame([1, 1, 1]).any()
+    c.close()
+
+
+def test_multi_device_context_refuses_the_single_device_plumbing():
+    import forma_amd
+    from forma_amd import FormaError
+    c = forma_amd.Context(devices=[0, 0])
+    for call in (lambda: c.set_band(0, 2), lambda: c.rasterize_frame(64, 64), lambda: c.stream_handle(), lambda: c.segments(0)):
+        with pytest.raises(FormaError) as e:
+            call()
+        assert e.value.code == -5
+    with pytest.raises(FormaError):
+        forma_amd.Context(devices=[0, 99])
+    with pytest.raises(FormaError):
+        forma_amd.Context(devices=[0] * 9)
+    c.close()
+
+
+def _full_size(workload):
+    from forma_amd import api, scenes
+    fn, W, H = scenes.WORKLOADS[workload]
+    r = api.Renderer(0)
+    r.render(fn(), api.BufferBuilder(np.zeros(W * H * 4, np.uint8), api.LinearLayout(W, W * 4, H)).build(), api.RGBA,
+             api.Color(1, 1, 1, 1), None)
+    t = dict(r.host_tables)
+    r._ctx.close()
+    o = oracle_for(t)
+    want = o.render(W, H, clear=(1.0, 1.0, 1.0, 1.0))
+    return t, W, H, want, o.segments(1)
+
+
+@pytest.mark.parametrize("workload,G", [("triangles-10m-8k", 8), ("paris-like-30k-4k", 4)])
+def test_multi_device_full_size(workload, G):
+    """BASELINE configs 3 (stand-in) and 4 through forma_hip_render on a multi-device context: image within one code value,
+    sorted stream of the painted rows bit-identical, on the planning frame and on the read-back-free frames after it"""
+    import forma_amd
+    t, W, H, want, sorted_full = _full_size(workload)
+    c = forma_amd.Context(devices=[0] * G)
+    S.load(c, t)
+    img = np.zeros((H, W * 4), np.uint8)
+    for frame in range(3):
+        img[:] = 0
+        c.render(W, H, clear=(1.0, 1.0, 1.0, 1.0), dst=img)
+        d = np.abs(img.astype(np.int16) - want.astype(np.int16))
+        assert d.max() <= 1, (frame, int(d.max()))
+        assert np.array_equal(c.segments(1), painted_rows(sorted_full, (H + 15) // 16)), frame
+    c.close()
+
+
+def test_product_api_renderer_over_several_devices():
+    """`Renderer::with_devices` through the product API: the reference's composition flow (compose -> render into a caller
+    buffer) on a multi-device renderer"""
+    from forma_amd import api, scenes
+    comp = scenes.random_cubics(200, 640, 480)
+    r1, rm = api.Renderer(0), api.Renderer(devices=[0, 0, 0, 0])
+    W, H = 640, 480
+    a, b = np.zeros(W * H * 4, np.uint8), np.zeros(W * H * 4, np.uint8)
+    lay = api.LinearLayout(W, W * 4, H)
+    for _ in range(3):
+        r1.render(comp, api.BufferBuilder(a, lay).build(), api.BGRA, api.Color(0.9, 0.9, 0.9, 1.0), None)
+        rm.render(comp, api.BufferBuilder(b, lay).build(), api.BGRA, api.Color(0.9, 0.9, 0.9, 1.0), None)
+        assert np.array_equal(a, b)
+    o = oracle_for(rm.host_tables)
+    assert np.array_equal(o.render(W, H, channels=S.BGRA, clear=(0.9, 0.9, 0.9, 1.0)).reshape(-1), b)
+
+
+_RCCL_WORLD1 = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+import torch                                    # (first: one HIP runtime in the process, tests/conftest.py)
+import scene as S
+from oracle import oracle as orc
+import forma_amd
+o = orc.Oracle()
+t = S.random_mixed().tables(o)
+S.load(o, t)
+W, H = 512, 384
+want = o.render(W, H)
+c = forma_amd.Context(devices=DEVICES)
+S.load(c, t)
+for frame in range(4):
+    img = np.full((H, W * 4), 7, np.uint8)
+    c.render(W, H, dst=img)
+    assert np.array_equal(img, want), frame
+ty = (o.segments(1) >> np.uint64(53)).astype(np.int64) - 1
+assert np.array_equal(c.segments(1), o.segments(1)[(ty >= 0) & (ty < (H + 15) // 16)])
+c.close()
+print("RCCL-OK")
+'''
+
+
+def _run_rccl_script(devices, env_extra):
+    env = dict(os.environ, **env_extra)
+    env.pop("FORMA_HIP_XCHG", None)
+    code = _RCCL_WORLD1.replace("ROOT", repr(ROOT)).replace("DEVICES", repr(devices))
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0 and "RCCL-OK" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
+
+
+@pytest.mark.timeout(300)
+def test_rccl_inside_the_library_with_a_world_of_one():
+    """everything the multi-device frame asks of RCCL, inside libforma_hip.so, on one GPU: librccl found with dlopen,
+    ncclCommInitAll over [0], grouped ncclAllToAll of the counts and of the padded buckets on the context's stream with
+    the library's own buffers, the received bucket sorted and painted (FORMA_HIP_FORCE_EXCHANGE=1)"""
+    _run_rccl_script([0], {"FORMA_HIP_FORCE_EXCHANGE": "1"})
+
+
+@pytest.mark.timeout(300)
+def test_two_devices_over_rccl_in_one_process():
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _run_rccl_script([0, 1], {})
+
+
+# ---- frames in flight inside ONE context ------------------------------------------------------------------------------------------
+def test_frames_in_flight_in_one_context():
+    import forma_amd
+    W, H = 512, 384
+    o = orc.Oracle()
+    t = S.random_mixed().tables(o)
+    S.load(o, t)
+    c = forma_amd.Context(0, frames_in_flight=3)
+    S.load(c, t)
+    clears = [(1, 1, 1, 1), (0.2, 0.3, 0.4, 1.0), (0, 0, 0, 0)]
+    for k in range(14):                                                # enqueue, enqueue, ...: results are read when asked for
+        clear = clears[k % 3]
+        assert c.render(W, H, clear=clear, device_only=True) is None
+        if k % 5 == 4:
+            assert np.array_equal(c.read_image(W, H), o.render(W, H, clear=clear)), k   # the MOST RECENT frame
+            assert np.array_equal(c.segments(1), o.segments(1))
+    c.sync()
+    # a frame into caller memory keeps the reference's contract and sees everything enqueued before it
+    img = c.render(W, H, clear=clears[1], dst=np.zeros((H, W * 4), np.uint8))
+    assert np.array_equal(img, o.render(W, H, clear=clears[1]))
+    # scene changes wait for the frames in flight, then every slot sees the new scene
+    g = t["geoms"].copy()
+    g["flags"] = 1
+    g["xf"] = np.array([0.8, 0.0, 0.0, 0.8, 30.0, 20.0], np.float32)
+    for k in range(4):
+        c.render(W, H, device_only=True)
+    o.set_geoms(g); c.set_geoms(g)
+    for k in range(7):
+        c.render(W, H, device_only=True)
+    assert np.array_equal(c.read_image(W, H), o.render(W, H))
+    c.set_frames_in_flight(1)
+    assert np.array_equal(c.render(W, H), o.render(W, H))
+    c.close()
+
+
+def test_frames_in_flight_reports_a_deferred_error():
+    """a frame that fails on the device after the call returned (a tile deeper than the painter's list) surfaces at the call
+    that completes it"""
+    import forma_amd
+    from forma_amd import FormaError
+    comp = S.Composition()
+    n = 4200
+    for i in range(n):
+        comp.get_mut_or_insert_default(i).insert(S.custom_square(2, 2, 12, 12)).set_props(S.solid((0.5, 0.5, 0.5, 0.5)))
+    o = orc.Oracle()
+    t = comp.tables(o)
+    c = forma_amd.Context(0, frames_in_flight=2)
+    S.load(c, t)
+    try:
+        for _ in range(4):
+            c.render(32, 32, device_only=True)
+        c.sync()
+        deep_ok = True
+    except FormaError as e:
+        deep_ok = False
+        assert e.code == -4
+    if deep_ok:                                                        # (builds without the layer cap render it)
+        S.load(o, t)
+        assert np.abs(c.read_image(32, 32).astype(int) - o.render(32, 32).astype(int)).max() <= 1
+    c.close()
