@@ -314,12 +314,25 @@ inline uint32_t integers_between(float a, float b) {                  // segment
     return f2u_sat(ceilf(mx) - floorf(mn) - 1.0f);
 }
 
+// The big per-frame arrays are written in full by the parallel loops that produce them, so they are allocated WITHOUT the
+// value-initialising pass of std::vector::resize: that pass runs on one thread and, on a multi-socket host, first-touches
+// every page on that thread's NUMA node — all workers then share one memory controller (the timed baseline of bench.py got
+// slower beyond 16 threads; with OMP_PROC_BIND=close the producing loop's static partition now places the pages).
+template <class T>
+struct default_init_alloc : std::allocator<T> {
+    template <class U> struct rebind { using other = default_init_alloc<U>; };
+    template <class U, class... A> void construct(U* p, A&&... a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void*)p) U; else ::new ((void*)p) U(std::forward<A>(a)...);
+    }
+};
+template <class T> using uvec = std::vector<T, default_init_alloc<T>>;
+
 struct Lines {
-    std::vector<uint32_t> orders, lengths;
-    std::vector<float> x0, y0, dx, dy, a, b, c, d;
-    void resize(size_t n) {
-        orders.assign(n, 0); lengths.assign(n, 0);
-        for (auto* v : {&x0, &y0, &dx, &dy, &a, &b, &c, &d}) v->assign(n, 0.0f);
+    uvec<uint32_t> orders, lengths;
+    uvec<float> x0, y0, dx, dy, a, b, c, d;
+    void resize(size_t n) {                                           // (every element is written by prepare_lines)
+        orders.resize(n); lengths.resize(n);
+        for (auto* v : {&x0, &y0, &dx, &dy, &a, &b, &c, &d}) v->resize(n);
     }
 };
 
@@ -442,7 +455,7 @@ inline uint64_t rasterize_one(const Lines& L, size_t li, uint32_t seg_i) {   // 
     return pixel_segment_new(L.orders[li], tile_x, tile_y, lx, ly, dam, cover);
 }
 
-void rasterize(const Lines& L, std::vector<uint64_t>& out) {           // rasterizer.rs:92-159
+void rasterize(const Lines& L, uvec<uint64_t>& out) {           // rasterizer.rs:92-159
     size_t n_lines = L.lengths.size();
     size_t N = n_lines ? L.lengths[n_lines - 1] : 0;
     out.resize(N);
@@ -461,11 +474,11 @@ void rasterize(const Lines& L, std::vector<uint64_t>& out) {           // raster
 // the textbook parallel form — contiguous chunk per thread, private histograms, offsets scanned digit-major then
 // thread-major (which keeps it stable), scatter through per-digit 64-byte write-combining buffers — so that the
 // reported CPU baseline is not held back by a serial sort (the reference's crumsort is parallel, rasterizer.rs:161-164).
-void sort_segments(std::vector<uint64_t>& v, int threads, std::vector<uint64_t>* scratch = nullptr) {
+void sort_segments(uvec<uint64_t>& v, int threads, uvec<uint64_t>* scratch = nullptr) {
     const size_t n = v.size();
     if (n < 2) return;
-    std::vector<uint64_t> local;
-    std::vector<uint64_t>& tmp = scratch ? *scratch : local;
+    uvec<uint64_t> local;
+    uvec<uint64_t>& tmp = scratch ? *scratch : local;
     if (tmp.size() < n) tmp.resize(n);
     int T = threads > 0 ? threads : 1;
     if (n < (1u << 16)) T = 1;
@@ -1197,7 +1210,7 @@ struct Oracle {
     std::vector<forma_geom_t> geoms;
     std::vector<uint32_t> style_offsets, style_words; std::vector<uint8_t> unchanged; bool has_unchanged = false;
     std::vector<forma_image_t> images; std::vector<uint16_t> texels;
-    Lines lines; std::vector<uint64_t> unsorted, sorted, sort_scratch;
+    Lines lines; uvec<uint64_t> unsorted, sorted, sort_scratch;
     void sort_frame() {                                                // Rasterizer::sort on a copy (the unsorted stream is kept for tests)
         const size_t n = unsorted.size();
         if (sorted.size() != n) sorted.resize(n);
@@ -1374,7 +1387,7 @@ void oracle_get_segments(void* o_, int which, uint64_t* out) {
 // stand-alone helpers for unit vectors
 // in place, `threads` OpenMP threads; returns seconds spent in the sort proper (copies excluded)
 double oracle_sort_array_mt(uint64_t* v, size_t n, int threads) {
-    std::vector<uint64_t> t(v, v + n), scratch(n);
+    uvec<uint64_t> t(v, v + n), scratch(n);
     set_threads(threads);
 #ifdef _OPENMP
     double t0 = omp_get_wtime();
@@ -1388,7 +1401,7 @@ double oracle_sort_array_mt(uint64_t* v, size_t n, int threads) {
     if (n) memcpy(v, t.data(), n * 8);
     return t1 - t0;
 }
-void oracle_sort_array(uint64_t* v, size_t n) { std::vector<uint64_t> t(v, v + n); sort_segments(t, 1); if (n) memcpy(v, t.data(), n * 8); }
+void oracle_sort_array(uint64_t* v, size_t n) { uvec<uint64_t> t(v, v + n); sort_segments(t, 1); if (n) memcpy(v, t.data(), n * 8); }
 uint64_t oracle_pixel_segment_new(uint32_t layer, int tile_x, int tile_y, int lx, int ly, int dam, int cover) {
     return pixel_segment_new(layer, (int16_t)tile_x, (int16_t)tile_y, (uint8_t)lx, (uint8_t)ly, (uint8_t)dam, (int8_t)cover);
 }

@@ -196,34 +196,37 @@ def test_exchange_local_count_outgrows_its_bound_between_frames():
     W, H = 512, 384
     o, t = scene_tables(S.random_mixed())
     tiles_h = (H + 15) // 16
+    edges = [0, tiles_h]
+
+    def scaled(k, tx=0.0, ty=0.0):
+        g = t["geoms"].copy()
+        g["flags"] = 1
+        g["xf"] = np.array([k, 0.0, 0.0, k, tx, ty], np.float32)      # (overrides the scene's own transforms: same for both backends)
+        return g
+
     c = forma_amd.Context(0)
     S.load(c, t)
-    c.rasterize_frame(W, H)
-    edges = [0, tiles_h]
-    n0 = len(c.segments(0))
-    x = sharding.ExchangeFrame(c, None, 0, 1, edges, W, H, 4 * sharding.pair_capacity(n0))
+    g = scaled(0.5, 100.0, 80.0)                                       # the scene at half size ...
+    o.set_geoms(g); c.set_geoms(g)
     want = o.render(W, H)
+    n0 = len(o.segments(0))
+    x = sharding.ExchangeFrame(c, None, 0, 1, edges, W, H, 8 * sharding.pair_capacity(n0))   # (bucket capacity is NOT what overflows)
     for _ in range(3):                                                 # synchronous, then read-back-free
         img = x.frame(clear=(1, 1, 1, 0), device_only=False, dst=np.zeros((H, W * 4), np.uint8))
         assert np.array_equal(img, want)
-    g = t["geoms"].copy()                                              # every layer scaled by 1.5 around the origin: N grows ~1.5x
-    g["flags"] = 1
-    g["xf"] = np.array([1.5, 0.0, 0.0, 1.5, 0.0, 0.0], np.float32)
+    g = scaled(0.9, 20.0, 10.0)                                        # ... grows: far more pixel segments than frame k - 1 + 6 %
     o.set_geoms(g); c.set_geoms(g)
     want2 = o.render(W, H)
-    assert len(o.segments(0)) > 1.2 * n0
+    assert len(o.segments(0)) > 1.3 * n0
     with pytest.raises(FormaError) as e:
         x.frame(clear=(1, 1, 1, 0), device_only=False, dst=np.zeros((H, W * 4), np.uint8))
     assert e.value.code == -4
-    c.rasterize_frame(W, H)
-    x = sharding.ExchangeFrame(c, None, 0, 1, edges, W, H, 4 * sharding.pair_capacity(len(c.segments(0))))   # re-planned
+    x = sharding.ExchangeFrame(c, None, 0, 1, edges, W, H, 8 * sharding.pair_capacity(len(o.segments(0))))   # re-planned
     for _ in range(3):
         img = x.frame(clear=(1, 1, 1, 0), device_only=False, dst=np.zeros((H, W * 4), np.uint8))
         assert np.array_equal(img, want2)
-    g2 = t["geoms"].copy()                                             # a drift the 6 % slack covers: stays read-back-free and right
-    g2["flags"] = 1
-    g2["xf"] = np.array([1.5, 0.0, 0.0, 1.5, 3.0, 2.0], np.float32)
-    o.set_geoms(g2); c.set_geoms(g2)
+    g = scaled(0.9, 23.0, 12.0)                                        # a drift the 6 % slack covers: stays read-back-free and right
+    o.set_geoms(g); c.set_geoms(g)
     want3 = o.render(W, H)
     for _ in range(2):
         img = x.frame(clear=(1, 1, 1, 0), device_only=False, dst=np.zeros((H, W * 4), np.uint8))

@@ -94,8 +94,9 @@ def test_multi_device_crop_channels_and_device_resident_frames():
 
 
 def test_multi_device_replans_when_the_scene_outgrows_its_buckets():
-    """a transform that makes every layer 1.6x larger overflows the planned bucket capacity: the frame fails ON THE DEVICE,
-    the context re-plans (new line shares, bands, capacity) and re-runs it — the caller only ever sees the right image"""
+    """a transform that makes the scene grow overflows what the plan provisioned (local segment counts, bucket capacity):
+    the frame fails ON THE DEVICE, the context re-plans (new line shares, bands, capacity) and re-runs it — the caller only
+    ever sees the right image"""
     import forma_amd
     W, H = 512, 384
     o = orc.Oracle()
@@ -103,16 +104,20 @@ def test_multi_device_replans_when_the_scene_outgrows_its_buckets():
     S.load(o, t)
     c = forma_amd.Context(devices=[0, 0])
     S.load(c, t)
-    for _ in range(3):
-        assert np.array_equal(c.render(W, H), o.render(W, H))
-    g = t["geoms"].copy()
-    g["flags"] = 1
-    g["xf"] = np.array([1.6, 0.0, 0.0, 1.6, -60.0, -40.0], np.float32)
-    o.set_geoms(g); c.set_geoms(g)
-    want = o.render(W, H)
-    for _ in range(3):
-        assert np.array_equal(c.render(W, H), want)
-    assert np.array_equal(c.segments(1), painted_rows(o.segments(1), (H + 15) // 16))
+
+    def scaled(k, tx, ty):
+        g = t["geoms"].copy()
+        g["flags"] = 1
+        g["xf"] = np.array([k, 0.0, 0.0, k, tx, ty], np.float32)
+        return g
+
+    for k, tx, ty in ((0.4, 150.0, 100.0), (0.95, 10.0, 5.0), (0.95, 14.0, 8.0), (0.3, 10.0, 250.0), (1.0, 0.0, 0.0)):
+        g = scaled(k, tx, ty)
+        o.set_geoms(g); c.set_geoms(g)
+        want = o.render(W, H)
+        for _ in range(3):
+            assert np.array_equal(c.render(W, H), want), (k, tx, ty)
+        assert np.array_equal(c.segments(1), painted_rows(o.segments(1), (H + 15) // 16))
     c.close()
 
 
