@@ -3,31 +3,37 @@
 
 A "step" is one `Renderer::render` frame (prepare lines -> rasterize -> radix sort -> carry pre-pass -> per-tile paint)
 of a synthetic scene whose geometry, layer table and styles are already resident in HBM; the image stays device-resident
-(the PCIe-inclusive rate is reported separately, never as `value`).  One process per GPU.
+(the PCIe-inclusive rate is reported separately, never as `value`).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME | --svg FILE [--svg-scale S]]
-                    [--in-flight F] [--mode exchange|bands|frames] [--animated] [--no-cpu-baseline]
+                    [--in-flight F] [--mode multi|exchange|bands|frames] [--no-animated] [--no-cpu-baseline]
 
-N = 1: `value` = frames completed / wall time of exactly K frames with `--in-flight` F frames in flight (default 3): F
-renderer contexts on the one GPU, each with its own HIP stream and buffers, each fed by its own host thread.  Every frame
-does all of the work (nothing is shared between contexts but the scene description); the kernels of this path are
-latency-bound, so frames that overlap fill the machine — what a frame server or an animation export does.  The rate of
-ONE context rendering frame after frame (`fps_one_frame_in_flight`, with its per-frame latency and per-stage device times)
-is always reported next to it, as is the spread over five more blocks of K frames.
+N = 1.  ONE renderer context — what a caller of `Renderer::render` has — renders exactly K frames; `value` = K / wall time.
+The context keeps `--in-flight` F frame slots (default 3, `forma_hip_set_frames_in_flight`): a device-resident frame is
+enqueued on the next slot and verified when the slot comes round, so the kernels of consecutive frames overlap on the GPU
+(they are bound by their own dependent round trips, not by a chip-wide resource).  Next to it, always:
+  * `fps_render_call`: the same context with ONE frame in flight, every call complete when it returns — SURVEY §8(d)'s
+    "1 / wall time of one render call" — with its latency, and `fps_including_d2h`: >= 60 such calls that also copy the
+    33 MB image into caller memory (what `Renderer::render` promises; never `value`);
+  * `stages_us` and `roofline` (the radix digit pass, HBM-bound): a further region of K frames with one frame in flight and
+    HIP events at the stage boundaries on the context's stream — with frames overlapping, a launch duration is not the
+    kernel's own;
+  * `animated`: BASELINE config 5 (deterministic spaceship, 600 frames at 4K, with and without the buffer-layer cache);
+  * `cpu_baseline`: the C++ oracle on the same scene tables (`kind: "port"`).
+`roofline.traffic` is NOT measured in the run: it is read from the committed counter summary (separate rocprofv3 --pmc
+passes of this command, tools/pmc_round.py) and labelled so.
 
-N > 1 (default `--mode exchange`, strong scaling, the north star's layout): ONE frame is split — every GPU rasterizes 1/N
-of the lines, HIP kernels bucket the pixel segments by tile-row owner, one RCCL all-to-all over xGMI moves them, the owner
-sorts and paints its band.  `--mode bands` replicates the scene and culls by band (no exchange); `--mode frames` renders
-whole frames on every GPU (weak scaling).  `value` is always the whole-job aggregate / max-over-ranks wall time.
+N > 1, launched as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (the contract): default `--mode
+multi` — rank 0 holds ONE renderer over all N GPUs (`forma_hip_create_multi`: per-device host threads inside the library,
+line-sharded rasterization, HIP bucketing by tile-row owner, ONE RCCL all-to-all of pixel segments over xGMI, band-local
+sort + paint, every device copying its rows into the one caller buffer) and the other ranks only take part in the barriers
+and the max-over-ranks timing; strong scaling, `value` = frames of the ONE scene per second.  A short preflight in a child
+process (killed on timeout) guards the first multi-GPU execution of that path; on failure the run falls back to `--mode
+exchange` (one process per GPU, the same layout driven through torch.distributed), then `bands`, then `frames`, and says so.
 
-`roofline` (the radix digit pass, HBM-bound) and `stages_us` come from a second timed region of the same run — K more
-frames with ONE frame in flight and HIP events recorded at the stage boundaries on the context's stream: with several frames
-in flight the kernels of different frames time-share the chip and a launch duration is no longer the kernel's own.
-`roofline.traffic` is NOT measured in the run: it is read from profiles/r02_pmc_summary.json (separate rocprofv3 --pmc passes
-of the same build, tools/pmc_round.py) and labelled so.  `cpu_baseline` = the C++ oracle on the same scene tables, N = 1 only.
-
-Rehearsal switches for single-GPU boxes (never set by the driver): FORMA_BENCH_MODE_AT_1=1 runs the sharded mode with one
-rank; FORMA_BENCH_BACKEND=gloo + FORMA_BENCH_ONE_DEVICE=1 run N ranks on one GPU without RCCL.
+Rehearsal switches for single-GPU boxes (never set by the driver): FORMA_BENCH_MODE_AT_1=1 runs a sharded mode with one rank
+(`multi`: FORMA_BENCH_DEVICES=0,0,0,0 lists the "devices"); FORMA_BENCH_BACKEND=gloo + FORMA_BENCH_ONE_DEVICE=1 run N ranks
+on one GPU without RCCL.
 
 Prints ONE JSON line on rank 0.
 """
@@ -37,9 +43,12 @@ import argparse
 import json
 import os
 import statistics
+import subprocess
 import sys
-import threading
 import time
+
+os.environ.setdefault("OMP_PROC_BIND", "close")      # the CPU baseline's OpenMP loops: threads stay where their pages are
+os.environ.setdefault("OMP_PLACES", "cores")
 
 import numpy as np
 
@@ -48,7 +57,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2   # wave64 VALU instructions/ns the chip can issue: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles
-PMC_FILE = os.path.join("profiles", "r02_pmc_summary.json")   # tools/pmc_round.py: separate rocprofv3 --pmc passes of this command
+PMC_FILES = [os.path.join("profiles", "r03_pmc_summary.json"), os.path.join("profiles", "r02_pmc_summary.json")]
 
 
 def parse():
@@ -57,21 +66,44 @@ def parse():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--workload", default="paris-like-30k-4k")
-    ap.add_argument("--in-flight", type=int, default=3, help="N = 1: renderer contexts rendering concurrently (frames in flight)")
-    ap.add_argument("--mode", default="exchange", choices=["exchange", "bands", "frames"],
-                    help="N > 1: 'exchange' = ONE frame, lines / N rasterized per GPU, all-to-all of pixel segments to the "
-                         "tile-row owners (strong scaling); 'bands' = ONE frame, scene replicated, band culling, no exchange "
-                         "(strong scaling); 'frames' = every GPU renders whole frames (weak scaling)")
+    ap.add_argument("--in-flight", type=int, default=3, help="N = 1: frame slots inside the ONE renderer context (frames in flight)")
+    ap.add_argument("--mode", default="multi", choices=["multi", "exchange", "bands", "frames"],
+                    help="N > 1: 'multi' = ONE renderer over all GPUs (forma_hip_create_multi, RCCL inside the library), driven "
+                         "by rank 0; 'exchange' = the same layout with one process per GPU (torch.distributed all-to-all); "
+                         "'bands' = replicated scene, band culling, no exchange; 'frames' = whole frames per GPU (weak scaling)")
     ap.add_argument("--svg", default=None, metavar="FILE", help="render this SVG (e.g. the real paris-30k.svg) instead of a synthetic workload")
     ap.add_argument("--svg-scale", type=float, default=1.0)
-    ap.add_argument("--animated", action="store_true", help="also measure BASELINE config 5 (deterministic spaceship, 4K, damage cache)")
+    ap.add_argument("--no-animated", action="store_true", help="skip BASELINE config 5 (deterministic spaceship, 600 frames at 4K)")
+    ap.add_argument("--animated-frames", type=int, default=600)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--preflight", default=None, help=argparse.SUPPRESS)     # child process: try a multi-device context, print OK
     return ap.parse_args()
+
+
+def preflight(devices):
+    """child process of `--mode multi`: ONE context over `devices`, a small scene, a few frames, compared across frames.
+    Runs where a hang can be killed without losing the bench line."""
+    import torch  # noqa: F401  (first: one HIP runtime in the process)
+    from forma_amd import api, scenes
+    comp = scenes.random_cubics(64, 512, 512)
+    r = api.Renderer(devices=devices)
+    buf = np.zeros(512 * 512 * 4, np.uint8)
+    lay = api.LinearLayout(512, 2048, 512)
+    first = None
+    for _ in range(4):
+        r.render(comp, api.BufferBuilder(buf, lay).build(), api.RGBA, api.Color(1, 1, 1, 1), None)
+        first = buf.copy() if first is None else first
+        assert np.array_equal(first, buf)
+    assert (buf != 255).any()
+    print("PREFLIGHT-OK", flush=True)
 
 
 def main():
     args = parse()
+    if args.preflight is not None:
+        preflight([int(v) for v in args.preflight.split(",")])
+        return
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -80,9 +112,6 @@ def main():
         if rank == 0:
             print(f"WORLD_SIZE={world} does not match --gpus {args.gpus}", file=sys.stderr)
         args.gpus = world
-    # Rehearsal switches (never set by the driver): FORMA_BENCH_BACKEND=gloo runs the whole multi-process flow without RCCL
-    # (collectives on CPU tensors, the all-to-all staged through host memory), FORMA_BENCH_ONE_DEVICE=1 puts every rank on
-    # device 0 — together they let N ranks share the one GPU of a single-GPU box and exercise all the host logic of N > 1.
     backend = os.environ.get("FORMA_BENCH_BACKEND", "nccl")
     if os.environ.get("FORMA_BENCH_ONE_DEVICE"):
         local = 0
@@ -97,6 +126,23 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from forma_amd import api, scenes, sharding
+    sharded = world > 1 or bool(os.environ.get("FORMA_BENCH_MODE_AT_1"))
+    multi_devices = [int(v) for v in os.environ["FORMA_BENCH_DEVICES"].split(",")] if os.environ.get("FORMA_BENCH_DEVICES") else list(range(world))
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn):
+        """wall seconds of fn(), bracketed by barrier + synchronize on both sides, maximum over ranks"""
+        sync_all()
+        t0 = time.perf_counter()
+        fn()
+        sync_all()
+        dt = time.perf_counter() - t0
+        return sharding.max_over_ranks(dist, dt, device=cdev) if dist is not None else dt
 
     def measure(workload, primary=True, mode_req=None):
         if args.svg and primary:
@@ -111,20 +157,23 @@ def main():
         clear = api.Color(1.0, 1.0, 1.0, 1.0)
         clr = (clear.r, clear.g, clear.b, clear.a)
         channels = api.RGBA
+        mode = (mode_req or args.mode) if sharded else "single"
+        driver = mode != "multi" or rank == 0                    # multi: rank 0 drives every GPU, the others only synchronise
+        image = np.zeros((height, width * 4), np.uint8)
 
-        def make_renderer():
-            """a context with the scene resident: first frame through the public API (flattens on the GPU, uploads the tables)"""
-            r = api.Renderer(device=local)
-            img = np.zeros((height, width * 4), np.uint8)
-            r.render(comp, api.BufferBuilder(img.reshape(-1), api.LinearLayout(width, width * 4, height)).build(), api.RGBA, clear, None, timings=True)
-            return r, img
-
-        renderer, image = make_renderer()
-        ctx = renderer._ctx
-        n_segments_full = renderer.last_timings["n_segments"]
-        mode = (mode_req or args.mode) if (world > 1 or os.environ.get("FORMA_BENCH_MODE_AT_1")) else "single"   # (env: exercise a sharded mode on one GPU)
-        in_flight = max(1, args.in_flight) if mode == "single" else 1     # (a sharded frame is one context per GPU)
-        pool = [ctx] + [make_renderer()[0]._ctx for _ in range(in_flight - 1)]
+        renderer = None
+        if driver:
+            renderer = api.Renderer(devices=multi_devices) if mode == "multi" else api.Renderer(device=local)
+            # first frame through the public API: flattens on the GPU, uploads the tables, plans (multi)
+            renderer.render(comp, api.BufferBuilder(image.reshape(-1), api.LinearLayout(width, width * 4, height)).build(), api.RGBA, clear, None, timings=True)
+        ctx = renderer._ctx if renderer else None
+        n_segments_full = renderer.last_timings["n_segments"] if renderer and mode != "multi" else 0
+        if mode == "multi":
+            n_full = torch.tensor([len(ctx.segments(1)) if driver else 0], dtype=torch.int64, device=cdev)
+            if dist is not None:
+                dist.broadcast(n_full, 0)
+            n_segments_full = int(n_full.item())
+        in_flight = max(1, min(4, args.in_flight)) if mode == "single" else 1
 
         crop, row0, row1, xf = None, 0, tiles_h, None
         if mode == "bands":
@@ -144,103 +193,91 @@ def main():
             cap = sharding.pair_capacity(sharding.max_pair_count(dist, ctx.segments(0), edges, world, device=cdev))
             xf = sharding.ExchangeFrame(ctx, dist, rank, world, edges, width, height, cap)
 
-        def frame(c=ctx, timings=False):
+        def frame(timings=False, dst=None):
+            if not driver:
+                return None
             if xf is not None:
-                return xf.frame(channels=channels, clear=clr, timings=timings, device_only=True)
-            return c.render(width, height, channels=channels, clear=clr, crop=crop, device_only=True, timings=timings)
+                return xf.frame(channels=channels, clear=clr, timings=timings, device_only=dst is None, dst=dst, stride=width * 4 if dst is not None else None)
+            if dst is not None:
+                return ctx.render(width, height, channels=channels, clear=clr, crop=crop, dst=dst, stride=width * 4, timings=timings)
+            return ctx.render(width, height, channels=channels, clear=clr, crop=crop, device_only=True, timings=timings)
 
-        def sync_all():
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-            torch.cuda.synchronize()
+        def frames(n):
+            """n frames; with frames in flight the calls return before their frames are done, so the block ends with a sync"""
+            for _ in range(n):
+                frame()
+            if driver and mode in ("single", "frames"):
+                ctx.sync()
 
-        def run_block(steps, ctxs, acc=None):
-            """exactly `steps` frames, len(ctxs) in flight: wall seconds (max over ranks).  With `acc` (a dict) every frame also
-            records HIP events at its stage boundaries on its context's stream (forma_timings_t) and the per-frame values are
-            summed into it: acc[key] = sum, acc["_frames"] = count."""
-            share = [steps // len(ctxs) + (1 if i < steps % len(ctxs) else 0) for i in range(len(ctxs))]
-            per = [dict() for _ in ctxs]
+        def rate(steps, per_step=1):
+            return per_step * steps / timed(lambda: frames(steps))
 
-            def work(c, n, a):
-                for _ in range(n):
-                    if acc is None:
-                        frame(c)
-                    else:
-                        _, t = frame(c, timings=True)
-                        for k, v in t.items():
-                            a[k] = a.get(k, 0.0) + float(v)
-                        a["_frames"] = a.get("_frames", 0) + 1
-
-            sync_all()
-            t0 = time.perf_counter()
-            if len(ctxs) == 1:
-                work(ctxs[0], steps, per[0])
-            else:
-                ths = [threading.Thread(target=work, args=(c, n, a)) for c, n, a in zip(ctxs, share, per)]
-                for t in ths:
-                    t.start()
-                for t in ths:
-                    t.join()
-            sync_all()
-            dt = time.perf_counter() - t0
-            if acc is not None:
-                for a in per:
-                    for k, v in a.items():
-                        acc[k] = acc.get(k, 0) + v
-            return sharding.max_over_ranks(dist, dt, device=cdev) if dist is not None else dt
-
-        for c in pool:
-            for _ in range(max(1, args.warmup // len(pool))):
-                frame(c)
-        acc_one = {}
-        elapsed = run_block(args.steps, pool)                       # THE timed region: exactly K frames, F in flight -> `value`
         frames_per_step = world if mode == "frames" else 1          # frames mode: one whole frame per GPU per step
+        if driver and in_flight > 1:
+            ctx.set_frames_in_flight(in_flight)
+        frames(max(args.warmup, in_flight + 1 if in_flight > 1 else 1))   # (every frame slot learns its predictions on its first frame)
+        elapsed = timed(lambda: frames(args.steps))                 # THE timed region: exactly K frames -> `value`
         fps = frames_per_step * args.steps / elapsed
         ms_per_step = elapsed / args.steps * 1e3
-        # spread: five more blocks of K frames, pipelined; and five blocks of K frames with ONE frame in flight — the second
-        # timed region of this run: a kernel's launch duration is its own only when nothing else shares the chip, so the
-        # per-stage times and the roofline of the radix pass are taken there (HIP events on the context's stream)
-        blocks = [frames_per_step * args.steps / run_block(args.steps, pool) for _ in range(5)]
-        blocks1 = [frames_per_step * args.steps / run_block(args.steps, pool[:1]) for _ in range(5)] if in_flight > 1 else blocks
-        run_block(args.steps, pool[:1], acc_one)                    # K more frames, one in flight, with the stage events
+        blocks = [rate(args.steps, frames_per_step) for _ in range(5)]
+        # one frame in flight: every render call is complete when it returns (SURVEY §8d: 1 / wall time of one render call)
+        if driver and in_flight > 1:
+            ctx.set_frames_in_flight(1)
+            frames(2)
+        blocks1 = [rate(args.steps, frames_per_step) for _ in range(5)] if in_flight > 1 else blocks
+        # K more frames, one in flight, HIP events at the stage boundaries on the context's stream(s)
+        acc = {}
 
-        def means(a):
-            n = max(a.get("_frames", 0), 1)
-            return {k: v / n for k, v in a.items() if k != "_frames"}
-
-        stage = means(acc_one)
-        n_local = int(round(stage["n_segments"]))                   # (exchange / bands: the segments this rank sorts)
-        passes = int(round(stage["n_sort_passes"]))
-        pass_us = stage["sort_pass_us"]
+        def staged():
+            for _ in range(args.steps):
+                r = frame(timings=True)
+                if r is None:
+                    continue
+                for k, v in r[1].items():
+                    acc[k] = acc.get(k, 0.0) + float(v)
+                acc["_frames"] = acc.get("_frames", 0) + 1
+        timed(staged)
+        nfr = max(acc.get("_frames", 0), 1)
+        stage = {k: v / nfr for k, v in acc.items() if k != "_frames"}
+        if dist is not None and mode == "multi":                      # rank 0 measured; everybody reports the same line
+            keys = ["prepare_us", "rasterize_us", "exchange_us", "sort_us", "sort_pass_us", "carry_us", "paint_us", "total_us", "n_segments", "n_sort_passes"]
+            tt = torch.tensor([stage.get(k, 0.0) for k in keys], dtype=torch.float64, device=cdev)
+            dist.broadcast(tt, 0)
+            stage = {k: float(v) for k, v in zip(keys, tt.tolist())}
+        n_local = int(round(stage.get("n_segments", 0)))            # segments one device sorts (multi: summed over the devices)
+        if mode == "multi":
+            n_local = max(1, n_local // max(len(multi_devices), 1))
+        passes = int(round(stage.get("n_sort_passes", 0)))
+        pass_us = stage.get("sort_pass_us", 0.0)
         algo_bytes_per_pass = 16.0 * n_local                        # 8 B read + 8 B written per key per digit pass (SURVEY §8d)
         achieved = (algo_bytes_per_pass / (pass_us * 1e-6) / 1e9) if pass_us > 0 else 0.0
-        pmc = None
-        try:
-            with open(os.path.join(ROOT, PMC_FILE)) as f:
-                pmc = json.load(f)
-        except Exception:
-            pmc = None
-        use_pmc = pmc is not None and workload == "paris-like-30k-4k" and world == 1
+        pmc, pmc_file = None, None
+        for f in PMC_FILES:
+            try:
+                with open(os.path.join(ROOT, f)) as fh:
+                    pmc, pmc_file = json.load(fh), f
+                break
+            except Exception:
+                continue
+        use_pmc = pmc is not None and workload == "paris-like-30k-4k" and mode == "single"
         roofline = {"bound": "hbm", "kernel": "k_onesweep<8>: one radix digit pass (LSB, 8-bit digits over live key bits, u64 keys, chained scan)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": next((v.get("hbm_bytes_per_launch") for k, v in pmc["kernels"].items() if k.startswith("k_onesweep<8")), None) if use_pmc else None,
-                    "traffic_source": (PMC_FILE + " — separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this command on "
+                    "traffic_source": (pmc_file + " — separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this command on "
                                        "the committed build (gfx950: FETCH_SIZE x 2), NOT measured in this run") if use_pmc else None,
                     "algorithmic_bytes_per_launch": algo_bytes_per_pass, "avg_launch_us": round(pass_us, 2), "passes": passes,
-                    "measured": f"HIP events on the context's stream around every k_onesweep launch of {acc_one.get('_frames', 0)} frames with ONE "
-                                "frame in flight (this run's second timed region; matches `rocprofv3 --kernel-trace --stats -- python "
-                                "bench.py --in-flight 1`, profiles/r02_kernel_stats_inflight1.csv)"}
+                    "measured": f"HIP events on the context's stream around every k_onesweep launch of {acc.get('_frames', 0)} frames with ONE "
+                                "frame in flight (a further timed region of this run; matches `rocprofv3 --kernel-trace --stats -- python "
+                                "bench.py --in-flight 1`, profiles/)"}
         if in_flight > 1:
-            roofline["while_pipelined"] = ("with several frames in flight the kernels of different frames time-share the chip: rocprofv3 of the "
-                                           "default command (profiles/r02_kernel_stats_default.csv) shows every kernel's average about "
-                                           "1.5-2x its one-in-flight duration, while the frame rate rises; a launch duration is the kernel's "
-                                           "own only with one frame in flight, which is where this roofline is measured")
+            roofline["while_pipelined"] = ("with several frames in flight the kernels of different frames time-share the chip (every kernel's "
+                                           "average rises to about 1.5-2x its one-in-flight duration while the frame rate rises): a launch "
+                                           "duration is the kernel's own only with one frame in flight, which is where this roofline is measured")
         # the painter is not an HBM kernel: VALU issue and LDS bound it.  Live: its launch time; from the committed counters of
         # the same build: wave-level VALU instructions per launch and the LDS bank-conflict ratio.
-        painter = {"kernel": "k_paint_wave (one wavefront per 16x16 tile)", "bound": "valu+lds", "avg_launch_us": round(stage["paint_us"], 1),
+        painter = {"kernel": "k_paint_wave (one wavefront per 16x16 tile)", "bound": "valu+lds", "avg_launch_us": round(stage.get("paint_us", 0.0), 1),
                    "hbm_algorithmic_bytes": 8.0 * n_local + 4.0 * width * height,
-                   "hbm_achieved_GBs": round((8.0 * n_local + 4.0 * width * height) / max(stage["paint_us"], 1e-3) / 1e3, 1)}
+                   "hbm_achieved_GBs": round((8.0 * n_local + 4.0 * width * height) / max(stage.get("paint_us", 0.0), 1e-3) / 1e3, 1)}
         if use_pmc and "k_paint_wave" in pmc["kernels"]:
             k = pmc["kernels"]["k_paint_wave"]
             valu = k.get("SQ_INSTS_VALU")
@@ -250,31 +287,26 @@ def main():
                                 "unit": "G wave64 VALU instructions/s", "frac": round(ach / VALU_PEAK_GINST, 4)})
             if k.get("SQ_LDS_IDX_ACTIVE"):
                 painter["lds_bank_conflict_ratio"] = round(k.get("SQ_LDS_BANK_CONFLICT", 0) / k["SQ_LDS_IDX_ACTIVE"], 4)
-            painter["counters_source"] = PMC_FILE + " (separate --pmc passes, NOT this run)"
+            painter["counters_source"] = pmc_file + " (separate --pmc passes, NOT this run)"
 
-        # PCIe-inclusive frames (image copied into caller memory) — reported, never `value`
-        fps_d2h = None
-        if mode in ("single", "frames", "bands"):
-            imgs = [image] + [np.zeros_like(image) for _ in pool[1:]]
+        # PCIe-inclusive frames: every call copies its image (its band) into caller memory and is complete when it returns
+        n_d2h = max(60, args.steps)
 
-            def d2h_frames(c, img, n):
-                for _ in range(n):
-                    c.render(width, height, channels=channels, clear=clr, crop=crop, dst=img.reshape(-1), stride=width * 4)
-            sync_all()
-            t1 = time.perf_counter()
-            ths = [threading.Thread(target=d2h_frames, args=(c, im, 6)) for c, im in zip(pool, imgs)]
-            for t in ths:
-                t.start()
-            for t in ths:
-                t.join()
-            torch.cuda.synchronize()
-            fps_d2h = round(6 * len(pool) / (time.perf_counter() - t1), 2)
+        def d2h_frames():
+            for _ in range(n_d2h):
+                frame(dst=image)
+        fps_d2h = round(frames_per_step * n_d2h / timed(d2h_frames), 2)
 
         sharding_txt = {
-            "single": "none", "frames": f"frame-parallel x{world}: every GPU renders whole frames of the workload (units = frames), no exchange",
+            "single": "none",
+            "multi": f"ONE renderer context over {len(multi_devices)} GPUs (forma_hip_create_multi, driven by rank 0; per-device host threads inside "
+                     f"libforma_hip.so): lines / {len(multi_devices)} rasterized per GPU, HIP bucketing by tile-row owner, one RCCL all-to-all of pixel "
+                     f"segments on the devices' streams, band-local sort + paint, every device writes its rows of the one caller buffer",
+            "frames": f"frame-parallel x{world}: every GPU renders whole frames of the workload (units = frames), no exchange",
             "bands": f"tile-row bands x{world} of ONE frame, replicated scene, band culling, no data-path collective",
-            "exchange": f"ONE frame: lines / {world} rasterized per GPU, HIP bucketing by tile-row owner, one RCCL all-to-all of pixel segments "
-                        f"(padded equal split on the context's stream), band-local sort + paint"}[mode]
+            "exchange": f"ONE frame, one process per GPU: lines / {world} rasterized per GPU, HIP bucketing by tile-row owner, one RCCL all-to-all of "
+                        f"pixel segments (torch.distributed, padded equal split on the context's stream), band-local sort + paint"}[mode]
+        lat = 1e3 / statistics.median(blocks1)
         out = {
             "metric": "frames/sec (sorted+painted, device-resident) + Mpixel-segments/sec",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -282,12 +314,17 @@ def main():
             "scaling": "weak" if mode in ("single", "frames") else "strong", "vs_baseline": None,
             "dtype": "u64 segments / f64+f32 rasterizer / f32 painter", "data": "synthetic",
             **({"rehearsal_backend": backend} if backend != "nccl" else {}),
+            "value_is": (f"ONE renderer context, {in_flight} frames in flight inside it (forma_hip_set_frames_in_flight), one host thread"
+                         if mode == "single" else sharding_txt),
             "mpixel_segments_per_s": round(n_segments_full * fps / 1e6, 1),
             "frames_in_flight": in_flight,
             "fps_blocks": {"median": round(statistics.median(blocks), 1), "min": round(min(blocks), 1), "max": round(max(blocks), 1), "blocks": 5},
-            "fps_one_frame_in_flight": {"median": round(statistics.median(blocks1), 1), "min": round(min(blocks1), 1), "max": round(max(blocks1), 1),
-                                        "frame_latency_ms": round(1e3 / statistics.median(blocks1), 4)},
+            "fps_render_call": {"median": round(statistics.median(blocks1), 1), "min": round(min(blocks1), 1), "max": round(max(blocks1), 1),
+                                "frame_latency_ms": round(lat, 4),
+                                "what": "the same context with ONE frame in flight: every render call is complete when it returns "
+                                        "(SURVEY §8d: 1 / wall time of one render call, device-resident output)"},
             "fps_including_d2h": fps_d2h,
+            "fps_including_d2h_frames": n_d2h,
             "config": {"workload": workload + (" (labelled stand-in: paris-30k.svg is not in the reference checkout)"
                                                      if workload.startswith("paris") else ""),
                        "canvas": [width, height], "layers": len(comp), "pixel_segments": int(n_segments_full),
@@ -296,13 +333,14 @@ def main():
             "roofline": roofline,
             "roofline_painter": painter,
         }
-        if primary and rank == 0 and world == 1 and args.animated:
-            out["animated"] = animated_leg(local)
+        out["fps_one_frame_in_flight"] = out["fps_render_call"]       # (the name earlier rounds used)
+        if primary and rank == 0 and world == 1 and not args.no_animated and mode == "single":
+            out["animated"] = animated_leg(local, args.animated_frames)
         if primary and rank == 0 and world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(renderer, width, height, args.cpu_seconds)
-        for c in pool:                                              # free the device buffers before the next workload
+        if ctx is not None:
             try:
-                c.close()
+                ctx.close()                                         # free the device buffers before the next workload
             except Exception:
                 pass
         return out
@@ -315,17 +353,37 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(int(t.item()))
 
-    # N > 1: the requested sharded mode first; if it fails on any rank (the RCCL exchange has only ever been exercised on
-    # single-GPU boxes and with gloo), fall back to the modes without a data-path collective rather than lose the line
-    modes = [args.mode] + [m for m in ("bands", "frames") if m != args.mode] if world > 1 else [None]
-    out, errors = None, {}
+    def multi_preflight_ok():
+        """rank 0 tries the multi-device context in a child process that can be killed; everybody learns the verdict"""
+        ok, why = True, ""
+        if rank == 0:
+            try:
+                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--preflight", ",".join(str(d) for d in multi_devices)],
+                                   capture_output=True, text=True, timeout=240)
+                ok = p.returncode == 0 and "PREFLIGHT-OK" in p.stdout
+                why = (p.stderr or p.stdout)[-400:] if not ok else ""
+            except subprocess.TimeoutExpired:
+                ok, why = False, "preflight timed out (killed)"
+            except Exception as e:                                    # noqa: BLE001
+                ok, why = False, repr(e)
+        return agreed(ok), why
+
+    # N > 1: the requested sharded mode first; if it fails on any rank, fall back to the next one rather than lose the line
+    chain = ["multi", "exchange", "bands", "frames"]
+    modes = [args.mode] + [m for m in chain[chain.index(args.mode) + 1:] if m != args.mode] if sharded else [None]
+    out, errors, m = None, {}, None
     for m in modes:
+        if m == "multi" and world > 1:
+            ok, why = multi_preflight_ok()
+            if not ok:
+                errors["multi"] = "preflight: " + why
+                continue
         try:
             out = measure(args.workload, mode_req=m)
             ok = True
-        except Exception as e:
+        except Exception as e:                                        # noqa: BLE001
             ok, errors[m or "single"] = False, repr(e)
-            if world == 1:
+            if not sharded:
                 raise
         if agreed(ok):
             break
@@ -334,7 +392,7 @@ def main():
         raise SystemExit(f"every mode failed: {errors}")
     if errors:
         out["mode_fallback_errors"] = errors
-    if world > 1 and not args.svg and args.workload != "triangles-10m-8k" and out["scaling"] == "strong":
+    if sharded and not args.svg and args.workload != "triangles-10m-8k" and out["scaling"] == "strong":
         # N > 1: the same sharded mode on BASELINE config 4 (10 M pixel segments at 8192 x 8192), the configuration the multi-GPU
         # target is quoted on; its numbers ride in the same JSON line
         try:
@@ -344,7 +402,7 @@ def main():
             ok, o2 = False, {"error": repr(e)}
         if agreed(ok):
             out["second_workload"] = {k: o2[k] for k in ("value", "unit", "ms_per_step", "scaling", "mpixel_segments_per_s", "fps_blocks",
-                                                           "config", "stages_us", "roofline")}
+                                                           "fps_including_d2h", "config", "stages_us", "roofline")}
         else:
             out["second_workload"] = {"error": o2.get("error", "failed on another rank")}
     if rank == 0:
@@ -353,11 +411,12 @@ def main():
         dist.destroy_process_group()
 
 
-def animated_leg(local, frames=240):
+def animated_leg(local, frames=600):
     """BASELINE config 5 on one GPU: the deterministic spaceship (forma_amd/spaceship.py = the reference demo's game logic,
-    fixed dt = 1/60 s) at 3840 x 2160, BGR1, clear (1, 1, 1, 0), through the product API exactly as the demo's runner does
-    (demo/src/runner.rs:150-165): compose, then render into a caller buffer — with one persistent BufferLayerCache (damage
-    tracking) and without a cache.  The game logic runs on the host between frames and is not timed."""
+    fixed dt = 1/60 s, 600 frames: `enemy_count(t)` keeps growing that long, spaceship.rs:213-216) at 3840 x 2160, BGR1, clear
+    (1, 1, 1, 0), through the product API exactly as the demo's runner does (demo/src/runner.rs:150-165): compose, then render
+    into a caller buffer — with one persistent BufferLayerCache (damage tracking) and without a cache.  The game logic runs on
+    the host between frames and is not timed."""
     import torch
     from forma_amd import api
     from forma_amd.spaceship import Spaceship
@@ -385,6 +444,7 @@ def animated_leg(local, frames=240):
         if cached:
             res["damaged_tile_fraction"] = round(float(np.mean(written)) / tiles, 4)
             res["actors_at_end"] = len(game.actors)
+        r._ctx.close()
     return {"workload": "spaceship (deterministic re-implementation of demo/src/demos/spaceship.rs, 3840x2160, BGR1)", "frames": frames,
             "fps_no_cache": res["no_cache"], "fps_with_cache": res["with_cache"], "damaged_tile_fraction": res["damaged_tile_fraction"],
             "actors_at_end": res["actors_at_end"],
@@ -394,9 +454,9 @@ def animated_leg(local, frames=240):
 def cpu_baseline(renderer, width, height, budget_s):
     """The CPU oracle (C++ restatement of forma's CPU backend: OpenMP over lines / pixel segments / tile rows, parallel
     stable radix sort, parallel prefix sum) timed on the host cores on the SAME scene tables the GPU rendered.  The thread
-    count is the fastest of a short sweep (all hardware threads is rarely the fastest on a many-core host: the sort and
-    the scan are memory-bound).  Reported baseline only — a restatement, not forma's own Rayon/SIMD build (no Rust
-    toolchain in this image)."""
+    count is the fastest of a short sweep; threads are pinned (OMP_PROC_BIND=close, OMP_PLACES=cores) and the big per-frame
+    arrays are first-touched by the loops that fill them, so pages live next to the threads that use them.  Reported baseline
+    only — a restatement, not forma's own Rayon/SIMD build (no Rust toolchain in this image)."""
     from oracle import oracle as orc
     hw = orc.lib().oracle_max_threads()
     t = renderer.host_tables
@@ -421,7 +481,7 @@ def cpu_baseline(renderer, width, height, budget_s):
     per = sum(tm.values())
     return {"value": round(1.0 / per, 3), "unit": "frames/s", "cores": best, "kind": "port", "host_threads": hw,
             "sample": f"{iters} full frames of the same workload (C++ restatement of the CPU backend, OpenMP on {best} of {hw} "
-                      f"hardware threads = the fastest of the sweep {sorted(sweep)}; parallel stable radix sort and prefix sum)",
+                      f"hardware threads = the fastest of the sweep {sorted(sweep)}, pinned; parallel stable radix sort and prefix sum)",
             "thread_sweep_ms": {str(k): round(v * 1e3, 1) for k, v in sweep.items()},
             "stages_ms": {k: round(v * 1e3, 2) for k, v in tm.items()}}
 

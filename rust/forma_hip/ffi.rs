@@ -17,6 +17,7 @@ pub const FORMA_E_NO_DEVICE: c_int = -3;
 pub const FORMA_E_CAPACITY: c_int = -4;
 pub const FORMA_E_STATE: c_int = -5;
 pub const FORMA_E_INTERNAL: c_int = -6;
+pub const FORMA_E_COMM: c_int = -7;
 
 pub const FORMA_GEOM_HAS_XF: u32 = 1;
 
@@ -124,6 +125,7 @@ pub struct forma_flatten_tables_t {
 extern "C" {
     // lifetime
     pub fn forma_hip_create(out: *mut *mut forma_hip_ctx, device: c_int) -> c_int;
+    pub fn forma_hip_create_multi(out: *mut *mut forma_hip_ctx, devices: *const c_int, n: c_int) -> c_int;
     pub fn forma_hip_destroy(ctx: *mut forma_hip_ctx);
     pub fn forma_hip_last_error(ctx: *const forma_hip_ctx) -> *const c_char;
     pub fn forma_hip_version() -> *const c_char;
@@ -222,6 +224,8 @@ extern "C" {
         timings: *mut forma_timings_t,
     ) -> c_int;
     pub fn forma_hip_cache_clear(ctx: *mut forma_hip_ctx, cache_id: c_int) -> c_int;
+    pub fn forma_hip_set_frames_in_flight(ctx: *mut forma_hip_ctx, n: c_int) -> c_int;
+    pub fn forma_hip_sync(ctx: *mut forma_hip_ctx) -> c_int;
 
     // inspection
     pub fn forma_hip_read_segments(

@@ -118,6 +118,45 @@ impl Renderer {
         }
     }
 
+    /// ONE renderer over several GPUs of this process (`forma_hip_create_multi`): `render` keeps its signature and its
+    /// contract — the buffer is fully written when it returns — and the multi-GPU frame happens inside the library:
+    /// every device rasterizes its share of the lines, one RCCL all-to-all over xGMI moves the pixel segments to the
+    /// device that owns their tile row, every device sorts and paints its band and copies its rows into the caller's
+    /// buffer.  `demo` and `e2e-tests` need no change beyond this constructor.
+    pub fn with_devices(devices: &[i32]) -> Self {
+        let mut ctx = ptr::null_mut();
+        // SAFETY: `devices` outlives the call; plain out-pointer.
+        let rc = unsafe { ffi::forma_hip_create_multi(&mut ctx, devices.as_ptr(), devices.len() as i32) };
+        if rc != ffi::FORMA_OK {
+            panic!("forma_hip_create_multi({:?}) failed with {}", devices, rc);
+        }
+
+        Self {
+            ctx,
+            buffers_with_caches: Rc::default(),
+            resident: Resident::default(),
+            linear_scratch: Vec::new(),
+            tile_flags: Vec::new(),
+            timings: forma_timings_t::default(),
+        }
+    }
+
+    /// Frames in flight inside this renderer (`forma_hip_set_frames_in_flight`): relevant to callers that keep the image
+    /// on the device (`ffi::forma_hip_render` with a null `dst`, e.g. a presenter that blits from device memory);
+    /// `render` into a `Buffer` stays synchronous — the reference's contract (`cpu/buffer/mod.rs:43-49`).
+    pub fn set_frames_in_flight(&mut self, n: i32) {
+        // SAFETY: `ctx` is live for the lifetime of `self`.
+        let rc = unsafe { ffi::forma_hip_set_frames_in_flight(self.ctx, n) };
+        self.check(rc, "forma_hip_set_frames_in_flight");
+    }
+
+    /// Waits for every enqueued frame (`forma_hip_sync`); panics with the first error one of them produced.
+    pub fn sync(&mut self) {
+        // SAFETY: as above.
+        let rc = unsafe { ffi::forma_hip_sync(self.ctx) };
+        self.check(rc, "forma_hip_sync");
+    }
+
     /// Same contract as `cpu::Renderer::create_buffer_layer_cache` (`cpu/renderer.rs:68-73`): at most 32 live caches.
     #[inline]
     pub fn create_buffer_layer_cache(&mut self) -> Option<BufferLayerCache> {
