@@ -1432,6 +1432,71 @@ void oracle_gradient_column(const uint32_t* style_words, float x, float y, float
     for (int c = 0; c < 4; c++) for (int j = 0; j < 8; j++) out32[c * 8 + j] = o[c][j];
 }
 
+// Texture::color_at (cpu/painter/styling.rs:145-193) on one 8-lane column: style words of a texture fill + the image table
+void oracle_texture_column(const uint32_t* style_words, const forma_image_t* images, size_t n_images, const uint16_t* texels,
+                           float x, float y, float* out32) {
+    Props p = decode_props(style_words);
+    Images im; im.tab = images; im.n = n_images; im.texels = texels;
+    float o[4][8]; texture_color_at(p, im, x, y, o);
+    for (int c = 0; c < 4; c++) for (int j = 0; j < 8; j++) out32[c * 8 + j] = o[c][j];
+}
+// Point::angle (math/point.rs:84-86 over approx_atan2 :53-78): returns 0 for None
+int oracle_point_angle(float x, float y, float* out) { OptF a = pt_angle(Pt{x, y}); if (a.some) *out = a.v; return a.some ? 1 : 0; }
+
+// ---- PrefixScanIter (utils/prefix_scan.rs:21-147), restated statement by statement: the flat pixel-segment index ->
+//      (line, index inside the line) map that Rasterizer::rasterize iterates in parallel (cpu/rasterizer.rs:95).  The
+//      oracle's own rasterize() walks lines directly; this is the reference's iterator itself, pinned by its own tests ----
+struct PrefixScanIter {
+    std::vector<uint32_t> sums;
+    uint32_t group_start = 0, group_end = 0, start = 0, end = 0;
+    bool next(uint32_t* g, uint32_t* l) {                               // :33-62
+        for (;;) {
+            if (start >= end) return false;
+            const uint32_t exclusive = group_start >= 1 ? sums[group_start - 1] : 0u;
+            const uint32_t inclusive = sums[group_start];
+            if (exclusive == inclusive) { group_start += 1; continue; }
+            *g = group_start; *l = start - exclusive;
+            start += 1;
+            if (start == inclusive) group_start += 1;
+            return true;
+        }
+    }
+    bool next_back(uint32_t* g, uint32_t* l) {                          // :65-95
+        for (;;) {
+            if (start >= end) return false;
+            const uint32_t exclusive = group_end >= 1 ? sums[group_end - 1] : 0u;
+            const uint32_t inclusive = sums[group_end];
+            if (exclusive == inclusive) { group_end = group_end ? group_end - 1 : 0; continue; }
+            *g = group_end; *l = end - 1 - exclusive;
+            end -= 1;
+            if (end == exclusive) group_end = group_end ? group_end - 1 : 0;
+            return true;
+        }
+    }
+};
+void* oracle_psi_new(const uint32_t* sums, size_t n) {                  // PrefixScanIter::new :150-160
+    PrefixScanIter* it = new PrefixScanIter();
+    it->sums.assign(sums, sums + n);
+    it->group_start = 0; it->group_end = n ? (uint32_t)(n - 1) : 0u; it->start = 0; it->end = n ? sums[n - 1] : 0u;
+    return it;
+}
+void oracle_psi_free(void* p) { delete (PrefixScanIter*)p; }
+int oracle_psi_next(void* p, uint32_t* g, uint32_t* l) { return ((PrefixScanIter*)p)->next(g, l) ? 1 : 0; }
+int oracle_psi_next_back(void* p, uint32_t* g, uint32_t* l) { return ((PrefixScanIter*)p)->next_back(g, l) ? 1 : 0; }
+uint32_t oracle_psi_len(void* p) { PrefixScanIter* it = (PrefixScanIter*)p; return it->end - it->start; }   // :98-102
+// Producer::split_at (:119-146): `p` becomes the left part, the right part is returned
+void* oracle_psi_split_at(void* p, size_t index_) {
+    PrefixScanIter* it = (PrefixScanIter*)p;
+    const uint32_t index = (uint32_t)index_ + it->start;
+    const auto lb = std::lower_bound(it->sums.begin(), it->sums.end(), index);     // binary_search: Ok(mid) -> mid + 1, Err(mid) -> mid
+    uint32_t mid = (uint32_t)(lb - it->sums.begin());
+    if (lb != it->sums.end() && *lb == index) mid += 1;
+    PrefixScanIter* r = new PrefixScanIter();
+    r->sums = it->sums; r->group_start = mid; r->group_end = it->group_end; r->start = index; r->end = it->end;
+    it->group_end = mid; it->end = index;
+    return r;
+}
+
 // paint a caller-supplied sorted stream.  cache_id < 0: no cache.  tile_dump (optional): f32 rgba
 // of every ColorBuffer tile, [tiles_h][tiles_w][256 column-major][4].
 static int paint_entry(void* o_, const uint64_t* segs, size_t n, uint8_t* dst, uint32_t width, uint32_t height, size_t stride,

@@ -116,6 +116,14 @@ def lib():
         L.oracle_srgb_to_linear.argtypes = [C.c_uint8]
         L.oracle_srgb_to_linear.restype = f
         L.oracle_gradient_column.argtypes = [vp, f, f, vp]
+        L.oracle_texture_column.argtypes = [vp, vp, sz, vp, f, f, vp]
+        L.oracle_point_angle.argtypes = [f, f, vp]; L.oracle_point_angle.restype = i32
+        L.oracle_psi_new.argtypes = [vp, sz]; L.oracle_psi_new.restype = vp
+        L.oracle_psi_free.argtypes = [vp]
+        L.oracle_psi_next.argtypes = [vp, vp, vp]; L.oracle_psi_next.restype = i32
+        L.oracle_psi_next_back.argtypes = [vp, vp, vp]; L.oracle_psi_next_back.restype = i32
+        L.oracle_psi_len.argtypes = [vp]; L.oracle_psi_len.restype = u32
+        L.oracle_psi_split_at.argtypes = [vp, sz]; L.oracle_psi_split_at.restype = vp
         L.oracle_paint.argtypes = [vp, vp, sz, vp, u32, u32, sz, vp, vp, vp, i32, vp]
         L.oracle_paint.restype = i32
         L.oracle_cache_clear.argtypes = [vp, i32]
