@@ -283,7 +283,10 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                           (uint32_t)ctx->n_orders, tiles_w, tiles_h, row_count, row_span_lo,
                           row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(),
                           (a.cache_id >= 0 && ctx->have_unchanged) ? ctx->unchanged.as<uint8_t>() : nullptr, dinfo,
-                          runs_edge_segments(ctx->legacy_runs), (a.height & 15u) ? (a.height & 15u) : 16u);
+                          runs_edge_segments(ctx->legacy_runs),
+                          // invisible carries of a partial last tile row are dropped only when nothing can observe them: with a
+                          // buffer-layer cache the layer count of a tile is state (passes/tile_unchanged.rs)
+                          (a.cache_id < 0 && (a.height & 15u)) ? (a.height & 15u) : 16u);
     } else {
         HIPCHECK(ctx->span_key.ensure(8));
         HIPCHECK(ctx->span_cov.ensure(16));

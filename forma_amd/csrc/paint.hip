@@ -689,7 +689,10 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
     // it (Cover::is_empty looks at all 16 rows) and paints the layer with zero visible coverage in every tile to the right;
     // here such a carry produces no span: its pixels are never written (painter/mod.rs:537-548 writes the canvas rows only),
     // and a busy scene would otherwise put thousands of invisible layers into every tile of that row.  Only the emptiness
-    // test of carry-only spans is masked; covers, runs and the `full` flag are untouched.
+    // test of carry-only spans is masked; covers, runs and the `full` flag are untouched.  The host asks for this
+    // (vis_last < 16) only on frames WITHOUT a buffer-layer cache: with one, a tile's layer count and the passes' verdicts
+    // are remembered across frames (passes/tile_unchanged.rs, CachedTile), the invisible layers are part of both, and they
+    // are carried exactly like the reference's.
     uint64_t vis_lo = ~0ull, vis_hi = ~0ull;
     if (ty + 1 == tiles_h && vis_last < 16u) {
         vis_lo = vis_last >= 8u ? ~0ull : ((1ull << (8u * vis_last)) - 1ull);
@@ -924,7 +927,12 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
                 uint32_t sh = same_next ? ntxb - 1u : tiles_w;          // exclusive; next tile_x = txb_next - 1
                 if (sh > tiles_w) sh = tiles_w;
                 span_hi[k] = sh;                                         // span_lo = tile_x + 1
-                if (!cover_is_empty(pl & vis_lo, ph & vis_hi, (meta[k] >> 12) & 1u) && span_lo[k] < sh) spanm |= 1u << k;
+                // (a clip layer is never masked: its span is what expires or overwrites an earlier clip in the tiles to the
+                //  right, painter/mod.rs:302-334 — dropping it would let a later clipped layer see a stale mask)
+                const bool is_clip = (meta[k] & SF_IS_CLIP) != 0u;
+                const bool empty = is_clip ? cover_is_empty(pl, ph, (meta[k] >> 12) & 1u)
+                                           : cover_is_empty(pl & vis_lo, ph & vis_hi, (meta[k] >> 12) & 1u);
+                if (!empty && span_lo[k] < sh) spanm |= 1u << k;
             }
         }
         // ordered compaction of the spans
