@@ -217,15 +217,18 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
         ctx->cur_image = ctx->image.as<uint8_t>();
     }
     // one buffer, zeroed by ONE memset per frame (launch_runs): [row_count | row_span_lo | row_span_cnt] (tiles_h + 1 words
-    // each) [painter overflow counter] [first-run table, T words]; the painter's overflow list (T words) follows un-zeroed
-    HIPCHECK(ctx->row_tab.ensure(((size_t)(tiles_h + 1) * 3 + 1 + 2 * (size_t)T) * 4));
+    // each) [painter overflow counters: wave -> deep, deep -> huge] [first-run table, T words]; the painter's overflow lists
+    // (T words of tiles, 2 T words of {tile, entries}) follow un-zeroed
+    HIPCHECK(ctx->row_tab.ensure(((size_t)(tiles_h + 1) * 3 + 2 + 4 * (size_t)T) * 4));
     FrameInfo* dinfo = ctx->info.as<FrameInfo>();
     uint32_t* row_count = ctx->row_tab.as<uint32_t>();
     uint32_t* row_span_lo = row_count + (tiles_h + 1);
     uint32_t* row_span_cnt = row_span_lo + (tiles_h + 1);
-    uint32_t* paint_overflow = row_span_cnt + (tiles_h + 1);          // [0] = count, then the first-run table ...
-    uint32_t* tile_first_run = paint_overflow + 1;
-    uint32_t* overflow_list = tile_first_run + T;                       // ... then the list itself
+    uint32_t* paint_overflow = row_span_cnt + (tiles_h + 1);          // [0], [1] = the two counts, then the first-run table ...
+    uint32_t* over2_n = paint_overflow + 1;
+    uint32_t* tile_first_run = paint_overflow + 2;
+    uint32_t* overflow_list = tile_first_run + T;                       // ... then the lists themselves
+    uint32_t* over2_list = overflow_list + T;
     uint32_t J = 0;
     // capacity: a run needs at least one segment, and so does a span's left neighbour
     const size_t cap = std::max<size_t>(bound_j ? bound_j : n, 1);
@@ -313,9 +316,44 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                  row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(), ctx->layer_col.as<uint4>(),
                  ctx->style_off.as<uint32_t>(),
                  ctx->style_words.as<uint32_t>(), ctx->images.as<forma_image_t>(), ctx->texels.as<uint16_t>(),
-                 ctx->cur_image, tc, dinfo, paint_overflow, overflow_list);
+                 ctx->cur_image, tc, dinfo, paint_overflow, overflow_list, over2_n, over2_list);
     stage_end(ctx, ST_PAINT, timing);
     HIPCHECK(hipGetLastError());
+    // what a later launch_paint_huge needs (tiles deeper than the painter's LDS lists: finish_paint)
+    ctx->huge = forma_hip_ctx::HugeArgs{P, jc, tc, tile_first_run, row_span_lo, row_span_cnt, over2_n, over2_list, T};
+    return FORMA_OK;
+}
+
+// Tiles whose layer list exceeds the painter's 4096-entry LDS lists were only RECORDED by k_paint_deep ({tile, entries},
+// info->error bit 3).  The reference has no limit on the layers of a tile (layer_workbench/mod.rs:250-278): paint them now
+// with lists in global memory sized from the recorded counts.  Called with the frame's FrameInfo in h_info, before anything
+// of the image is copied out.  Rare (thousands of layers in one 16 x 16 tile), so the extra round trip does not matter.
+int finish_paint(forma_hip_ctx* ctx) {
+    if (!(ctx->h_info->error & 8u)) return FORMA_OK;
+    const forma_hip_ctx::HugeArgs& h = ctx->huge;
+    uint32_t n = 0;
+    HIPCHECK(hipMemcpyAsync(&n, h.over2_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    n = std::min(n, h.T);
+    std::vector<uint32_t> list((size_t)2 * n);
+    if (n) HIPCHECK(hipMemcpy(list.data(), h.over2_list, (size_t)8 * n, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> offs(n);
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n; i++) { offs[i] = total; total += list[2 * i + 1]; }
+    if (total >= (1ull << 31)) return fail(ctx, FORMA_E_CAPACITY, "more than 2^31 layer-list entries in the deep tiles of one frame");
+    HIPCHECK(ctx->huge_offs.ensure(std::max<size_t>(n, 1) * 8));
+    HIPCHECK(ctx->huge_key.ensure(std::max<uint64_t>(total, 1) * 4 * 8));
+    HIPCHECK(ctx->huge_tmp.ensure(std::max<uint64_t>(total, 1) * 8));
+    HIPCHECK(ctx->huge_flag.ensure(std::max<uint64_t>(total, 1) * 4));
+    if (n) HIPCHECK(hipMemcpyAsync(ctx->huge_offs.p, offs.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    launch_paint_huge(ctx->stream, h.P, ctx->sorted, ctx->records.as<TileRecord>(), h.jc, h.tile_first_run, h.row_span_lo, h.row_span_cnt,
+                      ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(), ctx->layer_col.as<uint4>(), ctx->style_off.as<uint32_t>(),
+                      ctx->style_words.as<uint32_t>(), ctx->images.as<forma_image_t>(), ctx->texels.as<uint16_t>(), ctx->cur_image, h.tc,
+                      ctx->info.as<FrameInfo>(), h.over2_list, n, ctx->huge_offs.as<uint64_t>(), ctx->huge_key.as<uint64_t>(),
+                      ctx->huge_tmp.as<uint64_t>(), ctx->huge_flag.as<uint32_t>());
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(ctx->stream));           // (`offs` is host memory of this call)
+    ctx->h_info->error &= ~8u;
     return FORMA_OK;
 }
 
@@ -391,8 +429,7 @@ int finish_frame(forma_hip_ctx* ctx, forma_timings_t* t, bool have_info = false)
         HIPCHECK(hipStreamSynchronize(ctx->stream));
     }
     // device-side invariant flags
-    if (ctx->h_info->error & 2u) return fail(ctx, FORMA_E_CAPACITY, "a tile has more than 4096 layers (painter list capacity)");
-    if (ctx->h_info->error) return fail(ctx, FORMA_E_INTERNAL, "device-side invariant violated");
+    if (ctx->h_info->error & ~8u) return fail(ctx, FORMA_E_INTERNAL, "device-side invariant violated");
     if (!t) return FORMA_OK;
     memset(t, 0, sizeof *t);
     float* dstv[ST_COUNT] = {&t->prepare_us, &t->rasterize_us, &t->sort_us, &t->carry_us, &t->paint_us, &t->d2h_us, &t->exchange_us};
@@ -520,7 +557,7 @@ void forma_hip_destroy(forma_hip_ctx* ctx) {
                      &ctx->sort_counters, &ctx->info, &ctx->info_init, &ctx->records, &ctx->rk_u, &ctx->rk_a, &ctx->rk_b,
                      &ctx->blk_edge, &ctx->runs_scratch, &ctx->row_tab, &ctx->span_key, &ctx->span_cov,
                      &ctx->image, &ctx->xsend, &ctx->xrecv, &ctx->xsend_counts, &ctx->xrecv_counts, &ctx->xscratch,
-                     &ctx->ras_masks, &ctx->xmask};
+                     &ctx->ras_masks, &ctx->xmask, &ctx->huge_offs, &ctx->huge_key, &ctx->huge_tmp, &ctx->huge_flag};
     for (DevBuf* b : all) b->release();
     for (int s = 0; s < ST_COUNT; s++) { (void)hipEventDestroy(ctx->ev0[s]); (void)hipEventDestroy(ctx->ev1[s]); }
     for (int p = 0; p < MAX_PASS_EVENTS; p++) { (void)hipEventDestroy(ctx->pev0[p]); (void)hipEventDestroy(ctx->pev1[p]); }
@@ -802,8 +839,10 @@ int forma_hip_paint(forma_hip_ctx* ctx, const uint64_t* sorted_segments, size_t 
     ctx->live44 = n ? host_live44(sorted_segments, n) : 0;
     PaintArgs a{width, height, channels, clear_color, crop_or_null};
     if ((rc = run_paint(ctx, DevCount{nullptr, (uint32_t)n}, a, false))) return rc;
+    if ((rc = read_info(ctx)) || (rc = finish_paint(ctx))) return rc;
     if ((rc = copy_image_out(ctx, dst, stride_bytes, false, a))) return rc;
-    return finish_frame(ctx, nullptr);
+    if (dst) HIPCHECK(hipStreamSynchronize(ctx->stream));
+    return finish_frame(ctx, nullptr, true);
 }
 
 // ---- the frame ---------------------------------------------------------------------------------------
@@ -844,6 +883,7 @@ int complete_async_frame(forma_hip_ctx* ctx, const PaintArgs& a, uint8_t* dst, s
     }
     ctx->pred_N = N; ctx->pred_J = J; ctx->pred_max_row = ctx->h_info->max_row_runs;
     int rc;
+    if ((rc = finish_paint(ctx))) return rc;
     if ((rc = copy_image_out(ctx, dst, stride_bytes, timing, a))) return rc;
     if (dst) HIPCHECK(hipStreamSynchronize(ctx->stream));
     rc = finish_frame(ctx, timings, true);
@@ -860,8 +900,10 @@ int render_sync(forma_hip_ctx* ctx, const PaintArgs& a, uint8_t* dst, size_t str
         rc = run_paint(ctx, DevCount{nullptr, (uint32_t)ctx->n_seg}, a, timing);
         if (rc == FORMA_RETRY) { clear_stage_flags(ctx); continue; }
         if (rc) return rc;
+        if ((rc = read_info(ctx)) || (rc = finish_paint(ctx))) return rc;
         if ((rc = copy_image_out(ctx, dst, stride_bytes, timing, a))) return rc;
-        rc = finish_frame(ctx, timings);
+        if (dst) HIPCHECK(hipStreamSynchronize(ctx->stream));
+        rc = finish_frame(ctx, timings, true);
         if (rc == FORMA_OK) { ctx->pred_N = (uint32_t)ctx->n_seg; ctx->pred_J = ctx->last_runs; ctx->pred_counts_valid = true; }
         frame_done(ctx, rc, a);
         return rc;
@@ -1139,8 +1181,10 @@ int forma_hip_sort_paint_frame(forma_hip_ctx* ctx, size_t n, uint8_t* dst, uint3
     if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), DevCount{nullptr, (uint32_t)n}, timing))) return rc;
     PaintArgs a{width, height, channels, clear_color, crop_or_null};
     if ((rc = run_paint(ctx, DevCount{nullptr, (uint32_t)n}, a, timing))) return rc;
+    if ((rc = read_info(ctx)) || (rc = finish_paint(ctx))) return rc;
     if ((rc = copy_image_out(ctx, dst, stride_bytes, timing, a))) return rc;
-    return finish_frame(ctx, timings);
+    if (dst) HIPCHECK(hipStreamSynchronize(ctx->stream));
+    return finish_frame(ctx, timings, true);
 }
 
 
@@ -1299,6 +1343,7 @@ int fd_gather_sort_paint(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint3
         ctx->n_seg = N; ctx->last_runs = J;
         if (!ctx->h_info->plan_bad && J <= bJ) {
             ctx->pred_J = J; ctx->pred_max_row = ctx->h_info->max_row_runs;
+            if ((rc = finish_paint(ctx))) return rc;
             if ((rc = copy_image_out(ctx, dst, stride_bytes, timing, a))) return rc;
             if (dst) HIPCHECK(hipStreamSynchronize(ctx->stream));
             rc = finish_frame(ctx, timings, true);
@@ -1321,8 +1366,10 @@ int fd_gather_sort_paint(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint3
         rc = run_paint(ctx, DevCount{nullptr, (uint32_t)ctx->n_seg}, a, timing);
         if (rc == FORMA_RETRY) { clear_stage_flags(ctx); continue; }
         if (rc) return rc;
+        if ((rc = read_info(ctx)) || (rc = finish_paint(ctx))) return rc;
         if ((rc = copy_image_out(ctx, dst, stride_bytes, timing, a))) return rc;
-        rc = finish_frame(ctx, timings);
+        if (dst) HIPCHECK(hipStreamSynchronize(ctx->stream));
+        rc = finish_frame(ctx, timings, true);
         if (rc == FORMA_OK) { ctx->pred_J = ctx->last_runs; ctx->pred_counts_valid = true; }
         frame_done(ctx, rc, a);
         return rc;

@@ -92,6 +92,13 @@ struct forma_hip_ctx {
     FrameInfo* h_info = nullptr;            // pinned
     uint32_t* h_rows = nullptr;             // pinned: runs per tile row (synchronous frames), 2049 words
     uint32_t pred_max_row = 0xFFFFFFFFu;    // most runs in one tile row of the last verified frame (unknown: no local sort)
+    // tiles deeper than the painter's LDS lists (finish_paint): the launch arguments of the frame's painter and the scratch lists
+    struct HugeArgs {
+        PaintParams P; DevCount jc; TileCacheArgs tc;
+        const uint32_t* tile_first_run; const uint32_t* row_span_lo; const uint32_t* row_span_cnt;
+        uint32_t* over2_n; uint32_t* over2_list; uint32_t T;
+    } huge{};
+    DevBuf huge_offs, huge_key, huge_tmp, huge_flag;
     // band
     uint32_t band_row0 = 0, band_row1 = 0;
     // a sub-range [line_lo, line_hi) of the uploaded lines (line i joins points i and i + 1) when line_ranged.

@@ -558,9 +558,9 @@ void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t ti
                  uint32_t rec_cap, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge, uint32_t* row_tab,
                  uint32_t* scratch, FrameInfo* info, bool verify_plan, uint64_t spec_live44, bool spec_layer_sorted, bool legacy,
                  PendingMasks pm) {
-    // per-frame tile tables: [row_count | row_span_lo | row_span_cnt | painter overflow counter | first-run table] are
+    // per-frame tile tables: [row_count | row_span_lo | row_span_cnt | painter overflow counters (2) | first-run table] are
     // contiguous (api.cpp lays them out so) and zeroed by k_runs_count; 0 in the first-run table = the tile has no run
-    const uint32_t zero_words = (tiles_h + 1) * 3 + 1 + tiles_w * tiles_h;
+    const uint32_t zero_words = (tiles_h + 1) * 3 + 2 + tiles_w * tiles_h;
     if (nc.bound == 0) {
         (void)hipMemsetAsync(row_tab, 0, (size_t)zero_words * 4, s);
         (void)hipMemsetAsync(&info->n_runs, 0, 4, s);
@@ -1270,10 +1270,13 @@ __device__ __forceinline__ void texture_at(const uint32_t* __restrict__ w, const
     out[0] = f16b_to_f32(p[0]); out[1] = f16b_to_f32(p[1]); out[2] = f16b_to_f32(p[2]); out[3] = f16b_to_f32(p[3]);
 }
 
-// One tile.  MAXE bounds the tile's layer list held in LDS; a tile that does not fit is appended to `overflow` (a
-// second, low-occupancy launch with a larger MAXE paints those).
-template <int MAXE>
-__device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t tile, const uint64_t* __restrict__ sorted,
+// One tile, one 256-lane workgroup.  The tile's layer list lives in three caller-provided arrays: e_key (4 x stage entries:
+// the four waves stage their span hits there, then it holds the merged list, cap entries), e_tmp and e_flag (cap entries
+// each).  k_paint_deep passes LDS (cap 4096); a tile that does not fit is recorded as {tile, entries} in `over2`, and
+// k_paint_huge paints it with lists in global memory sized for exactly that tile — the reference has no limit on the layers
+// of a tile (LayerWorkbench::populate_layers, layer_workbench/mod.rs:250-278) and neither has this path.
+__device__ __forceinline__ void paint_tile(const uint32_t MAXE, const uint32_t STAGE, uint64_t* e_key, uint64_t* e_tmp, uint32_t* e_flag,
+                                           const PaintParams& P, const uint32_t tile, const uint64_t* __restrict__ sorted,
                                            const TileRecord* __restrict__ records, const uint32_t n_runs,
                                            const uint32_t* __restrict__ tile_first_run,
                                            const uint32_t* __restrict__ row_span_lo,
@@ -1284,17 +1287,14 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
                                            const uint32_t* __restrict__ style_words,
                                            const forma_image_t* __restrict__ images,
                                            const uint16_t* __restrict__ texels, uint8_t* __restrict__ image,
-                                           TileCacheArgs cache, FrameInfo* __restrict__ info, uint32_t* __restrict__ overflow) {
-    constexpr int STAGE = MAXE / 4;           // span hits one wave may stage
-    __shared__ uint64_t e_key[MAXE];          // staging for the span scan (4 x STAGE), then the merged layer list
-    __shared__ uint64_t e_tmp[MAXE];          // [0, na) own runs, [na, ne) crossing spans; later the list of painted entries
-    __shared__ uint32_t e_flag[MAXE];
+                                           TileCacheArgs cache, FrameInfo* __restrict__ info, uint32_t* __restrict__ over2_n,
+                                           uint32_t* __restrict__ over2_list) {
     __shared__ int cells[2][256];             // double-buffered coverage cells: one barrier per layer with segments
     __shared__ uint64_t t_seg[TSEG_CAP];      // the tile's own pixel segments (contiguous in the sorted stream)
     __shared__ uint4 b_cov[PBATCH];           // per painted entry of the current batch: carry-in cover,
     __shared__ uint4 b_col[PBATCH];           //   style words 2..5 (solid colour / gradient geometry),
     __shared__ uint32_t b_seg0[PBATCH], b_nseg[PBATCH], b_flag[PBATCH], b_layer[PBATCH];
-    __shared__ uint32_t s_solid, s_solid_bytes, s_seg0, s_seg1;
+    __shared__ uint32_t s_solid, s_solid_bytes, s_seg0, s_seg1, s_over;
     __shared__ uint32_t s_wcnt[4], s_wblk[4];
 
     const uint32_t ty = tile / P.tiles_w, tx = tile - ty * P.tiles_w;
@@ -1311,7 +1311,7 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
     const uint32_t j0 = tile_first_run[tile] - 1u;                      // 0 stored = no run -> FORMA_NONE
     const uint32_t sb = row_span_lo[ty], sc = row_span_cnt[ty];
     uint32_t na = 0;
-    if (tid == 0) { s_seg0 = 0; s_seg1 = 0; }
+    if (tid == 0) { s_seg0 = 0; s_seg1 = 0; s_over = 0; }
     // second round, issued together: the run records probed below and this wave's first 256 span keys
     const uint32_t sq = (sc + 3u) / 4u;
     const uint32_t c_lo = min(sc, (uint32_t)wv * sq), c_hi = min(sc, (uint32_t)(wv + 1) * sq);
@@ -1361,7 +1361,7 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
                 const uint64_t bal = __ballot(hit);
                 if (hit) {
                     const uint32_t pos = cw + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    if (pos < (uint32_t)STAGE) e_key[wv * STAGE + pos] = (sk[u] & 0xFFFFFFFF00000000ull) | REF_SPAN | (((uint32_t)sk[u] >> 31) ? REF_UNCH : 0u) | (sb + c + u * 64 + lane);
+                    if (pos < (uint32_t)STAGE) e_key[(size_t)wv * STAGE + pos] = (sk[u] & 0xFFFFFFFF00000000ull) | REF_SPAN | (((uint32_t)sk[u] >> 31) ? REF_UNCH : 0u) | (sb + c + u * 64 + lane);
                 }
                 cw += (uint32_t)__popcll(bal);
             }
@@ -1373,17 +1373,17 @@ __device__ __forceinline__ void paint_tile(const PaintParams& P, const uint32_t 
         uint32_t base = na, over = 0;
 #pragma unroll
         for (int i = 0; i < 4; i++) { const uint32_t t = s_wcnt[i]; if (i < wv) base += t; nb += t; over |= t > (uint32_t)STAGE ? 1u : 0u; }
-        if (over) nb = MAXE + 1;                                      // more crossing spans in one quarter than a wave may stage
-        else for (uint32_t i = lane; i < cw; i += 64) if (base + i < MAXE) e_tmp[base + i] = e_key[wv * STAGE + i];
+        if (over) s_over = 1;                                         // more crossing spans in one quarter than a wave may stage
+        else for (uint32_t i = lane; i < cw; i += 64) if (base + i < MAXE) e_tmp[base + i] = e_key[(size_t)wv * STAGE + i];
         __syncthreads();
     }
-    const uint32_t ne = na + nb;
+    const uint32_t ne = na + nb;                                      // the true length of the list, staged or not
     uint64_t* keys = e_key;
     uint32_t* flags = e_flag;
-    if (ne > MAXE) {                                                  // does not fit this variant's LDS
+    if (ne > MAXE || s_over) {                                        // does not fit the caller's lists
         if (tid == 0) {
-            if (overflow) overflow[1 + atomicAdd(&overflow[0], 1u)] = tile;
-            else atomicOr(&info->error, 2u);                          // deeper than the largest variant
+            if (over2_n) { const uint32_t q = atomicAdd(over2_n, 1u); over2_list[2 * q] = tile; over2_list[2 * q + 1] = ne; atomicOr(&info->error, 8u); }
+            else atomicOr(&info->error, 2u);                          // (cannot happen: k_paint_huge sizes its lists from `ne`)
         }
         return;
     }
@@ -2103,15 +2103,35 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
                      TileCacheArgs cache, FrameInfo* __restrict__ info
 
 #define PAINT_MAXE_DEEP 4096
+#define PAINT_ARGS2 P, tile, sorted, records, n_runs, tile_first_run, row_span_lo, row_span_cnt, span_key, span_cov, layer_col, \
+                    style_offsets, style_words, images, texels, image, cache, info
 // the rare deep tiles the first launch could not hold
 __global__ __launch_bounds__(256) void k_paint_deep(PAINT_PARAMS, const uint32_t* __restrict__ overflow_n,
-                                                    const uint32_t* __restrict__ overflow_list) {
+                                                    const uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ over2_n,
+                                                    uint32_t* __restrict__ over2_list) {
+    __shared__ uint64_t e_key[PAINT_MAXE_DEEP];                        // staging for the span scan (4 x 1024), then the merged layer list
+    __shared__ uint64_t e_tmp[PAINT_MAXE_DEEP];                        // [0, na) own runs, [na, ne) crossing spans; later the painted entries
+    __shared__ uint32_t e_flag[PAINT_MAXE_DEEP];
     if (info->plan_bad) return;
     const uint32_t n = overflow_n[0];
     const uint32_t n_runs = dev_count(nc_runs);
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
         const uint32_t tile = overflow_list[i];
-        paint_tile<PAINT_MAXE_DEEP>(PAINT_ARGS, nullptr);
+        paint_tile(PAINT_MAXE_DEEP, PAINT_MAXE_DEEP / 4, e_key, e_tmp, e_flag, PAINT_ARGS2, over2_n, over2_list);
+        __syncthreads();
+    }
+}
+// tiles deeper than the LDS lists: the same code with lists in global memory, sized per tile by the host from the entry
+// counts k_paint_deep recorded (offs[i] = first entry slot of tile i; the staging array is four times as long)
+__global__ __launch_bounds__(256) void k_paint_huge(PAINT_PARAMS, const uint32_t* __restrict__ over2_list, uint32_t n_tiles,
+                                                    const uint64_t* __restrict__ offs, uint64_t* __restrict__ g_key,
+                                                    uint64_t* __restrict__ g_tmp, uint32_t* __restrict__ g_flag) {
+    if (info->plan_bad) return;
+    const uint32_t n_runs = dev_count(nc_runs);
+    for (uint32_t i = blockIdx.x; i < n_tiles; i += gridDim.x) {
+        const uint32_t tile = over2_list[2 * i], cap = over2_list[2 * i + 1];
+        const uint64_t o = offs[i];
+        paint_tile(cap, cap, g_key + 4 * o, g_tmp + o, g_flag + o, PAINT_ARGS2, nullptr, nullptr);
         __syncthreads();
     }
 }
@@ -2121,7 +2141,7 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
                   const uint64_t* span_key, const uint4* span_cov, const uint4* layer_col,
                   const uint32_t* style_offsets, const uint32_t* style_words, const forma_image_t* images,
                   const uint16_t* texels, uint8_t* image, TileCacheArgs cache, FrameInfo* info, uint32_t* overflow_n,
-                  uint32_t* overflow_list) {
+                  uint32_t* overflow_list, uint32_t* over2_n, uint32_t* over2_list) {
     const uint32_t T = p.tiles_w * p.tiles_h;
     if (T == 0 || p.crop_y1 <= p.crop_y0) return;
     const uint32_t per = ((p.crop_y1 - p.crop_y0) * p.tiles_w + 7) / 8;
@@ -2130,5 +2150,17 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
                        cache, info, overflow_n, overflow_list);
     hipLaunchKernelGGL(k_paint_deep, dim3(T < 256 ? T : 256), dim3(256), 0, s, p, sorted, records, n_runs, tile_first_run,
                        row_span_lo, row_span_cnt, span_key, span_cov, layer_col, style_offsets, style_words, images,
-                       texels, image, cache, info, (const uint32_t*)overflow_n, (const uint32_t*)overflow_list);
+                       texels, image, cache, info, (const uint32_t*)overflow_n, (const uint32_t*)overflow_list, over2_n, over2_list);
+}
+
+void launch_paint_huge(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, DevCount n_runs,
+                       const uint32_t* tile_first_run, const uint32_t* row_span_lo, const uint32_t* row_span_cnt,
+                       const uint64_t* span_key, const uint4* span_cov, const uint4* layer_col,
+                       const uint32_t* style_offsets, const uint32_t* style_words, const forma_image_t* images,
+                       const uint16_t* texels, uint8_t* image, TileCacheArgs cache, FrameInfo* info, const uint32_t* over2_list,
+                       uint32_t n_tiles, const uint64_t* offs, uint64_t* g_key, uint64_t* g_tmp, uint32_t* g_flag) {
+    if (n_tiles == 0) return;
+    hipLaunchKernelGGL(k_paint_huge, dim3(n_tiles < 256 ? n_tiles : 256), dim3(256), 0, s, p, sorted, records, n_runs, tile_first_run,
+                       row_span_lo, row_span_cnt, span_key, span_cov, layer_col, style_offsets, style_words, images, texels, image,
+                       cache, info, over2_list, n_tiles, offs, g_key, g_tmp, g_flag);
 }

@@ -42,12 +42,13 @@ def test_random_scene_matches_oracle(seed, n, W, H):
         c.close()
 
 
-def test_rows_beyond_the_local_sort_take_the_global_sort_and_deep_tiles_are_reported():
+def test_rows_beyond_the_local_sort_take_the_global_sort_and_very_deep_tiles_render():
     """Capacity edges of the carry pre-pass / painter: (a) case 20 above really has a tile row with more than 16384 runs (so
-    k_carry_rows<false> + the global run-key sort ran, not the in-LDS sort); (b) a tile with more than 4096 layers fails the
-    frame with FORMA_E_CAPACITY instead of painting something wrong."""
+    k_carry_rows<false> + the global run-key sort ran, not the in-LDS sort); (b) a tile with more layers than the painter's
+    4096-entry LDS lists RENDERS — the reference has no such limit (LayerWorkbench::populate_layers,
+    layer_workbench/mod.rs:250-278): k_paint_deep records the tile, k_paint_huge paints it with lists in global memory —
+    on the synchronous frame and on the read-back-free ones, with and without a buffer-layer cache."""
     import forma_amd
-    from forma_amd import FormaError
     W, H = 16384, 48
     o = orc.Oracle()
     t = S.random_mixed(n=16000, width=W, height=H, seed=20).tables(o)
@@ -61,22 +62,35 @@ def test_rows_beyond_the_local_sort_take_the_global_sort_and_deep_tiles_are_repo
         ty = (srt[heads] >> np.uint64(53)).astype(np.int64) - 1
         per_row = np.bincount(ty[(ty >= 0) & (ty < 3)], minlength=3)
         assert per_row.max() > 16384, per_row
+        rng = np.random.default_rng(3)
         comp = S.Composition()
-        for order in range(4200):                                        # 4200 layers over the same tile
-            comp.get_mut_or_insert_default(order).insert(S.custom_square(2, 2, 30, 30)).set_props(S.solid((0.5, 0.5, 0.5, 0.5)))
-        S.load(c, comp.tables(o))
-        with pytest.raises(FormaError) as e:
-            c.render(32, 32)
-        assert e.value.code == -4
+        for order in range(9000):                                        # 9000 translucent layers over the same tiles
+            x0, y0 = float(rng.uniform(0, 20)), float(rng.uniform(0, 20))
+            shape = S.custom_square(x0, y0, x0 + float(rng.uniform(4, 30)), y0 + float(rng.uniform(4, 30)))
+            comp.get_mut_or_insert_default(order).insert(shape).set_props(
+                S.solid((float(rng.random()), float(rng.random()), float(rng.random()), 0.02 if order % 7 else 1.0)))
+        t2 = comp.tables(o)
+        S.load(o, t2); S.load(c, t2)
+        want = o.render(48, 48)
+        for frame in range(3):
+            got = c.render(48, 48)
+            assert np.abs(want.astype(int) - got.astype(int)).max() <= 1, frame
+        assert np.array_equal(c.segments(1), o.segments(1))
+        bo, bc = np.zeros((48, 48 * 4), np.uint8), np.zeros((48, 48 * 4), np.uint8)
+        for frame in range(2):                                           # the same through a buffer-layer cache
+            o.render(48, 48, cache_id=1, dst=bo); c.render(48, 48, cache_id=1, dst=bc)
+            assert np.abs(bo.astype(int) - bc.astype(int)).max() <= 1, frame
     finally:
         c.close()
 
 
-def test_layers_cut_by_the_bottom_edge_do_not_pile_up_in_a_partial_last_tile_row():
+def test_layers_cut_by_the_bottom_edge_in_a_partial_last_tile_row():
     """Canvas height not a multiple of 16: lines entirely below the canvas are culled (segment.rs:41-52), so a layer that crosses
     the bottom edge keeps a non-zero cover on the invisible pixel rows of the last tile row, which the reference carries through
     every tile to the right (and paints with zero visible coverage).  16 000 shapes on 8192 x 40 put 4 529 such layers into
-    one tile — beyond the painter's list.  The carry pre-pass drops carries that are empty on the VISIBLE rows: same pixels."""
+    one tile.  Without a buffer-layer cache nothing can observe them and the carry pre-pass drops carries that are empty on the
+    VISIBLE rows (same pixels, shallow tiles); with a cache they are state (a tile's layer count, passes/tile_unchanged.rs)
+    and are carried like the reference's — the tile is then deeper than the painter's LDS lists and goes to k_paint_huge."""
     import forma_amd
     W, H = 8192, 40
     o = orc.Oracle()
@@ -88,5 +102,9 @@ def test_layers_cut_by_the_bottom_edge_do_not_pile_up_in_a_partial_last_tile_row
         S.load(c, t)
         for _ in range(2):
             assert np.array_equal(c.render(W, H), want)
+        bo, bc = np.full((H, W * 4), 201, np.uint8), np.full((H, W * 4), 201, np.uint8)
+        for frame in range(2):
+            o.render(W, H, cache_id=2, dst=bo); c.render(W, H, cache_id=2, dst=bc)
+            assert np.array_equal(bo, bc), frame
     finally:
         c.close()
