@@ -247,7 +247,7 @@ def test_gpu_fill_columns_match_the_oracle():
     img = linear_image([C00, C01, C10, C11, C20, C21], 2, 3)
     for transform, _ in TEXTURE_CASES.values():
         t = list(transform)
-        t[4] += 2.0 * (t[0] + t[2]); t[5] += 2.0 * (t[1] + t[3])       # the tests sample at (-2, -2): shift the canvas origin there
+        t[4] -= 2.0 * (t[0] + t[2]); t[5] -= 2.0 * (t[1] + t[3])       # the tests sample from (-2, -2): pixel (0, 0) samples there
         fills.append(S.Texture(tuple(t), img))
     c = forma_amd.Context(0)
     for k, fill in enumerate(fills):
