@@ -11,7 +11,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "libforma_hip.so")
+# FORMA_HIP_LIB: another build of the library (tools/ab_fast.py A/B runs of kernel variants on one box); default = the in-tree one
+SO_PATH = os.environ.get("FORMA_HIP_LIB") or os.path.join(CSRC, "libforma_hip.so")
 
 NONE = 0xFFFFFFFF
 
