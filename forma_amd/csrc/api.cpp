@@ -316,7 +316,10 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                  row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(), ctx->layer_col.as<uint4>(),
                  ctx->style_off.as<uint32_t>(),
                  ctx->style_words.as<uint32_t>(), ctx->images.as<forma_image_t>(), ctx->texels.as<uint16_t>(),
-                 ctx->cur_image, tc, dinfo, paint_overflow, overflow_list, over2_n, over2_list);
+                 ctx->cur_image, tc, dinfo, paint_overflow, overflow_list, over2_n, over2_list,
+                 // the (empty) k_paint_deep launch costs ~5 us of every frame: a read-back-free frame without a cache skips it
+                 // when the last verified frame had no deep tile; a tile that needs it then voids the frame (re-run in full)
+                 /*launch_deep=*/!(bound_j != 0 && a.cache_id < 0 && ctx->pred_no_deep));
     stage_end(ctx, ST_PAINT, timing);
     HIPCHECK(hipGetLastError());
     // what a later launch_paint_huge needs (tiles deeper than the painter's LDS lists: finish_paint)
@@ -429,7 +432,8 @@ int finish_frame(forma_hip_ctx* ctx, forma_timings_t* t, bool have_info = false)
         HIPCHECK(hipStreamSynchronize(ctx->stream));
     }
     // device-side invariant flags
-    if (ctx->h_info->error & ~8u) return fail(ctx, FORMA_E_INTERNAL, "device-side invariant violated");
+    ctx->pred_no_deep = !(ctx->h_info->error & 16u);       // (8, 16: bookkeeping bits, not errors)
+    if (ctx->h_info->error & ~24u) return fail(ctx, FORMA_E_INTERNAL, "device-side invariant violated");
     if (!t) return FORMA_OK;
     memset(t, 0, sizeof *t);
     float* dstv[ST_COUNT] = {&t->prepare_us, &t->rasterize_us, &t->sort_us, &t->carry_us, &t->paint_us, &t->d2h_us, &t->exchange_us};

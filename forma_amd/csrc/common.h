@@ -43,7 +43,7 @@ struct FrameInfo {
     uint32_t n_entries;      // E
     uint32_t layer_unsorted; // != 0 if the rasterizer stream is not non-decreasing in layer
     uint32_t error;          // device-side invariant violations (1 style, 2 tile depth [unused], 4 look-back spin); 8 = not an
-                             // error: tiles deeper than the painter's LDS lists are pending (launch_paint_huge)
+                             // error: tiles deeper than the painter's LDS lists are pending (launch_paint_huge); 16 = not an error: some tile went to k_paint_deep
     uint32_t n_compact;      // lines with at least one pixel segment
     uint32_t plan_bad;       // asynchronous frames: the speculated sort plan does not match this frame's keys
     uint32_t max_row_runs;   // most runs in one tile row (the carry pre-pass sorts a row's runs in LDS when they fit)
@@ -211,7 +211,8 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
                   const uint32_t* style_offsets, const uint32_t* style_words, const forma_image_t* images,
                   const uint16_t* texels, uint8_t* image, TileCacheArgs cache, FrameInfo* info, uint32_t* overflow_n /* zeroed by launch_runs */,
                   uint32_t* overflow_list /* tiles_w * tiles_h words */, uint32_t* over2_n /* zeroed by launch_runs */,
-                  uint32_t* over2_list /* {tile, entries} pairs: 2 * tiles_w * tiles_h words */);
+                  uint32_t* over2_list /* {tile, entries} pairs: 2 * tiles_w * tiles_h words */,
+                  bool launch_deep /* false: k_paint_deep is not launched; a tile that needs it voids the frame (plan_bad) */);
 // tiles whose layer list exceeds the painter's LDS lists (info->error bit 3 after launch_paint): lists in global memory,
 // offs[i] = first entry slot of tile over2_list[2 i]; g_key holds 4 entries per slot, g_tmp / g_flag one
 void launch_paint_huge(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, DevCount n_runs,

@@ -50,6 +50,7 @@ struct forma_hip_ctx {
     // lines
     DevBuf l_order, l_x0, l_y0, l_dx, l_dy, l_a, l_b, l_c, l_d, l_len, scan_tmp;   // parity entry points only
     DevBuf cl_idx, cl_start, block_first, prep_scratch;                              // frame path: compacted line table
+    bool pred_no_deep = false;              // the last verified frame sent no tile to k_paint_deep
     DevBuf ras_masks;                       // k_rasterize: key masks per workgroup (8 words), combined by k_reduce_masks
     PendingMasks pending_masks{nullptr, 0u}; // ... or, on read-back-free frames, by k_runs_count
     size_t n_lines = 0, n_compact = 0;

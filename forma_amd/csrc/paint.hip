@@ -1712,7 +1712,7 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
                                                     const uint16_t* __restrict__ texels, uint8_t* __restrict__ image,
                                                     TileCacheArgs cache, FrameInfo* __restrict__ info,
                                                     uint32_t* __restrict__ overflow_n,
-                                                    uint32_t* __restrict__ overflow_list) {
+                                                    uint32_t* __restrict__ overflow_list, uint32_t deep_follows) {
     __shared__ uint64_t w_key[1][WMAX];
     __shared__ uint64_t w_tmp[1][WMAX];
     __shared__ uint32_t w_flag[1][WMAX];
@@ -1788,7 +1788,11 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
     PP_STAMP(0);                                                        // 0: tile's runs + crossing spans found
     PP_COUNT(17, ne); PP_COUNT(18, sc);
     if (ne > WMAX) {                                                    // too deep for a wave: the workgroup variant paints it
-        if (lane == 0) overflow_list[atomicAdd(overflow_n, 1u)] = tile;
+        if (lane == 0) {
+            overflow_list[atomicAdd(overflow_n, 1u)] = tile;
+            atomicOr(&info->error, 16u);                                // (not an error: "this frame has deep tiles", read by the host)
+            if (!deep_follows) info->plan_bad = 1u;                     // the host guessed "none" and did not launch k_paint_deep: re-run
+        }
         return;
     }
     wave_lds_sync();
@@ -2141,13 +2145,14 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
                   const uint64_t* span_key, const uint4* span_cov, const uint4* layer_col,
                   const uint32_t* style_offsets, const uint32_t* style_words, const forma_image_t* images,
                   const uint16_t* texels, uint8_t* image, TileCacheArgs cache, FrameInfo* info, uint32_t* overflow_n,
-                  uint32_t* overflow_list, uint32_t* over2_n, uint32_t* over2_list) {
+                  uint32_t* overflow_list, uint32_t* over2_n, uint32_t* over2_list, bool launch_deep) {
     const uint32_t T = p.tiles_w * p.tiles_h;
     if (T == 0 || p.crop_y1 <= p.crop_y0) return;
     const uint32_t per = ((p.crop_y1 - p.crop_y0) * p.tiles_w + 7) / 8;
     hipLaunchKernelGGL(k_paint_wave, dim3(per * 8), dim3(64), 0, s, p, sorted, records, n_runs, tile_first_run, row_span_lo,
                        row_span_cnt, span_key, span_cov, layer_col, style_offsets, style_words, images, texels, image,
-                       cache, info, overflow_n, overflow_list);
+                       cache, info, overflow_n, overflow_list, launch_deep ? 1u : 0u);
+    if (!launch_deep) return;                             // (read-back-free frame of a scene whose last frame had no deep tile)
     hipLaunchKernelGGL(k_paint_deep, dim3(T < 256 ? T : 256), dim3(256), 0, s, p, sorted, records, n_runs, tile_first_run,
                        row_span_lo, row_span_cnt, span_key, span_cov, layer_col, style_offsets, style_words, images,
                        texels, image, cache, info, (const uint32_t*)overflow_n, (const uint32_t*)overflow_list, over2_n, over2_list);
