@@ -216,15 +216,16 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
         HIPCHECK(ctx->image.ensure((size_t)a.width * a.height * 4));
         ctx->cur_image = ctx->image.as<uint8_t>();
     }
-    // one buffer, zeroed by ONE memset per frame (launch_runs): [row_count | row_span_lo | row_span_cnt] (tiles_h + 1 words
-    // each) [painter overflow counters: wave -> deep, deep -> huge] [first-run table, T words]; the painter's overflow lists
-    // (T words of tiles, 2 T words of {tile, entries}) follow un-zeroed
-    HIPCHECK(ctx->row_tab.ensure(((size_t)(tiles_h + 1) * 3 + 2 + 4 * (size_t)T) * 4));
+    // one buffer, zeroed by ONE memset per frame (launch_runs; layout: row_tab_zero_words in common.h): [row_count: tiles_h + 1]
+    // [row_span_lo | row_span_cnt: one pair per (row, slice of the carry pre-pass), 8 tiles_h + 1 each] [painter overflow
+    // counters: wave -> deep, deep -> huge] [first-run table, T words]; the painter's overflow lists (T words of tiles, 2 T
+    // words of {tile, entries}) follow un-zeroed
+    HIPCHECK(ctx->row_tab.ensure(((size_t)row_tab_zero_words(tiles_w, tiles_h) + 3 * (size_t)T) * 4));
     FrameInfo* dinfo = ctx->info.as<FrameInfo>();
     uint32_t* row_count = ctx->row_tab.as<uint32_t>();
     uint32_t* row_span_lo = row_count + (tiles_h + 1);
-    uint32_t* row_span_cnt = row_span_lo + (tiles_h + 1);
-    uint32_t* paint_overflow = row_span_cnt + (tiles_h + 1);          // [0], [1] = the two counts, then the first-run table ...
+    uint32_t* row_span_cnt = row_span_lo + (CR_MAX_SLICES_HOST * tiles_h + 1);
+    uint32_t* paint_overflow = row_span_cnt + (CR_MAX_SLICES_HOST * tiles_h + 1);   // [0], [1] = the two counts, then the first-run table ...
     uint32_t* over2_n = paint_overflow + 1;
     uint32_t* tile_first_run = paint_overflow + 2;
     uint32_t* overflow_list = tile_first_run + T;                       // ... then the lists themselves
@@ -247,9 +248,36 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     // the runs of a tile row are ordered by (layer, tile_x) inside k_carry_rows when they fit its LDS; else by a global sort
     // (the in-LDS key holds 16 layer bits: every order a geom can produce has to fit, not just the style table)
     bool local_sort = ctx->n_orders <= 65536 && ctx->max_geom_order < 65536 && !ctx->global_runsort;
+    // Several workgroups share a tile row, each a range of layers (k_carry_rows): as many as keep the chip busy for the rows
+    // this frame paints (a multi-GPU band is a fraction of the canvas).  The small-LDS variant (two workgroups per CU) is a
+    // read-back-free frame's guess — its slices must fit 4096 runs, known only from a previous frame; a slice that does not
+    // fit voids the frame (plan_bad), the synchronous re-run takes the large variant, and the guess is not made again.
+    uint32_t crow0 = 0, crow1 = tiles_h;                    // the tile rows the painter visits (Rect::new, renderer.rs:43-52)
+    if (a.crop) { crow0 = a.crop->y0 / 16; crow1 = std::min(tiles_h, (a.crop->y1 + 15) / 16); }
+    const uint32_t rows_painted = std::max(crow1 > crow0 ? crow1 - crow0 : 0u, 1u);
+    // Slicing pays when a row is heavy (measured on a 17-row band of the 4K scene, 4 800 runs per row: carry stage 80 -> 57 us
+    // with eight small workgroups per row) and costs when it is light (a 64-row band of the 8192 x 8192 scene, ~1 000 runs per
+    // row: 48 -> 55 us): a slice should keep >= ~768 runs.
+    auto slices_for = [&](uint32_t per_cu_budget, uint32_t max_row) {
+        const uint32_t by_chip = std::max(1u, per_cu_budget / rows_painted), by_load = std::max(1u, max_row / 768u);
+        return std::min<uint32_t>(CR_MAX_SLICES_HOST, std::min(by_chip, by_load));
+    };
+    uint32_t n_slices = 1;
+    bool small = false;
     if (bound_j) {
         jc = DevCount{&dinfo->n_runs, bound_j};
         local_sort = local_sort && ctx->pred_max_row <= carry_rows_local_cap();     // wrong guess -> plan_bad -> synchronous re-run
+        const uint32_t pmr = ctx->pred_max_row == 0xFFFFFFFFu ? 0u : ctx->pred_max_row;
+        n_slices = slices_for(256u, pmr);
+        const uint32_t ks = slices_for(512u, pmr);
+        // (a whole 4K frame — 135 rows, one workgroup each — gains nothing from three small workgroups per row and its painters
+        //  pay for the extra span lists: measured 124 -> 126 us carry, 133 -> 139 us paint; bands of <= 128 rows do gain)
+        if (local_sort && ks > 1u && rows_painted <= 128u && !ctx->small_banned && !ctx->no_small_carry && !ctx->force_slices) {
+            const bool known = ctx->pred_slice_n == ks && ctx->pred_slice_small;
+            const uint64_t guess = known ? (uint64_t)ctx->pred_max_slice * 10 / 9 : (uint64_t)ctx->pred_max_row * 5 / (3 * ks);
+            if (guess <= carry_rows_small_cap()) { small = true; n_slices = ks; }
+        }
+        ctx->small_tried = small;
     } else {
         if (n > 0) {
             HIPCHECK(hipMemcpyAsync(ctx->h_rows, row_count, (size_t)tiles_h * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -258,9 +286,10 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
             if ((rc = verify_speculation(ctx))) return rc;
             J = ctx->h_info->n_runs;
             uint32_t mx = 0;
-            for (uint32_t r = 0; r < tiles_h; r++) mx = std::max(mx, ctx->h_rows[r]);
+            for (uint32_t r = crow0; r < crow1; r++) mx = std::max(mx, ctx->h_rows[r]);      // (rows that are not painted get no workgroup)
             ctx->pred_max_row = mx;
             local_sort = local_sort && mx <= carry_rows_local_cap();
+            n_slices = slices_for(256u, mx);
         }
         jc = DevCount{nullptr, J};
     }
@@ -281,7 +310,11 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                                             ctx->rk_b.as<uint64_t>(), jc, rk_plan, ctx->digit_bits,
                                             ctx->sort_counters.as<uint32_t>(), &dinfo->error, nullptr, nullptr);
         }
-        launch_carry_rows(ctx->stream, local_sort, sorted_keys, ctx->records.as<TileRecord>(),
+        if (ctx->force_slices) n_slices = ctx->force_slices;  // FORMA_HIP_CARRY_SLICES (tests: every slice count on one GPU)
+        uint32_t bin_shift = 0;                             // 256 layer bins over the orders in use
+        while (bin_shift < 16 && (((uint64_t)std::max<size_t>(ctx->n_orders, 1) - 1) >> bin_shift) > 255) bin_shift++;
+        ctx->cur_slices = n_slices; ctx->cur_small = small;
+        launch_carry_rows(ctx->stream, local_sort, small, n_slices, bin_shift, sorted_keys, ctx->records.as<TileRecord>(),
                           ctx->blk_edge.as<BlkEdge>(), nc, jc, ctx->layer_sf.as<uint32_t>(),
                           (uint32_t)ctx->n_orders, tiles_w, tiles_h, row_count, row_span_lo,
                           row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(),
@@ -289,7 +322,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                           runs_edge_segments(ctx->legacy_runs),
                           // invisible carries of a partial last tile row are dropped only when nothing can observe them: with a
                           // buffer-layer cache the layer count of a tile is state (passes/tile_unchanged.rs)
-                          (a.cache_id < 0 && (a.height & 15u)) ? (a.height & 15u) : 16u);
+                          (a.cache_id < 0 && (a.height & 15u)) ? (a.height & 15u) : 16u, crow0, crow1);
     } else {
         HIPCHECK(ctx->span_key.ensure(8));
         HIPCHECK(ctx->span_cov.ensure(16));
@@ -311,6 +344,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     for (int i = 0; i < 4; i++) P.clear[i] = a.clear[i];
     P.stride_px = a.width; P.scene_has_clips = ctx->scene_has_clips ? 1u : 0u; P.n_orders = (uint32_t)ctx->n_orders;
     P.clear_unchanged = clear_unchanged;
+    P.n_slices = jc.bound > 0 ? n_slices : 1u;             // (no runs: the carry pre-pass did not run, the zeroed tables say "no spans")
     stage_begin(ctx, ST_PAINT, timing);
     launch_paint(ctx->stream, P, ctx->sorted, ctx->records.as<TileRecord>(), jc, tile_first_run, row_span_lo,
                  row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(), ctx->layer_col.as<uint4>(),
@@ -433,6 +467,7 @@ int finish_frame(forma_hip_ctx* ctx, forma_timings_t* t, bool have_info = false)
     }
     // device-side invariant flags
     ctx->pred_no_deep = !(ctx->h_info->error & 16u);       // (8, 16: bookkeeping bits, not errors)
+    if (!ctx->h_info->plan_bad) { ctx->pred_max_slice = ctx->h_info->max_slice_runs; ctx->pred_slice_n = ctx->cur_slices; ctx->pred_slice_small = ctx->cur_small; }
     if (ctx->h_info->error & ~24u) return fail(ctx, FORMA_E_INTERNAL, "device-side invariant violated");
     if (!t) return FORMA_OK;
     memset(t, 0, sizeof *t);
@@ -509,6 +544,8 @@ int forma_hip_create(forma_hip_ctx** out, int device) {
     ctx->global_runsort = getenv("FORMA_HIP_GLOBAL_RUNSORT") != nullptr;
     ctx->legacy_runs = getenv("FORMA_HIP_LEGACY_RUNS") != nullptr;
     ctx->xgather_always = getenv("FORMA_HIP_XGATHER") != nullptr;
+    ctx->no_small_carry = getenv("FORMA_HIP_NO_SMALL_CARRY") != nullptr;
+    if (const char* e = getenv("FORMA_HIP_CARRY_SLICES")) ctx->force_slices = (uint32_t)std::min(std::max(atoi(e), 1), (int)CR_MAX_SLICES_HOST);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx; return FORMA_E_HIP;
     }
@@ -881,6 +918,7 @@ int complete_async_frame(forma_hip_ctx* ctx, const PaintArgs& a, uint8_t* dst, s
     ctx->n_seg = N; ctx->n_compact = ctx->h_info->n_compact; ctx->last_runs = J;
     const bool ok = !ctx->h_info->plan_bad && N <= bN && J <= bJ;
     if (!ok) {
+        if (ctx->small_tried && ctx->h_info->plan_bad) ctx->small_banned = true;   // (one cause of plan_bad: a slice beyond the small variant)
         ctx->pred_counts_valid = false;                   // the synchronous path re-learns everything
         clear_stage_flags(ctx);
         return FORMA_RETRY;
@@ -973,8 +1011,8 @@ void share_scene(forma_hip_ctx* o) {
     }
 }
 void invalidate_counts(forma_hip_ctx* o) {                 // new geometry / band: every slot re-learns N and J synchronously
-    o->pred_counts_valid = false; o->xpred_valid = false;
-    for (forma_hip_ctx* sl : o->slots) { sl->pred_counts_valid = false; sl->xpred_valid = false; }
+    o->pred_counts_valid = false; o->xpred_valid = false; o->small_banned = false;
+    for (forma_hip_ctx* sl : o->slots) { sl->pred_counts_valid = false; sl->xpred_valid = false; sl->small_banned = false; }
 }
 }  // namespace
 
@@ -1345,6 +1383,7 @@ int fd_gather_sort_paint(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint3
         if (ctx->h_info->exchange_overflow) return fail(ctx, FORMA_E_CAPACITY, "exchange: a bucket exceeds the pair capacity (re-plan)");
         const uint32_t N = ctx->h_info->n_segments, J = ctx->h_info->n_runs;
         ctx->n_seg = N; ctx->last_runs = J;
+        if (ctx->h_info->plan_bad && ctx->small_tried) ctx->small_banned = true;
         if (!ctx->h_info->plan_bad && J <= bJ) {
             ctx->pred_J = J; ctx->pred_max_row = ctx->h_info->max_row_runs;
             if ((rc = finish_paint(ctx))) return rc;

@@ -48,6 +48,7 @@ struct FrameInfo {
     uint32_t plan_bad;       // asynchronous frames: the speculated sort plan does not match this frame's keys
     uint32_t max_row_runs;   // most runs in one tile row (the carry pre-pass sorts a row's runs in LDS when they fit)
     uint32_t exchange_overflow;   // multi-GPU exchange: a bucket did not fit the agreed pair capacity (here or at a sender)
+    uint32_t max_slice_runs;      // most runs one workgroup of the carry pre-pass sorted in LDS (a slice of a tile row)
 };
 
 // one run of the sorted stream = one painted (tile, layer) pair that owns pixel segments
@@ -69,6 +70,7 @@ struct PaintParams {
     uint32_t scene_has_clips;
     uint32_t n_orders;
     uint32_t clear_unchanged;                      // buffer-layer cache: this frame's clear colour == the cached one
+    uint32_t n_slices;                             // span lists per tile row (slices of the carry pre-pass)
 };
 
 // buffer-layer cache (reference cpu/buffer/mod.rs:113-197, painter/mod.rs:629-715 `CachedTile`), device-resident:
@@ -196,14 +198,22 @@ uint32_t runs_edge_segments(bool legacy);   // segments per BlkEdge entry of the
 #define SF_FILL_SHIFT  9          // 2 bits: fill type
 #define LSF_VALID      0x80000000u // layer_sf[] entry: the order has a style (else FORMA_NONE)
 
-uint32_t carry_rows_local_cap();      // most runs per tile row the in-LDS sort of launch_carry_rows(local_sort = true) takes
-void launch_carry_rows(hipStream_t s, bool local_sort, const uint64_t* sorted_run_keys, TileRecord* records,
+uint32_t carry_rows_local_cap();      // most runs a workgroup of launch_carry_rows(local_sort = true) sorts in LDS: large variant ...
+uint32_t carry_rows_small_cap();      // ... small variant (several workgroups per CU)
+#define CR_MAX_SLICES_HOST 8u         // workgroups that may share one tile row
+// the frame's tile tables, one buffer: [row_count: tiles_h + 1][row_span_lo: 8 tiles_h + 1][row_span_cnt: 8 tiles_h + 1]
+// [painter overflow counters: 2][first-run table: T] — zeroed every frame by launch_runs — then [overflow list: T][{tile, entries}: 2 T]
+static inline uint32_t row_tab_zero_words(uint32_t tiles_w, uint32_t tiles_h) { return (tiles_h + 1) + 2 * (CR_MAX_SLICES_HOST * tiles_h + 1) + 2 + tiles_w * tiles_h; }
+// n_slices workgroups per tile row (each a range of layers, 256 bins of layer >> bin_shift); small: the CR_CAP_S variant
+void launch_carry_rows(hipStream_t s, bool local_sort, bool small, uint32_t n_slices, uint32_t bin_shift,
+                       const uint64_t* sorted_run_keys, TileRecord* records,
                        const BlkEdge* blk_edge, DevCount n_segments, DevCount n_runs,
                        const uint32_t* layer_sf /* per order: SF_* | LSF_VALID */, uint32_t n_orders, uint32_t tiles_w,
                        uint32_t tiles_h, const uint32_t* row_count, uint32_t* row_span_lo, uint32_t* row_span_cnt,
                        uint64_t* span_key, uint4* span_cov, const uint8_t* unchanged /* per order, nullable */, FrameInfo* info,
                        uint32_t edge_segs,
-                       uint32_t vis_last /* visible pixel rows of the last tile row (height % 16, 16 if 0) */);
+                       uint32_t vis_last /* visible pixel rows of the last tile row (height % 16, 16 if 0) */,
+                       uint32_t row0, uint32_t row1 /* the tile rows that are painted (the crop): only those get workgroups */);
 void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, DevCount n_runs,
                   const uint32_t* tile_first_run, const uint32_t* row_span_lo, const uint32_t* row_span_cnt,
                   const uint64_t* span_key, const uint4* span_cov,

@@ -560,7 +560,7 @@ void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t ti
                  PendingMasks pm) {
     // per-frame tile tables: [row_count | row_span_lo | row_span_cnt | painter overflow counters (2) | first-run table] are
     // contiguous (api.cpp lays them out so) and zeroed by k_runs_count; 0 in the first-run table = the tile has no run
-    const uint32_t zero_words = (tiles_h + 1) * 3 + 2 + tiles_w * tiles_h;
+    const uint32_t zero_words = row_tab_zero_words(tiles_w, tiles_h);
     if (nc.bound == 0) {
         (void)hipMemsetAsync(row_tab, 0, (size_t)zero_words * 4, s);
         (void)hipMemsetAsync(&info->n_runs, 0, 4, s);
@@ -598,11 +598,9 @@ uint32_t runs_edge_segments(bool legacy) { return legacy ? RN_TILE : RW_CHUNK; }
 // ================================================================================================
 #define CR_THREADS 1024
 #define CR_WAVES   (CR_THREADS / 64)
-#define CR_CAP     16384                // runs of one tile row that the in-LDS sort holds (2 x 64 KiB of 32-bit keys)
-#ifndef CR_RPT
-#define CR_RPT     4                    // consecutive runs of the (layer, tile_x) order per lane in the row walk (2, 6: same; 8: slower)
-#endif
-#define CR_PIECE   (CR_THREADS * CR_RPT)   // runs per piece
+#define CR_CAP     16384                // runs one workgroup's in-LDS sort holds, large variant (2 x 64 KiB of 32-bit keys: one per CU)
+#define CR_CAP_S   4096                 // ... small variant (2 x 16 KiB: two to three workgroups per CU)
+#define CR_MAX_SLICES 8                 // workgroups that share one tile row (each takes a range of layers)
 
 // workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight across it
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -626,12 +624,13 @@ struct CarryLoad {
     uint4 oc;
 };
 template <bool LOCAL>
-__device__ __forceinline__ CarryLoad carry_load(uint32_t c0, int tid, uint32_t cnt, uint32_t row_lo, uint32_t n_runs, uint32_t ty,
+__device__ __forceinline__ CarryLoad carry_load(uint32_t c0, int tid, uint32_t cnt /* runs of the slice */, uint32_t row_lo /* first run of the row */,
+                                                uint32_t kbase /* !LOCAL: first sorted key of the slice */, uint32_t n_runs, uint32_t ty,
                                                 const uint32_t* lkeys, const uint64_t* __restrict__ sorted_keys,
                                                 const TileRecord* __restrict__ records,
                                                 const uint32_t* __restrict__ layer_sf, uint32_t n_orders) {
     CarryLoad L;
-    const uint32_t k = row_lo + c0 + tid;
+    const uint32_t k = (LOCAL ? row_lo : kbase) + c0 + tid;
     L.active = c0 + tid < cnt && k < n_runs;
     L.group = 0xFFFFFFFEu; L.jrun = 0; L.layer = 0; L.tile = 0; L.sc = 0; L.seg_start = 0; L.lsf = 0;
     L.oc = make_uint4(0, 0, 0, 0);
@@ -658,8 +657,17 @@ __device__ __forceinline__ CarryLoad carry_load(uint32_t c0, int tid, uint32_t c
 // LSB radix sort of `layer << 16 | index` in LDS, one or two 8-bit passes over the layer bits, wave-ranked like a sort
 // tile.  That replaces a global histogram + three chained radix passes over all J run keys (launch- and latency-bound:
 // ~60 us per frame at J = 1.3 M) by a few microseconds inside a kernel that is launched anyway.  Needs n_orders <= 65536
-// and cnt <= CR_CAP (checked on the device; the host falls back to the global sort, LOCAL = false).
-template <bool LOCAL>
+// and a slice of <= CAP runs (checked on the device; the host falls back to the global sort, LOCAL = false).
+//
+// SLICES.  A tile row is shared by n_slices workgroups (blockIdx.x = row * n_slices + slice), each taking a contiguous RANGE
+// OF LAYERS: carries never cross layers, so the slices are independent.  LOCAL: every workgroup of the row histograms the
+// row's run keys over 256 layer bins (layer >> bin_shift), cuts the bins into n_slices ranges of about equal run counts and
+// keeps (stable compaction) only the runs of its range — then sorts, gathers and scans a 1 / n_slices share.  !LOCAL: the
+// globally sorted keys of the row are cut at layer boundaries.  Slice h writes its spans into its own sub-range of the row's
+// span slots (row_lo + runs in the bins below it), and the painters walk a row's n_slices span lists one after the other —
+// ascending layers, as before.  One workgroup per row was 135 workgroups on 256 CUs for the 4K frame, each ~50 us of pure
+// latency (scattered record gathers through one CU's address pipe); on a multi-GPU band of 17 rows it was the frame's floor.
+template <bool LOCAL, int CAP, int RPT>
 __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __restrict__ sorted_keys,
                                                            TileRecord* __restrict__ records,
                                                            const BlkEdge* __restrict__ blk_edge, DevCount nc_segments,
@@ -672,18 +680,24 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
                                                            uint64_t* __restrict__ span_key, uint4* __restrict__ span_cov,
                                                            const uint8_t* __restrict__ unchanged,
                                                            FrameInfo* __restrict__ info, uint32_t edge_segs,
-                                                           uint32_t vis_last /* visible pixel rows of the last tile row, 16 = all */) {
+                                                           uint32_t vis_last /* visible pixel rows of the last tile row, 16 = all */,
+                                                           uint32_t n_slices, uint32_t bin_shift,
+                                                           uint32_t row0 /* first tile row that is painted: blockIdx.x = 0 */) {
+    constexpr int CR_RPT = RPT;                        // consecutive runs of the (layer, tile_x) order per lane in the row walk
+    constexpr int CR_PIECE = CR_THREADS * RPT;         // runs per piece
+    constexpr bool NB_IN_IDLE = LOCAL && 2 * (CR_PIECE + 1) <= CAP;   // group / tile_x of a piece's runs live in the sort's idle buffer
     __shared__ uint32_t s_red[CR_WAVES];
     __shared__ uint64_t s_wlo[CR_WAVES], s_whi[CR_WAVES];
     __shared__ uint32_t s_wflag[CR_WAVES], s_wspan[CR_WAVES];
-    __shared__ uint32_t s_group[256];                  // scratch of the in-LDS sort
-    __shared__ uint32_t s_nb[LOCAL ? 1 : 2 * (CR_PIECE + 1)];   // group / tile_x of a piece's runs (LOCAL: in the sort's idle buffer)
+    __shared__ uint32_t s_group[256];                  // scratch of the in-LDS sort; before it, the layer-bin histogram
+    __shared__ uint32_t s_nb[NB_IN_IDLE ? 1 : 2 * (CR_PIECE + 1)];
     __shared__ uint64_t s_clo, s_chi;                  // carry across chunks: inclusive acc of the last element
     __shared__ uint32_t s_cgroup, s_spans;
-    __shared__ uint32_t s_ka[LOCAL ? CR_CAP : 1], s_kb[LOCAL ? CR_CAP : 1];
+    __shared__ uint32_t s_ka[LOCAL ? CAP : 1], s_kb[LOCAL ? CAP : 1];
     __shared__ uint32_t s_wh[LOCAL ? CR_WAVES * 256 : 1];
+    __shared__ uint32_t s_cut[4];                      // this slice: first bin, end bin | first key, end key (!LOCAL)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t ty = blockIdx.x;
+    const uint32_t ty = row0 + blockIdx.x / n_slices, slice = blockIdx.x % n_slices;
     // A canvas whose height is not a multiple of 16: lines entirely below it are culled (segment.rs:41-52), so a layer that
     // crosses the bottom edge keeps a non-zero cover on the INVISIBLE pixel rows of the last tile row.  The reference carries
     // it (Cover::is_empty looks at all 16 rows) and paints the layer with zero visible coverage in every tile to the right;
@@ -725,34 +739,110 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
     uint32_t row_lo = 0;
 #pragma unroll
     for (int i = 0; i < CR_WAVES; i++) row_lo += s_red[i];
-    if (tid == 0) row_span_lo[ty] = row_lo;
-    const uint32_t* lkeys = s_ka;                        // LOCAL: the row's runs, ordered by (layer, tile_x)
-    if (tid == 0 && cnt) atomicMax(&info->max_row_runs, cnt);
+    const uint32_t* lkeys = s_ka;                        // LOCAL: the slice's runs, ordered by (layer, tile_x)
+    if (tid == 0 && cnt && slice == 0) atomicMax(&info->max_row_runs, cnt);
+    uint32_t m = cnt;                                    // runs of this slice
+    uint32_t off = 0;                                    // runs of the row in the slices before it (= its first span slot)
+    uint32_t kbase = row_lo;                             // !LOCAL: first sorted key of the slice
     if (LOCAL) {
-        if (cnt > CR_CAP || row_lo + cnt > n_runs) {      // does not fit (or inconsistent counts): the host re-runs the frame
+        if (cnt > 65535u || row_lo + cnt > n_runs) {      // (16 index bits per packed key) / inconsistent counts: the host re-runs the frame
             if (tid == 0) info->plan_bad = 1u;
             return;
         }
         CRP_STAMP(0);                                                   // prologue: counts, row prefix
-        for (uint32_t e = tid; e < cnt; e += CR_THREADS)
-            s_ka[e] = (((uint32_t)(sorted_keys[row_lo + e] >> 32) & 0xFFFFu) << 16) | e;
-        __syncthreads();
-        CRP_STAMP(1);                                                   // the row's run keys into LDS
+        if (n_slices > 1u) {
+            // ---- which layers are mine: 256-bin histogram of the row's run keys, cut into n_slices ranges of ~equal counts.
+            //      Every workgroup of the row computes the same cuts from the same keys. ------------------------------------
+            if (tid < 256) s_group[tid] = 0;
+            __syncthreads();
+            for (uint32_t e = tid; e < cnt; e += CR_THREADS) {
+                const uint32_t bin = min(255u, (((uint32_t)(sorted_keys[row_lo + e] >> 32) & 0xFFFFu) >> bin_shift));
+                atomicAdd(&s_group[bin], 1u);
+            }
+            __syncthreads();
+            uint32_t binc = 0;                            // inclusive prefix of the bins
+            if (tid < 256) {
+                binc = s_group[tid];
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(binc, d, 64); if (lane >= d) binc += t; }
+                if (lane == 63) s_red[w] = binc;
+            }
+            __syncthreads();
+            if (tid < 256) {
+                uint32_t base = 0;
+                for (int i = 0; i < w; i++) base += s_red[i];
+                s_group[tid] = base + binc;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                // slice h owns the bins [cut(h), cut(h + 1)): cut(h) = bins that lie entirely inside the first h / n_slices of the runs
+                uint32_t cutv[2];
+                for (int q = 0; q < 2; q++) {
+                    const uint32_t hh = slice + (uint32_t)q;
+                    uint32_t b = 0;
+                    if (hh >= n_slices) b = 256u;
+                    else if (hh > 0) {
+                        const uint32_t target = (uint32_t)(((uint64_t)hh * cnt) / n_slices);
+                        uint32_t lo = 0, hi = 256;
+                        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_group[mid] <= target) lo = mid + 1; else hi = mid; }
+                        b = lo;
+                    }
+                    cutv[q] = b;
+                }
+                s_cut[0] = cutv[0]; s_cut[1] = cutv[1];
+                s_cut[2] = cutv[0] ? s_group[cutv[0] - 1] : 0u;                           // runs below my bins
+                s_cut[3] = cutv[1] ? s_group[cutv[1] - 1] : 0u;                           // runs below the next slice's bins
+            }
+            __syncthreads();
+            const uint32_t blo = s_cut[0], bhi = s_cut[1];
+            off = s_cut[2]; m = s_cut[3] - s_cut[2];
+            if (m > (uint32_t)CAP) {                      // does not fit this variant's LDS: the host re-runs with the large variant / global sort
+                if (tid == 0) info->plan_bad = 1u;
+                return;
+            }
+            // ---- stable compaction of my runs, in stream (tile_x-major) order, 1024 keys per round ----------------------------
+            uint32_t filled = 0;
+            for (uint32_t e0 = 0; e0 < cnt; e0 += CR_THREADS) {
+                const uint32_t e = e0 + (uint32_t)tid;
+                uint32_t l16 = 0; bool keep = false;
+                if (e < cnt) {
+                    l16 = (uint32_t)(sorted_keys[row_lo + e] >> 32) & 0xFFFFu;
+                    const uint32_t bin = min(255u, l16 >> bin_shift);
+                    keep = bin >= blo && bin < bhi;
+                }
+                const uint64_t bal = __ballot(keep);
+                if (lane == 0) s_red[w] = (uint32_t)__popcll(bal);
+                __syncthreads();
+                uint32_t base = filled, tot = 0;
+#pragma unroll
+                for (int i = 0; i < CR_WAVES; i++) { const uint32_t t = s_red[i]; if (i < w) base += t; tot += t; }
+                if (keep) s_ka[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (l16 << 16) | e;
+                filled += tot;
+                __syncthreads();
+            }
+        } else {
+            if (cnt > (uint32_t)CAP) { if (tid == 0) info->plan_bad = 1u; return; }
+            for (uint32_t e = tid; e < cnt; e += CR_THREADS)
+                s_ka[e] = (((uint32_t)(sorted_keys[row_lo + e] >> 32) & 0xFFFFu) << 16) | e;
+            __syncthreads();
+        }
+        if (tid == 0 && m) atomicMax(&info->max_slice_runs, m);
+        CRP_STAMP(1);                                                   // the slice's run keys into LDS
         uint32_t* src = s_ka;
         uint32_t* dst = s_kb;
-        const uint32_t R = (cnt + CR_THREADS - 1) / CR_THREADS, CW = R * 64;       // key rows per wave, keys per wave
+        const uint32_t R = (m + CR_THREADS - 1) / CR_THREADS, CW = R * 64;         // key rows per wave, keys per wave
         const int npass = n_orders > 256u ? 2 : 1;
         for (int pass = 0; pass < npass; pass++) {
             const int sh = 16 + 8 * pass;
             for (int i = tid; i < CR_WAVES * 256; i += CR_THREADS) s_wh[i] = 0;
             __syncthreads();
             CRP_STAMP(5);                                               // sort: counters cleared
-            uint32_t kreg[CR_CAP / CR_THREADS], rreg[CR_CAP / CR_THREADS];
+            uint32_t kreg[CAP / CR_THREADS], rreg[CAP / CR_THREADS];
 #pragma unroll
-            for (int r = 0; r < CR_CAP / CR_THREADS; r++) {
+            for (int r = 0; r < CAP / CR_THREADS; r++) {
                 if ((uint32_t)r < R) {
                     const uint32_t e = w * CW + r * 64 + lane;
-                    const uint32_t key = e < cnt ? src[e] : 0xFFFFFFFFu;           // padding: last in stream order, digit 255
+                    const uint32_t key = e < m ? src[e] : 0xFFFFFFFFu;             // padding: last in stream order, digit 255
                     const uint32_t dg = (key >> sh) & 0xFFu;
                     uint32_t mlo, mhi;
                     match_any<8>(dg, mlo, mhi);
@@ -785,10 +875,10 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
             }
             __syncthreads();
 #pragma unroll
-            for (int r = 0; r < CR_CAP / CR_THREADS; r++) {
+            for (int r = 0; r < CAP / CR_THREADS; r++) {
                 if ((uint32_t)r < R) {
                     const uint32_t e = w * CW + r * 64 + lane;
-                    if (e < cnt) dst[s_wh[w * 256 + ((kreg[r] >> sh) & 0xFFu)] + rreg[r]] = kreg[r];
+                    if (e < m) dst[s_wh[w * 256 + ((kreg[r] >> sh) & 0xFFu)] + rreg[r]] = kreg[r];
                 }
             }
             __syncthreads();
@@ -796,6 +886,30 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
         }
         lkeys = src;
         CRP_STAMP(2);                                                   // in-LDS sort by layer
+    } else if (n_slices > 1u) {
+        // ---- !LOCAL: the row's keys are sorted by layer already; cut [row_lo, row_lo + cnt) at layer boundaries near h / n_slices
+        if (row_lo + cnt > n_runs) { if (tid == 0) info->plan_bad = 1u; return; }
+        for (int q = 0; q < 2; q++) {
+            const uint32_t hh = slice + (uint32_t)q;
+            uint32_t pos = hh >= n_slices ? cnt : (uint32_t)(((uint64_t)hh * cnt) / n_slices);
+            if (hh > 0 && hh < n_slices) {                // forward to the next position where the layer changes
+                if (tid == 0) s_cut[q] = cnt;
+                __syncthreads();
+                for (uint32_t p0 = pos; p0 < cnt; p0 += CR_THREADS) {
+                    const uint32_t pp = p0 + (uint32_t)tid;
+                    bool brk = false;
+                    if (pp < cnt && pp > 0) brk = (uint32_t)(sorted_keys[row_lo + pp] >> 32) != (uint32_t)(sorted_keys[row_lo + pp - 1] >> 32);
+                    if (pp == 0) brk = true;
+                    if (brk) atomicMin(&s_cut[q], pp);
+                    __syncthreads();
+                    if (s_cut[q] < cnt) break;            // (uniform)
+                }
+                pos = s_cut[q];
+                __syncthreads();
+            }
+            if (q == 0) off = pos; else m = pos - off;
+        }
+        kbase = row_lo + off;
     }
     // The row is walked in pieces of CR_PIECE = 1024 x CR_RPT runs, a lane owning CR_RPT CONSECUTIVE runs of the (layer,
     // tile_x) order: all of a lane's gathers (record, cover sums, the layer's style summary) are in flight at once, the
@@ -804,16 +918,16 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
     // cross-lane machinery and 27 % waiting for one round of gathers per piece: tools/cr_prof.py.)
     // Group / tile_x of every run of the piece (+ the run after it) sit in LDS for the neighbour tests; LOCAL: in the sort's
     // idle buffer.
-    uint32_t* a_group = LOCAL ? (lkeys == s_ka ? s_kb : s_ka) : s_nb;
+    uint32_t* a_group = NB_IN_IDLE ? (lkeys == s_ka ? s_kb : s_ka) : s_nb;
     uint32_t* a_txb = a_group + (CR_PIECE + 1);
-    for (uint32_t c0 = 0; c0 < cnt; c0 += CR_PIECE) {
+    for (uint32_t c0 = 0; c0 < m; c0 += CR_PIECE) {
         CRP_STAMP(4);                                                   // (rest of the previous piece: span compaction + stores)
         CarryLoad cl[CR_RPT];
 #pragma unroll
         for (int k = 0; k < CR_RPT; k++)
-            cl[k] = carry_load<LOCAL>(c0, tid * CR_RPT + k, cnt, row_lo, n_runs, ty, lkeys, sorted_keys, records, layer_sf, n_orders);
+            cl[k] = carry_load<LOCAL>(c0, tid * CR_RPT + k, m, row_lo, kbase, n_runs, ty, lkeys, sorted_keys, records, layer_sf, n_orders);
         if (tid == 0) {                                                 // the run after the piece: only its group and tile_x
-            const CarryLoad la = carry_load<LOCAL>(c0, CR_PIECE, cnt, row_lo, n_runs, ty, lkeys, sorted_keys, records, layer_sf, n_orders);
+            const CarryLoad la = carry_load<LOCAL>(c0, CR_PIECE, m, row_lo, kbase, n_runs, ty, lkeys, sorted_keys, records, layer_sf, n_orders);
             a_group[CR_PIECE] = la.active ? la.group : 0xFFFFFFFEu;
             a_txb[CR_PIECE] = la.active ? (la.tile & 0xFFFu) : 0u;
         }
@@ -920,7 +1034,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
             span_lo[k] = txb[k]; span_hi[k] = 0;
             if (active) {
                 const uint32_t e = c0 + tid * CR_RPT + k;
-                const bool last = e + 1 == cnt;
+                const bool last = e + 1 == m;                            // (slices end at layer boundaries: nothing of this group follows)
                 const uint32_t ngroup = (k + 1 < CR_RPT) ? group[(k + 1) % CR_RPT] : a_group[tid * CR_RPT + CR_RPT];
                 const uint32_t ntxb = (k + 1 < CR_RPT) ? txb[(k + 1) % CR_RPT] : a_txb[tid * CR_RPT + CR_RPT];
                 const bool same_next = !last && ngroup == group[k];
@@ -946,7 +1060,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
 #pragma unroll
         for (int k = 0; k < CR_RPT; k++) {
             if ((spanm >> k) & 1u) {
-                const uint32_t si = row_lo + sbase;
+                const uint32_t si = row_lo + off + sbase;
                 sbase++;
                 const bool even_odd = (meta[k] >> 12) & 1u;
                 const uint32_t sfl = meta[k] & 0x7FFu, unch = (meta[k] >> 11) & 1u;
@@ -961,25 +1075,33 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
         if (tid == 0) s_spans += stot;
         lds_barrier();
     }
-    if (tid == 0) { row_span_cnt[ty] = s_spans; if (s_spans) atomicAdd(&info->n_spans, s_spans); }
+    if (tid == 0) {
+        row_span_lo[ty * n_slices + slice] = row_lo + off; row_span_cnt[ty * n_slices + slice] = s_spans;   // (one pair per (row, slice))
+        if (s_spans) atomicAdd(&info->n_spans, s_spans);
+    }
 }
 
 uint32_t carry_rows_local_cap() { return CR_CAP; }
+uint32_t carry_rows_small_cap() { return CR_CAP_S; }
 
-void launch_carry_rows(hipStream_t s, bool local_sort, const uint64_t* sorted_run_keys, TileRecord* records,
+void launch_carry_rows(hipStream_t s, bool local_sort, bool small, uint32_t n_slices, uint32_t bin_shift,
+                       const uint64_t* sorted_run_keys, TileRecord* records,
                        const BlkEdge* blk_edge, DevCount n_segments, DevCount n_runs, const uint32_t* layer_sf,
                        uint32_t n_orders, uint32_t tiles_w, uint32_t tiles_h, const uint32_t* row_count,
                        uint32_t* row_span_lo, uint32_t* row_span_cnt, uint64_t* span_key, uint4* span_cov,
-                       const uint8_t* unchanged, FrameInfo* info, uint32_t edge_segs, uint32_t vis_last) {
-    if (tiles_h == 0) return;
-    if (local_sort)
-        hipLaunchKernelGGL(k_carry_rows<true>, dim3(tiles_h), dim3(CR_THREADS), 0, s, sorted_run_keys, records, blk_edge,
-                           n_segments, n_runs, layer_sf, n_orders, tiles_w, tiles_h, row_count, row_span_lo,
-                           row_span_cnt, span_key, span_cov, unchanged, info, edge_segs, vis_last);
-    else
-        hipLaunchKernelGGL(k_carry_rows<false>, dim3(tiles_h), dim3(CR_THREADS), 0, s, sorted_run_keys, records, blk_edge,
-                           n_segments, n_runs, layer_sf, n_orders, tiles_w, tiles_h, row_count, row_span_lo,
-                           row_span_cnt, span_key, span_cov, unchanged, info, edge_segs, vis_last);
+                       const uint8_t* unchanged, FrameInfo* info, uint32_t edge_segs, uint32_t vis_last, uint32_t row0, uint32_t row1) {
+    row1 = row1 < tiles_h ? row1 : tiles_h;
+    if (tiles_h == 0 || row0 >= row1) return;             // (only the tile rows that are painted: the others' carries are never read)
+    if (n_slices < 1u) n_slices = 1u;
+    if (n_slices > CR_MAX_SLICES) n_slices = CR_MAX_SLICES;
+    const dim3 grid((row1 - row0) * n_slices), block(CR_THREADS);
+#define CR_LAUNCH(L, C, R) hipLaunchKernelGGL((k_carry_rows<L, C, R>), grid, block, 0, s, sorted_run_keys, records, blk_edge, n_segments, \
+                                              n_runs, layer_sf, n_orders, tiles_w, tiles_h, row_count, row_span_lo, row_span_cnt, span_key, \
+                                              span_cov, unchanged, info, edge_segs, vis_last, n_slices, bin_shift, row0)
+    if (!local_sort) CR_LAUNCH(false, CR_CAP, 4);
+    else if (small) CR_LAUNCH(true, CR_CAP_S, 2);
+    else CR_LAUNCH(true, CR_CAP, 4);
+#undef CR_LAUNCH
 }
 
 // ================================================================================================
@@ -1270,6 +1392,34 @@ __device__ __forceinline__ void texture_at(const uint32_t* __restrict__ w, const
     out[0] = f16b_to_f32(p[0]); out[1] = f16b_to_f32(p[1]); out[2] = f16b_to_f32(p[2]); out[3] = f16b_to_f32(p[3]);
 }
 
+// The span lists of a tile row: one per slice of the carry pre-pass (launch_carry_rows), ascending layers from slice to slice.
+// The painters see them as ONE logical list [0, total): logical index -> position in the span arrays by <= 7 compares
+// (uniform; a row with one slice pays nothing).
+struct SpanLists { uint32_t n, total; uint32_t pre[CR_MAX_SLICES], base[CR_MAX_SLICES]; };
+__device__ __forceinline__ SpanLists load_span_lists(const uint32_t* __restrict__ row_span_lo, const uint32_t* __restrict__ row_span_cnt,
+                                                     uint32_t ty, uint32_t n_slices) {
+    SpanLists L;
+    L.n = n_slices; L.total = 0;
+    uint32_t b[CR_MAX_SLICES], c[CR_MAX_SLICES];
+#pragma unroll
+    for (int q = 0; q < CR_MAX_SLICES; q++) {              // (all loads in flight together)
+        const bool in = (uint32_t)q < n_slices;
+        b[q] = in ? row_span_lo[ty * n_slices + q] : 0u; c[q] = in ? row_span_cnt[ty * n_slices + q] : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < CR_MAX_SLICES; q++) { L.pre[q] = L.total; L.base[q] = b[q]; L.total += c[q]; }
+    return L;
+}
+__device__ __forceinline__ uint32_t span_phys(const SpanLists& L, uint32_t i) {
+    uint32_t p = L.base[0] + i;
+#pragma unroll
+    for (int q = 1; q < CR_MAX_SLICES; q++) {
+        if ((uint32_t)q >= L.n) break;
+        if (i >= L.pre[q]) p = L.base[q] + (i - L.pre[q]);
+    }
+    return p;
+}
+
 // One tile, one 256-lane workgroup.  The tile's layer list lives in three caller-provided arrays: e_key (4 x stage entries:
 // the four waves stage their span hits there, then it holds the merged list, cap entries), e_tmp and e_flag (cap entries
 // each).  k_paint_deep passes LDS (cap 4096); a tile that does not fit is recorded as {tile, entries} in `over2`, and
@@ -1309,7 +1459,8 @@ __device__ __forceinline__ void paint_tile(const uint32_t MAXE, const uint32_t S
     const uint32_t my_tile_key = ((ty + 1u) << 12) | (tx + 1u);
     // first round of loads, all independent: where this tile's runs start, where this row's spans are
     const uint32_t j0 = tile_first_run[tile] - 1u;                      // 0 stored = no run -> FORMA_NONE
-    const uint32_t sb = row_span_lo[ty], sc = row_span_cnt[ty];
+    const SpanLists SL = load_span_lists(row_span_lo, row_span_cnt, ty, P.n_slices);
+    const uint32_t sc = SL.total;
     uint32_t na = 0;
     if (tid == 0) { s_seg0 = 0; s_seg1 = 0; s_over = 0; }
     // second round, issued together: the run records probed below and this wave's first 256 span keys
@@ -1317,7 +1468,7 @@ __device__ __forceinline__ void paint_tile(const uint32_t MAXE, const uint32_t S
     const uint32_t c_lo = min(sc, (uint32_t)wv * sq), c_hi = min(sc, (uint32_t)(wv + 1) * sq);
     uint64_t sk[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) { const uint32_t i = c_lo + u * 64 + lane; sk[u] = i < c_hi ? span_key[sb + i] : 0ull; }
+    for (int u = 0; u < 4; u++) { const uint32_t i = c_lo + u * 64 + lane; sk[u] = i < c_hi ? span_key[span_phys(SL, i)] : 0ull; }
     __syncthreads();
     if (j0 != FORMA_NONE) {
         for (uint32_t c = 0;; c += 256) {                              // a tile's runs are contiguous from j0
@@ -1352,7 +1503,7 @@ __device__ __forceinline__ void paint_tile(const uint32_t MAXE, const uint32_t S
         for (uint32_t c = c_lo; c < c_hi; c += 256) {
             if (c != c_lo) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) { const uint32_t i = c + u * 64 + lane; sk[u] = i < c_hi ? span_key[sb + i] : 0ull; }
+                for (int u = 0; u < 4; u++) { const uint32_t i = c + u * 64 + lane; sk[u] = i < c_hi ? span_key[span_phys(SL, i)] : 0ull; }
             }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -1361,7 +1512,7 @@ __device__ __forceinline__ void paint_tile(const uint32_t MAXE, const uint32_t S
                 const uint64_t bal = __ballot(hit);
                 if (hit) {
                     const uint32_t pos = cw + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    if (pos < (uint32_t)STAGE) e_key[(size_t)wv * STAGE + pos] = (sk[u] & 0xFFFFFFFF00000000ull) | REF_SPAN | (((uint32_t)sk[u] >> 31) ? REF_UNCH : 0u) | (sb + c + u * 64 + lane);
+                    if (pos < (uint32_t)STAGE) e_key[(size_t)wv * STAGE + pos] = (sk[u] & 0xFFFFFFFF00000000ull) | REF_SPAN | (((uint32_t)sk[u] >> 31) ? REF_UNCH : 0u) | span_phys(SL, c + u * 64 + lane);
                 }
                 cw += (uint32_t)__popcll(bal);
             }
@@ -1749,11 +1900,12 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
     // ---- the tile's layer list: own runs (contiguous records, ascending layer) + the row's spans that cross it --------
     const uint32_t my_tile_key = ((ty + 1u) << 12) | (tx + 1u);
     const uint32_t j0 = tile_first_run[tile] - 1u;                      // 0 stored = no run -> FORMA_NONE
-    const uint32_t sb = row_span_lo[ty], sc = row_span_cnt[ty];
+    const SpanLists SL = load_span_lists(row_span_lo, row_span_cnt, ty, P.n_slices);
+    const uint32_t sc = SL.total;
     if (plan_bad) return;
     uint64_t sk[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) { const uint32_t i = u * 64 + lane; sk[u] = i < sc ? span_key[sb + i] : 0ull; }
+    for (int u = 0; u < 4; u++) { const uint32_t i = u * 64 + lane; sk[u] = i < sc ? span_key[span_phys(SL, i)] : 0ull; }
     uint32_t na = 0;
     if (j0 != FORMA_NONE) {
         for (uint32_t c = 0;; c += 64) {                                // a tile's runs are contiguous from j0
@@ -1770,7 +1922,7 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
     for (uint32_t c = 0; c < sc; c += 256) {
         if (c) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const uint32_t i = c + u * 64 + lane; sk[u] = i < sc ? span_key[sb + i] : 0ull; }
+            for (int u = 0; u < 4; u++) { const uint32_t i = c + u * 64 + lane; sk[u] = i < sc ? span_key[span_phys(SL, i)] : 0ull; }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -1779,7 +1931,7 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
             const uint64_t bal = __ballot(hit);
             if (hit) {
                 const uint32_t pos = na + nb + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                if (pos < WMAX) tmp[pos] = (sk[u] & 0xFFFFFFFF00000000ull) | REF_SPAN | (((uint32_t)sk[u] >> 31) ? REF_UNCH : 0u) | (sb + c + u * 64 + lane);
+                if (pos < WMAX) tmp[pos] = (sk[u] & 0xFFFFFFFF00000000ull) | REF_SPAN | (((uint32_t)sk[u] >> 31) ? REF_UNCH : 0u) | span_phys(SL, c + u * 64 + lane);
             }
             nb += (uint32_t)__popcll(bal);
         }

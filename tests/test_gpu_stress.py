@@ -108,3 +108,32 @@ def test_layers_cut_by_the_bottom_edge_in_a_partial_last_tile_row():
             assert np.array_equal(bo, bc), frame
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("slices,global_sort", [(2, False), (3, False), (8, False), (2, True), (5, True)])
+def test_carry_pre_pass_with_several_workgroups_per_tile_row(slices, global_sort, monkeypatch):
+    """k_carry_rows shares a tile row between `slices` workgroups, each a range of layers (single GPU: by itself only when
+    the rows are few; a multi-GPU band: always).  FORMA_HIP_CARRY_SLICES forces the count: every count, both run orders
+    (in-LDS sort of a slice / cut of the globally sorted keys), the same bits as the oracle — frames 1 (synchronous) to 3."""
+    import forma_amd
+    monkeypatch.setenv("FORMA_HIP_CARRY_SLICES", str(slices))
+    if global_sort:
+        monkeypatch.setenv("FORMA_HIP_GLOBAL_RUNSORT", "1")
+    for seed, n, W, H in ((31, 400, 640, 480), (32, 2500, 2048, 64), (33, 150, 100, 700)):
+        comp = S.random_mixed(n=n, width=W, height=H, seed=seed)
+        o = orc.Oracle()
+        t = comp.tables(o)
+        S.load(o, t)
+        want = o.render(W, H, clear=(0.3, 0.2, 0.1, 1.0))
+        c = forma_amd.Context(0)
+        try:
+            S.load(c, t)
+            for frame in range(3):
+                got = c.render(W, H, clear=(0.3, 0.2, 0.1, 1.0))
+                assert np.array_equal(got, want), (seed, slices, frame)
+            bo, bc = np.zeros((H, W * 4), np.uint8), np.zeros((H, W * 4), np.uint8)
+            for frame in range(2):
+                o.render(W, H, cache_id=0, dst=bo); c.render(W, H, cache_id=0, dst=bc)
+                assert np.array_equal(bo, bc), (seed, slices, frame)
+        finally:
+            c.close()

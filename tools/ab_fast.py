@@ -33,6 +33,13 @@ def child(args):
     c.set_geometry(t["x"], t["y"], t["line_slot"]); c.set_geoms(t["geoms"])
     c.set_styles(t["style_offsets"], t["style_words"], None); c.set_images(t["images"], t["texels"])
     clear = (1.0, 1.0, 1.0, 1.0)
+    crop = None
+    if os.environ.get("AB_BAND"):                         # "r0,r1": a multi-GPU band on one GPU (foreign segments culled, band painted)
+        r0, r1 = (int(v) for v in os.environ["AB_BAND"].split(","))
+        c.set_band(r0, r1)
+        crop = (0, W, r0 * 16, min(r1 * 16, H))
+    _render = c.render
+    c.render = lambda *a, **k: _render(*a, crop=crop, **k)
     for _ in range(4):
         c.render(W, H, clear=clear, device_only=True)
     acc = {}
