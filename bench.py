@@ -434,7 +434,12 @@ def main():
         else:
             out["second_workload"] = {"error": o2.get("error", "failed on another rank")}
     if rank == 0:
-        print(json.dumps(out))
+        try:                                                          # RCCL prints a version banner through C stdio when a communicator is
+            import ctypes                                             # created: flush it BEFORE the line, so that the JSON is the last line
+            ctypes.CDLL(None).fflush(None)
+        except Exception:                                             # noqa: BLE001
+            pass
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
