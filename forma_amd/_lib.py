@@ -87,7 +87,7 @@ SYMBOLS = {
     "forma_hip_sort_paint_frame": (_i, [_vp, _sz, _vp, _u32, _u32, _sz, _vp, _vp, _vp, _vp]),
     "forma_hip_stream": (_i, [_vp, _vp]),
     "forma_hip_exchange_plan": (_i, [_vp, _vp, _u32, _u32]),
-    "forma_hip_exchange_buffers": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "forma_hip_exchange_buffers": (_i, [_vp, _vp, _vp, _vp]),
     "forma_hip_rasterize_bucket_frame": (_i, [_vp, _u32, _u32, _vp]),
     "forma_hip_gather_sort_paint_frame": (_i, [_vp, _vp, _u32, _u32, _sz, _vp, _vp, _vp, _vp]),
 }

@@ -222,12 +222,12 @@ class Context:
         self._xplan = (len(e) - 1, int(pair_capacity))
 
     def exchange_views(self):
-        """torch views (no copies) of the send / receive buckets (int64, n_ranks * capacity) and their counts (int32, 2 per rank)"""
-        n, cap = self._xplan
-        ps, pc, pr, prc = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
-        self._check(self._L.forma_hip_exchange_buffers(self._h, C.byref(ps), C.byref(pc), C.byref(pr), C.byref(prc)))
-        return (self.device_view(ps.value, n * cap), self._device_view_i32(pc.value, 2 * n),
-                self.device_view(pr.value, n * cap), self._device_view_i32(prc.value, 2 * n))
+        """torch views (no copies) of the send / receive buckets (int64, n_ranks * words_per_pair: a bucket is pair_capacity
+        segments + its header word {count | overflow << 32}) and words_per_pair"""
+        n, _cap = self._xplan
+        ps, pr, w = C.c_void_p(), C.c_void_p(), C.c_size_t(0)
+        self._check(self._L.forma_hip_exchange_buffers(self._h, C.byref(ps), C.byref(pr), C.byref(w)))
+        return self.device_view(ps.value, n * w.value), self.device_view(pr.value, n * w.value), int(w.value)
 
     def _device_view_i32(self, ptr, n):
         import torch

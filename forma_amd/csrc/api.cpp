@@ -597,7 +597,7 @@ void forma_hip_destroy(forma_hip_ctx* ctx) {
                      &ctx->block_first, &ctx->prep_scratch, &ctx->seg_u, &ctx->seg_a, &ctx->seg_b,
                      &ctx->sort_counters, &ctx->info, &ctx->info_init, &ctx->records, &ctx->rk_u, &ctx->rk_a, &ctx->rk_b,
                      &ctx->blk_edge, &ctx->runs_scratch, &ctx->row_tab, &ctx->span_key, &ctx->span_cov,
-                     &ctx->image, &ctx->xsend, &ctx->xrecv, &ctx->xsend_counts, &ctx->xrecv_counts, &ctx->xscratch,
+                     &ctx->image, &ctx->xsend, &ctx->xrecv, &ctx->xscratch,
                      &ctx->ras_masks, &ctx->xmask, &ctx->huge_offs, &ctx->huge_key, &ctx->huge_tmp, &ctx->huge_flag};
     for (DevBuf* b : all) b->release();
     for (int s = 0; s < ST_COUNT; s++) { (void)hipEventDestroy(ctx->ev0[s]); (void)hipEventDestroy(ctx->ev1[s]); }
@@ -1252,25 +1252,23 @@ int forma_hip_exchange_plan(forma_hip_ctx* ctx, const uint32_t* row_edges, uint3
     ctx->xbands.n = n_ranks;
     for (uint32_t g = 0; g <= n_ranks; g++) ctx->xbands.edge[g] = row_edges[g];
     ctx->xcap = pair_capacity;
-    const size_t words = (size_t)n_ranks * pair_capacity;
+    const size_t words = (size_t)n_ranks * ((size_t)pair_capacity + 1);    // a bucket = pair_capacity data words + its header
     HIPCHECK(ctx->xsend.ensure((words + SEG_PAD) * 8));
     HIPCHECK(ctx->xrecv.ensure((words + SEG_PAD) * 8));
-    HIPCHECK(ctx->xsend_counts.ensure(FORMA_MAX_RANKS * 8));
-    HIPCHECK(ctx->xrecv_counts.ensure(FORMA_MAX_RANKS * 8));
-    HIPCHECK(hipMemsetAsync(ctx->xsend_counts.p, 0, FORMA_MAX_RANKS * 8, ctx->stream));
-    HIPCHECK(hipMemsetAsync(ctx->xrecv_counts.p, 0, FORMA_MAX_RANKS * 8, ctx->stream));
+    HIPCHECK(hipMemsetAsync(ctx->xsend.p, 0, (words + SEG_PAD) * 8, ctx->stream));      // (headers included: empty buckets until the first frame)
+    HIPCHECK(hipMemsetAsync(ctx->xrecv.p, 0, (words + SEG_PAD) * 8, ctx->stream));
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     ctx->xplanned = true;
     ctx->pred_valid = false; ctx->pred_counts_valid = false; ctx->xpred_valid = false;
     return FORMA_OK;
 }
 
-int forma_hip_exchange_buffers(forma_hip_ctx* ctx, uint64_t** send, uint32_t** send_counts, uint64_t** recv, uint32_t** recv_counts) {
-    if (!ctx || !send || !send_counts || !recv || !recv_counts) return FORMA_E_ARG;
+int forma_hip_exchange_buffers(forma_hip_ctx* ctx, uint64_t** send, uint64_t** recv, size_t* words_per_pair) {
+    if (!ctx || !send || !recv || !words_per_pair) return FORMA_E_ARG;
     ENTER_SINGLE(ctx);
     if (!ctx->xplanned) return fail(ctx, FORMA_E_STATE, "forma_hip_exchange_plan first");
-    *send = ctx->xsend.as<uint64_t>(); *send_counts = ctx->xsend_counts.as<uint32_t>();
-    *recv = ctx->xrecv.as<uint64_t>(); *recv_counts = ctx->xrecv_counts.as<uint32_t>();
+    *send = ctx->xsend.as<uint64_t>(); *recv = ctx->xrecv.as<uint64_t>();
+    *words_per_pair = (size_t)ctx->xcap + 1;
     return FORMA_OK;
 }
 
@@ -1301,7 +1299,7 @@ int forma_hip_rasterize_bucket_frame(forma_hip_ctx* ctx, uint32_t width, uint32_
     HIPCHECK(ctx->xscratch.ensure(owner_scratch_words(std::max<size_t>(nc.bound, 1)) * 4));
     stage_begin(ctx, ST_XCHG, timing);
     launch_owner_bucket(ctx->stream, ctx->seg_u.as<uint64_t>(), nc, ctx->xbands, ctx->xcap, ctx->xscratch.as<uint32_t>(),
-                        ctx->xsend.as<uint64_t>(), ctx->xsend_counts.as<uint32_t>(), dinfo);
+                        ctx->xsend.as<uint64_t>(), dinfo);
     stage_end(ctx, ST_XCHG, timing);
     HIPCHECK(hipGetLastError());
     if (bN) {
@@ -1342,7 +1340,6 @@ int fd_gather_sort_paint(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint3
     // (xuse_recv: a collective did run with a world of one — the RCCL rehearsal of a multi-device context on one GPU)
     const bool self = G == 1 && !ctx->xuse_recv;
     const uint64_t* recv = self ? ctx->xsend.as<uint64_t>() : ctx->xrecv.as<uint64_t>();
-    const uint32_t* rcnt = self ? ctx->xsend_counts.as<uint32_t>() : ctx->xrecv_counts.as<uint32_t>();
     FrameInfo* dinfo = ctx->info.as<FrameInfo>();
     PaintArgs a{width, height, channels, clear_color, crop_or_null, cache_id};
     HIPCHECK(ctx->seg_u.ensure(((size_t)bound + SEG_PAD) * 8));
@@ -1351,7 +1348,7 @@ int fd_gather_sort_paint(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint3
         int r = reset_info(ctx);
         if (r) return r;
         stage_begin(ctx, ST_XCHG, timing);
-        launch_gather_chunks(ctx->stream, recv, rcnt, G, ctx->xcap, ctx->seg_u.as<uint64_t>(), dinfo, ctx->xmask.as<uint32_t>(),
+        launch_gather_chunks(ctx->stream, recv, G, ctx->xcap, ctx->seg_u.as<uint64_t>(), dinfo, ctx->xmask.as<uint32_t>(),
                              /*reduce_now=*/!read_back_free);
         ctx->pending_masks = read_back_free ? PendingMasks{ctx->xmask.as<uint32_t>(), (uint32_t)(gather_mask_words(G, ctx->xcap) / 8)}
                                             : PendingMasks{nullptr, 0u};
@@ -1370,7 +1367,7 @@ int fd_gather_sort_paint(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint3
         if (!ctx->xgather_always && live != 0 && bound > 1) {
             if ((rc = reset_info(ctx))) return rc;
             ctx->have_unsorted = false; ctx->n_lines = 0;
-            const ChunkedSrc C{rcnt, G, ctx->xcap, ctx->xmask.as<uint32_t>()};
+            const ChunkedSrc C{recv, G, ctx->xcap, ctx->xmask.as<uint32_t>()};
             if ((rc = run_sort(ctx, recv, DevCount{&dinfo->n_segments, bound}, timing, 0, &C))) return rc;
             ctx->pending_masks = PendingMasks{ctx->xmask.as<uint32_t>(), sort_hist_blocks(bound)};
         } else {

@@ -148,11 +148,11 @@ size_t sort_scratch_words(size_t n);
 // `in` is read-only (preserved), a/b are ping-pong buffers; returns the buffer holding the result (== in when the
 // plan is empty).  scratch: >= sort_scratch_words(n) u32.  err: device word, bit 2 set if a look-back spin expired.
 // Multi-GPU exchange: the stream to sort is NOT contiguous — it is the rank-major concatenation of the n_chunks received
-// buckets, bucket q at in[q * capacity .. + min(counts[2 q], capacity)) (counts[2 q + 1] != 0: that sender overflowed).
+// buckets, bucket q at in[q * (capacity + 1) .. + count_q), its header {count_q | sender overflowed << 32} at + capacity.
 // k_sort_hist and the first digit pass read it in place (logical index -> bucket by <= 7 compares), which removes the
 // gather kernel; k_sort_hist also publishes the total (info->n_segments), the overflow flag and, per workgroup, the key
 // masks / layer-order bit the sort plan is verified with (mask_records, 8 words each: PendingMasks).  n_chunks == 0: plain.
-struct ChunkedSrc { const uint32_t* counts; uint32_t n_chunks; uint32_t capacity; uint32_t* mask_records; };
+struct ChunkedSrc { const uint64_t* buckets; uint32_t n_chunks; uint32_t capacity; uint32_t* mask_records; };
 uint32_t sort_hist_blocks(size_t n);           // grid of k_sort_hist for n keys = number of mask records it writes
 const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a, uint64_t* b, DevCount n,
                                   const SortPlan& plan, int digit_bits, uint32_t* scratch, uint32_t* err,
@@ -163,13 +163,13 @@ const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a
 #define FORMA_MAX_RANKS 8
 struct OwnerBands { uint32_t n; uint32_t edge[FORMA_MAX_RANKS + 1]; };   // rank g owns tile rows [edge[g], edge[g + 1])
 size_t owner_scratch_words(size_t n);
-// stable partition of seg[0 .. n) into send[g * capacity + ...]; send_counts[2 g] = segments for rank g, [2 g + 1] = overflow flag
+// stable partition of seg[0 .. n) into send[g * (capacity + 1) + ...]; bucket header at + capacity: segments for rank g | overflow << 32
 void launch_owner_bucket(hipStream_t s, const uint64_t* seg, DevCount n, const OwnerBands& B, uint32_t capacity,
-                         uint32_t* scratch, uint64_t* send, uint32_t* send_counts, FrameInfo* info);
+                         uint32_t* scratch, uint64_t* send, FrameInfo* info);
 void launch_row_histogram(hipStream_t s, const uint64_t* seg, DevCount n, uint32_t* hist /* 2048 words */);
-// recv[s * capacity + ...] (recv_counts[2 s] segments from rank s) -> out, info->{n_segments, key masks, layer_unsorted}
+// recv[s * (capacity + 1) + ...] (count in the bucket's header) -> out, info->{n_segments, key masks, layer_unsorted}
 size_t gather_mask_words(uint32_t n_ranks, uint32_t capacity);
-void launch_gather_chunks(hipStream_t s, const uint64_t* recv, const uint32_t* recv_counts, uint32_t n_ranks, uint32_t capacity,
+void launch_gather_chunks(hipStream_t s, const uint64_t* recv, uint32_t n_ranks, uint32_t capacity,
                           uint64_t* out, FrameInfo* info, uint32_t* mask_records /* gather_mask_words() */, bool reduce_now);
 
 // paint.hip

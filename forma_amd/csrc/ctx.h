@@ -131,7 +131,7 @@ struct forma_hip_ctx {
     OwnerBands xbands{};
     uint32_t xcap = 0;
     bool xplanned = false;
-    DevBuf xsend, xrecv, xsend_counts, xrecv_counts, xscratch, xmask;
+    DevBuf xsend, xrecv, xscratch, xmask;         // buckets: n_ranks x (xcap data words + 1 header word {count | overflow << 32})
     bool xuse_recv = false;                   // one rank, but a collective DID run (RCCL rehearsal): the buckets are in xrecv
     bool xgather_always = false;              // FORMA_HIP_XGATHER=1: materialise the received stream before sorting it
     bool xpred_valid = false;               // the local rasterized count of the previous exchange frame is known

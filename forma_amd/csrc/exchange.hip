@@ -10,8 +10,11 @@
 //   k_owner_count   : per 2048-segment block, segments per owner                       (1 read of the stream; counting
 //                     inside the rasterizer instead — two ballots per 64 segments in the common one-owner case — was
 //                     measured: rasterizer +65 us for the 29 us this kernel takes, dropped)
-//   k_owner_scan    : per owner, exclusive scan of the block counts; totals -> the counts the ranks exchange
-//   k_owner_scatter : stable scatter into the send buffer, bucket g at [g * C, g * C + count_g)
+//   k_owner_scan    : per owner, exclusive scan of the block counts; totals -> the bucket HEADERS the ranks exchange with the data
+//   k_owner_scatter : stable scatter into the send buffer, bucket g at [g * (C + 1), g * (C + 1) + count_g)
+// A bucket is C data words + ONE header word {count: 32 | sender overflowed: bit 32} at index C, so that ONE equal-split
+// all-to-all of (C + 1) words per pair moves everything (round 2 exchanged the counts in a collective of their own: a second
+// RCCL launch per frame, ~70 us with a world of one).
 //   k_gather_chunks : received buckets (rank-major = global line order) -> one contiguous stream, its length, the
 //                     varying-bit masks of its keys and whether it is non-decreasing in layer (what the sort plan needs)
 #include "common.h"
@@ -69,7 +72,10 @@ __global__ __launch_bounds__(XB_THREADS) void k_owner_count(const uint64_t* __re
 #define XS_PER 8
 __global__ __launch_bounds__(1024) void k_owner_scan(uint32_t* __restrict__ block_counts, DevCount nc, uint32_t nblocks_cap,
                                                      uint32_t n_owners /* n + 1 */, uint32_t capacity,
-                                                     uint32_t* __restrict__ send_counts /* [n][2], zeroed */, FrameInfo* __restrict__ info) {
+                                                     uint64_t* __restrict__ send /* headers at [g (capacity + 1) + capacity], zeroed */,
+                                                     FrameInfo* __restrict__ info) {
+    const size_t stride = (size_t)capacity + 1;
+    unsigned long long* hdr = reinterpret_cast<unsigned long long*>(send);
     __shared__ uint32_t lds[17];
     const uint32_t nb = (dev_count(nc) + XB_TILE - 1) / XB_TILE;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -97,14 +103,16 @@ __global__ __launch_bounds__(1024) void k_owner_scan(uint32_t* __restrict__ bloc
         carry += tot;
         __syncthreads();
     }
+    // (headers are zeroed before the launch and only ever OR-ed into: the count of bucket g by workgroup g, the overflow bit of
+    //  every bucket by whichever workgroup finds an excess)
     if (threadIdx.x == 0 && g == 0 && nc.ptr && *nc.ptr > nc.bound) {     // read-back-free frame: more local segments than were
-        for (uint32_t t = 0; t + 1 < n_owners; t++) atomicOr(&send_counts[2 * t + 1], 1u);   // provisioned — the excess was never
+        for (uint32_t t = 0; t + 1 < n_owners; t++) atomicOr(&hdr[t * stride + capacity], 1ull << 32);   // provisioned — the excess was never
         info->exchange_overflow = 1u;                                    // rasterized: every receiver fails the frame, the host re-plans
     }
     if (threadIdx.x == 0 && g + 1 < n_owners) {                          // (the last owner is the dropped bucket)
-        send_counts[2 * g] = carry < capacity ? carry : capacity;
+        atomicOr(&hdr[g * stride + capacity], (unsigned long long)(carry < capacity ? carry : capacity));
         if (carry > capacity) {                                          // every receiver learns that this sender overflowed
-            for (uint32_t t = 0; t + 1 < n_owners; t++) atomicOr(&send_counts[2 * t + 1], 1u);
+            for (uint32_t t = 0; t + 1 < n_owners; t++) atomicOr(&hdr[t * stride + capacity], 1ull << 32);
             info->exchange_overflow = 1u;
         }
     }
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(1024) void k_owner_scan(uint32_t* __restrict__ bloc
 
 __global__ __launch_bounds__(XB_THREADS) void k_owner_scatter(const uint64_t* __restrict__ seg, DevCount nc, OwnerBands B,
                                                               const uint32_t* __restrict__ block_offs, uint32_t nblocks_cap,
-                                                              uint32_t capacity, uint64_t* __restrict__ send /* [n][capacity] */) {
+                                                              uint32_t capacity, uint64_t* __restrict__ send /* [n][capacity + 1] */) {
     __shared__ uint32_t s_c[XB_WAVES][FORMA_MAX_RANKS + 1];
     const uint32_t n = dev_count(nc);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -159,7 +167,7 @@ __global__ __launch_bounds__(XB_THREADS) void k_owner_scatter(const uint64_t* __
                 const uint64_t bg = __ballot(o == (uint32_t)g);
                 if (o == (uint32_t)g) {
                     const uint32_t pos = run[g] + (uint32_t)__popcll(bg & lt);
-                    if (pos < capacity) send[(size_t)g * capacity + pos] = v[j];
+                    if (pos < capacity) send[(size_t)g * ((size_t)capacity + 1) + pos] = v[j];
                 }
                 run[g] += (uint32_t)__popcll(bg);
             }
@@ -167,25 +175,28 @@ __global__ __launch_bounds__(XB_THREADS) void k_owner_scatter(const uint64_t* __
     }
 }
 
-// received buckets (chunk s = what rank s sent: [s * capacity, + counts[2 s])), rank-major, -> out[0 .. N_r).
+// received buckets (chunk s = what rank s sent: [s * (capacity + 1), + count_s), header at + capacity), rank-major, -> out[0 .. N_r).
 // blockIdx.y = chunk: every workgroup copies a contiguous piece of ONE chunk (coalesced 8-byte loads and stores).
-__global__ __launch_bounds__(256) void k_gather_chunks(const uint64_t* __restrict__ recv, const uint32_t* __restrict__ recv_counts,
+__global__ __launch_bounds__(256) void k_gather_chunks(const uint64_t* __restrict__ recv,
                                                        uint32_t n_ranks, uint32_t capacity, uint64_t* __restrict__ out,
                                                        FrameInfo* __restrict__ info, uint32_t* __restrict__ mask_records) {
     __shared__ uint32_t red[5][4];
     const uint32_t s = blockIdx.y;
     uint32_t start = 0, total = 0, over = 0, prev_chunk = 0xFFFFFFFFu, prev_cnt = 0;
+    const size_t stride = (size_t)capacity + 1;
+    uint32_t cnt_s = 0;
     for (uint32_t q = 0; q < n_ranks; q++) {                            // (uniform: <= 8 scalar loads)
-        const uint32_t c0 = recv_counts[2 * q];
-        over |= recv_counts[2 * q + 1] | (c0 > capacity ? 1u : 0u);
+        const uint64_t h = recv[q * stride + capacity];
+        const uint32_t c0 = (uint32_t)h;
+        if (q == s) cnt_s = c0;
+        over |= (uint32_t)(h >> 32) | (c0 > capacity ? 1u : 0u);
         const uint32_t c = c0 < capacity ? c0 : capacity;
         if (q < s) { start += c; if (c) { prev_chunk = q; prev_cnt = c; } }
         total += c;
     }
-    const uint32_t cnt0 = recv_counts[2 * s];
-    const uint32_t cnt = cnt0 < capacity ? cnt0 : capacity;
+    const uint32_t cnt = cnt_s < capacity ? cnt_s : capacity;
     if (blockIdx.x == 0 && s == 0 && threadIdx.x == 0) { info->n_segments = total; if (over) info->exchange_overflow = 1u; }
-    const uint64_t* src = recv + (size_t)s * capacity;
+    const uint64_t* src = recv + (size_t)s * stride;
     uint32_t k_or = 0, k_or_hi = 0, k_and = 0xFFFFFFFFu, k_and_hi = 0xFFFFFFFFu, unsorted = 0;
     for (uint32_t k0 = blockIdx.x * 1024; k0 < cnt; k0 += gridDim.x * 1024) {
         uint64_t v[4], pv[4];
@@ -205,7 +216,7 @@ __global__ __launch_bounds__(256) void k_gather_chunks(const uint64_t* __restric
                 const uint32_t klo = (uint32_t)(v[j] >> 20), khi = (uint32_t)(v[j] >> 52);
                 k_or |= klo; k_or_hi |= khi; k_and &= klo; k_and_hi &= khi;
                 uint64_t p = pv[j];
-                if (k == 0) p = prev_chunk != 0xFFFFFFFFu ? recv[(size_t)prev_chunk * capacity + prev_cnt - 1] : v[j];
+                if (k == 0) p = prev_chunk != 0xFFFFFFFFu ? recv[(size_t)prev_chunk * stride + prev_cnt - 1] : v[j];
                 if (seg_layer(p) > seg_layer(v[j])) unsorted = 1;       // is the gathered stream non-decreasing in layer?
             }
         }
@@ -283,13 +294,14 @@ void launch_row_histogram(hipStream_t s, const uint64_t* seg, DevCount n, uint32
 size_t owner_scratch_words(size_t n) { return (size_t)(FORMA_MAX_RANKS + 1) * ((n + XB_TILE - 1) / XB_TILE + 1); }
 
 void launch_owner_bucket(hipStream_t s, const uint64_t* seg, DevCount nc, const OwnerBands& B, uint32_t capacity,
-                         uint32_t* scratch, uint64_t* send, uint32_t* send_counts, FrameInfo* info) {
+                         uint32_t* scratch, uint64_t* send, FrameInfo* info) {
     const uint32_t nblocks = (uint32_t)((nc.bound + XB_TILE - 1) / XB_TILE);
     const uint32_t cap = nblocks + 1;
-    (void)hipMemsetAsync(send_counts, 0, (size_t)FORMA_MAX_RANKS * 8, s);
+    // the B.n bucket headers (one word each, (capacity + 1) words apart) start from zero
+    (void)hipMemset2DAsync(send + capacity, ((size_t)capacity + 1) * 8, 0, 8, B.n, s);
     if (nblocks == 0) return;
     hipLaunchKernelGGL(k_owner_count, dim3(nblocks), dim3(XB_THREADS), 0, s, seg, nc, B, scratch, cap);
-    hipLaunchKernelGGL(k_owner_scan, dim3(B.n + 1), dim3(1024), 0, s, scratch, nc, cap, B.n + 1, capacity, send_counts, info);
+    hipLaunchKernelGGL(k_owner_scan, dim3(B.n + 1), dim3(1024), 0, s, scratch, nc, cap, B.n + 1, capacity, send, info);
     hipLaunchKernelGGL(k_owner_scatter, dim3(nblocks), dim3(XB_THREADS), 0, s, seg, nc, B, (const uint32_t*)scratch, cap, capacity, send);
 }
 
@@ -300,11 +312,11 @@ size_t gather_mask_words(uint32_t n_ranks, uint32_t capacity) {
     return (size_t)gx * n_ranks * 8;
 }
 
-void launch_gather_chunks(hipStream_t s, const uint64_t* recv, const uint32_t* recv_counts, uint32_t n_ranks, uint32_t capacity,
+void launch_gather_chunks(hipStream_t s, const uint64_t* recv, uint32_t n_ranks, uint32_t capacity,
                           uint64_t* out, FrameInfo* info, uint32_t* mask_records, bool reduce_now) {
     uint32_t gx = (capacity + 1023) / 1024;
     if (gx > 2048) gx = 2048;
     if (gx == 0) gx = 1;
-    hipLaunchKernelGGL(k_gather_chunks, dim3(gx, n_ranks), dim3(256), 0, s, recv, recv_counts, n_ranks, capacity, out, info, mask_records);
+    hipLaunchKernelGGL(k_gather_chunks, dim3(gx, n_ranks), dim3(256), 0, s, recv, n_ranks, capacity, out, info, mask_records);
     if (reduce_now) hipLaunchKernelGGL(k_reduce_gather_masks, dim3(1), dim3(1024), 0, s, (const uint32_t*)mask_records, gx * n_ranks, info);
 }

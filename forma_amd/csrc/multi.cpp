@@ -246,15 +246,15 @@ void device_frame(MultiState* M, int g) {
     for (int r = 0; r < G; r++) ok = ok && M->rc_stage[r] == FORMA_OK;
     if (ok && M->use_rccl) {
         // The canonical single-process form: ONE thread issues the collective for every communicator inside a group, each
-        // on its device's stream, behind the bucket kernels already enqueued there.  Equal splits (the pair capacity): no
-        // count has to reach the host before the exchange can be enqueued; the {count, overflow} pairs travel alongside.
+        // on its device's stream, behind the bucket kernels already enqueued there.  Equal splits (the pair capacity + the
+        // bucket's header word {count, overflow}): no count has to reach the host before the exchange can be enqueued, and
+        // ONE collective per frame moves everything.
         if (g == 0) {
             RcclApi* R = rccl_api();
             ncclResult_t r = R->GroupStart();
             for (int q = 0; q < G && r == ncclSuccess; q++) {
                 forma_hip_ctx* k = M->kid[q];
-                r = R->AllToAll(k->xsend_counts.p, k->xrecv_counts.p, 2, ncclUint32, M->comm[q], k->stream);
-                if (r == ncclSuccess) r = R->AllToAll(k->xsend.p, k->xrecv.p, M->cap, ncclUint64, M->comm[q], k->stream);
+                r = R->AllToAll(k->xsend.p, k->xrecv.p, (size_t)M->cap + 1, ncclUint64, M->comm[q], k->stream);   // data + header of every bucket
             }
             const ncclResult_t e = R->GroupEnd();
             if (r == ncclSuccess) r = e;
@@ -272,19 +272,15 @@ void device_frame(MultiState* M, int g) {
         for (int s = 0; s < G && rc == FORMA_OK; s++) {
             forma_hip_ctx* src = M->kid[s];
             if (hipStreamWaitEvent(kid->stream, M->ev_bucket[s], 0) != hipSuccess) { rc = fd_fail(kid, FORMA_E_HIP, "hipStreamWaitEvent"); break; }
-            hipError_t e1, e2;
-            if (M->dev[s] == M->dev[g]) {
-                e1 = hipMemcpyAsync(kid->xrecv.as<uint64_t>() + (size_t)s * M->cap, src->xsend.as<uint64_t>() + (size_t)g * M->cap,
-                                    (size_t)M->cap * 8, hipMemcpyDeviceToDevice, kid->stream);
-                e2 = hipMemcpyAsync(kid->xrecv_counts.as<uint32_t>() + 2 * s, src->xsend_counts.as<uint32_t>() + 2 * g, 8,
+            const size_t W = (size_t)M->cap + 1;          // a bucket: data + header
+            hipError_t e1;
+            if (M->dev[s] == M->dev[g])
+                e1 = hipMemcpyAsync(kid->xrecv.as<uint64_t>() + (size_t)s * W, src->xsend.as<uint64_t>() + (size_t)g * W, W * 8,
                                     hipMemcpyDeviceToDevice, kid->stream);
-            } else {
-                e1 = hipMemcpyPeerAsync(kid->xrecv.as<uint64_t>() + (size_t)s * M->cap, M->dev[g],
-                                        src->xsend.as<uint64_t>() + (size_t)g * M->cap, M->dev[s], (size_t)M->cap * 8, kid->stream);
-                e2 = hipMemcpyPeerAsync(kid->xrecv_counts.as<uint32_t>() + 2 * s, M->dev[g], src->xsend_counts.as<uint32_t>() + 2 * g,
-                                        M->dev[s], 8, kid->stream);
-            }
-            if (e1 != hipSuccess || e2 != hipSuccess) rc = fd_fail(kid, FORMA_E_HIP, "bucket copy", e1 != hipSuccess ? e1 : e2);
+            else
+                e1 = hipMemcpyPeerAsync(kid->xrecv.as<uint64_t>() + (size_t)s * W, M->dev[g], src->xsend.as<uint64_t>() + (size_t)g * W,
+                                        M->dev[s], W * 8, kid->stream);
+            if (e1 != hipSuccess) rc = fd_fail(kid, FORMA_E_HIP, "bucket copy", e1);
         }
         ok = rc == FORMA_OK;
     }

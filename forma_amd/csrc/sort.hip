@@ -55,12 +55,13 @@ __device__ __forceinline__ ChunkMap load_chunk_map(const ChunkedSrc& C, uint32_t
     for (int q = 0; q < FORMA_MAX_RANKS; q++) {                          // (uniform: <= 8 scalar loads)
         uint32_t c = 0;
         if (q < (int)C.n_chunks) {
-            const uint32_t c0 = C.counts[2 * q];
-            M.over |= C.counts[2 * q + 1] | (c0 > C.capacity ? 1u : 0u);
+            const uint64_t h = C.buckets[(size_t)q * ((size_t)C.capacity + 1) + C.capacity];   // bucket header {count | overflow << 32}
+            const uint32_t c0 = (uint32_t)h;
+            M.over |= (uint32_t)(h >> 32) | (c0 > C.capacity ? 1u : 0u);
             c = c0 < C.capacity ? c0 : C.capacity;
         }
         M.pre[q] = M.total;                                             // first logical index of bucket q
-        M.gap[q] = q ? C.capacity - prev : 0u;                          // unused slots between bucket q - 1's data and bucket q
+        M.gap[q] = q ? C.capacity + 1u - prev : 0u;                     // unused slots (and the header) between bucket q - 1's data and bucket q
         M.total += c; prev = c;
     }
     if (M.total > bound) M.total = bound;

@@ -119,23 +119,21 @@ class ExchangeFrame:
         self.width, self.height = width, height
         self.crop = band_crop(self.edges, rank, width, height)
         ctx.exchange_plan(self.edges, capacity)
-        self.send, self.send_counts, self.recv, self.recv_counts = ctx.exchange_views()
+        self.send, self.recv, self.words_per_pair = ctx.exchange_views()      # a bucket = capacity segments + its header word
         self.stream = torch.cuda.ExternalStream(ctx.stream_handle(), device=torch.device("cuda", ctx.device))
 
     def frame(self, channels=(0, 1, 2, 3), clear=(1, 1, 1, 1), dst=None, stride=None, timings=False, device_only=True):
         import torch
         t1 = self.ctx.rasterize_bucket_frame(self.width, self.height, timings=timings)
         if self.world > 1 and self.dist.get_backend() == "nccl":
-            with torch.cuda.stream(self.stream):                       # collectives ordered after the bucket kernels, before the gather
-                self.dist.all_to_all_single(self.recv_counts, self.send_counts)
-                self.dist.all_to_all_single(self.recv, self.send)
+            with torch.cuda.stream(self.stream):                       # ONE collective, ordered after the bucket kernels, before the gather
+                self.dist.all_to_all_single(self.recv, self.send)          # (equal splits of words_per_pair: the headers travel with the data)
         elif self.world > 1:                                           # rehearsal without RCCL (gloo): staged through host memory
             self.stream.synchronize()
-            for dst_t, src_t in ((self.recv_counts, self.send_counts), (self.recv, self.send)):
-                h_in, h_out = src_t.cpu(), torch.empty_like(src_t, device="cpu")
-                self.dist.all_to_all_single(h_out, h_in)
-                with torch.cuda.stream(self.stream):
-                    dst_t.copy_(h_out)
+            h_in, h_out = self.send.cpu(), torch.empty_like(self.send, device="cpu")
+            self.dist.all_to_all_single(h_out, h_in)
+            with torch.cuda.stream(self.stream):
+                self.recv.copy_(h_out)
             self.stream.synchronize()
         r = self.ctx.gather_sort_paint_frame(self.width, self.height, channels=channels, clear=clear, crop=self.crop, dst=dst,
                                              stride=stride, timings=timings, device_only=device_only)

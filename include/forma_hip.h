@@ -280,20 +280,20 @@ int forma_hip_sort_paint_frame(forma_hip_ctx* ctx, size_t n, uint8_t* dst, uint3
  * One process per GPU, every rank holds the layer / style tables and ITS contiguous share of the lines
  * (forma_hip_set_geometry with a slice).  Rank g owns the tile rows [row_edges[g], row_edges[g + 1]).  Per frame:
  *   1. forma_hip_rasterize_bucket_frame: stages 1-2 on the local lines, then a stable partition of the local pixel
- *      segments by owner into `send`: bucket g at send[g * pair_capacity], send_counts[2 g] segments (send_counts[2 g + 1]
- *      != 0: this sender overflowed the capacity — every receiver then fails the frame with FORMA_E_CAPACITY and the
- *      host re-plans with a larger capacity);
- *   2. the host language runs the collective on forma_hip_stream's stream: an equal-split all-to-all of the counts
- *      (2 words per pair) and of the payload (pair_capacity u64 per pair) from send / send_counts into recv / recv_counts
- *      — RCCL through torch.distributed in this repository; with one rank nothing is exchanged;
+ *      segments by owner into `send`.  A bucket is words_per_pair = pair_capacity + 1 u64: bucket g's segments at
+ *      send[g * words_per_pair ...], its header at send[g * words_per_pair + pair_capacity] = count | overflow << 32
+ *      (overflow: this sender exceeded the capacity, or rasterized more than a read-back-free frame provisioned — every
+ *      receiver then fails the frame with FORMA_E_CAPACITY and the host re-plans with a larger capacity);
+ *   2. the host language runs ONE collective on forma_hip_stream's stream: an equal-split all-to-all of words_per_pair
+ *      u64 per pair from send into recv (the headers travel with the data) — RCCL through torch.distributed in this
+ *      repository; with one rank nothing is exchanged;
  *   3. forma_hip_gather_sort_paint_frame: the received buckets, rank-major (= global line order, which keeps the sort
  *      bit-exact), become one stream; sort + paint of the band as in forma_hip_render (crop = the band).
  * No call waits for the device except the end of step 3 (and step 1 when timings are requested).                        */
 int forma_hip_stream(forma_hip_ctx* ctx, void** hip_stream);
 int forma_hip_exchange_plan(forma_hip_ctx* ctx, const uint32_t* row_edges /* n_ranks + 1 */, uint32_t n_ranks /* <= 8 */,
                             uint32_t pair_capacity);
-int forma_hip_exchange_buffers(forma_hip_ctx* ctx, uint64_t** send, uint32_t** send_counts, uint64_t** recv,
-                               uint32_t** recv_counts);
+int forma_hip_exchange_buffers(forma_hip_ctx* ctx, uint64_t** send, uint64_t** recv, size_t* words_per_pair);
 int forma_hip_rasterize_bucket_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, forma_timings_t* timings);
 int forma_hip_gather_sort_paint_frame(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t height,
                                       size_t stride_bytes, const uint8_t channels[4], const float clear_color[4],

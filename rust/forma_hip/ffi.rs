@@ -277,9 +277,8 @@ extern "C" {
     pub fn forma_hip_exchange_buffers(
         ctx: *mut forma_hip_ctx,
         send: *mut *mut u64,
-        send_counts: *mut *mut u32,
         recv: *mut *mut u64,
-        recv_counts: *mut *mut u32,
+        words_per_pair: *mut usize,
     ) -> c_int;
     pub fn forma_hip_rasterize_bucket_frame(
         ctx: *mut forma_hip_ctx,

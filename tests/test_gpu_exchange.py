@@ -61,10 +61,11 @@ def run_ranks(t, W, H, G, clear, frames=2, check=None, geoms_per_frame=None):
             x.ctx.rasterize_bucket_frame(W, H)
         torch.cuda.synchronize()
         for r, x in enumerate(xs):                                     # the all-to-all, by hand: recv[r][s] = send[s][r]
+            w = x.words_per_pair                                       # (a bucket: `cap` segments + its header word)
+            assert w == cap + 1
             for s, y in enumerate(xs):
                 if G > 1:
-                    x.recv[s * cap:(s + 1) * cap].copy_(y.send[r * cap:(r + 1) * cap])
-                    x.recv_counts[2 * s:2 * s + 2].copy_(y.send_counts[2 * r:2 * r + 2])
+                    x.recv[s * w:(s + 1) * w].copy_(y.send[r * w:(r + 1) * w])
         torch.cuda.synchronize()
         out = []
         for r, x in enumerate(xs):
@@ -306,15 +307,15 @@ def _rccl_world1_worker(rank, world, port, out_dir):
     assert sharding.max_over_ranks(dist, 1.5, device="cuda") == 1.5
     x = sharding.ExchangeFrame(c, dist, 0, 1, edges, W, H, sharding.pair_capacity(mx))
     c.rasterize_bucket_frame(W, H)
-    x.recv.zero_(); x.recv_counts.zero_()
+    x.recv.zero_()
     with torch.cuda.stream(x.stream):                                  # what ExchangeFrame.frame does when world > 1
-        dist.all_to_all_single(x.recv_counts, x.send_counts)
         dist.all_to_all_single(x.recv, x.send)
     x.stream.synchronize()
-    n = int(x.recv_counts[0].item())
+    hdr = int(x.recv[x.words_per_pair - 1].item())                     # the bucket's header: count | overflow << 32
+    n = hdr & 0xFFFFFFFF
     ty = (stream0 >> np.uint64(53)).astype(np.int64) - 1
     kept = stream0[(ty >= 0) & (ty < tiles_h)]
-    assert n == len(kept) and int(x.recv_counts[1].item()) == 0
+    assert n == len(kept) and (hdr >> 32) == 0
     assert np.array_equal(x.recv[:n].cpu().numpy().view(np.uint64), kept)     # the bucket arrived, in rasterizer order
     img = x.frame(clear=(1, 1, 1, 0), device_only=False, dst=np.zeros((H, W * 4), np.uint8))
     assert np.array_equal(img, want)

@@ -102,8 +102,8 @@ def test_line_shares_and_geometry_slices():
 
 
 def _padded_worker(rank, world, port, out_dir):
-    """The device-side exchange protocol (forma_hip_rasterize_bucket_frame -> equal-split all-to-all of counts and padded
-    buckets -> forma_hip_gather_sort_paint_frame) with the bucket / gather kernels restated in numpy: what crosses the
+    """The device-side exchange protocol (forma_hip_rasterize_bucket_frame -> ONE equal-split all-to-all of the padded
+    buckets, each carrying its header -> forma_hip_gather_sort_paint_frame) with the bucket / gather kernels restated in numpy: what crosses the
     collective, and in which layout, is exactly what sharding.ExchangeFrame moves over RCCL."""
     import sys
     import torch
@@ -138,16 +138,18 @@ def _padded_worker(rank, world, port, out_dir):
     ty = (mine >> np.uint64(53)).astype(np.int64) - 1
     owner = np.searchsorted(np.asarray(edges[1:-1], np.int64), ty, side="right")
     owner[(ty < edges[0]) | (ty >= edges[-1])] = world
-    send = np.zeros(world * cap, np.int64); counts = np.zeros(2 * world, np.int32)
+    w = cap + 1                                                         # a bucket: cap segments + its header word {count | overflow << 32}
+    send = np.zeros(world * w, np.int64)
     for g in range(world):
         b = mine[owner == g]
         assert len(b) <= cap
-        send[g * cap: g * cap + len(b)] = b.view(np.int64); counts[2 * g] = len(b)
-    recv = torch.zeros(world * cap, dtype=torch.int64); rc = torch.zeros(2 * world, dtype=torch.int32)
-    dist.all_to_all_single(rc, torch.from_numpy(counts))
-    dist.all_to_all_single(recv, torch.from_numpy(send))
+        send[g * w: g * w + len(b)] = b.view(np.int64); send[g * w + cap] = len(b)
+    recv = torch.zeros(world * w, dtype=torch.int64)
+    dist.all_to_all_single(recv, torch.from_numpy(send))                # ONE equal-split collective: the headers travel with the data
     # k_gather_chunks: rank-major concatenation of the valid prefix of every bucket
-    got = np.concatenate([recv.numpy()[s * cap: s * cap + int(rc[2 * s])] for s in range(world)]).view(np.uint64)
+    rn = recv.numpy()
+    assert all((int(rn[s * w + cap]) >> 32) == 0 for s in range(world))
+    got = np.concatenate([rn[s * w: s * w + (int(rn[s * w + cap]) & 0xFFFFFFFF)] for s in range(world)]).view(np.uint64)
     tyf = (full_stream >> np.uint64(53)).astype(np.int64) - 1
     want = full_stream[(tyf >= edges[rank]) & (tyf < edges[rank + 1])]
     assert np.array_equal(got, want)                                   # the band's slice of the single-device stream, same order
