@@ -255,6 +255,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     uint32_t crow0 = 0, crow1 = tiles_h;                    // the tile rows the painter visits (Rect::new, renderer.rs:43-52)
     if (a.crop) { crow0 = a.crop->y0 / 16; crow1 = std::min(tiles_h, (a.crop->y1 + 15) / 16); }
     const uint32_t rows_painted = std::max(crow1 > crow0 ? crow1 - crow0 : 0u, 1u);
+    ctx->cur_rows_painted = rows_painted;
     // Slicing pays when a row is heavy (measured on a 17-row band of the 4K scene, 4 800 runs per row: carry stage 80 -> 57 us
     // with eight small workgroups per row) and costs when it is light (a 64-row band of the 8192 x 8192 scene, ~1 000 runs per
     // row: 48 -> 55 us): a slice should keep >= ~768 runs.
@@ -293,10 +294,22 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
         }
         jc = DevCount{nullptr, J};
     }
+    SpanGroups groups{nullptr, nullptr, 0u, 0u};
+    const uint32_t n_groups = (tiles_w + SPAN_GROUP_TILES - 1u) >> SPAN_GROUP_SHIFT;
     if (jc.bound > 0) {
         const size_t jb = jc.bound;
         HIPCHECK(ctx->span_key.ensure(jb * 8));
         HIPCHECK(ctx->span_cov.ensure(jb * 16));
+        // (a frame whose rows hold few spans skips them altogether — the painters would load a table to learn "none": +10 us
+        //  on the 8192 x 8192 triangle scene; the first frame of a geometry does not know and goes without)
+        if (!ctx->no_span_groups && (ctx->force_span_groups || ctx->pred_row_spans > SPAN_GROUP_MIN_ROW)) {
+            // the row's spans again by tile-column group: a pool of two entries per run (a span has a run to its left, and spans
+            // longer than a group are the exception); a slice of a row that does not fit keeps only its row list
+            const size_t pool = std::min<size_t>(2 * jb, 0xFFFFFFFFu);
+            HIPCHECK(ctx->grp_tab.ensure((size_t)tiles_h * CR_MAX_SLICES_HOST * n_groups * sizeof(uint2)));
+            HIPCHECK(ctx->grp_list.ensure(pool * sizeof(uint4)));
+            groups = SpanGroups{ctx->grp_tab.as<uint2>(), ctx->grp_list.as<uint4>(), (uint32_t)pool, ctx->force_span_groups ? 0u : SPAN_GROUP_MIN_ROW};
+        }
         const uint64_t* sorted_keys = ctx->rk_u.as<uint64_t>();
         if (!local_sort) {
             HIPCHECK(ctx->rk_a.ensure(jb * 8));
@@ -322,7 +335,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                           runs_edge_segments(ctx->legacy_runs),
                           // invisible carries of a partial last tile row are dropped only when nothing can observe them: with a
                           // buffer-layer cache the layer count of a tile is state (passes/tile_unchanged.rs)
-                          (a.cache_id < 0 && (a.height & 15u)) ? (a.height & 15u) : 16u, crow0, crow1);
+                          (a.cache_id < 0 && (a.height & 15u)) ? (a.height & 15u) : 16u, crow0, crow1, groups);
     } else {
         HIPCHECK(ctx->span_key.ensure(8));
         HIPCHECK(ctx->span_cov.ensure(16));
@@ -342,9 +355,10 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
         for (int i = 0; i < 4; i++) if (ch[i] == FORMA_CH_ALPHA) ch[i] = FORMA_CH_ONE;
     P.channels = (uint32_t)ch[0] | ((uint32_t)ch[1] << 8) | ((uint32_t)ch[2] << 16) | ((uint32_t)ch[3] << 24);
     for (int i = 0; i < 4; i++) P.clear[i] = a.clear[i];
-    P.stride_px = a.width; P.scene_has_clips = ctx->scene_has_clips ? 1u : 0u; P.n_orders = (uint32_t)ctx->n_orders;
+    P.stride_px = a.width; P.scene_has_clips = ctx->scene_has_clips ? 1u : 0u; P.scene_simple = ctx->scene_simple ? 1u : 0u; P.n_orders = (uint32_t)ctx->n_orders; P.n_words = (uint32_t)ctx->n_words;
     P.clear_unchanged = clear_unchanged;
     P.n_slices = jc.bound > 0 ? n_slices : 1u;             // (no runs: the carry pre-pass did not run, the zeroed tables say "no spans")
+    P.n_groups = n_groups;
     stage_begin(ctx, ST_PAINT, timing);
     launch_paint(ctx->stream, P, ctx->sorted, ctx->records.as<TileRecord>(), jc, tile_first_run, row_span_lo,
                  row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(), ctx->layer_col.as<uint4>(),
@@ -353,7 +367,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                  ctx->cur_image, tc, dinfo, paint_overflow, overflow_list, over2_n, over2_list,
                  // the (empty) k_paint_deep launch costs ~5 us of every frame: a read-back-free frame without a cache skips it
                  // when the last verified frame had no deep tile; a tile that needs it then voids the frame (re-run in full)
-                 /*launch_deep=*/!(bound_j != 0 && a.cache_id < 0 && ctx->pred_no_deep));
+                 /*launch_deep=*/!(bound_j != 0 && a.cache_id < 0 && ctx->pred_no_deep), groups);
     stage_end(ctx, ST_PAINT, timing);
     HIPCHECK(hipGetLastError());
     // what a later launch_paint_huge needs (tiles deeper than the painter's LDS lists: finish_paint)
@@ -467,6 +481,7 @@ int finish_frame(forma_hip_ctx* ctx, forma_timings_t* t, bool have_info = false)
     }
     // device-side invariant flags
     ctx->pred_no_deep = !(ctx->h_info->error & 16u);       // (8, 16: bookkeeping bits, not errors)
+    if (!ctx->h_info->plan_bad) ctx->pred_row_spans = ctx->h_info->n_spans / ctx->cur_rows_painted;
     if (!ctx->h_info->plan_bad) { ctx->pred_max_slice = ctx->h_info->max_slice_runs; ctx->pred_slice_n = ctx->cur_slices; ctx->pred_slice_small = ctx->cur_small; }
     if (ctx->h_info->error & ~24u) return fail(ctx, FORMA_E_INTERNAL, "device-side invariant violated");
     if (!t) return FORMA_OK;
@@ -545,6 +560,8 @@ int forma_hip_create(forma_hip_ctx** out, int device) {
     ctx->legacy_runs = getenv("FORMA_HIP_LEGACY_RUNS") != nullptr;
     ctx->xgather_always = getenv("FORMA_HIP_XGATHER") != nullptr;
     ctx->no_small_carry = getenv("FORMA_HIP_NO_SMALL_CARRY") != nullptr;
+    ctx->no_span_groups = getenv("FORMA_HIP_NO_SPAN_GROUPS") != nullptr;
+    ctx->force_span_groups = getenv("FORMA_HIP_SPAN_GROUPS") != nullptr;
     if (const char* e = getenv("FORMA_HIP_CARRY_SLICES")) ctx->force_slices = (uint32_t)std::min(std::max(atoi(e), 1), (int)CR_MAX_SLICES_HOST);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx; return FORMA_E_HIP;
@@ -660,7 +677,7 @@ int forma_hip_set_styles(forma_hip_ctx* ctx, const uint32_t* style_offsets, size
     if (!ctx || (n_orders && !style_offsets) || (n_words && !style_words)) return fail(ctx, FORMA_E_ARG, "null styles");
     if (n_orders > (size_t)FORMA_LAYER_LIMIT + 1) return fail(ctx, FORMA_E_ARG, "order exceeds LAYER_LIMIT");
     if (ctx->multi) return multi_set_styles(ctx, style_offsets, n_orders, style_words, n_words, unchanged);
-    bool clips = false;
+    bool clips = false, simple = true;
     // per order: what the carry pre-pass attaches to every run and span of the layer (one gather instead of a chain through
     // the offset table and the style words): SF_* flags and the four words the painter's fast paths read
     ctx->h_layer_sf.assign(n_orders, 0u);
@@ -680,6 +697,7 @@ int forma_hip_set_styles(forma_hip_ctx* ctx, const uint32_t* style_offsets, size
         if (off + need > n_words) return fail(ctx, FORMA_E_ARG, "style payload out of range");
         if (!FORMA_STYLE_IS_CLIP(h) && FORMA_STYLE_FILL(h) == FORMA_FILL_TEXTURE) { any_texture = true; max_image = std::max(max_image, style_words[off + 8]); }
         if (FORMA_STYLE_IS_CLIP(h) || FORMA_STYLE_CLIPPED(h)) clips = true;
+        if (FORMA_STYLE_IS_CLIP(h) || FORMA_STYLE_CLIPPED(h) || FORMA_STYLE_FILL(h) != FORMA_FILL_SOLID || FORMA_STYLE_BLEND(h) != 0u) simple = false;
         uint32_t sfl = (FORMA_STYLE_EVENODD(h) ? SF_EVENODD : 0u) | (FORMA_STYLE_BLEND(h) << SF_BLEND_SHIFT) | (FORMA_STYLE_FILL(h) << SF_FILL_SHIFT);
         uint32_t* col = &ctx->h_layer_col[o * 4];
         if (FORMA_STYLE_IS_CLIP(h)) { sfl |= SF_IS_CLIP; col[0] = style_words[off + 1]; }
@@ -700,7 +718,7 @@ int forma_hip_set_styles(forma_hip_ctx* ctx, const uint32_t* style_offsets, size
     if ((rc = upload(ctx, ctx->layer_col, ctx->h_layer_col.data(), n_orders * 4))) return rc;
     if (unchanged && (rc = upload(ctx, ctx->unchanged, unchanged, n_orders))) return rc;
     HIPCHECK(hipStreamSynchronize(ctx->stream));
-    ctx->n_orders = n_orders; ctx->n_words = n_words; ctx->scene_has_clips = clips;
+    ctx->n_orders = n_orders; ctx->n_words = n_words; ctx->scene_has_clips = clips; ctx->scene_simple = simple;
     ctx->have_unchanged = unchanged != nullptr;
     ctx->any_texture = any_texture; ctx->max_image_index = max_image;
     share_scene(ctx);
@@ -1005,7 +1023,7 @@ void share_scene(forma_hip_ctx* o) {
         sl->images.borrow(o->images); sl->texels.borrow(o->texels); sl->layer_sf.borrow(o->layer_sf); sl->layer_col.borrow(o->layer_col);
         sl->n_points = o->n_points; sl->n_geoms = o->n_geoms; sl->n_orders = o->n_orders; sl->n_words = o->n_words; sl->n_images = o->n_images;
         sl->max_geom_order = o->max_geom_order; sl->max_image_index = o->max_image_index; sl->any_texture = o->any_texture;
-        sl->scene_has_clips = o->scene_has_clips; sl->have_unchanged = o->have_unchanged;
+        sl->scene_has_clips = o->scene_has_clips; sl->scene_simple = o->scene_simple; sl->have_unchanged = o->have_unchanged;
         sl->band_row0 = o->band_row0; sl->band_row1 = o->band_row1;
         sl->line_ranged = o->line_ranged; sl->line_lo = o->line_lo; sl->line_hi = o->line_hi;
     }

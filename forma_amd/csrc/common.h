@@ -68,9 +68,28 @@ struct PaintParams {
     float    clear[4];
     uint32_t stride_px;                            // device image row pitch in pixels
     uint32_t scene_has_clips;
+    uint32_t scene_simple;          // every layer: solid fill, BlendMode::Over, neither a clip nor clipped
     uint32_t n_orders;
+    uint32_t n_words;                              // length of the style word pool
     uint32_t clear_unchanged;                      // buffer-layer cache: this frame's clear colour == the cached one
     uint32_t n_slices;                             // span lists per tile row (slices of the carry pre-pass)
+    uint32_t n_groups;                             // tile-column groups per row (SPAN_GROUP_TILES tiles each): see SpanGroups
+};
+
+// The spans of a tile row, a second time, by TILE-COLUMN GROUP: k_carry_rows appends to the row's (layer, tile_x)-ordered span
+// list one list per group of SPAN_GROUP_TILES tile columns holding ready-made painter entries of the spans that overlap the
+// group (ascending layer, like the row list).  A wave painter scans its group's list (~65 entries on the 4K scene) instead
+// of the row's (739).  tab[(row * n_slices + slice) * n_groups + g] = {first entry, count}; count = SPAN_GROUP_NONE: the pool
+// was full, the painter scans the row list as before.
+#define SPAN_GROUP_SHIFT 4
+#define SPAN_GROUP_TILES (1u << SPAN_GROUP_SHIFT)
+#define SPAN_GROUP_NONE  0xFFFFFFFFu
+#define SPAN_GROUP_MIN_ROW 256u
+struct SpanGroups {
+    uint2*   tab;
+    uint4*   list;        // {key high word (layer | SF_* << 21), entry reference (REF_SPAN | REF_UNCH | span index), lo | hi << 16, 0}
+    uint32_t cap;         // entries in `list`: a slice of a row owns [2 * its first run, + 2 * its runs)
+    uint32_t min_row;     // a row with no more spans than this keeps only its row list (one round of painter loads either way)
 };
 
 // buffer-layer cache (reference cpu/buffer/mod.rs:113-197, painter/mod.rs:629-715 `CachedTile`), device-resident:
@@ -213,7 +232,8 @@ void launch_carry_rows(hipStream_t s, bool local_sort, bool small, uint32_t n_sl
                        uint64_t* span_key, uint4* span_cov, const uint8_t* unchanged /* per order, nullable */, FrameInfo* info,
                        uint32_t edge_segs,
                        uint32_t vis_last /* visible pixel rows of the last tile row (height % 16, 16 if 0) */,
-                       uint32_t row0, uint32_t row1 /* the tile rows that are painted (the crop): only those get workgroups */);
+                       uint32_t row0, uint32_t row1 /* the tile rows that are painted (the crop): only those get workgroups */,
+                       SpanGroups groups /* tab == nullptr: no group lists */);
 void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, DevCount n_runs,
                   const uint32_t* tile_first_run, const uint32_t* row_span_lo, const uint32_t* row_span_cnt,
                   const uint64_t* span_key, const uint4* span_cov,
@@ -222,7 +242,8 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
                   const uint16_t* texels, uint8_t* image, TileCacheArgs cache, FrameInfo* info, uint32_t* overflow_n /* zeroed by launch_runs */,
                   uint32_t* overflow_list /* tiles_w * tiles_h words */, uint32_t* over2_n /* zeroed by launch_runs */,
                   uint32_t* over2_list /* {tile, entries} pairs: 2 * tiles_w * tiles_h words */,
-                  bool launch_deep /* false: k_paint_deep is not launched; a tile that needs it voids the frame (plan_bad) */);
+                  bool launch_deep /* false: k_paint_deep is not launched; a tile that needs it voids the frame (plan_bad) */,
+                  SpanGroups groups /* tab == nullptr: the painters scan the row lists (p.n_groups is ignored) */);
 // tiles whose layer list exceeds the painter's LDS lists (info->error bit 3 after launch_paint): lists in global memory,
 // offs[i] = first entry slot of tile over2_list[2 i]; g_key holds 4 entries per slot, g_tmp / g_flag one
 void launch_paint_huge(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, DevCount n_runs,

@@ -46,6 +46,12 @@ struct forma_hip_ctx {
     uint32_t max_image_index = 0;           // largest image index a texture style names
     bool any_texture = false;
     bool scene_has_clips = false;
+    DevBuf grp_tab, grp_list;       // span group lists (SpanGroups, common.h): table per (row, slice, group) and the entry pool
+    bool no_span_groups = false;    // FORMA_HIP_NO_SPAN_GROUPS (A/B switch for tools/)
+    bool force_span_groups = false; // FORMA_HIP_SPAN_GROUPS: on every frame and for every row, however few spans (tests)
+    uint32_t pred_row_spans = 0;    // spans per painted tile row of the last verified frame: group lists pay above SPAN_GROUP_MIN_ROW
+    uint32_t cur_rows_painted = 1;
+    bool scene_simple = false;      // all layers solid + Over + unclipped: the painter's specialised kernel
     bool have_unchanged = false;            // set_styles supplied per-order Layer::is_unchanged bytes
     // lines
     DevBuf l_order, l_x0, l_y0, l_dx, l_dy, l_a, l_b, l_c, l_d, l_len, scan_tmp;   // parity entry points only

@@ -682,7 +682,8 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
                                                            FrameInfo* __restrict__ info, uint32_t edge_segs,
                                                            uint32_t vis_last /* visible pixel rows of the last tile row, 16 = all */,
                                                            uint32_t n_slices, uint32_t bin_shift,
-                                                           uint32_t row0 /* first tile row that is painted: blockIdx.x = 0 */) {
+                                                           uint32_t row0 /* first tile row that is painted: blockIdx.x = 0 */,
+                                                           SpanGroups groups) {
     constexpr int CR_RPT = RPT;                        // consecutive runs of the (layer, tile_x) order per lane in the row walk
     constexpr int CR_PIECE = CR_THREADS * RPT;         // runs per piece
     constexpr bool NB_IN_IDLE = LOCAL && 2 * (CR_PIECE + 1) <= CAP;   // group / tile_x of a piece's runs live in the sort's idle buffer
@@ -696,6 +697,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
     __shared__ uint32_t s_ka[LOCAL ? CAP : 1], s_kb[LOCAL ? CAP : 1];
     __shared__ uint32_t s_wh[LOCAL ? CR_WAVES * 256 : 1];
     __shared__ uint32_t s_cut[4];                      // this slice: first bin, end bin | first key, end key (!LOCAL)
+    __shared__ uint32_t s_gcnt[256], s_gpre[256];      // span group lists: entries per group, their exclusive prefix
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t ty = row0 + blockIdx.x / n_slices, slice = blockIdx.x % n_slices;
     // A canvas whose height is not a multiple of 16: lines entirely below it are culled (segment.rs:41-52), so a layer that
@@ -1079,6 +1081,72 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
         row_span_lo[ty * n_slices + slice] = row_lo + off; row_span_cnt[ty * n_slices + slice] = s_spans;   // (one pair per (row, slice))
         if (s_spans) atomicAdd(&info->n_spans, s_spans);
     }
+    // ---- the slice's spans once more, by tile-column group (SpanGroups in common.h): wave w owns the groups w, w + 16, ... and
+    //      compacts, in list order (= ascending layer), the spans that overlap each.  The (lo, hi) pairs are first brought into
+    //      LDS in one round of coalesced loads (the sort buffers are idle by now); a painter then reads ~1/10 of the keys. ------
+    if (!groups.tab) return;
+    __syncthreads();                                                    // s_spans is final, every span of the slice is stored
+    const uint32_t S = s_spans, sb0 = row_lo + off;
+    const uint32_t G = (tiles_w + SPAN_GROUP_TILES - 1u) >> SPAN_GROUP_SHIFT;
+    uint2* gt = groups.tab + (size_t)(ty * n_slices + slice) * G;
+    // A row list that a painter reads in one round anyway (<= 256 keys: the 8192 x 8192 triangle scene has 115 per row) gains
+    // nothing from group lists and this epilogue would cost its 512 small workgroups 12 us: such a slice says "none" and its
+    // row's painters scan the row list.  (The other two conditions cannot happen: tile_x has 12 bits, spans <= runs <= CAP.)
+    if (S * n_slices <= groups.min_row || G > 256u || (LOCAL && S > (uint32_t)CAP)) {
+        for (uint32_t g = tid; g < G; g += CR_THREADS) gt[g] = make_uint2(0u, SPAN_GROUP_NONE);
+        return;
+    }
+    // the slice's keys: low words (unch | lo | hi) and high words (layer | SF_*) into the idle sort buffers, one round of loads
+    uint32_t* s_lohi = LOCAL ? s_ka : nullptr;                          // (!LOCAL has no such buffers: it reads the keys in place)
+    uint32_t* s_khi = LOCAL ? s_kb : nullptr;
+    if (tid < 256) s_gcnt[tid] = 0;
+    if (LOCAL) {
+        for (uint32_t e = tid; e < S; e += CR_THREADS) { const uint64_t k = span_key[sb0 + e]; s_lohi[e] = (uint32_t)k; s_khi[e] = (uint32_t)(k >> 32); }
+    }
+    __syncthreads();
+    auto lohi_at = [&](uint32_t e) -> uint32_t { return LOCAL ? s_lohi[e] : (uint32_t)span_key[sb0 + e]; };
+    for (uint32_t e = tid; e < S; e += CR_THREADS) {                    // entries per group
+        const uint32_t lh = lohi_at(e) & 0x7FFFFFFFu;
+        const uint32_t lo = lh >> 16, hi = lh & 0xFFFFu;
+        if (hi > lo) for (uint32_t g = lo >> SPAN_GROUP_SHIFT; g <= ((hi - 1u) >> SPAN_GROUP_SHIFT) && g < G; g++) atomicAdd(&s_gcnt[g], 1u);
+    }
+    __syncthreads();
+    if (tid < 256) {                                                    // exclusive prefix over the groups
+        const uint32_t c = (uint32_t)tid < G ? s_gcnt[tid] : 0u;
+        uint32_t inc = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+        if (lane == 63) s_red[w] = inc;
+        s_gpre[tid] = inc - c;
+    }
+    __syncthreads();
+    // The slice's share of the pool is static — two entries per run of the slice, at twice its first run — so nothing is
+    // allocated at run time; a slice whose spans overlap more groups than that keeps only its row list.
+    const uint32_t total = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    const uint32_t gbase = 2u * sb0;
+    const bool fits = total <= 2u * m && 2ull * sb0 + total <= groups.cap;
+    for (uint32_t g = w; g < G; g += CR_WAVES) {
+        const uint32_t x0 = g << SPAN_GROUP_SHIFT, x1 = x0 + SPAN_GROUP_TILES;
+        const uint32_t cntg = s_gcnt[g];
+        uint32_t first = gbase + s_gpre[g];                             // s_gpre is exclusive within the scanning wave of g
+        for (uint32_t q = 0; q < (g >> 6); q++) first += s_red[q];
+        if (lane == 0) gt[g] = fits ? make_uint2(first, cntg) : make_uint2(0u, SPAN_GROUP_NONE);
+        if (!fits || !cntg) continue;
+        uint32_t pos = first;
+        for (uint32_t e0 = 0; e0 < S; e0 += 64) {                       // ordered compaction: list order = ascending layer
+            const uint32_t e = e0 + (uint32_t)lane;
+            const uint32_t lhu = e < S ? lohi_at(e) : 0u;
+            const uint32_t lh = lhu & 0x7FFFFFFFu;
+            const bool hit = (lh >> 16) < x1 && (lh & 0xFFFFu) > x0;
+            const uint64_t bal = __ballot(hit);
+            if (hit) {
+                const uint32_t khi = LOCAL ? s_khi[e] : (uint32_t)(span_key[sb0 + e] >> 32);
+                groups.list[pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] =
+                    make_uint4(khi, REF_SPAN | ((lhu >> 31) ? REF_UNCH : 0u) | (sb0 + e), lh, 0u);
+            }
+            pos += (uint32_t)__popcll(bal);
+        }
+    }
 }
 
 uint32_t carry_rows_local_cap() { return CR_CAP; }
@@ -1089,7 +1157,8 @@ void launch_carry_rows(hipStream_t s, bool local_sort, bool small, uint32_t n_sl
                        const BlkEdge* blk_edge, DevCount n_segments, DevCount n_runs, const uint32_t* layer_sf,
                        uint32_t n_orders, uint32_t tiles_w, uint32_t tiles_h, const uint32_t* row_count,
                        uint32_t* row_span_lo, uint32_t* row_span_cnt, uint64_t* span_key, uint4* span_cov,
-                       const uint8_t* unchanged, FrameInfo* info, uint32_t edge_segs, uint32_t vis_last, uint32_t row0, uint32_t row1) {
+                       const uint8_t* unchanged, FrameInfo* info, uint32_t edge_segs, uint32_t vis_last, uint32_t row0, uint32_t row1,
+                       SpanGroups groups) {
     row1 = row1 < tiles_h ? row1 : tiles_h;
     if (tiles_h == 0 || row0 >= row1) return;             // (only the tile rows that are painted: the others' carries are never read)
     if (n_slices < 1u) n_slices = 1u;
@@ -1097,7 +1166,7 @@ void launch_carry_rows(hipStream_t s, bool local_sort, bool small, uint32_t n_sl
     const dim3 grid((row1 - row0) * n_slices), block(CR_THREADS);
 #define CR_LAUNCH(L, C, R) hipLaunchKernelGGL((k_carry_rows<L, C, R>), grid, block, 0, s, sorted_run_keys, records, blk_edge, n_segments, \
                                               n_runs, layer_sf, n_orders, tiles_w, tiles_h, row_count, row_span_lo, row_span_cnt, span_key, \
-                                              span_cov, unchanged, info, edge_segs, vis_last, n_slices, bin_shift, row0)
+                                              span_cov, unchanged, info, edge_segs, vis_last, n_slices, bin_shift, row0, groups)
     if (!local_sort) CR_LAUNCH(false, CR_CAP, 4);
     else if (small) CR_LAUNCH(true, CR_CAP_S, 2);
     else CR_LAUNCH(true, CR_CAP, 4);
@@ -1328,7 +1397,8 @@ __device__ __forceinline__ float sel_channel(uint32_t c, float r, float g, float
 }
 
 // ---- fills (cpu/painter/styling.rs:58-193), per pixel -----------------------------------------------------
-__device__ __forceinline__ void gradient_at(const uint32_t* __restrict__ w, uint32_t fill, uint32_t nstops, float x,
+template <typename WP>
+__device__ __forceinline__ void gradient_at(WP w, uint32_t fill, uint32_t nstops, float x,
                                             float ybase, int j, float* out) {
     float sx = __uint_as_float(w[2]), sy = __uint_as_float(w[3]), ex = __uint_as_float(w[4]), ey = __uint_as_float(w[5]);
     float dx = ex - sx, dy = ey - sy;
@@ -1345,14 +1415,14 @@ __device__ __forceinline__ void gradient_at(const uint32_t* __restrict__ w, uint
         float py = (float)j + (ybase - sy);
         t = sqrtf(fmaf(py, py, px2) * dot_recip);
     }
-    const uint32_t* st = w + 6;
+    const auto st = w + 6;
     uint32_t ch[4] = {0, 0, 0, 0};
     bool acc = t <= __uint_as_float(st[4]);
     if (acc) { ch[0] |= st[0]; ch[1] |= st[1]; ch[2] |= st[2]; ch[3] |= st[3]; }
     float start_stop = 0.0f;
     uint32_t sc[4] = {st[0], st[1], st[2], st[3]};
     for (uint32_t k = 1; k < nstops; k++) {
-        const uint32_t* q = st + 5 * k;
+        const auto q = st + 5 * k;
         float end_stop = __uint_as_float(q[4]);
         bool mask = acc ^ (t < end_stop);
         if (mask) {
@@ -1369,7 +1439,7 @@ __device__ __forceinline__ void gradient_at(const uint32_t* __restrict__ w, uint
         sc[0] = q[0]; sc[1] = q[1]; sc[2] = q[2]; sc[3] = q[3];
     }
     if (!acc) {
-        const uint32_t* q = st + 5 * (nstops - 1);
+        const auto q = st + 5 * (nstops - 1);
         ch[0] |= q[0]; ch[1] |= q[1]; ch[2] |= q[2]; ch[3] |= q[3];
     }
     out[0] = __uint_as_float(ch[0]); out[1] = __uint_as_float(ch[1]); out[2] = __uint_as_float(ch[2]); out[3] = __uint_as_float(ch[3]);
@@ -1392,6 +1462,86 @@ __device__ __forceinline__ void texture_at(const uint32_t* __restrict__ w, const
     out[0] = f16b_to_f32(p[0]); out[1] = f16b_to_f32(p[1]); out[2] = f16b_to_f32(p[2]); out[3] = f16b_to_f32(p[3]);
 }
 
+// texture_at with the image descriptor already fetched (once per layer instead of once per pixel)
+template <typename WP>
+__device__ __forceinline__ void texture_at_im(WP w, const forma_image_t im, const uint16_t* __restrict__ texels, float x, float y,
+                                              float* out) {
+    float max_x = (float)im.width - 1.0f, max_y = (float)im.height - 1.0f;
+    float ux = __uint_as_float(w[2]), uy = __uint_as_float(w[3]), vx = __uint_as_float(w[4]), vy = __uint_as_float(w[5]);
+    float tx = __uint_as_float(w[6]), ty = __uint_as_float(w[7]);
+    float fx = fmaf(x, ux, fmaf(vx, y, tx));
+    float fy = fmaf(x, uy, fmaf(vy, y, ty));
+    float cx = avx_max(avx_min(fx, max_x), 0.0f), cy = avx_max(avx_min(fy, max_y), 0.0f);
+    uint32_t ix = (uint32_t)(int)cx, iy = (uint32_t)(int)cy;
+    uint32_t off = iy * im.width + ix;
+    const uint16_t* p = texels + 4 * (im.texel_offset + off);
+    out[0] = f16b_to_f32(p[0]); out[1] = f16b_to_f32(p[1]); out[2] = f16b_to_f32(p[2]); out[3] = f16b_to_f32(p[3]);
+}
+
+// gradient_at for the wave painter: the layer's style words sit in the wave's LDS window `ws` (words 0..5 = header and
+// geometry, then WSTOPS stops of five words).  Called by ALL 64 lanes (the caller selects afterwards), so a gradient with
+// more stops than the window holds re-fills the window from `wg` as it goes and puts the first stops back at the end.
+#define WSTYLE 64         // style words of a non-solid layer the wave painter keeps in LDS: header, geometry, 11 gradient stops
+#define WSTOPS ((WSTYLE - 6) / 5)
+__device__ __forceinline__ void gradient_at_lds(uint32_t* ws, const uint32_t* __restrict__ wg, uint32_t fill, uint32_t nstops, float x,
+                                                float ybase, int j, int lane, float* out) {
+    float sx = __uint_as_float(ws[2]), sy = __uint_as_float(ws[3]), ex = __uint_as_float(ws[4]), ey = __uint_as_float(ws[5]);
+    float dx = ex - sx, dy = ey - sy;
+    float dot = dx * dx + dy * dy;
+    float dot_recip = 1.0f / dot;
+    float t;
+    if (fill == FORMA_FILL_LINEAR) {
+        float tx = (x - sx) * dx * dot_recip;
+        float ty = ybase - sy;
+        t = fmaf(((float)j + ty) * dy, dot_recip, tx);
+    } else {
+        float px = x - sx;
+        float px2 = px * px;
+        float py = (float)j + (ybase - sy);
+        t = sqrtf(fmaf(py, py, px2) * dot_recip);
+    }
+    const uint32_t* st = ws + 6;
+    uint32_t ch[4] = {0, 0, 0, 0};
+    bool acc = t <= __uint_as_float(st[4]);
+    if (acc) { ch[0] |= st[0]; ch[1] |= st[1]; ch[2] |= st[2]; ch[3] |= st[3]; }
+    float start_stop = 0.0f;
+    uint32_t sc[4] = {st[0], st[1], st[2], st[3]};
+    uint32_t base = 0;                                                  // first stop of the window
+    for (uint32_t k = 1; k < nstops; k++) {
+        if (k - base >= (uint32_t)WSTOPS) {                             // (uniform) next window
+            base = k;
+            wave_lds_fence();
+            if (lane < WSTOPS * 5) ws[6 + lane] = 5u * base + (uint32_t)lane < 5u * nstops ? wg[6 + 5 * base + lane] : 0u;
+            wave_lds_fence();
+        }
+        const uint32_t* q = st + 5 * (k - base);
+        float end_stop = __uint_as_float(q[4]);
+        bool mask = acc ^ (t < end_stop);
+        if (mask) {
+            float d = end_stop - start_stop;
+            float lt = (t - start_stop) * (1.0f / d);
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                float s0 = __uint_as_float(sc[c]);
+                ch[c] |= __float_as_uint(fmaf(lt, __uint_as_float(q[c]), fmaf(-lt, s0, s0)));
+            }
+            acc = true;
+        }
+        start_stop = end_stop;
+        sc[0] = q[0]; sc[1] = q[1]; sc[2] = q[2]; sc[3] = q[3];
+    }
+    if (!acc) {
+        const uint32_t* q = st + 5 * (nstops - 1 - base);
+        ch[0] |= q[0]; ch[1] |= q[1]; ch[2] |= q[2]; ch[3] |= q[3];
+    }
+    if (base) {                                                         // the window goes back to the first stops
+        wave_lds_fence();
+        if (lane < WSTOPS * 5) ws[6 + lane] = wg[6 + lane];
+        wave_lds_fence();
+    }
+    out[0] = __uint_as_float(ch[0]); out[1] = __uint_as_float(ch[1]); out[2] = __uint_as_float(ch[2]); out[3] = __uint_as_float(ch[3]);
+}
+
 // The span lists of a tile row: one per slice of the carry pre-pass (launch_carry_rows), ascending layers from slice to slice.
 // The painters see them as ONE logical list [0, total): logical index -> position in the span arrays by <= 7 compares
 // (uniform; a row with one slice pays nothing).
@@ -1408,6 +1558,20 @@ __device__ __forceinline__ SpanLists load_span_lists(const uint32_t* __restrict_
     }
 #pragma unroll
     for (int q = 0; q < CR_MAX_SLICES; q++) { L.pre[q] = L.total; L.base[q] = b[q]; L.total += c[q]; }
+    return L;
+}
+// the same for one tile-column group: tab points at the group's entry of slice 0, the slices are n_groups entries apart.
+// total = SPAN_GROUP_NONE: some slice of the row has no group lists (pool full) — the caller scans the row lists instead.
+__device__ __forceinline__ SpanLists load_group_lists(const uint2* __restrict__ tab, uint32_t n_groups, uint32_t n_slices) {
+    SpanLists L;
+    L.n = n_slices; L.total = 0;
+    uint2 t[CR_MAX_SLICES];
+#pragma unroll
+    for (int q = 0; q < CR_MAX_SLICES; q++) t[q] = (uint32_t)q < n_slices ? tab[(size_t)q * n_groups] : make_uint2(0u, 0u);
+    bool none = false;
+#pragma unroll
+    for (int q = 0; q < CR_MAX_SLICES; q++) { L.pre[q] = L.total; L.base[q] = t[q].x; L.total += t[q].y; none |= t[q].y == SPAN_GROUP_NONE; }
+    if (none) L.total = SPAN_GROUP_NONE;
     return L;
 }
 __device__ __forceinline__ uint32_t span_phys(const SpanLists& L, uint32_t i) {
@@ -1837,6 +2001,12 @@ extern "C" int forma_hip_debug_paint_prof(unsigned long long* out24, int reset) 
 #define PP_COUNT(i, v) do { } while (0)
 #endif
 #define WMAX 128          // layer-list capacity of the wave painter
+#ifndef PAINT_GENERIC_OCC
+#define PAINT_GENERIC_OCC 6  // ... and the general one
+#endif
+#ifndef PAINT_SIMPLE_OCC
+#define PAINT_SIMPLE_OCC 8   // waves per SIMD the all-solid variant is compiled for
+#endif
 #define WB   16           // painted entries staged per batch
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -1850,7 +2020,11 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     return v;
 }
 
-__global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint64_t* __restrict__ sorted,
+// SIMPLE: every layer of the scene is a solid colour blended with BlendMode::Over and nothing is a clip or clipped (the host
+// knows from the style table, forma_hip_set_styles) — the fills, the sixteen blend modes and the clip state machine are
+// not even compiled in, which is worth registers (occupancy), instruction cache and the per-layer dispatch.
+template <bool SIMPLE>
+__global__ __launch_bounds__(64, SIMPLE ? PAINT_SIMPLE_OCC : PAINT_GENERIC_OCC) void k_paint_wave(PaintParams P, const uint64_t* __restrict__ sorted,
                                                     const TileRecord* __restrict__ records, DevCount nc_runs,
                                                     const uint32_t* __restrict__ tile_first_run,
                                                     const uint32_t* __restrict__ row_span_lo,
@@ -1863,13 +2037,16 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
                                                     const uint16_t* __restrict__ texels, uint8_t* __restrict__ image,
                                                     TileCacheArgs cache, FrameInfo* __restrict__ info,
                                                     uint32_t* __restrict__ overflow_n,
-                                                    uint32_t* __restrict__ overflow_list, uint32_t deep_follows) {
+                                                    uint32_t* __restrict__ overflow_list, uint32_t deep_follows,
+                                                    SpanGroups groups) {
     __shared__ uint64_t w_key[1][WMAX];
     __shared__ uint64_t w_tmp[1][WMAX];
-    __shared__ uint32_t w_flag[1][WMAX];
+    __shared__ uint16_t w_flag[1][WMAX];                                // (EF_* fit 10 bits; 5 120 B per wave = 32 waves per CU)
     __shared__ int w_cells[1][2][256];
     __shared__ uint4 w_cov[1][WB], w_col[1][WB];
     __shared__ uint32_t w_seg0[1][WB], w_nseg[1][WB], w_bflag[1][WB], w_blayer[1][WB];
+    __shared__ uint32_t w_woff[1][SIMPLE ? 1 : WB];                     // non-solid entries of the batch: where their style words are
+    __shared__ uint32_t w_style[1][SIMPLE ? 1 : WSTYLE];                // the current non-solid layer's style words
 
     const int lane = threadIdx.x & 63, wv = 0;
     // The guard word, the run count and the tile's three table entries are independent loads: issue all of them before
@@ -1890,7 +2067,7 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
 
     uint64_t* keys = w_key[wv];
     uint64_t* tmp = w_tmp[wv];
-    uint32_t* flags = w_flag[wv];
+    uint16_t* flags = w_flag[wv];
     const int lx = lane & 15, rg = lane >> 4;                           // this lane's pixels: (lx, 4 * rg + q), q = 0..3
 #ifdef PAINT_PROF
     unsigned long long pp_t = __builtin_readcyclecounter();
@@ -1900,12 +2077,25 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
     // ---- the tile's layer list: own runs (contiguous records, ascending layer) + the row's spans that cross it --------
     const uint32_t my_tile_key = ((ty + 1u) << 12) | (tx + 1u);
     const uint32_t j0 = tile_first_run[tile] - 1u;                      // 0 stored = no run -> FORMA_NONE
-    const SpanLists SL = load_span_lists(row_span_lo, row_span_cnt, ty, P.n_slices);
+    // the spans that may cross this tile: its tile-column group's lists (one per slice; SpanGroups in common.h), or — no group
+    // lists this frame, or the pool was full for this row — the row's
+    SpanLists SL = load_span_lists(row_span_lo, row_span_cnt, ty, P.n_slices);      // (both tables requested at once)
+    bool by_group = groups.tab != nullptr;
+    if (by_group) {
+        const SpanLists GL = load_group_lists(groups.tab + (size_t)ty * P.n_slices * P.n_groups + (tx >> SPAN_GROUP_SHIFT), P.n_groups, P.n_slices);
+        if (GL.total == SPAN_GROUP_NONE) by_group = false;              // (uniform)
+        else SL = GL;
+    }
     const uint32_t sc = SL.total;
     if (plan_bad) return;
-    uint64_t sk[4];
+    uint64_t sk[4];                                                     // (row list: the span key; group list: lo | hi << 16 in the low word)
+    uint4 ge[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) { const uint32_t i = u * 64 + lane; sk[u] = i < sc ? span_key[span_phys(SL, i)] : 0ull; }
+    for (int u = 0; u < 4; u++) {
+        const uint32_t i = u * 64 + lane;
+        if (by_group) { ge[u] = i < sc ? groups.list[span_phys(SL, i)] : make_uint4(0u, 0u, 0u, 0u); sk[u] = 0; }
+        else { sk[u] = i < sc ? span_key[span_phys(SL, i)] : 0ull; ge[u] = make_uint4(0u, 0u, 0u, 0u); }
+    }
     uint32_t na = 0;
     if (j0 != FORMA_NONE) {
         for (uint32_t c = 0;; c += 64) {                                // a tile's runs are contiguous from j0
@@ -1922,16 +2112,23 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
     for (uint32_t c = 0; c < sc; c += 256) {
         if (c) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const uint32_t i = c + u * 64 + lane; sk[u] = i < sc ? span_key[span_phys(SL, i)] : 0ull; }
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = c + u * 64 + lane;
+                if (by_group) ge[u] = i < sc ? groups.list[span_phys(SL, i)] : make_uint4(0u, 0u, 0u, 0u);
+                else sk[u] = i < sc ? span_key[span_phys(SL, i)] : 0ull;
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const uint32_t lo = (uint32_t)(sk[u] >> 16) & 0x7FFFu, hi = (uint32_t)sk[u] & 0xFFFFu;       // padding: lo = hi = 0
+            const uint32_t lh = by_group ? ge[u].z : (uint32_t)sk[u];
+            const uint32_t lo = (lh >> 16) & 0x7FFFu, hi = lh & 0xFFFFu;                                  // padding: lo = hi = 0
             const bool hit = tx >= lo && tx < hi;
             const uint64_t bal = __ballot(hit);
             if (hit) {
                 const uint32_t pos = na + nb + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                if (pos < WMAX) tmp[pos] = (sk[u] & 0xFFFFFFFF00000000ull) | REF_SPAN | (((uint32_t)sk[u] >> 31) ? REF_UNCH : 0u) | span_phys(SL, c + u * 64 + lane);
+                const uint64_t ent = by_group ? (((uint64_t)ge[u].x << 32) | ge[u].y)
+                                              : ((sk[u] & 0xFFFFFFFF00000000ull) | REF_SPAN | (((uint32_t)sk[u] >> 31) ? REF_UNCH : 0u) | span_phys(SL, c + u * 64 + lane));
+                if (pos < WMAX) tmp[pos] = ent;
             }
             nb += (uint32_t)__popcll(bal);
         }
@@ -1971,7 +2168,7 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
             if (sfl & SF_OPAQUE) f |= EF_OPAQUE;
             if (((sfl >> SF_BLEND_SHIFT) & 15u) == 0u) f |= EF_OVER;
         }
-        flags[rank] = f;
+        flags[rank] = (uint16_t)f;
     }
     wave_lds_sync();
 
@@ -1997,7 +2194,7 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
         }
     }
     // ---- optimizer passes (layer_workbench/passes/*.rs) -------------------------------------------------------------
-    if (P.scene_has_clips) {                                            // skip_trivial_clips_pass: serial (clip state machine)
+    if (!SIMPLE && P.scene_has_clips) {                                 // skip_trivial_clips_pass: serial (clip state machine)
         if (lane == 0) {
             bool has = false, c_full = false, c_used = false; uint32_t c_last = 0, c_i = 0;
             for (uint32_t i = 0; i < ne; i++) {
@@ -2024,9 +2221,9 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
     for (uint32_t i = lane; i < ne; i += 64) {
         const uint32_t f = flags[i];
         if (!(f & EF_MASK)) continue;
-        const bool clipped = !(f & EF_IS_CLIP) && (f & EF_CLIPPED) && !(f & EF_SKIPCLIP);
+        const bool clipped = !SIMPLE && !(f & EF_IS_CLIP) && (f & EF_CLIPPED) && !(f & EF_SKIPCLIP);
         if (clipped || !(f & EF_FULL)) blk = i + 1;
-        else if (!(f & EF_IS_CLIP) && (f & EF_SOLID) && (f & EF_OVER) && (f & EF_OPAQUE)) top = i + 1;
+        else if (SIMPLE ? (f & EF_OPAQUE) != 0 : (!(f & EF_IS_CLIP) && (f & EF_SOLID) && (f & EF_OVER) && (f & EF_OPAQUE))) top = i + 1;
     }
     top = wave_max_u32(top); blk = wave_max_u32(blk);
     const uint32_t skipped = top ? top - 1u : 0u;
@@ -2059,7 +2256,8 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
                 const uint4 c4 = b_col[t];
                 const Col src = {__uint_as_float(c4.x), __uint_as_float(c4.y), __uint_as_float(c4.z), __uint_as_float(c4.w)};
                 if (first == 1 && k0 + t == skipped) { dst = src; continue; }
-                if (!(f & EF_IS_CLIP) && (f & EF_SOLID)) dst = sc_blend((uint32_t)(keys[k0 + t] >> (53 + SF_BLEND_SHIFT)) & 15u, dst, src);
+                if (SIMPLE) dst = sc_blend(0u, dst, src);
+                else if (!(f & EF_IS_CLIP) && (f & EF_SOLID)) dst = sc_blend((uint32_t)(keys[k0 + t] >> (53 + SF_BLEND_SHIFT)) & 15u, dst, src);
                 else ok = false;
             }
         }
@@ -2120,6 +2318,8 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
             b_flag[lane] = flags[i] | ((uint32_t)(k >> 53) << 16);
             b_layer[lane] = (uint32_t)(k >> 32) & LAYER_MASK;
             b_col[lane] = layer_col[(uint32_t)(k >> 32) & LAYER_MASK];
+            if (!SIMPLE && (((uint32_t)(k >> 53) >> SF_FILL_SHIFT) & 3u) != FORMA_FILL_SOLID && !(flags[i] & EF_IS_CLIP))
+                w_woff[wv][lane] = style_offsets[(uint32_t)(k >> 32) & LAYER_MASK];
             if (ref & 0x80000000u) {
                 b_cov[lane] = span_cov[ref & REF_IDX];
                 b_seg0[lane] = 0; b_nseg[lane] = 0;
@@ -2168,20 +2368,20 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
 #pragma unroll
                 for (int q = 0; q < 4; q++) A[q] = 32 * (int)(int8_t)(cw >> (q * 8));
             }
-            if (clip_valid && clip_last < layer) clip_valid = false;    // :298-302
+            if (!SIMPLE && clip_valid && clip_last < layer) clip_valid = false;    // :298-302
             const bool eo = (f & EF_EVENODD) != 0;
-            if (f & EF_IS_CLIP) {                                       // clip_at :449-464
+            if (!SIMPLE && (f & EF_IS_CLIP)) {                          // clip_at :449-464
                 if (!clip_valid) { clip_valid = true; clip_last = layer + b_col[t].x; }
 #pragma unroll
                 for (int q = 0; q < 4; q++) clip_mask[q] = coverage_of(A[q], eo);
                 continue;
             }
-            const bool apply_clip = (f & EF_CLIPPED) && !(f & EF_SKIPCLIP);
+            const bool apply_clip = !SIMPLE && (f & EF_CLIPPED) && !(f & EF_SKIPCLIP);
             if (apply_clip && !clip_valid) continue;                    // :321-323
-            const uint32_t ft = (sfl >> SF_FILL_SHIFT) & 3u;
-            const uint32_t bm = (sfl >> SF_BLEND_SHIFT) & 15u;
+            const uint32_t ft = SIMPLE ? (uint32_t)FORMA_FILL_SOLID : (sfl >> SF_FILL_SHIFT) & 3u;
+            const uint32_t bm = SIMPLE ? 0u : (sfl >> SF_BLEND_SHIFT) & 15u;
             const uint4 col = b_col[t];
-            if (ft == FORMA_FILL_SOLID && bm == 0u && !apply_clip) {
+            if (SIMPLE || (ft == FORMA_FILL_SOLID && bm == 0u && !apply_clip)) {
                 // the common layer — solid colour, BlendMode::Over, not clipped — as straight-line code: the generic loop
                 // below dispatches on fill type and blend mode once per PIXEL (it is unrolled over the four pixels of a
                 // lane), ~4x the instructions.  Same operations in the same order, so the same bits.
@@ -2198,35 +2398,59 @@ __global__ __launch_bounds__(64, 6) void k_paint_wave(PaintParams P, const uint6
                     const bool skip = cov == 0.0f;                      // :317-319
                     dr[q] = skip ? dr[q] : nr; dg[q] = skip ? dg[q] : ng; db[q] = skip ? db[q] : nb2; da[q] = skip ? da[q] : na2;
                 }
-                PP_STAMP_IN(8);
+                PP_STAMP_IN(8); PP_COUNT(23, 1);                        // 8: coverage + blend of a solid / Over layer (23: how many)
                 continue;
             }
-            const uint32_t* w = (ft == FORMA_FILL_SOLID) ? nullptr : style_words + style_offsets[layer];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const float cov = coverage_of(A[q], eo);
-                if (cov == 0.0f) continue;                              // :317-319 (blend with 0 is the identity)
-                float fill[4];
-                if (ft == FORMA_FILL_SOLID) {
-                    fill[0] = __uint_as_float(col.x); fill[1] = __uint_as_float(col.y); fill[2] = __uint_as_float(col.z); fill[3] = __uint_as_float(col.w);
-                } else {
-                    const int ly = rg * 4 + q;
-                    const float fybase = (float)(ty * 16u + ((uint32_t)ly & 8u));                     // :326
-                    if (ft == FORMA_FILL_TEXTURE) texture_at(w, images, texels, fx, fybase + (float)(ly & 7), fill);
-                    else gradient_at(w, ft, FORMA_STYLE_STOPS(w[0]), fx, fybase, ly & 7, fill);
-                }
-                float src_a = fill[3] * cov;                            // blend_at :406-447
-                if (apply_clip) src_a *= clip_mask[q];
-                float bl[3];
-                blend_rgb(bm, dr[q], dg[q], db[q], fill[0], fill[1], fill[2], bl);
-                const float ida = 1.0f - da[q], k1 = ida * src_a, isa = 1.0f - src_a, k2 = da[q] * src_a;
-                const float cr = fmaf(fill[0], k1, bl[0] * k2);
-                const float cg = fmaf(fill[1], k1, bl[1] * k2);
-                const float cb2 = fmaf(fill[2], k1, bl[2] * k2);
-                dr[q] = fmaf(dr[q], isa, cr); dg[q] = fmaf(dg[q], isa, cg); db[q] = fmaf(db[q], isa, cb2);
-                da[q] = fmaf(da[q], isa, src_a);
+            // A gradient or a texture: its style words (geometry, stops, image transform) come into LDS with ONE round of loads,
+            // all lanes at once.  Read where they are used — inside the per-pixel branches — every word was a global round trip
+            // of its own (the loads cannot be hoisted out of a divergent branch): ~20 dependent L2 hits per gradient layer,
+            // 18 k clocks against 2 k for a solid one.
+            const uint32_t woff = (ft == FORMA_FILL_SOLID) ? 0u : w_woff[wv][t];
+            const uint32_t* w = style_words + woff;
+            uint32_t* ws = w_style[wv];
+            forma_image_t tex_im = {0, 0, 0};
+            if (ft != FORMA_FILL_SOLID) {
+                const uint32_t v = woff + (uint32_t)lane < P.n_words ? w[lane] : 0u;
+                wave_lds_sync();                                        // (the previous layer's readers are done)
+                ws[lane] = v;
+                wave_lds_sync();
+                if (ft == FORMA_FILL_TEXTURE) tex_im = images[ws[8]];
             }
-            PP_STAMP(8);                                                // 8: coverage + fill + blend of one layer
+            // The uncommon layer (gradient, texture, one of the fifteen other blend modes, clipped): ONE pixel row of the lane at
+            // a time in a loop that is not unrolled, the lane's four pixels rotating through slot 0 — unrolled, the compiler
+            // interleaves four fills and four blends.  All lanes evaluate (a pixel with coverage 0 keeps its colour, :317-319:
+            // blend with 0 is the identity), so nothing below sits in a divergent branch.
+#pragma unroll 1
+            for (int q = 0; q < 4; q++) {
+                const float cov = coverage_of(A[0], eo);
+                if (__any(cov != 0.0f)) {
+                    float fill[4];
+                    if (ft == FORMA_FILL_SOLID) {
+                        fill[0] = __uint_as_float(col.x); fill[1] = __uint_as_float(col.y); fill[2] = __uint_as_float(col.z); fill[3] = __uint_as_float(col.w);
+                    } else {
+                        const int ly = rg * 4 + q;
+                        const float fybase = (float)(ty * 16u + ((uint32_t)ly & 8u));                     // :326
+                        if (ft == FORMA_FILL_TEXTURE) texture_at_im(ws, tex_im, texels, fx, fybase + (float)(ly & 7), fill);
+                        else gradient_at_lds(ws, w, ft, FORMA_STYLE_STOPS(ws[0]), fx, fybase, ly & 7, lane, fill);
+                    }
+                    float src_a = fill[3] * cov;                        // blend_at :406-447
+                    if (apply_clip) src_a *= clip_mask[0];
+                    float bl[3];
+                    blend_rgb(bm, dr[0], dg[0], db[0], fill[0], fill[1], fill[2], bl);
+                    const float ida = 1.0f - da[0], k1 = ida * src_a, isa = 1.0f - src_a, k2 = da[0] * src_a;
+                    const float cr = fmaf(fill[0], k1, bl[0] * k2);
+                    const float cg = fmaf(fill[1], k1, bl[1] * k2);
+                    const float cb2 = fmaf(fill[2], k1, bl[2] * k2);
+                    const bool skip = cov == 0.0f;
+                    dr[0] = skip ? dr[0] : fmaf(dr[0], isa, cr); dg[0] = skip ? dg[0] : fmaf(dg[0], isa, cg);
+                    db[0] = skip ? db[0] : fmaf(db[0], isa, cb2); da[0] = skip ? da[0] : fmaf(da[0], isa, src_a);
+                }
+                { const int t0 = A[0]; A[0] = A[1]; A[1] = A[2]; A[2] = A[3]; A[3] = t0; }
+#define ROT4(v) do { const float t0_ = v[0]; v[0] = v[1]; v[1] = v[2]; v[2] = v[3]; v[3] = t0_; } while (0)
+                ROT4(dr); ROT4(dg); ROT4(db); ROT4(da); ROT4(clip_mask);
+#undef ROT4
+            }
+            PP_STAMP(10); PP_COUNT(22, 1);                              // 10: coverage + fill + blend of any other layer (22: how many)
         }
     }
     // ---- compute_srgb :466-483 + channel select, straight to the row-major RGBA8 image ----------------------------------
@@ -2297,13 +2521,20 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
                   const uint64_t* span_key, const uint4* span_cov, const uint4* layer_col,
                   const uint32_t* style_offsets, const uint32_t* style_words, const forma_image_t* images,
                   const uint16_t* texels, uint8_t* image, TileCacheArgs cache, FrameInfo* info, uint32_t* overflow_n,
-                  uint32_t* overflow_list, uint32_t* over2_n, uint32_t* over2_list, bool launch_deep) {
+                  uint32_t* overflow_list, uint32_t* over2_n, uint32_t* over2_list, bool launch_deep, SpanGroups groups) {
     const uint32_t T = p.tiles_w * p.tiles_h;
     if (T == 0 || p.crop_y1 <= p.crop_y0) return;
     const uint32_t per = ((p.crop_y1 - p.crop_y0) * p.tiles_w + 7) / 8;
-    hipLaunchKernelGGL(k_paint_wave, dim3(per * 8), dim3(64), 0, s, p, sorted, records, n_runs, tile_first_run, row_span_lo,
-                       row_span_cnt, span_key, span_cov, layer_col, style_offsets, style_words, images, texels, image,
-                       cache, info, overflow_n, overflow_list, launch_deep ? 1u : 0u);
+    static const bool no_simple = getenv("FORMA_HIP_NO_SIMPLE_PAINT") != nullptr;      // (A/B switch for tools/)
+    static const bool force_simple = getenv("FORMA_HIP_FORCE_SIMPLE_PAINT") != nullptr;  // (timing experiments only: wrong pixels on other scenes)
+    if ((p.scene_simple && !no_simple) || force_simple)
+        hipLaunchKernelGGL(k_paint_wave<true>, dim3(per * 8), dim3(64), 0, s, p, sorted, records, n_runs, tile_first_run, row_span_lo,
+                           row_span_cnt, span_key, span_cov, layer_col, style_offsets, style_words, images, texels, image,
+                           cache, info, overflow_n, overflow_list, launch_deep ? 1u : 0u, groups);
+    else
+        hipLaunchKernelGGL(k_paint_wave<false>, dim3(per * 8), dim3(64), 0, s, p, sorted, records, n_runs, tile_first_run, row_span_lo,
+                           row_span_cnt, span_key, span_cov, layer_col, style_offsets, style_words, images, texels, image,
+                           cache, info, overflow_n, overflow_list, launch_deep ? 1u : 0u, groups);
     if (!launch_deep) return;                             // (read-back-free frame of a scene whose last frame had no deep tile)
     hipLaunchKernelGGL(k_paint_deep, dim3(T < 256 ? T : 256), dim3(256), 0, s, p, sorted, records, n_runs, tile_first_run,
                        row_span_lo, row_span_cnt, span_key, span_cov, layer_col, style_offsets, style_words, images,

@@ -137,3 +137,43 @@ def test_carry_pre_pass_with_several_workgroups_per_tile_row(slices, global_sort
                 assert np.array_equal(bo, bc), (seed, slices, frame)
         finally:
             c.close()
+
+
+@pytest.mark.parametrize("slices,global_sort", [(1, False), (3, False), (8, False), (1, True), (4, True)])
+def test_span_group_lists(slices, global_sort, monkeypatch):
+    """k_carry_rows leaves the spans of a tile row a second time by group of 16 tile columns and the wave painter scans its
+    group's list instead of the row's (by itself only on frames whose rows hold > 256 spans; FORMA_HIP_SPAN_GROUPS forces them
+    on every frame and row).  Canvases of 1, 2, 7 and 128 groups, every slice count, both run orders, with and without a
+    cache: the same bits as the oracle.  The third scene is wide and shallow: its spans cross many groups, the static pool
+    (two entries per run) does not hold them and those rows fall back to the row lists on the device."""
+    import forma_amd
+    monkeypatch.setenv("FORMA_HIP_SPAN_GROUPS", "1")
+    monkeypatch.setenv("FORMA_HIP_CARRY_SLICES", str(slices))
+    if global_sort:
+        monkeypatch.setenv("FORMA_HIP_GLOBAL_RUNSORT", "1")
+    scenes = [(S.random_mixed(n=400, width=640, height=480, seed=41), 640, 480),
+              (S.random_mixed(n=2500, width=2048, height=64, seed=42), 2048, 64),
+              (S.random_mixed(n=150, width=100, height=700, seed=43), 100, 700),
+              (S.random_mixed(n=60, width=256, height=48, seed=44), 256, 48)]
+    wide = S.Composition()                                      # 300 canvas-wide bars: every span crosses all 8 groups
+    for i in range(300):
+        wide.get_mut_or_insert_default(i).insert(S.custom_square(3 + (i % 5), (i * 7) % 90, 2040 - (i % 11), (i * 7) % 90 + 9)).set_props(
+            S.Props(fill=(0.1 + (i % 7) * 0.1, 0.5, 0.9 - (i % 5) * 0.1, 0.6)))
+    scenes.append((wide, 2048, 96))
+    for k, (comp, W, H) in enumerate(scenes):
+        o = orc.Oracle()
+        t = comp.tables(o)
+        S.load(o, t)
+        want = o.render(W, H, clear=(0.3, 0.2, 0.1, 1.0))
+        c = forma_amd.Context(0)
+        try:
+            S.load(c, t)
+            for frame in range(3):
+                got = c.render(W, H, clear=(0.3, 0.2, 0.1, 1.0))
+                assert np.array_equal(got, want), (k, slices, frame)
+            bo, bc = np.zeros((H, W * 4), np.uint8), np.zeros((H, W * 4), np.uint8)
+            for frame in range(2):
+                o.render(W, H, cache_id=0, dst=bo); c.render(W, H, cache_id=0, dst=bc)
+                assert np.array_equal(bo, bc), (k, slices, frame)
+        finally:
+            c.close()

@@ -261,3 +261,34 @@ def test_gpu_fill_columns_match_the_oracle():
         assert np.array_equal(got, want), k
         assert len(np.unique(want.reshape(-1, 4), axis=0)) > 1, k       # the fill really varies over the tile
     c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nstops", [2, 3, 11, 12, 13, 22, 23, 40])
+def test_gpu_gradients_of_any_stop_count(nstops):
+    """the wave painter keeps a gradient's first 11 stops in LDS and walks longer ones window by window: linear and radial
+    gradients of 2..40 stops under partial coverage (circles), stacked with other blend modes, a texture-free clip and a solid
+    layer on top — pixels equal the oracle's (styling.rs:58-193; the reference has no limit on the stops)"""
+    import forma_amd
+    rng = np.random.default_rng(nstops)
+    cols = [tuple(float(v) for v in rng.uniform(0.0, 1.0, 3)) + (float(rng.uniform(0.3, 1.0)),) for _ in range(nstops)]
+    comp = S.Composition()
+    comp.get_mut_or_insert_default(0).insert(S.custom_square(0, 0, 96, 64)).set_props(S.Props(fill=(0.2, 0.3, 0.4, 1.0)))
+    comp.get_mut_or_insert_default(1).insert(S.custom_circle(40, 30, 28)).set_props(
+        S.Props(fill=S.gradient((3.0, 5.0), (90.0, 60.0), cols)))
+    comp.get_mut_or_insert_default(2).insert(S.custom_circle(60, 34, 25)).set_props(
+        S.Props(fill=S.gradient((60.0, 34.0), (85.0, 34.0), cols[::-1], radial=True), blend_mode="Multiply", fill_rule="EvenOdd"))
+    comp.get_mut_or_insert_default(3).insert(S.custom_circle(48, 32, 20)).set_props(S.Props(clip=2))
+    comp.get_mut_or_insert_default(4).insert(S.custom_square(10, 10, 90, 50)).set_props(
+        S.Props(fill=S.gradient((10.0, 50.0), (90.0, 10.0), cols), blend_mode="Hue", is_clipped=True))
+    comp.get_mut_or_insert_default(5).insert(S.custom_square(20, 20, 70, 60)).set_props(
+        S.Props(fill=(0.9, 0.1, 0.1, 0.5), blend_mode="Screen", is_clipped=True))
+    comp.get_mut_or_insert_default(6).insert(S.custom_circle(80, 50, 12)).set_props(S.Props(fill=(0.1, 0.8, 0.2, 0.7)))
+    o = orc.Oracle(); c = forma_amd.Context(0)
+    t = comp.tables(o)
+    S.load(o, t); S.load(c, t)
+    want = o.render(96, 64, clear=(1, 1, 1, 1))
+    got = c.render(96, 64, clear=(1, 1, 1, 1))
+    assert np.array_equal(got, want)
+    c.render(96, 64, clear=(1, 1, 1, 1))                                # read-back-free frames take the same painter
+    assert np.array_equal(c.render(96, 64, clear=(1, 1, 1, 1)), want)

@@ -20,11 +20,12 @@ for _ in range(N):
 L.forma_hip_debug_paint_prof(buf, 0)
 v = [x / N for x in buf]
 names = ["0 find runs+spans", "1 merge+flags", "2 passes", "3 solid fold+store", "4 fold failed", "5 painted list", "6 batch staging",
-         "7 seg accumulate", "8 cover/fill/blend", "9 srgb+store"]
+         "7 seg accumulate", "8 cover/blend solid+Over", "9 srgb+store", "10 cover/fill/blend other"]
 tiles = v[16]
-tot = sum(v[:10])
+tot = sum(v[:11])
 print(f"{wl}: tiles {tiles:.0f}, entries/tile {v[17]/tiles:.1f}, row spans/tile {v[18]/tiles:.1f}, solid tiles {v[19]:.0f}, "
       f"painted entries/tile {v[20]/max(tiles - v[19], 1):.1f}, segments accumulated/tile {v[21]/max(tiles - v[19], 1):.1f}")
 for i, n in enumerate(names):
     print(f"  {n:22s} {v[i]/tiles:9.0f} cycles/tile  {100*v[i]/tot:5.1f}%")
 print(f"  total {tot/tiles:.0f} cycles per tile (wave-serial)")
+print(f"  solid/Over layers painted {v[23]:.0f}: {v[8]/max(v[23],1):.0f} cycles each;  other layers {v[22]:.0f}: {v[10]/max(v[22],1):.0f} cycles each")
