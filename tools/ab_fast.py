@@ -53,7 +53,7 @@ def child(args):
         c.render(W, H, clear=clear, device_only=True)
     c.sync()
     fps1 = args.frames / (time.perf_counter() - t0)
-    c.set_frames_in_flight(3)
+    c.set_frames_in_flight(int(os.environ.get("AB_INFLIGHT", "3")))   # (AB_INFLIGHT: slots for the pipelined rate)
     for _ in range(6):
         c.render(W, H, clear=clear, device_only=True)
     c.sync()
