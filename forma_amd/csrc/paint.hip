@@ -1137,7 +1137,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
             const uint32_t e = e0 + (uint32_t)lane;
             const uint32_t lhu = e < S ? lohi_at(e) : 0u;
             const uint32_t lh = lhu & 0x7FFFFFFFu;
-            const bool hit = (lh >> 16) < x1 && (lh & 0xFFFFu) > x0;
+            const bool hit = (lh >> 16) < x1 && (lh & 0xFFFFu) > x0 && (lh & 0xFFFFu) > (lh >> 16);    // (as counted above)
             const uint64_t bal = __ballot(hit);
             if (hit) {
                 const uint32_t khi = LOCAL ? s_khi[e] : (uint32_t)(span_key[sb0 + e] >> 32);
@@ -1545,39 +1545,49 @@ __device__ __forceinline__ void gradient_at_lds(uint32_t* ws, const uint32_t* __
 // The span lists of a tile row: one per slice of the carry pre-pass (launch_carry_rows), ascending layers from slice to slice.
 // The painters see them as ONE logical list [0, total): logical index -> position in the span arrays by <= 7 compares
 // (uniform; a row with one slice pays nothing).
-struct SpanLists { uint32_t n, total; uint32_t pre[CR_MAX_SLICES], base[CR_MAX_SLICES]; };
-__device__ __forceinline__ SpanLists load_span_lists(const uint32_t* __restrict__ row_span_lo, const uint32_t* __restrict__ row_span_cnt,
-                                                     uint32_t ty, uint32_t n_slices) {
-    SpanLists L;
+// NS = 1: the kernel variant for frames whose rows have ONE slice (every whole-frame render: slices are for multi-GPU bands) —
+// the mapping is an add and the lists cost 2 scalar registers instead of 18.
+template <int NS> struct SpanListsT { uint32_t n, total; uint32_t pre[NS], base[NS]; };
+typedef SpanListsT<CR_MAX_SLICES> SpanLists;
+template <int NS>
+__device__ __forceinline__ SpanListsT<NS> load_span_lists_t(const uint32_t* __restrict__ row_span_lo, const uint32_t* __restrict__ row_span_cnt,
+                                                            uint32_t ty, uint32_t n_slices) {
+    SpanListsT<NS> L;
     L.n = n_slices; L.total = 0;
-    uint32_t b[CR_MAX_SLICES], c[CR_MAX_SLICES];
+    uint32_t b[NS], c[NS];
 #pragma unroll
-    for (int q = 0; q < CR_MAX_SLICES; q++) {              // (all loads in flight together)
+    for (int q = 0; q < NS; q++) {                         // (all loads in flight together)
         const bool in = (uint32_t)q < n_slices;
         b[q] = in ? row_span_lo[ty * n_slices + q] : 0u; c[q] = in ? row_span_cnt[ty * n_slices + q] : 0u;
     }
 #pragma unroll
-    for (int q = 0; q < CR_MAX_SLICES; q++) { L.pre[q] = L.total; L.base[q] = b[q]; L.total += c[q]; }
+    for (int q = 0; q < NS; q++) { L.pre[q] = L.total; L.base[q] = b[q]; L.total += c[q]; }
     return L;
+}
+__device__ __forceinline__ SpanLists load_span_lists(const uint32_t* __restrict__ row_span_lo, const uint32_t* __restrict__ row_span_cnt,
+                                                     uint32_t ty, uint32_t n_slices) {
+    return load_span_lists_t<CR_MAX_SLICES>(row_span_lo, row_span_cnt, ty, n_slices);
 }
 // the same for one tile-column group: tab points at the group's entry of slice 0, the slices are n_groups entries apart.
 // total = SPAN_GROUP_NONE: some slice of the row has no group lists (pool full) — the caller scans the row lists instead.
-__device__ __forceinline__ SpanLists load_group_lists(const uint2* __restrict__ tab, uint32_t n_groups, uint32_t n_slices) {
-    SpanLists L;
+template <int NS>
+__device__ __forceinline__ SpanListsT<NS> load_group_lists(const uint2* __restrict__ tab, uint32_t n_groups, uint32_t n_slices) {
+    SpanListsT<NS> L;
     L.n = n_slices; L.total = 0;
-    uint2 t[CR_MAX_SLICES];
+    uint2 t[NS];
 #pragma unroll
-    for (int q = 0; q < CR_MAX_SLICES; q++) t[q] = (uint32_t)q < n_slices ? tab[(size_t)q * n_groups] : make_uint2(0u, 0u);
+    for (int q = 0; q < NS; q++) t[q] = (uint32_t)q < n_slices ? tab[(size_t)q * n_groups] : make_uint2(0u, 0u);
     bool none = false;
 #pragma unroll
-    for (int q = 0; q < CR_MAX_SLICES; q++) { L.pre[q] = L.total; L.base[q] = t[q].x; L.total += t[q].y; none |= t[q].y == SPAN_GROUP_NONE; }
+    for (int q = 0; q < NS; q++) { L.pre[q] = L.total; L.base[q] = t[q].x; L.total += t[q].y; none |= t[q].y == SPAN_GROUP_NONE; }
     if (none) L.total = SPAN_GROUP_NONE;
     return L;
 }
-__device__ __forceinline__ uint32_t span_phys(const SpanLists& L, uint32_t i) {
+template <int NS>
+__device__ __forceinline__ uint32_t span_phys(const SpanListsT<NS>& L, uint32_t i) {
     uint32_t p = L.base[0] + i;
 #pragma unroll
-    for (int q = 1; q < CR_MAX_SLICES; q++) {
+    for (int q = 1; q < NS; q++) {
         if ((uint32_t)q >= L.n) break;
         if (i >= L.pre[q]) p = L.base[q] + (i - L.pre[q]);
     }
@@ -2023,7 +2033,8 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // SIMPLE: every layer of the scene is a solid colour blended with BlendMode::Over and nothing is a clip or clipped (the host
 // knows from the style table, forma_hip_set_styles) — the fills, the sixteen blend modes and the clip state machine are
 // not even compiled in, which is worth registers (occupancy), instruction cache and the per-layer dispatch.
-template <bool SIMPLE>
+// ONE_SLICE: the carry pre-pass ran one workgroup per tile row (P.n_slices == 1): SpanListsT<1>.
+template <bool SIMPLE, bool ONE_SLICE>
 __global__ __launch_bounds__(64, SIMPLE ? PAINT_SIMPLE_OCC : PAINT_GENERIC_OCC) void k_paint_wave(PaintParams P, const uint64_t* __restrict__ sorted,
                                                     const TileRecord* __restrict__ records, DevCount nc_runs,
                                                     const uint32_t* __restrict__ tile_first_run,
@@ -2079,10 +2090,11 @@ __global__ __launch_bounds__(64, SIMPLE ? PAINT_SIMPLE_OCC : PAINT_GENERIC_OCC) 
     const uint32_t j0 = tile_first_run[tile] - 1u;                      // 0 stored = no run -> FORMA_NONE
     // the spans that may cross this tile: its tile-column group's lists (one per slice; SpanGroups in common.h), or — no group
     // lists this frame, or the pool was full for this row — the row's
-    SpanLists SL = load_span_lists(row_span_lo, row_span_cnt, ty, P.n_slices);      // (both tables requested at once)
+    constexpr int NS = ONE_SLICE ? 1 : CR_MAX_SLICES;
+    SpanListsT<NS> SL = load_span_lists_t<NS>(row_span_lo, row_span_cnt, ty, P.n_slices);      // (both tables requested at once)
     bool by_group = groups.tab != nullptr;
     if (by_group) {
-        const SpanLists GL = load_group_lists(groups.tab + (size_t)ty * P.n_slices * P.n_groups + (tx >> SPAN_GROUP_SHIFT), P.n_groups, P.n_slices);
+        const SpanListsT<NS> GL = load_group_lists<NS>(groups.tab + (size_t)ty * P.n_slices * P.n_groups + (tx >> SPAN_GROUP_SHIFT), P.n_groups, P.n_slices);
         if (GL.total == SPAN_GROUP_NONE) by_group = false;              // (uniform)
         else SL = GL;
     }
@@ -2525,16 +2537,15 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
     const uint32_t T = p.tiles_w * p.tiles_h;
     if (T == 0 || p.crop_y1 <= p.crop_y0) return;
     const uint32_t per = ((p.crop_y1 - p.crop_y0) * p.tiles_w + 7) / 8;
-    static const bool no_simple = getenv("FORMA_HIP_NO_SIMPLE_PAINT") != nullptr;      // (A/B switch for tools/)
+    static const bool no_simple = getenv("FORMA_HIP_NO_SIMPLE_PAINT") != nullptr;      // (A/B switches for tools/)
     static const bool force_simple = getenv("FORMA_HIP_FORCE_SIMPLE_PAINT") != nullptr;  // (timing experiments only: wrong pixels on other scenes)
-    if ((p.scene_simple && !no_simple) || force_simple)
-        hipLaunchKernelGGL(k_paint_wave<true>, dim3(per * 8), dim3(64), 0, s, p, sorted, records, n_runs, tile_first_run, row_span_lo,
-                           row_span_cnt, span_key, span_cov, layer_col, style_offsets, style_words, images, texels, image,
-                           cache, info, overflow_n, overflow_list, launch_deep ? 1u : 0u, groups);
-    else
-        hipLaunchKernelGGL(k_paint_wave<false>, dim3(per * 8), dim3(64), 0, s, p, sorted, records, n_runs, tile_first_run, row_span_lo,
-                           row_span_cnt, span_key, span_cov, layer_col, style_offsets, style_words, images, texels, image,
-                           cache, info, overflow_n, overflow_list, launch_deep ? 1u : 0u, groups);
+    const bool simple = (p.scene_simple && !no_simple) || force_simple, one = p.n_slices == 1u;
+#define PW_LAUNCH(S_, O_) hipLaunchKernelGGL((k_paint_wave<S_, O_>), dim3(per * 8), dim3(64), 0, s, p, sorted, records, n_runs, tile_first_run, \
+                                             row_span_lo, row_span_cnt, span_key, span_cov, layer_col, style_offsets, style_words, images, \
+                                             texels, image, cache, info, overflow_n, overflow_list, launch_deep ? 1u : 0u, groups)
+    if (simple) { if (one) PW_LAUNCH(true, true); else PW_LAUNCH(true, false); }
+    else { if (one) PW_LAUNCH(false, true); else PW_LAUNCH(false, false); }
+#undef PW_LAUNCH
     if (!launch_deep) return;                             // (read-back-free frame of a scene whose last frame had no deep tile)
     hipLaunchKernelGGL(k_paint_deep, dim3(T < 256 ? T : 256), dim3(256), 0, s, p, sorted, records, n_runs, tile_first_run,
                        row_span_lo, row_span_cnt, span_key, span_cov, layer_col, style_offsets, style_words, images,
