@@ -2100,14 +2100,19 @@ __global__ __launch_bounds__(64, SIMPLE ? PAINT_SIMPLE_OCC : PAINT_GENERIC_OCC) 
     }
     const uint32_t sc = SL.total;
     if (plan_bad) return;
-    uint64_t sk[4];                                                     // (row list: the span key; group list: lo | hi << 16 in the low word)
-    uint4 ge[4];
+    // a candidate span as three words, whichever list it comes from: the entry (high word = layer | style bits, low word =
+    // reference) and lo | hi << 16
+    uint32_t eh[4], el[4], lh[4];
+    auto fetch = [&](uint32_t i, uint32_t& h, uint32_t& l, uint32_t& x) {
+        h = 0; l = 0; x = 0;                                            // padding: lo = hi = 0, crosses nothing
+        if (i < sc) {
+            const uint32_t ph = span_phys(SL, i);
+            if (by_group) { const uint4 g = groups.list[ph]; h = g.x; l = g.y; x = g.z; }
+            else { const uint64_t k = span_key[ph]; h = (uint32_t)(k >> 32); x = (uint32_t)k; l = REF_SPAN | ((x >> 31) ? REF_UNCH : 0u) | ph; }
+        }
+    };
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const uint32_t i = u * 64 + lane;
-        if (by_group) { ge[u] = i < sc ? groups.list[span_phys(SL, i)] : make_uint4(0u, 0u, 0u, 0u); sk[u] = 0; }
-        else { sk[u] = i < sc ? span_key[span_phys(SL, i)] : 0ull; ge[u] = make_uint4(0u, 0u, 0u, 0u); }
-    }
+    for (int u = 0; u < 4; u++) fetch(u * 64 + lane, eh[u], el[u], lh[u]);
     uint32_t na = 0;
     if (j0 != FORMA_NONE) {
         for (uint32_t c = 0;; c += 64) {                                // a tile's runs are contiguous from j0
@@ -2124,23 +2129,16 @@ __global__ __launch_bounds__(64, SIMPLE ? PAINT_SIMPLE_OCC : PAINT_GENERIC_OCC) 
     for (uint32_t c = 0; c < sc; c += 256) {
         if (c) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t i = c + u * 64 + lane;
-                if (by_group) ge[u] = i < sc ? groups.list[span_phys(SL, i)] : make_uint4(0u, 0u, 0u, 0u);
-                else sk[u] = i < sc ? span_key[span_phys(SL, i)] : 0ull;
-            }
+            for (int u = 0; u < 4; u++) fetch(c + u * 64 + lane, eh[u], el[u], lh[u]);
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const uint32_t lh = by_group ? ge[u].z : (uint32_t)sk[u];
-            const uint32_t lo = (lh >> 16) & 0x7FFFu, hi = lh & 0xFFFFu;                                  // padding: lo = hi = 0
+            const uint32_t lo = (lh[u] >> 16) & 0x7FFFu, hi = lh[u] & 0xFFFFu;
             const bool hit = tx >= lo && tx < hi;
             const uint64_t bal = __ballot(hit);
             if (hit) {
                 const uint32_t pos = na + nb + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                const uint64_t ent = by_group ? (((uint64_t)ge[u].x << 32) | ge[u].y)
-                                              : ((sk[u] & 0xFFFFFFFF00000000ull) | REF_SPAN | (((uint32_t)sk[u] >> 31) ? REF_UNCH : 0u) | span_phys(SL, c + u * 64 + lane));
-                if (pos < WMAX) tmp[pos] = ent;
+                if (pos < WMAX) tmp[pos] = ((uint64_t)eh[u] << 32) | el[u];
             }
             nb += (uint32_t)__popcll(bal);
         }
@@ -2466,15 +2464,21 @@ __global__ __launch_bounds__(64, SIMPLE ? PAINT_SIMPLE_OCC : PAINT_GENERIC_OCC) 
         }
     }
     // ---- compute_srgb :466-483 + channel select, straight to the row-major RGBA8 image ----------------------------------
+    uint32_t chan_sel = 0;                                              // v_perm_b32 selector: channel.rs:44-55 as byte indices
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const uint32_t ch = (P.channels >> (8 * c)) & 0xFFu;
+        chan_sel |= (ch <= 3u ? ch : (ch == 4u ? 0x0Cu : 0x0Du)) << (8 * c);     // 0x0C -> 0x00 (Zero), 0x0D -> 0xFF (One)
+    }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const uint32_t py = ty * 16u + (uint32_t)(rg * 4 + q);
         if (px < P.width && py < P.height) {
             const float sr = linear_to_srgb(dr[q]), sg = linear_to_srgb(dg[q]), sb2 = linear_to_srgb(db[q]);
-            uint32_t out = 0;
-#pragma unroll
-            for (int c = 0; c < 4; c++) out |= to_u8_x8(sel_channel((P.channels >> (8 * c)) & 0xFFu, sr, sg, sb2, da[q])) << (8 * c);
-            ((uint32_t*)image)[(size_t)py * P.stride_px + px] = out;
+            // the four candidates as bytes once, then the channel order with one byte permute (the selectors are uniform; a
+            // float select per output channel was 16 compare-and-select chains per lane)
+            const uint32_t rgba = to_u8_x8(sr) | (to_u8_x8(sg) << 8) | (to_u8_x8(sb2) << 16) | (to_u8_x8(da[q]) << 24);
+            ((uint32_t*)image)[(size_t)py * P.stride_px + px] = __builtin_amdgcn_perm(0u, rgba, chan_sel);
         }
     }
     PP_STAMP(9);                                                        // 9: sRGB encode + store
