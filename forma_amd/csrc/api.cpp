@@ -235,13 +235,16 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     const size_t cap = std::max<size_t>(bound_j ? bound_j : n, 1);
     HIPCHECK(ctx->records.ensure(cap * sizeof(TileRecord)));
     HIPCHECK(ctx->rk_u.ensure(cap * 8));
+    HIPCHECK(ctx->run_lt.ensure(cap * 4));
     HIPCHECK(ctx->blk_edge.ensure(runs_blocks(std::max<size_t>(n, 1)) * sizeof(BlkEdge)));
     HIPCHECK(ctx->runs_scratch.ensure(runs_scratch_words(std::max<size_t>(n, 1)) * 4));
     stage_begin(ctx, ST_CARRY, timing);
     launch_runs(ctx->stream, ctx->sorted, nc, tiles_w, tiles_h, ctx->records.as<TileRecord>(), (uint32_t)cap,
                 ctx->rk_u.as<uint64_t>(), tile_first_run, ctx->blk_edge.as<BlkEdge>(), row_count,
                 ctx->runs_scratch.as<uint32_t>(), dinfo, /*verify_plan=*/bound_j != 0 && ctx->speculated, ctx->live44,
-                ctx->layer_sorted, ctx->legacy_runs, ctx->pending_masks);
+                ctx->layer_sorted, ctx->legacy_runs, ctx->pending_masks,
+                RunStyle{ctx->layer_sf.as<uint32_t>(), (uint32_t)ctx->n_orders,
+                         (a.cache_id >= 0 && ctx->have_unchanged) ? ctx->unchanged.as<uint8_t>() : nullptr, ctx->run_lt.as<uint32_t>()});
     ctx->pending_masks = PendingMasks{nullptr, 0u};
     HIPCHECK(hipGetLastError());
     DevCount jc;
@@ -335,7 +338,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                           runs_edge_segments(ctx->legacy_runs),
                           // invisible carries of a partial last tile row are dropped only when nothing can observe them: with a
                           // buffer-layer cache the layer count of a tile is state (passes/tile_unchanged.rs)
-                          (a.cache_id < 0 && (a.height & 15u)) ? (a.height & 15u) : 16u, crow0, crow1, groups);
+                          (a.cache_id < 0 && (a.height & 15u)) ? (a.height & 15u) : 16u, crow0, crow1, groups, ctx->run_lt.as<uint32_t>());
     } else {
         HIPCHECK(ctx->span_key.ensure(8));
         HIPCHECK(ctx->span_cov.ensure(16));
@@ -615,7 +618,8 @@ void forma_hip_destroy(forma_hip_ctx* ctx) {
                      &ctx->sort_counters, &ctx->info, &ctx->info_init, &ctx->records, &ctx->rk_u, &ctx->rk_a, &ctx->rk_b,
                      &ctx->blk_edge, &ctx->runs_scratch, &ctx->row_tab, &ctx->span_key, &ctx->span_cov,
                      &ctx->image, &ctx->xsend, &ctx->xrecv, &ctx->xscratch,
-                     &ctx->ras_masks, &ctx->xmask, &ctx->huge_offs, &ctx->huge_key, &ctx->huge_tmp, &ctx->huge_flag};
+                     &ctx->ras_masks, &ctx->xmask, &ctx->huge_offs, &ctx->huge_key, &ctx->huge_tmp, &ctx->huge_flag,
+                     &ctx->grp_tab, &ctx->grp_list, &ctx->run_lt};
     for (DevBuf* b : all) b->release();
     for (int s = 0; s < ST_COUNT; s++) { (void)hipEventDestroy(ctx->ev0[s]); (void)hipEventDestroy(ctx->ev1[s]); }
     for (int p = 0; p < MAX_PASS_EVENTS; p++) { (void)hipEventDestroy(ctx->pev0[p]); (void)hipEventDestroy(ctx->pev1[p]); }

@@ -201,11 +201,23 @@ struct BlkEdge {             // what a k_runs tile contributes to a run that sta
 size_t runs_scratch_words(size_t n);
 size_t runs_blocks(size_t n);
 // run detection + per-run cover sums; row_tab = [row_count | row_span_lo | row_span_cnt], (tiles_h + 1) words each
+// What the run kernels attach to a record beyond the geometry — they run on the whole chip, k_carry_rows on one CU per tile
+// row, where every scattered access per run is a cycle of that CU's address unit: the layer's style bits (SF_*, bits 21.. of
+// the record's layer word) and "unchanged" flag (bit 31 of its tile word), and a 32-bit digest per run, in stream order,
+// that lets the carry pre-pass order a row and find the tile columns WITHOUT touching the records:
+//   run_lt[j] = (layer & 0xFFFF) << 16 | open << 15 | tile_x + 1        (open: the run continues past its chunk)
+struct RunStyle {
+    const uint32_t* layer_sf;     // per order: SF_* | LSF_VALID
+    uint32_t        n_orders;
+    const uint8_t*  unchanged;    // per order, nullable (Layer::is_unchanged(cache_id) of this frame's cache)
+    uint32_t*       run_lt;       // one word per run (rec_cap)
+};
+#define RUN_LT_OPEN 0x8000u
 void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount n, uint32_t tiles_w, uint32_t tiles_h, TileRecord* records,
                  uint32_t rec_cap, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge,
                  uint32_t* row_tab, uint32_t* scratch, FrameInfo* info, bool verify_plan, uint64_t spec_live44,
                  bool spec_layer_sorted, bool legacy /* workgroup-per-tile kernel with LDS bins instead of the wave kernel */,
-                 PendingMasks pm);
+                 PendingMasks pm, RunStyle rs);
 uint32_t runs_edge_segments(bool legacy);   // segments per BlkEdge entry of the kernel launch_runs picks
 // style flags of a layer as the carry pre-pass and the painter pass them around (bits 21.. of a record's layer word)
 #define SF_FULL        0x001u     // spans only: Cover::is_full (painter/mod.rs:200-215)
@@ -233,7 +245,7 @@ void launch_carry_rows(hipStream_t s, bool local_sort, bool small, uint32_t n_sl
                        uint32_t edge_segs,
                        uint32_t vis_last /* visible pixel rows of the last tile row (height % 16, 16 if 0) */,
                        uint32_t row0, uint32_t row1 /* the tile rows that are painted (the crop): only those get workgroups */,
-                       SpanGroups groups /* tab == nullptr: no group lists */);
+                       SpanGroups groups /* tab == nullptr: no group lists */, const uint32_t* run_lt /* RunStyle::run_lt */);
 void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, DevCount n_runs,
                   const uint32_t* tile_first_run, const uint32_t* row_span_lo, const uint32_t* row_span_cnt,
                   const uint64_t* span_key, const uint4* span_cov,

@@ -46,6 +46,7 @@ struct forma_hip_ctx {
     uint32_t max_image_index = 0;           // largest image index a texture style names
     bool any_texture = false;
     bool scene_has_clips = false;
+    DevBuf run_lt;                  // one word per run: layer16 | open | tile_x + 1 (RunStyle, common.h)
     DevBuf grp_tab, grp_list;       // span group lists (SpanGroups, common.h): table per (row, slice, group) and the entry pool
     bool no_span_groups = false;    // FORMA_HIP_NO_SPAN_GROUPS (A/B switch for tools/)
     bool force_span_groups = false; // FORMA_HIP_SPAN_GROUPS: on every frame and for every row, however few spans (tests)

@@ -88,6 +88,14 @@ __device__ __forceinline__ uint4 pack_bins(const int* b) {
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// what a run kernel adds to the record of a run of `layer` (RunStyle, common.h): the words stored as the record's layer and tile
+__device__ __forceinline__ uint2 run_style_words(const RunStyle& rs, uint32_t layer, uint32_t tile) {
+    const uint32_t lsf = layer < rs.n_orders ? rs.layer_sf[layer] : 0u;
+    const uint32_t sfl = (lsf & LSF_VALID) ? (lsf & ~LSF_VALID) : 0u;   // (a layer without a style: k_carry_rows reports it)
+    const uint32_t unch = (rs.unchanged && layer < rs.n_orders && rs.unchanged[layer]) ? 0x80000000u : 0u;
+    return make_uint2(layer | (sfl << 21), tile | unch);
+}
+
 // pass A: paintable run heads per tile (the run index of a tile's first head is the exclusive scan of these)
 #define RC_THREADS 256
 __global__ __launch_bounds__(RC_THREADS) void k_runs_count(const uint64_t* __restrict__ sorted, DevCount nc, uint32_t tiles_w,
@@ -193,7 +201,7 @@ __global__ __launch_bounds__(RN_THREADS, 8) void k_runs(const uint64_t* __restri
                                                         uint32_t* __restrict__ tile_first_run,
                                                         BlkEdge* __restrict__ blk_edge, uint32_t* __restrict__ row_count,
                                                         const uint32_t* __restrict__ run_counts, int counts_scanned,
-                                                        FrameInfo* __restrict__ info) {
+                                                        FrameInfo* __restrict__ info, RunStyle rs) {
     __shared__ uint64_t s_seg[RN_TILE + 1];                   // [0] = element before the tile, tile at [1 + i]
     __shared__ int s_bins[RN_SLOTS * RN_STRIDE];
     __shared__ uint16_t s_start[RN_TILE + 2];                 // s_start[slot] = tile-local index of the slot's first segment
@@ -308,10 +316,12 @@ __global__ __launch_bounds__(RN_THREADS, 8) void k_runs(const uint64_t* __restri
                 TileRecord rec;
                 const uint4 own = pack_bins(b);                                  // the run's own cover sum; k_carry_rows turns it
                 rec.cover[0] = own.x; rec.cover[1] = own.y; rec.cover[2] = own.z; rec.cover[3] = own.w;   // into the carry-in
-                rec.seg_start = base + i; rec.seg_count = cnt | open; rec.layer = layer; rec.tile = (uint32_t)(v >> 41);
+                const uint2 sw = run_style_words(rs, layer, (uint32_t)(v >> 41));
+                rec.seg_start = base + i; rec.seg_count = cnt | open; rec.layer = sw.x; rec.tile = sw.y;
                 if (j < rec_cap) {                                  // asynchronous frames provision for a predicted run count
                     records[j] = rec;
                     run_keys[j] = ((uint64_t)tyb << 53) | ((uint64_t)layer << 32) | j;
+                    rs.run_lt[j] = ((layer & 0xFFFFu) << 16) | (open ? RUN_LT_OPEN : 0u) | txb;
                 }
                 if (txb >= 1u && ((uint32_t)(pv >> 41) != (uint32_t)(v >> 41) || base + i == 0))
                     tile_first_run[(tyb - 1u) * tiles_w + (txb - 1u)] = j + 1u;        // 0 = the tile has no run
@@ -388,7 +398,7 @@ __global__ __launch_bounds__(RW_THREADS) void k_runs_wave(const uint64_t* __rest
                                                           uint32_t* __restrict__ row_count,
                                                           const uint32_t* __restrict__ run_counts, int counts_scanned,
                                                           const uint32_t* __restrict__ chunk_counts,
-                                                          FrameInfo* __restrict__ info) {
+                                                          FrameInfo* __restrict__ info, RunStyle rs) {
     __shared__ RunWaveLds s_w[RW_WAVES];
     __shared__ uint32_t s_rows[RN_ROWS];
     __shared__ uint32_t s_jb[RW_WAVES];
@@ -528,11 +538,13 @@ __global__ __launch_bounds__(RW_THREADS) void k_runs_wave(const uint64_t* __rest
             const uint32_t j = jnext + __builtin_amdgcn_mbcnt_hi((uint32_t)(bv >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bv, 0u));
             const uint32_t open = (sg == R && chunk_n == RW_CHUNK) ? RUN_OPEN : 0u;
             const uint32_t layer = ((khi & 0x1FFu) << 12) | (klo >> 20);
+            const uint2 sw = run_style_words(rs, layer, tile);          // (one gather per run, here on all 256 CUs)
             if (j < rec_cap) {                                          // asynchronous frames provision for a predicted run count
                 uint4* rp = reinterpret_cast<uint4*>(&records[j]);
                 rp[0] = pack_bins(b);                                   // the run's own cover sum; k_carry_rows turns it into the carry-in
-                rp[1] = make_uint4(cbase + st, (st_next - st) | open, layer, tile);
+                rp[1] = make_uint4(cbase + st, (st_next - st) | open, sw.x, sw.y);
                 run_keys[j] = ((uint64_t)tyb << 53) | ((uint64_t)layer << 32) | j;
+                rs.run_lt[j] = ((layer & 0xFFFFu) << 16) | (open ? RUN_LT_OPEN : 0u) | txb;
             }
             if (txb >= 1u && new_tile) tile_first_run[(tyb - 1u) * tiles_w + (txb - 1u)] = j + 1u;   // 0 = the tile has no run
             const uint32_t rr = (tyb - 1u) - row0;
@@ -557,7 +569,7 @@ size_t runs_blocks(size_t n) { return (n + RW_CHUNK - 1) / RW_CHUNK + 4; }      
 void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t tiles_w, uint32_t tiles_h, TileRecord* records,
                  uint32_t rec_cap, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge, uint32_t* row_tab,
                  uint32_t* scratch, FrameInfo* info, bool verify_plan, uint64_t spec_live44, bool spec_layer_sorted, bool legacy,
-                 PendingMasks pm) {
+                 PendingMasks pm, RunStyle rs) {
     // per-frame tile tables: [row_count | row_span_lo | row_span_cnt | painter overflow counters (2) | first-run table] are
     // contiguous (api.cpp lays them out so) and zeroed by k_runs_count; 0 in the first-run table = the tile has no run
     const uint32_t zero_words = row_tab_zero_words(tiles_w, tiles_h);
@@ -576,11 +588,11 @@ void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t ti
     if (scanned) launch_scan_small_u32(s, scratch, nc, RN_TILE, &info->n_runs);   // exclusive, in place; total -> n_runs
     if (legacy)
         hipLaunchKernelGGL(k_runs, dim3(ntiles), dim3(RN_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, records, rec_cap, run_keys,
-                           tile_first_run, blk_edge, row_tab, (const uint32_t*)scratch, scanned, info);
+                           tile_first_run, blk_edge, row_tab, (const uint32_t*)scratch, scanned, info, rs);
     else
         hipLaunchKernelGGL(k_runs_wave, dim3(ntiles), dim3(RW_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, records, rec_cap,
                            run_keys, tile_first_run, blk_edge, row_tab, (const uint32_t*)scratch, scanned,
-                           (const uint32_t*)chunk_counts, info);
+                           (const uint32_t*)chunk_counts, info, rs);
 }
 uint32_t runs_edge_segments(bool legacy) { return legacy ? RN_TILE : RW_CHUNK; }
 
@@ -628,25 +640,36 @@ __device__ __forceinline__ CarryLoad carry_load(uint32_t c0, int tid, uint32_t c
                                                 uint32_t kbase /* !LOCAL: first sorted key of the slice */, uint32_t n_runs, uint32_t ty,
                                                 const uint32_t* lkeys, const uint64_t* __restrict__ sorted_keys,
                                                 const TileRecord* __restrict__ records,
-                                                const uint32_t* __restrict__ layer_sf, uint32_t n_orders) {
+                                                const uint32_t* __restrict__ layer_sf, uint32_t n_orders,
+                                                const uint16_t* s_txo /* LOCAL, one slice: the row's run_lt low halves in LDS */,
+                                                const uint32_t* __restrict__ run_lt) {
     CarryLoad L;
     const uint32_t k = (LOCAL ? row_lo : kbase) + c0 + tid;
     L.active = c0 + tid < cnt && k < n_runs;
     L.group = 0xFFFFFFFEu; L.jrun = 0; L.layer = 0; L.tile = 0; L.sc = 0; L.seg_start = 0; L.lsf = 0;
     L.oc = make_uint4(0, 0, 0, 0);
     if (L.active) {
+        // Every scattered access is a cycle of this CU's address unit (a row's workgroup is alone on its CU): LOCAL takes the
+        // tile column and the "open" flag from the run digests (k_runs_wave's run_lt: in LDS when the row has one slice) and
+        // gathers ONLY the run's cover sum; the record's second half is read for the rare run that crosses its chunk.
+        const uint4* rp;
         if (LOCAL) {
             const uint32_t pk = lkeys[c0 + tid];
-            L.layer = pk >> 16; L.jrun = row_lo + (pk & 0xFFFFu); L.group = ((ty + 1u) << 21) | L.layer;
+            const uint32_t e = pk & 0xFFFFu;
+            L.layer = pk >> 16; L.jrun = row_lo + e; L.group = ((ty + 1u) << 21) | L.layer;
+            rp = reinterpret_cast<const uint4*>(&records[L.jrun]);
+            const uint32_t txo = s_txo ? (uint32_t)s_txo[e] : (run_lt[L.jrun] & 0xFFFFu);
+            L.tile = ((ty + 1u) << 12) | (txo & 0xFFFu);
+            if (txo & RUN_LT_OPEN) { const uint4 tail = rp[1]; L.seg_start = tail.x; L.sc = tail.y; }
         } else {
             const uint64_t key = sorted_keys[k];
             L.group = (uint32_t)(key >> 32); L.jrun = (uint32_t)key; L.layer = L.group & 0x1FFFFFu;
+            // the record in two 16-byte gathers (one cache line): own cover sum | seg_start, seg_count, layer, tile
+            rp = reinterpret_cast<const uint4*>(&records[L.jrun]);
+            const uint4 tail = rp[1];
+            L.seg_start = tail.x; L.sc = tail.y; L.tile = tail.w & 0x7FFFFFFFu;
         }
-        // the record in two 16-byte gathers (one cache line): own cover sum | seg_start, seg_count, layer, tile
-        const uint4* rp = reinterpret_cast<const uint4*>(&records[L.jrun]);
         L.oc = rp[0];
-        const uint4 tail = rp[1];
-        L.seg_start = tail.x; L.sc = tail.y; L.tile = tail.w;
         if (L.layer < n_orders) L.lsf = layer_sf[L.layer];
     }
     return L;
@@ -683,7 +706,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
                                                            uint32_t vis_last /* visible pixel rows of the last tile row, 16 = all */,
                                                            uint32_t n_slices, uint32_t bin_shift,
                                                            uint32_t row0 /* first tile row that is painted: blockIdx.x = 0 */,
-                                                           SpanGroups groups) {
+                                                           SpanGroups groups, const uint32_t* __restrict__ run_lt) {
     constexpr int CR_RPT = RPT;                        // consecutive runs of the (layer, tile_x) order per lane in the row walk
     constexpr int CR_PIECE = CR_THREADS * RPT;         // runs per piece
     constexpr bool NB_IN_IDLE = LOCAL && 2 * (CR_PIECE + 1) <= CAP;   // group / tile_x of a piece's runs live in the sort's idle buffer
@@ -758,7 +781,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
             if (tid < 256) s_group[tid] = 0;
             __syncthreads();
             for (uint32_t e = tid; e < cnt; e += CR_THREADS) {
-                const uint32_t bin = min(255u, (((uint32_t)(sorted_keys[row_lo + e] >> 32) & 0xFFFFu) >> bin_shift));
+                const uint32_t bin = min(255u, ((run_lt[row_lo + e] >> 16) >> bin_shift));
                 atomicAdd(&s_group[bin], 1u);
             }
             __syncthreads();
@@ -808,7 +831,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
                 const uint32_t e = e0 + (uint32_t)tid;
                 uint32_t l16 = 0; bool keep = false;
                 if (e < cnt) {
-                    l16 = (uint32_t)(sorted_keys[row_lo + e] >> 32) & 0xFFFFu;
+                    l16 = run_lt[row_lo + e] >> 16;
                     const uint32_t bin = min(255u, l16 >> bin_shift);
                     keep = bin >= blo && bin < bhi;
                 }
@@ -824,8 +847,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
             }
         } else {
             if (cnt > (uint32_t)CAP) { if (tid == 0) info->plan_bad = 1u; return; }
-            for (uint32_t e = tid; e < cnt; e += CR_THREADS)
-                s_ka[e] = (((uint32_t)(sorted_keys[row_lo + e] >> 32) & 0xFFFFu) << 16) | e;
+            for (uint32_t e = tid; e < cnt; e += CR_THREADS) s_ka[e] = (run_lt[row_lo + e] & 0xFFFF0000u) | e;
             __syncthreads();
         }
         if (tid == 0 && m) atomicMax(&info->max_slice_runs, m);
@@ -920,18 +942,27 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
     // cross-lane machinery and 27 % waiting for one round of gathers per piece: tools/cr_prof.py.)
     // Group / tile_x of every run of the piece (+ the run after it) sit in LDS for the neighbour tests; LOCAL: in the sort's
     // idle buffer.
-    uint32_t* a_group = NB_IN_IDLE ? (lkeys == s_ka ? s_kb : s_ka) : s_nb;
-    uint32_t* a_txb = a_group + (CR_PIECE + 1);
+    uint32_t* idle = lkeys == s_ka ? s_kb : s_ka;
+    uint32_t* a_group = NB_IN_IDLE ? idle : s_nb;
+    uint16_t* a_txb = reinterpret_cast<uint16_t*>(a_group + (CR_PIECE + 1));
+    // LOCAL, one slice per row: the low halves of the row's run digests (tile column + 1, "open" flag) by run index, next to them
+    uint16_t* s_txo = nullptr;
+    if (LOCAL && n_slices == 1u) {
+        s_txo = reinterpret_cast<uint16_t*>(NB_IN_IDLE ? idle + (CR_PIECE + 1) + (CR_PIECE + 4) / 2 : idle);
+        for (uint32_t e = tid; e < cnt; e += CR_THREADS) s_txo[e] = (uint16_t)run_lt[row_lo + e];
+        __syncthreads();
+    }
+    static_assert(!NB_IN_IDLE || (CR_PIECE + 1) + (CR_PIECE + 4) / 2 + CAP / 2 <= CAP, "group / tile_x / digest arrays share the idle sort buffer");
     for (uint32_t c0 = 0; c0 < m; c0 += CR_PIECE) {
         CRP_STAMP(4);                                                   // (rest of the previous piece: span compaction + stores)
         CarryLoad cl[CR_RPT];
 #pragma unroll
         for (int k = 0; k < CR_RPT; k++)
-            cl[k] = carry_load<LOCAL>(c0, tid * CR_RPT + k, m, row_lo, kbase, n_runs, ty, lkeys, sorted_keys, records, layer_sf, n_orders);
+            cl[k] = carry_load<LOCAL>(c0, tid * CR_RPT + k, m, row_lo, kbase, n_runs, ty, lkeys, sorted_keys, records, layer_sf, n_orders, s_txo, run_lt);
         if (tid == 0) {                                                 // the run after the piece: only its group and tile_x
-            const CarryLoad la = carry_load<LOCAL>(c0, CR_PIECE, m, row_lo, kbase, n_runs, ty, lkeys, sorted_keys, records, layer_sf, n_orders);
+            const CarryLoad la = carry_load<LOCAL>(c0, CR_PIECE, m, row_lo, kbase, n_runs, ty, lkeys, sorted_keys, records, layer_sf, n_orders, s_txo, run_lt);
             a_group[CR_PIECE] = la.active ? la.group : 0xFFFFFFFEu;
-            a_txb[CR_PIECE] = la.active ? (la.tile & 0xFFFu) : 0u;
+            a_txb[CR_PIECE] = (uint16_t)(la.active ? (la.tile & 0xFFFu) : 0u);
         }
         uint32_t group[CR_RPT], txb[CR_RPT], meta[CR_RPT];              // meta: sfl (11 bits) | unch << 11 | even_odd << 12 | active << 13
         uint64_t own_lo[CR_RPT], own_hi[CR_RPT];
@@ -960,16 +991,15 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
                     r->seg_count = sc;
                 }
                 if (cu.lsf & LSF_VALID) {
-                    // everything the painter's optimizer passes need to know about the layer's style, so that a tile can
-                    // classify its whole layer list without touching the style table (SF_* bits ride in the entry keys)
+                    // (the style bits and the "unchanged" flag are in the record already: the run kernel put them there, so that
+                    //  a tile can classify its layer list without touching the style table — here they go into the span keys)
                     sfl = cu.lsf & ~LSF_VALID;
                     even_odd = (sfl & SF_EVENODD) != 0;
-                    r->layer = cu.layer | (sfl << 21);
-                    if (unchanged && unchanged[cu.layer]) { unch = 1u; r->tile = cu.tile | 0x80000000u; }   // Layer::is_unchanged(cache_id)
+                    if (unchanged && unchanged[cu.layer]) unch = 1u;        // Layer::is_unchanged(cache_id)
                 } else atomicOr(&info->error, 1u);
             }
             meta[k] = sfl | (unch << 11) | ((even_odd ? 1u : 0u) << 12) | ((active ? 1u : 0u) << 13);
-            a_group[tid * CR_RPT + k] = group[k]; a_txb[tid * CR_RPT + k] = txb[k];
+            a_group[tid * CR_RPT + k] = group[k]; a_txb[tid * CR_RPT + k] = (uint16_t)txb[k];
         }
         lds_barrier();
         CRP_STAMP(3);                                                   // piece: gathers landed (records, covers, style summary)
@@ -1158,7 +1188,7 @@ void launch_carry_rows(hipStream_t s, bool local_sort, bool small, uint32_t n_sl
                        uint32_t n_orders, uint32_t tiles_w, uint32_t tiles_h, const uint32_t* row_count,
                        uint32_t* row_span_lo, uint32_t* row_span_cnt, uint64_t* span_key, uint4* span_cov,
                        const uint8_t* unchanged, FrameInfo* info, uint32_t edge_segs, uint32_t vis_last, uint32_t row0, uint32_t row1,
-                       SpanGroups groups) {
+                       SpanGroups groups, const uint32_t* run_lt) {
     row1 = row1 < tiles_h ? row1 : tiles_h;
     if (tiles_h == 0 || row0 >= row1) return;             // (only the tile rows that are painted: the others' carries are never read)
     if (n_slices < 1u) n_slices = 1u;
@@ -1166,7 +1196,7 @@ void launch_carry_rows(hipStream_t s, bool local_sort, bool small, uint32_t n_sl
     const dim3 grid((row1 - row0) * n_slices), block(CR_THREADS);
 #define CR_LAUNCH(L, C, R) hipLaunchKernelGGL((k_carry_rows<L, C, R>), grid, block, 0, s, sorted_run_keys, records, blk_edge, n_segments, \
                                               n_runs, layer_sf, n_orders, tiles_w, tiles_h, row_count, row_span_lo, row_span_cnt, span_key, \
-                                              span_cov, unchanged, info, edge_segs, vis_last, n_slices, bin_shift, row0, groups)
+                                              span_cov, unchanged, info, edge_segs, vis_last, n_slices, bin_shift, row0, groups, run_lt)
     if (!local_sort) CR_LAUNCH(false, CR_CAP, 4);
     else if (small) CR_LAUNCH(true, CR_CAP_S, 2);
     else CR_LAUNCH(true, CR_CAP, 4);
