@@ -252,7 +252,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     // (the in-LDS key holds 16 layer bits: every order a geom can produce has to fit, not just the style table)
     bool local_sort = ctx->n_orders <= 65536 && ctx->max_geom_order < 65536 && !ctx->global_runsort;
     // Several workgroups share a tile row, each a range of layers (k_carry_rows): as many as keep the chip busy for the rows
-    // this frame paints (a multi-GPU band is a fraction of the canvas).  The small-LDS variant (two workgroups per CU) is a
+    // this frame paints (a multi-GPU band is a fraction of the canvas).  The small-LDS variant (a quarter of the keys per workgroup) is a
     // read-back-free frame's guess — its slices must fit 4096 runs, known only from a previous frame; a slice that does not
     // fit voids the frame (plan_bad), the synchronous re-run takes the large variant, and the guess is not made again.
     uint32_t crow0 = 0, crow1 = tiles_h;                    // the tile rows the painter visits (Rect::new, renderer.rs:43-52)

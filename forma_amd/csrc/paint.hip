@@ -611,7 +611,8 @@ uint32_t runs_edge_segments(bool legacy) { return legacy ? RN_TILE : RW_CHUNK; }
 #define CR_THREADS 1024
 #define CR_WAVES   (CR_THREADS / 64)
 #define CR_CAP     16384                // runs one workgroup's in-LDS sort holds, large variant (2 x 64 KiB of 32-bit keys: one per CU)
-#define CR_CAP_S   4096                 // ... small variant (2 x 16 KiB: two to three workgroups per CU)
+#define CR_CAP_S   4096                 // ... small variant (2 x 16 KiB of keys, 66 KB in all.  NOT two per CU: its 81 VGPRs x 16 waves
+                                        // leave room for one workgroup per CU like the large one — it is the shorter sort that pays)
 #define CR_MAX_SLICES 8                 // workgroups that share one tile row (each takes a range of layers)
 
 // workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight across it
