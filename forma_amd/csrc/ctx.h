@@ -20,7 +20,13 @@ struct DevBuf {
         want = std::max<size_t>(want, 256);
         if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
         hipError_t e = hipMalloc(&p, want);
-        if (e == hipSuccess) cap = want;
+        if (e == hipSuccess) {
+            cap = want;
+            // FORMA_HIP_POISON=<byte>: every fresh device allocation is filled with that byte — a kernel that reads what nothing
+            // wrote this frame then misbehaves on every run instead of once per fresh box (tests/, tools/: hunting such reads)
+            static const char* poison = getenv("FORMA_HIP_POISON");
+            if (poison) { e = hipMemset(p, (int)strtol(poison, nullptr, 0), want); if (e == hipSuccess) e = hipDeviceSynchronize(); }
+        }
         return e;
     }
     void release() { if (p && !borrowed) (void)hipFree(p); p = nullptr; cap = 0; borrowed = false; }

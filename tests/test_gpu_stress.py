@@ -3,6 +3,8 @@ canvas shapes chosen to hit the paths a fixed scene list misses — tile rows wi
 walk (4096), rows beyond the in-LDS sort's capacity (16384: global run-key sort), one-tile-high and one-tile-wide
 canvases, canvases that are not multiples of the tile size.  Every case: first frame (synchronous) and second frame
 (read-back-free) both bit-equal to the oracle in the sorted stream and in the image."""
+import os
+
 import numpy as np
 import pytest
 
@@ -177,3 +179,41 @@ def test_span_group_lists(slices, global_sort, monkeypatch):
                 assert np.array_equal(bo, bc), (k, slices, frame)
         finally:
             c.close()
+
+
+_POISON_SCRIPT = r"""
+import os, sys
+import os
+
+import numpy as np
+sys.path.insert(0, os.path.join(os.getcwd(), "tests")); sys.path.insert(0, os.getcwd())
+import scene as S
+from oracle import oracle as orc
+import forma_amd
+for seed, n, W, H in ((51, 300, 640, 480), (52, 40, 100, 52)):
+    comp = S.random_mixed(n=n, width=W, height=H, seed=seed)
+    o = orc.Oracle(); t = comp.tables(o); S.load(o, t)
+    want = o.render(W, H, clear=(0.2, 0.4, 0.6, 1.0))
+    c = forma_amd.Context(0); S.load(c, t)
+    for frame in range(4):                       # synchronous frame, then read-back-free ones
+        assert np.array_equal(c.render(W, H, clear=(0.2, 0.4, 0.6, 1.0)), want), (seed, frame)
+    assert np.array_equal(c.segments(1), o.segments(1))
+    bo, bc = np.zeros((H, W * 4), np.uint8), np.zeros((H, W * 4), np.uint8)
+    for frame in range(3):
+        o.render(W, H, cache_id=1, dst=bo); c.render(W, H, cache_id=1, dst=bc)
+        assert np.array_equal(bo, bc), (seed, frame)
+    c.close()
+print("poison ok")
+"""
+
+
+@pytest.mark.parametrize("byte", ["0xFF", "0xA5", "0x00"])
+def test_nothing_reads_what_it_did_not_write(byte):
+    """FORMA_HIP_POISON fills every fresh device allocation with one byte: frames (synchronous and read-back-free, with and
+    without a cache, span group lists forced on) must not depend on what a buffer held before this frame wrote it — hipMalloc
+    does not zero, and a fresh box hands out whatever the last tenant left."""
+    import subprocess, sys
+    env = dict(os.environ, FORMA_HIP_POISON=byte, FORMA_HIP_SPAN_GROUPS="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _POISON_SCRIPT], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "poison ok" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
