@@ -77,6 +77,7 @@ SYMBOLS = {
     "forma_hip_cache_clear": (_i, [_vp, _i]),
     "forma_hip_set_frames_in_flight": (_i, [_vp, _i]),
     "forma_hip_sync": (_i, [_vp]),
+    "forma_hip_trim": (_i, [_vp]),
     "forma_hip_read_segments": (_i, [_vp, _i, _vp, _sz, _vp]),
     "forma_hip_read_image": (_i, [_vp, _vp, _sz]),
     "forma_hip_tiles_written": (_i, [_vp, _vp, _sz]),

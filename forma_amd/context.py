@@ -43,6 +43,10 @@ class Context:
         """forma_hip_set_frames_in_flight: device-resident, cache-less frames are enqueued on n frame slots; see sync()"""
         self._check(self._L.forma_hip_set_frames_in_flight(self._h, int(n)))
 
+    def trim(self):
+        """forma_hip_trim: give the per-frame device memory back (scene and caches stay)"""
+        self._check(self._L.forma_hip_trim(self._h))
+
     def sync(self):
         """forma_hip_sync: wait for every enqueued frame, raise the first error one of them produced"""
         self._check(self._L.forma_hip_sync(self._h))

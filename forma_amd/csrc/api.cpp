@@ -1106,6 +1106,45 @@ int forma_hip_sync(forma_hip_ctx* ctx) {
     return fd_drain(ctx);
 }
 
+// Per-frame device memory is grown to the largest frame seen and kept (a steady-state renderer never allocates).  trim gives
+// it back: everything a frame writes before it reads — streams, records, tables, the scratch image — of the context and of
+// its frame slots.  The scene (geometry, styles, images) and the buffer-layer caches (state across frames) stay.  The next
+// frame allocates what it needs and runs synchronously, like the first frame of a geometry.
+int forma_hip_trim(forma_hip_ctx* ctx) {
+    if (!ctx) return FORMA_E_ARG;
+    if (ctx->multi) return multi_trim(ctx);
+    { const int rc = fd_drain(ctx); if (rc) return rc; }
+    std::vector<forma_hip_ctx*> all{ctx};
+    for (forma_hip_ctx* sl : ctx->slots) if (sl != ctx) all.push_back(sl);
+    for (forma_hip_ctx* c : all) {
+        HIPCHECK(hipSetDevice(c->device));
+        HIPCHECK(hipStreamSynchronize(c->stream));
+        DevBuf* frame[] = {&c->l_order, &c->l_x0, &c->l_y0, &c->l_dx, &c->l_dy, &c->l_a, &c->l_b, &c->l_c, &c->l_d, &c->l_len,
+                           &c->scan_tmp, &c->cl_idx, &c->cl_start, &c->block_first, &c->prep_scratch, &c->seg_u, &c->seg_a, &c->seg_b,
+                           &c->sort_counters, &c->records, &c->rk_u, &c->rk_a, &c->rk_b, &c->blk_edge, &c->runs_scratch, &c->row_tab,
+                           &c->span_key, &c->span_cov, &c->image, &c->xscratch, &c->ras_masks, &c->xmask,
+                           &c->huge_offs, &c->huge_key, &c->huge_tmp, &c->huge_flag, &c->grp_tab, &c->grp_list, &c->run_lt};
+        size_t freed = 0;
+        for (DevBuf* b : frame) { if (!b->borrowed) freed += b->cap; b->release(); }
+        if (getenv("FORMA_HIP_TRIM_DEBUG")) {
+            size_t kept = 0;
+            DevBuf* rest[] = {&c->x, &c->y, &c->line_slot, &c->geoms, &c->style_off, &c->style_words, &c->layer_sf, &c->layer_col, &c->unchanged,
+                              &c->images, &c->texels, &c->info, &c->info_init, &c->cache_written, &c->xsend, &c->xrecv};
+            for (DevBuf* b : rest) if (!b->borrowed) kept += b->cap;
+            for (auto& tcache : c->caches) kept += tcache.tiles.cap + tcache.image.cap;
+            fprintf(stderr, "[forma_hip_trim] context %p: released %zu bytes, keeps %zu\n", (void*)c, freed, kept);
+        }
+        c->sorted = nullptr; c->n_seg = 0; c->have_unsorted = false;
+        c->cur_image = nullptr; c->img_w = 0; c->img_h = 0;
+        c->pending_masks = PendingMasks{nullptr, 0u};
+        c->last_written = 0;
+        clear_stage_flags(c);
+    }
+    invalidate_counts(ctx);
+    ctx->pred_counts_valid = false; ctx->xpred_valid = false;
+    return FORMA_OK;
+}
+
 int forma_hip_cache_clear(forma_hip_ctx* ctx, int cache_id) {
     if (!ctx || cache_id < 0 || cache_id >= 32) return fail(ctx, FORMA_E_ARG, "cache_id out of range");
     if (ctx->multi) return multi_cache_clear(ctx, cache_id);

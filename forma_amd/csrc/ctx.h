@@ -191,6 +191,7 @@ int  multi_render(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t hei
                   const uint8_t channels[4], const float clear_color[4], const forma_rect_t* crop_or_null, int cache_id,
                   forma_timings_t* timings);
 int  multi_cache_clear(forma_hip_ctx* ctx, int cache_id);
+int  multi_trim(forma_hip_ctx* ctx);
 int  multi_read_segments(forma_hip_ctx* ctx, int which, uint64_t* out, size_t capacity, size_t* out_n);
 int  multi_read_image(forma_hip_ctx* ctx, uint8_t* dst, size_t stride_bytes);
 int  multi_tiles_written(forma_hip_ctx* ctx, uint8_t* flags, size_t n_tiles);

@@ -200,7 +200,12 @@ int make_plan(forma_hip_ctx* ctx, uint32_t width, uint32_t height) {
     }
     std::vector<uint64_t> all(std::max<uint32_t>(tiles_h, 1), 0ull);
     for (int g = 0; g < G; g++) for (uint32_t r = 0; r < tiles_h && r < 2047; r++) all[r] += hist[(size_t)g * 2048 + r];
+    const bool had_plan = M->plans_made > 0 && M->plan_w == width && M->plan_h == height;
+    uint32_t old_edges[FORMA_MAX_DEVICES + 1];
+    for (int g = 0; g <= G; g++) old_edges[g] = M->edges[g];
     band_edges(all, tiles_h, G, M->edges);
+    bool bands_moved = !had_plan;
+    for (int g = 0; g <= G; g++) bands_moved |= old_edges[g] != M->edges[g];
     uint64_t max_pair = 0;
     for (int s = 0; s < G; s++)
         for (int g = 0; g < G; g++) {
@@ -213,8 +218,9 @@ int make_plan(forma_hip_ctx* ctx, uint32_t width, uint32_t height) {
     for (int g = 0; g < G; g++) {
         if ((rc = forma_hip_exchange_plan(M->kid[g], M->edges, (uint32_t)G, M->cap))) { copy_err(ctx, M->kid[g]); return rc; }
         M->kid[g]->xuse_recv = G == 1 && M->use_rccl;      // a world of one still runs its collective (the point of the rehearsal)
-        // a band that moved invalidates what a buffer-layer cache remembers about its rows: start over (everything repaints once)
-        for (int c = 0; c < 32; c++)
+        // a band that moved invalidates what a buffer-layer cache remembers about its rows: start over (everything repaints once).
+        // (A plan made again for the same scene — after forma_hip_trim — lands on the same bands and keeps the caches.)
+        for (int c = 0; c < 32 && bands_moved; c++)
             if (M->cache_used[c] && (rc = forma_hip_cache_clear(M->kid[g], c))) { copy_err(ctx, M->kid[g]); return rc; }
     }
     M->planned = true; M->plan_w = width; M->plan_h = height; M->plans_made++;
@@ -437,6 +443,12 @@ int multi_set_images(forma_hip_ctx* ctx, const forma_image_t* images, size_t n_i
     EACH_KID(forma_hip_set_images(k, images, n_images, texels, n_texels));
     return FORMA_OK;
 }
+int multi_trim(forma_hip_ctx* ctx) {
+    EACH_KID(forma_hip_trim(k));
+    ctx->multi->planned = false;                           // (the plan's measurements live in the kids' buffers: plan again)
+    return FORMA_OK;
+}
+
 int multi_cache_clear(forma_hip_ctx* ctx, int cache_id) {
     EACH_KID(forma_hip_cache_clear(k, cache_id));
     return FORMA_OK;

@@ -243,6 +243,11 @@ int forma_hip_cache_clear(forma_hip_ctx* ctx, int cache_id);
 int forma_hip_set_frames_in_flight(forma_hip_ctx* ctx, int n);
 /* Wait for every enqueued frame; returns the first error any of them produced. */
 int forma_hip_sync(forma_hip_ctx* ctx);
+/* Give per-frame device memory back (it is grown to the largest frame seen and otherwise kept until destroy): streams,
+ * records, tables and the scratch image of the context and of its frame slots.  The scene and the buffer-layer caches stay.
+ * forma_hip_read_image returns FORMA_E_STATE and forma_hip_read_segments an empty stream until the next render.  (The reference's renderer owns Vecs
+ * that keep their capacity the same way, cpu/renderer.rs:61-73; this is the shrink_to_fit it never needed on the host.) */
+int forma_hip_trim(forma_hip_ctx* ctx);
 
 /* ---- inspection of the last render (parity tests at full size, bench) ---------------------- */
 /* which: 0 = unsorted stream (rasterizer order), 1 = sorted stream. */

@@ -226,6 +226,7 @@ extern "C" {
     pub fn forma_hip_cache_clear(ctx: *mut forma_hip_ctx, cache_id: c_int) -> c_int;
     pub fn forma_hip_set_frames_in_flight(ctx: *mut forma_hip_ctx, n: c_int) -> c_int;
     pub fn forma_hip_sync(ctx: *mut forma_hip_ctx) -> c_int;
+    pub fn forma_hip_trim(ctx: *mut forma_hip_ctx) -> c_int;
 
     // inspection
     pub fn forma_hip_read_segments(

@@ -157,6 +157,13 @@ impl Renderer {
         self.check(rc, "forma_hip_sync");
     }
 
+    /// Gives the per-frame device memory back (`forma_hip_trim`): the scene and the caches stay, the next frame allocates again.
+    pub fn trim(&mut self) {
+        // SAFETY: as above.
+        let rc = unsafe { ffi::forma_hip_trim(self.ctx) };
+        self.check(rc, "forma_hip_trim");
+    }
+
     /// Same contract as `cpu::Renderer::create_buffer_layer_cache` (`cpu/renderer.rs:68-73`): at most 32 live caches.
     #[inline]
     pub fn create_buffer_layer_cache(&mut self) -> Option<BufferLayerCache> {

@@ -334,3 +334,61 @@ def test_frames_in_flight_reports_a_deferred_error():
         S.load(o, t)
         assert np.abs(c.read_image(32, 32).astype(int) - o.render(32, 32).astype(int)).max() <= 1
     c.close()
+
+
+def _device_free_bytes():
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    free, total = C.c_size_t(0), C.c_size_t(0)
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
+
+
+@pytest.mark.parametrize("devices", [None, [0, 0, 0]])
+def test_trim_gives_per_frame_memory_back(devices):
+    """forma_hip_trim: per-frame device memory (grown to the largest frame seen) is released, the scene and the buffer-layer
+    caches stay; the next frames — synchronous first, then read-back-free, in flight, with the cache — are the oracle's."""
+    import forma_amd
+    from forma_amd._lib import FormaError
+    W, H = 2048, 1536
+    comp = S.random_mixed(n=1500, width=W, height=H, seed=77)
+    o = orc.Oracle()
+    t = comp.tables(o)
+    S.load(o, t)
+    want = o.render(W, H, clear=(0.1, 0.2, 0.3, 1.0))
+    c = forma_amd.Context(0, devices=devices) if devices else forma_amd.Context(0, frames_in_flight=3)
+    S.load(c, t)
+    for k in range(6):                                                 # (the HIP runtime's own first-launch allocations — code objects,
+        c.render(48, 48, device_only=True)                             #  scratch, per-stream pools — are not ours to give back)
+    c.render(48, 48, cache_id=3, dst=np.zeros((48, 48 * 4), np.uint8))
+    c.trim()
+    base = _device_free_bytes()
+    bo, bc = np.zeros((H, W * 4), np.uint8), np.zeros((H, W * 4), np.uint8)
+    for k in range(5):
+        c.render(W, H, clear=(0.1, 0.2, 0.3, 1.0), device_only=True)
+    assert np.array_equal(c.read_image(W, H), want)
+    for k in range(2):
+        o.render(W, H, clear=(0.1, 0.2, 0.3, 1.0), cache_id=3, dst=bo); c.render(W, H, clear=(0.1, 0.2, 0.3, 1.0), cache_id=3, dst=bc)
+    assert np.array_equal(bo, bc)
+    grown = _device_free_bytes()
+    c.trim()
+    trimmed = _device_free_bytes()
+    assert base - grown > 64 << 20, (base, grown)                      # the frames did allocate
+    assert trimmed - grown > 0.4 * (base - grown), (base, grown, trimmed)   # ... and gave it back (what stays: the cache's image and
+                                                                            # tiles, and whatever the HIP runtime grew for itself)
+    if not devices:
+        with pytest.raises(FormaError):
+            c.read_image(W, H)                                         # no image on the device until the next render
+    c.trim()                                                           # (idempotent)
+    # the cache survived: with every layer flagged unchanged no tile is written, the caller's buffer keeps what it holds
+    unch = np.ones_like(t["unchanged"])
+    o.set_styles(t["style_offsets"], t["style_words"], unch); c.set_styles(t["style_offsets"], t["style_words"], unch)
+    bo2, bc2 = np.full_like(bo, 201), np.full_like(bc, 201)
+    o.render(W, H, clear=(0.1, 0.2, 0.3, 1.0), cache_id=3, dst=bo2); c.render(W, H, clear=(0.1, 0.2, 0.3, 1.0), cache_id=3, dst=bc2)
+    assert np.array_equal(bo2, bc2) and (bc2 == 201).all()
+    assert int(np.count_nonzero(c.tiles_written(W, H))) == 0
+    o.set_styles(t["style_offsets"], t["style_words"], t["unchanged"]); c.set_styles(t["style_offsets"], t["style_words"], t["unchanged"])
+    for k in range(4):
+        c.render(W, H, clear=(0.1, 0.2, 0.3, 1.0), device_only=True)
+    assert np.array_equal(c.read_image(W, H), want)
+    c.close()
