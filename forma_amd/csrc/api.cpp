@@ -338,7 +338,8 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                           runs_edge_segments(ctx->legacy_runs),
                           // invisible carries of a partial last tile row are dropped only when nothing can observe them: with a
                           // buffer-layer cache the layer count of a tile is state (passes/tile_unchanged.rs)
-                          (a.cache_id < 0 && (a.height & 15u)) ? (a.height & 15u) : 16u, crow0, crow1, groups, ctx->run_lt.as<uint32_t>());
+                          (a.cache_id < 0 && (a.height & 15u)) ? (a.height & 15u) : 16u, crow0, crow1, groups, ctx->run_lt.as<uint32_t>(),
+                          a.cache_id >= 0 ? (a.crop ? a.crop->x0 / 16 : 0u) : 0xFFFFFFFFu);
     } else {
         HIPCHECK(ctx->span_key.ensure(8));
         HIPCHECK(ctx->span_cov.ensure(16));
@@ -445,15 +446,46 @@ int copy_image_out(forma_hip_ctx* ctx, uint8_t* dst, size_t stride, bool timing,
         HIPCHECK(hipHostMalloc((void**)&ctx->h_written, T, hipHostMallocDefault));
         ctx->h_written_cap = T;
     }
+    // While the flags travel, the device packs the written tiles' pixels (list order = row-major over the crop): a frame that
+    // rewrote 1.5 % of a 4K canvas then moves 0.5 MB over PCIe instead of 33 MB.  More than a quarter of the crop written:
+    // one strided copy of the crop through the staging image is cheaper than the per-tile scatter on the host.
+    const size_t n_crop = (size_t)(tx1 - tx0) * (ty1 - ty0);
+    static const bool no_pack = getenv("FORMA_HIP_NO_PACKED_COPY") != nullptr;                        // (A/B switch for tools/, tests)
+    const uint32_t max_pack = no_pack ? 0u : (uint32_t)std::min<size_t>(std::max<size_t>(n_crop / 4, 1), 1u << 20);
+    HIPCHECK(ctx->pack_list.ensure((n_crop + 1) * 4));
+    HIPCHECK(ctx->pack_pix.ensure(std::max<size_t>((size_t)max_pack, 1) * 1024));
+    launch_pack_written(ctx->stream, ctx->cache_written.as<uint8_t>(), tiles_w, tx0, tx1, ty0, ty1, ctx->pack_list.as<uint32_t>() + 1,
+                        ctx->pack_list.as<uint32_t>(), max_pack, ctx->cur_image, a.width, a.height, ctx->pack_pix.as<uint32_t>());
+    HIPCHECK(hipGetLastError());
     HIPCHECK(hipMemcpyAsync(ctx->h_written, ctx->cache_written.p, T, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     ctx->lw_flags_on_host = true;
-    size_t n_written = 0, n_crop = (size_t)(tx1 - tx0) * (ty1 - ty0);
+    size_t n_written = 0;
     for (uint32_t ty = ty0; ty < ty1; ty++) for (uint32_t tx = tx0; tx < tx1; tx++) n_written += ctx->h_written[(size_t)ty * tiles_w + tx] ? 1 : 0;
     ctx->last_written = (uint32_t)n_written;
     if (n_written == n_crop) {                                         // everything was painted: one strided copy
         HIPCHECK(hipMemcpy2DAsync(dst + py0 * stride + px0 * 4, stride, ctx->cur_image + py0 * pitch + px0 * 4, pitch,
                                   (px1 - px0) * 4, py1 - py0, hipMemcpyDeviceToHost, ctx->stream));
+    } else if (n_written && n_written <= max_pack) {                   // the packed tiles, then each into its place
+        const size_t bytes = n_written * 1024;
+        if (ctx->h_stage_cap < bytes) {
+            if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+            ctx->h_stage = nullptr; ctx->h_stage_cap = 0;
+            HIPCHECK(hipHostMalloc((void**)&ctx->h_stage, std::max<size_t>(bytes, 1 << 20), hipHostMallocDefault));
+            ctx->h_stage_cap = std::max<size_t>(bytes, 1 << 20);
+        }
+        HIPCHECK(hipMemcpyAsync(ctx->h_stage, ctx->pack_pix.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHECK(hipStreamSynchronize(ctx->stream));
+        size_t k = 0;
+        for (uint32_t ty = ty0; ty < ty1; ty++)
+            for (uint32_t tx = tx0; tx < tx1; tx++) {
+                if (!ctx->h_written[(size_t)ty * tiles_w + tx]) continue;
+                const size_t x0 = (size_t)tx * 16, x1 = std::min<size_t>(x0 + 16, a.width);
+                const size_t y0 = (size_t)ty * 16, y1 = std::min<size_t>(y0 + 16, a.height);
+                const uint8_t* src = ctx->h_stage + k * 1024;
+                for (size_t y = y0; y < y1; y++) memcpy(dst + y * stride + x0 * 4, src + (y - y0) * 64, (x1 - x0) * 4);
+                k++;
+            }
     } else if (n_written) {                                            // stage, then copy only the written tiles
         const size_t bytes = pitch * a.height;
         if (ctx->h_stage_cap < bytes) {
@@ -619,7 +651,7 @@ void forma_hip_destroy(forma_hip_ctx* ctx) {
                      &ctx->blk_edge, &ctx->runs_scratch, &ctx->row_tab, &ctx->span_key, &ctx->span_cov,
                      &ctx->image, &ctx->xsend, &ctx->xrecv, &ctx->xscratch,
                      &ctx->ras_masks, &ctx->xmask, &ctx->huge_offs, &ctx->huge_key, &ctx->huge_tmp, &ctx->huge_flag,
-                     &ctx->grp_tab, &ctx->grp_list, &ctx->run_lt};
+                     &ctx->grp_tab, &ctx->grp_list, &ctx->run_lt, &ctx->pack_list, &ctx->pack_pix, &ctx->cache_written};
     for (DevBuf* b : all) b->release();
     for (int s = 0; s < ST_COUNT; s++) { (void)hipEventDestroy(ctx->ev0[s]); (void)hipEventDestroy(ctx->ev1[s]); }
     for (int p = 0; p < MAX_PASS_EVENTS; p++) { (void)hipEventDestroy(ctx->pev0[p]); (void)hipEventDestroy(ctx->pev1[p]); }
@@ -1123,7 +1155,7 @@ int forma_hip_trim(forma_hip_ctx* ctx) {
                            &c->scan_tmp, &c->cl_idx, &c->cl_start, &c->block_first, &c->prep_scratch, &c->seg_u, &c->seg_a, &c->seg_b,
                            &c->sort_counters, &c->records, &c->rk_u, &c->rk_a, &c->rk_b, &c->blk_edge, &c->runs_scratch, &c->row_tab,
                            &c->span_key, &c->span_cov, &c->image, &c->xscratch, &c->ras_masks, &c->xmask,
-                           &c->huge_offs, &c->huge_key, &c->huge_tmp, &c->huge_flag, &c->grp_tab, &c->grp_list, &c->run_lt};
+                           &c->huge_offs, &c->huge_key, &c->huge_tmp, &c->huge_flag, &c->grp_tab, &c->grp_list, &c->run_lt, &c->pack_list, &c->pack_pix};
         size_t freed = 0;
         for (DevBuf* b : frame) { if (!b->borrowed) freed += b->cap; b->release(); }
         if (getenv("FORMA_HIP_TRIM_DEBUG")) {

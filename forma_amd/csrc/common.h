@@ -218,7 +218,11 @@ void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount n, uint32_t til
                  uint32_t* row_tab, uint32_t* scratch, FrameInfo* info, bool verify_plan, uint64_t spec_live44,
                  bool spec_layer_sorted, bool legacy /* workgroup-per-tile kernel with LDS bins instead of the wave kernel */,
                  PendingMasks pm, RunStyle rs);
-uint32_t runs_edge_segments(bool legacy);   // segments per BlkEdge entry of the kernel launch_runs picks
+uint32_t runs_edge_segments(bool legacy);
+// cache frames: list of the written tiles of the crop (row-major) + their pixels packed into 1 KB slots, <= max_pack tiles
+void launch_pack_written(hipStream_t s, const uint8_t* written, uint32_t tiles_w, uint32_t tx0, uint32_t tx1, uint32_t ty0, uint32_t ty1,
+                         uint32_t* list, uint32_t* count, uint32_t max_pack, const uint8_t* image, uint32_t width, uint32_t height,
+                         uint32_t* packed);   // segments per BlkEdge entry of the kernel launch_runs picks
 // style flags of a layer as the carry pre-pass and the painter pass them around (bits 21.. of a record's layer word)
 #define SF_FULL        0x001u     // spans only: Cover::is_full (painter/mod.rs:200-215)
 #define SF_IS_CLIP     0x002u
@@ -245,7 +249,9 @@ void launch_carry_rows(hipStream_t s, bool local_sort, bool small, uint32_t n_sl
                        uint32_t edge_segs,
                        uint32_t vis_last /* visible pixel rows of the last tile row (height % 16, 16 if 0) */,
                        uint32_t row0, uint32_t row1 /* the tile rows that are painted (the crop): only those get workgroups */,
-                       SpanGroups groups /* tab == nullptr: no group lists */, const uint32_t* run_lt /* RunStyle::run_lt */);
+                       SpanGroups groups /* tab == nullptr: no group lists */, const uint32_t* run_lt /* RunStyle::run_lt */,
+                       uint32_t left_start /* cache frames: the first painted tile column, whose tiles list every layer with segments to
+                                              their left (painter/mod.rs:500-522); 0xFFFFFFFF: no cache, nothing can observe it */);
 void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, DevCount n_runs,
                   const uint32_t* tile_first_run, const uint32_t* row_span_lo, const uint32_t* row_span_cnt,
                   const uint64_t* span_key, const uint4* span_cov,

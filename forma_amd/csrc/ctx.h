@@ -89,6 +89,7 @@ struct forma_hip_ctx {
         float clear[4] = {0, 0, 0, 0};
     };
     TileCache caches[32];
+    DevBuf pack_list, pack_pix;             // cache frames: written tiles of the crop (list + count word in front), their pixels packed
     DevBuf cache_written;                   // one byte per tile: written this frame
     uint8_t* h_written = nullptr;           // pinned copy of cache_written
     size_t h_written_cap = 0;

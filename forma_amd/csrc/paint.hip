@@ -707,7 +707,8 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
                                                            uint32_t vis_last /* visible pixel rows of the last tile row, 16 = all */,
                                                            uint32_t n_slices, uint32_t bin_shift,
                                                            uint32_t row0 /* first tile row that is painted: blockIdx.x = 0 */,
-                                                           SpanGroups groups, const uint32_t* __restrict__ run_lt) {
+                                                           SpanGroups groups, const uint32_t* __restrict__ run_lt,
+                                                           uint32_t left_start /* see below; 0xFFFFFFFF: off */) {
     constexpr int CR_RPT = RPT;                        // consecutive runs of the (layer, tile_x) order per lane in the row walk
     constexpr int CR_PIECE = CR_THREADS * RPT;         // runs per piece
     constexpr bool NB_IN_IDLE = LOCAL && 2 * (CR_PIECE + 1) <= CAP;   // group / tile_x of a piece's runs live in the sort's idle buffer
@@ -1080,6 +1081,13 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
                 const bool empty = is_clip ? cover_is_empty(pl, ph, (meta[k] >> 12) & 1u)
                                            : cover_is_empty(pl & vis_lo, ph & vis_hi, (meta[k] >> 12) & 1u);
                 if (!empty && span_lo[k] < sh) spanm |= 1u << k;
+                // The first painted tile of a row (column `left_start`: 0, or the crop's first column) starts with EVERY layer
+                // that has a segment to its left — empty cover or not (paint_tile_row collects them in a map and hands all of it
+                // to LayerWorkbench::init, painter/mod.rs:500-522; the empty ones are dropped after that tile, :335-339).  Such an
+                // entry paints nothing, but it counts: the tile's layer count and what the passes decide are remembered by a
+                // buffer-layer cache (CachedTile).  With a cache attached the layer's last run left of the column therefore leaves
+                // a one-tile span for it even when its carry is empty; without one nothing can observe the entry and it is skipped.
+                else if (empty && span_lo[k] <= left_start && left_start < sh) { spanm |= 1u << k; span_lo[k] = left_start; span_hi[k] = left_start + 1u; }
             }
         }
         // ordered compaction of the spans
@@ -1189,7 +1197,7 @@ void launch_carry_rows(hipStream_t s, bool local_sort, bool small, uint32_t n_sl
                        uint32_t n_orders, uint32_t tiles_w, uint32_t tiles_h, const uint32_t* row_count,
                        uint32_t* row_span_lo, uint32_t* row_span_cnt, uint64_t* span_key, uint4* span_cov,
                        const uint8_t* unchanged, FrameInfo* info, uint32_t edge_segs, uint32_t vis_last, uint32_t row0, uint32_t row1,
-                       SpanGroups groups, const uint32_t* run_lt) {
+                       SpanGroups groups, const uint32_t* run_lt, uint32_t left_start) {
     row1 = row1 < tiles_h ? row1 : tiles_h;
     if (tiles_h == 0 || row0 >= row1) return;             // (only the tile rows that are painted: the others' carries are never read)
     if (n_slices < 1u) n_slices = 1u;
@@ -1197,7 +1205,7 @@ void launch_carry_rows(hipStream_t s, bool local_sort, bool small, uint32_t n_sl
     const dim3 grid((row1 - row0) * n_slices), block(CR_THREADS);
 #define CR_LAUNCH(L, C, R) hipLaunchKernelGGL((k_carry_rows<L, C, R>), grid, block, 0, s, sorted_run_keys, records, blk_edge, n_segments, \
                                               n_runs, layer_sf, n_orders, tiles_w, tiles_h, row_count, row_span_lo, row_span_cnt, span_key, \
-                                              span_cov, unchanged, info, edge_segs, vis_last, n_slices, bin_shift, row0, groups, run_lt)
+                                              span_cov, unchanged, info, edge_segs, vis_last, n_slices, bin_shift, row0, groups, run_lt, left_start)
     if (!local_sort) CR_LAUNCH(false, CR_CAP, 4);
     else if (small) CR_LAUNCH(true, CR_CAP_S, 2);
     else CR_LAUNCH(true, CR_CAP, 4);
@@ -2597,4 +2605,56 @@ void launch_paint_huge(hipStream_t s, const PaintParams& p, const uint64_t* sort
     hipLaunchKernelGGL(k_paint_huge, dim3(n_tiles < 256 ? n_tiles : 256), dim3(256), 0, s, p, sorted, records, n_runs, tile_first_run,
                        row_span_lo, row_span_cnt, span_key, span_cov, layer_col, style_offsets, style_words, images, texels, image,
                        cache, info, over2_list, n_tiles, offs, g_key, g_tmp, g_flag);
+}
+
+// ================================================================================================
+// copy-out of a cache frame: only the tiles the painters wrote (TileWriteOp != None) leave the device.
+// k_written_list compacts the written tiles of the crop, row-major, into a list (one workgroup: the canvas has
+// at most a few hundred thousand tiles); k_pack_written gathers their pixels into 1 KB slots, list order.
+// The host walks the same flags in the same order and drops slot k into the k-th written tile of the caller's
+// buffer (reference cpu/buffer/layout/mod.rs:264-295 writes tile by tile).
+// ================================================================================================
+__global__ __launch_bounds__(1024) void k_written_list(const uint8_t* __restrict__ written, uint32_t tiles_w, uint32_t tx0, uint32_t tx1,
+                                                       uint32_t ty0, uint32_t ty1, uint32_t* __restrict__ list, uint32_t* __restrict__ count) {
+    __shared__ uint32_t s_w[16], s_base;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t cw = tx1 - tx0, n = cw * (ty1 - ty0);
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < n; i0 += 1024) {
+        const uint32_t i = i0 + (uint32_t)tid;
+        uint32_t tile = 0; bool hit = false;
+        if (i < n) { const uint32_t ry = i / cw, rx = i - ry * cw; tile = (ty0 + ry) * tiles_w + tx0 + rx; hit = written[tile] != 0; }
+        const uint64_t bal = __ballot(hit);
+        if (lane == 0) s_w[w] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t base = s_base, tot = 0;
+#pragma unroll
+        for (int q = 0; q < 16; q++) { const uint32_t t = s_w[q]; if (q < w) base += t; tot += t; }
+        if (hit) list[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = tile;
+        __syncthreads();
+        if (tid == 0) s_base += tot;
+        __syncthreads();
+    }
+    if (tid == 0) *count = s_base;
+}
+__global__ __launch_bounds__(256) void k_pack_written(const uint32_t* __restrict__ list, const uint32_t* __restrict__ count, uint32_t max_pack,
+                                                      uint32_t tiles_w, const uint32_t* __restrict__ image, uint32_t width, uint32_t height,
+                                                      uint32_t* __restrict__ packed) {
+    const uint32_t n = *count;
+    if (n > max_pack) return;                              // (too many: the host copies the whole crop instead)
+    for (uint32_t k = blockIdx.x; k < n; k += gridDim.x) {
+        const uint32_t tile = list[k], ty = tile / tiles_w, tx = tile - ty * tiles_w;
+        const uint32_t px = tx * 16u + (threadIdx.x & 15u), py = ty * 16u + (threadIdx.x >> 4);
+        packed[(size_t)k * 256 + threadIdx.x] = (px < width && py < height) ? image[(size_t)py * width + px] : 0u;
+    }
+}
+void launch_pack_written(hipStream_t s, const uint8_t* written, uint32_t tiles_w, uint32_t tx0, uint32_t tx1, uint32_t ty0, uint32_t ty1,
+                         uint32_t* list, uint32_t* count, uint32_t max_pack, const uint8_t* image, uint32_t width, uint32_t height,
+                         uint32_t* packed) {
+    if (tx0 >= tx1 || ty0 >= ty1) { (void)hipMemsetAsync(count, 0, 4, s); return; }
+    hipLaunchKernelGGL(k_written_list, dim3(1), dim3(1024), 0, s, written, tiles_w, tx0, tx1, ty0, ty1, list, count);
+    const uint32_t n = (tx1 - tx0) * (ty1 - ty0);
+    hipLaunchKernelGGL(k_pack_written, dim3(std::max(1u, std::min<uint32_t>(std::min(n, max_pack), 4096u))), dim3(256), 0, s, (const uint32_t*)list,
+                       (const uint32_t*)count, max_pack, tiles_w, (const uint32_t*)image, width, height, packed);
 }

@@ -225,3 +225,36 @@ def test_damage_set_on_a_canvas_whose_height_is_not_a_multiple_of_16(ctx):
     want = o.render(w, h, clear=clear)
     got = ctx.render(w, h, clear=clear)
     assert np.abs(want.astype(int) - got.astype(int)).max() <= 1
+
+
+def test_small_damage_leaves_the_device_as_packed_tiles(ctx):
+    """A cache frame that rewrites a few tiles copies out only those (k_written_list / k_pack_written: the written tiles of the
+    crop, packed on the device, dropped into place on the host) instead of the whole canvas.  Canvas and crop are not
+    multiples of the tile size (partial edge tiles), one small layer moves per frame: buffers and written-tile sets equal the
+    oracle's frame after frame; the frame that moves everything takes the whole-crop path again."""
+    w, h = 602, 330
+    o = orc.Oracle()
+    comp = build(n=60, seed=33, w=w, h=h)
+    clear = (0.9, 0.8, 0.7, 1.0)
+    crop = (35, 571, 20, 317)                                           # x0, x1, y0, y1: cuts tiles on all four sides
+    bufs = [np.zeros((h, w * 4), np.uint8), np.zeros((h, w * 4), np.uint8)]
+    set_unchanged(comp, False)
+    t = comp.tables(o); S.load(o, t); S.load(ctx, t)
+    o.render(w, h, clear=clear, cache_id=1, dst=bufs[0], crop=crop); ctx.render(w, h, clear=clear, cache_id=1, dst=bufs[1], crop=crop)
+    assert np.array_equal(bufs[0], bufs[1])
+    rng = np.random.default_rng(5)
+    for step in range(8):
+        moved = {int(rng.integers(0, 60))} if step != 5 else set(range(60))
+        set_unchanged(comp, True, except_orders=moved)
+        for m in moved:
+            comp.layers[m].set_transform([1.0, 0.0, 0.0, 1.0, float(rng.uniform(-25, 25)), float(rng.uniform(-20, 20))])
+        t = comp.tables(o); S.load(o, t); ctx.set_geoms(t["geoms"]); ctx.set_styles(t["style_offsets"], t["style_words"], t["unchanged"])
+        sent = [np.full((h, w * 4), 201, np.uint8), np.full((h, w * 4), 201, np.uint8)]
+        o.render(w, h, clear=clear, cache_id=1, dst=sent[0], crop=crop); ctx.render(w, h, clear=clear, cache_id=1, dst=sent[1], crop=crop)
+        assert np.array_equal(sent[0], sent[1]), step
+        wr = _written(sent[1], 201, w, h)
+        assert np.array_equal(wr.reshape(-1), ctx.tiles_written(w, h) != 0), step
+        if step != 5:
+            assert 0 < wr.sum() < wr.size // 4, (step, wr.sum())        # few tiles: the packed path
+        o.render(w, h, clear=clear, cache_id=1, dst=bufs[0], crop=crop); ctx.render(w, h, clear=clear, cache_id=1, dst=bufs[1], crop=crop)
+        assert np.array_equal(bufs[0], bufs[1]), step
