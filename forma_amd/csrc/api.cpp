@@ -297,6 +297,13 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
         }
         jc = DevCount{nullptr, J};
     }
+    bool fold_equals_paint = true;
+    for (int i = 0; i < 4; i++) {
+        uint8_t sel = a.channels[i];
+        if (sel == FORMA_CH_ALPHA && a.clear[3] == 1.0f) sel = FORMA_CH_ONE;          // renderer.rs:85-92
+        const bool colour = sel == FORMA_CH_RED || sel == FORMA_CH_GREEN || sel == FORMA_CH_BLUE;
+        if (i < 3 ? sel == FORMA_CH_ALPHA : colour) fold_equals_paint = false;
+    }
     SpanGroups groups{nullptr, nullptr, 0u, 0u};
     const uint32_t n_groups = (tiles_w + SPAN_GROUP_TILES - 1u) >> SPAN_GROUP_SHIFT;
     if (jc.bound > 0) {
@@ -338,8 +345,12 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                           runs_edge_segments(ctx->legacy_runs),
                           // invisible carries of a partial last tile row are dropped only when nothing can observe them: with a
                           // buffer-layer cache the layer count of a tile is state (passes/tile_unchanged.rs)
-                          (a.cache_id < 0 && (a.height & 15u)) ? (a.height & 15u) : 16u, crow0, crow1, groups, ctx->run_lt.as<uint32_t>(),
-                          a.cache_id >= 0 ? (a.crop ? a.crop->x0 / 16 : 0u) : 0xFFFFFFFFu);
+                          // ... nor when the channel order tells a folded tile from a painted one: the solid fold encodes output
+                          // bytes 0..2 as sRGB and passes byte 3 through (to_srgb_bytes of the SELECTED channels, painter/mod.rs:
+                          // 156-162, 692), a painted tile encodes r, g, b and then selects (compute_srgb, :466-483) — the same bytes
+                          // unless alpha lands in bytes 0..2 or a colour in byte 3, and an invisible layer can block the fold
+                          (a.cache_id < 0 && (a.height & 15u) && fold_equals_paint) ? (a.height & 15u) : 16u, crow0, crow1, groups, ctx->run_lt.as<uint32_t>(),
+                          (a.cache_id >= 0 || !fold_equals_paint) ? (a.crop ? a.crop->x0 / 16 : 0u) : 0xFFFFFFFFu);
     } else {
         HIPCHECK(ctx->span_key.ensure(8));
         HIPCHECK(ctx->span_cov.ensure(16));

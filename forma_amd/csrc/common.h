@@ -251,7 +251,8 @@ void launch_carry_rows(hipStream_t s, bool local_sort, bool small, uint32_t n_sl
                        uint32_t row0, uint32_t row1 /* the tile rows that are painted (the crop): only those get workgroups */,
                        SpanGroups groups /* tab == nullptr: no group lists */, const uint32_t* run_lt /* RunStyle::run_lt */,
                        uint32_t left_start /* cache frames: the first painted tile column, whose tiles list every layer with segments to
-                                              their left (painter/mod.rs:500-522); 0xFFFFFFFF: no cache, nothing can observe it */);
+                                              their left (painter/mod.rs:500-522); 0xFFFFFFFF: no cache and a channel order under which a folded tile and a painted one
+                                              are the same bytes — nothing can observe the entry */);
 void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, DevCount n_runs,
                   const uint32_t* tile_first_run, const uint32_t* row_span_lo, const uint32_t* row_span_cnt,
                   const uint64_t* span_key, const uint4* span_cov,

@@ -1086,7 +1086,8 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
                 // to LayerWorkbench::init, painter/mod.rs:500-522; the empty ones are dropped after that tile, :335-339).  Such an
                 // entry paints nothing, but it counts: the tile's layer count and what the passes decide are remembered by a
                 // buffer-layer cache (CachedTile).  With a cache attached the layer's last run left of the column therefore leaves
-                // a one-tile span for it even when its carry is empty; without one nothing can observe the entry and it is skipped.
+                // a one-tile span for it even when its carry is empty; without one nothing can observe the entry and it is skipped
+                // (unless the channel order tells a folded tile from a painted one: api.cpp run_paint, fold_equals_paint).
                 else if (empty && span_lo[k] <= left_start && left_start < sh) { spanm |= 1u << k; span_lo[k] = left_start; span_hi[k] = left_start + 1u; }
             }
         }

@@ -3,6 +3,8 @@ solid colours, "TileWriteOp::None leaves the caller's buffer untouched" — mult
 CPU oracle, buffers carried from frame to frame on both sides (reference forma/src/cpu/buffer/mod.rs:113-197,
 cpu/painter/mod.rs:629-715, passes/tile_unchanged.rs, composition/mod.rs tests `render_changed_layers_only`,
 `clear_emptied_tiles`, `separate_layer_caches`, `draw_if_width_or_height_change`)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -258,3 +260,60 @@ def test_small_damage_leaves_the_device_as_packed_tiles(ctx):
             assert 0 < wr.sum() < wr.size // 4, (step, wr.sum())        # few tiles: the packed path
         o.render(w, h, clear=clear, cache_id=1, dst=bufs[0], crop=crop); ctx.render(w, h, clear=clear, cache_id=1, dst=bufs[1], crop=crop)
         assert np.array_equal(bufs[0], bufs[1]), step
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("FORMA_TEST_FUZZ_SEEDS", "12")))))
+def test_damage_sets_of_random_scenes(seed):
+    """Written-tile sets with a buffer-layer cache, randomised: all-features scenes (clips, clipped layers, gradients,
+    textures, blend modes, both fill rules, shapes over every canvas edge) on canvases off the tile grid, random crops, a
+    random subset of layers moving / toggling / restyled per frame.  Frame after frame the buffer a renderer carries and the
+    set of tiles it rewrote (sentinel buffer) equal the oracle's — `CachedTile` state (layer count, solid colour) is compared
+    by the reference itself on the next frame, so any drift shows up as a different damage set."""
+    import forma_amd
+    rng = np.random.default_rng(1000 + seed)
+    w, h = int(rng.integers(40, 700)), int(rng.integers(40, 420))
+    n = int(rng.integers(5, 140))
+    comp = S.random_mixed(n=n, width=w, height=h, seed=500 + seed)
+    orders = sorted(comp.layers.keys())
+    crop = None
+    if seed % 3 == 1:
+        x0, y0 = int(rng.integers(0, w // 2)), int(rng.integers(0, h // 2))
+        crop = (x0, int(rng.integers(x0 + 1, w + 1)), y0, int(rng.integers(y0 + 1, h + 1)))
+    clear = tuple(float(v) for v in rng.random(3)) + (1.0,)
+    o = orc.Oracle(); c = forma_amd.Context(0)
+    try:
+        bufs = [np.full((h, w * 4), 77, np.uint8), np.full((h, w * 4), 77, np.uint8)]
+        for frame_no in range(7):
+            if frame_no == 0:
+                set_unchanged(comp, False)
+            else:
+                k = int(rng.integers(0, max(2, len(orders) // 6)))
+                moved = set(int(v) for v in rng.choice(orders, size=min(k, len(orders)), replace=False))
+                set_unchanged(comp, True, except_orders=moved)
+                for m in moved:
+                    kind = int(rng.integers(0, 3))
+                    L = comp.layers[m]
+                    if kind == 0:
+                        L.set_transform([1.0, 0.0, 0.0, 1.0, float(rng.uniform(-60, 60)), float(rng.uniform(-40, 40))])
+                    elif kind == 1:
+                        L.enabled = not L.enabled
+                    elif L.props.clip is None and isinstance(L.props.fill, tuple):
+                        L.props.fill = tuple(float(v) for v in rng.random(3)) + (L.props.fill[3],)
+                if frame_no == 4:
+                    clear = tuple(float(v) for v in rng.random(3)) + (1.0,)      # a new clear colour repaints everything
+            t = comp.tables(o)
+            S.load(o, t)
+            if frame_no == 0:
+                S.load(c, t)
+            else:
+                c.set_geoms(t["geoms"]); c.set_styles(t["style_offsets"], t["style_words"], t["unchanged"])
+            sent = [np.full((h, w * 4), 201, np.uint8), np.full((h, w * 4), 201, np.uint8)]
+            # two renders per frame and backend would advance the cache twice: the sentinel pair is the frame, the carried
+            # buffers are patched from it (a sentinel pixel = the renderer left the tile alone)
+            o.render(w, h, clear=clear, cache_id=2, dst=sent[0], crop=crop); c.render(w, h, clear=clear, cache_id=2, dst=sent[1], crop=crop)
+            wo, wg = _written(sent[0], 201, w, h), _written(sent[1], 201, w, h)
+            assert np.array_equal(wo, wg), (seed, frame_no, int(wo.sum()), int(wg.sum()))
+            assert np.abs(sent[0].astype(int) - sent[1].astype(int)).max() <= 1, (seed, frame_no)
+            assert np.array_equal(wg.reshape(-1), c.tiles_written(w, h) != 0), (seed, frame_no)
+    finally:
+        c.close()

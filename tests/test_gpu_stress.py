@@ -217,3 +217,44 @@ def test_nothing_reads_what_it_did_not_write(byte):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _POISON_SCRIPT], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "poison ok" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("block", list(range(int(os.environ.get("FORMA_TEST_FUZZ_BLOCKS", "3")))))
+def test_random_frames_with_crops_and_channel_orders(block):
+    """Twenty random all-features scenes per block on canvases of any shape, a quarter of them cropped, under four channel orders
+    (one puts alpha first and red last: there a tile folded to a solid colour and a painted tile are DIFFERENT bytes —
+    to_srgb_bytes of the selected channels vs. select after encoding, painter/mod.rs:156-162, 466-483 — so every fold decision
+    has to be the reference's), translucent clear colours; synchronous, read-back-free and in-flight frames: sorted stream
+    bit-equal, image within one code value of the oracle.  (FORMA_TEST_FUZZ_BLOCKS=30 for a long run.)"""
+    import forma_amd
+    c = forma_amd.Context(0, frames_in_flight=3 if block % 2 else 1)
+    o = orc.Oracle()
+    try:
+        for seed in range(block * 20, block * 20 + 20):
+            rng = np.random.default_rng(7000 + seed)
+            w, h = int(rng.integers(17, 900)), int(rng.integers(17, 500))
+            comp = S.random_mixed(n=int(rng.integers(1, 260)), width=w, height=h, seed=9000 + seed)
+            t = comp.tables(o)
+            S.load(o, t); S.load(c, t)
+            crop = None
+            if seed % 4 == 1:
+                x0, y0 = int(rng.integers(0, w - 1)), int(rng.integers(0, h - 1))
+                crop = (x0, int(rng.integers(x0 + 1, w + 1)), y0, int(rng.integers(y0 + 1, h + 1)))
+            ch = [(0, 1, 2, 3), (2, 1, 0, 3), (0, 1, 2, 5), (3, 2, 1, 0)][seed % 4]
+            clear = tuple(float(v) for v in rng.random(4))
+            want = o.render(w, h, clear=clear, crop=crop, channels=ch).reshape(h, w, 4).astype(int)
+            m = np.ones((h, w), bool)
+            if crop is not None:                          # (outside the crop's tiles neither backend writes)
+                m[:] = False
+                m[crop[2] // 16 * 16: min(h, (crop[3] + 15) // 16 * 16), crop[0] // 16 * 16: min(w, (crop[1] + 15) // 16 * 16)] = True
+            for frame in range(4):
+                if frame < 2:
+                    got = c.render(w, h, clear=clear, crop=crop, channels=ch)
+                else:
+                    c.render(w, h, clear=clear, crop=crop, channels=ch, device_only=True)
+                    got = c.read_image(w, h)
+                d = np.abs(want - got.reshape(h, w, 4).astype(int))[m]
+                assert d.max(initial=0) <= 1, (seed, frame, w, h, crop, ch)
+                assert np.array_equal(c.segments(1), o.segments(1)), (seed, frame)
+    finally:
+        c.close()
