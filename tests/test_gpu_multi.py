@@ -392,3 +392,59 @@ def test_trim_gives_per_frame_memory_back(devices):
         c.render(W, H, clear=(0.1, 0.2, 0.3, 1.0), device_only=True)
     assert np.array_equal(c.read_image(W, H), want)
     c.close()
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("FORMA_TEST_FUZZ_SEEDS", "6")))))
+def test_multi_device_random_scenes_crops_and_caches(seed):
+    """ONE context over 2-5 emulated devices under the same randomised regime as the single-device cache tests: all-features
+    scenes on canvases off the tile grid, random crops and channel orders, layers moving / toggling between frames, a
+    buffer-layer cache — plain frames equal the oracle's image, cache frames the buffer it carries AND the set of tiles it
+    rewrote (the bands of the devices stitch the damage set of the whole canvas)."""
+    import forma_amd
+    rng = np.random.default_rng(52000 + seed)
+    G = int(rng.integers(2, 6))
+    w, h = int(rng.integers(60, 800)), int(rng.integers(60, 520))
+    comp = S.random_mixed(n=int(rng.integers(5, 200)), width=w, height=h, seed=53000 + seed)
+    orders = sorted(comp.layers.keys())
+    crop = None
+    if seed % 3 == 2:
+        x0, y0 = int(rng.integers(0, w // 2)), int(rng.integers(0, h // 2))
+        crop = (x0, int(rng.integers(x0 + 1, w + 1)), y0, int(rng.integers(y0 + 1, h + 1)))
+    ch = [(0, 1, 2, 3), (2, 1, 0, 3), (3, 2, 1, 0)][seed % 3]
+    clear = tuple(float(v) for v in rng.random(4))
+    o = orc.Oracle(); c = forma_amd.Context(0, devices=[0] * G)
+    try:
+        for frame_no in range(6):
+            if frame_no:
+                k = int(rng.integers(0, max(2, len(orders) // 5)))
+                moved = set(int(v) for v in rng.choice(orders, size=min(k, len(orders)), replace=False))
+                for order, layer in comp.layers.items():
+                    layer.unchanged = order not in moved
+                for m in moved:
+                    if rng.random() < 0.7:
+                        comp.layers[m].set_transform([1.0, 0.0, 0.0, 1.0, float(rng.uniform(-60, 60)), float(rng.uniform(-40, 40))])
+                    else:
+                        comp.layers[m].enabled = not comp.layers[m].enabled
+            t = comp.tables(o)
+            S.load(o, t)
+            if frame_no == 0:
+                S.load(c, t)
+            else:
+                c.set_geoms(t["geoms"]); c.set_styles(t["style_offsets"], t["style_words"], t["unchanged"])
+            want = o.render(w, h, clear=clear, crop=crop, channels=ch).reshape(h, w, 4).astype(int)
+            got = c.render(w, h, clear=clear, crop=crop, channels=ch).reshape(h, w, 4).astype(int)
+            m = np.ones((h, w), bool)
+            if crop is not None:
+                m[:] = False
+                m[crop[2] // 16 * 16: min(h, (crop[3] + 15) // 16 * 16), crop[0] // 16 * 16: min(w, (crop[1] + 15) // 16 * 16)] = True
+            assert np.abs(want - got)[m].max(initial=0) <= 1, (seed, G, frame_no, "plain")
+            sent = [np.full((h, w * 4), 201, np.uint8), np.full((h, w * 4), 201, np.uint8)]
+            o.render(w, h, clear=clear, crop=crop, channels=ch, cache_id=4, dst=sent[0])
+            c.render(w, h, clear=clear, crop=crop, channels=ch, cache_id=4, dst=sent[1])
+            assert np.abs(sent[0].astype(int) - sent[1].astype(int)).max() <= 1, (seed, G, frame_no, "cache")
+            wr = (sent[1].reshape(h, w, 4) != 201).any(axis=2)
+            tw, th = (w + 15) // 16, (h + 15) // 16
+            tiles = np.array([[wr[ty * 16: ty * 16 + 16, tx * 16: tx * 16 + 16].any() for tx in range(tw)] for ty in range(th)])
+            assert np.array_equal(tiles.reshape(-1), c.tiles_written(w, h) != 0), (seed, G, frame_no)
+    finally:
+        c.close()
