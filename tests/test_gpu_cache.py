@@ -274,6 +274,10 @@ def test_damage_sets_of_random_scenes(seed):
     w, h = int(rng.integers(40, 700)), int(rng.integers(40, 420))
     n = int(rng.integers(5, 140))
     comp = S.random_mixed(n=n, width=w, height=h, seed=500 + seed)
+    if seed % 4 == 3:                                     # all solid / Over / unclipped: the painter's kernel for such scenes
+        for layer in comp.layers.values():
+            layer.set_props(S.Props(fill_rule=layer.props.fill_rule,
+                                    fill=tuple(float(v) for v in rng.random(3)) + ((1.0,) if rng.random() < 0.4 else (float(rng.random()),))))
     orders = sorted(comp.layers.keys())
     crop = None
     if seed % 3 == 1:

@@ -234,6 +234,10 @@ def test_random_frames_with_crops_and_channel_orders(block):
             rng = np.random.default_rng(7000 + seed)
             w, h = int(rng.integers(17, 900)), int(rng.integers(17, 500))
             comp = S.random_mixed(n=int(rng.integers(1, 260)), width=w, height=h, seed=9000 + seed)
+            if seed % 5 == 0:                             # every fifth scene all solid / Over / unclipped: the painter's own kernel for those
+                for layer in comp.layers.values():
+                    layer.set_props(S.Props(fill_rule=layer.props.fill_rule,
+                                            fill=tuple(float(v) for v in rng.random(3)) + ((1.0,) if rng.random() < 0.4 else (float(rng.random()),))))
             t = comp.tables(o)
             S.load(o, t); S.load(c, t)
             crop = None
