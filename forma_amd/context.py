@@ -233,15 +233,6 @@ class Context:
         self._check(self._L.forma_hip_exchange_buffers(self._h, C.byref(ps), C.byref(pr), C.byref(w)))
         return self.device_view(ps.value, n * w.value), self.device_view(pr.value, n * w.value), int(w.value)
 
-    def _device_view_i32(self, ptr, n):
-        import torch
-
-        class _Span:
-            pass
-        sp = _Span()
-        sp.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
-        return torch.as_tensor(sp, device=torch.device("cuda", self.device))
-
     def rasterize_bucket_frame(self, width, height, timings=False):
         t = TimingsT() if timings else None
         self._check(self._L.forma_hip_rasterize_bucket_frame(self._h, width, height, None if t is None else C.addressof(t)))
