@@ -7,8 +7,9 @@
 //
 //   kid g: lines [cuts[g], cuts[g + 1])  --k_line_* / k_rasterize-->  its pixel segments, in line order
 //          --k_owner_count / _scan / _scatter-->  G buckets, bucket r = segments whose tile row device r owns
-//   ONE all-to-all over xGMI: RCCL, grouped ncclAllToAll of the padded buckets (and of their {count, overflow} pairs) on the
-//          kids' streams — equal splits, so no count has to reach the host first; every GPU pair has its own link
+//   ONE all-to-all over xGMI: RCCL, grouped ncclAllToAll of the padded buckets — each carries its {count, overflow} header
+//          as its last word — on the kids' streams: equal splits, so no count has to reach the host first; every GPU pair
+//          has its own link
 //   kid g: received buckets, rank-major = global line order  --stable radix sort (in place through the chunk map), carry
 //          pre-pass, painter-->  its band of tile rows  --hipMemcpy2D-->  its rows of the caller's buffer
 //
