@@ -133,8 +133,8 @@ int  forma_hip_create(forma_hip_ctx** out, int device);
  * whole multi-GPU frame happens inside the library, one host thread per device:
  *   every device holds the scene and rasterizes ITS share of the lines (equal pixel-segment counts, cut from the prefix
  *   sums of the line lengths) -> HIP kernels bucket the pixel segments by the device that owns their tile row -> ONE
- *   all-to-all over xGMI (RCCL: ncclCommInitAll over the devices, grouped ncclAllToAll of the padded buckets and their
- *   counts on the devices' streams, no host synchronisation) -> every device sorts and paints its band of tile rows and
+ *   all-to-all over xGMI (RCCL: ncclCommInitAll over the devices, grouped ncclAllToAll of the padded buckets, each with its
+ *   {count, overflow} header as last word, on the devices' streams, no host synchronisation) -> every device sorts and paints its band of tile rows and
  *   copies its rows straight into `dst` (disjoint row ranges, no gather collective).
  * Bands (equal pixel-segment counts per device), line shares and bucket capacities are planned on the first frame of a
  * geometry / canvas size and re-planned when a bucket outgrows its capacity.  Buffer-layer caches, crops, channel orders
