@@ -244,28 +244,37 @@ void launch_prepare_lines(hipStream_t s, const float* x, const float* y, const u
 __device__ __forceinline__ void mark_block_first(uint32_t* __restrict__ block_first, uint32_t bf_cap, uint32_t start,
                                                  uint32_t len, uint32_t c) {
     // every boundary b * RAS_TILE in [start, start + len) is owned by compacted line c
-    for (uint32_t b = (start + RAS_TILE - 1) / RAS_TILE; (uint64_t)b * RAS_TILE < (uint64_t)start + len; b++)
-        if (b < bf_cap) block_first[b] = c;
+    for (uint32_t b = (start + RAS_TILE - 1) / RAS_TILE; (uint64_t)b * RAS_TILE < (uint64_t)start + len && b < bf_cap; b++)
+        block_first[b] = c;
 }
 
 // pass A: segment count of every line + per-tile (sum, non-empty count)
 // A line costs a chain of dependent loads (slot -> geom entry; the points) behind data-dependent early exits, so the lines of
 // one thread are served one after the other: with 8 lines per thread (256-lane workgroups) the kernel took 8 such chains,
 // 19 us for 1.6 M lines on a chip that was three-quarters idle.  1024 lanes x 2 lines per tile of the same 2048 lines.
+#define LINE_LEN_SAT 0x40000000u      // a line's segment count as the frame path sums it (>= this: the frame cannot be rendered)
+#define SEG_SUM_SAT  0x7FFFFFFFu      // where 32-bit stores of segment sums saturate
 #define PL_THREADS 1024
 #define PL_IPT     (PC_TILE / PL_THREADS)
 __global__ __launch_bounds__(PL_THREADS) void k_line_len(LineSource S, uint32_t n_lines, uint32_t* __restrict__ lens,
                                                          uint32_t* __restrict__ tile_sum, uint32_t* __restrict__ tile_cnt) {
-    __shared__ uint32_t s_wsum[PL_THREADS / 64], s_wcnt[PL_THREADS / 64];
+    // Segment counts are summed in 64 bits and SATURATE at SEG_SUM_SAT where they are stored as 32-bit words: geometry that
+    // asks for more pixel segments than a device holds (a line from x = -1e20, a transform gone wild) must end as
+    // FORMA_E_CAPACITY on the host, not as prefix sums that wrapped around and tables that point anywhere (the reference wraps
+    // in release builds and panics in debug ones, segment.rs:86-98).  A single line is cut off at LINE_LEN_SAT: longer ones
+    // fail the frame anyway.
+    __shared__ uint64_t s_wsum[PL_THREADS / 64];
+    __shared__ uint32_t s_wcnt[PL_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t base = blockIdx.x * PC_TILE;
-    uint32_t sum = 0, cnt = 0;
+    uint64_t sum = 0;
+    uint32_t cnt = 0;
     if (S.sums) {
 #pragma unroll
         for (int r = 0; r < PL_IPT; r++) {
             const uint32_t i = base + r * PL_THREADS + tid;
             uint32_t len = 0;
-            if (i < n_lines) { len = S.sums[i] - (i ? S.sums[i - 1] : 0u); lens[i] = len; }
+            if (i < n_lines) { len = min(S.sums[i] - (i ? S.sums[i - 1] : 0u), LINE_LEN_SAT); lens[i] = len; }
             sum += len; cnt += len ? 1u : 0u;
         }
     } else {
@@ -288,7 +297,7 @@ __global__ __launch_bounds__(PL_THREADS) void k_line_len(LineSource S, uint32_t 
 #pragma unroll
         for (int r = 0; r < PL_IPT; r++) {
             const uint32_t i = base + r * PL_THREADS + tid;
-            const uint32_t len = line_params_loaded(g[r], p0x[r], p0y[r], p1x[r], p1y[r], S.width, S.height, S.band_lo, S.band_hi).len;
+            const uint32_t len = min(line_params_loaded(g[r], p0x[r], p0y[r], p1x[r], p1y[r], S.width, S.height, S.band_lo, S.band_hi).len, LINE_LEN_SAT);
             if (i < n_lines) lens[i] = len;
             sum += len; cnt += len ? 1u : 0u;
         }
@@ -298,37 +307,40 @@ __global__ __launch_bounds__(PL_THREADS) void k_line_len(LineSource S, uint32_t 
     if (lane == 0) { s_wsum[w] = sum; s_wcnt[w] = cnt; }
     __syncthreads();
     if (tid == 0) {
-        uint32_t ts = 0, tc = 0;
+        uint64_t ts = 0; uint32_t tc = 0;
         for (int i = 0; i < PL_THREADS / 64; i++) { ts += s_wsum[i]; tc += s_wcnt[i]; }
-        tile_sum[blockIdx.x] = ts; tile_cnt[blockIdx.x] = tc;
+        tile_sum[blockIdx.x] = (uint32_t)min(ts, (uint64_t)SEG_SUM_SAT); tile_cnt[blockIdx.x] = tc;
     }
 }
 
 // pass B: one workgroup, exclusive scan of both per-tile arrays in place; totals -> info
 __global__ __launch_bounds__(1024) void k_scan_line_tiles(uint32_t* __restrict__ tile_sum, uint32_t* __restrict__ tile_cnt,
                                                           uint32_t nb, FrameInfo* __restrict__ info) {
-    __shared__ uint32_t lds_a[17], lds_b[17];
-    uint32_t carry_a = 0, carry_b = 0;
+    __shared__ uint64_t lds_a[17];
+    __shared__ uint32_t lds_b[17];
+    uint64_t carry_a = 0;                               // (64-bit sums, saturating where stored: see k_line_len)
+    uint32_t carry_b = 0;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (uint32_t base = 0; base < nb; base += 1024) {
         const uint32_t idx = base + threadIdx.x;
-        const uint32_t a = idx < nb ? tile_sum[idx] : 0u, b = idx < nb ? tile_cnt[idx] : 0u;
-        uint32_t ia = a, ib = b;
+        const uint64_t a = idx < nb ? tile_sum[idx] : 0u;
+        const uint32_t b = idx < nb ? tile_cnt[idx] : 0u;
+        uint64_t ia = a; uint32_t ib = b;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t ta = __shfl_up(ia, d, 64), tb = __shfl_up(ib, d, 64);
+            const uint64_t ta = __shfl_up(ia, d, 64); const uint32_t tb = __shfl_up(ib, d, 64);
             if (lane >= d) { ia += ta; ib += tb; }
         }
         if (lane == 63) { lds_a[w] = ia; lds_b[w] = ib; }
         __syncthreads();
-        uint32_t wa = 0, wb = 0, ta = 0, tb = 0;
+        uint64_t wa = 0, ta = 0; uint32_t wb = 0, tb = 0;
 #pragma unroll
         for (int i = 0; i < 16; i++) { if (i < w) { wa += lds_a[i]; wb += lds_b[i]; } ta += lds_a[i]; tb += lds_b[i]; }
-        if (idx < nb) { tile_sum[idx] = carry_a + wa + ia - a; tile_cnt[idx] = carry_b + wb + ib - b; }
+        if (idx < nb) { tile_sum[idx] = (uint32_t)min(carry_a + wa + ia - a, (uint64_t)SEG_SUM_SAT); tile_cnt[idx] = carry_b + wb + ib - b; }
         carry_a += ta; carry_b += tb;
         __syncthreads();
     }
-    if (threadIdx.x == 0) { info->n_segments = carry_a; info->n_compact = carry_b; }
+    if (threadIdx.x == 0) { info->n_segments = (uint32_t)min(carry_a, (uint64_t)SEG_SUM_SAT); info->n_compact = carry_b; }
 }
 
 // pass C: compacted line table (cl_idx, cl_start) + block_first; no inter-workgroup dependency
@@ -337,20 +349,22 @@ __global__ __launch_bounds__(PC_THREADS) void k_line_compact(const uint32_t* __r
                                                              const uint32_t* __restrict__ tile_cnt,
                                                              uint32_t* __restrict__ cl_idx, uint32_t* __restrict__ cl_start,
                                                              uint32_t* __restrict__ block_first, uint32_t bf_cap) {
-    __shared__ uint32_t s_wsum[PC_THREADS / 64], s_wcnt[PC_THREADS / 64];
+    __shared__ uint64_t s_wsum[PC_THREADS / 64];
+    __shared__ uint32_t s_wcnt[PC_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t base = blockIdx.x * PC_TILE + tid * PC_IPT;         // 8 consecutive lines per thread
-    uint32_t l[PC_IPT], sum = 0, cnt = 0;
+    uint32_t l[PC_IPT], cnt = 0;
+    uint64_t sum = 0;                                                   // (64-bit sums, saturating where stored: see k_line_len)
 #pragma unroll
     for (int q = 0; q < PC_IPT; q++) { l[q] = base + q < n_lines ? lens[base + q] : 0u; sum += l[q]; cnt += l[q] ? 1u : 0u; }
-    uint32_t isum = sum, icnt = cnt;
+    uint64_t isum = sum; uint32_t icnt = cnt;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t ts = __shfl_up(isum, d, 64), tc = __shfl_up(icnt, d, 64);
+        const uint64_t ts = __shfl_up(isum, d, 64); const uint32_t tc = __shfl_up(icnt, d, 64);
         if (lane >= d) { isum += ts; icnt += tc; }
     }
     if (lane == 63) { s_wsum[w] = isum; s_wcnt[w] = icnt; }
-    uint32_t bsum = tile_sum[blockIdx.x], bcnt = tile_cnt[blockIdx.x];   // (in flight across the barrier)
+    uint64_t bsum = tile_sum[blockIdx.x]; uint32_t bcnt = tile_cnt[blockIdx.x];   // (in flight across the barrier)
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < PC_THREADS / 64; i++) if (i < w) { bsum += s_wsum[i]; bcnt += s_wcnt[i]; }
@@ -361,13 +375,14 @@ __global__ __launch_bounds__(PC_THREADS) void k_line_compact(const uint32_t* __r
     uint32_t tile_n = 0;
 #pragma unroll
     for (int i = 0; i < PC_THREADS / 64; i++) tile_n += s_wcnt[i];
-    uint32_t start = bsum + isum - sum, c = bcnt + icnt - cnt;
+    uint64_t start = bsum + isum - sum; uint32_t c = bcnt + icnt - cnt;
 #pragma unroll
     for (int q = 0; q < PC_IPT; q++) {
         if (l[q]) {
+            const uint32_t st = (uint32_t)min(start, (uint64_t)SEG_SUM_SAT);
             s_idx[c - tile_c0] = base + q;
-            s_start[c - tile_c0] = start;
-            mark_block_first(block_first, bf_cap, start, l[q], c);
+            s_start[c - tile_c0] = st;
+            mark_block_first(block_first, bf_cap, st, l[q], c);
             start += l[q]; c++;
         }
     }

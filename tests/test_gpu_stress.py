@@ -262,3 +262,43 @@ def test_random_frames_with_crops_and_channel_orders(block):
                 assert np.array_equal(c.segments(1), o.segments(1)), (seed, frame)
     finally:
         c.close()
+
+
+def test_absurd_geometry_is_an_error_not_a_fault():
+    """Coordinates no canvas can hold — a point at x = -1e20, 3e38, +-inf, NaN, 2^31 — ask for more pixel segments than a device
+    holds (or for none).  The reference wraps its 32-bit sums in release builds and panics in debug ones (segment.rs:86-98);
+    here the line kernels sum in 64 bits, saturate, and the frame ends as FORMA_E_CAPACITY (or renders, when the lines are
+    dropped) — never as prefix sums that wrapped around and a device memory fault.  The context stays usable."""
+    import forma_amd
+    from forma_amd._lib import FormaError
+    specials = [np.nan, np.inf, -np.inf, 3e38, -3e38, 1e20, -1e20, 2147483648.0, -2147483904.0, 16777216.0, -1e9]
+    o = orc.Oracle(); c = forma_amd.Context(0, frames_in_flight=2)
+    try:
+        good = S.random_mixed(n=40, width=320, height=200, seed=3)
+        tg = good.tables(o)
+        S.load(o, tg)
+        want = o.render(320, 200)
+        outcomes = set()
+        for seed in range(60):
+            rng = np.random.default_rng(66000 + seed)
+            t = dict(S.random_mixed(n=int(rng.integers(1, 30)), width=320, height=200, seed=67000 + seed).tables(o))
+            x, y = t["x"].copy(), t["y"].copy()
+            for _ in range(int(rng.integers(1, 6))):
+                i = int(rng.integers(0, len(x)))
+                (x if rng.random() < 0.5 else y)[i] = np.float32(specials[int(rng.integers(0, len(specials)))])
+            t["x"], t["y"] = x, y
+            S.load(c, t)
+            try:
+                for _ in range(3):
+                    c.render(320, 200, device_only=True)
+                c.sync()
+                outcomes.add("rendered")
+            except FormaError as e:
+                assert e.code == -4, e                                  # FORMA_E_CAPACITY
+                outcomes.add("capacity")
+            if seed % 10 == 9:                                          # the context is still good for a sane scene
+                S.load(c, tg)
+                assert np.array_equal(c.render(320, 200), want), seed
+        assert outcomes == {"rendered", "capacity"}
+    finally:
+        c.close()
