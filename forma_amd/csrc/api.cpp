@@ -529,6 +529,8 @@ int finish_frame(forma_hip_ctx* ctx, forma_timings_t* t, bool have_info = false)
     ctx->pred_no_deep = !(ctx->h_info->error & 16u);       // (8, 16: bookkeeping bits, not errors)
     if (!ctx->h_info->plan_bad) ctx->pred_row_spans = ctx->h_info->n_spans / ctx->cur_rows_painted;
     if (!ctx->h_info->plan_bad) { ctx->pred_max_slice = ctx->h_info->max_slice_runs; ctx->pred_slice_n = ctx->cur_slices; ctx->pred_slice_small = ctx->cur_small; }
+    if ((ctx->h_info->error & ~24u) == 1u)                   // (bit 0: k_carry_rows met a run of a layer without a style)
+        return fail(ctx, FORMA_E_ARG, "a geometry entry names an order that has no style (forma_hip_set_styles: offset FORMA_NONE or beyond the table)");
     if (ctx->h_info->error & ~24u) return fail(ctx, FORMA_E_INTERNAL, "device-side invariant violated");
     if (!t) return FORMA_OK;
     memset(t, 0, sizeof *t);
