@@ -81,7 +81,9 @@ struct PaintParams {
 // group (ascending layer, like the row list).  A wave painter scans its group's list (~65 entries on the 4K scene) instead
 // of the row's (739).  tab[(row * n_slices + slice) * n_groups + g] = {first entry, count}; count = SPAN_GROUP_NONE: the pool
 // was full, the painter scans the row list as before.
+#ifndef SPAN_GROUP_SHIFT
 #define SPAN_GROUP_SHIFT 4
+#endif
 #define SPAN_GROUP_TILES (1u << SPAN_GROUP_SHIFT)
 #define SPAN_GROUP_NONE  0xFFFFFFFFu
 #define SPAN_GROUP_MIN_ROW 256u
