@@ -1179,6 +1179,7 @@ int forma_hip_trim(forma_hip_ctx* ctx) {
             for (auto& tcache : c->caches) kept += tcache.tiles.cap + tcache.image.cap;
             fprintf(stderr, "[forma_hip_trim] context %p: released %zu bytes, keeps %zu\n", (void*)c, freed, kept);
         }
+        if (c->h_stage) { (void)hipHostFree(c->h_stage); c->h_stage = nullptr; c->h_stage_cap = 0; }   // (pinned: a whole 4K image after a cache frame)
         c->sorted = nullptr; c->n_seg = 0; c->have_unsorted = false;
         c->cur_image = nullptr; c->img_w = 0; c->img_h = 0;
         c->pending_masks = PendingMasks{nullptr, 0u};
