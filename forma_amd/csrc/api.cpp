@@ -962,6 +962,23 @@ void frame_done(forma_hip_ctx* ctx, int rc, const PaintArgs& a) {      // render
     if (rc == FORMA_OK && a.cache_id >= 0) { ctx->caches[a.cache_id].has_clear = true; memcpy(ctx->caches[a.cache_id].clear, a.clear, 16); }
 }
 
+// FORMA_HIP_POISON_FRAME=<byte> (tests, tools): every per-frame buffer is refilled with that byte when a frame starts.  Frames of
+// a test re-render one scene, so a kernel that reads what THIS frame never wrote normally finds last frame's (identical,
+// "right") data there; with the refill it finds the poison.  Scene uploads, caches and the scratch image (a cropped frame
+// legitimately leaves the rest of it alone) are not touched.
+int poison_frame_buffers(forma_hip_ctx* c) {
+    static const char* poison = getenv("FORMA_HIP_POISON_FRAME");
+    if (!poison) return FORMA_OK;
+    forma_hip_ctx* ctx = c;
+    const int byte = (int)strtol(poison, nullptr, 0);
+    DevBuf* frame[] = {&c->scan_tmp, &c->cl_idx, &c->cl_start, &c->block_first, &c->prep_scratch, &c->seg_u, &c->seg_a, &c->seg_b,
+                       &c->sort_counters, &c->records, &c->rk_u, &c->rk_a, &c->rk_b, &c->blk_edge, &c->runs_scratch, &c->row_tab,
+                       &c->span_key, &c->span_cov, &c->ras_masks, &c->huge_offs, &c->huge_key, &c->huge_tmp, &c->huge_flag,
+                       &c->grp_tab, &c->grp_list, &c->run_lt, &c->pack_list, &c->pack_pix};
+    for (DevBuf* b : frame) if (b->p && !b->borrowed) HIPCHECK(hipMemsetAsync(b->p, byte, b->cap, c->stream));
+    return FORMA_OK;
+}
+
 // A read-back-free frame, first half: everything is enqueued on the context's stream, nothing waits.  N, J and the sort
 // plan are predicted from the previous frame (bounds with slack); device-side guards keep a wrong guess memory-safe.
 int enqueue_async_frame(forma_hip_ctx* ctx, const PaintArgs& a, bool timing, uint32_t* bN_out, uint32_t* bJ_out) {
@@ -969,6 +986,7 @@ int enqueue_async_frame(forma_hip_ctx* ctx, const PaintArgs& a, bool timing, uin
     *bN_out = bN; *bJ_out = bJ;
     FrameInfo* dinfo = ctx->info.as<FrameInfo>();
     int rc;
+    if ((rc = poison_frame_buffers(ctx))) return rc;
     if ((rc = run_rasterize_frame(ctx, a.width, a.height, timing, true, bN))) return rc;
     if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), DevCount{&dinfo->n_segments, bN}, timing))) return rc;
     if ((rc = run_paint(ctx, DevCount{&dinfo->n_segments, bN}, a, timing, bJ))) return rc;
@@ -1004,6 +1022,7 @@ int complete_async_frame(forma_hip_ctx* ctx, const PaintArgs& a, uint8_t* dst, s
 int render_sync(forma_hip_ctx* ctx, const PaintArgs& a, uint8_t* dst, size_t stride_bytes, bool timing, forma_timings_t* timings) {
     int rc;
     for (int attempt = 0; attempt < 2; attempt++) {
+        if ((rc = poison_frame_buffers(ctx))) return rc;
         if ((rc = run_rasterize_frame(ctx, a.width, a.height, timing, /*speculate=*/attempt == 0))) return rc;
         if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), DevCount{nullptr, (uint32_t)ctx->n_seg}, timing))) return rc;
         rc = run_paint(ctx, DevCount{nullptr, (uint32_t)ctx->n_seg}, a, timing);
@@ -1295,6 +1314,7 @@ int forma_hip_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t heigh
     if (rc) return rc;
     HIPCHECK(hipSetDevice(ctx->device));
     clear_stage_flags(ctx);
+    if ((rc = poison_frame_buffers(ctx))) return rc;
     if ((rc = run_rasterize_frame(ctx, width, height, timings != nullptr))) return rc;
     ctx->n_passes = 0; ctx->last_runs = 0; ctx->last_entries = 0;
     return finish_frame(ctx, timings);
@@ -1398,6 +1418,7 @@ int forma_hip_rasterize_bucket_frame(forma_hip_ctx* ctx, uint32_t width, uint32_
     }
     ctx->h_xlocal[1] = 0;
     const uint32_t bN = (ctx->xpred_valid && !ctx->no_async) ? ctx->xpred_N + ctx->xpred_N / 16 + 4096 : 0;
+    if ((rc = poison_frame_buffers(ctx))) return rc;
     if ((rc = run_rasterize_frame(ctx, width, height, timing, false, bN))) return rc;
     FrameInfo* dinfo = ctx->info.as<FrameInfo>();
     DevCount nc = bN ? DevCount{&dinfo->n_segments, bN} : DevCount{nullptr, (uint32_t)ctx->n_seg};
