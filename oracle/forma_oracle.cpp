@@ -1533,10 +1533,19 @@ int oracle_paint_flush(void* o_, const uint64_t* segs, size_t n, uint8_t* dst, u
 int oracle_cache_clear(void* o_, int cache_id) { Oracle* o = (Oracle*)o_; auto it = o->caches.find(cache_id); if (it != o->caches.end()) it->second.clear_all(); return 0; }
 
 // the whole frame: cpu::Renderer::render (renderer.rs:75-224)
+// The reference's 32-bit prefix sums wrap in release builds and panic in debug ones (segment.rs:86-98) when geometry asks for
+// more pixel segments than a u32 counts; the checker refuses such a frame (the product's FORMA_E_CAPACITY, same limit)
+// instead of walking tables that wrapped around.
+static bool segment_sums_fit(const Lines& L) {
+    const size_t n = L.lengths.size();
+    for (size_t i = 1; i < n; i++) if (L.lengths[i] < L.lengths[i - 1]) return false;
+    return n == 0 || L.lengths[n - 1] < (1u << 30);
+}
 int oracle_render(void* o_, uint8_t* dst, uint32_t width, uint32_t height, size_t stride, const uint8_t channels[4],
                   const float clear[4], const forma_rect_t* crop, int cache_id, float* tile_dump) {
     Oracle* o = (Oracle*)o_; set_threads(o->threads);
     prepare_lines(o->x.data(), o->y.data(), o->line_slot.data(), o->x.size(), o->geoms.data(), o->geoms.size(), (float)width, (float)height, o->lines);
+    if (!segment_sums_fit(o->lines)) return -4;
     rasterize(o->lines, o->unsorted);
     o->sort_frame();
     return oracle_paint(o_, o->sorted.data(), o->sorted.size(), dst, width, height, stride, channels, clear, crop, cache_id, tile_dump);
@@ -1545,6 +1554,7 @@ int oracle_render_flush(void* o_, uint8_t* dst, uint32_t width, uint32_t height,
                         const float clear[4], const forma_rect_t* crop, int cache_id, oracle_flush_fn fn, void* user) {
     Oracle* o = (Oracle*)o_; set_threads(o->threads);
     prepare_lines(o->x.data(), o->y.data(), o->line_slot.data(), o->x.size(), o->geoms.data(), o->geoms.size(), (float)width, (float)height, o->lines);
+    if (!segment_sums_fit(o->lines)) return -4;
     rasterize(o->lines, o->unsorted);
     o->sort_frame();
     return oracle_paint_flush(o_, o->sorted.data(), o->sorted.size(), dst, width, height, stride, channels, clear, crop, cache_id, fn, user);
