@@ -48,6 +48,11 @@ class TimingsT(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class ContextInfoT(C.Structure):
+    _fields_ = [("n_devices", C.c_uint32), ("frames_in_flight", C.c_uint32), ("transport", C.c_uint32), ("reserved", C.c_uint32),
+                ("devices", C.c_int32 * 8)]
+
+
 class FlattenTablesT(C.Structure):
     _fields_ = [("point_commands", C.c_void_p), ("point_indices", C.c_void_p), ("quad_indices", C.c_void_p), ("n_points", C.c_size_t),
                 ("qx", C.c_void_p), ("qy", C.c_void_p), ("qw", C.c_void_p), ("x0", C.c_void_p), ("dx_recip", C.c_void_p),
@@ -77,6 +82,7 @@ SYMBOLS = {
     "forma_hip_cache_clear": (_i, [_vp, _i]),
     "forma_hip_set_frames_in_flight": (_i, [_vp, _i]),
     "forma_hip_sync": (_i, [_vp]),
+    "forma_hip_context_info": (_i, [_vp, _vp]),
     "forma_hip_trim": (_i, [_vp]),
     "forma_hip_read_segments": (_i, [_vp, _i, _vp, _sz, _vp]),
     "forma_hip_read_image": (_i, [_vp, _vp, _sz]),
@@ -114,6 +120,8 @@ def lib():
                                  f"(there is no CPU fallback)")
         L = C.CDLL(SO_PATH)
         for name, (res, args) in SYMBOLS.items():
+            if os.environ.get("FORMA_HIP_LIB") and not hasattr(L, name):
+                continue                                  # (tools/ab_fast.py: an older build of the library, for A/B timing only)
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args

@@ -43,6 +43,15 @@ class Context:
         """forma_hip_set_frames_in_flight: device-resident, cache-less frames are enqueued on n frame slots; see sync()"""
         self._check(self._L.forma_hip_set_frames_in_flight(self._h, int(n)))
 
+    def info(self):
+        """devices, frame slots and — for a multi-device context — the exchange transport ('rccl' / 'copy')."""
+        from ._lib import ContextInfoT
+        ci = ContextInfoT()
+        self._check(self._L.forma_hip_context_info(self._h, C.byref(ci)))
+        return {"n_devices": int(ci.n_devices), "frames_in_flight": int(ci.frames_in_flight),
+                "transport": {0: "none", 1: "rccl", 2: "copy"}.get(int(ci.transport), "?"),
+                "devices": [int(ci.devices[i]) for i in range(ci.n_devices)]}
+
     def trim(self):
         """forma_hip_trim: give the per-frame device memory back (scene and caches stay)"""
         self._check(self._L.forma_hip_trim(self._h))

@@ -32,7 +32,16 @@ int read_info(forma_hip_ctx* ctx) {
 }
 
 int reset_info(forma_hip_ctx* ctx) {              // device-to-device from a template: no host round trip
-    HIPCHECK(hipMemcpyAsync(ctx->info.p, ctx->info_init.p, sizeof(FrameInfo), hipMemcpyDeviceToDevice, ctx->stream));
+    // (a read-back-free frame ends with k_frame_tail, which leaves the device copy pristine: the next frame's reset is free)
+    if (!ctx->info_clean) HIPCHECK(hipMemcpyAsync(ctx->info.p, ctx->info_init.p, sizeof(FrameInfo), hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->info_clean = false;
+    return FORMA_OK;
+}
+// the end of a read-back-free frame: FrameInfo to pinned host memory (and / or the segment count to a pinned word), device copy reset
+int frame_tail(forma_hip_ctx* ctx, bool to_host_info, uint32_t* host_count) {
+    launch_frame_tail(ctx->stream, ctx->info.as<FrameInfo>(), to_host_info ? ctx->h_info : nullptr, host_count);
+    HIPCHECK(hipGetLastError());
+    ctx->info_clean = true;
     return FORMA_OK;
 }
 
@@ -44,7 +53,8 @@ int check_canvas(forma_hip_ctx* ctx, uint32_t width, uint32_t height) {
 
 // prepare + scan + compact.  Synchronous form (bound_n == 0): (n_segments, n_compact) are read back and block_first is
 // valid for N.  Asynchronous form: nothing is read back, block_first is provisioned for bound_n segments.
-int run_line_table(forma_hip_ctx* ctx, const LineSource& src, size_t n_lines, bool timing, uint32_t bound_n = 0) {
+int run_line_table(forma_hip_ctx* ctx, const LineSource& src, size_t n_lines, bool timing, uint32_t bound_n = 0,
+                   const ZeroJobs* zero = nullptr) {
     HIPCHECK(ctx->cl_idx.ensure(n_lines * 4));
     HIPCHECK(ctx->cl_start.ensure(n_lines * 4));
     HIPCHECK(ctx->prep_scratch.ensure(prepare_scratch_words(n_lines) * 4));
@@ -52,7 +62,7 @@ int run_line_table(forma_hip_ctx* ctx, const LineSource& src, size_t n_lines, bo
     const uint32_t bf_cap = (uint32_t)std::min<size_t>(ctx->block_first.cap / 4, 0xFFFFFFFFu);
     stage_begin(ctx, ST_PREPARE, timing);
     launch_prepare_compact(ctx->stream, src, (uint32_t)n_lines, ctx->cl_idx.as<uint32_t>(), ctx->cl_start.as<uint32_t>(),
-                           ctx->block_first.as<uint32_t>(), bf_cap, ctx->prep_scratch.as<uint32_t>(), ctx->info.as<FrameInfo>());
+                           ctx->block_first.as<uint32_t>(), bf_cap, ctx->prep_scratch.as<uint32_t>(), ctx->info.as<FrameInfo>(), zero);
     stage_end(ctx, ST_PREPARE, timing);
     HIPCHECK(hipGetLastError());
     if (bound_n) return FORMA_OK;
@@ -95,17 +105,19 @@ int finish_rasterize(forma_hip_ctx* ctx) {
 // bound_n != 0: fully asynchronous (no read-back): N is only known to the device, buffers / grids are provisioned for
 // bound_n segments, the sort plan is the speculated one.
 int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, bool timing, bool speculate = false,
-                        uint32_t bound_n = 0) {
+                        uint32_t bound_n = 0, const ZeroJobs* zero = nullptr, const forma_hip_ctx::PreZero* cleared = nullptr) {
     const size_t all_lines = ctx->n_points ? ctx->n_points - 1 : 0;
     const size_t n_lines = ctx->line_ranged ? std::min(ctx->line_hi, all_lines) - std::min(ctx->line_lo, all_lines) : all_lines;
     ctx->n_lines = n_lines;
     ctx->n_seg = 0; ctx->n_compact = 0; ctx->have_unsorted = true; ctx->live44 = 0; ctx->layer_sorted = true;
     ctx->speculated = false;
+    ctx->pz = forma_hip_ctx::PreZero();                   // (nothing of this frame has been cleared ahead of its stage yet)
     int rc = reset_info(ctx);
     if (rc) return rc;
     if (n_lines == 0) return FORMA_OK;
     const LineSource S = geometry_source(ctx, width, height);
-    if ((rc = run_line_table(ctx, S, n_lines, timing, bound_n))) return rc;
+    if ((rc = run_line_table(ctx, S, n_lines, timing, bound_n, zero))) return rc;
+    if (zero && cleared) ctx->pz = *cleared;              // (k_line_len ran: the words of `zero` are cleared for the later stages)
     FrameInfo* dinfo = ctx->info.as<FrameInfo>();
     DevCount nc_seg, nc_cmp;
     if (bound_n) {
@@ -137,6 +149,37 @@ int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, boo
     return finish_rasterize(ctx);
 }
 
+// the digit plan of a frame's segment sort: live key bits only; a stream that is already non-decreasing in layer needs a
+// stable sort by tile alone
+SortPlan frame_sort_plan(uint64_t live44, bool layer_sorted, int digit_bits) {
+    uint64_t live = live44;
+    if (layer_sorted) live &= ~0x1FFFFFull;
+    return make_sort_plan(live << 20, 20, 64, digit_bits);
+}
+
+// What the frame's FIRST kernel (k_line_len) clears for the later stages of a read-back-free frame — the sort's histograms,
+// tickets and status rows, the tile tables — instead of memset operations on the stream: a
+// band frame of a multi-device context is ~250 us of kernels, and every stream operation costs the host ~5 us and the device a
+// dispatch of its own.  The buffers are grown here, before anything of the frame is enqueued, so that the stages' own
+// `ensure` calls find them in place.  `sort_n`: the keys the frame's sort will see (its provisioning bound).
+int plan_zero_jobs(forma_hip_ctx* ctx, uint32_t width, uint32_t height, uint32_t sort_n, uint32_t runs_n, ZeroJobs* Z,
+                   forma_hip_ctx::PreZero* cleared) {
+    memset(Z, 0, sizeof *Z);
+    *cleared = forma_hip_ctx::PreZero();
+    if (ctx->dbg.no_prezero) return FORMA_OK;
+    const uint32_t tiles_w = (width + 15) / 16, tiles_h = (height + 15) / 16;
+    const SortPlan plan = frame_sort_plan(ctx->pred_live44, ctx->pred_layer_sorted, ctx->digit_bits);
+    HIPCHECK(ctx->sort_counters.ensure(sort_scratch_words(std::max<size_t>(sort_n, 1)) * 4));
+    HIPCHECK(ctx->row_tab.ensure(((size_t)row_tab_zero_words(tiles_w, tiles_h) + 3 * (size_t)tiles_w * tiles_h) * 4));
+    (void)runs_n;
+    const size_t sw = sort_n > 1 && plan.n_passes ? sort_zero_words(sort_n, plan) : 0;
+    const size_t tw = row_tab_zero_words(tiles_w, tiles_h);
+    if (sw > 0xFFFFFFFFull || tw > 0xFFFFFFFFull) return FORMA_OK;           // (absurd sizes: the stages clear for themselves)
+    if (sw) { Z->p[Z->n] = ctx->sort_counters.as<uint32_t>(); Z->words[Z->n++] = (uint32_t)sw; cleared->sort_p = ctx->sort_counters.p; cleared->sort_words = sw; }
+    Z->p[Z->n] = ctx->row_tab.as<uint32_t>(); Z->words[Z->n++] = (uint32_t)tw; cleared->tab_p = ctx->row_tab.p; cleared->tab_words = tw;
+    return FORMA_OK;
+}
+
 // stage 3 on `src` (nc segments, device): result pointer in ctx->sorted
 int run_sort(forma_hip_ctx* ctx, const uint64_t* src, DevCount nc, bool timing, int digit_bits = 0,
              const ChunkedSrc* chunked = nullptr) {
@@ -147,21 +190,21 @@ int run_sort(forma_hip_ctx* ctx, const uint64_t* src, DevCount nc, bool timing, 
     HIPCHECK(ctx->seg_a.ensure((std::max<size_t>(n, 1) + SEG_PAD) * 8));
     HIPCHECK(ctx->seg_b.ensure((std::max<size_t>(n, 1) + SEG_PAD) * 8));
     HIPCHECK(ctx->sort_counters.ensure(sort_scratch_words(std::max<size_t>(n, 1)) * 4));
-    uint64_t live = ctx->live44;
-    if (ctx->layer_sorted) live &= ~0x1FFFFFull;     // stream already non-decreasing in layer: stable sort by tile only
-    const SortPlan plan = make_sort_plan(live << 20, 20, 64, digit_bits);
+    const SortPlan plan = frame_sort_plan(ctx->live44, ctx->layer_sorted, digit_bits);
     ctx->n_passes = plan.n_passes;
+    const bool zeroed = ctx->pz.sort_p == ctx->sort_counters.p && ctx->pz.sort_words >= sort_zero_words(n, plan);
+    ctx->pz.sort_p = nullptr;
     stage_begin(ctx, ST_SORT, timing);
     ctx->sorted = (uint64_t*)launch_radix_sort(ctx->stream, src, ctx->seg_a.as<uint64_t>(), ctx->seg_b.as<uint64_t>(), nc, plan,
                                                digit_bits, ctx->sort_counters.as<uint32_t>(), &ctx->info.as<FrameInfo>()->error,
                                                timing ? ctx->pev0 : nullptr, timing ? ctx->pev1 : nullptr, chunked,
-                                               ctx->info.as<FrameInfo>());
+                                               ctx->info.as<FrameInfo>(), zeroed);
     stage_end(ctx, ST_SORT, timing);
     HIPCHECK(hipGetLastError());
     return FORMA_OK;
 }
 
-#define FORMA_RETRY 1     /* internal: the speculated sort plan was wrong, run the frame again */
+
 // h_info holds a fresh copy of the device FrameInfo: remember the sort-plan inputs of this frame and, if the plan was
 // speculated from the previous frame, verify it.  Called at the run-count read-back, i.e. BEFORE any kernel that
 // assumes a correctly sorted stream is launched (everything up to there is in-bounds for any digit plan).
@@ -239,12 +282,15 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     HIPCHECK(ctx->blk_edge.ensure(runs_blocks(std::max<size_t>(n, 1)) * sizeof(BlkEdge)));
     HIPCHECK(ctx->runs_scratch.ensure(runs_scratch_words(std::max<size_t>(n, 1)) * 4));
     stage_begin(ctx, ST_CARRY, timing);
+    const bool tables_zero = ctx->pz.tab_p == ctx->row_tab.p && ctx->pz.tab_words >= row_tab_zero_words(tiles_w, tiles_h);
+    ctx->pz.tab_p = nullptr;
     launch_runs(ctx->stream, ctx->sorted, nc, tiles_w, tiles_h, ctx->records.as<TileRecord>(), (uint32_t)cap,
                 ctx->rk_u.as<uint64_t>(), tile_first_run, ctx->blk_edge.as<BlkEdge>(), row_count,
                 ctx->runs_scratch.as<uint32_t>(), dinfo, /*verify_plan=*/bound_j != 0 && ctx->speculated, ctx->live44,
-                ctx->layer_sorted, ctx->legacy_runs, ctx->pending_masks,
+                ctx->layer_sorted, ctx->pending_masks,
                 RunStyle{ctx->layer_sf.as<uint32_t>(), (uint32_t)ctx->n_orders,
-                         (a.cache_id >= 0 && ctx->have_unchanged) ? ctx->unchanged.as<uint8_t>() : nullptr, ctx->run_lt.as<uint32_t>()});
+                         (a.cache_id >= 0 && ctx->have_unchanged) ? ctx->unchanged.as<uint8_t>() : nullptr, ctx->run_lt.as<uint32_t>()},
+                tables_zero);
     ctx->pending_masks = PendingMasks{nullptr, 0u};
     HIPCHECK(hipGetLastError());
     DevCount jc;
@@ -332,6 +378,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
             sorted_keys = launch_radix_sort(ctx->stream, ctx->rk_u.as<uint64_t>(), ctx->rk_a.as<uint64_t>(),
                                             ctx->rk_b.as<uint64_t>(), jc, rk_plan, ctx->digit_bits,
                                             ctx->sort_counters.as<uint32_t>(), &dinfo->error, nullptr, nullptr);
+            ctx->pz.sort_p = nullptr;
         }
         if (ctx->force_slices) n_slices = ctx->force_slices;  // FORMA_HIP_CARRY_SLICES (tests: every slice count on one GPU)
         uint32_t bin_shift = 0;                             // 256 layer bins over the orders in use
@@ -342,7 +389,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                           (uint32_t)ctx->n_orders, tiles_w, tiles_h, row_count, row_span_lo,
                           row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(),
                           (a.cache_id >= 0 && ctx->have_unchanged) ? ctx->unchanged.as<uint8_t>() : nullptr, dinfo,
-                          runs_edge_segments(ctx->legacy_runs),
+                          runs_edge_segments(),
                           // invisible carries of a partial last tile row are dropped only when nothing can observe them: with a
                           // buffer-layer cache the layer count of a tile is state (passes/tile_unchanged.rs)
                           // ... nor when the channel order tells a folded tile from a painted one: the solid fold encodes output
@@ -406,20 +453,28 @@ int finish_paint(forma_hip_ctx* ctx) {
     std::vector<uint64_t> offs(n);
     uint64_t total = 0;
     for (uint32_t i = 0; i < n; i++) { offs[i] = total; total += list[2 * i + 1]; }
-    if (total >= (1ull << 31)) return fail(ctx, FORMA_E_CAPACITY, "more than 2^31 layer-list entries in the deep tiles of one frame");
+    // (32 bytes of list per entry: 2^27 entries are 4 GB of scratch — beyond that the frame is refused, not attempted)
+    if (total >= (1ull << 27)) return fail(ctx, FORMA_E_CAPACITY, "more than 2^27 layer-list entries in the deep tiles of one frame");
     HIPCHECK(ctx->huge_offs.ensure(std::max<size_t>(n, 1) * 8));
     HIPCHECK(ctx->huge_key.ensure(std::max<uint64_t>(total, 1) * 4 * 8));
     HIPCHECK(ctx->huge_tmp.ensure(std::max<uint64_t>(total, 1) * 8));
     HIPCHECK(ctx->huge_flag.ensure(std::max<uint64_t>(total, 1) * 4));
     if (n) HIPCHECK(hipMemcpyAsync(ctx->huge_offs.p, offs.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-    launch_paint_huge(ctx->stream, h.P, ctx->sorted, ctx->records.as<TileRecord>(), h.jc, h.tile_first_run, h.row_span_lo, h.row_span_cnt,
+    // (a read-back-free frame ended with k_frame_tail: the device-side run count is back to zero — the host copy has it)
+    const DevCount jc = h.jc.ptr ? DevCount{nullptr, std::min(ctx->h_info->n_runs, h.jc.bound)} : h.jc;
+    launch_paint_huge(ctx->stream, h.P, ctx->sorted, ctx->records.as<TileRecord>(), jc, h.tile_first_run, h.row_span_lo, h.row_span_cnt,
                       ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(), ctx->layer_col.as<uint4>(), ctx->style_off.as<uint32_t>(),
                       ctx->style_words.as<uint32_t>(), ctx->images.as<forma_image_t>(), ctx->texels.as<uint16_t>(), ctx->cur_image, h.tc,
                       ctx->info.as<FrameInfo>(), h.over2_list, n, ctx->huge_offs.as<uint64_t>(), ctx->huge_key.as<uint64_t>(),
                       ctx->huge_tmp.as<uint64_t>(), ctx->huge_flag.as<uint32_t>());
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(ctx->stream));           // (`offs` is host memory of this call)
-    ctx->h_info->error &= ~8u;
+    // what the huge pass itself reported lands in the frame's host copy: finish_frame looks at fresh error bits
+    FrameInfo after;
+    HIPCHECK(hipMemcpy(&after, ctx->info.p, sizeof after, hipMemcpyDeviceToHost));
+    ctx->info_clean = false;
+    ctx->h_info->error = (ctx->h_info->error & ~8u) | (after.error & ~8u);
+    ctx->h_info->plan_bad |= after.plan_bad;
     return FORMA_OK;
 }
 
@@ -461,7 +516,7 @@ int copy_image_out(forma_hip_ctx* ctx, uint8_t* dst, size_t stride, bool timing,
     // rewrote 1.5 % of a 4K canvas then moves 0.5 MB over PCIe instead of 33 MB.  More than a quarter of the crop written:
     // one strided copy of the crop through the staging image is cheaper than the per-tile scatter on the host.
     const size_t n_crop = (size_t)(tx1 - tx0) * (ty1 - ty0);
-    static const bool no_pack = getenv("FORMA_HIP_NO_PACKED_COPY") != nullptr;                        // (A/B switch for tools/, tests)
+    const bool no_pack = ctx->dbg.no_packed_copy;                                                    // (A/B switch for tools/, tests)
     const uint32_t max_pack = no_pack ? 0u : (uint32_t)std::min<size_t>(std::max<size_t>(n_crop / 4, 1), 1u << 20);
     HIPCHECK(ctx->pack_list.ensure((n_crop + 1) * 4));
     HIPCHECK(ctx->pack_pix.ensure(std::max<size_t>((size_t)max_pack, 1) * 1024));
@@ -602,15 +657,15 @@ int forma_hip_create(forma_hip_ctx** out, int device) {
     forma_hip_ctx* ctx = new (std::nothrow) forma_hip_ctx();
     if (!ctx) return FORMA_E_INTERNAL;
     ctx->device = device;
-    if (const char* e = getenv("FORMA_HIP_DIGIT_BITS")) { if (atoi(e) == 4) ctx->digit_bits = 4; }
-    ctx->no_async = getenv("FORMA_HIP_SYNC") != nullptr;
-    ctx->global_runsort = getenv("FORMA_HIP_GLOBAL_RUNSORT") != nullptr;
-    ctx->legacy_runs = getenv("FORMA_HIP_LEGACY_RUNS") != nullptr;
-    ctx->xgather_always = getenv("FORMA_HIP_XGATHER") != nullptr;
-    ctx->no_small_carry = getenv("FORMA_HIP_NO_SMALL_CARRY") != nullptr;
-    ctx->no_span_groups = getenv("FORMA_HIP_NO_SPAN_GROUPS") != nullptr;
-    ctx->force_span_groups = getenv("FORMA_HIP_SPAN_GROUPS") != nullptr;
-    if (const char* e = getenv("FORMA_HIP_CARRY_SLICES")) ctx->force_slices = (uint32_t)std::min(std::max(atoi(e), 1), (int)CR_MAX_SLICES_HOST);
+    ctx->dbg = forma_debug_parse();                       // FORMA_HIP_DEBUG (debug.h): test / tool switches, never set in deployment
+    if (ctx->dbg.digit_bits == 4 || ctx->dbg.digit_bits == 8 || ctx->dbg.digit_bits == 9) ctx->digit_bits = ctx->dbg.digit_bits;
+    ctx->no_async = ctx->dbg.sync;
+    ctx->global_runsort = ctx->dbg.global_runsort;
+    ctx->xgather_always = ctx->dbg.xgather;
+    ctx->no_small_carry = ctx->dbg.no_small_carry;
+    ctx->no_span_groups = ctx->dbg.no_span_groups;
+    ctx->force_span_groups = ctx->dbg.span_groups;
+    if (ctx->dbg.carry_slices > 0) ctx->force_slices = (uint32_t)std::min(std::max(ctx->dbg.carry_slices, 1), (int)CR_MAX_SLICES_HOST);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx; return FORMA_E_HIP;
     }
@@ -641,9 +696,9 @@ int forma_hip_create(forma_hip_ctx** out, int device) {
 
 int forma_hip_create_multi(forma_hip_ctx** out, const int* devices, int n) {
     if (!out || !devices || n < 1 || n > FORMA_MAX_RANKS) return FORMA_E_ARG;
-    // one device: a plain context, unless FORMA_HIP_FORCE_EXCHANGE=1 asks for the exchange path with a world of one
+    // one device: a plain context, unless FORMA_HIP_DEBUG=force_exchange asks for the exchange path with a world of one
     // (rehearsal on single-GPU machines: same planner, same workers, same collective calls)
-    if (n == 1 && !getenv("FORMA_HIP_FORCE_EXCHANGE")) return forma_hip_create(out, devices[0]);
+    if (n == 1 && !forma_debug_parse().force_exchange) return forma_hip_create(out, devices[0]);
     return multi_create(out, devices, n);
 }
 
@@ -912,7 +967,7 @@ static uint64_t host_live44(const uint64_t* v, size_t n) {
 
 int forma_hip_sort(forma_hip_ctx* ctx, uint64_t* segments, size_t n, int digit_bits) {
     if (!ctx || (n && !segments)) return FORMA_E_ARG;
-    if (digit_bits != 0 && digit_bits != 4 && digit_bits != 8) return fail(ctx, FORMA_E_ARG, "digit_bits must be 0, 4 or 8");
+    if (digit_bits != 0 && digit_bits != 4 && digit_bits != 8 && digit_bits != 9) return fail(ctx, FORMA_E_ARG, "digit_bits must be 0, 4, 8 or 9");
     if (n > 0xFFFFFFF0ull) return fail(ctx, FORMA_E_ARG, "too many segments");   // u32 prefix sums, segment.rs:90-98
     if (n == 0) return FORMA_OK;
     ENTER_STAGE(ctx);
@@ -921,6 +976,7 @@ int forma_hip_sort(forma_hip_ctx* ctx, uint64_t* segments, size_t n, int digit_b
     HIPCHECK(hipMemcpyAsync(ctx->seg_u.p, segments, n * 8, hipMemcpyHostToDevice, ctx->stream));
     ctx->live44 = host_live44(segments, n);
     ctx->layer_sorted = false;
+    ctx->pz = forma_hip_ctx::PreZero();
     int rc = reset_info(ctx);
     if (rc) return rc;
     if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), DevCount{nullptr, (uint32_t)n}, false, digit_bits))) return rc;
@@ -939,6 +995,7 @@ int forma_hip_paint(forma_hip_ctx* ctx, const uint64_t* sorted_segments, size_t 
     ENTER_STAGE(ctx);
     HIPCHECK(hipSetDevice(ctx->device));
     clear_stage_flags(ctx);
+    ctx->pz = forma_hip_ctx::PreZero();
     if ((rc = reset_info(ctx))) return rc;
     HIPCHECK(ctx->seg_a.ensure((std::max<size_t>(n, 1) + SEG_PAD) * 8));
     if (n) HIPCHECK(hipMemcpyAsync(ctx->seg_a.p, sorted_segments, n * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -967,10 +1024,9 @@ void frame_done(forma_hip_ctx* ctx, int rc, const PaintArgs& a) {      // render
 // "right") data there; with the refill it finds the poison.  Scene uploads, caches and the scratch image (a cropped frame
 // legitimately leaves the rest of it alone) are not touched.
 int poison_frame_buffers(forma_hip_ctx* c) {
-    static const char* poison = getenv("FORMA_HIP_POISON_FRAME");
-    if (!poison) return FORMA_OK;
+    if (c->dbg.poison_frame < 0) return FORMA_OK;
     forma_hip_ctx* ctx = c;
-    const int byte = (int)strtol(poison, nullptr, 0);
+    const int byte = c->dbg.poison_frame;
     DevBuf* frame[] = {&c->scan_tmp, &c->cl_idx, &c->cl_start, &c->block_first, &c->prep_scratch, &c->seg_u, &c->seg_a, &c->seg_b,
                        &c->sort_counters, &c->records, &c->rk_u, &c->rk_a, &c->rk_b, &c->blk_edge, &c->runs_scratch, &c->row_tab,
                        &c->span_key, &c->span_cov, &c->ras_masks, &c->huge_offs, &c->huge_key, &c->huge_tmp, &c->huge_flag,
@@ -987,11 +1043,14 @@ int enqueue_async_frame(forma_hip_ctx* ctx, const PaintArgs& a, bool timing, uin
     FrameInfo* dinfo = ctx->info.as<FrameInfo>();
     int rc;
     if ((rc = poison_frame_buffers(ctx))) return rc;
-    if ((rc = run_rasterize_frame(ctx, a.width, a.height, timing, true, bN))) return rc;
+    // a frame of kernels only: what later stages need cleared is cleared by the first kernel, FrameInfo reaches the host
+    // (and returns to its pristine state) through the last one
+    ZeroJobs Z; forma_hip_ctx::PreZero cleared;
+    if ((rc = plan_zero_jobs(ctx, a.width, a.height, bN, bN, &Z, &cleared))) return rc;
+    if ((rc = run_rasterize_frame(ctx, a.width, a.height, timing, true, bN, &Z, &cleared))) return rc;
     if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), DevCount{&dinfo->n_segments, bN}, timing))) return rc;
     if ((rc = run_paint(ctx, DevCount{&dinfo->n_segments, bN}, a, timing, bJ))) return rc;
-    HIPCHECK(hipMemcpyAsync(ctx->h_info, ctx->info.p, sizeof(FrameInfo), hipMemcpyDeviceToHost, ctx->stream));
-    return FORMA_OK;
+    return frame_tail(ctx, true, nullptr);
 }
 
 // ... second half: wait, verify.  FORMA_RETRY: a prediction failed, nothing of the frame may be used (the caller re-runs it
@@ -1144,8 +1203,8 @@ int forma_hip_render(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t 
 
 int forma_hip_set_frames_in_flight(forma_hip_ctx* ctx, int n) {
     if (!ctx) return FORMA_E_ARG;
-    if (n < 1 || n > FORMA_MAX_FRAMES_IN_FLIGHT) return fail(ctx, FORMA_E_ARG, "frames in flight: 1 .. 4");
-    if (ctx->multi) return n == 1 ? FORMA_OK : fail(ctx, FORMA_E_STATE, "a multi-device context has one frame in flight");
+    if (n < 1 || n > FORMA_MAX_FRAMES_IN_FLIGHT) return fail(ctx, FORMA_E_ARG, "frames in flight: 1 .. 8");
+    if (ctx->multi) return multi_set_frames_in_flight(ctx, n);
     int rc = fd_drain(ctx);
     if (rc) return rc;
     if (ctx->slots.empty()) ctx->slots.push_back(ctx);
@@ -1154,7 +1213,7 @@ int forma_hip_set_frames_in_flight(forma_hip_ctx* ctx, int n) {
         forma_hip_ctx* sl = nullptr;
         if ((rc = forma_hip_create(&sl, ctx->device))) return fail(ctx, rc, "frames in flight: cannot create a frame slot");
         sl->owner = ctx;
-        sl->digit_bits = ctx->digit_bits; sl->no_async = ctx->no_async; sl->global_runsort = ctx->global_runsort; sl->legacy_runs = ctx->legacy_runs;
+        sl->digit_bits = ctx->digit_bits; sl->no_async = ctx->no_async; sl->global_runsort = ctx->global_runsort;
         ctx->slots.push_back(sl);
     }
     if (ctx->slots.size() == 1) ctx->slots.clear();
@@ -1166,8 +1225,17 @@ int forma_hip_set_frames_in_flight(forma_hip_ctx* ctx, int n) {
 
 int forma_hip_sync(forma_hip_ctx* ctx) {
     if (!ctx) return FORMA_E_ARG;
-    if (ctx->multi) return FORMA_OK;                       // (every frame of a multi-device context is complete when render returns)
+    if (ctx->multi) return multi_sync(ctx);
     return fd_drain(ctx);
+}
+
+int forma_hip_context_info(forma_hip_ctx* ctx, forma_context_info_t* out) {
+    if (!ctx || !out) return FORMA_E_ARG;
+    memset(out, 0, sizeof *out);
+    if (ctx->multi) { multi_info(ctx, out); return FORMA_OK; }
+    out->n_devices = 1; out->devices[0] = ctx->device; out->transport = FORMA_TRANSPORT_NONE;
+    out->frames_in_flight = ctx->slots.empty() ? 1u : (uint32_t)ctx->slots.size();
+    return FORMA_OK;
 }
 
 // Per-frame device memory is grown to the largest frame seen and kept (a steady-state renderer never allocates).  trim gives
@@ -1190,7 +1258,7 @@ int forma_hip_trim(forma_hip_ctx* ctx) {
                            &c->huge_offs, &c->huge_key, &c->huge_tmp, &c->huge_flag, &c->grp_tab, &c->grp_list, &c->run_lt, &c->pack_list, &c->pack_pix};
         size_t freed = 0;
         for (DevBuf* b : frame) { if (!b->borrowed) freed += b->cap; b->release(); }
-        if (getenv("FORMA_HIP_TRIM_DEBUG")) {
+        if (ctx->dbg.trim_debug) {
             size_t kept = 0;
             DevBuf* rest[] = {&c->x, &c->y, &c->line_slot, &c->geoms, &c->style_off, &c->style_words, &c->layer_sf, &c->layer_col, &c->unchanged,
                               &c->images, &c->texels, &c->info, &c->info_init, &c->cache_written, &c->xsend, &c->xrecv};
@@ -1231,16 +1299,7 @@ int forma_hip_read_segments(forma_hip_ctx* ctx, int which, uint64_t* out, size_t
     ctx = last_slot(ctx);                                 // the slot that rendered the most recent frame
     if (ctx != owner) ctx->err[0] = 0;
     struct CopyErr { forma_hip_ctx* o; forma_hip_ctx* s; ~CopyErr() { if (o != s && s->err[0]) memcpy(o->err, s->err, sizeof o->err); } } copy_err{owner, ctx};
-    *out_n = ctx->n_seg;
-    if (which == 0 && !ctx->have_unsorted) return fail(ctx, FORMA_E_STATE, "no unsorted stream on the device");
-    if (ctx->n_seg > capacity) return fail(ctx, FORMA_E_CAPACITY, "segment capacity too small");
-    if (ctx->n_seg == 0) return FORMA_OK;
-    if (!out) return FORMA_E_ARG;
-    HIPCHECK(hipSetDevice(ctx->device));
-    const void* src = which == 0 ? ctx->seg_u.p : (const void*)ctx->sorted;
-    if (!src) return fail(ctx, FORMA_E_STATE, "no segments on the device");
-    HIPCHECK(hipMemcpy(out, src, ctx->n_seg * 8, hipMemcpyDeviceToHost));
-    return FORMA_OK;
+    return fd_read_stream(ctx, which, out, capacity, out_n);
 }
 
 int forma_hip_read_image(forma_hip_ctx* ctx, uint8_t* dst, size_t stride_bytes) {
@@ -1266,9 +1325,30 @@ int forma_hip_tiles_written(forma_hip_ctx* ctx, uint8_t* flags, size_t n_tiles) 
     ctx = last_slot(ctx);
     if (ctx != owner) ctx->err[0] = 0;
     struct CopyErr { forma_hip_ctx* o; forma_hip_ctx* s; ~CopyErr() { if (o != s && s->err[0]) memcpy(o->err, s->err, sizeof o->err); } } copy_err{owner, ctx};
-    if (!ctx->lw_valid) return fail(ctx, FORMA_E_STATE, "no frame rendered yet");
+    return fd_tiles_written(ctx, flags, n_tiles);
+}
+
+}  // extern "C"
+
+// the stream / the written-tile flags of exactly this context's last frame (no slot resolution: multi.cpp names the slot)
+int fd_read_stream(forma_hip_ctx* ctx, int which, uint64_t* out, size_t capacity, size_t* out_n) {
+    *out_n = ctx->n_seg;
+    if (which == 0 && !ctx->have_unsorted) return fd_fail(ctx, FORMA_E_STATE, "no unsorted stream on the device");
+    if (ctx->n_seg > capacity) return fd_fail(ctx, FORMA_E_CAPACITY, "segment capacity too small");
+    if (ctx->n_seg == 0) return FORMA_OK;
+    if (!out) return FORMA_E_ARG;
+    HIPCHECK(hipSetDevice(ctx->device));
+    const void* src = which == 0 ? ctx->seg_u.p : (const void*)ctx->sorted;
+    if (!src) return fd_fail(ctx, FORMA_E_STATE, "no segments on the device");
+    HIPCHECK(hipMemcpy(out, src, ctx->n_seg * 8, hipMemcpyDeviceToHost));
+    return FORMA_OK;
+}
+int fd_read_sorted(forma_hip_ctx* ctx, uint64_t* out, size_t capacity, size_t* out_n) { return fd_read_stream(ctx, 1, out, capacity, out_n); }
+
+int fd_tiles_written(forma_hip_ctx* ctx, uint8_t* flags, size_t n_tiles) {
+    if (!ctx->lw_valid) return fd_fail(ctx, FORMA_E_STATE, "no frame rendered yet");
     const size_t T = (size_t)ctx->lw_tiles_w * ctx->lw_tiles_h;
-    if (n_tiles < T) return fail(ctx, FORMA_E_CAPACITY, "tile flag capacity too small");
+    if (n_tiles < T) return fd_fail(ctx, FORMA_E_CAPACITY, "tile flag capacity too small");
     memset(flags, 0, n_tiles);
     if (ctx->lw_cache && !ctx->lw_flags_on_host) {        // device-resident frame (dst == NULL): fetch the flags now
         HIPCHECK(hipSetDevice(ctx->device));
@@ -1289,6 +1369,8 @@ int forma_hip_tiles_written(forma_hip_ctx* ctx, uint8_t* flags, size_t n_tiles) 
         }
     return FORMA_OK;
 }
+
+extern "C" {
 
 // ---- multi-GPU -----------------------------------------------------------------------------------------------
 int forma_hip_set_band(forma_hip_ctx* ctx, uint32_t row0, uint32_t row1) {
@@ -1340,6 +1422,7 @@ int forma_hip_sort_paint_frame(forma_hip_ctx* ctx, size_t n, uint8_t* dst, uint3
     HIPCHECK(hipSetDevice(ctx->device));
     const bool timing = timings != nullptr;
     clear_stage_flags(ctx);
+    ctx->pz = forma_hip_ctx::PreZero();
     if ((rc = reset_info(ctx))) return rc;
     // the received stream lives in seg_b: move it to seg_u (the sort's read-only input) so a/b can ping-pong
     HIPCHECK(ctx->seg_u.ensure((std::max<size_t>(n, 1) + SEG_PAD) * 8));
@@ -1419,7 +1502,12 @@ int forma_hip_rasterize_bucket_frame(forma_hip_ctx* ctx, uint32_t width, uint32_
     ctx->h_xlocal[1] = 0;
     const uint32_t bN = (ctx->xpred_valid && !ctx->no_async) ? ctx->xpred_N + ctx->xpred_N / 16 + 4096 : 0;
     if ((rc = poison_frame_buffers(ctx))) return rc;
-    if ((rc = run_rasterize_frame(ctx, width, height, timing, false, bN))) return rc;
+    // read-back-free on both halves: this call's first kernel also clears what the owner's half of the frame
+    // (forma_hip_gather_sort_paint_frame: sort scratch, tile tables, run chain for a band of n_ranks x capacity segments) expects
+    ZeroJobs Z; forma_hip_ctx::PreZero cleared;
+    const bool ahead = bN && ctx->pred_valid && ctx->pred_counts_valid && !ctx->no_async;
+    if (ahead && (rc = plan_zero_jobs(ctx, width, height, ctx->xbands.n * ctx->xcap, ctx->xbands.n * ctx->xcap, &Z, &cleared))) return rc;
+    if ((rc = run_rasterize_frame(ctx, width, height, timing, false, bN, ahead ? &Z : nullptr, ahead ? &cleared : nullptr))) return rc;
     FrameInfo* dinfo = ctx->info.as<FrameInfo>();
     DevCount nc = bN ? DevCount{&dinfo->n_segments, bN} : DevCount{nullptr, (uint32_t)ctx->n_seg};
     if (!bN) { ctx->xpred_N = (uint32_t)ctx->n_seg; ctx->xpred_valid = true; }
@@ -1430,15 +1518,18 @@ int forma_hip_rasterize_bucket_frame(forma_hip_ctx* ctx, uint32_t width, uint32_
                         ctx->xsend.as<uint64_t>(), dinfo);
     stage_end(ctx, ST_XCHG, timing);
     HIPCHECK(hipGetLastError());
-    if (bN) {
-        HIPCHECK(hipMemcpyAsync(&ctx->h_xlocal[0], &dinfo->n_segments, 4, hipMemcpyDeviceToHost, ctx->stream));
-        ctx->h_xlocal[1] = 1;
-    }
     if (timing) {                                            // (the only host wait of this call, and only when timings are asked for)
+        if (bN) { HIPCHECK(hipMemcpyAsync(&ctx->h_xlocal[0], &dinfo->n_segments, 4, hipMemcpyDeviceToHost, ctx->stream)); ctx->h_xlocal[1] = 1; }
         HIPCHECK(hipStreamSynchronize(ctx->stream));
         ctx->n_passes = 0; ctx->last_runs = 0;
         HIPCHECK(hipMemcpy(ctx->h_info, ctx->info.p, sizeof(FrameInfo), hipMemcpyDeviceToHost));
         return finish_frame(ctx, timings, true);
+    }
+    if (bN) {
+        // the true local count goes to a pinned word and FrameInfo returns to its pristine state (the owner's half starts
+        // from one): one tiny kernel instead of a copy here and a reset there
+        if ((rc = frame_tail(ctx, false, &ctx->h_xlocal[0]))) return rc;
+        ctx->h_xlocal[1] = 1;
     }
     return FORMA_OK;
 }
@@ -1452,79 +1543,104 @@ int forma_hip_gather_sort_paint_frame(forma_hip_ctx* ctx, uint8_t* dst, uint32_t
 
 }  // extern "C"
 
-int fd_gather_sort_paint(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t height, size_t stride_bytes,
-                         const uint8_t channels[4], const float clear_color[4], const forma_rect_t* crop_or_null, int cache_id,
-                         forma_timings_t* timings) {
-    if (!ctx) return FORMA_E_ARG;
-    if (!ctx->xplanned) return fail(ctx, FORMA_E_STATE, "forma_hip_exchange_plan first");
-    int rc = check_paint_args(ctx, dst, width, height, stride_bytes, channels, clear_color);
-    if (rc) return rc;
-    if (cache_id >= 32) return fail(ctx, FORMA_E_ARG, "cache_id out of range");
-    HIPCHECK(hipSetDevice(ctx->device));
-    const bool timing = timings != nullptr;
-    clear_stage_flags(ctx);
+// The owner's half of an exchange frame (forma_hip_gather_sort_paint_frame; a device of a multi-device context), in three
+// pieces so that a multi-device context can keep frames in flight: ENQUEUE (read-back-free: everything goes onto the stream,
+// nothing waits), COMPLETE (wait, verify the predictions, copy out) and the SYNCHRONOUS form (first frame of a plan, or a
+// prediction failed: N, the key masks and J are read back).
+namespace {
+
+struct GspArgs {
+    uint8_t* dst; uint32_t width, height; size_t stride_bytes; const uint8_t* channels; const float* clear; const forma_rect_t* crop;
+    int cache_id; forma_timings_t* timings;
+};
+
+int gsp_overflow(forma_hip_ctx* ctx) {
+    ctx->xoverflowed = true;                               // (state, not text: multi_render re-plans on it)
+    return fail(ctx, FORMA_E_CAPACITY, "exchange: a bucket exceeds the pair capacity (re-plan)");
+}
+
+// *enqueued = false: the context has no predictions yet (or read-back-free frames are off) — nothing was enqueued
+int gsp_enqueue(forma_hip_ctx* ctx, const GspArgs& g, bool* enqueued, uint32_t* bJ_out) {
+    *enqueued = false;
+    if (!(ctx->pred_valid && ctx->pred_counts_valid && !ctx->no_async)) return FORMA_OK;
+    const bool timing = g.timings != nullptr;
     const uint32_t G = ctx->xbands.n, bound = G * ctx->xcap;
-    // one rank: what was bucketed is what is received (no collective ran)
-    // (xuse_recv: a collective did run with a world of one — the RCCL rehearsal of a multi-device context on one GPU)
     const bool self = G == 1 && !ctx->xuse_recv;
     const uint64_t* recv = self ? ctx->xsend.as<uint64_t>() : ctx->xrecv.as<uint64_t>();
     FrameInfo* dinfo = ctx->info.as<FrameInfo>();
-    PaintArgs a{width, height, channels, clear_color, crop_or_null, cache_id};
-    HIPCHECK(ctx->seg_u.ensure(((size_t)bound + SEG_PAD) * 8));
-    HIPCHECK(ctx->xmask.ensure(std::max<size_t>(gather_mask_words(G, ctx->xcap), (size_t)2048 * 8) * 4));
-    auto gather = [&](bool read_back_free) -> int {
-        int r = reset_info(ctx);
-        if (r) return r;
+    PaintArgs a{g.width, g.height, g.channels, g.clear, g.crop, g.cache_id};
+    int rc;
+    const uint32_t bJ = ctx->pred_J + ctx->pred_J / 16 + 4096;
+    *bJ_out = bJ;
+    ctx->live44 = ctx->pred_live44; ctx->layer_sorted = ctx->pred_layer_sorted; ctx->speculated = true;
+    uint64_t live = ctx->live44;
+    if (ctx->layer_sorted) live &= ~0x1FFFFFull;
+    // The received buckets are sorted where they lie: the histogram kernel and the first digit pass read the rank-major
+    // concatenation through a logical -> physical index map, so nothing is gathered (k_gather_chunks: one more read and
+    // write of the whole band).  Needs at least one digit pass; FORMA_HIP_DEBUG=xgather keeps the gather (A/B, tests).
+    if (!ctx->xgather_always && live != 0 && bound > 1) {
+        if ((rc = reset_info(ctx))) return rc;
+        ctx->have_unsorted = false; ctx->n_lines = 0;
+        const ChunkedSrc C{recv, G, ctx->xcap, ctx->xmask.as<uint32_t>()};
+        if ((rc = run_sort(ctx, recv, DevCount{&dinfo->n_segments, bound}, timing, 0, &C))) return rc;
+        ctx->pending_masks = PendingMasks{ctx->xmask.as<uint32_t>(), sort_hist_blocks(bound)};
+    } else {
+        if ((rc = reset_info(ctx))) return rc;
         stage_begin(ctx, ST_XCHG, timing);
-        launch_gather_chunks(ctx->stream, recv, G, ctx->xcap, ctx->seg_u.as<uint64_t>(), dinfo, ctx->xmask.as<uint32_t>(),
-                             /*reduce_now=*/!read_back_free);
-        ctx->pending_masks = read_back_free ? PendingMasks{ctx->xmask.as<uint32_t>(), (uint32_t)(gather_mask_words(G, ctx->xcap) / 8)}
-                                            : PendingMasks{nullptr, 0u};
+        launch_gather_chunks(ctx->stream, recv, G, ctx->xcap, ctx->seg_u.as<uint64_t>(), dinfo, ctx->xmask.as<uint32_t>(), /*reduce_now=*/false);
+        ctx->pending_masks = PendingMasks{ctx->xmask.as<uint32_t>(), (uint32_t)(gather_mask_words(G, ctx->xcap) / 8)};
         stage_end(ctx, ST_XCHG, timing);
         ctx->have_unsorted = true; ctx->n_lines = 0;
-        return FORMA_OK;
-    };
-    if (ctx->pred_valid && ctx->pred_counts_valid && !ctx->no_async) {       // read-back-free, verified when the frame is done
-        const uint32_t bJ = ctx->pred_J + ctx->pred_J / 16 + 4096;
-        ctx->live44 = ctx->pred_live44; ctx->layer_sorted = ctx->pred_layer_sorted; ctx->speculated = true;
-        uint64_t live = ctx->live44;
-        if (ctx->layer_sorted) live &= ~0x1FFFFFull;
-        // The received buckets are sorted where they lie: the histogram kernel and the first digit pass read the rank-major
-        // concatenation through a logical -> physical index map, so nothing is gathered (k_gather_chunks: one more read and
-        // write of the whole band).  Needs at least one digit pass; FORMA_HIP_XGATHER=1 keeps the gather (A/B, tests).
-        if (!ctx->xgather_always && live != 0 && bound > 1) {
-            if ((rc = reset_info(ctx))) return rc;
-            ctx->have_unsorted = false; ctx->n_lines = 0;
-            const ChunkedSrc C{recv, G, ctx->xcap, ctx->xmask.as<uint32_t>()};
-            if ((rc = run_sort(ctx, recv, DevCount{&dinfo->n_segments, bound}, timing, 0, &C))) return rc;
-            ctx->pending_masks = PendingMasks{ctx->xmask.as<uint32_t>(), sort_hist_blocks(bound)};
-        } else {
-            if ((rc = gather(true))) return rc;
-            if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), DevCount{&dinfo->n_segments, bound}, timing))) return rc;
-        }
-        if ((rc = run_paint(ctx, DevCount{&dinfo->n_segments, bound}, a, timing, bJ))) return rc;
-        HIPCHECK(hipMemcpyAsync(ctx->h_info, ctx->info.p, sizeof(FrameInfo), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHECK(hipStreamSynchronize(ctx->stream));
-        if (ctx->h_info->exchange_overflow) return fail(ctx, FORMA_E_CAPACITY, "exchange: a bucket exceeds the pair capacity (re-plan)");
-        const uint32_t N = ctx->h_info->n_segments, J = ctx->h_info->n_runs;
-        ctx->n_seg = N; ctx->last_runs = J;
-        if (ctx->h_info->plan_bad && ctx->small_tried) ctx->small_banned = true;
-        if (!ctx->h_info->plan_bad && J <= bJ) {
-            ctx->pred_J = J; ctx->pred_max_row = ctx->h_info->max_row_runs;
-            if ((rc = finish_paint(ctx))) return rc;
-            if ((rc = copy_image_out(ctx, dst, stride_bytes, timing, a))) return rc;
-            if (dst) HIPCHECK(hipStreamSynchronize(ctx->stream));
-            rc = finish_frame(ctx, timings, true);
-            frame_done(ctx, rc, a);
-            return rc;
-        }
-        ctx->pred_counts_valid = false;
-        clear_stage_flags(ctx);
+        if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), DevCount{&dinfo->n_segments, bound}, timing))) return rc;
     }
+    if ((rc = run_paint(ctx, DevCount{&dinfo->n_segments, bound}, a, timing, bJ))) return rc;
+    if ((rc = frame_tail(ctx, true, nullptr))) return rc;
+    *enqueued = true;
+    return FORMA_OK;
+}
+
+// FORMA_RETRY: a prediction failed, nothing of the frame may be used (the caller runs gsp_sync)
+int gsp_complete(forma_hip_ctx* ctx, const GspArgs& g, uint32_t bJ) {
+    const bool timing = g.timings != nullptr;
+    PaintArgs a{g.width, g.height, g.channels, g.clear, g.crop, g.cache_id};
+    int rc;
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_info->exchange_overflow) return gsp_overflow(ctx);
+    const uint32_t N = ctx->h_info->n_segments, J = ctx->h_info->n_runs;
+    ctx->n_seg = N; ctx->last_runs = J;
+    if (ctx->h_info->plan_bad && ctx->small_tried) ctx->small_banned = true;
+    if (!ctx->h_info->plan_bad && J <= bJ) {
+        ctx->pred_J = J; ctx->pred_max_row = ctx->h_info->max_row_runs;
+        if ((rc = finish_paint(ctx))) return rc;
+        if ((rc = copy_image_out(ctx, g.dst, g.stride_bytes, timing, a))) return rc;
+        if (g.dst) HIPCHECK(hipStreamSynchronize(ctx->stream));
+        rc = finish_frame(ctx, g.timings, true);
+        frame_done(ctx, rc, a);
+        return rc;
+    }
+    ctx->pred_counts_valid = false;
+    clear_stage_flags(ctx);
+    return FORMA_RETRY;
+}
+
+int gsp_sync(forma_hip_ctx* ctx, const GspArgs& g) {
+    const bool timing = g.timings != nullptr;
+    const uint32_t G = ctx->xbands.n;
+    const bool self = G == 1 && !ctx->xuse_recv;
+    const uint64_t* recv = self ? ctx->xsend.as<uint64_t>() : ctx->xrecv.as<uint64_t>();
+    FrameInfo* dinfo = ctx->info.as<FrameInfo>();
+    PaintArgs a{g.width, g.height, g.channels, g.clear, g.crop, g.cache_id};
+    int rc;
+    ctx->pz = forma_hip_ctx::PreZero();
     for (int attempt = 0; attempt < 2; attempt++) {                            // synchronous: N, key masks and J are read back
-        if ((rc = gather(false))) return rc;
+        if ((rc = reset_info(ctx))) return rc;
+        stage_begin(ctx, ST_XCHG, timing);
+        launch_gather_chunks(ctx->stream, recv, G, ctx->xcap, ctx->seg_u.as<uint64_t>(), dinfo, ctx->xmask.as<uint32_t>(), /*reduce_now=*/true);
+        ctx->pending_masks = PendingMasks{nullptr, 0u};
+        stage_end(ctx, ST_XCHG, timing);
+        ctx->have_unsorted = true; ctx->n_lines = 0;
         if ((rc = read_info(ctx))) return rc;
-        if (ctx->h_info->exchange_overflow) return fail(ctx, FORMA_E_CAPACITY, "exchange: a bucket exceeds the pair capacity (re-plan)");
+        if (ctx->h_info->exchange_overflow) return gsp_overflow(ctx);
         ctx->n_seg = ctx->h_info->n_segments;
         const uint64_t k_or = (uint64_t)ctx->h_info->key_or | ((uint64_t)ctx->h_info->key_or_hi << 32);
         const uint64_t k_and = (uint64_t)ctx->h_info->key_and | ((uint64_t)ctx->h_info->key_and_hi << 32);
@@ -1535,14 +1651,75 @@ int fd_gather_sort_paint(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint3
         if (rc == FORMA_RETRY) { clear_stage_flags(ctx); continue; }
         if (rc) return rc;
         if ((rc = read_info(ctx)) || (rc = finish_paint(ctx))) return rc;
-        if ((rc = copy_image_out(ctx, dst, stride_bytes, timing, a))) return rc;
-        if (dst) HIPCHECK(hipStreamSynchronize(ctx->stream));
-        rc = finish_frame(ctx, timings, true);
+        if ((rc = copy_image_out(ctx, g.dst, g.stride_bytes, timing, a))) return rc;
+        if (g.dst) HIPCHECK(hipStreamSynchronize(ctx->stream));
+        rc = finish_frame(ctx, g.timings, true);
         if (rc == FORMA_OK) { ctx->pred_J = ctx->last_runs; ctx->pred_counts_valid = true; }
         frame_done(ctx, rc, a);
         return rc;
     }
     return fail(ctx, FORMA_E_INTERNAL, "sort plan did not converge");
+}
+
+int gsp_prologue(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t height, size_t stride_bytes, const uint8_t channels[4],
+                 const float clear_color[4], int cache_id) {
+    if (!ctx) return FORMA_E_ARG;
+    if (!ctx->xplanned) return fail(ctx, FORMA_E_STATE, "forma_hip_exchange_plan first");
+    int rc = check_paint_args(ctx, dst, width, height, stride_bytes, channels, clear_color);
+    if (rc) return rc;
+    if (cache_id >= 32) return fail(ctx, FORMA_E_ARG, "cache_id out of range");
+    HIPCHECK(hipSetDevice(ctx->device));
+    clear_stage_flags(ctx);
+    ctx->xoverflowed = false;
+    const uint32_t G = ctx->xbands.n, bound = G * ctx->xcap;
+    HIPCHECK(ctx->seg_u.ensure(((size_t)bound + SEG_PAD) * 8));
+    HIPCHECK(ctx->xmask.ensure(std::max<size_t>(gather_mask_words(G, ctx->xcap), (size_t)2048 * 8) * 4));
+    return FORMA_OK;
+}
+
+}  // namespace
+
+int fd_gather_sort_paint(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t height, size_t stride_bytes,
+                         const uint8_t channels[4], const float clear_color[4], const forma_rect_t* crop_or_null, int cache_id,
+                         forma_timings_t* timings) {
+    int rc = gsp_prologue(ctx, dst, width, height, stride_bytes, channels, clear_color, cache_id);
+    if (rc) return rc;
+    const GspArgs g{dst, width, height, stride_bytes, channels, clear_color, crop_or_null, cache_id, timings};
+    bool enqueued = false; uint32_t bJ = 0;
+    if ((rc = gsp_enqueue(ctx, g, &enqueued, &bJ))) return rc;
+    if (enqueued) {
+        rc = gsp_complete(ctx, g, bJ);
+        if (rc != FORMA_RETRY) return rc;
+    }
+    return gsp_sync(ctx, g);
+}
+
+// A device-resident, cache-less frame of a multi-device context with frames in flight: the owner's half is ENQUEUED (or, when
+// this slot has no predictions yet, run synchronously to its end) and the arguments are parked in the slot ...
+int fd_gsp_defer(forma_hip_ctx* ctx, uint32_t width, uint32_t height, const uint8_t channels[4], const float clear_color[4],
+                 const forma_rect_t* crop_or_null) {
+    int rc = gsp_prologue(ctx, nullptr, width, height, 0, channels, clear_color, -1);
+    if (rc) return rc;
+    forma_hip_ctx::Deferred& d = ctx->def;
+    d.width = width; d.height = height; memcpy(d.channels, channels, 4); memcpy(d.clear, clear_color, 16);
+    d.has_crop = crop_or_null != nullptr; if (crop_or_null) d.crop = *crop_or_null;
+    const GspArgs g{nullptr, width, height, 0, d.channels, d.clear, d.has_crop ? &d.crop : nullptr, -1, nullptr};
+    bool enqueued = false;
+    if ((rc = gsp_enqueue(ctx, g, &enqueued, &d.bJ))) return rc;
+    if (enqueued) { ctx->xpending = true; return FORMA_OK; }
+    return gsp_sync(ctx, g);
+}
+// ... and completed when the slot comes round again (or any call needs the result): FORMA_E_CAPACITY with ctx->xoverflowed when a
+// bucket outgrew the plan (the caller re-plans and re-runs the frame), any other failed prediction is repaired here
+int fd_gsp_settle(forma_hip_ctx* ctx) {
+    if (!ctx->xpending) return FORMA_OK;
+    ctx->xpending = false;
+    HIPCHECK(hipSetDevice(ctx->device));
+    const forma_hip_ctx::Deferred& d = ctx->def;
+    const GspArgs g{nullptr, d.width, d.height, 0, d.channels, d.clear, d.has_crop ? &d.crop : nullptr, -1, nullptr};
+    int rc = gsp_complete(ctx, g, d.bJ);
+    if (rc == FORMA_RETRY) rc = gsp_sync(ctx, g);
+    return rc;
 }
 
 

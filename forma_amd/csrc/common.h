@@ -144,8 +144,10 @@ struct LineSource {               // either the uploaded geometry (sums == nullp
     const uint32_t* orders; const float *x0, *y0, *dx, *dy, *a, *b, *c, *d;
 };
 size_t prepare_scratch_words(size_t n_lines);
+struct ZeroJobs;
 void launch_prepare_compact(hipStream_t s, const LineSource& src, uint32_t n_lines, uint32_t* cl_idx, uint32_t* cl_start,
-                            uint32_t* block_first, uint32_t bf_cap, uint32_t* scratch, FrameInfo* info);
+                            uint32_t* block_first, uint32_t bf_cap, uint32_t* scratch, FrameInfo* info,
+                            const ZeroJobs* zero /* nullable: words the first kernel clears for later stages */);
 void launch_line_lengths(hipStream_t s, const LineSource& src, uint32_t n_lines, uint32_t* lens, uint32_t* scratch /* prepare_scratch_words */);
 // rebuilds block_first when the buffer launch_prepare_compact saw was too small for N
 void launch_block_first(hipStream_t s, const uint32_t* cl_start, uint32_t n_compact, uint32_t n_segments,
@@ -163,9 +165,11 @@ struct SortPlan {                 // digit p = (key >> shift[p]) & mask[p]
     int      shift[SORT_MAX_PASSES];
     uint32_t mask[SORT_MAX_PASSES];
 };
-// digits packed greedily over the live bits of [lo_bit, hi_bit); digit_bits = 4 or 8
+// digits packed greedily over the live bits of [lo_bit, hi_bit); digit_bits = 4, 8 or 9 bits per digit, 0 = 8, or 9 where
+// that saves a whole pass
 SortPlan make_sort_plan(uint64_t live_mask, int lo_bit, int hi_bit, int digit_bits);
 size_t sort_scratch_words(size_t n);
+size_t sort_zero_words(size_t n, const SortPlan& plan);     // leading words of the scratch that must be zero when the sort starts
 // `in` is read-only (preserved), a/b are ping-pong buffers; returns the buffer holding the result (== in when the
 // plan is empty).  scratch: >= sort_scratch_words(n) u32.  err: device word, bit 2 set if a look-back spin expired.
 // Multi-GPU exchange: the stream to sort is NOT contiguous — it is the rank-major concatenation of the n_chunks received
@@ -178,7 +182,8 @@ uint32_t sort_hist_blocks(size_t n);           // grid of k_sort_hist for n keys
 const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a, uint64_t* b, DevCount n,
                                   const SortPlan& plan, int digit_bits, uint32_t* scratch, uint32_t* err,
                                   hipEvent_t* pass_ev0, hipEvent_t* pass_ev1,
-                                  const ChunkedSrc* chunked = nullptr, FrameInfo* info = nullptr);
+                                  const ChunkedSrc* chunked = nullptr, FrameInfo* info = nullptr,
+                                  bool scratch_is_zero = false /* an earlier kernel of the frame cleared sort_zero_words() */);
 
 // exchange.hip — multi-GPU: bucket a rank's pixel segments by tile-row owner, gather what the owner received
 #define FORMA_MAX_RANKS 8
@@ -203,7 +208,7 @@ struct BlkEdge {             // what a k_runs tile contributes to a run that sta
 size_t runs_scratch_words(size_t n);
 size_t runs_blocks(size_t n);
 // run detection + per-run cover sums; row_tab = [row_count | row_span_lo | row_span_cnt], (tiles_h + 1) words each
-// What the run kernels attach to a record beyond the geometry — they run on the whole chip, k_carry_rows on one CU per tile
+// What the run kernel attaches to a record beyond the geometry — it runs on the whole chip, k_carry_rows on one CU per tile
 // row, where every scattered access per run is a cycle of that CU's address unit: the layer's style bits (SF_*, bits 21.. of
 // the record's layer word) and "unchanged" flag (bit 31 of its tile word), and a 32-bit digest per run, in stream order,
 // that lets the carry pre-pass order a row and find the tile columns WITHOUT touching the records:
@@ -215,12 +220,21 @@ struct RunStyle {
     uint32_t*       run_lt;       // one word per run (rec_cap)
 };
 #define RUN_LT_OPEN 0x8000u
+// tables_are_zero: the frame's tile tables (row_tab_zero_words() words of row_tab) were cleared by an earlier kernel of this
+// frame; else k_runs_count clears them
 void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount n, uint32_t tiles_w, uint32_t tiles_h, TileRecord* records,
                  uint32_t rec_cap, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge,
                  uint32_t* row_tab, uint32_t* scratch, FrameInfo* info, bool verify_plan, uint64_t spec_live44,
-                 bool spec_layer_sorted, bool legacy /* workgroup-per-tile kernel with LDS bins instead of the wave kernel */,
-                 PendingMasks pm, RunStyle rs);
-uint32_t runs_edge_segments(bool legacy);
+                 bool spec_layer_sorted, PendingMasks pm, RunStyle rs, bool tables_are_zero);
+uint32_t runs_edge_segments();            // segments per BlkEdge entry
+// The end of a read-back-free frame: the device-side FrameInfo goes to pinned host memory (`host_info`, nullable) and/or its
+// segment count to a pinned word (`host_count`, nullable), and the device copy returns to its pristine state for the next
+// frame of the stream — one tiny kernel instead of a device-to-host copy here and a device-to-device reset there.
+void launch_frame_tail(hipStream_t s, FrameInfo* info, FrameInfo* host_info, uint32_t* host_count);
+// Words the frame's FIRST kernel clears on behalf of later stages (sort scratch, tile tables): a few hundred
+// KB spread over a grid that exists anyway, instead of two or three memset operations on the stream.
+#define FORMA_ZERO_JOBS 4
+struct ZeroJobs { uint32_t* p[FORMA_ZERO_JOBS]; uint32_t words[FORMA_ZERO_JOBS]; uint32_t n; };
 // cache frames: list of the written tiles of the crop (row-major) + their pixels packed into 1 KB slots, <= max_pack tiles
 void launch_pack_written(hipStream_t s, const uint8_t* written, uint32_t tiles_w, uint32_t tx0, uint32_t tx1, uint32_t ty0, uint32_t ty1,
                          uint32_t* list, uint32_t* count, uint32_t max_pack, const uint8_t* image, uint32_t width, uint32_t height,

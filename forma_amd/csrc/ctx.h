@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "common.h"
+#include "debug.h"
 
 struct DevBuf {
     void* p = nullptr;
@@ -22,10 +23,10 @@ struct DevBuf {
         hipError_t e = hipMalloc(&p, want);
         if (e == hipSuccess) {
             cap = want;
-            // FORMA_HIP_POISON=<byte>: every fresh device allocation is filled with that byte — a kernel that reads what nothing
-            // wrote this frame then misbehaves on every run instead of once per fresh box (tests/, tools/: hunting such reads)
-            static const char* poison = getenv("FORMA_HIP_POISON");
-            if (poison) { e = hipMemset(p, (int)strtol(poison, nullptr, 0), want); if (e == hipSuccess) e = hipDeviceSynchronize(); }
+            // FORMA_HIP_DEBUG=poison=<byte>: every fresh device allocation is filled with that byte — a kernel that reads what
+            // nothing wrote this frame then misbehaves on every run instead of once per fresh box (tests/, tools/)
+            static const int poison = forma_debug_parse().poison;
+            if (poison >= 0) { e = hipMemset(p, poison, want); if (e == hipSuccess) e = hipDeviceSynchronize(); }
         }
         return e;
     }
@@ -54,8 +55,8 @@ struct forma_hip_ctx {
     bool scene_has_clips = false;
     DevBuf run_lt;                  // one word per run: layer16 | open | tile_x + 1 (RunStyle, common.h)
     DevBuf grp_tab, grp_list;       // span group lists (SpanGroups, common.h): table per (row, slice, group) and the entry pool
-    bool no_span_groups = false;    // FORMA_HIP_NO_SPAN_GROUPS (A/B switch for tools/)
-    bool force_span_groups = false; // FORMA_HIP_SPAN_GROUPS: on every frame and for every row, however few spans (tests)
+    bool no_span_groups = false;    // FORMA_HIP_DEBUG=no_span_groups (A/B switch for tools/)
+    bool force_span_groups = false; // FORMA_HIP_DEBUG=span_groups: on every frame and for every row, however few spans (tests)
     uint32_t pred_row_spans = 0;    // spans per painted tile row of the last verified frame: group lists pay above SPAN_GROUP_MIN_ROW
     uint32_t cur_rows_painted = 1;
     bool scene_simple = false;      // all layers solid + Over + unclipped: the painter's specialised kernel
@@ -77,7 +78,7 @@ struct forma_hip_ctx {
     bool have_unsorted = false;
     uint64_t live44 = 0xFFFFFFFFFFFull;     // varying bits of (v >> 20)
     bool layer_sorted = false;              // rasterizer stream is non-decreasing in layer
-    int digit_bits = 8;                     // radix digit width: 8 (default) or 4 (FORMA_HIP_DIGIT_BITS)
+    int digit_bits = 0;                     // radix digit width: 0 = 8, or 9 where that saves a pass (default); 4 / 8 / 9 forced (FORMA_HIP_DEBUG=digit_bits=)
     // paint
     DevBuf info_init;                       // pristine FrameInfo (reset template)
     // buffer-layer caches (reference cpu/buffer/mod.rs:113-197): per cache the CachedTile table, the device image the
@@ -100,14 +101,19 @@ struct forma_hip_ctx {
     // sort-plan speculation: the varying-bit mask and the layer-sortedness of a scene rarely change between frames, so
     // forma_hip_render plans the sort from the previous frame's values and verifies them when the frame is done
     bool pred_valid = false, pred_layer_sorted = false, speculated = false;
-    bool global_runsort = false;           // FORMA_HIP_GLOBAL_RUNSORT=1: never order a row's runs in LDS (test switch)
-    bool legacy_runs = false;              // FORMA_HIP_LEGACY_RUNS=1: run detection by the workgroup-per-tile kernel (A/B switch)
-    bool pred_counts_valid = false, no_async = false;    // N / J predictions for read-back-free frames (FORMA_HIP_SYNC=1 disables)
+    bool global_runsort = false;           // FORMA_HIP_DEBUG=global_runsort: never order a row's runs in LDS (test switch)
+    bool pred_counts_valid = false, no_async = false;    // N / J predictions for read-back-free frames (FORMA_HIP_DEBUG=sync disables)
     uint32_t pred_N = 0, pred_J = 0, pred_w = 0, pred_h = 0;
     uint64_t pred_live44 = 0;
     DevBuf info, records, rk_u, rk_a, rk_b, blk_edge, runs_scratch, row_tab, span_key, span_cov, image;
     uint32_t img_w = 0, img_h = 0;
     FrameInfo* h_info = nullptr;            // pinned
+    bool info_clean = false;                // the device FrameInfo is pristine: the last frame ended with k_frame_tail (reset_info is then free)
+    // what this frame's FIRST kernel cleared on behalf of later stages (ZeroJobs, common.h): consumed by run_sort / run_paint,
+    // which clear the words themselves when the pointer or the size is not what they need
+    struct PreZero { const void* sort_p = nullptr; size_t sort_words = 0; const void* tab_p = nullptr; size_t tab_words = 0;
+                     const void* chain_p = nullptr; size_t chain_words = 0; } pz;
+    ForMaDebug dbg;                         // FORMA_HIP_DEBUG as it stood when the context was created
     uint32_t* h_rows = nullptr;             // pinned: runs per tile row (synchronous frames), 2049 words
     uint32_t pred_max_row = 0xFFFFFFFFu;    // most runs in one tile row of the last verified frame (unknown: no local sort)
     // tiles deeper than the painter's LDS lists (finish_paint): the launch arguments of the frame's painter and the scratch lists
@@ -146,8 +152,10 @@ struct forma_hip_ctx {
     uint32_t xcap = 0;
     bool xplanned = false;
     DevBuf xsend, xrecv, xscratch, xmask;         // buckets: n_ranks x (xcap data words + 1 header word {count | overflow << 32})
+    bool xpending = false;                    // a deferred owner's half (fd_gsp_defer) nobody has settled yet
+    bool xoverflowed = false;                 // the last owner's half failed because a bucket outgrew the plan (FORMA_E_CAPACITY: re-plan)
     bool xuse_recv = false;                   // one rank, but a collective DID run (RCCL rehearsal): the buckets are in xrecv
-    bool xgather_always = false;              // FORMA_HIP_XGATHER=1: materialise the received stream before sorting it
+    bool xgather_always = false;              // FORMA_HIP_DEBUG=xgather: materialise the received stream before sorting it
     bool xpred_valid = false;               // the local rasterized count of the previous exchange frame is known
     uint32_t xpred_N = 0, xpred_w = 0, xpred_h = 0;
     uint32_t* h_xlocal = nullptr;           // pinned: [0] = local segment count of the last bucket frame (copied on the stream), [1] = 1 when pending
@@ -161,6 +169,8 @@ struct forma_hip_ctx {
     bool lw_valid = false, lw_cache = false, lw_flags_on_host = false;
 };
 
+
+#define FORMA_RETRY 1     /* internal: a speculation of the read-back-free path was wrong, run the frame again synchronously */
 
 // ---- internals shared by api.cpp and multi.cpp -------------------------------------------------------------------------
 int fd_fail(forma_hip_ctx* c, int code, const char* what, hipError_t e = hipSuccess);
@@ -177,10 +187,22 @@ int fd_row_histogram(forma_hip_ctx* ctx, uint32_t width, uint32_t height, uint32
 int fd_gather_sort_paint(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t height, size_t stride_bytes,
                          const uint8_t channels[4], const float clear_color[4], const forma_rect_t* crop_or_null, int cache_id,
                          forma_timings_t* timings);
+// the same frame for a multi-device context with frames in flight (device-resident, no cache): enqueue now, settle later
+int fd_gsp_defer(forma_hip_ctx* ctx, uint32_t width, uint32_t height, const uint8_t channels[4], const float clear_color[4],
+                 const forma_rect_t* crop_or_null);
+int fd_gsp_settle(forma_hip_ctx* ctx);
 // rows [y0, y1) of the context's last image -> dst (row-major, stride bytes per row, dst addresses row 0)
 int fd_copy_image_rows(forma_hip_ctx* ctx, uint8_t* dst, size_t stride_bytes, uint32_t y0, uint32_t y1);
 
+// the stream (0 unsorted, 1 sorted) / the written-tile flags of exactly this context's last frame
+int fd_read_stream(forma_hip_ctx* ctx, int which, uint64_t* out, size_t capacity, size_t* out_n);
+int fd_read_sorted(forma_hip_ctx* ctx, uint64_t* out, size_t capacity, size_t* out_n);
+int fd_tiles_written(forma_hip_ctx* ctx, uint8_t* flags, size_t n_tiles);
+
 // multi.cpp: the entry points of a multi-device context (ctx->multi != nullptr)
+int  multi_set_frames_in_flight(forma_hip_ctx* ctx, int n);
+int  multi_sync(forma_hip_ctx* ctx);
+void multi_info(forma_hip_ctx* ctx, forma_context_info_t* out);
 int  multi_create(forma_hip_ctx** out, const int* devices, int n);
 void multi_destroy(forma_hip_ctx* ctx);
 int  multi_set_geometry(forma_hip_ctx* ctx, const float* x, const float* y, const uint32_t* line_slot, size_t n_points);

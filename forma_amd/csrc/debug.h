@@ -1,0 +1,53 @@
+// debug.h — the ONE place libforma_hip.so looks at the environment.
+//
+// FORMA_HIP_DEBUG = "name[=value],name,..." holds the switches tests and tools use to force or forbid one path each; a
+// deployment never sets it.  Parsed when a context is created (tests flip switches between contexts of one process), except
+// the two process-wide ones noted below.
+//   sync                 no read-back-free frames (every frame reads N, the key masks and J back)
+//   global_runsort       the carry pre-pass never orders a row's runs in LDS
+//   xgather              multi-GPU: always materialise the received stream before sorting it
+//   no_small_carry       never pick the small-LDS variant of k_carry_rows
+//   span_groups / no_span_groups   span group lists on every frame / never
+//   carry_slices=N       N workgroups per tile row in the carry pre-pass
+//   digit_bits=4|8|9     radix digit width (default: 8, or 9 where that saves a pass)
+//   no_packed_copy       cache frames copy the whole crop out instead of the packed written tiles
+//   no_simple_paint / force_simple_paint   the all-solid painter kernel never / always (process-wide, read once)
+//   poison=BYTE          every fresh device allocation is filled with BYTE (process-wide, read once)
+//   poison_frame=BYTE    every per-frame buffer is refilled with BYTE when a frame starts
+//   no_prezero           the frame's first kernel clears nothing for later stages (they use memsets: A/B of the folding)
+//   trim_debug           forma_hip_trim prints what it releases
+//   force_exchange       forma_hip_create_multi with ONE device still builds the multi-device context (RCCL world of one)
+//   xchg=copy            multi-device contexts exchange with device copies instead of RCCL
+#pragma once
+#include <cstdlib>
+#include <cstring>
+
+struct ForMaDebug {
+    bool sync = false, global_runsort = false, xgather = false, no_small_carry = false, span_groups = false, no_span_groups = false;
+    bool no_packed_copy = false, no_simple_paint = false, force_simple_paint = false, trim_debug = false, force_exchange = false;
+    bool xchg_copy = false, no_prezero = false;
+    int carry_slices = 0, digit_bits = 0, poison = -1, poison_frame = -1;
+};
+
+inline ForMaDebug forma_debug_parse() {
+    ForMaDebug d;
+    const char* e = getenv("FORMA_HIP_DEBUG");
+    if (!e) return d;
+    char buf[512];
+    strncpy(buf, e, sizeof buf - 1); buf[sizeof buf - 1] = 0;
+    for (char* tok = strtok(buf, ",; "); tok; tok = strtok(nullptr, ",; ")) {
+        char* val = strchr(tok, '=');
+        if (val) *val++ = 0;
+        const long v = val ? strtol(val, nullptr, 0) : 0;
+#define FD_FLAG(name) if (!strcmp(tok, #name)) { d.name = true; continue; }
+        FD_FLAG(sync) FD_FLAG(global_runsort) FD_FLAG(xgather) FD_FLAG(no_small_carry) FD_FLAG(span_groups) FD_FLAG(no_span_groups)
+        FD_FLAG(no_prezero) FD_FLAG(no_packed_copy) FD_FLAG(no_simple_paint) FD_FLAG(force_simple_paint) FD_FLAG(trim_debug) FD_FLAG(force_exchange)
+#undef FD_FLAG
+        if (!strcmp(tok, "xchg")) { d.xchg_copy = val && !strcmp(val, "copy"); continue; }
+        if (!strcmp(tok, "carry_slices")) { d.carry_slices = (int)v; continue; }
+        if (!strcmp(tok, "digit_bits")) { d.digit_bits = (int)v; continue; }
+        if (!strcmp(tok, "poison")) { d.poison = (int)(v & 0xFF); continue; }
+        if (!strcmp(tok, "poison_frame")) { d.poison_frame = (int)(v & 0xFF); continue; }
+    }
+    return d;
+}

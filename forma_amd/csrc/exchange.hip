@@ -35,10 +35,12 @@ __device__ __forceinline__ uint32_t owner_of(uint64_t v, const OwnerBands& B) {
 
 __global__ __launch_bounds__(XB_THREADS) void k_owner_count(const uint64_t* __restrict__ seg, DevCount nc, OwnerBands B,
                                                             uint32_t* __restrict__ block_counts /* [n + 1][nblocks] */,
-                                                            uint32_t nblocks_cap) {
+                                                            uint32_t nblocks_cap, uint64_t* __restrict__ send, uint32_t capacity) {
     __shared__ uint32_t s_c[XB_WAVES][FORMA_MAX_RANKS + 1];
     const uint32_t n = dev_count(nc);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // the bucket headers (one word each, capacity + 1 words apart) start from zero: k_owner_scan, the next launch, ORs into them
+    if (blockIdx.x == 0 && tid < (int)B.n) send[(size_t)tid * ((size_t)capacity + 1) + capacity] = 0ull;
     const uint32_t base = blockIdx.x * XB_TILE + w * (64 * XB_ROWS);
     uint32_t cnt[FORMA_MAX_RANKS + 1];
 #pragma unroll
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(256) void k_gather_chunks(const uint64_t* __restric
         total += c;
     }
     const uint32_t cnt = cnt_s < capacity ? cnt_s : capacity;
-    if (blockIdx.x == 0 && s == 0 && threadIdx.x == 0) { info->n_segments = total; if (over) info->exchange_overflow = 1u; }
+    if (blockIdx.x == 0 && s == 0 && threadIdx.x == 0) { info->n_segments = total; if (over) { info->exchange_overflow = 1u; info->plan_bad = 1u; } }
     const uint64_t* src = recv + (size_t)s * stride;
     uint32_t k_or = 0, k_or_hi = 0, k_and = 0xFFFFFFFFu, k_and_hi = 0xFFFFFFFFu, unsorted = 0;
     for (uint32_t k0 = blockIdx.x * 1024; k0 < cnt; k0 += gridDim.x * 1024) {
@@ -297,10 +299,11 @@ void launch_owner_bucket(hipStream_t s, const uint64_t* seg, DevCount nc, const 
                          uint32_t* scratch, uint64_t* send, FrameInfo* info) {
     const uint32_t nblocks = (uint32_t)((nc.bound + XB_TILE - 1) / XB_TILE);
     const uint32_t cap = nblocks + 1;
-    // the B.n bucket headers (one word each, (capacity + 1) words apart) start from zero
-    (void)hipMemset2DAsync(send + capacity, ((size_t)capacity + 1) * 8, 0, 8, B.n, s);
-    if (nblocks == 0) return;
-    hipLaunchKernelGGL(k_owner_count, dim3(nblocks), dim3(XB_THREADS), 0, s, seg, nc, B, scratch, cap);
+    if (nblocks == 0) {                                   // (no kernel: the headers are cleared here)
+        (void)hipMemset2DAsync(send + capacity, ((size_t)capacity + 1) * 8, 0, 8, B.n, s);
+        return;
+    }
+    hipLaunchKernelGGL(k_owner_count, dim3(nblocks), dim3(XB_THREADS), 0, s, seg, nc, B, scratch, cap, send, capacity);
     hipLaunchKernelGGL(k_owner_scan, dim3(B.n + 1), dim3(1024), 0, s, scratch, nc, cap, B.n + 1, capacity, send, info);
     hipLaunchKernelGGL(k_owner_scatter, dim3(nblocks), dim3(XB_THREADS), 0, s, seg, nc, B, (const uint32_t*)scratch, cap, capacity, send);
 }

@@ -4,6 +4,7 @@
 // writes `mul_add`.  All kernels are HBM/L2-bound integer + f32/f64 scalar work: no MFMA.
 #include "common.h"
 #include "lookback.h"
+#include <string.h>
 #ifdef RAS_PROF
 // -DRAS_PROF (tools only): shader-clock stamps at the phase boundaries of k_rasterize (thread 0 of every workgroup)
 __device__ unsigned long long g_ras_prof[64][8];
@@ -257,7 +258,17 @@ __device__ __forceinline__ void mark_block_first(uint32_t* __restrict__ block_fi
 #define PL_THREADS 1024
 #define PL_IPT     (PC_TILE / PL_THREADS)
 __global__ __launch_bounds__(PL_THREADS) void k_line_len(LineSource S, uint32_t n_lines, uint32_t* __restrict__ lens,
-                                                         uint32_t* __restrict__ tile_sum, uint32_t* __restrict__ tile_cnt) {
+                                                         uint32_t* __restrict__ tile_sum, uint32_t* __restrict__ tile_cnt, ZeroJobs Z) {
+    // the frame's first kernel also clears what later stages expect to be zero (ZeroJobs, common.h): every workgroup a slice
+    // of every job, 16 bytes per lane (the buffers are hipMalloc'd and the counts padded by their owners; the tail goes by word)
+    for (uint32_t q = 0; q < Z.n; q++) {
+        const uint32_t words = Z.words[q], quads = words >> 2;
+        const uint32_t per = (quads + gridDim.x - 1) / gridDim.x;
+        const uint32_t q0 = blockIdx.x * per, q1 = min(quads, q0 + per);
+        uint4* z4 = reinterpret_cast<uint4*>(Z.p[q]);
+        for (uint32_t i = q0 + threadIdx.x; i < q1; i += PL_THREADS) z4[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (blockIdx.x == 0 && threadIdx.x < (words & 3u)) Z.p[q][(quads << 2) + threadIdx.x] = 0u;
+    }
     // Segment counts are summed in 64 bits and SATURATE at SEG_SUM_SAT where they are stored as 32-bit words: geometry that
     // asks for more pixel segments than a device holds (a line from x = -1e20, a transform gone wild) must end as
     // FORMA_E_CAPACITY on the host, not as prefix sums that wrapped around and tables that point anywhere (the reference wraps
@@ -393,15 +404,18 @@ __global__ __launch_bounds__(PC_THREADS) void k_line_compact(const uint32_t* __r
 size_t prepare_scratch_words(size_t n_lines) { return n_lines + 2 * ((n_lines + PC_TILE - 1) / PC_TILE + 1) + 16; }
 
 void launch_prepare_compact(hipStream_t s, const LineSource& src, uint32_t n_lines, uint32_t* cl_idx, uint32_t* cl_start,
-                            uint32_t* block_first, uint32_t bf_cap, uint32_t* scratch, FrameInfo* info) {
-    if (n_lines == 0) return;
+                            uint32_t* block_first, uint32_t bf_cap, uint32_t* scratch, FrameInfo* info, const ZeroJobs* zero) {
+    if (n_lines == 0) return;                             // (no kernel, nothing cleared: the caller keeps its memsets)
+    ZeroJobs Z;
+    memset(&Z, 0, sizeof Z);
+    if (zero) Z = *zero;
     // chain-free: count -> scan (one workgroup) -> compact.  (A single-pass chained scan was 2x slower here: with only
     // ~800 tiles the whole grid is resident at once, so every tile walks back through aggregates to tile 0.)
     const uint32_t ntiles = (n_lines + PC_TILE - 1) / PC_TILE;
     uint32_t* lens = scratch;
     uint32_t* tile_sum = scratch + n_lines;
     uint32_t* tile_cnt = tile_sum + ntiles + 1;
-    hipLaunchKernelGGL(k_line_len, dim3(ntiles), dim3(PL_THREADS), 0, s, src, n_lines, lens, tile_sum, tile_cnt);
+    hipLaunchKernelGGL(k_line_len, dim3(ntiles), dim3(PL_THREADS), 0, s, src, n_lines, lens, tile_sum, tile_cnt, Z);
     hipLaunchKernelGGL(k_scan_line_tiles, dim3(1), dim3(1024), 0, s, tile_sum, tile_cnt, ntiles, info);
     hipLaunchKernelGGL(k_line_compact, dim3(ntiles), dim3(PC_THREADS), 0, s, (const uint32_t*)lens, n_lines,
                        (const uint32_t*)tile_sum, (const uint32_t*)tile_cnt, cl_idx, cl_start, block_first, bf_cap);
@@ -413,7 +427,9 @@ void launch_line_lengths(hipStream_t s, const LineSource& src, uint32_t n_lines,
     const uint32_t ntiles = (n_lines + PC_TILE - 1) / PC_TILE;
     uint32_t* tile_sum = scratch + n_lines;
     uint32_t* tile_cnt = tile_sum + ntiles + 1;
-    hipLaunchKernelGGL(k_line_len, dim3(ntiles), dim3(PL_THREADS), 0, s, src, n_lines, lens, tile_sum, tile_cnt);
+    ZeroJobs Z;
+    memset(&Z, 0, sizeof Z);
+    hipLaunchKernelGGL(k_line_len, dim3(ntiles), dim3(PL_THREADS), 0, s, src, n_lines, lens, tile_sum, tile_cnt, Z);
 }
 
 __global__ __launch_bounds__(256) void k_block_first(const uint32_t* __restrict__ cl_start, uint32_t n_compact,

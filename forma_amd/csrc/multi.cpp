@@ -13,6 +13,17 @@
 //   kid g: received buckets, rank-major = global line order  --stable radix sort (in place through the chunk map), carry
 //          pre-pass, painter-->  its band of tile rows  --hipMemcpy2D-->  its rows of the caller's buffer
 //
+// FRAMES IN FLIGHT (forma_hip_set_frames_in_flight on the multi-device context, round 4).  A band frame is ~250 us of kernels
+// that are bound by their own dependent round trips, not by the chip: ONE frame at a time leaves every device mostly idle and
+// puts two host barriers and the collective's enqueue on the critical path.  With F slots every device holds F frame slots
+// (full contexts that borrow the device's scene: own stream, own per-frame and exchange buffers) and every slot has its own
+// set of communicators, so the collectives of consecutive frames never share a queue.  A device-resident, cache-less frame is
+// ENQUEUED on the next slot by the device threads — buckets, the slot's all-to-all, the owner's sort + paint, all stream-ordered
+// — and the call returns; it is verified when its slot comes round again (or when any call needs its result), re-planned and
+// re-run if a bucket outgrew the plan.  The host barriers between the two halves remain, but they only order ENQUEUES: the
+// devices work on the other slots' frames meanwhile.  Frames into caller memory, cache frames and timed frames keep the
+// synchronous contract (cpu/buffer/mod.rs:43-49).
+//
 // `tile_y` is the most significant key field and the cover carry never crosses tile rows (painter/mod.rs:518-522), so a
 // band is a complete sort + paint problem; the stable partition and the rank-major concatenation keep every band's sorted
 // stream bit-identical to the corresponding slice of the single-device stream.
@@ -92,6 +103,8 @@ struct SpinBarrier {
 };
 
 struct FrameJob {
+    enum Mode { FULL, DEFER, SETTLE } mode = FULL;  // whole frame now | enqueue on a slot | complete a slot's deferred frame
+    int slot = 0;
     uint8_t* dst = nullptr;
     uint32_t width = 0, height = 0;
     size_t stride = 0;
@@ -103,17 +116,25 @@ struct FrameJob {
     bool timings = false;
 };
 
+// the caller's current device is the caller's business: every entry point of a multi-device context restores it (the single-
+// device entry points it drives call hipSetDevice for each device in turn)
+struct DeviceGuard {
+    int dev = -1;
+    DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+    ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
+};
+
 }  // namespace
 
 struct MultiState {
-    int G = 0;
+    int G = 0, F = 1;                         // devices, frame slots
     forma_hip_ctx* owner = nullptr;
     forma_hip_ctx* kid[FORMA_MAX_RANKS] = {nullptr};
     int dev[FORMA_MAX_RANKS] = {0};
     bool duplicates = false;                  // a device is listed twice: rehearsal on one GPU, device copies instead of RCCL
     bool use_rccl = false;
-    ncclComm_t comm[FORMA_MAX_RANKS] = {nullptr};
-    hipEvent_t ev_bucket[FORMA_MAX_RANKS] = {nullptr};
+    ncclComm_t comm[FORMA_MAX_FRAMES_IN_FLIGHT][FORMA_MAX_RANKS] = {{nullptr}};   // one set of communicators per frame slot
+    hipEvent_t ev_bucket[FORMA_MAX_FRAMES_IN_FLIGHT][FORMA_MAX_RANKS] = {{nullptr}};
     // the plan
     bool planned = false;
     uint32_t plan_w = 0, plan_h = 0, cap = 0;
@@ -121,6 +142,12 @@ struct MultiState {
     size_t cuts[FORMA_MAX_RANKS + 1] = {0};
     uint32_t plans_made = 0;
     bool cache_used[32] = {false};
+    // frame slots
+    bool slot_pending[FORMA_MAX_FRAMES_IN_FLIGHT] = {false};
+    FrameJob slot_job[FORMA_MAX_FRAMES_IN_FLIGHT];                          // what a pending slot was asked to render
+    uint32_t slot_edges[FORMA_MAX_FRAMES_IN_FLIGHT][FORMA_MAX_RANKS + 1] = {{0}};   // the bands its frame was rendered with
+    unsigned next_slot = 0;
+    int last_slot = 0;
     // the per-device threads
     std::thread th[FORMA_MAX_RANKS];
     std::mutex m;
@@ -145,6 +172,12 @@ namespace {
 #define MFAIL(code, what) fd_fail(ctx, code, what)
 
 void copy_err(forma_hip_ctx* ctx, const forma_hip_ctx* from) { memcpy(ctx->err, from->err, sizeof ctx->err); }
+
+// the context of device g's frame slot s (slot 0 is the device's own context, the others borrow its scene)
+forma_hip_ctx* slot_ctx(const MultiState* M, int g, int s) {
+    forma_hip_ctx* k = M->kid[g];
+    return (s > 0 && (size_t)s < k->slots.size()) ? k->slots[s] : k;
+}
 
 // ---- planning (host logic; the Python launcher's copy is forma_amd/sharding.py) --------------------------------------------------
 // lines 0..n cut into G contiguous ranges carrying (nearly) equal pixel-segment counts
@@ -217,8 +250,11 @@ int make_plan(forma_hip_ctx* ctx, uint32_t width, uint32_t height) {
     M->cap = pair_capacity(max_pair);
     if ((uint64_t)M->cap * G >= (1ull << 30)) return MFAIL(FORMA_E_CAPACITY, "multi-device plan: more than 2^30-1 bucket slots per device");
     for (int g = 0; g < G; g++) {
-        if ((rc = forma_hip_exchange_plan(M->kid[g], M->edges, (uint32_t)G, M->cap))) { copy_err(ctx, M->kid[g]); return rc; }
-        M->kid[g]->xuse_recv = G == 1 && M->use_rccl;      // a world of one still runs its collective (the point of the rehearsal)
+        for (int sl = 0; sl < M->F; sl++) {                  // every frame slot of the device: its own buckets
+            forma_hip_ctx* k = slot_ctx(M, g, sl);
+            if ((rc = forma_hip_exchange_plan(k, M->edges, (uint32_t)G, M->cap))) { copy_err(ctx, k); return rc; }
+            k->xuse_recv = G == 1 && M->use_rccl;            // a world of one still runs its collective (the point of the rehearsal)
+        }
         // a band that moved invalidates what a buffer-layer cache remembers about its rows: start over (everything repaints once).
         // (A plan made again for the same scene — after forma_hip_trim — lands on the same bands and keeps the caches.)
         for (int c = 0; c < 32 && bands_moved; c++)
@@ -239,13 +275,17 @@ void add_timings(forma_timings_t& t, const forma_timings_t& a) {
 }
 
 void device_frame(MultiState* M, int g) {
-    forma_hip_ctx* kid = M->kid[g];
     const FrameJob& J = M->job;
+    forma_hip_ctx* kid = slot_ctx(M, g, J.slot);
     const int G = M->G;
+    if (J.mode == FrameJob::SETTLE) {                       // complete this device's part of the slot's deferred frame
+        M->rc[g] = fd_gsp_settle(kid);
+        return;
+    }
     forma_timings_t t1, t2;
     memset(&t1, 0, sizeof t1); memset(&t2, 0, sizeof t2);
     int rc = forma_hip_rasterize_bucket_frame(kid, J.width, J.height, J.timings ? &t1 : nullptr);
-    if (rc == FORMA_OK && !M->use_rccl && G > 1 && hipEventRecord(M->ev_bucket[g], kid->stream) != hipSuccess)
+    if (rc == FORMA_OK && !M->use_rccl && G > 1 && hipEventRecord(M->ev_bucket[J.slot][g], kid->stream) != hipSuccess)
         rc = fd_fail(kid, FORMA_E_HIP, "hipEventRecord (bucket)");
     M->rc_stage[g] = rc;
     M->bar.wait(G);                                        // A: every device has enqueued its buckets
@@ -255,13 +295,13 @@ void device_frame(MultiState* M, int g) {
         // The canonical single-process form: ONE thread issues the collective for every communicator inside a group, each
         // on its device's stream, behind the bucket kernels already enqueued there.  Equal splits (the pair capacity + the
         // bucket's header word {count, overflow}): no count has to reach the host before the exchange can be enqueued, and
-        // ONE collective per frame moves everything.
+        // ONE collective per frame moves everything.  Every frame slot has its own communicators.
         if (g == 0) {
             RcclApi* R = rccl_api();
             ncclResult_t r = R->GroupStart();
             for (int q = 0; q < G && r == ncclSuccess; q++) {
-                forma_hip_ctx* k = M->kid[q];
-                r = R->AllToAll(k->xsend.p, k->xrecv.p, (size_t)M->cap + 1, ncclUint64, M->comm[q], k->stream);   // data + header of every bucket
+                forma_hip_ctx* k = slot_ctx(M, q, J.slot);
+                r = R->AllToAll(k->xsend.p, k->xrecv.p, (size_t)M->cap + 1, ncclUint64, M->comm[J.slot][q], k->stream);   // data + header of every bucket
             }
             const ncclResult_t e = R->GroupEnd();
             if (r == ncclSuccess) r = e;
@@ -272,13 +312,13 @@ void device_frame(MultiState* M, int g) {
             }
         }
         M->bar.wait(G);                                    // B: the collective is enqueued on every stream
-        if (M->rc_coll) { ok = false; rc = M->rc_coll; if (g) memcpy(kid->err, M->kid[0]->err, sizeof kid->err); }
+        if (M->rc_coll) { ok = false; rc = M->rc_coll; if (g) memcpy(kid->err, slot_ctx(M, 0, J.slot)->err, sizeof kid->err); }
     } else if (ok && G > 1) {
-        // rehearsal / FORMA_HIP_XCHG=copy: the same data movement with device copies — recv[g][s] = send[s][g], each behind
-        // the sender's bucket kernels (event) and in front of this device's gather (stream order)
+        // rehearsal / FORMA_HIP_DEBUG=xchg=copy / no usable RCCL: the same data movement with device copies — recv[g][s] =
+        // send[s][g], each behind the sender's bucket kernels (event) and in front of this device's gather (stream order)
         for (int s = 0; s < G && rc == FORMA_OK; s++) {
-            forma_hip_ctx* src = M->kid[s];
-            if (hipStreamWaitEvent(kid->stream, M->ev_bucket[s], 0) != hipSuccess) { rc = fd_fail(kid, FORMA_E_HIP, "hipStreamWaitEvent"); break; }
+            forma_hip_ctx* src = slot_ctx(M, s, J.slot);
+            if (hipStreamWaitEvent(kid->stream, M->ev_bucket[J.slot][s], 0) != hipSuccess) { rc = fd_fail(kid, FORMA_E_HIP, "hipStreamWaitEvent"); break; }
             const size_t W = (size_t)M->cap + 1;          // a bucket: data + header
             hipError_t e1;
             if (M->dev[s] == M->dev[g])
@@ -292,8 +332,11 @@ void device_frame(MultiState* M, int g) {
         ok = rc == FORMA_OK;
     }
     if (ok) {
-        rc = fd_gather_sort_paint(kid, J.dst, J.width, J.height, J.stride, J.channels, J.clear, &M->band_crop[g], J.cache_id,
-                                  J.timings ? &t2 : nullptr);
+        if (J.mode == FrameJob::DEFER)
+            rc = fd_gsp_defer(kid, J.width, J.height, J.channels, J.clear, &M->band_crop[g]);
+        else
+            rc = fd_gather_sort_paint(kid, J.dst, J.width, J.height, J.stride, J.channels, J.clear, &M->band_crop[g], J.cache_id,
+                                      J.timings ? &t2 : nullptr);
     } else if (rc == FORMA_OK) {
         rc = FORMA_E_STATE;                                // another device failed: this one did not paint
         snprintf(kid->err, sizeof kid->err, "another device of the context failed its part of the frame");
@@ -324,7 +367,9 @@ void worker_main(MultiState* M, int g) {
     }
 }
 
-int run_frame(forma_hip_ctx* ctx) {
+// hands M->job to the device threads and waits until every one is through with it.  *overflow: some device's owner half met a
+// bucket beyond the pair capacity (the frame is void everywhere: re-plan and run it again)
+int run_job(forma_hip_ctx* ctx, bool* overflow) {
     MultiState* M = ctx->multi;
     M->done.store(0, std::memory_order_release);
     {
@@ -340,156 +385,59 @@ int run_frame(forma_hip_ctx* ctx) {
     }
     // the most specific failure wins: a capacity overflow (re-plan) over a plain error over "another device failed"
     int first = FORMA_OK, pick = -1;
+    bool over = false;
     for (int g = 0; g < M->G; g++) {
         const int r = M->rc[g];
+        forma_hip_ctx* k = slot_ctx(M, g, M->job.slot);
+        if (r == FORMA_E_CAPACITY && k->xoverflowed) over = true;
         if (r == FORMA_OK) continue;
         const bool better = pick < 0 || (r == FORMA_E_CAPACITY && first != FORMA_E_CAPACITY) || (first == FORMA_E_STATE && r != FORMA_E_STATE);
         if (better) { first = r; pick = g; }
     }
-    if (pick >= 0) copy_err(ctx, M->kid[pick]);
+    if (pick >= 0) copy_err(ctx, slot_ctx(M, pick, M->job.slot));
+    if (overflow) *overflow = over;
     return first;
 }
 
-}  // namespace
-
-// ---- entry points (dispatched from api.cpp when ctx->multi) -----------------------------------------------------------------------
-int multi_create(forma_hip_ctx** out, const int* devices, int n) {
-    *out = nullptr;
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return FORMA_E_NO_DEVICE;
-    for (int i = 0; i < n; i++) if (devices[i] < 0 || devices[i] >= count) return FORMA_E_ARG;
-    forma_hip_ctx* ctx = new (std::nothrow) forma_hip_ctx();
-    MultiState* M = new (std::nothrow) MultiState();
-    if (!ctx || !M) { delete ctx; delete M; return FORMA_E_INTERNAL; }
-    ctx->multi = M; ctx->device = devices[0];
-    M->owner = ctx; M->G = n;
-    for (int i = 0; i < n; i++) { M->dev[i] = devices[i]; for (int j = 0; j < i; j++) if (devices[j] == devices[i]) M->duplicates = true; }
-    const char* x = getenv("FORMA_HIP_XCHG");
-    M->use_rccl = !M->duplicates && !(x && !strcmp(x, "copy"));
-    int rc = FORMA_OK;
-    for (int i = 0; i < n && rc == FORMA_OK; i++) {
-        rc = forma_hip_create(&M->kid[i], devices[i]);
-        if (rc == FORMA_OK && hipEventCreateWithFlags(&M->ev_bucket[i], hipEventDisableTiming) != hipSuccess) rc = FORMA_E_HIP;
-    }
-    if (rc == FORMA_OK && !M->use_rccl && !M->duplicates) {             // copies between distinct devices: peer access both ways
-        for (int i = 0; i < n; i++) {
-            (void)hipSetDevice(devices[i]);
-            for (int j = 0; j < n; j++) if (j != i) (void)hipDeviceEnablePeerAccess(devices[j], 0);   // (already enabled is fine)
+// a device paints (and copies out) the intersection of its band with the crop, tile-rounded like Rect::new (renderer.rs:43-52)
+void set_band_crops(MultiState* M, uint32_t width, uint32_t height, const forma_rect_t* crop_or_null) {
+    const uint32_t tiles_h = (height + 15) / 16;
+    for (int g = 0; g < M->G; g++) {
+        uint32_t ty0 = M->edges[g], ty1 = M->edges[g + 1];
+        uint32_t x0 = 0, x1 = width;
+        if (crop_or_null) {
+            ty0 = std::max(ty0, crop_or_null->y0 / 16); ty1 = std::min(ty1, std::min(tiles_h, (crop_or_null->y1 + 15) / 16));
+            x0 = crop_or_null->x0; x1 = crop_or_null->x1;
         }
-        (void)hipGetLastError();
+        if (ty0 >= ty1) { ty0 = M->edges[g]; ty1 = ty0; }              // nothing of the band is inside the crop
+        M->band_crop[g] = forma_rect_t{x0, x1, ty0 * 16, std::min(ty1 * 16, height)};
+        if (ty0 == ty1) M->band_crop[g].y1 = M->band_crop[g].y0;
     }
-    if (rc == FORMA_OK && M->use_rccl) {
-        RcclApi* R = rccl_api();
-        if (!R->handle) rc = FORMA_E_COMM;
-        else if (R->CommInitAll(M->comm, n, M->dev) != ncclSuccess) rc = FORMA_E_COMM;
-    }
-    if (rc != FORMA_OK) { multi_destroy(ctx); return rc; }
-    for (int g = 0; g < n; g++) M->th[g] = std::thread(worker_main, M, g);
-    (void)hipSetDevice(devices[0]);
-    *out = ctx;
-    return FORMA_OK;
 }
 
-void multi_destroy(forma_hip_ctx* ctx) {
-    MultiState* M = ctx->multi;
-    if (M) {
-        {
-            std::lock_guard<std::mutex> lock(M->m);
-            M->quit = true;
-            M->job_gen.fetch_add(1, std::memory_order_acq_rel);
-        }
-        M->cv_job.notify_all();
-        for (int g = 0; g < M->G; g++) if (M->th[g].joinable()) M->th[g].join();
-        if (M->use_rccl) { RcclApi* R = rccl_api(); for (int g = 0; g < M->G; g++) if (M->comm[g] && R->handle) (void)R->CommDestroy(M->comm[g]); }
-        for (int g = 0; g < M->G; g++) {
-            if (M->ev_bucket[g]) { (void)hipSetDevice(M->dev[g]); (void)hipEventDestroy(M->ev_bucket[g]); }
-            if (M->kid[g]) forma_hip_destroy(M->kid[g]);
-        }
-        delete M;
-    }
-    ctx->multi = nullptr;
-    delete ctx;
-}
-
-forma_hip_ctx* multi_first(forma_hip_ctx* ctx) { return ctx->multi->kid[0]; }
-
-#define EACH_KID(call)                                                              \
-    do {                                                                            \
-        MultiState* M = ctx->multi;                                                 \
-        for (int g = 0; g < M->G; g++) {                                            \
-            forma_hip_ctx* k = M->kid[g];                                           \
-            const int rc = (call);                                                  \
-            if (rc) { copy_err(ctx, k); return rc; }                                \
-        }                                                                           \
-    } while (0)
-
-int multi_set_geometry(forma_hip_ctx* ctx, const float* x, const float* y, const uint32_t* line_slot, size_t n_points) {
-    ctx->multi->planned = false;                          // new geometry: new line shares, new bands
-    EACH_KID(forma_hip_set_geometry(k, x, y, line_slot, n_points));
-    EACH_KID(fd_set_line_range(k, false, 0, 0));
-    return FORMA_OK;
-}
-int multi_set_geoms(forma_hip_ctx* ctx, const forma_geom_t* geoms, size_t n_geoms) {
-    // (transforms move segments between bands: the plan stays — its capacity carries 6 % slack and a frame that outgrows it
-    //  re-plans; a layer that is switched on or off changes far less than that in practice)
-    EACH_KID(forma_hip_set_geoms(k, geoms, n_geoms));
-    return FORMA_OK;
-}
-int multi_set_styles(forma_hip_ctx* ctx, const uint32_t* style_offsets, size_t n_orders, const uint32_t* style_words, size_t n_words,
-                     const uint8_t* unchanged) {
-    EACH_KID(forma_hip_set_styles(k, style_offsets, n_orders, style_words, n_words, unchanged));
-    return FORMA_OK;
-}
-int multi_set_images(forma_hip_ctx* ctx, const forma_image_t* images, size_t n_images, const uint16_t* texels, size_t n_texels) {
-    EACH_KID(forma_hip_set_images(k, images, n_images, texels, n_texels));
-    return FORMA_OK;
-}
-int multi_trim(forma_hip_ctx* ctx) {
-    EACH_KID(forma_hip_trim(k));
-    ctx->multi->planned = false;                           // (the plan's measurements live in the kids' buffers: plan again)
-    return FORMA_OK;
-}
-
-int multi_cache_clear(forma_hip_ctx* ctx, int cache_id) {
-    EACH_KID(forma_hip_cache_clear(k, cache_id));
-    return FORMA_OK;
-}
-
-int multi_render(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t height, size_t stride_bytes, const uint8_t channels[4],
-                 const float clear_color[4], const forma_rect_t* crop_or_null, int cache_id, forma_timings_t* timings) {
+// One whole frame on frame slot `slot`, complete when it returns: plan if there is none, run, re-plan and run again when a
+// bucket outgrew the plan.  The caller has settled every other slot if a new plan may be needed (a plan re-sizes the exchange
+// buffers of ALL slots).
+int full_frame(forma_hip_ctx* ctx, const FrameJob& want, forma_timings_t* timings) {
     MultiState* M = ctx->multi;
     const int G = M->G;
-    const uint32_t tiles_h = (height + 15) / 16;
-    if (cache_id >= 0) M->cache_used[cache_id] = true;
     for (int attempt = 0; attempt < 3; attempt++) {
-        if (!M->planned || M->plan_w != width || M->plan_h != height) {
-            const int rc = make_plan(ctx, width, height);
+        if (!M->planned || M->plan_w != want.width || M->plan_h != want.height) {
+            const int rc = make_plan(ctx, want.width, want.height);
             if (rc) return rc;
         }
-        FrameJob& J = M->job;
-        J.dst = dst; J.width = width; J.height = height; J.stride = stride_bytes;
-        memcpy(J.channels, channels, 4); memcpy(J.clear, clear_color, 16);
-        J.has_crop = crop_or_null != nullptr; if (crop_or_null) J.crop = *crop_or_null;
-        J.cache_id = cache_id; J.timings = timings != nullptr;
-        // a device paints (and copies out) the intersection of its band with the crop, tile-rounded like Rect::new (renderer.rs:43-52)
-        for (int g = 0; g < G; g++) {
-            uint32_t ty0 = M->edges[g], ty1 = M->edges[g + 1];
-            uint32_t x0 = 0, x1 = width;
-            if (crop_or_null) {
-                ty0 = std::max(ty0, crop_or_null->y0 / 16); ty1 = std::min(ty1, std::min(tiles_h, (crop_or_null->y1 + 15) / 16));
-                x0 = crop_or_null->x0; x1 = crop_or_null->x1;
-            }
-            if (ty0 >= ty1) { ty0 = M->edges[g]; ty1 = ty0; }              // nothing of the band is inside the crop
-            M->band_crop[g] = forma_rect_t{x0, x1, ty0 * 16, std::min(ty1 * 16, height)};
-            if (ty0 == ty1) M->band_crop[g].y1 = M->band_crop[g].y0;
-        }
-        const int rc = run_frame(ctx);
-        if (rc == FORMA_E_CAPACITY && attempt < 2 && strstr(ctx->err, "exchange")) {   // a bucket outgrew the plan: measure again
+        M->job = want;
+        M->job.mode = FrameJob::FULL;
+        set_band_crops(M, want.width, want.height, want.has_crop ? &want.crop : nullptr);
+        bool overflow = false;
+        const int rc = run_job(ctx, &overflow);
+        if (rc == FORMA_E_CAPACITY && overflow && attempt < 2) {            // a bucket outgrew the plan: measure again
             M->planned = false;
             continue;
         }
         if (rc) return rc;
-        M->last_valid = true; M->last_w = width; M->last_h = height;
+        for (int g = 0; g <= G; g++) M->slot_edges[want.slot][g] = M->edges[g];
+        M->last_valid = true; M->last_w = want.width; M->last_h = want.height; M->last_slot = want.slot;
         if (timings) {
             // devices work side by side: a stage takes as long as its slowest device; counts add up
             memset(timings, 0, sizeof *timings);
@@ -510,13 +458,294 @@ int multi_render(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t heig
     return MFAIL(FORMA_E_CAPACITY, "multi-device plan did not converge");
 }
 
+// Every deferred frame is completed.  A frame whose buckets outgrew the plan is void on every device: once ALL slots have been
+// looked at (a new plan re-sizes everybody's exchange buffers) such frames are run again, whole, under a new plan.  The first
+// error that remains is returned (and is the context's error text).
+int drain_slots(forma_hip_ctx* ctx) {
+    MultiState* M = ctx->multi;
+    int first = FORMA_OK;
+    char first_err[sizeof ctx->err] = {0};
+    bool rerun[FORMA_MAX_FRAMES_IN_FLIGHT] = {false};
+    bool any = false;
+    for (int k = 0; k < M->F; k++) {
+        const int s = (int)((M->next_slot + (unsigned)k) % (unsigned)M->F);    // oldest first
+        if (!M->slot_pending[s]) continue;
+        M->slot_pending[s] = false;
+        M->job = M->slot_job[s];
+        M->job.mode = FrameJob::SETTLE; M->job.slot = s;
+        bool overflow = false;
+        const int rc = run_job(ctx, &overflow);
+        if (rc == FORMA_E_CAPACITY && overflow) { rerun[s] = true; any = true; continue; }
+        if (rc && !first) { first = rc; memcpy(first_err, ctx->err, sizeof first_err); }
+    }
+    if (any) {
+        M->planned = false;
+        for (int k = 0; k < M->F; k++) {
+            const int s = (int)((M->next_slot + (unsigned)k) % (unsigned)M->F);
+            if (!rerun[s]) continue;
+            FrameJob want = M->slot_job[s];
+            want.slot = s; want.dst = nullptr; want.cache_id = -1; want.timings = false;
+            const int rc = full_frame(ctx, want, nullptr);
+            if (rc && !first) { first = rc; memcpy(first_err, ctx->err, sizeof first_err); }
+        }
+    }
+    if (first) memcpy(ctx->err, first_err, sizeof ctx->err);
+    return first;
+}
+
+int create_slot_transport(MultiState* M, int s) {          // communicators / events of frame slot s
+    for (int g = 0; g < M->G; g++) {
+        if (M->ev_bucket[s][g]) continue;
+        (void)hipSetDevice(M->dev[g]);
+        if (hipEventCreateWithFlags(&M->ev_bucket[s][g], hipEventDisableTiming) != hipSuccess) return FORMA_E_HIP;
+    }
+    if (M->use_rccl && !M->comm[s][0]) {
+        RcclApi* R = rccl_api();
+        if (!R->handle || R->CommInitAll(M->comm[s], M->G, M->dev) != ncclSuccess) {
+            for (int g = 0; g < M->G; g++) M->comm[s][g] = nullptr;
+            return FORMA_E_COMM;
+        }
+    }
+    return FORMA_OK;
+}
+void destroy_slot_transport(MultiState* M, int s) {
+    if (M->comm[s][0]) { RcclApi* R = rccl_api(); for (int g = 0; g < M->G; g++) if (M->comm[s][g] && R->handle) (void)R->CommDestroy(M->comm[s][g]); }
+    for (int g = 0; g < M->G; g++) {
+        M->comm[s][g] = nullptr;
+        if (M->ev_bucket[s][g]) { (void)hipSetDevice(M->dev[g]); (void)hipEventDestroy(M->ev_bucket[s][g]); M->ev_bucket[s][g] = nullptr; }
+    }
+}
+// No usable RCCL (library missing, communicator creation failed): the exchange still works with peer copies behind events —
+// slower to enqueue, the same bytes over the same links.  Said once on stderr: a deployment wants to know.
+void fall_back_to_copies(MultiState* M, const char* why) {
+    for (int s = 0; s < FORMA_MAX_FRAMES_IN_FLIGHT; s++)
+        if (M->comm[s][0]) { RcclApi* R = rccl_api(); for (int g = 0; g < M->G; g++) { if (M->comm[s][g] && R->handle) (void)R->CommDestroy(M->comm[s][g]); M->comm[s][g] = nullptr; } }
+    M->use_rccl = false;
+    if (!M->duplicates) {                                   // copies between distinct devices: peer access both ways
+        for (int i = 0; i < M->G; i++) {
+            (void)hipSetDevice(M->dev[i]);
+            for (int j = 0; j < M->G; j++) if (j != i) (void)hipDeviceEnablePeerAccess(M->dev[j], 0);   // (already enabled is fine)
+        }
+        (void)hipGetLastError();
+    }
+    fprintf(stderr, "[forma_hip] multi-device context: RCCL is not usable (%s); pixel segments are exchanged with peer copies instead\n", why);
+    M->planned = false;                                    // (xuse_recv of a world of one depends on the transport)
+}
+
+}  // namespace
+
+// ---- entry points (dispatched from api.cpp when ctx->multi) -----------------------------------------------------------------------
+int multi_create(forma_hip_ctx** out, const int* devices, int n) {
+    *out = nullptr;
+    DeviceGuard guard;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return FORMA_E_NO_DEVICE;
+    for (int i = 0; i < n; i++) if (devices[i] < 0 || devices[i] >= count) return FORMA_E_ARG;
+    forma_hip_ctx* ctx = new (std::nothrow) forma_hip_ctx();
+    MultiState* M = new (std::nothrow) MultiState();
+    if (!ctx || !M) { delete ctx; delete M; return FORMA_E_INTERNAL; }
+    ctx->multi = M; ctx->device = devices[0];
+    M->owner = ctx; M->G = n;
+    for (int i = 0; i < n; i++) { M->dev[i] = devices[i]; for (int j = 0; j < i; j++) if (devices[j] == devices[i]) M->duplicates = true; }
+    M->use_rccl = !M->duplicates && !forma_debug_parse().xchg_copy;
+    int rc = FORMA_OK;
+    for (int i = 0; i < n && rc == FORMA_OK; i++) rc = forma_hip_create(&M->kid[i], devices[i]);
+    if (rc == FORMA_OK && !M->use_rccl && !M->duplicates) {             // copies between distinct devices: peer access both ways
+        for (int i = 0; i < n; i++) {
+            (void)hipSetDevice(devices[i]);
+            for (int j = 0; j < n; j++) if (j != i) (void)hipDeviceEnablePeerAccess(devices[j], 0);   // (already enabled is fine)
+        }
+        (void)hipGetLastError();
+    }
+    if (rc == FORMA_OK) {
+        rc = create_slot_transport(M, 0);
+        if (rc == FORMA_E_COMM) {                          // (a working peer-copy exchange beats FORMA_E_COMM)
+            fall_back_to_copies(M, rccl_api()->handle ? "ncclCommInitAll failed" : rccl_api()->why);
+            rc = FORMA_OK;
+        }
+    }
+    if (rc != FORMA_OK) { multi_destroy(ctx); return rc; }
+    for (int g = 0; g < n; g++) M->th[g] = std::thread(worker_main, M, g);
+    *out = ctx;
+    return FORMA_OK;
+}
+
+void multi_destroy(forma_hip_ctx* ctx) {
+    DeviceGuard guard;
+    MultiState* M = ctx->multi;
+    if (M) {
+        if (M->th[0].joinable()) (void)drain_slots(ctx);
+        {
+            std::lock_guard<std::mutex> lock(M->m);
+            M->quit = true;
+            M->job_gen.fetch_add(1, std::memory_order_acq_rel);
+        }
+        M->cv_job.notify_all();
+        for (int g = 0; g < M->G; g++) if (M->th[g].joinable()) M->th[g].join();
+        for (int s = 0; s < FORMA_MAX_FRAMES_IN_FLIGHT; s++) destroy_slot_transport(M, s);
+        for (int g = 0; g < M->G; g++) if (M->kid[g]) forma_hip_destroy(M->kid[g]);
+        delete M;
+    }
+    ctx->multi = nullptr;
+    delete ctx;
+}
+
+forma_hip_ctx* multi_first(forma_hip_ctx* ctx) { return ctx->multi->kid[0]; }
+
+int multi_sync(forma_hip_ctx* ctx) {
+    DeviceGuard guard;
+    return drain_slots(ctx);
+}
+
+int multi_set_frames_in_flight(forma_hip_ctx* ctx, int n) {
+    DeviceGuard guard;
+    MultiState* M = ctx->multi;
+    int rc = drain_slots(ctx);
+    if (rc) return rc;
+    for (int g = 0; g < M->G; g++)
+        if ((rc = forma_hip_set_frames_in_flight(M->kid[g], n))) { copy_err(ctx, M->kid[g]); return rc; }
+    for (int s = n; s < FORMA_MAX_FRAMES_IN_FLIGHT; s++) destroy_slot_transport(M, s);
+    for (int s = 0; s < n; s++) {
+        rc = create_slot_transport(M, s);
+        if (rc == FORMA_E_COMM) { fall_back_to_copies(M, "ncclCommInitAll failed for a frame slot"); rc = create_slot_transport(M, s); }
+        if (rc) return MFAIL(rc, "frames in flight: cannot create a frame slot's communicators");
+    }
+    M->F = n; M->next_slot = 0; M->last_slot = 0;
+    M->planned = false;                                    // the new slots need their exchange buffers: plan again
+    return FORMA_OK;
+}
+
+void multi_info(forma_hip_ctx* ctx, forma_context_info_t* out) {
+    MultiState* M = ctx->multi;
+    out->n_devices = (uint32_t)M->G; out->frames_in_flight = (uint32_t)M->F;
+    out->transport = M->G > 1 || M->use_rccl ? (M->use_rccl ? FORMA_TRANSPORT_RCCL : FORMA_TRANSPORT_COPY) : FORMA_TRANSPORT_NONE;
+    for (int g = 0; g < M->G && g < FORMA_MAX_DEVICES; g++) out->devices[g] = M->dev[g];
+}
+
+#define EACH_KID(call)                                                              \
+    do {                                                                            \
+        MultiState* M = ctx->multi;                                                 \
+        for (int g = 0; g < M->G; g++) {                                            \
+            forma_hip_ctx* k = M->kid[g];                                           \
+            const int rc = (call);                                                  \
+            if (rc) { copy_err(ctx, k); return rc; }                                \
+        }                                                                           \
+    } while (0)
+#define MULTI_ENTER()                                                               \
+    DeviceGuard guard;                                                              \
+    { const int _rc = drain_slots(ctx); if (_rc) return _rc; }
+
+int multi_set_geometry(forma_hip_ctx* ctx, const float* x, const float* y, const uint32_t* line_slot, size_t n_points) {
+    MULTI_ENTER();
+    ctx->multi->planned = false;                          // new geometry: new line shares, new bands
+    EACH_KID(forma_hip_set_geometry(k, x, y, line_slot, n_points));
+    EACH_KID(fd_set_line_range(k, false, 0, 0));
+    return FORMA_OK;
+}
+int multi_set_geoms(forma_hip_ctx* ctx, const forma_geom_t* geoms, size_t n_geoms) {
+    // (transforms move segments between bands: the plan stays — its capacity carries 6 % slack and a frame that outgrows it
+    //  re-plans; a layer that is switched on or off changes far less than that in practice)
+    MULTI_ENTER();
+    EACH_KID(forma_hip_set_geoms(k, geoms, n_geoms));
+    return FORMA_OK;
+}
+int multi_set_styles(forma_hip_ctx* ctx, const uint32_t* style_offsets, size_t n_orders, const uint32_t* style_words, size_t n_words,
+                     const uint8_t* unchanged) {
+    MULTI_ENTER();
+    EACH_KID(forma_hip_set_styles(k, style_offsets, n_orders, style_words, n_words, unchanged));
+    return FORMA_OK;
+}
+int multi_set_images(forma_hip_ctx* ctx, const forma_image_t* images, size_t n_images, const uint16_t* texels, size_t n_texels) {
+    MULTI_ENTER();
+    EACH_KID(forma_hip_set_images(k, images, n_images, texels, n_texels));
+    return FORMA_OK;
+}
+int multi_trim(forma_hip_ctx* ctx) {
+    MULTI_ENTER();
+    EACH_KID(forma_hip_trim(k));
+    ctx->multi->planned = false;                           // (the plan's measurements live in the kids' buffers: plan again)
+    ctx->multi->last_valid = false;
+    return FORMA_OK;
+}
+
+int multi_cache_clear(forma_hip_ctx* ctx, int cache_id) {
+    MULTI_ENTER();
+    EACH_KID(forma_hip_cache_clear(k, cache_id));
+    return FORMA_OK;
+}
+
+int multi_render(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t height, size_t stride_bytes, const uint8_t channels[4],
+                 const float clear_color[4], const forma_rect_t* crop_or_null, int cache_id, forma_timings_t* timings) {
+    DeviceGuard guard;
+    MultiState* M = ctx->multi;
+    if (cache_id >= 0) M->cache_used[cache_id] = true;
+    FrameJob want;
+    want.dst = dst; want.width = width; want.height = height; want.stride = stride_bytes;
+    memcpy(want.channels, channels, 4); memcpy(want.clear, clear_color, 16);
+    want.has_crop = crop_or_null != nullptr; if (crop_or_null) want.crop = *crop_or_null;
+    want.cache_id = cache_id; want.timings = timings != nullptr;
+    // Frames in flight: a device-resident frame without a cache is ENQUEUED on the next frame slot of every device and this
+    // call returns; it is verified when the slot comes round again or when any call needs its result.  Everything else keeps
+    // the synchronous contract of the reference: `dst` is fully written when the call returns.
+    if (M->F > 1 && !dst && cache_id < 0 && !timings) {
+        const int s = (int)(M->next_slot % (unsigned)M->F);
+        int rc;
+        if (M->slot_pending[s] || !M->planned || M->plan_w != width || M->plan_h != height) {
+            // the slot still owes a frame — or a plan has to be made, which re-sizes every slot's exchange buffers: settle
+            // (a settle that has to re-plan settles everybody; the common case is one SETTLE job on this slot)
+            bool simple = M->slot_pending[s] && M->planned && M->plan_w == width && M->plan_h == height;
+            if (simple) {
+                M->slot_pending[s] = false;
+                M->job = M->slot_job[s];
+                M->job.mode = FrameJob::SETTLE; M->job.slot = s;
+                bool overflow = false;
+                rc = run_job(ctx, &overflow);
+                if (rc == FORMA_E_CAPACITY && overflow) {                  // void under this plan: everybody settles, then it runs again
+                    if ((rc = drain_slots(ctx))) return rc;
+                    M->planned = false;
+                    FrameJob again = M->slot_job[s];
+                    again.slot = s; again.dst = nullptr; again.cache_id = -1; again.timings = false;
+                    if ((rc = full_frame(ctx, again, nullptr))) return rc;
+                } else if (rc) return rc;
+            } else if ((rc = drain_slots(ctx))) return rc;
+        }
+        M->next_slot++;
+        want.slot = s;
+        if (!M->planned || M->plan_w != width || M->plan_h != height) {    // first frame of a plan: whole and synchronous
+            return full_frame(ctx, want, nullptr);
+        }
+        M->job = want;
+        M->job.mode = FrameJob::DEFER;
+        set_band_crops(M, width, height, crop_or_null);
+        bool overflow = false;
+        rc = run_job(ctx, &overflow);
+        if (rc == FORMA_E_CAPACITY && overflow) {                          // (a slot without predictions ran synchronously and overflowed)
+            for (int g = 0; g < M->G; g++) slot_ctx(M, g, s)->xpending = false;
+            if ((rc = drain_slots(ctx))) return rc;
+            M->planned = false;
+            return full_frame(ctx, want, nullptr);
+        }
+        if (rc) { for (int g = 0; g < M->G; g++) slot_ctx(M, g, s)->xpending = false; return rc; }
+        M->slot_job[s] = want;
+        for (int g = 0; g <= M->G; g++) M->slot_edges[s][g] = M->edges[g];
+        M->slot_pending[s] = true;
+        M->last_valid = true; M->last_w = width; M->last_h = height; M->last_slot = s;
+        return FORMA_OK;
+    }
+    { const int rc = drain_slots(ctx); if (rc) return rc; }
+    want.slot = 0;
+    return full_frame(ctx, want, timings);
+}
+
 int multi_read_segments(forma_hip_ctx* ctx, int which, uint64_t* out, size_t capacity, size_t* out_n) {
+    MULTI_ENTER();
     MultiState* M = ctx->multi;
     *out_n = 0;
     if (which != 1) return MFAIL(FORMA_E_STATE, "a multi-device context holds no single unsorted stream (which = 1: the sorted stream of the painted rows)");
     if (!M->last_valid) return MFAIL(FORMA_E_STATE, "no frame rendered yet");
+    const int s = M->last_slot;
     size_t total = 0;
-    for (int g = 0; g < M->G; g++) total += M->kid[g]->n_seg;
+    for (int g = 0; g < M->G; g++) total += slot_ctx(M, g, s)->n_seg;
     *out_n = total;
     if (total > capacity) return MFAIL(FORMA_E_CAPACITY, "segment capacity too small");
     if (total == 0) return FORMA_OK;
@@ -524,25 +753,30 @@ int multi_read_segments(forma_hip_ctx* ctx, int which, uint64_t* out, size_t cap
     size_t at = 0;
     for (int g = 0; g < M->G; g++) {                      // bands ascend in tile_y, the most significant key field
         size_t n = 0;
-        const int rc = forma_hip_read_segments(M->kid[g], 1, out + at, capacity - at, &n);
-        if (rc) { copy_err(ctx, M->kid[g]); return rc; }
+        forma_hip_ctx* k = slot_ctx(M, g, s);
+        const int rc = fd_read_sorted(k, out + at, capacity - at, &n);
+        if (rc) { copy_err(ctx, k); return rc; }
         at += n;
     }
     return FORMA_OK;
 }
 
 int multi_read_image(forma_hip_ctx* ctx, uint8_t* dst, size_t stride_bytes) {
+    MULTI_ENTER();
     MultiState* M = ctx->multi;
     if (!M->last_valid) return MFAIL(FORMA_E_STATE, "no image on the device");
     if ((size_t)M->last_w * 4 > stride_bytes) return MFAIL(FORMA_E_ARG, "width exceeds width stride");
+    const int s = M->last_slot;
     for (int g = 0; g < M->G; g++) {
-        const int rc = fd_copy_image_rows(M->kid[g], dst, stride_bytes, M->edges[g] * 16, std::min(M->edges[g + 1] * 16, M->last_h));
-        if (rc) { copy_err(ctx, M->kid[g]); return rc; }
+        forma_hip_ctx* k = slot_ctx(M, g, s);
+        const int rc = fd_copy_image_rows(k, dst, stride_bytes, M->slot_edges[s][g] * 16, std::min(M->slot_edges[s][g + 1] * 16, M->last_h));
+        if (rc) { copy_err(ctx, k); return rc; }
     }
     return FORMA_OK;
 }
 
 int multi_tiles_written(forma_hip_ctx* ctx, uint8_t* flags, size_t n_tiles) {
+    MULTI_ENTER();
     MultiState* M = ctx->multi;
     if (!M->last_valid) return MFAIL(FORMA_E_STATE, "no frame rendered yet");
     const uint32_t tiles_w = (M->last_w + 15) / 16, tiles_h = (M->last_h + 15) / 16;
@@ -550,11 +784,14 @@ int multi_tiles_written(forma_hip_ctx* ctx, uint8_t* flags, size_t n_tiles) {
     if (n_tiles < T) return MFAIL(FORMA_E_CAPACITY, "tile flag capacity too small");
     memset(flags, 0, n_tiles);
     std::vector<uint8_t> tmp(T);
+    const int s = M->last_slot;
     for (int g = 0; g < M->G; g++) {
-        if (M->edges[g] >= M->edges[g + 1]) continue;
-        const int rc = forma_hip_tiles_written(M->kid[g], tmp.data(), T);
-        if (rc) { copy_err(ctx, M->kid[g]); return rc; }
-        for (uint32_t ty = M->edges[g]; ty < M->edges[g + 1] && ty < tiles_h; ty++)
+        const uint32_t e0 = M->slot_edges[s][g], e1 = M->slot_edges[s][g + 1];
+        if (e0 >= e1) continue;
+        forma_hip_ctx* k = slot_ctx(M, g, s);
+        const int rc = fd_tiles_written(k, tmp.data(), T);
+        if (rc) { copy_err(ctx, k); return rc; }
+        for (uint32_t ty = e0; ty < e1 && ty < tiles_h; ty++)
             memcpy(flags + (size_t)ty * tiles_w, tmp.data() + (size_t)ty * tiles_w, tiles_w);
     }
     return FORMA_OK;

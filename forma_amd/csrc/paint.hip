@@ -13,6 +13,7 @@
 #include "common.h"
 #include "lookback.h"
 #include "radix_rank.h"
+#include "debug.h"
 
 // ================================================================================================
 // helpers
@@ -59,24 +60,33 @@ __device__ __forceinline__ bool cover_full(const uint32_t* c, bool even_odd) {  
 
 // ================================================================================================
 // runs: maximal runs of equal 44-bit key (tile_y, tile_x, layer) in the sorted stream, found in ONE
-// pass (chained scan with look-back for the run index).  Per run: record {first segment, count, layer,
-// tile}, the wrapping i8 cover sum per pixel row (what LayerWorkbench::cover_carry accumulates), and
-// the (tile_y, layer | run) key the carry scan is ordered by.
+// read of the stream.  Per run: record {first segment, count, layer, tile}, the wrapping i8 cover sum per
+// pixel row (what LayerWorkbench::cover_carry accumulates), the (tile_y, layer | run) key the global run
+// sort is ordered by and a 32-bit digest for the in-LDS one.
 //
-// A workgroup owns RN_TILE consecutive segments.  Key changes ("boundaries") are numbered with wavefront
-// ballots; segment i belongs to slot = number of boundaries at or before i (slot 0 = the run that was
-// already open when the tile began).  Every segment then does ONE LDS atomic add of its cover into
-// bins[slot][local_y]; the thread that owns a run's first segment packs the 16 bins to 16 x i8 and writes
-// the record.  A run that leaves the tile is flagged RUN_OPEN and completed by the consumer from the
-// following tiles' slot-0 sums (BlkEdge) — no workgroup ever waits for a later one.
+// A wavefront owns RW_CHUNK = 512 consecutive segments, lane l the 8 consecutive segments [8 l, 8 l + 8), and
+// works in its own slice of LDS with no workgroup barrier in its loop:
+//   * key changes ("breaks") are numbered along the wave (one DPP scan of the lanes' break counts): segment i
+//     belongs to slot = number of breaks at or before i; slot 0 is the run an earlier chunk opened;
+//   * every segment does ONE ds_add of its cover into bins[slot][local_y] of the wave's slice; the lane that
+//     owns a break parks the run's start next to the bins;
+//   * then one lane per slot packs the 16 bins to 16 x i8 and writes the record — all runs of the chunk
+//     in one full-width step, whatever their length;
+//   * slot 0 goes to the chunk's BlkEdge, and a run still open at the end of a full chunk is flagged RUN_OPEN:
+//     the consumer (k_carry_rows) completes it from the following chunks' edges — no wave waits for a later one.
+// A chunk with more than RW_SLOTS runs sweeps again.
+//
+// Runs are numbered DENSELY in stream order (the painters read a tile's runs as consecutive records, the carry
+// pre-pass a tile row's as one range): k_runs_count reads the stream once to count the paintable run heads per chunk, every
+// workgroup of k_runs_wave sums the counts in front of it.  (Round 4 built the single-pass form — every workgroup publishes
+// its head count right after the break walk and looks back through its predecessors' status words — and measured it: 118 us
+// against 22 + 51 on the 4K scene.  A workgroup lives ~15 us and 2048 of them are resident: the window of predecessors that
+// have published an aggregate but no prefix grows until the walk is the kernel.  The chain needs few, long-lived tiles —
+// the radix sort's 840 x 16384 keys — not 6720 short ones.)
 // ================================================================================================
-#define RN_THREADS 512
-#define RN_IPT     4
-#define RN_TILE    (RN_THREADS * RN_IPT)
-#define RN_WAVES   (RN_THREADS / 64)
-#define RN_SLOTS   256                  // LDS accumulator slots per sweep (tiles with more runs sweep again)
+#define RN_TILE    2048                 // segments per workgroup of the run kernel (4 waves x RW_CHUNK)
 #define RN_STRIDE  17                   // words per slot: 16 bins + 1 pad (bank spread)
-#define RUN_OPEN   0x80000000u          // seg_count flag: the run continues past its workgroup's tile
+#define RUN_OPEN   0x80000000u          // seg_count flag: the run continues past its wave's chunk
 #define RN_ROWS    64                   // tile rows a workgroup aggregates in LDS before touching row_count[]
 
 __device__ __forceinline__ uint4 pack_bins(const int* b) {
@@ -95,6 +105,36 @@ __device__ __forceinline__ uint2 run_style_words(const RunStyle& rs, uint32_t la
     const uint32_t unch = (rs.unchanged && layer < rs.n_orders && rs.unchanged[layer]) ? 0x80000000u : 0u;
     return make_uint2(layer | (sfl << 21), tile | unch);
 }
+
+#define RW_SEGS    8
+#define RW_CHUNK   (64 * RW_SEGS)
+#define RW_WAVES   4
+#define RW_THREADS (64 * RW_WAVES)
+#define RW_SLOTS   64                   // runs per sweep = lanes
+static_assert(RW_WAVES * RW_CHUNK == RN_TILE, "a workgroup of the run kernel owns RN_TILE segments");
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v) {            // lane l gets lane l - 1's value, lane 0 gets 0
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true);
+}
+__device__ __forceinline__ void wave_lds_fence() {                      // LDS operations of one wave retire in order: compiler fence
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct RunWaveLds {                       // one wave's slice
+    int      bins[RW_SLOTS * RN_STRIDE];  // [slot][local_y], 17-word rows (bank spread)
+    uint32_t start[RW_SLOTS + 2];         // chunk-local index of the first segment of the sweep's slots (+ the end of the last one)
+};
 
 // pass A: paintable run heads per tile (the run index of a tile's first head is the exclusive scan of these)
 #define RC_THREADS 256
@@ -193,203 +233,6 @@ __global__ __launch_bounds__(RC_THREADS) void k_runs_count(const uint64_t* __res
         __syncthreads();
     }
 }
-
-// pass B: one workgroup per tile, no inter-workgroup dependency
-__global__ __launch_bounds__(RN_THREADS, 8) void k_runs(const uint64_t* __restrict__ sorted, DevCount nc, uint32_t tiles_w,
-                                                        uint32_t tiles_h, TileRecord* __restrict__ records, uint32_t rec_cap,
-                                                        uint64_t* __restrict__ run_keys,
-                                                        uint32_t* __restrict__ tile_first_run,
-                                                        BlkEdge* __restrict__ blk_edge, uint32_t* __restrict__ row_count,
-                                                        const uint32_t* __restrict__ run_counts, int counts_scanned,
-                                                        FrameInfo* __restrict__ info, RunStyle rs) {
-    __shared__ uint64_t s_seg[RN_TILE + 1];                   // [0] = element before the tile, tile at [1 + i]
-    __shared__ int s_bins[RN_SLOTS * RN_STRIDE];
-    __shared__ uint16_t s_start[RN_TILE + 2];                 // s_start[slot] = tile-local index of the slot's first segment
-    __shared__ uint32_t s_cb[RN_IPT * RN_WAVES], s_cv[RN_WAVES];            // boundaries per (row, wave); heads per wave
-    __shared__ uint32_t s_rows[RN_ROWS];
-    __shared__ uint32_t s_row0, s_R, s_jb[RN_WAVES];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t n = dev_count(nc);
-    if (blockIdx.x * RN_TILE >= n) return;                              // the grid was sized for the bound
-    // run index of this tile's first head = sum of the head counts of the tiles before it.  The count array is a few
-    // KB and L2-resident, so every workgroup sums it itself (saves a scan launch); big frames get it pre-scanned.
-    uint32_t run_base0 = 0;
-    if (counts_scanned) run_base0 = run_counts[blockIdx.x];
-    else {
-        uint32_t acc = 0;
-        for (uint32_t i = tid; i < blockIdx.x; i += RN_THREADS) acc += run_counts[i];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
-        if (lane == 0) s_jb[w] = acc;
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < RN_WAVES; q++) run_base0 += s_jb[q];
-        const uint32_t ntl = (n + RN_TILE - 1) / RN_TILE;
-        if (blockIdx.x == ntl - 1 && tid == 0) info->n_runs = run_base0 + run_counts[blockIdx.x];
-    }
-    {
-        const uint32_t tile = blockIdx.x;
-        if (tid == 0) s_row0 = 0xFFFFFFFFu;
-        if (tid < RN_ROWS) s_rows[tid] = 0;
-        const uint32_t base = tile * RN_TILE;
-        const uint32_t tile_n = min((uint32_t)RN_TILE, n - base);
-#pragma unroll
-        for (int r = 0; r < RN_IPT; r++) {
-            const uint32_t i = r * RN_THREADS + tid;
-            s_seg[1 + i] = i < tile_n ? sorted[base + i] : 0ull;
-        }
-        if (tid == 0) s_seg[0] = base > 0 ? sorted[base - 1] : 0ull;
-        __syncthreads();
-        // ---- phase 1: boundaries numbered in segment order; count of paintable heads ------------------------------
-        uint32_t bmask = 0;                                  // bit r: my segment of row r is a boundary
-        uint32_t slot[RN_IPT];
-        uint32_t nval = 0;                                   // wave-uniform: paintable heads seen by this wave
-#pragma unroll
-        for (int r = 0; r < RN_IPT; r++) {
-            const uint32_t i = r * RN_THREADS + tid;
-            const uint64_t v = s_seg[1 + i], pv = s_seg[i];
-            const bool bnd = i < tile_n && ((((v ^ pv) >> SEG_KEY_SHIFT) != 0) || base + i == 0);
-            const bool val = bnd && seg_paintable(v, tiles_w, tiles_h);
-            const uint64_t bb = __ballot(bnd);
-            slot[r] = __builtin_amdgcn_mbcnt_hi((uint32_t)(bb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bb, 0u)) + (bnd ? 1u : 0u);
-            nval += (uint32_t)__popcll(__ballot(val));
-            if (bnd) bmask |= 1u << r;
-            if (val) atomicMin(&s_row0, (uint32_t)(v >> 53) - 1u);
-            if (lane == 0) s_cb[r * RN_WAVES + w] = (uint32_t)__popcll(bb);
-        }
-        if (lane == 0) s_cv[w] = nval;
-        __syncthreads();
-        if (w == 0) {                                         // exclusive scan of the 32 (row, wave) boundary counts
-            const uint32_t cb = lane < RN_IPT * RN_WAVES ? s_cb[lane] : 0u;
-            uint32_t ib = cb;
-#pragma unroll
-            for (int d = 1; d < 32; d <<= 1) { const uint32_t tb = __shfl_up(ib, d, 64); if (lane >= d) ib += tb; }
-            if (lane < RN_IPT * RN_WAVES) s_cb[lane] = ib - cb;
-            const uint32_t R = __shfl(ib, RN_IPT * RN_WAVES - 1, 64);
-            if (lane == 0) s_R = R;
-        }
-        __syncthreads();
-        const uint32_t R = s_R;
-#pragma unroll
-        for (int r = 0; r < RN_IPT; r++) {
-            slot[r] += s_cb[r * RN_WAVES + w];
-            if (bmask & (1u << r)) s_start[slot[r]] = (uint16_t)(r * RN_THREADS + tid);
-        }
-        if (tid == 0) { s_start[R + 1] = (uint16_t)tile_n; s_start[0] = 0; }
-        const uint32_t row0 = s_row0;
-        uint32_t jbase = run_base0;                          // run index of the next paintable head (uniform)
-        // ---- phase 2 + 3, RN_SLOTS slots per sweep -----------------------------------------------------------------
-        for (uint32_t s0 = 0; s0 <= R; s0 += RN_SLOTS) {
-            for (int k = tid; k < RN_SLOTS * RN_STRIDE; k += RN_THREADS) s_bins[k] = 0;
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < RN_IPT; r++) {
-                const uint32_t i = r * RN_THREADS + tid;
-                const uint32_t sl = slot[r] - s0;
-                if (i < tile_n && sl < RN_SLOTS) {
-                    const uint64_t v = s_seg[1 + i];
-                    atomicAdd(&s_bins[sl * RN_STRIDE + seg_ly(v)], seg_cover(v));
-                }
-            }
-            __syncthreads();
-            // one thread per slot: slot s0 + tid (slot 0 = the run that was open when the tile began)
-            const uint32_t sg = s0 + tid;
-            uint32_t i = 0; uint64_t v = 0, pv = 0; bool val = false;
-            if (tid < RN_SLOTS && sg >= 1 && sg <= R) {
-                i = s_start[sg]; v = s_seg[1 + i]; pv = s_seg[i];
-                val = seg_paintable(v, tiles_w, tiles_h);
-            }
-            const uint64_t bv = __ballot(val);
-            if (lane == 0) s_cv[w] = (uint32_t)__popcll(bv);
-            __syncthreads();
-            uint32_t jw = jbase, jt = 0;
-#pragma unroll
-            for (int q = 0; q < RN_WAVES; q++) { const uint32_t t = s_cv[q]; if (q < w) jw += t; jt += t; }
-            if (val) {
-                const uint32_t j = jw + __builtin_amdgcn_mbcnt_hi((uint32_t)(bv >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bv, 0u));
-                int b[16];
-#pragma unroll
-                for (int k = 0; k < 16; k++) b[k] = s_bins[tid * RN_STRIDE + k];
-                const uint32_t cnt = (uint32_t)s_start[sg + 1] - i;
-                const uint32_t open = (sg == R && tile_n == RN_TILE) ? RUN_OPEN : 0u;
-                const uint32_t tyb = (uint32_t)(v >> 53), txb = (uint32_t)(v >> 41) & 0xFFFu, layer = seg_layer(v);
-                TileRecord rec;
-                const uint4 own = pack_bins(b);                                  // the run's own cover sum; k_carry_rows turns it
-                rec.cover[0] = own.x; rec.cover[1] = own.y; rec.cover[2] = own.z; rec.cover[3] = own.w;   // into the carry-in
-                const uint2 sw = run_style_words(rs, layer, (uint32_t)(v >> 41));
-                rec.seg_start = base + i; rec.seg_count = cnt | open; rec.layer = sw.x; rec.tile = sw.y;
-                if (j < rec_cap) {                                  // asynchronous frames provision for a predicted run count
-                    records[j] = rec;
-                    run_keys[j] = ((uint64_t)tyb << 53) | ((uint64_t)layer << 32) | j;
-                    rs.run_lt[j] = ((layer & 0xFFFFu) << 16) | (open ? RUN_LT_OPEN : 0u) | txb;
-                }
-                if (txb >= 1u && ((uint32_t)(pv >> 41) != (uint32_t)(v >> 41) || base + i == 0))
-                    tile_first_run[(tyb - 1u) * tiles_w + (txb - 1u)] = j + 1u;        // 0 = the tile has no run
-                const uint32_t rr = (tyb - 1u) - row0;
-                if (rr < RN_ROWS) atomicAdd(&s_rows[rr], 1u); else atomicAdd(&row_count[tyb - 1u], 1u);
-            }
-            jbase += jt;
-            if (sg == 0 && tid == 0) {                        // slot 0: what this tile adds to a run that began before it
-                int b[16];
-#pragma unroll
-                for (int k = 0; k < 16; k++) b[k] = s_bins[k];
-                const uint4 c = pack_bins(b);
-                BlkEdge e;
-                e.cov[0] = c.x; e.cov[1] = c.y; e.cov[2] = c.z; e.cov[3] = c.w;
-                e.cnt = R ? (uint32_t)s_start[1] : tile_n; e.has_boundary = R ? 1u : 0u; e.pad[0] = e.pad[1] = 0;
-                blk_edge[tile] = e;
-            }
-            __syncthreads();
-        }
-        if (tid < RN_ROWS && s_rows[tid]) atomicAdd(&row_count[row0 + tid], s_rows[tid]);
-    }
-}
-
-
-// ================================================================================================
-// runs, wave-autonomous form (the frame path).  A wavefront owns RW_CHUNK = 512 consecutive segments of the
-// sorted stream, lane l the 8 consecutive segments [8 l, 8 l + 8), and works in its own slice of LDS with no
-// workgroup barrier in the loop:
-//   * key changes ("breaks") are numbered along the wave (one DPP scan of the lanes' break counts): segment i
-//     belongs to slot = number of breaks at or before i; slot 0 is the run an earlier chunk opened;
-//   * every segment does ONE ds_add of its cover into bins[slot][local_y] of the wave's slice; the lane that
-//     owns a break parks the run's key, start and flags next to the bins;
-//   * then one lane per slot packs the 16 bins to 16 x i8 and writes the record — all runs of the chunk
-//     in one full-width step, whatever their length;
-//   * slot 0 goes to the chunk's BlkEdge, and a run still open at the end of a full chunk is flagged RUN_OPEN:
-//     the consumer (k_carry_rows) completes it from the following chunks' edges, as for the legacy kernel.
-// A chunk with more than RW_SLOTS runs sweeps again.  Run numbering stays dense: a workgroup is 4 waves = one
-// 2048-segment tile of k_runs_count's head counts; the only barrier orders the waves' head totals.
-// ================================================================================================
-#define RW_SEGS    8
-#define RW_CHUNK   (64 * RW_SEGS)
-#define RW_WAVES   4
-#define RW_THREADS (64 * RW_WAVES)
-#define RW_SLOTS   64                   // runs per sweep = lanes
-static_assert(RW_WAVES * RW_CHUNK == RN_TILE, "k_runs_count counts heads per RN_TILE segments");
-
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_shr1(uint32_t v) {            // lane l gets lane l - 1's value, lane 0 gets 0
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true);
-}
-__device__ __forceinline__ void wave_lds_fence() {                      // LDS operations of one wave retire in order: compiler fence
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-struct RunWaveLds {                       // one wave's slice
-    int      bins[RW_SLOTS * RN_STRIDE];  // [slot][local_y], 17-word rows (bank spread)
-    uint32_t start[RW_SLOTS + 2];         // chunk-local index of the first segment of the sweep's slots (+ the end of the last one)
-};
 
 __global__ __launch_bounds__(RW_THREADS) void k_runs_wave(const uint64_t* __restrict__ sorted, DevCount nc, uint32_t tiles_w,
                                                           uint32_t tiles_h, TileRecord* __restrict__ records, uint32_t rec_cap,
@@ -564,17 +407,18 @@ __global__ __launch_bounds__(RW_THREADS) void k_runs_wave(const uint64_t* __rest
 }
 
 size_t runs_scratch_words(size_t n) { return 5 * ((n + RN_TILE - 1) / RN_TILE + 2) + 16; }   // [tile counts | chunk counts]
-size_t runs_blocks(size_t n) { return (n + RW_CHUNK - 1) / RW_CHUNK + 4; }      // BlkEdge entries: one per wave chunk (legacy kernel: one per RN_TILE)
+size_t runs_blocks(size_t n) { return (n + RW_CHUNK - 1) / RW_CHUNK + 4; }      // BlkEdge entries: one per wave chunk
 
 void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t tiles_w, uint32_t tiles_h, TileRecord* records,
                  uint32_t rec_cap, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge, uint32_t* row_tab,
-                 uint32_t* scratch, FrameInfo* info, bool verify_plan, uint64_t spec_live44, bool spec_layer_sorted, bool legacy,
-                 PendingMasks pm, RunStyle rs) {
+                 uint32_t* scratch, FrameInfo* info, bool verify_plan, uint64_t spec_live44, bool spec_layer_sorted,
+                 PendingMasks pm, RunStyle rs, bool tables_are_zero) {
     // per-frame tile tables: [row_count | row_span_lo | row_span_cnt | painter overflow counters (2) | first-run table] are
-    // contiguous (api.cpp lays them out so) and zeroed by k_runs_count; 0 in the first-run table = the tile has no run
-    const uint32_t zero_words = row_tab_zero_words(tiles_w, tiles_h);
+    // contiguous (api.cpp lays them out so) and start from zero — cleared by k_runs_count, unless an earlier kernel of the frame
+    // already did (api.cpp folds that into the frame's first kernel); 0 in the first-run table = the tile has no run
+    const uint32_t zero_words = tables_are_zero ? 0u : row_tab_zero_words(tiles_w, tiles_h);
     if (nc.bound == 0) {
-        (void)hipMemsetAsync(row_tab, 0, (size_t)zero_words * 4, s);
+        if (zero_words) (void)hipMemsetAsync(row_tab, 0, (size_t)zero_words * 4, s);
         (void)hipMemsetAsync(&info->n_runs, 0, 4, s);
         return;
     }
@@ -584,17 +428,13 @@ void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t ti
     uint32_t* chunk_counts = scratch + ntiles + 8;                      // 4 per tile (+ slack for the last wave's second half)
     hipLaunchKernelGGL(k_runs_count, dim3(cgrid), dim3(RC_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, scratch, chunk_counts, row_tab,
                        zero_words, info, spec_live44, flags, pm);
-    const int scanned = (ntiles > 16384 || getenv("FORMA_HIP_SCAN_COUNTS")) ? 1 : 0;
+    const int scanned = ntiles > 16384 ? 1 : 0;
     if (scanned) launch_scan_small_u32(s, scratch, nc, RN_TILE, &info->n_runs);   // exclusive, in place; total -> n_runs
-    if (legacy)
-        hipLaunchKernelGGL(k_runs, dim3(ntiles), dim3(RN_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, records, rec_cap, run_keys,
-                           tile_first_run, blk_edge, row_tab, (const uint32_t*)scratch, scanned, info, rs);
-    else
-        hipLaunchKernelGGL(k_runs_wave, dim3(ntiles), dim3(RW_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, records, rec_cap,
-                           run_keys, tile_first_run, blk_edge, row_tab, (const uint32_t*)scratch, scanned,
-                           (const uint32_t*)chunk_counts, info, rs);
+    hipLaunchKernelGGL(k_runs_wave, dim3(ntiles), dim3(RW_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, records, rec_cap,
+                       run_keys, tile_first_run, blk_edge, row_tab, (const uint32_t*)scratch, scanned,
+                       (const uint32_t*)chunk_counts, info, rs);
 }
-uint32_t runs_edge_segments(bool legacy) { return legacy ? RN_TILE : RW_CHUNK; }
+uint32_t runs_edge_segments() { return RW_CHUNK; }
 
 // ================================================================================================
 // carry pre-pass: one 1024-lane workgroup per tile row.  The row's runs are brought into (layer, tile_x) order (LOCAL:
@@ -2581,8 +2421,9 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
     const uint32_t T = p.tiles_w * p.tiles_h;
     if (T == 0 || p.crop_y1 <= p.crop_y0) return;
     const uint32_t per = ((p.crop_y1 - p.crop_y0) * p.tiles_w + 7) / 8;
-    static const bool no_simple = getenv("FORMA_HIP_NO_SIMPLE_PAINT") != nullptr;      // (A/B switches for tools/)
-    static const bool force_simple = getenv("FORMA_HIP_FORCE_SIMPLE_PAINT") != nullptr;  // (timing experiments only: wrong pixels on other scenes)
+    static const ForMaDebug dbg = forma_debug_parse();               // FORMA_HIP_DEBUG (debug.h), process-wide for these two
+    static const bool no_simple = dbg.no_simple_paint;               // (A/B switches for tools/)
+    static const bool force_simple = dbg.force_simple_paint;         // (timing experiments only: wrong pixels on other scenes)
     const bool simple = (p.scene_simple && !no_simple) || force_simple, one = p.n_slices == 1u;
 #define PW_LAUNCH(S_, O_) hipLaunchKernelGGL((k_paint_wave<S_, O_>), dim3(per * 8), dim3(64), 0, s, p, sorted, records, n_runs, tile_first_run, \
                                              row_span_lo, row_span_cnt, span_key, span_cov, layer_col, style_offsets, style_words, images, \
@@ -2659,3 +2500,27 @@ void launch_pack_written(hipStream_t s, const uint8_t* written, uint32_t tiles_w
     hipLaunchKernelGGL(k_pack_written, dim3(std::max(1u, std::min<uint32_t>(std::min(n, max_pack), 4096u))), dim3(256), 0, s, (const uint32_t*)list,
                        (const uint32_t*)count, max_pack, tiles_w, (const uint32_t*)image, width, height, packed);
 }
+
+// ================================================================================================
+// the end of a read-back-free frame (launch_frame_tail, common.h)
+// ================================================================================================
+__global__ __launch_bounds__(64) void k_frame_tail(FrameInfo* __restrict__ info, FrameInfo* __restrict__ host_info,
+                                                   uint32_t* __restrict__ host_count) {
+    constexpr int W = (int)(sizeof(FrameInfo) / 4);
+    static_assert(W <= 64, "FrameInfo fits one wave");
+    const int t = threadIdx.x;
+    uint32_t* src = reinterpret_cast<uint32_t*>(info);
+    if (t < W) {
+        const uint32_t v = src[t];
+        // pinned host memory: system-scope stores, visible to the host once the stream has drained
+        if (host_info) __hip_atomic_store(reinterpret_cast<uint32_t*>(host_info) + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (host_count && t == (int)(offsetof(FrameInfo, n_segments) / 4)) __hip_atomic_store(host_count, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // the pristine FrameInfo: zeros, and all-ones where the keys' AND accumulates (forma_hip_create's template)
+        const bool ones = t == (int)(offsetof(FrameInfo, key_and) / 4) || t == (int)(offsetof(FrameInfo, key_and_hi) / 4);
+        src[t] = ones ? 0xFFFFFFFFu : 0u;
+    }
+}
+void launch_frame_tail(hipStream_t s, FrameInfo* info, FrameInfo* host_info, uint32_t* host_count) {
+    hipLaunchKernelGGL(k_frame_tail, dim3(1), dim3(64), 0, s, info, host_info, host_count);
+}
+

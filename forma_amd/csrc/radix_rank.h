@@ -61,6 +61,15 @@ __device__ __forceinline__ void match_any<8>(uint32_t dg, uint32_t& mlo, uint32_
         : "v"(dg)
         : "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99");
 }
+// nine bits: the hand-scheduled eight, then the ninth like the generic loop
+template <>
+__device__ __forceinline__ void match_any<9>(uint32_t dg, uint32_t& mlo, uint32_t& mhi) {
+    match_any<8>(dg, mlo, mhi);
+    const uint32_t nb = (uint32_t)(-(int32_t)((dg >> 8) & 1u));
+    const uint64_t bal = __ballot(nb != 0u);
+    mlo &= ~((uint32_t)bal ^ nb);
+    mhi &= ~((uint32_t)(bal >> 32) ^ nb);
+}
 __device__ __forceinline__ uint32_t lanes_below(uint32_t mlo, uint32_t mhi) {          // popcount(m & lanemask_lt)
     return __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
 }

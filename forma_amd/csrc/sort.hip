@@ -23,6 +23,7 @@
 #include "lookback.h"
 #include "radix_rank.h"
 #include <string.h>
+#include <hip/hip_ext.h>
 
 #ifndef OS_THREADS
 #define OS_THREADS 1024
@@ -41,6 +42,7 @@
 // (consecutive keys of a lane mostly share their tile digits) keeps the LDS atomics rare.
 // ------------------------------------------------------------------------------------------------
 #define HS_COPIES  16
+#define SORT_BINS  512                              // histogram words per pass (a pass has 16, 256 or 512 bins)
 #define HS_THREADS 256
 #define HS_KPT     16
 #define HS_TILE    (HS_THREADS * HS_KPT)
@@ -84,13 +86,13 @@ __global__ __launch_bounds__(HS_THREADS) void k_sort_hist(const uint64_t* __rest
     ChunkMap M;
     if (chunked) {
         M = load_chunk_map(C, nc.bound);
-        if (blockIdx.x == 0 && threadIdx.x == 0) { info->n_segments = M.total; if (M.over) info->exchange_overflow = 1u; }
+        if (blockIdx.x == 0 && threadIdx.x == 0) { info->n_segments = M.total; if (M.over) { info->exchange_overflow = 1u; info->plan_bad = 1u; } }
     }
     const uint32_t n = chunked ? M.total : dev_count(nc);
     uint32_t k_or = 0, k_or_hi = 0, k_and = 0xFFFFFFFFu, k_and_hi = 0xFFFFFFFFu, unsorted = 0;
-    __shared__ uint32_t lh[SORT_MAX_PASSES * 256];
+    __shared__ uint32_t lh[SORT_MAX_PASSES * SORT_BINS];
     const int P = plan.n_passes;
-    for (int i = threadIdx.x; i < P * 256; i += HS_THREADS) lh[i] = 0;
+    for (int i = threadIdx.x; i < P * SORT_BINS; i += HS_THREADS) lh[i] = 0;
     __syncthreads();
     const uint32_t ntiles = (n + HS_TILE - 1) / HS_TILE;
     for (uint32_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(HS_THREADS) void k_sort_hist(const uint64_t* __rest
                 if (head && valid) {
                     const uint64_t above = lane == 63 ? 0ull : (heads >> (lane + 1));
                     const uint32_t len = above ? (uint32_t)__builtin_ctzll(above) + 1u : (uint32_t)(64 - lane);
-                    atomicAdd(&lh[p * 256 + d], len);
+                    atomicAdd(&lh[p * SORT_BINS + d], len);
                 }
             }
         }
@@ -148,8 +150,8 @@ __global__ __launch_bounds__(HS_THREADS) void k_sort_hist(const uint64_t* __rest
     // the flush is up to 256 x P global atomics per workgroup on the same few hundred words: HS_COPIES private copies (one
     // per workgroup residue class, i.e. per XCD under round-robin dispatch) cut the same-address queue by that factor;
     // k_onesweep adds the copies up when it scans the histogram
-    uint32_t* mine = hist + (size_t)(blockIdx.x % HS_COPIES) * (SORT_MAX_PASSES * 256);
-    for (int i = threadIdx.x; i < P * 256; i += HS_THREADS) {
+    uint32_t* mine = hist + (size_t)(blockIdx.x % HS_COPIES) * (SORT_MAX_PASSES * SORT_BINS);
+    for (int i = threadIdx.x; i < P * SORT_BINS; i += HS_THREADS) {
         uint32_t v = lh[i];
         if (v) atomicAdd(&mine[i], v);
     }
@@ -221,10 +223,55 @@ extern "C" int forma_hip_debug_sort_prof(unsigned long long* out16, int reset) {
 #define SP_STAMP(i) do { } while (0)
 #endif
 
-template <int BITS, bool CHUNKED>
+// The per-wave digit counters of a tile.  256 bins (and 16): one 32-bit word per (wave, digit).  512 bins: 16-bit halves, two
+// digits per word — a wave holds 1024 keys and a tile 16384, so neither a count nor a tile-local start overflows a half, and
+// the 16 KB footprint (next to the 128 KB of staged keys) is the same.  The ranking adds with a 32-bit LDS atomic on the word
+// that holds the digit's half; the totals / bases phase reads and writes the halves as 16-bit LDS accesses.
+template <int BITS> struct WaveCounters;
+template <int BITS> struct WaveCounters {
+    static constexpr int RADIX = 1 << BITS;
+    uint32_t c[OS_WAVES][RADIX];
+    __device__ __forceinline__ uint32_t add_and_read(int w, uint32_t dg, bool leader, uint32_t cnt) {
+        if (leader) atomicAdd(&c[w][dg], cnt);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    // compiler barrier: keep the read after the add
+        return c[w][dg];
+    }
+    __device__ __forceinline__ uint32_t get(int w, uint32_t dg) const { return c[w][dg]; }
+    __device__ __forceinline__ void set(int w, uint32_t dg, uint32_t v) { c[w][dg] = v; }
+    __device__ __forceinline__ void clear_wave(int w, int lane) {
+#pragma unroll
+        for (int i = lane; i < RADIX; i += 64) c[w][i] = 0;
+    }
+};
+template <> struct WaveCounters<9> {
+    static constexpr int RADIX = 512;
+    uint32_t c[OS_WAVES][RADIX / 2];
+    __device__ __forceinline__ uint32_t add_and_read(int w, uint32_t dg, bool leader, uint32_t cnt) {
+        const uint32_t sh = (dg & 1u) * 16u;
+        if (leader) atomicAdd(&c[w][dg >> 1], cnt << sh);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        return (c[w][dg >> 1] >> sh) & 0xFFFFu;
+    }
+    __device__ __forceinline__ uint32_t get(int w, uint32_t dg) const { return reinterpret_cast<const uint16_t*>(&c[w][0])[dg]; }
+    __device__ __forceinline__ void set(int w, uint32_t dg, uint32_t v) { reinterpret_cast<uint16_t*>(&c[w][0])[dg] = (uint16_t)v; }
+    __device__ __forceinline__ void clear_wave(int w, int lane) {
+#pragma unroll
+        for (int i = lane; i < RADIX / 2; i += 64) c[w][i] = 0;
+    }
+};
+
+// HI: the digit lies in the key's high word (shift >= 32: the tile_y / tile_x fields, i.e. every pass of a layer-sorted
+// frame) — one 32-bit bit-field extract instead of a 64-bit shift.
+template <bool HI>
+__device__ __forceinline__ uint32_t key_digit(uint64_t key, int shift, uint32_t dmask) {
+    if (HI) return ((uint32_t)(key >> 32) >> (shift - 32)) & dmask;
+    return (uint32_t)(key >> shift) & dmask;
+}
+
+template <int BITS, bool CHUNKED, bool HI>
 __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
                                                          DevCount nc, int shift, uint32_t dmask,
-                                                         const uint32_t* __restrict__ ghist /* this pass, 256 */,
+                                                         const uint32_t* __restrict__ ghist /* this pass, SORT_BINS per copy */,
                                                          uint32_t* __restrict__ status /* [ntiles][RADIX] */,
                                                          uint32_t* __restrict__ ticket, uint32_t* __restrict__ err,
                                                          ChunkedSrc C /* first pass of a chunked stream, else n_chunks = 0 */) {
@@ -234,20 +281,24 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
     ChunkMap M;
     if (chunked) M = load_chunk_map(C, nc.bound);
     __shared__ uint64_t staged[OS_TILE];
-    __shared__ uint32_t whist[OS_WAVES][RADIX];
+    __shared__ WaveCounters<BITS> whist;
     __shared__ uint32_t s_gdelta[RADIX];
     __shared__ uint32_t s_scan[16];
     __shared__ uint32_t s_tile;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t ntiles = (n + OS_TILE - 1) / OS_TILE;
 
+    // a wave clears its own counters: here once, then right after it has staged a tile's keys (nobody else reads a wave's
+    // row between the barrier in front of the staging and the one behind the look-back) — the tile loop has no clearing
+    // phase and one barrier less than it had
+    whist.clear_wave(w, lane);
     // global digit starts = exclusive scan of this pass's histogram (identical in every block)
     uint32_t gstart = 0;
     {
         uint32_t g = 0, dummy = 0;
         if (tid < RADIX) {
 #pragma unroll
-            for (int c = 0; c < HS_COPIES; c++) g += ghist[(size_t)c * (SORT_MAX_PASSES * 256) + tid];
+            for (int c = 0; c < HS_COPIES; c++) g += ghist[(size_t)c * (SORT_MAX_PASSES * SORT_BINS) + tid];
         }
         scan2_excl<RADIX>(g, dummy, s_scan);
         gstart = g;
@@ -256,19 +307,13 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
 #ifdef SORT_PROF
     unsigned long long sp_t = __builtin_readcyclecounter();
 #endif
-#ifndef OS_TICKET_LATE
     if (tid == 0) s_tile = atomicAdd(ticket, 1u);
-#endif
+    lds_barrier();
     while (true) {
         SP_STAMP(7);                                        // scatter + end barrier (and the prologue, once)
-#ifdef OS_TICKET_LATE
-        if (tid == 0) s_tile = atomicAdd(ticket, 1u);
-#endif
-        for (int i = tid; i < OS_WAVES * RADIX; i += OS_THREADS) (&whist[0][0])[i] = 0;
-        lds_barrier();
         const uint32_t tile = s_tile;
         if (tile >= ntiles) break;
-        SP_STAMP(0);                                        // ticket + clear + barrier
+        SP_STAMP(0);
 #ifdef SORT_PROF
         if (tid == 0) atomicAdd(&g_sort_prof[15], 1ull);
 #endif
@@ -291,16 +336,17 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
         // the counter back (LDS operations of one wave retire in order): rank = counter - class size + lanes below.
 #pragma unroll
         for (int j = 0; j < OS_KPT; j++) {
-            const uint32_t dg = (uint32_t)(keys[j] >> shift) & dmask;
+            const uint32_t dg = key_digit<HI>(keys[j], shift, dmask);
             // (peeling the few distinct digits of a row off leader by leader — readlane, compare, mbcnt per class — was
-            //  measured slower than this fixed 8-ballot form: 71 vs 61 us per pass, the dependent scalar chain does not pipeline)
+            //  measured slower than this fixed 8-ballot form: 71 vs 61 us per pass, the dependent scalar chain does not pipeline;
+            //  so was a run-structured rank — head lanes add their run length with a returning LDS atomic, the others fetch it
+            //  with ds_bpermute, rows where a digit owns two runs fall back to this form: ~25 VALU per row instead of ~47, and
+            //  64.4 against 62.2 us per pass — NOTES.md)
             uint32_t mlo, mhi;
             match_any<BITS>(dg, mlo, mhi);
             const uint32_t below = lanes_below(mlo, mhi);
             const uint32_t cnt = (uint32_t)__popc(mlo) + (uint32_t)__popc(mhi);
-            if (below == 0) atomicAdd(&whist[w][dg], cnt);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    // compiler barrier: keep the read after the add
-            const uint32_t after = whist[w][dg];
+            const uint32_t after = whist.add_and_read(w, dg, below == 0, cnt);
             const uint32_t r = after - cnt + below;
             if (j & 1) rnk[j >> 1] |= r << 16; else rnk[j >> 1] = r;
         }
@@ -310,7 +356,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
         uint32_t tot = 0, lbase = 0;
         if (tid < RADIX) {
 #pragma unroll
-            for (int i = 0; i < OS_WAVES; i++) tot += whist[i][tid];
+            for (int i = 0; i < OS_WAVES; i++) tot += whist.get(i, tid);
             if (tile > 0) lb_st32(&status[(size_t)tile * RADIX + tid], (LB_AGG << 30) | tot);
         }
         {
@@ -321,7 +367,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
         if (tid < RADIX) {
             uint32_t acc = lbase;
 #pragma unroll
-            for (int i = 0; i < OS_WAVES; i++) { uint32_t c = whist[i][tid]; whist[i][tid] = acc; acc += c; }
+            for (int i = 0; i < OS_WAVES; i++) { uint32_t c = whist.get(i, tid); whist.set(i, tid, acc); acc += c; }
         }
         lds_barrier();
         SP_STAMP(3);                                        // totals, scan, bases
@@ -329,9 +375,11 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
         //      and the staging of waves 4..7 overlaps the global round trips of the look-back lanes ---------------------
 #pragma unroll
         for (int j = 0; j < OS_KPT; j++) {
-            const uint32_t dg = (uint32_t)(keys[j] >> shift) & dmask;
-            staged[whist[w][dg] + ((rnk[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu)] = keys[j];
+            const uint32_t dg = key_digit<HI>(keys[j], shift, dmask);
+            staged[whist.get(w, dg) + ((rnk[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu)] = keys[j];
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // compiler barrier; this wave's LDS operations retire in order
+        whist.clear_wave(w, lane);
         SP_STAMP(4);                                        // staging (issue)
         // ---- look-back: one lane per digit walks its own chain of status words, OS_LBW predecessors per probe.
         //      (A one-at-a-time walk moves ~1 tile per L2 round trip, which is about the rate at which tiles retire:
@@ -367,10 +415,8 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
         }
         lds_barrier();
         SP_STAMP(5);                                        // look-back + barrier
-#ifndef OS_TICKET_LATE
-        // the next ticket's round trip (~1 us) runs under the scatter; every thread read s_tile four barriers ago
+        // the next ticket's round trip (~1 us) runs under the scatter; every thread read s_tile barriers ago
         if (tid == OS_THREADS - 1) s_tile = atomicAdd(ticket, 1u);
-#endif
         // ---- coalesced stores: every digit run leaves the CU as one contiguous piece --------------------------------
         const uint32_t nvalid = min((uint32_t)OS_TILE, n - bbase);
 #pragma unroll
@@ -378,7 +424,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
             uint32_t i = j * OS_THREADS + tid;
             if (i < nvalid) {
                 uint64_t key = staged[i];
-                uint32_t dg = (uint32_t)(key >> shift) & dmask;
+                uint32_t dg = key_digit<HI>(key, shift, dmask);
                 out[i + s_gdelta[dg]] = key;
             }
         }
@@ -389,10 +435,9 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-SortPlan make_sort_plan(uint64_t live_mask, int lo_bit, int hi_bit, int digit_bits) {
+static SortPlan plan_with_width(uint64_t live_mask, int lo_bit, int hi_bit, int db) {
     SortPlan p;
     p.n_passes = 0;
-    const int db = digit_bits == 4 ? 4 : 8;
     int b = lo_bit;
     while (b < hi_bit && p.n_passes < SORT_MAX_PASSES) {
         if (!((live_mask >> b) & 1ull)) { b++; continue; }
@@ -407,29 +452,48 @@ SortPlan make_sort_plan(uint64_t live_mask, int lo_bit, int hi_bit, int digit_bi
     return p;
 }
 
-uint32_t sort_hist_blocks(size_t n) {
-    uint32_t hb = (uint32_t)((n + HS_TILE - 1) / HS_TILE);
-    return hb > 2048 ? 2048u : hb;                        // few workgroups: the final flush is 256 x passes global atomics each
+// digit_bits: 4 = the 16-bin instantiation throughout; 8 = 256 bins; 0 = 256 bins, or 512 where nine-bit digits save a
+// whole pass (17 or 18 live key bits — an 8192 x 8192 canvas has 9 + 9 — sort in two passes instead of three)
+SortPlan make_sort_plan(uint64_t live_mask, int lo_bit, int hi_bit, int digit_bits) {
+    if (digit_bits == 4 || digit_bits == 9) return plan_with_width(live_mask, lo_bit, hi_bit, digit_bits);
+    const SortPlan p8 = plan_with_width(live_mask, lo_bit, hi_bit, 8);
+    if (digit_bits == 8) return p8;
+    const SortPlan p9 = plan_with_width(live_mask, lo_bit, hi_bit, 9);
+    return p9.n_passes < p8.n_passes ? p9 : p8;
 }
 
+uint32_t sort_hist_blocks(size_t n) {
+    uint32_t hb = (uint32_t)((n + HS_TILE - 1) / HS_TILE);
+    return hb > 2048 ? 2048u : hb;                        // few workgroups: the final flush is bins x passes global atomics each
+}
+
+static inline size_t sort_fixed_words() { return (size_t)HS_COPIES * SORT_MAX_PASSES * SORT_BINS + 64; }
 size_t sort_scratch_words(size_t n) {
     size_t ntiles = (n + OS_TILE - 1) / OS_TILE;
-    // [hist: HS_COPIES x MAX_PASSES*256] [tickets: MAX_PASSES] [pad to 64] [status: MAX_PASSES * ntiles * 256]
-    return (size_t)HS_COPIES * SORT_MAX_PASSES * 256 + 64 + (size_t)SORT_MAX_PASSES * (ntiles + 1) * 256;
+    // [hist: HS_COPIES x MAX_PASSES x SORT_BINS] [tickets: MAX_PASSES] [pad to 64] [status: MAX_PASSES * ntiles * SORT_BINS]
+    return sort_fixed_words() + (size_t)SORT_MAX_PASSES * (ntiles + 1) * SORT_BINS;
+}
+// the words of the scratch a sort of `n` keys with this plan expects to be zero when it starts (histograms, tickets, the
+// status rows of the passes that run): launch_radix_sort clears them itself unless the caller says an earlier kernel of the
+// frame already did (api.cpp folds the clearing into the frame's first kernel)
+size_t sort_zero_words(size_t n, const SortPlan& plan) {
+    const size_t ntiles = (n + OS_TILE - 1) / OS_TILE;
+    return sort_fixed_words() + (size_t)plan.n_passes * ntiles * SORT_BINS;
 }
 
 const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a, uint64_t* b, DevCount nc,
                                   const SortPlan& plan, int digit_bits, uint32_t* scratch, uint32_t* err,
-                                  hipEvent_t* pass_ev0, hipEvent_t* pass_ev1, const ChunkedSrc* chunked, FrameInfo* info) {
+                                  hipEvent_t* pass_ev0, hipEvent_t* pass_ev1, const ChunkedSrc* chunked, FrameInfo* info,
+                                  bool scratch_is_zero) {
     const size_t n = nc.bound;                        // provisioning (grid, scratch); the kernels use the device count
     if (n <= 1 || plan.n_passes == 0) return in;
     const uint32_t ntiles = (uint32_t)((n + OS_TILE - 1) / OS_TILE);
     uint32_t* hist = scratch;
-    uint32_t* tickets = scratch + (size_t)HS_COPIES * SORT_MAX_PASSES * 256;
+    uint32_t* tickets = scratch + (size_t)HS_COPIES * SORT_MAX_PASSES * SORT_BINS;
     uint32_t* status = tickets + 64;
     const int P = plan.n_passes;
     // zero hist + tickets + the status words of the passes that run (re-initialised every call)
-    (void)hipMemsetAsync(scratch, 0, ((size_t)HS_COPIES * SORT_MAX_PASSES * 256 + 64 + (size_t)P * ntiles * 256) * 4, s);
+    if (!scratch_is_zero) (void)hipMemsetAsync(scratch, 0, sort_zero_words(n, plan) * 4, s);
     const uint32_t hb = sort_hist_blocks(n);
     ChunkedSrc C0;
     memset(&C0, 0, sizeof C0);
@@ -441,15 +505,21 @@ const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a
     const uint64_t* src = in;
     uint64_t* dst = a;
     for (int p = 0; p < P; p++) {
-        if (pass_ev0) (void)hipEventRecord(pass_ev0[p], s);
-        uint32_t* st = status + (size_t)p * ntiles * 256;
+        uint32_t* st = status + (size_t)p * ntiles * SORT_BINS;
         const bool ch = p == 0 && C.n_chunks > 1;                      // only the first pass reads the received buckets in place
-#define OS_LAUNCH(B, CH) hipLaunchKernelGGL((k_onesweep<B, CH>), dim3(grid), dim3(OS_THREADS), 0, s, src, dst, nc, plan.shift[p], \
-                                           plan.mask[p], (const uint32_t*)(hist + p * 256), st, tickets + p, err, ch ? C : C0)
-        if (digit_bits == 4) { if (ch) OS_LAUNCH(4, true); else OS_LAUNCH(4, false); }
-        else { if (ch) OS_LAUNCH(8, true); else OS_LAUNCH(8, false); }
+        const bool hi = plan.shift[p] >= 32;
+        // With pass events the launch carries them itself (hipExtLaunchKernelGGL: the events take the dispatch's own start and
+        // end timestamps, what a profiler reports as the kernel's duration) instead of markers in front of and behind it
+        hipEvent_t e0 = pass_ev0 ? pass_ev0[p] : nullptr, e1 = pass_ev1 ? pass_ev1[p] : nullptr;
+#define OS_LAUNCH(B, CH, HI_) hipExtLaunchKernelGGL((k_onesweep<B, CH, HI_>), dim3(grid), dim3(OS_THREADS), 0, s, e0, e1, 0, src, dst, nc, \
+                                           plan.shift[p], plan.mask[p], (const uint32_t*)(hist + p * SORT_BINS), st, tickets + p, err, ch ? C : C0)
+#define OS_LAUNCH_B(B) do { if (ch) { if (hi) OS_LAUNCH(B, true, true); else OS_LAUNCH(B, true, false); } \
+                            else { if (hi) OS_LAUNCH(B, false, true); else OS_LAUNCH(B, false, false); } } while (0)
+        if (digit_bits == 4) OS_LAUNCH_B(4);
+        else if (plan.mask[p] > 255u) OS_LAUNCH_B(9);
+        else OS_LAUNCH_B(8);
+#undef OS_LAUNCH_B
 #undef OS_LAUNCH
-        if (pass_ev1) (void)hipEventRecord(pass_ev1[p], s);
         src = dst;
         dst = (dst == a) ? b : a;
     }

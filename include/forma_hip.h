@@ -239,10 +239,25 @@ int forma_hip_cache_clear(forma_hip_ctx* ctx, int cache_id);
  * frame is returned by the call that completes it.  Frames with dst != NULL keep the reference's contract (the caller's
  * buffer is fully written when render returns, cpu/buffer/mod.rs:43-49); cache frames stay in order (frame k + 1 reads
  * what frame k left in the cache).  Default 1: every render call is complete when it returns. */
-#define FORMA_MAX_FRAMES_IN_FLIGHT 4
+#define FORMA_MAX_FRAMES_IN_FLIGHT 8
 int forma_hip_set_frames_in_flight(forma_hip_ctx* ctx, int n);
 /* Wait for every enqueued frame; returns the first error any of them produced. */
 int forma_hip_sync(forma_hip_ctx* ctx);
+/* What a context is made of: its devices, its frame slots and — for a multi-device context — how pixel segments travel
+ * between the devices (RCCL all-to-all over xGMI, or peer copies when librccl cannot be loaded / initialised; a context over
+ * one device exchanges nothing).  A renderer has no counterpart in the reference (its parallelism is a Rayon pool,
+ * cpu/renderer.rs:61-73); hosts and benchmarks report it. */
+#define FORMA_TRANSPORT_NONE 0u
+#define FORMA_TRANSPORT_RCCL 1u
+#define FORMA_TRANSPORT_COPY 2u
+typedef struct forma_context_info {
+    uint32_t n_devices;
+    uint32_t frames_in_flight;
+    uint32_t transport;                 /* FORMA_TRANSPORT_* */
+    uint32_t reserved;
+    int32_t  devices[FORMA_MAX_DEVICES];
+} forma_context_info_t;
+int forma_hip_context_info(forma_hip_ctx* ctx, forma_context_info_t* out);
 /* Give per-frame device memory back (it is grown to the largest frame seen and otherwise kept until destroy): streams,
  * records, tables and the scratch image of the context and of its frame slots.  The scene and the buffer-layer caches stay.
  * forma_hip_read_image returns FORMA_E_STATE and forma_hip_read_segments an empty stream until the next render.  (The reference's renderer owns Vecs

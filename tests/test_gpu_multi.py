@@ -6,7 +6,7 @@ the whole multi-GPU frame (line-sharded rasterization -> HIP bucketing by tile-r
 This pool hands out single-GPU boxes, so the devices of most tests are the same GPU listed several times: every device still
 has its own context, stream, buffers and host thread, the planner / bucket / gather / chunk-mapped sort run exactly as on G
 GPUs, and the all-to-all is done with device copies (the library's rehearsal transport).  The RCCL transport is exercised
-with a world of one (FORMA_HIP_FORCE_EXCHANGE=1: ncclCommInitAll over one device, grouped ncclAllToAll on the library's own
+with a world of one (FORMA_HIP_DEBUG=force_exchange: ncclCommInitAll over one device, grouped ncclAllToAll on the library's own
 buffers and stream) and, when two GPUs are visible, for real."""
 import os
 import subprocess
@@ -251,8 +251,9 @@ print("RCCL-OK")
 
 
 def _run_rccl_script(devices, env_extra):
-    env = dict(os.environ, **env_extra)
-    env.pop("FORMA_HIP_XCHG", None)
+    env = dict(os.environ)
+    env.pop("FORMA_HIP_DEBUG", None)                       # (no xchg=copy from the outside: this is the RCCL path)
+    env.update(env_extra)
     code = _RCCL_WORLD1.replace("ROOT", repr(ROOT)).replace("DEVICES", repr(devices))
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=280)
     assert p.returncode == 0 and "RCCL-OK" in p.stdout, (p.stdout[-2000:], p.stderr[-4000:])
@@ -262,8 +263,8 @@ def _run_rccl_script(devices, env_extra):
 def test_rccl_inside_the_library_with_a_world_of_one():
     """everything the multi-device frame asks of RCCL, inside libforma_hip.so, on one GPU: librccl found with dlopen,
     ncclCommInitAll over [0], grouped ncclAllToAll of the counts and of the padded buckets on the context's stream with
-    the library's own buffers, the received bucket sorted and painted (FORMA_HIP_FORCE_EXCHANGE=1)"""
-    _run_rccl_script([0], {"FORMA_HIP_FORCE_EXCHANGE": "1"})
+    the library's own buffers, the received bucket sorted and painted (FORMA_HIP_DEBUG=force_exchange)"""
+    _run_rccl_script([0], {"FORMA_HIP_DEBUG": "force_exchange"})
 
 
 @pytest.mark.timeout(300)
@@ -333,6 +334,119 @@ def test_frames_in_flight_reports_a_deferred_error():
     if deep_ok:                                                        # (builds without the layer cap render it)
         S.load(o, t)
         assert np.abs(c.read_image(32, 32).astype(int) - o.render(32, 32).astype(int)).max() <= 1
+    c.close()
+
+
+# ---- frames in flight on a MULTI-DEVICE context (round 4): F frame slots x G devices, one set of communicators per slot --------
+@pytest.mark.parametrize("devices,slots", [([0, 0], 2), ([0, 0], 3), ([0] * 8, 2), ([0] * 8, 3)])
+def test_multi_device_frames_in_flight(devices, slots):
+    """device-resident, cache-less frames are ENQUEUED on the next frame slot of every device (buckets, the slot's exchange,
+    the owner's sort + paint, all stream-ordered) and verified when the slot comes round; image and sorted stream of the most
+    recent frame equal the oracle's; frames into caller memory, scene changes and `sync` see everything enqueued before them"""
+    import forma_amd
+    W, H = 512, 384
+    o = orc.Oracle()
+    t = S.random_mixed().tables(o)
+    S.load(o, t)
+    c = forma_amd.Context(devices=devices, frames_in_flight=slots)
+    info = c.info()
+    assert info["n_devices"] == len(devices) and info["frames_in_flight"] == slots and info["transport"] == "copy"
+    S.load(c, t)
+    clears = [(1, 1, 1, 1), (0.2, 0.3, 0.4, 1.0), (0, 0, 0, 0)]
+    for k in range(17):
+        clear = clears[k % 3]
+        assert c.render(W, H, clear=clear, device_only=True) is None
+        if k % 5 == 4 or k < 2:
+            assert np.array_equal(c.read_image(W, H), o.render(W, H, clear=clear)), k          # the MOST RECENT frame
+            assert np.array_equal(c.segments(1), painted_rows(o.segments(1), (H + 15) // 16)), k
+            assert c.tiles_written(W, H).all()
+    c.sync()
+    img = c.render(W, H, clear=clears[1], dst=np.zeros((H, W * 4), np.uint8))                  # synchronous contract kept
+    assert np.array_equal(img, o.render(W, H, clear=clears[1]))
+    # a scene change waits for the frames in flight; every slot of every device then sees the new scene
+    g = t["geoms"].copy()
+    g["flags"] = 1
+    g["xf"] = np.array([0.8, 0.0, 0.0, 0.8, 30.0, 20.0], np.float32)
+    for k in range(slots + 1):
+        c.render(W, H, device_only=True)
+    o.set_geoms(g); c.set_geoms(g)
+    for k in range(2 * slots + 1):
+        c.render(W, H, device_only=True)
+    assert np.array_equal(c.read_image(W, H), o.render(W, H))
+    assert np.array_equal(c.segments(1), painted_rows(o.segments(1), (H + 15) // 16))
+    # a crop, and another canvas size (a new plan while frames are in flight)
+    crop = (40, 300, 50, 250)
+    for k in range(slots + 1):
+        c.render(W, H, crop=crop, device_only=True)
+    want = o.render(W, H, crop=crop, dst=np.zeros((H, W * 4), np.uint8))
+    got = c.read_image(W, H)
+    y0, y1, x0, x1 = crop[2] // 16 * 16, min(H, (crop[3] + 15) // 16 * 16), crop[0] // 16 * 16, min(W, (crop[1] + 15) // 16 * 16)
+    assert np.array_equal(got.reshape(H, W, 4)[y0:y1, x0:x1], want.reshape(H, W, 4)[y0:y1, x0:x1])
+    for k in range(slots + 2):
+        c.render(300, 200, device_only=True)
+    assert np.array_equal(c.read_image(300, 200), o.render(300, 200))
+    c.set_frames_in_flight(1)
+    assert np.array_equal(c.render(W, H), o.render(W, H))
+    c.close()
+
+
+@pytest.mark.parametrize("slots", [2, 3])
+def test_multi_device_frames_in_flight_replan_while_frames_are_deferred(slots):
+    """the scene grows while frames are in flight: deferred frames whose buckets outgrew the plan are void on every device; the
+    context settles every slot, re-plans and runs them again — the caller only ever reads the right image"""
+    import forma_amd
+    W, H = 512, 384
+    o = orc.Oracle()
+    t = S.random_mixed().tables(o)
+    S.load(o, t)
+    c = forma_amd.Context(devices=[0, 0, 0], frames_in_flight=slots)
+    S.load(c, t)
+
+    def scaled(k, tx, ty):
+        g = t["geoms"].copy()
+        g["flags"] = 1
+        g["xf"] = np.array([k, 0.0, 0.0, k, tx, ty], np.float32)
+        return g
+
+    for k, tx, ty in ((0.4, 150.0, 100.0), (0.95, 10.0, 5.0), (0.3, 10.0, 250.0), (1.0, 0.0, 0.0), (0.5, 200.0, 0.0)):
+        g = scaled(k, tx, ty)
+        o.set_geoms(g); c.set_geoms(g)
+        for _ in range(2 * slots + 1):
+            c.render(W, H, device_only=True)
+        assert np.array_equal(c.read_image(W, H), o.render(W, H)), (k, tx, ty)
+        assert np.array_equal(c.segments(1), painted_rows(o.segments(1), (H + 15) // 16))
+    c.close()
+
+
+def test_multi_device_frames_in_flight_report_a_deferred_error():
+    """a deferred frame that fails on a device after the call returned surfaces at the call that completes it, and the context
+    keeps working"""
+    import forma_amd
+    from forma_amd import FormaError
+    W, H = 256, 128
+    o = orc.Oracle()
+    t = S.random_mixed(width=W, height=H, seed=3).tables(o)
+    S.load(o, t)
+    c = forma_amd.Context(devices=[0, 0], frames_in_flight=2)
+    S.load(c, t)
+    for _ in range(4):
+        c.render(W, H, device_only=True)
+    c.sync()
+    bad = t["style_offsets"].copy()
+    bad[:] = 0xFFFFFFFF                                                # every order loses its style: k_carry_rows reports it (FORMA_E_ARG)
+    c.set_styles(bad, t["style_words"], t["unchanged"])
+    with pytest.raises(FormaError):
+        for _ in range(6):
+            c.render(W, H, device_only=True)
+        c.sync()
+    try:
+        c.sync()                                                       # (the other slots' frames failed the same way: flush them)
+    except FormaError:
+        pass
+    c.set_styles(t["style_offsets"], t["style_words"], t["unchanged"])
+    for _ in range(5):
+        c.render(W, H, device_only=True)
+    assert np.array_equal(c.read_image(W, H), o.render(W, H))
     c.close()
 
 

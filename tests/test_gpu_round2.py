@@ -47,19 +47,54 @@ def test_sort_ragged_sizes_both_digit_widths(ctx, n):
     v = rng.integers(0, 2 ** 63, n, dtype=np.uint64)
     v &= np.uint64(0xFFFFF00FFFFFFFFF)                      # a dead nibble inside the key: digit skipping with 4-bit digits
     ref = v[np.argsort(v >> np.uint64(20), kind="stable")]
-    for bits in (4, 8):
+    for bits in (4, 8, 9):
         assert np.array_equal(ctx.sort_array(v, digit_bits=bits), ref), (n, bits)
 
 
+def test_sort_9bit_digits_10m_keys(ctx):
+    """forma_hip_sort(..., digit_bits = 9): k_onesweep<9> — 512 bins, per-wave counters in 16-bit halves — which a frame picks by
+    itself when nine-bit digits save a whole pass: stable, a permutation, keys non-decreasing."""
+    rng = np.random.default_rng(19)
+    n = 10_000_000
+    v = rng.integers(0, 2 ** 63, n, dtype=np.uint64)
+    ref = v[np.argsort(v >> np.uint64(20), kind="stable")]
+    assert np.array_equal(ctx.sort_array(v, digit_bits=9), ref)
+
+
+@pytest.mark.parametrize("bits", [0, 4, 8, 9])
+def test_sort_coherent_streams(ctx, bits):
+    """what a rasterizer emits: long runs of equal tile digits, the same digit coming back within one wave row of 64 keys
+    (A A B B A A: an outline that leaves a tile and returns), rows of one digit, digits that alternate key by key — the
+    ranking takes its run-structured path where a row allows and the general one where it does not; both are stable"""
+    rng = np.random.default_rng(23 + bits)
+    n = 3_000_000
+    tiles = rng.integers(0, 1 << 23, 4000, dtype=np.uint64)             # (tile_y, tile_x) values in play
+    runs = rng.integers(1, 48, n // 8)
+    pick = rng.integers(0, 6, runs.size)                                # a few tiles alternate locally: repeats inside a row
+    base = np.repeat(np.arange(runs.size) // 50, 1)
+    tile_of_run = tiles[(base * 6 + pick) % tiles.size]
+    t = np.repeat(tile_of_run, runs)[:n]
+    t[1000:1200:2] = tiles[0]; t[1001:1200:2] = tiles[1]               # strict alternation
+    t[5000:9000] = tiles[2]                                             # whole tiles of the sort with one digit
+    low = rng.integers(0, 1 << 41, t.size, dtype=np.uint64)
+    v = (t << np.uint64(41)) | low
+    ref = v[np.argsort(v >> np.uint64(20), kind="stable")]
+    assert np.array_equal(ctx.sort_array(v, digit_bits=bits), ref)
+    # layer-sorted form: only the tile bits vary between neighbours (what a frame sorts: two or three digit passes)
+    v2 = (t << np.uint64(41)) | (np.arange(t.size, dtype=np.uint64) & np.uint64(0xFFFFF))
+    ref2 = v2[np.argsort(v2 >> np.uint64(20), kind="stable")]
+    assert np.array_equal(ctx.sort_array(v2, digit_bits=bits), ref2)
+
+
 def test_whole_frames_with_4bit_digits():
-    """One context created under FORMA_HIP_DIGIT_BITS=4 renders whole frames (synchronous first frame, read-back-free
+    """One context created under FORMA_HIP_DEBUG=digit_bits=4 renders whole frames (synchronous first frame, read-back-free
     second frame, out-of-order layers = full-key sort): streams bit-identical, image identical."""
     import forma_amd
-    os.environ["FORMA_HIP_DIGIT_BITS"] = "4"
+    os.environ["FORMA_HIP_DEBUG"] = "digit_bits=4"
     try:
         c4 = forma_amd.Context(0)
     finally:
-        del os.environ["FORMA_HIP_DIGIT_BITS"]
+        del os.environ["FORMA_HIP_DEBUG"]
     try:
         for comp, (w, h) in ((S.random_mixed(), (512, 384)), (S.random_cubics(300, 1920, 1080), (1920, 1080))):
             o, _ = both(c4, comp)

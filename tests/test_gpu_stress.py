@@ -115,12 +115,10 @@ def test_layers_cut_by_the_bottom_edge_in_a_partial_last_tile_row():
 @pytest.mark.parametrize("slices,global_sort", [(2, False), (3, False), (8, False), (2, True), (5, True)])
 def test_carry_pre_pass_with_several_workgroups_per_tile_row(slices, global_sort, monkeypatch):
     """k_carry_rows shares a tile row between `slices` workgroups, each a range of layers (single GPU: by itself only when
-    the rows are few; a multi-GPU band: always).  FORMA_HIP_CARRY_SLICES forces the count: every count, both run orders
+    the rows are few; a multi-GPU band: always).  FORMA_HIP_DEBUG=carry_slices=N forces the count: every count, both run orders
     (in-LDS sort of a slice / cut of the globally sorted keys), the same bits as the oracle — frames 1 (synchronous) to 3."""
     import forma_amd
-    monkeypatch.setenv("FORMA_HIP_CARRY_SLICES", str(slices))
-    if global_sort:
-        monkeypatch.setenv("FORMA_HIP_GLOBAL_RUNSORT", "1")
+    monkeypatch.setenv("FORMA_HIP_DEBUG", "carry_slices=%d%s" % (slices, ",global_runsort" if global_sort else ""))
     for seed, n, W, H in ((31, 400, 640, 480), (32, 2500, 2048, 64), (33, 150, 100, 700)):
         comp = S.random_mixed(n=n, width=W, height=H, seed=seed)
         o = orc.Oracle()
@@ -144,15 +142,12 @@ def test_carry_pre_pass_with_several_workgroups_per_tile_row(slices, global_sort
 @pytest.mark.parametrize("slices,global_sort", [(1, False), (3, False), (8, False), (1, True), (4, True)])
 def test_span_group_lists(slices, global_sort, monkeypatch):
     """k_carry_rows leaves the spans of a tile row a second time by group of 16 tile columns and the wave painter scans its
-    group's list instead of the row's (by itself only on frames whose rows hold > 256 spans; FORMA_HIP_SPAN_GROUPS forces them
+    group's list instead of the row's (by itself only on frames whose rows hold > 256 spans; FORMA_HIP_DEBUG=span_groups forces them
     on every frame and row).  Canvases of 1, 2, 7 and 128 groups, every slice count, both run orders, with and without a
     cache: the same bits as the oracle.  The third scene is wide and shallow: its spans cross many groups, the static pool
     (two entries per run) does not hold them and those rows fall back to the row lists on the device."""
     import forma_amd
-    monkeypatch.setenv("FORMA_HIP_SPAN_GROUPS", "1")
-    monkeypatch.setenv("FORMA_HIP_CARRY_SLICES", str(slices))
-    if global_sort:
-        monkeypatch.setenv("FORMA_HIP_GLOBAL_RUNSORT", "1")
+    monkeypatch.setenv("FORMA_HIP_DEBUG", "span_groups,carry_slices=%d%s" % (slices, ",global_runsort" if global_sort else ""))
     scenes = [(S.random_mixed(n=400, width=640, height=480, seed=41), 640, 480),
               (S.random_mixed(n=2500, width=2048, height=64, seed=42), 2048, 64),
               (S.random_mixed(n=150, width=100, height=700, seed=43), 100, 700),
@@ -209,11 +204,11 @@ print("poison ok")
 
 @pytest.mark.parametrize("byte", ["0xFF", "0xA5", "0x00"])
 def test_nothing_reads_what_it_did_not_write(byte):
-    """FORMA_HIP_POISON fills every fresh device allocation with one byte: frames (synchronous and read-back-free, with and
+    """FORMA_HIP_DEBUG=poison=BYTE fills every fresh device allocation with one byte: frames (synchronous and read-back-free, with and
     without a cache, span group lists forced on) must not depend on what a buffer held before this frame wrote it — hipMalloc
     does not zero, and a fresh box hands out whatever the last tenant left."""
     import subprocess, sys
-    env = dict(os.environ, FORMA_HIP_POISON=byte, FORMA_HIP_SPAN_GROUPS="1")
+    env = dict(os.environ, FORMA_HIP_DEBUG="poison=%s,span_groups" % byte)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _POISON_SCRIPT], cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "poison ok" in r.stdout, (r.stdout[-800:], r.stderr[-1500:])

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """What the multi-device frame costs over the plain one on ONE GPU (world of one, where all of it is overhead): the plain
-context, the exchange path without a collective (FORMA_HIP_XCHG=copy) and with RCCL (ncclAllToAll with itself).
+context, the exchange path without a collective (FORMA_HIP_DEBUG=xchg=copy) and with RCCL (ncclAllToAll with itself).
     python tools/multi_overhead.py [workload]        (scene tables: /tmp/ab_fast_scene_<workload>.npz, built by tools/ab_fast.py)"""
 import json, os, subprocess, sys, time
 import numpy as np
@@ -31,7 +31,7 @@ def child(kind):
 if "--child" in sys.argv:
     child(sys.argv[sys.argv.index("--child") + 1])
 else:
-    for kind, env in (("plain", {}), ("copy1", {"FORMA_HIP_FORCE_EXCHANGE": "1", "FORMA_HIP_XCHG": "copy"}), ("rccl1", {"FORMA_HIP_FORCE_EXCHANGE": "1"}),
+    for kind, env in (("plain", {}), ("copy1", {"FORMA_HIP_DEBUG": "force_exchange,xchg=copy"}), ("rccl1", {"FORMA_HIP_DEBUG": "force_exchange"}),
                       ("two", {})):
         e = dict(os.environ, **env)
         p = subprocess.run([sys.executable, os.path.abspath(__file__), wl, "--child", kind], env=e, capture_output=True, text=True, timeout=300)

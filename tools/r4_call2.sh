@@ -1,0 +1,14 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/r4b; mkdir -p $O
+export PYTHONUNBUFFERED=1
+timeout 900 python -m pytest tests -q -m gpu -n 6 --timeout 600 -p no:cacheprovider > $O/pytest.log 2>&1
+echo "pytest rc=$?" >> $O/pytest.log
+tail -40 $O/pytest.log
+( echo "== C3 full"; timeout 300 python tools/ab_fast.py --rounds 2 --frames 60 base.bin new.bin
+  echo "== C3 band 59,76 F=3"; AB_BAND=59,76 AB_INFLIGHT=3 timeout 300 python tools/ab_fast.py --rounds 2 --frames 120 base.bin new.bin
+  echo "== C4 full"; timeout 300 python tools/ab_fast.py --workload triangles-10m-8k --rounds 2 --frames 40 base.bin new.bin
+  echo "== C4 band 224,288 F=3"; AB_BAND=224,288 AB_INFLIGHT=3 timeout 300 python tools/ab_fast.py --workload triangles-10m-8k --rounds 2 --frames 120 base.bin new.bin
+  echo "== cubics"; timeout 300 python tools/ab_fast.py --workload cubics-1080p --rounds 1 --frames 60 base.bin new.bin
+) > $O/ab.txt 2>&1
+grep -v "^---- \|^base.bin  .*total  \|^new.bin  .*total  " $O/ab.txt | cut -c1-250

@@ -10,7 +10,7 @@ done
 # the multi-GPU paths rehearsed on the one GPU of the box: ONE context over four "devices" (forma_hip_create_multi, device copies
 # instead of RCCL), the same with a world of one through RCCL, and the process-per-GPU exchange layout with one rank
 FORMA_BENCH_MODE_AT_1=1 FORMA_BENCH_DEVICES=0,0,0,0 timeout 300 python bench.py $Q > $OUT/bench_multi_4x_one_gpu.json 2>> $OUT/bench_default.err
-FORMA_BENCH_MODE_AT_1=1 FORMA_HIP_FORCE_EXCHANGE=1 timeout 300 python bench.py $Q > $OUT/bench_multi_rccl_world1.json 2>> $OUT/bench_default.err
+FORMA_BENCH_MODE_AT_1=1 FORMA_HIP_DEBUG=force_exchange timeout 300 python bench.py $Q > $OUT/bench_multi_rccl_world1.json 2>> $OUT/bench_default.err
 FORMA_BENCH_MODE_AT_1=1 timeout 300 python bench.py $Q --mode exchange > $OUT/bench_exchange_world1.json 2>> $OUT/bench_default.err
 (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_default -- python $OLDPWD/bench.py $Q > $OUT/prof_default.log 2>&1)
 (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_inflight1 -- python $OLDPWD/bench.py $Q --in-flight 1 > $OUT/prof_inflight1.log 2>&1)
