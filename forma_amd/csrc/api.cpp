@@ -151,10 +151,11 @@ int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, boo
 
 // the digit plan of a frame's segment sort: live key bits only; a stream that is already non-decreasing in layer needs a
 // stable sort by tile alone
-SortPlan frame_sort_plan(uint64_t live44, bool layer_sorted, int digit_bits) {
-    uint64_t live = live44;
-    if (layer_sorted) live &= ~0x1FFFFFull;
-    return make_sort_plan(live << 20, 20, 64, digit_bits);
+SortPlan frame_sort_plan(forma_hip_ctx* ctx, uint64_t live44, bool layer_sorted, int digit_bits, bool speculated, bool* biased) {
+    // the tile fields relative to their minima (one digit fewer on 4096- and 8192-pixel canvases): only on read-back-free
+    // frames — the span is the PREVIOUS frame's, k_sort_hist checks this frame's keys against it and voids the frame otherwise
+    const KeyRange* range = speculated && ctx->pred_range.valid && !ctx->bias_banned && !ctx->dbg.no_bias ? &ctx->pred_range : nullptr;
+    return make_segment_sort_plan(live44, layer_sorted, digit_bits, range, biased);
 }
 
 // What the frame's FIRST kernel (k_line_len) clears for the later stages of a read-back-free frame — the sort's histograms,
@@ -168,7 +169,7 @@ int plan_zero_jobs(forma_hip_ctx* ctx, uint32_t width, uint32_t height, uint32_t
     *cleared = forma_hip_ctx::PreZero();
     if (ctx->dbg.no_prezero) return FORMA_OK;
     const uint32_t tiles_w = (width + 15) / 16, tiles_h = (height + 15) / 16;
-    const SortPlan plan = frame_sort_plan(ctx->pred_live44, ctx->pred_layer_sorted, ctx->digit_bits);
+    const SortPlan plan = frame_sort_plan(ctx, ctx->pred_live44, ctx->pred_layer_sorted, ctx->digit_bits, true, nullptr);
     HIPCHECK(ctx->sort_counters.ensure(sort_scratch_words(std::max<size_t>(sort_n, 1)) * 4));
     HIPCHECK(ctx->row_tab.ensure(((size_t)row_tab_zero_words(tiles_w, tiles_h) + 3 * (size_t)tiles_w * tiles_h) * 4));
     (void)runs_n;
@@ -190,8 +191,10 @@ int run_sort(forma_hip_ctx* ctx, const uint64_t* src, DevCount nc, bool timing, 
     HIPCHECK(ctx->seg_a.ensure((std::max<size_t>(n, 1) + SEG_PAD) * 8));
     HIPCHECK(ctx->seg_b.ensure((std::max<size_t>(n, 1) + SEG_PAD) * 8));
     HIPCHECK(ctx->sort_counters.ensure(sort_scratch_words(std::max<size_t>(n, 1)) * 4));
-    const SortPlan plan = frame_sort_plan(ctx->live44, ctx->layer_sorted, digit_bits);
+    const SortPlan plan = frame_sort_plan(ctx, ctx->live44, ctx->layer_sorted, digit_bits, ctx->speculated && nc.ptr != nullptr, &ctx->plan_biased);
     ctx->n_passes = plan.n_passes;
+    ctx->sort_range = n > 1 && plan.n_passes ? sort_range_words(ctx->sort_counters.as<uint32_t>()) : nullptr;
+    ctx->sort_range_n = sort_hist_blocks(n);
     const bool zeroed = ctx->pz.sort_p == ctx->sort_counters.p && ctx->pz.sort_words >= sort_zero_words(n, plan);
     ctx->pz.sort_p = nullptr;
     stage_begin(ctx, ST_SORT, timing);
@@ -290,7 +293,8 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                 ctx->layer_sorted, ctx->pending_masks,
                 RunStyle{ctx->layer_sf.as<uint32_t>(), (uint32_t)ctx->n_orders,
                          (a.cache_id >= 0 && ctx->have_unchanged) ? ctx->unchanged.as<uint8_t>() : nullptr, ctx->run_lt.as<uint32_t>()},
-                tables_zero);
+                tables_zero, ctx->sort_range, ctx->sort_range_n);
+    ctx->sort_range = nullptr;
     ctx->pending_masks = PendingMasks{nullptr, 0u};
     HIPCHECK(hipGetLastError());
     DevCount jc;
@@ -582,6 +586,10 @@ int finish_frame(forma_hip_ctx* ctx, forma_timings_t* t, bool have_info = false)
     }
     // device-side invariant flags
     ctx->pred_no_deep = !(ctx->h_info->error & 16u);       // (8, 16: bookkeeping bits, not errors)
+    if (!ctx->h_info->plan_bad) {                          // what the keys' tile fields spanned (a sort that did not run leaves min > max)
+        const uint32_t* r = ctx->h_info->tile_range;
+        ctx->pred_range = KeyRange{~r[0], r[1], ~r[2], r[3], true};
+    }
     if (!ctx->h_info->plan_bad) ctx->pred_row_spans = ctx->h_info->n_spans / ctx->cur_rows_painted;
     if (!ctx->h_info->plan_bad) { ctx->pred_max_slice = ctx->h_info->max_slice_runs; ctx->pred_slice_n = ctx->cur_slices; ctx->pred_slice_small = ctx->cur_small; }
     if ((ctx->h_info->error & ~24u) == 1u)                   // (bit 0: k_carry_rows met a run of a layer without a style)
@@ -1063,6 +1071,7 @@ int complete_async_frame(forma_hip_ctx* ctx, const PaintArgs& a, uint8_t* dst, s
     const bool ok = !ctx->h_info->plan_bad && N <= bN && J <= bJ;
     if (!ok) {
         if (ctx->small_tried && ctx->h_info->plan_bad) ctx->small_banned = true;   // (one cause of plan_bad: a slice beyond the small variant)
+        if (ctx->plan_biased && ctx->h_info->plan_bad) ctx->bias_banned = true;    // (another: a key outside the span the digits were planned for)
         ctx->pred_counts_valid = false;                   // the synchronous path re-learns everything
         clear_stage_flags(ctx);
         return FORMA_RETRY;
@@ -1156,8 +1165,8 @@ void share_scene(forma_hip_ctx* o) {
     }
 }
 void invalidate_counts(forma_hip_ctx* o) {                 // new geometry / band: every slot re-learns N and J synchronously
-    o->pred_counts_valid = false; o->xpred_valid = false; o->small_banned = false;
-    for (forma_hip_ctx* sl : o->slots) { sl->pred_counts_valid = false; sl->xpred_valid = false; sl->small_banned = false; }
+    o->pred_counts_valid = false; o->xpred_valid = false; o->small_banned = false; o->bias_banned = false; o->pred_range.valid = false;
+    for (forma_hip_ctx* sl : o->slots) { sl->pred_counts_valid = false; sl->xpred_valid = false; sl->small_banned = false; sl->bias_banned = false; sl->pred_range.valid = false; }
 }
 }  // namespace
 
@@ -1609,6 +1618,7 @@ int gsp_complete(forma_hip_ctx* ctx, const GspArgs& g, uint32_t bJ) {
     const uint32_t N = ctx->h_info->n_segments, J = ctx->h_info->n_runs;
     ctx->n_seg = N; ctx->last_runs = J;
     if (ctx->h_info->plan_bad && ctx->small_tried) ctx->small_banned = true;
+    if (ctx->h_info->plan_bad && ctx->plan_biased) ctx->bias_banned = true;
     if (!ctx->h_info->plan_bad && J <= bJ) {
         ctx->pred_J = J; ctx->pred_max_row = ctx->h_info->max_row_runs;
         if ((rc = finish_paint(ctx))) return rc;

@@ -49,6 +49,7 @@ struct FrameInfo {
     uint32_t max_row_runs;   // most runs in one tile row (the carry pre-pass sorts a row's runs in LDS when they fit)
     uint32_t exchange_overflow;   // multi-GPU exchange: a bucket did not fit the agreed pair capacity (here or at a sender)
     uint32_t max_slice_runs;      // most runs one workgroup of the carry pre-pass sorted in LDS (a slice of a tile row)
+    uint32_t tile_range[4];       // of the sorted keys' tile fields, as maxima: ~min(tile_x + 1), max(tile_x + 1), ~min(tile_y + 1), max(tile_y + 1)
 };
 
 // one run of the sorted stream = one painted (tile, layer) pair that owns pixel segments
@@ -160,16 +161,26 @@ void launch_flatten(hipStream_t s, const forma_flatten_tables_t* dev_tables, flo
 
 // sort.hip — stable LSB radix sort of u64 (chained-scan "onesweep" passes over the live key bits).
 #define SORT_MAX_PASSES 12
-struct SortPlan {                 // digit p = (key >> shift[p]) & mask[p]
+struct SortPlan {                 // digit p = ((key >> shift[p]) - bias[p]) & mask[p]
     int      n_passes;
     int      shift[SORT_MAX_PASSES];
     uint32_t mask[SORT_MAX_PASSES];
+    uint32_t bias[SORT_MAX_PASSES];   // != 0: the digit is a whole tile field minus its smallest value (KeyRange) ...
+    uint32_t fmask[SORT_MAX_PASSES];  // ... and this is the field's mask at `shift` (0: a plain bit window)
 };
+// What the keys' tile fields spanned on the previous frame.  A canvas of 2^k tiles uses the values 1 .. 2^k of a field that
+// stores tile + 1 (0 = left of / above the canvas): k + 1 live bits for one value, and on a 4096- or 8192-pixel canvas that
+// bit costs a whole digit pass.  Sorting by (field - min) is the same order in k bits.
+struct KeyRange { uint32_t min_x, max_x, min_y, max_y; bool valid; };
 // digits packed greedily over the live bits of [lo_bit, hi_bit); digit_bits = 4, 8 or 9 bits per digit, 0 = 8, or 9 where
 // that saves a whole pass
 SortPlan make_sort_plan(uint64_t live_mask, int lo_bit, int hi_bit, int digit_bits);
+// the same for a frame's pixel segments (key = bits 20..63), with the tile fields taken relative to their minima when `range`
+// is known and that saves a pass; *biased tells whether it did
+SortPlan make_segment_sort_plan(uint64_t live44, bool layer_sorted, int digit_bits, const KeyRange* range, bool* biased);
 size_t sort_scratch_words(size_t n);
-size_t sort_zero_words(size_t n, const SortPlan& plan);     // leading words of the scratch that must be zero when the sort starts
+size_t sort_zero_words(size_t n, const SortPlan& plan);
+const uint32_t* sort_range_words(const uint32_t* scratch);  // per k_sort_hist workgroup: {~min tile_x+1, max tile_x+1, ~min tile_y+1, max tile_y+1} of its keys     // leading words of the scratch that must be zero when the sort starts
 // `in` is read-only (preserved), a/b are ping-pong buffers; returns the buffer holding the result (== in when the
 // plan is empty).  scratch: >= sort_scratch_words(n) u32.  err: device word, bit 2 set if a look-back spin expired.
 // Multi-GPU exchange: the stream to sort is NOT contiguous — it is the rank-major concatenation of the n_chunks received
@@ -225,7 +236,9 @@ struct RunStyle {
 void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount n, uint32_t tiles_w, uint32_t tiles_h, TileRecord* records,
                  uint32_t rec_cap, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge,
                  uint32_t* row_tab, uint32_t* scratch, FrameInfo* info, bool verify_plan, uint64_t spec_live44,
-                 bool spec_layer_sorted, PendingMasks pm, RunStyle rs, bool tables_are_zero);
+                 bool spec_layer_sorted, PendingMasks pm, RunStyle rs, bool tables_are_zero,
+                 const uint32_t* range_records /* nullable: sort_range_words() of the sort that produced `sorted` ... */,
+                 uint32_t n_range_records /* ... and sort_hist_blocks() of its key count */);
 uint32_t runs_edge_segments();            // segments per BlkEdge entry
 // The end of a read-back-free frame: the device-side FrameInfo goes to pinned host memory (`host_info`, nullable) and/or its
 // segment count to a pinned word (`host_count`, nullable), and the device copy returns to its pristine state for the next

@@ -105,6 +105,10 @@ struct forma_hip_ctx {
     bool pred_counts_valid = false, no_async = false;    // N / J predictions for read-back-free frames (FORMA_HIP_DEBUG=sync disables)
     uint32_t pred_N = 0, pred_J = 0, pred_w = 0, pred_h = 0;
     uint64_t pred_live44 = 0;
+    KeyRange pred_range{0, 0, 0, 0, false};  // what the tile fields spanned on the last verified frame (value-range digits, SortPlan::bias)
+    bool plan_biased = false, bias_banned = false;   // this frame's plan leans on pred_range / a frame that did was void: plain digits for this geometry
+    const uint32_t* sort_range = nullptr;   // the tile-field spans the frame's sort leaves behind (k_runs_count folds them into FrameInfo) ...
+    uint32_t sort_range_n = 0;              // ... one record per k_sort_hist workgroup
     DevBuf info, records, rk_u, rk_a, rk_b, blk_edge, runs_scratch, row_tab, span_key, span_cov, image;
     uint32_t img_w = 0, img_h = 0;
     FrameInfo* h_info = nullptr;            // pinned

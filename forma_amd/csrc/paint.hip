@@ -144,7 +144,9 @@ __global__ __launch_bounds__(RC_THREADS) void k_runs_count(const uint64_t* __res
                                                            uint32_t* __restrict__ zero_base, uint32_t zero_words,
                                                            FrameInfo* __restrict__ info, uint64_t spec_live44,
                                                            uint32_t spec_flags /* bit0 verify, bit1 layer_sorted */,
-                                                           PendingMasks pm) {
+                                                           PendingMasks pm, const uint32_t* __restrict__ range_records /* nullable: the
+                                                           sort's tile-field spans, one 4-word record per k_sort_hist workgroup */,
+                                                           uint32_t n_range_records) {
     __shared__ uint32_t s_c[RC_THREADS / 64];
     __shared__ uint32_t s_red[5][RC_THREADS / 64];
     const uint32_t n = dev_count(nc);
@@ -156,6 +158,19 @@ __global__ __launch_bounds__(RC_THREADS) void k_runs_count(const uint64_t* __res
         const uint32_t z0 = blockIdx.x * per, z1 = min(zero_words, z0 + per);
         for (uint32_t i = z0 + tid; i < z1; i += RC_THREADS) zero_base[i] = 0;
         if (blockIdx.x == 0 && tid == 0 && nc.ptr && *nc.ptr > nc.bound) info->plan_bad = 1u;   // more segments than provisioned
+        if (blockIdx.x == gridDim.x - 1 && range_records) {             // what the tile fields spanned (next frame's sort plan)
+            uint4 m = make_uint4(0u, 0u, 0u, 0u);
+            for (uint32_t b = tid; b < n_range_records; b += RC_THREADS) {
+                const uint4 r = *reinterpret_cast<const uint4*>(range_records + (size_t)b * 4);
+                m.x = max(m.x, r.x); m.y = max(m.y, r.y); m.z = max(m.z, r.z); m.w = max(m.w, r.w);
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                m.x = max(m.x, (uint32_t)__shfl_xor(m.x, d, 64)); m.y = max(m.y, (uint32_t)__shfl_xor(m.y, d, 64));
+                m.z = max(m.z, (uint32_t)__shfl_xor(m.z, d, 64)); m.w = max(m.w, (uint32_t)__shfl_xor(m.w, d, 64));
+            }
+            if (lane == 0) { atomicMax(&info->tile_range[0], m.x); atomicMax(&info->tile_range[1], m.y); atomicMax(&info->tile_range[2], m.z); atomicMax(&info->tile_range[3], m.w); }
+        }
         if (blockIdx.x == 0) {
             // the key masks of the stream: on read-back-free frames the producer (k_rasterize / k_gather_chunks) left one
             // record per workgroup and nobody needed them combined until now — this workgroup does it instead of a launch
@@ -412,7 +427,7 @@ size_t runs_blocks(size_t n) { return (n + RW_CHUNK - 1) / RW_CHUNK + 4; }      
 void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t tiles_w, uint32_t tiles_h, TileRecord* records,
                  uint32_t rec_cap, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge, uint32_t* row_tab,
                  uint32_t* scratch, FrameInfo* info, bool verify_plan, uint64_t spec_live44, bool spec_layer_sorted,
-                 PendingMasks pm, RunStyle rs, bool tables_are_zero) {
+                 PendingMasks pm, RunStyle rs, bool tables_are_zero, const uint32_t* range_records, uint32_t n_range_records) {
     // per-frame tile tables: [row_count | row_span_lo | row_span_cnt | painter overflow counters (2) | first-run table] are
     // contiguous (api.cpp lays them out so) and start from zero — cleared by k_runs_count, unless an earlier kernel of the frame
     // already did (api.cpp folds that into the frame's first kernel); 0 in the first-run table = the tile has no run
@@ -427,7 +442,7 @@ void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t ti
     const uint32_t cgrid = std::min<uint32_t>((ntiles + 1) / 2, 4096u);
     uint32_t* chunk_counts = scratch + ntiles + 8;                      // 4 per tile (+ slack for the last wave's second half)
     hipLaunchKernelGGL(k_runs_count, dim3(cgrid), dim3(RC_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, scratch, chunk_counts, row_tab,
-                       zero_words, info, spec_live44, flags, pm);
+                       zero_words, info, spec_live44, flags, pm, range_records, n_range_records);
     const int scanned = ntiles > 16384 ? 1 : 0;
     if (scanned) launch_scan_small_u32(s, scratch, nc, RN_TILE, &info->n_runs);   // exclusive, in place; total -> n_runs
     hipLaunchKernelGGL(k_runs_wave, dim3(ntiles), dim3(RW_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, records, rec_cap,

@@ -90,6 +90,7 @@ __global__ __launch_bounds__(HS_THREADS) void k_sort_hist(const uint64_t* __rest
     }
     const uint32_t n = chunked ? M.total : dev_count(nc);
     uint32_t k_or = 0, k_or_hi = 0, k_and = 0xFFFFFFFFu, k_and_hi = 0xFFFFFFFFu, unsorted = 0;
+    uint32_t nmin_x = 0, max_x = 0, nmin_y = 0, max_y = 0;             // tile fields seen by this thread: ~min, max
     __shared__ uint32_t lh[SORT_MAX_PASSES * SORT_BINS];
     const int P = plan.n_passes;
     for (int i = threadIdx.x; i < P * SORT_BINS; i += HS_THREADS) lh[i] = 0;
@@ -102,6 +103,15 @@ __global__ __launch_bounds__(HS_THREADS) void k_sort_hist(const uint64_t* __rest
         for (int j = 0; j < HS_KPT; j++) {
             uint32_t idx = base + j * HS_THREADS;
             k[j] = idx < n ? in[chunked ? chunk_phys(M, idx) : idx] : 0ull;
+        }
+        // the span of the tile fields (KeyRange: next frame's plan; this frame's plan is checked against it below) — the kernel
+        // waits for HBM, the ALUs are idle
+#pragma unroll
+        for (int j = 0; j < HS_KPT; j++) {
+            if (base + j * HS_THREADS < n) {
+                const uint32_t hi = (uint32_t)(k[j] >> 32), tx = (hi >> 9) & 0xFFFu, ty = hi >> 21;
+                nmin_x = max(nmin_x, ~tx); max_x = max(max_x, tx); nmin_y = max(nmin_y, ~ty); max_y = max(max_y, ty);
+            }
         }
         if (chunked) {
             // the facts the sort plan is verified with (what k_gather_chunks computed when the stream was materialised):
@@ -130,11 +140,11 @@ __global__ __launch_bounds__(HS_THREADS) void k_sort_hist(const uint64_t* __rest
         const int lane = threadIdx.x & 63;
         for (int p = 0; p < P; p++) {
             const int sh = plan.shift[p];
-            const uint32_t mk = plan.mask[p];
+            const uint32_t mk = plan.mask[p], bs = plan.bias[p];
 #pragma unroll
             for (int j = 0; j < HS_KPT; j++) {
                 const bool valid = base + j * HS_THREADS < n;
-                const uint32_t d = valid ? ((uint32_t)(k[j] >> sh) & mk) : 0xFFFFFFFFu;
+                const uint32_t d = valid ? (((uint32_t)(k[j] >> sh) - bs) & mk) : 0xFFFFFFFFu;
                 const uint32_t dprev = __shfl_up(d, 1, 64);
                 const bool head = lane == 0 || d != dprev;
                 const uint64_t heads = __ballot(head);
@@ -154,6 +164,35 @@ __global__ __launch_bounds__(HS_THREADS) void k_sort_hist(const uint64_t* __rest
     for (int i = threadIdx.x; i < P * SORT_BINS; i += HS_THREADS) {
         uint32_t v = lh[i];
         if (v) atomicAdd(&mine[i], v);
+    }
+    {
+        // tile-field spans: ONE 16-byte record per workgroup behind the histograms, plain stores (neutral if it saw no key);
+        // k_runs_count folds the records into FrameInfo::tile_range.  (Four atomicMax per wave into 16 copies looked cheaper
+        // and cost 130 us: the copies shared two cache lines, and atomics on one line serialise.)
+        __shared__ uint32_t rr[4][HS_THREADS / 64];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            nmin_x = max(nmin_x, (uint32_t)__shfl_xor(nmin_x, d, 64)); max_x = max(max_x, (uint32_t)__shfl_xor(max_x, d, 64));
+            nmin_y = max(nmin_y, (uint32_t)__shfl_xor(nmin_y, d, 64)); max_y = max(max_y, (uint32_t)__shfl_xor(max_y, d, 64));
+        }
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { rr[0][w] = nmin_x; rr[1][w] = max_x; rr[2][w] = nmin_y; rr[3][w] = max_y; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int q = 1; q < HS_THREADS / 64; q++) { nmin_x = max(nmin_x, rr[0][q]); max_x = max(max_x, rr[1][q]); nmin_y = max(nmin_y, rr[2][q]); max_y = max(max_y, rr[3][q]); }
+            uint32_t* r = hist + (size_t)HS_COPIES * SORT_MAX_PASSES * SORT_BINS + 16 + (size_t)blockIdx.x * 4;
+            *reinterpret_cast<uint4*>(r) = make_uint4(nmin_x, max_x, nmin_y, max_y);
+            // a digit taken relative to a field's minimum (SortPlan::bias) was planned from the PREVIOUS frame's span: a key
+            // outside it voids the frame (the host runs it again with plain digits)
+            if (max_x | max_y | nmin_x | nmin_y) {
+                for (int p = 0; p < P; p++) {
+                    if (!plan.fmask[p]) continue;
+                    const bool is_x = plan.shift[p] == 41;
+                    const uint32_t lo = is_x ? ~nmin_x : ~nmin_y, hi_v = is_x ? max_x : max_y;
+                    if (lo < plan.bias[p] || hi_v - plan.bias[p] > plan.mask[p]) info->plan_bad = 1u;
+                }
+            }
+        }
     }
     if (chunked && C.mask_records) {                                    // one record per workgroup (neutral if it saw no key)
         __shared__ uint32_t red[5][HS_THREADS / 64];
@@ -178,7 +217,6 @@ __global__ __launch_bounds__(HS_THREADS) void k_sort_hist(const uint64_t* __rest
 // ------------------------------------------------------------------------------------------------
 // one digit pass
 // ------------------------------------------------------------------------------------------------
-// exclusive scan of (a, b) over the first RADIX threads of the block; every thread must call.
 // The barriers of k_onesweep's tile loop.  An LDS-only barrier (s_waitcnt lgkmcnt(0) + s_barrier, -DOS_LDS_BARRIER) that lets the
 // scatter stores drain under the next tile was measured: no difference (64.6 vs 65.0 us per pass), so the plain one stays.
 __device__ __forceinline__ void lds_barrier() {
@@ -189,25 +227,32 @@ __device__ __forceinline__ void lds_barrier() {
 #endif
 }
 
+// inclusive scan along the wave by DPP row shifts and broadcasts: six VALU instructions, no LDS crossbar (the __shfl_up form
+// kept six lane addresses alive across the tile loop — spilled at the register cap)
+__device__ __forceinline__ uint32_t os_wave_incl_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+// exclusive scan of `a` over the first RADIX threads of the block; every thread must call
 template <int RADIX>
-__device__ __forceinline__ void scan2_excl(uint32_t& a, uint32_t& b, uint32_t* lds /* 2 * 8 */) {
+__device__ __forceinline__ void scan_excl(uint32_t& a, uint32_t* lds /* 8 */) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint32_t ia = a, ib = b;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t ta = __shfl_up(ia, d, 64), tb = __shfl_up(ib, d, 64);
-        if (lane >= d) { ia += ta; ib += tb; }
-    }
+    const uint32_t ia = os_wave_incl_scan(a);
     if (RADIX > 64) {
-        if (lane == 63 && w < RADIX / 64) { lds[w] = ia; lds[8 + w] = ib; }
+        if (lane == 63 && w < RADIX / 64) lds[w] = ia;
         lds_barrier();
-        uint32_t ba = 0, bb = 0;
+        uint32_t ba = 0;
 #pragma unroll
-        for (int i = 0; i < RADIX / 64; i++) if (i < w) { ba += lds[i]; bb += lds[8 + i]; }
+        for (int i = 0; i < RADIX / 64; i++) if (i < w) ba += lds[i];
         lds_barrier();
-        a = ba + ia - a; b = bb + ib - b;
+        a = ba + ia - a;
     } else {
-        a = ia - a; b = ib - b;
+        a = ia - a;
     }
 }
 
@@ -263,14 +308,14 @@ template <> struct WaveCounters<9> {
 // HI: the digit lies in the key's high word (shift >= 32: the tile_y / tile_x fields, i.e. every pass of a layer-sorted
 // frame) — one 32-bit bit-field extract instead of a 64-bit shift.
 template <bool HI>
-__device__ __forceinline__ uint32_t key_digit(uint64_t key, int shift, uint32_t dmask) {
-    if (HI) return ((uint32_t)(key >> 32) >> (shift - 32)) & dmask;
-    return (uint32_t)(key >> shift) & dmask;
+__device__ __forceinline__ uint32_t key_digit(uint64_t key, int shift, uint32_t dmask, uint32_t bias) {
+    if (HI) return (((uint32_t)(key >> 32) >> (shift - 32)) - bias) & dmask;
+    return ((uint32_t)(key >> shift) - bias) & dmask;
 }
 
 template <int BITS, bool CHUNKED, bool HI>
 __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
-                                                         DevCount nc, int shift, uint32_t dmask,
+                                                         DevCount nc, int shift, uint32_t dmask, uint32_t bias,
                                                          const uint32_t* __restrict__ ghist /* this pass, SORT_BINS per copy */,
                                                          uint32_t* __restrict__ status /* [ntiles][RADIX] */,
                                                          uint32_t* __restrict__ ticket, uint32_t* __restrict__ err,
@@ -295,12 +340,12 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
     // global digit starts = exclusive scan of this pass's histogram (identical in every block)
     uint32_t gstart = 0;
     {
-        uint32_t g = 0, dummy = 0;
+        uint32_t g = 0;
         if (tid < RADIX) {
 #pragma unroll
             for (int c = 0; c < HS_COPIES; c++) g += ghist[(size_t)c * (SORT_MAX_PASSES * SORT_BINS) + tid];
         }
-        scan2_excl<RADIX>(g, dummy, s_scan);
+        scan_excl<RADIX>(g, s_scan);
         gstart = g;
     }
 
@@ -322,10 +367,13 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
 
         uint64_t keys[OS_KPT];
         uint32_t rnk[OS_KPT / 2];                          // 16-bit ranks, two per register
+        // what pads the stream's last tile must land behind every real key of the tile: the LAST digit — with a biased digit
+        // that is not the all-ones key ((~0 >> shift) - bias lands in the middle of the bins)
+        const uint64_t pad = (uint64_t)(dmask + bias) << shift;
 #pragma unroll
         for (int j = 0; j < OS_KPT; j++) {
             uint32_t idx = wbase + j * 64 + lane;
-            keys[j] = idx < n ? in[chunked ? chunk_phys(M, idx) : idx] : ~0ull;   // padding sorts last in stream order, never written
+            keys[j] = idx < n ? in[chunked ? chunk_phys(M, idx) : idx] : pad;      // padding: last digit, last in stream order, never written
         }
 #ifdef SORT_PROF
         if (keys[OS_KPT - 1] == 0x123456789ull) atomicAdd(&g_sort_prof[14], 1ull);      // forces the loads to have landed
@@ -336,7 +384,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
         // the counter back (LDS operations of one wave retire in order): rank = counter - class size + lanes below.
 #pragma unroll
         for (int j = 0; j < OS_KPT; j++) {
-            const uint32_t dg = key_digit<HI>(keys[j], shift, dmask);
+            const uint32_t dg = key_digit<HI>(keys[j], shift, dmask, bias);
             // (peeling the few distinct digits of a row off leader by leader — readlane, compare, mbcnt per class — was
             //  measured slower than this fixed 8-ballot form: 71 vs 61 us per pass, the dependent scalar chain does not pipeline;
             //  so was a run-structured rank — head lanes add their run length with a returning LDS atomic, the others fetch it
@@ -360,8 +408,8 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
             if (tile > 0) lb_st32(&status[(size_t)tile * RADIX + tid], (LB_AGG << 30) | tot);
         }
         {
-            uint32_t a = tot, dummy = 0;
-            scan2_excl<RADIX>(a, dummy, s_scan);
+            uint32_t a = tot;
+            scan_excl<RADIX>(a, s_scan);
             lbase = a;
         }
         if (tid < RADIX) {
@@ -375,7 +423,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
         //      and the staging of waves 4..7 overlaps the global round trips of the look-back lanes ---------------------
 #pragma unroll
         for (int j = 0; j < OS_KPT; j++) {
-            const uint32_t dg = key_digit<HI>(keys[j], shift, dmask);
+            const uint32_t dg = key_digit<HI>(keys[j], shift, dmask, bias);
             staged[whist.get(w, dg) + ((rnk[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu)] = keys[j];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // compiler barrier; this wave's LDS operations retire in order
@@ -419,12 +467,16 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
         if (tid == OS_THREADS - 1) s_tile = atomicAdd(ticket, 1u);
         // ---- coalesced stores: every digit run leaves the CU as one contiguous piece --------------------------------
         const uint32_t nvalid = min((uint32_t)OS_TILE, n - bbase);
+        // (the compiler otherwise hoists the sixteen `j * 1024 + tid` out of the tile loop and, at the register cap, SPILLS them:
+        //  29 scratch round trips per tile in the 512-bin instantiation — recomputing one OR per key is free)
+        uint32_t tid_here = (uint32_t)tid;
+        asm volatile("" : "+v"(tid_here));
 #pragma unroll
         for (int j = 0; j < OS_KPT; j++) {
-            uint32_t i = j * OS_THREADS + tid;
+            uint32_t i = j * OS_THREADS + tid_here;
             if (i < nvalid) {
                 uint64_t key = staged[i];
-                uint32_t dg = key_digit<HI>(key, shift, dmask);
+                uint32_t dg = key_digit<HI>(key, shift, dmask, bias);
                 out[i + s_gdelta[dg]] = key;
             }
         }
@@ -446,6 +498,7 @@ static SortPlan plan_with_width(uint64_t live_mask, int lo_bit, int hi_bit, int 
         while (width > 1 && !((live_mask >> (b + width - 1)) & 1ull)) width--;
         p.shift[p.n_passes] = b;
         p.mask[p.n_passes] = (1u << width) - 1u;
+        p.bias[p.n_passes] = 0; p.fmask[p.n_passes] = 0;
         p.n_passes++;
         b += width;
     }
@@ -462,15 +515,39 @@ SortPlan make_sort_plan(uint64_t live_mask, int lo_bit, int hi_bit, int digit_bi
     return p9.n_passes < p8.n_passes ? p9 : p8;
 }
 
+static int bit_length(uint32_t v) { int n = 0; while (v) { n++; v >>= 1; } return n; }
+
+SortPlan make_segment_sort_plan(uint64_t live44, bool layer_sorted, int digit_bits, const KeyRange* range, bool* biased) {
+    if (biased) *biased = false;
+    uint64_t live = live44;
+    if (layer_sorted) live &= ~0x1FFFFFull;               // a stream already non-decreasing in layer: stable sort by tile alone
+    const SortPlan plain = make_sort_plan(live << 20, 20, 64, digit_bits);
+    if (!range || !range->valid || digit_bits == 4) return plain;
+    if (range->min_x > range->max_x || range->min_y > range->max_y) return plain;
+    // layer digits as before (bits 20..40), then ONE digit per tile field: (field - min) in bit_length(max - min) bits
+    const int bx = bit_length(range->max_x - range->min_x), by = bit_length(range->max_y - range->min_y);
+    const int widest = digit_bits == 8 ? 8 : 9;
+    if (bx > widest || by > widest) return plain;
+    SortPlan p = make_sort_plan((live & 0x1FFFFFull) << 20, 20, 41, digit_bits);
+    if (p.n_passes + 2 > SORT_MAX_PASSES) return plain;
+    if (bx > 0) { const int i = p.n_passes++; p.shift[i] = 41; p.mask[i] = (1u << bx) - 1u; p.bias[i] = range->min_x; p.fmask[i] = 0xFFFu; }
+    if (by > 0) { const int i = p.n_passes++; p.shift[i] = 53; p.mask[i] = (1u << by) - 1u; p.bias[i] = range->min_y; p.fmask[i] = 0x7FFu; }
+    if (p.n_passes >= plain.n_passes) return plain;       // (only where it saves a pass: plain digits do not depend on the span)
+    if (biased) *biased = true;
+    return p;
+}
+
 uint32_t sort_hist_blocks(size_t n) {
     uint32_t hb = (uint32_t)((n + HS_TILE - 1) / HS_TILE);
     return hb > 2048 ? 2048u : hb;                        // few workgroups: the final flush is bins x passes global atomics each
 }
 
-static inline size_t sort_fixed_words() { return (size_t)HS_COPIES * SORT_MAX_PASSES * SORT_BINS + 64; }
+// [histograms] [tickets: 16 words] [tile-field spans: one 4-word record per k_sort_hist workgroup, <= 2048]
+static inline size_t sort_fixed_words() { return (size_t)HS_COPIES * SORT_MAX_PASSES * SORT_BINS + 16 + 2048 * 4; }
+const uint32_t* sort_range_words(const uint32_t* scratch) { return scratch + (size_t)HS_COPIES * SORT_MAX_PASSES * SORT_BINS + 16; }
 size_t sort_scratch_words(size_t n) {
     size_t ntiles = (n + OS_TILE - 1) / OS_TILE;
-    // [hist: HS_COPIES x MAX_PASSES x SORT_BINS] [tickets: MAX_PASSES] [pad to 64] [status: MAX_PASSES * ntiles * SORT_BINS]
+    // [hist: HS_COPIES x MAX_PASSES x SORT_BINS] [tickets: MAX_PASSES, pad to 16] [tile-field spans: 2048 x 4] [status: MAX_PASSES * ntiles * SORT_BINS]
     return sort_fixed_words() + (size_t)SORT_MAX_PASSES * (ntiles + 1) * SORT_BINS;
 }
 // the words of the scratch a sort of `n` keys with this plan expects to be zero when it starts (histograms, tickets, the
@@ -490,7 +567,7 @@ const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a
     const uint32_t ntiles = (uint32_t)((n + OS_TILE - 1) / OS_TILE);
     uint32_t* hist = scratch;
     uint32_t* tickets = scratch + (size_t)HS_COPIES * SORT_MAX_PASSES * SORT_BINS;
-    uint32_t* status = tickets + 64;
+    uint32_t* status = scratch + sort_fixed_words();
     const int P = plan.n_passes;
     // zero hist + tickets + the status words of the passes that run (re-initialised every call)
     if (!scratch_is_zero) (void)hipMemsetAsync(scratch, 0, sort_zero_words(n, plan) * 4, s);
@@ -512,7 +589,7 @@ const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a
         // end timestamps, what a profiler reports as the kernel's duration) instead of markers in front of and behind it
         hipEvent_t e0 = pass_ev0 ? pass_ev0[p] : nullptr, e1 = pass_ev1 ? pass_ev1[p] : nullptr;
 #define OS_LAUNCH(B, CH, HI_) hipExtLaunchKernelGGL((k_onesweep<B, CH, HI_>), dim3(grid), dim3(OS_THREADS), 0, s, e0, e1, 0, src, dst, nc, \
-                                           plan.shift[p], plan.mask[p], (const uint32_t*)(hist + p * SORT_BINS), st, tickets + p, err, ch ? C : C0)
+                                           plan.shift[p], plan.mask[p], plan.bias[p], (const uint32_t*)(hist + p * SORT_BINS), st, tickets + p, err, ch ? C : C0)
 #define OS_LAUNCH_B(B) do { if (ch) { if (hi) OS_LAUNCH(B, true, true); else OS_LAUNCH(B, true, false); } \
                             else { if (hi) OS_LAUNCH(B, false, true); else OS_LAUNCH(B, false, false); } } while (0)
         if (digit_bits == 4) OS_LAUNCH_B(4);

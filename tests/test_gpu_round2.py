@@ -61,6 +61,53 @@ def test_sort_9bit_digits_10m_keys(ctx):
     assert np.array_equal(ctx.sort_array(v, digit_bits=9), ref)
 
 
+def test_value_range_digits_on_a_power_of_two_canvas(monkeypatch):
+    """A canvas of 2^k tiles uses the values 1 .. 2^k of a key field that stores tile + 1: k + 1 live bits for ONE value, and at
+    4096 x 4096 (256 tiles: 9 + 9 live bits) that costs a third digit pass.  Read-back-free frames sort by (field - its minimum
+    on the previous frame) in two passes; k_sort_hist checks the keys against that span and voids a frame that leaves it (a
+    shape that moves left of the canvas stores tile_x + 1 = 0): the re-run and every later frame use plain digits.  Stream and
+    image equal the oracle's throughout.  (Eight-bit digits forced: with nine-bit ones 9 + 9 bits are two passes anyway; the
+    8192 x 8192 canvas of BASELINE config 4 — 10 + 10 bits — is where the default plan gains, tests/test_gpu_parity.py.)"""
+    W = H = 4096
+    rng = np.random.default_rng(41)
+    comp = S.Composition()
+    order = 0
+    for k in range(160):
+        x, y = float(rng.uniform(0, W - 220)), float(rng.uniform(0, H - 220))
+        comp.get_mut_or_insert_default(order).insert(S.custom_circle(x + 100, y + 100, float(rng.uniform(20, 100)))).set_props(
+            S.solid(tuple(float(v) for v in rng.random(3)) + (1.0,)))
+        order += 1
+    # shapes in the last tile column and row (tile 255: field value 256 = bit 8) and in the first ones
+    for (x0, y0, x1, y1) in ((4060, 10, 4095.5, 300), (10, 4060, 400, 4095.5), (4000, 4000, 4095.9, 4095.9), (0.5, 0.5, 40, 40)):
+        comp.get_mut_or_insert_default(order).insert(S.custom_square(x0, y0, x1, y1)).set_props(S.solid((0.2, 0.4, 0.6, 1.0)))
+        order += 1
+    import forma_amd
+    monkeypatch.setenv("FORMA_HIP_DEBUG", "digit_bits=8")              # (with nine-bit digits this canvas needs no help: 9 + 9 bits; 8192 x 8192 does)
+    ctx = forma_amd.Context(0)
+    o, t = both(ctx, comp)
+    want = o.render(W, H)
+    passes = []
+    for frame in range(5):
+        img, tm = ctx.render(W, H, timings=True)
+        passes.append(int(tm["n_sort_passes"]))
+        assert np.array_equal(ctx.segments(1), o.segments(1)), frame
+        assert np.abs(want.astype(int) - img.astype(int)).max() <= 1, frame
+    assert passes[0] == 3 and passes[-1] == 2, passes                  # plain digits on the synchronous frame, then the span is known
+    # the last layer moves left of the canvas: its segments store tile_x + 1 = 0, below the span the digits were planned for
+    g = t["geoms"].copy()
+    last = g["order"] == order - 1
+    g["flags"][last] = 1
+    g["xf"][last] = np.array([1.0, 0.0, 0.0, 1.0, -30.0, 0.0], np.float32)
+    o.set_geoms(g); ctx.set_geoms(g)
+    want = o.render(W, H)
+    for frame in range(4):
+        img, tm = ctx.render(W, H, timings=True)
+        assert np.array_equal(ctx.segments(1), o.segments(1)), ("moved", frame)
+        assert np.abs(want.astype(int) - img.astype(int)).max() <= 1, ("moved", frame)
+        assert int(tm["n_sort_passes"]) == 3, (frame, tm["n_sort_passes"])
+    ctx.close()
+
+
 @pytest.mark.parametrize("bits", [0, 4, 8, 9])
 def test_sort_coherent_streams(ctx, bits):
     """what a rasterizer emits: long runs of equal tile digits, the same digit coming back within one wave row of 64 keys
