@@ -79,6 +79,9 @@ SYMBOLS = {
     "forma_hip_sort": (_i, [_vp, _vp, _sz, _i]),
     "forma_hip_paint": (_i, [_vp, _vp, _sz, _vp, _u32, _u32, _sz, _vp, _vp, _vp]),
     "forma_hip_render": (_i, [_vp, _vp, _u32, _u32, _sz, _vp, _vp, _vp, _i, _vp]),
+    "forma_hip_render_enqueue": (_i, [_vp, _vp, _u32, _u32, _sz, _vp, _vp, _vp]),
+    "forma_hip_register_buffer": (_i, [_vp, _vp, _sz]),
+    "forma_hip_unregister_buffer": (_i, [_vp, _vp]),
     "forma_hip_cache_clear": (_i, [_vp, _i]),
     "forma_hip_set_frames_in_flight": (_i, [_vp, _i]),
     "forma_hip_sync": (_i, [_vp]),

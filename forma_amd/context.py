@@ -149,6 +149,22 @@ class Context:
             return dst, t.as_dict()
         return dst
 
+    def render_enqueue(self, width, height, dst, channels=(0, 1, 2, 3), clear=(1, 1, 1, 0), crop=None, stride=None):
+        """forma_hip_render_enqueue: the frame AND its copy into `dst` are enqueued on the next frame slot; `dst` is complete after
+        sync() or after frames_in_flight further enqueues"""
+        stride = stride or width * 4
+        ch = np.asarray(channels, np.uint8); cl = np.asarray(clear, np.float32)
+        rect = None if crop is None else RectT(*crop)
+        self._check(self._L.forma_hip_render_enqueue(self._h, _p(dst), width, height, stride, _p(ch), _p(cl),
+                                                     None if rect is None else C.addressof(rect)))
+
+    def register_buffer(self, arr):
+        """forma_hip_register_buffer: page-lock a numpy buffer the renderer writes often (keep it alive until unregister / close)"""
+        self._check(self._L.forma_hip_register_buffer(self._h, _p(arr), arr.nbytes))
+
+    def unregister_buffer(self, arr):
+        self._check(self._L.forma_hip_unregister_buffer(self._h, _p(arr)))
+
     def cache_clear(self, cache_id):                    # BufferLayerCache::clear
         self._check(self._L.forma_hip_cache_clear(self._h, cache_id))
 

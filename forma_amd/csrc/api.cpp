@@ -356,6 +356,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     }
     SpanGroups groups{nullptr, nullptr, 0u, 0u};
     const uint32_t n_groups = (tiles_w + SPAN_GROUP_TILES - 1u) >> SPAN_GROUP_SHIFT;
+    const uint64_t* sorted_keys = ctx->rk_u.as<uint64_t>();
     if (jc.bound > 0) {
         const size_t jb = jc.bound;
         HIPCHECK(ctx->span_key.ensure(jb * 8));
@@ -370,7 +371,6 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
             HIPCHECK(ctx->grp_list.ensure(pool * sizeof(uint4)));
             groups = SpanGroups{ctx->grp_tab.as<uint2>(), ctx->grp_list.as<uint4>(), (uint32_t)pool, ctx->force_span_groups ? 0u : SPAN_GROUP_MIN_ROW};
         }
-        const uint64_t* sorted_keys = ctx->rk_u.as<uint64_t>();
         if (!local_sort) {
             HIPCHECK(ctx->rk_a.ensure(jb * 8));
             HIPCHECK(ctx->rk_b.ensure(jb * 8));
@@ -384,30 +384,15 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                                             ctx->sort_counters.as<uint32_t>(), &dinfo->error, nullptr, nullptr);
             ctx->pz.sort_p = nullptr;
         }
-        if (ctx->force_slices) n_slices = ctx->force_slices;  // FORMA_HIP_CARRY_SLICES (tests: every slice count on one GPU)
-        uint32_t bin_shift = 0;                             // 256 layer bins over the orders in use
-        while (bin_shift < 16 && (((uint64_t)std::max<size_t>(ctx->n_orders, 1) - 1) >> bin_shift) > 255) bin_shift++;
+        if (ctx->force_slices) n_slices = ctx->force_slices;  // FORMA_HIP_DEBUG=carry_slices (tests: every slice count on one GPU)
         ctx->cur_slices = n_slices; ctx->cur_small = small;
-        launch_carry_rows(ctx->stream, local_sort, small, n_slices, bin_shift, sorted_keys, ctx->records.as<TileRecord>(),
-                          ctx->blk_edge.as<BlkEdge>(), nc, jc, ctx->layer_sf.as<uint32_t>(),
-                          (uint32_t)ctx->n_orders, tiles_w, tiles_h, row_count, row_span_lo,
-                          row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(),
-                          (a.cache_id >= 0 && ctx->have_unchanged) ? ctx->unchanged.as<uint8_t>() : nullptr, dinfo,
-                          runs_edge_segments(),
-                          // invisible carries of a partial last tile row are dropped only when nothing can observe them: with a
-                          // buffer-layer cache the layer count of a tile is state (passes/tile_unchanged.rs)
-                          // ... nor when the channel order tells a folded tile from a painted one: the solid fold encodes output
-                          // bytes 0..2 as sRGB and passes byte 3 through (to_srgb_bytes of the SELECTED channels, painter/mod.rs:
-                          // 156-162, 692), a painted tile encodes r, g, b and then selects (compute_srgb, :466-483) — the same bytes
-                          // unless alpha lands in bytes 0..2 or a colour in byte 3, and an invisible layer can block the fold
-                          (a.cache_id < 0 && (a.height & 15u) && fold_equals_paint) ? (a.height & 15u) : 16u, crow0, crow1, groups, ctx->run_lt.as<uint32_t>(),
-                          (a.cache_id >= 0 || !fold_equals_paint) ? (a.crop ? a.crop->x0 / 16 : 0u) : 0xFFFFFFFFu);
     } else {
         HIPCHECK(ctx->span_key.ensure(8));
         HIPCHECK(ctx->span_cov.ensure(16));
     }
-    stage_end(ctx, ST_CARRY, timing);
-    ctx->last_runs = J; ctx->last_entries = 0;
+    ctx->image_sent = false;
+    uint32_t bin_shift = 0;                               // 256 layer bins over the orders in use
+    while (bin_shift < 16 && (((uint64_t)std::max<size_t>(ctx->n_orders, 1) - 1) >> bin_shift) > 255) bin_shift++;
 
     PaintParams P;
     P.width = a.width; P.height = a.height; P.tiles_w = tiles_w; P.tiles_h = tiles_h;
@@ -425,16 +410,33 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     P.clear_unchanged = clear_unchanged;
     P.n_slices = jc.bound > 0 ? n_slices : 1u;             // (no runs: the carry pre-pass did not run, the zeroed tables say "no spans")
     P.n_groups = n_groups;
+    // the (empty) k_paint_deep launch costs ~5 us of every frame: a read-back-free frame without a cache skips it when the
+    // last verified frame had no deep tile; a tile that needs it then voids the frame (re-run in full)
+    const bool launch_deep = !(bound_j != 0 && a.cache_id < 0 && ctx->pred_no_deep);
+    if (jc.bound > 0)
+        launch_carry_rows(ctx->stream, local_sort, small, n_slices, bin_shift, sorted_keys, ctx->records.as<TileRecord>(),
+                          ctx->blk_edge.as<BlkEdge>(), nc, jc, ctx->layer_sf.as<uint32_t>(),
+                          (uint32_t)ctx->n_orders, tiles_w, tiles_h, row_count, row_span_lo,
+                          row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(),
+                          (a.cache_id >= 0 && ctx->have_unchanged) ? ctx->unchanged.as<uint8_t>() : nullptr, dinfo,
+                          runs_edge_segments(),
+                          // invisible carries of a partial last tile row are dropped only when nothing can observe them: with a
+                          // buffer-layer cache the layer count of a tile is state (passes/tile_unchanged.rs)
+                          // ... nor when the channel order tells a folded tile from a painted one: the solid fold encodes output
+                          // bytes 0..2 as sRGB and passes byte 3 through (to_srgb_bytes of the SELECTED channels, painter/mod.rs:
+                          // 156-162, 692), a painted tile encodes r, g, b and then selects (compute_srgb, :466-483) — the same bytes
+                          // unless alpha lands in bytes 0..2 or a colour in byte 3, and an invisible layer can block the fold
+                          (a.cache_id < 0 && (a.height & 15u) && fold_equals_paint) ? (a.height & 15u) : 16u, crow0, crow1, groups, ctx->run_lt.as<uint32_t>(),
+                          (a.cache_id >= 0 || !fold_equals_paint) ? (a.crop ? a.crop->x0 / 16 : 0u) : 0xFFFFFFFFu);
+    stage_end(ctx, ST_CARRY, timing);
     stage_begin(ctx, ST_PAINT, timing);
     launch_paint(ctx->stream, P, ctx->sorted, ctx->records.as<TileRecord>(), jc, tile_first_run, row_span_lo,
                  row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(), ctx->layer_col.as<uint4>(),
                  ctx->style_off.as<uint32_t>(),
                  ctx->style_words.as<uint32_t>(), ctx->images.as<forma_image_t>(), ctx->texels.as<uint16_t>(),
-                 ctx->cur_image, tc, dinfo, paint_overflow, overflow_list, over2_n, over2_list,
-                 // the (empty) k_paint_deep launch costs ~5 us of every frame: a read-back-free frame without a cache skips it
-                 // when the last verified frame had no deep tile; a tile that needs it then voids the frame (re-run in full)
-                 /*launch_deep=*/!(bound_j != 0 && a.cache_id < 0 && ctx->pred_no_deep), groups);
+                 ctx->cur_image, tc, dinfo, paint_overflow, overflow_list, over2_n, over2_list, launch_deep, groups);
     stage_end(ctx, ST_PAINT, timing);
+    ctx->last_runs = J; ctx->last_entries = 0;
     HIPCHECK(hipGetLastError());
     // what a later launch_paint_huge needs (tiles deeper than the painter's LDS lists: finish_paint)
     ctx->huge = forma_hip_ctx::HugeArgs{P, jc, tc, tile_first_run, row_span_lo, row_span_cnt, over2_n, over2_list, T};
@@ -482,10 +484,22 @@ int finish_paint(forma_hip_ctx* ctx) {
     return FORMA_OK;
 }
 
+// rows [py0, py1) x pixels [px0, px1) of the frame's device image -> the caller's buffer.  Whole rows without padding on
+// either side are ONE linear copy (the DMA engine's best case); anything else is a pitched copy.
+int copy_rows_out(forma_hip_ctx* ctx, hipStream_t s, uint8_t* dst, size_t stride, size_t px0, size_t px1, size_t py0, size_t py1, uint32_t width) {
+    const size_t pitch = (size_t)width * 4;
+    if (stride == pitch && px0 == 0 && px1 == width)
+        HIPCHECK(hipMemcpyAsync(dst + py0 * stride, ctx->cur_image + py0 * pitch, (py1 - py0) * pitch, hipMemcpyDeviceToHost, s));
+    else
+        HIPCHECK(hipMemcpy2DAsync(dst + py0 * stride + px0 * 4, stride, ctx->cur_image + py0 * pitch + px0 * 4, pitch, (px1 - px0) * 4,
+                                  py1 - py0, hipMemcpyDeviceToHost, s));
+    return FORMA_OK;
+}
+
 // Copy what the frame wrote into the caller's buffer — and nothing else: tiles outside the crop, and with a buffer-layer
 // cache the tiles the painter skipped (TileWriteOp::None), keep whatever the caller's buffer holds (reference
 // cpu/buffer/layout/mod.rs:264-295 writes tile by tile; forma/src/cpu/buffer/mod.rs doc test "skipped rendering").
-int copy_image_out(forma_hip_ctx* ctx, uint8_t* dst, size_t stride, bool timing, const PaintArgs& a) {
+int copy_image_out(forma_hip_ctx* ctx, uint8_t* dst, size_t stride, bool timing, const PaintArgs& a, bool already_there = false) {
     const uint32_t tiles_w = (a.width + 15) / 16, tiles_h = (a.height + 15) / 16;
     uint32_t tx0 = 0, tx1 = tiles_w, ty0 = 0, ty1 = tiles_h;
     if (a.crop) {
@@ -498,13 +512,13 @@ int copy_image_out(forma_hip_ctx* ctx, uint8_t* dst, size_t stride, bool timing,
     if (!dst) return FORMA_OK;
     if (tx0 >= tx1 || ty0 >= ty1) return FORMA_OK;
     ctx->last_written = (tx1 - tx0) * (ty1 - ty0);
+    if (already_there) return FORMA_OK;                    // (a deferred frame into caller memory: the image left behind the frame's kernels)
     const size_t px0 = (size_t)tx0 * 16, px1 = std::min<size_t>((size_t)tx1 * 16, a.width);
     const size_t py0 = (size_t)ty0 * 16, py1 = std::min<size_t>((size_t)ty1 * 16, a.height);
     const size_t pitch = (size_t)a.width * 4;
     stage_begin(ctx, ST_D2H, timing);
     if (a.cache_id < 0) {
-        HIPCHECK(hipMemcpy2DAsync(dst + py0 * stride + px0 * 4, stride, ctx->cur_image + py0 * pitch + px0 * 4, pitch,
-                                  (px1 - px0) * 4, py1 - py0, hipMemcpyDeviceToHost, ctx->stream));
+        { const int rc = copy_rows_out(ctx, ctx->stream, dst, stride, px0, px1, py0, py1, a.width); if (rc) return rc; }
         stage_end(ctx, ST_D2H, timing);
         return FORMA_OK;
     }
@@ -534,8 +548,7 @@ int copy_image_out(forma_hip_ctx* ctx, uint8_t* dst, size_t stride, bool timing,
     for (uint32_t ty = ty0; ty < ty1; ty++) for (uint32_t tx = tx0; tx < tx1; tx++) n_written += ctx->h_written[(size_t)ty * tiles_w + tx] ? 1 : 0;
     ctx->last_written = (uint32_t)n_written;
     if (n_written == n_crop) {                                         // everything was painted: one strided copy
-        HIPCHECK(hipMemcpy2DAsync(dst + py0 * stride + px0 * 4, stride, ctx->cur_image + py0 * pitch + px0 * 4, pitch,
-                                  (px1 - px0) * 4, py1 - py0, hipMemcpyDeviceToHost, ctx->stream));
+        { const int rc = copy_rows_out(ctx, ctx->stream, dst, stride, px0, px1, py0, py1, a.width); if (rc) return rc; }
     } else if (n_written && n_written <= max_pack) {                   // the packed tiles, then each into its place
         const size_t bytes = n_written * 1024;
         if (ctx->h_stage_cap < bytes) {
@@ -738,6 +751,7 @@ void forma_hip_destroy(forma_hip_ctx* ctx) {
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
     for (auto& c : ctx->caches) { c.tiles.release(); c.image.release(); }
     ctx->cache_written.release();
+    for (auto& r : ctx->registered) (void)hipHostUnregister(r.first);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1078,8 +1092,11 @@ int complete_async_frame(forma_hip_ctx* ctx, const PaintArgs& a, uint8_t* dst, s
     }
     ctx->pred_N = N; ctx->pred_J = J; ctx->pred_max_row = ctx->h_info->max_row_runs;
     int rc;
+    // (a deferred frame's image left speculatively behind its kernels; tiles that k_paint_huge paints only now: the crop is
+    //  copied again)
+    const bool in_place = ctx->image_sent && !(ctx->h_info->error & 8u);
     if ((rc = finish_paint(ctx))) return rc;
-    if ((rc = copy_image_out(ctx, dst, stride_bytes, timing, a))) return rc;
+    if ((rc = copy_image_out(ctx, dst, stride_bytes, timing, a, in_place))) return rc;
     if (dst) HIPCHECK(hipStreamSynchronize(ctx->stream));
     rc = finish_frame(ctx, timings, true);
     frame_done(ctx, rc, a);
@@ -1130,8 +1147,8 @@ int settle_slot(forma_hip_ctx* sl) {
     HIPCHECK(hipSetDevice(sl->device));
     const forma_hip_ctx::Deferred& d = sl->def;
     PaintArgs a{d.width, d.height, d.channels, d.clear, d.has_crop ? &d.crop : nullptr, -1};
-    int rc = complete_async_frame(sl, a, nullptr, 0, false, nullptr, d.bN, d.bJ);
-    if (rc == FORMA_RETRY) rc = render_sync(sl, a, nullptr, 0, false, nullptr);
+    int rc = complete_async_frame(sl, a, d.dst, d.stride, false, nullptr, d.bN, d.bJ);
+    if (rc == FORMA_RETRY) rc = render_sync(sl, a, d.dst, d.stride, false, nullptr);
     return rc;
 }
 
@@ -1172,9 +1189,9 @@ void invalidate_counts(forma_hip_ctx* o) {                 // new geometry / ban
 
 extern "C" {
 
-int forma_hip_render(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t height, size_t stride_bytes,
-                     const uint8_t channels[4], const float clear_color[4], const forma_rect_t* crop_or_null, int cache_id,
-                     forma_timings_t* timings) {
+static int render_impl(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t height, size_t stride_bytes,
+                       const uint8_t channels[4], const float clear_color[4], const forma_rect_t* crop_or_null, int cache_id,
+                       forma_timings_t* timings, bool defer_dst) {
     if (!ctx) return FORMA_E_ARG;
     int rc = check_paint_args(ctx, dst, width, height, stride_bytes, channels, clear_color);
     if (rc) return rc;
@@ -1185,8 +1202,9 @@ int forma_hip_render(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t 
     // Several frames in flight: a device-resident frame without a cache is ENQUEUED on the next slot and this call returns;
     // it is verified (and, if a prediction failed, re-run) when the slot is needed again or when any call needs its result.
     // Frames that write caller memory, use a buffer-layer cache (frame k + 1 reads what frame k left in it) or ask for
-    // timings keep the synchronous contract of the reference: `dst` is fully written when the call returns.
-    if (ctx->slots.size() > 1 && !dst && cache_id < 0 && !timings) {
+    // timings keep the synchronous contract of the reference: `dst` is fully written when the call returns — unless the
+    // caller asked for the deferred form (forma_hip_render_enqueue): then the image also travels while later frames run.
+    if (ctx->slots.size() > 1 && (!dst || defer_dst) && cache_id < 0 && !timings) {
         forma_hip_ctx* sl = ctx->slots[ctx->next_slot++ % ctx->slots.size()];
         if ((rc = settle_slot(sl))) { if (sl != ctx) memcpy(ctx->err, sl->err, sizeof ctx->err); return rc; }
         ctx->last = sl;
@@ -1196,11 +1214,18 @@ int forma_hip_render(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t 
             forma_hip_ctx::Deferred& d = sl->def;
             d.width = width; d.height = height; memcpy(d.channels, channels, 4); memcpy(d.clear, clear_color, 16);
             d.has_crop = crop_or_null != nullptr; if (crop_or_null) d.crop = *crop_or_null;
+            d.dst = dst; d.stride = stride_bytes;
             PaintArgs as{width, height, d.channels, d.clear, d.has_crop ? &d.crop : nullptr, -1};
             rc = enqueue_async_frame(sl, as, false, &d.bN, &d.bJ);
             if (rc == FORMA_OK) sl->pending = true;
+            if (rc == FORMA_OK && dst) {
+                // the image leaves speculatively, in one piece behind the frame's kernels (verified at settle time; a void frame
+                // is run again into `dst`): it crosses PCIe while the NEXT frames are rasterized, sorted and painted
+                rc = copy_image_out(sl, dst, stride_bytes, false, as);
+                sl->image_sent = rc == FORMA_OK;
+            }
         } else {
-            rc = render_sync(sl, a, nullptr, 0, false, nullptr);
+            rc = render_sync(sl, a, dst, stride_bytes, false, nullptr);
         }
         if (rc && sl != ctx) memcpy(ctx->err, sl->err, sizeof ctx->err);
         return rc;
@@ -1208,6 +1233,42 @@ int forma_hip_render(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t 
     if ((rc = fd_drain(ctx))) return rc;
     ctx->last = ctx;
     return render_on(ctx, dst, a, stride_bytes, timings);
+}
+
+int forma_hip_render(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t height, size_t stride_bytes,
+                     const uint8_t channels[4], const float clear_color[4], const forma_rect_t* crop_or_null, int cache_id,
+                     forma_timings_t* timings) {
+    return render_impl(ctx, dst, width, height, stride_bytes, channels, clear_color, crop_or_null, cache_id, timings, false);
+}
+
+int forma_hip_render_enqueue(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t height, size_t stride_bytes,
+                             const uint8_t channels[4], const float clear_color[4], const forma_rect_t* crop_or_null) {
+    return render_impl(ctx, dst, width, height, stride_bytes, channels, clear_color, crop_or_null, -1, nullptr, true);
+}
+
+// Caller buffers the renderer writes often (a window's frame buffer): page-locked once, the device-to-host copies into them are
+// truly asynchronous and run at the link's rate; memory HIP does not know is pinned and unpinned by the runtime on every copy.
+int forma_hip_register_buffer(forma_hip_ctx* ctx, void* ptr, size_t bytes) {
+    if (!ctx || !ptr || !bytes) return FORMA_E_ARG;
+    forma_hip_ctx* k = ctx->multi ? multi_first(ctx) : ctx;
+    HIPCHECK(hipSetDevice(k->device));
+    for (auto& r : k->registered) if (r.first == ptr) return fail(ctx, FORMA_E_STATE, "buffer already registered");
+    const hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterPortable);
+    if (e != hipSuccess) return fail(ctx, FORMA_E_HIP, "hipHostRegister", e);
+    k->registered.emplace_back(ptr, bytes);
+    return FORMA_OK;
+}
+int forma_hip_unregister_buffer(forma_hip_ctx* ctx, void* ptr) {
+    if (!ctx || !ptr) return FORMA_E_ARG;
+    { const int rc = forma_hip_sync(ctx); if (rc) return rc; }           // (nothing may still be on its way into it)
+    forma_hip_ctx* k = ctx->multi ? multi_first(ctx) : ctx;
+    for (size_t i = 0; i < k->registered.size(); i++)
+        if (k->registered[i].first == ptr) {
+            (void)hipHostUnregister(ptr);
+            k->registered.erase(k->registered.begin() + (long)i);
+            return FORMA_OK;
+        }
+    return fail(ctx, FORMA_E_ARG, "buffer was not registered");
 }
 
 int forma_hip_set_frames_in_flight(forma_hip_ctx* ctx, int n) {

@@ -96,6 +96,8 @@ struct forma_hip_ctx {
     size_t h_written_cap = 0;
     uint8_t* h_stage = nullptr;             // pinned staging image for tile-granular copy-out
     size_t h_stage_cap = 0;
+    bool image_sent = false;                // a deferred frame into caller memory: its image left behind the kernels, before the frame was verified
+    std::vector<std::pair<void*, size_t>> registered;   // caller buffers pinned by forma_hip_register_buffer
     int cur_cache = -1;                     // cache of the frame in flight
     uint8_t* cur_image = nullptr;           // device image of the frame in flight / last frame
     // sort-plan speculation: the varying-bit mask and the layer-sortedness of a scene rarely change between frames, so
@@ -142,6 +144,7 @@ struct forma_hip_ctx {
     forma_hip_ctx* last = nullptr;          // the slot that holds the most recent frame (inspection calls read it)
     bool pending = false;                   // this slot holds an enqueued frame nobody has verified yet
     struct Deferred {
+        uint8_t* dst = nullptr; size_t stride = 0;           // forma_hip_render_enqueue: the frame also travels to caller memory
         uint32_t width = 0, height = 0, bN = 0, bJ = 0;
         uint8_t channels[4] = {0, 1, 2, 3};
         float clear[4] = {0, 0, 0, 0};

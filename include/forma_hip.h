@@ -226,6 +226,22 @@ int forma_hip_render(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t 
                      size_t stride_bytes, const uint8_t channels[4],
                      const float clear_color[4], const forma_rect_t* crop_or_null,
                      int cache_id, forma_timings_t* timings);
+/* forma_hip_render into caller memory WITHOUT waiting for the frame.  With n > 1 frame slots (forma_hip_set_frames_in_flight)
+ * the frame — kernels AND the copy of its rows into `dst`, band by band under the painters — is enqueued on the next slot and the
+ * call returns: the 33 MB of a 4K frame cross PCIe while the next frames are rasterized, sorted and painted.  `dst` is complete
+ * (and must not be touched before) once forma_hip_sync has returned or n further frames have been enqueued; a host that shows
+ * frames hands over n + 1 buffers in turn.  Register the buffers (below): a copy into pageable memory holds the calling thread
+ * until it is done and nothing overlaps.  With one frame slot, on a multi-device context, the call is forma_hip_render.
+ * (The reference's render is synchronous, cpu/renderer.rs:75-84: this is the one place where the drop-in offers more, and the
+ * shim keeps `render` itself on forma_hip_render.) */
+int forma_hip_render_enqueue(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t height,
+                             size_t stride_bytes, const uint8_t channels[4],
+                             const float clear_color[4], const forma_rect_t* crop_or_null);
+/* Page-lock a caller buffer the renderer writes often (hipHostRegister): copies into it are asynchronous and run at the
+ * link's rate.  The caller keeps the memory alive until forma_hip_unregister_buffer (which waits for frames in flight) or
+ * forma_hip_destroy. */
+int forma_hip_register_buffer(forma_hip_ctx* ctx, void* ptr, size_t bytes);
+int forma_hip_unregister_buffer(forma_hip_ctx* ctx, void* ptr);
 /* Drop a cache's tile state (BufferLayerCache::clear, buffer/mod.rs:189-196). */
 int forma_hip_cache_clear(forma_hip_ctx* ctx, int cache_id);
 

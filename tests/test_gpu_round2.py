@@ -369,3 +369,90 @@ def test_bad_texture_index_and_style_offsets_are_rejected(ctx):
     S.load(ctx, t)
     S.load(o, t)
     assert np.array_equal(ctx.render(64, 64), o.render(64, 64))
+
+
+# ---- frames into caller memory ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("crop", [None, (37, 500, 130, 1333)])
+def test_frames_into_caller_memory_strided_and_registered(crop):
+    """`dst` is complete when render returns (cpu/buffer/mod.rs:43-49), pixels outside the crop are untouched; a strided
+    destination and a registered (page-locked) one receive the same bytes"""
+    import forma_amd
+    W, H = 560, 1400                                                   # 88 tile rows, the last one partial
+    o = orc.Oracle()
+    t = S.random_mixed(n=500, width=W, height=H, seed=61).tables(o)
+    S.load(o, t)
+    c = forma_amd.Context(0)
+    S.load(c, t)
+    for frame in range(4):                                             # synchronous first, then read-back-free frames
+        clear = (0.1 * frame, 0.3, 0.5, 1.0)
+        want = o.render(W, H, clear=clear, crop=crop, dst=np.full((H, W * 4), 77, np.uint8))
+        got = c.render(W, H, clear=clear, crop=crop, dst=np.full((H, W * 4), 77, np.uint8))
+        assert np.abs(want.astype(int) - got.astype(int)).max() <= 1, frame
+    assert np.array_equal(c.segments(1), o.segments(1))
+    wide = np.full((H, W * 4 + 64), 5, np.uint8)
+    c.register_buffer(wide)
+    c.render(W, H, dst=wide, stride=W * 4 + 64)
+    assert np.abs(wide[:, :W * 4].astype(int) - o.render(W, H).astype(int)).max() <= 1 and (wide[:, W * 4:] == 5).all()
+    c.unregister_buffer(wide)
+    c.close()
+
+
+def test_render_enqueue_and_tiles_deeper_than_the_painters_lists():
+    """a deferred frame's image leaves behind its kernels, before the frame is verified; tiles that only k_paint_huge can paint
+    (lists in global memory, sized by the host at settle time) are painted after that: the crop is copied again and the caller
+    sees the finished image"""
+    import forma_amd
+    W, H = 64, 256
+    comp = S.Composition()
+    for i in range(4300):                                              # beyond k_paint_deep's 4096-entry lists
+        comp.get_mut_or_insert_default(i).insert(S.custom_square(8, 100, 40, 130)).set_props(S.solid((0.5, 0.4, 0.3, 0.01)))
+    for i in range(4300, 4310):
+        comp.get_mut_or_insert_default(i).insert(S.custom_circle(32, 20 + 22 * (i - 4300), 18)).set_props(S.solid((0.1, 0.6, 0.9, 0.7)))
+    o = orc.Oracle()
+    t = comp.tables(o)
+    S.load(o, t)
+    want = o.render(W, H)
+    c = forma_amd.Context(0, frames_in_flight=2)
+    S.load(c, t)
+    bufs = [np.zeros((H, W * 4), np.uint8) for _ in range(3)]
+    for k in range(7):
+        c.render_enqueue(W, H, bufs[k % 3])
+    c.sync()
+    for b in bufs:
+        assert np.abs(want.astype(int) - b.astype(int)).max() <= 1
+    c.close()
+
+
+def test_render_enqueue_into_registered_buffers():
+    """forma_hip_render_enqueue: frame AND copy are enqueued on the next frame slot; a buffer is complete once `frames in flight`
+    further frames have been enqueued, or after sync — three buffers in turn, scene changes in between"""
+    import forma_amd
+    W, H = 640, 1100
+    o = orc.Oracle()
+    t = S.random_mixed(n=300, width=W, height=H, seed=62).tables(o)
+    S.load(o, t)
+    c = forma_amd.Context(0, frames_in_flight=2)
+    S.load(c, t)
+    bufs = [np.zeros((H, W * 4), np.uint8) for _ in range(3)]
+    for b in bufs:
+        c.register_buffer(b)
+    clears = [(1, 1, 1, 1), (0.2, 0.3, 0.4, 1.0), (0, 0, 0, 0), (0.5, 0.1, 0.9, 0.5)]
+    wants = [o.render(W, H, clear=cl) for cl in clears]
+    shown = 0
+    for k in range(14):
+        c.render_enqueue(W, H, bufs[k % 3], clear=clears[k % 4])
+        if k >= 2:                                                     # two frames were enqueued behind frame k - 2: its buffer is done
+            j = k - 2
+            assert np.abs(bufs[j % 3].astype(int) - wants[j % 4].astype(int)).max() <= 1, j
+            shown += 1
+    c.sync()
+    for j in (12, 13):
+        assert np.abs(bufs[j % 3].astype(int) - wants[j % 4].astype(int)).max() <= 1, j
+    assert shown == 12
+    # the synchronous call still is: complete on return, and it sees everything enqueued before it
+    got = c.render(W, H, clear=clears[1], dst=np.zeros((H, W * 4), np.uint8))
+    assert np.abs(got.astype(int) - wants[1].astype(int)).max() <= 1
+    for b in bufs:
+        c.unregister_buffer(b)
+    c.close()
+
