@@ -98,6 +98,23 @@ class Context:
         self._check(self._L.forma_hip_set_images(self._h, _p(im), len(im), _p(tx), len(tx)))
 
     # ---- stages
+    def flatten_tables(self, t):
+        """forma_hip_flatten on caller-supplied work items (the fields of forma_flatten_tables_t as numpy arrays + n_points,
+        n_quads, n_splines): the parallel map of Primitives::into_segments, path.rs:487-534"""
+        from ._lib import FlattenTablesT
+        ft = FlattenTablesT()
+        keep = []
+        for name, _ in FlattenTablesT._fields_:
+            if name.startswith("n_"):
+                setattr(ft, name, int(t[name]))
+            else:
+                a = np.ascontiguousarray(t[name]); keep.append(a)
+                setattr(ft, name, a.ctypes.data)
+        n = int(t["n_points"])
+        x = np.zeros(max(n, 1), np.float32); y = np.zeros(max(n, 1), np.float32)
+        self._check(self._L.forma_hip_flatten(self._h, C.byref(ft), _p(x), _p(y)))
+        return x[:n], y[:n]
+
     def prepare_lines(self, width, height):
         n = max(self.n_points - 1, 0)
         out = {k: np.zeros(n, np.float32) for k in ("x0", "y0", "dx", "dy", "a", "b", "c", "d")}

@@ -215,6 +215,32 @@ struct Primitives {                                                             
         return {px, py};
     }
 
+    // populate_buffers ALONE (path.rs:400-445): the per-output-point work items — PointCommand bits (path.rs:137-168), point
+    // index, quad index — exactly as the reference leaves them in ScratchBuffers.  Together with the per-quad arrays above they
+    // are the tables of the C ABI's forma_flatten_tables_t; tests drive forma_hip_flatten with THESE (not with the product's own
+    // host-side flattener) so that the ABI contract of stage 1 is pinned independently.
+    void populate_buffers(std::vector<uint32_t>& cmds, std::vector<uint32_t>& point_idx, std::vector<uint32_t>& quad_idx) const {
+        cmds.clear(); point_idx.clear(); quad_idx.clear();
+        size_t i = 0;
+        const Spline* last = nullptr;
+        for (size_t si = 0; si < splines.size(); si++) {
+            const Spline& sp = splines[si];
+            size_t subdivisions = f2usize_sat(ceilf(sp.curvature));
+            float point_command = sp.curvature / (float)subdivisions;
+            bool needs_start = !last || last->contour || pt_len(last->p2 - sp.p0) > MAX_ERROR;
+            if (needs_start) { point_idx.push_back(0); quad_idx.push_back(0); cmds.push_back(0x7F800000u | ((uint32_t)si & 0x3FFFFFu)); }
+            for (size_t pi = 1; pi < subdivisions; pi++) {
+                if ((float)pi > partial_curvatures[i].second) i++;
+                uint32_t bits; memcpy(&bits, &point_command, 4);
+                point_idx.push_back((uint32_t)pi); quad_idx.push_back((uint32_t)i); cmds.push_back(bits);
+            }
+            point_idx.push_back(0); quad_idx.push_back(0);
+            cmds.push_back(0xFF800000u | ((uint32_t)si & 0x3FFFFFu) | ((sp.contour ? 1u : 0u) << 22));
+            last = &sp;
+            if (subdivisions > 0) i++;
+        }
+    }
+
     // populate_buffers (path.rs:400-445) + the parallel map of into_segments (path.rs:473-538).
     void into_segments(std::vector<float>& ox, std::vector<float>& oy, std::vector<uint8_t>& onc) const {
         size_t i = 0;
@@ -857,6 +883,8 @@ struct PaintCtx {
     const std::vector<uint8_t>* have_props;
     const uint8_t* unchanged;   // per order, may be null
     bool has_cache;
+    bool passes_off = false;    // test switch (oracle_set_optimizer): paint every tile layer by layer, no optimizer pass — SURVEY parity
+                                // contract 3 wants the image within one code value of the reference with the passes on AND off
     Images images;
     const Props& get(uint32_t id) const { return (*props_by_order)[id]; }
     bool is_unchanged(uint32_t id) const { return has_cache && unchanged && unchanged[id]; }   // renderer.rs:143-156
@@ -1068,6 +1096,7 @@ int skip_fully_covered_layers_pass(Workbench& wb, const TileCtx& t, const PaintC
     solid = dst; return 2;
 }
 int optimization_passes(Workbench& wb, const TileCtx& t, const PaintCtx& ctx, Color& solid) {   // layer_workbench/mod.rs:236-248
+    if (ctx.passes_off) return 0;
     if (int r = tile_unchanged_pass(wb, t, ctx)) return r;
     if (int r = skip_trivial_clips_pass(wb, t, ctx)) return r;
     return skip_fully_covered_layers_pass(wb, t, ctx, solid);
@@ -1223,6 +1252,7 @@ struct Oracle {
     // flatten scratch
     std::vector<float> fx, fy; std::vector<uint8_t> fnc;
     int threads = 1;
+    bool passes_off = false;
 
     void decode_styles() {
         props.assign(style_offsets.size(), Props()); have.assign(style_offsets.size(), 0);
@@ -1233,6 +1263,7 @@ struct Oracle {
         PaintCtx c; c.props_by_order = &props; c.have_props = &have;
         c.unchanged = has_unchanged ? unchanged.data() : nullptr; c.has_cache = has_cache;
         c.images = {images.data(), images.size(), texels.data()};
+        c.passes_off = passes_off;
         return c;
     }
 };
@@ -1255,6 +1286,7 @@ extern "C" {
 void* oracle_create(void) { return new Oracle(); }
 void  oracle_destroy(void* o) { delete (Oracle*)o; }
 void  oracle_set_threads(void* o, int t) { ((Oracle*)o)->threads = t > 0 ? t : 1; }
+void  oracle_set_optimizer(void* o, int enabled) { ((Oracle*)o)->passes_off = !enabled; }     // (test switch: see PaintCtx::passes_off)
 int   oracle_max_threads(void) {
 #ifdef _OPENMP
     return omp_get_num_procs();
@@ -1325,6 +1357,28 @@ void  oracle_prim_push_cubic(void* p, const float* q) {
     WPt w[4] = {{{q[0], q[1]}, q[2]}, {{q[3], q[4]}, q[5]}, {{q[6], q[7]}, q[8]}, {{q[9], q[10]}, q[11]}};
     ((Primitives*)p)->push_cubic(w);
 }
+// the work items of populate_buffers + the per-quad / per-spline arrays, in the layout of forma_flatten_tables_t.  Two calls:
+// counts first (outputs may be null), then the arrays.
+size_t oracle_prim_tables(void* p_, size_t* n_quads, size_t* n_splines, uint32_t* cmds, uint32_t* point_idx, uint32_t* quad_idx,
+                          float* qx, float* qy, float* qw, float* x0, float* dx_recip, float* k0, float* dk, float* curv_recip,
+                          uint32_t* partial_spline, float* partial_curv, float* sp0x, float* sp0y, float* sp2x, float* sp2y) {
+    const Primitives& P = *(Primitives*)p_;
+    std::vector<uint32_t> c, pi, qi;
+    P.populate_buffers(c, pi, qi);
+    const size_t nq = P.x0.size(), ns = P.splines.size();
+    if (n_quads) *n_quads = nq;
+    if (n_splines) *n_splines = ns;
+    if (!cmds) return c.size();
+    std::copy(c.begin(), c.end(), cmds); std::copy(pi.begin(), pi.end(), point_idx); std::copy(qi.begin(), qi.end(), quad_idx);
+    std::copy(P.x.begin(), P.x.end(), qx); std::copy(P.y.begin(), P.y.end(), qy); std::copy(P.weight.begin(), P.weight.end(), qw);
+    std::copy(P.x0.begin(), P.x0.end(), x0); std::copy(P.dx_recip.begin(), P.dx_recip.end(), dx_recip);
+    std::copy(P.k0.begin(), P.k0.end(), k0); std::copy(P.dk.begin(), P.dk.end(), dk);
+    std::copy(P.curvatures_recip.begin(), P.curvatures_recip.end(), curv_recip);
+    for (size_t i = 0; i < nq; i++) { partial_spline[i] = P.partial_curvatures[i].first; partial_curv[i] = P.partial_curvatures[i].second; }
+    for (size_t i = 0; i < ns; i++) { sp0x[i] = P.splines[i].p0.x; sp0y[i] = P.splines[i].p0.y; sp2x[i] = P.splines[i].p2.x; sp2y[i] = P.splines[i].p2.y; }
+    return c.size();
+}
+
 size_t oracle_prim_flatten(void* o_, void* p) {
     Oracle* o = (Oracle*)o_;
     o->fx.clear(); o->fy.clear(); o->fnc.clear();

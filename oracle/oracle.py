@@ -58,6 +58,7 @@ def lib():
         L.oracle_create.restype = vp
         L.oracle_destroy.argtypes = [vp]
         L.oracle_set_threads.argtypes = [vp, i32]
+        L.oracle_set_optimizer.argtypes = [vp, i32]
         L.oracle_max_threads.restype = i32
         L.oracle_path_new.restype = vp
         L.oracle_path_free.argtypes = [vp]
@@ -241,6 +242,26 @@ class Primitives:
     def push_cubic(self, *pts):
         a = self._pts(pts); lib().oracle_prim_push_cubic(self._h, _p(a)); return self
 
+    def tables(self):
+        """populate_buffers (path.rs:400-445) + the per-quad / per-spline arrays: the fields of the C ABI's
+        forma_flatten_tables_t, as a dict of numpy arrays (what a host hands to forma_hip_flatten)"""
+        L = lib()
+        L.oracle_prim_tables.restype = C.c_size_t
+        L.oracle_prim_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 19
+        nq, ns = C.c_size_t(0), C.c_size_t(0)
+        n = L.oracle_prim_tables(self._h, C.byref(nq), C.byref(ns), *([None] * 17))
+        nq, ns = nq.value, ns.value
+        u = lambda k: np.zeros(max(k, 1), np.uint32)
+        f = lambda k: np.zeros(max(k, 1), np.float32)
+        t = {"point_commands": u(n), "point_indices": u(n), "quad_indices": u(n), "qx": f(3 * nq), "qy": f(3 * nq), "qw": f(3 * nq),
+             "x0": f(nq), "dx_recip": f(nq), "k0": f(nq), "dk": f(nq), "curvatures_recip": f(nq), "partial_spline": u(nq),
+             "partial_curv": f(nq), "sp0x": f(ns), "sp0y": f(ns), "sp2x": f(ns), "sp2y": f(ns)}
+        order = ["point_commands", "point_indices", "quad_indices", "qx", "qy", "qw", "x0", "dx_recip", "k0", "dk", "curvatures_recip",
+                 "partial_spline", "partial_curv", "sp0x", "sp0y", "sp2x", "sp2y"]
+        L.oracle_prim_tables(self._h, None, None, *[_p(t[k]) for k in order])
+        t["n_points"], t["n_quads"], t["n_splines"] = int(n), nq, ns
+        return t
+
 
 class Oracle:
     def __init__(self, threads: int = 1):
@@ -253,6 +274,10 @@ class Oracle:
             lib().oracle_destroy(self._h)
         except Exception:
             pass
+
+    def set_optimizer(self, enabled: bool):
+        """test switch: with False every tile is painted layer by layer, no optimizer pass (layer_workbench/mod.rs:236-248 skipped)"""
+        lib().oracle_set_optimizer(self._h, 1 if enabled else 0)
 
     def set_threads(self, t):
         lib().oracle_set_threads(self._h, t)

@@ -121,6 +121,22 @@ pub struct forma_flatten_tables_t {
     pub n_splines: usize,
 }
 
+pub const FORMA_MAX_DEVICES: usize = 8;
+pub const FORMA_TRANSPORT_NONE: u32 = 0;
+pub const FORMA_TRANSPORT_RCCL: u32 = 1;
+pub const FORMA_TRANSPORT_COPY: u32 = 2;
+
+/// `forma_context_info_t` (`include/forma_hip.h`): devices, frame slots and the exchange transport of a context.
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct forma_context_info_t {
+    pub n_devices: u32,
+    pub frames_in_flight: u32,
+    pub transport: u32,
+    pub reserved: u32,
+    pub devices: [i32; FORMA_MAX_DEVICES],
+}
+
 #[link(name = "forma_hip")]
 extern "C" {
     // lifetime
@@ -226,6 +242,19 @@ extern "C" {
     pub fn forma_hip_cache_clear(ctx: *mut forma_hip_ctx, cache_id: c_int) -> c_int;
     pub fn forma_hip_set_frames_in_flight(ctx: *mut forma_hip_ctx, n: c_int) -> c_int;
     pub fn forma_hip_sync(ctx: *mut forma_hip_ctx) -> c_int;
+    pub fn forma_hip_context_info(ctx: *mut forma_hip_ctx, out: *mut forma_context_info_t) -> c_int;
+    pub fn forma_hip_render_enqueue(
+        ctx: *mut forma_hip_ctx,
+        dst: *mut u8,
+        width: u32,
+        height: u32,
+        stride_bytes: usize,
+        channels: *const u8,
+        clear_color: *const f32,
+        crop_or_null: *const forma_rect_t,
+    ) -> c_int;
+    pub fn forma_hip_register_buffer(ctx: *mut forma_hip_ctx, ptr: *mut c_void, bytes: usize) -> c_int;
+    pub fn forma_hip_unregister_buffer(ctx: *mut forma_hip_ctx, ptr: *mut c_void) -> c_int;
     pub fn forma_hip_trim(ctx: *mut forma_hip_ctx) -> c_int;
 
     // inspection

@@ -157,6 +157,69 @@ impl Renderer {
         self.check(rc, "forma_hip_sync");
     }
 
+    /// What this renderer is made of (`forma_hip_context_info`): devices, frame slots, how pixel segments travel.
+    pub fn info(&self) -> ffi::forma_context_info_t {
+        let mut out = ffi::forma_context_info_t::default();
+        // SAFETY: `ctx` is live; `out` is a plain `#[repr(C)]` value of the layout the header declares.
+        let rc = unsafe { ffi::forma_hip_context_info(self.ctx, &mut out) };
+        self.check(rc, "forma_hip_context_info");
+        out
+    }
+
+    /// The frame AND its copy into `buffer` are enqueued on the next frame slot (`forma_hip_render_enqueue`); `buffer` must be one
+    /// the caller registered with [`Renderer::register`] and must not be read before `sync()` — or before `frames in flight`
+    /// further frames have been enqueued.  This is the one call that offers more than `cpu::Renderer`: a presenter that rotates
+    /// three window buffers gets the 33 MB PCIe copy of frame k under the kernels of frames k + 1 and k + 2 (1 650 frames/s at 4K
+    /// against 900 for `render`, which stays synchronous — `cpu/buffer/mod.rs:43-49`).  Same scene walk as `render`.
+    pub fn render_enqueue(
+        &mut self,
+        composition: &mut Composition,
+        pixels: &mut [u8],
+        layout: &crate::buffer::layout::LinearLayout,
+        channels: [Channel; 4],
+        clear_color: Color,
+        crop: Option<Rect>,
+    ) {
+        // cpu/renderer.rs:113-118, then the same scene walk as `render`
+        composition.compact_geom();
+        composition.shared_state.borrow_mut().props_interner.compact();
+        self.upload_geometry(composition);
+        self.upload_tables(composition, None);
+        let stride = layout.linear_stride().expect("LinearLayout has a stride");
+        assert!(pixels.len() >= stride * layout.height());
+        let ch = channel_codes(channels, clear_color);
+        let clear = [clear_color.r, clear_color.g, clear_color.b, clear_color.a];
+        let rect = pixel_rect(crop.as_ref(), layout.width(), layout.height());
+        // SAFETY: `pixels` is registered (page-locked, kept alive by the caller until `unregister`), `ch` / `clear` / `rect` live
+        // for the call; the library copies what it needs to keep (the arguments of a deferred frame) before returning.
+        let rc = unsafe {
+            ffi::forma_hip_render_enqueue(
+                self.ctx,
+                pixels.as_mut_ptr(),
+                layout.width() as u32,
+                layout.height() as u32,
+                stride,
+                ch.as_ptr(),
+                clear.as_ptr(),
+                rect.as_ref().map_or(std::ptr::null(), |r| r as *const _),
+            )
+        };
+        self.check(rc, "forma_hip_render_enqueue");
+    }
+
+    /// Page-locks a pixel buffer the renderer writes often (`forma_hip_register_buffer`); undo with [`Renderer::unregister`]
+    /// before the memory is freed.
+    pub fn register(&mut self, pixels: &mut [u8]) {
+        // SAFETY: the slice is valid for its length; the caller keeps it alive until `unregister`.
+        let rc = unsafe { ffi::forma_hip_register_buffer(self.ctx, pixels.as_mut_ptr().cast(), pixels.len()) };
+        self.check(rc, "forma_hip_register_buffer");
+    }
+    pub fn unregister(&mut self, pixels: &mut [u8]) {
+        // SAFETY: as above; the call waits for frames in flight first.
+        let rc = unsafe { ffi::forma_hip_unregister_buffer(self.ctx, pixels.as_mut_ptr().cast()) };
+        self.check(rc, "forma_hip_unregister_buffer");
+    }
+
     /// Gives the per-frame device memory back (`forma_hip_trim`): the scene and the caches stay, the next frame allocates again.
     pub fn trim(&mut self) {
         // SAFETY: as above.
@@ -242,22 +305,9 @@ impl Renderer {
         self.upload_geometry(composition);
         self.upload_tables(composition, cache_id);
 
-        let channels = channels.map(|c| match c {
-            Channel::Red => ffi::FORMA_CH_RED,
-            Channel::Green => ffi::FORMA_CH_GREEN,
-            Channel::Blue => ffi::FORMA_CH_BLUE,
-            Channel::Alpha => ffi::FORMA_CH_ALPHA,
-            Channel::Zero => ffi::FORMA_CH_ZERO,
-            Channel::One => ffi::FORMA_CH_ONE,
-        });
+        let channels = channel_codes(channels, clear_color);
         let clear = [clear_color.r, clear_color.g, clear_color.b, clear_color.a];
-        // `Rect` holds TILE ranges (renderer.rs:43-52); the ABI takes pixels and rounds out to the same grid.
-        let rect = crop.as_ref().map(|rect| forma_rect_t {
-            x0: (rect.hor.start * TILE_WIDTH).min(width) as u32,
-            x1: (rect.hor.end * TILE_WIDTH).min(width) as u32,
-            y0: (rect.vert.start * TILE_HEIGHT).min(height) as u32,
-            y1: (rect.vert.end * TILE_HEIGHT).min(height) as u32,
-        });
+        let rect = pixel_rect(crop.as_ref(), width, height);
         let rect_ptr = rect.as_ref().map_or(ptr::null(), |rect| rect as *const forma_rect_t);
         let cache_arg = cache_id.map_or(-1, i32::from);
 
@@ -656,3 +706,109 @@ mod tests {
         assert_eq!(want, got);
     }
 }
+
+/// `Channel` -> the ABI's selector bytes, after the alpha upgrade of `cpu/renderer.rs:87-92`.
+fn channel_codes(channels: [Channel; 4], clear_color: Color) -> [u8; 4] {
+    channels.map(|c| match c {
+        Channel::Alpha if clear_color.a == 1.0 => ffi::FORMA_CH_ONE,
+        Channel::Red => ffi::FORMA_CH_RED,
+        Channel::Green => ffi::FORMA_CH_GREEN,
+        Channel::Blue => ffi::FORMA_CH_BLUE,
+        Channel::Alpha => ffi::FORMA_CH_ALPHA,
+        Channel::Zero => ffi::FORMA_CH_ZERO,
+        Channel::One => ffi::FORMA_CH_ONE,
+    })
+}
+
+/// `Rect` holds TILE ranges (`cpu/renderer.rs:43-52`); the ABI takes pixels and rounds out to the same grid.
+fn pixel_rect(crop: Option<&Rect>, width: usize, height: usize) -> Option<forma_rect_t> {
+    crop.map(|rect| forma_rect_t {
+        x0: (rect.hor.start * TILE_WIDTH).min(width) as u32,
+        x1: (rect.hor.end * TILE_WIDTH).min(width) as u32,
+        y0: (rect.vert.start * TILE_HEIGHT).min(height) as u32,
+        y1: (rect.vert.end * TILE_HEIGHT).min(height) as u32,
+    })
+}
+
+// ---- hook 4: stage 1 behind the drop-in ------------------------------------------------------------------------------------
+// The reference flattens a `Path` once, inside `PathData::segments` (`path.rs:617-654`), by `Primitives::into_segments`
+// (`:473-538`): `populate_buffers` (`:400-445`, sequential) writes one work item per output point into thread-local
+// `ScratchBuffers`, then a Rayon map evaluates the points.  That map is `k_flatten` (`forma_hip_flatten`).  The hook below is
+// what `into_segments` calls INSTEAD of the `par_iter` map when the path is large enough to pay for a launch: it hands the
+// scratch buffers and the per-quad arrays to the device and fills `Segments::{x, y}`; `start_new_contour` comes from the End
+// commands on the host (bit 22, `path.rs:137-168`).  Everything up to and including `populate_buffers` stays the reference's
+// own code, so the points are bit-identical (tests/test_parity_contract.py drives `forma_hip_flatten` with tables produced by an
+// independent restatement of `populate_buffers`, not by this library's host code).
+//
+// In `forma/src/path.rs` (new lines only; `Primitives`' fields are private to that file, so the hook lives next to them):
+//
+//     #[cfg(feature = "hip")]
+//     if buffers.point_commands.len() >= crate::hip::FLATTEN_ON_DEVICE_MIN_POINTS {
+//         if let Some((x, y)) = crate::hip::flatten_on_device(&crate::hip::FlattenTables {
+//             point_commands: &buffers.point_commands, point_indices: &buffers.point_indices, quad_indices: &buffers.quad_indices,
+//             qx: &self.x, qy: &self.y, qw: &self.weight, x0: &self.x0, dx_recip: &self.dx_recip, k0: &self.k0, dk: &self.dk,
+//             curvatures_recip: &self.curvatures_recip, partial_curvatures: &self.partial_curvatures, splines: &self.splines,
+//         }) {
+//             segments.start_new_contour = buffers.point_commands.iter().map(|&c| c & 0xFFC0_0000 == 0xFFC0_0000).collect();
+//             segments.x = x; segments.y = y;
+//             return segments;
+//         }
+//     }
+//
+// (`point_indices` / `quad_indices` are `Vec<usize>` in the reference; the hook narrows them to `u32` — a path has far fewer
+// than 2^32 points.)
+
+/// Below this many output points a path is flattened by the reference's own Rayon map: a launch plus two copies cost ~30 us.
+pub const FLATTEN_ON_DEVICE_MIN_POINTS: usize = 16_384;
+
+/// Borrowed view of `Primitives` + `ScratchBuffers` (`path.rs:123-127, 190-203`) for [`flatten_on_device`].
+pub struct FlattenTables<'a> {
+    pub point_commands: &'a [u32],
+    pub point_indices: &'a [usize],
+    pub quad_indices: &'a [usize],
+    pub qx: &'a [f32],
+    pub qy: &'a [f32],
+    pub qw: &'a [f32],
+    pub x0: &'a [f32],
+    pub dx_recip: &'a [f32],
+    pub k0: &'a [f32],
+    pub dk: &'a [f32],
+    pub curvatures_recip: &'a [f32],
+    pub partial_curvatures: &'a [(u32, f32)],
+    pub splines: &'a [crate::path::Spline],
+}
+
+thread_local! {
+    /// `Path`s are built and flattened on whatever thread the application uses, before any `Renderer` exists: stage 1 has its
+    /// own small context per thread (device 0), created on first use.  `None` = no device / no library: the caller falls back
+    /// to the reference's map (flattening is not part of `Renderer::render`, so this is the one place a fallback is right).
+    static FLATTEN_CTX: std::cell::RefCell<Option<Option<*mut ffi::forma_hip_ctx>>> = std::cell::RefCell::new(None);
+}
+
+pub fn flatten_on_device(t: &FlattenTables<'_>) -> Option<(Vec<f32>, Vec<f32>)> {
+    let ctx = FLATTEN_CTX.with(|c| {
+        *c.borrow_mut().get_or_insert_with(|| {
+            let mut ctx = std::ptr::null_mut();
+            // SAFETY: plain out-pointer call.
+            (unsafe { ffi::forma_hip_create(&mut ctx, 0) } == 0).then_some(ctx)
+        })
+    })?;
+    let n = t.point_commands.len();
+    let narrow = |v: &[usize]| v.iter().map(|&i| i as u32).collect::<Vec<u32>>();
+    let (pi, qi) = (narrow(t.point_indices), narrow(t.quad_indices));
+    let (ps, pc): (Vec<u32>, Vec<f32>) = t.partial_curvatures.iter().copied().unzip();
+    let col = |f: fn(&crate::path::Spline) -> f32| t.splines.iter().map(f).collect::<Vec<f32>>();
+    let (sp0x, sp0y, sp2x, sp2y) = (col(|s| s.p0.x), col(|s| s.p0.y), col(|s| s.p2.x), col(|s| s.p2.y));
+    let tables = ffi::forma_flatten_tables_t {
+        point_commands: t.point_commands.as_ptr(), point_indices: pi.as_ptr(), quad_indices: qi.as_ptr(), n_points: n,
+        qx: t.qx.as_ptr(), qy: t.qy.as_ptr(), qw: t.qw.as_ptr(), x0: t.x0.as_ptr(), dx_recip: t.dx_recip.as_ptr(),
+        k0: t.k0.as_ptr(), dk: t.dk.as_ptr(), curvatures_recip: t.curvatures_recip.as_ptr(),
+        partial_spline: ps.as_ptr(), partial_curv: pc.as_ptr(), n_quads: t.x0.len(),
+        sp0x: sp0x.as_ptr(), sp0y: sp0y.as_ptr(), sp2x: sp2x.as_ptr(), sp2y: sp2y.as_ptr(), n_splines: t.splines.len(),
+    };
+    let (mut x, mut y) = (vec![0.0f32; n], vec![0.0f32; n]);
+    // SAFETY: every pointer of `tables` borrows a slice that outlives the call; `x` / `y` hold `n` floats each.
+    let rc = unsafe { ffi::forma_hip_flatten(ctx, &tables, x.as_mut_ptr(), y.as_mut_ptr()) };
+    (rc == 0).then_some((x, y))
+}
+
