@@ -47,6 +47,11 @@ import subprocess
 import sys
 import time
 
+# HIP maps streams onto a handful of hardware queues (4 by default); frame slots beyond what the queues hold share one and
+# serialise.  Eight queues let a multi-device context (and the band proxy) run four frame slots per device: measured on one GPU,
+# a 1/8 band of the 4K scene at F = 4 takes 80 us per frame with 8 queues and 128 us with 4 (profiles/r04_band_proxy.json).
+# Read by the HIP runtime when it initialises: has to be in the environment before the first HIP call of the process.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 os.environ.setdefault("OMP_PROC_BIND", "close")      # the CPU baseline's OpenMP loops: threads stay where their pages are
 os.environ.setdefault("OMP_PLACES", "cores")
 
@@ -57,7 +62,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2   # wave64 VALU instructions/ns the chip can issue: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles
-PMC_FILES = [os.path.join("profiles", "r03_pmc_summary.json"), os.path.join("profiles", "r02_pmc_summary.json")]
+PMC_FILES = [os.path.join("profiles", "r04_pmc_summary.json"), os.path.join("profiles", "r03_pmc_summary.json")]
 
 
 def parse():
@@ -173,7 +178,8 @@ def main():
             if dist is not None:
                 dist.broadcast(n_full, 0)
             n_segments_full = int(n_full.item())
-        in_flight = max(1, min(4, args.in_flight)) if mode == "single" else 1
+        # frame slots: inside the ONE context (single GPU), and — round 4 — on every device of a multi-device context
+        in_flight = max(1, min(4, args.in_flight)) if mode in ("single", "multi") else 1
 
         crop, row0, row1, xf = None, 0, tiles_h, None
         if mode == "bands":
@@ -206,7 +212,7 @@ def main():
             """n frames; with frames in flight the calls return before their frames are done, so the block ends with a sync"""
             for _ in range(n):
                 frame()
-            if driver and mode in ("single", "frames"):
+            if driver and mode in ("single", "frames", "multi"):
                 ctx.sync()
 
         def rate(steps, per_step=1):
@@ -215,7 +221,12 @@ def main():
         frames_per_step = world if mode == "frames" else 1          # frames mode: one whole frame per GPU per step
         if driver and in_flight > 1:
             ctx.set_frames_in_flight(in_flight)
-        frames(max(args.warmup, in_flight + 1 if in_flight > 1 else 1))   # (every frame slot learns its predictions on its first frame)
+            # SET-UP, not warm-up: every frame slot runs its first frame synchronously (it learns N, the key masks and J), its
+            # second one read-back-free for the first time (buffers grow to their bounds).  Until round 3 the W warm-up frames
+            # did this, and with W = 5 over three slots the timed region still held first-time work: `value` sat 17 % under the
+            # median of the blocks that followed.
+            frames(3 * in_flight + 3)
+        frames(max(args.warmup, 1))                                 # W warm-up frames
         elapsed = timed(lambda: frames(args.steps))                 # THE timed region: exactly K frames -> `value`
         fps = frames_per_step * args.steps / elapsed
         ms_per_step = elapsed / args.steps * 1e3
@@ -260,15 +271,29 @@ def main():
             except Exception:
                 continue
         use_pmc = pmc is not None and workload == "paris-like-30k-4k" and mode == "single"
-        roofline = {"bound": "hbm", "kernel": "k_onesweep<8>: one radix digit pass (LSB, 8-bit digits over live key bits, u64 keys, chained scan)",
+        roofline = {"bound": "hbm", "kernel": "k_onesweep: one radix digit pass (LSB; 8-bit digits over live key bits, 9-bit where that saves a pass; "
+                                              "u64 keys, chained scan)",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": next((v.get("hbm_bytes_per_launch") for k, v in pmc["kernels"].items() if k.startswith("k_onesweep<8")), None) if use_pmc else None,
+                    "traffic": next((v.get("hbm_bytes_per_launch") for k, v in pmc["kernels"].items() if k.startswith("k_onesweep")), None) if use_pmc else None,
                     "traffic_source": (pmc_file + " — separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this command on "
                                        "the committed build (gfx950: FETCH_SIZE x 2), NOT measured in this run") if use_pmc else None,
                     "algorithmic_bytes_per_launch": algo_bytes_per_pass, "avg_launch_us": round(pass_us, 2), "passes": passes,
-                    "measured": f"HIP events on the context's stream around every k_onesweep launch of {acc.get('_frames', 0)} frames with ONE "
-                                "frame in flight (a further timed region of this run; matches `rocprofv3 --kernel-trace --stats -- python "
-                                "bench.py --in-flight 1`, profiles/)"}
+                    "measured": f"HIP events carried by every k_onesweep launch (hipExtLaunchKernelGGL: the dispatch's own start and end) of "
+                                f"{acc.get('_frames', 0)} frames with ONE frame in flight, a further timed region of this run; matches `rocprofv3 "
+                                "--kernel-trace --stats -- python bench.py --in-flight 1`, profiles/"}
+        # the whole sort against the same roofline: histogram read + p digit passes = 8 N (2 p + 1) bytes
+        sort_us = stage.get("sort_us", 0.0)
+        if sort_us > 0 and passes:
+            whole = 8.0 * n_local * (2 * passes + 1) / (sort_us * 1e-6) / 1e9
+            roofline["whole_sort"] = {"algorithmic_bytes": 8.0 * n_local * (2 * passes + 1), "us": round(sort_us, 1), "achieved": round(whole, 1),
+                                      "frac": round(whole / HBM_PEAK_GBS, 4),
+                                      "what": "k_sort_hist + every digit pass + the gaps between them, stage events of the same frames"}
+        # what the stages behind the sort move, against what they have to (8 N in + 4 W H out): counters of the committed build
+        if use_pmc:
+            post = [v.get("hbm_bytes_per_launch", 0) for k, v in pmc["kernels"].items()
+                    if k.startswith(("k_runs_count", "k_runs_wave", "k_carry_rows", "k_paint_wave"))]
+            if post and all(post):
+                roofline["post_sort_traffic_ratio"] = round(sum(post) / (8.0 * n_local + 4.0 * width * height), 3)
         if in_flight > 1:
             roofline["while_pipelined"] = ("with several frames in flight the kernels of different frames time-share the chip (every kernel's "
                                            "average rises to about 1.5-2x its one-in-flight duration while the frame rate rises): a launch "
@@ -296,6 +321,28 @@ def main():
             for _ in range(n_d2h):
                 frame(dst=image)
         fps_d2h = round(frames_per_step * n_d2h / timed(d2h_frames), 2)
+        # frame AND copy enqueued (forma_hip_render_enqueue): three registered caller buffers in turn, two frame slots, ONE context
+        # and ONE host thread — the 33 MB copy of frame k crosses PCIe under the kernels of frames k + 1, k + 2; a buffer is
+        # complete two enqueues later (what a presenter that rotates window buffers does)
+        fps_d2h_enqueue = None
+        if mode == "single" and primary:
+            bufs = [np.zeros_like(image) for _ in range(3)]
+            for b in bufs:
+                ctx.register_buffer(b)
+            ctx.set_frames_in_flight(2)
+            kq = [0]
+
+            def enq(n):
+                for _ in range(n):
+                    ctx.render_enqueue(width, height, bufs[kq[0] % 3], channels=channels, clear=clr, crop=crop)
+                    kq[0] += 1
+                ctx.sync()
+            enq(8)
+            fps_d2h_enqueue = round(n_d2h / timed(lambda: enq(n_d2h)), 2)
+            ctx.set_frames_in_flight(1)
+            for b in bufs:
+                ctx.unregister_buffer(b)
+            del bufs
         # the frame-server case: three INDEPENDENT renderer contexts (three host threads) each delivering complete frames into
         # its own caller buffer — the 33 MB PCIe copy of one context's frame overlaps the kernels of the others
         fps_d2h_server = None
@@ -352,6 +399,7 @@ def main():
                                         "(SURVEY §8d: 1 / wall time of one render call, device-resident output)"},
             "fps_including_d2h": fps_d2h,
             "fps_including_d2h_frames": n_d2h,
+            "fps_including_d2h_enqueued_three_buffers": fps_d2h_enqueue,
             "fps_including_d2h_three_contexts": fps_d2h_server,
             "config": {"workload": workload + (" (labelled stand-in: paris-30k.svg is not in the reference checkout)"
                                                      if workload.startswith("paris") else ""),
@@ -362,6 +410,11 @@ def main():
             "roofline_painter": painter,
         }
         out["fps_one_frame_in_flight"] = out["fps_render_call"]       # (the name earlier rounds used)
+        if driver and ctx is not None:
+            try:
+                out["context"] = ctx.info()                           # devices, frame slots, exchange transport (rccl / copy)
+            except Exception:                                         # noqa: BLE001
+                pass
         if primary and rank == 0 and world == 1 and not args.no_animated and mode == "single":
             out["animated"] = animated_leg(local, args.animated_frames)
         if primary and rank == 0 and world == 1 and not args.no_cpu_baseline:

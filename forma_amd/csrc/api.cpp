@@ -277,23 +277,44 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     uint32_t* overflow_list = tile_first_run + T;                       // ... then the lists themselves
     uint32_t* over2_list = overflow_list + T;
     uint32_t J = 0;
-    // capacity: a run needs at least one segment, and so does a span's left neighbour
-    const size_t cap = std::max<size_t>(bound_j ? bound_j : n, 1);
-    HIPCHECK(ctx->records.ensure(cap * sizeof(TileRecord)));
-    HIPCHECK(ctx->rk_u.ensure(cap * 8));
-    HIPCHECK(ctx->run_lt.ensure(cap * 4));
     HIPCHECK(ctx->blk_edge.ensure(runs_blocks(std::max<size_t>(n, 1)) * sizeof(BlkEdge)));
     HIPCHECK(ctx->runs_scratch.ensure(runs_scratch_words(std::max<size_t>(n, 1)) * 4));
     stage_begin(ctx, ST_CARRY, timing);
     const bool tables_zero = ctx->pz.tab_p == ctx->row_tab.p && ctx->pz.tab_words >= row_tab_zero_words(tiles_w, tiles_h);
     ctx->pz.tab_p = nullptr;
-    launch_runs(ctx->stream, ctx->sorted, nc, tiles_w, tiles_h, ctx->records.as<TileRecord>(), (uint32_t)cap,
-                ctx->rk_u.as<uint64_t>(), tile_first_run, ctx->blk_edge.as<BlkEdge>(), row_count,
-                ctx->runs_scratch.as<uint32_t>(), dinfo, /*verify_plan=*/bound_j != 0 && ctx->speculated, ctx->live44,
-                ctx->layer_sorted, ctx->pending_masks,
-                RunStyle{ctx->layer_sf.as<uint32_t>(), (uint32_t)ctx->n_orders,
-                         (a.cache_id >= 0 && ctx->have_unchanged) ? ctx->unchanged.as<uint8_t>() : nullptr, ctx->run_lt.as<uint32_t>()},
-                tables_zero, ctx->sort_range, ctx->sort_range_n);
+    // Records, run keys and digests are sized for the RUNS, not for the segments (a run needs a segment, so N would always do:
+    // 440 MB of records per frame slot on the 4K scene, for 21 MB of runs).  A read-back-free frame has its bound from the last
+    // verified frame; a synchronous one launches the counting kernel, reads the count and sizes the buffers before the kernel
+    // that fills them.
+    size_t cap = std::max<size_t>(bound_j, 1);
+    auto runs = [&](int what) {
+        launch_runs(ctx->stream, ctx->sorted, nc, tiles_w, tiles_h, ctx->records.as<TileRecord>(), (uint32_t)cap,
+                    ctx->rk_u.as<uint64_t>(), tile_first_run, ctx->blk_edge.as<BlkEdge>(), row_count,
+                    ctx->runs_scratch.as<uint32_t>(), dinfo, /*verify_plan=*/bound_j != 0 && ctx->speculated, ctx->live44,
+                    ctx->layer_sorted, ctx->pending_masks,
+                    RunStyle{ctx->layer_sf.as<uint32_t>(), (uint32_t)ctx->n_orders,
+                             (a.cache_id >= 0 && ctx->have_unchanged) ? ctx->unchanged.as<uint8_t>() : nullptr, ctx->run_lt.as<uint32_t>()},
+                    tables_zero, ctx->sort_range, ctx->sort_range_n, what);
+    };
+    if (!bound_j && n > 0) {
+        runs(1);
+        HIPCHECK(hipGetLastError());
+        bool scanned = false;
+        const uint32_t nt = runs_count_tiles(n, &scanned);
+        uint64_t total = 0;
+        if (scanned) { int rc = read_info(ctx); if (rc) return rc; total = ctx->h_info->n_runs; }
+        else {
+            std::vector<uint32_t> counts(nt);
+            HIPCHECK(hipMemcpyAsync(counts.data(), ctx->runs_scratch.p, (size_t)nt * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHECK(hipStreamSynchronize(ctx->stream));
+            for (uint32_t c : counts) total += c;
+        }
+        cap = std::max<size_t>(std::min<uint64_t>(total, n), 1);
+    }
+    HIPCHECK(ctx->records.ensure(cap * sizeof(TileRecord)));
+    HIPCHECK(ctx->rk_u.ensure(cap * 8));
+    HIPCHECK(ctx->run_lt.ensure(cap * 4));
+    runs(bound_j || n == 0 ? 3 : 2);
     ctx->sort_range = nullptr;
     ctx->pending_masks = PendingMasks{nullptr, 0u};
     HIPCHECK(hipGetLastError());

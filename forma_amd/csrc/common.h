@@ -238,7 +238,11 @@ void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount n, uint32_t til
                  uint32_t* row_tab, uint32_t* scratch, FrameInfo* info, bool verify_plan, uint64_t spec_live44,
                  bool spec_layer_sorted, PendingMasks pm, RunStyle rs, bool tables_are_zero,
                  const uint32_t* range_records /* nullable: sort_range_words() of the sort that produced `sorted` ... */,
-                 uint32_t n_range_records /* ... and sort_hist_blocks() of its key count */);
+                 uint32_t n_range_records /* ... and sort_hist_blocks() of its key count */,
+                 int what = 3 /* bit 0: k_runs_count (per-tile head counts into `scratch`), bit 1: k_runs_wave (the records) — a
+                                 synchronous frame reads the count back in between and sizes the records for it */);
+// the per-tile counts k_runs_count leaves in `scratch`: how many (host sum = J), or — big frames — already scanned (J = info->n_runs)
+uint32_t runs_count_tiles(size_t n, bool* scanned);
 uint32_t runs_edge_segments();            // segments per BlkEdge entry
 // The end of a read-back-free frame: the device-side FrameInfo goes to pinned host memory (`host_info`, nullable) and/or its
 // segment count to a pinned word (`host_count`, nullable), and the device copy returns to its pristine state for the next

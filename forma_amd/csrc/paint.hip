@@ -427,29 +427,35 @@ size_t runs_blocks(size_t n) { return (n + RW_CHUNK - 1) / RW_CHUNK + 4; }      
 void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t tiles_w, uint32_t tiles_h, TileRecord* records,
                  uint32_t rec_cap, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge, uint32_t* row_tab,
                  uint32_t* scratch, FrameInfo* info, bool verify_plan, uint64_t spec_live44, bool spec_layer_sorted,
-                 PendingMasks pm, RunStyle rs, bool tables_are_zero, const uint32_t* range_records, uint32_t n_range_records) {
+                 PendingMasks pm, RunStyle rs, bool tables_are_zero, const uint32_t* range_records, uint32_t n_range_records, int what) {
     // per-frame tile tables: [row_count | row_span_lo | row_span_cnt | painter overflow counters (2) | first-run table] are
     // contiguous (api.cpp lays them out so) and start from zero — cleared by k_runs_count, unless an earlier kernel of the frame
     // already did (api.cpp folds that into the frame's first kernel); 0 in the first-run table = the tile has no run
     const uint32_t zero_words = tables_are_zero ? 0u : row_tab_zero_words(tiles_w, tiles_h);
     if (nc.bound == 0) {
-        if (zero_words) (void)hipMemsetAsync(row_tab, 0, (size_t)zero_words * 4, s);
-        (void)hipMemsetAsync(&info->n_runs, 0, 4, s);
+        if (what & 1) {
+            if (zero_words) (void)hipMemsetAsync(row_tab, 0, (size_t)zero_words * 4, s);
+            (void)hipMemsetAsync(&info->n_runs, 0, 4, s);
+        }
         return;
     }
     const uint32_t ntiles = (nc.bound + RN_TILE - 1) / RN_TILE;
     const uint32_t flags = (verify_plan ? 1u : 0u) | (spec_layer_sorted ? 2u : 0u);
     const uint32_t cgrid = std::min<uint32_t>((ntiles + 1) / 2, 4096u);
     uint32_t* chunk_counts = scratch + ntiles + 8;                      // 4 per tile (+ slack for the last wave's second half)
-    hipLaunchKernelGGL(k_runs_count, dim3(cgrid), dim3(RC_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, scratch, chunk_counts, row_tab,
-                       zero_words, info, spec_live44, flags, pm, range_records, n_range_records);
     const int scanned = ntiles > 16384 ? 1 : 0;
-    if (scanned) launch_scan_small_u32(s, scratch, nc, RN_TILE, &info->n_runs);   // exclusive, in place; total -> n_runs
+    if (what & 1) {
+        hipLaunchKernelGGL(k_runs_count, dim3(cgrid), dim3(RC_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, scratch, chunk_counts, row_tab,
+                           zero_words, info, spec_live44, flags, pm, range_records, n_range_records);
+        if (scanned) launch_scan_small_u32(s, scratch, nc, RN_TILE, &info->n_runs);   // exclusive, in place; total -> n_runs
+    }
+    if (what & 2)
     hipLaunchKernelGGL(k_runs_wave, dim3(ntiles), dim3(RW_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, records, rec_cap,
                        run_keys, tile_first_run, blk_edge, row_tab, (const uint32_t*)scratch, scanned,
                        (const uint32_t*)chunk_counts, info, rs);
 }
 uint32_t runs_edge_segments() { return RW_CHUNK; }
+uint32_t runs_count_tiles(size_t n, bool* scanned) { const uint32_t t = (uint32_t)((n + RN_TILE - 1) / RN_TILE); *scanned = t > 16384; return t; }
 
 // ================================================================================================
 // carry pre-pass: one 1024-lane workgroup per tile row.  The row's runs are brought into (layer, tile_x) order (LOCAL:
