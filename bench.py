@@ -47,11 +47,6 @@ import subprocess
 import sys
 import time
 
-# HIP maps streams onto a handful of hardware queues (4 by default); frame slots beyond what the queues hold share one and
-# serialise.  Eight queues let a multi-device context (and the band proxy) run four frame slots per device: measured on one GPU,
-# a 1/8 band of the 4K scene at F = 4 takes 80 us per frame with 8 queues and 128 us with 4 (profiles/r04_band_proxy.json).
-# Read by the HIP runtime when it initialises: has to be in the environment before the first HIP call of the process.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 os.environ.setdefault("OMP_PROC_BIND", "close")      # the CPU baseline's OpenMP loops: threads stay where their pages are
 os.environ.setdefault("OMP_PLACES", "cores")
 
@@ -81,6 +76,8 @@ def parse():
     ap.add_argument("--no-animated", action="store_true", help="skip BASELINE config 5 (deterministic spaceship, 600 frames at 4K)")
     ap.add_argument("--animated-frames", type=int, default=600)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-d2h", action="store_true", help="skip the PCIe-inclusive legs (profiling runs: their pipelined frames would be "
+                    "averaged into the per-kernel durations of the one-frame-in-flight region)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--preflight", default=None, help=argparse.SUPPRESS)     # child process: try a multi-device context, print OK
     return ap.parse_args()
@@ -280,7 +277,7 @@ def main():
                     "algorithmic_bytes_per_launch": algo_bytes_per_pass, "avg_launch_us": round(pass_us, 2), "passes": passes,
                     "measured": f"HIP events carried by every k_onesweep launch (hipExtLaunchKernelGGL: the dispatch's own start and end) of "
                                 f"{acc.get('_frames', 0)} frames with ONE frame in flight, a further timed region of this run; matches `rocprofv3 "
-                                "--kernel-trace --stats -- python bench.py --in-flight 1`, profiles/"}
+                                "--kernel-trace --stats -- python bench.py --in-flight 1 --no-d2h --no-animated --no-cpu-baseline`, profiles/r04_kernel_stats_inflight1.csv"}
         # the whole sort against the same roofline: histogram read + p digit passes = 8 N (2 p + 1) bytes
         sort_us = stage.get("sort_us", 0.0)
         if sort_us > 0 and passes:
@@ -320,12 +317,12 @@ def main():
         def d2h_frames():
             for _ in range(n_d2h):
                 frame(dst=image)
-        fps_d2h = round(frames_per_step * n_d2h / timed(d2h_frames), 2)
+        fps_d2h = None if args.no_d2h else round(frames_per_step * n_d2h / timed(d2h_frames), 2)
         # frame AND copy enqueued (forma_hip_render_enqueue): three registered caller buffers in turn, two frame slots, ONE context
         # and ONE host thread — the 33 MB copy of frame k crosses PCIe under the kernels of frames k + 1, k + 2; a buffer is
         # complete two enqueues later (what a presenter that rotates window buffers does)
         fps_d2h_enqueue = None
-        if mode == "single" and primary:
+        if mode == "single" and primary and not args.no_d2h:
             bufs = [np.zeros_like(image) for _ in range(3)]
             for b in bufs:
                 ctx.register_buffer(b)
@@ -338,7 +335,7 @@ def main():
                     kq[0] += 1
                 ctx.sync()
             enq(8)
-            fps_d2h_enqueue = round(n_d2h / timed(lambda: enq(n_d2h)), 2)
+            fps_d2h_enqueue = round(statistics.median(n_d2h / timed(lambda: enq(n_d2h)) for _ in range(3)), 2)    # (3 blocks: PCIe rates wobble)
             ctx.set_frames_in_flight(1)
             for b in bufs:
                 ctx.unregister_buffer(b)
@@ -346,7 +343,7 @@ def main():
         # the frame-server case: three INDEPENDENT renderer contexts (three host threads) each delivering complete frames into
         # its own caller buffer — the 33 MB PCIe copy of one context's frame overlaps the kernels of the others
         fps_d2h_server = None
-        if mode == "single" and primary:
+        if mode == "single" and primary and not args.no_d2h:
             import threading
             extra = []
             for _ in range(2):

@@ -19,7 +19,6 @@ import time
 
 import numpy as np
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # (before the first HIP call: frame slots beyond the hardware queues share one)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 SCENE = "/tmp/ab_fast_scene_%s.npz"

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """frames/s of Renderer::render INTO CALLER MEMORY from one context and one host thread (the PCIe-inclusive rate):
-pageable and registered destinations, one piece vs row bands (FORMA_HIP_DEBUG=no_band_copy), and forma_hip_render_enqueue over
-three registered buffers.   python tools/d2h_bench.py [workload]"""
+pageable and registered destinations, and forma_hip_render_enqueue over three registered buffers (two runs: PCIe rates wobble).   python tools/d2h_bench.py [workload]"""
 import json, os, subprocess, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -56,6 +55,6 @@ if __name__ == "__main__":
     else:
         if not os.path.exists(SCENE % wl):
             subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "ab_fast.py"), "--workload", wl, "--rounds", "0"])
-        for name, env in (("row bands", {}), ("one piece", {"FORMA_HIP_DEBUG": "no_band_copy"})):
+        for name, env in (("run 1", {}), ("run 2", {})):
             p = subprocess.run([sys.executable, os.path.abspath(__file__), wl, "--child"], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
             print(name, [l for l in p.stdout.splitlines() if l.startswith("{")] or p.stderr[-600:])

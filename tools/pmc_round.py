@@ -10,7 +10,7 @@ whose only traffic is one read of the 8 N byte stream).  Values are means over t
 import collections, csv, glob, json, os, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BENCH = ["python", os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--in-flight", "1", "--no-cpu-baseline", "--no-animated"]
+BENCH = ["python", os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--in-flight", "1", "--no-cpu-baseline", "--no-animated", "--no-d2h"]
 PASSES = [["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAIT_INST_LDS", "SQ_WAVES", "SQ_BUSY_CYCLES"],
           ["FETCH_SIZE"], ["WRITE_SIZE"]]
 
