@@ -254,7 +254,9 @@ int forma_hip_cache_clear(forma_hip_ctx* ctx, int cache_id);
  * refer to the most recent frame, every scene upload and forma_hip_sync wait for all of them.  An error of a deferred
  * frame is returned by the call that completes it.  Frames with dst != NULL keep the reference's contract (the caller's
  * buffer is fully written when render returns, cpu/buffer/mod.rs:43-49); cache frames stay in order (frame k + 1 reads
- * what frame k left in the cache).  Default 1: every render call is complete when it returns. */
+ * what frame k left in the cache).  Default 1: every render call is complete when it returns.  Three slots are the
+ * measured optimum on one device.  On a multi-device context (forma_hip_create_multi) every device gets n slots and every
+ * slot its own communicators; a frame whose exchange buckets outgrew the plan is re-planned and re-run when it is settled. */
 #define FORMA_MAX_FRAMES_IN_FLIGHT 8
 int forma_hip_set_frames_in_flight(forma_hip_ctx* ctx, int n);
 /* Wait for every enqueued frame; returns the first error any of them produced. */
