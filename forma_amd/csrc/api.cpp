@@ -101,16 +101,19 @@ int finish_rasterize(forma_hip_ctx* ctx) {
     return FORMA_OK;
 }
 
+SortPlan frame_sort_plan(forma_hip_ctx* ctx, uint64_t live44, bool layer_sorted, int digit_bits, bool speculated, bool* biased);
+
 // stages 1-2 on the uploaded geometry: line table + rasterize -> seg_u.
 // bound_n != 0: fully asynchronous (no read-back): N is only known to the device, buffers / grids are provisioned for
 // bound_n segments, the sort plan is the speculated one.
 int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, bool timing, bool speculate = false,
-                        uint32_t bound_n = 0, const ZeroJobs* zero = nullptr, const forma_hip_ctx::PreZero* cleared = nullptr) {
+                        uint32_t bound_n = 0, const ZeroJobs* zero = nullptr, const forma_hip_ctx::PreZero* cleared = nullptr,
+                        bool hist_too = false /* count the speculated sort plan's digits while the keys are made (RasHist) */) {
     const size_t all_lines = ctx->n_points ? ctx->n_points - 1 : 0;
     const size_t n_lines = ctx->line_ranged ? std::min(ctx->line_hi, all_lines) - std::min(ctx->line_lo, all_lines) : all_lines;
     ctx->n_lines = n_lines;
     ctx->n_seg = 0; ctx->n_compact = 0; ctx->have_unsorted = true; ctx->live44 = 0; ctx->layer_sorted = true;
-    ctx->speculated = false;
+    ctx->speculated = false; ctx->ras_hist_on = false;
     ctx->pz = forma_hip_ctx::PreZero();                   // (nothing of this frame has been cleared ahead of its stage yet)
     int rc = reset_info(ctx);
     if (rc) return rc;
@@ -132,12 +135,21 @@ int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, boo
     }
     HIPCHECK(ctx->seg_u.ensure(((size_t)nc_seg.bound + SEG_PAD) * 8));
     HIPCHECK(ctx->ras_masks.ensure(((size_t)nc_seg.bound / RAS_TILE + 2) * 32));
+    // the sort's histograms from the rasterizer: a read-back-free frame whose first kernel cleared the sort's scratch, with
+    // the plan the sort will use if the speculation holds (run_sort checks that it is the same plan)
+    RasHist RH;
+    memset(&RH, 0, sizeof RH);
+    if (hist_too && bound_n && ctx->pred_valid && ctx->pz.sort_p && ctx->pz.sort_p == ctx->sort_counters.p && !ctx->dbg.no_ras_hist) {
+        ctx->ras_plan = frame_sort_plan(ctx, ctx->pred_live44, ctx->pred_layer_sorted, ctx->digit_bits, true, nullptr);
+        RH = make_ras_hist(ctx->ras_plan, ctx->sort_counters.as<uint32_t>());
+        ctx->ras_hist_on = RH.hist != nullptr;
+    }
     stage_begin(ctx, ST_RASTER, timing);
     launch_rasterize(ctx->stream, S, nc_cmp, nc_seg, ctx->cl_idx.as<uint32_t>(), ctx->cl_start.as<uint32_t>(),
                      ctx->block_first.as<uint32_t>(), ctx->seg_u.as<uint64_t>(), dinfo, (int)ctx->band_row0,
-                     (int)ctx->band_row1, ctx->ras_masks.as<uint32_t>(), /*reduce_now=*/bound_n == 0);
+                     (int)ctx->band_row1, ctx->ras_masks.as<uint32_t>(), /*reduce_now=*/bound_n == 0, &RH);
     // read-back-free frame: the masks stay per-workgroup records until k_runs_count combines them (nothing reads them earlier)
-    ctx->pending_masks = bound_n ? PendingMasks{ctx->ras_masks.as<uint32_t>(), 0u} : PendingMasks{nullptr, 0u};
+    ctx->pending_masks = bound_n ? PendingMasks{ctx->ras_masks.as<uint32_t>(), 0u, ctx->ras_hist_on ? 1u : 0u} : PendingMasks{nullptr, 0u, 0u};
     stage_end(ctx, ST_RASTER, timing);
     HIPCHECK(hipGetLastError());
     ctx->speculated = (speculate || bound_n) && ctx->pred_valid;
@@ -195,13 +207,21 @@ int run_sort(forma_hip_ctx* ctx, const uint64_t* src, DevCount nc, bool timing, 
     ctx->n_passes = plan.n_passes;
     ctx->sort_range = n > 1 && plan.n_passes ? sort_range_words(ctx->sort_counters.as<uint32_t>()) : nullptr;
     ctx->sort_range_n = sort_hist_blocks(n);
-    const bool zeroed = ctx->pz.sort_p == ctx->sort_counters.p && ctx->pz.sort_words >= sort_zero_words(n, plan);
+    bool zeroed = ctx->pz.sort_p == ctx->sort_counters.p && ctx->pz.sort_words >= sort_zero_words(n, plan);
     ctx->pz.sort_p = nullptr;
+    // did the rasterizer count exactly this plan's digits?  (if it counted another plan's, the scratch is no longer clear)
+    bool hist_ready = ctx->ras_hist_on && zeroed && !chunked && plan.n_passes == ctx->ras_plan.n_passes && src == ctx->seg_u.as<uint64_t>();
+    for (int p = 0; hist_ready && p < plan.n_passes; p++)
+        hist_ready = plan.shift[p] == ctx->ras_plan.shift[p] && plan.mask[p] == ctx->ras_plan.mask[p] && plan.bias[p] == ctx->ras_plan.bias[p] &&
+                     plan.fmask[p] == ctx->ras_plan.fmask[p];
+    if (ctx->ras_hist_on && !hist_ready) zeroed = false;
+    ctx->ras_hist_on = false;
+    if (hist_ready) ctx->sort_range = nullptr;               // (the spans travel in the rasterizer's mask records: PendingMasks::has_range)
     stage_begin(ctx, ST_SORT, timing);
     ctx->sorted = (uint64_t*)launch_radix_sort(ctx->stream, src, ctx->seg_a.as<uint64_t>(), ctx->seg_b.as<uint64_t>(), nc, plan,
                                                digit_bits, ctx->sort_counters.as<uint32_t>(), &ctx->info.as<FrameInfo>()->error,
                                                timing ? ctx->pev0 : nullptr, timing ? ctx->pev1 : nullptr, chunked,
-                                               ctx->info.as<FrameInfo>(), zeroed);
+                                               ctx->info.as<FrameInfo>(), zeroed, hist_ready);
     stage_end(ctx, ST_SORT, timing);
     HIPCHECK(hipGetLastError());
     return FORMA_OK;
@@ -1090,7 +1110,7 @@ int enqueue_async_frame(forma_hip_ctx* ctx, const PaintArgs& a, bool timing, uin
     // (and returns to its pristine state) through the last one
     ZeroJobs Z; forma_hip_ctx::PreZero cleared;
     if ((rc = plan_zero_jobs(ctx, a.width, a.height, bN, bN, &Z, &cleared))) return rc;
-    if ((rc = run_rasterize_frame(ctx, a.width, a.height, timing, true, bN, &Z, &cleared))) return rc;
+    if ((rc = run_rasterize_frame(ctx, a.width, a.height, timing, true, bN, &Z, &cleared, /*hist_too=*/true))) return rc;
     if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), DevCount{&dinfo->n_segments, bN}, timing))) return rc;
     if ((rc = run_paint(ctx, DevCount{&dinfo->n_segments, bN}, a, timing, bJ))) return rc;
     return frame_tail(ctx, true, nullptr);

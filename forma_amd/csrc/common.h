@@ -137,7 +137,9 @@ void launch_scan_small_u32(hipStream_t s, uint32_t* data, DevCount n, uint32_t p
 // Key masks of a stream as per-workgroup records (8 words: or, or_hi, and, and_hi, layer_unsorted, pad) that nobody has
 // combined yet: on read-back-free frames k_runs_count does it (rec == nullptr: info already holds them).
 // n_fixed == 0: one record per RAS_TILE block of the info->n_segments segments (k_rasterize); else exactly n_fixed (k_gather_chunks).
-struct PendingMasks { const uint32_t* rec; uint32_t n_fixed; };
+// has_range: words 5, 6 of a record hold what the workgroup's keys spanned in tile_x / tile_y (min | max << 16): k_rasterize with
+// the sort's histograms fused in (RasHist) — k_runs_count folds them into FrameInfo::tile_range like k_sort_hist's records.
+struct PendingMasks { const uint32_t* rec; uint32_t n_fixed; uint32_t has_range; };
 struct LineSource {               // either the uploaded geometry (sums == nullptr) or caller-supplied line parameters
     const float* x; const float* y; const uint32_t* line_slot; const forma_geom_t* geoms; uint32_t n_geoms;
     float width, height, band_lo, band_hi;
@@ -153,10 +155,19 @@ void launch_line_lengths(hipStream_t s, const LineSource& src, uint32_t n_lines,
 // rebuilds block_first when the buffer launch_prepare_compact saw was too small for N
 void launch_block_first(hipStream_t s, const uint32_t* cl_start, uint32_t n_compact, uint32_t n_segments,
                         uint32_t* block_first);
+// The sort's digit histograms taken where the keys are made (read-back-free frames: the plan is the previous frame's): the
+// rasterizer counts the digits of the RH_MAX_PASSES passes of `plan` into the sort's histogram copies (cleared by the frame's
+// first kernel), leaves the tile-field span of its keys in its mask record and voids the frame if a biased digit leaves the
+// planned span — everything k_sort_hist does, without its read of the whole stream.  hist == nullptr: off.
+#define HS_COPIES  16                               // private copies of the sort's digit histograms (added up by k_onesweep)
+#define SORT_BINS  512                              // histogram words per pass (a pass has 16, 256 or 512 bins)
+#define RH_MAX_PASSES 3
+struct RasHist { uint32_t* hist; uint32_t n_passes; uint32_t shift[RH_MAX_PASSES], mask[RH_MAX_PASSES], bias[RH_MAX_PASSES], fmask[RH_MAX_PASSES]; };
 void launch_rasterize(hipStream_t s, const LineSource& src, DevCount n_compact, DevCount n_segments,
                       const uint32_t* cl_idx, const uint32_t* cl_start, const uint32_t* block_first, uint64_t* out,
                       FrameInfo* info, int band_row0, int band_row1, uint32_t* wg_masks /* 8 words per RAS_TILE block */,
-                      bool reduce_now /* false: the caller hands the records on as PendingMasks */);
+                      bool reduce_now /* false: the caller hands the records on as PendingMasks */,
+                      const RasHist* hist = nullptr);
 void launch_flatten(hipStream_t s, const forma_flatten_tables_t* dev_tables, float* out_x, float* out_y);
 
 // sort.hip — stable LSB radix sort of u64 (chained-scan "onesweep" passes over the live key bits).
@@ -194,7 +205,9 @@ const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a
                                   const SortPlan& plan, int digit_bits, uint32_t* scratch, uint32_t* err,
                                   hipEvent_t* pass_ev0, hipEvent_t* pass_ev1,
                                   const ChunkedSrc* chunked = nullptr, FrameInfo* info = nullptr,
-                                  bool scratch_is_zero = false /* an earlier kernel of the frame cleared sort_zero_words() */);
+                                  bool scratch_is_zero = false /* an earlier kernel of the frame cleared sort_zero_words() */,
+                                  bool hist_ready = false /* ... and the producer of the keys counted the digits (RasHist) */);
+RasHist make_ras_hist(const SortPlan& plan, uint32_t* sort_scratch);      // hist == nullptr if the plan does not qualify
 
 // exchange.hip — multi-GPU: bucket a rank's pixel segments by tile-row owner, gather what the owner received
 #define FORMA_MAX_RANKS 8

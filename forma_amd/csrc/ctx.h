@@ -109,6 +109,7 @@ struct forma_hip_ctx {
     uint64_t pred_live44 = 0;
     KeyRange pred_range{0, 0, 0, 0, false};  // what the tile fields spanned on the last verified frame (value-range digits, SortPlan::bias)
     bool plan_biased = false, bias_banned = false;   // this frame's plan leans on pred_range / a frame that did was void: plain digits for this geometry
+    bool ras_hist_on = false; SortPlan ras_plan;     // the rasterizer of this frame counted the digits of ras_plan into the sort's histograms (RasHist)
     const uint32_t* sort_range = nullptr;   // the tile-field spans the frame's sort leaves behind (k_runs_count folds them into FrameInfo) ...
     uint32_t sort_range_n = 0;              // ... one record per k_sort_hist workgroup
     DevBuf info, records, rk_u, rk_a, rk_b, blk_edge, runs_scratch, row_tab, span_key, span_cov, image;

@@ -355,14 +355,28 @@ __global__ __launch_bounds__(1024) void k_scan_line_tiles(uint32_t* __restrict__
 }
 
 // pass C: compacted line table (cl_idx, cl_start) + block_first; no inter-workgroup dependency
+#define PC_SELF_SCAN_TILES 2048u
 __global__ __launch_bounds__(PC_THREADS) void k_line_compact(const uint32_t* __restrict__ lens, uint32_t n_lines,
                                                              const uint32_t* __restrict__ tile_sum,
                                                              const uint32_t* __restrict__ tile_cnt,
                                                              uint32_t* __restrict__ cl_idx, uint32_t* __restrict__ cl_start,
-                                                             uint32_t* __restrict__ block_first, uint32_t bf_cap) {
+                                                             uint32_t* __restrict__ block_first, uint32_t bf_cap,
+                                                             FrameInfo* __restrict__ info /* non-null: tile_sum / tile_cnt hold the
+                                                             tiles' OWN totals (no k_scan_line_tiles ran) */) {
     __shared__ uint64_t s_wsum[PC_THREADS / 64];
     __shared__ uint32_t s_wcnt[PC_THREADS / 64];
+    __shared__ uint64_t s_psum[PC_THREADS / 64];
+    __shared__ uint32_t s_pcnt[PC_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // With a few hundred tiles every workgroup adds up the totals of the tiles in front of it by itself (a handful of cached
+    // loads per lane) — the one-workgroup scan kernel between k_line_len and this one was a launch and 5 us of an idle chip.
+    uint64_t ps = 0; uint32_t pc = 0;
+    if (info) {
+        for (uint32_t i = tid; i < blockIdx.x; i += PC_THREADS) { ps += tile_sum[i]; pc += tile_cnt[i]; }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { ps += __shfl_xor(ps, d, 64); pc += __shfl_xor(pc, d, 64); }
+        if (lane == 0) { s_psum[w] = ps; s_pcnt[w] = pc; }
+    }
     const uint32_t base = blockIdx.x * PC_TILE + tid * PC_IPT;         // 8 consecutive lines per thread
     uint32_t l[PC_IPT], cnt = 0;
     uint64_t sum = 0;                                                   // (64-bit sums, saturating where stored: see k_line_len)
@@ -375,14 +389,25 @@ __global__ __launch_bounds__(PC_THREADS) void k_line_compact(const uint32_t* __r
         if (lane >= d) { isum += ts; icnt += tc; }
     }
     if (lane == 63) { s_wsum[w] = isum; s_wcnt[w] = icnt; }
-    uint64_t bsum = tile_sum[blockIdx.x]; uint32_t bcnt = tile_cnt[blockIdx.x];   // (in flight across the barrier)
+    uint64_t bsum = 0; uint32_t bcnt = 0;
+    if (!info) { bsum = tile_sum[blockIdx.x]; bcnt = tile_cnt[blockIdx.x]; }      // (in flight across the barrier)
     __syncthreads();
+    if (info) {
+#pragma unroll
+        for (int i = 0; i < PC_THREADS / 64; i++) { bsum += s_psum[i]; bcnt += s_pcnt[i]; }
+        bsum = min(bsum, (uint64_t)SEG_SUM_SAT);                        // (what the scan kernel stores)
+    }
+    const uint32_t tile_c0 = bcnt;                                      // first compacted index of the tile
+    if (info && blockIdx.x == gridDim.x - 1 && tid == 0) {              // the frame's totals
+        uint64_t ts = bsum; uint32_t tc = bcnt;
+        for (int i = 0; i < PC_THREADS / 64; i++) { ts += s_wsum[i]; tc += s_wcnt[i]; }
+        info->n_segments = (uint32_t)min(ts, (uint64_t)SEG_SUM_SAT); info->n_compact = tc;
+    }
 #pragma unroll
     for (int i = 0; i < PC_THREADS / 64; i++) if (i < w) { bsum += s_wsum[i]; bcnt += s_wcnt[i]; }
     // the tile's entries go through LDS so that they leave as full, coalesced rows (a lane's entries are consecutive but the
     // lanes' pieces are ~8 words apart: written directly, every store instruction touched 16 partial cache lines)
     __shared__ uint32_t s_idx[PC_TILE], s_start[PC_TILE];
-    const uint32_t tile_c0 = tile_cnt[blockIdx.x];                      // first compacted index of the tile (same load as above: cached)
     uint32_t tile_n = 0;
 #pragma unroll
     for (int i = 0; i < PC_THREADS / 64; i++) tile_n += s_wcnt[i];
@@ -416,9 +441,11 @@ void launch_prepare_compact(hipStream_t s, const LineSource& src, uint32_t n_lin
     uint32_t* tile_sum = scratch + n_lines;
     uint32_t* tile_cnt = tile_sum + ntiles + 1;
     hipLaunchKernelGGL(k_line_len, dim3(ntiles), dim3(PL_THREADS), 0, s, src, n_lines, lens, tile_sum, tile_cnt, Z);
-    hipLaunchKernelGGL(k_scan_line_tiles, dim3(1), dim3(1024), 0, s, tile_sum, tile_cnt, ntiles, info);
+    const bool self_scan = ntiles <= PC_SELF_SCAN_TILES;               // (beyond: tiles^2 / 2 loads stop being "a handful")
+    if (!self_scan) hipLaunchKernelGGL(k_scan_line_tiles, dim3(1), dim3(1024), 0, s, tile_sum, tile_cnt, ntiles, info);
     hipLaunchKernelGGL(k_line_compact, dim3(ntiles), dim3(PC_THREADS), 0, s, (const uint32_t*)lens, n_lines,
-                       (const uint32_t*)tile_sum, (const uint32_t*)tile_cnt, cl_idx, cl_start, block_first, bf_cap);
+                       (const uint32_t*)tile_sum, (const uint32_t*)tile_cnt, cl_idx, cl_start, block_first, bf_cap,
+                       self_scan ? info : (FrameInfo*)nullptr);
 }
 
 // only the per-line pixel-segment counts (the planner of a multi-device context cuts its line shares from their prefix sums)
@@ -507,18 +534,21 @@ __device__ __forceinline__ LineP load_line(const LineSource& S, uint32_t li) {
     return line_params(S.x, S.y, S.line_slot, li, S.geoms, S.n_geoms, S.width, S.height, S.band_lo, S.band_hi);
 }
 
+template <bool HIST>         // HIST = false is the plain kernel, instruction for instruction
 __global__ __launch_bounds__(RAS_THREADS) void k_rasterize(LineSource S, DevCount nc_compact, DevCount nc_segments,
                                                            const uint32_t* __restrict__ cl_idx,
                                                            const uint32_t* __restrict__ cl_start,
                                                            const uint32_t* __restrict__ block_first,
                                                            uint64_t* __restrict__ out, FrameInfo* __restrict__ info,
-                                                           int band_row0, int band_row1, uint32_t* __restrict__ wg_masks) {
+                                                           int band_row0, int band_row1, uint32_t* __restrict__ wg_masks,
+                                                           RasHist RH) {
+    __shared__ uint32_t lh[HIST ? RH_MAX_PASSES * SORT_BINS : 1];       // the sort's digit histograms of this workgroup's keys
     __shared__ uint32_t w_start[RAS_WIN + 1];
     __shared__ uint32_t w_order[RAS_WIN];
     __shared__ float w_x0[RAS_WIN], w_y0[RAS_WIN], w_dx[RAS_WIN], w_dy[RAS_WIN];
     __shared__ float w_a[RAS_WIN], w_b[RAS_WIN], w_c[RAS_WIN], w_d[RAS_WIN];
     __shared__ double w_aab[RAS_WIN], w_bab[RAS_WIN], w_cdab[RAS_WIN];
-    __shared__ uint32_t red[5][RAS_THREADS / 64];
+    __shared__ uint32_t red[HIST ? 7 : 5][RAS_THREADS / 64];
     const int tid = threadIdx.x;
     // the two counts and the workgroup's two table entries are independent loads: all four in flight before the first test
     // (the table is provisioned for the grid, so the entries exist even for a workgroup past the end)
@@ -539,6 +569,7 @@ __global__ __launch_bounds__(RAS_THREADS) void k_rasterize(LineSource S, DevCoun
     uint64_t vout[RAS_PER_THREAD];
 #pragma unroll
     for (int q = 0; q < RAS_PER_THREAD; q++) vout[q] = 0;
+    if (HIST) for (uint32_t i = tid; i < RH.n_passes * SORT_BINS; i += RAS_THREADS) lh[i] = 0;   // (barriers: the staging loop's)
 
     for (uint32_t c0 = lo; c0 <= hi; c0 += RAS_WIN) {
         const uint32_t cnt = min((uint32_t)RAS_WIN, hi - c0 + 1);
@@ -599,6 +630,40 @@ __global__ __launch_bounds__(RAS_THREADS) void k_rasterize(LineSource S, DevCoun
         }
     }
     RP_STAMP(2);                                                        // the 8 pixel segments of the lane
+    uint32_t min_x = 0xFFFFu, max_x = 0, min_y = 0xFFFFu, max_y = 0;   // tile fields of this thread's keys (HIST)
+    if (HIST) {
+        // The digits of the sort's passes, counted where the keys are made.  A thread's 8 keys are consecutive segments of a
+        // line (or of neighbouring lines): mostly one tile, so a run-length pass over the registers leaves one or two LDS
+        // atomics per digit and thread.  (Electing one lane per digit of the wavefront first — the 64 lanes mostly add to the
+        // same word — was built and cost 44 us instead of 13: scalar loops of readlane / ballot, against LDS atomics that
+        // were never the limit.)
+        const uint32_t nv = kt < k1 ? min((uint32_t)RAS_PER_THREAD, k1 - kt) : 0u;
+        __syncthreads();                                                // (lh cleared, also for a workgroup whose loop ran dry)
+        if (nv) {
+#pragma unroll
+            for (int q = 0; q < RAS_PER_THREAD; q++) {
+                if ((uint32_t)q < nv) {
+                    const uint32_t hw = (uint32_t)(vout[q] >> 32), tx = (hw >> 9) & 0xFFFu, ty = hw >> 21;
+                    min_x = min(min_x, tx); max_x = max(max_x, tx); min_y = min(min_y, ty); max_y = max(max_y, ty);
+                }
+            }
+            for (uint32_t p = 0; p < RH.n_passes; p++) {
+                const uint32_t sh = RH.shift[p], mk = RH.mask[p], bs = RH.bias[p];
+                uint32_t* h = lh + p * SORT_BINS;
+                uint32_t run_d = 0, run_c = 0;
+#pragma unroll
+                for (int q = 0; q < RAS_PER_THREAD; q++) {
+                    if ((uint32_t)q < nv) {
+                        const uint32_t f = sh >= 32 ? (uint32_t)(vout[q] >> 32) >> (sh - 32) : (uint32_t)(vout[q] >> sh);
+                        const uint32_t d = (f - bs) & mk;
+                        if (run_c && d != run_d) { atomicAdd(&h[run_d], run_c); run_c = 0; }
+                        run_d = d; run_c++;
+                    }
+                }
+                atomicAdd(&h[run_d], run_c);
+            }
+        }
+    }
     // 64 contiguous bytes per thread: 16-byte stores (the tile base is a multiple of 2048 segments)
 #pragma unroll
     for (int q = 0; q < RAS_PER_THREAD; q += 2) {
@@ -613,13 +678,48 @@ __global__ __launch_bounds__(RAS_THREADS) void k_rasterize(LineSource S, DevCoun
         k_and &= __shfl_xor(k_and, d, 64); k_and_hi &= __shfl_xor(k_and_hi, d, 64);
         unsorted |= __shfl_xor(unsorted, d, 64);
     }
+    if (HIST) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            min_x = min(min_x, (uint32_t)__shfl_xor(min_x, d, 64)); max_x = max(max_x, (uint32_t)__shfl_xor(max_x, d, 64));
+            min_y = min(min_y, (uint32_t)__shfl_xor(min_y, d, 64)); max_y = max(max_y, (uint32_t)__shfl_xor(max_y, d, 64));
+        }
+    }
     const int w = tid >> 6;
     __syncthreads();
-    if ((tid & 63) == 0) { red[0][w] = k_or; red[1][w] = k_or_hi; red[2][w] = k_and; red[3][w] = k_and_hi; red[4][w] = unsorted; }
+    if ((tid & 63) == 0) {
+        red[0][w] = k_or; red[1][w] = k_or_hi; red[2][w] = k_and; red[3][w] = k_and_hi; red[4][w] = unsorted;
+        if (HIST) { red[5][w] = min_x | (max_x << 16); red[6][w] = min_y | (max_y << 16); }
+    }
     __syncthreads();
+    if (HIST) {
+        // flush: the non-empty bins into this workgroup's copy of the sort's histograms (a workgroup's keys cover a handful of tiles)
+        uint32_t* mine = RH.hist + (size_t)(blockIdx.x % HS_COPIES) * (SORT_MAX_PASSES * SORT_BINS);
+        for (uint32_t i = tid; i < RH.n_passes * SORT_BINS; i += RAS_THREADS) {
+            const uint32_t v = lh[i];
+            if (v) atomicAdd(&mine[i], v);
+        }
+    }
     if (tid == 0) {
         uint32_t o = 0, oh = 0, a = 0xFFFFFFFFu, ah = 0xFFFFFFFFu, u = 0;
         for (int i = 0; i < RAS_THREADS / 64; i++) { o |= red[0][i]; oh |= red[1][i]; a &= red[2][i]; ah &= red[3][i]; u |= red[4][i]; }
+        if (HIST) {
+            uint32_t lo_x = 0xFFFFu, hi_x = 0, lo_y = 0xFFFFu, hi_y = 0;
+            for (int i = 0; i < RAS_THREADS / 64; i++) {
+                lo_x = min(lo_x, red[5][i] & 0xFFFFu); hi_x = max(hi_x, red[5][i] >> 16);
+                lo_y = min(lo_y, red[6][i] & 0xFFFFu); hi_y = max(hi_y, red[6][i] >> 16);
+            }
+            uint32_t* mr = wg_masks + (size_t)blockIdx.x * 8;
+            mr[5] = lo_x | (hi_x << 16); mr[6] = lo_y | (hi_y << 16);
+            // a digit taken relative to a field's minimum was planned from the PREVIOUS frame's span: a key outside it voids
+            // the frame (the host runs it again with plain digits) — what k_sort_hist checks when it takes the histograms
+            for (uint32_t p = 0; p < RH.n_passes; p++) {
+                if (!RH.fmask[p]) continue;
+                const bool is_x = RH.shift[p] == 41;
+                const uint32_t lo_v = is_x ? lo_x : lo_y, hi_v = is_x ? hi_x : hi_y;
+                if (lo_v < RH.bias[p] || hi_v - RH.bias[p] > RH.mask[p]) info->plan_bad = 1u;
+            }
+        }
         // one record per workgroup, combined by k_reduce_masks: five plain stores.  (Until round 2 every workgroup read the
         // frame's masks through the caches and issued atomics when it added information: thread 0 of each of the 6 700
         // workgroups then finished thousands of clocks after its workgroup's stores, holding the workgroup's LDS and
@@ -663,11 +763,17 @@ __global__ __launch_bounds__(1024) void k_reduce_masks(const uint32_t* __restric
 
 void launch_rasterize(hipStream_t s, const LineSource& src, DevCount n_compact, DevCount n_segments,
                       const uint32_t* cl_idx, const uint32_t* cl_start, const uint32_t* block_first, uint64_t* out,
-                      FrameInfo* info, int band_row0, int band_row1, uint32_t* wg_masks, bool reduce_now) {
+                      FrameInfo* info, int band_row0, int band_row1, uint32_t* wg_masks, bool reduce_now, const RasHist* hist) {
     if (n_segments.bound == 0 || n_compact.bound == 0) return;
     uint32_t blocks = (n_segments.bound + RAS_TILE - 1) / RAS_TILE;
-    hipLaunchKernelGGL(k_rasterize, dim3(blocks), dim3(RAS_THREADS), 0, s, src, n_compact, n_segments, cl_idx, cl_start,
-                       block_first, out, info, band_row0, band_row1, wg_masks);
+    RasHist RH;
+    memset(&RH, 0, sizeof RH);
+    if (hist && hist->hist)
+        hipLaunchKernelGGL(k_rasterize<true>, dim3(blocks), dim3(RAS_THREADS), 0, s, src, n_compact, n_segments, cl_idx, cl_start,
+                           block_first, out, info, band_row0, band_row1, wg_masks, *hist);
+    else
+        hipLaunchKernelGGL(k_rasterize<false>, dim3(blocks), dim3(RAS_THREADS), 0, s, src, n_compact, n_segments, cl_idx, cl_start,
+                           block_first, out, info, band_row0, band_row1, wg_masks, RH);
     if (reduce_now) hipLaunchKernelGGL(k_reduce_masks, dim3(1), dim3(1024), 0, s, (const uint32_t*)wg_masks, n_segments, info);
 }
 

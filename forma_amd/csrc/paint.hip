@@ -158,7 +158,7 @@ __global__ __launch_bounds__(RC_THREADS) void k_runs_count(const uint64_t* __res
         const uint32_t z0 = blockIdx.x * per, z1 = min(zero_words, z0 + per);
         for (uint32_t i = z0 + tid; i < z1; i += RC_THREADS) zero_base[i] = 0;
         if (blockIdx.x == 0 && tid == 0 && nc.ptr && *nc.ptr > nc.bound) info->plan_bad = 1u;   // more segments than provisioned
-        if (blockIdx.x == gridDim.x - 1 && range_records) {             // what the tile fields spanned (next frame's sort plan)
+        if (blockIdx.x == 0 && range_records) {                         // what the tile fields spanned (next frame's sort plan)
             uint4 m = make_uint4(0u, 0u, 0u, 0u);
             for (uint32_t b = tid; b < n_range_records; b += RC_THREADS) {
                 const uint4 r = *reinterpret_cast<const uint4*>(range_records + (size_t)b * 4);
@@ -175,20 +175,40 @@ __global__ __launch_bounds__(RC_THREADS) void k_runs_count(const uint64_t* __res
             // the key masks of the stream: on read-back-free frames the producer (k_rasterize / k_gather_chunks) left one
             // record per workgroup and nobody needed them combined until now — this workgroup does it instead of a launch
             uint32_t o = 0, oh = 0, a = 0xFFFFFFFFu, ah = 0xFFFFFFFFu, u = 0;
+            uint32_t r_nmin_x = 0, r_max_x = 0, r_nmin_y = 0, r_max_y = 0;     // pm.has_range: the producer's tile-field spans
             if (pm.rec) {
                 // (the CLAMPED count: the producer wrote one record per block of the provisioned bound, and a frame whose true
                 //  count exceeds it is voided by plan_bad above — reading info->n_segments here walked past the buffer)
                 const uint32_t nrec = pm.n_fixed ? pm.n_fixed : (n + RAS_TILE - 1) / RAS_TILE;
-                for (uint32_t b0 = 0; b0 < nrec; b0 += 8 * RC_THREADS) {
-                    uint4 m[8]; uint32_t mu[8];
+                // four records (two 16-byte loads each) in flight per lane: the registers of this loop must stay below what the
+                // streaming loop needs — at eight records the kernel lost a wave per SIMD and 16 us
+                for (uint32_t b0 = 0; b0 < nrec; b0 += 4 * RC_THREADS) {
+                    uint4 m[4], m2[4];
 #pragma unroll
-                    for (int k = 0; k < 8; k++) {
+                    for (int k = 0; k < 4; k++) {
                         const uint32_t b = b0 + k * RC_THREADS + tid;
                         m[k] = b < nrec ? *reinterpret_cast<const uint4*>(pm.rec + (size_t)b * 8) : make_uint4(0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu);
-                        mu[k] = b < nrec ? pm.rec[(size_t)b * 8 + 4] : 0u;
+                        m2[k] = b < nrec ? *reinterpret_cast<const uint4*>(pm.rec + (size_t)b * 8 + 4) : make_uint4(0u, 0x0000FFFFu, 0x0000FFFFu, 0u);
                     }
 #pragma unroll
-                    for (int k = 0; k < 8; k++) { o |= m[k].x; oh |= m[k].y; a &= m[k].z; ah &= m[k].w; u |= mu[k]; }
+                    for (int k = 0; k < 4; k++) {
+                        o |= m[k].x; oh |= m[k].y; a &= m[k].z; ah &= m[k].w; u |= m2[k].x;
+                        if (pm.has_range) {                                        // words 5, 6: min | max << 16 of tile_x, tile_y
+                            r_nmin_x = max(r_nmin_x, ~(m2[k].y & 0xFFFFu)); r_max_x = max(r_max_x, m2[k].y >> 16);
+                            r_nmin_y = max(r_nmin_y, ~(m2[k].z & 0xFFFFu)); r_max_y = max(r_max_y, m2[k].z >> 16);
+                        }
+                    }
+                }
+                if (pm.has_range) {
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) {
+                        r_nmin_x = max(r_nmin_x, (uint32_t)__shfl_xor(r_nmin_x, d, 64)); r_max_x = max(r_max_x, (uint32_t)__shfl_xor(r_max_x, d, 64));
+                        r_nmin_y = max(r_nmin_y, (uint32_t)__shfl_xor(r_nmin_y, d, 64)); r_max_y = max(r_max_y, (uint32_t)__shfl_xor(r_max_y, d, 64));
+                    }
+                    if (lane == 0 && nrec) {
+                        atomicMax(&info->tile_range[0], r_nmin_x); atomicMax(&info->tile_range[1], r_max_x);
+                        atomicMax(&info->tile_range[2], r_nmin_y); atomicMax(&info->tile_range[3], r_max_y);
+                    }
                 }
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) {
@@ -214,9 +234,13 @@ __global__ __launch_bounds__(RC_THREADS) void k_runs_count(const uint64_t* __res
     // A pure streaming read, shaped like the copy kernels that reach 6 TB/s on this chip (tools/ubench_bw.hip): 256-lane
     // workgroups in a grid-stride loop, eight 16-byte loads (two consecutive segments each) in flight per lane.  One
     // iteration covers two k_runs tiles (waves 0-1 and 2-3).
+    // Workgroup 0 of a grid of several only keeps house: its round trips (records -> reductions -> FrameInfo) would otherwise
+    // sit in front of its share of the stream, and the kernel ends with its slowest workgroup.
+    if (gridDim.x > 1 && blockIdx.x == 0) return;
+    const uint32_t sblocks = gridDim.x > 1 ? gridDim.x - 1 : 1u, sb = gridDim.x > 1 ? blockIdx.x - 1 : 0u;
     const uint4* s4 = (const uint4*)sorted;                              // hipMalloc'd: 16-byte aligned
     const uint32_t ntiles = (n + RN_TILE - 1) / RN_TILE;
-    for (uint32_t t0 = blockIdx.x * 2; t0 < ntiles; t0 += gridDim.x * 2) {
+    for (uint32_t t0 = sb * 2; t0 < ntiles; t0 += sblocks * 2) {
         const uint32_t wbase = t0 * RN_TILE + w * 1024;                   // this wave's 1024 consecutive segments
         uint4 v[8];
 #pragma unroll
@@ -445,7 +469,7 @@ void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t ti
     uint32_t* chunk_counts = scratch + ntiles + 8;                      // 4 per tile (+ slack for the last wave's second half)
     const int scanned = ntiles > 16384 ? 1 : 0;
     if (what & 1) {
-        hipLaunchKernelGGL(k_runs_count, dim3(cgrid), dim3(RC_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, scratch, chunk_counts, row_tab,
+        hipLaunchKernelGGL(k_runs_count, dim3(cgrid + 1), dim3(RC_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, scratch, chunk_counts, row_tab,
                            zero_words, info, spec_live44, flags, pm, range_records, n_range_records);
         if (scanned) launch_scan_small_u32(s, scratch, nc, RN_TILE, &info->n_runs);   // exclusive, in place; total -> n_runs
     }

@@ -41,8 +41,6 @@
 // up-front histograms of every planned digit: hist[p * 256 + d].  Per-lane run-length compression
 // (consecutive keys of a lane mostly share their tile digits) keeps the LDS atomics rare.
 // ------------------------------------------------------------------------------------------------
-#define HS_COPIES  16
-#define SORT_BINS  512                              // histogram words per pass (a pass has 16, 256 or 512 bins)
 #define HS_THREADS 256
 #define HS_KPT     16
 #define HS_TILE    (HS_THREADS * HS_KPT)
@@ -558,10 +556,23 @@ size_t sort_zero_words(size_t n, const SortPlan& plan) {
     return sort_fixed_words() + (size_t)plan.n_passes * ntiles * SORT_BINS;
 }
 
+RasHist make_ras_hist(const SortPlan& plan, uint32_t* sort_scratch) {
+    RasHist R;
+    memset(&R, 0, sizeof R);
+    if (plan.n_passes < 1 || plan.n_passes > RH_MAX_PASSES) return R;
+    for (int p = 0; p < plan.n_passes; p++) {
+        if (plan.mask[p] >= SORT_BINS) return R;
+        R.shift[p] = (uint32_t)plan.shift[p]; R.mask[p] = plan.mask[p]; R.bias[p] = plan.bias[p]; R.fmask[p] = plan.fmask[p];
+    }
+    R.n_passes = (uint32_t)plan.n_passes;
+    R.hist = sort_scratch;                                   // [HS_COPIES][SORT_MAX_PASSES][SORT_BINS] at the head of the scratch
+    return R;
+}
+
 const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a, uint64_t* b, DevCount nc,
                                   const SortPlan& plan, int digit_bits, uint32_t* scratch, uint32_t* err,
                                   hipEvent_t* pass_ev0, hipEvent_t* pass_ev1, const ChunkedSrc* chunked, FrameInfo* info,
-                                  bool scratch_is_zero) {
+                                  bool scratch_is_zero, bool hist_ready) {
     const size_t n = nc.bound;                        // provisioning (grid, scratch); the kernels use the device count
     if (n <= 1 || plan.n_passes == 0) return in;
     const uint32_t ntiles = (uint32_t)((n + OS_TILE - 1) / OS_TILE);
@@ -576,7 +587,7 @@ const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a
     memset(&C0, 0, sizeof C0);
     const ChunkedSrc C = chunked ? *chunked : C0;
     if (chunked) hipLaunchKernelGGL(k_sort_hist<true>, dim3(hb), dim3(HS_THREADS), 0, s, in, nc, plan, hist, C, info);
-    else hipLaunchKernelGGL(k_sort_hist<false>, dim3(hb), dim3(HS_THREADS), 0, s, in, nc, plan, hist, C, info);
+    else if (!(hist_ready && scratch_is_zero)) hipLaunchKernelGGL(k_sort_hist<false>, dim3(hb), dim3(HS_THREADS), 0, s, in, nc, plan, hist, C, info);
     const uint32_t cap = 512u * 512u / OS_THREADS;        // persistent: 16 waves per CU
     uint32_t grid = ntiles < cap ? ntiles : cap;
     const uint64_t* src = in;

@@ -108,6 +108,46 @@ def test_value_range_digits_on_a_power_of_two_canvas(monkeypatch):
     ctx.close()
 
 
+@pytest.mark.parametrize("switch", ["", "no_ras_hist", "no_prezero", "digit_bits=4"])
+@pytest.mark.parametrize("paint_order", [True, False])
+def test_sort_histograms_taken_by_the_rasterizer(monkeypatch, switch, paint_order):
+    """On read-back-free frames k_rasterize counts the digits of the speculated sort plan while it makes the keys (up to three
+    passes: the sort then runs without k_sort_hist's read of the whole stream), leaves the tile-field spans in its mask records
+    and voids the frame if a key leaves the span a biased digit was planned for.  Frames with it, without it (no_ras_hist; no_prezero:
+    nobody cleared the histograms ahead of the rasterizer; four-bit digits and layers inserted out of paint order: more passes
+    than the rasterizer counts) — sorted stream and image equal the oracle's on every frame, also after the geometry moves."""
+    W, H = 1500, 1100
+    rng = np.random.default_rng(77)
+    comp = S.Composition()
+    orders = list(range(90))
+    if not paint_order:
+        rng.shuffle(orders)                                             # the stream is not non-decreasing in layer: layer digits too
+    for order in orders:
+        x, y = float(rng.uniform(-40, W - 100)), float(rng.uniform(-40, H - 100))
+        comp.get_mut_or_insert_default(int(order)).insert(S.custom_circle(x + 60, y + 60, float(rng.uniform(10, 140)))).set_props(
+            S.solid(tuple(float(v) for v in rng.random(3)) + (float(rng.uniform(0.3, 1.0)),)))
+    import forma_amd
+    if switch:
+        monkeypatch.setenv("FORMA_HIP_DEBUG", switch)
+    ctx = forma_amd.Context(0)
+    o, t = both(ctx, comp)
+    want = o.render(W, H)
+    for frame in range(4):
+        img = ctx.render(W, H)
+        assert np.array_equal(ctx.segments(1), o.segments(1)), frame
+        assert np.abs(want.astype(int) - img.astype(int)).max() <= 1, frame
+    g = t["geoms"].copy()
+    g["flags"][:] = 1
+    g["xf"][:] = np.array([0.9, 0.0, 0.0, 1.1, 35.0, -20.0], np.float32)      # every shape moves: other digits, other spans
+    o.set_geoms(g); ctx.set_geoms(g)
+    want = o.render(W, H)
+    for frame in range(3):
+        img = ctx.render(W, H)
+        assert np.array_equal(ctx.segments(1), o.segments(1)), ("moved", frame)
+        assert np.abs(want.astype(int) - img.astype(int)).max() <= 1, ("moved", frame)
+    ctx.close()
+
+
 @pytest.mark.parametrize("bits", [0, 4, 8, 9])
 def test_sort_coherent_streams(ctx, bits):
     """what a rasterizer emits: long runs of equal tile digits, the same digit coming back within one wave row of 64 keys
