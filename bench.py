@@ -278,13 +278,20 @@ def main():
                     "measured": f"HIP events carried by every k_onesweep launch (hipExtLaunchKernelGGL: the dispatch's own start and end) of "
                                 f"{acc.get('_frames', 0)} frames with ONE frame in flight, a further timed region of this run; matches `rocprofv3 "
                                 "--kernel-trace --stats -- python bench.py --in-flight 1 --no-d2h --no-animated --no-cpu-baseline`, profiles/r04_kernel_stats_inflight1.csv"}
-        # the whole sort against the same roofline: histogram read + p digit passes = 8 N (2 p + 1) bytes
+        # the whole sort against the same roofline: histogram read + p digit passes = 8 N (2 p + 1) bytes — or 16 N p
+        # when the histograms come out of the rasterizer's registers (read-back-free frames with <= 3 passes: k_sort_hist and its
+        # read of the stream do not run; the counting costs k_rasterize ~13 us, which stays in the rasterize stage)
         sort_us = stage.get("sort_us", 0.0)
+        dbg = os.environ.get("FORMA_HIP_DEBUG", "")
+        hist_fused = mode in ("single", "bands", "frames") and 0 < passes <= 3 and not any(t in dbg for t in ("no_ras_hist", "no_prezero", "sync"))
         if sort_us > 0 and passes:
-            whole = 8.0 * n_local * (2 * passes + 1) / (sort_us * 1e-6) / 1e9
-            roofline["whole_sort"] = {"algorithmic_bytes": 8.0 * n_local * (2 * passes + 1), "us": round(sort_us, 1), "achieved": round(whole, 1),
-                                      "frac": round(whole / HBM_PEAK_GBS, 4),
-                                      "what": "k_sort_hist + every digit pass + the gaps between them, stage events of the same frames"}
+            sort_bytes = 8.0 * n_local * (2 * passes + (0 if hist_fused else 1))
+            whole = sort_bytes / (sort_us * 1e-6) / 1e9
+            roofline["whole_sort"] = {"algorithmic_bytes": sort_bytes, "us": round(sort_us, 1), "achieved": round(whole, 1),
+                                      "frac": round(whole / HBM_PEAK_GBS, 4), "histograms": "k_rasterize" if hist_fused else "k_sort_hist",
+                                      "what": ("every digit pass + the gaps between them (the digit histograms are counted by k_rasterize "
+                                               "while it makes the keys)" if hist_fused else
+                                               "k_sort_hist + every digit pass + the gaps between them") + ", stage events of the same frames"}
         # what the stages behind the sort move, against what they have to (8 N in + 4 W H out): counters of the committed build
         if use_pmc:
             post = [v.get("hbm_bytes_per_launch", 0) for k, v in pmc["kernels"].items()
