@@ -29,8 +29,10 @@
 #define OS_THREADS 1024
 #endif
 #define OS_WAVES   (OS_THREADS / 64)
-#define OS_KPT     16                               // keys per lane
-#define OS_TILE    (OS_THREADS * OS_KPT)            // 16384 keys per tile -> 128 KiB of LDS staging, 1 workgroup (16 waves) per CU
+// keys per lane: 16 (16384 keys per tile -> 128 KiB of LDS staging, 1 workgroup = 16 waves per CU); the 512-bin pass takes 14 —
+// its counters and 9-bit ranks cost registers, at 16 keys it spilled (C4: 59.2 -> 53.6 us per pass; 256 bins: 62.1 -> 63.4)
+__host__ __device__ constexpr int os_kpt(int bits) { return bits == 9 ? 14 : 16; }
+#define OS_TILE_MIN (OS_THREADS * 14)               // provisioning: the most tiles any pass of n keys can have
 #define ST_VALMASK 0x3FFFFFFFu
 #ifndef OS_LBW
 #define OS_LBW     8
@@ -319,17 +321,18 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
                                                          uint32_t* __restrict__ ticket, uint32_t* __restrict__ err,
                                                          ChunkedSrc C /* first pass of a chunked stream, else n_chunks = 0 */) {
     constexpr int RADIX = 1 << BITS;
+    constexpr int KPT = os_kpt(BITS), TILE = OS_THREADS * KPT;  // keys per lane, keys per tile
     const uint32_t n = dev_count(nc);                       // (chunked: k_sort_hist has published the total)
     constexpr bool chunked = CHUNKED;                       // (one bucket at offset 0 is launched as a plain stream)
     ChunkMap M;
     if (chunked) M = load_chunk_map(C, nc.bound);
-    __shared__ uint64_t staged[OS_TILE];
+    __shared__ uint64_t staged[TILE];
     __shared__ WaveCounters<BITS> whist;
     __shared__ uint32_t s_gdelta[RADIX];
     __shared__ uint32_t s_scan[16];
     __shared__ uint32_t s_tile;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t ntiles = (n + OS_TILE - 1) / OS_TILE;
+    const uint32_t ntiles = (n + TILE - 1) / TILE;
 
     // a wave clears its own counters: here once, then right after it has staged a tile's keys (nobody else reads a wave's
     // row between the barrier in front of the staging and the one behind the look-back) — the tile loop has no clearing
@@ -360,28 +363,28 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
 #ifdef SORT_PROF
         if (tid == 0) atomicAdd(&g_sort_prof[15], 1ull);
 #endif
-        const uint32_t bbase = tile * OS_TILE;
-        const uint32_t wbase = bbase + w * (64 * OS_KPT);
+        const uint32_t bbase = tile * TILE;
+        const uint32_t wbase = bbase + w * (64 * KPT);
 
-        uint64_t keys[OS_KPT];
-        uint32_t rnk[OS_KPT / 2];                          // 16-bit ranks, two per register
+        uint64_t keys[KPT];
+        uint32_t rnk[KPT / 2];                          // 16-bit ranks, two per register
         // what pads the stream's last tile must land behind every real key of the tile: the LAST digit — with a biased digit
         // that is not the all-ones key ((~0 >> shift) - bias lands in the middle of the bins)
         const uint64_t pad = (uint64_t)(dmask + bias) << shift;
 #pragma unroll
-        for (int j = 0; j < OS_KPT; j++) {
+        for (int j = 0; j < KPT; j++) {
             uint32_t idx = wbase + j * 64 + lane;
             keys[j] = idx < n ? in[chunked ? chunk_phys(M, idx) : idx] : pad;      // padding: last digit, last in stream order, never written
         }
 #ifdef SORT_PROF
-        if (keys[OS_KPT - 1] == 0x123456789ull) atomicAdd(&g_sort_prof[14], 1ull);      // forces the loads to have landed
+        if (keys[KPT - 1] == 0x123456789ull) atomicAdd(&g_sort_prof[14], 1ull);      // forces the loads to have landed
         SP_STAMP(1);                                        // key loads
 #endif
         // ---- stable rank of every key among the same-digit keys of its wave ----------------------------------
         // per row: the lowest peer lane adds the class size to the wave's LDS digit counter, then every lane reads
         // the counter back (LDS operations of one wave retire in order): rank = counter - class size + lanes below.
 #pragma unroll
-        for (int j = 0; j < OS_KPT; j++) {
+        for (int j = 0; j < KPT; j++) {
             const uint32_t dg = key_digit<HI>(keys[j], shift, dmask, bias);
             // (peeling the few distinct digits of a row off leader by leader — readlane, compare, mbcnt per class — was
             //  measured slower than this fixed 8-ballot form: 71 vs 61 us per pass, the dependent scalar chain does not pipeline;
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
         // ---- stage in digit order (needs only tile-local positions), BEFORE the look-back: the key registers die here
         //      and the staging of waves 4..7 overlaps the global round trips of the look-back lanes ---------------------
 #pragma unroll
-        for (int j = 0; j < OS_KPT; j++) {
+        for (int j = 0; j < KPT; j++) {
             const uint32_t dg = key_digit<HI>(keys[j], shift, dmask, bias);
             staged[whist.get(w, dg) + ((rnk[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu)] = keys[j];
         }
@@ -464,13 +467,13 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
         // the next ticket's round trip (~1 us) runs under the scatter; every thread read s_tile barriers ago
         if (tid == OS_THREADS - 1) s_tile = atomicAdd(ticket, 1u);
         // ---- coalesced stores: every digit run leaves the CU as one contiguous piece --------------------------------
-        const uint32_t nvalid = min((uint32_t)OS_TILE, n - bbase);
+        const uint32_t nvalid = min((uint32_t)TILE, n - bbase);
         // (the compiler otherwise hoists the sixteen `j * 1024 + tid` out of the tile loop and, at the register cap, SPILLS them:
         //  29 scratch round trips per tile in the 512-bin instantiation — recomputing one OR per key is free)
         uint32_t tid_here = (uint32_t)tid;
         asm volatile("" : "+v"(tid_here));
 #pragma unroll
-        for (int j = 0; j < OS_KPT; j++) {
+        for (int j = 0; j < KPT; j++) {
             uint32_t i = j * OS_THREADS + tid_here;
             if (i < nvalid) {
                 uint64_t key = staged[i];
@@ -544,7 +547,7 @@ uint32_t sort_hist_blocks(size_t n) {
 static inline size_t sort_fixed_words() { return (size_t)HS_COPIES * SORT_MAX_PASSES * SORT_BINS + 16 + 2048 * 4; }
 const uint32_t* sort_range_words(const uint32_t* scratch) { return scratch + (size_t)HS_COPIES * SORT_MAX_PASSES * SORT_BINS + 16; }
 size_t sort_scratch_words(size_t n) {
-    size_t ntiles = (n + OS_TILE - 1) / OS_TILE;
+    size_t ntiles = (n + OS_TILE_MIN - 1) / OS_TILE_MIN;
     // [hist: HS_COPIES x MAX_PASSES x SORT_BINS] [tickets: MAX_PASSES, pad to 16] [tile-field spans: 2048 x 4] [status: MAX_PASSES * ntiles * SORT_BINS]
     return sort_fixed_words() + (size_t)SORT_MAX_PASSES * (ntiles + 1) * SORT_BINS;
 }
@@ -552,7 +555,7 @@ size_t sort_scratch_words(size_t n) {
 // status rows of the passes that run): launch_radix_sort clears them itself unless the caller says an earlier kernel of the
 // frame already did (api.cpp folds the clearing into the frame's first kernel)
 size_t sort_zero_words(size_t n, const SortPlan& plan) {
-    const size_t ntiles = (n + OS_TILE - 1) / OS_TILE;
+    const size_t ntiles = (n + OS_TILE_MIN - 1) / OS_TILE_MIN;
     return sort_fixed_words() + (size_t)plan.n_passes * ntiles * SORT_BINS;
 }
 
@@ -575,7 +578,7 @@ const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a
                                   bool scratch_is_zero, bool hist_ready) {
     const size_t n = nc.bound;                        // provisioning (grid, scratch); the kernels use the device count
     if (n <= 1 || plan.n_passes == 0) return in;
-    const uint32_t ntiles = (uint32_t)((n + OS_TILE - 1) / OS_TILE);
+    const uint32_t ntiles = (uint32_t)((n + OS_TILE_MIN - 1) / OS_TILE_MIN);     // (row stride of the status words: sort_zero_words)
     uint32_t* hist = scratch;
     uint32_t* tickets = scratch + (size_t)HS_COPIES * SORT_MAX_PASSES * SORT_BINS;
     uint32_t* status = scratch + sort_fixed_words();
@@ -589,7 +592,6 @@ const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a
     if (chunked) hipLaunchKernelGGL(k_sort_hist<true>, dim3(hb), dim3(HS_THREADS), 0, s, in, nc, plan, hist, C, info);
     else if (!(hist_ready && scratch_is_zero)) hipLaunchKernelGGL(k_sort_hist<false>, dim3(hb), dim3(HS_THREADS), 0, s, in, nc, plan, hist, C, info);
     const uint32_t cap = 512u * 512u / OS_THREADS;        // persistent: 16 waves per CU
-    uint32_t grid = ntiles < cap ? ntiles : cap;
     const uint64_t* src = in;
     uint64_t* dst = a;
     for (int p = 0; p < P; p++) {
@@ -599,6 +601,10 @@ const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a
         // With pass events the launch carries them itself (hipExtLaunchKernelGGL: the events take the dispatch's own start and
         // end timestamps, what a profiler reports as the kernel's duration) instead of markers in front of and behind it
         hipEvent_t e0 = pass_ev0 ? pass_ev0[p] : nullptr, e1 = pass_ev1 ? pass_ev1[p] : nullptr;
+        const int bits = digit_bits == 4 ? 4 : (plan.mask[p] > 255u ? 9 : 8);
+        const uint32_t tile = (uint32_t)OS_THREADS * (uint32_t)os_kpt(bits);
+        const uint32_t ptiles = (uint32_t)((n + tile - 1) / tile);
+        const uint32_t grid = ptiles < cap ? ptiles : cap;
 #define OS_LAUNCH(B, CH, HI_) hipExtLaunchKernelGGL((k_onesweep<B, CH, HI_>), dim3(grid), dim3(OS_THREADS), 0, s, e0, e1, 0, src, dst, nc, \
                                            plan.shift[p], plan.mask[p], plan.bias[p], (const uint32_t*)(hist + p * SORT_BINS), st, tickets + p, err, ch ? C : C0)
 #define OS_LAUNCH_B(B) do { if (ch) { if (hi) OS_LAUNCH(B, true, true); else OS_LAUNCH(B, true, false); } \
