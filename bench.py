@@ -40,6 +40,7 @@ Prints ONE JSON line on rank 0.
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import statistics
@@ -138,12 +139,19 @@ def main():
         torch.cuda.synchronize()
 
     def timed(fn):
-        """wall seconds of fn(), bracketed by barrier + synchronize on both sides, maximum over ranks"""
+        """wall seconds of fn(), bracketed by barrier + synchronize on both sides, maximum over ranks.  The Python collector
+        stays out of the timed region: the host loop allocates a few small objects per render call, and a generation-2 pass
+        over a 30 000-layer composition is tens of milliseconds — one such pass inside a 23 ms region halved `value` once
+        (profiles/r04: 1 362 fps next to blocks of 2 570)."""
         sync_all()
+        gc_was = gc.isenabled()
+        gc.disable()
         t0 = time.perf_counter()
         fn()
         sync_all()
         dt = time.perf_counter() - t0
+        if gc_was:
+            gc.enable()
         return sharding.max_over_ranks(dist, dt, device=cdev) if dist is not None else dt
 
     def measure(workload, primary=True, mode_req=None):
@@ -216,6 +224,9 @@ def main():
             return per_step * steps / timed(lambda: frames(steps))
 
         frames_per_step = world if mode == "frames" else 1          # frames mode: one whole frame per GPU per step
+        gc.collect()
+        gc.freeze()                                                 # (the scene's objects leave the collector's generations — before
+        #                                                             the GPU warms up: a collection here idles it for ~0.1 s)
         if driver and in_flight > 1:
             ctx.set_frames_in_flight(in_flight)
             # SET-UP, not warm-up: every frame slot runs its first frame synchronously (it learns N, the key masks and J), its
@@ -223,6 +234,14 @@ def main():
             # did this, and with W = 5 over three slots the timed region still held first-time work: `value` sat 17 % under the
             # median of the blocks that followed.
             frames(3 * in_flight + 3)
+            # ... and the clocks: the GPU sat idle while Python built the scene; a quarter of a second of frames before the
+            # warm-up lets the power management settle (untimed, like everything above)
+            if mode in ("single", "multi"):                         # (one process renders: a time-based loop is safe)
+                t_ramp = time.perf_counter()
+                while time.perf_counter() - t_ramp < 0.25:
+                    frames(8)
+            else:
+                frames(64)                                          # (every rank the same count: frames may hold collectives)
         frames(max(args.warmup, 1))                                 # W warm-up frames
         elapsed = timed(lambda: frames(args.steps))                 # THE timed region: exactly K frames -> `value`
         fps = frames_per_step * args.steps / elapsed
@@ -237,7 +256,7 @@ def main():
         acc = {}
 
         def staged():
-            for _ in range(args.steps):
+            for _ in range(max(args.steps, 60)):                       # (>= 60 frames: a 20-frame mean of 60 us kernels wobbles by 2 %)
                 r = frame(timings=True)
                 if r is None:
                     continue
