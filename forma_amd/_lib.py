@@ -53,6 +53,10 @@ class ContextInfoT(C.Structure):
                 ("devices", C.c_int32 * 8)]
 
 
+class SortPlanT(C.Structure):
+    _fields_ = [("n_passes", C.c_uint32), ("biased", C.c_uint32), ("shift", C.c_uint32 * 12), ("mask", C.c_uint32 * 12), ("bias", C.c_uint32 * 12)]
+
+
 class FlattenTablesT(C.Structure):
     _fields_ = [("point_commands", C.c_void_p), ("point_indices", C.c_void_p), ("quad_indices", C.c_void_p), ("n_points", C.c_size_t),
                 ("qx", C.c_void_p), ("qy", C.c_void_p), ("qw", C.c_void_p), ("x0", C.c_void_p), ("dx_recip", C.c_void_p),
@@ -86,6 +90,7 @@ SYMBOLS = {
     "forma_hip_set_frames_in_flight": (_i, [_vp, _i]),
     "forma_hip_sync": (_i, [_vp]),
     "forma_hip_context_info": (_i, [_vp, _vp]),
+    "forma_hip_sort_plan": (_i, [C.c_uint64, _i, _i, _vp, _vp]),
     "forma_hip_trim": (_i, [_vp]),
     "forma_hip_read_segments": (_i, [_vp, _i, _vp, _sz, _vp]),
     "forma_hip_read_image": (_i, [_vp, _vp, _sz]),

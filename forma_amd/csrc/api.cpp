@@ -1349,6 +1349,21 @@ int forma_hip_context_info(forma_hip_ctx* ctx, forma_context_info_t* out) {
     return FORMA_OK;
 }
 
+// The digit plan of a frame's segment sort, as the library would make it (host logic only: no device is touched).
+int forma_hip_sort_plan(uint64_t live_key_bits, int layer_sorted, int digit_bits, const uint32_t* field_range, forma_sort_plan_t* out) {
+    if (!out || (digit_bits != 0 && digit_bits != 4 && digit_bits != 8 && digit_bits != 9)) return FORMA_E_ARG;
+    KeyRange R{0u, 0u, 0u, 0u, false};
+    if (field_range) R = KeyRange{field_range[0], field_range[1], field_range[2], field_range[3], true};
+    bool biased = false;
+    const SortPlan P = make_segment_sort_plan(live_key_bits & 0xFFFFFFFFFFFull, layer_sorted != 0, digit_bits, field_range ? &R : nullptr, &biased);
+    memset(out, 0, sizeof *out);
+    out->n_passes = (uint32_t)P.n_passes; out->biased = biased ? 1u : 0u;
+    for (int p = 0; p < P.n_passes && p < FORMA_SORT_MAX_PASSES; p++) {
+        out->shift[p] = (uint32_t)P.shift[p]; out->mask[p] = P.mask[p]; out->bias[p] = P.bias[p];
+    }
+    return FORMA_OK;
+}
+
 // Per-frame device memory is grown to the largest frame seen and kept (a steady-state renderer never allocates).  trim gives
 // it back: everything a frame writes before it reads — streams, records, tables, the scratch image — of the context and of
 // its frame slots.  The scene (geometry, styles, images) and the buffer-layer caches (state across frames) stay.  The next

@@ -276,6 +276,22 @@ typedef struct forma_context_info {
     int32_t  devices[FORMA_MAX_DEVICES];
 } forma_context_info_t;
 int forma_hip_context_info(forma_hip_ctx* ctx, forma_context_info_t* out);
+/* Introspection, host logic only (no device is touched): the digit plan the library makes for a frame's pixel-segment sort
+ * (reference: one `par_sort_unstable` on the 44 key bits, cpu/rasterizer.rs:161-164, pixel_segment.rs:161-171).  Pass p is a
+ * stable counting pass on digit = ((segment >> shift[p]) - bias[p]) & mask[p], least significant pass first.
+ * live_key_bits: bit i set = bit 20 + i of the segments varies in the stream (OR ^ AND of the keys); layer_sorted: the stream
+ * is non-decreasing in layer (the layer digits are dropped); digit_bits: 0 (8, or 9 where that saves a pass), 4, 8 or 9;
+ * field_range = {min tile_x + 1, max tile_x + 1, min tile_y + 1, max tile_y + 1} as stored in the keys, or NULL: with it a tile
+ * field may be sorted relative to its minimum (one digit of bit_length(max - min) bits) where that saves a pass.
+ * The CPU test suite checks the property that matters: the passes, applied as stable sorts, order any keys with those live bits
+ * and that range exactly like a stable sort on bits 20..63. */
+#define FORMA_SORT_MAX_PASSES 12
+typedef struct forma_sort_plan {
+    uint32_t n_passes;
+    uint32_t biased;                    /* some pass uses a non-zero bias (needs field_range to hold for every key) */
+    uint32_t shift[FORMA_SORT_MAX_PASSES], mask[FORMA_SORT_MAX_PASSES], bias[FORMA_SORT_MAX_PASSES];
+} forma_sort_plan_t;
+int forma_hip_sort_plan(uint64_t live_key_bits, int layer_sorted, int digit_bits, const uint32_t* field_range, forma_sort_plan_t* out);
 /* Give per-frame device memory back (it is grown to the largest frame seen and otherwise kept until destroy): streams,
  * records, tables and the scratch image of the context and of its frame slots.  The scene and the buffer-layer caches stay.
  * forma_hip_read_image returns FORMA_E_STATE and forma_hip_read_segments an empty stream until the next render.  (The reference's renderer owns Vecs

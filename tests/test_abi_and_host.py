@@ -112,6 +112,8 @@ int main(void) {
     printf("rect %zu\n", sizeof(forma_rect_t));
     printf("image %zu\n", sizeof(forma_image_t));
     printf("timings %zu %zu %zu\n", sizeof(forma_timings_t), offsetof(forma_timings_t, n_lines), offsetof(forma_timings_t, n_tile_entries));
+    printf("info %zu %zu\n", sizeof(forma_context_info_t), offsetof(forma_context_info_t, devices));
+    printf("plan %zu %zu %zu\n", sizeof(forma_sort_plan_t), offsetof(forma_sort_plan_t, mask), offsetof(forma_sort_plan_t, bias));
     return 0;
 }
 ''')
@@ -126,6 +128,77 @@ int main(void) {
     from forma_amd import _lib
     t = _lib.TimingsT
     assert out["timings"].split() == [str(C.sizeof(t)), str(t.n_lines.offset), str(t.n_tile_entries.offset)]
+    assert out["info"].split() == [str(C.sizeof(_lib.ContextInfoT)), str(_lib.ContextInfoT.devices.offset)]
+    assert out["plan"].split() == [str(C.sizeof(_lib.SortPlanT)), str(_lib.SortPlanT.mask.offset), str(_lib.SortPlanT.bias.offset)]
+
+
+def _plan(live, layer_sorted, digit_bits, rng=None):
+    from forma_amd import _lib
+    L = _lib.lib()
+    out = _lib.SortPlanT()
+    r = None if rng is None else (C.c_uint32 * 4)(*rng)
+    assert L.forma_hip_sort_plan(C.c_uint64(live), int(layer_sorted), digit_bits, r, C.byref(out)) == 0
+    return out
+
+
+@pytest.mark.parametrize("digit_bits", [0, 4, 8, 9])
+def test_sort_plans_order_like_a_stable_sort_on_the_key(digit_bits):
+    """The digit plan of the segment sort is host logic (`forma_hip_sort_plan`: no device): digits packed over the LIVE key bits
+    only, the layer digits dropped when the stream is already non-decreasing in layer, nine-bit digits where they save a pass,
+    a tile field taken relative to its minimum where the span is known and that saves another.  The property every plan must
+    have, checked here on the CPU with numpy's stable sort standing in for the counting passes: applied least significant pass
+    first, the passes order any keys with those live bits (and that span) exactly like ONE stable sort on bits 20..63
+    (pixel_segment.rs:161-171) — for random live masks, canvases of 2^k tiles (field value 2^k: the extra bit), both layer
+    orders."""
+    rng = np.random.default_rng(900 + digit_bits)
+    for trial in range(60):
+        tiles_w = int(rng.choice([3, 16, 64, 240, 256, 512, 1024, 4095]))
+        tiles_h = int(rng.choice([2, 16, 68, 135, 256, 512, 2047]))
+        n_layers = int(rng.choice([1, 2, 200, 70000, (1 << 21) - 1]))
+        n = 4000
+        x0 = int(rng.integers(0, tiles_w)); x1 = int(rng.integers(x0, tiles_w + 1))          # tile_x + 1 in [x0, x1]  (0 = left of the canvas)
+        y0 = int(rng.integers(1, tiles_h + 1)); y1 = int(rng.integers(y0, tiles_h + 1))
+        tx = rng.integers(x0, x1 + 1, n, dtype=np.uint64)
+        ty = rng.integers(y0, y1 + 1, n, dtype=np.uint64)
+        layer = rng.integers(0, n_layers, n, dtype=np.uint64)
+        layer_sorted = bool(trial & 1)
+        if layer_sorted:
+            layer = np.sort(layer)                                       # non-decreasing along the stream, ties everywhere
+        low = rng.integers(0, 1 << 20, n, dtype=np.uint64)               # local_x / local_y / area / cover: never sorted on
+        v = (ty << np.uint64(53)) | (tx << np.uint64(41)) | (layer << np.uint64(20)) | low
+        key = v >> np.uint64(20)
+        live = int(np.bitwise_or.reduce(key) ^ np.bitwise_and.reduce(key))
+        for use_range in (False, True):
+            r = (int(tx.min()), int(tx.max()), int(ty.min()), int(ty.max())) if use_range else None
+            P = _plan(live, layer_sorted, digit_bits, r)
+            assert P.n_passes <= 12
+            assert use_range or not P.biased
+            out = v.copy()
+            for p in range(P.n_passes):
+                assert 20 <= P.shift[p] < 64 and P.mask[p] < (16 if digit_bits == 4 else 512)
+                d = ((out >> np.uint64(P.shift[p])) - np.uint64(P.bias[p])) & np.uint64(P.mask[p])
+                out = out[np.argsort(d, kind="stable")]
+            want = v[np.argsort(key, kind="stable")]
+            assert np.array_equal(out, want), (trial, use_range, tiles_w, tiles_h, n_layers, layer_sorted, P.n_passes, list(P.shift)[:P.n_passes])
+        # what the plan is for: no digit is spent on bits that do not vary
+        plain = _plan(live, layer_sorted, digit_bits)
+        covered = 0
+        for p in range(plain.n_passes):
+            covered |= plain.mask[p] << (plain.shift[p] - 20)
+        need = live & (~0x1FFFFF if layer_sorted else ~0)
+        assert covered & need == need
+
+
+def test_sort_plan_saves_the_pass_of_a_power_of_two_canvas():
+    """8192 x 8192 pixels = 512 x 512 tiles: the fields store 1..512, ten live bits each — three 8-bit passes, or (9-bit digits,
+    fields relative to their minima) two; 3840 x 2160 is two 8-bit passes either way."""
+    live = ((0x3FF << 33) | (0x3FF << 21))                               # tile_y, tile_x: ten live bits each (key bit = segment bit - 20)
+    assert _plan(live, True, 0).n_passes == 3
+    P = _plan(live, True, 0, (1, 512, 1, 512))
+    assert P.n_passes == 2 and P.biased and sorted(P.mask[:2]) == [511, 511]
+    live4k = ((0xFF << 33) | (0xFF << 21))
+    assert _plan(live4k, True, 0).n_passes == 2 and _plan(live4k, True, 0, (1, 240, 1, 135)).n_passes == 2
+    assert _plan(live4k | 0x7FFF, False, 0).n_passes == 4                # 15 live layer bits on top: two more digits
 
 
 class _FakeCtx:
