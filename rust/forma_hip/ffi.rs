@@ -137,6 +137,19 @@ pub struct forma_context_info_t {
     pub devices: [i32; FORMA_MAX_DEVICES],
 }
 
+pub const FORMA_SORT_MAX_PASSES: usize = 12;
+
+/// `forma_sort_plan_t` (`include/forma_hip.h`): the digit plan of a frame's segment sort (introspection, host logic only).
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct forma_sort_plan_t {
+    pub n_passes: u32,
+    pub biased: u32,
+    pub shift: [u32; FORMA_SORT_MAX_PASSES],
+    pub mask: [u32; FORMA_SORT_MAX_PASSES],
+    pub bias: [u32; FORMA_SORT_MAX_PASSES],
+}
+
 #[link(name = "forma_hip")]
 extern "C" {
     // lifetime
@@ -243,6 +256,13 @@ extern "C" {
     pub fn forma_hip_set_frames_in_flight(ctx: *mut forma_hip_ctx, n: c_int) -> c_int;
     pub fn forma_hip_sync(ctx: *mut forma_hip_ctx) -> c_int;
     pub fn forma_hip_context_info(ctx: *mut forma_hip_ctx, out: *mut forma_context_info_t) -> c_int;
+    pub fn forma_hip_sort_plan(
+        live_key_bits: u64,
+        layer_sorted: c_int,
+        digit_bits: c_int,
+        field_range: *const u32,
+        out: *mut forma_sort_plan_t,
+    ) -> c_int;
     pub fn forma_hip_render_enqueue(
         ctx: *mut forma_hip_ctx,
         dst: *mut u8,
