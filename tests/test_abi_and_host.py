@@ -29,6 +29,33 @@ def test_library_exports_every_symbol():
     assert b"gfx950" in L.forma_hip_version()
 
 
+def _c_struct_fields(hdr, name):
+    """field names of `typedef struct ... { ... } name;` in declaration order (`a[N], b[N]` declares two)"""
+    end = re.search(r"\}\s*" + name + r"\s*;", hdr)
+    assert end, name
+    body = hdr[hdr.rindex("{", 0, end.start()) + 1:end.start()]
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = decl.split(None, 1)[1] if not decl.startswith("const ") else decl.split(None, 2)[2]
+        fields += [re.sub(r"\[.*?\]", "", d).replace("*", "").strip() for d in names.split(",")]
+    return fields
+
+
+def test_rust_shim_declares_the_same_abi():
+    """rust/forma_hip/ffi.rs (the `extern "C"` block a forma maintainer compiles; no toolchain here) names exactly the entry
+    points of include/forma_hip.h, and its `#[repr(C)]` mirrors have the header's fields in the header's order."""
+    ffi = open(os.path.join(ROOT, "rust", "forma_hip", "ffi.rs")).read()
+    assert sorted(set(re.findall(r"pub fn (forma_hip_[a-z_0-9]+)", ffi))) == declared_symbols()
+    hdr = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for name in ("forma_geom_t", "forma_rect_t", "forma_image_t", "forma_timings_t", "forma_context_info_t", "forma_sort_plan_t"):
+        r = re.search(r"pub struct " + name + r"\s*\{(.*?)\n\}", ffi, flags=re.S)
+        assert r, name + " missing in ffi.rs"
+        assert re.findall(r"pub (\w+)\s*:", r.group(1)) == _c_struct_fields(hdr, name), name
+
+
 def test_no_cpu_fallback():
     """Without a visible MI355X the product path raises; it never computes on the CPU."""
     import forma_amd
