@@ -58,7 +58,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2   # wave64 VALU instructions/ns the chip can issue: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles
-PMC_FILES = [os.path.join("profiles", "r04_pmc_summary.json"), os.path.join("profiles", "r03_pmc_summary.json")]
+PMC_FILES = [os.path.join("profiles", f"r0{r}_pmc_summary.json") for r in (5, 4, 3)]
 
 
 def parse():
@@ -253,7 +253,7 @@ def main():
             frames(2)
         blocks1 = [rate(args.steps, frames_per_step) for _ in range(5)] if in_flight > 1 else blocks
         # K more frames, one in flight, HIP events at the stage boundaries on the context's stream(s)
-        acc = {}
+        acc, kacc = {}, {}
 
         def staged():
             for _ in range(max(args.steps, 60)):                       # (>= 60 frames: a 20-frame mean of 60 us kernels wobbles by 2 %)
@@ -263,9 +263,16 @@ def main():
                 for k, v in r[1].items():
                     acc[k] = acc.get(k, 0.0) + float(v)
                 acc["_frames"] = acc.get("_frames", 0) + 1
+                if mode == "single":                                   # every kernel's own launch events (forma_hip_kernel_times)
+                    for name, _st, _t0, us in ctx.kernel_times():
+                        e = kacc.setdefault(name, [0.0, 0])
+                        e[0] += us
+                        e[1] += 1
         timed(staged)
         nfr = max(acc.get("_frames", 0), 1)
         stage = {k: v / nfr for k, v in acc.items() if k != "_frames"}
+        # per kernel: microseconds per FRAME (all its launches of a frame together) and launches per frame
+        kernels_us = {k: {"us_per_frame": round(v[0] / nfr, 2), "launches_per_frame": round(v[1] / nfr, 2)} for k, v in kacc.items()}
         if dist is not None and mode == "multi":                      # rank 0 measured; everybody reports the same line
             keys = ["prepare_us", "rasterize_us", "exchange_us", "sort_us", "sort_pass_us", "carry_us", "paint_us", "total_us", "n_segments", "n_sort_passes"]
             tt = torch.tensor([stage.get(k, 0.0) for k in keys], dtype=torch.float64, device=cdev)
@@ -303,14 +310,18 @@ def main():
         sort_us = stage.get("sort_us", 0.0)
         dbg = os.environ.get("FORMA_HIP_DEBUG", "")
         hist_fused = mode in ("single", "bands", "frames") and 0 < passes <= 3 and not any(t in dbg for t in ("no_ras_hist", "no_prezero", "sync"))
+        if passes and pass_us > 0:
+            # the digit passes alone, no gaps: 16 N p bytes over the sum of the pass kernels' own durations
+            roofline["whole_sort_kernels"] = {"algorithmic_bytes": 16.0 * n_local * passes, "us": round(pass_us * passes, 1),
+                                              "frac": round(16.0 * n_local * passes / (pass_us * passes * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
         if sort_us > 0 and passes:
             sort_bytes = 8.0 * n_local * (2 * passes + (0 if hist_fused else 1))
             whole = sort_bytes / (sort_us * 1e-6) / 1e9
             roofline["whole_sort"] = {"algorithmic_bytes": sort_bytes, "us": round(sort_us, 1), "achieved": round(whole, 1),
                                       "frac": round(whole / HBM_PEAK_GBS, 4), "histograms": "k_rasterize" if hist_fused else "k_sort_hist",
-                                      "what": ("every digit pass + the gaps between them (the digit histograms are counted by k_rasterize "
+                                      "what": ("every digit pass (the digit histograms are counted by k_rasterize "
                                                "while it makes the keys)" if hist_fused else
-                                               "k_sort_hist + every digit pass + the gaps between them") + ", stage events of the same frames"}
+                                               "k_sort_hist + every digit pass") + ": the sum of the sort kernels' own launch-event durations of the same frames"}
         # what the stages behind the sort move, against what they have to (8 N in + 4 W H out): counters of the committed build
         if use_pmc:
             post = [v.get("hbm_bytes_per_launch", 0) for k, v in pmc["kernels"].items()
@@ -323,14 +334,16 @@ def main():
                                            "duration is the kernel's own only with one frame in flight, which is where this roofline is measured")
         # the painter is not an HBM kernel: VALU issue and LDS bound it.  Live: its launch time; from the committed counters of
         # the same build: wave-level VALU instructions per launch and the LDS bank-conflict ratio.
-        painter = {"kernel": "k_paint_wave (one wavefront per 16x16 tile)", "bound": "valu+lds", "avg_launch_us": round(stage.get("paint_us", 0.0), 1),
+        paint_k_us = kernels_us.get("k_paint_wave", {}).get("us_per_frame") or stage.get("paint_us", 0.0)   # (the kernel's own launch events)
+        painter = {"kernel": "k_paint_wave (one wavefront per 16x16 tile)", "bound": "valu+lds", "avg_launch_us": round(paint_k_us, 1),
                    "hbm_algorithmic_bytes": 8.0 * n_local + 4.0 * width * height,
-                   "hbm_achieved_GBs": round((8.0 * n_local + 4.0 * width * height) / max(stage.get("paint_us", 0.0), 1e-3) / 1e3, 1)}
-        if use_pmc and "k_paint_wave" in pmc["kernels"]:
-            k = pmc["kernels"]["k_paint_wave"]
+                   "hbm_achieved_GBs": round((8.0 * n_local + 4.0 * width * height) / max(paint_k_us, 1e-3) / 1e3, 1)}
+        pk = next((v for n_, v in pmc["kernels"].items() if n_.startswith("k_paint_wave")), None) if use_pmc else None
+        if pk is not None:                                            # (the counters' key carries template arguments: match by prefix)
+            k = pk
             valu = k.get("SQ_INSTS_VALU")
             if valu:
-                ach = valu / max(stage["paint_us"], 1e-3) / 1e3       # G wave-instructions / s
+                ach = valu / max(paint_k_us, 1e-3) / 1e3              # G wave-instructions / s
                 painter.update({"valu_wave_instructions_per_launch": valu, "achieved": round(ach, 1), "peak": round(VALU_PEAK_GINST, 1),
                                 "unit": "G wave64 VALU instructions/s", "frac": round(ach / VALU_PEAK_GINST, 4)})
             if k.get("SQ_LDS_IDX_ACTIVE"):
@@ -429,6 +442,9 @@ def main():
                        "canvas": [width, height], "layers": len(comp), "pixel_segments": int(n_segments_full),
                        "frames_in_flight": in_flight, "sharding": sharding_txt, "band_rows": [row0, row1]},
             "stages_us": {k: round(stage.get(k, 0.0), 1) for k in ("prepare_us", "rasterize_us", "exchange_us", "sort_us", "carry_us", "paint_us", "total_us")},
+            "stages_us_what": "sum of the stage's kernels' own durations (events carried by each launch: no marker overhead); total_us = "
+                              "first kernel start -> last kernel end of a frame, gaps included",
+            "kernels_us": kernels_us,
             "roofline": roofline,
             "roofline_painter": painter,
         }

@@ -53,6 +53,10 @@ class ContextInfoT(C.Structure):
                 ("devices", C.c_int32 * 8)]
 
 
+class KernelTimeT(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("start_us", C.c_float), ("us", C.c_float), ("stage", C.c_uint32), ("reserved", C.c_uint32)]
+
+
 class SortPlanT(C.Structure):
     _fields_ = [("n_passes", C.c_uint32), ("biased", C.c_uint32), ("shift", C.c_uint32 * 12), ("mask", C.c_uint32 * 12), ("bias", C.c_uint32 * 12)]
 
@@ -91,6 +95,7 @@ SYMBOLS = {
     "forma_hip_sync": (_i, [_vp]),
     "forma_hip_context_info": (_i, [_vp, _vp]),
     "forma_hip_sort_plan": (_i, [C.c_uint64, _i, _i, _vp, _vp]),
+    "forma_hip_kernel_times": (_i, [_vp, _vp, _sz, _vp]),
     "forma_hip_trim": (_i, [_vp]),
     "forma_hip_read_segments": (_i, [_vp, _i, _vp, _sz, _vp]),
     "forma_hip_read_image": (_i, [_vp, _vp, _sz]),

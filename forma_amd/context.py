@@ -52,6 +52,15 @@ class Context:
                 "transport": {0: "none", 1: "rccl", 2: "copy"}.get(int(ci.transport), "?"),
                 "devices": [int(ci.devices[i]) for i in range(ci.n_devices)]}
 
+    def kernel_times(self):
+        """forma_hip_kernel_times: the kernels of the last timed render call in launch order, each with the duration its own
+        launch events measured: [(name, stage, start_us, us)]"""
+        from ._lib import KernelTimeT
+        arr = (KernelTimeT * 96)()
+        n = C.c_size_t(0)
+        self._check(self._L.forma_hip_kernel_times(self._h, arr, 96, C.byref(n)))
+        return [(arr[i].name.decode(), int(arr[i].stage), float(arr[i].start_us), float(arr[i].us)) for i in range(min(n.value, 96))]
+
     def trim(self):
         """forma_hip_trim: give the per-frame device memory back (scene and caches stay)"""
         self._check(self._L.forma_hip_trim(self._h))

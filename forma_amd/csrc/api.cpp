@@ -5,6 +5,9 @@
 
 #include "ctx.h"
 
+thread_local KernelTimer* g_ktimer = nullptr;
+static inline float* kt_us(forma_hip_ctx* c) { return c->kt_dur_us; }
+
 int fd_fail(forma_hip_ctx* c, int code, const char* what, hipError_t e) {
     if (c) snprintf(c->err, sizeof c->err, "%s%s%s", what, e != hipSuccess ? ": " : "", e != hipSuccess ? hipGetErrorString(e) : "");
     return code;
@@ -22,8 +25,20 @@ inline forma_hip_ctx* last_slot(forma_hip_ctx* ctx) { return ctx->last ? ctx->la
         if (_e != hipSuccess) return fail(ctx, FORMA_E_HIP, #expr, _e);       \
     } while (0)
 
-inline void stage_begin(forma_hip_ctx* c, int st, bool timing) { if (timing) { (void)hipEventRecord(c->ev0[st], c->stream); c->stage_used[st] = true; } }
-inline void stage_end(forma_hip_ctx* c, int st, bool timing) { if (timing) (void)hipEventRecord(c->ev1[st], c->stream); }
+// A timed frame: every kernel launched between stage_begin and stage_end carries its own pair of events (FORMA_LAUNCH,
+// common.h) and is booked on the stage; only the copy into caller memory — not a kernel — is bracketed by markers.  (Until
+// round 4 every stage was bracketed: ~12 us of marker packets per stage sat inside the stage times.)
+inline void stage_begin(forma_hip_ctx* c, int st, bool timing) {
+    if (!timing) return;
+    c->stage_used[st] = true;
+    if (st == ST_D2H) { (void)hipEventRecord(c->ev0[st], c->stream); return; }
+    c->kt.cur_stage = st; g_ktimer = &c->kt;
+}
+inline void stage_end(forma_hip_ctx* c, int st, bool timing) {
+    if (!timing) return;
+    if (st == ST_D2H) { (void)hipEventRecord(c->ev1[st], c->stream); return; }
+    g_ktimer = nullptr;
+}
 
 int read_info(forma_hip_ctx* ctx) {
     HIPCHECK(hipMemcpyAsync(ctx->h_info, ctx->info.p, sizeof(FrameInfo), hipMemcpyDeviceToHost, ctx->stream));
@@ -39,7 +54,10 @@ int reset_info(forma_hip_ctx* ctx) {              // device-to-device from a tem
 }
 // the end of a read-back-free frame: FrameInfo to pinned host memory (and / or the segment count to a pinned word), device copy reset
 int frame_tail(forma_hip_ctx* ctx, bool to_host_info, uint32_t* host_count) {
+    const bool timed = ctx->stage_used[ST_PAINT];         // (a timed frame books the tail on the paint stage)
+    stage_begin(ctx, ST_PAINT, timed);
     launch_frame_tail(ctx->stream, ctx->info.as<FrameInfo>(), to_host_info ? ctx->h_info : nullptr, host_count);
+    stage_end(ctx, ST_PAINT, timed);
     HIPCHECK(hipGetLastError());
     ctx->info_clean = true;
     return FORMA_OK;
@@ -161,6 +179,14 @@ int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, boo
     return finish_rasterize(ctx);
 }
 
+// A biased plan met a void frame.  plan_bad has other causes too (a slice beyond the small carry variant, a count over its
+// bound), so this is a suspicion, not a proof: plain digits for a while, then the cheaper plan is tried again; every repeat
+// doubles the ban (64 .. 4096 frames), new geometry lifts it (invalidate_counts).
+static void ban_bias(forma_hip_ctx* ctx) {
+    ctx->bias_ban_len = ctx->bias_ban_len ? std::min(ctx->bias_ban_len * 2u, 4096u) : 64u;
+    ctx->bias_banned = ctx->bias_ban_len;
+}
+
 // the digit plan of a frame's segment sort: live key bits only; a stream that is already non-decreasing in layer needs a
 // stable sort by tile alone
 SortPlan frame_sort_plan(forma_hip_ctx* ctx, uint64_t live44, bool layer_sorted, int digit_bits, bool speculated, bool* biased) {
@@ -220,7 +246,7 @@ int run_sort(forma_hip_ctx* ctx, const uint64_t* src, DevCount nc, bool timing, 
     stage_begin(ctx, ST_SORT, timing);
     ctx->sorted = (uint64_t*)launch_radix_sort(ctx->stream, src, ctx->seg_a.as<uint64_t>(), ctx->seg_b.as<uint64_t>(), nc, plan,
                                                digit_bits, ctx->sort_counters.as<uint32_t>(), &ctx->info.as<FrameInfo>()->error,
-                                               timing ? ctx->pev0 : nullptr, timing ? ctx->pev1 : nullptr, chunked,
+                                               chunked,
                                                ctx->info.as<FrameInfo>(), zeroed, hist_ready);
     stage_end(ctx, ST_SORT, timing);
     HIPCHECK(hipGetLastError());
@@ -652,17 +678,29 @@ int finish_frame(forma_hip_ctx* ctx, forma_timings_t* t, bool have_info = false)
     if (!t) return FORMA_OK;
     memset(t, 0, sizeof *t);
     float* dstv[ST_COUNT] = {&t->prepare_us, &t->rasterize_us, &t->sort_us, &t->carry_us, &t->paint_us, &t->d2h_us, &t->exchange_us};
-    float total = 0;
-    for (int s = 0; s < ST_COUNT; s++) {
-        if (!ctx->stage_used[s]) continue;
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, ctx->ev0[s], ctx->ev1[s]) == hipSuccess) { *dstv[s] = ms * 1000.0f; if (s != ST_D2H) total += ms * 1000.0f; }
-    }
-    t->total_us = total;
+    // stage = the sum of its kernels' own durations; total = first kernel's start -> last kernel's end (gaps included)
     float pass = 0; int np = 0;
-    for (int p = 0; p < ctx->n_passes && p < MAX_PASS_EVENTS; p++) {
+    KernelTimer& kt = ctx->kt;
+    for (int i = 0; i < kt.n; i++) {
         float ms = 0;
-        if (ctx->stage_used[ST_SORT] && hipEventElapsedTime(&ms, ctx->pev0[p], ctx->pev1[p]) == hipSuccess) { pass += ms * 1000.0f; np++; }
+        kt_us(ctx)[i] = 0.0f;
+        if (hipEventElapsedTime(&ms, kt.e0[i], kt.e1[i]) != hipSuccess) continue;
+        kt_us(ctx)[i] = ms * 1000.0f;
+        if (kt.stage[i] >= 0 && kt.stage[i] < ST_COUNT) *dstv[kt.stage[i]] += ms * 1000.0f;
+        if (!strncmp(kt.name[i], "(k_onesweep", 11)) { pass += ms * 1000.0f; np++; }
+    }
+    if (kt.n) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, kt.e0[0], kt.e1[kt.n - 1]) == hipSuccess) t->total_us = ms * 1000.0f;
+        for (int i = 0; i < kt.n; i++) {
+            ms = 0;
+            ctx->kt_start_us[i] = hipEventElapsedTime(&ms, kt.e0[0], kt.e0[i]) == hipSuccess ? ms * 1000.0f : 0.0f;
+        }
+    }
+    ctx->kt_n_done = kt.n;
+    if (ctx->stage_used[ST_D2H]) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ctx->ev0[ST_D2H], ctx->ev1[ST_D2H]) == hipSuccess) t->d2h_us = ms * 1000.0f;
     }
     t->sort_pass_us = np ? pass / np : 0.0f;
     t->n_lines = (uint32_t)ctx->n_lines; t->n_segments = (uint32_t)ctx->n_seg; t->n_sort_passes = (uint32_t)ctx->n_passes;
@@ -671,7 +709,7 @@ int finish_frame(forma_hip_ctx* ctx, forma_timings_t* t, bool have_info = false)
     return FORMA_OK;
 }
 
-void clear_stage_flags(forma_hip_ctx* ctx) { for (int s = 0; s < ST_COUNT; s++) ctx->stage_used[s] = false; }
+void clear_stage_flags(forma_hip_ctx* ctx) { for (int s = 0; s < ST_COUNT; s++) ctx->stage_used[s] = false; ctx->kt.n = 0; g_ktimer = nullptr; }
 
 int check_paint_args(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t height, size_t stride,
                      const uint8_t* channels, const float* clear) {
@@ -716,6 +754,10 @@ int forma_hip_create(forma_hip_ctx** out, int device) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return FORMA_E_NO_DEVICE;
     if (device < 0 || device >= count) return FORMA_E_ARG;
+    {   // the kernels are gfx950 code objects only (no fat binary): any other device is "no device" (forma_hip.h)
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) return FORMA_E_NO_DEVICE;
+    }
     forma_hip_ctx* ctx = new (std::nothrow) forma_hip_ctx();
     if (!ctx) return FORMA_E_INTERNAL;
     ctx->device = device;
@@ -745,13 +787,13 @@ int forma_hip_create(forma_hip_ctx** out, int device) {
         ok = hipEventCreate(&ctx->ev0[s]) == hipSuccess && hipEventCreate(&ctx->ev1[s]) == hipSuccess;
         ctx->stage_used[s] = false;
     }
-    for (int p = 0; p < MAX_PASS_EVENTS && ok; p++)
-        ok = hipEventCreate(&ctx->pev0[p]) == hipSuccess && hipEventCreate(&ctx->pev1[p]) == hipSuccess;
     if (!ok) { delete ctx; return FORMA_E_HIP; }
     // empty-scene defaults so that a render before any upload is well defined
-    ctx->style_off.ensure(4); ctx->style_words.ensure(4); ctx->layer_sf.ensure(4); ctx->layer_col.ensure(16); ctx->geoms.ensure(sizeof(forma_geom_t));
-    ctx->images.ensure(sizeof(forma_image_t)); ctx->texels.ensure(8);
-    ctx->x.ensure(4); ctx->y.ensure(4); ctx->line_slot.ensure(4);
+    ok = ctx->style_off.ensure(4) == hipSuccess && ctx->style_words.ensure(4) == hipSuccess && ctx->layer_sf.ensure(4) == hipSuccess &&
+         ctx->layer_col.ensure(16) == hipSuccess && ctx->geoms.ensure(sizeof(forma_geom_t)) == hipSuccess &&
+         ctx->images.ensure(sizeof(forma_image_t)) == hipSuccess && ctx->texels.ensure(8) == hipSuccess &&
+         ctx->x.ensure(4) == hipSuccess && ctx->y.ensure(4) == hipSuccess && ctx->line_slot.ensure(4) == hipSuccess;
+    if (!ok) { forma_hip_destroy(ctx); return FORMA_E_HIP; }
     *out = ctx;
     return FORMA_OK;
 }
@@ -784,7 +826,7 @@ void forma_hip_destroy(forma_hip_ctx* ctx) {
                      &ctx->grp_tab, &ctx->grp_list, &ctx->run_lt, &ctx->pack_list, &ctx->pack_pix, &ctx->cache_written};
     for (DevBuf* b : all) b->release();
     for (int s = 0; s < ST_COUNT; s++) { (void)hipEventDestroy(ctx->ev0[s]); (void)hipEventDestroy(ctx->ev1[s]); }
-    for (int p = 0; p < MAX_PASS_EVENTS; p++) { (void)hipEventDestroy(ctx->pev0[p]); (void)hipEventDestroy(ctx->pev1[p]); }
+    for (int i = 0; i < ctx->kt.made; i++) { (void)hipEventDestroy(ctx->kt.e0[i]); (void)hipEventDestroy(ctx->kt.e1[i]); }
     if (ctx->h_info) (void)hipHostFree(ctx->h_info);
     if (ctx->h_rows) (void)hipHostFree(ctx->h_rows);
     if (ctx->h_xlocal) (void)hipHostFree(ctx->h_xlocal);
@@ -1126,12 +1168,13 @@ int complete_async_frame(forma_hip_ctx* ctx, const PaintArgs& a, uint8_t* dst, s
     const bool ok = !ctx->h_info->plan_bad && N <= bN && J <= bJ;
     if (!ok) {
         if (ctx->small_tried && ctx->h_info->plan_bad) ctx->small_banned = true;   // (one cause of plan_bad: a slice beyond the small variant)
-        if (ctx->plan_biased && ctx->h_info->plan_bad) ctx->bias_banned = true;    // (another: a key outside the span the digits were planned for)
+        if (ctx->plan_biased && ctx->h_info->plan_bad) ban_bias(ctx);              // (another: a key outside the span the digits were planned for)
         ctx->pred_counts_valid = false;                   // the synchronous path re-learns everything
         clear_stage_flags(ctx);
         return FORMA_RETRY;
     }
     ctx->pred_N = N; ctx->pred_J = J; ctx->pred_max_row = ctx->h_info->max_row_runs;
+    if (ctx->bias_banned) ctx->bias_banned--;
     int rc;
     // (a deferred frame's image left speculatively behind its kernels; tiles that k_paint_huge paints only now: the crop is
     //  copied again)
@@ -1223,8 +1266,8 @@ void share_scene(forma_hip_ctx* o) {
     }
 }
 void invalidate_counts(forma_hip_ctx* o) {                 // new geometry / band: every slot re-learns N and J synchronously
-    o->pred_counts_valid = false; o->xpred_valid = false; o->small_banned = false; o->bias_banned = false; o->pred_range.valid = false;
-    for (forma_hip_ctx* sl : o->slots) { sl->pred_counts_valid = false; sl->xpred_valid = false; sl->small_banned = false; sl->bias_banned = false; sl->pred_range.valid = false; }
+    o->pred_counts_valid = false; o->xpred_valid = false; o->small_banned = false; o->bias_banned = 0; o->bias_ban_len = 0; o->pred_range.valid = false;
+    for (forma_hip_ctx* sl : o->slots) { sl->pred_counts_valid = false; sl->xpred_valid = false; sl->small_banned = false; sl->bias_banned = 0; sl->bias_ban_len = 0; sl->pred_range.valid = false; }
 }
 }  // namespace
 
@@ -1346,6 +1389,23 @@ int forma_hip_context_info(forma_hip_ctx* ctx, forma_context_info_t* out) {
     if (ctx->multi) { multi_info(ctx, out); return FORMA_OK; }
     out->n_devices = 1; out->devices[0] = ctx->device; out->transport = FORMA_TRANSPORT_NONE;
     out->frames_in_flight = ctx->slots.empty() ? 1u : (uint32_t)ctx->slots.size();
+    return FORMA_OK;
+}
+
+int forma_hip_kernel_times(forma_hip_ctx* ctx, forma_kernel_time_t* out, size_t capacity, size_t* out_n) {
+    if (!ctx || !out_n || (capacity && !out)) return FORMA_E_ARG;
+    if (ctx->multi) return fail(ctx, FORMA_E_STATE, "kernel times are kept per device: ask a single-device context");
+    const forma_hip_ctx* c = last_slot(ctx);
+    *out_n = (size_t)c->kt_n_done;
+    for (int i = 0; i < c->kt_n_done && (size_t)i < capacity; i++) {
+        forma_kernel_time_t& o = out[i];
+        memset(&o, 0, sizeof o);
+        const char* nm = c->kt.name[i];                   // "#kern" of FORMA_LAUNCH: "k_name" or "(k_name<ARGS>)"
+        while (*nm == '(' || *nm == ' ') nm++;
+        size_t k = 0;
+        while (nm[k] && nm[k] != '<' && nm[k] != ')' && k + 1 < sizeof o.name) { o.name[k] = nm[k]; k++; }
+        o.start_us = c->kt_start_us[i]; o.us = c->kt_dur_us[i]; o.stage = (uint32_t)c->kt.stage[i];
+    }
     return FORMA_OK;
 }
 
@@ -1735,8 +1795,9 @@ int gsp_complete(forma_hip_ctx* ctx, const GspArgs& g, uint32_t bJ) {
     const uint32_t N = ctx->h_info->n_segments, J = ctx->h_info->n_runs;
     ctx->n_seg = N; ctx->last_runs = J;
     if (ctx->h_info->plan_bad && ctx->small_tried) ctx->small_banned = true;
-    if (ctx->h_info->plan_bad && ctx->plan_biased) ctx->bias_banned = true;
+    if (ctx->h_info->plan_bad && ctx->plan_biased) ban_bias(ctx);
     if (!ctx->h_info->plan_bad && J <= bJ) {
+        if (ctx->bias_banned) ctx->bias_banned--;
         ctx->pred_J = J; ctx->pred_max_row = ctx->h_info->max_row_runs;
         if ((rc = finish_paint(ctx))) return rc;
         if ((rc = copy_image_out(ctx, g.dst, g.stride_bytes, timing, a))) return rc;

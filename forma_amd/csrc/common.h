@@ -2,6 +2,7 @@
 // Product code: never includes or links anything under oracle/.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stddef.h>
 
@@ -117,6 +118,40 @@ struct DevCount {
 __device__ __forceinline__ uint32_t dev_count(DevCount c) { return c.ptr ? min(*c.ptr, c.bound) : c.bound; }
 #endif
 
+// ---- per-kernel timing of a `timings` frame -------------------------------------------------------
+// Every launch of the library goes through FORMA_LAUNCH.  While a timed frame is being enqueued (forma_hip_render with a
+// forma_timings_t) the calling thread's g_ktimer points at the context's KernelTimer and the launch carries a pair of events
+// (hipExtLaunchKernelGGL: the dispatch's own start / end timestamps — what rocprofv3 reports as the kernel's duration, with no
+// marker packets in front of or behind it); otherwise it is a plain launch.  forma_hip_kernel_times returns the list.
+struct KernelTimer {
+    static constexpr int CAP = 96;
+    hipEvent_t e0[CAP], e1[CAP];
+    const char* name[CAP];
+    int stage[CAP];
+    int n = 0, made = 0, cur_stage = 0;
+};
+extern thread_local KernelTimer* g_ktimer;
+inline bool ktimer_slot(KernelTimer* kt, const char* name, hipEvent_t* e0, hipEvent_t* e1) {
+    if (!kt || kt->n >= KernelTimer::CAP) return false;
+    if (kt->n >= kt->made) {
+        if (hipEventCreate(&kt->e0[kt->made]) != hipSuccess) return false;
+        if (hipEventCreate(&kt->e1[kt->made]) != hipSuccess) { (void)hipEventDestroy(kt->e0[kt->made]); return false; }
+        kt->made++;
+    }
+    const int i = kt->n++;
+    kt->name[i] = name; kt->stage[i] = kt->cur_stage;
+    *e0 = kt->e0[i]; *e1 = kt->e1[i];
+    return true;
+}
+#define FORMA_LAUNCH(kern, grid, block, shm, s, ...)                                                        \
+    do {                                                                                                    \
+        hipEvent_t fl_e0_, fl_e1_;                                                                          \
+        if (g_ktimer && ktimer_slot(g_ktimer, #kern, &fl_e0_, &fl_e1_))                                     \
+            hipExtLaunchKernelGGL(kern, grid, block, shm, s, fl_e0_, fl_e1_, 0, __VA_ARGS__);               \
+        else                                                                                                \
+            hipLaunchKernelGGL(kern, grid, block, shm, s, __VA_ARGS__);                                     \
+    } while (0)
+
 // ---- kernel launch wrappers (defined in the .hip files) ------------------------------------------
 // lines.hip
 void launch_prepare_lines(hipStream_t s, const float* x, const float* y, const uint32_t* line_slot, uint32_t n_lines,
@@ -203,7 +238,6 @@ struct ChunkedSrc { const uint64_t* buckets; uint32_t n_chunks; uint32_t capacit
 uint32_t sort_hist_blocks(size_t n);           // grid of k_sort_hist for n keys = number of mask records it writes
 const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a, uint64_t* b, DevCount n,
                                   const SortPlan& plan, int digit_bits, uint32_t* scratch, uint32_t* err,
-                                  hipEvent_t* pass_ev0, hipEvent_t* pass_ev1,
                                   const ChunkedSrc* chunked = nullptr, FrameInfo* info = nullptr,
                                   bool scratch_is_zero = false /* an earlier kernel of the frame cleared sort_zero_words() */,
                                   bool hist_ready = false /* ... and the producer of the keys counted the digits (RasHist) */);

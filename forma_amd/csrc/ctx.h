@@ -35,7 +35,6 @@ struct DevBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
-constexpr int MAX_PASS_EVENTS = 16;
 constexpr size_t SEG_PAD = 16;          // segment buffers are over-allocated: stream kernels read whole 64-byte lane pieces
 enum { ST_PREPARE = 0, ST_RASTER, ST_SORT, ST_CARRY, ST_PAINT, ST_D2H, ST_XCHG, ST_COUNT };
 
@@ -108,7 +107,8 @@ struct forma_hip_ctx {
     uint32_t pred_N = 0, pred_J = 0, pred_w = 0, pred_h = 0;
     uint64_t pred_live44 = 0;
     KeyRange pred_range{0, 0, 0, 0, false};  // what the tile fields spanned on the last verified frame (value-range digits, SortPlan::bias)
-    bool plan_biased = false, bias_banned = false;   // this frame's plan leans on pred_range / a frame that did was void: plain digits for this geometry
+    bool plan_biased = false; uint32_t bias_banned = 0, bias_ban_len = 0;   // bias_banned: frames left of a ban (re-armed with back-off: an animated scene
+                                                      // that left its span once gets the cheaper plan back), bias_ban_len: length of the last ban //   // this frame's plan leans on pred_range / a frame that did was void: plain digits for this geometry
     bool ras_hist_on = false; SortPlan ras_plan;     // the rasterizer of this frame counted the digits of ras_plan into the sort's histograms (RasHist)
     const uint32_t* sort_range = nullptr;   // the tile-field spans the frame's sort leaves behind (k_runs_count folds them into FrameInfo) ...
     uint32_t sort_range_n = 0;              // ... one record per k_sort_hist workgroup
@@ -168,7 +168,9 @@ struct forma_hip_ctx {
     uint32_t xpred_N = 0, xpred_w = 0, xpred_h = 0;
     uint32_t* h_xlocal = nullptr;           // pinned: [0] = local segment count of the last bucket frame (copied on the stream), [1] = 1 when pending
     // timing
-    hipEvent_t ev0[ST_COUNT], ev1[ST_COUNT], pev0[MAX_PASS_EVENTS], pev1[MAX_PASS_EVENTS];
+    hipEvent_t ev0[ST_COUNT], ev1[ST_COUNT];
+    KernelTimer kt;                          // per-kernel events of a timed frame (FORMA_LAUNCH, common.h) ...
+    float kt_dur_us[KernelTimer::CAP] = {0}, kt_start_us[KernelTimer::CAP] = {0}; int kt_n_done = 0;   // ... resolved by finish_frame
     bool stage_used[ST_COUNT];
     int n_passes = 0;
     uint32_t last_runs = 0, last_entries = 0, last_written = 0;

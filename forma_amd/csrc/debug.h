@@ -37,7 +37,8 @@ inline ForMaDebug forma_debug_parse() {
     if (!e) return d;
     char buf[512];
     strncpy(buf, e, sizeof buf - 1); buf[sizeof buf - 1] = 0;
-    for (char* tok = strtok(buf, ",; "); tok; tok = strtok(nullptr, ",; ")) {
+    char* save = nullptr;   // strtok_r: contexts may be created from several threads at once
+    for (char* tok = strtok_r(buf, ",; ", &save); tok; tok = strtok_r(nullptr, ",; ", &save)) {
         char* val = strchr(tok, '=');
         if (val) *val++ = 0;
         const long v = val ? strtol(val, nullptr, 0) : 0;

@@ -290,7 +290,7 @@ void launch_row_histogram(hipStream_t s, const uint64_t* seg, DevCount n, uint32
     if (n.bound == 0) return;
     uint32_t blocks = (n.bound + 2047) / 2048;
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(k_row_histogram, dim3(blocks), dim3(256), 0, s, seg, n, hist);
+    FORMA_LAUNCH(k_row_histogram, dim3(blocks), dim3(256), 0, s, seg, n, hist);
 }
 
 size_t owner_scratch_words(size_t n) { return (size_t)(FORMA_MAX_RANKS + 1) * ((n + XB_TILE - 1) / XB_TILE + 1); }
@@ -303,9 +303,9 @@ void launch_owner_bucket(hipStream_t s, const uint64_t* seg, DevCount nc, const 
         (void)hipMemset2DAsync(send + capacity, ((size_t)capacity + 1) * 8, 0, 8, B.n, s);
         return;
     }
-    hipLaunchKernelGGL(k_owner_count, dim3(nblocks), dim3(XB_THREADS), 0, s, seg, nc, B, scratch, cap, send, capacity);
-    hipLaunchKernelGGL(k_owner_scan, dim3(B.n + 1), dim3(1024), 0, s, scratch, nc, cap, B.n + 1, capacity, send, info);
-    hipLaunchKernelGGL(k_owner_scatter, dim3(nblocks), dim3(XB_THREADS), 0, s, seg, nc, B, (const uint32_t*)scratch, cap, capacity, send);
+    FORMA_LAUNCH(k_owner_count, dim3(nblocks), dim3(XB_THREADS), 0, s, seg, nc, B, scratch, cap, send, capacity);
+    FORMA_LAUNCH(k_owner_scan, dim3(B.n + 1), dim3(1024), 0, s, scratch, nc, cap, B.n + 1, capacity, send, info);
+    FORMA_LAUNCH(k_owner_scatter, dim3(nblocks), dim3(XB_THREADS), 0, s, seg, nc, B, (const uint32_t*)scratch, cap, capacity, send);
 }
 
 size_t gather_mask_words(uint32_t n_ranks, uint32_t capacity) {
@@ -320,6 +320,6 @@ void launch_gather_chunks(hipStream_t s, const uint64_t* recv, uint32_t n_ranks,
     uint32_t gx = (capacity + 1023) / 1024;
     if (gx > 2048) gx = 2048;
     if (gx == 0) gx = 1;
-    hipLaunchKernelGGL(k_gather_chunks, dim3(gx, n_ranks), dim3(256), 0, s, recv, n_ranks, capacity, out, info, mask_records);
-    if (reduce_now) hipLaunchKernelGGL(k_reduce_gather_masks, dim3(1), dim3(1024), 0, s, (const uint32_t*)mask_records, gx * n_ranks, info);
+    FORMA_LAUNCH(k_gather_chunks, dim3(gx, n_ranks), dim3(256), 0, s, recv, n_ranks, capacity, out, info, mask_records);
+    if (reduce_now) FORMA_LAUNCH(k_reduce_gather_masks, dim3(1), dim3(1024), 0, s, (const uint32_t*)mask_records, gx * n_ranks, info);
 }

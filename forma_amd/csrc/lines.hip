@@ -117,7 +117,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_apply(uint32_t* __restric
 
 // exclusive scan in place of a small array (one workgroup); total -> *d_total
 void launch_scan_small_u32(hipStream_t s, uint32_t* data, DevCount n, uint32_t per, uint32_t* d_total) {
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, data, n, per, d_total);
+    FORMA_LAUNCH(k_scan_block_sums, dim3(1), dim3(1024), 0, s, data, n, per, d_total);
 }
 
 size_t scan_tmp_words(size_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE + 8; }
@@ -128,12 +128,12 @@ static void scan_u32(hipStream_t s, uint32_t* data, size_t n, uint32_t* tmp, uin
         return;
     }
     uint32_t nb = (uint32_t)((n + SCAN_TILE - 1) / SCAN_TILE);
-    hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, s, data, (uint32_t)n, tmp);
-    hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, tmp, DevCount{nullptr, nb}, 1u, d_total);
+    FORMA_LAUNCH(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, s, data, (uint32_t)n, tmp);
+    FORMA_LAUNCH(k_scan_block_sums, dim3(1), dim3(1024), 0, s, tmp, DevCount{nullptr, nb}, 1u, d_total);
     if (inclusive)
-        hipLaunchKernelGGL(k_scan_apply<true>, dim3(nb), dim3(SCAN_THREADS), 0, s, data, (uint32_t)n, tmp);
+        FORMA_LAUNCH(k_scan_apply<true>, dim3(nb), dim3(SCAN_THREADS), 0, s, data, (uint32_t)n, tmp);
     else
-        hipLaunchKernelGGL(k_scan_apply<false>, dim3(nb), dim3(SCAN_THREADS), 0, s, data, (uint32_t)n, tmp);
+        FORMA_LAUNCH(k_scan_apply<false>, dim3(nb), dim3(SCAN_THREADS), 0, s, data, (uint32_t)n, tmp);
 }
 void launch_inclusive_scan_u32(hipStream_t s, uint32_t* data, size_t n, uint32_t* tmp, uint32_t* d_total) {
     scan_u32(s, data, n, tmp, d_total, true);
@@ -227,7 +227,7 @@ void launch_prepare_lines(hipStream_t s, const float* x, const float* y, const u
     if (n_lines == 0) return;
     uint32_t blocks = (n_lines + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_prepare_lines, dim3(blocks), dim3(256), 0, s, x, y, line_slot, n_lines, geoms, n_geoms, width,
+    FORMA_LAUNCH(k_prepare_lines, dim3(blocks), dim3(256), 0, s, x, y, line_slot, n_lines, geoms, n_geoms, width,
                        height, band_lo, band_hi, orders, x0, y0, dx, dy, a, b, c, d, lengths);
 }
 
@@ -440,10 +440,10 @@ void launch_prepare_compact(hipStream_t s, const LineSource& src, uint32_t n_lin
     uint32_t* lens = scratch;
     uint32_t* tile_sum = scratch + n_lines;
     uint32_t* tile_cnt = tile_sum + ntiles + 1;
-    hipLaunchKernelGGL(k_line_len, dim3(ntiles), dim3(PL_THREADS), 0, s, src, n_lines, lens, tile_sum, tile_cnt, Z);
+    FORMA_LAUNCH(k_line_len, dim3(ntiles), dim3(PL_THREADS), 0, s, src, n_lines, lens, tile_sum, tile_cnt, Z);
     const bool self_scan = ntiles <= PC_SELF_SCAN_TILES;               // (beyond: tiles^2 / 2 loads stop being "a handful")
-    if (!self_scan) hipLaunchKernelGGL(k_scan_line_tiles, dim3(1), dim3(1024), 0, s, tile_sum, tile_cnt, ntiles, info);
-    hipLaunchKernelGGL(k_line_compact, dim3(ntiles), dim3(PC_THREADS), 0, s, (const uint32_t*)lens, n_lines,
+    if (!self_scan) FORMA_LAUNCH(k_scan_line_tiles, dim3(1), dim3(1024), 0, s, tile_sum, tile_cnt, ntiles, info);
+    FORMA_LAUNCH(k_line_compact, dim3(ntiles), dim3(PC_THREADS), 0, s, (const uint32_t*)lens, n_lines,
                        (const uint32_t*)tile_sum, (const uint32_t*)tile_cnt, cl_idx, cl_start, block_first, bf_cap,
                        self_scan ? info : (FrameInfo*)nullptr);
 }
@@ -456,7 +456,7 @@ void launch_line_lengths(hipStream_t s, const LineSource& src, uint32_t n_lines,
     uint32_t* tile_cnt = tile_sum + ntiles + 1;
     ZeroJobs Z;
     memset(&Z, 0, sizeof Z);
-    hipLaunchKernelGGL(k_line_len, dim3(ntiles), dim3(PL_THREADS), 0, s, src, n_lines, lens, tile_sum, tile_cnt, Z);
+    FORMA_LAUNCH(k_line_len, dim3(ntiles), dim3(PL_THREADS), 0, s, src, n_lines, lens, tile_sum, tile_cnt, Z);
 }
 
 __global__ __launch_bounds__(256) void k_block_first(const uint32_t* __restrict__ cl_start, uint32_t n_compact,
@@ -472,7 +472,7 @@ void launch_block_first(hipStream_t s, const uint32_t* cl_start, uint32_t n_comp
     if (n_compact == 0) return;
     uint32_t blocks = (n_compact + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_block_first, dim3(blocks), dim3(256), 0, s, cl_start, n_compact, n_segments, block_first);
+    FORMA_LAUNCH(k_block_first, dim3(blocks), dim3(256), 0, s, cl_start, n_compact, n_segments, block_first);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -769,12 +769,12 @@ void launch_rasterize(hipStream_t s, const LineSource& src, DevCount n_compact, 
     RasHist RH;
     memset(&RH, 0, sizeof RH);
     if (hist && hist->hist)
-        hipLaunchKernelGGL(k_rasterize<true>, dim3(blocks), dim3(RAS_THREADS), 0, s, src, n_compact, n_segments, cl_idx, cl_start,
+        FORMA_LAUNCH(k_rasterize<true>, dim3(blocks), dim3(RAS_THREADS), 0, s, src, n_compact, n_segments, cl_idx, cl_start,
                            block_first, out, info, band_row0, band_row1, wg_masks, *hist);
     else
-        hipLaunchKernelGGL(k_rasterize<false>, dim3(blocks), dim3(RAS_THREADS), 0, s, src, n_compact, n_segments, cl_idx, cl_start,
+        FORMA_LAUNCH(k_rasterize<false>, dim3(blocks), dim3(RAS_THREADS), 0, s, src, n_compact, n_segments, cl_idx, cl_start,
                            block_first, out, info, band_row0, band_row1, wg_masks, RH);
-    if (reduce_now) hipLaunchKernelGGL(k_reduce_masks, dim3(1), dim3(1024), 0, s, (const uint32_t*)wg_masks, n_segments, info);
+    if (reduce_now) FORMA_LAUNCH(k_reduce_masks, dim3(1), dim3(1024), 0, s, (const uint32_t*)wg_masks, n_segments, info);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -822,5 +822,5 @@ void launch_flatten(hipStream_t s, const forma_flatten_tables_t* dev_tables, flo
     if (dev_tables->n_points == 0) return;
     size_t blocks = (dev_tables->n_points + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_flatten, dim3((uint32_t)blocks), dim3(256), 0, s, *dev_tables, out_x, out_y);
+    FORMA_LAUNCH(k_flatten, dim3((uint32_t)blocks), dim3(256), 0, s, *dev_tables, out_x, out_y);
 }

@@ -469,12 +469,12 @@ void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t ti
     uint32_t* chunk_counts = scratch + ntiles + 8;                      // 4 per tile (+ slack for the last wave's second half)
     const int scanned = ntiles > 16384 ? 1 : 0;
     if (what & 1) {
-        hipLaunchKernelGGL(k_runs_count, dim3(cgrid + 1), dim3(RC_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, scratch, chunk_counts, row_tab,
+        FORMA_LAUNCH(k_runs_count, dim3(cgrid + 1), dim3(RC_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, scratch, chunk_counts, row_tab,
                            zero_words, info, spec_live44, flags, pm, range_records, n_range_records);
         if (scanned) launch_scan_small_u32(s, scratch, nc, RN_TILE, &info->n_runs);   // exclusive, in place; total -> n_runs
     }
     if (what & 2)
-    hipLaunchKernelGGL(k_runs_wave, dim3(ntiles), dim3(RW_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, records, rec_cap,
+    FORMA_LAUNCH(k_runs_wave, dim3(ntiles), dim3(RW_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, records, rec_cap,
                        run_keys, tile_first_run, blk_edge, row_tab, (const uint32_t*)scratch, scanned,
                        (const uint32_t*)chunk_counts, info, rs);
 }
@@ -1089,7 +1089,7 @@ void launch_carry_rows(hipStream_t s, bool local_sort, bool small, uint32_t n_sl
     if (n_slices < 1u) n_slices = 1u;
     if (n_slices > CR_MAX_SLICES) n_slices = CR_MAX_SLICES;
     const dim3 grid((row1 - row0) * n_slices), block(CR_THREADS);
-#define CR_LAUNCH(L, C, R) hipLaunchKernelGGL((k_carry_rows<L, C, R>), grid, block, 0, s, sorted_run_keys, records, blk_edge, n_segments, \
+#define CR_LAUNCH(L, C, R) FORMA_LAUNCH((k_carry_rows<L, C, R>), grid, block, 0, s, sorted_run_keys, records, blk_edge, n_segments, \
                                               n_runs, layer_sf, n_orders, tiles_w, tiles_h, row_count, row_span_lo, row_span_cnt, span_key, \
                                               span_cov, unchanged, info, edge_segs, vis_last, n_slices, bin_shift, row0, groups, run_lt, left_start)
     if (!local_sort) CR_LAUNCH(false, CR_CAP, 4);
@@ -2470,14 +2470,14 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
     static const bool no_simple = dbg.no_simple_paint;               // (A/B switches for tools/)
     static const bool force_simple = dbg.force_simple_paint;         // (timing experiments only: wrong pixels on other scenes)
     const bool simple = (p.scene_simple && !no_simple) || force_simple, one = p.n_slices == 1u;
-#define PW_LAUNCH(S_, O_) hipLaunchKernelGGL((k_paint_wave<S_, O_>), dim3(per * 8), dim3(64), 0, s, p, sorted, records, n_runs, tile_first_run, \
+#define PW_LAUNCH(S_, O_) FORMA_LAUNCH((k_paint_wave<S_, O_>), dim3(per * 8), dim3(64), 0, s, p, sorted, records, n_runs, tile_first_run, \
                                              row_span_lo, row_span_cnt, span_key, span_cov, layer_col, style_offsets, style_words, images, \
                                              texels, image, cache, info, overflow_n, overflow_list, launch_deep ? 1u : 0u, groups)
     if (simple) { if (one) PW_LAUNCH(true, true); else PW_LAUNCH(true, false); }
     else { if (one) PW_LAUNCH(false, true); else PW_LAUNCH(false, false); }
 #undef PW_LAUNCH
     if (!launch_deep) return;                             // (read-back-free frame of a scene whose last frame had no deep tile)
-    hipLaunchKernelGGL(k_paint_deep, dim3(T < 256 ? T : 256), dim3(256), 0, s, p, sorted, records, n_runs, tile_first_run,
+    FORMA_LAUNCH(k_paint_deep, dim3(T < 256 ? T : 256), dim3(256), 0, s, p, sorted, records, n_runs, tile_first_run,
                        row_span_lo, row_span_cnt, span_key, span_cov, layer_col, style_offsets, style_words, images,
                        texels, image, cache, info, (const uint32_t*)overflow_n, (const uint32_t*)overflow_list, over2_n, over2_list);
 }
@@ -2489,7 +2489,7 @@ void launch_paint_huge(hipStream_t s, const PaintParams& p, const uint64_t* sort
                        const uint16_t* texels, uint8_t* image, TileCacheArgs cache, FrameInfo* info, const uint32_t* over2_list,
                        uint32_t n_tiles, const uint64_t* offs, uint64_t* g_key, uint64_t* g_tmp, uint32_t* g_flag) {
     if (n_tiles == 0) return;
-    hipLaunchKernelGGL(k_paint_huge, dim3(n_tiles < 256 ? n_tiles : 256), dim3(256), 0, s, p, sorted, records, n_runs, tile_first_run,
+    FORMA_LAUNCH(k_paint_huge, dim3(n_tiles < 256 ? n_tiles : 256), dim3(256), 0, s, p, sorted, records, n_runs, tile_first_run,
                        row_span_lo, row_span_cnt, span_key, span_cov, layer_col, style_offsets, style_words, images, texels, image,
                        cache, info, over2_list, n_tiles, offs, g_key, g_tmp, g_flag);
 }
@@ -2540,9 +2540,9 @@ void launch_pack_written(hipStream_t s, const uint8_t* written, uint32_t tiles_w
                          uint32_t* list, uint32_t* count, uint32_t max_pack, const uint8_t* image, uint32_t width, uint32_t height,
                          uint32_t* packed) {
     if (tx0 >= tx1 || ty0 >= ty1) { (void)hipMemsetAsync(count, 0, 4, s); return; }
-    hipLaunchKernelGGL(k_written_list, dim3(1), dim3(1024), 0, s, written, tiles_w, tx0, tx1, ty0, ty1, list, count);
+    FORMA_LAUNCH(k_written_list, dim3(1), dim3(1024), 0, s, written, tiles_w, tx0, tx1, ty0, ty1, list, count);
     const uint32_t n = (tx1 - tx0) * (ty1 - ty0);
-    hipLaunchKernelGGL(k_pack_written, dim3(std::max(1u, std::min<uint32_t>(std::min(n, max_pack), 4096u))), dim3(256), 0, s, (const uint32_t*)list,
+    FORMA_LAUNCH(k_pack_written, dim3(std::max(1u, std::min<uint32_t>(std::min(n, max_pack), 4096u))), dim3(256), 0, s, (const uint32_t*)list,
                        (const uint32_t*)count, max_pack, tiles_w, (const uint32_t*)image, width, height, packed);
 }
 
@@ -2566,6 +2566,6 @@ __global__ __launch_bounds__(64) void k_frame_tail(FrameInfo* __restrict__ info,
     }
 }
 void launch_frame_tail(hipStream_t s, FrameInfo* info, FrameInfo* host_info, uint32_t* host_count) {
-    hipLaunchKernelGGL(k_frame_tail, dim3(1), dim3(64), 0, s, info, host_info, host_count);
+    FORMA_LAUNCH(k_frame_tail, dim3(1), dim3(64), 0, s, info, host_info, host_count);
 }
 

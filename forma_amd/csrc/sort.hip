@@ -574,7 +574,7 @@ RasHist make_ras_hist(const SortPlan& plan, uint32_t* sort_scratch) {
 
 const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a, uint64_t* b, DevCount nc,
                                   const SortPlan& plan, int digit_bits, uint32_t* scratch, uint32_t* err,
-                                  hipEvent_t* pass_ev0, hipEvent_t* pass_ev1, const ChunkedSrc* chunked, FrameInfo* info,
+                                  const ChunkedSrc* chunked, FrameInfo* info,
                                   bool scratch_is_zero, bool hist_ready) {
     const size_t n = nc.bound;                        // provisioning (grid, scratch); the kernels use the device count
     if (n <= 1 || plan.n_passes == 0) return in;
@@ -589,8 +589,8 @@ const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a
     ChunkedSrc C0;
     memset(&C0, 0, sizeof C0);
     const ChunkedSrc C = chunked ? *chunked : C0;
-    if (chunked) hipLaunchKernelGGL(k_sort_hist<true>, dim3(hb), dim3(HS_THREADS), 0, s, in, nc, plan, hist, C, info);
-    else if (!(hist_ready && scratch_is_zero)) hipLaunchKernelGGL(k_sort_hist<false>, dim3(hb), dim3(HS_THREADS), 0, s, in, nc, plan, hist, C, info);
+    if (chunked) FORMA_LAUNCH(k_sort_hist<true>, dim3(hb), dim3(HS_THREADS), 0, s, in, nc, plan, hist, C, info);
+    else if (!(hist_ready && scratch_is_zero)) FORMA_LAUNCH(k_sort_hist<false>, dim3(hb), dim3(HS_THREADS), 0, s, in, nc, plan, hist, C, info);
     const uint32_t cap = 512u * 512u / OS_THREADS;        // persistent: 16 waves per CU
     const uint64_t* src = in;
     uint64_t* dst = a;
@@ -598,14 +598,12 @@ const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a
         uint32_t* st = status + (size_t)p * ntiles * SORT_BINS;
         const bool ch = p == 0 && C.n_chunks > 1;                      // only the first pass reads the received buckets in place
         const bool hi = plan.shift[p] >= 32;
-        // With pass events the launch carries them itself (hipExtLaunchKernelGGL: the events take the dispatch's own start and
-        // end timestamps, what a profiler reports as the kernel's duration) instead of markers in front of and behind it
-        hipEvent_t e0 = pass_ev0 ? pass_ev0[p] : nullptr, e1 = pass_ev1 ? pass_ev1[p] : nullptr;
+        // (on a timed frame the launch carries its own events, FORMA_LAUNCH: the dispatch's start and end timestamps)
         const int bits = digit_bits == 4 ? 4 : (plan.mask[p] > 255u ? 9 : 8);
         const uint32_t tile = (uint32_t)OS_THREADS * (uint32_t)os_kpt(bits);
         const uint32_t ptiles = (uint32_t)((n + tile - 1) / tile);
         const uint32_t grid = ptiles < cap ? ptiles : cap;
-#define OS_LAUNCH(B, CH, HI_) hipExtLaunchKernelGGL((k_onesweep<B, CH, HI_>), dim3(grid), dim3(OS_THREADS), 0, s, e0, e1, 0, src, dst, nc, \
+#define OS_LAUNCH(B, CH, HI_) FORMA_LAUNCH((k_onesweep<B, CH, HI_>), dim3(grid), dim3(OS_THREADS), 0, s, src, dst, nc, \
                                            plan.shift[p], plan.mask[p], plan.bias[p], (const uint32_t*)(hist + p * SORT_BINS), st, tickets + p, err, ch ? C : C0)
 #define OS_LAUNCH_B(B) do { if (ch) { if (hi) OS_LAUNCH(B, true, true); else OS_LAUNCH(B, true, false); } \
                             else { if (hi) OS_LAUNCH(B, false, true); else OS_LAUNCH(B, false, false); } } while (0)

@@ -299,6 +299,20 @@ int forma_hip_sort_plan(uint64_t live_key_bits, int layer_sorted, int digit_bits
 int forma_hip_trim(forma_hip_ctx* ctx);
 
 /* ---- inspection of the last render (parity tests at full size, bench) ---------------------- */
+/* The kernels of the last forma_hip_render call that asked for timings, in launch order: each launch carried its own pair of
+ * events (the dispatch's start / end timestamps, i.e. what `rocprofv3 --kernel-trace` reports), so `us` holds no marker or
+ * launch overhead; forma_timings_t's stage times are sums of these.  `stage`: 0 prepare, 1 rasterize, 2 sort, 3 carry (runs +
+ * cover carry), 4 paint, 6 exchange.  `start_us` is relative to the first kernel's start.  Writes min(count, capacity) entries,
+ * *out_n = count.  Single-device contexts (a multi-device context returns FORMA_E_STATE).  No reference counterpart: forma
+ * times its stages on the host (`duration!`, cpu/renderer.rs:106-223). */
+typedef struct forma_kernel_time_t {
+    char     name[48];        /* kernel name without template arguments, NUL-terminated */
+    float    start_us;
+    float    us;
+    uint32_t stage;
+    uint32_t reserved;
+} forma_kernel_time_t;
+int forma_hip_kernel_times(forma_hip_ctx* ctx, forma_kernel_time_t* out, size_t capacity, size_t* out_n);
 /* which: 0 = unsorted stream (rasterizer order), 1 = sorted stream. */
 int forma_hip_read_segments(forma_hip_ctx* ctx, int which, uint64_t* out, size_t capacity,
                             size_t* out_n);

@@ -137,6 +137,17 @@ pub struct forma_context_info_t {
     pub devices: [i32; FORMA_MAX_DEVICES],
 }
 
+/// `forma_kernel_time_t` (`include/forma_hip.h`): one kernel of the last timed frame, timed by its own launch events.
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct forma_kernel_time_t {
+    pub name: [c_char; 48],
+    pub start_us: f32,
+    pub us: f32,
+    pub stage: u32,
+    pub reserved: u32,
+}
+
 pub const FORMA_SORT_MAX_PASSES: usize = 12;
 
 /// `forma_sort_plan_t` (`include/forma_hip.h`): the digit plan of a frame's segment sort (introspection, host logic only).
@@ -256,6 +267,7 @@ extern "C" {
     pub fn forma_hip_set_frames_in_flight(ctx: *mut forma_hip_ctx, n: c_int) -> c_int;
     pub fn forma_hip_sync(ctx: *mut forma_hip_ctx) -> c_int;
     pub fn forma_hip_context_info(ctx: *mut forma_hip_ctx, out: *mut forma_context_info_t) -> c_int;
+    pub fn forma_hip_kernel_times(ctx: *mut forma_hip_ctx, out: *mut forma_kernel_time_t, capacity: usize, out_n: *mut usize) -> c_int;
     pub fn forma_hip_sort_plan(
         live_key_bits: u64,
         layer_sorted: c_int,

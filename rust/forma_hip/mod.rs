@@ -171,7 +171,13 @@ impl Renderer {
     /// further frames have been enqueued.  This is the one call that offers more than `cpu::Renderer`: a presenter that rotates
     /// three window buffers gets the 33 MB PCIe copy of frame k under the kernels of frames k + 1 and k + 2 (1 650 frames/s at 4K
     /// against 900 for `render`, which stays synchronous — `cpu/buffer/mod.rs:43-49`).  Same scene walk as `render`.
-    pub fn render_enqueue(
+    ///
+    /// # Safety
+    /// The library keeps `pixels.as_mut_ptr()` and DMA-writes through it AFTER this call returns, until `sync()` (or until
+    /// `frames in flight` further frames were enqueued).  The caller must keep the allocation alive, registered and untouched
+    /// for that long: dropping, reallocating or reading the buffer earlier is a use-after-free / data race the borrow checker
+    /// cannot see, which is why this is not a safe fn.
+    pub unsafe fn render_enqueue(
         &mut self,
         composition: &mut Composition,
         pixels: &mut [u8],
@@ -209,12 +215,18 @@ impl Renderer {
 
     /// Page-locks a pixel buffer the renderer writes often (`forma_hip_register_buffer`); undo with [`Renderer::unregister`]
     /// before the memory is freed.
-    pub fn register(&mut self, pixels: &mut [u8]) {
+    ///
+    /// # Safety
+    /// `hipHostRegister` pins the pages behind `pixels` beyond the borrow: the allocation must stay alive and must not move
+    /// (no `Vec` growth) until `unregister` was called with the same slice.
+    pub unsafe fn register(&mut self, pixels: &mut [u8]) {
         // SAFETY: the slice is valid for its length; the caller keeps it alive until `unregister`.
         let rc = unsafe { ffi::forma_hip_register_buffer(self.ctx, pixels.as_mut_ptr().cast(), pixels.len()) };
         self.check(rc, "forma_hip_register_buffer");
     }
-    pub fn unregister(&mut self, pixels: &mut [u8]) {
+    /// # Safety
+    /// `pixels` must be the slice given to [`Renderer::register`]; no frame enqueued into it may be read before this returns.
+    pub unsafe fn unregister(&mut self, pixels: &mut [u8]) {
         // SAFETY: as above; the call waits for frames in flight first.
         let rc = unsafe { ffi::forma_hip_unregister_buffer(self.ctx, pixels.as_mut_ptr().cast()) };
         self.check(rc, "forma_hip_unregister_buffer");
@@ -782,16 +794,35 @@ thread_local! {
     /// `Path`s are built and flattened on whatever thread the application uses, before any `Renderer` exists: stage 1 has its
     /// own small context per thread (device 0), created on first use.  `None` = no device / no library: the caller falls back
     /// to the reference's map (flattening is not part of `Renderer::render`, so this is the one place a fallback is right).
-    static FLATTEN_CTX: std::cell::RefCell<Option<Option<*mut ffi::forma_hip_ctx>>> = std::cell::RefCell::new(None);
+    static FLATTEN_CTX: std::cell::RefCell<Option<Option<FlattenCtx>>> = std::cell::RefCell::new(None);
+}
+
+/// Owns a thread's stage-1 context: destroyed when the thread ends (thread-local destructors run `Drop`), so paths built on a
+/// thread pool do not leak a stream, events and pinned memory per worker.
+struct FlattenCtx(*mut ffi::forma_hip_ctx);
+impl Drop for FlattenCtx {
+    fn drop(&mut self) {
+        // SAFETY: the pointer came from `forma_hip_create` and is destroyed exactly once.
+        unsafe { ffi::forma_hip_destroy(self.0) }
+    }
+}
+
+/// Device stage 1 runs on: `FORMA_HIP_FLATTEN_DEVICE` (default 0) — a `Path` is flattened before any `Renderer` exists, so the
+/// host, not a renderer, has to say which GPU of the machine does it.
+fn flatten_device() -> i32 {
+    std::env::var("FORMA_HIP_FLATTEN_DEVICE").ok().and_then(|v| v.parse().ok()).unwrap_or(0)
 }
 
 pub fn flatten_on_device(t: &FlattenTables<'_>) -> Option<(Vec<f32>, Vec<f32>)> {
     let ctx = FLATTEN_CTX.with(|c| {
-        *c.borrow_mut().get_or_insert_with(|| {
-            let mut ctx = std::ptr::null_mut();
-            // SAFETY: plain out-pointer call.
-            (unsafe { ffi::forma_hip_create(&mut ctx, 0) } == 0).then_some(ctx)
-        })
+        c.borrow_mut()
+            .get_or_insert_with(|| {
+                let mut ctx = std::ptr::null_mut();
+                // SAFETY: plain out-pointer call.
+                (unsafe { ffi::forma_hip_create(&mut ctx, flatten_device()) } == 0).then(|| FlattenCtx(ctx))
+            })
+            .as_ref()
+            .map(|f| f.0)
     })?;
     let n = t.point_commands.len();
     let narrow = |v: &[usize]| v.iter().map(|&i| i as u32).collect::<Vec<u32>>();

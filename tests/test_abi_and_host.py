@@ -50,7 +50,7 @@ def test_rust_shim_declares_the_same_abi():
     ffi = open(os.path.join(ROOT, "rust", "forma_hip", "ffi.rs")).read()
     assert sorted(set(re.findall(r"pub fn (forma_hip_[a-z_0-9]+)", ffi))) == declared_symbols()
     hdr = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
-    for name in ("forma_geom_t", "forma_rect_t", "forma_image_t", "forma_timings_t", "forma_context_info_t", "forma_sort_plan_t"):
+    for name in ("forma_geom_t", "forma_rect_t", "forma_image_t", "forma_timings_t", "forma_context_info_t", "forma_sort_plan_t", "forma_kernel_time_t"):
         r = re.search(r"pub struct " + name + r"\s*\{(.*?)\n\}", ffi, flags=re.S)
         assert r, name + " missing in ffi.rs"
         assert re.findall(r"pub (\w+)\s*:", r.group(1)) == _c_struct_fields(hdr, name), name
@@ -141,6 +141,7 @@ int main(void) {
     printf("timings %zu %zu %zu\n", sizeof(forma_timings_t), offsetof(forma_timings_t, n_lines), offsetof(forma_timings_t, n_tile_entries));
     printf("info %zu %zu\n", sizeof(forma_context_info_t), offsetof(forma_context_info_t, devices));
     printf("plan %zu %zu %zu\n", sizeof(forma_sort_plan_t), offsetof(forma_sort_plan_t, mask), offsetof(forma_sort_plan_t, bias));
+    printf("ktime %zu %zu %zu\n", sizeof(forma_kernel_time_t), offsetof(forma_kernel_time_t, start_us), offsetof(forma_kernel_time_t, stage));
     return 0;
 }
 ''')
@@ -157,6 +158,7 @@ int main(void) {
     assert out["timings"].split() == [str(C.sizeof(t)), str(t.n_lines.offset), str(t.n_tile_entries.offset)]
     assert out["info"].split() == [str(C.sizeof(_lib.ContextInfoT)), str(_lib.ContextInfoT.devices.offset)]
     assert out["plan"].split() == [str(C.sizeof(_lib.SortPlanT)), str(_lib.SortPlanT.mask.offset), str(_lib.SortPlanT.bias.offset)]
+    assert out["ktime"].split() == [str(C.sizeof(_lib.KernelTimeT)), str(_lib.KernelTimeT.start_us.offset), str(_lib.KernelTimeT.stage.offset)]
 
 
 def _plan(live, layer_sorted, digit_bits, rng=None):
