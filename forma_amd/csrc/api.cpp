@@ -179,6 +179,15 @@ int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, boo
     return finish_rasterize(ctx);
 }
 
+// Strip painters (k_paint_wave<.., NPX = 1>: four wavefronts per tile) for frames whose tiles do not fill the chip's wave slots
+// with one wavefront each — 1080p canvases, the band of a multi-device rank, crops: such a launch is as long as its deepest
+// tile, and a strip walks that tile's pixels four times as fast.  Bigger frames are bound by throughput, and the strips'
+// fourfold list work would cost them.  FORMA_HIP_DEBUG=strip_tiles=N moves the limit (0: never).
+static bool paint_by_strips(const forma_hip_ctx* ctx, uint32_t tiles_painted) {
+    const uint32_t limit = ctx->dbg.strip_tiles >= 0 ? (uint32_t)ctx->dbg.strip_tiles : PAINT_STRIP_TILES;
+    return tiles_painted <= limit;
+}
+
 // A biased plan met a void frame.  plan_bad has other causes too (a slice beyond the small carry variant, a count over its
 // bound), so this is a suspicion, not a proof: plain digits for a while, then the cheaper plan is tried again; every repeat
 // doubles the ban (64 .. 4096 frames), new geometry lifts it (invalidate_counts).
@@ -477,6 +486,9 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     P.clear_unchanged = clear_unchanged;
     P.n_slices = jc.bound > 0 ? n_slices : 1u;             // (no runs: the carry pre-pass did not run, the zeroed tables say "no spans")
     P.n_groups = n_groups;
+    // occlusion culling (PaintParams::cull): not with a buffer-layer cache (a tile's layer count is state there), not with clips
+    const bool cull = a.cache_id < 0 && !ctx->scene_has_clips && !ctx->dbg.no_cull;
+    P.cull = cull ? 1u : 0u;
     // the (empty) k_paint_deep launch costs ~5 us of every frame: a read-back-free frame without a cache skips it when the
     // last verified frame had no deep tile; a tile that needs it then voids the frame (re-run in full)
     const bool launch_deep = !(bound_j != 0 && a.cache_id < 0 && ctx->pred_no_deep);
@@ -494,6 +506,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                           // 156-162, 692), a painted tile encodes r, g, b and then selects (compute_srgb, :466-483) — the same bytes
                           // unless alpha lands in bytes 0..2 or a colour in byte 3, and an invisible layer can block the fold
                           (a.cache_id < 0 && (a.height & 15u) && fold_equals_paint) ? (a.height & 15u) : 16u, crow0, crow1, groups, ctx->run_lt.as<uint32_t>(),
+                          cull,
                           (a.cache_id >= 0 || !fold_equals_paint) ? (a.crop ? a.crop->x0 / 16 : 0u) : 0xFFFFFFFFu);
     stage_end(ctx, ST_CARRY, timing);
     stage_begin(ctx, ST_PAINT, timing);
@@ -501,7 +514,8 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                  row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(), ctx->layer_col.as<uint4>(),
                  ctx->style_off.as<uint32_t>(),
                  ctx->style_words.as<uint32_t>(), ctx->images.as<forma_image_t>(), ctx->texels.as<uint16_t>(),
-                 ctx->cur_image, tc, dinfo, paint_overflow, overflow_list, over2_n, over2_list, launch_deep, groups);
+                 ctx->cur_image, tc, dinfo, paint_overflow, overflow_list, over2_n, over2_list, launch_deep, groups,
+                 paint_by_strips(ctx, (P.crop_y1 > P.crop_y0 ? P.crop_y1 - P.crop_y0 : 0u) * tiles_w));
     stage_end(ctx, ST_PAINT, timing);
     ctx->last_runs = J; ctx->last_entries = 0;
     HIPCHECK(hipGetLastError());

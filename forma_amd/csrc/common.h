@@ -76,6 +76,14 @@ struct PaintParams {
     uint32_t clear_unchanged;                      // buffer-layer cache: this frame's clear colour == the cached one
     uint32_t n_slices;                             // span lists per tile row (slices of the carry pre-pass)
     uint32_t n_groups;                             // tile-column groups per row (SPAN_GROUP_TILES tiles each): see SpanGroups
+    // Occlusion culling: a painter drops, while it builds its tile's layer list, every entry below the topmost OCCLUDER that
+    // crosses the tile — a carry-only span with a FULL cover of an opaque solid colour, BlendMode::Over, unclipped.  That is
+    // what skip_fully_covered_layers_pass (layer_workbench/passes/skip_fully_covered_layers.rs) skips anyway: the same pixels
+    // from a list a fraction as long (the 1080p cubic scene: 69 entries per tile, 1.7 painted; lists beyond the wave painter's
+    // 128 entries become rare), and k_carry_rows leaves out of a tile-column group's list what an occluder of the whole group
+    // hides.  What changes is a tile's layer COUNT, which only a buffer-layer cache remembers (CachedTile), and a clip below the
+    // occluder may govern layers above it: 0 on cache frames and for scenes with clips.
+    uint32_t cull;
 };
 
 // The spans of a tile row, a second time, by TILE-COLUMN GROUP: k_carry_rows appends to the row's (layer, tile_x)-ordered span
@@ -330,6 +338,7 @@ void launch_carry_rows(hipStream_t s, bool local_sort, bool small, uint32_t n_sl
                        uint32_t vis_last /* visible pixel rows of the last tile row (height % 16, 16 if 0) */,
                        uint32_t row0, uint32_t row1 /* the tile rows that are painted (the crop): only those get workgroups */,
                        SpanGroups groups /* tab == nullptr: no group lists */, const uint32_t* run_lt /* RunStyle::run_lt */,
+                       bool cull /* PaintParams::cull */,
                        uint32_t left_start /* cache frames: the first painted tile column, whose tiles list every layer with segments to
                                               their left (painter/mod.rs:500-522); 0xFFFFFFFF: no cache and a channel order under which a folded tile and a painted one
                                               are the same bytes — nothing can observe the entry */);
@@ -342,7 +351,9 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
                   uint32_t* overflow_list /* tiles_w * tiles_h words */, uint32_t* over2_n /* zeroed by launch_runs */,
                   uint32_t* over2_list /* {tile, entries} pairs: 2 * tiles_w * tiles_h words */,
                   bool launch_deep /* false: k_paint_deep is not launched; a tile that needs it voids the frame (plan_bad) */,
-                  SpanGroups groups /* tab == nullptr: the painters scan the row lists (p.n_groups is ignored) */);
+                  SpanGroups groups /* tab == nullptr: the painters scan the row lists (p.n_groups is ignored) */,
+                  bool strips = false /* four wavefronts per tile, each a 16 x 4 strip (k_paint_wave<.., NPX = 1>): frames that do not
+                                         fill the chip with one wavefront per tile; ignored with a buffer-layer cache */);
 // tiles whose layer list exceeds the painter's LDS lists (info->error bit 3 after launch_paint): lists in global memory,
 // offs[i] = first entry slot of tile over2_list[2 i]; g_key holds 4 entries per slot, g_tmp / g_flag one
 void launch_paint_huge(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, DevCount n_runs,

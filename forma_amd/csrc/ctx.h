@@ -35,6 +35,7 @@ struct DevBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
+constexpr uint32_t PAINT_STRIP_TILES = 6144;    // = the wave slots of the general painter (256 CUs x 24): every tile gets one at once   // frames of at most this many painted tiles are painted by strips (api.cpp paint_by_strips)
 constexpr size_t SEG_PAD = 16;          // segment buffers are over-allocated: stream kernels read whole 64-byte lane pieces
 enum { ST_PREPARE = 0, ST_RASTER, ST_SORT, ST_CARRY, ST_PAINT, ST_D2H, ST_XCHG, ST_COUNT };
 

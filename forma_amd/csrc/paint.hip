@@ -43,6 +43,15 @@ __device__ __forceinline__ bool cover_is_empty(uint64_t lo, uint64_t hi, bool ev
 // the painter's entry keys): enough for LayerWorkbench's optimizer passes to classify a layer without the style table
 #define LAYER_MASK     0x1FFFFFu
 
+// An OCCLUDER: a carry-only span whose cover is full, of an opaque solid colour, blended Over, neither a clip nor clipped —
+// what skip_fully_covered_layers_pass looks for (layer_workbench/passes/skip_fully_covered_layers.rs).  `khi` = the high word of
+// a span key / group-list entry: layer | SF_* << 21.
+__device__ __forceinline__ bool span_is_occluder(uint32_t khi) {
+    const uint32_t sfl = khi >> 21;
+    return (sfl & SF_FULL) && (sfl & SF_OPAQUE) && !(sfl & (SF_IS_CLIP | SF_CLIPPED)) &&
+           ((sfl >> SF_FILL_SHIFT) & 3u) == FORMA_FILL_SOLID && ((sfl >> SF_BLEND_SHIFT) & 15u) == 0u;
+}
+
 __device__ __forceinline__ bool cover_full(const uint32_t* c, bool even_odd) {     // Cover::is_full painter/mod.rs:200-215
     uint32_t ok = 1;
 #pragma unroll
@@ -593,6 +602,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
                                                            uint32_t n_slices, uint32_t bin_shift,
                                                            uint32_t row0 /* first tile row that is painted: blockIdx.x = 0 */,
                                                            SpanGroups groups, const uint32_t* __restrict__ run_lt,
+                                                           uint32_t cull /* PaintParams::cull: the group lists leave out what an occluder of the whole group hides */,
                                                            uint32_t left_start /* see below; 0xFFFFFFFF: off */) {
     constexpr int CR_RPT = RPT;                        // consecutive runs of the (layer, tile_x) order per lane in the row walk
     constexpr int CR_PIECE = CR_THREADS * RPT;         // runs per piece
@@ -1052,25 +1062,41 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
     const bool fits = total <= 2u * m && 2ull * sb0 + total <= groups.cap;
     for (uint32_t g = w; g < G; g += CR_WAVES) {
         const uint32_t x0 = g << SPAN_GROUP_SHIFT, x1 = x0 + SPAN_GROUP_TILES;
-        const uint32_t cntg = s_gcnt[g];
+        const uint32_t cntg = s_gcnt[g];                                // (an upper bound once spans are culled below: the list's slots)
         uint32_t first = gbase + s_gpre[g];                             // s_gpre is exclusive within the scanning wave of g
         for (uint32_t q = 0; q < (g >> 6); q++) first += s_red[q];
-        if (lane == 0) gt[g] = fits ? make_uint2(first, cntg) : make_uint2(0u, SPAN_GROUP_NONE);
-        if (!fits || !cntg) continue;
+        if (!fits || !cntg) { if (lane == 0) gt[g] = fits ? make_uint2(first, 0u) : make_uint2(0u, SPAN_GROUP_NONE); continue; }
+        // occlusion culling (PaintParams::cull): a span that covers the WHOLE group with a full cover of an opaque solid colour,
+        // blended Over, unclipped, hides every lower layer in each of the group's tiles — their painters would drop those entries
+        // one by one (k_paint_wave); they do not enter the group's list in the first place.
+        uint32_t gocc = 0;
+        if (cull) {
+            for (uint32_t e0 = 0; e0 < S; e0 += 64) {
+                const uint32_t e = e0 + (uint32_t)lane;
+                const uint32_t lh = e < S ? (lohi_at(e) & 0x7FFFFFFFu) : 0u;
+                if ((lh >> 16) <= x0 && (lh & 0xFFFFu) >= min(x1, tiles_w) && (lh & 0xFFFFu) > (lh >> 16)) {
+                    const uint32_t khi = LOCAL ? s_khi[e] : (uint32_t)(span_key[sb0 + e] >> 32);
+                    if (span_is_occluder(khi)) gocc = max(gocc, (khi & LAYER_MASK) + 1u);
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) gocc = max(gocc, (uint32_t)__shfl_xor(gocc, d, 64));
+        }
         uint32_t pos = first;
         for (uint32_t e0 = 0; e0 < S; e0 += 64) {                       // ordered compaction: list order = ascending layer
             const uint32_t e = e0 + (uint32_t)lane;
             const uint32_t lhu = e < S ? lohi_at(e) : 0u;
             const uint32_t lh = lhu & 0x7FFFFFFFu;
-            const bool hit = (lh >> 16) < x1 && (lh & 0xFFFFu) > x0 && (lh & 0xFFFFu) > (lh >> 16);    // (as counted above)
+            bool hit = (lh >> 16) < x1 && (lh & 0xFFFFu) > x0 && (lh & 0xFFFFu) > (lh >> 16);          // (as counted above)
+            const uint32_t khi = hit ? (LOCAL ? s_khi[e] : (uint32_t)(span_key[sb0 + e] >> 32)) : 0u;
+            if (hit && (khi & LAYER_MASK) + 1u < gocc) hit = false;
             const uint64_t bal = __ballot(hit);
-            if (hit) {
-                const uint32_t khi = LOCAL ? s_khi[e] : (uint32_t)(span_key[sb0 + e] >> 32);
+            if (hit)
                 groups.list[pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] =
                     make_uint4(khi, REF_SPAN | ((lhu >> 31) ? REF_UNCH : 0u) | (sb0 + e), lh, 0u);
-            }
             pos += (uint32_t)__popcll(bal);
         }
+        if (lane == 0) gt[g] = make_uint2(first, pos - first);
     }
 }
 
@@ -1083,7 +1109,7 @@ void launch_carry_rows(hipStream_t s, bool local_sort, bool small, uint32_t n_sl
                        uint32_t n_orders, uint32_t tiles_w, uint32_t tiles_h, const uint32_t* row_count,
                        uint32_t* row_span_lo, uint32_t* row_span_cnt, uint64_t* span_key, uint4* span_cov,
                        const uint8_t* unchanged, FrameInfo* info, uint32_t edge_segs, uint32_t vis_last, uint32_t row0, uint32_t row1,
-                       SpanGroups groups, const uint32_t* run_lt, uint32_t left_start) {
+                       SpanGroups groups, const uint32_t* run_lt, bool cull, uint32_t left_start) {
     row1 = row1 < tiles_h ? row1 : tiles_h;
     if (tiles_h == 0 || row0 >= row1) return;             // (only the tile rows that are painted: the others' carries are never read)
     if (n_slices < 1u) n_slices = 1u;
@@ -1091,7 +1117,7 @@ void launch_carry_rows(hipStream_t s, bool local_sort, bool small, uint32_t n_sl
     const dim3 grid((row1 - row0) * n_slices), block(CR_THREADS);
 #define CR_LAUNCH(L, C, R) FORMA_LAUNCH((k_carry_rows<L, C, R>), grid, block, 0, s, sorted_run_keys, records, blk_edge, n_segments, \
                                               n_runs, layer_sf, n_orders, tiles_w, tiles_h, row_count, row_span_lo, row_span_cnt, span_key, \
-                                              span_cov, unchanged, info, edge_segs, vis_last, n_slices, bin_shift, row0, groups, run_lt, left_start)
+                                              span_cov, unchanged, info, edge_segs, vis_last, n_slices, bin_shift, row0, groups, run_lt, cull ? 1u : 0u, left_start)
     if (!local_sort) CR_LAUNCH(false, CR_CAP, 4);
     else if (small) CR_LAUNCH(true, CR_CAP_S, 2);
     else CR_LAUNCH(true, CR_CAP, 4);
@@ -1942,6 +1968,9 @@ extern "C" int forma_hip_debug_paint_prof(unsigned long long* out24, int reset) 
 #ifndef PAINT_SIMPLE_OCC
 #define PAINT_SIMPLE_OCC 8   // waves per SIMD the all-solid variant is compiled for
 #endif
+#ifndef PAINT_STRIP_OCC
+#define PAINT_STRIP_OCC 8    // ... and the strip variants (one pixel per lane: a quarter of the colour registers)
+#endif
 #define WB   16           // painted entries staged per batch
 
 __device__ __forceinline__ void wave_lds_sync() {
@@ -1959,8 +1988,16 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // knows from the style table, forma_hip_set_styles) — the fills, the sixteen blend modes and the clip state machine are
 // not even compiled in, which is worth registers (occupancy), instruction cache and the per-layer dispatch.
 // ONE_SLICE: the carry pre-pass ran one workgroup per tile row (P.n_slices == 1): SpanListsT<1>.
-template <bool SIMPLE, bool ONE_SLICE>
-__global__ __launch_bounds__(64, SIMPLE ? PAINT_SIMPLE_OCC : PAINT_GENERIC_OCC) void k_paint_wave(PaintParams P, const uint64_t* __restrict__ sorted,
+// NPX: pixels per lane.  4 = one wavefront per tile (lane = column lx of row group rg, pixel rows 4 rg .. 4 rg + 3).
+// 1 = STRIPS: four independent wavefronts per tile, each owning the 16 x 4 strip of pixel rows 4 s .. 4 s + 3 (lane = one
+// pixel, the reference GPU backend's tile shape, consts.rs:45-48).  Every strip builds the tile's layer list itself — no
+// workgroup barrier, no traffic between the strips, the x-prefix stays inside 16-lane DPP rows — accumulates only the
+// segments of its rows and takes its four bytes of the carry cover.  The pixel work of a tile (segments, coverage, fills,
+// blends, encode) is then spread over four wavefronts with a quarter of the colour registers each: a launch's floor — its
+// deepest tile walked by ONE wavefront — drops accordingly, which is what small frames (1080p, a multi-GPU band) are bound
+// by.  The list work is done four times, so frames that fill the chip with one wavefront per tile keep NPX = 4.
+template <bool SIMPLE, bool ONE_SLICE, int NPX>
+__global__ __launch_bounds__(64, NPX == 1 ? PAINT_STRIP_OCC : (SIMPLE ? PAINT_SIMPLE_OCC : PAINT_GENERIC_OCC)) void k_paint_wave(PaintParams P, const uint64_t* __restrict__ sorted,
                                                     const TileRecord* __restrict__ records, DevCount nc_runs,
                                                     const uint32_t* __restrict__ tile_first_run,
                                                     const uint32_t* __restrict__ row_span_lo,
@@ -1978,7 +2015,7 @@ __global__ __launch_bounds__(64, SIMPLE ? PAINT_SIMPLE_OCC : PAINT_GENERIC_OCC) 
     __shared__ uint64_t w_key[1][WMAX];
     __shared__ uint64_t w_tmp[1][WMAX];
     __shared__ uint16_t w_flag[1][WMAX];                                // (EF_* fit 10 bits; 5 120 B per wave = 32 waves per CU)
-    __shared__ int w_cells[1][2][256];
+    __shared__ int w_cells[1][2][64 * NPX];
     __shared__ uint4 w_cov[1][WB], w_col[1][WB];
     __shared__ uint32_t w_seg0[1][WB], w_nseg[1][WB], w_bflag[1][WB], w_blayer[1][WB];
     __shared__ uint32_t w_woff[1][SIMPLE ? 1 : WB];                     // non-solid entries of the batch: where their style words are
@@ -1994,8 +2031,11 @@ __global__ __launch_bounds__(64, SIMPLE ? PAINT_SIMPLE_OCC : PAINT_GENERIC_OCC) 
     // Only the crop's tile rows are launched (a multi-GPU rank paints its band only).
     const uint32_t tile0 = P.crop_y0 * P.tiles_w, T = (P.crop_y1 - P.crop_y0) * P.tiles_w, per = (T + 7) / 8;
     const uint32_t bid = blockIdx.x;
-    if ((bid >> 3) >= per) return;
-    const uint32_t tidx = (bid & 7u) * per + (bid >> 3);
+    // (strips: the four wavefronts of a tile are consecutive workgroups of ONE XCD — they read the same records and segments)
+    const uint32_t kx = NPX == 1 ? (bid >> 5) : (bid >> 3);
+    const uint32_t strip = NPX == 1 ? ((bid >> 3) & 3u) : 0u;
+    if (kx >= per) return;
+    const uint32_t tidx = (bid & 7u) * per + kx;
     if (tidx >= T) return;
     const uint32_t tile = tile0 + tidx;
     const uint32_t ty = tile / P.tiles_w, tx = tile - ty * P.tiles_w;
@@ -2004,7 +2044,9 @@ __global__ __launch_bounds__(64, SIMPLE ? PAINT_SIMPLE_OCC : PAINT_GENERIC_OCC) 
     uint64_t* keys = w_key[wv];
     uint64_t* tmp = w_tmp[wv];
     uint16_t* flags = w_flag[wv];
-    const int lx = lane & 15, rg = lane >> 4;                           // this lane's pixels: (lx, 4 * rg + q), q = 0..3
+    const int lx = lane & 15, rg = lane >> 4;                           // this lane's pixels: (lx, 4 * rg + q), q = 0..3; strips: (lx, 4 * strip + rg)
+    const int row0 = NPX == 1 ? (int)strip * 4 + rg : rg * 4;           // first (strips: the only) pixel row of the lane
+    const bool lead = NPX == 4 || strip == 0u;                          // the wavefront that speaks for the tile (overflow list, counters)
 #ifdef PAINT_PROF
     unsigned long long pp_t = __builtin_readcyclecounter();
     PP_COUNT(16, 1);
@@ -2038,15 +2080,40 @@ __global__ __launch_bounds__(64, SIMPLE ? PAINT_SIMPLE_OCC : PAINT_GENERIC_OCC) 
     };
 #pragma unroll
     for (int u = 0; u < 4; u++) fetch(u * 64 + lane, eh[u], el[u], lh[u]);
+    // Occlusion culling (PaintParams::cull): occ = 1 + the layer of the topmost OCCLUDER among the spans that cross this tile.
+    // Everything below it is what skip_fully_covered_layers_pass skips anyway; dropped here, while the list is built, the merge
+    // and the passes work on a fraction of the entries and lists beyond WMAX become rare.
+    uint32_t occ = 0;
+    if (P.cull) {
+        for (uint32_t c = 0; c < sc; c += 256) {
+            if (c) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) fetch(c + u * 64 + lane, eh[u], el[u], lh[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {                               // (the lists ascend in layer: the LAST occluder found is the topmost)
+                const uint32_t lo = (lh[u] >> 16) & 0x7FFFu, hi = lh[u] & 0xFFFFu;
+                const uint64_t ob = __ballot(tx >= lo && tx < hi && span_is_occluder(eh[u]));
+                if (ob) occ = ((uint32_t)__builtin_amdgcn_readlane((int)eh[u], 63 - __builtin_clzll(ob)) & LAYER_MASK) + 1u;
+            }
+        }
+        if (sc > 256u) {                                                // (rare: the row's list in several rounds — back to the first)
+#pragma unroll
+            for (int u = 0; u < 4; u++) fetch(u * 64 + lane, eh[u], el[u], lh[u]);
+        }
+    }
     uint32_t na = 0;
     if (j0 != FORMA_NONE) {
         for (uint32_t c = 0;; c += 64) {                                // a tile's runs are contiguous from j0
             const uint32_t j = j0 + c + lane;
             bool mine = false; uint32_t layer = 0, unch = 0;
             if (j < n_runs) { const TileRecord* r = &records[j]; mine = (r->tile & 0x7FFFFFFFu) == my_tile_key; layer = r->layer; unch = (r->tile >> 31) ? REF_UNCH : 0u; }
-            if (mine && c + lane < WMAX) tmp[c + lane] = ((uint64_t)layer << 32) | unch | j;
+            const bool keep = mine && (layer & LAYER_MASK) + 1u >= occ; // (ascending layers: the kept runs are a suffix of the tile's)
+            const uint64_t kb = __ballot(keep);
+            const uint32_t pos = na + __builtin_amdgcn_mbcnt_hi((uint32_t)(kb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)kb, 0u));
+            if (keep && pos < WMAX) tmp[pos] = ((uint64_t)layer << 32) | unch | j;
             const uint32_t got = (uint32_t)__popcll(__ballot(mine));
-            na += got;
+            na += (uint32_t)__popcll(kb);
             if (got < 64u) break;
         }
     }
@@ -2059,7 +2126,7 @@ __global__ __launch_bounds__(64, SIMPLE ? PAINT_SIMPLE_OCC : PAINT_GENERIC_OCC) 
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t lo = (lh[u] >> 16) & 0x7FFFu, hi = lh[u] & 0xFFFFu;
-            const bool hit = tx >= lo && tx < hi;
+            const bool hit = tx >= lo && tx < hi && (eh[u] & LAYER_MASK) + 1u >= occ;
             const uint64_t bal = __ballot(hit);
             if (hit) {
                 const uint32_t pos = na + nb + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
@@ -2072,7 +2139,7 @@ __global__ __launch_bounds__(64, SIMPLE ? PAINT_SIMPLE_OCC : PAINT_GENERIC_OCC) 
     PP_STAMP(0);                                                        // 0: tile's runs + crossing spans found
     PP_COUNT(17, ne); PP_COUNT(18, sc);
     if (ne > WMAX) {                                                    // too deep for a wave: the workgroup variant paints it
-        if (lane == 0) {
+        if (lane == 0 && lead) {
             overflow_list[atomicAdd(overflow_n, 1u)] = tile;
             atomicOr(&info->error, 16u);                                // (not an error: "this frame has deep tiles", read by the host)
             if (!deep_follows) info->plan_bad = 1u;                     // the host guessed "none" and did not launch k_paint_deep: re-run
@@ -2211,8 +2278,8 @@ __global__ __launch_bounds__(64, SIMPLE ? PAINT_SIMPLE_OCC : PAINT_GENERIC_OCC) 
                 if (same) return;                                       // same solid colour as last frame: TileWriteOp::None
             }
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const uint32_t py = ty * 16u + (uint32_t)(rg * 4 + q);
+            for (int q = 0; q < NPX; q++) {
+                const uint32_t py = ty * 16u + (uint32_t)(row0 + q);
                 if (px < P.width && py < P.height) ((uint32_t*)image)[(size_t)py * P.stride_px + px] = bytes;
             }
             PP_STAMP(3); PP_COUNT(19, 1);                               // 3: solid fold + store (19: solid tiles)
@@ -2233,14 +2300,16 @@ __global__ __launch_bounds__(64, SIMPLE ? PAINT_SIMPLE_OCC : PAINT_GENERIC_OCC) 
         np += (uint32_t)__popcll(bal);
     }
 #pragma unroll
-    for (int q = 0; q < 4; q++) { w_cells[wv][0][q * 64 + lane] = 0; w_cells[wv][1][q * 64 + lane] = 0; }
+    for (int q = 0; q < NPX; q++) { w_cells[wv][0][q * 64 + lane] = 0; w_cells[wv][1][q * 64 + lane] = 0; }
 
     // ---- paint (Painter::paint_layer, painter/mod.rs:290-347): four pixels per lane ------------------------------------
     PP_STAMP(5); PP_COUNT(20, np);                                      // 5: painted-entry list (20: painted entries)
-    float dr[4], dg[4], db[4], da[4];
+    float dr[NPX], dg[NPX], db[NPX], da[NPX];
 #pragma unroll
-    for (int q = 0; q < 4; q++) { dr[q] = clear.r; dg[q] = clear.g; db[q] = clear.b; da[q] = clear.a; }   // Painter::clear :277-288
-    bool clip_valid = false; uint32_t clip_last = 0; float clip_mask[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int q = 0; q < NPX; q++) { dr[q] = clear.r; dg[q] = clear.g; db[q] = clear.b; da[q] = clear.a; }   // Painter::clear :277-288
+    bool clip_valid = false; uint32_t clip_last = 0; float clip_mask[NPX];
+#pragma unroll
+    for (int q = 0; q < NPX; q++) clip_mask[q] = 0.0f;
     const float fx = (float)px;
     uint32_t cbuf = 0;
     for (uint32_t b0 = 0; b0 < np; b0 += WB) {
@@ -2271,9 +2340,11 @@ __global__ __launch_bounds__(64, SIMPLE ? PAINT_SIMPLE_OCC : PAINT_GENERIC_OCC) 
             const uint32_t layer = b_layer[t];
             const uint32_t sfl = f >> 16;
             const uint4 cv4 = b_cov[t];
-            const uint32_t cw = rg == 0 ? cv4.x : (rg == 1 ? cv4.y : (rg == 2 ? cv4.z : cv4.w));   // bytes = rows 4 rg .. 4 rg + 3
+            const uint32_t cwi = NPX == 1 ? strip : (uint32_t)rg;       // the cover word of the lane's rows: bytes = rows 4 i .. 4 i + 3
+            const uint32_t cww = cwi == 0 ? cv4.x : (cwi == 1 ? cv4.y : (cwi == 2 ? cv4.z : cv4.w));
+            const uint32_t cw = NPX == 1 ? cww >> (8 * rg) : cww;       // (strips: the lane's row in byte 0)
             const uint32_t nseg = b_nseg[t];
-            int A[4];
+            int A[NPX];
             if (nseg) {
                 PP_COUNT(21, nseg);
                 int* cb = w_cells[wv][cbuf];
@@ -2281,12 +2352,14 @@ __global__ __launch_bounds__(64, SIMPLE ? PAINT_SIMPLE_OCC : PAINT_GENERIC_OCC) 
                 for (uint32_t sidx = lane; sidx < nseg; sidx += 64) {   // acc_segment :257-271
                     const uint64_t v = sp[sidx];
                     const int cv = seg_cover(v);
-                    atomicAdd(&cb[seg_ly(v) * 16 + seg_lx(v)], (int)((uint32_t)(seg_dam(v) * cv) << 16) + cv);
+                    if (NPX == 4) atomicAdd(&cb[seg_ly(v) * 16 + seg_lx(v)], (int)((uint32_t)(seg_dam(v) * cv) << 16) + cv);
+                    else if ((uint32_t)(seg_ly(v) >> 2) == strip)       // (a strip takes the segments of its four rows)
+                        atomicAdd(&cb[(seg_ly(v) & 3) * 16 + seg_lx(v)], (int)((uint32_t)(seg_dam(v) * cv) << 16) + cv);
                 }
                 wave_lds_sync();
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int ci = (rg * 4 + q) * 16 + lx;
+                for (int q = 0; q < NPX; q++) {
+                    const int ci = NPX == 1 ? lane : (rg * 4 + q) * 16 + lx;
                     const int S = cb[ci];
                     cb[ci] = 0;                                         // ready for the layer after next
                     const int c = (int)(int16_t)(S & 0xFFFF);
@@ -2301,14 +2374,14 @@ __global__ __launch_bounds__(64, SIMPLE ? PAINT_SIMPLE_OCC : PAINT_GENERIC_OCC) 
                 PP_STAMP(7);                                            // 7: segment accumulation + cover prefix
             } else {
 #pragma unroll
-                for (int q = 0; q < 4; q++) A[q] = 32 * (int)(int8_t)(cw >> (q * 8));
+                for (int q = 0; q < NPX; q++) A[q] = 32 * (int)(int8_t)(cw >> (q * 8));
             }
             if (!SIMPLE && clip_valid && clip_last < layer) clip_valid = false;    // :298-302
             const bool eo = (f & EF_EVENODD) != 0;
             if (!SIMPLE && (f & EF_IS_CLIP)) {                          // clip_at :449-464
                 if (!clip_valid) { clip_valid = true; clip_last = layer + b_col[t].x; }
 #pragma unroll
-                for (int q = 0; q < 4; q++) clip_mask[q] = coverage_of(A[q], eo);
+                for (int q = 0; q < NPX; q++) clip_mask[q] = coverage_of(A[q], eo);
                 continue;
             }
             const bool apply_clip = !SIMPLE && (f & EF_CLIPPED) && !(f & EF_SKIPCLIP);
@@ -2322,7 +2395,7 @@ __global__ __launch_bounds__(64, SIMPLE ? PAINT_SIMPLE_OCC : PAINT_GENERIC_OCC) 
                 // lane), ~4x the instructions.  Same operations in the same order, so the same bits.
                 const float fr = __uint_as_float(col.x), fg = __uint_as_float(col.y), fb = __uint_as_float(col.z), fa = __uint_as_float(col.w);
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < NPX; q++) {
                     const float cov = coverage_of(A[q], eo);
                     const float src_a = fa * cov;                       // blend_at :406-447 with blend = Over (the source colour)
                     const float ida = 1.0f - da[q], k1 = ida * src_a, isa = 1.0f - src_a, k2 = da[q] * src_a;
@@ -2356,14 +2429,14 @@ __global__ __launch_bounds__(64, SIMPLE ? PAINT_SIMPLE_OCC : PAINT_GENERIC_OCC) 
             // interleaves four fills and four blends.  All lanes evaluate (a pixel with coverage 0 keeps its colour, :317-319:
             // blend with 0 is the identity), so nothing below sits in a divergent branch.
 #pragma unroll 1
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < NPX; q++) {
                 const float cov = coverage_of(A[0], eo);
                 if (__any(cov != 0.0f)) {
                     float fill[4];
                     if (ft == FORMA_FILL_SOLID) {
                         fill[0] = __uint_as_float(col.x); fill[1] = __uint_as_float(col.y); fill[2] = __uint_as_float(col.z); fill[3] = __uint_as_float(col.w);
                     } else {
-                        const int ly = rg * 4 + q;
+                        const int ly = row0 + q;
                         const float fybase = (float)(ty * 16u + ((uint32_t)ly & 8u));                     // :326
                         if (ft == FORMA_FILL_TEXTURE) texture_at_im(ws, tex_im, texels, fx, fybase + (float)(ly & 7), fill);
                         else gradient_at_lds(ws, w, ft, FORMA_STYLE_STOPS(ws[0]), fx, fybase, ly & 7, lane, fill);
@@ -2380,10 +2453,12 @@ __global__ __launch_bounds__(64, SIMPLE ? PAINT_SIMPLE_OCC : PAINT_GENERIC_OCC) 
                     dr[0] = skip ? dr[0] : fmaf(dr[0], isa, cr); dg[0] = skip ? dg[0] : fmaf(dg[0], isa, cg);
                     db[0] = skip ? db[0] : fmaf(db[0], isa, cb2); da[0] = skip ? da[0] : fmaf(da[0], isa, src_a);
                 }
-                { const int t0 = A[0]; A[0] = A[1]; A[1] = A[2]; A[2] = A[3]; A[3] = t0; }
-#define ROT4(v) do { const float t0_ = v[0]; v[0] = v[1]; v[1] = v[2]; v[2] = v[3]; v[3] = t0_; } while (0)
-                ROT4(dr); ROT4(dg); ROT4(db); ROT4(da); ROT4(clip_mask);
+                if (NPX == 4) {
+                    { const int t0 = A[0]; A[0] = A[1 % NPX]; A[1 % NPX] = A[2 % NPX]; A[2 % NPX] = A[3 % NPX]; A[3 % NPX] = t0; }
+#define ROT4(v) do { const float t0_ = v[0]; v[0] = v[1 % NPX]; v[1 % NPX] = v[2 % NPX]; v[2 % NPX] = v[3 % NPX]; v[3 % NPX] = t0_; } while (0)
+                    ROT4(dr); ROT4(dg); ROT4(db); ROT4(da); ROT4(clip_mask);
 #undef ROT4
+                }
             }
             PP_STAMP(10); PP_COUNT(22, 1);                              // 10: coverage + fill + blend of any other layer (22: how many)
         }
@@ -2396,8 +2471,8 @@ __global__ __launch_bounds__(64, SIMPLE ? PAINT_SIMPLE_OCC : PAINT_GENERIC_OCC) 
         chan_sel |= (ch <= 3u ? ch : (ch == 4u ? 0x0Cu : 0x0Du)) << (8 * c);     // 0x0C -> 0x00 (Zero), 0x0D -> 0xFF (One)
     }
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const uint32_t py = ty * 16u + (uint32_t)(rg * 4 + q);
+    for (int q = 0; q < NPX; q++) {
+        const uint32_t py = ty * 16u + (uint32_t)(row0 + q);
         if (px < P.width && py < P.height) {
             const float sr = linear_to_srgb(dr[q]), sg = linear_to_srgb(dg[q]), sb2 = linear_to_srgb(db[q]);
             // the four candidates as bytes once, then the channel order with one byte permute (the selectors are uniform; a
@@ -2462,7 +2537,7 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
                   const uint64_t* span_key, const uint4* span_cov, const uint4* layer_col,
                   const uint32_t* style_offsets, const uint32_t* style_words, const forma_image_t* images,
                   const uint16_t* texels, uint8_t* image, TileCacheArgs cache, FrameInfo* info, uint32_t* overflow_n,
-                  uint32_t* overflow_list, uint32_t* over2_n, uint32_t* over2_list, bool launch_deep, SpanGroups groups) {
+                  uint32_t* overflow_list, uint32_t* over2_n, uint32_t* over2_list, bool launch_deep, SpanGroups groups, bool strips) {
     const uint32_t T = p.tiles_w * p.tiles_h;
     if (T == 0 || p.crop_y1 <= p.crop_y0) return;
     const uint32_t per = ((p.crop_y1 - p.crop_y0) * p.tiles_w + 7) / 8;
@@ -2470,11 +2545,16 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
     static const bool no_simple = dbg.no_simple_paint;               // (A/B switches for tools/)
     static const bool force_simple = dbg.force_simple_paint;         // (timing experiments only: wrong pixels on other scenes)
     const bool simple = (p.scene_simple && !no_simple) || force_simple, one = p.n_slices == 1u;
-#define PW_LAUNCH(S_, O_) FORMA_LAUNCH((k_paint_wave<S_, O_>), dim3(per * 8), dim3(64), 0, s, p, sorted, records, n_runs, tile_first_run, \
-                                             row_span_lo, row_span_cnt, span_key, span_cov, layer_col, style_offsets, style_words, images, \
-                                             texels, image, cache, info, overflow_n, overflow_list, launch_deep ? 1u : 0u, groups)
-    if (simple) { if (one) PW_LAUNCH(true, true); else PW_LAUNCH(true, false); }
-    else { if (one) PW_LAUNCH(false, true); else PW_LAUNCH(false, false); }
+    // strips (four wavefronts per tile, NPX = 1): never with a buffer-layer cache — a tile's cache entry is read by every strip
+    // and rewritten by the first one that finishes
+    if (cache.tiles) strips = false;
+#define PW_LAUNCH(S_, O_, N_) FORMA_LAUNCH((k_paint_wave<S_, O_, N_>), dim3(per * 8 * (N_ == 1 ? 4 : 1)), dim3(64), 0, s, p, sorted, records, n_runs, \
+                                             tile_first_run, row_span_lo, row_span_cnt, span_key, span_cov, layer_col, style_offsets, style_words, \
+                                             images, texels, image, cache, info, overflow_n, overflow_list, launch_deep ? 1u : 0u, groups)
+#define PW_LAUNCH_N(S_, O_) do { if (strips) PW_LAUNCH(S_, O_, 1); else PW_LAUNCH(S_, O_, 4); } while (0)
+    if (simple) { if (one) PW_LAUNCH_N(true, true); else PW_LAUNCH_N(true, false); }
+    else { if (one) PW_LAUNCH_N(false, true); else PW_LAUNCH_N(false, false); }
+#undef PW_LAUNCH_N
 #undef PW_LAUNCH
     if (!launch_deep) return;                             // (read-back-free frame of a scene whose last frame had no deep tile)
     FORMA_LAUNCH(k_paint_deep, dim3(T < 256 ? T : 256), dim3(256), 0, s, p, sorted, records, n_runs, tile_first_run,

@@ -496,3 +496,42 @@ def test_render_enqueue_into_registered_buffers():
         c.unregister_buffer(b)
     c.close()
 
+
+
+def test_kernel_times_of_a_timed_frame(ctx):
+    """forma_hip_kernel_times: every kernel of a timed frame, with its own launch-event duration.  The stage times of
+    forma_timings_t are sums over the list; the frame's total (first start -> last end) is at least the sum."""
+    both(ctx, S.random_mixed(n=200, width=1024, height=512, seed=5))
+    for _ in range(3):                                       # third frame: read-back-free path
+        _, tm = ctx.render(1024, 512, clear=(1, 1, 1, 1), device_only=True, timings=True)
+    ks = ctx.kernel_times()
+    names = [k[0] for k in ks]
+    assert any(n.startswith("k_rasterize") for n in names) and any(n.startswith("k_paint_wave") for n in names), names
+    assert all(us > 0.0 for _, _, _, us in ks)
+    for stage, key in ((0, "prepare_us"), (1, "rasterize_us"), (2, "sort_us"), (3, "carry_us"), (4, "paint_us")):
+        assert abs(sum(us for _, st, _, us in ks if st == stage) - tm[key]) < 0.05 + 1e-3 * tm[key], key
+    assert tm["total_us"] + 1.0 >= sum(us for _, st, _, us in ks if st != 5)
+    starts = [t0 for _, _, t0, _ in ks]
+    assert starts == sorted(starts)
+
+
+@pytest.mark.parametrize("switch", ["", "no_cull", "strip_tiles=100000000", "no_cull,strip_tiles=0"])
+def test_occlusion_culling_and_strip_painters_change_no_pixel(monkeypatch, switch):
+    """The painters drop the entries below a tile's topmost occluder while they build its list (PaintParams::cull), and small
+    frames are painted by four strip wavefronts per tile (k_paint_wave<.., NPX = 1>): neither may change a pixel.  Opaque cubics
+    over the whole canvas (hundreds of hidden layers per tile: the case culling exists for), a mixed scene with gradients, blend
+    modes and clips (culling must switch itself off), each against the oracle under every switch."""
+    import forma_amd
+    monkeypatch.setenv("FORMA_HIP_DEBUG", switch)
+    c = forma_amd.Context(0)
+    try:
+        for comp, (w, h) in ((S.random_cubics(n=400, width=640, height=360, seed=3), (640, 360)),
+                             (S.random_cubics(n=300, width=512, height=256, seed=4, alpha=0.6), (512, 256)),
+                             (S.random_mixed(n=300, width=512, height=384, seed=9), (512, 384))):
+            o, _ = both(c, comp)
+            for _ in range(3):                               # synchronous, then read-back-free frames
+                img = c.render(w, h, clear=(1.0, 1.0, 1.0, 1.0))
+            ref = o.render(w, h, clear=(1.0, 1.0, 1.0, 1.0))
+            assert np.abs(img.astype(np.int16) - ref.astype(np.int16)).max() <= 1
+    finally:
+        c.close()

@@ -42,12 +42,18 @@ def child(args):
     c.render = lambda *a, **k: _render(*a, crop=crop, **k)
     for _ in range(4):
         c.render(W, H, clear=clear, device_only=True)
-    acc = {}
+    acc, kacc = {}, {}
     for _ in range(args.frames):
         _, tm = c.render(W, H, clear=clear, device_only=True, timings=True)
         for k, v in tm.items():
             acc.setdefault(k, []).append(v)
+        per = {}
+        for name, _st, _t0, us in c.kernel_times():           # every kernel's own launch events, summed per name and frame
+            per[name] = per.get(name, 0.0) + us
+        for k, v in per.items():
+            kacc.setdefault(k, []).append(v)
     med = {k: statistics.median(v) for k, v in acc.items()}
+    kern = {k[2:] if k.startswith("k_") else k: round(statistics.median(v), 1) for k, v in kacc.items()}
     t0 = time.perf_counter()
     for _ in range(args.frames):
         c.render(W, H, clear=clear, device_only=True)
@@ -66,7 +72,7 @@ def child(args):
     print(json.dumps({"fps1": round(fps1, 1), "fps3": round(fps3, 1), "pass_us": round(med["sort_pass_us"], 1),
                       "stages": {k[:-3]: round(med[k], 1) for k in ("prepare_us", "rasterize_us", "sort_us", "carry_us", "paint_us", "total_us")},
                       "crc": int(np.bitwise_xor.reduce(img.view(np.uint32).reshape(-1))) & 0xFFFFFFFF,
-                      "n": int(med["n_segments"])}))
+                      "n": int(med["n_segments"]), "kern": kern}))
     c.close()
 
 
@@ -105,6 +111,8 @@ def main():
             d = json.loads(line[-1])
             rows.setdefault(v, []).append(d)
             print("%-18s fps1 %7.1f fps3 %7.1f pass %6.1f  %s crc %08x" % (v, d["fps1"], d["fps3"], d["pass_us"], d["stages"], d["crc"]), flush=True)
+            if os.environ.get("AB_KERNELS"):
+                print("    kernels: " + " ".join("%s %.1f" % kv for kv in d.get("kern", {}).items()), flush=True)
     print("---- medians")
     for v, ds in rows.items():
         print("%-18s fps1 %7.1f fps3 %7.1f pass %6.1f total %6.1f" % (v, statistics.median(x["fps1"] for x in ds), statistics.median(x["fps3"] for x in ds),
