@@ -393,7 +393,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
         return std::min<uint32_t>(CR_MAX_SLICES_HOST, std::min(by_chip, by_load));
     };
     uint32_t n_slices = 1;
-    bool small = false;
+    bool small = false, half = false;
     if (bound_j) {
         jc = DevCount{&dinfo->n_runs, bound_j};
         local_sort = local_sort && ctx->pred_max_row <= carry_rows_local_cap();     // wrong guess -> plan_bad -> synchronous re-run
@@ -406,6 +406,18 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
             const bool known = ctx->pred_slice_n == ks && ctx->pred_slice_small;
             const uint64_t guess = known ? (uint64_t)ctx->pred_max_slice * 10 / 9 : (uint64_t)ctx->pred_max_row * 5 / (3 * ks);
             if (guess <= carry_rows_small_cap()) { small = true; n_slices = ks; }
+        }
+        // The HALF variant (512 lanes, one piece of <= 2048 runs, three workgroups per CU) for frames whose rows are LIGHT — the
+        // 8192 x 8192 triangle scene (512 rows of ~1 000 runs), 1080p: one workgroup per row as before, but 768 of them resident
+        // at once instead of 256, each without the large variant's 148 KB of LDS to itself (carry 57 -> 32 us on the 8K scene,
+        // 42 -> 27 at 1080p).  Heavy rows (the 4K scene: 4 800 runs) gain nothing from 3-6 half workgroups per row — measured:
+        // the carry kernel saves 0-12 us and the painters pay as much for the extra span lists.
+        if (!small && local_sort && !ctx->small_banned && !ctx->no_small_carry && !ctx->force_slices && ctx->dbg.carry_half != 0 && pmr) {
+            uint32_t kh = 1u;
+            if (ctx->dbg.carry_half > 1) kh = (uint32_t)std::min<int>(ctx->dbg.carry_half, (int)CR_MAX_SLICES_HOST);   // (tools: N slices per row)
+            const bool known = ctx->pred_slice_n == kh && ctx->pred_slice_small && ctx->pred_slice_half;
+            const uint64_t guess = known ? (uint64_t)ctx->pred_max_slice * 10 / 9 : (kh > 1u ? (uint64_t)pmr * 5 / (3 * kh) : (uint64_t)pmr * 6 / 5);
+            if (guess <= carry_rows_half_cap()) { small = true; half = true; n_slices = kh; }
         }
         ctx->small_tried = small;
     } else {
@@ -461,7 +473,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
             ctx->pz.sort_p = nullptr;
         }
         if (ctx->force_slices) n_slices = ctx->force_slices;  // FORMA_HIP_DEBUG=carry_slices (tests: every slice count on one GPU)
-        ctx->cur_slices = n_slices; ctx->cur_small = small;
+        ctx->cur_slices = n_slices; ctx->cur_small = small; ctx->cur_half = half;
     } else {
         HIPCHECK(ctx->span_key.ensure(8));
         HIPCHECK(ctx->span_cov.ensure(16));
@@ -493,7 +505,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     // last verified frame had no deep tile; a tile that needs it then voids the frame (re-run in full)
     const bool launch_deep = !(bound_j != 0 && a.cache_id < 0 && ctx->pred_no_deep);
     if (jc.bound > 0)
-        launch_carry_rows(ctx->stream, local_sort, small, n_slices, bin_shift, sorted_keys, ctx->records.as<TileRecord>(),
+        launch_carry_rows(ctx->stream, local_sort, small, half, n_slices, bin_shift, sorted_keys, ctx->records.as<TileRecord>(),
                           ctx->blk_edge.as<BlkEdge>(), nc, jc, ctx->layer_sf.as<uint32_t>(),
                           (uint32_t)ctx->n_orders, tiles_w, tiles_h, row_count, row_span_lo,
                           row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(),
@@ -685,7 +697,7 @@ int finish_frame(forma_hip_ctx* ctx, forma_timings_t* t, bool have_info = false)
         ctx->pred_range = KeyRange{~r[0], r[1], ~r[2], r[3], true};
     }
     if (!ctx->h_info->plan_bad) ctx->pred_row_spans = ctx->h_info->n_spans / ctx->cur_rows_painted;
-    if (!ctx->h_info->plan_bad) { ctx->pred_max_slice = ctx->h_info->max_slice_runs; ctx->pred_slice_n = ctx->cur_slices; ctx->pred_slice_small = ctx->cur_small; }
+    if (!ctx->h_info->plan_bad) { ctx->pred_max_slice = ctx->h_info->max_slice_runs; ctx->pred_slice_n = ctx->cur_slices; ctx->pred_slice_small = ctx->cur_small; ctx->pred_slice_half = ctx->cur_half; }
     if ((ctx->h_info->error & ~24u) == 1u)                   // (bit 0: k_carry_rows met a run of a layer without a style)
         return fail(ctx, FORMA_E_ARG, "a geometry entry names an order that has no style (forma_hip_set_styles: offset FORMA_NONE or beyond the table)");
     if (ctx->h_info->error & ~24u) return fail(ctx, FORMA_E_INTERNAL, "device-side invariant violated");

@@ -323,12 +323,14 @@ void launch_pack_written(hipStream_t s, const uint8_t* written, uint32_t tiles_w
 
 uint32_t carry_rows_local_cap();      // most runs a workgroup of launch_carry_rows(local_sort = true) sorts in LDS: large variant ...
 uint32_t carry_rows_small_cap();      // ... small variant (several workgroups per CU)
+uint32_t carry_rows_half_cap();       // ... its 512-lane form
 #define CR_MAX_SLICES_HOST 8u         // workgroups that may share one tile row
 // the frame's tile tables, one buffer: [row_count: tiles_h + 1][row_span_lo: 8 tiles_h + 1][row_span_cnt: 8 tiles_h + 1]
 // [painter overflow counters: 2][first-run table: T] — zeroed every frame by launch_runs — then [overflow list: T][{tile, entries}: 2 T]
 static inline uint32_t row_tab_zero_words(uint32_t tiles_w, uint32_t tiles_h) { return (tiles_h + 1) + 2 * (CR_MAX_SLICES_HOST * tiles_h + 1) + 2 + tiles_w * tiles_h; }
 // n_slices workgroups per tile row (each a range of layers, 256 bins of layer >> bin_shift); small: the CR_CAP_S variant
-void launch_carry_rows(hipStream_t s, bool local_sort, bool small, uint32_t n_slices, uint32_t bin_shift,
+void launch_carry_rows(hipStream_t s, bool local_sort, bool small, bool half /* with small: 512-lane workgroups, slices of <= 2048 runs */,
+                       uint32_t n_slices, uint32_t bin_shift,
                        const uint64_t* sorted_run_keys, TileRecord* records,
                        const BlkEdge* blk_edge, DevCount n_segments, DevCount n_runs,
                        const uint32_t* layer_sf /* per order: SF_* | LSF_VALID */, uint32_t n_orders, uint32_t tiles_w,

@@ -67,6 +67,7 @@ struct forma_hip_ctx {
     bool pred_no_deep = false;              // the last verified frame sent no tile to k_paint_deep
     // carry pre-pass: slices per tile row and the LDS variant (api.cpp run_paint)
     uint32_t cur_slices = 1, pred_slice_n = 0, pred_max_slice = 0, force_slices = 0;
+    bool cur_half = false, pred_slice_half = false;   // the 512-lane variant of the small carry kernel (api.cpp run_paint)
     bool cur_small = false, pred_slice_small = false, small_tried = false, small_banned = false, no_small_carry = false;
     DevBuf ras_masks;                       // k_rasterize: key masks per workgroup (8 words), combined by k_reduce_masks
     PendingMasks pending_masks{nullptr, 0u}; // ... or, on read-back-free frames, by k_runs_count

@@ -507,6 +507,14 @@ uint32_t runs_count_tiles(size_t n, bool* scanned) { const uint32_t t = (uint32_
 #define CR_CAP     16384                // runs one workgroup's in-LDS sort holds, large variant (2 x 64 KiB of 32-bit keys: one per CU)
 #define CR_CAP_S   4096                 // ... small variant (2 x 16 KiB of keys, 66 KB in all.  NOT two per CU: its 81 VGPRs x 16 waves
                                         // leave room for one workgroup per CU like the large one — it is the shorter sort that pays)
+#ifndef CR_SMALL_OCC
+#define CR_SMALL_OCC 4
+#endif
+#ifndef CR_HALF_OCC
+#define CR_HALF_OCC 6
+#endif
+#define CR_THREADS_H 512                // the HALF variant: 512 lanes, one piece of 2048 runs — three per CU (LDS 33 KB, 24 of the CU's
+#define CR_CAP_H   2048                 // waves), so that a whole 4K frame (135 rows x 3 slices) is resident at once on all 256 CUs
 #define CR_MAX_SLICES 8                 // workgroups that share one tile row (each takes a range of layers)
 
 // workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight across it
@@ -585,8 +593,9 @@ __device__ __forceinline__ CarryLoad carry_load(uint32_t c0, int tid, uint32_t c
 // span slots (row_lo + runs in the bins below it), and the painters walk a row's n_slices span lists one after the other —
 // ascending layers, as before.  One workgroup per row was 135 workgroups on 256 CUs for the 4K frame, each ~50 us of pure
 // latency (scattered record gathers through one CU's address pipe); on a multi-GPU band of 17 rows it was the frame's floor.
-template <bool LOCAL, int CAP, int RPT>
-__global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __restrict__ sorted_keys,
+template <bool LOCAL, int CAP, int RPT, int TH>
+__global__ __launch_bounds__(TH, TH == 512 ? CR_HALF_OCC : (CAP == CR_CAP_S ? CR_SMALL_OCC : 1)) void k_carry_rows(   // (512 lanes: three workgroups per CU = six waves per SIMD)
+    const uint64_t* __restrict__ sorted_keys,
                                                            TileRecord* __restrict__ records,
                                                            const BlkEdge* __restrict__ blk_edge, DevCount nc_segments,
                                                            DevCount nc_runs,
@@ -605,17 +614,17 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
                                                            uint32_t cull /* PaintParams::cull: the group lists leave out what an occluder of the whole group hides */,
                                                            uint32_t left_start /* see below; 0xFFFFFFFF: off */) {
     constexpr int CR_RPT = RPT;                        // consecutive runs of the (layer, tile_x) order per lane in the row walk
-    constexpr int CR_PIECE = CR_THREADS * RPT;         // runs per piece
+    constexpr int CR_PIECE = TH * RPT;         // runs per piece
     constexpr bool NB_IN_IDLE = LOCAL && 2 * (CR_PIECE + 1) <= CAP;   // group / tile_x of a piece's runs live in the sort's idle buffer
-    __shared__ uint32_t s_red[CR_WAVES];
-    __shared__ uint64_t s_wlo[CR_WAVES], s_whi[CR_WAVES];
-    __shared__ uint32_t s_wflag[CR_WAVES], s_wspan[CR_WAVES];
+    __shared__ uint32_t s_red[(TH / 64)];
+    __shared__ uint64_t s_wlo[(TH / 64)], s_whi[(TH / 64)];
+    __shared__ uint32_t s_wflag[(TH / 64)], s_wspan[(TH / 64)];
     __shared__ uint32_t s_group[256];                  // scratch of the in-LDS sort; before it, the layer-bin histogram
     __shared__ uint32_t s_nb[NB_IN_IDLE ? 1 : 2 * (CR_PIECE + 1)];
     __shared__ uint64_t s_clo, s_chi;                  // carry across chunks: inclusive acc of the last element
     __shared__ uint32_t s_cgroup, s_spans;
     __shared__ uint32_t s_ka[LOCAL ? CAP : 1], s_kb[LOCAL ? CAP : 1];
-    __shared__ uint32_t s_wh[LOCAL ? CR_WAVES * 256 : 1];
+    __shared__ uint32_t s_wh[LOCAL ? (TH / 64) * 256 : 1];
     __shared__ uint32_t s_cut[4];                      // this slice: first bin, end bin | first key, end key (!LOCAL)
     __shared__ uint32_t s_gcnt[256], s_gpre[256];      // span group lists: entries per group, their exclusive prefix
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -645,7 +654,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
     const uint32_t n_blk = (dev_count(nc_segments) + edge_segs - 1) / edge_segs;   // BlkEdge entries (one per edge_segs segments)
     // first run of this row = sum of the run counts of the rows above
     uint32_t part = 0;
-    for (uint32_t r = tid; r < ty; r += CR_THREADS) part += row_count[r];
+    for (uint32_t r = tid; r < ty; r += TH) part += row_count[r];
     const uint32_t cnt = row_count[ty];
     if (plan_bad) return;
     if (runs_dev > nc_runs.bound) {                                     // more runs than provisioned: the frame is void, and
@@ -660,7 +669,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
     __syncthreads();
     uint32_t row_lo = 0;
 #pragma unroll
-    for (int i = 0; i < CR_WAVES; i++) row_lo += s_red[i];
+    for (int i = 0; i < (TH / 64); i++) row_lo += s_red[i];
     const uint32_t* lkeys = s_ka;                        // LOCAL: the slice's runs, ordered by (layer, tile_x)
     if (tid == 0 && cnt && slice == 0) atomicMax(&info->max_row_runs, cnt);
     uint32_t m = cnt;                                    // runs of this slice
@@ -677,7 +686,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
             //      Every workgroup of the row computes the same cuts from the same keys. ------------------------------------
             if (tid < 256) s_group[tid] = 0;
             __syncthreads();
-            for (uint32_t e = tid; e < cnt; e += CR_THREADS) {
+            for (uint32_t e = tid; e < cnt; e += TH) {
                 const uint32_t bin = min(255u, ((run_lt[row_lo + e] >> 16) >> bin_shift));
                 atomicAdd(&s_group[bin], 1u);
             }
@@ -724,7 +733,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
             }
             // ---- stable compaction of my runs, in stream (tile_x-major) order, 1024 keys per round ----------------------------
             uint32_t filled = 0;
-            for (uint32_t e0 = 0; e0 < cnt; e0 += CR_THREADS) {
+            for (uint32_t e0 = 0; e0 < cnt; e0 += TH) {
                 const uint32_t e = e0 + (uint32_t)tid;
                 uint32_t l16 = 0; bool keep = false;
                 if (e < cnt) {
@@ -737,30 +746,30 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
                 __syncthreads();
                 uint32_t base = filled, tot = 0;
 #pragma unroll
-                for (int i = 0; i < CR_WAVES; i++) { const uint32_t t = s_red[i]; if (i < w) base += t; tot += t; }
+                for (int i = 0; i < (TH / 64); i++) { const uint32_t t = s_red[i]; if (i < w) base += t; tot += t; }
                 if (keep) s_ka[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = (l16 << 16) | e;
                 filled += tot;
                 __syncthreads();
             }
         } else {
             if (cnt > (uint32_t)CAP) { if (tid == 0) info->plan_bad = 1u; return; }
-            for (uint32_t e = tid; e < cnt; e += CR_THREADS) s_ka[e] = (run_lt[row_lo + e] & 0xFFFF0000u) | e;
+            for (uint32_t e = tid; e < cnt; e += TH) s_ka[e] = (run_lt[row_lo + e] & 0xFFFF0000u) | e;
             __syncthreads();
         }
         if (tid == 0 && m) atomicMax(&info->max_slice_runs, m);
         CRP_STAMP(1);                                                   // the slice's run keys into LDS
         uint32_t* src = s_ka;
         uint32_t* dst = s_kb;
-        const uint32_t R = (m + CR_THREADS - 1) / CR_THREADS, CW = R * 64;         // key rows per wave, keys per wave
+        const uint32_t R = (m + TH - 1) / TH, CW = R * 64;         // key rows per wave, keys per wave
         const int npass = n_orders > 256u ? 2 : 1;
         for (int pass = 0; pass < npass; pass++) {
             const int sh = 16 + 8 * pass;
-            for (int i = tid; i < CR_WAVES * 256; i += CR_THREADS) s_wh[i] = 0;
+            for (int i = tid; i < (TH / 64) * 256; i += TH) s_wh[i] = 0;
             __syncthreads();
             CRP_STAMP(5);                                               // sort: counters cleared
-            uint32_t kreg[CAP / CR_THREADS], rreg[CAP / CR_THREADS];
+            uint32_t kreg[CAP / TH], rreg[CAP / TH];
 #pragma unroll
-            for (int r = 0; r < CAP / CR_THREADS; r++) {
+            for (int r = 0; r < CAP / TH; r++) {
                 if ((uint32_t)r < R) {
                     const uint32_t e = w * CW + r * 64 + lane;
                     const uint32_t key = e < m ? src[e] : 0xFFFFFFFFu;             // padding: last in stream order, digit 255
@@ -780,7 +789,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
             if (tid < 256) {                              // digit tid: start of every wave's share of it
                 uint32_t tot = 0;
 #pragma unroll
-                for (int i = 0; i < CR_WAVES; i++) tot += s_wh[i * 256 + tid];
+                for (int i = 0; i < (TH / 64); i++) tot += s_wh[i * 256 + tid];
                 uint32_t inc = tot;
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) { const uint32_t t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
@@ -792,11 +801,11 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
                 uint32_t acc = s_group[tid];
                 for (int i = 0; i < w; i++) acc += s_red[i];
 #pragma unroll
-                for (int i = 0; i < CR_WAVES; i++) { const uint32_t c = s_wh[i * 256 + tid]; s_wh[i * 256 + tid] = acc; acc += c; }
+                for (int i = 0; i < (TH / 64); i++) { const uint32_t c = s_wh[i * 256 + tid]; s_wh[i * 256 + tid] = acc; acc += c; }
             }
             __syncthreads();
 #pragma unroll
-            for (int r = 0; r < CAP / CR_THREADS; r++) {
+            for (int r = 0; r < CAP / TH; r++) {
                 if ((uint32_t)r < R) {
                     const uint32_t e = w * CW + r * 64 + lane;
                     if (e < m) dst[s_wh[w * 256 + ((kreg[r] >> sh) & 0xFFu)] + rreg[r]] = kreg[r];
@@ -816,7 +825,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
             if (hh > 0 && hh < n_slices) {                // forward to the next position where the layer changes
                 if (tid == 0) s_cut[q] = cnt;
                 __syncthreads();
-                for (uint32_t p0 = pos; p0 < cnt; p0 += CR_THREADS) {
+                for (uint32_t p0 = pos; p0 < cnt; p0 += TH) {
                     const uint32_t pp = p0 + (uint32_t)tid;
                     bool brk = false;
                     if (pp < cnt && pp > 0) brk = (uint32_t)(sorted_keys[row_lo + pp] >> 32) != (uint32_t)(sorted_keys[row_lo + pp - 1] >> 32);
@@ -846,7 +855,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
     uint16_t* s_txo = nullptr;
     if (LOCAL && n_slices == 1u) {
         s_txo = reinterpret_cast<uint16_t*>(NB_IN_IDLE ? idle + (CR_PIECE + 1) + (CR_PIECE + 4) / 2 : idle);
-        for (uint32_t e = tid; e < cnt; e += CR_THREADS) s_txo[e] = (uint16_t)run_lt[row_lo + e];
+        for (uint32_t e = tid; e < cnt; e += TH) s_txo[e] = (uint16_t)run_lt[row_lo + e];
         __syncthreads();
     }
     static_assert(!NB_IN_IDLE || (CR_PIECE + 1) + (CR_PIECE + 4) / 2 + CAP / 2 <= CAP, "group / tile_x / digest arrays share the idle sort buffer");
@@ -922,13 +931,13 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
         if (lane == 63) { s_wlo[w] = lo; s_whi[w] = hi; s_wflag[w] = f; }
         lds_barrier();
         if (w == 0) {                                     // wave carry-ins: segmented scan of the 16 wave totals, seeded by the
-            const bool in = lane < CR_WAVES;              // piece carry — done by 16 lanes, not by one lane 16 times
+            const bool in = lane < (TH / 64);              // piece carry — done by 16 lanes, not by one lane 16 times
             uint64_t l = in ? s_wlo[lane] : 0ull, h = in ? s_whi[lane] : 0ull;
             uint32_t fl = in ? s_wflag[lane] : 0u;
             const uint64_t seed_lo = s_clo, seed_hi = s_chi;
             if (lane == 0 && !fl) { l = swar_add8(seed_lo, l); h = swar_add8(seed_hi, h); }
 #pragma unroll
-            for (int d = 1; d < CR_WAVES; d <<= 1) {
+            for (int d = 1; d < (TH / 64); d <<= 1) {
                 const uint64_t tl = __shfl_up(l, d, 64), th = __shfl_up(h, d, 64);
                 const uint32_t tf = __shfl_up(fl, d, 64);
                 if (lane >= d) { if (!fl) { l = swar_add8(l, tl); h = swar_add8(h, th); } fl |= tf; }
@@ -993,7 +1002,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
         lds_barrier();
         uint32_t sbase = s_spans + nsp_incl - nsp, stot = 0;
 #pragma unroll
-        for (int i = 0; i < CR_WAVES; i++) { const uint32_t t = s_wspan[i]; if (i < w) sbase += t; stot += t; }
+        for (int i = 0; i < (TH / 64); i++) { const uint32_t t = s_wspan[i]; if (i < w) sbase += t; stot += t; }
 #pragma unroll
         for (int k = 0; k < CR_RPT; k++) {
             if ((spanm >> k) & 1u) {
@@ -1008,7 +1017,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
             }
         }
         lds_barrier();
-        if (tid == CR_THREADS - 1) { s_clo = out_lo[CR_RPT - 1]; s_chi = out_hi[CR_RPT - 1]; s_cgroup = group[CR_RPT - 1]; }   // only used when the piece is full
+        if (tid == TH - 1) { s_clo = out_lo[CR_RPT - 1]; s_chi = out_hi[CR_RPT - 1]; s_cgroup = group[CR_RPT - 1]; }   // only used when the piece is full
         if (tid == 0) s_spans += stot;
         lds_barrier();
     }
@@ -1028,7 +1037,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
     // nothing from group lists and this epilogue would cost its 512 small workgroups 12 us: such a slice says "none" and its
     // row's painters scan the row list.  (The other two conditions cannot happen: tile_x has 12 bits, spans <= runs <= CAP.)
     if (S * n_slices <= groups.min_row || G > 256u || (LOCAL && S > (uint32_t)CAP)) {
-        for (uint32_t g = tid; g < G; g += CR_THREADS) gt[g] = make_uint2(0u, SPAN_GROUP_NONE);
+        for (uint32_t g = tid; g < G; g += TH) gt[g] = make_uint2(0u, SPAN_GROUP_NONE);
         return;
     }
     // the slice's keys: low words (unch | lo | hi) and high words (layer | SF_*) into the idle sort buffers, one round of loads
@@ -1036,11 +1045,11 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
     uint32_t* s_khi = LOCAL ? s_kb : nullptr;
     if (tid < 256) s_gcnt[tid] = 0;
     if (LOCAL) {
-        for (uint32_t e = tid; e < S; e += CR_THREADS) { const uint64_t k = span_key[sb0 + e]; s_lohi[e] = (uint32_t)k; s_khi[e] = (uint32_t)(k >> 32); }
+        for (uint32_t e = tid; e < S; e += TH) { const uint64_t k = span_key[sb0 + e]; s_lohi[e] = (uint32_t)k; s_khi[e] = (uint32_t)(k >> 32); }
     }
     __syncthreads();
     auto lohi_at = [&](uint32_t e) -> uint32_t { return LOCAL ? s_lohi[e] : (uint32_t)span_key[sb0 + e]; };
-    for (uint32_t e = tid; e < S; e += CR_THREADS) {                    // entries per group
+    for (uint32_t e = tid; e < S; e += TH) {                    // entries per group
         const uint32_t lh = lohi_at(e) & 0x7FFFFFFFu;
         const uint32_t lo = lh >> 16, hi = lh & 0xFFFFu;
         if (hi > lo) for (uint32_t g = lo >> SPAN_GROUP_SHIFT; g <= ((hi - 1u) >> SPAN_GROUP_SHIFT) && g < G; g++) atomicAdd(&s_gcnt[g], 1u);
@@ -1060,7 +1069,7 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
     const uint32_t total = s_red[0] + s_red[1] + s_red[2] + s_red[3];
     const uint32_t gbase = 2u * sb0;
     const bool fits = total <= 2u * m && 2ull * sb0 + total <= groups.cap;
-    for (uint32_t g = w; g < G; g += CR_WAVES) {
+    for (uint32_t g = w; g < G; g += (TH / 64)) {
         const uint32_t x0 = g << SPAN_GROUP_SHIFT, x1 = x0 + SPAN_GROUP_TILES;
         const uint32_t cntg = s_gcnt[g];                                // (an upper bound once spans are culled below: the list's slots)
         uint32_t first = gbase + s_gpre[g];                             // s_gpre is exclusive within the scanning wave of g
@@ -1102,8 +1111,9 @@ __global__ __launch_bounds__(CR_THREADS) void k_carry_rows(const uint64_t* __res
 
 uint32_t carry_rows_local_cap() { return CR_CAP; }
 uint32_t carry_rows_small_cap() { return CR_CAP_S; }
+uint32_t carry_rows_half_cap() { return CR_CAP_H; }
 
-void launch_carry_rows(hipStream_t s, bool local_sort, bool small, uint32_t n_slices, uint32_t bin_shift,
+void launch_carry_rows(hipStream_t s, bool local_sort, bool small, bool half, uint32_t n_slices, uint32_t bin_shift,
                        const uint64_t* sorted_run_keys, TileRecord* records,
                        const BlkEdge* blk_edge, DevCount n_segments, DevCount n_runs, const uint32_t* layer_sf,
                        uint32_t n_orders, uint32_t tiles_w, uint32_t tiles_h, const uint32_t* row_count,
@@ -1114,13 +1124,14 @@ void launch_carry_rows(hipStream_t s, bool local_sort, bool small, uint32_t n_sl
     if (tiles_h == 0 || row0 >= row1) return;             // (only the tile rows that are painted: the others' carries are never read)
     if (n_slices < 1u) n_slices = 1u;
     if (n_slices > CR_MAX_SLICES) n_slices = CR_MAX_SLICES;
-    const dim3 grid((row1 - row0) * n_slices), block(CR_THREADS);
-#define CR_LAUNCH(L, C, R) FORMA_LAUNCH((k_carry_rows<L, C, R>), grid, block, 0, s, sorted_run_keys, records, blk_edge, n_segments, \
+    const dim3 grid((row1 - row0) * n_slices);
+#define CR_LAUNCH(L, C, R, T_) FORMA_LAUNCH((k_carry_rows<L, C, R, T_>), grid, dim3(T_), 0, s, sorted_run_keys, records, blk_edge, n_segments, \
                                               n_runs, layer_sf, n_orders, tiles_w, tiles_h, row_count, row_span_lo, row_span_cnt, span_key, \
                                               span_cov, unchanged, info, edge_segs, vis_last, n_slices, bin_shift, row0, groups, run_lt, cull ? 1u : 0u, left_start)
-    if (!local_sort) CR_LAUNCH(false, CR_CAP, 4);
-    else if (small) CR_LAUNCH(true, CR_CAP_S, 2);
-    else CR_LAUNCH(true, CR_CAP, 4);
+    if (!local_sort) CR_LAUNCH(false, CR_CAP, 4, CR_THREADS);
+    else if (small && half) CR_LAUNCH(true, CR_CAP_H, 4, CR_THREADS_H);
+    else if (small) CR_LAUNCH(true, CR_CAP_S, 2, CR_THREADS);
+    else CR_LAUNCH(true, CR_CAP, 4, CR_THREADS);
 #undef CR_LAUNCH
 }
 
