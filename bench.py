@@ -590,24 +590,38 @@ def cpu_baseline(renderer, width, height, budget_s):
     o.set_styles(t["style_offsets"], t["style_words"], None); o.set_images(t["images"], t["texels"])
     cands = sorted({c for c in (8, 16, 32, 48, 64, 96, 128, hw) if c <= hw} or {hw})
     t_start = time.perf_counter()
-    sweep = {}
+    sweep, per_stage = {}, {}
     for c in cands:
         o.set_threads(c)
         o.time_frame(width, height, 1)                      # first touch of this thread count's buffers / thread pool
-        sweep[c] = sum(o.time_frame(width, height, 1).values())
+        tm = o.time_frame(width, height, 1)
+        sweep[c], per_stage[c] = sum(tm.values()), tm
         if time.perf_counter() - t_start > budget_s * 0.5:
             break
     best = min(sweep, key=sweep.get)
+    # every stage at ITS fastest thread count of the sweep: the radix sort stops scaling where memory bandwidth does, the
+    # painter (135 tile rows, one task each — forma's own granularity: painter/mod.rs:717-778) goes on for a while
+    stage_best = {st: min(per_stage, key=lambda c: per_stage[c][st]) for st in ("prepare", "rasterize", "sort", "paint")}
     o.set_threads(best)
-    per = sweep[best]
+    o.set_stage_threads(**stage_best)
+    o.time_frame(width, height, 1)
+    per = sum(o.time_frame(width, height, 1).values())
+    if per > sweep[best]:                                     # (mixing thread counts lost: stay with the best single count)
+        o.set_stage_threads(0, 0, 0, 0)
+        stage_best = {st: best for st in stage_best}
+        per = sweep[best]
     left = max(1.0, budget_s - (time.perf_counter() - t_start))
     iters = max(3, min(40, int(left / max(per, 1e-3))))
     tm = o.time_frame(width, height, iters)
     per = sum(tm.values())
-    return {"value": round(1.0 / per, 3), "unit": "frames/s", "cores": best, "kind": "port", "host_threads": hw,
-            "sample": f"{iters} full frames of the same workload (C++ restatement of the CPU backend, OpenMP on {best} of {hw} "
-                      f"hardware threads = the fastest of the sweep {sorted(sweep)}, pinned; parallel stable radix sort and prefix sum)",
+    cores = max(stage_best.values())
+    return {"value": round(1.0 / per, 3), "unit": "frames/s", "cores": cores, "kind": "port", "host_threads": hw,
+            "sample": f"{iters} full frames of the same workload (C++ restatement of the CPU backend, OpenMP, pinned; every stage at the "
+                      f"fastest thread count of the sweep {sorted(sweep)}: {stage_best}; parallel stable radix sort and prefix sum; the "
+                      f"painter works a tile row per task like forma's)",
+            "threads_per_stage": stage_best,
             "thread_sweep_ms": {str(k): round(v * 1e3, 1) for k, v in sweep.items()},
+            "thread_sweep_stage_ms": {str(k): {st: round(v * 1e3, 1) for st, v in per_stage[k].items()} for k in per_stage},
             "stages_ms": {k: round(v * 1e3, 2) for k, v in tm.items()}}
 
 

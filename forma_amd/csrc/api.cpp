@@ -56,7 +56,9 @@ int reset_info(forma_hip_ctx* ctx) {              // device-to-device from a tem
 int frame_tail(forma_hip_ctx* ctx, bool to_host_info, uint32_t* host_count) {
     const bool timed = ctx->stage_used[ST_PAINT];         // (a timed frame books the tail on the paint stage)
     stage_begin(ctx, ST_PAINT, timed);
-    launch_frame_tail(ctx->stream, ctx->info.as<FrameInfo>(), to_host_info ? ctx->h_info : nullptr, host_count);
+    launch_frame_tail(ctx->stream, ctx->info.as<FrameInfo>(), to_host_info ? ctx->h_info : nullptr, host_count,
+                      ctx->order_cnt_dev, ctx->order_keep_dev);
+    ctx->order_cnt_dev = nullptr; ctx->order_keep_dev = nullptr;
     stage_end(ctx, ST_PAINT, timed);
     HIPCHECK(hipGetLastError());
     ctx->info_clean = true;
@@ -329,7 +331,8 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     uint32_t* paint_overflow = row_span_cnt + (CR_MAX_SLICES_HOST * tiles_h + 1);   // [0], [1] = the two counts, then the first-run table ...
     uint32_t* over2_n = paint_overflow + 1;
     uint32_t* tile_first_run = paint_overflow + 2;
-    uint32_t* overflow_list = tile_first_run + T;                       // ... then the lists themselves
+    uint32_t* order_cnt = tile_first_run + T;                           // ... the painters' order counts (PaintParams::order_cnt_out) ...
+    uint32_t* overflow_list = order_cnt + PAINT_ORDER_WORDS;            // ... then the lists themselves
     uint32_t* over2_list = overflow_list + T;
     uint32_t J = 0;
     HIPCHECK(ctx->blk_edge.ensure(runs_blocks(std::max<size_t>(n, 1)) * sizeof(BlkEdge)));
@@ -501,6 +504,32 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     // occlusion culling (PaintParams::cull): not with a buffer-layer cache (a tile's layer count is state there), not with clips
     const bool cull = a.cache_id < 0 && !ctx->scene_has_clips && !ctx->dbg.no_cull;
     P.cull = cull ? 1u : 0u;
+    // heaviest tiles first (PaintParams::order_*): read-back-free frames without a cache, one wavefront per tile
+    P.order_cnt_in = nullptr; P.order_list_in = nullptr; P.order_cnt_out = nullptr; P.order_list_out = nullptr;
+    ctx->order_pending = -1; ctx->order_cnt_dev = nullptr; ctx->order_keep_dev = nullptr;
+    const uint32_t tiles_painted = (P.crop_y1 > P.crop_y0 ? P.crop_y1 - P.crop_y0 : 0u) * tiles_w;
+    const bool strips = paint_by_strips(ctx, tiles_painted);
+    P.order_flag_in = nullptr; P.order_flag_out = nullptr; P.order_hcap = 0; P.order_thr = 0;
+    if (ctx->order_off) ctx->order_off--;                 // (a flat scene: the order is retried every 256 frames)
+    if (ctx->order_enable && bound_j && a.cache_id < 0 && !strips && !ctx->dbg.no_order && jc.bound > 0 && tiles_painted && !ctx->order_off) {
+        const size_t per = (tiles_painted + 7) / 8, hcap = (per + 7) / 8;
+        const size_t set_words = PAINT_ORDER_WORDS + 8 * hcap + (8 * per + 3) / 4;      // counts | lists | one flag byte per tile
+        if (ctx->order_buf.cap < 2 * set_words * 4) { HIPCHECK(ctx->order_buf.ensure(2 * set_words * 4)); ctx->order_cur = -1; }
+        const forma_hip_ctx::OrderSig sig{tiles_w, tiles_h, P.crop_x0, P.crop_x1, P.crop_y0, P.crop_y1};
+        uint32_t* base = ctx->order_buf.as<uint32_t>();
+        if (ctx->order_cur >= 0 && !(ctx->order_sig == sig)) ctx->order_cur = -1;
+        const int w = ctx->order_cur == 0 ? 1 : 0;
+        if (ctx->order_cur >= 0) {
+            P.order_cnt_in = base + (size_t)ctx->order_cur * set_words; P.order_list_in = P.order_cnt_in + PAINT_ORDER_WORDS;
+            P.order_flag_in = reinterpret_cast<const uint8_t*>(P.order_list_in + 8 * hcap);
+        }
+        uint32_t* wset = base + (size_t)w * set_words;
+        P.order_cnt_out = order_cnt; P.order_list_out = wset + PAINT_ORDER_WORDS;
+        P.order_flag_out = reinterpret_cast<uint8_t*>(wset + PAINT_ORDER_WORDS + 8 * hcap);
+        P.order_hcap = (uint32_t)hcap; P.order_thr = ctx->order_thr;
+        ctx->order_pending = w; ctx->order_pending_sig = sig; ctx->order_tiles = tiles_painted;
+        ctx->order_cnt_dev = order_cnt; ctx->order_keep_dev = wset;
+    } else ctx->order_cur = -1;                              // (any other frame in between: the lists are stale)
     // the (empty) k_paint_deep launch costs ~5 us of every frame: a read-back-free frame without a cache skips it when the
     // last verified frame had no deep tile; a tile that needs it then voids the frame (re-run in full)
     const bool launch_deep = !(bound_j != 0 && a.cache_id < 0 && ctx->pred_no_deep);
@@ -527,7 +556,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                  ctx->style_off.as<uint32_t>(),
                  ctx->style_words.as<uint32_t>(), ctx->images.as<forma_image_t>(), ctx->texels.as<uint16_t>(),
                  ctx->cur_image, tc, dinfo, paint_overflow, overflow_list, over2_n, over2_list, launch_deep, groups,
-                 paint_by_strips(ctx, (P.crop_y1 > P.crop_y0 ? P.crop_y1 - P.crop_y0 : 0u) * tiles_w));
+                 strips);
     stage_end(ctx, ST_PAINT, timing);
     ctx->last_runs = J; ctx->last_entries = 0;
     HIPCHECK(hipGetLastError());
@@ -735,7 +764,11 @@ int finish_frame(forma_hip_ctx* ctx, forma_timings_t* t, bool have_info = false)
     return FORMA_OK;
 }
 
-void clear_stage_flags(forma_hip_ctx* ctx) { for (int s = 0; s < ST_COUNT; s++) ctx->stage_used[s] = false; ctx->kt.n = 0; g_ktimer = nullptr; }
+void clear_stage_flags(forma_hip_ctx* ctx) {
+    for (int s = 0; s < ST_COUNT; s++) ctx->stage_used[s] = false;
+    ctx->kt.n = 0; g_ktimer = nullptr;
+    ctx->order_cnt_dev = nullptr; ctx->order_keep_dev = nullptr;       // (a frame that never reached its k_frame_tail)
+}
 
 int check_paint_args(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t height, size_t stride,
                      const uint8_t* channels, const float* clear) {
@@ -849,7 +882,7 @@ void forma_hip_destroy(forma_hip_ctx* ctx) {
                      &ctx->blk_edge, &ctx->runs_scratch, &ctx->row_tab, &ctx->span_key, &ctx->span_cov,
                      &ctx->image, &ctx->xsend, &ctx->xrecv, &ctx->xscratch,
                      &ctx->ras_masks, &ctx->xmask, &ctx->huge_offs, &ctx->huge_key, &ctx->huge_tmp, &ctx->huge_flag,
-                     &ctx->grp_tab, &ctx->grp_list, &ctx->run_lt, &ctx->pack_list, &ctx->pack_pix, &ctx->cache_written};
+                     &ctx->grp_tab, &ctx->grp_list, &ctx->run_lt, &ctx->pack_list, &ctx->pack_pix, &ctx->cache_written, &ctx->order_buf};
     for (DevBuf* b : all) b->release();
     for (int s = 0; s < ST_COUNT; s++) { (void)hipEventDestroy(ctx->ev0[s]); (void)hipEventDestroy(ctx->ev1[s]); }
     for (int i = 0; i < ctx->kt.made; i++) { (void)hipEventDestroy(ctx->kt.e0[i]); (void)hipEventDestroy(ctx->kt.e1[i]); }
@@ -1180,7 +1213,10 @@ int enqueue_async_frame(forma_hip_ctx* ctx, const PaintArgs& a, bool timing, uin
     if ((rc = plan_zero_jobs(ctx, a.width, a.height, bN, bN, &Z, &cleared))) return rc;
     if ((rc = run_rasterize_frame(ctx, a.width, a.height, timing, true, bN, &Z, &cleared, /*hist_too=*/true))) return rc;
     if ((rc = run_sort(ctx, ctx->seg_u.as<uint64_t>(), DevCount{&dinfo->n_segments, bN}, timing))) return rc;
-    if ((rc = run_paint(ctx, DevCount{&dinfo->n_segments, bN}, a, timing, bJ))) return rc;
+    ctx->order_enable = true;                             // (this frame ends with k_frame_tail: the painters may leave their order lists)
+    rc = run_paint(ctx, DevCount{&dinfo->n_segments, bN}, a, timing, bJ);
+    ctx->order_enable = false;
+    if (rc) return rc;
     return frame_tail(ctx, true, nullptr);
 }
 
@@ -1196,8 +1232,26 @@ int complete_async_frame(forma_hip_ctx* ctx, const PaintArgs& a, uint8_t* dst, s
         if (ctx->small_tried && ctx->h_info->plan_bad) ctx->small_banned = true;   // (one cause of plan_bad: a slice beyond the small variant)
         if (ctx->plan_biased && ctx->h_info->plan_bad) ban_bias(ctx);              // (another: a key outside the span the digits were planned for)
         ctx->pred_counts_valid = false;                   // the synchronous path re-learns everything
+        ctx->order_cur = -1; ctx->order_pending = -1;
         clear_stage_flags(ctx);
         return FORMA_RETRY;
+    }
+    if (ctx->order_pending >= 0) {
+        ctx->order_cur = ctx->order_pending; ctx->order_sig = ctx->order_pending_sig; ctx->order_pending = -1;
+        // steer the threshold: the heavy section should hold the few percent of the tiles that make the launch's tail
+        const uint32_t nh = ctx->h_info->n_heavy, nt = std::max(ctx->order_tiles, 1u);
+        if (nh * 16u > nt) ctx->order_thr = std::min<uint32_t>(ctx->order_thr + ctx->order_thr / 4u, 1u << 24);        // > 6 %
+        else if (nh * 50u < nt) ctx->order_thr = std::max<uint32_t>(ctx->order_thr - ctx->order_thr / 5u, 1u << 12);     // < 2 %
+        // ... of a scene that HAS a tail: a tile is heavy from twice the average on (sampled: FrameInfo::cost_*)
+        if (ctx->h_info->cost_n) {
+            const uint64_t mean = ((uint64_t)ctx->h_info->cost_sum << 8) / ctx->h_info->cost_n;
+            ctx->order_thr = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(ctx->order_thr, 2 * mean), 1u << 24);
+            // a FLAT scene (the 8K triangle scene: 262 144 tiles of ~21 k clocks, none beyond twice that) has no tail to hide, and
+            // the bookkeeping of the order — a flag byte per tile, the empty heavy section — costs its painter 10 %: three such
+            // frames in a row switch the order off for the next 256
+            if (ctx->order_thr <= 2 * mean && nh * 200u < nt) { if (++ctx->order_flat >= 3) { ctx->order_off = 256; ctx->order_flat = 0; ctx->order_cur = -1; } }
+            else ctx->order_flat = 0;
+        }
     }
     ctx->pred_N = N; ctx->pred_J = J; ctx->pred_max_row = ctx->h_info->max_row_runs;
     if (ctx->bias_banned) ctx->bias_banned--;
@@ -1293,6 +1347,8 @@ void share_scene(forma_hip_ctx* o) {
 }
 void invalidate_counts(forma_hip_ctx* o) {                 // new geometry / band: every slot re-learns N and J synchronously
     o->pred_counts_valid = false; o->xpred_valid = false; o->small_banned = false; o->bias_banned = 0; o->bias_ban_len = 0; o->pred_range.valid = false;
+    o->order_off = 0; o->order_flat = 0; o->order_cur = -1;
+    for (forma_hip_ctx* sl : o->slots) { sl->order_off = 0; sl->order_flat = 0; sl->order_cur = -1; }
     for (forma_hip_ctx* sl : o->slots) { sl->pred_counts_valid = false; sl->xpred_valid = false; sl->small_banned = false; sl->bias_banned = 0; sl->bias_ban_len = 0; sl->pred_range.valid = false; }
 }
 }  // namespace
@@ -1467,7 +1523,9 @@ int forma_hip_trim(forma_hip_ctx* ctx) {
                            &c->scan_tmp, &c->cl_idx, &c->cl_start, &c->block_first, &c->prep_scratch, &c->seg_u, &c->seg_a, &c->seg_b,
                            &c->sort_counters, &c->records, &c->rk_u, &c->rk_a, &c->rk_b, &c->blk_edge, &c->runs_scratch, &c->row_tab,
                            &c->span_key, &c->span_cov, &c->image, &c->xscratch, &c->ras_masks, &c->xmask,
-                           &c->huge_offs, &c->huge_key, &c->huge_tmp, &c->huge_flag, &c->grp_tab, &c->grp_list, &c->run_lt, &c->pack_list, &c->pack_pix};
+                           &c->huge_offs, &c->huge_key, &c->huge_tmp, &c->huge_flag, &c->grp_tab, &c->grp_list, &c->run_lt, &c->pack_list, &c->pack_pix,
+                           &c->order_buf};
+        c->order_cur = -1; c->order_pending = -1; c->order_cnt_dev = nullptr; c->order_keep_dev = nullptr;
         size_t freed = 0;
         for (DevBuf* b : frame) { if (!b->borrowed) freed += b->cap; b->release(); }
         if (ctx->dbg.trim_debug) {

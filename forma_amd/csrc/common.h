@@ -51,6 +51,8 @@ struct FrameInfo {
     uint32_t exchange_overflow;   // multi-GPU exchange: a bucket did not fit the agreed pair capacity (here or at a sender)
     uint32_t max_slice_runs;      // most runs one workgroup of the carry pre-pass sorted in LDS (a slice of a tile row)
     uint32_t tile_range[4];       // of the sorted keys' tile fields, as maxima: ~min(tile_x + 1), max(tile_x + 1), ~min(tile_y + 1), max(tile_y + 1)
+    uint32_t n_heavy;             // tiles the painters filed as heavy this frame (PaintParams::order_*; summed by k_frame_tail)
+    uint32_t cost_sum, cost_n;    // ... and a 1-in-256 sample of what a tile cost: shader clocks >> 8, tiles sampled
 };
 
 // one run of the sorted stream = one painted (tile, layer) pair that owns pixel segments
@@ -84,6 +86,18 @@ struct PaintParams {
     // hides.  What changes is a tile's layer COUNT, which only a buffer-layer cache remembers (CachedTile), and a clip below the
     // occluder may govern layers above it: 0 on cache frames and for scenes with clips.
     uint32_t cull;
+    // Heaviest tiles first (k_paint_wave, one wavefront per tile).  A launch ends with its slowest wavefront, and a tile with
+    // many gradient / blend-mode layers lives three times the average: dispatched last it IS the tail of the launch.  A
+    // wavefront whose tile took >= order_thr shader clocks therefore appends it to its XCD band's HEAVY list and sets the tile's
+    // flag (order_*_out; the eight counts are zeroed with the frame's tile tables and kept by k_frame_tail).  The NEXT frame of
+    // the same canvas and crop puts order_hcap workgroups per band in front of the grid: workgroup k of that section paints
+    // heavy_list[k] (or exits: fewer heavy tiles than that), and the workgroup of a flagged tile in the main section exits.  A
+    // schedule only — every tile is painted by exactly one wavefront either way.  Only the heavy tiles (the host steers the
+    // threshold towards ~4 % of the tiles, but never below twice the average tile: a flat scene has no tail to hide) pay an atomic: one per tile on a handful of addresses serialises in the L2 (measured:
+    // 324 -> 1 570 us on the 8K scene).  order_cnt_out == nullptr: off; order_cnt_in == nullptr: nothing to read yet.
+    const uint32_t* order_cnt_in;  const uint32_t* order_list_in;  const uint8_t* order_flag_in;
+    uint32_t*       order_cnt_out; uint32_t*       order_list_out; uint8_t*       order_flag_out;
+    uint32_t        order_hcap, order_thr;
 };
 
 // The spans of a tile row, a second time, by TILE-COLUMN GROUP: k_carry_rows appends to the row's (layer, tile_x)-ordered span
@@ -302,7 +316,8 @@ uint32_t runs_edge_segments();            // segments per BlkEdge entry
 // The end of a read-back-free frame: the device-side FrameInfo goes to pinned host memory (`host_info`, nullable) and/or its
 // segment count to a pinned word (`host_count`, nullable), and the device copy returns to its pristine state for the next
 // frame of the stream — one tiny kernel instead of a device-to-host copy here and a device-to-device reset there.
-void launch_frame_tail(hipStream_t s, FrameInfo* info, FrameInfo* host_info, uint32_t* host_count);
+void launch_frame_tail(hipStream_t s, FrameInfo* info, FrameInfo* host_info, uint32_t* host_count,
+                       const uint32_t* order_cnt = nullptr, uint32_t* order_keep = nullptr /* PAINT_ORDER_WORDS words copied (PaintParams::order_*) */);
 // Words the frame's FIRST kernel clears on behalf of later stages (sort scratch, tile tables): a few hundred
 // KB spread over a grid that exists anyway, instead of two or three memset operations on the stream.
 #define FORMA_ZERO_JOBS 4
@@ -324,10 +339,12 @@ void launch_pack_written(hipStream_t s, const uint8_t* written, uint32_t tiles_w
 uint32_t carry_rows_local_cap();      // most runs a workgroup of launch_carry_rows(local_sort = true) sorts in LDS: large variant ...
 uint32_t carry_rows_small_cap();      // ... small variant (several workgroups per CU)
 uint32_t carry_rows_half_cap();       // ... its 512-lane form
+#define PAINT_ORDER_WORDS 8u           // heavy-tile counts of the painters' order, one per XCD band (PaintParams::order_*)
 #define CR_MAX_SLICES_HOST 8u         // workgroups that may share one tile row
 // the frame's tile tables, one buffer: [row_count: tiles_h + 1][row_span_lo: 8 tiles_h + 1][row_span_cnt: 8 tiles_h + 1]
-// [painter overflow counters: 2][first-run table: T] — zeroed every frame by launch_runs — then [overflow list: T][{tile, entries}: 2 T]
-static inline uint32_t row_tab_zero_words(uint32_t tiles_w, uint32_t tiles_h) { return (tiles_h + 1) + 2 * (CR_MAX_SLICES_HOST * tiles_h + 1) + 2 + tiles_w * tiles_h; }
+// [painter overflow counters: 2][first-run table: T][painter order counts: PAINT_ORDER_WORDS] — zeroed every frame by launch_runs —
+// then [overflow list: T][{tile, entries}: 2 T]
+static inline uint32_t row_tab_zero_words(uint32_t tiles_w, uint32_t tiles_h) { return (tiles_h + 1) + 2 * (CR_MAX_SLICES_HOST * tiles_h + 1) + 2 + tiles_w * tiles_h + PAINT_ORDER_WORDS; }
 // n_slices workgroups per tile row (each a range of layers, 256 bins of layer >> bin_shift); small: the CR_CAP_S variant
 void launch_carry_rows(hipStream_t s, bool local_sort, bool small, bool half /* with small: 512-lane workgroups, slices of <= 2048 runs */,
                        uint32_t n_slices, uint32_t bin_shift,

@@ -67,6 +67,17 @@ struct forma_hip_ctx {
     bool pred_no_deep = false;              // the last verified frame sent no tile to k_paint_deep
     // carry pre-pass: slices per tile row and the LDS variant (api.cpp run_paint)
     uint32_t cur_slices = 1, pred_slice_n = 0, pred_max_slice = 0, force_slices = 0;
+    // the painters' heaviest-first order (PaintParams::order_*): two sets of {counts, lists}; a read-back-free frame reads the set
+    // the last verified frame of the same canvas / crop wrote and writes the other one
+    DevBuf order_buf;
+    struct OrderSig { uint32_t tiles_w = 0, tiles_h = 0, x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+                      bool operator==(const OrderSig& o) const { return tiles_w == o.tiles_w && tiles_h == o.tiles_h && x0 == o.x0 && x1 == o.x1 && y0 == o.y0 && y1 == o.y1; } };
+    OrderSig order_sig, order_pending_sig;
+    uint32_t order_flat = 0, order_off = 0;       // frames in a row without a tail / frames left with the order switched off
+    uint32_t order_thr = 1u << 16, order_tiles = 0;  // shader clocks that make a tile heavy (steered per frame), tiles of the pending frame
+    int order_cur = -1, order_pending = -1;       // set with valid lists (-1: none) / set this frame's painter writes (-1: none)
+    bool order_enable = false;                    // set by the caller of run_paint for frames that end with k_frame_tail
+    const uint32_t* order_cnt_dev = nullptr; uint32_t* order_keep_dev = nullptr;   // what that k_frame_tail copies
     bool cur_half = false, pred_slice_half = false;   // the 512-lane variant of the small carry kernel (api.cpp run_paint)
     bool cur_small = false, pred_slice_small = false, small_tried = false, small_banned = false, no_small_carry = false;
     DevBuf ras_masks;                       // k_rasterize: key masks per workgroup (8 words), combined by k_reduce_masks

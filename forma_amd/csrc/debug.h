@@ -18,6 +18,7 @@
 //   no_prezero           the frame's first kernel clears nothing for later stages (they use memsets: A/B of the folding)
 //   no_ras_hist          the sort's digit histograms are always taken by k_sort_hist, never by the rasterizer
 //   carry_half=0|1|N     never / by policy / with N slices per row: the 512-lane carry kernel (three workgroups per CU)
+//   no_order             the painters always take their tiles in index order (PaintParams::order_*)
 //   no_cull              the painters never drop the entries below a tile's topmost occluder (PaintParams::cull)
 //   strip_tiles=N        the painter runs four strip wavefronts per tile on frames of <= N painted tiles (0: never)
 //   trim_debug           forma_hip_trim prints what it releases
@@ -31,7 +32,7 @@
 struct ForMaDebug {
     bool sync = false, global_runsort = false, xgather = false, no_small_carry = false, span_groups = false, no_span_groups = false;
     bool no_packed_copy = false, no_simple_paint = false, force_simple_paint = false, trim_debug = false, force_exchange = false;
-    bool xchg_copy = false, no_prezero = false, no_bias = false, no_ras_hist = false, no_cull = false;
+    bool xchg_copy = false, no_prezero = false, no_bias = false, no_ras_hist = false, no_cull = false, no_order = false;
     int carry_slices = 0, digit_bits = 0, poison = -1, poison_frame = -1, strip_tiles = -1, carry_half = 1;
 };
 
@@ -48,7 +49,7 @@ inline ForMaDebug forma_debug_parse() {
         const long v = val ? strtol(val, nullptr, 0) : 0;
 #define FD_FLAG(name) if (!strcmp(tok, #name)) { d.name = true; continue; }
         FD_FLAG(sync) FD_FLAG(global_runsort) FD_FLAG(xgather) FD_FLAG(no_small_carry) FD_FLAG(span_groups) FD_FLAG(no_span_groups)
-        FD_FLAG(no_cull) FD_FLAG(no_prezero) FD_FLAG(no_bias) FD_FLAG(no_ras_hist) FD_FLAG(no_packed_copy) FD_FLAG(no_simple_paint) FD_FLAG(force_simple_paint) FD_FLAG(trim_debug) FD_FLAG(force_exchange)
+        FD_FLAG(no_cull) FD_FLAG(no_order) FD_FLAG(no_prezero) FD_FLAG(no_bias) FD_FLAG(no_ras_hist) FD_FLAG(no_packed_copy) FD_FLAG(no_simple_paint) FD_FLAG(force_simple_paint) FD_FLAG(trim_debug) FD_FLAG(force_exchange)
 #undef FD_FLAG
         if (!strcmp(tok, "xchg")) { d.xchg_copy = val && !strcmp(val, "copy"); continue; }
         if (!strcmp(tok, "carry_slices")) { d.carry_slices = (int)v; continue; }

@@ -2045,12 +2045,47 @@ __global__ __launch_bounds__(64, NPX == 1 ? PAINT_STRIP_OCC : (SIMPLE ? PAINT_SI
     // (strips: the four wavefronts of a tile are consecutive workgroups of ONE XCD — they read the same records and segments)
     const uint32_t kx = NPX == 1 ? (bid >> 5) : (bid >> 3);
     const uint32_t strip = NPX == 1 ? ((bid >> 3) & 3u) : 0u;
-    if (kx >= per) return;
-    const uint32_t tidx = (bid & 7u) * per + kx;
-    if (tidx >= T) return;
+    // which tile of the band: the heavy section in front of the grid takes the previous frame's heavy tiles, the main section
+    // every tile in index order that is not flagged (PaintParams::order_*)
+    const bool ordered = NPX == 4 && P.order_cnt_out != nullptr;
+    const uint32_t hcap = ordered ? P.order_hcap : 0u;
+    if (kx >= per + hcap) return;
+    const uint32_t band0 = (bid & 7u) * per, band_n = band0 < T ? min(per, T - band0) : 0u;
+    uint32_t tin;
+    unsigned long long ord_t0 = 0;
+    if (ordered) {
+        ord_t0 = __builtin_readcyclecounter();
+        if (kx < hcap) {
+            if (!P.order_cnt_in || kx >= min(P.order_cnt_in[bid & 7u], hcap)) return;
+            tin = P.order_list_in[(size_t)(bid & 7u) * hcap + kx];
+            if (tin >= band_n) return;                                  // (never: a list holds tiles of its own band)
+        } else {
+            tin = kx - hcap;
+            if (tin >= band_n) return;
+            if (P.order_cnt_in && P.order_flag_in[band0 + tin]) return; // painted by the heavy section
+        }
+    } else {
+        tin = kx;
+        if (tin >= band_n) return;
+    }
+    // a wavefront that is done with its tile says whether the next frame should start it early
+    auto tile_done = [&]() {
+        if (ordered && (threadIdx.x & 63) == 0) {
+            const unsigned long long dt = __builtin_readcyclecounter() - ord_t0;
+            // (one tile in 256 tells the host what a tile costs on average: the threshold never goes below twice that)
+            if (((band0 + tin) & 255u) == 0u) { atomicAdd(&info->cost_sum, (uint32_t)min(dt >> 8, 0xFFFFull)); atomicAdd(&info->cost_n, 1u); }
+            uint8_t heavy = 0;
+            if (dt >= (unsigned long long)P.order_thr) {
+                const uint32_t pos = atomicAdd(&P.order_cnt_out[bid & 7u], 1u);
+                if (pos < hcap) { P.order_list_out[(size_t)(bid & 7u) * hcap + pos] = tin; heavy = 1; }
+            }
+            P.order_flag_out[band0 + tin] = heavy;
+        }
+    };
+    const uint32_t tidx = band0 + tin;
     const uint32_t tile = tile0 + tidx;
     const uint32_t ty = tile / P.tiles_w, tx = tile - ty * P.tiles_w;
-    if (tx < P.crop_x0 || tx >= P.crop_x1 || ty < P.crop_y0 || ty >= P.crop_y1) return;   // print_row :588-592, :525-529
+    if (tx < P.crop_x0 || tx >= P.crop_x1 || ty < P.crop_y0 || ty >= P.crop_y1) { tile_done(); return; }   // print_row :588-592, :525-529
 
     uint64_t* keys = w_key[wv];
     uint64_t* tmp = w_tmp[wv];
@@ -2155,6 +2190,7 @@ __global__ __launch_bounds__(64, NPX == 1 ? PAINT_STRIP_OCC : (SIMPLE ? PAINT_SI
             atomicOr(&info->error, 16u);                                // (not an error: "this frame has deep tiles", read by the host)
             if (!deep_follows) info->plan_bad = 1u;                     // the host guessed "none" and did not launch k_paint_deep: re-run
         }
+        tile_done();
         return;
     }
     wave_lds_sync();
@@ -2203,6 +2239,7 @@ __global__ __launch_bounds__(64, NPX == 1 ? PAINT_STRIP_OCC : (SIMPLE ? PAINT_SI
         if (had) { layers_were_removed = ne < prev; tile_unchanged = prev == ne && all_unch; }
         if (P.clear_unchanged && tile_unchanged) {                      // TileWriteOp::None: the buffer keeps last frame's pixels
             if (lane == 0) cache.tiles[tile] = make_uint2(ct_tags | (ne << 8), ct_solid);
+            tile_done();
             return;
         }
     }
@@ -2246,6 +2283,7 @@ __global__ __launch_bounds__(64, NPX == 1 ? PAINT_STRIP_OCC : (SIMPLE ? PAINT_SI
         for (uint32_t i = skipped + lane; i < ne; i += 64) if ((flags[i] & EF_MASK) && !((uint32_t)keys[i] & REF_UNCH)) vis = 0;
         if (__all(vis)) {
             if (lane == 0) cache.tiles[tile] = make_uint2(ct_tags | (ne << 8), ct_solid);
+            tile_done();
             return;
         }
     }
@@ -2286,7 +2324,7 @@ __global__ __launch_bounds__(64, NPX == 1 ? PAINT_STRIP_OCC : (SIMPLE ? PAINT_SI
                     cache.tiles[tile] = make_uint2(ct_tags | 1u | (ne << 8), bytes);
                     if (!same) cache.written[tile] = 1;
                 }
-                if (same) return;                                       // same solid colour as last frame: TileWriteOp::None
+                if (same) { tile_done(); return; }                      // same solid colour as last frame: TileWriteOp::None
             }
 #pragma unroll
             for (int q = 0; q < NPX; q++) {
@@ -2294,6 +2332,7 @@ __global__ __launch_bounds__(64, NPX == 1 ? PAINT_STRIP_OCC : (SIMPLE ? PAINT_SI
                 if (px < P.width && py < P.height) ((uint32_t*)image)[(size_t)py * P.stride_px + px] = bytes;
             }
             PP_STAMP(3); PP_COUNT(19, 1);                               // 3: solid fold + store (19: solid tiles)
+            tile_done();
             return;
         }
         PP_STAMP(4);                                                    // 4: fold attempted, failed
@@ -2497,6 +2536,7 @@ __global__ __launch_bounds__(64, NPX == 1 ? PAINT_STRIP_OCC : (SIMPLE ? PAINT_SI
         cache.tiles[tile] = make_uint2((ct_tags & 2u) | (ne << 8), ct_solid);
         cache.written[tile] = 1;
     }
+    tile_done();
 }
 
 #define PAINT_ARGS P, tile, sorted, records, n_runs, tile_first_run, row_span_lo, row_span_cnt, span_key, span_cov, layer_col, \
@@ -2559,7 +2599,7 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
     // strips (four wavefronts per tile, NPX = 1): never with a buffer-layer cache — a tile's cache entry is read by every strip
     // and rewritten by the first one that finishes
     if (cache.tiles) strips = false;
-#define PW_LAUNCH(S_, O_, N_) FORMA_LAUNCH((k_paint_wave<S_, O_, N_>), dim3(per * 8 * (N_ == 1 ? 4 : 1)), dim3(64), 0, s, p, sorted, records, n_runs, \
+#define PW_LAUNCH(S_, O_, N_) FORMA_LAUNCH((k_paint_wave<S_, O_, N_>), dim3(N_ == 1 ? per * 32 : (per + (p.order_cnt_out ? p.order_hcap : 0u)) * 8), dim3(64), 0, s, p, sorted, records, n_runs, \
                                              tile_first_run, row_span_lo, row_span_cnt, span_key, span_cov, layer_col, style_offsets, style_words, \
                                              images, texels, image, cache, info, overflow_n, overflow_list, launch_deep ? 1u : 0u, groups)
 #define PW_LAUNCH_N(S_, O_) do { if (strips) PW_LAUNCH(S_, O_, 1); else PW_LAUNCH(S_, O_, 4); } while (0)
@@ -2641,13 +2681,22 @@ void launch_pack_written(hipStream_t s, const uint8_t* written, uint32_t tiles_w
 // the end of a read-back-free frame (launch_frame_tail, common.h)
 // ================================================================================================
 __global__ __launch_bounds__(64) void k_frame_tail(FrameInfo* __restrict__ info, FrameInfo* __restrict__ host_info,
-                                                   uint32_t* __restrict__ host_count) {
+                                                   uint32_t* __restrict__ host_count, const uint32_t* __restrict__ order_cnt,
+                                                   uint32_t* __restrict__ order_keep) {
     constexpr int W = (int)(sizeof(FrameInfo) / 4);
     static_assert(W <= 64, "FrameInfo fits one wave");
     const int t = threadIdx.x;
     uint32_t* src = reinterpret_cast<uint32_t*>(info);
+    // the painters' list counts live in the frame's tile tables, which the next frame clears: kept where it will look for them
+    uint32_t heavy = 0;
+    if (order_cnt) {
+        heavy = t < (int)PAINT_ORDER_WORDS ? order_cnt[t] : 0u;
+        if (t < (int)PAINT_ORDER_WORDS) order_keep[t] = heavy;
+        heavy += __shfl_xor(heavy, 1, 64); heavy += __shfl_xor(heavy, 2, 64); heavy += __shfl_xor(heavy, 4, 64);
+        heavy = (uint32_t)__shfl(heavy, 0, 64);
+    }
     if (t < W) {
-        const uint32_t v = src[t];
+        const uint32_t v = t == (int)(offsetof(FrameInfo, n_heavy) / 4) ? heavy : src[t];
         // pinned host memory: system-scope stores, visible to the host once the stream has drained
         if (host_info) __hip_atomic_store(reinterpret_cast<uint32_t*>(host_info) + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (host_count && t == (int)(offsetof(FrameInfo, n_segments) / 4)) __hip_atomic_store(host_count, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -2656,7 +2705,8 @@ __global__ __launch_bounds__(64) void k_frame_tail(FrameInfo* __restrict__ info,
         src[t] = ones ? 0xFFFFFFFFu : 0u;
     }
 }
-void launch_frame_tail(hipStream_t s, FrameInfo* info, FrameInfo* host_info, uint32_t* host_count) {
-    FORMA_LAUNCH(k_frame_tail, dim3(1), dim3(64), 0, s, info, host_info, host_count);
+void launch_frame_tail(hipStream_t s, FrameInfo* info, FrameInfo* host_info, uint32_t* host_count, const uint32_t* order_cnt,
+                       uint32_t* order_keep) {
+    FORMA_LAUNCH(k_frame_tail, dim3(1), dim3(64), 0, s, info, host_info, host_count, order_cnt, order_keep);
 }
 

@@ -33,13 +33,11 @@ def random_cubics(n=1000, width=1920, height=1080, seed=42) -> Composition:
     return comp
 
 
-def paris_like(n_layers=30000, width=3840, height=2160, seed=30000) -> Composition:
-    """Labelled STAND-IN for paris-30k.svg: closed polygons of 4-40 vertices (30 % with cubic edges), bbox
-    log-uniform 8-400 px, centres uniform; 90 % solid / 8 % linear / 2 % radial; 5 % non-Over blend;
-    alpha in {1.0, 0.5}."""
+def _paris_like_shapes(n_layers, width, height, seed):
+    """The stand-in's shapes, one dict per layer, in the order (and with exactly the random draws) `paris_like` has always
+    used: the API-built composition and its SVG serialisation are two views of the same sequence."""
     rng = np.random.default_rng(seed)
-    comp = Composition()
-    for i in range(n_layers):
+    for _ in range(n_layers):
         k = int(rng.integers(4, 41))
         size = float(np.exp(rng.uniform(np.log(8.0), np.log(400.0))))
         cx, cy = float(rng.uniform(0, width)), float(rng.uniform(0, height))
@@ -47,33 +45,103 @@ def paris_like(n_layers=30000, width=3840, height=2160, seed=30000) -> Compositi
         rad = size * 0.5 * rng.uniform(0.55, 1.0, k)
         xs = (cx + rad * np.cos(ang)).astype(np.float32); ys = (cy + rad * np.sin(ang)).astype(np.float32)
         curved = rng.random() < 0.3
-        b = PathBuilder().move_to(Point(float(xs[0]), float(ys[0])))
+        cmds = [("M", float(xs[0]), float(ys[0]))]
         for j in range(1, k):
             if curved:
                 dx, dy = float(xs[j] - xs[j - 1]), float(ys[j] - ys[j - 1])
                 nx, ny = -dy * 0.25, dx * 0.25
-                b.cubic_to(Point(float(np.float32(xs[j - 1] + dx * 0.33 + nx)), float(np.float32(ys[j - 1] + dy * 0.33 + ny))),
-                           Point(float(np.float32(xs[j - 1] + dx * 0.66 + nx)), float(np.float32(ys[j - 1] + dy * 0.66 + ny))),
-                           Point(float(xs[j]), float(ys[j])))
+                cmds.append(("C", float(np.float32(xs[j - 1] + dx * 0.33 + nx)), float(np.float32(ys[j - 1] + dy * 0.33 + ny)),
+                             float(np.float32(xs[j - 1] + dx * 0.66 + nx)), float(np.float32(ys[j - 1] + dy * 0.66 + ny)),
+                             float(xs[j]), float(ys[j])))
             else:
-                b.line_to(Point(float(xs[j]), float(ys[j])))
-        path = b.build()
+                cmds.append(("L", float(xs[j]), float(ys[j])))
         col = rng.random(3, dtype=np.float32)
         alpha = 1.0 if rng.random() < 0.5 else 0.5
         blend = BLEND_MODES[int(rng.integers(1, 16))] if rng.random() < 0.05 else "Over"
         u = rng.random()
-        if u < 0.90:
-            fill = Fill.Solid(Color(float(col[0]), float(col[1]), float(col[2]), alpha))
-        else:
-            gb = GradientBuilder(Point(cx - size * 0.5, cy - size * 0.5), Point(cx + size * 0.5, cy + size * 0.25))
-            if u >= 0.98:
-                gb.type(GradientType.Radial)
+        shape = {"cmds": cmds, "color": (float(col[0]), float(col[1]), float(col[2]), alpha), "blend": blend, "gradient": None}
+        if u >= 0.90:
+            stops = []
             for _ in range(int(rng.integers(2, 4))):
                 c2 = rng.random(3, dtype=np.float32)
-                gb.color(Color(float(c2[0]), float(c2[1]), float(c2[2]), alpha))
+                stops.append((float(c2[0]), float(c2[1]), float(c2[2]), alpha))
+            shape["gradient"] = {"start": (cx - size * 0.5, cy - size * 0.5), "end": (cx + size * 0.5, cy + size * 0.25),
+                                 "radial": u >= 0.98, "stops": stops}
+        yield shape
+
+
+def paris_like(n_layers=30000, width=3840, height=2160, seed=30000) -> Composition:
+    """Labelled STAND-IN for paris-30k.svg: closed polygons of 4-40 vertices (30 % with cubic edges), bbox
+    log-uniform 8-400 px, centres uniform; 90 % solid / 8 % linear / 2 % radial; 5 % non-Over blend;
+    alpha in {1.0, 0.5}."""
+    comp = Composition()
+    for i, sh in enumerate(_paris_like_shapes(n_layers, width, height, seed)):
+        b = PathBuilder()
+        for c in sh["cmds"]:
+            if c[0] == "M":
+                b.move_to(Point(c[1], c[2]))
+            elif c[0] == "L":
+                b.line_to(Point(c[1], c[2]))
+            else:
+                b.cubic_to(Point(c[1], c[2]), Point(c[3], c[4]), Point(c[5], c[6]))
+        g = sh["gradient"]
+        if g is None:
+            fill = Fill.Solid(Color(*sh["color"]))
+        else:
+            gb = GradientBuilder(Point(*g["start"]), Point(*g["end"]))
+            if g["radial"]:
+                gb.type(GradientType.Radial)
+            for st in g["stops"]:
+                gb.color(Color(*st))
             fill = Fill.Gradient(gb.build())
-        comp.get_mut_or_insert_default(Order(i)).insert(path).set_props(Props(func=Func.Draw(Style(fill=fill, blend_mode=blend))))
+        comp.get_mut_or_insert_default(Order(i)).insert(b.build()).set_props(Props(func=Func.Draw(Style(fill=fill, blend_mode=sh["blend"]))))
     return comp
+
+
+_CSS_BLEND = {"Over": "normal", "Multiply": "multiply", "Screen": "screen", "Overlay": "overlay", "Darken": "darken", "Lighten": "lighten",
+              "ColorDodge": "color-dodge", "ColorBurn": "color-burn", "HardLight": "hard-light", "SoftLight": "soft-light",
+              "Difference": "difference", "Exclusion": "exclusion", "Hue": "hue", "Saturation": "saturation", "Color": "color",
+              "Luminosity": "luminosity"}
+
+
+def paris_like_svg(n_layers=30000, width=3840, height=2160, seed=30000) -> str:
+    """The stand-in as SVG TEXT — what `paris-30k.svg` is to the reference's demo (demo/src/demos/svg.rs) — for the loader route
+    (`forma_amd.svg.Svg(text, is_text=True).compose(...)`, `bench.py --svg FILE`).  Same geometry to the bit as `paris_like`
+    (every coordinate is written with `repr`, which round-trips a float32 exactly): the two compositions rasterize to the same
+    pixel-segment streams.  Colours cannot round-trip (SVG colours are 8-bit sRGB, the stand-in's are linear floats), so the
+    loaded scene has its own, equally distributed colours; gradients become userSpaceOnUse gradients with evenly spaced stops,
+    blend modes `mix-blend-mode`, alpha `fill-opacity` / `stop-opacity`."""
+    def hexcol(c):
+        v = [max(0, min(255, int(round((x ** (1 / 2.2)) * 255)))) for x in c[:3]]
+        return "#%02x%02x%02x" % tuple(v)
+    out = ['<svg xmlns="http://www.w3.org/2000/svg" width="%d" height="%d" viewBox="0 0 %d %d">' % (width, height, width, height)]
+    for i, sh in enumerate(_paris_like_shapes(n_layers, width, height, seed)):
+        d = []
+        for c in sh["cmds"]:
+            d.append(c[0] + " ".join(repr(v) for v in c[1:]))
+        d.append("Z")
+        attrs = ""
+        g = sh["gradient"]
+        if g is None:
+            attrs = 'fill="%s" fill-opacity="%s"' % (hexcol(sh["color"]), repr(sh["color"][3]))
+        else:
+            n = len(g["stops"])
+            stops = "".join('<stop offset="%s%%" stop-color="%s" stop-opacity="%s"/>' % (repr(100.0 * j / (n - 1)), hexcol(st), repr(st[3]))
+                            for j, st in enumerate(g["stops"]))
+            (x1, y1), (x2, y2) = g["start"], g["end"]
+            if g["radial"]:
+                r = float(np.hypot(x2 - x1, y2 - y1))
+                out.append('<radialGradient id="g%d" gradientUnits="userSpaceOnUse" cx="%s" cy="%s" r="%s">%s</radialGradient>'
+                           % (i, repr(x1), repr(y1), repr(r), stops))
+            else:
+                out.append('<linearGradient id="g%d" gradientUnits="userSpaceOnUse" x1="%s" y1="%s" x2="%s" y2="%s">%s</linearGradient>'
+                           % (i, repr(x1), repr(y1), repr(x2), repr(y2), stops))
+            attrs = 'fill="url(#g%d)"' % i
+        if sh["blend"] != "Over":
+            attrs += ' style="mix-blend-mode: %s"' % _CSS_BLEND[sh["blend"]]
+        out.append('<path d="%s" %s/>' % (" ".join(d), attrs))
+    out.append("</svg>")
+    return "\n".join(out)
 
 
 def circles(count=100, width=1000, height=1000, seed=42) -> Composition:

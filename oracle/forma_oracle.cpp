@@ -972,13 +972,36 @@ struct Painter {                                                       // painte
 
 enum class TileOp { None, Solid, ColorBuffer };
 
+// The reference keeps a tile's layer tables in FxHashMaps (layer_workbench/mod.rs:147-160).  A node-based std::unordered_map
+// allocates on every insert — thousands of mallocs per tile row from every thread, which is what made this port's thread sweep
+// collapse beyond 32 threads (bench.py cpu_baseline).  Same interface over a vector kept sorted by key: a tile's layers arrive in
+// ascending order anyway (the stream is sorted), so an insert is a push_back, a lookup a binary search, and nothing is
+// allocated once a thread's tables are warm.
+template <class V> struct FlatMap {
+    struct E { uint32_t first; V second; };
+    std::vector<E> v;
+    void clear() { v.clear(); }
+    size_t lower(uint32_t k) const { size_t lo = 0, hi = v.size(); while (lo < hi) { size_t m = (lo + hi) / 2; if (v[m].first < k) lo = m + 1; else hi = m; } return lo; }
+    const E* find(uint32_t k) const { size_t i = lower(k); return i < v.size() && v[i].first == k ? &v[i] : nullptr; }
+    size_t count(uint32_t k) const { return find(k) ? 1 : 0; }
+    V& operator[](uint32_t k) {
+        if (v.empty() || v.back().first < k) { v.push_back(E{k, V{}}); return v.back().second; }
+        size_t i = lower(k);
+        if (i == v.size() || v[i].first != k) v.insert(v.begin() + (ptrdiff_t)i, E{k, V{}});
+        return v[i].second;
+    }
+    void insert(uint32_t k) { (void)(*this)[k]; }
+    typename std::vector<E>::const_iterator begin() const { return v.begin(); }
+    typename std::vector<E>::const_iterator end() const { return v.end(); }
+};
 struct Workbench {                                                     // layer_workbench/mod.rs:147-342
     struct Id { uint32_t id; bool mask; };
+    struct Unit {};
     std::vector<Id> ids; size_t skipped = 0;
-    std::unordered_map<uint32_t, std::pair<size_t, size_t>> seg_ranges;   // inclusive
-    std::unordered_map<uint32_t, size_t> queue_idx;
+    FlatMap<std::pair<size_t, size_t>> seg_ranges;                        // inclusive
+    FlatMap<size_t> queue_idx;
     std::vector<CoverCarry> queue, next_queue;
-    std::unordered_set<uint32_t> skip_clipping; bool layers_were_removed = true;
+    FlatMap<Unit> skip_clipping; bool layers_were_removed = true;
 
     void init(std::vector<CoverCarry>&& cc) { queue = std::move(cc); }
     void next_tile() {
@@ -986,7 +1009,7 @@ struct Workbench {                                                     // layer_
         std::swap(queue, next_queue); next_queue.clear();
         skip_clipping.clear(); layers_were_removed = true;
     }
-    const Cover* cover(uint32_t id) const { auto it = queue_idx.find(id); return it == queue_idx.end() ? nullptr : &queue[it->second].cover; }
+    const Cover* cover(uint32_t id) const { auto it = queue_idx.find(id); return !it ? nullptr : &queue[it->second].cover; }
     bool has_segments(uint32_t id) const { return seg_ranges.count(id) != 0; }
     bool layer_is_full(uint32_t id, bool even_odd) const {             // :175-187
         if (has_segments(id)) return false;
@@ -995,7 +1018,7 @@ struct Workbench {                                                     // layer_
     bool cover_carry(const uint64_t* segs, uint32_t id, const PaintCtx& ctx, CoverCarry& out) const {  // :213-234
         Cover acc;
         auto it = seg_ranges.find(id);
-        if (it != seg_ranges.end())
+        if (it)
             for (size_t k = it->second.first; k <= it->second.second; k++) acc.c[seg_ly(segs[k])] = (int8_t)(acc.c[seg_ly(segs[k])] + seg_cover(segs[k]));
         if (const Cover* c = cover(id)) for (int i = 0; i < 16; i++) acc.c[i] = (int8_t)(acc.c[i] + c->c[i]);
         if (acc.is_empty(ctx.get(id).even_odd)) return false;
@@ -1134,7 +1157,7 @@ TileOp drive_tile_painting(Workbench& wb, Painter& painter, const TileCtx& t, co
         if (mask) {
             painter.clear_cells();
             auto it = wb.seg_ranges.find(id);
-            if (it != wb.seg_ranges.end()) for (size_t s = it->second.first; s <= it->second.second; s++) painter.acc_segment(t.segs[s]);
+            if (it) for (size_t s = it->second.first; s <= it->second.second; s++) painter.acc_segment(t.segs[s]);
             if (const Cover* c = wb.cover(id)) painter.acc_cover(*c);
             const Props& p = ctx.get(id);
             bool apply_clip = !p.is_clip && p.is_clipped && !wb.skip_clipping.count(id);
@@ -1252,6 +1275,7 @@ struct Oracle {
     // flatten scratch
     std::vector<float> fx, fy; std::vector<uint8_t> fnc;
     int threads = 1;
+    int stage_threads[4] = {0, 0, 0, 0};   // prepare, rasterize, sort, paint: 0 = `threads` (oracle_time_frame: every stage at its own best count)
     bool passes_off = false;
 
     void decode_styles() {
@@ -1286,6 +1310,11 @@ extern "C" {
 void* oracle_create(void) { return new Oracle(); }
 void  oracle_destroy(void* o) { delete (Oracle*)o; }
 void  oracle_set_threads(void* o, int t) { ((Oracle*)o)->threads = t > 0 ? t : 1; }
+// CPU baseline only: the four stages of oracle_time_frame with a thread count each (0: the frame's).  A stage that stops scaling
+// — the radix sort is bound by memory bandwidth at 16 threads — then does not hold back one that scales further.
+void  oracle_set_stage_threads(void* o_, int prepare, int raster, int sort, int paint) {
+    Oracle* o = (Oracle*)o_; o->stage_threads[0] = prepare; o->stage_threads[1] = raster; o->stage_threads[2] = sort; o->stage_threads[3] = paint;
+}
 void  oracle_set_optimizer(void* o, int enabled) { ((Oracle*)o)->passes_off = !enabled; }     // (test switch: see PaintCtx::passes_off)
 int   oracle_max_threads(void) {
 #ifdef _OPENMP
@@ -1624,14 +1653,20 @@ int oracle_time_frame(void* o_, uint32_t width, uint32_t height, int iters, doub
     uint8_t ch[4] = {0, 1, 2, 3}; Color cc{1, 1, 1, 1};
     for (int i = 0; i < 4; i++) if (ch[i] == 3) ch[i] = 5;
     double tp = 0, tr = 0, ts = 0, tq = 0;
+    auto st = [&](int k) { const int t = o->stage_threads[k] > 0 ? o->stage_threads[k] : o->threads; set_threads(t); return t; };
     for (int it = 0; it < iters; it++) {
+        st(0);
         double t0 = omp_get_wtime();
         prepare_lines(o->x.data(), o->y.data(), o->line_slot.data(), o->x.size(), o->geoms.data(), o->geoms.size(), (float)width, (float)height, o->lines);
         double t1 = omp_get_wtime();
+        st(1);
         rasterize(o->lines, o->unsorted);
         double t2 = omp_get_wtime();
+        const int keep = o->threads; o->threads = st(2);
         o->sort_frame();
+        o->threads = keep;
         double t3 = omp_get_wtime();
+        st(3);
         PaintCtx ctx = o->pctx(false);
         paint(o->sorted.data(), o->sorted.size(), ctx, img.data(), width, height, (size_t)width * 4, ch, cc, Crop{false, 0, 0, 0, 0}, nullptr, nullptr);
         double t4 = omp_get_wtime();
@@ -1708,12 +1743,12 @@ size_t oracle_wb_ids(void* h_, uint32_t* out, size_t cap, int masked_only) {   /
 int oracle_wb_skip_clipping(void* h_, uint32_t id) { return (int)((WbHarness*)h_)->wb.skip_clipping.count(id); }
 int oracle_wb_seg_range(void* h_, uint32_t id, size_t* lo, size_t* hi) {
     WbHarness* h = (WbHarness*)h_; auto it = h->wb.seg_ranges.find(id);
-    if (it == h->wb.seg_ranges.end()) return 0;
+    if (!it) return 0;
     *lo = it->second.first; *hi = it->second.second; return 1;
 }
 int oracle_wb_queue_index(void* h_, uint32_t id) {
     WbHarness* h = (WbHarness*)h_; auto it = h->wb.queue_idx.find(id);
-    return it == h->wb.queue_idx.end() ? -1 : (int)it->second;
+    return !it ? -1 : (int)it->second;
 }
 size_t oracle_wb_queue(void* h_, uint32_t* layers, int8_t* covers, size_t cap) {    // carries handed to the next tile
     WbHarness* h = (WbHarness*)h_; size_t n = h->wb.queue.size();

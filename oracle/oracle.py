@@ -58,6 +58,8 @@ def lib():
         L.oracle_create.restype = vp
         L.oracle_destroy.argtypes = [vp]
         L.oracle_set_threads.argtypes = [vp, i32]
+        L.oracle_set_stage_threads.argtypes = [vp, i32, i32, i32, i32]
+        L.oracle_set_stage_threads.restype = None
         L.oracle_set_optimizer.argtypes = [vp, i32]
         L.oracle_max_threads.restype = i32
         L.oracle_path_new.restype = vp
@@ -281,6 +283,10 @@ class Oracle:
 
     def set_threads(self, t):
         lib().oracle_set_threads(self._h, t)
+
+    def set_stage_threads(self, prepare=0, rasterize=0, sort=0, paint=0):
+        """time_frame only: a thread count per stage (0 = the frame's)"""
+        lib().oracle_set_stage_threads(self._h, int(prepare), int(rasterize), int(sort), int(paint))
 
     # ---- stage 1
     def flatten(self, path: Path):

@@ -320,6 +320,49 @@ def test_paris_like_30k_4k_full_size():
     assert np.array_equal(img, img2)
 
 
+def test_svg_loader_route_at_full_size_matches_the_api_built_stand_in():
+    """SURVEY §8 f1 at BASELINE configs[2] scale: the stand-in serialised as SVG TEXT (30 000 <path>s, linear / radial
+    gradients, mix-blend-mode, fill-opacity — `scenes.paris_like_svg`) goes through the loader (`forma_amd.svg`, after
+    demo/src/demos/svg.rs:337-863,904-920) and the product API.  Geometry round-trips to the bit, so both pixel-segment
+    streams must equal the API-built stand-in's; the loaded scene's image (its colours went through 8-bit sRGB) is checked
+    against the oracle on the loaded scene's own tables; a read-back-free second frame repeats the first."""
+    import time
+    from forma_amd import api, scenes, svg
+    _, W, H = scenes.WORKLOADS["paris-like-30k-4k"]
+    text = scenes.paris_like_svg()
+    t0 = time.perf_counter()
+    loaded = svg.Svg(text, 1.0, is_text=True)
+    comp = loaded.compose(api.Composition())
+    load_s = time.perf_counter() - t0
+    assert len(comp) == 30000 and load_s < 60.0
+    kinds = {}
+    for _, layer in comp.layers_iter():
+        st = layer.props().func[1]
+        kinds[(st.fill[0], st.blend_mode != "Over")] = kinds.get((st.fill[0], st.blend_mode != "Over"), 0) + 1
+    assert kinds.get(("gradient", False), 0) > 2000 and sum(v for (k, b), v in kinds.items() if b) > 1000
+    lay = api.LinearLayout(W, W * 4, H)
+    r = api.Renderer(0)
+    img = np.zeros(W * H * 4, np.uint8)
+    r.render(comp, api.BufferBuilder(img, lay).build(), api.RGBA, api.Color(1, 1, 1, 1), None, timings=True)
+    n = r.last_timings["n_segments"]
+    u_svg, s_svg = r._ctx.segments(0), r._ctx.segments(1)
+    o = orc.Oracle()
+    S.load(o, r.host_tables)
+    want = o.render(W, H, clear=(1.0, 1.0, 1.0, 1.0))
+    d = np.abs(want.astype(np.int16) - img.reshape(want.shape).astype(np.int16))
+    assert d.max() <= 1, (int(d.max()), int((d > 0).sum()))
+    img2 = np.zeros(W * H * 4, np.uint8)
+    r.render(comp, api.BufferBuilder(img2, lay).build(), api.RGBA, api.Color(1, 1, 1, 1), None)
+    assert np.array_equal(img, img2)
+    del o, want
+    r2 = api.Renderer(0)                                       # the API-built stand-in: same geometry, so the same streams
+    r2.render(scenes.paris_like(), api.BufferBuilder(np.zeros(W * H * 4, np.uint8), lay).build(), api.RGBA, api.Color(1, 1, 1, 1), None,
+              timings=True)
+    assert r2.last_timings["n_segments"] == n > 13_000_000
+    assert np.array_equal(u_svg, r2._ctx.segments(0))
+    assert np.array_equal(s_svg, r2._ctx.segments(1))
+
+
 def test_circles_demo_scene_matches_oracle():
     """The reference demo's `circles` mode (demo/src/demos/circles.rs) through the product API: 3 000 translucent discs
     on 1000 x 1000 — tiles ~20 layers deep, nothing opaque, so every layer is blended."""
