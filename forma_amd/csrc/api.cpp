@@ -511,8 +511,12 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     const bool strips = paint_by_strips(ctx, tiles_painted);
     P.order_flag_in = nullptr; P.order_flag_out = nullptr; P.order_hcap = 0; P.order_thr = 0;
     if (ctx->order_off) ctx->order_off--;                 // (a flat scene: the order is retried every 256 frames)
-    if (ctx->order_enable && bound_j && a.cache_id < 0 && !strips && !ctx->dbg.no_order && jc.bound > 0 && tiles_painted && !ctx->order_off) {
-        const size_t per = (tiles_painted + 7) / 8, hcap = (per + 7) / 8;
+    // ... of launches that are a handful of rounds of wavefronts: one tile's life is then a good part of the launch's.  A frame
+    // of 32 rounds (the 8K scene: 262 144 tiles on 8 192 wave slots) has no tail worth 10 % of bookkeeping.
+    if (ctx->order_enable && bound_j && a.cache_id < 0 && !strips && !ctx->dbg.no_order && jc.bound > 0 && tiles_painted && !ctx->order_off &&
+        tiles_painted <= 16u * PAINT_STRIP_TILES) {
+        // (heavy section: an eighth of the band's tiles, as PAINT_ORDER_SUBS lists of equal capacity)
+        const size_t per = (tiles_painted + 7) / 8, hcap = std::max<size_t>((per / 8 + PAINT_ORDER_SUBS - 1) / PAINT_ORDER_SUBS, 2) * PAINT_ORDER_SUBS;
         const size_t set_words = PAINT_ORDER_WORDS + 8 * hcap + (8 * per + 3) / 4;      // counts | lists | one flag byte per tile
         if (ctx->order_buf.cap < 2 * set_words * 4) { HIPCHECK(ctx->order_buf.ensure(2 * set_words * 4)); ctx->order_cur = -1; }
         const forma_hip_ctx::OrderSig sig{tiles_w, tiles_h, P.crop_x0, P.crop_x1, P.crop_y0, P.crop_y1};
@@ -1249,7 +1253,7 @@ int complete_async_frame(forma_hip_ctx* ctx, const PaintArgs& a, uint8_t* dst, s
             // a FLAT scene (the 8K triangle scene: 262 144 tiles of ~21 k clocks, none beyond twice that) has no tail to hide, and
             // the bookkeeping of the order — a flag byte per tile, the empty heavy section — costs its painter 10 %: three such
             // frames in a row switch the order off for the next 256
-            if (ctx->order_thr <= 2 * mean && nh * 200u < nt) { if (++ctx->order_flat >= 3) { ctx->order_off = 256; ctx->order_flat = 0; ctx->order_cur = -1; } }
+            if (ctx->order_thr <= 2 * mean && nh * 100u < nt) { if (++ctx->order_flat >= 3) { ctx->order_off = 256; ctx->order_flat = 0; ctx->order_cur = -1; } }
             else ctx->order_flat = 0;
         }
     }

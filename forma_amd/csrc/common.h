@@ -91,7 +91,8 @@ struct PaintParams {
     // wavefront whose tile took >= order_thr shader clocks therefore appends it to its XCD band's HEAVY list and sets the tile's
     // flag (order_*_out; the eight counts are zeroed with the frame's tile tables and kept by k_frame_tail).  The NEXT frame of
     // the same canvas and crop puts order_hcap workgroups per band in front of the grid: workgroup k of that section paints
-    // heavy_list[k] (or exits: fewer heavy tiles than that), and the workgroup of a flagged tile in the main section exits.  A
+    // entry k / PAINT_ORDER_SUBS of the band's list k % PAINT_ORDER_SUBS (or exits: the list is shorter), and the workgroup of
+    // a flagged tile in the main section exits.  A
     // schedule only — every tile is painted by exactly one wavefront either way.  Only the heavy tiles (the host steers the
     // threshold towards ~4 % of the tiles, but never below twice the average tile: a flat scene has no tail to hide) pay an atomic: one per tile on a handful of addresses serialises in the L2 (measured:
     // 324 -> 1 570 us on the 8K scene).  order_cnt_out == nullptr: off; order_cnt_in == nullptr: nothing to read yet.
@@ -339,7 +340,8 @@ void launch_pack_written(hipStream_t s, const uint8_t* written, uint32_t tiles_w
 uint32_t carry_rows_local_cap();      // most runs a workgroup of launch_carry_rows(local_sort = true) sorts in LDS: large variant ...
 uint32_t carry_rows_small_cap();      // ... small variant (several workgroups per CU)
 uint32_t carry_rows_half_cap();       // ... its 512-lane form
-#define PAINT_ORDER_WORDS 8u           // heavy-tile counts of the painters' order, one per XCD band (PaintParams::order_*)
+#define PAINT_ORDER_SUBS  64u          // heavy lists per XCD band of the painters' order (PaintParams::order_*): appends spread over
+#define PAINT_ORDER_WORDS (8u * PAINT_ORDER_SUBS)   // 512 counters — one address takes ~150 ns per returning atomic, one after the other
 #define CR_MAX_SLICES_HOST 8u         // workgroups that may share one tile row
 // the frame's tile tables, one buffer: [row_count: tiles_h + 1][row_span_lo: 8 tiles_h + 1][row_span_cnt: 8 tiles_h + 1]
 // [painter overflow counters: 2][first-run table: T][painter order counts: PAINT_ORDER_WORDS] — zeroed every frame by launch_runs —

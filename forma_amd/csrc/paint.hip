@@ -2055,9 +2055,10 @@ __global__ __launch_bounds__(64, NPX == 1 ? PAINT_STRIP_OCC : (SIMPLE ? PAINT_SI
     unsigned long long ord_t0 = 0;
     if (ordered) {
         ord_t0 = __builtin_readcyclecounter();
-        if (kx < hcap) {
-            if (!P.order_cnt_in || kx >= min(P.order_cnt_in[bid & 7u], hcap)) return;
-            tin = P.order_list_in[(size_t)(bid & 7u) * hcap + kx];
+        if (kx < hcap) {                                                // list kx % SUBS of the band, entry kx / SUBS (hcap = SUBS x list capacity)
+            const uint32_t sub = kx % PAINT_ORDER_SUBS, idx = kx / PAINT_ORDER_SUBS, cap = hcap / PAINT_ORDER_SUBS;
+            if (!P.order_cnt_in || idx >= min(P.order_cnt_in[(bid & 7u) * PAINT_ORDER_SUBS + sub], cap)) return;
+            tin = P.order_list_in[((size_t)(bid & 7u) * PAINT_ORDER_SUBS + sub) * cap + idx];
             if (tin >= band_n) return;                                  // (never: a list holds tiles of its own band)
         } else {
             tin = kx - hcap;
@@ -2076,8 +2077,9 @@ __global__ __launch_bounds__(64, NPX == 1 ? PAINT_STRIP_OCC : (SIMPLE ? PAINT_SI
             if (((band0 + tin) & 255u) == 0u) { atomicAdd(&info->cost_sum, (uint32_t)min(dt >> 8, 0xFFFFull)); atomicAdd(&info->cost_n, 1u); }
             uint8_t heavy = 0;
             if (dt >= (unsigned long long)P.order_thr) {
-                const uint32_t pos = atomicAdd(&P.order_cnt_out[bid & 7u], 1u);
-                if (pos < hcap) { P.order_list_out[(size_t)(bid & 7u) * hcap + pos] = tin; heavy = 1; }
+                const uint32_t slot = (bid & 7u) * PAINT_ORDER_SUBS + (tin % PAINT_ORDER_SUBS), cap = hcap / PAINT_ORDER_SUBS;
+                const uint32_t pos = atomicAdd(&P.order_cnt_out[slot], 1u);
+                if (pos < cap) { P.order_list_out[(size_t)slot * cap + pos] = tin; heavy = 1; }
             }
             P.order_flag_out[band0 + tin] = heavy;
         }
@@ -2690,10 +2692,9 @@ __global__ __launch_bounds__(64) void k_frame_tail(FrameInfo* __restrict__ info,
     // the painters' list counts live in the frame's tile tables, which the next frame clears: kept where it will look for them
     uint32_t heavy = 0;
     if (order_cnt) {
-        heavy = t < (int)PAINT_ORDER_WORDS ? order_cnt[t] : 0u;
-        if (t < (int)PAINT_ORDER_WORDS) order_keep[t] = heavy;
-        heavy += __shfl_xor(heavy, 1, 64); heavy += __shfl_xor(heavy, 2, 64); heavy += __shfl_xor(heavy, 4, 64);
-        heavy = (uint32_t)__shfl(heavy, 0, 64);
+        for (int i = t; i < (int)PAINT_ORDER_WORDS; i += 64) { const uint32_t c = order_cnt[i]; order_keep[i] = c; heavy += c; }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) heavy += __shfl_xor(heavy, d, 64);
     }
     if (t < W) {
         const uint32_t v = t == (int)(offsetof(FrameInfo, n_heavy) / 4) ? heavy : src[t];

@@ -77,14 +77,21 @@ def main():
             crop = (0, W, band[0] * 16, min(band[1] * 16, H))
         for _ in range(4):
             c.render(W, H, clear=(1, 1, 1, 1), crop=crop, device_only=True)
-        acc = {}
+        acc, kacc = {}, {}
         for _ in range(30):
             _, tm = c.render(W, H, clear=(1, 1, 1, 1), crop=crop, device_only=True, timings=True)
             for k, v in tm.items():
                 acc.setdefault(k, []).append(v)
+            per = {}
+            for name, _st, _t0, us in c.kernel_times():       # every kernel's own launch events (forma_hip_kernel_times)
+                per[name] = per.get(name, 0.0) + us
+            for k, v in per.items():
+                kacc.setdefault(k, []).append(v)
         st = {k[:-3]: round(statistics.median(acc[k]), 1) for k in ("prepare_us", "rasterize_us", "sort_us", "carry_us", "paint_us", "total_us")}
         row = {"what": what, "rows": list(band) if band else [0, tiles_h], "n_segments": int(statistics.median(acc["n_segments"])),
-               "stages_us_one_in_flight": st, "us_per_frame": {}}
+               "stages_us_one_in_flight": st, "kernels_us_one_in_flight": {k: round(statistics.median(v), 1) for k, v in kacc.items()},
+               "us_per_frame": {}}
+        row["gaps_us_one_in_flight"] = round(st["total"] - sum(row["kernels_us_one_in_flight"].values()), 1)
         for s in (int(v) for v in a.slots.split(",")):
             row["us_per_frame"]["F=%d" % s] = round(run(c, W, H, crop, a.frames, s), 1)
         out["runs"].append(row)
