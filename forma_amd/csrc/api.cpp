@@ -190,6 +190,17 @@ static bool paint_by_strips(const forma_hip_ctx* ctx, uint32_t tiles_painted) {
     return tiles_painted <= limit;
 }
 
+// Quad painters (k_paint_quad: four tiles per wavefront) for all-solid scenes whose tiles are shallow AND many: the list work of
+// a tile with a handful of entries is done by a 16-lane group, but a wavefront then paints its four tiles' pixels one after the
+// other — a gain where the launch is many rounds of wavefronts (the 8K scene, 262 144 tiles: paint 329 -> 287 us, +13 % frames/s
+// pipelined), a loss where it is one or two (a 64-row band of that scene: 56 -> 72 us; 1080p: 23 -> 40 us).  Shallow = few runs
+// per tile (a tile with more than 16 entries after culling goes to k_paint_deep).  FORMA_HIP_DEBUG=paint_quad=0|2: never / always.
+static bool paint_by_quads(const forma_hip_ctx* ctx, int cache_id, uint32_t runs_bound, uint32_t tiles) {
+    if (!ctx->scene_simple || ctx->dbg.no_simple_paint || cache_id >= 0 || ctx->dbg.paint_quad == 0) return false;
+    if (ctx->dbg.paint_quad == 2) return true;
+    return tiles >= 16u * 8192u && (uint64_t)runs_bound <= 8ull * tiles;     // (>= 4 rounds of quads on the chip's 8 192 wave slots)
+}
+
 // A biased plan met a void frame.  plan_bad has other causes too (a slice beyond the small carry variant, a count over its
 // bound), so this is a suspicion, not a proof: plain digits for a while, then the cheaper plan is tried again; every repeat
 // doubles the ban (64 .. 4096 frames), new geometry lifts it (invalidate_counts).
@@ -560,7 +571,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                  ctx->style_off.as<uint32_t>(),
                  ctx->style_words.as<uint32_t>(), ctx->images.as<forma_image_t>(), ctx->texels.as<uint16_t>(),
                  ctx->cur_image, tc, dinfo, paint_overflow, overflow_list, over2_n, over2_list, launch_deep, groups,
-                 strips);
+                 strips, paint_by_quads(ctx, a.cache_id, jc.bound, T));
     stage_end(ctx, ST_PAINT, timing);
     ctx->last_runs = J; ctx->last_entries = 0;
     HIPCHECK(hipGetLastError());

@@ -374,7 +374,8 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
                   bool launch_deep /* false: k_paint_deep is not launched; a tile that needs it voids the frame (plan_bad) */,
                   SpanGroups groups /* tab == nullptr: the painters scan the row lists (p.n_groups is ignored) */,
                   bool strips = false /* four wavefronts per tile, each a 16 x 4 strip (k_paint_wave<.., NPX = 1>): frames that do not
-                                         fill the chip with one wavefront per tile; ignored with a buffer-layer cache */);
+                                         fill the chip with one wavefront per tile; ignored with a buffer-layer cache */,
+                  bool quads = false /* four tiles per wavefront (k_paint_quad): all-solid scenes with shallow tiles; ignored otherwise */);
 // tiles whose layer list exceeds the painter's LDS lists (info->error bit 3 after launch_paint): lists in global memory,
 // offs[i] = first entry slot of tile over2_list[2 i]; g_key holds 4 entries per slot, g_tmp / g_flag one
 void launch_paint_huge(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, DevCount n_runs,

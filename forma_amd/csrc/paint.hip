@@ -2541,6 +2541,278 @@ __global__ __launch_bounds__(64, NPX == 1 ? PAINT_STRIP_OCC : (SIMPLE ? PAINT_SI
     tile_done();
 }
 
+// ================================================================================================
+// The QUAD painter: ONE wavefront paints FOUR neighbouring tiles of a row, for scenes whose layers are all solid / Over /
+// unclipped (SIMPLE) and whose tiles are shallow — the 8192 x 8192 triangle scene: 262 144 tiles of 2.7 entries and 40
+// segments, where k_paint_wave spends 70 % of a tile's 21 k clocks on the dependent round trips and LDS phases that build a
+// three-entry list with three of its 64 lanes.  Here the 16-lane group g builds tile g's list — tile table, record probe,
+// span scan, merge, optimizer pass, solid fold: the same steps, four tiles wide, lists of <= 16 entries held one per lane —
+// and only the pixel work (segments -> coverage -> blend -> sRGB) runs tile after tile with all 64 lanes, exactly as in
+// k_paint_wave<SIMPLE>.  A tile with more than 16 entries goes to k_paint_deep like a list beyond WMAX does.
+// No buffer-layer cache (the host keeps k_paint_wave for cache frames), no clips (SIMPLE).
+// ================================================================================================
+#define QE 16             // entries per tile = lanes per group
+template <bool ONE_SLICE>
+__global__ __launch_bounds__(64, PAINT_SIMPLE_OCC) void k_paint_quad(PaintParams P, const uint64_t* __restrict__ sorted,
+                                                                    const TileRecord* __restrict__ records, DevCount nc_runs,
+                                                                    const uint32_t* __restrict__ tile_first_run,
+                                                                    const uint32_t* __restrict__ row_span_lo,
+                                                                    const uint32_t* __restrict__ row_span_cnt,
+                                                                    const uint64_t* __restrict__ span_key,
+                                                                    const uint4* __restrict__ span_cov, const uint4* __restrict__ layer_col,
+                                                                    uint8_t* __restrict__ image, FrameInfo* __restrict__ info,
+                                                                    uint32_t* __restrict__ overflow_n,
+                                                                    uint32_t* __restrict__ overflow_list, uint32_t deep_follows,
+                                                                    SpanGroups groups) {
+    __shared__ int q_cells[2][256];
+    __shared__ uint32_t q_hi[2][4][QE], q_lo[2][4][QE];                 // [0]: arrival order (runs, then spans); [1]: by layer
+    const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
+    const uint32_t plan_bad = info->plan_bad;
+    const uint32_t n_runs = dev_count(nc_runs);
+    // a quad = four consecutive tiles of one row (always inside one tile-column group: 4 divides SPAN_GROUP_TILES); XCD-aware
+    // like k_paint_wave: workgroup b runs on XCD b % 8, every XCD a contiguous band of quads
+    const uint32_t qw = (P.tiles_w + 3u) / 4u, Q = (P.crop_y1 - P.crop_y0) * qw, per = (Q + 7u) / 8u;
+    const uint32_t bid = blockIdx.x;
+    if ((bid >> 3) >= per) return;
+    const uint32_t qidx = (bid & 7u) * per + (bid >> 3);
+    if (qidx >= Q) return;
+    const uint32_t ty = P.crop_y0 + qidx / qw, qx = qidx % qw;
+    const uint32_t tx = qx * 4u + (uint32_t)g;                          // this group's tile
+    const bool t_in = tx < P.tiles_w && tx >= P.crop_x0 && tx < P.crop_x1;   // (a tile outside the canvas / the crop: its group idles)
+    const uint32_t tile = ty * P.tiles_w + min(tx, P.tiles_w - 1u);
+    const uint32_t my_tile_key = ((ty + 1u) << 12) | (tx + 1u);
+    const uint32_t j0 = t_in ? tile_first_run[tile] - 1u : FORMA_NONE;  // 0 stored = no run -> FORMA_NONE
+    constexpr int NS = ONE_SLICE ? 1 : CR_MAX_SLICES;
+    SpanListsT<NS> SL = load_span_lists_t<NS>(row_span_lo, row_span_cnt, ty, P.n_slices);
+    bool by_group = groups.tab != nullptr;
+    if (by_group) {
+        const SpanListsT<NS> GL = load_group_lists<NS>(groups.tab + (size_t)ty * P.n_slices * P.n_groups + ((qx * 4u) >> SPAN_GROUP_SHIFT), P.n_groups, P.n_slices);
+        if (GL.total == SPAN_GROUP_NONE) by_group = false;
+        else SL = GL;
+    }
+    const uint32_t sc = SL.total;
+    if (plan_bad) return;
+    auto fetch = [&](uint32_t i, uint32_t& h, uint32_t& l, uint32_t& x) {          // candidate span i of the row / group list
+        h = 0; l = 0; x = 0;
+        if (i < sc) {
+            const uint32_t ph = span_phys(SL, i);
+            if (by_group) { const uint4 e = groups.list[ph]; h = e.x; l = e.y; x = e.z; }
+            else { const uint64_t k = span_key[ph]; h = (uint32_t)(k >> 32); x = (uint32_t)k; l = REF_SPAN | ((x >> 31) ? REF_UNCH : 0u) | ph; }
+        }
+    };
+    auto covers = [&](uint32_t x, uint32_t t) { const uint32_t lo = (x >> 16) & 0x7FFFu, hi = x & 0xFFFFu; return t >= lo && t < hi; };
+    // the first 64 candidate spans and the first 16 records of every tile: all loads in flight together
+    uint32_t eh, el, ex;
+    fetch((uint32_t)lane, eh, el, ex);
+    uint32_t r_tile = 0, r_layer = 0;
+    if (j0 != FORMA_NONE && j0 + (uint32_t)li < n_runs) { const TileRecord* r = &records[j0 + (uint32_t)li]; r_tile = r->tile; r_layer = r->layer; }
+    // ---- occluders (PaintParams::cull): per tile, the topmost span that crosses it with a full opaque cover ----------------
+    uint32_t occ = 0;                                                   // (the same in the 16 lanes of a group)
+    if (P.cull) {
+        for (uint32_t c = 0; c < sc; c += 64) {
+            if (c) fetch(c + (uint32_t)lane, eh, el, ex);
+            const bool oc = span_is_occluder(eh);
+#pragma unroll
+            for (int t = 0; t < 4; t++) {                               // (lists ascend in layer: the last one found is the topmost)
+                const uint64_t ob = __ballot(oc && covers(ex, qx * 4u + (uint32_t)t));
+                if (ob) { const uint32_t o = ((uint32_t)__builtin_amdgcn_readlane((int)eh, 63 - __builtin_clzll(ob)) & LAYER_MASK) + 1u; if (g == t) occ = o; }
+            }
+        }
+        if (sc > 64u) fetch((uint32_t)lane, eh, el, ex);
+    }
+    // ---- the tiles' own runs: 16 records per round and group, the kept ones (ascending layer: a suffix) to q_*[0][g] -------
+    uint32_t ne = 0;                                                    // entries of this group's tile so far
+    bool over = false;                                                  // more than QE entries: k_paint_deep paints the tile
+    for (uint32_t c = 0;; c += QE) {
+        if (c) {
+            r_tile = 0; r_layer = 0;
+            if (j0 != FORMA_NONE && j0 + c + (uint32_t)li < n_runs) { const TileRecord* r = &records[j0 + c + (uint32_t)li]; r_tile = r->tile; r_layer = r->layer; }
+        }
+        const bool mine = j0 != FORMA_NONE && (r_tile & 0x7FFFFFFFu) == my_tile_key;
+        const bool keep = mine && (r_layer & LAYER_MASK) + 1u >= occ;
+        const uint64_t mb = __ballot(mine), kb = __ballot(keep);
+        const uint32_t gk = (uint32_t)(kb >> (16 * g)) & 0xFFFFu, gm = (uint32_t)(mb >> (16 * g)) & 0xFFFFu;
+        if (keep) {
+            const uint32_t pos = ne + (uint32_t)__popc(gk & ((1u << li) - 1u));
+            if (pos < QE) { q_hi[0][g][pos] = r_layer; q_lo[0][g][pos] = ((r_tile >> 31) ? REF_UNCH : 0u) | (j0 + c + (uint32_t)li); }
+        }
+        ne += (uint32_t)__popc(gk);
+        // another round while some tile's 16 probes were all its own
+        if (!__any(gm == 0xFFFFu)) break;
+        if (gm != 0xFFFFu) { /* this group is done: its later probes are not `mine` (j0 + c runs past the tile's runs) */ }
+    }
+    // ---- spans that cross the tiles -----------------------------------------------------------------------------------------
+    for (uint32_t c = 0; c < sc; c += 64) {
+        if (c) fetch(c + (uint32_t)lane, eh, el, ex);
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const uint32_t occ_t = (uint32_t)__builtin_amdgcn_readlane((int)occ, 16 * t);
+            const uint32_t ne_t = (uint32_t)__builtin_amdgcn_readlane((int)ne, 16 * t);
+            const bool hit = covers(ex, qx * 4u + (uint32_t)t) && (eh & LAYER_MASK) + 1u >= occ_t;
+            const uint64_t hb = __ballot(hit);
+            if (hit) {
+                const uint32_t pos = ne_t + __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0u));
+                if (pos < QE) { q_hi[0][t][pos] = eh; q_lo[0][t][pos] = el; }
+            }
+            if (g == t) ne += (uint32_t)__popcll(hb);
+        }
+    }
+    if (!t_in) ne = 0;
+    if (ne > QE) {
+        over = true;
+        if (li == 0) {
+            overflow_list[atomicAdd(overflow_n, 1u)] = tile;
+            atomicOr(&info->error, 16u);
+            if (!deep_follows) info->plan_bad = 1u;
+        }
+        ne = 0;
+    }
+    wave_lds_sync();
+    // ---- merge by layer: lane li holds entry li of its tile; rank = entries of the tile with a smaller layer (layers are unique) ---
+    const bool have = (uint32_t)li < ne;
+    uint32_t a_hi = have ? q_hi[0][g][li] : 0u, a_lo = have ? q_lo[0][g][li] : 0u;
+    {
+        const uint32_t ne_max = wave_max_u32(ne);
+        uint32_t rank = 0;
+        const uint32_t myl = a_hi & LAYER_MASK;
+        for (uint32_t j = 0; j < ne_max; j++) if (j < ne && (q_hi[0][g][j] & LAYER_MASK) < myl) rank++;
+        if (have) { q_hi[1][g][rank] = a_hi; q_lo[1][g][rank] = a_lo; }
+    }
+    wave_lds_sync();
+    a_hi = have ? q_hi[1][g][li] : 0u; a_lo = have ? q_lo[1][g][li] : 0u;   // entry li of the tile's layer list
+    // ---- skip_fully_covered_layers_pass (SIMPLE: every layer is a solid colour, Over, unclipped) ------------------------------
+    const uint32_t sfl = a_hi >> 21;
+    const bool is_span = (a_lo & 0x80000000u) != 0u;
+    const bool full = have && is_span && (sfl & SF_FULL);
+    const uint64_t topb = __ballot(full && (sfl & SF_OPAQUE)), blkb = __ballot(have && !full);
+    const uint32_t gt = (uint32_t)(topb >> (16 * g)) & 0xFFFFu, gb = (uint32_t)(blkb >> (16 * g)) & 0xFFFFu;
+    const uint32_t top = gt ? 32u - (uint32_t)__builtin_clz(gt) : 0u, blk = gb ? 32u - (uint32_t)__builtin_clz(gb) : 0u;   // index + 1
+    const uint32_t skipped = top ? top - 1u : 0u;
+    const int first = top ? (blk > top ? 2 : 1) : (blk ? 2 : 0);
+    // what the fold and the layer loop need of the entries from `skipped` up: requested by the entry's own lane, once
+    const bool used = have && (uint32_t)li >= skipped;
+    const uint32_t layer = a_hi & LAYER_MASK;
+    uint4 pcol = make_uint4(0u, 0u, 0u, 0u), pcov = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t pseg0 = 0, pnseg = 0;
+    if (used) {
+        pcol = layer_col[layer];
+        if (first == 2) {
+            if (is_span) pcov = span_cov[a_lo & REF_IDX];
+            else { const TileRecord* r = &records[a_lo & REF_IDX]; pcov = make_uint4(r->cover[0], r->cover[1], r->cover[2], r->cover[3]); pseg0 = r->seg_start; pnseg = r->seg_count; }
+        }
+    }
+    const Col clear = {P.clear[0], P.clear[1], P.clear[2], P.clear[3]};
+    // ---- fold (first != 2): every layer from `skipped` up is a full cover -> the tile is one colour.  The four tiles fold side by
+    //      side: step k blends entry skipped + k of every tile (its lane's colour, fetched through the group) ------------------------
+    {
+        Col dst = clear;
+        const uint32_t steps = wave_max_u32((first != 2 && t_in && !over) ? ne - skipped : 0u);
+        for (uint32_t k = 0; k < steps; k++) {
+            const int src_lane = 16 * g + (int)min(skipped + k, (uint32_t)QE - 1u);
+            const Col src = {__uint_as_float((uint32_t)__shfl((int)pcol.x, src_lane, 64)), __uint_as_float((uint32_t)__shfl((int)pcol.y, src_lane, 64)),
+                             __uint_as_float((uint32_t)__shfl((int)pcol.z, src_lane, 64)), __uint_as_float((uint32_t)__shfl((int)pcol.w, src_lane, 64))};
+            if (first != 2 && skipped + k < ne) {
+                if (first == 1 && k == 0) dst = src; else dst = sc_blend(0u, dst, src);
+            }
+        }
+        if (first != 2 && t_in && !over) {                              // TileWriteOp::Solid: to_srgb_bytes :156-162, 690
+            float sel[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) sel[c] = sel_channel((P.channels >> (8 * c)) & 0xFFu, dst.r, dst.g, dst.b, dst.a);
+            const uint32_t bytes = to_u8_x4(linear_to_srgb(sel[0])) | (to_u8_x4(linear_to_srgb(sel[1])) << 8) |
+                                   (to_u8_x4(linear_to_srgb(sel[2])) << 16) | (to_u8_x4(sel[3]) << 24);
+            const uint32_t px = tx * 16u + (uint32_t)li;
+#pragma unroll 4
+            for (int row = 0; row < 16; row++) {                         // the group's 16 lanes: one pixel column each
+                const uint32_t py = ty * 16u + (uint32_t)row;
+                if (px < P.width && py < P.height) ((uint32_t*)image)[(size_t)py * P.stride_px + px] = bytes;
+            }
+        }
+    }
+    // ---- the tiles that are painted, one after the other with all 64 lanes (Painter::paint_layer, painter/mod.rs:290-347:
+    //      k_paint_wave<SIMPLE>'s layer loop; an entry's data comes out of its lane by readlane) --------------------------------
+    const bool paint_me = first == 2 && t_in && !over;
+    if (!__any(paint_me)) return;
+#pragma unroll
+    for (int q = 0; q < 4; q++) { q_cells[0][q * 64 + lane] = 0; q_cells[1][q * 64 + lane] = 0; }
+    uint32_t chan_sel = 0;                                              // v_perm_b32 selector: channel.rs:44-55 as byte indices
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const uint32_t ch = (P.channels >> (8 * c)) & 0xFFu;
+        chan_sel |= (ch <= 3u ? ch : (ch == 4u ? 0x0Cu : 0x0Du)) << (8 * c);
+    }
+    const int lx = lane & 15, rg = lane >> 4;                           // pixel mapping of the pixel phase: (lx, 4 * rg + q)
+    uint32_t cbuf = 0;
+    for (int t = 0; t < 4; t++) {
+        if (!__builtin_amdgcn_readlane((int)paint_me, 16 * t)) continue;
+        const uint32_t ne_t = (uint32_t)__builtin_amdgcn_readlane((int)ne, 16 * t), sk_t = (uint32_t)__builtin_amdgcn_readlane((int)skipped, 16 * t);
+        const uint32_t ttx = qx * 4u + (uint32_t)t, px = ttx * 16u + (uint32_t)lx;
+        float dr[4], dg[4], db[4], da[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { dr[q] = clear.r; dg[q] = clear.g; db[q] = clear.b; da[q] = clear.a; }
+        for (uint32_t e = sk_t; e < ne_t; e++) {
+            const int sl = 16 * t + (int)e;
+            const uint32_t e_sfl = (uint32_t)__builtin_amdgcn_readlane((int)a_hi, sl) >> 21;
+            const uint32_t nseg = (uint32_t)__builtin_amdgcn_readlane((int)pnseg, sl);
+            const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)pcov.x, sl), c1 = (uint32_t)__builtin_amdgcn_readlane((int)pcov.y, sl);
+            const uint32_t c2 = (uint32_t)__builtin_amdgcn_readlane((int)pcov.z, sl), c3 = (uint32_t)__builtin_amdgcn_readlane((int)pcov.w, sl);
+            const uint32_t cw = rg == 0 ? c0 : (rg == 1 ? c1 : (rg == 2 ? c2 : c3));
+            int A[4];
+            if (nseg) {
+                int* cb = q_cells[cbuf];
+                const uint64_t* sp = sorted + (uint32_t)__builtin_amdgcn_readlane((int)pseg0, sl);
+                for (uint32_t sidx = lane; sidx < nseg; sidx += 64) {   // acc_segment :257-271
+                    const uint64_t v = sp[sidx];
+                    const int cv = seg_cover(v);
+                    atomicAdd(&cb[seg_ly(v) * 16 + seg_lx(v)], (int)((uint32_t)(seg_dam(v) * cv) << 16) + cv);
+                }
+                wave_lds_sync();
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int ci = (rg * 4 + q) * 16 + lx;
+                    const int S = cb[ci];
+                    cb[ci] = 0;
+                    const int c = (int)(int16_t)(S & 0xFFFF);
+                    const int area = (int)(int16_t)((uint32_t)(S - c) >> 16);
+                    int inc = c;
+                    inc += dpp_row_shr(inc, 1); inc += dpp_row_shr(inc, 2); inc += dpp_row_shr(inc, 4); inc += dpp_row_shr(inc, 8);
+                    const int carry = (int)(int8_t)(cw >> (q * 8));
+                    const int acc = (int)(int8_t)(carry + (inc - c));
+                    A[q] = 32 * acc + area;
+                }
+                cbuf ^= 1u;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; q++) A[q] = 32 * (int)(int8_t)(cw >> (q * 8));
+            }
+            const bool eo = (e_sfl & SF_EVENODD) != 0;
+            const float fr = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)pcol.x, sl)), fg = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)pcol.y, sl));
+            const float fb = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)pcol.z, sl)), fa = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)pcol.w, sl));
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float cov = coverage_of(A[q], eo);
+                const float src_a = fa * cov;                           // blend_at :406-447 with blend = Over
+                const float ida = 1.0f - da[q], k1 = ida * src_a, isa = 1.0f - src_a, k2 = da[q] * src_a;
+                const float nr = fmaf(dr[q], isa, fmaf(fr, k1, fr * k2));
+                const float ng = fmaf(dg[q], isa, fmaf(fg, k1, fg * k2));
+                const float nb2 = fmaf(db[q], isa, fmaf(fb, k1, fb * k2));
+                const float na2 = fmaf(da[q], isa, src_a);
+                const bool skip = cov == 0.0f;                          // :317-319
+                dr[q] = skip ? dr[q] : nr; dg[q] = skip ? dg[q] : ng; db[q] = skip ? db[q] : nb2; da[q] = skip ? da[q] : na2;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {                                   // compute_srgb :466-483 + channel select
+            const uint32_t py = ty * 16u + (uint32_t)(rg * 4 + q);
+            if (px < P.width && py < P.height) {
+                const float sr = linear_to_srgb(dr[q]), sg = linear_to_srgb(dg[q]), sb2 = linear_to_srgb(db[q]);
+                const uint32_t rgba = to_u8_x8(sr) | (to_u8_x8(sg) << 8) | (to_u8_x8(sb2) << 16) | (to_u8_x8(da[q]) << 24);
+                ((uint32_t*)image)[(size_t)py * P.stride_px + px] = __builtin_amdgcn_perm(0u, rgba, chan_sel);
+            }
+        }
+    }
+}
+
 #define PAINT_ARGS P, tile, sorted, records, n_runs, tile_first_run, row_span_lo, row_span_cnt, span_key, span_cov, layer_col, \
                    style_offsets, style_words, images, texels, image, cache, info
 #define PAINT_PARAMS PaintParams P, const uint64_t* __restrict__ sorted, const TileRecord* __restrict__ records, DevCount nc_runs, \
@@ -2590,7 +2862,7 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
                   const uint64_t* span_key, const uint4* span_cov, const uint4* layer_col,
                   const uint32_t* style_offsets, const uint32_t* style_words, const forma_image_t* images,
                   const uint16_t* texels, uint8_t* image, TileCacheArgs cache, FrameInfo* info, uint32_t* overflow_n,
-                  uint32_t* overflow_list, uint32_t* over2_n, uint32_t* over2_list, bool launch_deep, SpanGroups groups, bool strips) {
+                  uint32_t* overflow_list, uint32_t* over2_n, uint32_t* over2_list, bool launch_deep, SpanGroups groups, bool strips, bool quads) {
     const uint32_t T = p.tiles_w * p.tiles_h;
     if (T == 0 || p.crop_y1 <= p.crop_y0) return;
     const uint32_t per = ((p.crop_y1 - p.crop_y0) * p.tiles_w + 7) / 8;
@@ -2601,6 +2873,14 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
     // strips (four wavefronts per tile, NPX = 1): never with a buffer-layer cache — a tile's cache entry is read by every strip
     // and rewritten by the first one that finishes
     if (cache.tiles) strips = false;
+    // quads (k_paint_quad: four tiles per wavefront): all-solid scenes with shallow tiles, no cache
+    if (quads && simple && !cache.tiles) {
+        const uint32_t qper = ((p.crop_y1 - p.crop_y0) * ((p.tiles_w + 3u) / 4u) + 7u) / 8u;
+        if (one) FORMA_LAUNCH(k_paint_quad<true>, dim3(qper * 8), dim3(64), 0, s, p, sorted, records, n_runs, tile_first_run, row_span_lo, row_span_cnt,
+                              span_key, span_cov, layer_col, image, info, overflow_n, overflow_list, launch_deep ? 1u : 0u, groups);
+        else FORMA_LAUNCH(k_paint_quad<false>, dim3(qper * 8), dim3(64), 0, s, p, sorted, records, n_runs, tile_first_run, row_span_lo, row_span_cnt,
+                          span_key, span_cov, layer_col, image, info, overflow_n, overflow_list, launch_deep ? 1u : 0u, groups);
+    } else {
 #define PW_LAUNCH(S_, O_, N_) FORMA_LAUNCH((k_paint_wave<S_, O_, N_>), dim3(N_ == 1 ? per * 32 : (per + (p.order_cnt_out ? p.order_hcap : 0u)) * 8), dim3(64), 0, s, p, sorted, records, n_runs, \
                                              tile_first_run, row_span_lo, row_span_cnt, span_key, span_cov, layer_col, style_offsets, style_words, \
                                              images, texels, image, cache, info, overflow_n, overflow_list, launch_deep ? 1u : 0u, groups)
@@ -2609,6 +2889,7 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
     else { if (one) PW_LAUNCH_N(false, true); else PW_LAUNCH_N(false, false); }
 #undef PW_LAUNCH_N
 #undef PW_LAUNCH
+    }
     if (!launch_deep) return;                             // (read-back-free frame of a scene whose last frame had no deep tile)
     FORMA_LAUNCH(k_paint_deep, dim3(T < 256 ? T : 256), dim3(256), 0, s, p, sorted, records, n_runs, tile_first_run,
                        row_span_lo, row_span_cnt, span_key, span_cov, layer_col, style_offsets, style_words, images,
