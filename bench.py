@@ -334,11 +334,14 @@ def main():
                                            "duration is the kernel's own only with one frame in flight, which is where this roofline is measured")
         # the painter is not an HBM kernel: VALU issue and LDS bound it.  Live: its launch time; from the committed counters of
         # the same build: wave-level VALU instructions per launch and the LDS bank-conflict ratio.
-        paint_k_us = kernels_us.get("k_paint_wave", {}).get("us_per_frame") or stage.get("paint_us", 0.0)   # (the kernel's own launch events)
-        painter = {"kernel": "k_paint_wave (one wavefront per 16x16 tile)", "bound": "valu+lds", "avg_launch_us": round(paint_k_us, 1),
+        pk_name = next((k for k in ("k_paint_wave", "k_paint_quad") if k in kernels_us), None)
+        paint_k_us = kernels_us[pk_name]["us_per_frame"] if pk_name else stage.get("paint_us", 0.0)   # (the kernel's own launch events)
+        painter = {"kernel": {"k_paint_quad": "k_paint_quad (one wavefront per four 16x16 tiles: all-solid scenes with many shallow tiles)"}.get(
+                       pk_name, "k_paint_wave (one wavefront per 16x16 tile; frames below the chip's wave slots: four strip wavefronts per tile)"),
+                   "bound": "valu+lds", "avg_launch_us": round(paint_k_us, 1),
                    "hbm_algorithmic_bytes": 8.0 * n_local + 4.0 * width * height,
                    "hbm_achieved_GBs": round((8.0 * n_local + 4.0 * width * height) / max(paint_k_us, 1e-3) / 1e3, 1)}
-        pk = next((v for n_, v in pmc["kernels"].items() if n_.startswith("k_paint_wave")), None) if use_pmc else None
+        pk = next((v for n_, v in pmc["kernels"].items() if n_.startswith(pk_name or "k_paint_wave")), None) if use_pmc else None
         if pk is not None:                                            # (the counters' key carries template arguments: match by prefix)
             k = pk
             valu = k.get("SQ_INSTS_VALU")

@@ -521,6 +521,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     const uint32_t tiles_painted = (P.crop_y1 > P.crop_y0 ? P.crop_y1 - P.crop_y0 : 0u) * tiles_w;
     const bool strips = paint_by_strips(ctx, tiles_painted);
     P.order_flag_in = nullptr; P.order_flag_out = nullptr; P.order_hcap = 0; P.order_thr = 0;
+    if (ctx->dbg.order_thr >= 0) ctx->order_off = 0;
     if (ctx->order_off) ctx->order_off--;                 // (a flat scene: the order is retried every 256 frames)
     // ... of launches that are a handful of rounds of wavefronts: one tile's life is then a good part of the launch's.  A frame
     // of 32 rounds (the 8K scene: 262 144 tiles on 8 192 wave slots) has no tail worth 10 % of bookkeeping.
@@ -541,7 +542,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
         uint32_t* wset = base + (size_t)w * set_words;
         P.order_cnt_out = order_cnt; P.order_list_out = wset + PAINT_ORDER_WORDS;
         P.order_flag_out = reinterpret_cast<uint8_t*>(wset + PAINT_ORDER_WORDS + 8 * hcap);
-        P.order_hcap = (uint32_t)hcap; P.order_thr = ctx->order_thr;
+        P.order_hcap = (uint32_t)hcap; P.order_thr = ctx->dbg.order_thr >= 0 ? (uint32_t)ctx->dbg.order_thr : ctx->order_thr;
         ctx->order_pending = w; ctx->order_pending_sig = sig; ctx->order_tiles = tiles_painted;
         ctx->order_cnt_dev = order_cnt; ctx->order_keep_dev = wset;
     } else ctx->order_cur = -1;                              // (any other frame in between: the lists are stale)

@@ -19,6 +19,7 @@
 //   no_ras_hist          the sort's digit histograms are always taken by k_sort_hist, never by the rasterizer
 //   carry_half=0|1|N     never / by policy / with N slices per row: the 512-lane carry kernel (three workgroups per CU)
 //   paint_quad=0|1|2     the four-tiles-per-wavefront painter of all-solid scenes: never / by policy / always
+//   order_thr=N          the painters file a tile as heavy from N shader clocks on (no steering, never switched off): tests
 //   no_order             the painters always take their tiles in index order (PaintParams::order_*)
 //   no_cull              the painters never drop the entries below a tile's topmost occluder (PaintParams::cull)
 //   strip_tiles=N        the painter runs four strip wavefronts per tile on frames of <= N painted tiles (0: never)
@@ -34,7 +35,7 @@ struct ForMaDebug {
     bool sync = false, global_runsort = false, xgather = false, no_small_carry = false, span_groups = false, no_span_groups = false;
     bool no_packed_copy = false, no_simple_paint = false, force_simple_paint = false, trim_debug = false, force_exchange = false;
     bool xchg_copy = false, no_prezero = false, no_bias = false, no_ras_hist = false, no_cull = false, no_order = false;
-    int carry_slices = 0, digit_bits = 0, poison = -1, poison_frame = -1, strip_tiles = -1, carry_half = 1, paint_quad = 1;
+    int carry_slices = 0, digit_bits = 0, poison = -1, poison_frame = -1, strip_tiles = -1, carry_half = 1, paint_quad = 1, order_thr = -1;
 };
 
 inline ForMaDebug forma_debug_parse() {
@@ -56,6 +57,7 @@ inline ForMaDebug forma_debug_parse() {
         if (!strcmp(tok, "carry_slices")) { d.carry_slices = (int)v; continue; }
         if (!strcmp(tok, "digit_bits")) { d.digit_bits = (int)v; continue; }
         if (!strcmp(tok, "carry_half")) { d.carry_half = (int)std::max(v, 0L); continue; }
+        if (!strcmp(tok, "order_thr")) { d.order_thr = (int)std::max(v, 0L); continue; }
         if (!strcmp(tok, "paint_quad")) { d.paint_quad = (int)std::max(v, 0L); continue; }
         if (!strcmp(tok, "strip_tiles")) { d.strip_tiles = (int)std::max(v, 0L); continue; }
         if (!strcmp(tok, "poison")) { d.poison = (int)(v & 0xFF); continue; }

@@ -535,3 +535,52 @@ def test_occlusion_culling_and_strip_painters_change_no_pixel(monkeypatch, switc
             assert np.abs(img.astype(np.int16) - ref.astype(np.int16)).max() <= 1
     finally:
         c.close()
+
+
+def test_painter_order_survives_crops_canvas_changes_and_voided_frames(monkeypatch):
+    """The painters start with the previous frame's heavy tiles (PaintParams::order_*): a schedule only.  Many frames of one
+    scene with a low threshold (every tile "heavy": the heavy section and the flags are exercised to their capacity), the
+    crop and the canvas changing in between, a frame voided by new geometry — every image equals the oracle's."""
+    import forma_amd
+    monkeypatch.setenv("FORMA_HIP_DEBUG", "strip_tiles=0,paint_quad=0,order_thr=1")   # (one wavefront per tile, every tile "heavy")
+    c = forma_amd.Context(0)
+    try:
+        comp = S.random_mixed(n=400, width=1024, height=768, seed=21)
+        o, _ = both(c, comp)
+        for (w, h), crop in (((1024, 768), None), ((1024, 768), (100, 900, 64, 700)), ((1024, 768), (100, 900, 64, 700)), ((800, 600), None),
+                             ((1024, 768), None)):
+            ref = o.render(w, h, clear=(0.9, 0.9, 0.9, 1.0), crop=crop)
+            for k in range(7):                           # (the threshold is steered frame by frame: the lists change under the same scene)
+                img = c.render(w, h, clear=(0.9, 0.9, 0.9, 1.0), crop=crop)
+                y0, y1, x0, x1 = (crop[2], crop[3], crop[0], crop[1]) if crop else (0, h, 0, w)
+                a = img.reshape(h, -1)[y0:y1, 4 * x0:4 * x1].astype(np.int16); b = ref.reshape(h, -1)[y0:y1, 4 * x0:4 * x1].astype(np.int16)
+                assert np.abs(a - b).max() <= 1, (w, h, crop, k)
+        o2, _ = both(c, S.random_cubics(n=300, width=1024, height=768, seed=22, alpha=0.7))     # new geometry: predictions void
+        ref = o2.render(1024, 768, clear=(1.0, 1.0, 1.0, 1.0))
+        for k in range(5):
+            img = c.render(1024, 768, clear=(1.0, 1.0, 1.0, 1.0))
+            assert np.abs(img.astype(np.int16) - ref.astype(np.int16)).max() <= 1, k
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("size", [(1000, 500), (1936, 1088), (72, 40)])
+def test_quad_painter_on_canvases_that_are_no_multiple_of_four_tiles(monkeypatch, size):
+    """k_paint_quad (four tiles per wavefront, all-solid scenes) forced on canvases whose tile rows end inside a quad, with a
+    crop that starts and ends inside quads, translucent and opaque layers (culling on: opaque cubics hide most entries)."""
+    import forma_amd
+    monkeypatch.setenv("FORMA_HIP_DEBUG", "paint_quad=2")
+    w, h = size
+    c = forma_amd.Context(0)
+    try:
+        for comp in (S.random_cubics(n=250, width=w, height=h, seed=31), S.random_cubics(n=120, width=w, height=h, seed=32, alpha=0.5)):
+            o, _ = both(c, comp)
+            for crop in (None, (16 * 3 + 5, max(w - 40, 16 * 3 + 6), 17, max(h - 9, 18))):
+                ref = o.render(w, h, clear=(1.0, 1.0, 1.0, 0.0), crop=crop)
+                for _ in range(3):
+                    img = c.render(w, h, clear=(1.0, 1.0, 1.0, 0.0), crop=crop)
+                y0, y1, x0, x1 = (crop[2], crop[3], crop[0], crop[1]) if crop else (0, h, 0, w)
+                a = img.reshape(h, -1)[y0:y1, 4 * x0:4 * x1].astype(np.int16); b = ref.reshape(h, -1)[y0:y1, 4 * x0:4 * x1].astype(np.int16)
+                assert np.abs(a - b).max() <= 1, (size, crop)
+    finally:
+        c.close()
