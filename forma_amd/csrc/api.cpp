@@ -185,9 +185,13 @@ int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, boo
 // with one wavefront each — 1080p canvases, the band of a multi-device rank, crops: such a launch is as long as its deepest
 // tile, and a strip walks that tile's pixels four times as fast.  Bigger frames are bound by throughput, and the strips'
 // fourfold list work would cost them.  FORMA_HIP_DEBUG=strip_tiles=N moves the limit (0: never).
+// ... and only for scenes with COSTLY layers (gradients, textures, the fifteen other blend modes, clipped layers: ~7 500 clocks per
+// layer and tile against ~900 for a solid colour blended Over): a strip does a quarter of a layer's pixel arithmetic but all of its
+// fixed work — segment loads, LDS phases — and builds the tile's list itself.  Translucent discs 120 layers deep lose 16 % to
+// strips, the 4K scene's band (one layer in seven costly) gains 20 %.
 static bool paint_by_strips(const forma_hip_ctx* ctx, uint32_t tiles_painted) {
-    const uint32_t limit = ctx->dbg.strip_tiles >= 0 ? (uint32_t)ctx->dbg.strip_tiles : PAINT_STRIP_TILES;
-    return tiles_painted <= limit;
+    if (ctx->dbg.strip_tiles >= 0) return tiles_painted <= (uint32_t)ctx->dbg.strip_tiles;
+    return tiles_painted <= PAINT_STRIP_TILES && !ctx->scene_simple && (uint64_t)ctx->costly_layers * 32u >= ctx->n_orders;
 }
 
 // Quad painters (k_paint_quad: four tiles per wavefront) for all-solid scenes whose tiles are shallow AND many: the list work of
@@ -962,6 +966,7 @@ int forma_hip_set_styles(forma_hip_ctx* ctx, const uint32_t* style_offsets, size
     if (n_orders > (size_t)FORMA_LAYER_LIMIT + 1) return fail(ctx, FORMA_E_ARG, "order exceeds LAYER_LIMIT");
     if (ctx->multi) return multi_set_styles(ctx, style_offsets, n_orders, style_words, n_words, unchanged);
     bool clips = false, simple = true;
+    size_t costly = 0;                                    // layers with a gradient, texture, blend mode or clip (strip painters)
     // per order: what the carry pre-pass attaches to every run and span of the layer (one gather instead of a chain through
     // the offset table and the style words): SF_* flags and the four words the painter's fast paths read
     ctx->h_layer_sf.assign(n_orders, 0u);
@@ -982,6 +987,7 @@ int forma_hip_set_styles(forma_hip_ctx* ctx, const uint32_t* style_offsets, size
         if (!FORMA_STYLE_IS_CLIP(h) && FORMA_STYLE_FILL(h) == FORMA_FILL_TEXTURE) { any_texture = true; max_image = std::max(max_image, style_words[off + 8]); }
         if (FORMA_STYLE_IS_CLIP(h) || FORMA_STYLE_CLIPPED(h)) clips = true;
         if (FORMA_STYLE_IS_CLIP(h) || FORMA_STYLE_CLIPPED(h) || FORMA_STYLE_FILL(h) != FORMA_FILL_SOLID || FORMA_STYLE_BLEND(h) != 0u) simple = false;
+        if (!FORMA_STYLE_IS_CLIP(h) && (FORMA_STYLE_FILL(h) != FORMA_FILL_SOLID || FORMA_STYLE_BLEND(h) != 0u || FORMA_STYLE_CLIPPED(h))) costly++;
         uint32_t sfl = (FORMA_STYLE_EVENODD(h) ? SF_EVENODD : 0u) | (FORMA_STYLE_BLEND(h) << SF_BLEND_SHIFT) | (FORMA_STYLE_FILL(h) << SF_FILL_SHIFT);
         uint32_t* col = &ctx->h_layer_col[o * 4];
         if (FORMA_STYLE_IS_CLIP(h)) { sfl |= SF_IS_CLIP; col[0] = style_words[off + 1]; }
@@ -1003,6 +1009,7 @@ int forma_hip_set_styles(forma_hip_ctx* ctx, const uint32_t* style_offsets, size
     if (unchanged && (rc = upload(ctx, ctx->unchanged, unchanged, n_orders))) return rc;
     HIPCHECK(hipStreamSynchronize(ctx->stream));
     ctx->n_orders = n_orders; ctx->n_words = n_words; ctx->scene_has_clips = clips; ctx->scene_simple = simple;
+    ctx->costly_layers = costly;
     ctx->have_unchanged = unchanged != nullptr;
     ctx->any_texture = any_texture; ctx->max_image_index = max_image;
     share_scene(ctx);
@@ -1356,7 +1363,7 @@ void share_scene(forma_hip_ctx* o) {
         sl->images.borrow(o->images); sl->texels.borrow(o->texels); sl->layer_sf.borrow(o->layer_sf); sl->layer_col.borrow(o->layer_col);
         sl->n_points = o->n_points; sl->n_geoms = o->n_geoms; sl->n_orders = o->n_orders; sl->n_words = o->n_words; sl->n_images = o->n_images;
         sl->max_geom_order = o->max_geom_order; sl->max_image_index = o->max_image_index; sl->any_texture = o->any_texture;
-        sl->scene_has_clips = o->scene_has_clips; sl->scene_simple = o->scene_simple; sl->have_unchanged = o->have_unchanged;
+        sl->scene_has_clips = o->scene_has_clips; sl->scene_simple = o->scene_simple; sl->costly_layers = o->costly_layers; sl->have_unchanged = o->have_unchanged;
         sl->band_row0 = o->band_row0; sl->band_row1 = o->band_row1;
         sl->line_ranged = o->line_ranged; sl->line_lo = o->line_lo; sl->line_hi = o->line_hi;
     }

@@ -60,6 +60,7 @@ struct forma_hip_ctx {
     uint32_t pred_row_spans = 0;    // spans per painted tile row of the last verified frame: group lists pay above SPAN_GROUP_MIN_ROW
     uint32_t cur_rows_painted = 1;
     bool scene_simple = false;      // all layers solid + Over + unclipped: the painter's specialised kernel
+    size_t costly_layers = 0;       // layers with a gradient / texture fill, a blend mode other than Over, or clipped (strip painters: api.cpp)
     bool have_unchanged = false;            // set_styles supplied per-order Layer::is_unchanged bytes
     // lines
     DevBuf l_order, l_x0, l_y0, l_dx, l_dy, l_a, l_b, l_c, l_d, l_len, scan_tmp;   // parity entry points only

@@ -1037,6 +1037,18 @@ struct Workbench {                                                     // layer_
         // ids.extend(segment_ranges.keys ++ queue_indices.keys) with mask = true, then sort_and_dedup (:266-277,
         // MaskedVec :105-118): cells already present (a second populate without next_tile, as the reference's own
         // tests do) keep their place in front of the newly pushed duplicates
+        if (ids.empty()) {
+            // (the frame path: both tables are sorted by layer, so the sorted, de-duplicated union is one linear merge — and
+            //  std::stable_sort allocates its scratch buffer on every call: a malloc per TILE from every painter thread)
+            auto a = seg_ranges.begin(), ae = seg_ranges.end();
+            auto b = queue_idx.begin(), be = queue_idx.end();
+            while (a != ae || b != be) {
+                if (b == be || (a != ae && a->first < b->first)) { ids.push_back({a->first, true}); ++a; }
+                else if (a == ae || b->first < a->first) { ids.push_back({b->first, true}); ++b; }
+                else { ids.push_back({a->first, true}); ++a; ++b; }
+            }
+            return;
+        }
         for (auto& kv : seg_ranges) ids.push_back({kv.first, true});
         for (auto& kv : queue_idx) ids.push_back({kv.first, true});
         std::stable_sort(ids.begin(), ids.end(), [](const Id& a, const Id& b) { return a.id < b.id; });
@@ -1212,7 +1224,9 @@ void paint(const uint64_t* segs, size_t n, const PaintCtx& ctx, uint8_t* buf, si
     bool has_prev_clear = cache && cache->has_clear; Color prev_clear = cache ? cache->clear : Color{};
 #pragma omp parallel
     {
-        Painter painter; Workbench wb;
+        // (a thread keeps its painter and layer tables from frame to frame: their vectors are warm after the first one)
+        static thread_local Painter painter; static thread_local Workbench wb;
+        wb.next_tile(); wb.queue.clear(); wb.next_queue.clear();
 #pragma omp for schedule(dynamic, 1)
         for (long j = 0; j < (long)tiles_h; j++) {
             if (crop.some && !((size_t)j >= crop.v0 && (size_t)j < crop.v1)) continue;     // print_row :588-592
