@@ -618,10 +618,21 @@ def cpu_baseline(renderer, width, height, budget_s):
     tm = o.time_frame(width, height, iters)
     per = sum(tm.values())
     cores = max(stage_best.values())
-    return {"value": round(1.0 / per, 3), "unit": "frames/s", "cores": cores, "kind": "port", "host_threads": hw,
+    quota = None                                              # the container's CPU quota (cgroup v2 cpu.max / v1 cfs): threads beyond it only queue
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else round(int(q) / int(period), 2)
+    except Exception:                                         # noqa: BLE001
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = None if q <= 0 else round(q / period, 2)
+        except Exception:                                     # noqa: BLE001
+            pass
+    return {"value": round(1.0 / per, 3), "unit": "frames/s", "cores": cores, "kind": "port", "host_threads": hw, "host_cpu_quota": quota,
             "sample": f"{iters} full frames of the same workload (C++ restatement of the CPU backend, OpenMP, pinned; every stage at the "
                       f"fastest thread count of the sweep {sorted(sweep)}: {stage_best}; parallel stable radix sort and prefix sum; the "
-                      f"painter works a tile row per task like forma's)",
+                      f"painter works a tile row per task like forma's)" + (f"; the box's cgroup grants {quota:g} CPUs of its {hw} hardware threads, which "
+                                                                        f"is where the sweep stops improving" if quota else ""),
             "threads_per_stage": stage_best,
             "thread_sweep_ms": {str(k): round(v * 1e3, 1) for k, v in sweep.items()},
             "thread_sweep_stage_ms": {str(k): {st: round(v * 1e3, 1) for st, v in per_stage[k].items()} for k in per_stage},

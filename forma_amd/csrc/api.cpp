@@ -189,9 +189,17 @@ int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, boo
 // layer and tile against ~900 for a solid colour blended Over): a strip does a quarter of a layer's pixel arithmetic but all of its
 // fixed work — segment loads, LDS phases — and builds the tile's list itself.  Translucent discs 120 layers deep lose 16 % to
 // strips, the 4K scene's band (one layer in seven costly) gains 20 %.
+// Both schedules that shorten ONE frame's painter launch at the price of more work — strips, and the heavy-first order below —
+// are for a context with one frame in flight.  With frame slots (forma_hip_set_frames_in_flight) the tail of a launch is filled by
+// the other frames' kernels anyway and the extra work is a loss: measured with three slots, the 4K scene -2.5 % frames/s with the
+// order on, its 1/8 band -5 % with strips.
+static bool one_frame_in_flight(const forma_hip_ctx* ctx) {
+    const forma_hip_ctx* o = ctx->owner ? ctx->owner : ctx;
+    return o->slots.size() <= 1;
+}
 static bool paint_by_strips(const forma_hip_ctx* ctx, uint32_t tiles_painted) {
     if (ctx->dbg.strip_tiles >= 0) return tiles_painted <= (uint32_t)ctx->dbg.strip_tiles;
-    return tiles_painted <= PAINT_STRIP_TILES && !ctx->scene_simple && (uint64_t)ctx->costly_layers * 32u >= ctx->n_orders;
+    return tiles_painted <= PAINT_STRIP_TILES && !ctx->scene_simple && (uint64_t)ctx->costly_layers * 32u >= ctx->n_orders && one_frame_in_flight(ctx);
 }
 
 // Quad painters (k_paint_quad: four tiles per wavefront) for all-solid scenes whose tiles are shallow AND many: the list work of
@@ -530,7 +538,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     // ... of launches that are a handful of rounds of wavefronts: one tile's life is then a good part of the launch's.  A frame
     // of 32 rounds (the 8K scene: 262 144 tiles on 8 192 wave slots) has no tail worth 10 % of bookkeeping.
     if (ctx->order_enable && bound_j && a.cache_id < 0 && !strips && !ctx->dbg.no_order && jc.bound > 0 && tiles_painted && !ctx->order_off &&
-        tiles_painted <= 16u * PAINT_STRIP_TILES) {
+        tiles_painted <= 16u * PAINT_STRIP_TILES && (one_frame_in_flight(ctx) || ctx->dbg.order_thr >= 0)) {
         // (heavy section: an eighth of the band's tiles, as PAINT_ORDER_SUBS lists of equal capacity)
         const size_t per = (tiles_painted + 7) / 8, hcap = std::max<size_t>((per / 8 + PAINT_ORDER_SUBS - 1) / PAINT_ORDER_SUBS, 2) * PAINT_ORDER_SUBS;
         const size_t set_words = PAINT_ORDER_WORDS + 8 * hcap + (8 * per + 3) / 4;      // counts | lists | one flag byte per tile

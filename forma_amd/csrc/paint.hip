@@ -47,9 +47,10 @@ __device__ __forceinline__ bool cover_is_empty(uint64_t lo, uint64_t hi, bool ev
 // what skip_fully_covered_layers_pass looks for (layer_workbench/passes/skip_fully_covered_layers.rs).  `khi` = the high word of
 // a span key / group-list entry: layer | SF_* << 21.
 __device__ __forceinline__ bool span_is_occluder(uint32_t khi) {
-    const uint32_t sfl = khi >> 21;
-    return (sfl & SF_FULL) && (sfl & SF_OPAQUE) && !(sfl & (SF_IS_CLIP | SF_CLIPPED)) &&
-           ((sfl >> SF_FILL_SHIFT) & 3u) == FORMA_FILL_SOLID && ((sfl >> SF_BLEND_SHIFT) & 15u) == 0u;
+    // FULL and OPAQUE set; IS_CLIP, CLIPPED, the blend ordinal and the fill type (FORMA_FILL_SOLID = 0) all zero; EVENODD free
+    constexpr uint32_t care = (SF_FULL | SF_IS_CLIP | SF_CLIPPED | SF_OPAQUE | (15u << SF_BLEND_SHIFT) | (3u << SF_FILL_SHIFT)) << 21;
+    static_assert(FORMA_FILL_SOLID == 0, "the occluder test reads the fill type as a zero field");
+    return (khi & care) == ((SF_FULL | SF_OPAQUE) << 21);
 }
 
 __device__ __forceinline__ bool cover_full(const uint32_t* c, bool even_odd) {     // Cover::is_full painter/mod.rs:200-215
