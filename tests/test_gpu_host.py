@@ -320,6 +320,34 @@ def test_paris_like_30k_4k_full_size():
     assert np.array_equal(img, img2)
 
 
+def test_paris_like_30k_4k_with_three_frames_in_flight_matches_the_oracle():
+    """BASELINE.json configs[2] through the path `bench.py` reports as `value`: ONE context with three frame slots, device-resident
+    frames enqueued round-robin.  The most recent frame's sorted stream and image are compared with the oracle after the slots
+    have each run their synchronous and their read-back-free frames, and again after a change of the clear colour in flight."""
+    import forma_amd
+    from forma_amd import api, scenes
+    fn, W, H = scenes.WORKLOADS["paris-like-30k-4k"]
+    r = api.Renderer(0)
+    r.render(fn(), api.BufferBuilder(np.zeros(W * H * 4, np.uint8), api.LinearLayout(W, W * 4, H)).build(), api.RGBA, api.Color(1, 1, 1, 1), None)
+    t = r.host_tables
+    o = orc.Oracle()
+    S.load(o, t)
+    c = forma_amd.Context(0, frames_in_flight=3)
+    S.load(c, t)
+    clears = [(1.0, 1.0, 1.0, 1.0), (0.1, 0.2, 0.3, 1.0)]
+    want = {cl: o.render(W, H, clear=cl) for cl in clears}
+    sorted_ref = o.segments(1)
+    for k in range(14):
+        cl = clears[(k // 5) % 2]
+        assert c.render(W, H, clear=cl, device_only=True) is None
+        if k in (8, 13):
+            d = np.abs(c.read_image(W, H).astype(np.int16) - want[cl].astype(np.int16))
+            assert d.max() <= 1, (k, int(d.max()), int((d > 0).sum()))
+            assert np.array_equal(c.segments(1), sorted_ref), k
+    c.sync()
+    c.close()
+
+
 def test_svg_loader_route_at_full_size_matches_the_api_built_stand_in():
     """SURVEY §8 f1 at BASELINE configs[2] scale: the stand-in serialised as SVG TEXT (30 000 <path>s, linear / radial
     gradients, mix-blend-mode, fill-opacity — `scenes.paris_like_svg`) goes through the loader (`forma_amd.svg`, after
