@@ -189,6 +189,16 @@ int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, boo
 // layer and tile against ~900 for a solid colour blended Over): a strip does a quarter of a layer's pixel arithmetic but all of its
 // fixed work — segment loads, LDS phases — and builds the tile's list itself.  Translucent discs 120 layers deep lose 16 % to
 // strips, the 4K scene's band (one layer in seven costly) gains 20 %.
+// A digit pass is one persistent 1 024-lane workgroup per CU: 148 KB of LDS and the whole register file, nothing co-resides.  With
+// frames in flight the passes of three frames therefore run one after the other on an otherwise idle chip; on fewer CUs a pass
+// is slower but the other frames' kernels run beside it (round 4 measured 128 of 256: +2.5 % frames/s with three slots, -10 %
+// with one — so only with frame slots).  FORMA_HIP_DEBUG=sort_cus=N sets it (0: all).
+static uint32_t sort_workgroups(const forma_hip_ctx* ctx) {
+    if (ctx->dbg.sort_cus >= 0) return (uint32_t)ctx->dbg.sort_cus;
+    const forma_hip_ctx* o = ctx->owner ? ctx->owner : ctx;
+    return o->slots.size() > 1 ? SORT_CUS_IN_FLIGHT : 0u;
+}
+
 // Both schedules that shorten ONE frame's painter launch at the price of more work — strips, and the heavy-first order below —
 // are for a context with one frame in flight.  With frame slots (forma_hip_set_frames_in_flight) the tail of a launch is filled by
 // the other frames' kernels anyway and the extra work is a loss: measured with three slots, the 4K scene -2.5 % frames/s with the
@@ -281,7 +291,7 @@ int run_sort(forma_hip_ctx* ctx, const uint64_t* src, DevCount nc, bool timing, 
     ctx->sorted = (uint64_t*)launch_radix_sort(ctx->stream, src, ctx->seg_a.as<uint64_t>(), ctx->seg_b.as<uint64_t>(), nc, plan,
                                                digit_bits, ctx->sort_counters.as<uint32_t>(), &ctx->info.as<FrameInfo>()->error,
                                                chunked,
-                                               ctx->info.as<FrameInfo>(), zeroed, hist_ready);
+                                               ctx->info.as<FrameInfo>(), zeroed, hist_ready, sort_workgroups(ctx));
     stage_end(ctx, ST_SORT, timing);
     HIPCHECK(hipGetLastError());
     return FORMA_OK;
@@ -525,7 +535,10 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     P.n_slices = jc.bound > 0 ? n_slices : 1u;             // (no runs: the carry pre-pass did not run, the zeroed tables say "no spans")
     P.n_groups = n_groups;
     // occlusion culling (PaintParams::cull): not with a buffer-layer cache (a tile's layer count is state there), not with clips
-    const bool cull = a.cache_id < 0 && !ctx->scene_has_clips && !ctx->dbg.no_cull;
+    // ... and only for a geometry whose tiles have been seen to overflow the wave painter's lists (k_paint_deep ran): that is where
+    // culling pays — 1080p cubics: painter 85 -> 24 us — while a scene of moderate lists (the 4K stand-in: 39 entries per tile,
+    // phases bound by their dependent steps, not by the entries) only pays for the occluder scan, ~1 % of its frames/s.
+    const bool cull = a.cache_id < 0 && !ctx->scene_has_clips && !ctx->dbg.no_cull && (ctx->cull_on || ctx->dbg.force_cull);
     P.cull = cull ? 1u : 0u;
     // heaviest tiles first (PaintParams::order_*): read-back-free frames without a cache, one wavefront per tile
     P.order_cnt_in = nullptr; P.order_list_in = nullptr; P.order_cnt_out = nullptr; P.order_list_out = nullptr;
@@ -749,6 +762,7 @@ int finish_frame(forma_hip_ctx* ctx, forma_timings_t* t, bool have_info = false)
     }
     // device-side invariant flags
     ctx->pred_no_deep = !(ctx->h_info->error & 16u);       // (8, 16: bookkeeping bits, not errors)
+    if (ctx->h_info->error & 16u) ctx->cull_on = true;     // deep tiles: from now on the painters cull (until the geometry changes)
     if (!ctx->h_info->plan_bad) {                          // what the keys' tile fields spanned (a sort that did not run leaves min > max)
         const uint32_t* r = ctx->h_info->tile_range;
         ctx->pred_range = KeyRange{~r[0], r[1], ~r[2], r[3], true};
@@ -1378,8 +1392,8 @@ void share_scene(forma_hip_ctx* o) {
 }
 void invalidate_counts(forma_hip_ctx* o) {                 // new geometry / band: every slot re-learns N and J synchronously
     o->pred_counts_valid = false; o->xpred_valid = false; o->small_banned = false; o->bias_banned = 0; o->bias_ban_len = 0; o->pred_range.valid = false;
-    o->order_off = 0; o->order_flat = 0; o->order_cur = -1;
-    for (forma_hip_ctx* sl : o->slots) { sl->order_off = 0; sl->order_flat = 0; sl->order_cur = -1; }
+    o->order_off = 0; o->order_flat = 0; o->order_cur = -1; o->cull_on = false;
+    for (forma_hip_ctx* sl : o->slots) { sl->order_off = 0; sl->order_flat = 0; sl->order_cur = -1; sl->cull_on = false; }
     for (forma_hip_ctx* sl : o->slots) { sl->pred_counts_valid = false; sl->xpred_valid = false; sl->small_banned = false; sl->bias_banned = 0; sl->bias_ban_len = 0; sl->pred_range.valid = false; }
 }
 }  // namespace

@@ -263,7 +263,8 @@ const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a
                                   const SortPlan& plan, int digit_bits, uint32_t* scratch, uint32_t* err,
                                   const ChunkedSrc* chunked = nullptr, FrameInfo* info = nullptr,
                                   bool scratch_is_zero = false /* an earlier kernel of the frame cleared sort_zero_words() */,
-                                  bool hist_ready = false /* ... and the producer of the keys counted the digits (RasHist) */);
+                                  bool hist_ready = false /* ... and the producer of the keys counted the digits (RasHist) */,
+                                  uint32_t max_workgroups = 0 /* 0: one persistent workgroup per CU; else at most this many */);
 RasHist make_ras_hist(const SortPlan& plan, uint32_t* sort_scratch);      // hist == nullptr if the plan does not qualify
 
 // exchange.hip — multi-GPU: bucket a rank's pixel segments by tile-row owner, gather what the owner received

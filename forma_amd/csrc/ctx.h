@@ -36,6 +36,7 @@ struct DevBuf {
 };
 
 constexpr uint32_t PAINT_STRIP_TILES = 6144;    // = the wave slots of the general painter (256 CUs x 24): every tile gets one at once   // frames of at most this many painted tiles are painted by strips (api.cpp paint_by_strips)
+constexpr uint32_t SORT_CUS_IN_FLIGHT = 128;    // persistent sort workgroups of a context with frame slots (api.cpp sort_workgroups)
 constexpr size_t SEG_PAD = 16;          // segment buffers are over-allocated: stream kernels read whole 64-byte lane pieces
 enum { ST_PREPARE = 0, ST_RASTER, ST_SORT, ST_CARRY, ST_PAINT, ST_D2H, ST_XCHG, ST_COUNT };
 
@@ -79,6 +80,7 @@ struct forma_hip_ctx {
     int order_cur = -1, order_pending = -1;       // set with valid lists (-1: none) / set this frame's painter writes (-1: none)
     bool order_enable = false;                    // set by the caller of run_paint for frames that end with k_frame_tail
     const uint32_t* order_cnt_dev = nullptr; uint32_t* order_keep_dev = nullptr;   // what that k_frame_tail copies
+    bool cull_on = false;                         // this geometry has had tiles beyond the wave painter's lists: occlusion culling is on
     bool cur_half = false, pred_slice_half = false;   // the 512-lane variant of the small carry kernel (api.cpp run_paint)
     bool cur_small = false, pred_slice_small = false, small_tried = false, small_banned = false, no_small_carry = false;
     DevBuf ras_masks;                       // k_rasterize: key masks per workgroup (8 words), combined by k_reduce_masks

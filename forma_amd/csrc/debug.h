@@ -20,8 +20,10 @@
 //   carry_half=0|1|N     never / by policy / with N slices per row: the 512-lane carry kernel (three workgroups per CU)
 //   paint_quad=0|1|2     the four-tiles-per-wavefront painter of all-solid scenes: never / by policy / always
 //   order_thr=N          the painters file a tile as heavy from N shader clocks on (no steering, never switched off): tests
+//   sort_cus=N           persistent workgroups of a digit pass (0: one per CU; default: all, or 128 of 256 with frame slots)
 //   no_order             the painters always take their tiles in index order (PaintParams::order_*)
-//   no_cull              the painters never drop the entries below a tile's topmost occluder (PaintParams::cull)
+//   no_cull / force_cull the painters never / always drop the entries below a tile's topmost occluder (PaintParams::cull; default:
+//                        once the geometry has had tiles beyond the wave painter's lists)
 //   strip_tiles=N        the painter runs four strip wavefronts per tile on frames of <= N painted tiles (0: never)
 //   trim_debug           forma_hip_trim prints what it releases
 //   force_exchange       forma_hip_create_multi with ONE device still builds the multi-device context (RCCL world of one)
@@ -34,8 +36,8 @@
 struct ForMaDebug {
     bool sync = false, global_runsort = false, xgather = false, no_small_carry = false, span_groups = false, no_span_groups = false;
     bool no_packed_copy = false, no_simple_paint = false, force_simple_paint = false, trim_debug = false, force_exchange = false;
-    bool xchg_copy = false, no_prezero = false, no_bias = false, no_ras_hist = false, no_cull = false, no_order = false;
-    int carry_slices = 0, digit_bits = 0, poison = -1, poison_frame = -1, strip_tiles = -1, carry_half = 1, paint_quad = 1, order_thr = -1;
+    bool xchg_copy = false, no_prezero = false, no_bias = false, no_ras_hist = false, no_cull = false, force_cull = false, no_order = false;
+    int carry_slices = 0, digit_bits = 0, poison = -1, poison_frame = -1, strip_tiles = -1, carry_half = 1, paint_quad = 1, order_thr = -1, sort_cus = -1;
 };
 
 inline ForMaDebug forma_debug_parse() {
@@ -51,12 +53,13 @@ inline ForMaDebug forma_debug_parse() {
         const long v = val ? strtol(val, nullptr, 0) : 0;
 #define FD_FLAG(name) if (!strcmp(tok, #name)) { d.name = true; continue; }
         FD_FLAG(sync) FD_FLAG(global_runsort) FD_FLAG(xgather) FD_FLAG(no_small_carry) FD_FLAG(span_groups) FD_FLAG(no_span_groups)
-        FD_FLAG(no_cull) FD_FLAG(no_order) FD_FLAG(no_prezero) FD_FLAG(no_bias) FD_FLAG(no_ras_hist) FD_FLAG(no_packed_copy) FD_FLAG(no_simple_paint) FD_FLAG(force_simple_paint) FD_FLAG(trim_debug) FD_FLAG(force_exchange)
+        FD_FLAG(no_cull) FD_FLAG(force_cull) FD_FLAG(no_order) FD_FLAG(no_prezero) FD_FLAG(no_bias) FD_FLAG(no_ras_hist) FD_FLAG(no_packed_copy) FD_FLAG(no_simple_paint) FD_FLAG(force_simple_paint) FD_FLAG(trim_debug) FD_FLAG(force_exchange)
 #undef FD_FLAG
         if (!strcmp(tok, "xchg")) { d.xchg_copy = val && !strcmp(val, "copy"); continue; }
         if (!strcmp(tok, "carry_slices")) { d.carry_slices = (int)v; continue; }
         if (!strcmp(tok, "digit_bits")) { d.digit_bits = (int)v; continue; }
         if (!strcmp(tok, "carry_half")) { d.carry_half = (int)std::max(v, 0L); continue; }
+        if (!strcmp(tok, "sort_cus")) { d.sort_cus = (int)std::max(v, 0L); continue; }
         if (!strcmp(tok, "order_thr")) { d.order_thr = (int)std::max(v, 0L); continue; }
         if (!strcmp(tok, "paint_quad")) { d.paint_quad = (int)std::max(v, 0L); continue; }
         if (!strcmp(tok, "strip_tiles")) { d.strip_tiles = (int)std::max(v, 0L); continue; }

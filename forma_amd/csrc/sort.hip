@@ -575,7 +575,7 @@ RasHist make_ras_hist(const SortPlan& plan, uint32_t* sort_scratch) {
 const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a, uint64_t* b, DevCount nc,
                                   const SortPlan& plan, int digit_bits, uint32_t* scratch, uint32_t* err,
                                   const ChunkedSrc* chunked, FrameInfo* info,
-                                  bool scratch_is_zero, bool hist_ready) {
+                                  bool scratch_is_zero, bool hist_ready, uint32_t max_workgroups) {
     const size_t n = nc.bound;                        // provisioning (grid, scratch); the kernels use the device count
     if (n <= 1 || plan.n_passes == 0) return in;
     const uint32_t ntiles = (uint32_t)((n + OS_TILE_MIN - 1) / OS_TILE_MIN);     // (row stride of the status words: sort_zero_words)
@@ -591,7 +591,8 @@ const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a
     const ChunkedSrc C = chunked ? *chunked : C0;
     if (chunked) FORMA_LAUNCH(k_sort_hist<true>, dim3(hb), dim3(HS_THREADS), 0, s, in, nc, plan, hist, C, info);
     else if (!(hist_ready && scratch_is_zero)) FORMA_LAUNCH(k_sort_hist<false>, dim3(hb), dim3(HS_THREADS), 0, s, in, nc, plan, hist, C, info);
-    const uint32_t cap = 512u * 512u / OS_THREADS;        // persistent: 16 waves per CU
+    uint32_t cap = 512u * 512u / OS_THREADS;              // persistent: 16 waves per CU
+    if (max_workgroups && max_workgroups < cap) cap = max_workgroups;   // (frames in flight: leave CUs to the other frames' kernels)
     const uint64_t* src = in;
     uint64_t* dst = a;
     for (int p = 0; p < P; p++) {

@@ -515,7 +515,7 @@ def test_kernel_times_of_a_timed_frame(ctx):
     assert starts == sorted(starts)
 
 
-@pytest.mark.parametrize("switch", ["", "no_cull", "strip_tiles=100000000", "no_cull,strip_tiles=0"])
+@pytest.mark.parametrize("switch", ["", "force_cull", "no_cull", "force_cull,strip_tiles=100000000", "no_cull,strip_tiles=0"])
 def test_occlusion_culling_and_strip_painters_change_no_pixel(monkeypatch, switch):
     """The painters drop the entries below a tile's topmost occluder while they build its list (PaintParams::cull), and small
     frames are painted by four strip wavefronts per tile (k_paint_wave<.., NPX = 1>): neither may change a pixel.  Opaque cubics
