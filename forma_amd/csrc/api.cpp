@@ -927,6 +927,7 @@ void forma_hip_destroy(forma_hip_ctx* ctx) {
                      &ctx->grp_tab, &ctx->grp_list, &ctx->run_lt, &ctx->pack_list, &ctx->pack_pix, &ctx->cache_written, &ctx->order_buf};
     for (DevBuf* b : all) b->release();
     for (int s = 0; s < ST_COUNT; s++) { (void)hipEventDestroy(ctx->ev0[s]); (void)hipEventDestroy(ctx->ev1[s]); }
+    if (g_ktimer == &ctx->kt) g_ktimer = nullptr;           // (a timed frame of this context that failed between stage_begin and stage_end)
     for (int i = 0; i < ctx->kt.made; i++) { (void)hipEventDestroy(ctx->kt.e0[i]); (void)hipEventDestroy(ctx->kt.e1[i]); }
     if (ctx->h_info) (void)hipHostFree(ctx->h_info);
     if (ctx->h_rows) (void)hipHostFree(ctx->h_rows);
