@@ -195,8 +195,10 @@ int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, boo
 // with one — so only with frame slots).  FORMA_HIP_DEBUG=sort_cus=N sets it (0: all).
 static uint32_t sort_workgroups(const forma_hip_ctx* ctx) {
     if (ctx->dbg.sort_cus >= 0) return (uint32_t)ctx->dbg.sort_cus;
+    // (measured with THREE slots, the setting this library recommends; with four, two half-chip passes hold every CU's LDS while
+    //  the third waits and nothing else gets a CU: 2 627 -> 900 frames/s — so exactly three)
     const forma_hip_ctx* o = ctx->owner ? ctx->owner : ctx;
-    return o->slots.size() > 1 ? SORT_CUS_IN_FLIGHT : 0u;
+    return o->slots.size() == 3 ? SORT_CUS_IN_FLIGHT : 0u;
 }
 
 // Both schedules that shorten ONE frame's painter launch at the price of more work — strips, and the heavy-first order below —
