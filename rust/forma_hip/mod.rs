@@ -166,6 +166,24 @@ impl Renderer {
         out
     }
 
+    /// The kernels of the last `render` call that asked for timings, in launch order: (name, stage, start µs, µs), each timed
+    /// by its own launch (`forma_hip_kernel_times`) — what replaces the reference's host-side `duration!` timers
+    /// (`cpu/renderer.rs:106-223`) when the stages run on the device.
+    pub fn kernel_times(&self) -> Vec<(String, u32, f32, f32)> {
+        // SAFETY: `forma_kernel_time_t` is plain `#[repr(C)]` data; the library writes at most `capacity` entries.
+        let mut raw: Vec<ffi::forma_kernel_time_t> = vec![unsafe { std::mem::zeroed() }; 96];
+        let mut n = 0usize;
+        let rc = unsafe { ffi::forma_hip_kernel_times(self.ctx, raw.as_mut_ptr(), raw.len(), &mut n) };
+        self.check(rc, "forma_hip_kernel_times");
+        raw.truncate(n.min(96));
+        raw.iter()
+            .map(|k| {
+                let name: Vec<u8> = k.name.iter().take_while(|&&c| c != 0).map(|&c| c as u8).collect();
+                (String::from_utf8_lossy(&name).into_owned(), k.stage, k.start_us, k.us)
+            })
+            .collect()
+    }
+
     /// The frame AND its copy into `buffer` are enqueued on the next frame slot (`forma_hip_render_enqueue`); `buffer` must be one
     /// the caller registered with [`Renderer::register`] and must not be read before `sync()` — or before `frames in flight`
     /// further frames have been enqueued.  This is the one call that offers more than `cpu::Renderer`: a presenter that rotates
