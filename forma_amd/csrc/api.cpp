@@ -195,8 +195,8 @@ int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, boo
 // with one — so only with frame slots).  FORMA_HIP_DEBUG=sort_cus=N sets it (0: all).
 static uint32_t sort_workgroups(const forma_hip_ctx* ctx) {
     if (ctx->dbg.sort_cus >= 0) return (uint32_t)ctx->dbg.sort_cus;
-    // (measured with THREE slots, the setting this library recommends; with four, two half-chip passes hold every CU's LDS while
-    //  the third waits and nothing else gets a CU: 2 627 -> 900 frames/s — so exactly three)
+    // (measured, frames/s on all / on 128 CUs: two slots 2 448 / 2 431, three 2 520 / 2 631, four 2 426 / 2 405 — so exactly three,
+    //  the setting this library recommends)
     const forma_hip_ctx* o = ctx->owner ? ctx->owner : ctx;
     return o->slots.size() == 3 ? SORT_CUS_IN_FLIGHT : 0u;
 }

@@ -59,8 +59,9 @@ def child(args):
         c.render(W, H, clear=clear, device_only=True)
     c.sync()
     fps1 = args.frames / (time.perf_counter() - t0)
-    c.set_frames_in_flight(int(os.environ.get("AB_INFLIGHT", "3")))   # (AB_INFLIGHT: slots for the pipelined rate)
-    for _ in range(6):
+    slots = int(os.environ.get("AB_INFLIGHT", "3"))                   # (AB_INFLIGHT: slots for the pipelined rate)
+    c.set_frames_in_flight(slots)
+    for _ in range(3 * slots + 3):                                    # every slot: its synchronous frame, its first read-back-free one, one more
         c.render(W, H, clear=clear, device_only=True)
     c.sync()
     t0 = time.perf_counter()
