@@ -56,6 +56,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+STAGE_KEYS = ("prepare_us", "rasterize_us", "exchange_us", "sort_us", "carry_us", "paint_us")
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2   # wave64 VALU instructions/ns the chip can issue: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles
 PMC_FILES = [os.path.join("profiles", f"r0{r}_pmc_summary.json") for r in (5, 4, 3)]
@@ -444,9 +445,12 @@ def main():
                                                      if workload.startswith("paris") else ""),
                        "canvas": [width, height], "layers": len(comp), "pixel_segments": int(n_segments_full),
                        "frames_in_flight": in_flight, "sharding": sharding_txt, "band_rows": [row0, row1]},
-            "stages_us": {k: round(stage.get(k, 0.0), 1) for k in ("prepare_us", "rasterize_us", "exchange_us", "sort_us", "carry_us", "paint_us", "total_us")},
-            "stages_us_what": "sum of the stage's kernels' own durations (events carried by each launch: no marker overhead); total_us = "
-                              "first kernel start -> last kernel end of a frame, gaps included",
+            "stages_us": {**{k: round(stage.get(k, 0.0), 1) for k in STAGE_KEYS}, "total_us": round(sum(stage.get(k, 0.0) for k in STAGE_KEYS), 1)},
+            "stages_us_what": "a stage = the sum of its kernels' own durations (events carried by each launch: no marker overhead), total_us = "
+                              "the sum of the stages = GPU time of a frame's kernels; compare with fps_render_call.frame_latency_ms (wall time of "
+                              "an untimed call: kernels + the gaps between ten dependent launches + the host's share)",
+            # first kernel start -> last kernel end of a TIMED frame: launches that carry events sit ~3 us further apart than plain ones
+            "timed_frame_span_us": round(stage.get("total_us", 0.0), 1),
             "kernels_us": kernels_us,
             "roofline": roofline,
             "roofline_painter": painter,
