@@ -194,6 +194,8 @@ def test_exchange_local_count_outgrows_its_bound_between_frames():
     (k_owner_scan flags it to every receiver) instead of returning a wrong image; after a re-plan it renders right."""
     import forma_amd
     from forma_amd import sharding, FormaError
+    if "sync" in os.environ.get("FORMA_HIP_DEBUG", ""):
+        pytest.skip("FORMA_HIP_DEBUG=sync: no read-back-free frames, nothing is provisioned from a previous frame")
     W, H = 512, 384
     o, t = scene_tables(S.random_mixed())
     tiles_h = (H + 15) // 16
