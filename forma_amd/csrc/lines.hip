@@ -484,7 +484,9 @@ void launch_block_first(hipStream_t s, const uint32_t* cl_start, uint32_t n_comp
 // of one per pixel segment).  The flat index -> (line, i) map of PrefixScanIter
 // (utils/prefix_scan.rs:30-63) is a binary search over the staged window.
 // ------------------------------------------------------------------------------------------------
+#ifndef RAS_THREADS
 #define RAS_THREADS 256
+#endif
 #define RAS_PER_THREAD (RAS_TILE / RAS_THREADS)
 #define RAS_WIN 256
 
