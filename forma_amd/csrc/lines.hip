@@ -488,7 +488,9 @@ void launch_block_first(hipStream_t s, const uint32_t* cl_start, uint32_t n_comp
 #define RAS_THREADS 256
 #endif
 #define RAS_PER_THREAD (RAS_TILE / RAS_THREADS)
+#ifndef RAS_WIN
 #define RAS_WIN 256
+#endif
 
 __device__ __forceinline__ float find_term(int i, double a_ab, double b_ab, double cd_ab, float a, float b, float c,
                                            float d) {               // rasterizer.rs:32-61
