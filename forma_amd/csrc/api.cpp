@@ -555,7 +555,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     if (ctx->order_enable && bound_j && a.cache_id < 0 && !strips && !ctx->dbg.no_order && jc.bound > 0 && tiles_painted && !ctx->order_off &&
         tiles_painted <= 16u * PAINT_STRIP_TILES && (one_frame_in_flight(ctx) || ctx->dbg.order_thr >= 0)) {
         // (heavy section: an eighth of the band's tiles, as PAINT_ORDER_SUBS lists of equal capacity)
-        const size_t per = (tiles_painted + 7) / 8, hcap = std::max<size_t>((per / 8 + PAINT_ORDER_SUBS - 1) / PAINT_ORDER_SUBS, 2) * PAINT_ORDER_SUBS;
+        const size_t per = paint_band_tiles(P.crop_y1 > P.crop_y0 ? P.crop_y1 - P.crop_y0 : 0u, tiles_w), hcap = std::max<size_t>((per / 8 + PAINT_ORDER_SUBS - 1) / PAINT_ORDER_SUBS, 2) * PAINT_ORDER_SUBS;
         const size_t set_words = PAINT_ORDER_WORDS + 8 * hcap + (8 * per + 3) / 4;      // counts | lists | one flag byte per tile
         if (ctx->order_buf.cap < 2 * set_words * 4) { HIPCHECK(ctx->order_buf.ensure(2 * set_words * 4)); ctx->order_cur = -1; }
         const forma_hip_ctx::OrderSig sig{tiles_w, tiles_h, P.crop_x0, P.crop_x1, P.crop_y0, P.crop_y1};

@@ -341,6 +341,21 @@ void launch_pack_written(hipStream_t s, const uint8_t* written, uint32_t tiles_w
 uint32_t carry_rows_local_cap();      // most runs a workgroup of launch_carry_rows(local_sort = true) sorts in LDS: large variant ...
 uint32_t carry_rows_small_cap();      // ... small variant (several workgroups per CU)
 uint32_t carry_rows_half_cap();       // ... its 512-lane form
+// Tiles per XCD "band" of the wave painters' grid (workgroup b runs on XCD b % 8).  PAINT_ROW_XCD = 1: band x = the tile rows x,
+// x + 8, ... of the crop: the rows of a frame are spread over all eight XCDs from the first workgroup on (1/8 band of the 4K
+// scene: painter 55.5 -> 48.1 us, whole frame 106.4 -> 103.9; dealing k_runs_wave's tiles to the same XCD as their row — so that the
+// records would be read from the L2 they were written to — changed nothing: the gain is the dispatch order, not cache affinity);
+// 0: eight contiguous bands of tiles (rounds 1-4).
+#ifndef PAINT_ROW_XCD
+#define PAINT_ROW_XCD 1
+#endif
+static inline uint32_t paint_band_tiles(uint32_t rows, uint32_t tiles_w) {
+#if PAINT_ROW_XCD
+    return ((rows + 7u) / 8u) * tiles_w;
+#else
+    return (rows * tiles_w + 7u) / 8u;
+#endif
+}
 #define PAINT_ORDER_SUBS  64u          // heavy lists per XCD band of the painters' order (PaintParams::order_*): appends spread over
 #define PAINT_ORDER_WORDS (8u * PAINT_ORDER_SUBS)   // 512 counters — one address takes ~150 ns per returning atomic, one after the other
 #define CR_MAX_SLICES_HOST 8u         // workgroups that may share one tile row

@@ -296,14 +296,15 @@ __global__ __launch_bounds__(RW_THREADS) void k_runs_wave(const uint64_t* __rest
     __shared__ uint32_t s_jb[RW_WAVES];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t n = dev_count(nc);
-    if (blockIdx.x * RN_TILE >= n) return;                             // whole workgroup: the grid was sized for the bound
+    const uint32_t tb = blockIdx.x;                                     // this workgroup's 2 048-segment tile
+    if ((uint64_t)tb * RN_TILE >= n) return;                           // whole workgroup: the grid was sized for the bound
     RunWaveLds& L = s_w[w];
     if (tid < RN_ROWS) s_rows[tid] = 0;
 
     // ---- the lane's 8 segments (64 contiguous bytes: four independent 16-byte loads) and the key in front of them.
     //      A lane past the end reads the stream's head instead; one that straddles the end over-reads by less than 64
     //      bytes, which the segment buffers are padded for.  Both are patched below.
-    const uint32_t cbase = blockIdx.x * RN_TILE + w * RW_CHUNK;        // first segment of the wave's chunk
+    const uint32_t cbase = tb * RN_TILE + w * RW_CHUNK;        // first segment of the wave's chunk
     const uint32_t g0 = cbase + lane * RW_SEGS;
     const uint32_t chunk_n = cbase < n ? min((uint32_t)RW_CHUNK, n - cbase) : 0u;
     uint32_t lo[RW_SEGS], hi[RW_SEGS];
@@ -316,18 +317,18 @@ __global__ __launch_bounds__(RW_THREADS) void k_runs_wave(const uint64_t* __rest
         for (int q = 0; q < RW_SEGS / 2; q++) { lo[2 * q] = t[q].x; hi[2 * q] = t[q].y; lo[2 * q + 1] = t[q].z; hi[2 * q + 1] = t[q].w; }
     }
     const uint64_t k_before = (lane == 0 && cbase > 0 && cbase < n) ? sorted[cbase - 1] : 0ull;
-    const uint32_t row0_tyb = (uint32_t)(sorted[blockIdx.x * RN_TILE] >> 53);
+    const uint32_t row0_tyb = (uint32_t)(sorted[tb * RN_TILE] >> 53);
     // run index of this tile's first head = sum of the head counts of the tiles before it (the count array is L2-resident:
     // every workgroup adds it up itself, which saves a scan launch; big frames get it pre-scanned).  Issued AFTER the segment
     // loads and eight loads at a time: a one-load-per-round-trip loop here was most of a workgroup's life.
     uint32_t jnext = 0;                                                 // dense index of the chunk's next paintable head
-    if (counts_scanned) jnext = run_counts[blockIdx.x];
+    if (counts_scanned) jnext = run_counts[tb];
     else {
         uint32_t acc = 0;
-        for (uint32_t i0 = 0; i0 < blockIdx.x; i0 += 8 * RW_THREADS) {
+        for (uint32_t i0 = 0; i0 < tb; i0 += 8 * RW_THREADS) {
             uint32_t c[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) { const uint32_t i = i0 + k * RW_THREADS + tid; c[k] = i < blockIdx.x ? run_counts[i] : 0u; }
+            for (int k = 0; k < 8; k++) { const uint32_t i = i0 + k * RW_THREADS + tid; c[k] = i < tb ? run_counts[i] : 0u; }
 #pragma unroll
             for (int k = 0; k < 8; k++) acc += c[k];
         }
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(RW_THREADS) void k_runs_wave(const uint64_t* __rest
         if (lane == 0) s_jb[w] = acc;
     }
     {                                                                   // + the heads of the tile's earlier chunks
-        uint32_t c = (lane < w) ? chunk_counts[(blockIdx.x * RN_TILE >> 9) + lane] : 0u;           // w <= 3 loads
+        uint32_t c = (lane < w) ? chunk_counts[(tb * RN_TILE >> 9) + lane] : 0u;           // w <= 3 loads
         c += __shfl_xor(c, 1, 64); c += __shfl_xor(c, 2, 64);
         jnext += (uint32_t)__builtin_amdgcn_readlane((int)c, 0);
     }
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(RW_THREADS) void k_runs_wave(const uint64_t* __rest
     if (!counts_scanned) {
 #pragma unroll
         for (int q = 0; q < RW_WAVES; q++) jnext += s_jb[q];
-        if (tid == 0 && blockIdx.x == (n + RN_TILE - 1) / RN_TILE - 1) info->n_runs = jnext + run_counts[blockIdx.x];
+        if (tid == 0 && tb == (n + RN_TILE - 1) / RN_TILE - 1) info->n_runs = jnext + run_counts[tb];
     }
     // first tile row any head of this tile can have (rows are non-decreasing along the stream)
     const uint32_t row0 = row0_tyb ? row0_tyb - 1u : 0u;
@@ -484,9 +485,9 @@ void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t ti
         if (scanned) launch_scan_small_u32(s, scratch, nc, RN_TILE, &info->n_runs);   // exclusive, in place; total -> n_runs
     }
     if (what & 2)
-    FORMA_LAUNCH(k_runs_wave, dim3(ntiles), dim3(RW_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, records, rec_cap,
-                       run_keys, tile_first_run, blk_edge, row_tab, (const uint32_t*)scratch, scanned,
-                       (const uint32_t*)chunk_counts, info, rs);
+        FORMA_LAUNCH(k_runs_wave, dim3(ntiles), dim3(RW_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, records, rec_cap,
+                           run_keys, tile_first_run, blk_edge, row_tab, (const uint32_t*)scratch, scanned,
+                           (const uint32_t*)chunk_counts, info, rs);
 }
 uint32_t runs_edge_segments() { return RW_CHUNK; }
 uint32_t runs_count_tiles(size_t n, bool* scanned) { const uint32_t t = (uint32_t)((n + RN_TILE - 1) / RN_TILE); *scanned = t > 16384; return t; }
@@ -2041,7 +2042,8 @@ __global__ __launch_bounds__(64, NPX == 1 ? PAINT_STRIP_OCC : (SIMPLE ? PAINT_SI
     // one-wave workgroups (a wave's slot frees as soon as ITS tile is done).  XCD-aware mapping: workgroup b runs on
     // XCD b % 8; give each XCD a contiguous band of tiles so a tile row's records / spans stay in one L2
     // Only the crop's tile rows are launched (a multi-GPU rank paints its band only).
-    const uint32_t tile0 = P.crop_y0 * P.tiles_w, T = (P.crop_y1 - P.crop_y0) * P.tiles_w, per = (T + 7) / 8;
+    const uint32_t tile0 = P.crop_y0 * P.tiles_w, T = (P.crop_y1 - P.crop_y0) * P.tiles_w;
+    const uint32_t per = PAINT_ROW_XCD ? ((P.crop_y1 - P.crop_y0 + 7u) / 8u) * P.tiles_w : (T + 7u) / 8u;
     const uint32_t bid = blockIdx.x;
     // (strips: the four wavefronts of a tile are consecutive workgroups of ONE XCD — they read the same records and segments)
     const uint32_t kx = NPX == 1 ? (bid >> 5) : (bid >> 3);
@@ -2051,7 +2053,12 @@ __global__ __launch_bounds__(64, NPX == 1 ? PAINT_STRIP_OCC : (SIMPLE ? PAINT_SI
     const bool ordered = NPX == 4 && P.order_cnt_out != nullptr;
     const uint32_t hcap = ordered ? P.order_hcap : 0u;
     if (kx >= per + hcap) return;
+#if PAINT_ROW_XCD
+    const uint32_t band_rows = (P.crop_y1 - P.crop_y0) > (bid & 7u) ? ((P.crop_y1 - P.crop_y0) - (bid & 7u) + 7u) / 8u : 0u;
+    const uint32_t band0 = (bid & 7u) * per, band_n = band_rows * P.tiles_w;
+#else
     const uint32_t band0 = (bid & 7u) * per, band_n = band0 < T ? min(per, T - band0) : 0u;
+#endif
     uint32_t tin;
     unsigned long long ord_t0 = 0;
     if (ordered) {
@@ -2085,7 +2092,11 @@ __global__ __launch_bounds__(64, NPX == 1 ? PAINT_STRIP_OCC : (SIMPLE ? PAINT_SI
             P.order_flag_out[band0 + tin] = heavy;
         }
     };
+#if PAINT_ROW_XCD
+    const uint32_t tidx = ((bid & 7u) + 8u * (tin / P.tiles_w)) * P.tiles_w + tin % P.tiles_w;
+#else
     const uint32_t tidx = band0 + tin;
+#endif
     const uint32_t tile = tile0 + tidx;
     const uint32_t ty = tile / P.tiles_w, tx = tile - ty * P.tiles_w;
     if (tx < P.crop_x0 || tx >= P.crop_x1 || ty < P.crop_y0 || ty >= P.crop_y1) { tile_done(); return; }   // print_row :588-592, :525-529
@@ -2866,7 +2877,7 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
                   uint32_t* overflow_list, uint32_t* over2_n, uint32_t* over2_list, bool launch_deep, SpanGroups groups, bool strips, bool quads) {
     const uint32_t T = p.tiles_w * p.tiles_h;
     if (T == 0 || p.crop_y1 <= p.crop_y0) return;
-    const uint32_t per = ((p.crop_y1 - p.crop_y0) * p.tiles_w + 7) / 8;
+    const uint32_t per = paint_band_tiles(p.crop_y1 - p.crop_y0, p.tiles_w);
     static const ForMaDebug dbg = forma_debug_parse();               // FORMA_HIP_DEBUG (debug.h), process-wide for these two
     static const bool no_simple = dbg.no_simple_paint;               // (A/B switches for tools/)
     static const bool force_simple = dbg.force_simple_paint;         // (timing experiments only: wrong pixels on other scenes)
