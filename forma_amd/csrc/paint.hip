@@ -2564,6 +2564,9 @@ __global__ __launch_bounds__(64, NPX == 1 ? PAINT_STRIP_OCC : (SIMPLE ? PAINT_SI
 // No buffer-layer cache (the host keeps k_paint_wave for cache frames), no clips (SIMPLE).
 // ================================================================================================
 #define QE 16             // entries per tile = lanes per group
+#ifndef QUAD_ROW_XCD
+#define QUAD_ROW_XCD 1
+#endif
 template <bool ONE_SLICE>
 __global__ __launch_bounds__(64, PAINT_SIMPLE_OCC) void k_paint_quad(PaintParams P, const uint64_t* __restrict__ sorted,
                                                                     const TileRecord* __restrict__ records, DevCount nc_runs,
@@ -2583,12 +2586,20 @@ __global__ __launch_bounds__(64, PAINT_SIMPLE_OCC) void k_paint_quad(PaintParams
     const uint32_t n_runs = dev_count(nc_runs);
     // a quad = four consecutive tiles of one row (always inside one tile-column group: 4 divides SPAN_GROUP_TILES); XCD-aware
     // like k_paint_wave: workgroup b runs on XCD b % 8, every XCD a contiguous band of quads
-    const uint32_t qw = (P.tiles_w + 3u) / 4u, Q = (P.crop_y1 - P.crop_y0) * qw, per = (Q + 7u) / 8u;
+    const uint32_t qw = (P.tiles_w + 3u) / 4u;
     const uint32_t bid = blockIdx.x;
+#if QUAD_ROW_XCD
+    // (the rows dealt over the XCDs like k_paint_wave's: band x = the rows x, x + 8, ...)
+    const uint32_t qrow = (bid & 7u) + 8u * ((bid >> 3) / qw), qx = (bid >> 3) % qw;
+    if (qrow >= P.crop_y1 - P.crop_y0) return;
+    const uint32_t ty = P.crop_y0 + qrow;
+#else
+    const uint32_t Q = (P.crop_y1 - P.crop_y0) * qw, per = (Q + 7u) / 8u;
     if ((bid >> 3) >= per) return;
     const uint32_t qidx = (bid & 7u) * per + (bid >> 3);
     if (qidx >= Q) return;
     const uint32_t ty = P.crop_y0 + qidx / qw, qx = qidx % qw;
+#endif
     const uint32_t tx = qx * 4u + (uint32_t)g;                          // this group's tile
     const bool t_in = tx < P.tiles_w && tx >= P.crop_x0 && tx < P.crop_x1;   // (a tile outside the canvas / the crop: its group idles)
     const uint32_t tile = ty * P.tiles_w + min(tx, P.tiles_w - 1u);
@@ -2887,7 +2898,8 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
     if (cache.tiles) strips = false;
     // quads (k_paint_quad: four tiles per wavefront): all-solid scenes with shallow tiles, no cache
     if (quads && simple && !cache.tiles) {
-        const uint32_t qper = ((p.crop_y1 - p.crop_y0) * ((p.tiles_w + 3u) / 4u) + 7u) / 8u;
+        const uint32_t qper = QUAD_ROW_XCD ? ((p.crop_y1 - p.crop_y0 + 7u) / 8u) * ((p.tiles_w + 3u) / 4u)
+                                            : ((p.crop_y1 - p.crop_y0) * ((p.tiles_w + 3u) / 4u) + 7u) / 8u;
         if (one) FORMA_LAUNCH(k_paint_quad<true>, dim3(qper * 8), dim3(64), 0, s, p, sorted, records, n_runs, tile_first_run, row_span_lo, row_span_cnt,
                               span_key, span_cov, layer_col, image, info, overflow_n, overflow_list, launch_deep ? 1u : 0u, groups);
         else FORMA_LAUNCH(k_paint_quad<false>, dim3(qper * 8), dim3(64), 0, s, p, sorted, records, n_runs, tile_first_run, row_span_lo, row_span_cnt,
