@@ -57,8 +57,8 @@ int frame_tail(forma_hip_ctx* ctx, bool to_host_info, uint32_t* host_count) {
     const bool timed = ctx->stage_used[ST_PAINT];         // (a timed frame books the tail on the paint stage)
     stage_begin(ctx, ST_PAINT, timed);
     launch_frame_tail(ctx->stream, ctx->info.as<FrameInfo>(), to_host_info ? ctx->h_info : nullptr, host_count,
-                      ctx->order_cnt_dev, ctx->order_keep_dev);
-    ctx->order_cnt_dev = nullptr; ctx->order_keep_dev = nullptr;
+                      ctx->order_cnt_dev, ctx->order_keep_dev, ctx->chain_rows, ctx->n_chain_rows);
+    ctx->order_cnt_dev = nullptr; ctx->order_keep_dev = nullptr; ctx->chain_rows = nullptr; ctx->n_chain_rows = 0;
     stage_end(ctx, ST_PAINT, timed);
     HIPCHECK(hipGetLastError());
     ctx->info_clean = true;
@@ -255,13 +255,16 @@ int plan_zero_jobs(forma_hip_ctx* ctx, uint32_t width, uint32_t height, uint32_t
     const uint32_t tiles_w = (width + 15) / 16, tiles_h = (height + 15) / 16;
     const SortPlan plan = frame_sort_plan(ctx, ctx->pred_live44, ctx->pred_layer_sorted, ctx->digit_bits, true, nullptr);
     HIPCHECK(ctx->sort_counters.ensure(sort_scratch_words(std::max<size_t>(sort_n, 1)) * 4));
-    HIPCHECK(ctx->row_tab.ensure(((size_t)row_tab_zero_words(tiles_w, tiles_h) + 3 * (size_t)tiles_w * tiles_h) * 4));
-    (void)runs_n;
+    HIPCHECK(ctx->row_tab.ensure(row_tab_total_words(tiles_w, tiles_h) * 4));
+    HIPCHECK(ctx->runs_scratch.ensure(runs_scratch_words(std::max<size_t>(runs_n, 1)) * 4));
     const size_t sw = sort_n > 1 && plan.n_passes ? sort_zero_words(sort_n, plan) : 0;
     const size_t tw = row_tab_zero_words(tiles_w, tiles_h);
     if (sw > 0xFFFFFFFFull || tw > 0xFFFFFFFFull) return FORMA_OK;           // (absurd sizes: the stages clear for themselves)
     if (sw) { Z->p[Z->n] = ctx->sort_counters.as<uint32_t>(); Z->words[Z->n++] = (uint32_t)sw; cleared->sort_p = ctx->sort_counters.p; cleared->sort_words = sw; }
     Z->p[Z->n] = ctx->row_tab.as<uint32_t>(); Z->words[Z->n++] = (uint32_t)tw; cleared->tab_p = ctx->row_tab.p; cleared->tab_words = tw;
+    // (the status words of the chained run kernel: a word per 2 048 segments)
+    const size_t cw = runs_n ? runs_chain_words(runs_n) : 0;
+    if (cw && cw <= 0xFFFFFFFFull) { Z->p[Z->n] = ctx->runs_scratch.as<uint32_t>(); Z->words[Z->n++] = (uint32_t)cw; cleared->chain_p = ctx->runs_scratch.p; cleared->chain_words = cw; }
     return FORMA_OK;
 }
 
@@ -332,6 +335,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     const uint32_t tiles_w = (a.width + 15) / 16, tiles_h = (a.height + 15) / 16;
     const uint32_t T = tiles_w * tiles_h;
     ctx->img_w = a.width; ctx->img_h = a.height;
+    ctx->chain_rows = nullptr; ctx->n_chain_rows = 0;
     // where this frame is painted: the cache's own image (it must keep what its buffer showed last frame) or the scratch one
     TileCacheArgs tc{nullptr, nullptr};
     uint32_t clear_unchanged = 0;
@@ -358,7 +362,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     // [row_span_lo | row_span_cnt: one pair per (row, slice of the carry pre-pass), 8 tiles_h + 1 each] [painter overflow
     // counters: wave -> deep, deep -> huge] [first-run table, T words]; the painter's overflow lists (T words of tiles, 2 T
     // words of {tile, entries}) follow un-zeroed
-    HIPCHECK(ctx->row_tab.ensure(((size_t)row_tab_zero_words(tiles_w, tiles_h) + 3 * (size_t)T) * 4));
+    HIPCHECK(ctx->row_tab.ensure(row_tab_total_words(tiles_w, tiles_h) * 4));
     FrameInfo* dinfo = ctx->info.as<FrameInfo>();
     uint32_t* row_count = ctx->row_tab.as<uint32_t>();
     uint32_t* row_span_lo = row_count + (tiles_h + 1);
@@ -369,17 +373,31 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     uint32_t* order_cnt = tile_first_run + T;                           // ... the painters' order counts (PaintParams::order_cnt_out) ...
     uint32_t* overflow_list = order_cnt + PAINT_ORDER_WORDS;            // ... then the lists themselves
     uint32_t* over2_list = overflow_list + T;
+    uint32_t* row_base = over2_list + 2 * (size_t)T;                    // (chain numbering: where each row's runs begin)
     uint32_t J = 0;
     HIPCHECK(ctx->blk_edge.ensure(runs_blocks(std::max<size_t>(n, 1)) * sizeof(BlkEdge)));
     HIPCHECK(ctx->runs_scratch.ensure(runs_scratch_words(std::max<size_t>(n, 1)) * 4));
     stage_begin(ctx, ST_CARRY, timing);
     const bool tables_zero = ctx->pz.tab_p == ctx->row_tab.p && ctx->pz.tab_words >= row_tab_zero_words(tiles_w, tiles_h);
     ctx->pz.tab_p = nullptr;
+    // the rows' runs are ordered inside k_carry_rows when they fit its LDS; else by a global sort
+    // (the in-LDS key holds 16 layer bits: every order a geom can produce has to fit, not just the style table)
+    bool local_sort = ctx->n_orders <= 65536 && ctx->max_geom_order < 65536 && !ctx->global_runsort;
+    // A read-back-free frame whose rows are ordered in LDS needs no dense run numbering (the global run sort does): its runs are
+    // found by ONE kernel, numbered per tile row from the index of the row's first segment (launch_runs' chain) — no counting
+    // pass, the sorted stream is read once less.  The record arrays are then indexed like the segments: provisioned for N.
+    // It pays while the run kernel's workgroups are all resident at once (1080p: 9.8 + 15.3 -> 19.6 us, a 17-row band of the 4K
+    // scene: 8.2 + 14.6 -> 16.0): the look-back is a round trip that a workgroup of 15 us cannot hide, and a frame of several
+    // rounds of workgroups pays it in every round (4K: 23.8 + 52.8 -> 84.8 us, 8K: 16.4 + 31.0 -> 54.5) — those keep the counting pass.
+    const bool chain = bound_j != 0 && n > 0 && local_sort && ctx->pred_max_row <= carry_rows_local_cap() &&
+                       (ctx->dbg.runs_chain < 0 ? (RUNS_CHAIN_DEFAULT != 0 && runs_chain_words(n) <= RUNS_CHAIN_MAX_TILES) : ctx->dbg.runs_chain != 0);
+    const bool chain_zero = chain && ctx->pz.chain_p == ctx->runs_scratch.p && ctx->pz.chain_words >= runs_chain_words(n);
+    ctx->pz.chain_p = nullptr;
     // Records, run keys and digests are sized for the RUNS, not for the segments (a run needs a segment, so N would always do:
     // 440 MB of records per frame slot on the 4K scene, for 21 MB of runs).  A read-back-free frame has its bound from the last
     // verified frame; a synchronous one launches the counting kernel, reads the count and sizes the buffers before the kernel
     // that fills them.
-    size_t cap = std::max<size_t>(bound_j, 1);
+    size_t cap = std::max<size_t>(chain ? n : bound_j, 1);
     auto runs = [&](int what) {
         launch_runs(ctx->stream, ctx->sorted, nc, tiles_w, tiles_h, ctx->records.as<TileRecord>(), (uint32_t)cap,
                     ctx->rk_u.as<uint64_t>(), tile_first_run, ctx->blk_edge.as<BlkEdge>(), row_count,
@@ -387,7 +405,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                     ctx->layer_sorted, ctx->pending_masks,
                     RunStyle{ctx->layer_sf.as<uint32_t>(), (uint32_t)ctx->n_orders,
                              (a.cache_id >= 0 && ctx->have_unchanged) ? ctx->unchanged.as<uint8_t>() : nullptr, ctx->run_lt.as<uint32_t>()},
-                    tables_zero, ctx->sort_range, ctx->sort_range_n, what);
+                    tables_zero, ctx->sort_range, ctx->sort_range_n, what, chain ? row_base : nullptr, chain_zero);
     };
     if (!bound_j && n > 0) {
         runs(1);
@@ -405,16 +423,13 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
         cap = std::max<size_t>(std::min<uint64_t>(total, n), 1);
     }
     HIPCHECK(ctx->records.ensure(cap * sizeof(TileRecord)));
-    HIPCHECK(ctx->rk_u.ensure(cap * 8));
+    HIPCHECK(ctx->rk_u.ensure((chain ? 1 : cap) * 8));                  // (the global run sort's keys)
     HIPCHECK(ctx->run_lt.ensure(cap * 4));
     runs(bound_j || n == 0 ? 3 : 2);
     ctx->sort_range = nullptr;
     ctx->pending_masks = PendingMasks{nullptr, 0u};
     HIPCHECK(hipGetLastError());
     DevCount jc;
-    // the runs of a tile row are ordered by (layer, tile_x) inside k_carry_rows when they fit its LDS; else by a global sort
-    // (the in-LDS key holds 16 layer bits: every order a geom can produce has to fit, not just the style table)
-    bool local_sort = ctx->n_orders <= 65536 && ctx->max_geom_order < 65536 && !ctx->global_runsort;
     // Several workgroups share a tile row, each a range of layers (k_carry_rows): as many as keep the chip busy for the rows
     // this frame paints (a multi-GPU band is a fraction of the canvas).  The small-LDS variant (a quarter of the keys per workgroup) is a
     // read-back-free frame's guess — its slices must fit 4096 runs, known only from a previous frame; a slice that does not
@@ -433,7 +448,8 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     uint32_t n_slices = 1;
     bool small = false, half = false;
     if (bound_j) {
-        jc = DevCount{&dinfo->n_runs, bound_j};
+        jc = chain ? DevCount{nullptr, (uint32_t)n} : DevCount{&dinfo->n_runs, bound_j};   // (chain: run indices are segment indices)
+        if (chain) { ctx->chain_rows = row_count; ctx->n_chain_rows = tiles_h; }
         local_sort = local_sort && ctx->pred_max_row <= carry_rows_local_cap();     // wrong guess -> plan_bad -> synchronous re-run
         const uint32_t pmr = ctx->pred_max_row == 0xFFFFFFFFu ? 0u : ctx->pred_max_row;
         n_slices = slices_for(256u, pmr);
@@ -544,6 +560,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     P.cull = cull ? 1u : 0u;
     // heaviest tiles first (PaintParams::order_*): read-back-free frames without a cache, one wavefront per tile
     P.order_cnt_in = nullptr; P.order_list_in = nullptr; P.order_cnt_out = nullptr; P.order_list_out = nullptr;
+    P.row_base = chain ? row_base : nullptr; P.row_cnt = chain ? row_count : nullptr;
     ctx->order_pending = -1; ctx->order_cnt_dev = nullptr; ctx->order_keep_dev = nullptr;
     const uint32_t tiles_painted = (P.crop_y1 > P.crop_y0 ? P.crop_y1 - P.crop_y0 : 0u) * tiles_w;
     const bool strips = paint_by_strips(ctx, tiles_painted);
@@ -591,7 +608,8 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                           // unless alpha lands in bytes 0..2 or a colour in byte 3, and an invisible layer can block the fold
                           (a.cache_id < 0 && (a.height & 15u) && fold_equals_paint) ? (a.height & 15u) : 16u, crow0, crow1, groups, ctx->run_lt.as<uint32_t>(),
                           cull,
-                          (a.cache_id >= 0 || !fold_equals_paint) ? (a.crop ? a.crop->x0 / 16 : 0u) : 0xFFFFFFFFu);
+                          (a.cache_id >= 0 || !fold_equals_paint) ? (a.crop ? a.crop->x0 / 16 : 0u) : 0xFFFFFFFFu,
+                          chain ? row_base : nullptr);
     stage_end(ctx, ST_CARRY, timing);
     stage_begin(ctx, ST_PAINT, timing);
     launch_paint(ctx->stream, P, ctx->sorted, ctx->records.as<TileRecord>(), jc, tile_first_run, row_span_lo,
@@ -599,7 +617,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                  ctx->style_off.as<uint32_t>(),
                  ctx->style_words.as<uint32_t>(), ctx->images.as<forma_image_t>(), ctx->texels.as<uint16_t>(),
                  ctx->cur_image, tc, dinfo, paint_overflow, overflow_list, over2_n, over2_list, launch_deep, groups,
-                 strips, paint_by_quads(ctx, a.cache_id, jc.bound, tiles_painted));
+                 strips, paint_by_quads(ctx, a.cache_id, chain ? bound_j : jc.bound, tiles_painted));
     stage_end(ctx, ST_PAINT, timing);
     ctx->last_runs = J; ctx->last_entries = 0;
     HIPCHECK(hipGetLastError());

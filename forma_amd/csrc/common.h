@@ -99,7 +99,12 @@ struct PaintParams {
     const uint32_t* order_cnt_in;  const uint32_t* order_list_in;  const uint8_t* order_flag_in;
     uint32_t*       order_cnt_out; uint32_t*       order_list_out; uint8_t*       order_flag_out;
     uint32_t        order_hcap, order_thr;
+    // launch_runs' chain numbering (row_base != nullptr): the runs of tile row y are records[row_base[y] .. + row_cnt[y]), and what
+    // lies between two rows' ranges is stale — a tile's probes end with its ROW, not with the frame's run count
+    const uint32_t* row_base; const uint32_t* row_cnt;
 };
+// the end of the records a tile of row `ty` may probe
+#define PAINT_RUN_END(P, ty, n_runs) ((P).row_base ? (P).row_base[ty] + (P).row_cnt[ty] : (n_runs))
 
 // The spans of a tile row, a second time, by TILE-COLUMN GROUP: k_carry_rows appends to the row's (layer, tile_x)-ordered span
 // list one list per group of SPAN_GROUP_TILES tile columns holding ready-made painter entries of the spans that overlap the
@@ -311,7 +316,12 @@ void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount n, uint32_t til
                  const uint32_t* range_records /* nullable: sort_range_words() of the sort that produced `sorted` ... */,
                  uint32_t n_range_records /* ... and sort_hist_blocks() of its key count */,
                  int what = 3 /* bit 0: k_runs_count (per-tile head counts into `scratch`), bit 1: k_runs_wave (the records) — a
-                                 synchronous frame reads the count back in between and sizes the records for it */);
+                                 synchronous frame reads the count back in between and sizes the records for it */,
+                 uint32_t* chain_row_base = nullptr /* tiles_h + 1 words.  Not null: ONE kernel, no counting pass — runs are numbered per
+                                 tile row from the index of the row's first segment (here: where each row begins), `records` and
+                                 the arrays indexed like it hold n.bound entries, the run count is the sum of the row counts */,
+                 bool chain_status_is_zero = false /* the first runs_chain_words(n.bound) words of `scratch` were cleared by an earlier kernel */);
+size_t runs_chain_words(size_t n);
 // the per-tile counts k_runs_count leaves in `scratch`: how many (host sum = J), or — big frames — already scanned (J = info->n_runs)
 uint32_t runs_count_tiles(size_t n, bool* scanned);
 uint32_t runs_edge_segments();            // segments per BlkEdge entry
@@ -319,7 +329,9 @@ uint32_t runs_edge_segments();            // segments per BlkEdge entry
 // segment count to a pinned word (`host_count`, nullable), and the device copy returns to its pristine state for the next
 // frame of the stream — one tiny kernel instead of a device-to-host copy here and a device-to-device reset there.
 void launch_frame_tail(hipStream_t s, FrameInfo* info, FrameInfo* host_info, uint32_t* host_count,
-                       const uint32_t* order_cnt = nullptr, uint32_t* order_keep = nullptr /* PAINT_ORDER_WORDS words copied (PaintParams::order_*) */);
+                       const uint32_t* order_cnt = nullptr, uint32_t* order_keep = nullptr /* PAINT_ORDER_WORDS words copied (PaintParams::order_*) */,
+                       const uint32_t* chain_rows = nullptr, uint32_t n_chain_rows = 0 /* launch_runs' chain numbering: the frame's row
+                       counts, summed into the host copy's n_runs */);
 // Words the frame's FIRST kernel clears on behalf of later stages (sort scratch, tile tables): a few hundred
 // KB spread over a grid that exists anyway, instead of two or three memset operations on the stream.
 #define FORMA_ZERO_JOBS 4
@@ -362,7 +374,16 @@ static inline uint32_t paint_band_tiles(uint32_t rows, uint32_t tiles_w) {
 // the frame's tile tables, one buffer: [row_count: tiles_h + 1][row_span_lo: 8 tiles_h + 1][row_span_cnt: 8 tiles_h + 1]
 // [painter overflow counters: 2][first-run table: T][painter order counts: PAINT_ORDER_WORDS] — zeroed every frame by launch_runs —
 // then [overflow list: T][{tile, entries}: 2 T]
+// ... then [where each row's runs begin (launch_runs' chain numbering): tiles_h + 1]
+#ifndef RUNS_CHAIN_DEFAULT
+#define RUNS_CHAIN_DEFAULT 1            // read-back-free frames number their runs per tile row, without the counting pass (debug.h: runs_chain) ...
+#endif
+#ifndef RUNS_CHAIN_MAX_TILES
+#define RUNS_CHAIN_MAX_TILES 1536u      // ... when the stream is at most this many 2 048-segment tiles, i.e. about one round of the run kernel's workgroups
+#endif
+static inline size_t row_tab_total_words(uint32_t tiles_w, uint32_t tiles_h);
 static inline uint32_t row_tab_zero_words(uint32_t tiles_w, uint32_t tiles_h) { return (tiles_h + 1) + 2 * (CR_MAX_SLICES_HOST * tiles_h + 1) + 2 + tiles_w * tiles_h + PAINT_ORDER_WORDS; }
+static inline size_t row_tab_total_words(uint32_t tiles_w, uint32_t tiles_h) { return (size_t)row_tab_zero_words(tiles_w, tiles_h) + 3 * (size_t)tiles_w * tiles_h + tiles_h + 1; }
 // n_slices workgroups per tile row (each a range of layers, 256 bins of layer >> bin_shift); small: the CR_CAP_S variant
 void launch_carry_rows(hipStream_t s, bool local_sort, bool small, bool half /* with small: 512-lane workgroups, slices of <= 2048 runs */,
                        uint32_t n_slices, uint32_t bin_shift,
@@ -378,7 +399,8 @@ void launch_carry_rows(hipStream_t s, bool local_sort, bool small, bool half /* 
                        bool cull /* PaintParams::cull */,
                        uint32_t left_start /* cache frames: the first painted tile column, whose tiles list every layer with segments to
                                               their left (painter/mod.rs:500-522); 0xFFFFFFFF: no cache and a channel order under which a folded tile and a painted one
-                                              are the same bytes — nothing can observe the entry */);
+                                              are the same bytes — nothing can observe the entry */,
+                       const uint32_t* row_base = nullptr /* launch_runs' chain numbering: where each row's runs begin */);
 void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, DevCount n_runs,
                   const uint32_t* tile_first_run, const uint32_t* row_span_lo, const uint32_t* row_span_cnt,
                   const uint64_t* span_key, const uint4* span_cov,

@@ -137,6 +137,8 @@ struct forma_hip_ctx {
     struct PreZero { const void* sort_p = nullptr; size_t sort_words = 0; const void* tab_p = nullptr; size_t tab_words = 0;
                      const void* chain_p = nullptr; size_t chain_words = 0; } pz;
     ForMaDebug dbg;                         // FORMA_HIP_DEBUG as it stood when the context was created
+    const uint32_t* chain_rows = nullptr;   // this frame's runs were numbered per tile row (launch_runs' chain): its row counts, for the
+    uint32_t n_chain_rows = 0;              //   frame tail, which sums them into the host's n_runs
     uint32_t* h_rows = nullptr;             // pinned: runs per tile row (synchronous frames), 2049 words
     uint32_t pred_max_row = 0xFFFFFFFFu;    // most runs in one tile row of the last verified frame (unknown: no local sort)
     // tiles deeper than the painter's LDS lists (finish_paint): the launch arguments of the frame's painter and the scratch lists

@@ -146,29 +146,19 @@ struct RunWaveLds {                       // one wave's slice
     uint32_t start[RW_SLOTS + 2];         // chunk-local index of the first segment of the sweep's slots (+ the end of the last one)
 };
 
-// pass A: paintable run heads per tile (the run index of a tile's first head is the exclusive scan of these)
+// What one workgroup does per frame besides its share of the stream — k_runs_count's workgroup 0, or the extra workgroup of the
+// chained k_runs_wave: the guard on the provisioned count, the tile-field spans (next frame's sort plan), the key masks of the
+// stream (read-back-free frames: one record per producer workgroup, combined here instead of by a launch) and the check of the
+// speculated sort plan.  `first` = this is that workgroup.
 #define RC_THREADS 256
-__global__ __launch_bounds__(RC_THREADS) void k_runs_count(const uint64_t* __restrict__ sorted, DevCount nc, uint32_t tiles_w,
-                                                           uint32_t tiles_h, uint32_t* __restrict__ counts,
-                                                           uint32_t* __restrict__ chunk_counts /* per 512 segments */,
-                                                           uint32_t* __restrict__ zero_base, uint32_t zero_words,
-                                                           FrameInfo* __restrict__ info, uint64_t spec_live44,
-                                                           uint32_t spec_flags /* bit0 verify, bit1 layer_sorted */,
-                                                           PendingMasks pm, const uint32_t* __restrict__ range_records /* nullable: the
-                                                           sort's tile-field spans, one 4-word record per k_sort_hist workgroup */,
-                                                           uint32_t n_range_records) {
-    __shared__ uint32_t s_c[RC_THREADS / 64];
-    __shared__ uint32_t s_red[5][RC_THREADS / 64];
-    const uint32_t n = dev_count(nc);
+__device__ __forceinline__ void runs_housekeeping(const bool first, const uint32_t n, const DevCount nc, FrameInfo* __restrict__ info,
+                                                  const uint64_t spec_live44, const uint32_t spec_flags, const PendingMasks pm,
+                                                  const uint32_t* __restrict__ range_records, const uint32_t n_range_records,
+                                                  uint32_t (*s_red)[RC_THREADS / 64]) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    // housekeeping that would otherwise be separate launches: zero this frame's tile tables (row counts, span tables,
-    // painter overflow counter, first-run table: consumed by k_runs and later), verify the speculated sort plan
     {
-        const uint32_t per = (zero_words + gridDim.x - 1) / gridDim.x;
-        const uint32_t z0 = blockIdx.x * per, z1 = min(zero_words, z0 + per);
-        for (uint32_t i = z0 + tid; i < z1; i += RC_THREADS) zero_base[i] = 0;
-        if (blockIdx.x == 0 && tid == 0 && nc.ptr && *nc.ptr > nc.bound) info->plan_bad = 1u;   // more segments than provisioned
-        if (blockIdx.x == 0 && range_records) {                         // what the tile fields spanned (next frame's sort plan)
+        if (first && tid == 0 && nc.ptr && *nc.ptr > nc.bound) info->plan_bad = 1u;   // more segments than provisioned
+        if (first && range_records) {                         // what the tile fields spanned (next frame's sort plan)
             uint4 m = make_uint4(0u, 0u, 0u, 0u);
             for (uint32_t b = tid; b < n_range_records; b += RC_THREADS) {
                 const uint4 r = *reinterpret_cast<const uint4*>(range_records + (size_t)b * 4);
@@ -181,7 +171,7 @@ __global__ __launch_bounds__(RC_THREADS) void k_runs_count(const uint64_t* __res
             }
             if (lane == 0) { atomicMax(&info->tile_range[0], m.x); atomicMax(&info->tile_range[1], m.y); atomicMax(&info->tile_range[2], m.z); atomicMax(&info->tile_range[3], m.w); }
         }
-        if (blockIdx.x == 0) {
+        if (first) {
             // the key masks of the stream: on read-back-free frames the producer (k_rasterize / k_gather_chunks) left one
             // record per workgroup and nobody needed them combined until now — this workgroup does it instead of a launch
             uint32_t o = 0, oh = 0, a = 0xFFFFFFFFu, ah = 0xFFFFFFFFu, u = 0;
@@ -241,6 +231,30 @@ __global__ __launch_bounds__(RC_THREADS) void k_runs_count(const uint64_t* __res
             }
         }
     }
+}
+
+// pass A: paintable run heads per tile (the run index of a tile's first head is the exclusive scan of these)
+__global__ __launch_bounds__(RC_THREADS) void k_runs_count(const uint64_t* __restrict__ sorted, DevCount nc, uint32_t tiles_w,
+                                                           uint32_t tiles_h, uint32_t* __restrict__ counts,
+                                                           uint32_t* __restrict__ chunk_counts /* per 512 segments */,
+                                                           uint32_t* __restrict__ zero_base, uint32_t zero_words,
+                                                           FrameInfo* __restrict__ info, uint64_t spec_live44,
+                                                           uint32_t spec_flags /* bit0 verify, bit1 layer_sorted */,
+                                                           PendingMasks pm, const uint32_t* __restrict__ range_records /* nullable: the
+                                                           sort's tile-field spans, one 4-word record per k_sort_hist workgroup */,
+                                                           uint32_t n_range_records) {
+    __shared__ uint32_t s_c[RC_THREADS / 64];
+    __shared__ uint32_t s_red[5][RC_THREADS / 64];
+    const uint32_t n = dev_count(nc);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // housekeeping that would otherwise be separate launches: zero this frame's tile tables (row counts, span tables,
+    // painter overflow counter, first-run table: consumed by k_runs and later), verify the speculated sort plan
+    {
+        const uint32_t per = (zero_words + gridDim.x - 1) / gridDim.x;
+        const uint32_t z0 = blockIdx.x * per, z1 = min(zero_words, z0 + per);
+        for (uint32_t i = z0 + tid; i < z1; i += RC_THREADS) zero_base[i] = 0;
+    }
+    runs_housekeeping(blockIdx.x == 0, n, nc, info, spec_live44, spec_flags, pm, range_records, n_range_records, s_red);
     // A pure streaming read, shaped like the copy kernels that reach 6 TB/s on this chip (tools/ubench_bw.hip): 256-lane
     // workgroups in a grid-stride loop, eight 16-byte loads (two consecutive segments each) in flight per lane.  One
     // iteration covers two k_runs tiles (waves 0-1 and 2-3).
@@ -283,6 +297,28 @@ __global__ __launch_bounds__(RC_THREADS) void k_runs_count(const uint64_t* __res
     }
 }
 
+// CHAIN (read-back-free frames whose rows are ordered inside k_carry_rows): there is no counting pass.  Runs are numbered per
+// TILE ROW: the row's first run takes the index of the row's first segment (a run owns a segment, so the rows' ranges cannot
+// overlap; the record arrays are provisioned for N), the others follow densely.  A workgroup counts its own heads during the break
+// walk, publishes them as one status word — the aggregate of its 2 048 segments, or at once the next index of the row its last
+// segment belongs to when that row begins inside the tile — and takes the heads of its predecessors from theirs: a look-back that
+// ends at the tile where the row began, i.e. after N / rows / 2 048 tiles (50 on the 4K scene, 10 on the 8K one), one wave-wide
+// probe, with nothing to wait for but aggregates that are published a few microseconds into a workgroup's life.  (The single chain
+// over all 6 720 tiles of round 4 — see above — needed every predecessor's PREFIX.)  The probe is made LATE, right in front of
+// the first store that needs the index: a wave's predecessors were dispatched less than a microsecond before it, so a probe
+// made when the wave itself has just published finds half of them unpublished and costs a second round trip (measured: the
+// kernel at 112 us instead of 55); by the time the covers are summed and the style words requested they all have.  `status`
+// starts from zero; row_base[row] = where the row begins; the first workgroup of the grid only keeps house (runs_housekeeping).
+struct RunChain {
+    uint32_t*       status;       // one word per 2 048-segment tile, lookback.h's u32 layout
+    uint32_t*       row_base;     // tiles_h + 1 words
+    uint64_t        spec_live44;  // runs_housekeeping's arguments
+    uint32_t        spec_flags;
+    PendingMasks    pm;
+    const uint32_t* range_records;
+    uint32_t        n_range_records;
+};
+template <bool CHAIN>
 __global__ __launch_bounds__(RW_THREADS) void k_runs_wave(const uint64_t* __restrict__ sorted, DevCount nc, uint32_t tiles_w,
                                                           uint32_t tiles_h, TileRecord* __restrict__ records, uint32_t rec_cap,
                                                           uint64_t* __restrict__ run_keys, uint32_t* __restrict__ tile_first_run,
@@ -290,13 +326,19 @@ __global__ __launch_bounds__(RW_THREADS) void k_runs_wave(const uint64_t* __rest
                                                           uint32_t* __restrict__ row_count,
                                                           const uint32_t* __restrict__ run_counts, int counts_scanned,
                                                           const uint32_t* __restrict__ chunk_counts,
-                                                          FrameInfo* __restrict__ info, RunStyle rs) {
+                                                          FrameInfo* __restrict__ info, RunStyle rs, RunChain ch) {
     __shared__ RunWaveLds s_w[RW_WAVES];
     __shared__ uint32_t s_rows[RN_ROWS];
     __shared__ uint32_t s_jb[RW_WAVES];
+    __shared__ uint32_t s_ws[CHAIN ? RW_WAVES : 1][3];                  // CHAIN, per wave: heads | heads from its last row start on | that row start + 1 (0: none)
+    __shared__ uint32_t s_hk[CHAIN ? 5 : 1][RC_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t n = dev_count(nc);
-    const uint32_t tb = blockIdx.x;                                     // this workgroup's 2 048-segment tile
+    if (CHAIN && blockIdx.x == 0) {                                     // (the FIRST workgroup: its round trips run beside the others' work)
+        runs_housekeeping(true, n, nc, info, ch.spec_live44, ch.spec_flags, ch.pm, ch.range_records, ch.n_range_records, s_hk);
+        return;
+    }
+    const uint32_t tb = CHAIN ? blockIdx.x - 1u : blockIdx.x;           // this workgroup's 2 048-segment tile
     if ((uint64_t)tb * RN_TILE >= n) return;                           // whole workgroup: the grid was sized for the bound
     RunWaveLds& L = s_w[w];
     if (tid < RN_ROWS) s_rows[tid] = 0;
@@ -322,7 +364,8 @@ __global__ __launch_bounds__(RW_THREADS) void k_runs_wave(const uint64_t* __rest
     // every workgroup adds it up itself, which saves a scan launch; big frames get it pre-scanned).  Issued AFTER the segment
     // loads and eight loads at a time: a one-load-per-round-trip loop here was most of a workgroup's life.
     uint32_t jnext = 0;                                                 // dense index of the chunk's next paintable head
-    if (counts_scanned) jnext = run_counts[tb];
+    if (CHAIN) {}
+    else if (counts_scanned) jnext = run_counts[tb];
     else {
         uint32_t acc = 0;
         for (uint32_t i0 = 0; i0 < tb; i0 += 8 * RW_THREADS) {
@@ -336,7 +379,7 @@ __global__ __launch_bounds__(RW_THREADS) void k_runs_wave(const uint64_t* __rest
         for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
         if (lane == 0) s_jb[w] = acc;
     }
-    {                                                                   // + the heads of the tile's earlier chunks
+    if (!CHAIN) {                                                       // + the heads of the tile's earlier chunks
         uint32_t c = (lane < w) ? chunk_counts[(tb * RN_TILE >> 9) + lane] : 0u;           // w <= 3 loads
         c += __shfl_xor(c, 1, 64); c += __shfl_xor(c, 2, 64);
         jnext += (uint32_t)__builtin_amdgcn_readlane((int)c, 0);
@@ -367,8 +410,71 @@ __global__ __launch_bounds__(RW_THREADS) void k_runs_wave(const uint64_t* __rest
     const uint32_t R = (uint32_t)__builtin_amdgcn_readlane((int)nb_incl, 63);   // breaks in the chunk = its last slot
     const uint32_t first_hi = (uint32_t)__builtin_amdgcn_readlane((int)hi[0], 0);
     const uint32_t before_hi = (uint32_t)__builtin_amdgcn_readlane((int)phi, 0);
+    if (CHAIN) {
+        // the wave's paintable heads and row starts (both are breaks), from the registers of walk 1
+        uint32_t hm = 0, rm = 0;
+        if (chunk_n) {
+            uint32_t qhi = phi;
+#pragma unroll
+            for (int q = 0; q < RW_SEGS; q++) {
+                if ((bm >> q) & 1u) {
+                    const uint32_t tybq = hi[q] >> 21, txbq = (hi[q] >> 9) & 0xFFFu;
+                    if (tybq - 1u < tiles_h && txbq <= tiles_w) hm |= 1u << q;      // seg_paintable
+                    if ((qhi >> 21) != tybq) rm |= 1u << q;                          // (the stream's first segment: phi = ~hi[0])
+                }
+                qhi = hi[q];
+            }
+        }
+        const uint32_t nh = (uint32_t)__popc(hm);
+        const uint32_t tot = lb_wave_sum(nh);
+        const uint64_t rsl = __ballot(rm != 0u);
+        uint32_t aft = tot, rsp1 = 0;
+        if (rsl) {                                                      // (wave-uniform)
+            const int Ls = 63 - __builtin_clzll(rsl);                   // the lane of the wave's last row start, its segment there
+            const uint32_t rmL = (uint32_t)__shfl((int)rm, Ls, 64);
+            const int ql = 31 - __builtin_clz(rmL);
+            aft = lb_wave_sum(lane > Ls ? nh : (lane == Ls ? (uint32_t)__popc(hm >> ql) : 0u));
+            rsp1 = cbase + (uint32_t)(Ls * RW_SEGS + ql) + 1u;
+        }
+        if (lane == 0) { s_ws[w][0] = tot; s_ws[w][1] = aft; s_ws[w][2] = rsp1; }
+    }
     __syncthreads();
-    if (!counts_scanned) {
+    uint32_t jrow = 0;                                                  // CHAIN: the next run index of the row the wave's next slot continues ...
+    bool lb_pending = false, pfx_pending = false;                       // ... still without the heads of the tiles in front / the tile's PREFIX is this wave's to publish
+    uint32_t pfx_add = 0;
+    if (CHAIN) {
+        uint32_t wt[RW_WAVES], wa[RW_WAVES], wr[RW_WAVES];
+#pragma unroll
+        for (int v = 0; v < RW_WAVES; v++) { wt[v] = s_ws[v][0]; wa[v] = s_ws[v][1]; wr[v] = s_ws[v][2]; }
+        int ul = -1;                                                    // the tile's last wave with a row start
+#pragma unroll
+        for (int v = 0; v < RW_WAVES; v++) if (wr[v]) ul = v;
+        if (w == 0 && lane == 0) {                                      // the tile's status word, before anybody waits for anything
+            uint32_t val = 0, flag = LB_AGG;
+#pragma unroll
+            for (int v = 0; v < RW_WAVES; v++) {
+                if (v == ul) { val = (wr[v] - 1u) + wa[v]; flag = LB_PREFIX; }
+                else if (v > ul) val += wt[v];
+            }
+            lb_st32(&ch.status[tb], (flag << 30) | (val & 0x3FFFFFFFu));
+        }
+        int u = -1;                                                     // the last wave in front of this one with a row start
+#pragma unroll
+        for (int v = 0; v < RW_WAVES; v++) if (v < w && wr[v]) u = v;
+        if (u >= 0) {
+#pragma unroll
+            for (int v = 0; v < RW_WAVES; v++) {
+                if (v == u) jrow = (wr[v] - 1u) + wa[v];
+                else if (v > u && v < w) jrow += wt[v];
+            }
+        } else {
+            // the row continues from the tiles in front: their heads are looked up where the first index is needed (below)
+            lb_pending = true;
+#pragma unroll
+            for (int v = 0; v < RW_WAVES; v++) if (v < w) jrow += wt[v];
+            if (w == RW_WAVES - 1 && ul < 0) { pfx_pending = true; pfx_add = jrow + wt[RW_WAVES - 1]; }   // (this wave completes the tile's status)
+        }
+    } else if (!counts_scanned) {
 #pragma unroll
         for (int q = 0; q < RW_WAVES; q++) jnext += s_jb[q];
         if (tid == 0 && tb == (n + RN_TILE - 1) / RN_TILE - 1) info->n_runs = jnext + run_counts[tb];
@@ -427,27 +533,70 @@ __global__ __launch_bounds__(RW_THREADS) void k_runs_wave(const uint64_t* __rest
         int b[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) b[k] = L.bins[lane * RN_STRIDE + k];
-        if (val) {
+        const uint4 pb = pack_bins(b);                                  // the slot's cover sum, 16 x i8
+        if (!CHAIN) {
             const uint32_t j = jnext + __builtin_amdgcn_mbcnt_hi((uint32_t)(bv >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bv, 0u));
+            if (val) {
+                const uint32_t open = (sg == R && chunk_n == RW_CHUNK) ? RUN_OPEN : 0u;
+                const uint32_t layer = ((khi & 0x1FFu) << 12) | (klo >> 20);
+                const uint2 sw = run_style_words(rs, layer, tile);          // (one gather per run, here on all 256 CUs)
+                if (j < rec_cap) {                                          // asynchronous frames provision for a predicted run count
+                    uint4* rp = reinterpret_cast<uint4*>(&records[j]);
+                    rp[0] = pb;                                             // the run's own cover sum; k_carry_rows turns it into the carry-in
+                    rp[1] = make_uint4(cbase + st, (st_next - st) | open, sw.x, sw.y);
+                    run_keys[j] = ((uint64_t)tyb << 53) | ((uint64_t)layer << 32) | j;
+                    rs.run_lt[j] = ((layer & 0xFFFFu) << 16) | (open ? RUN_LT_OPEN : 0u) | txb;
+                }
+                if (txb >= 1u && new_tile) tile_first_run[(tyb - 1u) * tiles_w + (txb - 1u)] = j + 1u;   // 0 = the tile has no run
+                const uint32_t rr = (tyb - 1u) - row0;
+                if (rr < RN_ROWS) atomicAdd(&s_rows[rr], 1u); else atomicAdd(&row_count[tyb - 1u], 1u);
+            }
+        } else {
+            // a slot that begins a tile row restarts the numbering at its own segment index
+            const bool rs_slot = mine && (((ptile >> 12) != tyb) || (cbase + st) == 0u);
+            const uint64_t rsb = __ballot(rs_slot);
+            const uint64_t below = (1ull << lane) - 1ull;
+            const uint64_t rs_le = rsb & ((below << 1) | 1ull);          // row starts at or before this slot
+            const uint32_t pos = cbase + st;
+            const int r = rs_le ? 63 - __builtin_clzll(rs_le) : 0;
+            const uint32_t pos_r = (uint32_t)__shfl((int)pos, r, 64);
+            const bool jabs = rs_le != 0ull;                             // the slot's row began in this sweep: its index needs nobody
+            const uint32_t jpart = jabs ? pos_r + (uint32_t)__popcll(bv & below & ~((1ull << r) - 1ull)) : (uint32_t)__popcll(bv & below);
+            if (rs_slot && tyb - 1u < tiles_h) ch.row_base[tyb - 1u] = pos;
             const uint32_t open = (sg == R && chunk_n == RW_CHUNK) ? RUN_OPEN : 0u;
             const uint32_t layer = ((khi & 0x1FFu) << 12) | (klo >> 20);
-            const uint2 sw = run_style_words(rs, layer, tile);          // (one gather per run, here on all 256 CUs)
-            if (j < rec_cap) {                                          // asynchronous frames provision for a predicted run count
-                uint4* rp = reinterpret_cast<uint4*>(&records[j]);
-                rp[0] = pack_bins(b);                                   // the run's own cover sum; k_carry_rows turns it into the carry-in
-                rp[1] = make_uint4(cbase + st, (st_next - st) | open, sw.x, sw.y);
-                run_keys[j] = ((uint64_t)tyb << 53) | ((uint64_t)layer << 32) | j;
-                rs.run_lt[j] = ((layer & 0xFFFFu) << 16) | (open ? RUN_LT_OPEN : 0u) | txb;
+            uint2 sw = make_uint2(0u, 0u);
+            if (val) sw = run_style_words(rs, layer, tile);              // (one gather per run, here on all 256 CUs)
+            if (lb_pending && (__ballot(val && !jabs) != 0ull || pfx_pending)) {       // (wave-uniform)
+                __builtin_amdgcn_sched_barrier(0);                       // (the probe goes out behind the gathers, not in front of the wave's loads)
+                const uint32_t lb = lb_lookback_u32(ch.status, tb, &info->plan_bad);   // (a predecessor that never shows up voids the frame)
+                __builtin_amdgcn_sched_barrier(0);
+                jrow += lb; lb_pending = false;
+                if (pfx_pending && lane == 0) lb_st32(&ch.status[tb], (LB_PREFIX << 30) | ((lb + pfx_add) & 0x3FFFFFFFu));
+                pfx_pending = false;
             }
-            if (txb >= 1u && new_tile) tile_first_run[(tyb - 1u) * tiles_w + (txb - 1u)] = j + 1u;   // 0 = the tile has no run
-            const uint32_t rr = (tyb - 1u) - row0;
-            if (rr < RN_ROWS) atomicAdd(&s_rows[rr], 1u); else atomicAdd(&row_count[tyb - 1u], 1u);
+            if (val) {
+                const uint32_t j = jabs ? jpart : jrow + jpart;
+                if (j < rec_cap) {
+                    uint4* rp = reinterpret_cast<uint4*>(&records[j]);
+                    rp[0] = pb;
+                    rp[1] = make_uint4(cbase + st, (st_next - st) | open, sw.x, sw.y);
+                    rs.run_lt[j] = ((layer & 0xFFFFu) << 16) | (open ? RUN_LT_OPEN : 0u) | txb;
+                }
+                if (txb >= 1u && new_tile) tile_first_run[(tyb - 1u) * tiles_w + (txb - 1u)] = j + 1u;
+                const uint32_t rr = (tyb - 1u) - row0;
+                if (rr < RN_ROWS) atomicAdd(&s_rows[rr], 1u); else atomicAdd(&row_count[tyb - 1u], 1u);
+            }
+            if (rsb) {                                                   // (wave-uniform) what the next sweep continues
+                const int rl = 63 - __builtin_clzll(rsb);
+                jrow = (uint32_t)__shfl((int)pos, rl, 64) + (uint32_t)__popcll(bv >> rl);
+                lb_pending = false;                                      // (absolute from here on)
+            } else jrow += (uint32_t)__popcll(bv);
         }
         jnext += (uint32_t)__popcll(bv);
         if (sg == 0) {                                                  // slot 0: what this chunk adds to a run that began before it
-            const uint4 c = pack_bins(b);
             uint4* ep = reinterpret_cast<uint4*>(&blk_edge[cbase / RW_CHUNK]);
-            ep[0] = c;
+            ep[0] = pb;
             ep[1] = make_uint4(R ? L.start[1] : chunk_n, R ? 1u : 0u, 0u, 0u);
         }
         wave_lds_fence();
@@ -457,12 +606,14 @@ __global__ __launch_bounds__(RW_THREADS) void k_runs_wave(const uint64_t* __rest
 }
 
 size_t runs_scratch_words(size_t n) { return 5 * ((n + RN_TILE - 1) / RN_TILE + 2) + 16; }   // [tile counts | chunk counts]
+size_t runs_chain_words(size_t n) { return (n + RN_TILE - 1) / RN_TILE + 1; }                  // (chain: the tiles' status words)
 size_t runs_blocks(size_t n) { return (n + RW_CHUNK - 1) / RW_CHUNK + 4; }      // BlkEdge entries: one per wave chunk
 
 void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t tiles_w, uint32_t tiles_h, TileRecord* records,
                  uint32_t rec_cap, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge, uint32_t* row_tab,
                  uint32_t* scratch, FrameInfo* info, bool verify_plan, uint64_t spec_live44, bool spec_layer_sorted,
-                 PendingMasks pm, RunStyle rs, bool tables_are_zero, const uint32_t* range_records, uint32_t n_range_records, int what) {
+                 PendingMasks pm, RunStyle rs, bool tables_are_zero, const uint32_t* range_records, uint32_t n_range_records, int what,
+                 uint32_t* chain_row_base, bool chain_status_is_zero) {
     // per-frame tile tables: [row_count | row_span_lo | row_span_cnt | painter overflow counters (2) | first-run table] are
     // contiguous (api.cpp lays them out so) and start from zero — cleared by k_runs_count, unless an earlier kernel of the frame
     // already did (api.cpp folds that into the frame's first kernel); 0 in the first-run table = the tile has no run
@@ -479,15 +630,25 @@ void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t ti
     const uint32_t cgrid = std::min<uint32_t>((ntiles + 1) / 2, 4096u);
     uint32_t* chunk_counts = scratch + ntiles + 8;                      // 4 per tile (+ slack for the last wave's second half)
     const int scanned = ntiles > 16384 ? 1 : 0;
+    if (chain_row_base) {
+        // no counting pass (k_runs_wave<true>): the tables and the tiles' status words (the head of `scratch`) are cleared by an
+        // earlier kernel of the frame or by two memsets here; one more workgroup (the first) keeps house
+        if (zero_words) (void)hipMemsetAsync(row_tab, 0, (size_t)zero_words * 4, s);
+        if (!chain_status_is_zero) (void)hipMemsetAsync(scratch, 0, (size_t)ntiles * 4, s);
+        FORMA_LAUNCH(k_runs_wave<true>, dim3(ntiles + 1), dim3(RW_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, records, rec_cap,
+                           run_keys, tile_first_run, blk_edge, row_tab, (const uint32_t*)nullptr, 0, (const uint32_t*)nullptr, info, rs,
+                           RunChain{scratch, chain_row_base, spec_live44, flags, pm, range_records, n_range_records});
+        return;
+    }
     if (what & 1) {
         FORMA_LAUNCH(k_runs_count, dim3(cgrid + 1), dim3(RC_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, scratch, chunk_counts, row_tab,
                            zero_words, info, spec_live44, flags, pm, range_records, n_range_records);
         if (scanned) launch_scan_small_u32(s, scratch, nc, RN_TILE, &info->n_runs);   // exclusive, in place; total -> n_runs
     }
     if (what & 2)
-        FORMA_LAUNCH(k_runs_wave, dim3(ntiles), dim3(RW_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, records, rec_cap,
+        FORMA_LAUNCH(k_runs_wave<false>, dim3(ntiles), dim3(RW_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, records, rec_cap,
                            run_keys, tile_first_run, blk_edge, row_tab, (const uint32_t*)scratch, scanned,
-                           (const uint32_t*)chunk_counts, info, rs);
+                           (const uint32_t*)chunk_counts, info, rs, RunChain{nullptr, nullptr, 0ull, 0u, PendingMasks{nullptr, 0u}, nullptr, 0u});
 }
 uint32_t runs_edge_segments() { return RW_CHUNK; }
 uint32_t runs_count_tiles(size_t n, bool* scanned) { const uint32_t t = (uint32_t)((n + RN_TILE - 1) / RN_TILE); *scanned = t > 16384; return t; }
@@ -614,7 +775,9 @@ __global__ __launch_bounds__(TH, TH == 512 ? CR_HALF_OCC : (CAP == CR_CAP_S ? CR
                                                            uint32_t row0 /* first tile row that is painted: blockIdx.x = 0 */,
                                                            SpanGroups groups, const uint32_t* __restrict__ run_lt,
                                                            uint32_t cull /* PaintParams::cull: the group lists leave out what an occluder of the whole group hides */,
-                                                           uint32_t left_start /* see below; 0xFFFFFFFF: off */) {
+                                                           uint32_t left_start /* see below; 0xFFFFFFFF: off */,
+                                                           const uint32_t* __restrict__ row_base /* nullable: where each row's runs begin
+                                                           (launch_runs' chain numbering); else the rows' runs are dense in row order */) {
     constexpr int CR_RPT = RPT;                        // consecutive runs of the (layer, tile_x) order per lane in the row walk
     constexpr int CR_PIECE = TH * RPT;         // runs per piece
     constexpr bool NB_IN_IDLE = LOCAL && 2 * (CR_PIECE + 1) <= CAP;   // group / tile_x of a piece's runs live in the sort's idle buffer
@@ -656,7 +819,8 @@ __global__ __launch_bounds__(TH, TH == 512 ? CR_HALF_OCC : (CAP == CR_CAP_S ? CR
     const uint32_t n_blk = (dev_count(nc_segments) + edge_segs - 1) / edge_segs;   // BlkEdge entries (one per edge_segs segments)
     // first run of this row = sum of the run counts of the rows above
     uint32_t part = 0;
-    for (uint32_t r = tid; r < ty; r += TH) part += row_count[r];
+    if (row_base) { if (tid == 0) part = row_count[ty] ? row_base[ty] : 0u; }   // (a row without runs has no entry)
+    else for (uint32_t r = tid; r < ty; r += TH) part += row_count[r];
     const uint32_t cnt = row_count[ty];
     if (plan_bad) return;
     if (runs_dev > nc_runs.bound) {                                     // more runs than provisioned: the frame is void, and
@@ -1121,7 +1285,7 @@ void launch_carry_rows(hipStream_t s, bool local_sort, bool small, bool half, ui
                        uint32_t n_orders, uint32_t tiles_w, uint32_t tiles_h, const uint32_t* row_count,
                        uint32_t* row_span_lo, uint32_t* row_span_cnt, uint64_t* span_key, uint4* span_cov,
                        const uint8_t* unchanged, FrameInfo* info, uint32_t edge_segs, uint32_t vis_last, uint32_t row0, uint32_t row1,
-                       SpanGroups groups, const uint32_t* run_lt, bool cull, uint32_t left_start) {
+                       SpanGroups groups, const uint32_t* run_lt, bool cull, uint32_t left_start, const uint32_t* row_base) {
     row1 = row1 < tiles_h ? row1 : tiles_h;
     if (tiles_h == 0 || row0 >= row1) return;             // (only the tile rows that are painted: the others' carries are never read)
     if (n_slices < 1u) n_slices = 1u;
@@ -1129,7 +1293,7 @@ void launch_carry_rows(hipStream_t s, bool local_sort, bool small, bool half, ui
     const dim3 grid((row1 - row0) * n_slices);
 #define CR_LAUNCH(L, C, R, T_) FORMA_LAUNCH((k_carry_rows<L, C, R, T_>), grid, dim3(T_), 0, s, sorted_run_keys, records, blk_edge, n_segments, \
                                               n_runs, layer_sf, n_orders, tiles_w, tiles_h, row_count, row_span_lo, row_span_cnt, span_key, \
-                                              span_cov, unchanged, info, edge_segs, vis_last, n_slices, bin_shift, row0, groups, run_lt, cull ? 1u : 0u, left_start)
+                                              span_cov, unchanged, info, edge_segs, vis_last, n_slices, bin_shift, row0, groups, run_lt, cull ? 1u : 0u, left_start, row_base)
     if (!local_sort) CR_LAUNCH(false, CR_CAP, 4, CR_THREADS);
     else if (small && half) CR_LAUNCH(true, CR_CAP_H, 4, CR_THREADS_H);
     else if (small) CR_LAUNCH(true, CR_CAP_S, 2, CR_THREADS);
@@ -1565,7 +1729,7 @@ __device__ __forceinline__ uint32_t span_phys(const SpanListsT<NS>& L, uint32_t 
 // of a tile (LayerWorkbench::populate_layers, layer_workbench/mod.rs:250-278) and neither has this path.
 __device__ __forceinline__ void paint_tile(const uint32_t MAXE, const uint32_t STAGE, uint64_t* e_key, uint64_t* e_tmp, uint32_t* e_flag,
                                            const PaintParams& P, const uint32_t tile, const uint64_t* __restrict__ sorted,
-                                           const TileRecord* __restrict__ records, const uint32_t n_runs,
+                                           const TileRecord* __restrict__ records, const uint32_t n_runs_frame,
                                            const uint32_t* __restrict__ tile_first_run,
                                            const uint32_t* __restrict__ row_span_lo,
                                            const uint32_t* __restrict__ row_span_cnt,
@@ -1595,6 +1759,7 @@ __device__ __forceinline__ void paint_tile(const uint32_t MAXE, const uint32_t S
     //      its own runs (contiguous records, ascending layer) merged with the row's spans that cross it.
     //      entry = (layer << 32) | ref, ref = run index, or 0x80000000 | span index ------------------------------
     const uint32_t my_tile_key = ((ty + 1u) << 12) | (tx + 1u);
+    const uint32_t n_runs = PAINT_RUN_END(P, ty, n_runs_frame);
     // first round of loads, all independent: where this tile's runs start, where this row's spans are
     const uint32_t j0 = tile_first_run[tile] - 1u;                      // 0 stored = no run -> FORMA_NONE
     const SpanLists SL = load_span_lists(row_span_lo, row_span_cnt, ty, P.n_slices);
@@ -2038,7 +2203,7 @@ __global__ __launch_bounds__(64, NPX == 1 ? PAINT_STRIP_OCC : (SIMPLE ? PAINT_SI
     // The guard word, the run count and the tile's three table entries are independent loads: issue all of them before
     // the first is tested (as written before, `plan_bad` was a global round trip of its own in front of everything).
     const uint32_t plan_bad = info->plan_bad;                           // mis-sorted stream (async frame): the host re-runs
-    const uint32_t n_runs = dev_count(nc_runs);
+    const uint32_t n_runs_frame = dev_count(nc_runs);
     // one-wave workgroups (a wave's slot frees as soon as ITS tile is done).  XCD-aware mapping: workgroup b runs on
     // XCD b % 8; give each XCD a contiguous band of tiles so a tile row's records / spans stay in one L2
     // Only the crop's tile rows are launched (a multi-GPU rank paints its band only).
@@ -2114,6 +2279,7 @@ __global__ __launch_bounds__(64, NPX == 1 ? PAINT_STRIP_OCC : (SIMPLE ? PAINT_SI
 
     // ---- the tile's layer list: own runs (contiguous records, ascending layer) + the row's spans that cross it --------
     const uint32_t my_tile_key = ((ty + 1u) << 12) | (tx + 1u);
+    const uint32_t n_runs = PAINT_RUN_END(P, ty, n_runs_frame);
     const uint32_t j0 = tile_first_run[tile] - 1u;                      // 0 stored = no run -> FORMA_NONE
     // the spans that may cross this tile: its tile-column group's lists (one per slice; SpanGroups in common.h), or — no group
     // lists this frame, or the pool was full for this row — the row's
@@ -2583,7 +2749,7 @@ __global__ __launch_bounds__(64, PAINT_SIMPLE_OCC) void k_paint_quad(PaintParams
     __shared__ uint32_t q_hi[2][4][QE], q_lo[2][4][QE];                 // [0]: arrival order (runs, then spans); [1]: by layer
     const int lane = threadIdx.x & 63, g = lane >> 4, li = lane & 15;
     const uint32_t plan_bad = info->plan_bad;
-    const uint32_t n_runs = dev_count(nc_runs);
+    const uint32_t n_runs_frame = dev_count(nc_runs);
     // a quad = four consecutive tiles of one row (always inside one tile-column group: 4 divides SPAN_GROUP_TILES); XCD-aware
     // like k_paint_wave: workgroup b runs on XCD b % 8, every XCD a contiguous band of quads
     const uint32_t qw = (P.tiles_w + 3u) / 4u;
@@ -2604,6 +2770,7 @@ __global__ __launch_bounds__(64, PAINT_SIMPLE_OCC) void k_paint_quad(PaintParams
     const bool t_in = tx < P.tiles_w && tx >= P.crop_x0 && tx < P.crop_x1;   // (a tile outside the canvas / the crop: its group idles)
     const uint32_t tile = ty * P.tiles_w + min(tx, P.tiles_w - 1u);
     const uint32_t my_tile_key = ((ty + 1u) << 12) | (tx + 1u);
+    const uint32_t n_runs = PAINT_RUN_END(P, ty, n_runs_frame);
     const uint32_t j0 = t_in ? tile_first_run[tile] - 1u : FORMA_NONE;  // 0 stored = no run -> FORMA_NONE
     constexpr int NS = ONE_SLICE ? 1 : CR_MAX_SLICES;
     SpanListsT<NS> SL = load_span_lists_t<NS>(row_span_lo, row_span_cnt, ty, P.n_slices);
@@ -2989,7 +3156,8 @@ void launch_pack_written(hipStream_t s, const uint8_t* written, uint32_t tiles_w
 // ================================================================================================
 __global__ __launch_bounds__(64) void k_frame_tail(FrameInfo* __restrict__ info, FrameInfo* __restrict__ host_info,
                                                    uint32_t* __restrict__ host_count, const uint32_t* __restrict__ order_cnt,
-                                                   uint32_t* __restrict__ order_keep) {
+                                                   uint32_t* __restrict__ order_keep, const uint32_t* __restrict__ chain_rows,
+                                                   uint32_t n_chain_rows) {
     constexpr int W = (int)(sizeof(FrameInfo) / 4);
     static_assert(W <= 64, "FrameInfo fits one wave");
     const int t = threadIdx.x;
@@ -3001,8 +3169,16 @@ __global__ __launch_bounds__(64) void k_frame_tail(FrameInfo* __restrict__ info,
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) heavy += __shfl_xor(heavy, d, 64);
     }
+    // launch_runs' chain numbering: nobody counted the frame's runs — they are the sum of the row counts
+    uint32_t runs = 0;
+    if (chain_rows) {
+        for (uint32_t i = (uint32_t)t; i < n_chain_rows; i += 64) runs += chain_rows[i];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) runs += __shfl_xor(runs, d, 64);
+    }
     if (t < W) {
-        const uint32_t v = t == (int)(offsetof(FrameInfo, n_heavy) / 4) ? heavy : src[t];
+        uint32_t v = t == (int)(offsetof(FrameInfo, n_heavy) / 4) ? heavy : src[t];
+        if (chain_rows && t == (int)(offsetof(FrameInfo, n_runs) / 4)) v = runs;
         // pinned host memory: system-scope stores, visible to the host once the stream has drained
         if (host_info) __hip_atomic_store(reinterpret_cast<uint32_t*>(host_info) + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (host_count && t == (int)(offsetof(FrameInfo, n_segments) / 4)) __hip_atomic_store(host_count, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -3012,7 +3188,7 @@ __global__ __launch_bounds__(64) void k_frame_tail(FrameInfo* __restrict__ info,
     }
 }
 void launch_frame_tail(hipStream_t s, FrameInfo* info, FrameInfo* host_info, uint32_t* host_count, const uint32_t* order_cnt,
-                       uint32_t* order_keep) {
-    FORMA_LAUNCH(k_frame_tail, dim3(1), dim3(64), 0, s, info, host_info, host_count, order_cnt, order_keep);
+                       uint32_t* order_keep, const uint32_t* chain_rows, uint32_t n_chain_rows) {
+    FORMA_LAUNCH(k_frame_tail, dim3(1), dim3(64), 0, s, info, host_info, host_count, order_cnt, order_keep, chain_rows, n_chain_rows);
 }
 

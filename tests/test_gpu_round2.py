@@ -584,3 +584,32 @@ def test_quad_painter_on_canvases_that_are_no_multiple_of_four_tiles(monkeypatch
                 assert np.abs(a - b).max() <= 1, (size, crop)
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("switch", ["runs_chain=1", "runs_chain=0", "runs_chain=1,no_prezero", "runs_chain=1,carry_slices=3"])
+def test_runs_numbered_per_tile_row_without_a_counting_pass(monkeypatch, switch):
+    """launch_runs' chain (k_runs_wave<true>): read-back-free frames number their runs per tile row from the index of the row's
+    first segment, every workgroup taking its predecessors' head counts from their status words — no k_runs_count.  Same
+    images as the oracle's on canvases whose 2 048-segment tiles hold many rows (a 1080 x 40 strip), one row only (4096 x 16,
+    a row of more than 64 tiles: the look-back probes twice), the usual mix with a crop; with every per-frame buffer poisoned
+    (what lies between two rows' records is never a run), and after the scene SHRANK (last frame's records of the same tile
+    sit right behind this frame's)."""
+    import forma_amd
+    monkeypatch.setenv("FORMA_HIP_DEBUG", switch + ",poison_frame=255")
+    c = forma_amd.Context(0)
+    try:
+        cases = (((1024, 768), S.random_mixed(n=400, width=1024, height=768, seed=41), S.random_mixed(n=150, width=1024, height=768, seed=42)),
+                 ((1080, 40), S.random_cubics(n=300, width=1080, height=40, seed=43, alpha=0.6), S.random_cubics(n=40, width=1080, height=40, seed=44)),
+                 ((4096, 16), S.random_cubics(n=1500, width=4096, height=16, seed=45, alpha=0.5), S.random_cubics(n=900, width=4096, height=16, seed=46)))
+        for (w, h), big, small in cases:
+            for comp in (big, small):                    # (the second scene of a canvas has fewer runs in every row)
+                o, _ = both(c, comp)
+                for crop in (None, (16 * 2 + 3, w - 21, 0, h) if h <= 48 else (16 * 2 + 3, w - 21, 33, h - 50)):
+                    ref = o.render(w, h, clear=(1.0, 1.0, 1.0, 1.0), crop=crop)
+                    for k in range(4):                   # (the first frame of a geometry is synchronous: the chain starts with the second)
+                        img = c.render(w, h, clear=(1.0, 1.0, 1.0, 1.0), crop=crop)
+                        y0, y1, x0, x1 = (crop[2], crop[3], crop[0], crop[1]) if crop else (0, h, 0, w)
+                        a = img.reshape(h, -1)[y0:y1, 4 * x0:4 * x1].astype(np.int16); b = ref.reshape(h, -1)[y0:y1, 4 * x0:4 * x1].astype(np.int16)
+                        assert np.abs(a - b).max() <= 1, (switch, (w, h), crop, k)
+    finally:
+        c.close()
