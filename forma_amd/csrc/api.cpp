@@ -389,8 +389,11 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     // It pays while the run kernel's workgroups are all resident at once (1080p: 9.8 + 15.3 -> 19.6 us, a 17-row band of the 4K
     // scene: 8.2 + 14.6 -> 16.0): the look-back is a round trip that a workgroup of 15 us cannot hide, and a frame of several
     // rounds of workgroups pays it in every round (4K: 23.8 + 52.8 -> 84.8 us, 8K: 16.4 + 31.0 -> 54.5) — those keep the counting pass.
+    // With several frames in flight the waves that wait take issue slots from the other frames' kernels (1080p, three slots:
+    // 9 942 -> 9 707 frames/s while the call alone gains 2.6 %): one frame in flight only, like the strip painters.
     const bool chain = bound_j != 0 && n > 0 && local_sort && ctx->pred_max_row <= carry_rows_local_cap() &&
-                       (ctx->dbg.runs_chain < 0 ? (RUNS_CHAIN_DEFAULT != 0 && runs_chain_words(n) <= RUNS_CHAIN_MAX_TILES) : ctx->dbg.runs_chain != 0);
+                       (ctx->dbg.runs_chain < 0 ? (RUNS_CHAIN_DEFAULT != 0 && runs_chain_words(n) <= RUNS_CHAIN_MAX_TILES && one_frame_in_flight(ctx))
+                                                : ctx->dbg.runs_chain != 0);
     const bool chain_zero = chain && ctx->pz.chain_p == ctx->runs_scratch.p && ctx->pz.chain_words >= runs_chain_words(n);
     ctx->pz.chain_p = nullptr;
     // Records, run keys and digests are sized for the RUNS, not for the segments (a run needs a segment, so N would always do:

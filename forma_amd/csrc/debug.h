@@ -25,7 +25,7 @@
 //   no_cull / force_cull the painters never / always drop the entries below a tile's topmost occluder (PaintParams::cull; default:
 //                        once the geometry has had tiles beyond the wave painter's lists)
 //   runs_chain=0|1       read-back-free frames never / always find their runs without the counting pass (k_runs_count): the chained
-//                        k_runs_wave, runs numbered per tile row (default: streams of <= RUNS_CHAIN_MAX_TILES x 2 048 segments)
+//                        k_runs_wave, runs numbered per tile row (default: streams of <= RUNS_CHAIN_MAX_TILES x 2 048 segments, one frame in flight)
 //   strip_tiles=N        the painter runs four strip wavefronts per tile on frames of <= N painted tiles (0: never)
 //   trim_debug           forma_hip_trim prints what it releases
 //   force_exchange       forma_hip_create_multi with ONE device still builds the multi-device context (RCCL world of one)
