@@ -32,7 +32,20 @@
 // keys per lane: 16 (16384 keys per tile -> 128 KiB of LDS staging, 1 workgroup = 16 waves per CU); the 512-bin pass takes 14 —
 // its counters and 9-bit ranks cost registers, at 16 keys it spilled (C4: 59.2 -> 53.6 us per pass; 256 bins: 62.1 -> 63.4)
 __host__ __device__ constexpr int os_kpt(int bits) { return bits == 9 ? 14 : 16; }
-#define OS_TILE_MIN (OS_THREADS * 14)               // provisioning: the most tiles any pass of n keys can have
+// ... and fewer where n keys are not 256 such tiles: a pass of 2.7 M keys (1080p) was 164 tiles on 256 CUs, each the full
+// latency of a 16 384-key tile — load, rank, stage, look-back, scatter, about half of it proportional to the keys per lane.
+// With 8 / 12 keys per lane the same keys are ONE round of shorter tiles on (nearly) every CU.  0: the default of the digit width.
+#ifndef OS_SMALL_TILES
+#define OS_SMALL_TILES 1
+#endif
+static inline int os_kpt_small(size_t n) {
+    if (!OS_SMALL_TILES) return 0;
+    if (n <= (size_t)256 * OS_THREADS * 8) return 8;
+    if (n <= (size_t)256 * OS_THREADS * 12) return 12;
+    return 0;
+}
+// provisioning (row stride of the status words): the most tiles any pass of n keys can have
+static inline size_t os_tile_min(size_t n) { const int k = os_kpt_small(n); return (size_t)OS_THREADS * (size_t)(k ? k : 14); }
 #define ST_VALMASK 0x3FFFFFFFu
 #ifndef OS_LBW
 #define OS_LBW     8
@@ -313,7 +326,7 @@ __device__ __forceinline__ uint32_t key_digit(uint64_t key, int shift, uint32_t 
     return ((uint32_t)(key >> shift) - bias) & dmask;
 }
 
-template <int BITS, bool CHUNKED, bool HI>
+template <int BITS, bool CHUNKED, bool HI, int KPT_ = 0>
 __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __restrict__ in, uint64_t* __restrict__ out,
                                                          DevCount nc, int shift, uint32_t dmask, uint32_t bias,
                                                          const uint32_t* __restrict__ ghist /* this pass, SORT_BINS per copy */,
@@ -321,7 +334,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
                                                          uint32_t* __restrict__ ticket, uint32_t* __restrict__ err,
                                                          ChunkedSrc C /* first pass of a chunked stream, else n_chunks = 0 */) {
     constexpr int RADIX = 1 << BITS;
-    constexpr int KPT = os_kpt(BITS), TILE = OS_THREADS * KPT;  // keys per lane, keys per tile
+    constexpr int KPT = KPT_ ? KPT_ : os_kpt(BITS), TILE = OS_THREADS * KPT;  // keys per lane, keys per tile
     const uint32_t n = dev_count(nc);                       // (chunked: k_sort_hist has published the total)
     constexpr bool chunked = CHUNKED;                       // (one bucket at offset 0 is launched as a plain stream)
     ChunkMap M;
@@ -547,7 +560,7 @@ uint32_t sort_hist_blocks(size_t n) {
 static inline size_t sort_fixed_words() { return (size_t)HS_COPIES * SORT_MAX_PASSES * SORT_BINS + 16 + 2048 * 4; }
 const uint32_t* sort_range_words(const uint32_t* scratch) { return scratch + (size_t)HS_COPIES * SORT_MAX_PASSES * SORT_BINS + 16; }
 size_t sort_scratch_words(size_t n) {
-    size_t ntiles = (n + OS_TILE_MIN - 1) / OS_TILE_MIN;
+    size_t ntiles = (n + os_tile_min(n) - 1) / os_tile_min(n);
     // [hist: HS_COPIES x MAX_PASSES x SORT_BINS] [tickets: MAX_PASSES, pad to 16] [tile-field spans: 2048 x 4] [status: MAX_PASSES * ntiles * SORT_BINS]
     return sort_fixed_words() + (size_t)SORT_MAX_PASSES * (ntiles + 1) * SORT_BINS;
 }
@@ -555,7 +568,7 @@ size_t sort_scratch_words(size_t n) {
 // status rows of the passes that run): launch_radix_sort clears them itself unless the caller says an earlier kernel of the
 // frame already did (api.cpp folds the clearing into the frame's first kernel)
 size_t sort_zero_words(size_t n, const SortPlan& plan) {
-    const size_t ntiles = (n + OS_TILE_MIN - 1) / OS_TILE_MIN;
+    const size_t ntiles = (n + os_tile_min(n) - 1) / os_tile_min(n);
     return sort_fixed_words() + (size_t)plan.n_passes * ntiles * SORT_BINS;
 }
 
@@ -578,7 +591,8 @@ const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a
                                   bool scratch_is_zero, bool hist_ready, uint32_t max_workgroups) {
     const size_t n = nc.bound;                        // provisioning (grid, scratch); the kernels use the device count
     if (n <= 1 || plan.n_passes == 0) return in;
-    const uint32_t ntiles = (uint32_t)((n + OS_TILE_MIN - 1) / OS_TILE_MIN);     // (row stride of the status words: sort_zero_words)
+    const uint32_t ntiles = (uint32_t)((n + os_tile_min(n) - 1) / os_tile_min(n));     // (row stride of the status words: sort_zero_words)
+    const int small_kpt = digit_bits == 4 ? 0 : os_kpt_small(n);
     uint32_t* hist = scratch;
     uint32_t* tickets = scratch + (size_t)HS_COPIES * SORT_MAX_PASSES * SORT_BINS;
     uint32_t* status = scratch + sort_fixed_words();
@@ -601,17 +615,19 @@ const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a
         const bool hi = plan.shift[p] >= 32;
         // (on a timed frame the launch carries its own events, FORMA_LAUNCH: the dispatch's start and end timestamps)
         const int bits = digit_bits == 4 ? 4 : (plan.mask[p] > 255u ? 9 : 8);
-        const uint32_t tile = (uint32_t)OS_THREADS * (uint32_t)os_kpt(bits);
+        const uint32_t tile = (uint32_t)OS_THREADS * (uint32_t)(small_kpt ? small_kpt : os_kpt(bits));
         const uint32_t ptiles = (uint32_t)((n + tile - 1) / tile);
         const uint32_t grid = ptiles < cap ? ptiles : cap;
-#define OS_LAUNCH(B, CH, HI_) FORMA_LAUNCH((k_onesweep<B, CH, HI_>), dim3(grid), dim3(OS_THREADS), 0, s, src, dst, nc, \
+#define OS_LAUNCH(B, CH, HI_, K_) FORMA_LAUNCH((k_onesweep<B, CH, HI_, K_>), dim3(grid), dim3(OS_THREADS), 0, s, src, dst, nc, \
                                            plan.shift[p], plan.mask[p], plan.bias[p], (const uint32_t*)(hist + p * SORT_BINS), st, tickets + p, err, ch ? C : C0)
-#define OS_LAUNCH_B(B) do { if (ch) { if (hi) OS_LAUNCH(B, true, true); else OS_LAUNCH(B, true, false); } \
-                            else { if (hi) OS_LAUNCH(B, false, true); else OS_LAUNCH(B, false, false); } } while (0)
-        if (digit_bits == 4) OS_LAUNCH_B(4);
+#define OS_LAUNCH_K(B, K_) do { if (ch) { if (hi) OS_LAUNCH(B, true, true, K_); else OS_LAUNCH(B, true, false, K_); } \
+                                else { if (hi) OS_LAUNCH(B, false, true, K_); else OS_LAUNCH(B, false, false, K_); } } while (0)
+#define OS_LAUNCH_B(B) do { if (small_kpt == 8) OS_LAUNCH_K(B, 8); else if (small_kpt == 12) OS_LAUNCH_K(B, 12); else OS_LAUNCH_K(B, 0); } while (0)
+        if (digit_bits == 4) OS_LAUNCH_K(4, 0);
         else if (plan.mask[p] > 255u) OS_LAUNCH_B(9);
         else OS_LAUNCH_B(8);
 #undef OS_LAUNCH_B
+#undef OS_LAUNCH_K
 #undef OS_LAUNCH
         src = dst;
         dst = (dst == a) ? b : a;

@@ -42,6 +42,7 @@ def main():
     _, tm = c.render(W, H, device_only=True, timings=True)
     out["kernels_us_of_a_frame"] = round(sum(us for _n, _s, _t0, us in c.kernel_times()), 1)
     out["kernel_launches"] = len(c.kernel_times())
+    out["kernel_floors_us"] = {n: round(us, 1) for n, _s, _t0, us in c.kernel_times()}     # (what each launch costs when it has next to nothing to do)
     t0 = time.perf_counter()
     for _ in range(args.frames):
         c._L.forma_hip_version()
