@@ -205,6 +205,9 @@ static uint32_t sort_workgroups(const forma_hip_ctx* ctx) {
 // are for a context with one frame in flight.  With frame slots (forma_hip_set_frames_in_flight) the tail of a launch is filled by
 // the other frames' kernels anyway and the extra work is a loss: measured with three slots, the 4K scene -2.5 % frames/s with the
 // order on, its 1/8 band -5 % with strips.
+#ifndef CARRY_HALF_SLICED
+#define CARRY_HALF_SLICED 1
+#endif
 static bool one_frame_in_flight(const forma_hip_ctx* ctx) {
     const forma_hip_ctx* o = ctx->owner ? ctx->owner : ctx;
     return o->slots.size() <= 1;
@@ -463,6 +466,11 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
             const bool known = ctx->pred_slice_n == ks && ctx->pred_slice_small;
             const uint64_t guess = known ? (uint64_t)ctx->pred_max_slice * 10 / 9 : (uint64_t)ctx->pred_max_row * 5 / (3 * ks);
             if (guess <= carry_rows_small_cap()) { small = true; n_slices = ks; }
+            // ... as 512-lane workgroups when the slices fit those AND the frame is many workgroups (the painters see the same ks
+            // span lists either way).  Two measurements stand behind the count: 1080p, 68 rows x 3 slices of ~900 runs: 36.1 -> 27.3 us,
+            // +4.7 % frames/s per call, +8.8 % with three slots; a 17-row band of the 4K scene, 6 slices of ~800 runs each with
+            // long span lists: 25.4 -> 29.1 us — a hundred workgroups have a CU each and the 1 024-lane one finishes its slice sooner.
+            if (small && CARRY_HALF_SLICED && ctx->dbg.carry_half == 1 && guess <= carry_rows_half_cap() && rows_painted * ks >= 192u) half = true;
         }
         // The HALF variant (512 lanes, one piece of <= 2048 runs, three workgroups per CU) for frames whose rows are LIGHT — the
         // 8192 x 8192 triangle scene (512 rows of ~1 000 runs), 1080p: one workgroup per row as before, but 768 of them resident

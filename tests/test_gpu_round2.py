@@ -613,3 +613,26 @@ def test_runs_numbered_per_tile_row_without_a_counting_pass(monkeypatch, switch)
                         assert np.abs(a - b).max() <= 1, (switch, (w, h), crop, k)
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("switch", ["carry_half=2", "carry_half=4", ""])
+def test_sliced_tile_rows_on_half_workgroups(monkeypatch, switch):
+    """k_carry_rows<true, 2048, 4, 512> with SEVERAL workgroups per tile row (each a range of layers): the policy takes it for
+    frames of many sliced rows (1080p), `carry_half=N` forces N slices.  Heavy rows on a canvas of 48 tile rows, translucent
+    layers (every carry is visible), a crop, then fewer shapes (the slices' predictions void): images equal the oracle's."""
+    import forma_amd
+    monkeypatch.setenv("FORMA_HIP_DEBUG", (switch + "," if switch else "") + "poison_frame=255")
+    c = forma_amd.Context(0)
+    try:
+        for comp in (S.random_cubics(n=900, width=1920, height=768, seed=51, alpha=0.5), S.random_mixed(n=500, width=1920, height=768, seed=52),
+                     S.random_cubics(n=120, width=1920, height=768, seed=53, alpha=0.8)):
+            o, _ = both(c, comp)
+            for crop in (None, (40, 1900, 35, 700)):
+                ref = o.render(1920, 768, clear=(0.2, 0.3, 0.4, 1.0), crop=crop)
+                for k in range(4):
+                    img = c.render(1920, 768, clear=(0.2, 0.3, 0.4, 1.0), crop=crop)
+                    y0, y1, x0, x1 = (crop[2], crop[3], crop[0], crop[1]) if crop else (0, 768, 0, 1920)
+                    a = img.reshape(768, -1)[y0:y1, 4 * x0:4 * x1].astype(np.int16); b = ref.reshape(768, -1)[y0:y1, 4 * x0:4 * x1].astype(np.int16)
+                    assert np.abs(a - b).max() <= 1, (switch, crop, k)
+    finally:
+        c.close()
