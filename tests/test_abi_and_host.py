@@ -319,3 +319,19 @@ def test_dropped_layers_release_their_geometry():
     comp.remove(api.Order(0)); del lay
     gc.collect()
     assert not comp._shared.geom_id_to_order
+
+
+def test_every_debug_switch_is_documented():
+    """forma_amd/csrc/debug.h is the one place the library reads the environment: every token its parser accepts is described
+    in the header's own comment and listed in tools/README.md (the switches the suite is run under)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "forma_amd", "csrc", "debug.h")).read()
+    head = src[:src.index("#pragma once")]
+    toks = set(re.findall(r"FD_FLAG\((\w+)\)", src.split("#define FD_FLAG", 1)[1])) | set(re.findall(r'strcmp\(tok, "(\w+)"\)', src))
+    toks.discard("name")
+    assert len(toks) >= 25
+    readme = open(os.path.join(root, "tools", "README.md")).read()
+    for t in sorted(toks):
+        assert t in head, f"{t}: not described in debug.h's header comment"
+        assert t in readme, f"{t}: not listed in tools/README.md"
