@@ -112,9 +112,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and not (world == 1 and args.gpus == 1):
+    # `python bench.py --gpus N` WITHOUT a launcher (no WORLD_SIZE): ONE process drives all N GPUs — forma_hip_create_multi needs
+    # no second process (per-device host threads and the RCCL communicators live inside the library).  The line then says
+    # n_gpus = N.  Fewer than N visible devices is an error (rc 2), never a silent one-GPU measurement.
+    in_process = "WORLD_SIZE" not in os.environ and args.gpus > 1
+    if not in_process and world != args.gpus:
         if rank == 0:
-            print(f"WORLD_SIZE={world} does not match --gpus {args.gpus}", file=sys.stderr)
+            print(f"WORLD_SIZE={world} does not match --gpus {args.gpus}: measuring {world} GPU(s), n_gpus says so", file=sys.stderr)
         args.gpus = world
     backend = os.environ.get("FORMA_BENCH_BACKEND", "nccl")
     if os.environ.get("FORMA_BENCH_ONE_DEVICE"):
@@ -130,8 +134,19 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     from forma_amd import api, scenes, sharding
-    sharded = world > 1 or bool(os.environ.get("FORMA_BENCH_MODE_AT_1"))
-    multi_devices = [int(v) for v in os.environ["FORMA_BENCH_DEVICES"].split(",")] if os.environ.get("FORMA_BENCH_DEVICES") else list(range(world))
+    sharded = world > 1 or in_process or bool(os.environ.get("FORMA_BENCH_MODE_AT_1"))
+    n_gpus = args.gpus if in_process else world
+    multi_devices = [int(v) for v in os.environ["FORMA_BENCH_DEVICES"].split(",")] if os.environ.get("FORMA_BENCH_DEVICES") else list(range(n_gpus))
+    if in_process:
+        visible = torch.cuda.device_count()
+        if len(multi_devices) != args.gpus or min(multi_devices) < 0 or max(multi_devices) >= visible:
+            print(f"bench.py --gpus {args.gpus}: needs devices {multi_devices}, {visible} visible (FORMA_BENCH_DEVICES=0,0,.. rehearses "
+                  f"on fewer) — refusing to measure fewer GPUs than asked for", file=sys.stderr)
+            raise SystemExit(2)
+        if args.mode != "multi":
+            print(f"bench.py --gpus {args.gpus} without a launcher runs --mode multi (the other modes are one process per GPU: "
+                  f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} --mode {args.mode})", file=sys.stderr)
+            args.mode = "multi"
 
     def sync_all():
         torch.cuda.synchronize()
@@ -423,11 +438,14 @@ def main():
         lat = 1e3 / statistics.median(blocks1)
         out = {
             "metric": "frames/sec (sorted+painted, device-resident) + Mpixel-segments/sec",
-            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak" if mode in ("single", "frames") else "strong", "vs_baseline": None,
             "dtype": "u64 segments / f64+f32 rasterizer / f32 painter", "data": "synthetic",
             **({"rehearsal_backend": backend} if backend != "nccl" else {}),
+            **({"rehearsal_devices": multi_devices, "rehearsal": "ONE physical GPU listed several times: n_gpus counts device CONTEXTS, not GPUs"}
+               if mode == "multi" and len(set(multi_devices)) < len(multi_devices) else {}),
+            **({"launched": "in-process: one host process drives every GPU (no torchrun)"} if in_process else {}),
             "value_is": (f"ONE renderer context, {in_flight} frames in flight inside it (forma_hip_set_frames_in_flight), one host thread"
                          if mode == "single" else sharding_txt),
             "mpixel_segments_per_s": round(n_segments_full * fps / 1e6, 1),
@@ -498,9 +516,11 @@ def main():
     # N > 1: the requested sharded mode first; if it fails on any rank, fall back to the next one rather than lose the line
     chain = ["multi", "exchange", "bands", "frames"]
     modes = [args.mode] + [m for m in chain[chain.index(args.mode) + 1:] if m != args.mode] if sharded else [None]
+    if in_process:
+        modes = ["multi"]                                             # (the other modes need one process per GPU: relaunch() below)
     out, errors, m = None, {}, None
     for m in modes:
-        if m == "multi" and world > 1:
+        if m == "multi" and (world > 1 or len(set(multi_devices)) > 1):    # (the first execution on distinct devices: in a child that can be killed)
             ok, why = multi_preflight_ok()
             if not ok:
                 errors["multi"] = "preflight: " + why
@@ -515,6 +535,24 @@ def main():
         if agreed(ok):
             break
         out = None
+    if out is None and in_process and len(set(multi_devices)) == len(multi_devices):
+        # ONE process could not drive the N GPUs: the same layout with one process per GPU (the launcher the contract names), its
+        # line handed through with the reason attached
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup",
+               str(args.warmup), "--workload", args.workload, "--mode", "exchange"]
+        p = subprocess.run(cmd, capture_output=True, text=True)
+        line = next((ln for ln in reversed(p.stdout.splitlines()) if ln.startswith("{")), None)
+        if p.returncode != 0 or line is None:
+            raise SystemExit(f"every mode failed: {errors}; relaunch under torch.distributed.run: rc {p.returncode}: {(p.stderr or p.stdout)[-400:]}")
+        o = json.loads(line)
+        o.setdefault("mode_fallback_errors", {}).update(errors)
+        print(json.dumps(o), flush=True)
+        return
     if out is None:
         raise SystemExit(f"every mode failed: {errors}")
     if errors:

@@ -5,6 +5,10 @@
 
 #include "ctx.h"
 
+#ifndef FORMA_ARCH
+#define FORMA_ARCH "gfx950"
+#endif
+
 thread_local KernelTimer* g_ktimer = nullptr;
 static inline float* kt_us(forma_hip_ctx* c) { return c->kt_dur_us; }
 
@@ -32,7 +36,7 @@ inline void stage_begin(forma_hip_ctx* c, int st, bool timing) {
     if (!timing) return;
     c->stage_used[st] = true;
     if (st == ST_D2H) { (void)hipEventRecord(c->ev0[st], c->stream); return; }
-    c->kt.cur_stage = st; g_ktimer = &c->kt;
+    c->kt.cur_stage = st; c->kt.stream = c->stream; g_ktimer = &c->kt;
 }
 inline void stage_end(forma_hip_ctx* c, int st, bool timing) {
     if (!timing) return;
@@ -198,7 +202,7 @@ static uint32_t sort_workgroups(const forma_hip_ctx* ctx) {
     // (measured, frames/s on all / on 128 CUs: two slots 2 448 / 2 431, three 2 520 / 2 631, four 2 426 / 2 405 — so exactly three,
     //  the setting this library recommends)
     const forma_hip_ctx* o = ctx->owner ? ctx->owner : ctx;
-    return o->slots.size() == 3 ? SORT_CUS_IN_FLIGHT : 0u;
+    return o->slots.size() == 3 ? o->n_cus / 2u : 0u;
 }
 
 // Both schedules that shorten ONE frame's painter launch at the price of more work — strips, and the heavy-first order below —
@@ -214,7 +218,7 @@ static bool one_frame_in_flight(const forma_hip_ctx* ctx) {
 }
 static bool paint_by_strips(const forma_hip_ctx* ctx, uint32_t tiles_painted) {
     if (ctx->dbg.strip_tiles >= 0) return tiles_painted <= (uint32_t)ctx->dbg.strip_tiles;
-    return tiles_painted <= PAINT_STRIP_TILES && !ctx->scene_simple && (uint64_t)ctx->costly_layers * 32u >= ctx->n_orders && one_frame_in_flight(ctx);
+    return tiles_painted <= paint_strip_tiles(ctx) && !ctx->scene_simple && (uint64_t)ctx->costly_layers * 32u >= ctx->n_orders && one_frame_in_flight(ctx);
 }
 
 // Quad painters (k_paint_quad: four tiles per wavefront) for all-solid scenes whose tiles are shallow AND many: the list work of
@@ -575,17 +579,22 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     ctx->order_pending = -1; ctx->order_cnt_dev = nullptr; ctx->order_keep_dev = nullptr;
     const uint32_t tiles_painted = (P.crop_y1 > P.crop_y0 ? P.crop_y1 - P.crop_y0 : 0u) * tiles_w;
     const bool strips = paint_by_strips(ctx, tiles_painted);
+    const bool quads = paint_by_quads(ctx, a.cache_id, chain ? bound_j : jc.bound, tiles_painted);   // (k_paint_quad ignores order_*)
     P.order_flag_in = nullptr; P.order_flag_out = nullptr; P.order_hcap = 0; P.order_thr = 0;
     if (ctx->dbg.order_thr >= 0) ctx->order_off = 0;
     if (ctx->order_off) ctx->order_off--;                 // (a flat scene: the order is retried every 256 frames)
     // ... of launches that are a handful of rounds of wavefronts: one tile's life is then a good part of the launch's.  A frame
     // of 32 rounds (the 8K scene: 262 144 tiles on 8 192 wave slots) has no tail worth 10 % of bookkeeping.
-    if (ctx->order_enable && bound_j && a.cache_id < 0 && !strips && !ctx->dbg.no_order && jc.bound > 0 && tiles_painted && !ctx->order_off &&
-        tiles_painted <= 16u * PAINT_STRIP_TILES && (one_frame_in_flight(ctx) || ctx->dbg.order_thr >= 0)) {
+    if (ctx->order_enable && bound_j && a.cache_id < 0 && !strips && !quads && !ctx->dbg.no_order && jc.bound > 0 && tiles_painted && !ctx->order_off &&
+        tiles_painted <= 16u * paint_strip_tiles(ctx) && (one_frame_in_flight(ctx) || ctx->dbg.order_thr >= 0)) {
         // (heavy section: an eighth of the band's tiles, as PAINT_ORDER_SUBS lists of equal capacity)
         const size_t per = paint_band_tiles(P.crop_y1 > P.crop_y0 ? P.crop_y1 - P.crop_y0 : 0u, tiles_w), hcap = std::max<size_t>((per / 8 + PAINT_ORDER_SUBS - 1) / PAINT_ORDER_SUBS, 2) * PAINT_ORDER_SUBS;
         const size_t set_words = PAINT_ORDER_WORDS + 8 * hcap + (8 * per + 3) / 4;      // counts | lists | one flag byte per tile
-        if (ctx->order_buf.cap < 2 * set_words * 4) { HIPCHECK(ctx->order_buf.ensure(2 * set_words * 4)); ctx->order_cur = -1; }
+        if (ctx->order_buf.cap < 2 * set_words * 4) {
+            HIPCHECK(ctx->order_buf.ensure(2 * set_words * 4));
+            HIPCHECK(hipMemsetAsync(ctx->order_buf.p, 0, ctx->order_buf.cap, ctx->stream));   // (flag bytes nobody has written yet say "not heavy")
+            ctx->order_cur = -1;
+        }
         const forma_hip_ctx::OrderSig sig{tiles_w, tiles_h, P.crop_x0, P.crop_x1, P.crop_y0, P.crop_y1};
         uint32_t* base = ctx->order_buf.as<uint32_t>();
         if (ctx->order_cur >= 0 && !(ctx->order_sig == sig)) ctx->order_cur = -1;
@@ -628,7 +637,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                  ctx->style_off.as<uint32_t>(),
                  ctx->style_words.as<uint32_t>(), ctx->images.as<forma_image_t>(), ctx->texels.as<uint16_t>(),
                  ctx->cur_image, tc, dinfo, paint_overflow, overflow_list, over2_n, over2_list, launch_deep, groups,
-                 strips, paint_by_quads(ctx, a.cache_id, chain ? bound_j : jc.bound, tiles_painted));
+                 strips, quads);
     stage_end(ctx, ST_PAINT, timing);
     ctx->last_runs = J; ctx->last_entries = 0;
     HIPCHECK(hipGetLastError());
@@ -815,7 +824,7 @@ int finish_frame(forma_hip_ctx* ctx, forma_timings_t* t, bool have_info = false)
         if (hipEventElapsedTime(&ms, kt.e0[i], kt.e1[i]) != hipSuccess) continue;
         kt_us(ctx)[i] = ms * 1000.0f;
         if (kt.stage[i] >= 0 && kt.stage[i] < ST_COUNT) *dstv[kt.stage[i]] += ms * 1000.0f;
-        if (!strncmp(kt.name[i], "(k_onesweep", 11)) { pass += ms * 1000.0f; np++; }
+        if (strstr(kt.name[i], "k_onesweep")) { pass += ms * 1000.0f; np++; }   // (#kern text: "(k_onesweep<8>)" — any bracketing)
     }
     if (kt.n) {
         float ms = 0;
@@ -839,7 +848,7 @@ int finish_frame(forma_hip_ctx* ctx, forma_timings_t* t, bool have_info = false)
 
 void clear_stage_flags(forma_hip_ctx* ctx) {
     for (int s = 0; s < ST_COUNT; s++) ctx->stage_used[s] = false;
-    ctx->kt.n = 0; g_ktimer = nullptr;
+    ctx->kt.n = 0; ctx->kt.dropped = 0; g_ktimer = nullptr;
     ctx->order_cnt_dev = nullptr; ctx->order_keep_dev = nullptr;       // (a frame that never reached its k_frame_tail)
 }
 
@@ -886,13 +895,14 @@ int forma_hip_create(forma_hip_ctx** out, int device) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return FORMA_E_NO_DEVICE;
     if (device < 0 || device >= count) return FORMA_E_ARG;
-    {   // the kernels are gfx950 code objects only (no fat binary): any other device is "no device" (forma_hip.h)
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0) return FORMA_E_NO_DEVICE;
-    }
+    // the kernels are code objects of ONE architecture (no fat binary) — the Makefile's ARCH, gfx950: a device of any other is
+    // "no device" (forma_hip.h).  The CU count sizes the policies that speak of "the chip" (sort_workgroups, paint_by_strips).
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess || strncmp(prop.gcnArchName, FORMA_ARCH, strlen(FORMA_ARCH)) != 0) return FORMA_E_NO_DEVICE;
     forma_hip_ctx* ctx = new (std::nothrow) forma_hip_ctx();
     if (!ctx) return FORMA_E_INTERNAL;
     ctx->device = device;
+    ctx->n_cus = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
     ctx->dbg = forma_debug_parse();                       // FORMA_HIP_DEBUG (debug.h): test / tool switches, never set in deployment
     if (ctx->dbg.digit_bits == 4 || ctx->dbg.digit_bits == 8 || ctx->dbg.digit_bits == 9) ctx->digit_bits = ctx->dbg.digit_bits;
     ctx->no_async = ctx->dbg.sync;
@@ -1555,8 +1565,8 @@ int forma_hip_kernel_times(forma_hip_ctx* ctx, forma_kernel_time_t* out, size_t 
     if (!ctx || !out_n || (capacity && !out)) return FORMA_E_ARG;
     if (ctx->multi) return fail(ctx, FORMA_E_STATE, "kernel times are kept per device: ask a single-device context");
     const forma_hip_ctx* c = last_slot(ctx);
-    *out_n = (size_t)c->kt_n_done;
-    for (int i = 0; i < c->kt_n_done && (size_t)i < capacity; i++) {
+    *out_n = (size_t)c->kt_n_done + (size_t)c->kt.dropped;   // (> KernelTimer::CAP: that many launches of the frame ran untimed)
+    for (int i = 0; i < c->kt_n_done && (size_t)i < capacity; i++) {       // (dropped launches have no entry: only the count says so)
         forma_kernel_time_t& o = out[i];
         memset(&o, 0, sizeof o);
         const char* nm = c->kt.name[i];                   // "#kern" of FORMA_LAUNCH: "k_name" or "(k_name<ARGS>)"

@@ -151,16 +151,21 @@ __device__ __forceinline__ uint32_t dev_count(DevCount c) { return c.ptr ? min(*
 // forma_timings_t) the calling thread's g_ktimer points at the context's KernelTimer and the launch carries a pair of events
 // (hipExtLaunchKernelGGL: the dispatch's own start / end timestamps — what rocprofv3 reports as the kernel's duration, with no
 // marker packets in front of or behind it); otherwise it is a plain launch.  forma_hip_kernel_times returns the list.
+// The timer names its context's stream: a frame that failed between stage_begin and stage_end leaves g_ktimer set, and a launch
+// of ANOTHER context on the same thread (another stream, maybe another device) must not pick up this context's events.
 struct KernelTimer {
     static constexpr int CAP = 96;
     hipEvent_t e0[CAP], e1[CAP];
     const char* name[CAP];
     int stage[CAP];
     int n = 0, made = 0, cur_stage = 0;
+    int dropped = 0;                    // launches of the timed frame beyond CAP (they ran untimed: forma_hip_kernel_times says how many)
+    hipStream_t stream = nullptr;       // the stream of the context whose frame is being timed: only ITS launches carry events
 };
 extern thread_local KernelTimer* g_ktimer;
 inline bool ktimer_slot(KernelTimer* kt, const char* name, hipEvent_t* e0, hipEvent_t* e1) {
-    if (!kt || kt->n >= KernelTimer::CAP) return false;
+    if (!kt) return false;
+    if (kt->n >= KernelTimer::CAP) { kt->dropped++; return false; }
     if (kt->n >= kt->made) {
         if (hipEventCreate(&kt->e0[kt->made]) != hipSuccess) return false;
         if (hipEventCreate(&kt->e1[kt->made]) != hipSuccess) { (void)hipEventDestroy(kt->e0[kt->made]); return false; }
@@ -174,7 +179,7 @@ inline bool ktimer_slot(KernelTimer* kt, const char* name, hipEvent_t* e0, hipEv
 #define FORMA_LAUNCH(kern, grid, block, shm, s, ...)                                                        \
     do {                                                                                                    \
         hipEvent_t fl_e0_, fl_e1_;                                                                          \
-        if (g_ktimer && ktimer_slot(g_ktimer, #kern, &fl_e0_, &fl_e1_))                                     \
+        if (g_ktimer && g_ktimer->stream == (s) && ktimer_slot(g_ktimer, #kern, &fl_e0_, &fl_e1_))          \
             hipExtLaunchKernelGGL(kern, grid, block, shm, s, fl_e0_, fl_e1_, 0, __VA_ARGS__);               \
         else                                                                                                \
             hipLaunchKernelGGL(kern, grid, block, shm, s, __VA_ARGS__);                                     \
@@ -380,6 +385,10 @@ static inline uint32_t paint_band_tiles(uint32_t rows, uint32_t tiles_w) {
 #endif
 #ifndef RUNS_CHAIN_MAX_TILES
 #define RUNS_CHAIN_MAX_TILES 1536u      // ... when the stream is at most this many 2 048-segment tiles, i.e. about one round of the run kernel's workgroups
+// MEMORY: a chained frame indexes its run arrays like its segments, so records (32 B), run_lt (4), span_key (8), span_cov (16) and
+// the group pool (2 x 16) are provisioned for the segment bound N instead of the run bound J: 92 B per segment, ~290 MB per
+// frame slot at this limit (3.1 M segments), kept — like every per-frame buffer — until forma_hip_trim; a context that
+// alternates between chained and counted frames keeps the larger set.
 #endif
 static inline size_t row_tab_total_words(uint32_t tiles_w, uint32_t tiles_h);
 static inline uint32_t row_tab_zero_words(uint32_t tiles_w, uint32_t tiles_h) { return (tiles_h + 1) + 2 * (CR_MAX_SLICES_HOST * tiles_h + 1) + 2 + tiles_w * tiles_h + PAINT_ORDER_WORDS; }

@@ -35,13 +35,14 @@ struct DevBuf {
     template <class T> T* as() const { return (T*)p; }
 };
 
-constexpr uint32_t PAINT_STRIP_TILES = 6144;    // = the wave slots of the general painter (256 CUs x 24): every tile gets one at once   // frames of at most this many painted tiles are painted by strips (api.cpp paint_by_strips)
-constexpr uint32_t SORT_CUS_IN_FLIGHT = 128;    // persistent sort workgroups of a context with frame slots (api.cpp sort_workgroups)
+constexpr uint32_t PAINT_WAVES_PER_CU = 24;     // wave slots of the general painter per CU (6 per SIMD): frames of at most n_cus x 24 painted
+                                                // tiles — every tile gets a slot at once — are painted by strips (api.cpp paint_by_strips)
 constexpr size_t SEG_PAD = 16;          // segment buffers are over-allocated: stream kernels read whole 64-byte lane pieces
 enum { ST_PREPARE = 0, ST_RASTER, ST_SORT, ST_CARRY, ST_PAINT, ST_D2H, ST_XCHG, ST_COUNT };
 
 struct forma_hip_ctx {
     int device = 0;
+    uint32_t n_cus = 256;                   // hipDeviceProp_t::multiProcessorCount of `device` (MI355X: 256)
     hipStream_t stream = nullptr;
     char err[512] = {0};
 
@@ -197,6 +198,8 @@ struct forma_hip_ctx {
     bool lw_valid = false, lw_cache = false, lw_flags_on_host = false;
 };
 
+
+inline uint32_t paint_strip_tiles(const forma_hip_ctx* c) { return c->n_cus * PAINT_WAVES_PER_CU; }
 
 #define FORMA_RETRY 1     /* internal: a speculation of the read-back-free path was wrong, run the frame again synchronously */
 

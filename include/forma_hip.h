@@ -303,7 +303,8 @@ int forma_hip_trim(forma_hip_ctx* ctx);
  * events (the dispatch's start / end timestamps, i.e. what `rocprofv3 --kernel-trace` reports), so `us` holds no marker or
  * launch overhead; forma_timings_t's stage times are sums of these.  `stage`: 0 prepare, 1 rasterize, 2 sort, 3 carry (runs +
  * cover carry), 4 paint, 6 exchange.  `start_us` is relative to the first kernel's start.  Writes min(count, capacity) entries,
- * *out_n = count.  Single-device contexts (a multi-device context returns FORMA_E_STATE).  No reference counterpart: forma
+ * *out_n = count.  At most 96 launches of a frame are timed; a frame with more still reports its full count (the launches
+ * beyond ran untimed: *out_n > 96 says the stage sums are short by them).  Single-device contexts (a multi-device context returns FORMA_E_STATE).  No reference counterpart: forma
  * times its stages on the host (`duration!`, cpu/renderer.rs:106-223). */
 typedef struct forma_kernel_time_t {
     char     name[48];        /* kernel name without template arguments, NUL-terminated */
