@@ -194,15 +194,21 @@ int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, boo
 // fixed work — segment loads, LDS phases — and builds the tile's list itself.  Translucent discs 120 layers deep lose 16 % to
 // strips, the 4K scene's band (one layer in seven costly) gains 20 %.
 // A digit pass is one persistent 1 024-lane workgroup per CU: 148 KB of LDS and the whole register file, nothing co-resides.  With
-// frames in flight the passes of three frames therefore run one after the other on an otherwise idle chip; on fewer CUs a pass
-// is slower but the other frames' kernels run beside it (round 4 measured 128 of 256: +2.5 % frames/s with three slots, -10 %
-// with one — so only with frame slots).  FORMA_HIP_DEBUG=sort_cus=N sets it (0: all).
-static uint32_t sort_workgroups(const forma_hip_ctx* ctx) {
+// frames in flight the passes of the frames therefore run one after the other on an otherwise idle chip; on half the CUs a pass
+// is slower (89 against 60 us) but costs less CU-time, and the other frames' kernels run beside it.  Round 6 swept it
+// (tools/policy_sweep.py, profiles/r06_policy_sweep.json: 4 scene families x 5 canvases x 1-4 slots, each setting forced): with one
+// slot half the CUs lose 4-16 % everywhere; with THREE they win 0-5 % in 18 of 20 cells (never lose more than 1 %); with TWO they
+// win 1-5 % on frames of >= 4 M pixel segments and lose as much on smaller ones; with four it is a wash (+-2 %).  96 and 64 CUs
+// with three slots: +1.4 % / -1.7 % on the 4K scene (profiles/r06_experiments.txt) - the rate is set by the CU-time of all the
+// frame's kernels, not by the passes alone.  A frame whose image also crosses PCIe behind its kernels (forma_hip_render_enqueue)
+// keeps all CUs: there the passes are on the frame's critical path (two slots: 1 453 -> 1 134 frames/s with half of them).
+// FORMA_HIP_DEBUG=sort_cus=N sets it (0: all).
+static uint32_t sort_workgroups(const forma_hip_ctx* ctx, size_t n_keys) {
     if (ctx->dbg.sort_cus >= 0) return (uint32_t)ctx->dbg.sort_cus;
-    // (measured, frames/s on all / on 128 CUs: two slots 2 448 / 2 431, three 2 520 / 2 631, four 2 426 / 2 405 — so exactly three,
-    //  the setting this library recommends)
     const forma_hip_ctx* o = ctx->owner ? ctx->owner : ctx;
-    return o->slots.size() == 3 ? o->n_cus / 2u : 0u;
+    const size_t slots = o->slots.size();
+    if (ctx->frame_has_dst) return 0u;
+    return slots == 3 || (slots == 2 && n_keys >= ((size_t)1 << 22)) ? o->n_cus / 2u : 0u;
 }
 
 // Both schedules that shorten ONE frame's painter launch at the price of more work — strips, and the heavy-first order below —
@@ -303,7 +309,7 @@ int run_sort(forma_hip_ctx* ctx, const uint64_t* src, DevCount nc, bool timing, 
     ctx->sorted = (uint64_t*)launch_radix_sort(ctx->stream, src, ctx->seg_a.as<uint64_t>(), ctx->seg_b.as<uint64_t>(), nc, plan,
                                                digit_bits, ctx->sort_counters.as<uint32_t>(), &ctx->info.as<FrameInfo>()->error,
                                                chunked,
-                                               ctx->info.as<FrameInfo>(), zeroed, hist_ready, sort_workgroups(ctx));
+                                               ctx->info.as<FrameInfo>(), zeroed, hist_ready, sort_workgroups(ctx, n));
     stage_end(ctx, ST_SORT, timing);
     HIPCHECK(hipGetLastError());
     return FORMA_OK;
@@ -374,13 +380,15 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     uint32_t* row_count = ctx->row_tab.as<uint32_t>();
     uint32_t* row_span_lo = row_count + (tiles_h + 1);
     uint32_t* row_span_cnt = row_span_lo + (CR_MAX_SLICES_HOST * tiles_h + 1);
-    uint32_t* paint_overflow = row_span_cnt + (CR_MAX_SLICES_HOST * tiles_h + 1);   // [0], [1] = the two counts, then the first-run table ...
+    uint32_t* paint_overflow = row_span_cnt + (CR_MAX_SLICES_HOST * tiles_h + 1);   // [0], [1], [2] = the three counts (wave -> mid, deep -> huge, mid -> deep), then the first-run table ...
     uint32_t* over2_n = paint_overflow + 1;
-    uint32_t* tile_first_run = paint_overflow + 2;
+    uint32_t* mid_n = paint_overflow + 2;
+    uint32_t* tile_first_run = paint_overflow + 3;
     uint32_t* order_cnt = tile_first_run + T;                           // ... the painters' order counts (PaintParams::order_cnt_out) ...
     uint32_t* overflow_list = order_cnt + PAINT_ORDER_WORDS;            // ... then the lists themselves
     uint32_t* over2_list = overflow_list + T;
     uint32_t* row_base = over2_list + 2 * (size_t)T;                    // (chain numbering: where each row's runs begin)
+    uint32_t* mid_list = row_base + (tiles_h + 1);                      // {tile, entries} of the tiles beyond the mid tier's lists: 2 T words
     uint32_t J = 0;
     HIPCHECK(ctx->blk_edge.ensure(runs_blocks(std::max<size_t>(n, 1)) * sizeof(BlkEdge)));
     HIPCHECK(ctx->runs_scratch.ensure(runs_scratch_words(std::max<size_t>(n, 1)) * 4));
@@ -637,7 +645,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                  ctx->style_off.as<uint32_t>(),
                  ctx->style_words.as<uint32_t>(), ctx->images.as<forma_image_t>(), ctx->texels.as<uint16_t>(),
                  ctx->cur_image, tc, dinfo, paint_overflow, overflow_list, over2_n, over2_list, launch_deep, groups,
-                 strips, quads);
+                 strips, quads, mid_n, mid_list, ctx->n_cus);
     stage_end(ctx, ST_PAINT, timing);
     ctx->last_runs = J; ctx->last_entries = 0;
     HIPCHECK(hipGetLastError());
@@ -1469,7 +1477,9 @@ static int render_impl(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_
             d.has_crop = crop_or_null != nullptr; if (crop_or_null) d.crop = *crop_or_null;
             d.dst = dst; d.stride = stride_bytes;
             PaintArgs as{width, height, d.channels, d.clear, d.has_crop ? &d.crop : nullptr, -1};
+            sl->frame_has_dst = dst != nullptr;                   // (sort_workgroups: such a frame's digit passes keep the whole chip)
             rc = enqueue_async_frame(sl, as, false, &d.bN, &d.bJ);
+            sl->frame_has_dst = false;
             if (rc == FORMA_OK) sl->pending = true;
             if (rc == FORMA_OK && dst) {
                 // the image leaves speculatively, in one piece behind the frame's kernels (verified at settle time; a void frame

@@ -391,8 +391,8 @@ static inline uint32_t paint_band_tiles(uint32_t rows, uint32_t tiles_w) {
 // alternates between chained and counted frames keeps the larger set.
 #endif
 static inline size_t row_tab_total_words(uint32_t tiles_w, uint32_t tiles_h);
-static inline uint32_t row_tab_zero_words(uint32_t tiles_w, uint32_t tiles_h) { return (tiles_h + 1) + 2 * (CR_MAX_SLICES_HOST * tiles_h + 1) + 2 + tiles_w * tiles_h + PAINT_ORDER_WORDS; }
-static inline size_t row_tab_total_words(uint32_t tiles_w, uint32_t tiles_h) { return (size_t)row_tab_zero_words(tiles_w, tiles_h) + 3 * (size_t)tiles_w * tiles_h + tiles_h + 1; }
+static inline uint32_t row_tab_zero_words(uint32_t tiles_w, uint32_t tiles_h) { return (tiles_h + 1) + 2 * (CR_MAX_SLICES_HOST * tiles_h + 1) + 3 + tiles_w * tiles_h + PAINT_ORDER_WORDS; }
+static inline size_t row_tab_total_words(uint32_t tiles_w, uint32_t tiles_h) { return (size_t)row_tab_zero_words(tiles_w, tiles_h) + 5 * (size_t)tiles_w * tiles_h + tiles_h + 1; }
 // n_slices workgroups per tile row (each a range of layers, 256 bins of layer >> bin_shift); small: the CR_CAP_S variant
 void launch_carry_rows(hipStream_t s, bool local_sort, bool small, bool half /* with small: 512-lane workgroups, slices of <= 2048 runs */,
                        uint32_t n_slices, uint32_t bin_shift,
@@ -422,7 +422,10 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
                   SpanGroups groups /* tab == nullptr: the painters scan the row lists (p.n_groups is ignored) */,
                   bool strips = false /* four wavefronts per tile, each a 16 x 4 strip (k_paint_wave<.., NPX = 1>): frames that do not
                                          fill the chip with one wavefront per tile; ignored with a buffer-layer cache */,
-                  bool quads = false /* four tiles per wavefront (k_paint_quad): all-solid scenes with shallow tiles; ignored otherwise */);
+                  bool quads = false /* four tiles per wavefront (k_paint_quad): all-solid scenes with shallow tiles; ignored otherwise */,
+                  uint32_t* mid_n = nullptr /* zeroed by launch_runs */, uint32_t* mid_list = nullptr /* {tile, entries} pairs of the tiles beyond
+                                         k_paint_deep's 1024-entry tier: 2 * tiles_w * tiles_h words (both required with launch_deep) */,
+                  uint32_t n_cus = 256);
 // tiles whose layer list exceeds the painter's LDS lists (info->error bit 3 after launch_paint): lists in global memory,
 // offs[i] = first entry slot of tile over2_list[2 i]; g_key holds 4 entries per slot, g_tmp / g_flag one
 void launch_paint_huge(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, DevCount n_runs,

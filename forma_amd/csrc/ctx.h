@@ -112,6 +112,7 @@ struct forma_hip_ctx {
     size_t h_written_cap = 0;
     uint8_t* h_stage = nullptr;             // pinned staging image for tile-granular copy-out
     size_t h_stage_cap = 0;
+    bool frame_has_dst = false;             // the frame being enqueued on this slot also copies its image out (forma_hip_render_enqueue)
     bool image_sent = false;                // a deferred frame into caller memory: its image left behind the kernels, before the frame was verified
     std::vector<std::pair<void*, size_t>> registered;   // caller buffers pinned by forma_hip_register_buffer
     int cur_cache = -1;                     // cache of the frame in flight

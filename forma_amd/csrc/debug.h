@@ -20,7 +20,7 @@
 //   carry_half=0|1|N     never / by policy / with N slices per row: the 512-lane carry kernel (three workgroups per CU)
 //   paint_quad=0|1|2     the four-tiles-per-wavefront painter of all-solid scenes: never / by policy / always
 //   order_thr=N          the painters file a tile as heavy from N shader clocks on (no steering, never switched off): tests
-//   sort_cus=N           persistent workgroups of a digit pass (0: one per CU; default: all, or 128 of 256 in a context with three frame slots)
+//   sort_cus=N           persistent workgroups of a digit pass (0: one per CU; default: all, or half the CUs in a context with three frame slots — with two from 4 M keys on)
 //   no_order             the painters always take their tiles in index order (PaintParams::order_*)
 //   no_cull / force_cull the painters never / always drop the entries below a tile's topmost occluder (PaintParams::cull; default:
 //                        once the geometry has had tiles beyond the wave painter's lists)

@@ -3014,21 +3014,28 @@ __global__ __launch_bounds__(64, PAINT_SIMPLE_OCC) void k_paint_quad(PaintParams
                      TileCacheArgs cache, FrameInfo* __restrict__ info
 
 #define PAINT_MAXE_DEEP 4096
+#define PAINT_MAXE_MID  1024
 #define PAINT_ARGS2 P, tile, sorted, records, n_runs, tile_first_run, row_span_lo, row_span_cnt, span_key, span_cov, layer_col, \
                     style_offsets, style_words, images, texels, image, cache, info
-// the rare deep tiles the first launch could not hold
-__global__ __launch_bounds__(256) void k_paint_deep(PAINT_PARAMS, const uint32_t* __restrict__ overflow_n,
-                                                    const uint32_t* __restrict__ overflow_list, uint32_t* __restrict__ over2_n,
-                                                    uint32_t* __restrict__ over2_list) {
-    __shared__ uint64_t e_key[PAINT_MAXE_DEEP];                        // staging for the span scan (4 x 1024), then the merged layer list
-    __shared__ uint64_t e_tmp[PAINT_MAXE_DEEP];                        // [0, na) own runs, [na, ne) crossing spans; later the painted entries
-    __shared__ uint32_t e_flag[PAINT_MAXE_DEEP];
+// The deep tiles the first launch could not hold, in two tiers.  MAXE = 1024 (20 KB of lists + 7 KB of paint_tile's own LDS,
+// 105 VGPRs: FOUR workgroups per CU) takes the wave painters' overflow list; what does not fit it goes on to MAXE = 4096 (80 KB of
+// lists: one workgroup per CU), and from there to k_paint_huge.  Until round 5 there was only the 4096-entry kernel: one
+// 256-lane workgroup per CU — 1 wave per SIMD — painted every tile beyond the wave painters' 128 entries, and the reference
+// demo's own `circles` mode at 20 000 discs (120 layers per tile: half its tiles are "deep") spent 102 us there.
+// STRIDE: the words per entry of `list` (1: tile ids — the wave painters' list; 2: {tile, entries} pairs — the mid tier's).
+template <int MAXE, int STRIDE>
+__global__ __launch_bounds__(256) void k_paint_deep(PAINT_PARAMS, const uint32_t* __restrict__ list_n,
+                                                    const uint32_t* __restrict__ list, uint32_t* __restrict__ over_n,
+                                                    uint32_t* __restrict__ over_list) {
+    __shared__ uint64_t e_key[MAXE];                                   // staging for the span scan (4 x MAXE / 4), then the merged layer list
+    __shared__ uint64_t e_tmp[MAXE];                                   // [0, na) own runs, [na, ne) crossing spans; later the painted entries
+    __shared__ uint32_t e_flag[MAXE];
     if (info->plan_bad) return;
-    const uint32_t n = overflow_n[0];
+    const uint32_t n = list_n[0];
     const uint32_t n_runs = dev_count(nc_runs);
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-        const uint32_t tile = overflow_list[i];
-        paint_tile(PAINT_MAXE_DEEP, PAINT_MAXE_DEEP / 4, e_key, e_tmp, e_flag, PAINT_ARGS2, over2_n, over2_list);
+        const uint32_t tile = list[(size_t)STRIDE * i];
+        paint_tile(MAXE, MAXE / 4, e_key, e_tmp, e_flag, PAINT_ARGS2, over_n, over_list);
         __syncthreads();
     }
 }
@@ -3052,7 +3059,8 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
                   const uint64_t* span_key, const uint4* span_cov, const uint4* layer_col,
                   const uint32_t* style_offsets, const uint32_t* style_words, const forma_image_t* images,
                   const uint16_t* texels, uint8_t* image, TileCacheArgs cache, FrameInfo* info, uint32_t* overflow_n,
-                  uint32_t* overflow_list, uint32_t* over2_n, uint32_t* over2_list, bool launch_deep, SpanGroups groups, bool strips, bool quads) {
+                  uint32_t* overflow_list, uint32_t* over2_n, uint32_t* over2_list, bool launch_deep, SpanGroups groups, bool strips, bool quads,
+                  uint32_t* mid_n, uint32_t* mid_list, uint32_t n_cus) {
     const uint32_t T = p.tiles_w * p.tiles_h;
     if (T == 0 || p.crop_y1 <= p.crop_y0) return;
     const uint32_t per = paint_band_tiles(p.crop_y1 - p.crop_y0, p.tiles_w);
@@ -3082,9 +3090,15 @@ void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, c
 #undef PW_LAUNCH
     }
     if (!launch_deep) return;                             // (read-back-free frame of a scene whose last frame had no deep tile)
-    FORMA_LAUNCH(k_paint_deep, dim3(T < 256 ? T : 256), dim3(256), 0, s, p, sorted, records, n_runs, tile_first_run,
+    // mid tier: four workgroups per CU; its own overflow ({tile, entries} pairs in mid_list) goes to the 4096-entry tier, whose
+    // launch is empty (~4 us) in every frame without a tile beyond 1024 entries — paid only by frames that have deep tiles at all
+    const uint32_t g_mid = std::min<uint32_t>(T, 4u * n_cus), g_deep = std::min<uint32_t>(T, n_cus);
+    FORMA_LAUNCH((k_paint_deep<PAINT_MAXE_MID, 1>), dim3(g_mid), dim3(256), 0, s, p, sorted, records, n_runs, tile_first_run,
                        row_span_lo, row_span_cnt, span_key, span_cov, layer_col, style_offsets, style_words, images,
-                       texels, image, cache, info, (const uint32_t*)overflow_n, (const uint32_t*)overflow_list, over2_n, over2_list);
+                       texels, image, cache, info, (const uint32_t*)overflow_n, (const uint32_t*)overflow_list, mid_n, mid_list);
+    FORMA_LAUNCH((k_paint_deep<PAINT_MAXE_DEEP, 2>), dim3(g_deep), dim3(256), 0, s, p, sorted, records, n_runs, tile_first_run,
+                       row_span_lo, row_span_cnt, span_key, span_cov, layer_col, style_offsets, style_words, images,
+                       texels, image, cache, info, (const uint32_t*)mid_n, (const uint32_t*)mid_list, over2_n, over2_list);
 }
 
 void launch_paint_huge(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, DevCount n_runs,

@@ -31,7 +31,10 @@
 #define OS_WAVES   (OS_THREADS / 64)
 // keys per lane: 16 (16384 keys per tile -> 128 KiB of LDS staging, 1 workgroup = 16 waves per CU); the 512-bin pass takes 14 —
 // its counters and 9-bit ranks cost registers, at 16 keys it spilled (C4: 59.2 -> 53.6 us per pass; 256 bins: 62.1 -> 63.4)
-__host__ __device__ constexpr int os_kpt(int bits) { return bits == 9 ? 14 : 16; }
+#ifndef OS_KPT9
+#define OS_KPT9 14
+#endif
+__host__ __device__ constexpr int os_kpt(int bits) { return bits == 9 ? OS_KPT9 : 16; }
 // ... and fewer where n keys are not 256 such tiles: a pass of 2.7 M keys (1080p) was 164 tiles on 256 CUs, each the full
 // latency of a 16 384-key tile — load, rank, stage, look-back, scatter, about half of it proportional to the keys per lane.
 // With 8 / 12 keys per lane the same keys are ONE round of shorter tiles on (nearly) every CU.  0: the default of the digit width.
@@ -45,7 +48,7 @@ static inline int os_kpt_small(size_t n) {
     return 0;
 }
 // provisioning (row stride of the status words): the most tiles any pass of n keys can have
-static inline size_t os_tile_min(size_t n) { const int k = os_kpt_small(n); return (size_t)OS_THREADS * (size_t)(k ? k : 14); }
+static inline size_t os_tile_min(size_t n) { const int k = os_kpt_small(n); return (size_t)OS_THREADS * (size_t)(k ? k : (OS_KPT9 < 16 ? OS_KPT9 : 16)); }
 #define ST_VALMASK 0x3FFFFFFFu
 #ifndef OS_LBW
 #define OS_LBW     8
@@ -335,6 +338,7 @@ __global__ __launch_bounds__(OS_THREADS, 4) void k_onesweep(const uint64_t* __re
                                                          ChunkedSrc C /* first pass of a chunked stream, else n_chunks = 0 */) {
     constexpr int RADIX = 1 << BITS;
     constexpr int KPT = KPT_ ? KPT_ : os_kpt(BITS), TILE = OS_THREADS * KPT;  // keys per lane, keys per tile
+    static_assert(KPT % 2 == 0, "the 16-bit ranks of a lane are packed two per register");
     const uint32_t n = dev_count(nc);                       // (chunked: k_sort_hist has published the total)
     constexpr bool chunked = CHUNKED;                       // (one bucket at offset 0 is launched as a plain stream)
     ChunkMap M;

@@ -148,8 +148,13 @@ def main():
         t0 = time.perf_counter(); loop(c, a.frames)
         d = (time.perf_counter() - t0) / a.frames * 1e6
         best1 = d if best1 is None else min(best1, d)
-    pool = [c] + [rank_context()[0] for _ in range(a.contexts - 1)]
-    for cc in pool[1:]:
+    # (frame slots of a multi-device context run their digit passes on half the CUs — api.cpp sort_workgroups; three independent
+    #  contexts do not know of each other: the switch gives them what the slots' policy would)
+    c.close()
+    os.environ["FORMA_HIP_DEBUG"] = "sort_cus=128"
+    pool = [rank_context()[0] for _ in range(a.contexts)]
+    os.environ.pop("FORMA_HIP_DEBUG", None)
+    for cc in pool:
         for _ in range(6):
             frame(cc)
     bestF = None
