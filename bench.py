@@ -95,12 +95,16 @@ def preflight(devices):
     buf = np.zeros(512 * 512 * 4, np.uint8)
     lay = api.LinearLayout(512, 2048, 512)
     first = None
-    for _ in range(4):
-        r.render(comp, api.BufferBuilder(buf, lay).build(), api.RGBA, api.Color(1, 1, 1, 1), None)
-        first = buf.copy() if first is None else first
-        assert np.array_equal(first, buf)
-    assert (buf != 255).any()
-    print("PREFLIGHT-OK", flush=True)
+    # both layouts of the multi-device context (forma_hip_multi_layout): BANDS needs no collective; EXCHANGE is the first
+    # execution of the RCCL all-to-all over more than one device that this project has ever seen — each announces itself
+    for layout in ("bands", "exchange"):
+        r._ctx.set_layout(layout)
+        for _ in range(4):
+            r.render(comp, api.BufferBuilder(buf, lay).build(), api.RGBA, api.Color(1, 1, 1, 1), None)
+            first = buf.copy() if first is None else first
+            assert np.array_equal(first, buf), layout
+        assert (buf != 255).any()
+        print("PREFLIGHT-OK " + layout, flush=True)
 
 
 def main():
@@ -263,6 +267,28 @@ def main():
         fps = frames_per_step * args.steps / elapsed
         ms_per_step = elapsed / args.steps * 1e3
         blocks = [rate(args.steps, frames_per_step) for _ in range(5)]
+        # the multi-device context's two layouts (forma_hip_multi_layout): `value` is the default's (AUTO), both are listed
+        layouts = None
+        if mode == "multi" and driver:
+            chosen = ctx.info().get("layout")
+            layouts = {chosen: round(statistics.median(blocks), 1)}
+            other = "exchange" if chosen == "bands" else "bands"
+            if other == "exchange" and os.environ.get("FORMA_BENCH_NO_EXCHANGE"):
+                layouts[other] = None
+            else:
+                try:
+                    ctx.set_layout(other)
+                    frames(3 * in_flight + 3)
+                    layouts[other] = round(statistics.median(rate(args.steps, frames_per_step) for _ in range(3)), 1)
+                except Exception as e:                                  # noqa: BLE001  (never lose the line to the second layout)
+                    layouts[other] = None
+                    errors_layout = repr(e)
+                    layouts["error"] = errors_layout
+                try:
+                    ctx.set_layout("auto")
+                    frames(3 * in_flight + 3)
+                except Exception:                                       # noqa: BLE001
+                    pass
         # one frame in flight: every render call is complete when it returns (1 / wall time of one render call)
         if driver and in_flight > 1:
             ctx.set_frames_in_flight(1)
@@ -429,8 +455,9 @@ def main():
         sharding_txt = {
             "single": "none",
             "multi": f"ONE renderer context over {len(multi_devices)} GPUs (forma_hip_create_multi, driven by rank 0; per-device host threads inside "
-                     f"libforma_hip.so): lines / {len(multi_devices)} rasterized per GPU, HIP bucketing by tile-row owner, one RCCL all-to-all of pixel "
-                     f"segments on the devices' streams, band-local sort + paint, every device writes its rows of the one caller buffer",
+                     f"libforma_hip.so), tile-row bands of equal pixel-segment counts, every device writes its rows of the one caller buffer; layout "
+                     f"AUTO (forma_hip_multi_layout): BANDS = every device culls the whole scene to its band, no exchange; EXCHANGE = lines / "
+                     f"{len(multi_devices)} rasterized per GPU, HIP bucketing by tile-row owner, one RCCL all-to-all of pixel segments",
             "frames": f"frame-parallel x{world}: every GPU renders whole frames of the workload (units = frames), no exchange",
             "bands": f"tile-row bands x{world} of ONE frame, replicated scene, band culling, no data-path collective",
             "exchange": f"ONE frame, one process per GPU: lines / {world} rasterized per GPU, HIP bucketing by tile-row owner, one RCCL all-to-all of "
@@ -474,6 +501,11 @@ def main():
             "roofline_painter": painter,
         }
         out["fps_one_frame_in_flight"] = out["fps_render_call"]       # (the name earlier rounds used)
+        if layouts is not None:
+            out["multi_layouts_fps"] = layouts
+            out["multi_layouts_what"] = ("frames/s of the same multi-device context in both layouts (forma_hip_multi_layout): 'bands' = no exchange, every "
+                                         "device culls the scene to its band of tile rows; 'exchange' = line shares + one all-to-all of pixel segments; "
+                                         "`value` is the default layout's (AUTO picks per scene)")
         if driver and ctx is not None:
             try:
                 out["context"] = ctx.info()                           # devices, frame slots, exchange transport (rccl / copy)
@@ -505,10 +537,17 @@ def main():
             try:
                 p = subprocess.run([sys.executable, os.path.abspath(__file__), "--preflight", ",".join(str(d) for d in multi_devices)],
                                    capture_output=True, text=True, timeout=240)
-                ok = p.returncode == 0 and "PREFLIGHT-OK" in p.stdout
+                ok = "PREFLIGHT-OK bands" in p.stdout                 # (BANDS is enough to go on; EXCHANGE is measured only if it passed too)
+                if "PREFLIGHT-OK exchange" not in p.stdout:
+                    os.environ["FORMA_BENCH_NO_EXCHANGE"] = "1"
+                    errors["multi-exchange"] = "preflight: " + (p.stderr or p.stdout)[-400:]
                 why = (p.stderr or p.stdout)[-400:] if not ok else ""
-            except subprocess.TimeoutExpired:
-                ok, why = False, "preflight timed out (killed)"
+            except subprocess.TimeoutExpired as e:
+                out_so_far = (e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or ""))
+                ok = "PREFLIGHT-OK bands" in out_so_far
+                os.environ["FORMA_BENCH_NO_EXCHANGE"] = "1"
+                errors["multi-exchange"] = "preflight timed out in the exchange layout (killed)"
+                why = "" if ok else "preflight timed out (killed)"
             except Exception as e:                                    # noqa: BLE001
                 ok, why = False, repr(e)
         return agreed(ok), why

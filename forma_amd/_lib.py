@@ -49,7 +49,7 @@ class TimingsT(C.Structure):
 
 
 class ContextInfoT(C.Structure):
-    _fields_ = [("n_devices", C.c_uint32), ("frames_in_flight", C.c_uint32), ("transport", C.c_uint32), ("reserved", C.c_uint32),
+    _fields_ = [("n_devices", C.c_uint32), ("frames_in_flight", C.c_uint32), ("transport", C.c_uint32), ("layout", C.c_uint32),
                 ("devices", C.c_int32 * 8)]
 
 
@@ -92,6 +92,7 @@ SYMBOLS = {
     "forma_hip_unregister_buffer": (_i, [_vp, _vp]),
     "forma_hip_cache_clear": (_i, [_vp, _i]),
     "forma_hip_set_frames_in_flight": (_i, [_vp, _i]),
+    "forma_hip_multi_layout": (_i, [_vp, _i]),
     "forma_hip_sync": (_i, [_vp]),
     "forma_hip_context_info": (_i, [_vp, _vp]),
     "forma_hip_sort_plan": (_i, [C.c_uint64, _i, _i, _vp, _vp]),

@@ -21,7 +21,9 @@ class Context:
     several GPUs behind the same calls (forma_hip_create_multi: line-sharded rasterization, one RCCL all-to-all of pixel
     segments, band-local sort + paint, every device writing its rows of the caller's buffer)."""
 
-    def __init__(self, device: int = 0, devices=None, frames_in_flight: int = 1):
+    LAYOUTS = {"auto": 0, "exchange": 1, "bands": 2}
+
+    def __init__(self, device: int = 0, devices=None, frames_in_flight: int = 1, layout=None):
         self._L = _lib.lib()
         h = C.c_void_p()
         if devices is not None:
@@ -36,8 +38,15 @@ class Context:
         self.device = device
         self.devices = None if devices is None else [int(d) for d in devices]
         self.n_points = 0
+        if layout is not None:
+            self.set_layout(layout)
         if frames_in_flight != 1:
             self.set_frames_in_flight(frames_in_flight)
+
+    def set_layout(self, layout):
+        """forma_hip_multi_layout: how a multi-device context splits a frame — 'exchange' (line shares + one all-to-all of
+        pixel segments), 'bands' (no exchange: every device culls the scene to its band of tile rows) or 'auto'."""
+        self._check(self._L.forma_hip_multi_layout(self._h, self.LAYOUTS[layout] if isinstance(layout, str) else int(layout)))
 
     def set_frames_in_flight(self, n: int):
         """forma_hip_set_frames_in_flight: device-resident, cache-less frames are enqueued on n frame slots; see sync()"""
@@ -50,6 +59,7 @@ class Context:
         self._check(self._L.forma_hip_context_info(self._h, C.byref(ci)))
         return {"n_devices": int(ci.n_devices), "frames_in_flight": int(ci.frames_in_flight),
                 "transport": {0: "none", 1: "rccl", 2: "copy"}.get(int(ci.transport), "?"),
+                "layout": {0: "single", 1: "exchange", 2: "bands"}.get(int(ci.layout), "?") if ci.n_devices > 1 else "single",
                 "devices": [int(ci.devices[i]) for i in range(ci.n_devices)]}
 
     def kernel_times(self):

@@ -111,7 +111,10 @@ LineSource geometry_source(forma_hip_ctx* ctx, uint32_t width, uint32_t height) 
     S.geoms = ctx->geoms.as<forma_geom_t>(); S.n_geoms = (uint32_t)ctx->n_geoms;
     S.width = (float)width; S.height = (float)height;
     S.band_lo = -3.0e38f; S.band_hi = 3.0e38f;
-    if (ctx->band_row1 > 0) { S.band_lo = (float)(ctx->band_row0 * 16u); S.band_hi = (float)(ctx->band_row1 * 16u); }
+    // (an eighth of a pixel = two sub-pixel steps wider than the band: a line within half a sub-pixel step of the band's edge can
+    //  round INTO the band's first or last tile row (a zero-cover segment: invisible, but part of the sorted stream) — lines are
+    //  only culled where no rounding can bring them back; k_rasterize's exact tile-row test flags what a kept line leaves outside)
+    if (ctx->band_row1 > 0) { S.band_lo = (float)(ctx->band_row0 * 16u) - 0.125f; S.band_hi = (float)(ctx->band_row1 * 16u) + 0.125f; }
     return S;
 }
 
@@ -1556,6 +1559,12 @@ int forma_hip_set_frames_in_flight(forma_hip_ctx* ctx, int n) {
     return FORMA_OK;
 }
 
+int forma_hip_multi_layout(forma_hip_ctx* ctx, int layout) {
+    if (!ctx) return FORMA_E_ARG;
+    if (!ctx->multi) return fail(ctx, FORMA_E_STATE, "not a multi-device context");
+    return multi_set_layout(ctx, layout);
+}
+
 int forma_hip_sync(forma_hip_ctx* ctx) {
     if (!ctx) return FORMA_E_ARG;
     if (ctx->multi) return multi_sync(ctx);
@@ -2117,9 +2126,10 @@ int fd_line_sums(forma_hip_ctx* ctx, uint32_t width, uint32_t height, std::vecto
     HIPCHECK(ctx->prep_scratch.ensure(prepare_scratch_words(n) * 4));
     HIPCHECK(ctx->scan_tmp.ensure(scan_tmp_words(std::max<size_t>(n, 1 << 16)) * 4));
     const bool keep = ctx->line_ranged;
-    ctx->line_ranged = false;
+    const uint32_t keep_b0 = ctx->band_row0, keep_b1 = ctx->band_row1;     // (ALL lines, whole canvas: neither a line share nor a band)
+    ctx->line_ranged = false; ctx->band_row0 = 0; ctx->band_row1 = 0;
     const LineSource S = geometry_source(ctx, width, height);
-    ctx->line_ranged = keep;
+    ctx->line_ranged = keep; ctx->band_row0 = keep_b0; ctx->band_row1 = keep_b1;
     launch_line_lengths(ctx->stream, S, (uint32_t)n, ctx->l_len.as<uint32_t>(), ctx->prep_scratch.as<uint32_t>());
     launch_inclusive_scan_u32(ctx->stream, ctx->l_len.as<uint32_t>(), n, ctx->scan_tmp.as<uint32_t>(), nullptr);
     HIPCHECK(hipGetLastError());
@@ -2143,6 +2153,8 @@ int fd_row_histogram(forma_hip_ctx* ctx, uint32_t width, uint32_t height, uint32
     if (n_segments) *n_segments = (uint32_t)ctx->n_seg;
     return FORMA_OK;
 }
+
+forma_hip_ctx* fd_last_slot(forma_hip_ctx* ctx) { return ctx->last ? ctx->last : ctx; }
 
 int fd_copy_image_rows(forma_hip_ctx* ctx, uint8_t* dst, size_t stride_bytes, uint32_t y0, uint32_t y1) {
     if (!ctx || !dst) return FORMA_E_ARG;

@@ -225,6 +225,8 @@ int fd_gsp_defer(forma_hip_ctx* ctx, uint32_t width, uint32_t height, const uint
 int fd_gsp_settle(forma_hip_ctx* ctx);
 // rows [y0, y1) of the context's last image -> dst (row-major, stride bytes per row, dst addresses row 0)
 int fd_copy_image_rows(forma_hip_ctx* ctx, uint8_t* dst, size_t stride_bytes, uint32_t y0, uint32_t y1);
+// the frame slot that holds the context's most recent frame (the context itself without frame slots)
+forma_hip_ctx* fd_last_slot(forma_hip_ctx* ctx);
 
 // the stream (0 unsorted, 1 sorted) / the written-tile flags of exactly this context's last frame
 int fd_read_stream(forma_hip_ctx* ctx, int which, uint64_t* out, size_t capacity, size_t* out_n);
@@ -233,6 +235,7 @@ int fd_tiles_written(forma_hip_ctx* ctx, uint8_t* flags, size_t n_tiles);
 
 // multi.cpp: the entry points of a multi-device context (ctx->multi != nullptr)
 int  multi_set_frames_in_flight(forma_hip_ctx* ctx, int n);
+int  multi_set_layout(forma_hip_ctx* ctx, int layout);
 int  multi_sync(forma_hip_ctx* ctx);
 void multi_info(forma_hip_ctx* ctx, forma_context_info_t* out);
 int  multi_create(forma_hip_ctx** out, const int* devices, int n);

@@ -30,6 +30,7 @@
 //   trim_debug           forma_hip_trim prints what it releases
 //   force_exchange       forma_hip_create_multi with ONE device still builds the multi-device context (RCCL world of one)
 //   xchg=copy            multi-device contexts exchange with device copies instead of RCCL
+//   multi_layout=exchange|bands   the layout a multi-device context starts with (forma_hip_multi_layout; default: auto)
 #pragma once
 #include <cstdlib>
 #include <cstring>
@@ -39,7 +40,7 @@ struct ForMaDebug {
     bool sync = false, global_runsort = false, xgather = false, no_small_carry = false, span_groups = false, no_span_groups = false;
     bool no_packed_copy = false, no_simple_paint = false, force_simple_paint = false, trim_debug = false, force_exchange = false;
     bool xchg_copy = false, no_prezero = false, no_bias = false, no_ras_hist = false, no_cull = false, force_cull = false, no_order = false;
-    int carry_slices = 0, digit_bits = 0, poison = -1, poison_frame = -1, strip_tiles = -1, carry_half = 1, paint_quad = 1, order_thr = -1, sort_cus = -1, runs_chain = -1;
+    int carry_slices = 0, digit_bits = 0, poison = -1, poison_frame = -1, strip_tiles = -1, carry_half = 1, paint_quad = 1, order_thr = -1, sort_cus = -1, runs_chain = -1, multi_layout = 0;
 };
 
 inline ForMaDebug forma_debug_parse() {
@@ -58,6 +59,7 @@ inline ForMaDebug forma_debug_parse() {
         FD_FLAG(no_cull) FD_FLAG(force_cull) FD_FLAG(no_order) FD_FLAG(no_prezero) FD_FLAG(no_bias) FD_FLAG(no_ras_hist) FD_FLAG(no_packed_copy) FD_FLAG(no_simple_paint) FD_FLAG(force_simple_paint) FD_FLAG(trim_debug) FD_FLAG(force_exchange)
 #undef FD_FLAG
         if (!strcmp(tok, "xchg")) { d.xchg_copy = val && !strcmp(val, "copy"); continue; }
+        if (!strcmp(tok, "multi_layout")) { d.multi_layout = val && !strcmp(val, "exchange") ? 1 : (val && !strcmp(val, "bands") ? 2 : 0); continue; }
         if (!strcmp(tok, "carry_slices")) { d.carry_slices = (int)v; continue; }
         if (!strcmp(tok, "digit_bits")) { d.digit_bits = (int)v; continue; }
         if (!strcmp(tok, "carry_half")) { d.carry_half = (int)std::max(v, 0L); continue; }

@@ -133,6 +133,16 @@ struct MultiState {
     int dev[FORMA_MAX_RANKS] = {0};
     bool duplicates = false;                  // a device is listed twice: rehearsal on one GPU, device copies instead of RCCL
     bool use_rccl = false;
+    // LAYOUT of a frame across the devices (forma_hip_multi_layout, forma_hip.h).  EXCHANGE: the north star's — every device
+    // rasterizes a share of the LINES, the pixel segments travel to the owner of their tile row (one all-to-all).  BANDS: no
+    // exchange at all — every device holds the whole scene anyway, so it prepares ALL lines but culls them to its band of tile
+    // rows in the frame's first kernel (LineSource::band_lo / band_hi: a line outside the band has length 0; the segments of a
+    // line that crosses the band's edge are flagged out of it by k_rasterize), then runs the plain single-device frame on its
+    // band.  What BANDS repeats on every device is k_line_len over all lines (14 us for the 1.6 M lines of the 4K scene); what
+    // it saves is the three bucketing kernels, the collective, and k_sort_hist on the received stream (the rasterizer's fused
+    // histograms need the keys it made itself).  AUTO picks by that trade (choose_layout).
+    int layout_req = FORMA_LAYOUT_AUTO, layout = FORMA_LAYOUT_EXCHANGE;
+    bool kids_banded = false;                 // the kids carry forma_hip_set_band restrictions (BANDS plan): an EXCHANGE plan lifts them
     ncclComm_t comm[FORMA_MAX_FRAMES_IN_FLIGHT][FORMA_MAX_RANKS] = {{nullptr}};   // one set of communicators per frame slot
     hipEvent_t ev_bucket[FORMA_MAX_FRAMES_IN_FLIGHT][FORMA_MAX_RANKS] = {{nullptr}};
     // the plan
@@ -219,11 +229,72 @@ uint32_t pair_capacity(uint64_t max_pair) {          // 6 % slack, whole 2048-se
     return (uint32_t)std::min<uint64_t>((c + 2047) / 2048 * 2048, 0x3FFFFFFFull);
 }
 
+int create_slot_transport(MultiState* M, int s);
+void fall_back_to_copies(MultiState* M, const char* why);
+
+// EXCHANGE against BANDS, per device and frame, in bytes that cross HBM: the exchange re-touches the device's N / G pixel
+// segments about four times (k_owner_count reads them, k_owner_scatter reads and writes them, k_sort_hist reads what arrived)
+// and pays four more launches and the collective (a fixed 8 MB-equivalent each: ~2 us of a 4 TB/s stream); BANDS prepares the
+// (G - 1) / G of the lines that are not the device's share once more (12 B each).  With the bench scenes (8-170 pixel segments per
+// line) BANDS wins at every device count; EXCHANGE needs a scene of many short lines — more lines than pixel segments.
+int choose_layout(size_t n_lines, uint64_t n_segments, int G) {
+    const double exchange_extra = 32.0 * (double)n_segments / G + 5.0 * 8.0e6;
+    const double bands_extra = 12.0 * (double)n_lines * (G - 1) / G;
+    return bands_extra > exchange_extra ? FORMA_LAYOUT_EXCHANGE : FORMA_LAYOUT_BANDS;
+}
+
+// BANDS: tile-row bands of (nearly) equal pixel-segment counts from ONE row histogram of the whole scene (device 0); device g is
+// restricted to its band (forma_hip_set_band), nobody to a line range.  No capacities: nothing can overflow.
+int make_plan_bands(forma_hip_ctx* ctx, uint32_t width, uint32_t height) {
+    MultiState* M = ctx->multi;
+    const int G = M->G;
+    const uint32_t tiles_h = (height + 15) / 16;
+    int rc;
+    for (int g = 0; g < G; g++) {
+        if ((rc = fd_set_line_range(M->kid[g], false, 0, 0))) { copy_err(ctx, M->kid[g]); return rc; }
+        if ((rc = forma_hip_set_band(M->kid[g], 0, 0))) { copy_err(ctx, M->kid[g]); return rc; }
+    }
+    std::vector<uint32_t> hist(2048, 0u);
+    if ((rc = fd_row_histogram(M->kid[0], width, height, hist.data(), nullptr))) { copy_err(ctx, M->kid[0]); return rc; }
+    std::vector<uint64_t> all(std::max<uint32_t>(tiles_h, 1), 0ull);
+    for (uint32_t r = 0; r < tiles_h && r < 2047; r++) all[r] = hist[r];
+    const bool had_plan = M->plans_made > 0 && M->plan_w == width && M->plan_h == height;
+    uint32_t old_edges[FORMA_MAX_DEVICES + 1];
+    for (int g = 0; g <= G; g++) old_edges[g] = M->edges[g];
+    band_edges(all, tiles_h, G, M->edges);
+    bool bands_moved = !had_plan;
+    for (int g = 0; g <= G; g++) bands_moved |= old_edges[g] != M->edges[g];
+    for (int g = 0; g < G; g++) {
+        // (an empty band — more devices than tile rows — gets no restriction and no frames: device_frame skips it)
+        if (M->edges[g] < M->edges[g + 1] && (rc = forma_hip_set_band(M->kid[g], M->edges[g], M->edges[g + 1]))) { copy_err(ctx, M->kid[g]); return rc; }
+        for (int c = 0; c < 32 && bands_moved; c++)
+            if (M->cache_used[c] && (rc = forma_hip_cache_clear(M->kid[g], c))) { copy_err(ctx, M->kid[g]); return rc; }
+    }
+    M->kids_banded = true;
+    M->cap = 0;
+    M->planned = true; M->plan_w = width; M->plan_h = height; M->plans_made++;
+    return FORMA_OK;
+}
+
 int make_plan(forma_hip_ctx* ctx, uint32_t width, uint32_t height) {
     MultiState* M = ctx->multi;
     const int G = M->G;
     const uint32_t tiles_h = (height + 15) / 16;
     int rc;
+    if (M->layout == FORMA_LAYOUT_BANDS) return make_plan_bands(ctx, width, height);
+    if (M->kids_banded) {                                  // (the last plan was a BANDS plan: every device sees all tile rows again)
+        for (int g = 0; g < G; g++) if ((rc = forma_hip_set_band(M->kid[g], 0, 0))) { copy_err(ctx, M->kid[g]); return rc; }
+        M->kids_banded = false;
+    }
+    // the exchange's transport, made when the first EXCHANGE plan is: communicators (or events for the copy transport) per slot
+    for (int sl = 0; sl < M->F; sl++) {
+        rc = create_slot_transport(M, sl);
+        if (rc == FORMA_E_COMM) {                          // (ADVICE r3: a working peer-copy exchange beats FORMA_E_COMM)
+            fall_back_to_copies(M, rccl_api()->handle ? "ncclCommInitAll failed" : rccl_api()->why);
+            rc = create_slot_transport(M, sl);
+        }
+        if (rc) return MFAIL(rc, "multi-device context: cannot create a frame slot's transport");
+    }
     std::vector<uint32_t> sums;
     if ((rc = fd_line_sums(M->kid[0], width, height, sums))) { copy_err(ctx, M->kid[0]); return rc; }
     line_shares(sums, G, M->cuts);
@@ -278,6 +349,20 @@ void device_frame(MultiState* M, int g) {
     const FrameJob& J = M->job;
     forma_hip_ctx* kid = slot_ctx(M, g, J.slot);
     const int G = M->G;
+    if (M->layout == FORMA_LAYOUT_BANDS) {
+        // the plain single-device frame of this device's band: forma_hip_render on the device's own context, cropped to the band
+        // (it paints and copies out the band's rows only); with frame slots a device-resident frame is enqueued by the device's
+        // own slot logic (api.cpp render_impl) and settled there
+        forma_hip_ctx* k0 = M->kid[g];
+        memset(&M->tm[g], 0, sizeof M->tm[g]);
+        if (J.mode == FrameJob::SETTLE) { M->rc[g] = forma_hip_sync(k0); return; }
+        const forma_rect_t& bc = M->band_crop[g];
+        // (a band outside the caller's crop still rasterizes and sorts — an empty crop paints nothing — so that the context's
+        //  sorted stream is whole, as in the EXCHANGE layout; only a device without a band, more devices than tile rows, sits out)
+        if (M->edges[g] >= M->edges[g + 1]) { M->rc[g] = FORMA_OK; return; }
+        M->rc[g] = forma_hip_render(k0, J.dst, J.width, J.height, J.stride, J.channels, J.clear, &bc, J.cache_id, J.timings ? &M->tm[g] : nullptr);
+        return;
+    }
     if (J.mode == FrameJob::SETTLE) {                       // complete this device's part of the slot's deferred frame
         M->rc[g] = fd_gsp_settle(kid);
         return;
@@ -415,6 +500,22 @@ void set_band_crops(MultiState* M, uint32_t width, uint32_t height, const forma_
     }
 }
 
+// devices work side by side: a stage takes as long as its slowest device; counts add up
+void sum_timings(const MultiState* M, forma_timings_t* timings) {
+    memset(timings, 0, sizeof *timings);
+    for (int g = 0; g < M->G; g++) {
+        const forma_timings_t& t = M->tm[g];
+        timings->prepare_us = std::max(timings->prepare_us, t.prepare_us); timings->rasterize_us = std::max(timings->rasterize_us, t.rasterize_us);
+        timings->sort_us = std::max(timings->sort_us, t.sort_us); timings->sort_pass_us = std::max(timings->sort_pass_us, t.sort_pass_us);
+        timings->carry_us = std::max(timings->carry_us, t.carry_us); timings->paint_us = std::max(timings->paint_us, t.paint_us);
+        timings->total_us = std::max(timings->total_us, t.total_us); timings->d2h_us = std::max(timings->d2h_us, t.d2h_us);
+        timings->exchange_us = std::max(timings->exchange_us, t.exchange_us);
+        timings->n_lines += t.n_lines; timings->n_segments += t.n_segments; timings->n_runs += t.n_runs;
+        timings->n_tile_entries += t.n_tile_entries; timings->n_tiles_written += t.n_tiles_written;
+        timings->n_sort_passes = std::max(timings->n_sort_passes, t.n_sort_passes);
+    }
+}
+
 // One whole frame on frame slot `slot`, complete when it returns: plan if there is none, run, re-plan and run again when a
 // bucket outgrew the plan.  The caller has settled every other slot if a new plan may be needed (a plan re-sizes the exchange
 // buffers of ALL slots).
@@ -438,21 +539,7 @@ int full_frame(forma_hip_ctx* ctx, const FrameJob& want, forma_timings_t* timing
         if (rc) return rc;
         for (int g = 0; g <= G; g++) M->slot_edges[want.slot][g] = M->edges[g];
         M->last_valid = true; M->last_w = want.width; M->last_h = want.height; M->last_slot = want.slot;
-        if (timings) {
-            // devices work side by side: a stage takes as long as its slowest device; counts add up
-            memset(timings, 0, sizeof *timings);
-            for (int g = 0; g < G; g++) {
-                const forma_timings_t& t = M->tm[g];
-                timings->prepare_us = std::max(timings->prepare_us, t.prepare_us); timings->rasterize_us = std::max(timings->rasterize_us, t.rasterize_us);
-                timings->sort_us = std::max(timings->sort_us, t.sort_us); timings->sort_pass_us = std::max(timings->sort_pass_us, t.sort_pass_us);
-                timings->carry_us = std::max(timings->carry_us, t.carry_us); timings->paint_us = std::max(timings->paint_us, t.paint_us);
-                timings->total_us = std::max(timings->total_us, t.total_us); timings->d2h_us = std::max(timings->d2h_us, t.d2h_us);
-                timings->exchange_us = std::max(timings->exchange_us, t.exchange_us);
-                timings->n_lines += t.n_lines; timings->n_segments += t.n_segments; timings->n_runs += t.n_runs;
-                timings->n_tile_entries += t.n_tile_entries; timings->n_tiles_written += t.n_tiles_written;
-                timings->n_sort_passes = std::max(timings->n_sort_passes, t.n_sort_passes);
-            }
-        }
+        if (timings) sum_timings(M, timings);
         return FORMA_OK;
     }
     return MFAIL(FORMA_E_CAPACITY, "multi-device plan did not converge");
@@ -465,6 +552,14 @@ int drain_slots(forma_hip_ctx* ctx) {
     MultiState* M = ctx->multi;
     int first = FORMA_OK;
     char first_err[sizeof ctx->err] = {0};
+    if (M->layout == FORMA_LAYOUT_BANDS) {                  // the devices' own frame slots hold what is in flight
+        for (int g = 0; g < M->G; g++) {
+            const int rc = forma_hip_sync(M->kid[g]);
+            if (rc && !first) { first = rc; memcpy(first_err, M->kid[g]->err, sizeof first_err); }
+        }
+        if (first) memcpy(ctx->err, first_err, sizeof ctx->err);
+        return first;
+    }
     bool rerun[FORMA_MAX_FRAMES_IN_FLIGHT] = {false};
     bool any = false;
     for (int k = 0; k < M->F; k++) {
@@ -557,12 +652,14 @@ int multi_create(forma_hip_ctx** out, const int* devices, int n) {
         }
         (void)hipGetLastError();
     }
-    if (rc == FORMA_OK) {
-        rc = create_slot_transport(M, 0);
-        if (rc == FORMA_E_COMM) {                          // (ADVICE r3: a working peer-copy exchange beats FORMA_E_COMM)
-            fall_back_to_copies(M, rccl_api()->handle ? "ncclCommInitAll failed" : rccl_api()->why);
-            rc = FORMA_OK;
-        }
+    // (the exchange's transport — RCCL communicators per frame slot, or events for the copy transport — is made by the first
+    //  EXCHANGE plan: a context that only ever renders BANDS frames never loads librccl)
+    {
+        const ForMaDebug dbg = forma_debug_parse();
+        if (dbg.multi_layout == 1) M->layout_req = FORMA_LAYOUT_EXCHANGE;
+        else if (dbg.multi_layout == 2) M->layout_req = FORMA_LAYOUT_BANDS;
+        if (n == 1) M->layout_req = FORMA_LAYOUT_EXCHANGE;      // (force_exchange: the rehearsal of the exchange path with a world of one)
+        M->layout = M->layout_req == FORMA_LAYOUT_BANDS ? FORMA_LAYOUT_BANDS : FORMA_LAYOUT_EXCHANGE;
     }
     if (rc != FORMA_OK) { multi_destroy(ctx); return rc; }
     for (int g = 0; g < n; g++) M->th[g] = std::thread(worker_main, M, g);
@@ -605,11 +702,7 @@ int multi_set_frames_in_flight(forma_hip_ctx* ctx, int n) {
     for (int g = 0; g < M->G; g++)
         if ((rc = forma_hip_set_frames_in_flight(M->kid[g], n))) { copy_err(ctx, M->kid[g]); return rc; }
     for (int s = n; s < FORMA_MAX_FRAMES_IN_FLIGHT; s++) destroy_slot_transport(M, s);
-    for (int s = 0; s < n; s++) {
-        rc = create_slot_transport(M, s);
-        if (rc == FORMA_E_COMM) { fall_back_to_copies(M, "ncclCommInitAll failed for a frame slot"); rc = create_slot_transport(M, s); }
-        if (rc) return MFAIL(rc, "frames in flight: cannot create a frame slot's communicators");
-    }
+    // (the new slots' communicators / events are made by the next EXCHANGE plan: make_plan)
     M->F = n; M->next_slot = 0; M->last_slot = 0;
     M->planned = false;                                    // the new slots need their exchange buffers: plan again
     return FORMA_OK;
@@ -618,8 +711,21 @@ int multi_set_frames_in_flight(forma_hip_ctx* ctx, int n) {
 void multi_info(forma_hip_ctx* ctx, forma_context_info_t* out) {
     MultiState* M = ctx->multi;
     out->n_devices = (uint32_t)M->G; out->frames_in_flight = (uint32_t)M->F;
-    out->transport = M->G > 1 || M->use_rccl ? (M->use_rccl ? FORMA_TRANSPORT_RCCL : FORMA_TRANSPORT_COPY) : FORMA_TRANSPORT_NONE;
+    out->transport = M->layout == FORMA_LAYOUT_BANDS ? FORMA_TRANSPORT_NONE
+                     : (M->G > 1 || M->use_rccl ? (M->use_rccl ? FORMA_TRANSPORT_RCCL : FORMA_TRANSPORT_COPY) : FORMA_TRANSPORT_NONE);
+    out->layout = (uint32_t)M->layout;
     for (int g = 0; g < M->G && g < FORMA_MAX_DEVICES; g++) out->devices[g] = M->dev[g];
+}
+
+int multi_set_layout(forma_hip_ctx* ctx, int layout) {
+    DeviceGuard guard;
+    MultiState* M = ctx->multi;
+    if (layout != FORMA_LAYOUT_AUTO && layout != FORMA_LAYOUT_EXCHANGE && layout != FORMA_LAYOUT_BANDS) return MFAIL(FORMA_E_ARG, "layout: FORMA_LAYOUT_AUTO / _EXCHANGE / _BANDS");
+    { const int rc = drain_slots(ctx); if (rc) return rc; }
+    M->layout_req = layout;
+    if (layout != FORMA_LAYOUT_AUTO) M->layout = layout;   // (what forma_hip_context_info says until the next plan; AUTO: decided then)
+    M->planned = false;                                    // the next frame plans for the layout asked for
+    return FORMA_OK;
 }
 
 #define EACH_KID(call)                                                              \
@@ -684,6 +790,30 @@ int multi_render(forma_hip_ctx* ctx, uint8_t* dst, uint32_t width, uint32_t heig
     memcpy(want.channels, channels, 4); memcpy(want.clear, clear_color, 16);
     want.has_crop = crop_or_null != nullptr; if (crop_or_null) want.crop = *crop_or_null;
     want.cache_id = cache_id; want.timings = timings != nullptr;
+    if (!M->planned || M->plan_w != width || M->plan_h != height) {
+        // a plan is due: settle what is in flight under the old one, then decide the layout the new plan is made for
+        { const int rc = drain_slots(ctx); if (rc) return rc; }
+        int lay = M->layout_req;
+        if (lay == FORMA_LAYOUT_AUTO) {
+            std::vector<uint32_t> sums;
+            const int rc = fd_line_sums(M->kid[0], width, height, sums);
+            if (rc) { copy_err(ctx, M->kid[0]); return rc; }
+            lay = choose_layout(sums.size(), sums.empty() ? 0u : sums.back(), M->G);
+        }
+        M->layout = lay;
+    }
+    if (M->layout == FORMA_LAYOUT_BANDS) {
+        if (!M->planned || M->plan_w != width || M->plan_h != height) { const int rc = make_plan(ctx, width, height); if (rc) return rc; }
+        M->job = want;
+        M->job.mode = FrameJob::FULL; M->job.slot = 0;
+        set_band_crops(M, width, height, crop_or_null);
+        const int rc = run_job(ctx, nullptr);
+        if (rc) return rc;
+        for (int g = 0; g <= M->G; g++) M->slot_edges[0][g] = M->edges[g];
+        M->last_valid = true; M->last_w = width; M->last_h = height; M->last_slot = 0;
+        if (timings) sum_timings(M, timings);
+        return FORMA_OK;
+    }
     // Frames in flight: a device-resident frame without a cache is ENQUEUED on the next frame slot of every device and this
     // call returns; it is verified when the slot comes round again or when any call needs its result.  Everything else keeps
     // the synchronous contract of the reference: `dst` is fully written when the call returns.
@@ -744,6 +874,31 @@ int multi_read_segments(forma_hip_ctx* ctx, int which, uint64_t* out, size_t cap
     if (which != 1) return MFAIL(FORMA_E_STATE, "a multi-device context holds no single unsorted stream (which = 1: the sorted stream of the painted rows)");
     if (!M->last_valid) return MFAIL(FORMA_E_STATE, "no frame rendered yet");
     const int s = M->last_slot;
+    if (M->layout == FORMA_LAYOUT_BANDS) {
+        // every device's sorted stream holds its band's rows plus what it flagged out of the band (tile row -1, in front): the
+        // painted rows of the frame are the bands' own rows, concatenated in band order
+        std::vector<uint64_t> part;
+        size_t at = 0;
+        for (int g = 0; g < M->G; g++) {
+            const uint32_t e0 = M->slot_edges[s][g], e1 = M->slot_edges[s][g + 1];
+            if (e0 >= e1) continue;
+            forma_hip_ctx* k = M->kid[g];
+            size_t n = 0;
+            int rc = forma_hip_read_segments(k, 1, nullptr, 0, &n);
+            if (rc && rc != FORMA_E_CAPACITY) { copy_err(ctx, k); return rc; }
+            part.resize(n);
+            if (n && (rc = forma_hip_read_segments(k, 1, part.data(), n, &n))) { copy_err(ctx, k); return rc; }
+            const auto lo = std::lower_bound(part.begin(), part.end(), (uint64_t)(e0 + 1) << 53);
+            const auto hi = std::lower_bound(part.begin(), part.end(), (uint64_t)(e1 + 1) << 53);
+            const size_t m = (size_t)(hi - lo);
+            if (out && at + m <= capacity) memcpy(out + at, &*part.begin() + (lo - part.begin()), m * 8);
+            at += m;
+        }
+        *out_n = at;
+        if (at > capacity) return MFAIL(FORMA_E_CAPACITY, "segment capacity too small");
+        if (at && !out) return FORMA_E_ARG;
+        return FORMA_OK;
+    }
     size_t total = 0;
     for (int g = 0; g < M->G; g++) total += slot_ctx(M, g, s)->n_seg;
     *out_n = total;
@@ -768,7 +923,8 @@ int multi_read_image(forma_hip_ctx* ctx, uint8_t* dst, size_t stride_bytes) {
     if ((size_t)M->last_w * 4 > stride_bytes) return MFAIL(FORMA_E_ARG, "width exceeds width stride");
     const int s = M->last_slot;
     for (int g = 0; g < M->G; g++) {
-        forma_hip_ctx* k = slot_ctx(M, g, s);
+        if (M->layout == FORMA_LAYOUT_BANDS && M->slot_edges[s][g] >= M->slot_edges[s][g + 1]) continue;
+        forma_hip_ctx* k = M->layout == FORMA_LAYOUT_BANDS ? fd_last_slot(M->kid[g]) : slot_ctx(M, g, s);
         const int rc = fd_copy_image_rows(k, dst, stride_bytes, M->slot_edges[s][g] * 16, std::min(M->slot_edges[s][g + 1] * 16, M->last_h));
         if (rc) { copy_err(ctx, k); return rc; }
     }
@@ -788,7 +944,7 @@ int multi_tiles_written(forma_hip_ctx* ctx, uint8_t* flags, size_t n_tiles) {
     for (int g = 0; g < M->G; g++) {
         const uint32_t e0 = M->slot_edges[s][g], e1 = M->slot_edges[s][g + 1];
         if (e0 >= e1) continue;
-        forma_hip_ctx* k = slot_ctx(M, g, s);
+        forma_hip_ctx* k = M->layout == FORMA_LAYOUT_BANDS ? fd_last_slot(M->kid[g]) : slot_ctx(M, g, s);
         const int rc = fd_tiles_written(k, tmp.data(), T);
         if (rc) { copy_err(ctx, k); return rc; }
         for (uint32_t ty = e0; ty < e1 && ty < tiles_h; ty++)

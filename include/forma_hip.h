@@ -271,11 +271,27 @@ int forma_hip_sync(forma_hip_ctx* ctx);
 typedef struct forma_context_info {
     uint32_t n_devices;
     uint32_t frames_in_flight;
-    uint32_t transport;                 /* FORMA_TRANSPORT_* */
-    uint32_t reserved;
+    uint32_t transport;                 /* FORMA_TRANSPORT_* (NONE: one device, or the BANDS layout) */
+    uint32_t layout;                    /* FORMA_LAYOUT_EXCHANGE / _BANDS: what the last plan of a multi-device context was made for */
     int32_t  devices[FORMA_MAX_DEVICES];
 } forma_context_info_t;
 int forma_hip_context_info(forma_hip_ctx* ctx, forma_context_info_t* out);
+/* How a multi-device context (forma_hip_create_multi) splits a frame.  The tile rows are always cut into one band per device
+ * (the reference's own unit of parallelism: painter/mod.rs:741-776 paints tile rows in parallel, and the cover carry never
+ * crosses rows, :518-522); the layouts differ in how a band's pixel segments reach its device:
+ *   FORMA_LAYOUT_EXCHANGE  every device rasterizes 1/G of the LINES; HIP kernels bucket the pixel segments by the device that
+ *                          owns their tile row and ONE all-to-all (RCCL over xGMI) delivers them;
+ *   FORMA_LAYOUT_BANDS     no exchange: every device holds the whole scene, prepares all lines but culls them to its band in
+ *                          the frame's first kernel, and renders its band like a single device (section 8e's "replicate stages
+ *                          1-2, keep only own-band segments: zero communication");
+ *   FORMA_LAYOUT_AUTO      (default) the cheaper of the two for the scene, decided whenever a plan is made: BANDS unless the
+ *                          scene has more lines than pixel segments.
+ * Both paint bit-identical images.  Frames in flight are settled first; the next frame plans anew.  FORMA_E_STATE on a
+ * single-device context. */
+#define FORMA_LAYOUT_AUTO     0
+#define FORMA_LAYOUT_EXCHANGE 1
+#define FORMA_LAYOUT_BANDS    2
+int forma_hip_multi_layout(forma_hip_ctx* ctx, int layout);
 /* Introspection, host logic only (no device is touched): the digit plan the library makes for a frame's pixel-segment sort
  * (reference: one `par_sort_unstable` on the 44 key bits, cpu/rasterizer.rs:161-164, pixel_segment.rs:161-171).  Pass p is a
  * stable counting pass on digit = ((segment >> shift[p]) - bias[p]) & mask[p], least significant pass first.

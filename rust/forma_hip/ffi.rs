@@ -125,6 +125,9 @@ pub const FORMA_MAX_DEVICES: usize = 8;
 pub const FORMA_TRANSPORT_NONE: u32 = 0;
 pub const FORMA_TRANSPORT_RCCL: u32 = 1;
 pub const FORMA_TRANSPORT_COPY: u32 = 2;
+pub const FORMA_LAYOUT_AUTO: c_int = 0;
+pub const FORMA_LAYOUT_EXCHANGE: c_int = 1;
+pub const FORMA_LAYOUT_BANDS: c_int = 2;
 
 /// `forma_context_info_t` (`include/forma_hip.h`): devices, frame slots and the exchange transport of a context.
 #[repr(C)]
@@ -133,7 +136,7 @@ pub struct forma_context_info_t {
     pub n_devices: u32,
     pub frames_in_flight: u32,
     pub transport: u32,
-    pub reserved: u32,
+    pub layout: u32,
     pub devices: [i32; FORMA_MAX_DEVICES],
 }
 
@@ -265,6 +268,7 @@ extern "C" {
     ) -> c_int;
     pub fn forma_hip_cache_clear(ctx: *mut forma_hip_ctx, cache_id: c_int) -> c_int;
     pub fn forma_hip_set_frames_in_flight(ctx: *mut forma_hip_ctx, n: c_int) -> c_int;
+    pub fn forma_hip_multi_layout(ctx: *mut forma_hip_ctx, layout: c_int) -> c_int;
     pub fn forma_hip_sync(ctx: *mut forma_hip_ctx) -> c_int;
     pub fn forma_hip_context_info(ctx: *mut forma_hip_ctx, out: *mut forma_context_info_t) -> c_int;
     pub fn forma_hip_kernel_times(ctx: *mut forma_hip_ctx, out: *mut forma_kernel_time_t, capacity: usize, out_n: *mut usize) -> c_int;

@@ -150,6 +150,15 @@ impl Renderer {
         self.check(rc, "forma_hip_set_frames_in_flight");
     }
 
+    /// How a renderer over several devices splits a frame (`forma_hip_multi_layout`): `ffi::FORMA_LAYOUT_EXCHANGE` (line
+    /// shares + one all-to-all of pixel segments), `ffi::FORMA_LAYOUT_BANDS` (no exchange: every device culls the scene to its
+    /// band of tile rows) or `ffi::FORMA_LAYOUT_AUTO` (the default).  Same image either way.
+    pub fn set_multi_layout(&mut self, layout: i32) {
+        // SAFETY: `ctx` is live for the lifetime of `self`.
+        let rc = unsafe { ffi::forma_hip_multi_layout(self.ctx, layout) };
+        self.check(rc, "forma_hip_multi_layout");
+    }
+
     /// Waits for every enqueued frame (`forma_hip_sync`); panics with the first error one of them produced.
     pub fn sync(&mut self) {
         // SAFETY: as above.

@@ -1,7 +1,8 @@
 """SURVEY.md §8(e) behind the C ABI: `forma_hip_create_multi` — ONE context over several devices whose `forma_hip_render` is
-the whole multi-GPU frame (line-sharded rasterization -> HIP bucketing by tile-row owner -> one all-to-all -> band-local sort
-+ paint -> every device copies its rows into the ONE caller buffer) — and frames in flight inside one context
-(`forma_hip_set_frames_in_flight`).
+the whole multi-GPU frame, in both layouts (`forma_hip_multi_layout`): EXCHANGE (line-sharded rasterization -> HIP bucketing by
+tile-row owner -> one all-to-all -> band-local sort + paint) and BANDS (no exchange: every device culls the whole scene to its
+band of tile rows and renders it like a single device); every device copies its rows into the ONE caller buffer — and frames in
+flight inside one context (`forma_hip_set_frames_in_flight`).
 
 This pool hands out single-GPU boxes, so the devices of most tests are the same GPU listed several times: every device still
 has its own context, stream, buffers and host thread, the planner / bucket / gather / chunk-mapped sort run exactly as on G
@@ -33,8 +34,12 @@ def painted_rows(sorted_full, tiles_h):
     return sorted_full[(ty >= 0) & (ty < tiles_h)]
 
 
+LAYOUTS = ["exchange", "bands"]
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
 @pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0], [0] * 8])
-def test_multi_device_context_matches_the_oracle(devices):
+def test_multi_device_context_matches_the_oracle(devices, layout):
     import forma_amd
     W, H = 512, 384
     clear = (0.2, 0.3, 0.4, 1.0)
@@ -42,7 +47,7 @@ def test_multi_device_context_matches_the_oracle(devices):
     t = S.random_mixed().tables(o)
     S.load(o, t)
     want = o.render(W, H, clear=clear)
-    c = forma_amd.Context(devices=devices)
+    c = forma_amd.Context(devices=devices, layout=layout)
     S.load(c, t)
     for frame in range(4):                                             # plan + synchronous, then read-back-free
         img = np.full((H, W * 4), 7, np.uint8)
@@ -52,15 +57,16 @@ def test_multi_device_context_matches_the_oracle(devices):
         assert np.array_equal(c.read_image(W, H), want)
         assert c.tiles_written(W, H).all()
     img, tm = c.render(W, H, clear=clear, timings=True)
-    assert np.array_equal(img, want) and tm["n_segments"] > 0 and tm["exchange_us"] > 0
+    assert np.array_equal(img, want) and tm["n_segments"] > 0 and (tm["exchange_us"] > 0) == (layout == "exchange")
+    assert c.info()["layout"] == layout and c.info()["transport"] == ("copy" if layout == "exchange" else "none")
     c.close()
 
 
 def test_multi_device_e2e_scenes_and_tiny_canvases():
     """the reference's e2e scenes (64 x 64: four tile rows) on 2 and 8 devices — more devices than tile rows leaves bands empty"""
     import forma_amd
-    for devices in ([0, 0], [0] * 8):
-        c = forma_amd.Context(devices=devices)
+    for devices, layout in (([0, 0], "exchange"), ([0] * 8, "exchange"), ([0, 0], "bands"), ([0] * 8, "bands")):
+        c = forma_amd.Context(devices=devices, layout=layout)
         for name, comp in S.e2e_scenes().items():
             o = orc.Oracle()
             t = comp.tables(o)
@@ -68,17 +74,18 @@ def test_multi_device_e2e_scenes_and_tiny_canvases():
             want = o.render(64, 64)
             for frame in range(2):
                 got = c.render(64, 64)
-                assert np.abs(want.astype(int) - got.astype(int)).max() <= 1, (name, len(devices), frame)
+                assert np.abs(want.astype(int) - got.astype(int)).max() <= 1, (name, len(devices), layout, frame)
         c.close()
 
 
-def test_multi_device_crop_channels_and_device_resident_frames():
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_multi_device_crop_channels_and_device_resident_frames(layout):
     import forma_amd
     W, H = 500, 333                                                     # odd canvas: partial last tile row and column
     o = orc.Oracle()
     t = S.random_mixed(width=W, height=H, seed=5).tables(o)
     S.load(o, t)
-    c = forma_amd.Context(devices=[0, 0, 0])
+    c = forma_amd.Context(devices=[0, 0, 0], layout=layout)
     S.load(c, t)
     for ch in (S.RGBA, S.BGR1, S.RGB0):
         want = o.render(W, H, channels=ch, clear=(0.1, 0.2, 0.3, 0.5))
@@ -93,7 +100,8 @@ def test_multi_device_crop_channels_and_device_resident_frames():
     c.close()
 
 
-def test_multi_device_replans_when_the_scene_outgrows_its_buckets():
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_multi_device_replans_when_the_scene_outgrows_its_buckets(layout):
     """a transform that makes the scene grow overflows what the plan provisioned (local segment counts, bucket capacity):
     the frame fails ON THE DEVICE, the context re-plans (new line shares, bands, capacity) and re-runs it — the caller only
     ever sees the right image"""
@@ -102,7 +110,7 @@ def test_multi_device_replans_when_the_scene_outgrows_its_buckets():
     o = orc.Oracle()
     t = S.random_mixed().tables(o)
     S.load(o, t)
-    c = forma_amd.Context(devices=[0, 0])
+    c = forma_amd.Context(devices=[0, 0], layout=layout)        # (BANDS has no buckets to outgrow: the same frames, unbalanced bands)
     S.load(c, t)
 
     def scaled(k, tx, ty):
@@ -121,7 +129,8 @@ def test_multi_device_replans_when_the_scene_outgrows_its_buckets():
     c.close()
 
 
-def test_multi_device_buffer_layer_cache():
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_multi_device_buffer_layer_cache(layout):
     """damage tracking across devices: every device keeps the cache state of its band; an unchanged frame writes nothing,
     a moved layer rewrites the tiles the oracle-backed reference rewrites"""
     import forma_amd
@@ -133,7 +142,7 @@ def test_multi_device_buffer_layer_cache():
     o = orc.Oracle()
     t = comp.tables(o)
     S.load(o, t)
-    c = forma_amd.Context(devices=[0, 0, 0])
+    c = forma_amd.Context(devices=[0, 0, 0], layout=layout)
     S.load(c, t)
     n_orders = len(t["style_offsets"])
 
@@ -159,6 +168,41 @@ def test_multi_device_buffer_layer_cache():
     assert w.any() and not w.all()
     assert not frame([1, 1, 1]).any()
     c.close()
+
+
+def test_multi_layout_auto_and_switching_on_a_live_context():
+    """FORMA_LAYOUT_AUTO (the default) decides per plan — BANDS for every scene with more pixel segments than lines; the layout
+    can be changed on a live context with frames in flight: in flight frames are settled, the next frame plans anew, every image
+    and sorted stream stays the oracle's"""
+    import forma_amd
+    from forma_amd import FormaError
+    W, H = 512, 384
+    o = orc.Oracle()
+    t = S.random_mixed().tables(o)
+    S.load(o, t)
+    want = o.render(W, H)
+    c = forma_amd.Context(devices=[0, 0, 0], frames_in_flight=2)
+    S.load(c, t)
+    assert np.array_equal(c.render(W, H), want)
+    assert c.info()["layout"] == "bands" and c.info()["transport"] == "none"
+    for layout in ("exchange", "bands", "exchange", "auto", "exchange"):
+        for _ in range(3):
+            c.render(W, H, device_only=True)                           # (frames in flight under the old layout)
+        c.set_layout(layout)
+        for _ in range(5):
+            c.render(W, H, device_only=True)
+        assert np.array_equal(c.read_image(W, H), want), layout
+        assert np.array_equal(c.segments(1), painted_rows(o.segments(1), (H + 15) // 16)), layout
+        assert c.info()["layout"] == ("bands" if layout == "auto" else layout)
+        assert np.array_equal(c.render(W, H), want), layout
+    with pytest.raises(FormaError):
+        c.set_layout(7)
+    c.close()
+    single = forma_amd.Context(0)
+    with pytest.raises(FormaError) as e:
+        single.set_layout("bands")
+    assert e.value.code == -5
+    single.close()
 
 
 def test_multi_device_context_refuses_the_single_device_plumbing():
@@ -189,13 +233,14 @@ def _full_size(workload):
     return t, W, H, want, o.segments(1)
 
 
-@pytest.mark.parametrize("workload,G", [("triangles-10m-8k", 8), ("paris-like-30k-4k", 4)])
-def test_multi_device_full_size(workload, G):
+@pytest.mark.parametrize("workload,G,layout", [("triangles-10m-8k", 8, "exchange"), ("paris-like-30k-4k", 4, "exchange"),
+                                               ("triangles-10m-8k", 8, "bands"), ("paris-like-30k-4k", 8, "bands")])
+def test_multi_device_full_size(workload, G, layout):
     """BASELINE configs 3 (stand-in) and 4 through forma_hip_render on a multi-device context: image within one code value,
     sorted stream of the painted rows bit-identical, on the planning frame and on the read-back-free frames after it"""
     import forma_amd
     t, W, H, want, sorted_full = _full_size(workload)
-    c = forma_amd.Context(devices=[0] * G)
+    c = forma_amd.Context(devices=[0] * G, layout=layout)
     S.load(c, t)
     img = np.zeros((H, W * 4), np.uint8)
     for frame in range(3):
@@ -338,8 +383,9 @@ def test_frames_in_flight_reports_a_deferred_error():
 
 
 # ---- frames in flight on a MULTI-DEVICE context (round 4): F frame slots x G devices, one set of communicators per slot --------
+@pytest.mark.parametrize("layout", LAYOUTS)
 @pytest.mark.parametrize("devices,slots", [([0, 0], 2), ([0, 0], 3), ([0] * 8, 2), ([0] * 8, 3)])
-def test_multi_device_frames_in_flight(devices, slots):
+def test_multi_device_frames_in_flight(devices, slots, layout):
     """device-resident, cache-less frames are ENQUEUED on the next frame slot of every device (buckets, the slot's exchange,
     the owner's sort + paint, all stream-ordered) and verified when the slot comes round; image and sorted stream of the most
     recent frame equal the oracle's; frames into caller memory, scene changes and `sync` see everything enqueued before them"""
@@ -348,9 +394,10 @@ def test_multi_device_frames_in_flight(devices, slots):
     o = orc.Oracle()
     t = S.random_mixed().tables(o)
     S.load(o, t)
-    c = forma_amd.Context(devices=devices, frames_in_flight=slots)
+    c = forma_amd.Context(devices=devices, frames_in_flight=slots, layout=layout)
     info = c.info()
-    assert info["n_devices"] == len(devices) and info["frames_in_flight"] == slots and info["transport"] == "copy"
+    assert info["n_devices"] == len(devices) and info["frames_in_flight"] == slots
+    assert info["transport"] == ("copy" if layout == "exchange" else "none") and info["layout"] == layout
     S.load(c, t)
     clears = [(1, 1, 1, 1), (0.2, 0.3, 0.4, 1.0), (0, 0, 0, 0)]
     for k in range(17):
@@ -390,8 +437,9 @@ def test_multi_device_frames_in_flight(devices, slots):
     c.close()
 
 
+@pytest.mark.parametrize("layout", LAYOUTS)
 @pytest.mark.parametrize("slots", [2, 3])
-def test_multi_device_frames_in_flight_replan_while_frames_are_deferred(slots):
+def test_multi_device_frames_in_flight_replan_while_frames_are_deferred(slots, layout):
     """the scene grows while frames are in flight: deferred frames whose buckets outgrew the plan are void on every device; the
     context settles every slot, re-plans and runs them again — the caller only ever reads the right image"""
     import forma_amd
@@ -399,7 +447,7 @@ def test_multi_device_frames_in_flight_replan_while_frames_are_deferred(slots):
     o = orc.Oracle()
     t = S.random_mixed().tables(o)
     S.load(o, t)
-    c = forma_amd.Context(devices=[0, 0, 0], frames_in_flight=slots)
+    c = forma_amd.Context(devices=[0, 0, 0], frames_in_flight=slots, layout=layout)
     S.load(c, t)
 
     def scaled(k, tx, ty):
@@ -418,7 +466,8 @@ def test_multi_device_frames_in_flight_replan_while_frames_are_deferred(slots):
     c.close()
 
 
-def test_multi_device_frames_in_flight_report_a_deferred_error():
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_multi_device_frames_in_flight_report_a_deferred_error(layout):
     """a deferred frame that fails on a device after the call returned surfaces at the call that completes it, and the context
     keeps working"""
     import forma_amd
@@ -427,7 +476,7 @@ def test_multi_device_frames_in_flight_report_a_deferred_error():
     o = orc.Oracle()
     t = S.random_mixed(width=W, height=H, seed=3).tables(o)
     S.load(o, t)
-    c = forma_amd.Context(devices=[0, 0], frames_in_flight=2)
+    c = forma_amd.Context(devices=[0, 0], frames_in_flight=2, layout=layout)
     S.load(c, t)
     for _ in range(4):
         c.render(W, H, device_only=True)
