@@ -538,8 +538,11 @@ __device__ __forceinline__ LineP load_line(const LineSource& S, uint32_t li) {
     return line_params(S.x, S.y, S.line_slot, li, S.geoms, S.n_geoms, S.width, S.height, S.band_lo, S.band_hi);
 }
 
+#ifndef RAS_OCC
+#define RAS_OCC 6             // waves per SIMD the kernel is compiled for (<= 80 VGPRs: the three-round staging alone took 82 = five)
+#endif
 template <bool HIST>         // HIST = false is the plain kernel, instruction for instruction
-__global__ __launch_bounds__(RAS_THREADS) void k_rasterize(LineSource S, DevCount nc_compact, DevCount nc_segments,
+__global__ __launch_bounds__(RAS_THREADS, RAS_OCC) void k_rasterize(LineSource S, DevCount nc_compact, DevCount nc_segments,
                                                            const uint32_t* __restrict__ cl_idx,
                                                            const uint32_t* __restrict__ cl_start,
                                                            const uint32_t* __restrict__ block_first,
@@ -580,7 +583,26 @@ __global__ __launch_bounds__(RAS_THREADS) void k_rasterize(LineSource S, DevCoun
         if (c0 != lo) __syncthreads();
         for (uint32_t j = tid; j < cnt; j += RAS_THREADS) {
             const uint32_t cidx = c0 + j;
-            const LineP L = load_line(S, cl_idx[cidx]);
+            // The line's loads in THREE rounds, each issued whole before anything waits (round 6): its compacted entry and its
+            // predecessor's; both slots and the four coordinates; the geom entry and the predecessor's order.  As `load_line` wrote
+            // it — slot, then the order test, then the points, then (after the arithmetic) the predecessor's index -> slot ->
+            // order — a workgroup's staging was SEVEN dependent round trips, 17 k of its 30 k clocks.  A compacted line owns
+            // pixel segments, so its slot and its geom entry are valid: nothing here needs an early exit.
+            LineP L;
+            uint32_t prev_order = 0;
+            if (S.sums) {
+                L = load_line(S, cl_idx[cidx]);
+                if (cidx > 0) prev_order = S.orders[cl_idx[cidx - 1]];
+            } else {
+                const uint32_t li = cl_idx[cidx], lp = cl_idx[cidx > 0 ? cidx - 1 : cidx];
+                const uint32_t slot = S.line_slot[li], slotp = S.line_slot[lp];
+                const float p0x = S.x[li], p1x = S.x[li + 1], p0y = S.y[li], p1y = S.y[li + 1];
+                forma_geom_t g;
+                g.order = FORMA_NONE; g.flags = 0;
+                if (slot < S.n_geoms) g = S.geoms[slot];
+                if (slotp < S.n_geoms) prev_order = S.geoms[slotp].order;
+                L = line_params_loaded(g, p0x, p0y, p1x, p1y, S.width, S.height, S.band_lo, S.band_hi);
+            }
             w_start[j] = cl_start[cidx];
             w_order[j] = L.order; w_x0[j] = L.x0; w_y0[j] = L.y0; w_dx[j] = L.dx; w_dy[j] = L.dy;
             w_a[j] = L.a; w_b[j] = L.b; w_c[j] = L.c; w_d[j] = L.d;
@@ -588,12 +610,7 @@ __global__ __launch_bounds__(RAS_THREADS) void k_rasterize(LineSource S, DevCoun
             w_aab[j] = (double)L.a * sum_recip; w_bab[j] = (double)L.b * sum_recip;
             w_cdab[j] = ((double)L.c - (double)L.d) * sum_recip;
             // is the stream non-decreasing in layer?  (lets the sort skip the layer digits)
-            if (cidx > 0) {
-                uint32_t prev_order;
-                if (S.sums) prev_order = S.orders[cl_idx[cidx - 1]];
-                else { const uint32_t ps = S.line_slot[cl_idx[cidx - 1]]; prev_order = S.geoms[ps].order; }
-                if (prev_order > L.order) unsorted = 1;
-            }
+            if (cidx > 0 && prev_order > L.order) unsorted = 1;
         }
         if (tid == 0) w_start[cnt] = (c0 + cnt < n_compact) ? cl_start[c0 + cnt] : n_segments;
         __syncthreads();
