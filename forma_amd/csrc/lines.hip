@@ -528,6 +528,42 @@ __device__ __forceinline__ uint64_t rasterize_one(uint32_t order, float lx0, flo
     return v;
 }
 
+// The same two functions with what is constant along a LINE folded into its staged constants (round 6):
+//   * `isfinite(b) ? ceil(fma(B, i, -CD)) : i` — a non-finite b (dy so small that 1 / dy overflows) gets B' = 1, CD' = 0 instead of
+//     the select: ceil(fma(1.0, (double)fi, -0.0)) = fi exactly (fi is an integer-valued float; +0 + -0 = +0), likewise for a
+//     (vertical lines: 1 / dx = inf — common) with +0.0: two v_cmp_class and two v_cndmask per `find` less;
+//   * `i - (c != 0) - (d != 0)` is one staged integer per line.
+__device__ __forceinline__ float find_term_k(int i, double a_k, double b_k, double cda_k, double cdb_k, float a, float b, float c, float d) {
+    const float fi = (float)i;
+    const float ja = (float)ceil(fma(b_k, (double)fi, cdb_k));          // cdb_k = -CD (or -0.0)
+    const float jb = (float)ceil(fma(a_k, (double)fi, cda_k));          // cda_k = +CD (or +0.0)
+    return fminf(fmaf(a, ja, c), fmaf(b, jb, d));
+}
+__device__ __forceinline__ uint64_t rasterize_one_k(uint32_t order, float lx0, float ly0, float ldx, float ldy, float a, float b, float c,
+                                                    float d, double a_k, double b_k, double cda_k, double cdb_k, int i) {
+    float t0 = fmaxf(find_term_k(i, a_k, b_k, cda_k, cdb_k, a, b, c, d), 0.0f);
+    float t1 = fminf(find_term_k(i + 1, a_k, b_k, cda_k, cdb_k, a, b, c, d), 1.0f);
+    float x0f = fmaf(t0, ldx, lx0), y0f = fmaf(t0, ldy, ly0);                        // :112-127
+    float x1f = fmaf(t1, ldx, lx0), y1f = fmaf(t1, ldy, ly0);
+    int x0s = (int)floorf(x0f + 0.5f), x1s = (int)floorf(x1f + 0.5f);                // round :78-80
+    int y0s = (int)floorf(y0f + 0.5f), y1s = (int)floorf(y1f + 0.5f);
+    int border_x = min(x0s, x1s) >> 4, border_y = min(y0s, y1s) >> 4;
+    int tile_x = (int)(int16_t)(border_x >> 4), tile_y = (int)(int16_t)(border_y >> 4);
+    uint32_t lx = (uint32_t)border_x & 15u, ly = (uint32_t)border_y & 15u;
+    int border = (int)((uint32_t)border_x << 4) + 16;
+    uint32_t dam = (uint32_t)(abs(x1s - x0s) + 2 * (border - max(x0s, x1s))) & 0xFFu;   // `as u8`
+    int cover = (int)(int8_t)(y1s - y0s);                                                // `as i8`
+    int ty1 = (int)(int16_t)(tile_y + 1), tx1 = (int)(int16_t)(tile_x + 1);
+    uint64_t v = (uint64_t)(ty1 > 0 ? ty1 : 0) & 0x7FFull;
+    v = (v << 12) | ((uint64_t)(tx1 > 0 ? tx1 : 0) & 0xFFFull);
+    v = (v << 21) | ((uint64_t)order & 0x1FFFFFull);
+    v = (v << 4) | lx;
+    v = (v << 4) | ly;
+    v = (v << 6) | (dam & 0x3Fu);
+    v = (v << 6) | ((uint32_t)cover & 0x3Fu);
+    return v;
+}
+
 __device__ __forceinline__ LineP load_line(const LineSource& S, uint32_t li) {
     if (S.sums) {
         LineP L;
@@ -554,7 +590,8 @@ __global__ __launch_bounds__(RAS_THREADS, RAS_OCC) void k_rasterize(LineSource S
     __shared__ uint32_t w_order[RAS_WIN];
     __shared__ float w_x0[RAS_WIN], w_y0[RAS_WIN], w_dx[RAS_WIN], w_dy[RAS_WIN];
     __shared__ float w_a[RAS_WIN], w_b[RAS_WIN], w_c[RAS_WIN], w_d[RAS_WIN];
-    __shared__ double w_aab[RAS_WIN], w_bab[RAS_WIN], w_cdab[RAS_WIN];
+    __shared__ double w_aab[RAS_WIN], w_bab[RAS_WIN], w_cdab[RAS_WIN], w_cdb[RAS_WIN];   // find's constants per line (find_term_k)
+    __shared__ int w_ioff[RAS_WIN];                                      // start - ioff: segment k of the line has i = k - w_ibase
     __shared__ uint32_t red[HIST ? 7 : 5][RAS_THREADS / 64];
     const int tid = threadIdx.x;
     // the two counts and the workgroup's two table entries are independent loads: all four in flight before the first test
@@ -607,8 +644,11 @@ __global__ __launch_bounds__(RAS_THREADS, RAS_OCC) void k_rasterize(LineSource S
             w_order[j] = L.order; w_x0[j] = L.x0; w_y0[j] = L.y0; w_dx[j] = L.dx; w_dy[j] = L.dy;
             w_a[j] = L.a; w_b[j] = L.b; w_c[j] = L.c; w_d[j] = L.d;
             const double sum_recip = 1.0 / ((double)L.a + (double)L.b);          // rasterizer.rs:104-110
-            w_aab[j] = (double)L.a * sum_recip; w_bab[j] = (double)L.b * sum_recip;
-            w_cdab[j] = ((double)L.c - (double)L.d) * sum_recip;
+            const double cd = ((double)L.c - (double)L.d) * sum_recip;
+            const bool fa = isfinite(L.a), fb = isfinite(L.b);                   // (find: `isfinite(a) ? ceil(..) : i`, folded: find_term_k)
+            w_aab[j] = fa ? (double)L.a * sum_recip : 1.0; w_bab[j] = fb ? (double)L.b * sum_recip : 1.0;
+            w_cdab[j] = fa ? cd : 0.0; w_cdb[j] = fb ? -cd : -0.0;
+            w_ioff[j] = (int)cl_start[cidx] + (L.c != 0.0f ? 1 : 0) + (L.d != 0.0f ? 1 : 0);   // i = k - this (rasterizer.rs:63-76)
             // is the stream non-decreasing in layer?  (lets the sort skip the layer digits)
             if (cidx > 0 && prev_order > L.order) unsorted = 1;
         }
@@ -627,7 +667,8 @@ __global__ __launch_bounds__(RAS_THREADS, RAS_OCC) void k_rasterize(LineSource S
             RP_STAMP(1);                                                // binary search
             uint32_t l_start = w_start[a], l_next = w_start[a + 1], l_order = w_order[a];
             float l_x0 = w_x0[a], l_y0 = w_y0[a], l_dx = w_dx[a], l_dy = w_dy[a], l_a = w_a[a], l_b = w_b[a], l_c = w_c[a], l_d = w_d[a];
-            double l_aab = w_aab[a], l_bab = w_bab[a], l_cdab = w_cdab[a];
+            double l_aab = w_aab[a], l_bab = w_bab[a], l_cdab = w_cdab[a], l_cdb = w_cdb[a];
+            int l_ioff = w_ioff[a];
 #pragma unroll
             for (int q = 0; q < RAS_PER_THREAD; q++) {
                 const uint32_t k = kt + q;
@@ -637,9 +678,9 @@ __global__ __launch_bounds__(RAS_THREADS, RAS_OCC) void k_rasterize(LineSource S
                     l_start = l_next; l_next = w_start[a + 1]; l_order = w_order[a];
                     l_x0 = w_x0[a]; l_y0 = w_y0[a]; l_dx = w_dx[a]; l_dy = w_dy[a];
                     l_a = w_a[a]; l_b = w_b[a]; l_c = w_c[a]; l_d = w_d[a];
-                    l_aab = w_aab[a]; l_bab = w_bab[a]; l_cdab = w_cdab[a];
+                    l_aab = w_aab[a]; l_bab = w_bab[a]; l_cdab = w_cdab[a]; l_cdb = w_cdb[a]; l_ioff = w_ioff[a];
                 }
-                uint64_t v = rasterize_one(l_order, l_x0, l_y0, l_dx, l_dy, l_a, l_b, l_c, l_d, l_aab, l_bab, l_cdab, k - l_start);
+                uint64_t v = rasterize_one_k(l_order, l_x0, l_y0, l_dx, l_dy, l_a, l_b, l_c, l_d, l_aab, l_bab, l_cdab, l_cdb, (int)k - l_ioff);
                 if (band_row1 > 0) {
                     int ty = seg_tile_y(v);
                     if (ty < band_row0 || ty >= band_row1) v &= 0x001FFFFFFFFFFFFFull;   // -> tile row -1: never painted
