@@ -170,6 +170,16 @@ int run_rasterize_frame(forma_hip_ctx* ctx, uint32_t width, uint32_t height, boo
         ctx->ras_plan = frame_sort_plan(ctx, ctx->pred_live44, ctx->pred_layer_sorted, ctx->digit_bits, true, nullptr);
         RH = make_ras_hist(ctx->ras_plan, ctx->sort_counters.as<uint32_t>());
         ctx->ras_hist_on = RH.hist != nullptr;
+        // the tile fields' spans are worth measuring only where a biased plan could ever beat the plain one: the plain digits of
+        // the tile fields take more than two passes (canvases beyond 255 tiles in a dimension), or this frame's plan is biased
+        // already (its digits are checked against the spans).  4K and below: no — 80 VALU instructions per rasterizer lane less.
+        {
+            const SortPlan plain = make_segment_sort_plan(ctx->pred_live44, ctx->pred_layer_sorted, ctx->digit_bits, nullptr, nullptr);
+            const SortPlan lay = ctx->pred_layer_sorted ? SortPlan{} : make_sort_plan((ctx->pred_live44 & 0x1FFFFFull) << 20, 20, 41, ctx->digit_bits);
+            bool biased = false;
+            for (int p = 0; p < ctx->ras_plan.n_passes; p++) biased |= ctx->ras_plan.fmask[p] != 0u;
+            RH.track_range = (biased || plain.n_passes > (ctx->pred_layer_sorted ? 0 : lay.n_passes) + 2) ? 1u : 0u;
+        }
     }
     stage_begin(ctx, ST_RASTER, timing);
     launch_rasterize(ctx->stream, S, nc_cmp, nc_seg, ctx->cl_idx.as<uint32_t>(), ctx->cl_start.as<uint32_t>(),

@@ -230,7 +230,9 @@ void launch_block_first(hipStream_t s, const uint32_t* cl_start, uint32_t n_comp
 #define HS_COPIES  16                               // private copies of the sort's digit histograms (added up by k_onesweep)
 #define SORT_BINS  512                              // histogram words per pass (a pass has 16, 256 or 512 bins)
 #define RH_MAX_PASSES 3
-struct RasHist { uint32_t* hist; uint32_t n_passes; uint32_t shift[RH_MAX_PASSES], mask[RH_MAX_PASSES], bias[RH_MAX_PASSES], fmask[RH_MAX_PASSES]; };
+struct RasHist { uint32_t* hist; uint32_t n_passes; uint32_t shift[RH_MAX_PASSES], mask[RH_MAX_PASSES], bias[RH_MAX_PASSES], fmask[RH_MAX_PASSES];
+                 uint32_t track_range; /* also measure what the keys' tile fields span (KeyRange for the next frame's plan): only
+                                          where a field taken relative to its minimum can save a digit pass — else the records say "unknown" */ };
 void launch_rasterize(hipStream_t s, const LineSource& src, DevCount n_compact, DevCount n_segments,
                       const uint32_t* cl_idx, const uint32_t* cl_start, const uint32_t* block_first, uint64_t* out,
                       FrameInfo* info, int band_row0, int band_row1, uint32_t* wg_masks /* 8 words per RAS_TILE block */,

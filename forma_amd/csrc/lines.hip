@@ -692,21 +692,25 @@ __global__ __launch_bounds__(RAS_THREADS, RAS_OCC) void k_rasterize(LineSource S
         }
     }
     RP_STAMP(2);                                                        // the 8 pixel segments of the lane
-    uint32_t min_x = 0xFFFFu, max_x = 0, min_y = 0xFFFFu, max_y = 0;   // tile fields of this thread's keys (HIST)
+    uint32_t min_x = 0xFFFFu, max_x = 0, min_y = 0xFFFFu, max_y = 0;   // tile fields of this thread's keys (HIST, RH.track_range)
     if (HIST) {
         // The digits of the sort's passes, counted where the keys are made.  A thread's 8 keys are consecutive segments of a
         // line (or of neighbouring lines): mostly one tile, so a run-length pass over the registers leaves one or two LDS
         // atomics per digit and thread.  (Electing one lane per digit of the wavefront first — the 64 lanes mostly add to the
         // same word — was built and cost 44 us instead of 13: scalar loops of readlane / ballot, against LDS atomics that
-        // were never the limit.)
+        // were never the limit.  Round 6: ONE walk that cuts the keys into runs of equal `v >> 20` and counts every run in every
+        // pass — fewer VALU on paper, a loop over the passes behind each of eight divergent branches in the machine: 86.3 -> 89.5
+        // us on the 4K scene, 47.5 -> 53.2 on the 8K one.)
         const uint32_t nv = kt < k1 ? min((uint32_t)RAS_PER_THREAD, k1 - kt) : 0u;
         __syncthreads();                                                // (lh cleared, also for a workgroup whose loop ran dry)
         if (nv) {
+            if (RH.track_range) {                                       // (only where a tile field relative to its minimum can save a pass)
 #pragma unroll
-            for (int q = 0; q < RAS_PER_THREAD; q++) {
-                if ((uint32_t)q < nv) {
-                    const uint32_t hw = (uint32_t)(vout[q] >> 32), tx = (hw >> 9) & 0xFFFu, ty = hw >> 21;
-                    min_x = min(min_x, tx); max_x = max(max_x, tx); min_y = min(min_y, ty); max_y = max(max_y, ty);
+                for (int q = 0; q < RAS_PER_THREAD; q++) {
+                    if ((uint32_t)q < nv) {
+                        const uint32_t hw = (uint32_t)(vout[q] >> 32), tx = (hw >> 9) & 0xFFFu, ty = hw >> 21;
+                        min_x = min(min_x, tx); max_x = max(max_x, tx); min_y = min(min_y, ty); max_y = max(max_y, ty);
+                    }
                 }
             }
             for (uint32_t p = 0; p < RH.n_passes; p++) {
@@ -740,7 +744,7 @@ __global__ __launch_bounds__(RAS_THREADS, RAS_OCC) void k_rasterize(LineSource S
         k_and &= __shfl_xor(k_and, d, 64); k_and_hi &= __shfl_xor(k_and_hi, d, 64);
         unsorted |= __shfl_xor(unsorted, d, 64);
     }
-    if (HIST) {
+    if (HIST && RH.track_range) {                                       // (uniform)
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             min_x = min(min_x, (uint32_t)__shfl_xor(min_x, d, 64)); max_x = max(max_x, (uint32_t)__shfl_xor(max_x, d, 64));
