@@ -59,7 +59,7 @@ sys.path.insert(0, ROOT)
 STAGE_KEYS = ("prepare_us", "rasterize_us", "exchange_us", "sort_us", "carry_us", "paint_us")
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2   # wave64 VALU instructions/ns the chip can issue: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles
-PMC_FILES = [os.path.join("profiles", f"r0{r}_pmc_summary.json") for r in (5, 4, 3)]
+PMC_FILES = [os.path.join("profiles", f"r0{r}_pmc_summary.json") for r in (6, 5, 4, 3)]
 
 
 def parse():
@@ -345,7 +345,7 @@ def main():
                     "algorithmic_bytes_per_launch": algo_bytes_per_pass, "avg_launch_us": round(pass_us, 2), "passes": passes,
                     "measured": f"HIP events carried by every k_onesweep launch (hipExtLaunchKernelGGL: the dispatch's own start and end) of "
                                 f"{acc.get('_frames', 0)} frames with ONE frame in flight, a further timed region of this run; matches `rocprofv3 "
-                                "--kernel-trace --stats -- python bench.py --in-flight 1 --no-d2h --no-animated --no-cpu-baseline`, profiles/r05_kernel_stats_inflight1.csv"}
+                                "--kernel-trace --stats -- python bench.py --in-flight 1 --no-d2h --no-animated --no-cpu-baseline`, profiles/r06_kernel_stats_inflight1.csv"}
         # the whole sort against the same roofline: histogram read + p digit passes = 8 N (2 p + 1) bytes — or 16 N p
         # when the histograms come out of the rasterizer's registers (read-back-free frames with <= 3 passes: k_sort_hist and its
         # read of the stream do not run; the counting costs k_rasterize ~13 us, which stays in the rasterize stage)
