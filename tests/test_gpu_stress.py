@@ -86,6 +86,39 @@ def test_rows_beyond_the_local_sort_take_the_global_sort_and_very_deep_tiles_ren
         c.close()
 
 
+@pytest.mark.parametrize("layers", [100, 129, 600, 1024, 1025, 2500, 4096, 4097])
+def test_every_tier_of_the_deep_painters(layers):
+    """A tile's layer list decides who paints it: <= 128 entries the wave painters, <= 1 024 `k_paint_deep<1024>` (four workgroups
+    per CU, round 6), <= 4 096 `k_paint_deep<4096>`, beyond that `k_paint_huge` (lists in global memory).  Translucent squares
+    (nothing is culled, every layer blends) stacked over the same few tiles, counts on both sides of every tier's limit, with a
+    few tiles of every depth below in the same frame; synchronous, read-back-free and three-slot frames."""
+    import forma_amd
+    rng = np.random.default_rng(1000 + layers)
+    comp = S.Composition()
+    for order in range(layers):
+        # the first tile (0..16 x 0..16) is covered by EVERY layer; tiles to the right by fewer and fewer
+        x1 = 16.0 + float(rng.uniform(0, 112)) * (order % 3 != 0)
+        comp.get_mut_or_insert_default(order).insert(S.custom_square(1.0, 1.0 + float(rng.uniform(0, 6)), x1, 15.0)).set_props(
+            S.solid((float(rng.random()), float(rng.random()), float(rng.random()), 0.03)))
+    o = orc.Oracle()
+    t = comp.tables(o)
+    S.load(o, t)
+    want = o.render(160, 32)
+    c = forma_amd.Context(0)
+    try:
+        S.load(c, t)
+        for frame in range(3):
+            got = c.render(160, 32)
+            assert np.abs(want.astype(int) - got.astype(int)).max() <= 1, (layers, frame)
+        assert np.array_equal(c.segments(1), o.segments(1))
+        c.set_frames_in_flight(3)
+        for frame in range(7):
+            c.render(160, 32, device_only=True)
+        assert np.abs(want.astype(int) - c.read_image(160, 32).astype(int)).max() <= 1, (layers, "slots")
+    finally:
+        c.close()
+
+
 def test_layers_cut_by_the_bottom_edge_in_a_partial_last_tile_row():
     """Canvas height not a multiple of 16: lines entirely below the canvas are culled (segment.rs:41-52), so a layer that crosses
     the bottom edge keeps a non-zero cover on the invisible pixel rows of the last tile row, which the reference carries through
