@@ -42,6 +42,9 @@ __host__ __device__ constexpr int os_kpt(int bits) { return bits == 9 ? OS_KPT9 
 #define OS_SMALL_TILES 1
 #endif
 static inline int os_kpt_small(size_t n) {
+#ifdef OS_FORCE_KPT
+    return OS_FORCE_KPT;                                  // (tools: 8 or 12 keys per lane whatever the stream's size)
+#endif
     if (!OS_SMALL_TILES) return 0;
     if (n <= (size_t)256 * OS_THREADS * 8) return 8;
     if (n <= (size_t)256 * OS_THREADS * 12) return 12;
