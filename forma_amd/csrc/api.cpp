@@ -477,7 +477,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
         return std::min<uint32_t>(CR_MAX_SLICES_HOST, std::min(by_chip, by_load));
     };
     uint32_t n_slices = 1;
-    bool small = false, half = false;
+    bool small = false, half = false, covl = false;
     if (bound_j) {
         jc = chain ? DevCount{nullptr, (uint32_t)n} : DevCount{&dinfo->n_runs, bound_j};   // (chain: run indices are segment indices)
         if (chain) { ctx->chain_rows = row_count; ctx->n_chain_rows = tiles_h; }
@@ -564,6 +564,18 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
         }
         if (ctx->force_slices) n_slices = ctx->force_slices;  // FORMA_HIP_DEBUG=carry_slices (tests: every slice count on one GPU)
         ctx->cur_slices = n_slices; ctx->cur_small = small; ctx->cur_half = half;
+        // COVL (paint.hip): a row in ONE slice whose runs fit carry_rows_covl_cap() — the 4K scene's 4 800 — stages its cover sums
+        // and style summaries in LDS before the walk.  A read-back-free frame guesses from the last verified frame's heaviest row
+        // (6 % head-room); a row beyond the cap voids the frame and the synchronous re-run knows the rows.
+        {
+            const uint32_t mxr = bound_j ? ctx->pred_max_row : ctx->pred_max_row;      // (both paths have set pred_max_row by now, or left it unknown)
+            // (the 512-lane variant for light rows in one slice — the 8K triangle scene — has the room as well: 32 KB of covers, two
+            //  workgroups per CU instead of three, still one round for 512 rows)
+            const bool big = !small && !half && mxr != 0xFFFFFFFFu &&
+                             (bound_j ? !ctx->covl_banned && (uint64_t)mxr + mxr / 64u <= carry_rows_covl_cap() : mxr <= carry_rows_covl_cap());
+            covl = local_sort && n_slices == 1u && ctx->dbg.carry_covl != 0 && (big || (small && half && (ctx->dbg.carry_covl & 2) == 0));
+            ctx->covl_tried = covl && bound_j != 0;
+        }
     } else {
         HIPCHECK(ctx->span_key.ensure(8));
         HIPCHECK(ctx->span_cov.ensure(16));
@@ -650,7 +662,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                           (a.cache_id < 0 && (a.height & 15u) && fold_equals_paint) ? (a.height & 15u) : 16u, crow0, crow1, groups, ctx->run_lt.as<uint32_t>(),
                           cull,
                           (a.cache_id >= 0 || !fold_equals_paint) ? (a.crop ? a.crop->x0 / 16 : 0u) : 0xFFFFFFFFu,
-                          chain ? row_base : nullptr);
+                          chain ? row_base : nullptr, covl);
     stage_end(ctx, ST_CARRY, timing);
     stage_begin(ctx, ST_PAINT, timing);
     launch_paint(ctx->stream, P, ctx->sorted, ctx->records.as<TileRecord>(), jc, tile_first_run, row_span_lo,
@@ -1338,6 +1350,7 @@ int complete_async_frame(forma_hip_ctx* ctx, const PaintArgs& a, uint8_t* dst, s
     const bool ok = !ctx->h_info->plan_bad && N <= bN && J <= bJ;
     if (!ok) {
         if (ctx->small_tried && ctx->h_info->plan_bad) ctx->small_banned = true;   // (one cause of plan_bad: a slice beyond the small variant)
+        if (ctx->covl_tried && ctx->h_info->plan_bad) ctx->covl_banned = true;     // (another: a row beyond the COVL carry variant's LDS)
         if (ctx->plan_biased && ctx->h_info->plan_bad) ban_bias(ctx);              // (another: a key outside the span the digits were planned for)
         ctx->pred_counts_valid = false;                   // the synchronous path re-learns everything
         ctx->order_cur = -1; ctx->order_pending = -1;
@@ -1454,10 +1467,10 @@ void share_scene(forma_hip_ctx* o) {
     }
 }
 void invalidate_counts(forma_hip_ctx* o) {                 // new geometry / band: every slot re-learns N and J synchronously
-    o->pred_counts_valid = false; o->xpred_valid = false; o->small_banned = false; o->bias_banned = 0; o->bias_ban_len = 0; o->pred_range.valid = false;
+    o->pred_counts_valid = false; o->xpred_valid = false; o->small_banned = false; o->covl_banned = false; o->bias_banned = 0; o->bias_ban_len = 0; o->pred_range.valid = false;
     o->order_off = 0; o->order_flat = 0; o->order_cur = -1; o->cull_on = false;
     for (forma_hip_ctx* sl : o->slots) { sl->order_off = 0; sl->order_flat = 0; sl->order_cur = -1; sl->cull_on = false; }
-    for (forma_hip_ctx* sl : o->slots) { sl->pred_counts_valid = false; sl->xpred_valid = false; sl->small_banned = false; sl->bias_banned = 0; sl->bias_ban_len = 0; sl->pred_range.valid = false; }
+    for (forma_hip_ctx* sl : o->slots) { sl->pred_counts_valid = false; sl->xpred_valid = false; sl->small_banned = false; sl->covl_banned = false; sl->bias_banned = 0; sl->bias_ban_len = 0; sl->pred_range.valid = false; }
 }
 }  // namespace
 
@@ -1995,6 +2008,7 @@ int gsp_complete(forma_hip_ctx* ctx, const GspArgs& g, uint32_t bJ) {
     const uint32_t N = ctx->h_info->n_segments, J = ctx->h_info->n_runs;
     ctx->n_seg = N; ctx->last_runs = J;
     if (ctx->h_info->plan_bad && ctx->small_tried) ctx->small_banned = true;
+    if (ctx->h_info->plan_bad && ctx->covl_tried) ctx->covl_banned = true;
     if (ctx->h_info->plan_bad && ctx->plan_biased) ban_bias(ctx);
     if (!ctx->h_info->plan_bad && J <= bJ) {
         if (ctx->bias_banned) ctx->bias_banned--;

@@ -360,6 +360,7 @@ void launch_pack_written(hipStream_t s, const uint8_t* written, uint32_t tiles_w
 uint32_t carry_rows_local_cap();      // most runs a workgroup of launch_carry_rows(local_sort = true) sorts in LDS: large variant ...
 uint32_t carry_rows_small_cap();      // ... small variant (several workgroups per CU)
 uint32_t carry_rows_half_cap();       // ... its 512-lane form
+uint32_t carry_rows_covl_cap();       // ... the large variant with the covers in LDS (one slice per row)
 // Tiles per XCD "band" of the wave painters' grid (workgroup b runs on XCD b % 8).  PAINT_ROW_XCD = 1: band x = the tile rows x,
 // x + 8, ... of the crop: the rows of a frame are spread over all eight XCDs from the first workgroup on (1/8 band of the 4K
 // scene: painter 55.5 -> 48.1 us, whole frame 106.4 -> 103.9; dealing k_runs_wave's tiles to the same XCD as their row — so that the
@@ -411,7 +412,9 @@ void launch_carry_rows(hipStream_t s, bool local_sort, bool small, bool half /* 
                        uint32_t left_start /* cache frames: the first painted tile column, whose tiles list every layer with segments to
                                               their left (painter/mod.rs:500-522); 0xFFFFFFFF: no cache and a channel order under which a folded tile and a painted one
                                               are the same bytes — nothing can observe the entry */,
-                       const uint32_t* row_base = nullptr /* launch_runs' chain numbering: where each row's runs begin */);
+                       const uint32_t* row_base = nullptr /* launch_runs' chain numbering: where each row's runs begin */,
+                       bool covl = false /* one slice per row, rows of <= carry_rows_covl_cap() runs, neither small nor half: the variant that
+                                            brings the row's cover sums and style summaries into LDS before the walk */);
 void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, DevCount n_runs,
                   const uint32_t* tile_first_run, const uint32_t* row_span_lo, const uint32_t* row_span_cnt,
                   const uint64_t* span_key, const uint4* span_cov,

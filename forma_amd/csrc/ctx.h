@@ -84,6 +84,7 @@ struct forma_hip_ctx {
     bool cull_on = false;                         // this geometry has had tiles beyond the wave painter's lists: occlusion culling is on
     bool cur_half = false, pred_slice_half = false;   // the 512-lane variant of the small carry kernel (api.cpp run_paint)
     bool cur_small = false, pred_slice_small = false, small_tried = false, small_banned = false, no_small_carry = false;
+    bool covl_tried = false, covl_banned = false;   // the COVL carry variant (rows' covers in LDS) was this read-back-free frame's guess / a frame that guessed it was void
     DevBuf ras_masks;                       // k_rasterize: key masks per workgroup (8 words), combined by k_reduce_masks
     PendingMasks pending_masks{nullptr, 0u}; // ... or, on read-back-free frames, by k_runs_count
     size_t n_lines = 0, n_compact = 0;

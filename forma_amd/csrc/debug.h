@@ -18,6 +18,7 @@
 //   no_prezero           the frame's first kernel clears nothing for later stages (they use memsets: A/B of the folding)
 //   no_ras_hist          the sort's digit histograms are always taken by k_sort_hist, never by the rasterizer
 //   carry_half=0|1|N     never / by policy / with N slices per row: the 512-lane carry kernel (three workgroups per CU)
+//   carry_covl=0|1       never / by policy (default): the carry kernel that stages a row's cover sums and style summaries in LDS
 //   paint_quad=0|1|2     the four-tiles-per-wavefront painter of all-solid scenes: never / by policy / always
 //   order_thr=N          the painters file a tile as heavy from N shader clocks on (no steering, never switched off): tests
 //   sort_cus=N           persistent workgroups of a digit pass (0: one per CU; default: all, or half the CUs in a context with three frame slots — with two from 4 M keys on)
@@ -40,7 +41,7 @@ struct ForMaDebug {
     bool sync = false, global_runsort = false, xgather = false, no_small_carry = false, span_groups = false, no_span_groups = false;
     bool no_packed_copy = false, no_simple_paint = false, force_simple_paint = false, trim_debug = false, force_exchange = false;
     bool xchg_copy = false, no_prezero = false, no_bias = false, no_ras_hist = false, no_cull = false, force_cull = false, no_order = false;
-    int carry_slices = 0, digit_bits = 0, poison = -1, poison_frame = -1, strip_tiles = -1, carry_half = 1, paint_quad = 1, order_thr = -1, sort_cus = -1, runs_chain = -1, multi_layout = 0;
+    int carry_slices = 0, digit_bits = 0, poison = -1, poison_frame = -1, strip_tiles = -1, carry_half = 1, paint_quad = 1, order_thr = -1, sort_cus = -1, runs_chain = -1, multi_layout = 0, carry_covl = 1;
 };
 
 inline ForMaDebug forma_debug_parse() {
@@ -63,6 +64,7 @@ inline ForMaDebug forma_debug_parse() {
         if (!strcmp(tok, "carry_slices")) { d.carry_slices = (int)v; continue; }
         if (!strcmp(tok, "digit_bits")) { d.digit_bits = (int)v; continue; }
         if (!strcmp(tok, "carry_half")) { d.carry_half = (int)std::max(v, 0L); continue; }
+        if (!strcmp(tok, "carry_covl")) { d.carry_covl = (int)std::max(v, 0L); continue; }
         if (!strcmp(tok, "sort_cus")) { d.sort_cus = (int)std::max(v, 0L); continue; }
         if (!strcmp(tok, "order_thr")) { d.order_thr = (int)std::max(v, 0L); continue; }
         if (!strcmp(tok, "paint_quad")) { d.paint_quad = (int)std::max(v, 0L); continue; }

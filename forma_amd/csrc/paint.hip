@@ -679,6 +679,13 @@ uint32_t runs_count_tiles(size_t n, bool* scanned) { const uint32_t t = (uint32_
 #define CR_THREADS_H 512                // the HALF variant: 512 lanes, one piece of 2048 runs — three per CU (LDS 33 KB, 24 of the CU's
 #define CR_CAP_H   2048                 // waves), so that a whole 4K frame (135 rows x 3 slices) is resident at once on all 256 CUs
 #define CR_MAX_SLICES 8                 // workgroups that share one tile row (each takes a range of layers)
+// COVL (round 6): rows of <= CR_CAP_L runs in ONE slice — the 4K scene's heaviest has 5 512 — bring what the row walk gathered per
+// run into LDS first: the runs' own cover sums (16 B each, ONE round of coalesced loads over the row's contiguous records once the
+// in-LDS sort is done: 88 KB, in the space the sort's wave counters used) and their layers' style summaries (one gather per run,
+// issued before the sort and parked in 16 bits per run next to the run digests in the sort's idle key buffer).  The walk then
+// reads LDS only.  tools/cr_prof.py: "waiting for the gathers" was 28 k of a row's 80 k clocks — 8 scattered requests per lane
+// through the one address unit of the row's CU.
+#define CR_CAP_L   5632
 
 // workgroup barrier that orders LDS traffic only: global loads issued before it stay in flight across it
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -701,14 +708,16 @@ struct CarryLoad {
     uint32_t group, jrun, layer, tile, sc, seg_start, lsf;
     uint4 oc;
 };
-template <bool LOCAL>
+template <bool LOCAL, bool COVL = false>
 __device__ __forceinline__ CarryLoad carry_load(uint32_t c0, int tid, uint32_t cnt /* runs of the slice */, uint32_t row_lo /* first run of the row */,
                                                 uint32_t kbase /* !LOCAL: first sorted key of the slice */, uint32_t n_runs, uint32_t ty,
                                                 const uint32_t* lkeys, const uint64_t* __restrict__ sorted_keys,
                                                 const TileRecord* __restrict__ records,
                                                 const uint32_t* __restrict__ layer_sf, uint32_t n_orders,
                                                 const uint16_t* s_txo /* LOCAL, one slice: the row's run_lt low halves in LDS */,
-                                                const uint32_t* __restrict__ run_lt) {
+                                                const uint32_t* __restrict__ run_lt,
+                                                const uint4* s_cov = nullptr /* COVL: the row's cover sums by run index, in LDS */,
+                                                const uint16_t* s_sf16 = nullptr /* COVL: sfl | valid << 15 by run index, in LDS */) {
     CarryLoad L;
     const uint32_t k = (LOCAL ? row_lo : kbase) + c0 + tid;
     L.active = c0 + tid < cnt && k < n_runs;
@@ -735,8 +744,15 @@ __device__ __forceinline__ CarryLoad carry_load(uint32_t c0, int tid, uint32_t c
             const uint4 tail = rp[1];
             L.seg_start = tail.x; L.sc = tail.y; L.tile = tail.w & 0x7FFFFFFFu;
         }
-        L.oc = rp[0];
-        if (L.layer < n_orders) L.lsf = layer_sf[L.layer];
+        if (COVL) {
+            const uint32_t e = L.jrun - row_lo;
+            L.oc = s_cov[e];
+            const uint32_t p = s_sf16[e];
+            L.lsf = (p & 0x7FFFu) | ((p & 0x8000u) ? LSF_VALID : 0u);
+        } else {
+            L.oc = rp[0];
+            if (L.layer < n_orders) L.lsf = layer_sf[L.layer];
+        }
     }
     return L;
 }
@@ -756,8 +772,8 @@ __device__ __forceinline__ CarryLoad carry_load(uint32_t c0, int tid, uint32_t c
 // span slots (row_lo + runs in the bins below it), and the painters walk a row's n_slices span lists one after the other —
 // ascending layers, as before.  One workgroup per row was 135 workgroups on 256 CUs for the 4K frame, each ~50 us of pure
 // latency (scattered record gathers through one CU's address pipe); on a multi-GPU band of 17 rows it was the frame's floor.
-template <bool LOCAL, int CAP, int RPT, int TH>
-__global__ __launch_bounds__(TH, TH == 512 ? CR_HALF_OCC : (CAP == CR_CAP_S ? CR_SMALL_OCC : 1)) void k_carry_rows(   // (512 lanes: three workgroups per CU = six waves per SIMD)
+template <bool LOCAL, int CAP, int RPT, int TH, bool COVL = false>
+__global__ __launch_bounds__(TH, TH == 512 ? (COVL ? 4 : CR_HALF_OCC) : (CAP == CR_CAP_S ? CR_SMALL_OCC : 1)) void k_carry_rows(   // (512 lanes: three workgroups per CU = six waves per SIMD; with COVL's 32 KB of covers two = four)
     const uint64_t* __restrict__ sorted_keys,
                                                            TileRecord* __restrict__ records,
                                                            const BlkEdge* __restrict__ blk_edge, DevCount nc_segments,
@@ -780,16 +796,22 @@ __global__ __launch_bounds__(TH, TH == 512 ? CR_HALF_OCC : (CAP == CR_CAP_S ? CR
                                                            (launch_runs' chain numbering); else the rows' runs are dense in row order */) {
     constexpr int CR_RPT = RPT;                        // consecutive runs of the (layer, tile_x) order per lane in the row walk
     constexpr int CR_PIECE = TH * RPT;         // runs per piece
-    constexpr bool NB_IN_IDLE = LOCAL && 2 * (CR_PIECE + 1) <= CAP;   // group / tile_x of a piece's runs live in the sort's idle buffer
+    constexpr bool NB_IN_IDLE = LOCAL && !COVL && 2 * (CR_PIECE + 1) <= CAP;   // group / tile_x of a piece's runs live in the sort's idle buffer
+    static_assert(!COVL || LOCAL, "COVL is a LOCAL variant");
     __shared__ uint32_t s_red[(TH / 64)];
     __shared__ uint64_t s_wlo[(TH / 64)], s_whi[(TH / 64)];
     __shared__ uint32_t s_wflag[(TH / 64)], s_wspan[(TH / 64)];
     __shared__ uint32_t s_group[256];                  // scratch of the in-LDS sort; before it, the layer-bin histogram
-    __shared__ uint32_t s_nb[NB_IN_IDLE ? 1 : 2 * (CR_PIECE + 1)];
+    __shared__ uint32_t s_nb[NB_IN_IDLE ? 1 : (COVL ? (CR_PIECE + 1) + (CR_PIECE + 4) / 2 : 2 * (CR_PIECE + 1))];   // a_group (words) + a_txb (halves)
     __shared__ uint64_t s_clo, s_chi;                  // carry across chunks: inclusive acc of the last element
     __shared__ uint32_t s_cgroup, s_spans;
     __shared__ uint32_t s_ka[LOCAL ? CAP : 1], s_kb[LOCAL ? CAP : 1];
-    __shared__ uint32_t s_wh[LOCAL ? (TH / 64) * 256 : 1];
+    constexpr int KPL = (CAP + TH - 1) / TH;           // keys per lane of the in-LDS sort (CAP need not be a multiple of TH)
+    __shared__ uint32_t s_wh_own[LOCAL && !COVL ? (TH / 64) * 256 : 1];
+    __shared__ uint4 s_cov[COVL ? CAP : 1];            // COVL: the row's cover sums by run index — loaded AFTER the sort, whose wave counters live here until then
+    static_assert(!COVL || (size_t)CAP * 16 >= (size_t)(TH / 64) * 256 * 4, "the sort's wave counters fit the cover array");
+    uint32_t* s_wh = COVL ? reinterpret_cast<uint32_t*>(s_cov) : s_wh_own;
+    uint32_t lsf_reg[COVL ? KPL : 1];                   // COVL: the style summaries of this lane's runs (stream order), in flight across the sort
     __shared__ uint32_t s_cut[4];                      // this slice: first bin, end bin | first key, end key (!LOCAL)
     __shared__ uint32_t s_gcnt[256], s_gpre[256];      // span group lists: entries per group, their exclusive prefix
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -919,9 +941,27 @@ __global__ __launch_bounds__(TH, TH == 512 ? CR_HALF_OCC : (CAP == CR_CAP_S ? CR
             }
         } else {
             if (cnt > (uint32_t)CAP) { if (tid == 0) info->plan_bad = 1u; return; }
-            for (uint32_t e = tid; e < cnt; e += TH) s_ka[e] = (run_lt[row_lo + e] & 0xFFFF0000u) | e;
+            if (COVL) {
+                // the run digests (coalesced), then the layers' style summaries: a gather behind the digest that lands while the sort runs
+                uint32_t rl[KPL];
+#pragma unroll
+                for (int r = 0; r < KPL; r++) {
+                    const uint32_t e = (uint32_t)r * TH + (uint32_t)tid;
+                    rl[r] = e < cnt ? run_lt[row_lo + e] : 0u;
+                }
+#pragma unroll
+                for (int r = 0; r < KPL; r++) {
+                    const uint32_t e = (uint32_t)r * TH + (uint32_t)tid;
+                    const uint32_t layer = rl[r] >> 16;
+                    lsf_reg[r] = (e < cnt && layer < n_orders) ? layer_sf[layer] : 0u;
+                    if (e < cnt) s_ka[e] = (rl[r] & 0xFFFF0000u) | e;
+                }
+            } else {
+                for (uint32_t e = tid; e < cnt; e += TH) s_ka[e] = (run_lt[row_lo + e] & 0xFFFF0000u) | e;
+            }
             __syncthreads();
         }
+        if (COVL && n_slices > 1u) { if (tid == 0) info->plan_bad = 1u; return; }        // (the host launches COVL for one slice per row only)
         if (tid == 0 && m) atomicMax(&info->max_slice_runs, m);
         CRP_STAMP(1);                                                   // the slice's run keys into LDS
         uint32_t* src = s_ka;
@@ -933,9 +973,9 @@ __global__ __launch_bounds__(TH, TH == 512 ? CR_HALF_OCC : (CAP == CR_CAP_S ? CR
             for (int i = tid; i < (TH / 64) * 256; i += TH) s_wh[i] = 0;
             __syncthreads();
             CRP_STAMP(5);                                               // sort: counters cleared
-            uint32_t kreg[CAP / TH], rreg[CAP / TH];
+            uint32_t kreg[KPL], rreg[KPL];
 #pragma unroll
-            for (int r = 0; r < CAP / TH; r++) {
+            for (int r = 0; r < KPL; r++) {
                 if ((uint32_t)r < R) {
                     const uint32_t e = w * CW + r * 64 + lane;
                     const uint32_t key = e < m ? src[e] : 0xFFFFFFFFu;             // padding: last in stream order, digit 255
@@ -971,7 +1011,7 @@ __global__ __launch_bounds__(TH, TH == 512 ? CR_HALF_OCC : (CAP == CR_CAP_S ? CR
             }
             __syncthreads();
 #pragma unroll
-            for (int r = 0; r < CAP / TH; r++) {
+            for (int r = 0; r < KPL; r++) {
                 if ((uint32_t)r < R) {
                     const uint32_t e = w * CW + r * 64 + lane;
                     if (e < m) dst[s_wh[w * 256 + ((kreg[r] >> sh) & 0xFFu)] + rreg[r]] = kreg[r];
@@ -1019,6 +1059,22 @@ __global__ __launch_bounds__(TH, TH == 512 ? CR_HALF_OCC : (CAP == CR_CAP_S ? CR
     uint16_t* a_txb = reinterpret_cast<uint16_t*>(a_group + (CR_PIECE + 1));
     // LOCAL, one slice per row: the low halves of the row's run digests (tile column + 1, "open" flag) by run index, next to them
     uint16_t* s_txo = nullptr;
+    // COVL: the sort is done — its wave counters' space takes the row's cover sums (one round of coalesced loads: the records of a
+    // row are contiguous), the idle key buffer's upper half the style summaries (its lower half: the run digests, s_txo below)
+    uint16_t* s_sf16 = COVL ? reinterpret_cast<uint16_t*>(idle) + CAP : nullptr;
+    if (COVL) {
+        uint4 cv[COVL ? KPL : 1];
+#pragma unroll
+        for (int r = 0; r < (COVL ? KPL : 1); r++) {
+            const uint32_t e = (uint32_t)r * TH + (uint32_t)tid;
+            cv[r] = e < cnt ? *reinterpret_cast<const uint4*>(&records[row_lo + e]) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int r = 0; r < (COVL ? KPL : 1); r++) {
+            const uint32_t e = (uint32_t)r * TH + (uint32_t)tid;
+            if (e < cnt) { s_cov[e] = cv[r]; s_sf16[e] = (uint16_t)((lsf_reg[r] & 0x7FFFu) | ((lsf_reg[r] & LSF_VALID) ? 0x8000u : 0u)); }
+        }
+    }
     if (LOCAL && n_slices == 1u) {
         s_txo = reinterpret_cast<uint16_t*>(NB_IN_IDLE ? idle + (CR_PIECE + 1) + (CR_PIECE + 4) / 2 : idle);
         for (uint32_t e = tid; e < cnt; e += TH) s_txo[e] = (uint16_t)run_lt[row_lo + e];
@@ -1030,9 +1086,9 @@ __global__ __launch_bounds__(TH, TH == 512 ? CR_HALF_OCC : (CAP == CR_CAP_S ? CR
         CarryLoad cl[CR_RPT];
 #pragma unroll
         for (int k = 0; k < CR_RPT; k++)
-            cl[k] = carry_load<LOCAL>(c0, tid * CR_RPT + k, m, row_lo, kbase, n_runs, ty, lkeys, sorted_keys, records, layer_sf, n_orders, s_txo, run_lt);
+            cl[k] = carry_load<LOCAL, COVL>(c0, tid * CR_RPT + k, m, row_lo, kbase, n_runs, ty, lkeys, sorted_keys, records, layer_sf, n_orders, s_txo, run_lt, s_cov, s_sf16);
         if (tid == 0) {                                                 // the run after the piece: only its group and tile_x
-            const CarryLoad la = carry_load<LOCAL>(c0, CR_PIECE, m, row_lo, kbase, n_runs, ty, lkeys, sorted_keys, records, layer_sf, n_orders, s_txo, run_lt);
+            const CarryLoad la = carry_load<LOCAL, COVL>(c0, CR_PIECE, m, row_lo, kbase, n_runs, ty, lkeys, sorted_keys, records, layer_sf, n_orders, s_txo, run_lt, s_cov, s_sf16);
             a_group[CR_PIECE] = la.active ? la.group : 0xFFFFFFFEu;
             a_txb[CR_PIECE] = (uint16_t)(la.active ? (la.tile & 0xFFFu) : 0u);
         }
@@ -1278,6 +1334,7 @@ __global__ __launch_bounds__(TH, TH == 512 ? CR_HALF_OCC : (CAP == CR_CAP_S ? CR
 uint32_t carry_rows_local_cap() { return CR_CAP; }
 uint32_t carry_rows_small_cap() { return CR_CAP_S; }
 uint32_t carry_rows_half_cap() { return CR_CAP_H; }
+uint32_t carry_rows_covl_cap() { return CR_CAP_L; }
 
 void launch_carry_rows(hipStream_t s, bool local_sort, bool small, bool half, uint32_t n_slices, uint32_t bin_shift,
                        const uint64_t* sorted_run_keys, TileRecord* records,
@@ -1285,18 +1342,20 @@ void launch_carry_rows(hipStream_t s, bool local_sort, bool small, bool half, ui
                        uint32_t n_orders, uint32_t tiles_w, uint32_t tiles_h, const uint32_t* row_count,
                        uint32_t* row_span_lo, uint32_t* row_span_cnt, uint64_t* span_key, uint4* span_cov,
                        const uint8_t* unchanged, FrameInfo* info, uint32_t edge_segs, uint32_t vis_last, uint32_t row0, uint32_t row1,
-                       SpanGroups groups, const uint32_t* run_lt, bool cull, uint32_t left_start, const uint32_t* row_base) {
+                       SpanGroups groups, const uint32_t* run_lt, bool cull, uint32_t left_start, const uint32_t* row_base, bool covl) {
     row1 = row1 < tiles_h ? row1 : tiles_h;
     if (tiles_h == 0 || row0 >= row1) return;             // (only the tile rows that are painted: the others' carries are never read)
     if (n_slices < 1u) n_slices = 1u;
     if (n_slices > CR_MAX_SLICES) n_slices = CR_MAX_SLICES;
     const dim3 grid((row1 - row0) * n_slices);
-#define CR_LAUNCH(L, C, R, T_) FORMA_LAUNCH((k_carry_rows<L, C, R, T_>), grid, dim3(T_), 0, s, sorted_run_keys, records, blk_edge, n_segments, \
+#define CR_LAUNCH(L, C, R, T_, ...) FORMA_LAUNCH((k_carry_rows<L, C, R, T_ __VA_OPT__(,) __VA_ARGS__>), grid, dim3(T_), 0, s, sorted_run_keys, records, blk_edge, n_segments, \
                                               n_runs, layer_sf, n_orders, tiles_w, tiles_h, row_count, row_span_lo, row_span_cnt, span_key, \
                                               span_cov, unchanged, info, edge_segs, vis_last, n_slices, bin_shift, row0, groups, run_lt, cull ? 1u : 0u, left_start, row_base)
     if (!local_sort) CR_LAUNCH(false, CR_CAP, 4, CR_THREADS);
+    else if (small && half && covl && n_slices == 1u) CR_LAUNCH(true, CR_CAP_H, 4, CR_THREADS_H, true);
     else if (small && half) CR_LAUNCH(true, CR_CAP_H, 4, CR_THREADS_H);
     else if (small) CR_LAUNCH(true, CR_CAP_S, 2, CR_THREADS);
+    else if (covl && n_slices == 1u) CR_LAUNCH(true, CR_CAP_L, 3, CR_THREADS, true);
     else CR_LAUNCH(true, CR_CAP, 4, CR_THREADS);
 #undef CR_LAUNCH
 }

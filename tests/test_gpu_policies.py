@@ -28,7 +28,7 @@ SWITCHES = [
     "no_order", "order_thr=1",                     # heavy-first order never / every tile filed as heavy
     "runs_chain=1", "runs_chain=0",                # k_runs_wave<true> alone / k_runs_count + k_runs_wave
     "sort_cus=0", "sort_cus=64", "sort_cus=128",   # persistent workgroups of a digit pass
-    "carry_half=0", "carry_half=2", "carry_half=4",
+    "carry_half=0", "carry_half=2", "carry_half=4", "carry_covl=0", "carry_covl=0,carry_slices=1",
     "carry_slices=1", "carry_slices=3", "carry_slices=8", "no_small_carry",
     "force_cull", "no_cull",
     "digit_bits=4", "digit_bits=8", "digit_bits=9", "no_bias", "no_ras_hist", "no_prezero",

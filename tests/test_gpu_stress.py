@@ -119,6 +119,47 @@ def test_every_tier_of_the_deep_painters(layers):
         c.close()
 
 
+def _runs_per_row(sorted_stream, tiles_w, tiles_h):
+    key = sorted_stream >> np.uint64(20)
+    heads = sorted_stream[np.concatenate(([True], key[1:] != key[:-1]))]
+    ty = (heads >> np.uint64(53)).astype(np.int64) - 1
+    tx = ((heads >> np.uint64(41)) & np.uint64(0xFFF)).astype(np.int64)
+    ok = (ty >= 0) & (ty < tiles_h) & (tx <= tiles_w)
+    return np.bincount(ty[ok], minlength=tiles_h)
+
+
+def test_carry_rows_with_the_rows_covers_in_lds_and_rows_that_outgrow_it():
+    """k_carry_rows<.., COVL> (round 6): a tile row in ONE slice whose runs fit 5 632 stages its cover sums and style summaries in
+    LDS before the walk.  Rows just below the cap (the variant runs), a transform that grows them beyond it between two
+    read-back-free frames (the frame that guessed COVL is void, the re-run takes the large variant, the guess is not made again
+    for this geometry), and back; the 512-lane form on light rows.  Images and streams against the oracle every time."""
+    import forma_amd
+    W, H = 4096, 48
+    o = orc.Oracle()
+    c = forma_amd.Context(0)
+    try:
+        seen_below = seen_above = False
+        for n in (70, 110):
+            t = S.random_cubics(n=n, width=W, height=H, seed=70 + n, alpha=0.6).tables(o)
+            S.load(o, t); S.load(c, t)
+            for scale in (1.0, 1.0, 1.6, 1.6, 1.0, 0.5):       # (n = 70: rows of 5 291 -> 5 676 -> 5 291 runs)
+                g = t["geoms"].copy()
+                g["flags"] = 1
+                g["xf"] = np.array([scale, 0.0, 0.0, 1.0, 0.0, 0.0], np.float32)
+                o.set_geoms(g); c.set_geoms(g)
+                want = o.render(W, H)
+                for frame in range(3):
+                    got = c.render(W, H)
+                    assert np.abs(want.astype(int) - got.astype(int)).max() <= 1, (n, scale, frame)
+                assert np.array_equal(c.segments(1), o.segments(1)), (n, scale)
+                mx = int(_runs_per_row(o.segments(1), W // 16, H // 16).max())
+                seen_below |= 2048 < mx <= 5632
+                seen_above |= mx > 5632
+        assert seen_below and seen_above, "the scenes must bracket the COVL variant's capacity"
+    finally:
+        c.close()
+
+
 def test_layers_cut_by_the_bottom_edge_in_a_partial_last_tile_row():
     """Canvas height not a multiple of 16: lines entirely below the canvas are culled (segment.rs:41-52), so a layer that crosses
     the bottom edge keeps a non-zero cover on the invisible pixel rows of the last tile row, which the reference carries through
