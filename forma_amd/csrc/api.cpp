@@ -424,42 +424,6 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                                                 : ctx->dbg.runs_chain != 0);
     const bool chain_zero = chain && ctx->pz.chain_p == ctx->runs_scratch.p && ctx->pz.chain_words >= runs_chain_words(n);
     ctx->pz.chain_p = nullptr;
-    // Records, run keys and digests are sized for the RUNS, not for the segments (a run needs a segment, so N would always do:
-    // 440 MB of records per frame slot on the 4K scene, for 21 MB of runs).  A read-back-free frame has its bound from the last
-    // verified frame; a synchronous one launches the counting kernel, reads the count and sizes the buffers before the kernel
-    // that fills them.
-    size_t cap = std::max<size_t>(chain ? n : bound_j, 1);
-    auto runs = [&](int what) {
-        launch_runs(ctx->stream, ctx->sorted, nc, tiles_w, tiles_h, ctx->records.as<TileRecord>(), (uint32_t)cap,
-                    ctx->rk_u.as<uint64_t>(), tile_first_run, ctx->blk_edge.as<BlkEdge>(), row_count,
-                    ctx->runs_scratch.as<uint32_t>(), dinfo, /*verify_plan=*/bound_j != 0 && ctx->speculated, ctx->live44,
-                    ctx->layer_sorted, ctx->pending_masks,
-                    RunStyle{ctx->layer_sf.as<uint32_t>(), (uint32_t)ctx->n_orders,
-                             (a.cache_id >= 0 && ctx->have_unchanged) ? ctx->unchanged.as<uint8_t>() : nullptr, ctx->run_lt.as<uint32_t>()},
-                    tables_zero, ctx->sort_range, ctx->sort_range_n, what, chain ? row_base : nullptr, chain_zero);
-    };
-    if (!bound_j && n > 0) {
-        runs(1);
-        HIPCHECK(hipGetLastError());
-        bool scanned = false;
-        const uint32_t nt = runs_count_tiles(n, &scanned);
-        uint64_t total = 0;
-        if (scanned) { int rc = read_info(ctx); if (rc) return rc; total = ctx->h_info->n_runs; }
-        else {
-            std::vector<uint32_t> counts(nt);
-            HIPCHECK(hipMemcpyAsync(counts.data(), ctx->runs_scratch.p, (size_t)nt * 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHECK(hipStreamSynchronize(ctx->stream));
-            for (uint32_t c : counts) total += c;
-        }
-        cap = std::max<size_t>(std::min<uint64_t>(total, n), 1);
-    }
-    HIPCHECK(ctx->records.ensure(cap * sizeof(TileRecord)));
-    HIPCHECK(ctx->rk_u.ensure((chain ? 1 : cap) * 8));                  // (the global run sort's keys)
-    HIPCHECK(ctx->run_lt.ensure(cap * 4));
-    runs(bound_j || n == 0 ? 3 : 2);
-    ctx->sort_range = nullptr;
-    ctx->pending_masks = PendingMasks{nullptr, 0u};
-    HIPCHECK(hipGetLastError());
     DevCount jc;
     // Several workgroups share a tile row, each a range of layers (k_carry_rows): as many as keep the chip busy for the rows
     // this frame paints (a multi-GPU band is a fraction of the canvas).  The small-LDS variant (a quarter of the keys per workgroup) is a
@@ -479,8 +443,6 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     uint32_t n_slices = 1;
     bool small = false, half = false, covl = false;
     if (bound_j) {
-        jc = chain ? DevCount{nullptr, (uint32_t)n} : DevCount{&dinfo->n_runs, bound_j};   // (chain: run indices are segment indices)
-        if (chain) { ctx->chain_rows = row_count; ctx->n_chain_rows = tiles_h; }
         local_sort = local_sort && ctx->pred_max_row <= carry_rows_local_cap();     // wrong guess -> plan_bad -> synchronous re-run
         const uint32_t pmr = ctx->pred_max_row == 0xFFFFFFFFu ? 0u : ctx->pred_max_row;
         n_slices = slices_for(256u, pmr);
@@ -510,7 +472,58 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
             if (guess <= carry_rows_half_cap()) { small = true; half = true; n_slices = kh; }
         }
         ctx->small_tried = small;
-    } else {
+    }
+    // BLOCKS (launch_runs, k_carry_rows): a read-back-free frame whose tile rows take ONE carry workgroup each needs neither the counting
+    // pass nor the chain: the run kernel numbers per 2 048-segment tile into sparse arrays and the row's workgroup compacts them.
+    const uint32_t ns_final = ctx->force_slices ? std::min<uint32_t>(ctx->force_slices, CR_MAX_SLICES_HOST) : n_slices;
+    const bool blk = bound_j != 0 && n > 0 && !chain && local_sort && ns_final == 1u && n <= 0x3FFFFFFFull &&
+                     (ctx->dbg.runs_blk < 0 ? RUNS_BLK_DEFAULT != 0 : ctx->dbg.runs_blk != 0);
+    if (bound_j) {
+        jc = chain ? DevCount{nullptr, (uint32_t)n} : (blk ? DevCount{nullptr, bound_j} : DevCount{&dinfo->n_runs, bound_j});   // (chain: run indices are segment indices; blk: dense, counted by nobody before the tail)
+        if (chain || blk) { ctx->chain_rows = row_count; ctx->n_chain_rows = tiles_h; }
+    }
+    // Records, run keys and digests are sized for the RUNS, not for the segments (a run needs a segment, so N would always do:
+    // 440 MB of records per frame slot on the 4K scene, for 21 MB of runs).  A read-back-free frame has its bound from the last
+    // verified frame; a synchronous one launches the counting kernel, reads the count and sizes the buffers before the kernel
+    // that fills them.
+    size_t cap = std::max<size_t>(chain ? n : bound_j, 1);
+    auto runs = [&](int what) {
+        launch_runs(ctx->stream, ctx->sorted, nc, tiles_w, tiles_h, blk ? ctx->rec_sp.as<TileRecord>() : ctx->records.as<TileRecord>(), (uint32_t)(blk ? n : cap),
+                    ctx->rk_u.as<uint64_t>(), tile_first_run, ctx->blk_edge.as<BlkEdge>(), row_count,
+                    ctx->runs_scratch.as<uint32_t>(), dinfo, /*verify_plan=*/bound_j != 0 && ctx->speculated, ctx->live44,
+                    ctx->layer_sorted, ctx->pending_masks,
+                    RunStyle{ctx->layer_sf.as<uint32_t>(), (uint32_t)ctx->n_orders,
+                             (a.cache_id >= 0 && ctx->have_unchanged) ? ctx->unchanged.as<uint8_t>() : nullptr,
+                             blk ? ctx->run_lt_sp.as<uint32_t>() : ctx->run_lt.as<uint32_t>()},
+                    tables_zero, ctx->sort_range, ctx->sort_range_n, what, (chain || blk) ? row_base : nullptr, chain_zero, blk);
+    };
+    if (!bound_j && n > 0) {
+        runs(1);
+        HIPCHECK(hipGetLastError());
+        bool scanned = false;
+        const uint32_t nt = runs_count_tiles(n, &scanned);
+        uint64_t total = 0;
+        if (scanned) { int rc = read_info(ctx); if (rc) return rc; total = ctx->h_info->n_runs; }
+        else {
+            std::vector<uint32_t> counts(nt);
+            HIPCHECK(hipMemcpyAsync(counts.data(), ctx->runs_scratch.p, (size_t)nt * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHECK(hipStreamSynchronize(ctx->stream));
+            for (uint32_t c : counts) total += c;
+        }
+        cap = std::max<size_t>(std::min<uint64_t>(total, n), 1);
+    }
+    HIPCHECK(ctx->records.ensure(cap * sizeof(TileRecord)));
+    HIPCHECK(ctx->rk_u.ensure((chain ? 1 : cap) * 8));                  // (the global run sort's keys)
+    HIPCHECK(ctx->run_lt.ensure(cap * 4));
+    if (blk) {                                                          // (the sparse arrays: indexed like the segments)
+        HIPCHECK(ctx->rec_sp.ensure(std::max<size_t>(n, 1) * sizeof(TileRecord)));
+        HIPCHECK(ctx->run_lt_sp.ensure(std::max<size_t>(n, 1) * 4));
+    }
+    runs(bound_j || n == 0 ? 3 : 2);
+    ctx->sort_range = nullptr;
+    ctx->pending_masks = PendingMasks{nullptr, 0u};
+    HIPCHECK(hipGetLastError());
+    if (!bound_j) {
         if (n > 0) {
             HIPCHECK(hipMemcpyAsync(ctx->h_rows, row_count, (size_t)tiles_h * 4, hipMemcpyDeviceToHost, ctx->stream));
             int rc = read_info(ctx);
@@ -608,7 +621,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     P.cull = cull ? 1u : 0u;
     // heaviest tiles first (PaintParams::order_*): read-back-free frames without a cache, one wavefront per tile
     P.order_cnt_in = nullptr; P.order_list_in = nullptr; P.order_cnt_out = nullptr; P.order_list_out = nullptr;
-    P.row_base = chain ? row_base : nullptr; P.row_cnt = chain ? row_count : nullptr;
+    P.row_base = (chain || blk) ? row_base : nullptr; P.row_cnt = (chain || blk) ? row_count : nullptr;
     ctx->order_pending = -1; ctx->order_cnt_dev = nullptr; ctx->order_keep_dev = nullptr;
     const uint32_t tiles_painted = (P.crop_y1 > P.crop_y0 ? P.crop_y1 - P.crop_y0 : 0u) * tiles_w;
     const bool strips = paint_by_strips(ctx, tiles_painted);
@@ -662,7 +675,10 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                           (a.cache_id < 0 && (a.height & 15u) && fold_equals_paint) ? (a.height & 15u) : 16u, crow0, crow1, groups, ctx->run_lt.as<uint32_t>(),
                           cull,
                           (a.cache_id >= 0 || !fold_equals_paint) ? (a.crop ? a.crop->x0 / 16 : 0u) : 0xFFFFFFFFu,
-                          chain ? row_base : nullptr, covl);
+                          chain ? row_base : nullptr, covl,
+                          blk ? BlkRuns{ctx->rec_sp.as<TileRecord>(), ctx->run_lt_sp.as<uint32_t>(), ctx->runs_scratch.as<uint32_t>(), row_base,
+                                        tile_first_run, ctx->run_lt.as<uint32_t>()}
+                              : BlkRuns{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
     stage_end(ctx, ST_CARRY, timing);
     stage_begin(ctx, ST_PAINT, timing);
     launch_paint(ctx->stream, P, ctx->sorted, ctx->records.as<TileRecord>(), jc, tile_first_run, row_span_lo,
@@ -998,7 +1014,7 @@ void forma_hip_destroy(forma_hip_ctx* ctx) {
                      &ctx->blk_edge, &ctx->runs_scratch, &ctx->row_tab, &ctx->span_key, &ctx->span_cov,
                      &ctx->image, &ctx->xsend, &ctx->xrecv, &ctx->xscratch,
                      &ctx->ras_masks, &ctx->xmask, &ctx->huge_offs, &ctx->huge_key, &ctx->huge_tmp, &ctx->huge_flag,
-                     &ctx->grp_tab, &ctx->grp_list, &ctx->run_lt, &ctx->pack_list, &ctx->pack_pix, &ctx->cache_written, &ctx->order_buf};
+                     &ctx->grp_tab, &ctx->grp_list, &ctx->run_lt, &ctx->rec_sp, &ctx->run_lt_sp, &ctx->pack_list, &ctx->pack_pix, &ctx->cache_written, &ctx->order_buf};
     for (DevBuf* b : all) b->release();
     for (int s = 0; s < ST_COUNT; s++) { (void)hipEventDestroy(ctx->ev0[s]); (void)hipEventDestroy(ctx->ev1[s]); }
     if (g_ktimer == &ctx->kt) g_ktimer = nullptr;           // (a timed frame of this context that failed between stage_begin and stage_end)
@@ -1314,7 +1330,7 @@ int poison_frame_buffers(forma_hip_ctx* c) {
     DevBuf* frame[] = {&c->scan_tmp, &c->cl_idx, &c->cl_start, &c->block_first, &c->prep_scratch, &c->seg_u, &c->seg_a, &c->seg_b,
                        &c->sort_counters, &c->records, &c->rk_u, &c->rk_a, &c->rk_b, &c->blk_edge, &c->runs_scratch, &c->row_tab,
                        &c->span_key, &c->span_cov, &c->ras_masks, &c->huge_offs, &c->huge_key, &c->huge_tmp, &c->huge_flag,
-                       &c->grp_tab, &c->grp_list, &c->run_lt, &c->pack_list, &c->pack_pix};
+                       &c->grp_tab, &c->grp_list, &c->run_lt, &c->rec_sp, &c->run_lt_sp, &c->pack_list, &c->pack_pix};
     for (DevBuf* b : frame) if (b->p && !b->borrowed) HIPCHECK(hipMemsetAsync(b->p, byte, b->cap, c->stream));
     return FORMA_OK;
 }
@@ -1652,7 +1668,7 @@ int forma_hip_trim(forma_hip_ctx* ctx) {
                            &c->scan_tmp, &c->cl_idx, &c->cl_start, &c->block_first, &c->prep_scratch, &c->seg_u, &c->seg_a, &c->seg_b,
                            &c->sort_counters, &c->records, &c->rk_u, &c->rk_a, &c->rk_b, &c->blk_edge, &c->runs_scratch, &c->row_tab,
                            &c->span_key, &c->span_cov, &c->image, &c->xscratch, &c->ras_masks, &c->xmask,
-                           &c->huge_offs, &c->huge_key, &c->huge_tmp, &c->huge_flag, &c->grp_tab, &c->grp_list, &c->run_lt, &c->pack_list, &c->pack_pix,
+                           &c->huge_offs, &c->huge_key, &c->huge_tmp, &c->huge_flag, &c->grp_tab, &c->grp_list, &c->run_lt, &c->rec_sp, &c->run_lt_sp, &c->pack_list, &c->pack_pix,
                            &c->order_buf};
         c->order_cur = -1; c->order_pending = -1; c->order_cnt_dev = nullptr; c->order_keep_dev = nullptr;
         size_t freed = 0;

@@ -314,6 +314,16 @@ struct RunStyle {
     uint32_t*       run_lt;       // one word per run (rec_cap)
 };
 #define RUN_LT_OPEN 0x8000u
+// launch_runs' BLOCKS numbering (round 6; paint.hip): the run kernel wrote SPARSE records / digests — tile b of 2 048 segments owns
+// [2048 b, 2048 b + heads[b]) — and k_carry_rows copies every row's runs into the dense arrays.  rec_sp == nullptr: not this frame.
+struct BlkRuns {
+    const TileRecord* rec_sp;       // n.bound records, sparse
+    const uint32_t*   run_lt_sp;    // n.bound digests, sparse
+    const uint32_t*   heads;        // paintable run heads per 2 048-segment tile (the head of launch_runs' `scratch`)
+    uint32_t*         row_base;     // in: index of the row's first run in the sparse numbering; out: in the dense one (PaintParams::row_base)
+    uint32_t*         tile_first_run;
+    uint32_t*         run_lt_out;   // the dense digests (= k_carry_rows' run_lt)
+};
 // tables_are_zero: the frame's tile tables (row_tab_zero_words() words of row_tab) were cleared by an earlier kernel of this
 // frame; else k_runs_count clears them
 void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount n, uint32_t tiles_w, uint32_t tiles_h, TileRecord* records,
@@ -327,7 +337,9 @@ void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount n, uint32_t til
                  uint32_t* chain_row_base = nullptr /* tiles_h + 1 words.  Not null: ONE kernel, no counting pass — runs are numbered per
                                  tile row from the index of the row's first segment (here: where each row begins), `records` and
                                  the arrays indexed like it hold n.bound entries, the run count is the sum of the row counts */,
-                 bool chain_status_is_zero = false /* the first runs_chain_words(n.bound) words of `scratch` were cleared by an earlier kernel */);
+                 bool chain_status_is_zero = false /* the first runs_chain_words(n.bound) words of `scratch` were cleared by an earlier kernel */,
+                 bool blocks = false /* with chain_row_base: numbered per 2 048-segment tile instead (BlkRuns): no look-back, `records` and
+                                 rs.run_lt are the sparse arrays, the head of `scratch` takes the tiles' head counts */);
 size_t runs_chain_words(size_t n);
 // the per-tile counts k_runs_count leaves in `scratch`: how many (host sum = J), or — big frames — already scanned (J = info->n_runs)
 uint32_t runs_count_tiles(size_t n, bool* scanned);
@@ -383,6 +395,9 @@ static inline uint32_t paint_band_tiles(uint32_t rows, uint32_t tiles_w) {
 // [painter overflow counters: 2][first-run table: T][painter order counts: PAINT_ORDER_WORDS] — zeroed every frame by launch_runs —
 // then [overflow list: T][{tile, entries}: 2 T]
 // ... then [where each row's runs begin (launch_runs' chain numbering): tiles_h + 1]
+#ifndef RUNS_BLK_DEFAULT
+#define RUNS_BLK_DEFAULT 1              // read-back-free frames with one carry workgroup per tile row number their runs per 2 048-segment tile (BlkRuns; debug.h: runs_blk)
+#endif
 #ifndef RUNS_CHAIN_DEFAULT
 #define RUNS_CHAIN_DEFAULT 1            // read-back-free frames number their runs per tile row, without the counting pass (debug.h: runs_chain) ...
 #endif
@@ -414,7 +429,8 @@ void launch_carry_rows(hipStream_t s, bool local_sort, bool small, bool half /* 
                                               are the same bytes — nothing can observe the entry */,
                        const uint32_t* row_base = nullptr /* launch_runs' chain numbering: where each row's runs begin */,
                        bool covl = false /* one slice per row, rows of <= carry_rows_covl_cap() runs, neither small nor half: the variant that
-                                            brings the row's cover sums and style summaries into LDS before the walk */);
+                                            brings the row's cover sums and style summaries into LDS before the walk */,
+                       BlkRuns bk = BlkRuns{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr} /* local_sort, ONE slice per row */);
 void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, DevCount n_runs,
                   const uint32_t* tile_first_run, const uint32_t* row_span_lo, const uint32_t* row_span_cnt,
                   const uint64_t* span_key, const uint4* span_cov,

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(RC_THREADS) void k_runs_count(const uint64_t* __res
 // kernel at 112 us instead of 55); by the time the covers are summed and the style words requested they all have.  `status`
 // starts from zero; row_base[row] = where the row begins; the first workgroup of the grid only keeps house (runs_housekeeping).
 struct RunChain {
-    uint32_t*       status;       // one word per 2 048-segment tile, lookback.h's u32 layout
+    uint32_t*       status;       // one word per 2 048-segment tile, lookback.h's u32 layout (BLOCKS: the tile's paintable run heads)
     uint32_t*       row_base;     // tiles_h + 1 words
     uint64_t        spec_live44;  // runs_housekeeping's arguments
     uint32_t        spec_flags;
@@ -318,7 +318,14 @@ struct RunChain {
     const uint32_t* range_records;
     uint32_t        n_range_records;
 };
-template <bool CHAIN>
+// BLOCKS (MODE 2, round 6): no counting pass and no look-back either.  Runs are numbered per 2 048-SEGMENT TILE of this kernel:
+// the tile's first paintable head takes the index of the tile's first segment, the others follow densely (a run owns a segment:
+// the tiles' ranges cannot overlap; `records` and `run_lt` are then SPARSE arrays provisioned for N).  A tile leaves its head count in
+// `status[tile]` and the first head of a tile row its index in `row_base[row]`; k_carry_rows — one workgroup per row, which reads
+// every run of its row anyway — walks the row's tiles, copies the runs into the DENSE stream-order numbering the painters expect
+// (records[row_lo + e], row_lo = the runs of the rows above) and fills the first-run table.  What the counting pass cost — a second
+// read of the sorted stream, 20 us on the 4K scene — is gone; the price is one 32-byte copy per run inside the carry kernel.
+template <int MODE>
 __global__ __launch_bounds__(RW_THREADS) void k_runs_wave(const uint64_t* __restrict__ sorted, DevCount nc, uint32_t tiles_w,
                                                           uint32_t tiles_h, TileRecord* __restrict__ records, uint32_t rec_cap,
                                                           uint64_t* __restrict__ run_keys, uint32_t* __restrict__ tile_first_run,
@@ -327,18 +334,19 @@ __global__ __launch_bounds__(RW_THREADS) void k_runs_wave(const uint64_t* __rest
                                                           const uint32_t* __restrict__ run_counts, int counts_scanned,
                                                           const uint32_t* __restrict__ chunk_counts,
                                                           FrameInfo* __restrict__ info, RunStyle rs, RunChain ch) {
+    constexpr bool CHAIN = MODE == 1, BLOCKS = MODE == 2, OWN_HOUSE = MODE != 0;   // (OWN_HOUSE: no k_runs_count in front: the first workgroup keeps house)
     __shared__ RunWaveLds s_w[RW_WAVES];
     __shared__ uint32_t s_rows[RN_ROWS];
     __shared__ uint32_t s_jb[RW_WAVES];
-    __shared__ uint32_t s_ws[CHAIN ? RW_WAVES : 1][3];                  // CHAIN, per wave: heads | heads from its last row start on | that row start + 1 (0: none)
-    __shared__ uint32_t s_hk[CHAIN ? 5 : 1][RC_THREADS / 64];
+    __shared__ uint32_t s_ws[OWN_HOUSE ? RW_WAVES : 1][3];              // CHAIN, per wave: heads | heads from its last row start on | that row start + 1 (0: none); BLOCKS: heads
+    __shared__ uint32_t s_hk[OWN_HOUSE ? 5 : 1][RC_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t n = dev_count(nc);
-    if (CHAIN && blockIdx.x == 0) {                                     // (the FIRST workgroup: its round trips run beside the others' work)
+    if (OWN_HOUSE && blockIdx.x == 0) {                                 // (the FIRST workgroup: its round trips run beside the others' work)
         runs_housekeeping(true, n, nc, info, ch.spec_live44, ch.spec_flags, ch.pm, ch.range_records, ch.n_range_records, s_hk);
         return;
     }
-    const uint32_t tb = CHAIN ? blockIdx.x - 1u : blockIdx.x;           // this workgroup's 2 048-segment tile
+    const uint32_t tb = OWN_HOUSE ? blockIdx.x - 1u : blockIdx.x;       // this workgroup's 2 048-segment tile
     if ((uint64_t)tb * RN_TILE >= n) return;                           // whole workgroup: the grid was sized for the bound
     RunWaveLds& L = s_w[w];
     if (tid < RN_ROWS) s_rows[tid] = 0;
@@ -364,7 +372,7 @@ __global__ __launch_bounds__(RW_THREADS) void k_runs_wave(const uint64_t* __rest
     // every workgroup adds it up itself, which saves a scan launch; big frames get it pre-scanned).  Issued AFTER the segment
     // loads and eight loads at a time: a one-load-per-round-trip loop here was most of a workgroup's life.
     uint32_t jnext = 0;                                                 // dense index of the chunk's next paintable head
-    if (CHAIN) {}
+    if (OWN_HOUSE) {}
     else if (counts_scanned) jnext = run_counts[tb];
     else {
         uint32_t acc = 0;
@@ -379,7 +387,7 @@ __global__ __launch_bounds__(RW_THREADS) void k_runs_wave(const uint64_t* __rest
         for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
         if (lane == 0) s_jb[w] = acc;
     }
-    if (!CHAIN) {                                                       // + the heads of the tile's earlier chunks
+    if (!OWN_HOUSE) {                                                   // + the heads of the tile's earlier chunks
         uint32_t c = (lane < w) ? chunk_counts[(tb * RN_TILE >> 9) + lane] : 0u;           // w <= 3 loads
         c += __shfl_xor(c, 1, 64); c += __shfl_xor(c, 2, 64);
         jnext += (uint32_t)__builtin_amdgcn_readlane((int)c, 0);
@@ -438,6 +446,19 @@ __global__ __launch_bounds__(RW_THREADS) void k_runs_wave(const uint64_t* __rest
         }
         if (lane == 0) { s_ws[w][0] = tot; s_ws[w][1] = aft; s_ws[w][2] = rsp1; }
     }
+    if (BLOCKS) {
+        // the wave's paintable heads (breaks whose tile fields lie on the canvas: seg_paintable), from the registers of walk 1
+        uint32_t nh = 0;
+        if (chunk_n) {
+#pragma unroll
+            for (int q = 0; q < RW_SEGS; q++) {
+                const uint32_t tybq = hi[q] >> 21, txbq = (hi[q] >> 9) & 0xFFFu;
+                if (((bm >> q) & 1u) && tybq - 1u < tiles_h && txbq <= tiles_w) nh++;
+            }
+        }
+        const uint32_t tot = lb_wave_sum(nh);
+        if (lane == 0) s_ws[w][0] = tot;
+    }
     __syncthreads();
     uint32_t jrow = 0;                                                  // CHAIN: the next run index of the row the wave's next slot continues ...
     bool lb_pending = false, pfx_pending = false;                       // ... still without the heads of the tiles in front / the tile's PREFIX is this wave's to publish
@@ -474,6 +495,13 @@ __global__ __launch_bounds__(RW_THREADS) void k_runs_wave(const uint64_t* __rest
             for (int v = 0; v < RW_WAVES; v++) if (v < w) jrow += wt[v];
             if (w == RW_WAVES - 1 && ul < 0) { pfx_pending = true; pfx_add = jrow + wt[RW_WAVES - 1]; }   // (this wave completes the tile's status)
         }
+    } else if (BLOCKS) {
+        // the tile's first head takes the index of the tile's first segment; this wave's first one follows the heads of the waves in front
+        uint32_t heads = 0;
+        jnext = tb * RN_TILE;
+#pragma unroll
+        for (int v = 0; v < RW_WAVES; v++) { const uint32_t t = s_ws[v][0]; if (v < w) jnext += t; heads += t; }
+        if (tid == 0) ch.status[tb] = heads;
     } else if (!counts_scanned) {
 #pragma unroll
         for (int q = 0; q < RW_WAVES; q++) jnext += s_jb[q];
@@ -534,7 +562,7 @@ __global__ __launch_bounds__(RW_THREADS) void k_runs_wave(const uint64_t* __rest
 #pragma unroll
         for (int k = 0; k < 16; k++) b[k] = L.bins[lane * RN_STRIDE + k];
         const uint4 pb = pack_bins(b);                                  // the slot's cover sum, 16 x i8
-        if (!CHAIN) {
+        if (!CHAIN) {                                                   // (dense numbering, or BLOCKS: dense from the tile's first segment index)
             const uint32_t j = jnext + __builtin_amdgcn_mbcnt_hi((uint32_t)(bv >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bv, 0u));
             if (val) {
                 const uint32_t open = (sg == R && chunk_n == RW_CHUNK) ? RUN_OPEN : 0u;
@@ -544,9 +572,13 @@ __global__ __launch_bounds__(RW_THREADS) void k_runs_wave(const uint64_t* __rest
                     uint4* rp = reinterpret_cast<uint4*>(&records[j]);
                     rp[0] = pb;                                             // the run's own cover sum; k_carry_rows turns it into the carry-in
                     rp[1] = make_uint4(cbase + st, (st_next - st) | open, sw.x, sw.y);
-                    run_keys[j] = ((uint64_t)tyb << 53) | ((uint64_t)layer << 32) | j;
+                    if (!BLOCKS) run_keys[j] = ((uint64_t)tyb << 53) | ((uint64_t)layer << 32) | j;
                     rs.run_lt[j] = ((layer & 0xFFFFu) << 16) | (open ? RUN_LT_OPEN : 0u) | txb;
                 }
+                if (BLOCKS) {
+                    // (the first-run table is k_carry_rows' to fill, with dense indices) the first head of a tile row says where the row begins
+                    if ((ptile >> 12) != tyb || (cbase + st) == 0u) ch.row_base[tyb - 1u] = j;
+                } else
                 if (txb >= 1u && new_tile) tile_first_run[(tyb - 1u) * tiles_w + (txb - 1u)] = j + 1u;   // 0 = the tile has no run
                 const uint32_t rr = (tyb - 1u) - row0;
                 if (rr < RN_ROWS) atomicAdd(&s_rows[rr], 1u); else atomicAdd(&row_count[tyb - 1u], 1u);
@@ -613,7 +645,7 @@ void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t ti
                  uint32_t rec_cap, uint64_t* run_keys, uint32_t* tile_first_run, BlkEdge* blk_edge, uint32_t* row_tab,
                  uint32_t* scratch, FrameInfo* info, bool verify_plan, uint64_t spec_live44, bool spec_layer_sorted,
                  PendingMasks pm, RunStyle rs, bool tables_are_zero, const uint32_t* range_records, uint32_t n_range_records, int what,
-                 uint32_t* chain_row_base, bool chain_status_is_zero) {
+                 uint32_t* chain_row_base, bool chain_status_is_zero, bool blocks) {
     // per-frame tile tables: [row_count | row_span_lo | row_span_cnt | painter overflow counters (2) | first-run table] are
     // contiguous (api.cpp lays them out so) and start from zero — cleared by k_runs_count, unless an earlier kernel of the frame
     // already did (api.cpp folds that into the frame's first kernel); 0 in the first-run table = the tile has no run
@@ -630,12 +662,21 @@ void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t ti
     const uint32_t cgrid = std::min<uint32_t>((ntiles + 1) / 2, 4096u);
     uint32_t* chunk_counts = scratch + ntiles + 8;                      // 4 per tile (+ slack for the last wave's second half)
     const int scanned = ntiles > 16384 ? 1 : 0;
+    if (chain_row_base && blocks) {
+        // no counting pass and no look-back (k_runs_wave<2>): runs numbered per 2 048-segment tile, `records` / rs.run_lt are the SPARSE
+        // arrays (n.bound entries), the head of `scratch` takes the tiles' head counts (every tile of the stream writes its own)
+        if (zero_words) (void)hipMemsetAsync(row_tab, 0, (size_t)zero_words * 4, s);
+        FORMA_LAUNCH(k_runs_wave<2>, dim3(ntiles + 1), dim3(RW_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, records, rec_cap,
+                           run_keys, tile_first_run, blk_edge, row_tab, (const uint32_t*)nullptr, 0, (const uint32_t*)nullptr, info, rs,
+                           RunChain{scratch, chain_row_base, spec_live44, flags, pm, range_records, n_range_records});
+        return;
+    }
     if (chain_row_base) {
-        // no counting pass (k_runs_wave<true>): the tables and the tiles' status words (the head of `scratch`) are cleared by an
+        // no counting pass (k_runs_wave<1>): the tables and the tiles' status words (the head of `scratch`) are cleared by an
         // earlier kernel of the frame or by two memsets here; one more workgroup (the first) keeps house
         if (zero_words) (void)hipMemsetAsync(row_tab, 0, (size_t)zero_words * 4, s);
         if (!chain_status_is_zero) (void)hipMemsetAsync(scratch, 0, (size_t)ntiles * 4, s);
-        FORMA_LAUNCH(k_runs_wave<true>, dim3(ntiles + 1), dim3(RW_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, records, rec_cap,
+        FORMA_LAUNCH(k_runs_wave<1>, dim3(ntiles + 1), dim3(RW_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, records, rec_cap,
                            run_keys, tile_first_run, blk_edge, row_tab, (const uint32_t*)nullptr, 0, (const uint32_t*)nullptr, info, rs,
                            RunChain{scratch, chain_row_base, spec_live44, flags, pm, range_records, n_range_records});
         return;
@@ -646,7 +687,7 @@ void launch_runs(hipStream_t s, const uint64_t* sorted, DevCount nc, uint32_t ti
         if (scanned) launch_scan_small_u32(s, scratch, nc, RN_TILE, &info->n_runs);   // exclusive, in place; total -> n_runs
     }
     if (what & 2)
-        FORMA_LAUNCH(k_runs_wave<false>, dim3(ntiles), dim3(RW_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, records, rec_cap,
+        FORMA_LAUNCH(k_runs_wave<0>, dim3(ntiles), dim3(RW_THREADS), 0, s, sorted, nc, tiles_w, tiles_h, records, rec_cap,
                            run_keys, tile_first_run, blk_edge, row_tab, (const uint32_t*)scratch, scanned,
                            (const uint32_t*)chunk_counts, info, rs, RunChain{nullptr, nullptr, 0ull, 0u, PendingMasks{nullptr, 0u}, nullptr, 0u});
 }
@@ -793,7 +834,8 @@ __global__ __launch_bounds__(TH, TH == 512 ? (COVL ? 4 : CR_HALF_OCC) : (CAP == 
                                                            uint32_t cull /* PaintParams::cull: the group lists leave out what an occluder of the whole group hides */,
                                                            uint32_t left_start /* see below; 0xFFFFFFFF: off */,
                                                            const uint32_t* __restrict__ row_base /* nullable: where each row's runs begin
-                                                           (launch_runs' chain numbering); else the rows' runs are dense in row order */) {
+                                                           (launch_runs' chain numbering); else the rows' runs are dense in row order */,
+                                                           BlkRuns bk /* rec_sp != nullptr: the run kernel numbered per 2 048-segment tile (below) */) {
     constexpr int CR_RPT = RPT;                        // consecutive runs of the (layer, tile_x) order per lane in the row walk
     constexpr int CR_PIECE = TH * RPT;         // runs per piece
     constexpr bool NB_IN_IDLE = LOCAL && !COVL && 2 * (CR_PIECE + 1) <= CAP;   // group / tile_x of a piece's runs live in the sort's idle buffer
@@ -841,9 +883,11 @@ __global__ __launch_bounds__(TH, TH == 512 ? (COVL ? 4 : CR_HALF_OCC) : (CAP == 
     const uint32_t n_blk = (dev_count(nc_segments) + edge_segs - 1) / edge_segs;   // BlkEdge entries (one per edge_segs segments)
     // first run of this row = sum of the run counts of the rows above
     uint32_t part = 0;
-    if (row_base) { if (tid == 0) part = row_count[ty] ? row_base[ty] : 0u; }   // (a row without runs has no entry)
+    const bool blocks = LOCAL && bk.rec_sp != nullptr;                  // (uniform; one slice per row: the host's condition)
+    if (row_base && !blocks) { if (tid == 0) part = row_count[ty] ? row_base[ty] : 0u; }   // (a row without runs has no entry)
     else for (uint32_t r = tid; r < ty; r += TH) part += row_count[r];
     const uint32_t cnt = row_count[ty];
+    const uint32_t row_sp = (blocks && cnt) ? bk.row_base[ty] : 0u;     // BLOCKS: the row's first run in the sparse numbering
     if (plan_bad) return;
     if (runs_dev > nc_runs.bound) {                                     // more runs than provisioned: the frame is void, and
         if (threadIdx.x == 0) info->plan_bad = 1u;                      // the painters (next launches) must not touch anything
@@ -860,6 +904,57 @@ __global__ __launch_bounds__(TH, TH == 512 ? (COVL ? 4 : CR_HALF_OCC) : (CAP == 
     for (int i = 0; i < (TH / 64); i++) row_lo += s_red[i];
     const uint32_t* lkeys = s_ka;                        // LOCAL: the slice's runs, ordered by (layer, tile_x)
     if (tid == 0 && cnt && slice == 0) atomicMax(&info->max_row_runs, cnt);
+    if (LOCAL && blocks) {
+        // ---- BLOCKS: the run kernel numbered the runs per 2 048-segment tile b — [2048 b, 2048 b + heads[b]) — without knowing how
+        //      many heads lie in front of a tile.  This row's runs are cnt consecutive ones of that sparse order from row_sp on: they
+        //      are copied into the dense stream-order numbering [row_lo, row_lo + cnt) every later step (and the painters) use —
+        //      32 + 4 bytes per run, coalesced on both sides, by the one workgroup that reads every run of the row anyway.  256 tiles
+        //      per round: a lane per tile scans the head counts, then a wave per tile copies.  (s_group / s_gcnt / s_gpre are idle.)
+        if (row_lo + cnt > n_runs) { if (tid == 0) info->plan_bad = 1u; return; }       // (more runs than provisioned: the host re-runs)
+        const uint32_t n_tiles2k = (dev_count(nc_segments) + RN_TILE - 1u) / RN_TILE;
+        const uint32_t b0 = row_sp / RN_TILE, o0 = row_sp % RN_TILE;
+        uint32_t done = 0;
+        __syncthreads();                                                                // (s_red: every lane has its row_lo)
+        for (uint32_t bb = b0; done < cnt; bb += 256u) {
+            if (bb >= n_tiles2k) { if (tid == 0) info->plan_bad = 1u; return; }         // (uniform: the counts do not add up)
+            uint32_t avail = 0;
+            if (tid < 256) {
+                const uint32_t b = bb + (uint32_t)tid;
+                if (b < n_tiles2k) { const uint32_t h = bk.heads[b]; const uint32_t skip = b == b0 ? o0 : 0u; avail = h > skip ? h - skip : 0u; }
+            }
+            uint32_t inc = wave_incl_scan_u32(avail);
+            if (tid < 256 && lane == 63) s_red[w] = inc;
+            __syncthreads();
+            if (tid < 256) {
+                for (int i = 0; i < w; i++) inc += s_red[i];
+                const uint32_t ex = inc - avail, left = cnt - done;
+                const uint32_t take = ex >= left ? 0u : min(avail, left - ex);
+                s_group[tid] = done + ex;                                               // dense offset of the tile's first run in the row
+                s_gcnt[tid] = (bb + (uint32_t)tid) * RN_TILE + ((bb + (uint32_t)tid) == b0 ? o0 : 0u);   // its sparse index
+                s_gpre[tid] = take;
+            }
+            __syncthreads();
+            const uint32_t batch = min(cnt - done, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
+            for (uint32_t t = (uint32_t)w; t < 256u; t += (uint32_t)(TH / 64)) {
+                const uint32_t take = s_gpre[t];
+                if (!take) continue;                                                    // (wave-uniform)
+                const uint32_t d0 = row_lo + s_group[t], sp0 = s_gcnt[t];
+                for (uint32_t i = (uint32_t)lane; i < take; i += 64u) {
+                    const uint4* sp = reinterpret_cast<const uint4*>(&bk.rec_sp[sp0 + i]);
+                    const uint4 c0 = sp[0], c1 = sp[1];
+                    const uint32_t lt = bk.run_lt_sp[sp0 + i];
+                    uint4* dp = reinterpret_cast<uint4*>(&records[d0 + i]);
+                    dp[0] = c0; dp[1] = c1;
+                    bk.run_lt_out[d0 + i] = lt;
+                }
+            }
+            done += batch;
+            __syncthreads();                                                            // (the tables are rewritten by the next round)
+        }
+        __threadfence_block();
+        __syncthreads();                                                                // the row's dense records are this workgroup's own writes
+    }
+    if (LOCAL && blocks && tid == 0) bk.row_base[ty] = row_lo;          // (read above, as row_sp) what the painters bound a row's probes by: dense from here on
     uint32_t m = cnt;                                    // runs of this slice
     uint32_t off = 0;                                    // runs of the row in the slices before it (= its first span slot)
     uint32_t kbase = row_lo;                             // !LOCAL: first sorted key of the slice
@@ -1079,6 +1174,13 @@ __global__ __launch_bounds__(TH, TH == 512 ? (COVL ? 4 : CR_HALF_OCC) : (CAP == 
         s_txo = reinterpret_cast<uint16_t*>(NB_IN_IDLE ? idle + (CR_PIECE + 1) + (CR_PIECE + 4) / 2 : idle);
         for (uint32_t e = tid; e < cnt; e += TH) s_txo[e] = (uint16_t)run_lt[row_lo + e];
         __syncthreads();
+        if (blocks) {
+            // the first-run table (0 = the tile has no run): a run whose tile column differs from its predecessor's begins a tile
+            for (uint32_t e = tid; e < cnt; e += TH) {
+                const uint32_t tx = (uint32_t)s_txo[e] & 0xFFFu, px = e ? ((uint32_t)s_txo[e - 1] & 0xFFFu) : 0xFFFFu;
+                if (tx >= 1u && tx != px) bk.tile_first_run[ty * tiles_w + (tx - 1u)] = row_lo + e + 1u;
+            }
+        }
     }
     static_assert(!NB_IN_IDLE || (CR_PIECE + 1) + (CR_PIECE + 4) / 2 + CAP / 2 <= CAP, "group / tile_x / digest arrays share the idle sort buffer");
     for (uint32_t c0 = 0; c0 < m; c0 += CR_PIECE) {
@@ -1342,15 +1444,16 @@ void launch_carry_rows(hipStream_t s, bool local_sort, bool small, bool half, ui
                        uint32_t n_orders, uint32_t tiles_w, uint32_t tiles_h, const uint32_t* row_count,
                        uint32_t* row_span_lo, uint32_t* row_span_cnt, uint64_t* span_key, uint4* span_cov,
                        const uint8_t* unchanged, FrameInfo* info, uint32_t edge_segs, uint32_t vis_last, uint32_t row0, uint32_t row1,
-                       SpanGroups groups, const uint32_t* run_lt, bool cull, uint32_t left_start, const uint32_t* row_base, bool covl) {
+                       SpanGroups groups, const uint32_t* run_lt, bool cull, uint32_t left_start, const uint32_t* row_base, bool covl, BlkRuns bk) {
     row1 = row1 < tiles_h ? row1 : tiles_h;
     if (tiles_h == 0 || row0 >= row1) return;             // (only the tile rows that are painted: the others' carries are never read)
     if (n_slices < 1u) n_slices = 1u;
     if (n_slices > CR_MAX_SLICES) n_slices = CR_MAX_SLICES;
     const dim3 grid((row1 - row0) * n_slices);
+    if (bk.rec_sp && (!local_sort || n_slices != 1u)) bk = BlkRuns{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // (the caller's condition)
 #define CR_LAUNCH(L, C, R, T_, ...) FORMA_LAUNCH((k_carry_rows<L, C, R, T_ __VA_OPT__(,) __VA_ARGS__>), grid, dim3(T_), 0, s, sorted_run_keys, records, blk_edge, n_segments, \
                                               n_runs, layer_sf, n_orders, tiles_w, tiles_h, row_count, row_span_lo, row_span_cnt, span_key, \
-                                              span_cov, unchanged, info, edge_segs, vis_last, n_slices, bin_shift, row0, groups, run_lt, cull ? 1u : 0u, left_start, row_base)
+                                              span_cov, unchanged, info, edge_segs, vis_last, n_slices, bin_shift, row0, groups, run_lt, cull ? 1u : 0u, left_start, row_base, bk)
     if (!local_sort) CR_LAUNCH(false, CR_CAP, 4, CR_THREADS);
     else if (small && half && covl && n_slices == 1u) CR_LAUNCH(true, CR_CAP_H, 4, CR_THREADS_H, true);
     else if (small && half) CR_LAUNCH(true, CR_CAP_H, 4, CR_THREADS_H);
