@@ -476,8 +476,19 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     // BLOCKS (launch_runs, k_carry_rows): a read-back-free frame whose tile rows take ONE carry workgroup each needs neither the counting
     // pass nor the chain: the run kernel numbers per 2 048-segment tile into sparse arrays and the row's workgroup compacts them.
     const uint32_t ns_final = ctx->force_slices ? std::min<uint32_t>(ctx->force_slices, CR_MAX_SLICES_HOST) : n_slices;
-    const bool blk = bound_j != 0 && n > 0 && !chain && local_sort && ns_final == 1u && n <= 0x3FFFFFFFull &&
-                     (ctx->dbg.runs_blk < 0 ? RUNS_BLK_DEFAULT != 0 : ctx->dbg.runs_blk != 0);
+    // (... and takes a COVL variant of the carry kernel — decided below, from the same predictions)
+    auto covl_choice = [&](uint32_t slices) {
+        const uint32_t mxr = ctx->pred_max_row;
+        const bool big = !small && !half && mxr != 0xFFFFFFFFu &&
+                         (bound_j ? !ctx->covl_banned && (uint64_t)mxr + mxr / 64u <= carry_rows_covl_cap() : mxr <= carry_rows_covl_cap());
+        return local_sort && slices == 1u && ctx->dbg.carry_covl != 0 && (big || (small && half && (ctx->dbg.carry_covl & 2) == 0));
+    };
+    // Measured (profiles/r06_experiments.txt, r6n-r6v): the 4K scene (135 heavy rows, a CU each) runs + carry 112.8 -> 94.1 us, frames/s per
+    // call +3.9 %, three slots +3.8 %; the 8K triangle scene (512 light rows, two workgroups per CU) 72 -> 73 us — the head counts are one
+    // more dependent round trip at the start of k_carry_rows, and with every workgroup of a full chip asking at once that costs what
+    // the counting pass did: by default only for frames of at most one carry workgroup per CU.
+    const bool blk = bound_j != 0 && n > 0 && !chain && covl_choice(ns_final) && n <= 0x3FFFFFFFull &&
+                     (ctx->dbg.runs_blk < 0 ? (RUNS_BLK_DEFAULT != 0 && rows_painted <= (uint32_t)ctx->n_cus) : ctx->dbg.runs_blk != 0);
     if (bound_j) {
         jc = chain ? DevCount{nullptr, (uint32_t)n} : (blk ? DevCount{nullptr, bound_j} : DevCount{&dinfo->n_runs, bound_j});   // (chain: run indices are segment indices; blk: dense, counted by nobody before the tail)
         if (chain || blk) { ctx->chain_rows = row_count; ctx->n_chain_rows = tiles_h; }
@@ -495,7 +506,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                     RunStyle{ctx->layer_sf.as<uint32_t>(), (uint32_t)ctx->n_orders,
                              (a.cache_id >= 0 && ctx->have_unchanged) ? ctx->unchanged.as<uint8_t>() : nullptr,
                              blk ? ctx->run_lt_sp.as<uint32_t>() : ctx->run_lt.as<uint32_t>()},
-                    tables_zero, ctx->sort_range, ctx->sort_range_n, what, (chain || blk) ? row_base : nullptr, chain_zero, blk);
+                    tables_zero, ctx->sort_range, ctx->sort_range_n, what, chain ? row_base : (blk ? ctx->row_sp.as<uint32_t>() : nullptr), chain_zero, blk);
     };
     if (!bound_j && n > 0) {
         runs(1);
@@ -518,6 +529,7 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     if (blk) {                                                          // (the sparse arrays: indexed like the segments)
         HIPCHECK(ctx->rec_sp.ensure(std::max<size_t>(n, 1) * sizeof(TileRecord)));
         HIPCHECK(ctx->run_lt_sp.ensure(std::max<size_t>(n, 1) * 4));
+        HIPCHECK(ctx->row_sp.ensure(((size_t)tiles_h + 1) * 4));
     }
     runs(bound_j || n == 0 ? 3 : 2);
     ctx->sort_range = nullptr;
@@ -581,12 +593,9 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
         // and style summaries in LDS before the walk.  A read-back-free frame guesses from the last verified frame's heaviest row
         // (6 % head-room); a row beyond the cap voids the frame and the synchronous re-run knows the rows.
         {
-            const uint32_t mxr = bound_j ? ctx->pred_max_row : ctx->pred_max_row;      // (both paths have set pred_max_row by now, or left it unknown)
             // (the 512-lane variant for light rows in one slice — the 8K triangle scene — has the room as well: 32 KB of covers, two
             //  workgroups per CU instead of three, still one round for 512 rows)
-            const bool big = !small && !half && mxr != 0xFFFFFFFFu &&
-                             (bound_j ? !ctx->covl_banned && (uint64_t)mxr + mxr / 64u <= carry_rows_covl_cap() : mxr <= carry_rows_covl_cap());
-            covl = local_sort && n_slices == 1u && ctx->dbg.carry_covl != 0 && (big || (small && half && (ctx->dbg.carry_covl & 2) == 0));
+            covl = covl_choice(n_slices);
             ctx->covl_tried = covl && bound_j != 0;
         }
     } else {
@@ -676,9 +685,10 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                           cull,
                           (a.cache_id >= 0 || !fold_equals_paint) ? (a.crop ? a.crop->x0 / 16 : 0u) : 0xFFFFFFFFu,
                           chain ? row_base : nullptr, covl,
-                          blk ? BlkRuns{ctx->rec_sp.as<TileRecord>(), ctx->run_lt_sp.as<uint32_t>(), ctx->runs_scratch.as<uint32_t>(), row_base,
-                                        tile_first_run, ctx->run_lt.as<uint32_t>()}
-                              : BlkRuns{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
+                          blk ? BlkRuns{ctx->rec_sp.as<TileRecord>(), ctx->run_lt_sp.as<uint32_t>(), ctx->runs_scratch.as<uint32_t>(),
+                                        ctx->row_sp.as<uint32_t>(), row_base, tile_first_run, ctx->run_lt.as<uint32_t>(),
+                                        (uint32_t)ctx->dbg.blk_round}
+                              : BlkRuns{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 256u});
     stage_end(ctx, ST_CARRY, timing);
     stage_begin(ctx, ST_PAINT, timing);
     launch_paint(ctx->stream, P, ctx->sorted, ctx->records.as<TileRecord>(), jc, tile_first_run, row_span_lo,
@@ -1014,7 +1024,7 @@ void forma_hip_destroy(forma_hip_ctx* ctx) {
                      &ctx->blk_edge, &ctx->runs_scratch, &ctx->row_tab, &ctx->span_key, &ctx->span_cov,
                      &ctx->image, &ctx->xsend, &ctx->xrecv, &ctx->xscratch,
                      &ctx->ras_masks, &ctx->xmask, &ctx->huge_offs, &ctx->huge_key, &ctx->huge_tmp, &ctx->huge_flag,
-                     &ctx->grp_tab, &ctx->grp_list, &ctx->run_lt, &ctx->rec_sp, &ctx->run_lt_sp, &ctx->pack_list, &ctx->pack_pix, &ctx->cache_written, &ctx->order_buf};
+                     &ctx->grp_tab, &ctx->grp_list, &ctx->run_lt, &ctx->rec_sp, &ctx->run_lt_sp, &ctx->row_sp, &ctx->pack_list, &ctx->pack_pix, &ctx->cache_written, &ctx->order_buf};
     for (DevBuf* b : all) b->release();
     for (int s = 0; s < ST_COUNT; s++) { (void)hipEventDestroy(ctx->ev0[s]); (void)hipEventDestroy(ctx->ev1[s]); }
     if (g_ktimer == &ctx->kt) g_ktimer = nullptr;           // (a timed frame of this context that failed between stage_begin and stage_end)
@@ -1330,7 +1340,7 @@ int poison_frame_buffers(forma_hip_ctx* c) {
     DevBuf* frame[] = {&c->scan_tmp, &c->cl_idx, &c->cl_start, &c->block_first, &c->prep_scratch, &c->seg_u, &c->seg_a, &c->seg_b,
                        &c->sort_counters, &c->records, &c->rk_u, &c->rk_a, &c->rk_b, &c->blk_edge, &c->runs_scratch, &c->row_tab,
                        &c->span_key, &c->span_cov, &c->ras_masks, &c->huge_offs, &c->huge_key, &c->huge_tmp, &c->huge_flag,
-                       &c->grp_tab, &c->grp_list, &c->run_lt, &c->rec_sp, &c->run_lt_sp, &c->pack_list, &c->pack_pix};
+                       &c->grp_tab, &c->grp_list, &c->run_lt, &c->rec_sp, &c->run_lt_sp, &c->row_sp, &c->pack_list, &c->pack_pix};
     for (DevBuf* b : frame) if (b->p && !b->borrowed) HIPCHECK(hipMemsetAsync(b->p, byte, b->cap, c->stream));
     return FORMA_OK;
 }
@@ -1668,7 +1678,7 @@ int forma_hip_trim(forma_hip_ctx* ctx) {
                            &c->scan_tmp, &c->cl_idx, &c->cl_start, &c->block_first, &c->prep_scratch, &c->seg_u, &c->seg_a, &c->seg_b,
                            &c->sort_counters, &c->records, &c->rk_u, &c->rk_a, &c->rk_b, &c->blk_edge, &c->runs_scratch, &c->row_tab,
                            &c->span_key, &c->span_cov, &c->image, &c->xscratch, &c->ras_masks, &c->xmask,
-                           &c->huge_offs, &c->huge_key, &c->huge_tmp, &c->huge_flag, &c->grp_tab, &c->grp_list, &c->run_lt, &c->rec_sp, &c->run_lt_sp, &c->pack_list, &c->pack_pix,
+                           &c->huge_offs, &c->huge_key, &c->huge_tmp, &c->huge_flag, &c->grp_tab, &c->grp_list, &c->run_lt, &c->rec_sp, &c->run_lt_sp, &c->row_sp, &c->pack_list, &c->pack_pix,
                            &c->order_buf};
         c->order_cur = -1; c->order_pending = -1; c->order_cnt_dev = nullptr; c->order_keep_dev = nullptr;
         size_t freed = 0;

@@ -314,15 +314,18 @@ struct RunStyle {
     uint32_t*       run_lt;       // one word per run (rec_cap)
 };
 #define RUN_LT_OPEN 0x8000u
+#define RUN_LT_NEWTILE 0x4000u          // BLOCKS numbering only: the run is the first of its tile
 // launch_runs' BLOCKS numbering (round 6; paint.hip): the run kernel wrote SPARSE records / digests — tile b of 2 048 segments owns
 // [2048 b, 2048 b + heads[b]) — and k_carry_rows copies every row's runs into the dense arrays.  rec_sp == nullptr: not this frame.
 struct BlkRuns {
     const TileRecord* rec_sp;       // n.bound records, sparse
     const uint32_t*   run_lt_sp;    // n.bound digests, sparse
     const uint32_t*   heads;        // paintable run heads per 2 048-segment tile (the head of launch_runs' `scratch`)
-    uint32_t*         row_base;     // in: index of the row's first run in the sparse numbering; out: in the dense one (PaintParams::row_base)
+    const uint32_t*   row_sp;       // index of each row's first run in the sparse numbering (launch_runs' chain_row_base of that frame)
+    uint32_t*         row_base_out; // ... in the dense one, written by the row's workgroup (PaintParams::row_base)
     uint32_t*         tile_first_run;
-    uint32_t*         run_lt_out;   // the dense digests (= k_carry_rows' run_lt)
+    uint32_t*         run_lt_out;   // (unused: the dense digests)
+    uint32_t          round_tiles;  // tiles of the run kernel a round of k_carry_rows' table takes: 256 (tests: a power of two below)
 };
 // tables_are_zero: the frame's tile tables (row_tab_zero_words() words of row_tab) were cleared by an earlier kernel of this
 // frame; else k_runs_count clears them
@@ -430,7 +433,7 @@ void launch_carry_rows(hipStream_t s, bool local_sort, bool small, bool half /* 
                        const uint32_t* row_base = nullptr /* launch_runs' chain numbering: where each row's runs begin */,
                        bool covl = false /* one slice per row, rows of <= carry_rows_covl_cap() runs, neither small nor half: the variant that
                                             brings the row's cover sums and style summaries into LDS before the walk */,
-                       BlkRuns bk = BlkRuns{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr} /* local_sort, ONE slice per row */);
+                       BlkRuns bk = BlkRuns{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 256u} /* a COVL variant: local_sort, ONE slice per row */);
 void launch_paint(hipStream_t s, const PaintParams& p, const uint64_t* sorted, const TileRecord* records, DevCount n_runs,
                   const uint32_t* tile_first_run, const uint32_t* row_span_lo, const uint32_t* row_span_cnt,
                   const uint64_t* span_key, const uint4* span_cov,

@@ -56,7 +56,7 @@ struct forma_hip_ctx {
     bool any_texture = false;
     bool scene_has_clips = false;
     DevBuf run_lt;                  // one word per run: layer16 | open | tile_x + 1 (RunStyle, common.h)
-    DevBuf rec_sp, run_lt_sp;       // launch_runs' BLOCKS numbering (BlkRuns, common.h): records and digests indexed like the segments (N entries)
+    DevBuf rec_sp, run_lt_sp, row_sp;       // launch_runs' BLOCKS numbering (BlkRuns, common.h): records and digests indexed like the segments (N entries)
     DevBuf grp_tab, grp_list;       // span group lists (SpanGroups, common.h): table per (row, slice, group) and the entry pool
     bool no_span_groups = false;    // FORMA_HIP_DEBUG=no_span_groups (A/B switch for tools/)
     bool force_span_groups = false; // FORMA_HIP_DEBUG=span_groups: on every frame and for every row, however few spans (tests)

@@ -95,6 +95,9 @@ __device__ __forceinline__ bool cover_full(const uint32_t* c, bool even_odd) {  
 // the radix sort's 840 x 16384 keys — not 6720 short ones.)
 // ================================================================================================
 #define RN_TILE    2048                 // segments per workgroup of the run kernel (4 waves x RW_CHUNK)
+#ifndef BLK_STRIDE
+#define BLK_STRIDE RN_TILE              // BLOCKS numbering: index range a tile of the run kernel owns (experiments: a smaller stride = a smaller footprint)
+#endif
 #define RN_STRIDE  17                   // words per slot: 16 bins + 1 pad (bank spread)
 #define RUN_OPEN   0x80000000u          // seg_count flag: the run continues past its wave's chunk
 #define RN_ROWS    64                   // tile rows a workgroup aggregates in LDS before touching row_count[]
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(RW_THREADS) void k_runs_wave(const uint64_t* __rest
     } else if (BLOCKS) {
         // the tile's first head takes the index of the tile's first segment; this wave's first one follows the heads of the waves in front
         uint32_t heads = 0;
-        jnext = tb * RN_TILE;
+        jnext = tb * BLK_STRIDE;
 #pragma unroll
         for (int v = 0; v < RW_WAVES; v++) { const uint32_t t = s_ws[v][0]; if (v < w) jnext += t; heads += t; }
         if (tid == 0) ch.status[tb] = heads;
@@ -573,7 +576,7 @@ __global__ __launch_bounds__(RW_THREADS) void k_runs_wave(const uint64_t* __rest
                     rp[0] = pb;                                             // the run's own cover sum; k_carry_rows turns it into the carry-in
                     rp[1] = make_uint4(cbase + st, (st_next - st) | open, sw.x, sw.y);
                     if (!BLOCKS) run_keys[j] = ((uint64_t)tyb << 53) | ((uint64_t)layer << 32) | j;
-                    rs.run_lt[j] = ((layer & 0xFFFFu) << 16) | (open ? RUN_LT_OPEN : 0u) | txb;
+                    rs.run_lt[j] = ((layer & 0xFFFFu) << 16) | (open ? RUN_LT_OPEN : 0u) | ((BLOCKS && new_tile) ? RUN_LT_NEWTILE : 0u) | txb;
                 }
                 if (BLOCKS) {
                     // (the first-run table is k_carry_rows' to fill, with dense indices) the first head of a tile row says where the row begins
@@ -883,11 +886,19 @@ __global__ __launch_bounds__(TH, TH == 512 ? (COVL ? 4 : CR_HALF_OCC) : (CAP == 
     const uint32_t n_blk = (dev_count(nc_segments) + edge_segs - 1) / edge_segs;   // BlkEdge entries (one per edge_segs segments)
     // first run of this row = sum of the run counts of the rows above
     uint32_t part = 0;
-    const bool blocks = LOCAL && bk.rec_sp != nullptr;                  // (uniform; one slice per row: the host's condition)
+    const bool blocks = COVL && bk.rec_sp != nullptr;                   // (uniform; a COVL variant, one slice per row: the host's condition)
     if (row_base && !blocks) { if (tid == 0) part = row_count[ty] ? row_base[ty] : 0u; }   // (a row without runs has no entry)
     else for (uint32_t r = tid; r < ty; r += TH) part += row_count[r];
     const uint32_t cnt = row_count[ty];
-    const uint32_t row_sp = (blocks && cnt) ? bk.row_base[ty] : 0u;     // BLOCKS: the row's first run in the sparse numbering
+    // BLOCKS: the row's first run in the sparse numbering (an entry nobody wrote — a row without runs — is not used), and the head
+    // counts of the 256 tiles from there on: requested HERE, behind the first round of loads, not behind the barriers below
+    const uint32_t row_sp = blocks ? bk.row_sp[ty] : 0u;
+    uint32_t blk_avail0 = 0;
+    const uint32_t blk_round = bk.round_tiles;                          // (256; tests: fewer, so that small rows take several rounds)
+    if (COVL && blocks && (uint32_t)tid < blk_round) {
+        const uint32_t nt2k = (dev_count(nc_segments) + RN_TILE - 1u) / RN_TILE, b = row_sp / BLK_STRIDE + (uint32_t)tid;
+        if (b < nt2k) { const uint32_t h = bk.heads[b]; const uint32_t skip = tid == 0 ? row_sp % BLK_STRIDE : 0u; blk_avail0 = h > skip ? h - skip : 0u; }
+    }
     if (plan_bad) return;
     if (runs_dev > nc_runs.bound) {                                     // more runs than provisioned: the frame is void, and
         if (threadIdx.x == 0) info->plan_bad = 1u;                      // the painters (next launches) must not touch anything
@@ -904,57 +915,62 @@ __global__ __launch_bounds__(TH, TH == 512 ? (COVL ? 4 : CR_HALF_OCC) : (CAP == 
     for (int i = 0; i < (TH / 64); i++) row_lo += s_red[i];
     const uint32_t* lkeys = s_ka;                        // LOCAL: the slice's runs, ordered by (layer, tile_x)
     if (tid == 0 && cnt && slice == 0) atomicMax(&info->max_row_runs, cnt);
-    if (LOCAL && blocks) {
-        // ---- BLOCKS: the run kernel numbered the runs per 2 048-segment tile b — [2048 b, 2048 b + heads[b]) — without knowing how
-        //      many heads lie in front of a tile.  This row's runs are cnt consecutive ones of that sparse order from row_sp on: they
-        //      are copied into the dense stream-order numbering [row_lo, row_lo + cnt) every later step (and the painters) use —
-        //      32 + 4 bytes per run, coalesced on both sides, by the one workgroup that reads every run of the row anyway.  256 tiles
-        //      per round: a lane per tile scans the head counts, then a wave per tile copies.  (s_group / s_gcnt / s_gpre are idle.)
-        if (row_lo + cnt > n_runs) { if (tid == 0) info->plan_bad = 1u; return; }       // (more runs than provisioned: the host re-runs)
+    // ---- BLOCKS: the run kernel numbered the runs per 2 048-segment tile b — [2048 b, 2048 b + heads[b]) — without knowing how many
+    //      heads lie in front of a tile.  This row's runs are cnt consecutive ones of that sparse order from row_sp on; run e of the
+    //      row (stream order) has the dense index row_lo + e every later step and the painters use.  A lane owns the runs
+    //      e = r TH + tid like the loads below always did; where run e lies in the sparse arrays — blk_j[r] — comes from the head
+    //      counts of the row's tiles: a lane per tile scans them (256 tiles per round: a 4K row spans ~50), every lane then finds its
+    //      runs' tiles by binary search.  The digests (in front of the sort) and the cover sums (behind it) are loaded from there in
+    //      one round of independent loads each, as before; the records' second halves go to their dense places on the way, with the
+    //      segment count of a run that crosses its chunk made whole, and the first run of a tile enters the first-run table.
+    //      (First form: whole records copied in front of everything else, a wave per tile — each of its steps a round trip of its
+    //      own: k_carry_rows 44.6 -> 58.5 us on the 4K scene.  Second: the copies by a helper workgroup per row, the loads still a
+    //      wave per tile: 56 us, and the 8K scene's 512 helpers made a second round of workgroups: 28.5 -> 46.  This form: 50-51 us
+    //      on the 4K scene — the head counts are one more dependent round trip in front of everything, 13 k clocks per row with the
+    //      scan and the search — for the 20.6 us of k_runs_count and 4 of k_runs_wave.  On the 8K triangle scene, 512 rows of light
+    //      work on two workgroups per CU, the same round trip costs 30 k clocks at the start of a launch whose every workgroup asks at
+    //      once: 28 -> 46 us, all that the counting pass cost — the host keeps the counting pass for frames of more rows than CUs.)
+    uint32_t blk_j[COVL ? KPL : 1];
+    if (COVL && blocks) {
+        if (row_lo + cnt > n_runs || cnt > (uint32_t)CAP) { if (tid == 0) info->plan_bad = 1u; return; }   // (more runs than provisioned / than this variant holds: the host re-runs)
+        if (tid == 0) bk.row_base_out[ty] = row_lo;                     // what the painters bound a row's probes by (PaintParams::row_base)
         const uint32_t n_tiles2k = (dev_count(nc_segments) + RN_TILE - 1u) / RN_TILE;
-        const uint32_t b0 = row_sp / RN_TILE, o0 = row_sp % RN_TILE;
+        const uint32_t b0 = row_sp / BLK_STRIDE, o0 = row_sp % BLK_STRIDE;
+#pragma unroll
+        for (int r = 0; r < (COVL ? KPL : 1); r++) blk_j[r] = 0;
         uint32_t done = 0;
-        __syncthreads();                                                                // (s_red: every lane has its row_lo)
-        for (uint32_t bb = b0; done < cnt; bb += 256u) {
-            if (bb >= n_tiles2k) { if (tid == 0) info->plan_bad = 1u; return; }         // (uniform: the counts do not add up)
-            uint32_t avail = 0;
-            if (tid < 256) {
+        __syncthreads();                                                // (s_red: every lane has its row_lo)
+        for (uint32_t bb = b0; done < cnt; bb += blk_round) {
+            if (bb >= n_tiles2k) { if (tid == 0) info->plan_bad = 1u; return; }     // (uniform: the counts do not add up)
+            uint32_t avail = blk_avail0;
+            if ((uint32_t)tid < blk_round && bb != b0) {
                 const uint32_t b = bb + (uint32_t)tid;
-                if (b < n_tiles2k) { const uint32_t h = bk.heads[b]; const uint32_t skip = b == b0 ? o0 : 0u; avail = h > skip ? h - skip : 0u; }
+                avail = b < n_tiles2k ? bk.heads[b] : 0u;
             }
             uint32_t inc = wave_incl_scan_u32(avail);
             if (tid < 256 && lane == 63) s_red[w] = inc;
             __syncthreads();
             if (tid < 256) {
                 for (int i = 0; i < w; i++) inc += s_red[i];
-                const uint32_t ex = inc - avail, left = cnt - done;
-                const uint32_t take = ex >= left ? 0u : min(avail, left - ex);
-                s_group[tid] = done + ex;                                               // dense offset of the tile's first run in the row
-                s_gcnt[tid] = (bb + (uint32_t)tid) * RN_TILE + ((bb + (uint32_t)tid) == b0 ? o0 : 0u);   // its sparse index
-                s_gpre[tid] = take;
+                s_group[tid] = done + (inc - avail);                                  // the tile's first run: its place in the row ...
+                s_gcnt[tid] = (bb + (uint32_t)tid) * BLK_STRIDE + ((bb + (uint32_t)tid) == b0 ? o0 : 0u);   // ... and in the sparse arrays
             }
             __syncthreads();
             const uint32_t batch = min(cnt - done, s_red[0] + s_red[1] + s_red[2] + s_red[3]);
-            for (uint32_t t = (uint32_t)w; t < 256u; t += (uint32_t)(TH / 64)) {
-                const uint32_t take = s_gpre[t];
-                if (!take) continue;                                                    // (wave-uniform)
-                const uint32_t d0 = row_lo + s_group[t], sp0 = s_gcnt[t];
-                for (uint32_t i = (uint32_t)lane; i < take; i += 64u) {
-                    const uint4* sp = reinterpret_cast<const uint4*>(&bk.rec_sp[sp0 + i]);
-                    const uint4 c0 = sp[0], c1 = sp[1];
-                    const uint32_t lt = bk.run_lt_sp[sp0 + i];
-                    uint4* dp = reinterpret_cast<uint4*>(&records[d0 + i]);
-                    dp[0] = c0; dp[1] = c1;
-                    bk.run_lt_out[d0 + i] = lt;
+#pragma unroll
+            for (int r = 0; r < (COVL ? KPL : 1); r++) {
+                const uint32_t e = (uint32_t)r * TH + (uint32_t)tid;
+                if (e >= done && e < done + batch) {                    // last tile of the round that begins at or before e (empty tiles share their successor's place)
+                    uint32_t lo = 0, hi = 256;
+#pragma unroll
+                    for (int st = 0; st < 8; st++) { const uint32_t mid = (lo + hi) >> 1; if (s_group[mid] <= e) lo = mid; else hi = mid; }
+                    blk_j[r] = s_gcnt[lo] + (e - s_group[lo]);
                 }
             }
             done += batch;
-            __syncthreads();                                                            // (the tables are rewritten by the next round)
+            __syncthreads();                                            // (the tables are rewritten by the next round)
         }
-        __threadfence_block();
-        __syncthreads();                                                                // the row's dense records are this workgroup's own writes
     }
-    if (LOCAL && blocks && tid == 0) bk.row_base[ty] = row_lo;          // (read above, as row_sp) what the painters bound a row's probes by: dense from here on
     uint32_t m = cnt;                                    // runs of this slice
     uint32_t off = 0;                                    // runs of the row in the slices before it (= its first span slot)
     uint32_t kbase = row_lo;                             // !LOCAL: first sorted key of the slice
@@ -1042,7 +1058,7 @@ __global__ __launch_bounds__(TH, TH == 512 ? (COVL ? 4 : CR_HALF_OCC) : (CAP == 
 #pragma unroll
                 for (int r = 0; r < KPL; r++) {
                     const uint32_t e = (uint32_t)r * TH + (uint32_t)tid;
-                    rl[r] = e < cnt ? run_lt[row_lo + e] : 0u;
+                    rl[r] = e < cnt ? (blocks ? bk.run_lt_sp[blk_j[r]] : run_lt[row_lo + e]) : 0u;
                 }
 #pragma unroll
                 for (int r = 0; r < KPL; r++) {
@@ -1157,7 +1173,7 @@ __global__ __launch_bounds__(TH, TH == 512 ? (COVL ? 4 : CR_HALF_OCC) : (CAP == 
     // COVL: the sort is done — its wave counters' space takes the row's cover sums (one round of coalesced loads: the records of a
     // row are contiguous), the idle key buffer's upper half the style summaries (its lower half: the run digests, s_txo below)
     uint16_t* s_sf16 = COVL ? reinterpret_cast<uint16_t*>(idle) + CAP : nullptr;
-    if (COVL) {
+    if (COVL && !blocks) {
         uint4 cv[COVL ? KPL : 1];
 #pragma unroll
         for (int r = 0; r < (COVL ? KPL : 1); r++) {
@@ -1170,17 +1186,75 @@ __global__ __launch_bounds__(TH, TH == 512 ? (COVL ? 4 : CR_HALF_OCC) : (CAP == 
             if (e < cnt) { s_cov[e] = cv[r]; s_sf16[e] = (uint16_t)((lsf_reg[r] & 0x7FFFu) | ((lsf_reg[r] & LSF_VALID) ? 0x8000u : 0u)); }
         }
     }
-    if (LOCAL && n_slices == 1u) {
-        s_txo = reinterpret_cast<uint16_t*>(NB_IN_IDLE ? idle + (CR_PIECE + 1) + (CR_PIECE + 4) / 2 : idle);
-        for (uint32_t e = tid; e < cnt; e += TH) s_txo[e] = (uint16_t)run_lt[row_lo + e];
-        __syncthreads();
-        if (blocks) {
-            // the first-run table (0 = the tile has no run): a run whose tile column differs from its predecessor's begins a tile
-            for (uint32_t e = tid; e < cnt; e += TH) {
-                const uint32_t tx = (uint32_t)s_txo[e] & 0xFFFu, px = e ? ((uint32_t)s_txo[e - 1] & 0xFFFu) : 0xFFFFu;
-                if (tx >= 1u && tx != px) bk.tile_first_run[ty * tiles_w + (tx - 1u)] = row_lo + e + 1u;
+    if (COVL && blocks) {
+        // the same from the sparse arrays (blk_j): cover sums and the digests' low halves in one round of loads, then the records'
+        // second halves — on their way to the dense records.  A run that crosses its chunk is made whole HERE from the following
+        // chunks' edges (cover sum and segment count: the walk below never sees an open run).
+        uint16_t* txo_b = reinterpret_cast<uint16_t*>(idle);
+        uint4 cv[COVL ? KPL : 1], tl[COVL ? KPL : 1];                   // (both halves of the records and the digests: ONE round of loads)
+        uint32_t lt[COVL ? KPL : 1];
+#pragma unroll
+        for (int r = 0; r < (COVL ? KPL : 1); r++) {
+            const uint32_t e = (uint32_t)r * TH + (uint32_t)tid;
+            cv[r] = e < cnt ? reinterpret_cast<const uint4*>(&bk.rec_sp[blk_j[r]])[0] : make_uint4(0u, 0u, 0u, 0u);
+            tl[r] = e < cnt ? reinterpret_cast<const uint4*>(&bk.rec_sp[blk_j[r]])[1] : make_uint4(0u, 0u, 0u, 0u);
+            lt[r] = e < cnt ? bk.run_lt_sp[blk_j[r]] : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < (COVL ? KPL : 1); r++) {
+            const uint32_t e = (uint32_t)r * TH + (uint32_t)tid;
+            if (e < cnt) {
+                s_cov[e] = cv[r];
+                s_sf16[e] = (uint16_t)((lsf_reg[r] & 0x7FFFu) | ((lsf_reg[r] & LSF_VALID) ? 0x8000u : 0u));
+                txo_b[e] = (uint16_t)(lt[r] & 0xFFFu);                  // (neither "open" nor "first of its tile": both are dealt with here)
             }
         }
+        // the runs that cross their chunk, all of a lane's at once: one round of edge loads per step of the longest walk (nearly
+        // always one or two), not one walk after the other
+        uint32_t eb[COVL ? KPL : 1], openm = 0;
+#pragma unroll
+        for (int r = 0; r < (COVL ? KPL : 1); r++) {
+            const uint32_t e = (uint32_t)r * TH + (uint32_t)tid;
+            eb[r] = tl[r].x / edge_segs + 1u;
+            if (e < cnt && (tl[r].y & RUN_OPEN)) { tl[r].y &= ~RUN_OPEN; if (eb[r] < n_blk) openm |= 1u << r; }
+        }
+        while (__any(openm != 0u)) {
+            uint4 ec[COVL ? KPL : 1]; uint2 ex[COVL ? KPL : 1];
+#pragma unroll
+            for (int r = 0; r < (COVL ? KPL : 1); r++) {
+                if ((openm >> r) & 1u) {
+                    const uint4* ep = reinterpret_cast<const uint4*>(&blk_edge[eb[r]]);
+                    ec[r] = ep[0]; ex[r] = *reinterpret_cast<const uint2*>(ep + 1);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < (COVL ? KPL : 1); r++) {
+                if ((openm >> r) & 1u) {
+                    const uint32_t e = (uint32_t)r * TH + (uint32_t)tid;
+                    const uint4 c = s_cov[e];
+                    const uint64_t clo = swar_add8((uint64_t)c.x | ((uint64_t)c.y << 32), (uint64_t)ec[r].x | ((uint64_t)ec[r].y << 32));
+                    const uint64_t chi = swar_add8((uint64_t)c.z | ((uint64_t)c.w << 32), (uint64_t)ec[r].z | ((uint64_t)ec[r].w << 32));
+                    s_cov[e] = make_uint4((uint32_t)clo, (uint32_t)(clo >> 32), (uint32_t)chi, (uint32_t)(chi >> 32));
+                    tl[r].y += ex[r].x;
+                    eb[r]++;
+                    if (ex[r].y || eb[r] >= n_blk) openm &= ~(1u << r);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < (COVL ? KPL : 1); r++) {
+            const uint32_t e = (uint32_t)r * TH + (uint32_t)tid;
+            if (e < cnt) {
+                reinterpret_cast<uint4*>(&records[row_lo + e])[1] = tl[r];
+                const uint32_t tx = lt[r] & 0xFFFu;
+                if ((lt[r] & RUN_LT_NEWTILE) && tx >= 1u) bk.tile_first_run[ty * tiles_w + (tx - 1u)] = row_lo + e + 1u;   // (0 = the tile has no run)
+            }
+        }
+    }
+    if (LOCAL && n_slices == 1u) {
+        s_txo = reinterpret_cast<uint16_t*>(NB_IN_IDLE ? idle + (CR_PIECE + 1) + (CR_PIECE + 4) / 2 : idle);
+        if (!(COVL && blocks)) for (uint32_t e = tid; e < cnt; e += TH) s_txo[e] = (uint16_t)run_lt[row_lo + e];
+        __syncthreads();
     }
     static_assert(!NB_IN_IDLE || (CR_PIECE + 1) + (CR_PIECE + 4) / 2 + CAP / 2 <= CAP, "group / tile_x / digest arrays share the idle sort buffer");
     for (uint32_t c0 = 0; c0 < m; c0 += CR_PIECE) {
@@ -1450,7 +1524,9 @@ void launch_carry_rows(hipStream_t s, bool local_sort, bool small, bool half, ui
     if (n_slices < 1u) n_slices = 1u;
     if (n_slices > CR_MAX_SLICES) n_slices = CR_MAX_SLICES;
     const dim3 grid((row1 - row0) * n_slices);
-    if (bk.rec_sp && (!local_sort || n_slices != 1u)) bk = BlkRuns{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // (the caller's condition)
+    const bool covl_variant = local_sort && covl && n_slices == 1u && (!small || half);
+    if (bk.rec_sp && !covl_variant) bk = BlkRuns{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 256u};   // (the caller's condition)
+    if (bk.round_tiles < 1u || bk.round_tiles > 256u || (bk.round_tiles & (bk.round_tiles - 1u))) bk.round_tiles = 256u;
 #define CR_LAUNCH(L, C, R, T_, ...) FORMA_LAUNCH((k_carry_rows<L, C, R, T_ __VA_OPT__(,) __VA_ARGS__>), grid, dim3(T_), 0, s, sorted_run_keys, records, blk_edge, n_segments, \
                                               n_runs, layer_sf, n_orders, tiles_w, tiles_h, row_count, row_span_lo, row_span_cnt, span_key, \
                                               span_cov, unchanged, info, edge_segs, vis_last, n_slices, bin_shift, row0, groups, run_lt, cull ? 1u : 0u, left_start, row_base, bk)

@@ -26,7 +26,8 @@ SWITCHES = [
     "strip_tiles=100000000", "strip_tiles=0",      # k_paint_wave<.., NPX = 1> everywhere / never
     "paint_quad=2", "paint_quad=0",                # k_paint_quad for every all-solid scene / never
     "no_order", "order_thr=1",                     # heavy-first order never / every tile filed as heavy
-    "runs_chain=1", "runs_chain=0",                # k_runs_wave<true> alone / k_runs_count + k_runs_wave
+    "runs_chain=1", "runs_chain=0",                # k_runs_wave<1> alone / k_runs_count + k_runs_wave<0>
+    "runs_blk=1,runs_chain=0", "runs_blk=0,runs_chain=0", "runs_blk=1,runs_chain=0,carry_slices=1",   # k_runs_wave<2> (runs numbered per tile of the run kernel) / never
     "sort_cus=0", "sort_cus=64", "sort_cus=128",   # persistent workgroups of a digit pass
     "carry_half=0", "carry_half=2", "carry_half=4", "carry_covl=0", "carry_covl=0,carry_slices=1",
     "carry_slices=1", "carry_slices=3", "carry_slices=8", "no_small_carry",
@@ -38,6 +39,7 @@ SWITCHES = [
     # combinations that meet in the bench configurations
     "strip_tiles=100000000,force_cull,runs_chain=1", "paint_quad=2,runs_chain=1,carry_half=2", "order_thr=1,force_cull,sort_cus=128",
     "poison_frame=255,runs_chain=1,strip_tiles=100000000", "poison_frame=0,order_thr=1,paint_quad=2",
+    "poison_frame=255,runs_blk=1,runs_chain=0,carry_slices=1,force_cull", "poison_frame=0,runs_blk=1,runs_chain=0,blk_round=2,strip_tiles=100000000",
 ]
 
 

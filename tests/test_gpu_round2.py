@@ -615,6 +615,49 @@ def test_runs_numbered_per_tile_row_without_a_counting_pass(monkeypatch, switch)
         c.close()
 
 
+@pytest.mark.parametrize("switch", ["runs_blk=1,runs_chain=0", "runs_blk=1,runs_chain=0,carry_slices=1", "runs_blk=1,runs_chain=0,blk_round=4",
+                                    "runs_blk=1,runs_chain=0,carry_slices=1,blk_round=1", "runs_blk=1,runs_chain=0,no_prezero,blk_round=2",
+                                    "runs_blk=0,runs_chain=0"])
+def test_runs_numbered_per_tile_of_the_run_kernel(monkeypatch, switch):
+    """launch_runs' BLOCKS numbering (k_runs_wave<2>): read-back-free frames whose tile rows take one COVL carry workgroup each
+    number their runs per 2 048-segment tile of the run kernel — no counting pass, no look-back — into sparse arrays, and
+    k_carry_rows finds a row's runs through the tiles' head counts (256 tiles per round; `blk_round` forces several rounds on small
+    rows), writes the dense records' second halves, completes the runs that cross their chunk and fills the first-run table.
+    Same images as the oracle's: the usual mix with a crop, a strip whose tiles of the run kernel hold many rows (1080 x 40), one
+    row of more than 64 such tiles (4096 x 16), light rows (the 512-lane variant) and heavy ones (`carry_slices=1`: the 1 024-lane
+    one); every per-frame buffer poisoned (what lies between two tiles' records is never a run); after the scene SHRANK."""
+    import forma_amd
+    monkeypatch.setenv("FORMA_HIP_DEBUG", switch + ",poison_frame=255")
+    c = forma_amd.Context(0)
+    blk_frames = 0
+    try:
+        cases = (((1024, 768), S.random_mixed(n=400, width=1024, height=768, seed=41), S.random_mixed(n=150, width=1024, height=768, seed=42)),
+                 ((1080, 40), S.random_cubics(n=300, width=1080, height=40, seed=43, alpha=0.6), S.random_cubics(n=40, width=1080, height=40, seed=44)),
+                 ((4096, 16), S.random_cubics(n=1500, width=4096, height=16, seed=45, alpha=0.5), S.random_cubics(n=900, width=4096, height=16, seed=46)),
+                 ((2048, 256), S.random_cubics(n=700, width=2048, height=256, seed=47, alpha=0.7), S.random_cubics(n=90, width=2048, height=256, seed=48)))
+        for (w, h), big, small in cases:
+            for comp in (big, small):                    # (the second scene of a canvas has fewer runs in every row)
+                o, _ = both(c, comp)
+                for crop in (None, (16 * 2 + 3, w - 21, 0, h) if h <= 48 else (16 * 2 + 3, w - 21, 33, h - 50)):
+                    ref = o.render(w, h, clear=(1.0, 1.0, 1.0, 1.0), crop=crop)
+                    for k in range(4):                   # (the first frame of a geometry is synchronous)
+                        img, _tm = c.render(w, h, clear=(1.0, 1.0, 1.0, 1.0), crop=crop, timings=True)
+                        names = [nm for nm, _st, _t0, _us in c.kernel_times()]
+                        # (with the chain switched off, a frame that finds its runs without the counting pass is a BLOCKS frame)
+                        if any("k_runs_wave" in nm for nm in names) and not any("k_runs_count" in nm for nm in names):
+                            blk_frames += 1
+                        y0, y1, x0, x1 = (crop[2], crop[3], crop[0], crop[1]) if crop else (0, h, 0, w)
+                        a = img.reshape(h, -1)[y0:y1, 4 * x0:4 * x1].astype(np.int16); b = ref.reshape(h, -1)[y0:y1, 4 * x0:4 * x1].astype(np.int16)
+                        assert np.abs(a - b).max() <= 1, (switch, (w, h), crop, k)
+        # the switch is a request, the carry variant decides: the numbering must have been used by most read-back-free frames
+        if switch.startswith("runs_blk=1"):
+            assert blk_frames >= 24, (switch, blk_frames)
+        else:
+            assert blk_frames == 0, (switch, blk_frames)
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("switch", ["carry_half=2", "carry_half=4", ""])
 def test_sliced_tile_rows_on_half_workgroups(monkeypatch, switch):
     """k_carry_rows<true, 2048, 4, 512> with SEVERAL workgroups per tile row (each a range of layers): the policy takes it for
