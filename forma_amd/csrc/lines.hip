@@ -483,6 +483,11 @@ void launch_block_first(hipStream_t s, const uint32_t* cl_start, uint32_t n_comp
 // 40) and the three f64 constants of `find` (rasterizer.rs:104-110, one f64 division per LINE instead
 // of one per pixel segment).  The flat index -> (line, i) map of PrefixScanIter
 // (utils/prefix_scan.rs:30-63) is a binary search over the staged window.
+// (Round 6 built the transposed form — a wave walks its 512 segments in eight steps of 64 CONSECUTIVE ones, a segment's line is a
+// population count over a 2 048-bit map of line starts plus v_mbcnt, no search and no line walk, what is constant along a line comes
+// out of an 80-byte LDS record per step, the sort's digits are counted along the wave — and measured it: 84.4 -> 97.8 us on the 4K
+// scene, 50.0 -> 55.2 on the 8K one, 18.9 -> 23.0 at 1080p: five 16-byte LDS reads per segment cost more than the search and the
+// walk they replace, which a lane pays once per eight segments.  profiles/r06_experiments.txt, r6x.)
 // ------------------------------------------------------------------------------------------------
 #ifndef RAS_THREADS
 #define RAS_THREADS 256
