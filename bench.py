@@ -366,8 +366,15 @@ def main():
                                                "k_sort_hist + every digit pass") + ": the sum of the sort kernels' own launch-event durations of the same frames"}
         # what the stages behind the sort move, against what they have to (8 N in + 4 W H out): counters of the committed build
         if use_pmc:
-            post = [v.get("hbm_bytes_per_launch", 0) for k, v in pmc["kernels"].items()
-                    if k.startswith(("k_runs_count", "k_runs_wave", "k_carry_rows", "k_paint_wave"))]
+            # (per kernel name the instantiation that runs on EVERY frame — `dispatches` — and only kernels of this run's frames:
+            #  the synchronous first frame of a scene launches k_runs_count and k_runs_wave<0> once each)
+            post = []
+            for base in ("k_runs_count", "k_runs_wave", "k_carry_rows", "k_paint_wave"):
+                if base not in kernels_us:
+                    continue
+                cands = [v for k, v in pmc["kernels"].items() if k.split("<")[0] == base]
+                if cands:
+                    post.append(max(cands, key=lambda v: v.get("dispatches", 0)).get("hbm_bytes_per_launch", 0))
             if post and all(post):
                 roofline["post_sort_traffic_ratio"] = round(sum(post) / (8.0 * n_local + 4.0 * width * height), 3)
         if in_flight > 1:

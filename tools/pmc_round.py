@@ -36,6 +36,7 @@ def per_kernel(d):
             big = max(g for g, _ in v)                       # the frame-sized launches only
             vals = [x for g, x in v if g == big]
             out[k][c] = sum(vals) / len(vals)
+            out[k]["dispatches"] = max(out[k].get("dispatches", 0), len(vals))   # (how often the kernel ran at frame size: once = the synchronous first frame)
     return out
 
 
@@ -55,6 +56,7 @@ def main():
             v["hbm_bytes_per_launch"] = int(v["FETCH_SIZE"] * 1024 * 2 + v["WRITE_SIZE"] * 1024)
         for c in list(v):
             v[c] = round(v[c], 1) if isinstance(v[c], float) else v[c]
+
     cal = kern.get("k_runs_count", {}).get("FETCH_SIZE", 0) * 1024 * 2 / (8.0 * n) if n else 0
     json.dump({"_note": "rocprofv3 --pmc, three passes of `bench.py --steps 3 --warmup 1 --in-flight 1 --no-cpu-baseline`; mean over the "
                         "frame-sized dispatches; FETCH_SIZE / WRITE_SIZE in KB per dispatch, hbm_bytes_per_launch = 2 x FETCH + WRITE "
