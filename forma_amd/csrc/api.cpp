@@ -486,9 +486,12 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     // Measured (profiles/r06_experiments.txt, r6n-r6v): the 4K scene (135 heavy rows, a CU each) runs + carry 112.8 -> 94.1 us, frames/s per
     // call +3.9 %, three slots +3.8 %; the 8K triangle scene (512 light rows, two workgroups per CU) 72 -> 73 us — the head counts are one
     // more dependent round trip at the start of k_carry_rows, and with every workgroup of a full chip asking at once that costs what
-    // the counting pass did: by default only for frames of at most one carry workgroup per CU.
+    // the counting pass did: by default not for frames of more LIGHT rows (the 512-lane carry variant, several workgroups per CU) than CUs.
+    // Sweep of the switch over 4 scene families x 5 canvases x 1 / 3 slots (profiles/r06_policy_sweep_blk.json): heavy rows gain at every
+    // canvas, also with two rounds of row workgroups (the 30 000-layer scene at 8192 x 8192: +3.9 %); light rows gain up to 4K (+4 %) and lose
+    // 0-2 % at 8192 x 8192.
     const bool blk = bound_j != 0 && n > 0 && !chain && covl_choice(ns_final) && n <= 0x3FFFFFFFull &&
-                     (ctx->dbg.runs_blk < 0 ? (RUNS_BLK_DEFAULT != 0 && rows_painted <= (uint32_t)ctx->n_cus) : ctx->dbg.runs_blk != 0);
+                     (ctx->dbg.runs_blk < 0 ? (RUNS_BLK_DEFAULT != 0 && (rows_painted <= (uint32_t)ctx->n_cus || !(small && half))) : ctx->dbg.runs_blk != 0);
     if (bound_j) {
         jc = chain ? DevCount{nullptr, (uint32_t)n} : (blk ? DevCount{nullptr, bound_j} : DevCount{&dinfo->n_runs, bound_j});   // (chain: run indices are segment indices; blk: dense, counted by nobody before the tail)
         if (chain || blk) { ctx->chain_rows = row_count; ctx->n_chain_rows = tiles_h; }

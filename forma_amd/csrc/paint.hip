@@ -929,7 +929,7 @@ __global__ __launch_bounds__(TH, TH == 512 ? (COVL ? 4 : CR_HALF_OCC) : (CAP == 
     //      on the 4K scene — the head counts are one more dependent round trip in front of everything, 13 k clocks per row with the
     //      scan and the search — for the 20.6 us of k_runs_count and 4 of k_runs_wave.  On the 8K triangle scene, 512 rows of light
     //      work on two workgroups per CU, the same round trip costs 30 k clocks at the start of a launch whose every workgroup asks at
-    //      once: 28 -> 46 us, all that the counting pass cost — the host keeps the counting pass for frames of more rows than CUs.)
+    //      once: 28 -> 46 us, all that the counting pass cost — the host keeps the counting pass for frames of more LIGHT rows (this 512-lane variant) than CUs.)
     uint32_t blk_j[COVL ? KPL : 1];
     if (COVL && blocks) {
         if (row_lo + cnt > n_runs || cnt > (uint32_t)CAP) { if (tid == 0) info->plan_bad = 1u; return; }   // (more runs than provisioned / than this variant holds: the host re-runs)
