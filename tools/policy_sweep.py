@@ -10,7 +10,7 @@ coordinates scaled to the canvas (the styles stay: a scaled gradient is still a 
 canvas: cubics (1 000 opaque cubics), paris (30 000 mixed layers), triangles (19 400 small opaque triangles), circles (20 000
 translucent discs).  Per (canvas, family, slots) cell every schedule switch of csrc/debug.h is forced both ways in a context of
 its own (FORMA_HIP_DEBUG is read at context creation) and K device-resident frames are timed after the set-up frames:
-    default | strip_tiles=0 / =huge | paint_quad=0 / =2 | no_order / order_thr=32768 | runs_chain=0 / =1 | sort_cus=0 / =128 |
+    default | strip_tiles=0 / =huge | paint_quad=0 / =2 | no_order / order_thr=32768 | runs_chain=0 / =1 | runs_blk=0 / =1 | sort_cus=0 / =128 |
     carry_half=0 / =2 | carry_covl=0
 `loss` of a cell = 1 - fps(default) / max over all settings; the report lists the cells where the default loses more than 5 %.
 Images are checked equal across the settings of a cell (xor-fold of the last frame)."""
@@ -29,7 +29,7 @@ SCENE = "/tmp/ab_fast_scene_%s.npz"
 CANVAS = {"720p": (1280, 720), "1080p": (1920, 1080), "1440p": (2560, 1440), "4k": (3840, 2160), "8k": (8192, 8192)}
 FAMILY = {"cubics": "cubics-1080p", "paris": "paris-like-30k-4k", "triangles": "triangles-10m-8k", "circles": "circles-20k"}
 SETTINGS = ["", "strip_tiles=0", "strip_tiles=100000000", "paint_quad=0", "paint_quad=2", "no_order", "order_thr=32768",
-            "runs_chain=0", "runs_chain=1", "sort_cus=0", "sort_cus=128", "carry_half=0", "carry_half=2", "carry_covl=0"]
+            "runs_chain=0", "runs_chain=1", "runs_blk=0", "runs_blk=1", "sort_cus=0", "sort_cus=128", "carry_half=0", "carry_half=2", "carry_covl=0"]
 
 
 def main():
