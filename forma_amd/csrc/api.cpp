@@ -61,7 +61,8 @@ int frame_tail(forma_hip_ctx* ctx, bool to_host_info, uint32_t* host_count) {
     const bool timed = ctx->stage_used[ST_PAINT];         // (a timed frame books the tail on the paint stage)
     stage_begin(ctx, ST_PAINT, timed);
     launch_frame_tail(ctx->stream, ctx->info.as<FrameInfo>(), to_host_info ? ctx->h_info : nullptr, host_count,
-                      ctx->order_cnt_dev, ctx->order_keep_dev, ctx->chain_rows, ctx->n_chain_rows);
+                      ctx->order_cnt_dev, ctx->order_keep_dev, ctx->chain_rows, ctx->n_chain_rows,
+                      to_host_info ? ctx->h_seq : nullptr, to_host_info ? ++ctx->tail_seq : 0u);
     ctx->order_cnt_dev = nullptr; ctx->order_keep_dev = nullptr; ctx->chain_rows = nullptr; ctx->n_chain_rows = 0;
     stage_end(ctx, ST_PAINT, timed);
     HIPCHECK(hipGetLastError());
@@ -977,10 +978,12 @@ int forma_hip_create(forma_hip_ctx** out, int device) {
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx; return FORMA_E_HIP;
     }
-    bool ok = hipHostMalloc((void**)&ctx->h_info, sizeof(FrameInfo), hipHostMallocDefault) == hipSuccess &&
+    // (coherent = fine-grained: the host polls the word behind the FrameInfo while the frame's kernels still run)
+    bool ok = hipHostMalloc((void**)&ctx->h_info, sizeof(FrameInfo) + 64, hipHostMallocCoherent) == hipSuccess &&
               hipHostMalloc((void**)&ctx->h_rows, 2049 * 4, hipHostMallocDefault) == hipSuccess &&
               hipHostMalloc((void**)&ctx->h_xlocal, 2 * 4, hipHostMallocDefault) == hipSuccess &&
               ctx->info.ensure(sizeof(FrameInfo)) == hipSuccess && ctx->info_init.ensure(sizeof(FrameInfo)) == hipSuccess;
+    if (ok) { ctx->h_seq = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx->h_info) + ((sizeof(FrameInfo) + 15) & ~(size_t)15)); *ctx->h_seq = 0; }
     if (ok) {
         FrameInfo fi;
         memset(&fi, 0, sizeof fi);
@@ -1371,9 +1374,27 @@ int enqueue_async_frame(forma_hip_ctx* ctx, const PaintArgs& a, bool timing, uin
 
 // ... second half: wait, verify.  FORMA_RETRY: a prediction failed, nothing of the frame may be used (the caller re-runs it
 // synchronously).  The frame is verified BEFORE anything lands in caller memory: a mispredicted frame never shows in `dst`.
+// The end of a read-back-free frame as the host sees it.  k_frame_tail writes the frame's number into pinned memory behind the
+// FrameInfo (system-scope release): polling that word returns a few microseconds before hipStreamSynchronize would — the stream's
+// completion signal takes the runtime's wake-up path — and the frame's kernels are all complete when its last one has stored.
+// Timed frames wait for the stream: their events must have been recorded.  A frame that never arrives (a fault) falls back to
+// the stream's own error after a bounded spin.
+int wait_frame_tail(forma_hip_ctx* ctx, bool timing) {
+    if (!timing && ctx->dbg.tail_poll && ctx->h_seq) {
+        const uint32_t want = ctx->tail_seq;
+        for (uint32_t spin = 0; spin < (1u << 21); spin++) {            // (~50 ms: a frame that long waits on the stream instead)
+            if (__atomic_load_n(ctx->h_seq, __ATOMIC_ACQUIRE) == want) return FORMA_OK;
+            __builtin_ia32_pause();
+            if ((spin & 0xFFFFu) == 0xFFFFu && hipStreamQuery(ctx->stream) != hipErrorNotReady) break;   // done without the word, or failed
+        }
+    }
+    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    return FORMA_OK;
+}
+
 int complete_async_frame(forma_hip_ctx* ctx, const PaintArgs& a, uint8_t* dst, size_t stride_bytes, bool timing,
                          forma_timings_t* timings, uint32_t bN, uint32_t bJ) {
-    HIPCHECK(hipStreamSynchronize(ctx->stream));
+    { const int wrc = wait_frame_tail(ctx, timing); if (wrc) return wrc; }
     const uint32_t N = ctx->h_info->n_segments, J = ctx->h_info->n_runs;
     ctx->n_seg = N; ctx->n_compact = ctx->h_info->n_compact; ctx->last_runs = J;
     const bool ok = !ctx->h_info->plan_bad && N <= bN && J <= bJ;

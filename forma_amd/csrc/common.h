@@ -353,7 +353,8 @@ uint32_t runs_edge_segments();            // segments per BlkEdge entry
 void launch_frame_tail(hipStream_t s, FrameInfo* info, FrameInfo* host_info, uint32_t* host_count,
                        const uint32_t* order_cnt = nullptr, uint32_t* order_keep = nullptr /* PAINT_ORDER_WORDS words copied (PaintParams::order_*) */,
                        const uint32_t* chain_rows = nullptr, uint32_t n_chain_rows = 0 /* launch_runs' chain numbering: the frame's row
-                       counts, summed into the host copy's n_runs */);
+                       counts, summed into the host copy's n_runs */,
+                       uint32_t* host_seq = nullptr, uint32_t seq = 0 /* pinned word that takes `seq` when everything else has landed */);
 // Words the frame's FIRST kernel clears on behalf of later stages (sort scratch, tile tables): a few hundred
 // KB spread over a grid that exists anyway, instead of two or three memset operations on the stream.
 #define FORMA_ZERO_JOBS 4

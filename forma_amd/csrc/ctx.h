@@ -135,6 +135,8 @@ struct forma_hip_ctx {
     DevBuf info, records, rk_u, rk_a, rk_b, blk_edge, runs_scratch, row_tab, span_key, span_cov, image;
     uint32_t img_w = 0, img_h = 0;
     FrameInfo* h_info = nullptr;            // pinned
+    uint32_t*  h_seq = nullptr;             // pinned (behind h_info): the number of the last read-back-free frame whose k_frame_tail has run
+    uint32_t   tail_seq = 0;                // ... and of the last one enqueued
     bool info_clean = false;                // the device FrameInfo is pristine: the last frame ended with k_frame_tail (reset_info is then free)
     // what this frame's FIRST kernel cleared on behalf of later stages (ZeroJobs, common.h): consumed by run_sort / run_paint,
     // which clear the words themselves when the pointer or the size is not what they need

@@ -3409,7 +3409,7 @@ void launch_pack_written(hipStream_t s, const uint8_t* written, uint32_t tiles_w
 __global__ __launch_bounds__(64) void k_frame_tail(FrameInfo* __restrict__ info, FrameInfo* __restrict__ host_info,
                                                    uint32_t* __restrict__ host_count, const uint32_t* __restrict__ order_cnt,
                                                    uint32_t* __restrict__ order_keep, const uint32_t* __restrict__ chain_rows,
-                                                   uint32_t n_chain_rows) {
+                                                   uint32_t n_chain_rows, uint32_t* __restrict__ host_seq, uint32_t seq) {
     constexpr int W = (int)(sizeof(FrameInfo) / 4);
     static_assert(W <= 64, "FrameInfo fits one wave");
     const int t = threadIdx.x;
@@ -3438,9 +3438,12 @@ __global__ __launch_bounds__(64) void k_frame_tail(FrameInfo* __restrict__ info,
         const bool ones = t == (int)(offsetof(FrameInfo, key_and) / 4) || t == (int)(offsetof(FrameInfo, key_and_hi) / 4);
         src[t] = ones ? 0xFFFFFFFFu : 0u;
     }
+    // the frame's number, LAST: the release waits for every store of this wave (vmcnt(0) is the wave's), so a host that sees the
+    // number sees the whole FrameInfo — it polls this word instead of waiting for the stream's completion signal
+    if (host_seq && t == 0) __hip_atomic_store(host_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 void launch_frame_tail(hipStream_t s, FrameInfo* info, FrameInfo* host_info, uint32_t* host_count, const uint32_t* order_cnt,
-                       uint32_t* order_keep, const uint32_t* chain_rows, uint32_t n_chain_rows) {
-    FORMA_LAUNCH(k_frame_tail, dim3(1), dim3(64), 0, s, info, host_info, host_count, order_cnt, order_keep, chain_rows, n_chain_rows);
+                       uint32_t* order_keep, const uint32_t* chain_rows, uint32_t n_chain_rows, uint32_t* host_seq, uint32_t seq) {
+    FORMA_LAUNCH(k_frame_tail, dim3(1), dim3(64), 0, s, info, host_info, host_count, order_cnt, order_keep, chain_rows, n_chain_rows, host_seq, seq);
 }
 

@@ -43,7 +43,7 @@ __host__ __device__ constexpr int os_kpt(int bits) { return bits == 9 ? OS_KPT9 
 #endif
 static inline int os_kpt_small(size_t n) {
 #ifdef OS_FORCE_KPT
-    return OS_FORCE_KPT;                                  // (tools: 8 or 12 keys per lane whatever the stream's size)
+    return OS_FORCE_KPT;                                  // (tools: that many keys per lane — even — whatever the stream's size)
 #endif
     if (!OS_SMALL_TILES) return 0;
     if (n <= (size_t)256 * OS_THREADS * 8) return 8;
@@ -629,7 +629,11 @@ const uint64_t* launch_radix_sort(hipStream_t s, const uint64_t* in, uint64_t* a
                                            plan.shift[p], plan.mask[p], plan.bias[p], (const uint32_t*)(hist + p * SORT_BINS), st, tickets + p, err, ch ? C : C0)
 #define OS_LAUNCH_K(B, K_) do { if (ch) { if (hi) OS_LAUNCH(B, true, true, K_); else OS_LAUNCH(B, true, false, K_); } \
                                 else { if (hi) OS_LAUNCH(B, false, true, K_); else OS_LAUNCH(B, false, false, K_); } } while (0)
+#ifdef OS_FORCE_KPT
+#define OS_LAUNCH_B(B) OS_LAUNCH_K(B, OS_FORCE_KPT)                   // (tools: any even count)
+#else
 #define OS_LAUNCH_B(B) do { if (small_kpt == 8) OS_LAUNCH_K(B, 8); else if (small_kpt == 12) OS_LAUNCH_K(B, 12); else OS_LAUNCH_K(B, 0); } while (0)
+#endif
         if (digit_bits == 4) OS_LAUNCH_K(4, 0);
         else if (plan.mask[p] > 255u) OS_LAUNCH_B(9);
         else OS_LAUNCH_B(8);

@@ -35,6 +35,7 @@ SWITCHES = [
     "digit_bits=4", "digit_bits=8", "digit_bits=9", "no_bias", "no_ras_hist", "no_prezero",
     "global_runsort", "span_groups", "no_span_groups",
     "sync",                                        # no read-back-free frames at all
+    "tail_poll=0",                                 # the host waits for the stream instead of polling k_frame_tail's word
     "no_simple_paint",                             # (process-wide, read once: effective only if this is the process's first context)
     # combinations that meet in the bench configurations
     "strip_tiles=100000000,force_cull,runs_chain=1", "paint_quad=2,runs_chain=1,carry_half=2", "order_thr=1,force_cull,sort_cus=128",
