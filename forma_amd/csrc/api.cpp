@@ -353,6 +353,29 @@ struct PaintArgs {
     int cache_id = -1;
 };
 
+// A synchronous frame into caller memory is PCIe from the painter's last tile on: 33 MB of a 4K image take ~600 us behind ~450 us
+// of kernels.  Painted in bands of tile rows — one launch and one event per band — the first band's pixels leave after an
+// eighth of the painter instead, on a second stream, and the link is busy while the rest is painted (the copies then end ~70 us
+// earlier; what the bands cost the painter — no heavy-first order across launches, eight tails — hides under the copy).
+// Only read-back-free frames of render_on that deliver into `dst` ask for it (split_want), never with a cache (the written-tile
+// set decides what is copied) and not for images of a few MB.  Returns the number of bands, 0: one launch as ever.
+int split_plan(forma_hip_ctx* ctx, const PaintArgs& a, const PaintParams& P, uint32_t bound_j, bool timing) {
+    if (!ctx->split_want || !bound_j || timing || a.cache_id >= 0 || ctx->dbg.paint_split == 0) return 0;
+    const uint32_t rows = P.crop_y1 > P.crop_y0 ? P.crop_y1 - P.crop_y0 : 0u;
+    const uint32_t cols = P.crop_x1 > P.crop_x0 ? P.crop_x1 - P.crop_x0 : 0u;
+    const bool forced = ctx->dbg.paint_split > 1;
+    if (!forced && ((uint64_t)rows * cols < 16384u || rows < 32u)) return 0;   // (< 16 MB of pixels: the copy is not the frame)
+    if (rows < 2u) return 0;
+    if (!ctx->copy_stream) {
+        if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) { ctx->copy_stream = nullptr; return 0; }
+        for (int k = 0; k < forma_hip_ctx::SPLIT_MAX; k++)
+            if (hipEventCreateWithFlags(&ctx->split_ev[k], hipEventDisableTiming) != hipSuccess) {
+                (void)hipStreamDestroy(ctx->copy_stream); ctx->copy_stream = nullptr; return 0;
+            }
+    }
+    return (int)std::min<uint32_t>(forced ? (uint32_t)ctx->dbg.paint_split : 2u, rows);   // (the policy: two bands, run_paint places the cut)
+}
+
 // stage 4 on ctx->sorted (n segments): runs + carry pre-pass + per-tile painter -> ctx->image
 // bound_j != 0: asynchronous — the run count stays on the device (info->n_runs), buffers are provisioned for bound_j runs.
 int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, uint32_t bound_j = 0) {
@@ -644,7 +667,9 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
     if (ctx->order_off) ctx->order_off--;                 // (a flat scene: the order is retried every 256 frames)
     // ... of launches that are a handful of rounds of wavefronts: one tile's life is then a good part of the launch's.  A frame
     // of 32 rounds (the 8K scene: 262 144 tiles on 8 192 wave slots) has no tail worth 10 % of bookkeeping.
-    if (ctx->order_enable && bound_j && a.cache_id < 0 && !strips && !quads && !ctx->dbg.no_order && jc.bound > 0 && tiles_painted && !ctx->order_off &&
+    // a frame that leaves in bands (split_plan below) paints in several launches: no heavy-first order across them
+    const int split_n = split_plan(ctx, a, P, bound_j, timing);
+    if (ctx->order_enable && bound_j && a.cache_id < 0 && !strips && !quads && !ctx->dbg.no_order && jc.bound > 0 && tiles_painted && !ctx->order_off && split_n == 0 &&
         tiles_painted <= 16u * paint_strip_tiles(ctx) && (one_frame_in_flight(ctx) || ctx->dbg.order_thr >= 0)) {
         // (heavy section: an eighth of the band's tiles, as PAINT_ORDER_SUBS lists of equal capacity)
         const size_t per = paint_band_tiles(P.crop_y1 > P.crop_y0 ? P.crop_y1 - P.crop_y0 : 0u, tiles_w), hcap = std::max<size_t>((per / 8 + PAINT_ORDER_SUBS - 1) / PAINT_ORDER_SUBS, 2) * PAINT_ORDER_SUBS;
@@ -695,6 +720,27 @@ int run_paint(forma_hip_ctx* ctx, DevCount nc, const PaintArgs& a, bool timing, 
                               : BlkRuns{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 256u});
     stage_end(ctx, ST_CARRY, timing);
     stage_begin(ctx, ST_PAINT, timing);
+    ctx->split_n = 0;
+    if (split_n > 1 && !launch_deep) {
+        // the painter in bands of tile rows, an event behind each: render_on sends the bands' pixels out behind those events
+        const uint32_t rows = P.crop_y1 - P.crop_y0;
+        for (int k = 0; k <= split_n; k++) ctx->split_row[k] = P.crop_y0 + (uint32_t)((uint64_t)rows * (uint32_t)k / (uint32_t)split_n);
+        // the policy's two bands: the first a quarter of the rows (split_first) — its copy must last until the rest is painted, or
+        // the link idles between the two (10 %: slower than one launch; 22-30 %: the plateau; profiles/r06_experiments.txt, r8g)
+        if (split_n == 2) ctx->split_row[1] = P.crop_y0 + std::min(std::max(rows * (uint32_t)ctx->dbg.split_first / 100u, 1u), rows - 1u);
+        for (int k = 0; k < split_n; k++) {
+            PaintParams Pk = P;
+            Pk.crop_y0 = ctx->split_row[k]; Pk.crop_y1 = ctx->split_row[k + 1];
+            launch_paint(ctx->stream, Pk, ctx->sorted, ctx->records.as<TileRecord>(), jc, tile_first_run, row_span_lo,
+                         row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(), ctx->layer_col.as<uint4>(),
+                         ctx->style_off.as<uint32_t>(),
+                         ctx->style_words.as<uint32_t>(), ctx->images.as<forma_image_t>(), ctx->texels.as<uint16_t>(),
+                         ctx->cur_image, tc, dinfo, paint_overflow, overflow_list, over2_n, over2_list, false, groups,
+                         strips, quads, mid_n, mid_list, ctx->n_cus);
+            HIPCHECK(hipEventRecord(ctx->split_ev[k], ctx->stream));
+        }
+        ctx->split_n = split_n;
+    } else
     launch_paint(ctx->stream, P, ctx->sorted, ctx->records.as<TileRecord>(), jc, tile_first_run, row_span_lo,
                  row_span_cnt, ctx->span_key.as<uint64_t>(), ctx->span_cov.as<uint4>(), ctx->layer_col.as<uint4>(),
                  ctx->style_off.as<uint32_t>(),
@@ -759,6 +805,34 @@ int copy_rows_out(forma_hip_ctx* ctx, hipStream_t s, uint8_t* dst, size_t stride
     else
         HIPCHECK(hipMemcpy2DAsync(dst + py0 * stride + px0 * 4, stride, ctx->cur_image + py0 * pitch + px0 * 4, pitch, (px1 - px0) * 4,
                                   py1 - py0, hipMemcpyDeviceToHost, s));
+    return FORMA_OK;
+}
+
+// the bands of a split frame (run_paint): each leaves on copy_stream behind its painter launch's event.  Called when ALL of the
+// frame's kernels are enqueued — a copy into pageable memory blocks the host until it is done.
+int send_split_bands(forma_hip_ctx* ctx, uint8_t* dst, size_t stride, const PaintArgs& a) {
+    if (ctx->split_n < 2 || !dst) return FORMA_OK;
+    const uint32_t tiles_w = (a.width + 15) / 16;
+    uint32_t tx0 = 0, tx1 = tiles_w;
+    if (a.crop) { tx0 = a.crop->x0 / 16; tx1 = std::min(tiles_w, (a.crop->x1 + 15) / 16); }
+    if (tx0 >= tx1) return FORMA_OK;
+    const size_t px0 = (size_t)tx0 * 16, px1 = std::min<size_t>((size_t)tx1 * 16, a.width);
+    ctx->split_sent = true;
+    for (int k = 0; k < ctx->split_n; k++) {
+        const size_t py0 = (size_t)ctx->split_row[k] * 16, py1 = std::min<size_t>((size_t)ctx->split_row[k + 1] * 16, a.height);
+        HIPCHECK(hipStreamWaitEvent(ctx->copy_stream, ctx->split_ev[k], 0));
+        if (py0 >= py1) continue;
+        const int rc = copy_rows_out(ctx, ctx->copy_stream, dst, stride, px0, px1, py0, py1, a.width);
+        if (rc) return rc;
+    }
+    ctx->image_sent = true;
+    return FORMA_OK;
+}
+// ... and nothing touches `dst` (or repaints the device image) before they have landed
+int settle_split(forma_hip_ctx* ctx) {
+    if (!ctx->split_sent) return FORMA_OK;
+    ctx->split_sent = false;
+    HIPCHECK(hipStreamSynchronize(ctx->copy_stream));
     return FORMA_OK;
 }
 
@@ -1043,6 +1117,11 @@ void forma_hip_destroy(forma_hip_ctx* ctx) {
     for (auto& c : ctx->caches) { c.tiles.release(); c.image.release(); }
     ctx->cache_written.release();
     for (auto& r : ctx->registered) (void)hipHostUnregister(r.first);
+    if (ctx->copy_stream) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        for (int k = 0; k < forma_hip_ctx::SPLIT_MAX; k++) if (ctx->split_ev[k]) (void)hipEventDestroy(ctx->split_ev[k]);
+        (void)hipStreamDestroy(ctx->copy_stream);
+    }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1399,6 +1478,7 @@ int complete_async_frame(forma_hip_ctx* ctx, const PaintArgs& a, uint8_t* dst, s
     ctx->n_seg = N; ctx->n_compact = ctx->h_info->n_compact; ctx->last_runs = J;
     const bool ok = !ctx->h_info->plan_bad && N <= bN && J <= bJ;
     if (!ok) {
+        { const int src = settle_split(ctx); if (src) return src; }               // (a split frame's bands are on their way: the re-run writes `dst` again)
         if (ctx->small_tried && ctx->h_info->plan_bad) ctx->small_banned = true;   // (one cause of plan_bad: a slice beyond the small variant)
         if (ctx->covl_tried && ctx->h_info->plan_bad) ctx->covl_banned = true;     // (another: a row beyond the COVL carry variant's LDS)
         if (ctx->plan_biased && ctx->h_info->plan_bad) ban_bias(ctx);              // (another: a key outside the span the digits were planned for)
@@ -1430,9 +1510,11 @@ int complete_async_frame(forma_hip_ctx* ctx, const PaintArgs& a, uint8_t* dst, s
     // (a deferred frame's image left speculatively behind its kernels; tiles that k_paint_huge paints only now: the crop is
     //  copied again)
     const bool in_place = ctx->image_sent && !(ctx->h_info->error & 8u);
+    const bool was_split = ctx->split_sent;
+    if ((rc = settle_split(ctx))) return rc;               // (a split frame: its bands have landed — or land before the crop is copied again)
     if ((rc = finish_paint(ctx))) return rc;
     if ((rc = copy_image_out(ctx, dst, stride_bytes, timing, a, in_place))) return rc;
-    if (dst) HIPCHECK(hipStreamSynchronize(ctx->stream));
+    if (dst && !(was_split && in_place)) HIPCHECK(hipStreamSynchronize(ctx->stream));   // (split: the tail has run, the copy stream is drained)
     rc = finish_frame(ctx, timings, true);
     frame_done(ctx, rc, a);
     return rc;
@@ -1466,8 +1548,12 @@ int render_on(forma_hip_ctx* ctx, uint8_t* dst, const PaintArgs& a, size_t strid
     if (a.width != ctx->pred_w || a.height != ctx->pred_h) { ctx->pred_counts_valid = false; ctx->pred_w = a.width; ctx->pred_h = a.height; }
     if (ctx->pred_valid && ctx->pred_counts_valid && !ctx->no_async) {
         uint32_t bN, bJ;
+        ctx->split_want = dst != nullptr && !timing;        // (a frame into caller memory: the painter may run in bands, run_paint)
+        ctx->split_n = 0;
         int rc = enqueue_async_frame(ctx, a, timing, &bN, &bJ);
+        ctx->split_want = false;
         if (rc) return rc;
+        if ((rc = send_split_bands(ctx, dst, stride_bytes, a))) { (void)settle_split(ctx); return rc; }
         rc = complete_async_frame(ctx, a, dst, stride_bytes, timing, timings, bN, bJ);
         if (rc != FORMA_RETRY) return rc;
     }

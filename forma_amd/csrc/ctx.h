@@ -116,6 +116,16 @@ struct forma_hip_ctx {
     size_t h_stage_cap = 0;
     bool frame_has_dst = false;             // the frame being enqueued on this slot also copies its image out (forma_hip_render_enqueue)
     bool image_sent = false;                // a deferred frame into caller memory: its image left behind the kernels, before the frame was verified
+    // A synchronous frame into caller memory (one frame in flight, no cache): the painter runs as two launches (tests: up to SPLIT_MAX) over
+    // bands of tile rows, each followed by an event; the bands' copies go out on `copy_stream` behind those events, so the image
+    // crosses PCIe while the rest of it is still being painted (api.cpp: run_paint, send_split_bands).
+    static constexpr int SPLIT_MAX = 8;
+    hipStream_t copy_stream = nullptr;      // created on first use
+    hipEvent_t  split_ev[SPLIT_MAX] = {};
+    bool     split_want = false;            // set by render_on around the frame's enqueue: this frame may split
+    int      split_n = 0;                   // bands of the frame just enqueued (0: not split)
+    uint32_t split_row[SPLIT_MAX + 1] = {}; // tile-row boundaries of the bands
+    bool     split_sent = false;            // copies are on copy_stream: wait for it before `dst` is touched again
     std::vector<std::pair<void*, size_t>> registered;   // caller buffers pinned by forma_hip_register_buffer
     int cur_cache = -1;                     // cache of the frame in flight
     uint8_t* cur_image = nullptr;           // device image of the frame in flight / last frame

@@ -32,6 +32,9 @@
 //   blk_round=N          (tests) tiles per round of k_carry_rows' table of a row's tiles under the BLOCKS numbering: a power of two <= 256 (default 256)
 //   strip_tiles=N        the painter runs four strip wavefronts per tile on frames of <= N painted tiles (0: never)
 //   tail_poll=0|1        the host waits for a read-back-free frame by hipStreamSynchronize / by polling the pinned word k_frame_tail writes last (default)
+//   paint_split=0|1|N    a synchronous frame into caller memory paints in bands whose copies leave while the rest is painted: never / by
+//                        policy (default: two bands) / always, in N equal bands (tests: small canvases too)
+//   split_first=P        ... the policy's first band: P percent of the painted tile rows (default 25)
 //   trim_debug           forma_hip_trim prints what it releases
 //   force_exchange       forma_hip_create_multi with ONE device still builds the multi-device context (RCCL world of one)
 //   xchg=copy            multi-device contexts exchange with device copies instead of RCCL
@@ -45,7 +48,7 @@ struct ForMaDebug {
     bool sync = false, global_runsort = false, xgather = false, no_small_carry = false, span_groups = false, no_span_groups = false;
     bool no_packed_copy = false, no_simple_paint = false, force_simple_paint = false, trim_debug = false, force_exchange = false;
     bool xchg_copy = false, no_prezero = false, no_bias = false, no_ras_hist = false, no_cull = false, force_cull = false, no_order = false;
-    int carry_slices = 0, digit_bits = 0, poison = -1, poison_frame = -1, strip_tiles = -1, carry_half = 1, paint_quad = 1, order_thr = -1, sort_cus = -1, runs_chain = -1, multi_layout = 0, carry_covl = 1, runs_blk = -1, blk_round = 256, tail_poll = 1;
+    int carry_slices = 0, digit_bits = 0, poison = -1, poison_frame = -1, strip_tiles = -1, carry_half = 1, paint_quad = 1, order_thr = -1, sort_cus = -1, runs_chain = -1, multi_layout = 0, carry_covl = 1, runs_blk = -1, blk_round = 256, tail_poll = 1, paint_split = 1, split_first = 25;
 };
 
 inline ForMaDebug forma_debug_parse() {
@@ -75,6 +78,8 @@ inline ForMaDebug forma_debug_parse() {
         if (!strcmp(tok, "runs_chain")) { d.runs_chain = (int)std::max(v, 0L); continue; }
         if (!strcmp(tok, "runs_blk")) { d.runs_blk = (int)std::max(v, 0L); continue; }
         if (!strcmp(tok, "blk_round")) { d.blk_round = (int)std::min(std::max(v, 1L), 256L); continue; }
+        if (!strcmp(tok, "paint_split")) { d.paint_split = (int)std::min(std::max(v, 0L), 8L); continue; }
+        if (!strcmp(tok, "split_first")) { d.split_first = (int)std::min(std::max(v, 1L), 99L); continue; }
         if (!strcmp(tok, "tail_poll")) { d.tail_poll = (int)std::max(v, 0L); continue; }
         if (!strcmp(tok, "strip_tiles")) { d.strip_tiles = (int)std::max(v, 0L); continue; }
         if (!strcmp(tok, "poison")) { d.poison = (int)(v & 0xFF); continue; }

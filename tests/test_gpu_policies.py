@@ -36,6 +36,9 @@ SWITCHES = [
     "global_runsort", "span_groups", "no_span_groups",
     "sync",                                        # no read-back-free frames at all
     "tail_poll=0",                                 # the host waits for the stream instead of polling k_frame_tail's word
+    "paint_split=3", "paint_split=8", "paint_split=0",   # frames into caller memory: the painter in bands whose copies leave early / never
+    "paint_split=5,strip_tiles=100000000", "paint_split=4,paint_quad=2", "paint_split=2,poison_frame=255,force_cull",
+    "paint_split=2,split_first=10", "paint_split=2,split_first=70",   # the policy's two bands (first band: split_first percent of the rows)
     "no_simple_paint",                             # (process-wide, read once: effective only if this is the process's first context)
     # combinations that meet in the bench configurations
     "strip_tiles=100000000,force_cull,runs_chain=1", "paint_quad=2,runs_chain=1,carry_half=2", "order_thr=1,force_cull,sort_cus=128",
@@ -108,5 +111,32 @@ def test_two_and_four_frame_slots(cases, slots):
             if k >= 3 * slots:
                 _same(c.read_image(W, H), imgs[None], None, (slots, name, k))
         assert np.array_equal(c.segments(1), sorted_)
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("split", ["paint_split=0", "paint_split=2", "paint_split=3", "paint_split=8"])
+def test_split_frames_into_a_padded_buffer_leave_the_rest_alone(monkeypatch, cases, split):
+    """A frame into caller memory whose painter runs in bands (api.cpp split_plan / send_split_bands: every band's copy leaves behind
+    its launch's event on a second stream): pitched destination, a crop inside tiles — what lies outside the crop's tiles and
+    in the padding keeps the caller's bytes, what lies inside equals the one-launch frame's."""
+    import forma_amd
+    monkeypatch.setenv("FORMA_HIP_DEBUG", split)
+    name, t, imgs, _, _ = cases[0]
+    stride = W * 4 + 192
+    c = forma_amd.Context(0)
+    try:
+        S.load(c, t)
+        for crop in (None, CROP):
+            for k in range(4):
+                dst = np.full((H, stride), 0xA5, np.uint8)
+                out = c.render(W, H, clear=CLEAR, crop=crop, dst=dst, stride=stride)
+                got = np.asarray(out).reshape(H, stride)
+                assert (got[:, W * 4:] == 0xA5).all(), (split, crop, k, "padding overwritten")
+                _same(got[:, :W * 4].reshape(H, W, 4), imgs[crop], crop, (split, name, crop, "padded frame %d" % k))
+                if crop is not None:
+                    x0, x1, y0, y1 = crop
+                    ty0, ty1 = (y0 // 16) * 16, min(-(-y1 // 16) * 16, H)
+                    assert (got[:ty0] == 0xA5).all() and (got[ty1:] == 0xA5).all(), (split, k, "rows outside the crop's tiles overwritten")
     finally:
         c.close()
