@@ -140,3 +140,38 @@ def test_split_frames_into_a_padded_buffer_leave_the_rest_alone(monkeypatch, cas
                     assert (got[:ty0] == 0xA5).all() and (got[ty1:] == 0xA5).all(), (split, k, "rows outside the crop's tiles overwritten")
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("split", ["paint_split=3", "paint_split=2,split_first=40"])
+def test_a_split_frame_whose_prediction_fails_is_rendered_again(monkeypatch, split):
+    """The bands of a split frame leave before the frame is verified (send_split_bands): when frame k + 1 has far more pixel
+    segments than frame k predicted, the copies on their way are waited for, the frame runs again synchronously and `dst`
+    holds the right image when the call returns (complete_async_frame: settle_split before FORMA_RETRY)."""
+    import forma_amd
+    monkeypatch.setenv("FORMA_HIP_DEBUG", split)
+    rng = np.random.default_rng(5)
+    comp = S.Composition()
+    for i in range(150):
+        x0, y0 = rng.uniform(0, 300, 2)
+        comp.get_mut_or_insert_default(i).insert(S.custom_circle(float(x0), float(y0), float(rng.uniform(5, 30)))) \
+            .set_props(S.solid((float(rng.random()), float(rng.random()), float(rng.random()), 0.7)))
+    o = orc.Oracle()
+    c = forma_amd.Context(0)
+    try:
+        for shift in (-5000.0, -5000.0, 0.0, 0.0, -120.0, 40.0, -5000.0, 0.0):
+            for order, layer in comp.layers.items():
+                layer.set_transform([1.0, 0.0, 0.0, 1.0, shift, 0.0])
+            t = comp.tables(o)
+            S.load(o, t)
+            c.set_geoms(t["geoms"])
+            if shift == -5000.0 and not getattr(c, "_loaded", False):
+                S.load(c, t)
+                c._loaded = True
+                c.render(320, 320, clear=(1, 1, 1, 1))                  # first frame of the scene: synchronous
+            want = o.render(320, 320, clear=(1, 1, 1, 1))
+            dst = np.full((320, 320 * 4), 0x5A, np.uint8)
+            got = np.asarray(c.render(320, 320, clear=(1, 1, 1, 1), dst=dst, stride=320 * 4)).reshape(want.shape)
+            assert np.array_equal(c.segments(1), o.segments(1)), (split, shift)
+            assert np.abs(want.astype(int) - got.astype(int)).max() <= 1, (split, shift)
+    finally:
+        c.close()
