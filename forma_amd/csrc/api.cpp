@@ -359,12 +359,16 @@ struct PaintArgs {
 // earlier; what the bands cost the painter — no heavy-first order across launches, eight tails — hides under the copy).
 // Only read-back-free frames of render_on that deliver into `dst` ask for it (split_want), never with a cache (the written-tile
 // set decides what is copied) and not for images of a few MB.  Returns the number of bands, 0: one launch as ever.
+#define SPLIT_MIN_RUNS 262144u
 int split_plan(forma_hip_ctx* ctx, const PaintArgs& a, const PaintParams& P, uint32_t bound_j, bool timing) {
     if (!ctx->split_want || !bound_j || timing || a.cache_id >= 0 || ctx->dbg.paint_split == 0) return 0;
     const uint32_t rows = P.crop_y1 > P.crop_y0 ? P.crop_y1 - P.crop_y0 : 0u;
     const uint32_t cols = P.crop_x1 > P.crop_x0 ? P.crop_x1 - P.crop_x0 : 0u;
     const bool forced = ctx->dbg.paint_split > 1;
     if (!forced && ((uint64_t)rows * cols < 16384u || rows < 32u)) return 0;   // (< 16 MB of pixels: the copy is not the frame)
+    // ... and a painter of a few dozen microseconds has nothing to hide a copy under: the second copy's hand-over (~20 us) costs
+    // more than starting the first one early gains (the 4K spaceship frame: a dozen shapes, 32 400 mostly empty tiles)
+    if (!forced && bound_j < SPLIT_MIN_RUNS) return 0;
     if (rows < 2u) return 0;
     if (!ctx->copy_stream) {
         if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) { ctx->copy_stream = nullptr; return 0; }
