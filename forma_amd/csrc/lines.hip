@@ -533,6 +533,9 @@ __device__ __forceinline__ uint64_t rasterize_one(uint32_t order, float lx0, flo
     return v;
 }
 
+// `(x + 0.5).floor() as i32` (rasterizer.rs:78-80).  NOT gfx950's one-instruction v_cvt_rpi_i32_f32: it rounds the exact sum, the
+// reference the f32 sum — tools/ubench_rpi.hip: they differ on 0.49999997, on the odd integers of magnitude 2^23..2^24 and on NaN.
+__device__ __forceinline__ int round_half_up(float x) { return (int)floorf(x + 0.5f); }
 // The same two functions with what is constant along a LINE folded into its staged constants (round 6):
 //   * `isfinite(b) ? ceil(fma(B, i, -CD)) : i` — a non-finite b (dy so small that 1 / dy overflows) gets B' = 1, CD' = 0 instead of
 //     the select: ceil(fma(1.0, (double)fi, -0.0)) = fi exactly (fi is an integer-valued float; +0 + -0 = +0), likewise for a
@@ -550,8 +553,8 @@ __device__ __forceinline__ uint64_t rasterize_one_k(uint32_t order, float lx0, f
     float t1 = fminf(find_term_k(i + 1, a_k, b_k, cda_k, cdb_k, a, b, c, d), 1.0f);
     float x0f = fmaf(t0, ldx, lx0), y0f = fmaf(t0, ldy, ly0);                        // :112-127
     float x1f = fmaf(t1, ldx, lx0), y1f = fmaf(t1, ldy, ly0);
-    int x0s = (int)floorf(x0f + 0.5f), x1s = (int)floorf(x1f + 0.5f);                // round :78-80
-    int y0s = (int)floorf(y0f + 0.5f), y1s = (int)floorf(y1f + 0.5f);
+    int x0s = round_half_up(x0f), x1s = round_half_up(x1f);                          // round :78-80
+    int y0s = round_half_up(y0f), y1s = round_half_up(y1f);
     int border_x = min(x0s, x1s) >> 4, border_y = min(y0s, y1s) >> 4;
     int tile_x = (int)(int16_t)(border_x >> 4), tile_y = (int)(int16_t)(border_y >> 4);
     uint32_t lx = (uint32_t)border_x & 15u, ly = (uint32_t)border_y & 15u;
@@ -670,7 +673,7 @@ __global__ __launch_bounds__(RAS_THREADS, RAS_OCC) void k_rasterize(LineSource S
                 if (w_start[mid] <= t_lo) a = mid; else b = mid;
             }
             RP_STAMP(1);                                                // binary search
-            uint32_t l_start = w_start[a], l_next = w_start[a + 1], l_order = w_order[a];
+            uint32_t l_next = w_start[a + 1], l_order = w_order[a];
             float l_x0 = w_x0[a], l_y0 = w_y0[a], l_dx = w_dx[a], l_dy = w_dy[a], l_a = w_a[a], l_b = w_b[a], l_c = w_c[a], l_d = w_d[a];
             double l_aab = w_aab[a], l_bab = w_bab[a], l_cdab = w_cdab[a], l_cdb = w_cdb[a];
             int l_ioff = w_ioff[a];
@@ -678,9 +681,9 @@ __global__ __launch_bounds__(RAS_THREADS, RAS_OCC) void k_rasterize(LineSource S
             for (int q = 0; q < RAS_PER_THREAD; q++) {
                 const uint32_t k = kt + q;
                 if (k < t_lo || k >= t_hi) continue;
-                while (k >= l_next) {                      // next line (lines own >= 1 segment, so this advances by one)
+                if (k >= l_next) {                         // next line (a compacted line owns >= 1 segment: never more than one step)
                     a++;
-                    l_start = l_next; l_next = w_start[a + 1]; l_order = w_order[a];
+                    l_next = w_start[a + 1]; l_order = w_order[a];
                     l_x0 = w_x0[a]; l_y0 = w_y0[a]; l_dx = w_dx[a]; l_dy = w_dy[a];
                     l_a = w_a[a]; l_b = w_b[a]; l_c = w_c[a]; l_d = w_d[a];
                     l_aab = w_aab[a]; l_bab = w_bab[a]; l_cdab = w_cdab[a]; l_cdb = w_cdb[a]; l_ioff = w_ioff[a];
