@@ -60,8 +60,12 @@ STAGE_KEYS = ("prepare_us", "rasterize_us", "exchange_us", "sort_us", "carry_us"
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 VALU_PEAK_GINST = 256 * 4 * 2.4 / 2   # wave64 VALU instructions/ns the chip can issue: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles
 # ... and what it does issue (tools/ubench_issue.hip, profiles/r06_valu_issue_peak.txt: one workgroup per CU, four waves per SIMD of 16
-# independent chains each): 930-940 G/s of v_fma_f32 / v_and_b32; every f64 instruction (fma, ceil) and v_pk_fma_f32 is HALF rate: 560-585 G/s
-VALU_MEASURED_GINST = 940.0
+# independent chains each): ~1 000 G/s of the FULL-rate instructions (mov, add / sub, and / or / xor, lshr, mul / add / fma f32, bitop3) and
+# ~570 G/s of everything else (HALF rate: conversions, floor, compares, cndmask, min / max, lshl, bfe / bfi, and_or / or3 / lshl_add, mul_lo,
+# mbcnt, DPP moves, every 64-bit and f64 instruction, packed f32); rcp at a quarter.  A kernel's instructions therefore cost
+# `slots_per_instruction` full-rate issue slots on average (tools/isa_mix.py over its ISA: 1.63 for k_paint_wave, 1.60 for k_rasterize).
+VALU_MEASURED_GINST = 1000.0
+PAINT_SLOTS_PER_INST = 1.63
 PMC_FILES = [os.path.join("profiles", f"r0{r}_pmc_summary.json") for r in (6, 5, 4, 3)]
 
 
@@ -401,8 +405,11 @@ def main():
                 ach = valu / max(paint_k_us, 1e-3) / 1e3              # G wave-instructions / s
                 painter.update({"valu_wave_instructions_per_launch": valu, "achieved": round(ach, 1), "peak": round(VALU_PEAK_GINST, 1),
                                 "unit": "G wave64 VALU instructions/s", "frac": round(ach / VALU_PEAK_GINST, 4),
-                                "peak_measured": VALU_MEASURED_GINST, "frac_of_measured": round(ach / VALU_MEASURED_GINST, 4),
-                                "peak_measured_what": "tools/ubench_issue.hip: four waves per SIMD of independent v_fma_f32 on every CU (f64 / packed-f32 instructions issue at half that rate)"})
+                                "peak_measured": VALU_MEASURED_GINST, "slots_per_instruction": PAINT_SLOTS_PER_INST,
+                                "frac_of_measured": round(ach * PAINT_SLOTS_PER_INST / VALU_MEASURED_GINST, 4),
+                                "peak_measured_what": "tools/ubench_issue.hip: G full-rate issue slots/s with four waves per SIMD on every CU (mov / add / logic / "
+                                                      "f32 mul-add issue at this rate, conversions / compares / selects / min-max / 64-bit / f64 / packed at half); "
+                                                      "frac_of_measured = achieved x slots_per_instruction (static mix of the kernel's ISA, tools/isa_mix.py) / peak_measured"})
             if k.get("SQ_LDS_IDX_ACTIVE"):
                 painter["lds_bank_conflict_ratio"] = round(k.get("SQ_LDS_BANK_CONFLICT", 0) / k["SQ_LDS_IDX_ACTIVE"], 4)
             painter["counters_source"] = pmc_file + " (separate --pmc passes, NOT this run)"

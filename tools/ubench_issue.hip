@@ -27,6 +27,43 @@ KERNEL(k_fma_f64, double, (double)seed + i, "v_fma_f64 %0, %0, %0, %0")
 KERNEL(k_and_b32, uint32_t, (uint32_t)seed + i, "v_and_b32 %0, 0x7ff000, %0")
 KERNEL(k_pk_fma_f32, double, (double)seed + i, "v_pk_fma_f32 %0, %0, %0, %0")
 KERNEL(k_ceil_f64, double, (double)seed + i, "v_ceil_f64 %0, %0")
+KERNEL(k_lshl_b64, uint64_t, (uint64_t)seed + i, "v_lshlrev_b64 %0, 3, %0")
+KERNEL(k_mul_lo_u32, uint32_t, (uint32_t)seed + i, "v_mul_lo_u32 %0, %0, %0")
+KERNEL(k_cvt_i32_f32, float, seed + i, "v_cvt_i32_f32 %0, %0")
+KERNEL(k_bfe_u32, uint32_t, (uint32_t)seed + i, "v_bfe_u32 %0, %0, 3, 9")
+KERNEL(k_cndmask, uint32_t, (uint32_t)seed + i, "v_cndmask_b32 %0, %0, %0, vcc")
+KERNEL(k_cndmask_e64, uint32_t, (uint32_t)seed + i, "v_cndmask_b32_e64 %0, %0, %0, s[20:21]")
+KERNEL(k_cmp_cnd, uint32_t, (uint32_t)seed + i, "v_cmp_lt_u32 vcc, 5, %0\n\tv_cndmask_b32 %0, %0, %0, vcc")
+KERNEL(k_cmp_cnd_e64, uint32_t, (uint32_t)seed + i, "v_cmp_lt_u32_e64 s[20:21], 5, %0\n\ts_nop 1\n\tv_cndmask_b32_e64 %0, %0, %0, s[20:21]")
+KERNEL(k_cmp_4_cnd, uint32_t, (uint32_t)seed + i, "v_cmp_lt_u32 vcc, 5, %0\n\tv_add_u32 %0, 3, %0\n\tv_add_u32 %0, 3, %0\n\tv_add_u32 %0, 3, %0\n\tv_add_u32 %0, 3, %0\n\tv_cndmask_b32 %0, %0, %0, vcc")
+KERNEL(k_cmp_4_cnd_e64, uint32_t, (uint32_t)seed + i, "v_cmp_lt_u32_e64 s[20:21], 5, %0\n\tv_add_u32 %0, 3, %0\n\tv_add_u32 %0, 3, %0\n\tv_add_u32 %0, 3, %0\n\tv_add_u32 %0, 3, %0\n\tv_cndmask_b32_e64 %0, %0, %0, s[20:21]")
+KERNEL(k_addc, uint32_t, (uint32_t)seed + i, "v_add_co_u32 %0, vcc, 3, %0")
+KERNEL(k_mov_b32, uint32_t, (uint32_t)seed + i, "v_mov_b32 %0, %0")
+KERNEL(k_lshl_b32, uint32_t, (uint32_t)seed + i, "v_lshlrev_b32 %0, 3, %0")
+KERNEL(k_lshr_b32, uint32_t, (uint32_t)seed + i, "v_lshrrev_b32 %0, 3, %0")
+KERNEL(k_or_b32, uint32_t, (uint32_t)seed + i, "v_or_b32 %0, 5, %0")
+KERNEL(k_sub_u32, uint32_t, (uint32_t)seed + i, "v_sub_u32 %0, %0, %0")
+KERNEL(k_max_i32, uint32_t, (uint32_t)seed + i, "v_max_i32 %0, 5, %0")
+KERNEL(k_max_f32, float, seed + i, "v_max_f32 %0, 0, %0")
+KERNEL(k_mul_f32, float, seed + i, "v_mul_f32 %0, %0, %0")
+KERNEL(k_add_f32, float, seed + i, "v_add_f32 %0, 0.5, %0")
+KERNEL(k_and_or, uint32_t, (uint32_t)seed + i, "v_and_or_b32 %0, %0, 15, %0")
+KERNEL(k_or3, uint32_t, (uint32_t)seed + i, "v_or3_b32 %0, %0, %0, %0")
+KERNEL(k_bitop3, uint32_t, (uint32_t)seed + i, "v_bitop3_b32 %0, %0, %0, %0 bitop3:0x90")
+KERNEL(k_mbcnt, uint32_t, (uint32_t)seed + i, "v_mbcnt_lo_u32_b32 %0, %0, %0")
+KERNEL(k_mad_u32_u24, uint32_t, (uint32_t)seed + i, "v_mad_u32_u24 %0, %0, %0, %0")
+KERNEL(k_alignbit, uint32_t, (uint32_t)seed + i, "v_alignbit_b32 %0, %0, %0, 20")
+KERNEL(k_perm, uint32_t, (uint32_t)seed + i, "v_perm_b32 %0, %0, %0, %0")
+KERNEL(k_cvt_f32_i32, float, seed + i, "v_cvt_f32_i32 %0, %0")
+KERNEL(k_rcp_f32, float, seed + i, "v_rcp_f32 %0, %0")
+KERNEL(k_add_f64, double, (double)seed + i, "v_add_f64 %0, %0, %0")
+KERNEL(k_mov_dpp, uint32_t, (uint32_t)seed + i, "v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf")
+KERNEL(k_cmp_e64, uint32_t, (uint32_t)seed + i, "v_cmp_lt_u32_e64 s[20:21], 5, %0")
+KERNEL(k_min_u32, uint32_t, (uint32_t)seed + i, "v_min_u32 %0, 77, %0")
+KERNEL(k_bfi, uint32_t, (uint32_t)seed + i, "v_bfi_b32 %0, %0, %0, %0")
+KERNEL(k_lshl_add, uint32_t, (uint32_t)seed + i, "v_lshl_add_u32 %0, %0, 2, %0")
+KERNEL(k_add_u32, uint32_t, (uint32_t)seed + i, "v_add_u32 %0, 3, %0")
+KERNEL(k_floor_f32, float, seed + i, "v_floor_f32 %0, %0")
 
 int main() {
     uint64_t* d; (void)hipMalloc(&d, 2048 * 8);
@@ -44,6 +81,6 @@ int main() {
         printf("%-14s %d waves/SIMD: %8.1f G wave-instr/s chip-wide (%.1f us), %.2f shader clocks per instruction per SIMD\n", \
                #K, W, insts / (ms * 1e-3) * 1e-9, ms * 1e3, (double)h / ((double)W * ITERS * CHAINS));               \
     } while (0)
-    for (int w = 1; w <= 4; w *= 2) { RUN(k_fma_f32, w); RUN(k_fma_f64, w); RUN(k_and_b32, w); RUN(k_pk_fma_f32, w); RUN(k_ceil_f64, w); }
+    for (int w = 4; w <= 4; w *= 4) { RUN(k_fma_f32, w); RUN(k_fma_f64, w); RUN(k_and_b32, w); RUN(k_pk_fma_f32, w); RUN(k_ceil_f64, w); RUN(k_lshl_b64, w); RUN(k_mul_lo_u32, w); RUN(k_cvt_i32_f32, w); RUN(k_bfe_u32, w); RUN(k_cndmask, w); RUN(k_cndmask_e64, w); RUN(k_cmp_cnd, w); RUN(k_cmp_cnd_e64, w); RUN(k_cmp_4_cnd, w); RUN(k_cmp_4_cnd_e64, w); RUN(k_addc, w); RUN(k_mov_b32, w); RUN(k_lshl_b32, w); RUN(k_lshr_b32, w); RUN(k_or_b32, w); RUN(k_sub_u32, w); RUN(k_max_i32, w); RUN(k_max_f32, w); RUN(k_mul_f32, w); RUN(k_add_f32, w); RUN(k_and_or, w); RUN(k_or3, w); RUN(k_bitop3, w); RUN(k_mbcnt, w); RUN(k_mad_u32_u24, w); RUN(k_alignbit, w); RUN(k_perm, w); RUN(k_cvt_f32_i32, w); RUN(k_rcp_f32, w); RUN(k_add_f64, w); RUN(k_mov_dpp, w); RUN(k_cmp_e64, w); RUN(k_min_u32, w); RUN(k_bfi, w); RUN(k_lshl_add, w); RUN(k_add_u32, w); RUN(k_floor_f32, w); }
     return 0;
 }
