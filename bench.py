@@ -417,10 +417,17 @@ def main():
         # PCIe-inclusive frames: every call copies its image (its band) into caller memory and is complete when it returns
         n_d2h = max(60, args.steps)
 
-        def d2h_frames():
-            for _ in range(n_d2h):
+        def d2h_frames(n=None):
+            for _ in range(n or n_d2h):
                 frame(dst=image)
-        fps_d2h = None if args.no_d2h else round(frames_per_step * n_d2h / timed(d2h_frames), 2)
+        # (eight untimed frames first: the first frame into caller memory allocates the pinned staging image and a frame into caller memory
+        #  learns where to split its painter launch; then the median of three blocks — PCIe rates wobble from block to block, as in the
+        #  enqueued leg below: 909 and 972 frames/s came out of two runs of the same build on the same box with one block each)
+        fps_d2h, fps_d2h_blocks = None, None
+        if not args.no_d2h:
+            d2h_frames(8)
+            fps_d2h_blocks = [round(frames_per_step * n_d2h / timed(d2h_frames), 2) for _ in range(3)]
+            fps_d2h = round(statistics.median(fps_d2h_blocks), 2)
         # frame AND copy enqueued (forma_hip_render_enqueue): three registered caller buffers in turn, two frame slots, ONE context
         # and ONE host thread — the 33 MB copy of frame k crosses PCIe under the kernels of frames k + 1, k + 2; a buffer is
         # complete two enqueues later (what a presenter that rotates window buffers does)
@@ -502,6 +509,7 @@ def main():
                                 "what": "the same context with ONE frame in flight: every render call is complete when it returns "
                                         "(SURVEY §8d: 1 / wall time of one render call, device-resident output)"},
             "fps_including_d2h": fps_d2h,
+            "fps_including_d2h_blocks": fps_d2h_blocks,
             "fps_including_d2h_frames": n_d2h,
             "fps_including_d2h_enqueued_three_buffers": fps_d2h_enqueue,
             "fps_including_d2h_three_contexts": fps_d2h_server,
