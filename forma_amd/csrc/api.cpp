@@ -374,6 +374,8 @@ int split_plan(forma_hip_ctx* ctx, const PaintArgs& a, const PaintParams& P, uin
         if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) { ctx->copy_stream = nullptr; return 0; }
         for (int k = 0; k < forma_hip_ctx::SPLIT_MAX; k++)
             if (hipEventCreateWithFlags(&ctx->split_ev[k], hipEventDisableTiming) != hipSuccess) {
+                ctx->split_ev[k] = nullptr;
+                for (int q = 0; q < k; q++) { (void)hipEventDestroy(ctx->split_ev[q]); ctx->split_ev[q] = nullptr; }   // (no stream: one launch as ever)
                 (void)hipStreamDestroy(ctx->copy_stream); ctx->copy_stream = nullptr; return 0;
             }
     }
