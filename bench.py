@@ -20,8 +20,8 @@ enqueued on the next slot and verified when the slot comes round, so the kernels
     kernel's own;
   * `animated`: BASELINE config 5 (deterministic spaceship, 600 frames at 4K, with and without the buffer-layer cache);
   * `cpu_baseline`: the C++ oracle on the same scene tables (`kind: "port"`).
-`roofline.traffic` is NOT measured in the run: it is read from the committed counter summary (separate rocprofv3 --pmc
-passes of this command, tools/pmc_round.py) and labelled so.
+`roofline.traffic` is measured in the run at N = 1 (two child runs of this command under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`,
+tools/pmc_round.py, ~40 s; `--no-pmc` skips them); without rocprofv3 it is read from the committed counter summary and labelled so.
 
 N > 1, launched as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (the contract): default `--mode
 multi` — rank 0 holds ONE renderer over all N GPUs (`forma_hip_create_multi`: per-device host threads inside the library,
@@ -85,6 +85,8 @@ def parse():
     ap.add_argument("--no-animated", action="store_true", help="skip BASELINE config 5 (deterministic spaceship, 600 frames at 4K)")
     ap.add_argument("--animated-frames", type=int, default=600)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 --pmc child runs (two short runs of this "
+                                                          "command, ~40 s); the figure of the committed counter summary is reported instead")
     ap.add_argument("--no-d2h", action="store_true", help="skip the PCIe-inclusive legs (profiling runs: their pipelined frames would be "
                     "averaged into the per-kernel durations of the one-frame-in-flight region)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -623,6 +625,11 @@ def main():
         raise SystemExit(f"every mode failed: {errors}")
     if errors:
         out["mode_fallback_errors"] = errors
+    if rank == 0 and world == 1 and args.gpus == 1 and not args.no_pmc and not args.svg and args.workload == "paris-like-30k-4k" \
+            and isinstance(out.get("roofline"), dict):
+        live = live_traffic()
+        if live is not None:
+            out["roofline"].update(live)
     if sharded and not args.svg and args.workload != "triangles-10m-8k" and out["scaling"] == "strong":
         # N > 1: the same sharded mode on BASELINE config 4 (10 M pixel segments at 8192 x 8192), the configuration the multi-GPU
         # target is quoted on; its numbers ride in the same JSON line
@@ -645,6 +652,36 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def live_traffic():
+    """roofline.traffic measured in THIS run: two child runs of this command under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate
+    passes, as the MI355X guide's HBM section prescribes; gfx950: FETCH_SIZE counts 128-byte requests as 64 -> x 2), three frames each, the
+    per-frame k_onesweep instantiation's mean bytes per launch (tools/pmc_round.py).  None — and the committed summary's figure stays — when
+    rocprofv3 is missing, a pass fails or takes more than two minutes."""
+    import shutil
+    if not shutil.which("rocprofv3"):
+        return None
+    if any("ROCPROF" in k or k.startswith("ROCP_") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None                                                   # (this run is being profiled itself: no profiler inside a profiler)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import pmc_round
+        t0 = time.perf_counter()
+        kern, line = pmc_round.collect([["FETCH_SIZE"], ["WRITE_SIZE"]], timeout=120)
+        cands = [v for k, v in kern.items() if k.startswith("k_onesweep") and "hbm_bytes_per_launch" in v]
+        if not cands or not line:
+            return None
+        k = max(cands, key=lambda v: v.get("dispatches", 0))
+        n = line["config"]["pixel_segments"]
+        return {"traffic": int(k["hbm_bytes_per_launch"]),
+                "traffic_source": "measured in this run: two child runs of this command under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` "
+                                  "(separate passes, --in-flight 1, three frames; gfx950: FETCH_SIZE x 2 + WRITE_SIZE), mean over the "
+                                  f"{k.get('dispatches', 0)} frame-sized k_onesweep launches; {round(time.perf_counter() - t0, 1)} s",
+                "traffic_over_algorithmic": round(k["hbm_bytes_per_launch"] / (16.0 * n), 4) if n else None}
+    except Exception as e:                                            # noqa: BLE001 (never lose the line to the counters)
+        print(f"bench.py: live counter passes failed ({e!r}); roofline.traffic is the committed summary's", file=sys.stderr)
+        return None
 
 
 def animated_leg(local, frames=600):

@@ -6,7 +6,7 @@ cd forma_amd/csrc; cp libforma_hip.so /tmp/lib_keep.so
 for r in $(seq 1 $R); do
   for v in "$@"; do
     cp variants/$v libforma_hip.so
-    (cd ../..; timeout 100 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-animated 2>&1 | tail -1 | python -c "
+    (cd ../..; timeout 100 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-pmc --no-animated 2>&1 | tail -1 | python -c "
 import sys,json
 d=json.loads(sys.stdin.read()); s=d['stages_us']; print('%-14s' % '$v', d['value'], 'pass_us', d['roofline']['avg_launch_us'], {k:round(v) for k,v in s.items()})")
   done

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 for v in "$@"; do
   cp forma_amd/csrc/variants/$v forma_amd/csrc/libforma_hip.so
   rm -rf /tmp/abp_$v
-  (cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abp_$v -- python $OLDPWD/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-animated --in-flight 1 > /tmp/abp_$v.log 2>&1)
+  (cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abp_$v -- python $OLDPWD/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pmc --no-animated --in-flight 1 > /tmp/abp_$v.log 2>&1)
   f=$(ls /tmp/abp_$v/*/*kernel_stats.csv | head -1)
   python - "$f" "$K" "$v" <<'PY'
 import csv, sys

@@ -8,7 +8,7 @@ for spec in "$@"; do
   v=${spec%%@*}; e=""; [ "$spec" != "$v" ] && e=${spec#*@}
   rm -rf /tmp/abpa
   (cd /tmp && env FORMA_HIP_LIB=$OLDPWD/forma_amd/csrc/variants/$v $e timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abpa -- \
-     python $OLDPWD/bench.py --workload $W --steps 20 --warmup 3 --no-cpu-baseline --no-animated --no-d2h --in-flight 1 > /tmp/abpa.log 2>&1)
+     python $OLDPWD/bench.py --workload $W --steps 20 --warmup 3 --no-cpu-baseline --no-pmc --no-animated --no-d2h --in-flight 1 > /tmp/abpa.log 2>&1)
   f=$(ls /tmp/abpa/*/*kernel_stats.csv | head -1)
   python - "$f" "$spec" <<'PY'
 import csv, sys

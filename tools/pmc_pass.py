@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 counters = sys.argv[1:]
 with tempfile.TemporaryDirectory(dir="/tmp") as d:
     cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", d, "--",
-           "python", os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--in-flight", "1", "--no-cpu-baseline", "--no-animated"]
+           "python", os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--in-flight", "1", "--no-cpu-baseline", "--no-pmc", "--no-animated"]
     r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True)
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):

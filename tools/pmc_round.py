@@ -10,15 +10,15 @@ whose only traffic is one read of the 8 N byte stream).  Values are means over t
 import collections, csv, glob, json, os, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BENCH = ["python", os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--in-flight", "1", "--no-cpu-baseline", "--no-animated", "--no-d2h"]
+BENCH = ["python", os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--in-flight", "1", "--no-cpu-baseline", "--no-animated", "--no-d2h", "--no-pmc"]
 PASSES = [["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAIT_INST_LDS", "SQ_WAVES", "SQ_BUSY_CYCLES"],
           ["FETCH_SIZE"], ["WRITE_SIZE"]]
 
 
-def run_pass(counters, d):
+def run_pass(counters, d, timeout=None):
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", d, "--"] + BENCH
-    out = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
+    out = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
     line = [l for l in out.stdout.splitlines() if l.startswith("{")]
     return json.loads(line[-1]) if line else None
 
@@ -40,20 +40,27 @@ def per_kernel(d):
     return out
 
 
-def main():
-    dst = sys.argv[1]
+def collect(passes, timeout=None):
+    """one rocprofv3 --pmc run of the short bench command per counter list -> ({kernel: {counter: mean per frame-sized dispatch}}, the run's bench line)"""
     kern, bench_line = collections.defaultdict(dict), None
-    for counters in PASSES:
+    for counters in passes:
         with tempfile.TemporaryDirectory(dir="/tmp") as d:
-            line = run_pass(counters, d)
+            line = run_pass(counters, d, timeout)
             bench_line = bench_line or line
             for k, v in per_kernel(d).items():
                 if not k.startswith("__amd"):
                     kern[k].update(v)
-    n = bench_line["config"]["pixel_segments"] if bench_line else 0
     for k, v in kern.items():
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             v["hbm_bytes_per_launch"] = int(v["FETCH_SIZE"] * 1024 * 2 + v["WRITE_SIZE"] * 1024)
+    return kern, bench_line
+
+
+def main():
+    dst = sys.argv[1]
+    kern, bench_line = collect(PASSES)
+    n = bench_line["config"]["pixel_segments"] if bench_line else 0
+    for k, v in kern.items():
         for c in list(v):
             v[c] = round(v[c], 1) if isinstance(v[c], float) else v[c]
 

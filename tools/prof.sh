@@ -4,7 +4,7 @@ TAG=${1:-prof}; shift
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-(cd $OLDPWD && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-animated "$@" > $OUT/bench.log 2>&1)
+(cd $OLDPWD && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-pmc --no-animated "$@" > $OUT/bench.log 2>&1)
 cd $OLDPWD
 f=$(ls $OUT/*/*kernel_stats.csv 2>/dev/null | head -1)
 python - "$f" <<'PY'

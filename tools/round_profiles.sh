@@ -5,7 +5,7 @@
 # of a one-row and a 1/8 band, the D2H rates.
 TAG=${1:-r06}; OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp PYTHONUNBUFFERED=1
-Q="--no-cpu-baseline --no-animated"
+Q="--no-cpu-baseline --no-pmc --no-animated"
 timeout 400 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_form.json 2> $OUT/bench_driver_form.err
 for w in cubics-1080p triangles-10m-8k circles-20k; do
