@@ -20,8 +20,8 @@ enqueued on the next slot and verified when the slot comes round, so the kernels
     kernel's own;
   * `animated`: BASELINE config 5 (deterministic spaceship, 600 frames at 4K, with and without the buffer-layer cache);
   * `cpu_baseline`: the C++ oracle on the same scene tables (`kind: "port"`).
-`roofline.traffic` is measured in the run at N = 1 (two child runs of this command under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`,
-tools/pmc_round.py, ~40 s; `--no-pmc` skips them); without rocprofv3 it is read from the committed counter summary and labelled so.
+`roofline.traffic`, `post_sort_traffic_ratio` and the painter's counters are measured in the run at N = 1 (three child runs of this command under
+`rocprofv3 --pmc`: the SQ counters, FETCH_SIZE, WRITE_SIZE; tools/pmc_round.py, ~15 s; `--no-pmc` skips them); without rocprofv3 it is read from the committed counter summary and labelled so.
 
 N > 1, launched as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (the contract): default `--mode
 multi` — rank 0 holds ONE renderer over all N GPUs (`forma_hip_create_multi`: per-device host threads inside the library,
@@ -85,8 +85,8 @@ def parse():
     ap.add_argument("--no-animated", action="store_true", help="skip BASELINE config 5 (deterministic spaceship, 600 frames at 4K)")
     ap.add_argument("--animated-frames", type=int, default=600)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 --pmc child runs (two short runs of this "
-                                                          "command, ~40 s); the figure of the committed counter summary is reported instead")
+    ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic and the painter's counters with rocprofv3 --pmc child runs (three short runs of this "
+                                                          "command, ~15 s); the figure of the committed counter summary is reported instead")
     ap.add_argument("--no-d2h", action="store_true", help="skip the PCIe-inclusive legs (profiling runs: their pipelined frames would be "
                     "averaged into the per-kernel durations of the one-frame-in-flight region)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -627,9 +627,11 @@ def main():
         out["mode_fallback_errors"] = errors
     if rank == 0 and world == 1 and args.gpus == 1 and not args.no_pmc and not args.svg and args.workload == "paris-like-30k-4k" \
             and isinstance(out.get("roofline"), dict):
-        live = live_traffic()
+        live = live_traffic(out)
         if live is not None:
-            out["roofline"].update(live)
+            out["roofline"].update(live["roofline"])
+            if isinstance(out.get("roofline_painter"), dict):
+                out["roofline_painter"].update(live["roofline_painter"])
     if sharded and not args.svg and args.workload != "triangles-10m-8k" and out["scaling"] == "strong":
         # N > 1: the same sharded mode on BASELINE config 4 (10 M pixel segments at 8192 x 8192), the configuration the multi-GPU
         # target is quoted on; its numbers ride in the same JSON line
@@ -654,11 +656,12 @@ def main():
         dist.destroy_process_group()
 
 
-def live_traffic():
-    """roofline.traffic measured in THIS run: two child runs of this command under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate
-    passes, as the MI355X guide's HBM section prescribes; gfx950: FETCH_SIZE counts 128-byte requests as 64 -> x 2), three frames each, the
-    per-frame k_onesweep instantiation's mean bytes per launch (tools/pmc_round.py).  None — and the committed summary's figure stays — when
-    rocprofv3 is missing, a pass fails or takes more than two minutes."""
+def live_traffic(out):
+    """The counter-derived figures of the line measured in THIS run: three child runs of this command under `rocprofv3 --pmc` (the SQ
+    counters; FETCH_SIZE; WRITE_SIZE — separate passes, as the MI355X guide's HBM section prescribes; gfx950: FETCH_SIZE counts 128-byte
+    requests as 64 -> x 2), three frames each; per kernel the instantiation that runs on every frame, mean over its frame-sized launches
+    (tools/pmc_round.py).  Returns {"roofline": {...}, "roofline_painter": {...}} to merge into the line, or None — and the committed
+    summary's figures stay — when rocprofv3 is missing, a pass fails or takes more than two minutes, or this run is itself profiled."""
     import shutil
     if not shutil.which("rocprofv3"):
         return None
@@ -668,19 +671,39 @@ def live_traffic():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import pmc_round
         t0 = time.perf_counter()
-        kern, line = pmc_round.collect([["FETCH_SIZE"], ["WRITE_SIZE"]], timeout=120)
-        cands = [v for k, v in kern.items() if k.startswith("k_onesweep") and "hbm_bytes_per_launch" in v]
-        if not cands or not line:
+        kern, line = pmc_round.collect(pmc_round.PASSES, timeout=120)
+        if not line:
             return None
-        k = max(cands, key=lambda v: v.get("dispatches", 0))
         n = line["config"]["pixel_segments"]
-        return {"traffic": int(k["hbm_bytes_per_launch"]),
-                "traffic_source": "measured in this run: two child runs of this command under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` "
-                                  "(separate passes, --in-flight 1, three frames; gfx950: FETCH_SIZE x 2 + WRITE_SIZE), mean over the "
-                                  f"{k.get('dispatches', 0)} frame-sized k_onesweep launches; {round(time.perf_counter() - t0, 1)} s",
-                "traffic_over_algorithmic": round(k["hbm_bytes_per_launch"] / (16.0 * n), 4) if n else None}
+        w, h = line["config"]["canvas"]
+
+        def per_frame(base):                                          # the instantiation of a kernel that runs on every frame
+            cands = [v for k, v in kern.items() if k.split("<")[0] == base]
+            return max(cands, key=lambda v: v.get("dispatches", 0)) if cands else None
+        src = ("measured in this run: child runs of this command under `rocprofv3 --pmc` (separate passes for the SQ counters, FETCH_SIZE and "
+               f"WRITE_SIZE; --in-flight 1, three frames; gfx950: 2 x FETCH_SIZE + WRITE_SIZE); {round(time.perf_counter() - t0, 1)} s")
+        res = {"roofline": {}, "roofline_painter": {}}
+        k = per_frame("k_onesweep")
+        if not k or "hbm_bytes_per_launch" not in k:
+            return None
+        res["roofline"].update({"traffic": int(k["hbm_bytes_per_launch"]), "traffic_source": src + f"; mean over {k.get('dispatches', 0)} k_onesweep launches",
+                                "traffic_over_algorithmic": round(k["hbm_bytes_per_launch"] / (16.0 * n), 4) if n else None})
+        post = [per_frame(b) for b in ("k_runs_count", "k_runs_wave", "k_carry_rows", "k_paint_wave") if b in out.get("kernels_us", {})]
+        if post and all(p_ and p_.get("hbm_bytes_per_launch") for p_ in post):
+            res["roofline"]["post_sort_traffic_ratio"] = round(sum(p_["hbm_bytes_per_launch"] for p_ in post) / (8.0 * n + 4.0 * w * h), 3)
+        pk_name = next((b for b in ("k_paint_wave", "k_paint_quad") if b in out.get("kernels_us", {})), None)
+        pk = per_frame(pk_name) if pk_name else None
+        paint_us = out["kernels_us"][pk_name]["us_per_frame"] if pk_name else 0.0
+        if pk and pk.get("SQ_INSTS_VALU") and paint_us > 0:
+            ach = pk["SQ_INSTS_VALU"] / paint_us / 1e3                 # G wave-instructions / s (the launch time: this run's own events)
+            res["roofline_painter"].update({"valu_wave_instructions_per_launch": round(pk["SQ_INSTS_VALU"], 1), "achieved": round(ach, 1),
+                                            "frac": round(ach / VALU_PEAK_GINST, 4),
+                                            "frac_of_measured": round(ach * PAINT_SLOTS_PER_INST / VALU_MEASURED_GINST, 4), "counters_source": src})
+            if pk.get("SQ_LDS_IDX_ACTIVE"):
+                res["roofline_painter"]["lds_bank_conflict_ratio"] = round(pk.get("SQ_LDS_BANK_CONFLICT", 0) / pk["SQ_LDS_IDX_ACTIVE"], 4)
+        return res
     except Exception as e:                                            # noqa: BLE001 (never lose the line to the counters)
-        print(f"bench.py: live counter passes failed ({e!r}); roofline.traffic is the committed summary's", file=sys.stderr)
+        print(f"bench.py: live counter passes failed ({e!r}); the counter figures are the committed summary's", file=sys.stderr)
         return None
 
 
