@@ -354,7 +354,7 @@ def main():
                     "algorithmic_bytes_per_launch": algo_bytes_per_pass, "avg_launch_us": round(pass_us, 2), "passes": passes,
                     "measured": f"HIP events carried by every k_onesweep launch (hipExtLaunchKernelGGL: the dispatch's own start and end) of "
                                 f"{acc.get('_frames', 0)} frames with ONE frame in flight, a further timed region of this run; matches `rocprofv3 "
-                                "--kernel-trace --stats -- python bench.py --in-flight 1 --no-d2h --no-animated --no-cpu-baseline`, profiles/r06_kernel_stats_inflight1.csv"}
+                                "--kernel-trace --stats -- python bench.py --in-flight 1 --no-d2h --no-animated --no-cpu-baseline`, profiles/r06g_kernel_stats_inflight1.csv"}
         # the whole sort against the same roofline: histogram read + p digit passes = 8 N (2 p + 1) bytes — or 16 N p
         # when the histograms come out of the rasterizer's registers (read-back-free frames with <= 3 passes: k_sort_hist and its
         # read of the stream do not run; the counting costs k_rasterize ~13 us, which stays in the rasterize stage)
