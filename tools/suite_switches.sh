@@ -13,7 +13,11 @@ if [ ${#SW[@]} -eq 0 ]; then
 fi
 for sw in "${SW[@]}"; do
   t0=$(date +%s)
-  res=$(FORMA_HIP_DEBUG="$sw" timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -40)
+  log=gpurun_out/suite_switches_$(echo "${sw:-default}" | tr -c 'A-Za-z0-9\n' '_').log
+  FORMA_HIP_DEBUG="$sw" timeout 900 python -X faulthandler -m pytest tests -m gpu -q -p no:cacheprovider > $log 2>&1
+  rc=$?
+  res=$(tail -n 40 $log)
+  [ $rc -eq 0 ] && rm -f $log                            # (the whole log of a run that failed — or died — stays in gpurun_out/)
   last=$(echo "$res" | grep -E "passed|failed|error" | tail -1)
   fails=$(echo "$res" | grep -E "^FAILED|^ERROR" | cut -c1-160 | tr '\n' ';')
   echo "[${sw:-(default)}]  $last  ($(( $(date +%s) - t0 )) s)  $fails" | tee -a $OUT
